@@ -1,0 +1,182 @@
+"""Pins the CPU oracle (oracle/) against the golden vectors captured from the reference itself
+(tools/gen_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, TRACES, STICKY_TRACES, trace_config
+from oracle import lattice, philox, referee, env_oracle
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    assert philox.philox4x32((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert philox.philox4x32((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert philox.philox4x32((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == (
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+    c = np.arange(17, dtype=np.uint32)
+    v = philox.philox4x32_np(c, 5, c * 3, 9, (1, 2))
+    for i in range(17):
+        assert tuple(int(x[i]) for x in v) == philox.philox4x32((i, 5, 3 * i, 9), (1, 2))
+
+
+def test_threshold_equivalence():
+    rng = np.random.RandomState(0)
+    for p in (0.0, 1e-9, 0.001, 0.007, 0.011, 0.3, 0.5, 1.0):
+        T = philox.threshold(p)
+        ws = np.concatenate([rng.randint(0, 2 ** 32, size=2000, dtype=np.uint64),
+                             np.array([0, 1, max(T - 1, 0), min(T, 2 ** 32 - 1), 2 ** 32 - 1], dtype=np.uint64)])
+        for w in ws:
+            assert (int(w) / 4294967296.0 < p) == (int(w) < T)
+
+
+@pytest.mark.parametrize("d", [3, 5, 7])
+def test_tables(d):
+    g = load_golden("tables")
+    assert np.array_equal(lattice.qubit_table(d), g[f"qubits_d{d}"])
+    stabs = lattice.qubit_stabilizers(d)
+    for q in range(d * d):
+        want = [tuple(x) for x in g[f"qubit_stabilizers_d{d}"][q] if x[0] >= 0]
+        assert stabs[q] == want
+    neigh = lattice.qubit_neighbours(d)
+    for q in range(d * d):
+        assert neigh[q] == [int(x) for x in g[f"qubit_neighbours_d{d}"][q] if x >= 0]
+    assert np.array_equal(lattice.identity_indicator(d), g[f"identity_indicator_d{d}"])
+    assert np.array_equal(lattice.static_plane(d), g[f"static_plane_d{d}"])
+    for model, use_Y in (("X", False), ("DP", True), ("DP", False)):
+        n_act, layers = lattice.num_actions(d, model, use_Y)
+        meta = g[f"meta_d{d}_{model}_{int(use_Y)}"]
+        assert (n_act, layers, n_act - 1) == tuple(meta[:3])
+        assert tuple(meta[3:]) == (d + layers, 2 * d + 1, 2 * d + 1)
+    m = lattice.Masks(d)
+    assert m.n_stab == d * d - 1 and len(m.typed[1]) == len(m.typed[3]) == (d * d - 1) // 2
+
+
+def test_even_distance_raises():
+    with pytest.raises(Exception):
+        lattice.qubit_table(4)
+
+
+@pytest.mark.parametrize("d", [3, 5, 7])
+def test_helper_kats(d):
+    g = load_golden("kats")
+    errs = g[f"kat_err_d{d}"]
+    for i in range(0, len(errs), 3 if d == 7 else 1):
+        e = errs[i].astype(int)
+        assert np.array_equal(env_oracle.syndrome_grid(e), g[f"kat_syn_d{d}"][i])
+        assert np.array_equal(env_oracle.homology_label(e, "DP"), g[f"kat_label_dp_d{d}"][i])
+        assert np.array_equal(env_oracle.homology_label(e * (e == 1), "X"), g[f"kat_label_x_d{d}"][i])
+    # Pauli product == XOR of codes
+    assert np.array_equal(g[f"kat_mul_d{d}"], np.arange(4)[:, None] ^ np.arange(4)[None, :])
+    a, b = errs[-200:-100].astype(int), errs[-100:].astype(int)
+    assert np.array_equal(a ^ b, g[f"kat_prod_d{d}"])
+    for i in range(64):
+        out = env_oracle.faulty_syndrome_from_words(d, g[f"kat_faulty_true_d{d}"][i].astype(int),
+                                                    g[f"kat_faulty_words_d{d}"][i], float(g[f"kat_faulty_p_d{d}"][i]))
+        assert np.array_equal(out, g[f"kat_faulty_out_d{d}"][i])
+    for i in range(32):
+        assert np.array_equal(env_oracle.padding_syndrome(d, g[f"kat_padsyn_in_d{d}"][i]), g[f"kat_padsyn_out_d{d}"][i])
+        assert np.array_equal(env_oracle.padding_actions(d, g[f"kat_padact_in_d{d}"][i]), g[f"kat_padact_out_d{d}"][i])
+    for model, use_Y in (("X", False), ("DP", True), ("DP", False)):
+        want = g[f"kat_move_d{d}_{model}_{int(use_Y)}"]
+        for a in range(want.shape[0]):
+            assert np.array_equal(env_oracle.index_to_move(d, a, model, use_Y), want[a])
+
+
+def test_readme_known_answer():
+    """README.md:712-780: X flip on qubit (4,1) of d=5 violates exactly plaquettes (4,1) and (5,2)."""
+    g = load_golden("kats")
+    e = np.zeros((5, 5), int)
+    e[4, 1] = 1
+    syn = env_oracle.syndrome_grid(e)
+    assert np.array_equal(syn, g["kat_readme_syn"])
+    assert sorted(zip(*np.nonzero(syn))) == [(4, 1), (5, 2)]
+
+
+def test_logical_operator_kats():
+    g = load_golden("kats")
+    classes = []
+    for i in range(5):
+        e = g["kat_logical_err"][i].astype(int)
+        assert np.array_equal(env_oracle.syndrome_grid(e), g["kat_logical_syn"][i])
+        lab = env_oracle.homology_label(e, "DP")
+        assert np.array_equal(lab, g["kat_logical_label"][i])
+        classes.append((int(g["kat_logical_syn"][i].sum()), int(lab.argmax())))
+    assert classes == [(0, 1), (0, 2), (1, 1), (2, 0), (1, 3)]
+
+
+@pytest.mark.parametrize("d", [3, 5])
+def test_referee_lut(d):
+    g = load_golden("referee_lut")
+    for typ, nm in ((3, "x"), (1, "z")):
+        lut = referee.build_lut(d, typ)
+        assert np.array_equal(lut, g[f"lut_{nm}_d{d}"])
+        assert hashlib.sha256(lut.tobytes()).digest() == g[f"lut_{nm}_sha256_d{d}"].tobytes()
+        assert lut[0] == 0
+        # a single flip is always decoded correctly by a min-weight referee
+        n, deltas = referee.component_deltas(d, typ)
+        for dl in deltas:
+            assert lut[dl & ((1 << n) - 1)] == dl >> n
+
+
+def _luts(d):
+    from functools import lru_cache
+    return _lut_cache(d)
+
+
+_CACHE = {}
+
+
+def _lut_cache(d):
+    if d not in _CACHE:
+        if d == 7:
+            from oracle import c_oracle
+            _CACHE[d] = (c_oracle.build_lut(7, 3), c_oracle.build_lut(7, 1))
+        else:
+            _CACHE[d] = (referee.build_lut(d, 3), referee.build_lut(d, 1))
+    return _CACHE[d]
+
+
+def _replay_trace(name, auto_reset):
+    g = load_golden("trace_" + name)
+    cfg, n_envs, n_steps, seed = trace_config(g)
+    d = cfg["d"]
+    lx, lz = _lut_cache(d)
+    m = lattice.Masks(d)
+    # the pure-Python restatement is slow; the C restatement (test_oracle_c.py) replays every lattice
+    for e in range(min(n_envs, {3: 16, 5: 6, 7: 3}[d])):
+        env = env_oracle.OracleEnv(referee=referee.LutReferee(d, cfg["error_model"], lx, lz), seed=seed, env_id=e, **cfg)
+
+        def check(t):
+            assert np.array_equal(env.board_state, g["obs"][e, t]), (name, e, t)
+            assert env.done == bool(g["done"][e, t]) and env.lifetime == g["lifetime"][e, t], (name, e, t)
+            assert np.array_equal(env.hidden_state, g["hidden"][e, t])
+            assert np.array_equal(env.current_true_syndrome, g["true_syndrome"][e, t])
+            assert np.array_equal(m.word_to_grid(env.summed_word), g["summed_nonzero"][e, t])
+            assert env.legal & (2 ** 64 - 1) == int(g["legal"][e, t, 0]) and env.legal >> 64 == int(g["legal"][e, t, 1])
+            assert [(env.completed >> a) & 1 for a in range(env.num_actions)] == list(g["completed"][e, t])
+            assert env.acted == int(g["acted"][e, t]) and env.round == g["rounds"][e, t]
+
+        env.reset()
+        check(0)
+        for t in range(n_steps):
+            if auto_reset and env.done:
+                assert g["was_reset"][e, t] == 1
+                env.reset()
+                r = 0.0
+            else:
+                assert g["was_reset"][e, t] == 0
+                _, r, _, _ = env.step(int(g["action"][e, t]))
+            assert r == g["reward"][e, t]
+            check(t + 1)
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_episode_traces(name):
+    _replay_trace(name, auto_reset=True)
+
+
+@pytest.mark.parametrize("name", STICKY_TRACES)
+def test_sticky_done_traces(name):
+    _replay_trace(name, auto_reset=False)
