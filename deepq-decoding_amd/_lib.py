@@ -1,0 +1,93 @@
+"""ctypes binding of libdeepq_hip.so (include/deepq_hip.h).
+
+The HIP library IS the product: if it cannot be loaded this module raises, and every compute
+entry point raises when no GPU is visible.  There is no CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdeepq_hip.so")
+
+DQ_MODEL_X, DQ_MODEL_DP = 0, 1
+STREAM_ENV, STREAM_POLICY, STREAM_REPLAY, STREAM_DROPOUT, STREAM_INIT = range(5)
+
+
+class DeepQError(RuntimeError):
+    pass
+
+
+class EnvCfg(ctypes.Structure):
+    _fields_ = [("d", ctypes.c_int32), ("error_model", ctypes.c_int32), ("use_Y", ctypes.c_int32),
+                ("volume_depth", ctypes.c_int32), ("n_envs", ctypes.c_int32), ("env_id_base", ctypes.c_uint32),
+                ("seed", ctypes.c_uint32 * 2)]
+
+
+class EnvInfo(ctypes.Structure):
+    _fields_ = [("num_actions", ctypes.c_int32), ("n_action_layers", ctypes.c_int32), ("identity_index", ctypes.c_int32),
+                ("obs_c", ctypes.c_int32), ("obs_h", ctypes.c_int32), ("obs_w", ctypes.c_int32),
+                ("n_stab", ctypes.c_int32), ("state_words", ctypes.c_int32)]
+
+
+_vp, _i, _u32, _u64, _dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
+
+# name -> (restype, argtypes); must list every symbol include/deepq_hip.h declares
+SIGNATURES = {
+    "dq_version": (_i, []),
+    "dq_last_error": (ctypes.c_char_p, []),
+    "dq_device_count": (_i, []),
+    "dq_env_create": (_i, [ctypes.POINTER(EnvCfg), ctypes.POINTER(_vp)]),
+    "dq_env_destroy": (None, [_vp]),
+    "dq_env_get_info": (_i, [_vp, ctypes.POINTER(EnvInfo)]),
+    "dq_env_set_rates": (_i, [_vp, _dbl, _dbl]),
+    "dq_env_build_referee": (_i, [_vp, _vp]),
+    "dq_env_set_referee": (_i, [_vp, _vp, _vp]),
+    "dq_env_get_referee": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "dq_env_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "dq_env_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dq_env_export_state": (_i, [_vp, _vp, _vp]),
+    "dq_env_import_state": (_i, [_vp, _vp, _vp]),
+    "dq_env_get_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "dq_policy_select": (_i, [_vp, _vp, _i, _i, _dbl, _i, ctypes.POINTER(_u32), _u32, _u64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises DeepQError if the .so is absent)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DeepQError(
+                f"{LIB_PATH} not found: build it with `python deepq-decoding_amd/build.py` "
+                "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise DeepQError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the build is stale
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise DeepQError(f"libdeepq_hip error {status}: {lib().dq_last_error().decode()}")
+
+
+def require_gpu():
+    if lib().dq_device_count() < 1:
+        raise DeepQError("no HIP device visible: the DeepQ-Decoding hot path runs only on an MI355X (no CPU fallback)")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,52 @@
+"""Builds libdeepq_hip.so (all HIP kernels + the C ABI of include/deepq_hip.h) for gfx950, in-tree.
+
+    python deepq-decoding_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box.
+"""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT_DIR, "libdeepq_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "deepq_hip.h")]
+    objs, jobs = [], []
+    for s in srcs:
+        o = os.path.join(OUT_DIR, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

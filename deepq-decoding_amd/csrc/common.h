@@ -1,0 +1,99 @@
+// Shared helpers of libdeepq_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/deepq_hip.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define DQ_WAVE 64
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void dq_set_error(const char* fmt, ...);
+
+#define DQ_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            dq_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return DQ_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define DQ_REQUIRE(cond, code, ...)  \
+    do {                             \
+        if (!(cond)) {               \
+            dq_set_error(__VA_ARGS__); \
+            return (code);           \
+        }                            \
+    } while (0)
+
+#define DQ_LAUNCH_CHECK()                                                           \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            dq_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return DQ_ERR_HIP;                                                      \
+        }                                                                           \
+    } while (0)
+
+// W / 2^32 < p  <=>  W < ceil(p * 2^32)   (oracle/philox.py threshold())
+static inline u64 dq_rate_threshold(double p) {
+    double t = p * 4294967296.0;
+    if (!(t > 0.0)) return 0;
+    if (t >= 4294967296.0) return 1ull << 32;
+    u64 f = (u64)t;
+    return ((double)f < t) ? f + 1 : f;
+}
+
+// ---- device helpers -----------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// Philox4x32-10 (Salmon et al., SC'11).  Counter words c0..c3, key k0,k1.
+__device__ __forceinline__ void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Broadcast lane `src` (compile-time or wave-uniform) of a 64-bit value to the whole wave (SGPR pair).
+__device__ __forceinline__ u64 wave_bcast64(u64 v, int src) {
+    const u32 lo = __builtin_amdgcn_readlane((int)(u32)v, src);
+    const u32 hi = __builtin_amdgcn_readlane((int)(u32)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 wave_uniform64(u64 v) {
+    const u32 lo = __builtin_amdgcn_readfirstlane((int)(u32)v);
+    const u32 hi = __builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// index of the k-th (0-based) set bit of a 128-bit mask; -1 if fewer bits are set
+__device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
+    const int nlo = __popcll(lo);
+    u64 m = lo;
+    int base = 0;
+    if (k >= nlo) { m = hi; k -= nlo; base = 64; }
+    if (k >= __popcll(m)) return -1;
+    for (int i = 0; i < k; ++i) m &= m - 1;      // drop the k lowest set bits
+    return base + __ffsll((long long)m) - 1;
+}
+
+#endif  // __HIPCC__

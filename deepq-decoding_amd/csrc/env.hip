@@ -1,0 +1,590 @@
+// Batched surface-code decoding environment for gfx950: one lattice per wavefront.
+//
+// Replaces Surface_Code_Environment_Multi_Decoding_Cycles.reset()/step()
+// (/root/reference/example_notebooks/Environments.py:99-235, "ENV") together with the helper loops
+// it calls in Function_Library.py ("FL": generate_error FL:67-122, syndrome FL:152-174,
+// generate_faulty_syndrome FL:176-223, obtain_new_error_configuration FL:226-241, index_to_move
+// FL:243-294, generate_one_hot_labels_surface_code FL:296-326).
+//
+// Formulation.  Pauli codes multiply as XOR (FL:54-62), so a lattice's hidden state is two qubit
+// bit-planes (xmask, zmask) held wave-uniform in SGPRs.  Lane l owns qubit l and stabilizer l:
+//   * noise: one Philox4x32-10 evaluation per lane per measurement round gives the lane's error
+//     uniform, Pauli type and measurement uniform; three wave ballots turn 64 comparisons into the
+//     round's error planes and measurement-flip word;
+//   * syndrome: lane s ANDs the matching plane with its plaquette's qubit mask, popcounts, and a
+//     ballot assembles the syndrome word (parity reduction by ballot, no LDS traffic);
+//   * referee: a per-lane bit pick + ballot permutes the syndrome word into the two look-up
+//     indices; the bit-packed tables sit in L2;
+//   * observation: the C x (2d+1) x (2d+1) uint8 planes of the block's four lattices are composed
+//     in LDS from the volume words / action mask and leave as coalesced dword stores.
+// HBM traffic per lattice-step: one 128 B state record in, one out, plus the observation.
+#include "common.h"
+#include <new>
+#include <stdarg.h>
+
+#define DQ_MAX_DEPTH 16
+#define ENVS_PER_BLOCK 4
+#define STATE_FIXED 9      // internal record: xmask zmask acted round comp0 comp1 legal0 legal1 meta, then volume
+#define EXPORT_FIXED 11
+
+struct EnvTables {
+    u64 stab_qmask[64];    // qubits of stabilizer s (measurement order), 0 beyond n_stab
+    u64 qubit_smask[64];   // live stabilizers touched by qubit q (ENV:262-271)
+    u64 neigh_qmask[64];   // 8-neighbourhood of qubit q (ENV:349-372)
+    u8 stab_isx[64];       // 1: type-3 plaquette (parity of the X component), 0: type 1 (Z component)
+    u8 stab_type[64];
+    u8 ref_src[64];        // lane h <- stabilizer whose bit lands at referee position h (255: none)
+    u8 cell_static[256];   // padding_syndrome decoration (ENV:284-298)
+    u8 cell_stab[256];     // stabilizer shown at an even-even cell (ENV:292-294), 255: none
+    u8 cell_qubit[256];    // qubit shown at an odd-odd cell of an action plane (ENV:301-314), 255: none
+    u64 col0, row0;        // FL:312-317
+};
+
+struct dq_env {
+    dq_env_cfg cfg;
+    dq_env_info info;
+    int sw;                // internal state stride in u64 words
+    int P;                 // cells per observation plane
+    u64 T_phys, T_meas;
+    bool rates_set;
+    EnvTables h_tab;
+    EnvTables* d_tab;
+    u64* d_state;
+    u32 *d_lut_x, *d_lut_z;        // owned tables (dq_env_build_referee)
+    const u32 *lut_x, *lut_z;      // tables in use
+    u32 ref_delta[2][64];          // BFS generators per component (x, z)
+};
+
+struct EnvParams {
+    const EnvTables* tab;
+    u64* state;
+    const u32 *lut_x, *lut_z;
+    int n_envs, d2, n_stab, depth, layers, n_actions, identity, model, use_Y, sw, P, C, obs_size;
+    u32 env_id_base, seed0, seed1;
+    u64 T_phys, T_meas;
+    int mode, auto_reset;          // mode 0: reset, 1: step
+    const u8* which;
+    const int32_t* action;
+    u8* obs;
+    float* reward;
+    u8* done;
+    u64* legal;
+    u32* lifetime;
+    u8* was_reset;
+};
+
+static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s) {
+    if (s == 0) { lo |= v; }
+    else if (s < 64) { lo |= v << s; hi |= v >> (64 - s); }
+    else { hi |= v << (s - 64); }
+}
+
+__global__ __launch_bounds__(256) void env_kernel(EnvParams p) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u64* s_vol = reinterpret_cast<u64*>(smem);                              // [4][16]
+    u8* s_static = smem + ENVS_PER_BLOCK * DQ_MAX_DEPTH * 8;                // [256]
+    u8* s_stab = s_static + 256;
+    u8* s_qubit = s_stab + 256;
+    u8* s_stage = s_qubit + 256;                                            // [4 * obs_size]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * ENVS_PER_BLOCK + wave;
+    const bool active = i < p.n_envs;                                        // wave-uniform
+
+    s_static[tid] = p.tab->cell_static[tid];
+    s_stab[tid] = p.tab->cell_stab[tid];
+    s_qubit[tid] = p.tab->cell_qubit[tid];
+
+    const u64 sq = p.tab->stab_qmask[lane];
+    const u64 qs = p.tab->qubit_smask[lane];
+    const bool isx = p.tab->stab_isx[lane] != 0;
+    const int rsrc = p.tab->ref_src[lane];
+    volatile u64* vol = s_vol + wave * DQ_MAX_DEPTH;   // written by lane 0, read by other lanes of the same wave
+
+    u64 comp0 = 0, comp1 = 0;
+    if (active) {
+        u64* rec = p.state + (size_t)i * p.sw;
+        const u64 word = lane < p.sw ? rec[lane] : 0;
+        u64 xmask = wave_bcast64(word, 0), zmask = wave_bcast64(word, 1), acted = wave_bcast64(word, 2);
+        u64 round = wave_bcast64(word, 3);
+        comp0 = wave_bcast64(word, 4);
+        comp1 = wave_bcast64(word, 5);
+        u64 legal0 = wave_bcast64(word, 6), legal1 = wave_bcast64(word, 7);
+        const u64 meta = wave_bcast64(word, 8);
+        u32 lifetime = (u32)meta;
+        int done = (int)((meta >> 32) & 1);
+        if (lane >= STATE_FIXED && lane < STATE_FIXED + p.depth) vol[lane - STATE_FIXED] = word;
+
+        bool do_reset;
+        if (p.mode == 0) {
+            do_reset = p.which ? (__builtin_amdgcn_readfirstlane((int)p.which[i]) != 0) : true;
+        } else {
+            do_reset = p.auto_reset && done;
+        }
+        const bool do_step = p.mode == 1 && !do_reset;
+        float reward = 0.f;
+        bool need_volume = do_reset;
+        if (do_reset) {                                                     // ENV:106-107, 211-213
+            done = 0; lifetime = 0; xmask = 0; zmask = 0;
+        }
+        if (do_step) {
+            int a = __builtin_amdgcn_readfirstlane(p.action[i]);
+            if ((unsigned)a >= (unsigned)p.n_actions) a = p.identity;
+            const u64 cw = a < 64 ? comp0 : comp1;
+            const bool done_identity = a == p.identity || ((cw >> (a & 63)) & 1);      // ENV:131
+            if (a != p.identity) {                                          // ENV:135-136, FL:243-294
+                const int layer = a / p.d2, q = a - layer * p.d2;
+                const int pauli = p.model == DQ_MODEL_X ? 1 : (p.use_Y ? layer + 1 : (layer == 0 ? 1 : 3));
+                if (pauli != 3) xmask ^= 1ull << q;
+                if (pauli != 1) zmask ^= 1ull << q;
+            }
+            const u64 true_word = __ballot(__popcll((isx ? xmask : zmask) & sq) & 1);   // ENV:139, FL:152-174
+            const int cls = (__popcll(xmask & p.tab->col0) & 1) + 2 * (__popcll(zmask & p.tab->row0) & 1);  // ENV:143
+            const u64 refw = __ballot(rsrc < 64 && ((true_word >> (rsrc & 63)) & 1));
+            const u32 ix = (u32)refw, iz = (u32)(refw >> 32);
+            int dec = (p.lut_x[ix >> 5] >> (ix & 31)) & 1;                  // ENV:144
+            if (p.model != DQ_MODEL_X) dec += 2 * ((p.lut_z[iz >> 5] >> (iz & 31)) & 1);
+            dec = __builtin_amdgcn_readfirstlane(dec);
+            if (cls == 0 && true_word == 0) reward = 1.f;                   // ENV:148-149
+            else if (dec != cls) done = 1;                                  // ENV:150-151
+            if (done_identity) {
+                need_volume = true;                                         // ENV:155
+            } else {                                                        // ENV:185-196
+                if (a < 64) comp0 |= 1ull << a; else comp1 |= 1ull << (a - 64);
+                const int q = a % p.d2;
+                if (!((acted >> q) & 1)) {
+                    acted |= 1ull << q;
+                    const u64 nm = p.tab->neigh_qmask[q];
+                    for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, nm, j * p.d2);
+                }
+            }
+        }
+        if (need_volume) {                                                  // ENV:157-172 == ENV:216-231
+            u64 summed;
+            do {
+                summed = 0;
+                for (int j = 0; j < p.depth; ++j) {
+                    u32 w[4];
+                    philox4x32_10((u32)round, (u32)(round >> 32), p.env_id_base + (u32)i, (u32)lane, p.seed0, p.seed1, w);
+                    const bool hit = lane < p.d2 && (u64)w[0] < p.T_phys;   // FL:99 / FL:119
+                    const int typ = p.model == DQ_MODEL_X ? 1 : 1 + (int)__umulhi(w[1], 3u);   // FL:100
+                    const u64 ex = __ballot(hit && typ != 3);
+                    const u64 ez = __ballot(hit && typ != 1);
+                    const u64 flips = __ballot(lane < p.n_stab && (u64)w[2] < p.T_meas);      // FL:191-221
+                    ++round;
+                    xmask ^= ex;                                            // ENV:164, FL:226-241
+                    zmask ^= ez;
+                    const u64 tw = __ballot(__popcll((isx ? xmask : zmask) & sq) & 1);        // ENV:165
+                    const u64 v = tw ^ flips;                               // ENV:166
+                    if (lane == 0) vol[j] = v;
+                    summed |= v;                                            // ENV:168
+                    ++lifetime;                                             // ENV:169
+                }
+            } while (summed == 0);                                          // ENV:171
+            // reset_legal_moves, ENV:238-258
+            comp0 = comp1 = 0; acted = 0;
+            const u64 legal_q = __ballot(lane < p.d2 && (qs & summed) != 0);
+            legal0 = legal1 = 0;
+            or_shl128(legal0, legal1, 1ull, p.identity);
+            for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, legal_q, j * p.d2);
+        }
+
+        // ---- state record and scalar outputs ----------------------------------------------------
+        const u64 meta_out = (u64)lifetime | ((u64)done << 32);
+        u64 o = 0;
+        o = lane == 0 ? xmask : o;  o = lane == 1 ? zmask : o;  o = lane == 2 ? acted : o;
+        o = lane == 3 ? round : o;  o = lane == 4 ? comp0 : o;  o = lane == 5 ? comp1 : o;
+        o = lane == 6 ? legal0 : o; o = lane == 7 ? legal1 : o; o = lane == 8 ? meta_out : o;
+        if (lane >= STATE_FIXED && lane < STATE_FIXED + p.depth) o = vol[lane - STATE_FIXED];
+        if (lane < p.sw) rec[lane] = o;
+        if (lane == 0) {
+            if (p.reward) p.reward[i] = reward;
+            if (p.done) p.done[i] = (u8)done;
+            if (p.lifetime) p.lifetime[i] = lifetime;
+            if (p.was_reset) p.was_reset[i] = (u8)(p.mode == 1 && do_reset);
+            if (p.legal) { p.legal[2 * (size_t)i] = legal0; p.legal[2 * (size_t)i + 1] = legal1; }
+        }
+    }
+
+    if (!p.obs) return;                                                     // block-uniform
+    __syncthreads();                                                        // cell tables visible
+    if (active) {
+        // observation planes into the LDS stage (ENV:174-175, 200-201, 273-314)
+        u8* st = s_stage + wave * p.obs_size;
+        for (int j = 0; j < p.depth; ++j) {
+            const u64 v = vol[j];
+            for (int c = lane; c < p.P; c += 64) {
+                const int sidx = s_stab[c];
+                st[j * p.P + c] = (u8)(s_static[c] | (sidx < 64 ? (u32)((v >> (sidx & 63)) & 1) : 0u));
+            }
+        }
+        for (int k = 0; k < p.layers; ++k) {
+            for (int c = lane; c < p.P; c += 64) {
+                const int qi = s_qubit[c];
+                u32 bit = 0;
+                if (qi < 64) {
+                    const int a = k * p.d2 + qi;
+                    bit = (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1);
+                }
+                st[(p.depth + k) * p.P + c] = (u8)bit;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int first = blockIdx.x * ENVS_PER_BLOCK;
+        const int n_valid = min(ENVS_PER_BLOCK, p.n_envs - first);
+        const int total = n_valid * p.obs_size;
+        u8* g = p.obs + (size_t)first * p.obs_size;
+        if ((reinterpret_cast<uintptr_t>(g) & 3) == 0) {
+            const u32* s32 = reinterpret_cast<const u32*>(s_stage);
+            u32* g32 = reinterpret_cast<u32*>(g);
+            const int ndw = total >> 2;
+            for (int k = tid; k < ndw; k += 256) g32[k] = s32[k];
+            for (int k = (ndw << 2) + tid; k < total; k += 256) g[k] = s_stage[k];
+        } else {
+            for (int k = tid; k < total; k += 256) g[k] = s_stage[k];
+        }
+    }
+}
+
+// ---- state export / import (tests, checkpointing) ------------------------------------------------
+__global__ void env_export_kernel(const EnvTables* tab, const u64* state, u64* out, int n_envs, int sw, int depth) {
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_envs) return;
+    const u64* rec = state + (size_t)i * sw;
+    const u64 word = lane < sw ? rec[lane] : 0;
+    const u64 xmask = wave_bcast64(word, 0), zmask = wave_bcast64(word, 1);
+    const u64 true_word = __ballot(__popcll((tab->stab_isx[lane] ? xmask : zmask) & tab->stab_qmask[lane]) & 1);
+    u64 summed = 0;
+    for (int j = 0; j < depth; ++j) summed |= wave_bcast64(word, STATE_FIXED + j);
+    u64* o = out + (size_t)i * (EXPORT_FIXED + depth);
+    // export order: xmask zmask true summed acted round comp0 comp1 legal0 legal1 meta volume...
+    if (lane < 2) o[lane] = word;
+    if (lane == 2) { o[2] = true_word; o[3] = summed; }
+    if (lane >= 2 && lane < STATE_FIXED) o[lane + 2] = word;
+    if (lane >= STATE_FIXED && lane < STATE_FIXED + depth) o[lane + 2] = word;
+}
+
+__global__ void env_import_kernel(u64* state, const u64* in, int n_envs, int sw, int depth) {
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_envs) return;
+    const u64* src = in + (size_t)i * (EXPORT_FIXED + depth);
+    u64 v = 0;
+    if (lane < 2) v = src[lane];
+    else if (lane < STATE_FIXED + depth) v = src[lane + 2];
+    if (lane < sw) state[(size_t)i * sw + lane] = v;
+}
+
+// ---- referee look-up tables: level-synchronous BFS over (syndrome, class) on the GPU --------------
+struct BfsDeltas { u32 d[64]; int nq; };
+
+__global__ void bfs_fill_kernel(u8* dist, size_t size) {
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < size; s += (size_t)gridDim.x * blockDim.x)
+        dist[s] = s == 0 ? 0 : 255;
+}
+
+__global__ void bfs_level_kernel(u8* dist, u32 size, BfsDeltas dl, u8 w, u32* changed) {
+    bool any = false;
+    for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < size; s += gridDim.x * blockDim.x) {
+        if (dist[s] != (u8)(w - 1)) continue;
+        for (int q = 0; q < dl.nq; ++q) {
+            const u32 t = s ^ dl.d[q];
+            if (dist[t] == 255) { dist[t] = w; any = true; }     // every racing writer stores the same w
+        }
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(changed, 1u);
+}
+
+__global__ void bfs_pack_kernel(const u8* dist, u32 half, u32* lut) {
+    const u32 wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= (half + 31) / 32) return;
+    u32 bits = 0;
+    for (int b = 0; b < 32; ++b) {
+        const u32 s = wi * 32 + b;
+        if (s < half && dist[half + s] < dist[s]) bits |= 1u << b;   // class 1 iff strictly lighter
+    }
+    lut[wi] = bits;
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+static int plaquette_type(int d, int a, int b) {     // FL:32-35, FL:42-50
+    if ((a == 0 && b % 2 == 0) || (a == d && b % 2 == 1) || (b == 0 && a % 2 == 1) || (b == d && a % 2 == 0)) return 0;
+    return ((a + b) & 1) ? 3 : 1;
+}
+
+static void build_tables(dq_env* E) {
+    EnvTables& T = E->h_tab;
+    memset(&T, 0, sizeof(T));
+    memset(T.ref_src, 255, sizeof(T.ref_src));
+    memset(T.cell_stab, 255, sizeof(T.cell_stab));
+    memset(T.cell_qubit, 255, sizeof(T.cell_qubit));
+    const int d = E->cfg.d, n_stab = d * d - 1, half = (d + 1) / 2 - 1, n = 2 * d + 1;
+    int sa[64], sb[64], index[16][16];
+    for (int a = 0; a <= d; ++a) for (int b = 0; b <= d; ++b) index[a][b] = -1;
+    int s = 0;
+    for (int a = 1; a < d; ++a) for (int b = 1; b < d; ++b) { sa[s] = a; sb[s] = b; ++s; }   // FL:189-194
+    for (int x = 0; x < half; ++x) { sa[s] = 0; sb[s] = 2 * x + 1; ++s; }                    // FL:197-202
+    for (int x = 0; x < half; ++x) { sa[s] = d; sb[s] = 2 * x + 2; ++s; }                    // FL:203-208
+    for (int x = 0; x < half; ++x) { sa[s] = 2 * x + 2; sb[s] = 0; ++s; }                    // FL:210-215
+    for (int x = 0; x < half; ++x) { sa[s] = 2 * x + 1; sb[s] = d; ++s; }                    // FL:216-221
+    for (s = 0; s < n_stab; ++s) {
+        const int a = sa[s], b = sb[s];
+        index[a][b] = s;
+        T.stab_type[s] = (u8)plaquette_type(d, a, b);
+        T.stab_isx[s] = T.stab_type[s] == 3;
+        for (int x = a - 1; x <= a; ++x) for (int y = b - 1; y <= b; ++y)
+            if (x >= 0 && x < d && y >= 0 && y < d) {
+                T.stab_qmask[s] |= 1ull << (x * d + y);
+                T.qubit_smask[x * d + y] |= 1ull << s;
+            }
+        T.cell_stab[2 * a * n + 2 * b] = (u8)s;                                              // ENV:292-294
+    }
+    // referee bit order: rank among same-type plaquettes in row-major (a,b); X part -> lanes 0.., Z part -> lanes 32..
+    int rank3 = 0, rank1 = 0, ref_bit[64];
+    for (int a = 0; a <= d; ++a) for (int b = 0; b <= d; ++b) {
+        const int t = plaquette_type(d, a, b);
+        if (t == 3) { ref_bit[index[a][b]] = rank3; T.ref_src[rank3++] = (u8)index[a][b]; }
+        if (t == 1) { ref_bit[index[a][b]] = rank1; T.ref_src[32 + rank1++] = (u8)index[a][b]; }
+    }
+    for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) {
+        for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {
+            const int rr = r + dr, cc = c + dc;
+            if ((dr || dc) && rr >= 0 && rr < d && cc >= 0 && cc < d) T.neigh_qmask[r * d + c] |= 1ull << (rr * d + cc);
+        }
+        T.cell_qubit[(2 * r + 1) * n + 2 * c + 1] = (u8)(r * d + c);                         // ENV:309-312
+    }
+    for (int x = 0; x < d; ++x) T.col0 |= 1ull << (x * d);
+    for (int y = 0; y < d; ++y) T.row0 |= 1ull << y;
+    for (int x = 0; x < n; ++x) for (int y = 0; y < n; ++y) {                                // ENV:284-298
+        u8 v = 0;
+        if ((x == 0 || x == n - 1) && (y & 1)) v = 1;
+        if ((y == 0 || y == n - 1) && (x & 1)) v = 1;
+        if ((x & 1) && (y & 1) && ((x + y) % 4 == 0)) v = 1;
+        T.cell_static[x * n + y] = v;
+    }
+    // BFS generators: flipping component `comp` of qubit q toggles these referee-index bits (+ the logical bit)
+    const int nh = n_stab / 2;
+    for (int comp = 0; comp < 2; ++comp) {
+        const int typ = comp == 0 ? 3 : 1;
+        for (int x = 0; x < d; ++x) for (int y = 0; y < d; ++y) {
+            u32 dl = 0;
+            for (s = 0; s < n_stab; ++s)
+                if (((T.qubit_smask[x * d + y] >> s) & 1) && T.stab_type[s] == typ) dl |= 1u << ref_bit[s];
+            const int logical = comp == 0 ? (y == 0) : (x == 0);                             // FL:312-317
+            E->ref_delta[comp][x * d + y] = dl | ((u32)logical << nh);
+        }
+    }
+}
+
+static thread_local char g_err[512] = "";
+void dq_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int dq_version(void) { return 1; }
+const char* dq_last_error(void) { return g_err; }
+int dq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+dq_status dq_env_create(const dq_env_cfg* cfg, dq_env** out) {
+    DQ_REQUIRE(cfg && out, DQ_ERR_INVALID, "dq_env_create: null argument");
+    *out = nullptr;
+    DQ_REQUIRE(cfg->d % 2 == 1, DQ_ERR_INVALID, "for the surface code d must be odd!");     // FL:28-29
+    DQ_REQUIRE(cfg->d >= 3 && cfg->d <= 7, DQ_ERR_UNSUPPORTED, "d=%d unsupported: one lattice per 64-lane wavefront needs d*d <= 64", cfg->d);
+    DQ_REQUIRE(cfg->error_model == DQ_MODEL_X || cfg->error_model == DQ_MODEL_DP, DQ_ERR_UNSUPPORTED,
+               "specified error model not currently supported!");                              // ENV:66-67
+    DQ_REQUIRE(cfg->volume_depth >= 1 && cfg->volume_depth <= DQ_MAX_DEPTH, DQ_ERR_UNSUPPORTED, "volume_depth must be in 1..%d", DQ_MAX_DEPTH);
+    DQ_REQUIRE(cfg->n_envs >= 1, DQ_ERR_INVALID, "n_envs must be positive");
+    dq_env* E = new (std::nothrow) dq_env();
+    DQ_REQUIRE(E, DQ_ERR_NOMEM, "out of host memory");
+    memset(E, 0, sizeof(*E));
+    E->cfg = *cfg;
+    const int d = cfg->d, d2 = d * d;
+    const int layers = cfg->error_model == DQ_MODEL_X ? 1 : (cfg->use_Y ? 3 : 2);             // ENV:55-65
+    E->info.n_action_layers = layers;
+    E->info.num_actions = layers * d2 + 1;
+    E->info.identity_index = E->info.num_actions - 1;                                         // ENV:69
+    E->info.obs_c = cfg->volume_depth + layers;                                               // ENV:78-82
+    E->info.obs_h = E->info.obs_w = 2 * d + 1;
+    E->info.n_stab = d2 - 1;
+    E->info.state_words = EXPORT_FIXED + cfg->volume_depth;
+    E->sw = STATE_FIXED + cfg->volume_depth <= 16 ? 16 : 32;
+    E->P = (2 * d + 1) * (2 * d + 1);
+    build_tables(E);
+    hipError_t e = hipMalloc(&E->d_tab, sizeof(EnvTables));
+    if (e == hipSuccess) e = hipMemcpy(E->d_tab, &E->h_tab, sizeof(EnvTables), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&E->d_state, (size_t)cfg->n_envs * E->sw * sizeof(u64));
+    if (e == hipSuccess) e = hipMemset(E->d_state, 0, (size_t)cfg->n_envs * E->sw * sizeof(u64));
+    if (e != hipSuccess) {
+        dq_set_error("dq_env_create: %s", hipGetErrorString(e));
+        dq_env_destroy(E);
+        return DQ_ERR_HIP;
+    }
+    *out = E;
+    return DQ_OK;
+}
+
+void dq_env_destroy(dq_env* E) {
+    if (!E) return;
+    if (E->d_tab) (void)hipFree(E->d_tab);
+    if (E->d_state) (void)hipFree(E->d_state);
+    if (E->d_lut_x) (void)hipFree(E->d_lut_x);
+    if (E->d_lut_z) (void)hipFree(E->d_lut_z);
+    delete E;
+}
+
+dq_status dq_env_get_info(const dq_env* E, dq_env_info* out) {
+    DQ_REQUIRE(E && out, DQ_ERR_INVALID, "dq_env_get_info: null argument");
+    *out = E->info;
+    return DQ_OK;
+}
+
+dq_status dq_env_set_rates(dq_env* E, double p_phys, double p_meas) {
+    DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_set_rates: null handle");
+    DQ_REQUIRE(p_phys >= 0.0 && p_phys <= 1.0 && p_meas >= 0.0 && p_meas <= 1.0, DQ_ERR_INVALID, "rates must be in [0,1]");
+    E->T_phys = dq_rate_threshold(p_phys);
+    E->T_meas = dq_rate_threshold(p_meas);
+    E->rates_set = true;
+    return DQ_OK;
+}
+
+static dq_status build_one_lut(dq_env* E, int comp, u32** out, hipStream_t st) {
+    const int nh = E->info.n_stab / 2;
+    const size_t size = (size_t)1 << (nh + 1), half = (size_t)1 << nh;
+    u8* dist = nullptr;
+    u32* changed = nullptr;
+    DQ_HIP(hipMalloc(&dist, size));
+    DQ_HIP(hipMalloc(&changed, sizeof(u32)));
+    const size_t words = (half + 31) / 32;
+    if (!*out) DQ_HIP(hipMalloc(out, words * sizeof(u32)));
+    BfsDeltas dl;
+    dl.nq = E->cfg.d * E->cfg.d;
+    for (int q = 0; q < 64; ++q) dl.d[q] = q < dl.nq ? E->ref_delta[comp][q] : 0;
+    const int blocks = (int)((size + 255) / 256 < 4096 ? (size + 255) / 256 : 4096);
+    bfs_fill_kernel<<<blocks, 256, 0, st>>>(dist, size);
+    for (int w = 1; w <= dl.nq + 1; ++w) {
+        u32 h = 0;
+        DQ_HIP(hipMemsetAsync(changed, 0, sizeof(u32), st));
+        bfs_level_kernel<<<blocks, 256, 0, st>>>(dist, (u32)size, dl, (u8)w, changed);
+        DQ_HIP(hipMemcpyAsync(&h, changed, sizeof(u32), hipMemcpyDeviceToHost, st));
+        DQ_HIP(hipStreamSynchronize(st));
+        if (!h) break;
+    }
+    bfs_pack_kernel<<<(int)((words + 255) / 256), 256, 0, st>>>(dist, (u32)half, *out);
+    DQ_LAUNCH_CHECK();
+    DQ_HIP(hipStreamSynchronize(st));
+    DQ_HIP(hipFree(dist));
+    DQ_HIP(hipFree(changed));
+    return DQ_OK;
+}
+
+dq_status dq_env_build_referee(dq_env* E, void* stream) {
+    DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_build_referee: null handle");
+    hipStream_t st = (hipStream_t)stream;
+    dq_status rc = build_one_lut(E, 0, &E->d_lut_x, st);
+    if (rc != DQ_OK) return rc;
+    rc = build_one_lut(E, 1, &E->d_lut_z, st);
+    if (rc != DQ_OK) return rc;
+    E->lut_x = E->d_lut_x;
+    E->lut_z = E->d_lut_z;
+    return DQ_OK;
+}
+
+dq_status dq_env_set_referee(dq_env* E, const uint32_t* lut_x_dev, const uint32_t* lut_z_dev) {
+    DQ_REQUIRE(E && lut_x_dev, DQ_ERR_INVALID, "dq_env_set_referee: null argument");
+    DQ_REQUIRE(lut_z_dev || E->cfg.error_model == DQ_MODEL_X, DQ_ERR_INVALID, "dq_env_set_referee: the DP model needs a Z table");
+    E->lut_x = lut_x_dev;
+    E->lut_z = lut_z_dev ? lut_z_dev : lut_x_dev;
+    return DQ_OK;
+}
+
+dq_status dq_env_get_referee(dq_env* E, uint8_t* lut_x_host, uint8_t* lut_z_host, size_t entries) {
+    DQ_REQUIRE(E && E->lut_x, DQ_ERR_STATE, "dq_env_get_referee: no referee installed");
+    const size_t half = (size_t)1 << (E->info.n_stab / 2), words = (half + 31) / 32;
+    DQ_REQUIRE(entries == half, DQ_ERR_INVALID, "dq_env_get_referee: expected %zu entries", half);
+    u32* tmp = new (std::nothrow) u32[words];
+    DQ_REQUIRE(tmp, DQ_ERR_NOMEM, "out of host memory");
+    const u32* src[2] = {E->lut_x, E->lut_z};
+    u8* dst[2] = {lut_x_host, lut_z_host};
+    for (int c = 0; c < 2; ++c) {
+        if (!dst[c] || !src[c]) continue;
+        hipError_t e = hipMemcpy(tmp, src[c], words * sizeof(u32), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { delete[] tmp; dq_set_error("dq_env_get_referee: %s", hipGetErrorString(e)); return DQ_ERR_HIP; }
+        for (size_t s = 0; s < half; ++s) dst[c][s] = (tmp[s >> 5] >> (s & 31)) & 1;
+    }
+    delete[] tmp;
+    return DQ_OK;
+}
+
+static dq_status launch_env(dq_env* E, EnvParams& p, hipStream_t st) {
+    DQ_REQUIRE(E->rates_set, DQ_ERR_STATE, "dq_env_set_rates has not been called");
+    p.tab = E->d_tab; p.state = E->d_state; p.lut_x = E->lut_x; p.lut_z = E->lut_z;
+    p.n_envs = E->cfg.n_envs; p.d2 = E->cfg.d * E->cfg.d; p.n_stab = E->info.n_stab; p.depth = E->cfg.volume_depth;
+    p.layers = E->info.n_action_layers; p.n_actions = E->info.num_actions; p.identity = E->info.identity_index;
+    p.model = E->cfg.error_model; p.use_Y = E->cfg.use_Y; p.sw = E->sw; p.P = E->P; p.C = E->info.obs_c;
+    p.obs_size = E->info.obs_c * E->P;
+    p.env_id_base = E->cfg.env_id_base; p.seed0 = E->cfg.seed[0]; p.seed1 = E->cfg.seed[1];
+    p.T_phys = E->T_phys; p.T_meas = E->T_meas;
+    const int blocks = (p.n_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    const size_t lds = ENVS_PER_BLOCK * DQ_MAX_DEPTH * 8 + 3 * 256 + (size_t)ENVS_PER_BLOCK * ((p.obs_size + 3) & ~3);
+    env_kernel<<<blocks, 256, lds, st>>>(p);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_env_reset(dq_env* E, const uint8_t* which_dev, uint8_t* obs_dev, uint64_t* legal_dev,
+                       uint32_t* lifetime_dev, void* stream) {
+    DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_reset: null handle");
+    EnvParams p;
+    memset(&p, 0, sizeof(p));
+    p.mode = 0; p.which = which_dev; p.obs = obs_dev; p.legal = legal_dev; p.lifetime = lifetime_dev;
+    return launch_env(E, p, (hipStream_t)stream);
+}
+
+dq_status dq_env_step(dq_env* E, const int32_t* action_dev, int auto_reset, uint8_t* obs_dev,
+                      float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev, uint32_t* lifetime_dev,
+                      uint8_t* was_reset_dev, void* stream) {
+    DQ_REQUIRE(E && action_dev, DQ_ERR_INVALID, "dq_env_step: null argument");
+    DQ_REQUIRE(E->lut_x, DQ_ERR_STATE, "dq_env_step: no referee installed (dq_env_build_referee / dq_env_set_referee)");
+    EnvParams p;
+    memset(&p, 0, sizeof(p));
+    p.mode = 1; p.auto_reset = auto_reset; p.action = action_dev; p.obs = obs_dev; p.reward = reward_dev;
+    p.done = done_dev; p.legal = legal_dev; p.lifetime = lifetime_dev; p.was_reset = was_reset_dev;
+    return launch_env(E, p, (hipStream_t)stream);
+}
+
+dq_status dq_env_export_state(dq_env* E, uint64_t* state_dev, void* stream) {
+    DQ_REQUIRE(E && state_dev, DQ_ERR_INVALID, "dq_env_export_state: null argument");
+    const int n = E->cfg.n_envs;
+    env_export_kernel<<<(n + 3) / 4, 256, 0, (hipStream_t)stream>>>(E->d_tab, E->d_state, state_dev, n, E->sw, E->cfg.volume_depth);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_env_import_state(dq_env* E, const uint64_t* state_dev, void* stream) {
+    DQ_REQUIRE(E && state_dev, DQ_ERR_INVALID, "dq_env_import_state: null argument");
+    const int n = E->cfg.n_envs;
+    env_import_kernel<<<(n + 3) / 4, 256, 0, (hipStream_t)stream>>>(E->d_state, state_dev, n, E->sw, E->cfg.volume_depth);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_env_get_tables(const dq_env* E, uint64_t* stab_qmask, uint64_t* qubit_smask, uint64_t* neigh_qmask, uint8_t* stab_type) {
+    DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_get_tables: null handle");
+    if (stab_qmask) memcpy(stab_qmask, E->h_tab.stab_qmask, sizeof(E->h_tab.stab_qmask));
+    if (qubit_smask) memcpy(qubit_smask, E->h_tab.qubit_smask, sizeof(E->h_tab.qubit_smask));
+    if (neigh_qmask) memcpy(neigh_qmask, E->h_tab.neigh_qmask, sizeof(E->h_tab.neigh_qmask));
+    if (stab_type) memcpy(stab_type, E->h_tab.stab_type, sizeof(E->h_tab.stab_type));
+    return DQ_OK;
+}
+
+}  // extern "C"

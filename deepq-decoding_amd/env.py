@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference environment over the HIP library.
+
+* ``VectorEnv``  -- N independent lattices stepped by one kernel launch; all tensors stay on the GPU.
+* ``Surface_Code_Environment_Multi_Decoding_Cycles`` -- drop-in for the reference class of the same
+  name (/root/reference/example_notebooks/Environments.py:10-385, "ENV"): one lattice, numpy/int
+  views, same attributes and methods, so keras-rl-style loops and the notebooks' helper calls work
+  unchanged.
+
+PyTorch is used for device memory and streams only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import EnvCfg, EnvInfo, check, ptr
+
+DEFAULT_SEED = (0x5EED, 0xD0DEC0DE)
+_MODELS = {"X": _lib.DQ_MODEL_X, "DP": _lib.DQ_MODEL_DP}
+
+
+class _Space:
+    """Stand-in for gym.spaces.Box / Discrete (ENV:78-84 only reads shape / n)."""
+
+    def __init__(self, shape=None, n=None, dtype=np.uint8):
+        self.shape, self.n, self.dtype, self.low, self.high = shape, n, dtype, 0, 1
+
+
+class VectorEnv:
+    """Batched environment: lattice i has global id ``env_id_base + i`` (its RNG stream)."""
+
+    def __init__(self, d=5, p_phys=0.01, p_meas=0.01, error_model="DP", use_Y=True, volume_depth=3,
+                 n_envs=1, seed=DEFAULT_SEED, env_id_base=0, device=None, referee="lut"):
+        if d % 2 != 1:
+            raise Exception("for the surface code d must be odd!")          # Function_Library.py:28-29
+        if error_model not in _MODELS:
+            raise ValueError("specified error model not currently supported!")   # ENV:66-67 (reference only prints)
+        _lib.require_gpu()
+        self.L = _lib.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.d, self.error_model, self.use_Y, self.volume_depth = d, error_model, bool(use_Y), volume_depth
+        self.n_envs, self.seed, self.env_id_base = int(n_envs), (int(seed[0]), int(seed[1])), int(env_id_base)
+        cfg = EnvCfg(d, _MODELS[error_model], int(bool(use_Y)), volume_depth, self.n_envs, self.env_id_base,
+                     (ctypes.c_uint32 * 2)(*self.seed))
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.L.dq_env_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        info = EnvInfo()
+        check(self.L.dq_env_get_info(self._h, ctypes.byref(info)))
+        self.num_actions, self.n_action_layers = info.num_actions, info.n_action_layers
+        self.identity_index = info.identity_index
+        self.obs_shape = (info.obs_c, info.obs_h, info.obs_w)
+        self.state_words, self.n_stab = info.state_words, info.n_stab
+        self.observation_space = _Space(shape=self.obs_shape)
+        self.action_space = _Space(n=self.num_actions)
+        self._p_phys, self._p_meas = float(p_phys), float(p_meas)
+        check(self.L.dq_env_set_rates(self._h, self._p_phys, self._p_meas))
+        dev, n = self.device, self.n_envs
+        self.obs = torch.zeros((n,) + self.obs_shape, dtype=torch.uint8, device=dev)
+        self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.legal = torch.zeros((n, 2), dtype=torch.int64, device=dev)     # uint64 bit masks
+        self.lifetime = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.was_reset = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._lut = None
+        if referee == "lut":
+            with torch.cuda.device(self.device):
+                check(self.L.dq_env_build_referee(self._h, self._stream()))
+        elif referee is not None:
+            self.set_referee(*referee)
+
+    # -- plumbing -----------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.dq_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- rates are plain mutable attributes in the reference (Single_Point_Training_Script.py:200-201) ---
+    @property
+    def p_phys(self):
+        return self._p_phys
+
+    @p_phys.setter
+    def p_phys(self, v):
+        self._p_phys = float(v)
+        check(self.L.dq_env_set_rates(self._h, self._p_phys, self._p_meas))
+
+    @property
+    def p_meas(self):
+        return self._p_meas
+
+    @p_meas.setter
+    def p_meas(self, v):
+        self._p_meas = float(v)
+        check(self.L.dq_env_set_rates(self._h, self._p_phys, self._p_meas))
+
+    def set_referee(self, lut_x, lut_z=None):
+        """Install caller tables: uint8 0/1 arrays of 2**((d*d-1)//2) entries (bit order: include/deepq_hip.h)."""
+        def pack(a):
+            bits = np.packbits(np.asarray(a, dtype=np.uint8), bitorder="little")
+            bits = np.concatenate([bits, np.zeros((-len(bits)) % 4, np.uint8)])
+            return torch.from_numpy(bits.view(np.int32).copy()).to(self.device)
+        self._lut = (pack(lut_x), None if lut_z is None else pack(lut_z))
+        check(self.L.dq_env_set_referee(self._h, ptr(self._lut[0]), ptr(self._lut[1])))
+
+    def get_referee(self):
+        n = 1 << (self.n_stab // 2)
+        lx, lz = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        check(self.L.dq_env_get_referee(self._h, lx.ctypes.data, lz.ctypes.data, n))
+        return lx, lz
+
+    # -- gym protocol, batched ----------------------------------------------------------------------
+    def reset(self, which=None, out_obs=None):
+        """ENV:99-115 for every lattice (or those with which[i] != 0).  Returns the uint8 observation tensor."""
+        obs = self.obs if out_obs is None else out_obs
+        w = None if which is None else torch.as_tensor(which, dtype=torch.uint8, device=self.device).contiguous()
+        check(self.L.dq_env_reset(self._h, ptr(w), ptr(obs), ptr(self.legal), ptr(self.lifetime), self._stream()))
+        if which is None:
+            self.done.zero_()
+        else:
+            self.done.masked_fill_(w != 0, 0)
+        return obs
+
+    def step(self, action, auto_reset=False, out_obs=None):
+        """ENV:118-204 for every lattice.  `action`: int32 device tensor [n_envs].  Returns (obs, reward, done)."""
+        if not (isinstance(action, torch.Tensor) and action.dtype == torch.int32 and action.is_cuda and action.is_contiguous()):
+            action = torch.as_tensor(action, dtype=torch.int32, device=self.device).contiguous()
+        obs = self.obs if out_obs is None else out_obs
+        check(self.L.dq_env_step(self._h, ptr(action), int(auto_reset), ptr(obs), ptr(self.reward), ptr(self.done),
+                                 ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), self._stream()))
+        return obs, self.reward, self.done
+
+    def select_actions(self, t, q=None, eps=1.0, masked_greedy=False, out=None):
+        """Epsilon-greedy over the legal set on the device (include/deepq_hip.h: dq_policy_select)."""
+        if out is None:
+            out = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        seed = (ctypes.c_uint32 * 2)(*self.seed)
+        check(self.L.dq_policy_select(ptr(q), ptr(self.legal), self.n_envs, self.num_actions, float(eps), int(masked_greedy),
+                                      seed, self.env_id_base, int(t), ptr(out), self._stream()))
+        return out
+
+    # -- state views --------------------------------------------------------------------------------------
+    def export_state(self):
+        """int64 tensor [n_envs, 11 + depth] of uint64 words (layout: include/deepq_hip.h)."""
+        st = torch.zeros((self.n_envs, self.state_words), dtype=torch.int64, device=self.device)
+        check(self.L.dq_env_export_state(self._h, ptr(st), self._stream()))
+        return st
+
+    def import_state(self, st):
+        st = torch.as_tensor(st, dtype=torch.int64, device=self.device).contiguous()
+        assert st.shape == (self.n_envs, self.state_words)
+        check(self.L.dq_env_import_state(self._h, ptr(st), self._stream()))
+
+    def tables(self):
+        sq, qs, nq = (np.zeros(64, np.uint64) for _ in range(3))
+        ty = np.zeros(64, np.uint8)
+        check(self.L.dq_env_get_tables(self._h, sq.ctypes.data, qs.ctypes.data, nq.ctypes.data, ty.ctypes.data))
+        return dict(stab_qmask=sq, qubit_smask=qs, neigh_qmask=nq, stab_type=ty)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# lattice helpers for the single-lattice facade (host-side table code; init-time / notebook helpers only)
+# ---------------------------------------------------------------------------------------------------------
+
+def _plaquette_type(d, a, b):
+    if (a == 0 and b % 2 == 0) or (a == d and b % 2 == 1) or (b == 0 and a % 2 == 1) or (b == d and a % 2 == 0):
+        return 0
+    return 3 if (a + b) % 2 else 1
+
+
+def generateSurfaceCodeLattice(d):
+    """Function_Library.py:13-51."""
+    if np.mod(d, 2) != 1:
+        raise Exception("for the surface code d must be odd!")
+    q = np.zeros((d, d, 4, 3), dtype=np.int64)
+    for x in range(d):
+        for y in range(d):
+            for k, (a, b) in enumerate(((x, y), (x, y + 1), (x + 1, y), (x + 1, y + 1))):
+                q[x, y, k] = (a, b, _plaquette_type(d, a, b))
+    return q
+
+
+def _measurement_order(d):
+    half = (d + 1) // 2 - 1
+    return ([(a, b) for a in range(1, d) for b in range(1, d)] + [(0, 2 * x + 1) for x in range(half)] +
+            [(d, 2 * x + 2) for x in range(half)] + [(2 * x + 2, 0) for x in range(half)] + [(2 * x + 1, d) for x in range(half)])
+
+
+def _u64(x):
+    return int(x) & 0xFFFFFFFFFFFFFFFF
+
+
+class Surface_Code_Environment_Multi_Decoding_Cycles:
+    """Drop-in for ENV:10-385 running on the GPU (one lattice).
+
+    Differences from the reference, all forced by what the checkout lacks:
+      * randomness comes from the site-indexed Philox stream (``seed``, ``env_id``) instead of numpy's
+        unseeded global generator;
+      * ``static_decoder`` is the built-in minimum-weight look-up referee (None / "lut"), or a pair of
+        0/1 tables; arbitrary ``.predict`` objects cannot run inside the kernel and are rejected.
+    """
+
+    def __init__(self, d=5, p_phys=0.01, p_meas=0.01, error_model="DP", use_Y=True, volume_depth=3, static_decoder=None,
+                 seed=DEFAULT_SEED, env_id=0, device=None):
+        if static_decoder is None or static_decoder == "lut" or static_decoder is True:
+            referee = "lut"
+        elif isinstance(static_decoder, (tuple, list)):
+            referee = tuple(static_decoder)
+        else:
+            raise NotImplementedError("static_decoder must be None/'lut' (built-in min-weight referee) or a (lut_x, lut_z) pair; "
+                                      "a Keras model cannot be evaluated inside the HIP kernel")
+        self._v = VectorEnv(d, p_phys, p_meas, error_model, use_Y, volume_depth, n_envs=1, seed=seed, env_id_base=env_id,
+                            device=device, referee=referee)
+        v = self._v
+        self.d, self.error_model, self.use_Y, self.volume_depth, self.static_decoder = d, error_model, use_Y, volume_depth, static_decoder
+        self.num_actions, self.n_action_layers, self.identity_index = v.num_actions, v.n_action_layers, v.identity_index
+        self.identity_indicator = self.generate_identity_indicator(d)
+        self.qubits = generateSurfaceCodeLattice(d)
+        self.qubit_stabilizers = self.get_stabilizer_list(self.qubits, d)
+        self.qubit_neighbours = self.get_qubit_neighbour_list(d)
+        self.observation_space, self.action_space = v.observation_space, v.action_space
+        self.board_state = np.zeros(v.obs_shape, dtype=np.int64)
+        self.done = False
+        self.lifetime = 0
+        self.multi_cycle = True                                              # ENV:97
+        self._order = _measurement_order(d)
+        self._action = torch.zeros(1, dtype=torch.int32, device=v.device)
+        self._state = None
+
+    # rates ------------------------------------------------------------------------------------------------
+    p_phys = property(lambda self: self._v.p_phys, lambda self, x: setattr(self._v, "p_phys", x))
+    p_meas = property(lambda self: self._v.p_meas, lambda self, x: setattr(self._v, "p_meas", x))
+
+    # gym protocol --------------------------------------------------------------------------------------------
+    def _pull(self):
+        self.board_state[...] = self._v.obs[0].cpu().numpy()               # same ndarray object every call (ENV:115,204)
+        self.done = bool(self._v.done[0].item())
+        self.lifetime = int(self._v.lifetime[0].item())
+        self._state = None
+
+    def reset(self):
+        self._v.reset()
+        self._pull()
+        return self.board_state
+
+    def step(self, action):
+        action = int(action)
+        if not 0 <= action < self.num_actions:
+            raise IndexError(f"index {action} is out of bounds for axis 0 with size {self.num_actions}")   # ENV:131
+        self._action.fill_(action)
+        self._v.step(self._action)
+        reward = float(self._v.reward[0].item())
+        self._pull()
+        return self.board_state, reward, self.done, {}
+
+    def initialize_state(self):
+        """ENV:206-235 (also resets legal moves on the device; the reference leaves them stale until reset())."""
+        self._v.reset()
+        self._pull()
+
+    def reset_legal_moves(self):
+        raise NotImplementedError("legal-move bookkeeping lives on the device; call reset()")
+
+    # state views in the reference's data types ----------------------------------------------------------------
+    def _words(self):
+        if self._state is None:
+            self._state = [_u64(x) for x in self._v.export_state()[0].cpu().tolist()]
+        return self._state
+
+    @staticmethod
+    def _mask_to_set(lo, hi):
+        return {a for a in range(128) if ((lo if a < 64 else hi) >> (a & 63)) & 1}
+
+    @property
+    def legal_actions(self):
+        w = self._words()
+        return self._mask_to_set(w[8], w[9])
+
+    @property
+    def acted_on_qubits(self):
+        return self._mask_to_set(self._words()[4], 0)
+
+    @property
+    def completed_actions(self):
+        w = self._words()
+        done = self._mask_to_set(w[6], w[7])
+        return np.array([int(a in done) for a in range(self.num_actions)], dtype=int)
+
+    @property
+    def hidden_state(self):
+        w, d = self._words(), self.d
+        out = np.zeros(d * d)
+        for q in range(d * d):
+            out[q] = (1 if (w[0] >> q) & 1 else 0) ^ (3 if (w[1] >> q) & 1 else 0)
+        return out.reshape(d, d)
+
+    def _word_to_grid(self, word):
+        g = np.zeros((self.d + 1, self.d + 1), dtype=int)
+        for s, (a, b) in enumerate(self._order):
+            g[a, b] = (word >> s) & 1
+        return g
+
+    @property
+    def current_true_syndrome(self):
+        return self._word_to_grid(self._words()[2])
+
+    @property
+    def summed_syndrome_volume(self):
+        w = self._words()
+        return sum(self._word_to_grid(x) for x in w[11:11 + self.volume_depth])
+
+    def is_adjacent_to_syndrome(self, qubit_number):
+        s = self.summed_syndrome_volume
+        return any(s[st] != 0 for st in self.qubit_stabilizers[qubit_number])   # ENV:262-271
+
+    # embedding helpers used by the notebooks' "production decoding" demo (ENV:273-324) -------------------------
+    def padding_syndrome(self, syndrome_in):
+        n = 2 * self.d + 1
+        out = np.zeros((n, n), int)
+        out[0, 1::2] = out[n - 1, 1::2] = 1
+        out[1::2, 0] = out[1::2, n - 1] = 1
+        for x in range(1, n, 2):
+            for y in range(1, n, 2):
+                if (x + y) % 4 == 0:
+                    out[x, y] = 1
+        out[0::2, 0::2] = np.asarray(syndrome_in)
+        return out
+
+    def padding_actions(self, actions_in):
+        n = 2 * self.d + 1
+        out = np.zeros((n, n), int)
+        for i, taken in enumerate(actions_in):
+            if taken:
+                out[2 * (i // self.d) + 1, 2 * (i % self.d) + 1] = 1
+        return out
+
+    def indicate_identity(self, board_state):
+        for k in range(self.n_action_layers):
+            board_state[self.volume_depth + k] = board_state[self.volume_depth + k] + self.identity_indicator
+        return board_state
+
+    def get_qubit_stabilizer_list(self, qubits, qubit):
+        row, col = qubit
+        return [tuple(qubits[row, col, j, :2]) for j in range(4) if qubits[row, col, j, 2] != 0]
+
+    def get_stabilizer_list(self, qubits, d):
+        return [self.get_qubit_stabilizer_list(qubits, [r, c]) for r in range(d) for c in range(d)]
+
+    def get_qubit_neighbour_list(self, d):
+        out = []
+        for row in range(d):
+            for col in range(d):
+                cells = [(row + a, col + b) for a in (0, -1, 1) for b in (0, -1, 1)][1:]
+                out.append([r * d + c for (r, c) in cells if 0 <= r < d and 0 <= c < d])
+        return out
+
+    def generate_identity_indicator(self, d):
+        ind = np.ones((2 * d + 1, 2 * d + 1), int)
+        ind[1::2, 1::2] = 0
+        return ind

@@ -1,0 +1,161 @@
+/*
+ * deepq_hip.h -- C ABI of the MI355X-native DeepQ-Decoding hot path (libdeepq_hip.so).
+ *
+ * The reference (R-Sweke/DeepQ-Decoding) is pure Python and has no FFI layer; its boundary for
+ * this path is two duck-typed Python protocols: the gym-style environment
+ * `Surface_Code_Environment_Multi_Decoding_Cycles` (example_notebooks/Environments.py:10-385) and
+ * the keras-rl `DQNAgent` surface used by the driver scripts
+ * (cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:109-152,206).  Each entry point
+ * below names the reference interface it replaces.  The host-side mirror of those protocols
+ * lives in `deepq-decoding_amd/` and reaches this library through ctypes.
+ *
+ * Conventions
+ *   - every `*_dev` pointer is DEVICE memory owned by the caller (e.g. a torch tensor's data_ptr);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only ENQUEUES
+ *     work on it and returns; nothing here synchronises unless its comment says so;
+ *   - no call allocates or frees device memory except *_create / *_destroy / dq_env_build_referee,
+ *     so step-type calls are hipGraph-capturable;
+ *   - return value 0 = DQ_OK, negative = error; dq_last_error() gives a thread-local message;
+ *   - no exceptions cross the ABI; a handle must not be used from two host threads at once.
+ *
+ * Bit conventions (shared with oracle/lattice.py)
+ *   - qubit q = row*d + col is bit q of a "qubit mask";
+ *   - stabilizers are numbered in the order generate_faulty_syndrome draws its uniforms
+ *     (Function_Library.py:189-221): bulk plaquettes (a,b), 1<=a,b<=d-1 row-major, then row 0
+ *     (b=1,3,..), row d (b=2,4,..), column 0 (a=2,4,..), column d (a=1,3,..); stabilizer s is bit s
+ *     of a "syndrome word";
+ *   - action a is bit a of a 128-bit "action mask" stored as two uint64 (lo, hi);
+ *   - referee tables are bit-packed: entry i is bit (i & 31) of word i >> 5; index bit k is the
+ *     k-th live plaquette of that type in row-major (a,b) order.
+ *
+ * Random numbers: Philox4x32-10, key = seed, counter = (t_lo, t_hi, env_id, lane | stream << 16)
+ * (SURVEY.md §8c).  Stream 0 = environment noise with t = the lattice's measurement-round counter:
+ * word 0 < ceil(p_phys*2^32) <=> qubit `lane` errs, word 1 -> Pauli type 1 + ((w*3) >> 32),
+ * word 2 < ceil(p_meas*2^32) <=> stabilizer `lane` is mis-measured.
+ */
+#ifndef DEEPQ_HIP_H
+#define DEEPQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int dq_status;
+enum {
+    DQ_OK = 0,
+    DQ_ERR_INVALID = -1,     /* bad argument */
+    DQ_ERR_UNSUPPORTED = -2, /* configuration outside what the kernels implement */
+    DQ_ERR_HIP = -3,         /* a HIP runtime call failed */
+    DQ_ERR_NOMEM = -4,
+    DQ_ERR_STATE = -5        /* call made in the wrong state (e.g. step before referee is set) */
+};
+
+enum { DQ_MODEL_X = 0, DQ_MODEL_DP = 1 };
+enum { DQ_STREAM_ENV = 0, DQ_STREAM_POLICY = 1, DQ_STREAM_REPLAY = 2, DQ_STREAM_DROPOUT = 3, DQ_STREAM_INIT = 4 };
+
+int dq_version(void);
+const char* dq_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable).  Never fails. */
+int dq_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Environment: replaces Surface_Code_Environment_Multi_Decoding_Cycles (Environments.py:10-385),
+ * batched over n_envs independent lattices, one lattice per wavefront.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dq_env dq_env;
+
+typedef struct {
+    int32_t d;            /* code distance: 3, 5 or 7 (Environments.py:45; odd, Function_Library.py:28-29) */
+    int32_t error_model;  /* DQ_MODEL_X / DQ_MODEL_DP (Environments.py:56-67) */
+    int32_t use_Y;        /* Environments.py:60-65 */
+    int32_t volume_depth; /* 1..16 (Environments.py:52) */
+    int32_t n_envs;       /* lattices owned by this handle */
+    uint32_t env_id_base; /* global id of lattice 0 (rank * n_local): results do not depend on sharding */
+    uint32_t seed[2];     /* Philox key */
+} dq_env_cfg;
+
+typedef struct {
+    int32_t num_actions;     /* Environments.py:57-64 */
+    int32_t n_action_layers; /* Environments.py:58-65 */
+    int32_t identity_index;  /* Environments.py:69 */
+    int32_t obs_c, obs_h, obs_w; /* observation_space.shape, Environments.py:78-82 */
+    int32_t n_stab;          /* d*d - 1 live stabilizers */
+    int32_t state_words;     /* uint64 words per lattice in dq_env_export_state */
+} dq_env_info;
+
+dq_status dq_env_create(const dq_env_cfg* cfg, dq_env** out);     /* Environments.py:45-97 */
+void dq_env_destroy(dq_env* env);
+dq_status dq_env_get_info(const dq_env* env, dq_env_info* out);
+
+/* env.p_phys / env.p_meas are plain attributes the drivers mutate between test sweeps
+ * (Single_Point_Training_Script.py:200-201); converted to integer thresholds on the host. */
+dq_status dq_env_set_rates(dq_env* env, double p_phys, double p_meas);
+
+/* Referee ("static_decoder", Environments.py:53,144,150).  The reference's Keras referee blobs are
+ * not in the checkout; the library builds the deterministic minimum-weight look-up referee defined
+ * in oracle/referee.py ON THE GPU (level-synchronous BFS).  Synchronises `stream`. */
+dq_status dq_env_build_referee(dq_env* env, void* stream);
+/* ... or installs caller-provided bit-packed tables (device pointers, 2^((d*d-1)/2) bits each; must
+ * stay alive while the handle uses them).  lut_z_dev may be NULL for DQ_MODEL_X. */
+dq_status dq_env_set_referee(dq_env* env, const uint32_t* lut_x_dev, const uint32_t* lut_z_dev);
+/* Copies the referee tables to host memory as one byte per entry (tests). Synchronises. */
+dq_status dq_env_get_referee(dq_env* env, uint8_t* lut_x_host, uint8_t* lut_z_host, size_t entries);
+
+/* reset(): Environments.py:99-115 + initialize_state 206-235 + reset_legal_moves 238-258.
+ * which_dev == NULL resets every lattice, else lattice i iff which_dev[i] != 0 (others keep their
+ * state; outputs are written for all lattices).  Nullable outputs are skipped.
+ *   obs_dev      uint8 [n_envs, C, H, W]   (0/1 cells)
+ *   legal_dev    uint64 [n_envs, 2]        action mask of env.legal_actions
+ *   lifetime_dev uint32 [n_envs]           env.lifetime */
+dq_status dq_env_reset(dq_env* env, const uint8_t* which_dev, uint8_t* obs_dev, uint64_t* legal_dev,
+                       uint32_t* lifetime_dev, void* stream);
+
+/* step(action): Environments.py:118-204.  An action outside [0, num_actions) is treated as the
+ * identity.  auto_reset != 0: a lattice whose `done` flag is set when the call starts is reset
+ * instead of stepped -- its action is ignored, reward 0, done 0 -- which is keras-rl's convention of
+ * spending one agent step on the terminal observation before env.reset(); auto_reset == 0 keeps the
+ * reference's sticky `done` (Environments.py:151 never clears it).
+ *   action_dev    int32 [n_envs]
+ *   reward_dev    float [n_envs]     (Environments.py:146-149)
+ *   done_dev      uint8 [n_envs]     (Environments.py:150-151)
+ *   was_reset_dev uint8 [n_envs]     1 where auto_reset replaced the step */
+dq_status dq_env_step(dq_env* env, const int32_t* action_dev, int auto_reset, uint8_t* obs_dev,
+                      float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev, uint32_t* lifetime_dev,
+                      uint8_t* was_reset_dev, void* stream);
+
+/* Hidden state for tests / checkpointing: uint64 [n_envs, state_words], state_words = 11 + volume_depth:
+ *   0 xmask (hidden_state codes 1,2)   1 zmask (codes 2,3)
+ *   2 current_true_syndrome word       3 OR of the volume's faulty words (summed_syndrome_volume != 0)
+ *     (2 and 3 are recomputed on the device at export and ignored by import)
+ *   4 acted_on_qubits   5 measurement-round counter   6,7 completed_actions mask   8,9 legal_actions mask
+ *   10 lifetime | done << 32           11.. faulty syndrome words of the current volume. */
+dq_status dq_env_export_state(dq_env* env, uint64_t* state_dev, void* stream);
+dq_status dq_env_import_state(dq_env* env, const uint64_t* state_dev, void* stream);
+
+/* Static lattice tables as the kernels use them (tests compare them with the reference's
+ * generateSurfaceCodeLattice / get_stabilizer_list / get_qubit_neighbour_list outputs).
+ * Host pointers, each 64 entries: stab_qmask[s], qubit_smask[q], neigh_qmask[q]; stab_type[s] in {1,3,0}. */
+dq_status dq_env_get_tables(const dq_env* env, uint64_t* stab_qmask, uint64_t* qubit_smask,
+                            uint64_t* neigh_qmask, uint8_t* stab_type);
+
+/* ---------------------------------------------------------------------------------------------
+ * Action selection: replaces EpsGreedyQPolicy / GreedyQPolicy(masked_greedy=...) of the keras-rl
+ * fork (call sites Single_Point_Training_Script.py:110-115,166-167; README.md:168,262).
+ *   q_dev      float [n, n_actions] or NULL (then every lattice explores: uniform over legal)
+ *   legal_dev  uint64 [n, 2]
+ * Per lattice i, words w = Philox(key=seed, ctr=(t_lo, t_hi, env_id_base+i, DQ_STREAM_POLICY<<16)):
+ *   explore <=> w[1] < ceil(eps * 2^32);  explore action = k-th smallest legal action,
+ *   k = (w[0] * n_legal) >> 32;  otherwise argmax_a q (first maximum), over the legal set only when
+ *   masked_greedy != 0.
+ * ------------------------------------------------------------------------------------------- */
+dq_status dq_policy_select(const float* q_dev, const uint64_t* legal_dev, int n, int n_actions, double eps,
+                           int masked_greedy, const uint32_t seed[2], uint32_t env_id_base, uint64_t t,
+                           int32_t* action_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPQ_HIP_H */

@@ -1,0 +1,270 @@
+"""GPU parity tests of the HIP environment (through the C ABI) against the golden vectors captured
+from the reference, the CPU oracle, and size-independent properties at BASELINE.json sizes."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, TRACES, STICKY_TRACES, trace_config
+
+pytestmark = pytest.mark.gpu
+U64 = np.uint64
+
+
+def _np_u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return torch
+
+
+def _state_checks(cfg, g, t, st, n_act):
+    """st: uint64 [n_envs, 11+depth] export; compare with golden arrays at snapshot t."""
+    from oracle import lattice, env_oracle
+    d = cfg["d"]
+    m = lattice.Masks(d)
+    for e in range(st.shape[0]):
+        w = [int(x) for x in st[e]]
+        assert np.array_equal(env_oracle.masks_to_codes(d, w[0], w[1]), g["hidden"][e, t]), ("hidden", e, t)
+        assert np.array_equal(m.word_to_grid(w[2]), g["true_syndrome"][e, t]), ("true_syndrome", e, t)
+        assert np.array_equal(m.word_to_grid(w[3]), g["summed_nonzero"][e, t]), ("summed", e, t)
+        assert w[4] == int(g["acted"][e, t]) and w[5] == int(g["rounds"][e, t])
+        comp = w[6] | (w[7] << 64)
+        assert [(comp >> a) & 1 for a in range(n_act)] == list(g["completed"][e, t])
+        assert w[8] == int(g["legal"][e, t, 0]) and w[9] == int(g["legal"][e, t, 1])
+        assert (w[10] & 0xFFFFFFFF) == g["lifetime"][e, t] and (w[10] >> 32) == g["done"][e, t]
+
+
+def _replay(dq, torch, name, auto_reset):
+    g = load_golden("trace_" + name)
+    cfg, n_envs, n_steps, seed = trace_config(g)
+    env = dq.VectorEnv(n_envs=n_envs, seed=seed, **cfg)
+    actions = torch.from_numpy(g["action"].astype(np.int32)).cuda()
+
+    def check(t):
+        assert np.array_equal(env.obs.cpu().numpy(), g["obs"][:, t]), (name, "obs", t)
+        assert np.array_equal(env.done.cpu().numpy(), g["done"][:, t]), (name, "done", t)
+        assert np.array_equal(env.lifetime.cpu().numpy(), g["lifetime"][:, t]), (name, "lifetime", t)
+        assert np.array_equal(_np_u64(env.legal), g["legal"][:, t]), (name, "legal", t)
+        _state_checks(cfg, g, t, _np_u64(env.export_state()), env.num_actions)
+
+    env.reset()
+    check(0)
+    for t in range(n_steps):
+        env.step(actions[:, t].contiguous(), auto_reset=auto_reset)
+        assert np.array_equal(env.reward.cpu().numpy(), g["reward"][:, t]), (name, "reward", t)
+        if auto_reset:
+            assert np.array_equal(env.was_reset.cpu().numpy(), g["was_reset"][:, t])
+        check(t + 1)
+    env.close()
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_golden_traces(dq, torch_mod, name):
+    _replay(dq, torch_mod, name, True)
+
+
+@pytest.mark.parametrize("name", STICKY_TRACES)
+def test_golden_sticky_traces(dq, torch_mod, name):
+    _replay(dq, torch_mod, name, False)
+
+
+@pytest.mark.parametrize("d", [3, 5, 7])
+def test_tables_and_referee(dq, torch_mod, d):
+    """Kernel tables == reference tables (golden G1); GPU-built referee == oracle definition."""
+    from oracle import lattice, c_oracle
+    g = load_golden("tables")
+    env = dq.VectorEnv(d=d, error_model="DP", use_Y=False, volume_depth=d, n_envs=1)
+    tb = env.tables()
+    m = lattice.Masks(d)
+    for s, (a, b) in enumerate(m.order):
+        qs = sorted(q for q in range(d * d) if (int(tb["stab_qmask"][s]) >> q) & 1)
+        # qubits whose reference stabilizer list (golden) contains plaquette (a, b)
+        want = sorted(q for q in range(d * d) if any(tuple(x) == (a, b) for x in g[f"qubit_stabilizers_d{d}"][q]))
+        assert qs == want
+        x, y = want[0] // d, want[0] % d
+        k = [(x, y), (x, y + 1), (x + 1, y), (x + 1, y + 1)].index((a, b))
+        assert tb["stab_type"][s] == g[f"qubits_d{d}"][x, y, k, 2]
+    for q in range(d * d):
+        assert sorted(n for n in range(d * d) if (int(tb["neigh_qmask"][q]) >> n) & 1) == sorted(
+            int(x) for x in g[f"qubit_neighbours_d{d}"][q] if x >= 0)
+    lx, lz = env.get_referee()
+    gl = load_golden("referee_lut")
+    assert hashlib.sha256(lx.tobytes()).digest() == gl[f"lut_x_sha256_d{d}"].tobytes()
+    assert hashlib.sha256(lz.tobytes()).digest() == gl[f"lut_z_sha256_d{d}"].tobytes()
+    cx, cz = c_oracle.luts(d)
+    assert np.array_equal(lx, cx) and np.array_equal(lz, cz)
+    env.close()
+
+
+CONFIGS = {
+    "c2": dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007),
+    "c3": dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011),
+    "c5": dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005),
+}
+
+
+@pytest.mark.parametrize("name,n_envs,steps", [("c2", 4096, 40), ("c3", 4096, 60), ("c5", 1024, 30), ("c3", 1027, 25)])
+def test_full_size_vs_c_oracle(dq, torch_mod, name, n_envs, steps):
+    """BASELINE.json batch sizes, device policy (uniform over legal) vs the C oracle, every output
+    compared bit-exactly at every step; n_envs=1027 covers a ragged last workgroup."""
+    from oracle import c_oracle
+    torch = torch_mod
+    cfg = CONFIGS[name]
+    seed, base = (0x5EED, 0xD0DEC0DE), 4096 * 3
+    env = dq.VectorEnv(n_envs=n_envs, seed=seed, env_id_base=base, **cfg)
+    ref = c_oracle.COracleEnv(n_envs=n_envs, seed=seed, env_id_base=base, **cfg)
+    env.reset()
+    ref.reset()
+    assert np.array_equal(env.obs.cpu().numpy(), ref.obs)
+    assert np.array_equal(_np_u64(env.legal), ref.legal)
+    for t in range(steps):
+        a = env.select_actions(t)
+        a_ref = ref.policy_uniform_legal(t)
+        assert np.array_equal(a.cpu().numpy(), a_ref), (name, "policy", t)
+        env.step(a, auto_reset=True)
+        ref.step(a_ref, auto_reset=True)
+        assert np.array_equal(env.obs.cpu().numpy(), ref.obs), (name, "obs", t)
+        assert np.array_equal(env.reward.cpu().numpy(), ref.reward), (name, "reward", t)
+        assert np.array_equal(env.done.cpu().numpy(), ref.done), (name, "done", t)
+        assert np.array_equal(env.lifetime.cpu().numpy().view(np.uint32), ref.lifetime), (name, "lifetime", t)
+        assert np.array_equal(_np_u64(env.legal), ref.legal), (name, "legal", t)
+        assert np.array_equal(env.was_reset.cpu().numpy(), ref.was_reset)
+    st, rs = _np_u64(env.export_state()), ref.export()
+    assert np.array_equal(st[:, 0], rs["xmask"]) and np.array_equal(st[:, 1], rs["zmask"])
+    assert np.array_equal(st[:, 2], rs["true_word"]) and np.array_equal(st[:, 3], rs["summed"])
+    assert np.array_equal(st[:, 5], rs["round"]) and np.array_equal(st[:, 11:], rs["volume"])
+    env.close()
+
+
+def test_sharding_invariance(dq, torch_mod):
+    """Results depend on the global lattice id only: 2 x 512 lattices == 1 x 1024 lattices."""
+    torch = torch_mod
+    cfg = CONFIGS["c3"]
+    whole = dq.VectorEnv(n_envs=1024, **cfg)
+    parts = [dq.VectorEnv(n_envs=512, env_id_base=512 * r, **cfg) for r in range(2)]
+    whole.reset()
+    for p in parts:
+        p.reset()
+    for t in range(20):
+        a = whole.select_actions(t)
+        whole.step(a, auto_reset=True)
+        for r, p in enumerate(parts):
+            ap = p.select_actions(t)
+            assert torch.equal(ap, a[512 * r:512 * (r + 1)])
+            p.step(ap, auto_reset=True)
+            assert torch.equal(p.obs, whole.obs[512 * r:512 * (r + 1)])
+            assert torch.equal(p.reward, whole.reward[512 * r:512 * (r + 1)])
+            assert torch.equal(p.done, whole.done[512 * r:512 * (r + 1)])
+
+
+def test_properties_at_full_size(dq, torch_mod):
+    """Size-independent invariants on c3 @ 4096: syndrome linearity (GF(2)), flip-twice = identity on the
+    hidden state, observation decoration, legal set always contains the identity, export/import round trip."""
+    torch = torch_mod
+    cfg = CONFIGS["c3"]
+    env = dq.VectorEnv(n_envs=4096, **cfg)
+    env.reset()
+    static = torch.from_numpy(load_golden("tables")["static_plane_d5"]).cuda()
+    for t in range(30):
+        env.step(env.select_actions(t), auto_reset=True)
+        obs = env.obs
+        assert int(obs.max()) <= 1
+        # decoration cells are constant; syndrome planes differ from it only on even-even cells
+        diff = (obs[:, :5] != static).any(dim=0).any(dim=0)
+        assert not bool(diff[1::2, :].any()) and not bool(diff[:, 1::2].any())
+        assert not bool(obs[:, 5:, 0::2, :].any()) and not bool(obs[:, 5:, :, 0::2].any())   # action planes: odd-odd only
+        legal = _np_u64(env.legal)
+        assert ((legal[:, 0] >> U64(50)) & U64(1)).all()          # identity (index 50) always legal
+    st = env.export_state()
+    before = st.clone()
+    # flipping the same qubit twice (second time = repeat -> new volume) leaves (xmask ^ errors) consistent:
+    # here we only check the pure part: import/export round trip is the identity
+    env.import_state(st)
+    after = env.export_state()
+    assert torch.equal(before, after)
+    # linearity: true syndrome word of (x1^x2, z1^z2) == word1 ^ word2
+    s = _np_u64(st)
+    n = 2048
+    st2 = st.clone()
+    st2[:n, 0] = st[:n, 0] ^ st[n:2 * n, 0]
+    st2[:n, 1] = st[:n, 1] ^ st[n:2 * n, 1]
+    env.import_state(st2)
+    s2 = _np_u64(env.export_state())
+    assert np.array_equal(s2[:n, 2], s[:n, 2] ^ s[n:2 * n, 2])
+    env.close()
+
+
+def test_edge_semantics(dq, torch_mod):
+    """Edge cases the reference exhibits (SURVEY.md §8c ii): identity in the ground state earns +1; a hidden
+    logical operator with a class-0 referee answer -> reward 0, done; out-of-range action == identity;
+    partial reset leaves other lattices untouched; p = 0 noise with p_meas = 1 still terminates."""
+    torch = torch_mod
+    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    env = dq.VectorEnv(n_envs=8, **cfg)
+    env.reset()
+    st = env.export_state()
+    st[:, 0] = 0
+    st[:, 1] = 0                                   # ground state everywhere
+    st[1, 0] = 0b11111                             # lattice 1: logical X along row 0
+    st[2, 1] = sum(1 << (5 * r) for r in range(5))  # lattice 2: logical Z along column 0
+    env.import_state(st)
+    rounds_before = _np_u64(env.export_state())[:, 5].copy()
+    a = torch.full((8,), 50, dtype=torch.int32, device="cuda")
+    a[3] = 999                                     # out of range -> identity
+    a[4] = -7
+    env.step(a)
+    r, dn = env.reward.cpu().numpy(), env.done.cpu().numpy()
+    assert r[0] == 1.0 and dn[0] == 0
+    assert r[1] == 0.0 and dn[1] == 1 and r[2] == 0.0 and dn[2] == 1
+    assert r[3] == 1.0 and r[4] == 1.0
+    rounds_after = _np_u64(env.export_state())[:, 5]
+    assert ((rounds_after - rounds_before) % U64(5) == 0).all() and (rounds_after > rounds_before).all()
+    # sticky done without auto_reset; cleared by a partial reset of exactly those lattices
+    env.step(a)
+    assert env.done.cpu().numpy()[1] == 1
+    before = _np_u64(env.export_state()).copy()
+    which = torch.tensor([0, 1, 1, 0, 0, 0, 0, 0], dtype=torch.uint8)
+    env.reset(which=which)
+    after = _np_u64(env.export_state())
+    assert (after[[1, 2], 10] >> U64(32) == 0).all()
+    assert np.array_equal(before[[0, 3, 4, 5, 6, 7]], after[[0, 3, 4, 5, 6, 7]])
+    # no physical noise but every measurement wrong: volumes are non-trivial immediately, hidden stays clean
+    env.p_phys, env.p_meas = 0.0, 1.0
+    env.reset()
+    s = _np_u64(env.export_state())
+    assert (s[:, 0] == 0).all() and (s[:, 1] == 0).all() and (s[:, 3] == U64((1 << 24) - 1)).all()
+    assert (env.lifetime.cpu().numpy() == 5).all()
+    env.close()
+
+
+def test_single_env_facade(dq, torch_mod):
+    """The drop-in class reproduces the c1 golden trace through reset()/step() with the reference's types."""
+    g = load_golden("trace_c1_d3_x")
+    cfg, n_envs, n_steps, seed = trace_config(g)
+    for e in (0, 5):
+        env = dq.Surface_Code_Environment_Multi_Decoding_Cycles(seed=seed, env_id=e, **cfg)
+        obs = env.reset()
+        assert obs is env.board_state and obs.dtype == np.int64
+        assert np.array_equal(obs, g["obs"][e, 0])
+        for t in range(n_steps):
+            if env.done:
+                assert g["was_reset"][e, t] == 1
+                env.reset()
+                r = 0.0
+            else:
+                o, r, done, info = env.step(int(g["action"][e, t]))
+                assert o is obs and info == {} and isinstance(r, float) and isinstance(done, bool)
+            assert r == g["reward"][e, t] and env.lifetime == g["lifetime"][e, t + 1]
+            assert np.array_equal(env.board_state, g["obs"][e, t + 1])
+            assert np.array_equal(env.hidden_state, g["hidden"][e, t + 1])
+            assert np.array_equal(env.current_true_syndrome, g["true_syndrome"][e, t + 1])
+            assert np.array_equal(env.completed_actions, g["completed"][e, t + 1])
+            lo = sum(1 << a for a in env.legal_actions)
+            assert lo == int(g["legal"][e, t + 1, 0])
+    with pytest.raises(Exception):
+        dq.Surface_Code_Environment_Multi_Decoding_Cycles(d=4)
