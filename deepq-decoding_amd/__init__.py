@@ -19,4 +19,7 @@ def __getattr__(name):
     if name in ("VectorEnv", "Surface_Code_Environment_Multi_Decoding_Cycles", "generateSurfaceCodeLattice"):
         from . import env
         return getattr(env, name)
+    if name in ("QNetwork", "td_target", "td_loss_grad", "adam_step", "replay_sample"):
+        from . import qnet
+        return getattr(qnet, name)
     raise AttributeError(name)

@@ -29,7 +29,16 @@ class EnvInfo(ctypes.Structure):
                 ("n_stab", ctypes.c_int32), ("state_words", ctypes.c_int32)]
 
 
+class QNetCfg(ctypes.Structure):
+    _fields_ = [("in_c", ctypes.c_int32), ("in_h", ctypes.c_int32), ("in_w", ctypes.c_int32), ("n_conv", ctypes.c_int32),
+                ("conv", (ctypes.c_int32 * 3) * 4), ("n_ff", ctypes.c_int32), ("ff_units", ctypes.c_int32 * 4),
+                ("ff_dropout", ctypes.c_float * 4), ("n_actions", ctypes.c_int32), ("dueling", ctypes.c_int32),
+                ("max_batch", ctypes.c_int32)]
+
+
 _vp, _i, _u32, _u64, _dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
+_sz = ctypes.c_size_t
+_seedp = ctypes.POINTER(ctypes.c_uint32)
 
 # name -> (restype, argtypes); must list every symbol include/deepq_hip.h declares
 SIGNATURES = {
@@ -49,6 +58,18 @@ SIGNATURES = {
     "dq_env_import_state": (_i, [_vp, _vp, _vp]),
     "dq_env_get_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dq_policy_select": (_i, [_vp, _vp, _i, _i, _dbl, _i, ctypes.POINTER(_u32), _u32, _u64, _vp, _vp]),
+    "dq_qnet_create": (_i, [ctypes.POINTER(QNetCfg), ctypes.POINTER(_vp)]),
+    "dq_qnet_destroy": (None, [_vp]),
+    "dq_qnet_param_count": (_sz, [_vp]),
+    "dq_qnet_num_layers": (_i, [_vp]),
+    "dq_qnet_layer_info": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                ctypes.POINTER(ctypes.c_int32 * 4), ctypes.POINTER(ctypes.c_int32)]),
+    "dq_qnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
+    "dq_qnet_backward": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "dq_replay_sample": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
+    "dq_td_target": (_i, [_vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _vp, _vp]),
+    "dq_td_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _vp, _vp, _vp]),
+    "dq_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
 }
 
 _lib = None

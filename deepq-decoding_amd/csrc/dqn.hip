@@ -1,0 +1,165 @@
+// DQN update pieces around the Q-network: replay minibatch sampling, double-DQN TD target,
+// masked squared-error loss + gradient, Keras-style Adam.
+//
+// Replaces, from the un-vendored keras-rl fork (call sites
+// /root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:109,119-130):
+//   SequentialMemory.sample          -> replay_sample_kernel (time-major device ring, validity rule kept)
+//   DQNAgent.backward (double DQN)   -> td_target_kernel, td_loss_grad_kernel
+//   keras.optimizers.Adam            -> adam_kernel
+#include "common.h"
+
+// Device replay ring: row r = slot * n_envs + env holds (obs s_r, action, reward, terminal of the step taken
+// in s_r); the successor observation of row r is row r + n_envs (mod n_slots*n_envs).  keras-rl's rule: a
+// transition is not sampled when the PREVIOUS entry of that lattice was terminal (its s0 is then the terminal
+// observation the agent only looked at before env.reset()).
+__global__ void replay_sample_kernel(const u8* __restrict__ terminal, int n_envs, int n_slots, int head_slot, int filled,
+                                     int batch, u32 seed0, u32 seed1, u64 t, u32 sample_base, int32_t* __restrict__ index) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int cand = filled - 1;                        // slots that already have a successor
+    int row = 0;
+    for (u32 attempt = 0; attempt < 64; ++attempt) {
+        u32 w[4];
+        philox4x32_10((u32)t, (u32)(t >> 32), sample_base + (u32)b, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
+        const int j = (int)__umulhi(w[0], (u32)cand);   // 0 = newest complete transition
+        const int env = (int)__umulhi(w[1], (u32)n_envs);
+        int slot = head_slot - 1 - j;
+        if (slot < 0) slot += n_slots;
+        row = slot * n_envs + env;
+        if (j + 1 >= cand) break;                       // oldest stored slot: predecessor unknown -> accepted (keras-rl idx < 2)
+        int prev = slot - 1;
+        if (prev < 0) prev += n_slots;
+        if (!terminal[(size_t)prev * n_envs + env]) break;
+    }
+    index[b] = row;
+}
+
+// y_b = r_b + gamma * (1 - terminal_b) * Q_target(s1_b)[argmax_a Q_online(s1_b)[a]]; one wave per sample
+__global__ void td_target_kernel(const float* __restrict__ q_online, const float* __restrict__ q_target,
+                                 const float* __restrict__ reward, const u8* __restrict__ terminal,
+                                 const int32_t* __restrict__ index, float gamma, int B, int A, float* __restrict__ y) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float* row = q_online + (size_t)b * A;
+    float best = -INFINITY;
+    int best_a = 0x7fffffff;
+    for (int a = lane; a < A; a += 64) {
+        const float v = row[a];
+        if (best_a == 0x7fffffff || v > best) { best = v; best_a = a; }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m);
+        const int oa = __shfl_xor(best_a, m);
+        if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
+    }
+    if (lane == 0) {
+        const int r = index ? index[b] : b;
+        const float qn = q_target[(size_t)b * A + best_a];
+        y[b] = reward[r] + (terminal[r] ? 0.f : gamma * qn);
+    }
+}
+
+// dq[b, a] = grad_scale * (Q[b,a_b] - y_b) at a = a_b, else 0;  metrics[0] = mean_b 0.5 (Q[b,a_b]-y_b)^2,
+// metrics[1] = mean_b max_a Q[b,a].  Single block => fixed summation order.
+__global__ __launch_bounds__(1024) void td_loss_grad_kernel(const float* __restrict__ q, const int32_t* __restrict__ action,
+                                                            const int32_t* __restrict__ index, const float* __restrict__ y, int B,
+                                                            int A, float grad_scale, float* __restrict__ dq, float* __restrict__ metrics) {
+    __shared__ float s_loss[1024], s_q[1024];
+    float loss = 0.f, mq = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* row = q + (size_t)b * A;
+        float* drow = dq + (size_t)b * A;
+        const int a_b = action[index ? index[b] : b];
+        float mx = -INFINITY;
+        for (int a = 0; a < A; ++a) { mx = fmaxf(mx, row[a]); drow[a] = 0.f; }
+        const float diff = row[a_b] - y[b];
+        drow[a_b] = diff * grad_scale;
+        loss += 0.5f * diff * diff;
+        mq += mx;
+    }
+    s_loss[threadIdx.x] = loss;
+    s_q[threadIdx.x] = mq;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) { s_loss[threadIdx.x] += s_loss[threadIdx.x + s]; s_q[threadIdx.x] += s_q[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && metrics) { metrics[0] = s_loss[0] / (float)B; metrics[1] = s_q[0] / (float)B; }
+}
+
+// Keras 2.2 Adam.get_updates: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float lr_t, float b1, float b2, float eps) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 3 < n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                        reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        float4 pp = *reinterpret_cast<float4*>(p + i4);
+        const float4 gg = *reinterpret_cast<const float4*>(g + i4);
+        float4 mm = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
+#define ADAM1(c)                                   \
+        mm.c = b1 * mm.c + (1.f - b1) * gg.c;      \
+        vv.c = b2 * vv.c + (1.f - b2) * gg.c * gg.c; \
+        pp.c = pp.c - lr_t * mm.c / (sqrtf(vv.c) + eps);
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        *reinterpret_cast<float4*>(p + i4) = pp;
+        *reinterpret_cast<float4*>(m + i4) = mm;
+        *reinterpret_cast<float4*>(v + i4) = vv;
+    } else {
+        for (size_t i = i4; i < n && i < i4 + 4; ++i) {
+            const float gi = g[i];
+            const float mi = b1 * m[i] + (1.f - b1) * gi;
+            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            m[i] = mi; v[i] = vi;
+            p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+}
+
+extern "C" {
+
+dq_status dq_replay_sample(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots, int batch,
+                           const uint32_t seed[2], uint64_t t, uint32_t sample_base, int32_t* index_dev, void* stream) {
+    DQ_REQUIRE(terminal_ring_dev && index_dev && seed, DQ_ERR_INVALID, "dq_replay_sample: null argument");
+    DQ_REQUIRE(n_envs >= 1 && n_slots >= 2 && batch >= 1 && head_slot >= 0 && head_slot < n_slots, DQ_ERR_INVALID, "dq_replay_sample: bad sizes");
+    DQ_REQUIRE(filled_slots >= 2 && filled_slots <= n_slots, DQ_ERR_STATE, "dq_replay_sample: need at least one complete transition per lattice");
+    DQ_REQUIRE((long long)n_envs * n_slots < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_replay_sample: ring too large for 32-bit rows");
+    replay_sample_kernel<<<(batch + 255) / 256, 256, 0, (hipStream_t)stream>>>(terminal_ring_dev, n_envs, n_slots, head_slot, filled_slots,
+                                                                             batch, seed[0], seed[1], t, sample_base, index_dev);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_td_target(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* reward_dev, const uint8_t* terminal_dev,
+                       const int32_t* index_dev, double gamma, int batch, int n_actions, float* y_dev, void* stream) {
+    DQ_REQUIRE(q_online_s1_dev && q_target_s1_dev && reward_dev && terminal_dev && y_dev, DQ_ERR_INVALID, "dq_td_target: null argument");
+    DQ_REQUIRE(batch >= 1 && n_actions >= 1, DQ_ERR_INVALID, "dq_td_target: bad sizes");
+    td_target_kernel<<<(batch + 3) / 4, 256, 0, (hipStream_t)stream>>>(q_online_s1_dev, q_target_s1_dev, reward_dev, terminal_dev, index_dev,
+                                                                       (float)gamma, batch, n_actions, y_dev);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_td_loss_grad(const float* q_s0_dev, const int32_t* action_dev, const int32_t* index_dev, const float* y_dev, int batch,
+                          int n_actions, double grad_scale, float* dq_dev, float* metrics_dev, void* stream) {
+    DQ_REQUIRE(q_s0_dev && action_dev && y_dev && dq_dev, DQ_ERR_INVALID, "dq_td_loss_grad: null argument");
+    DQ_REQUIRE(batch >= 1 && n_actions >= 1, DQ_ERR_INVALID, "dq_td_loss_grad: bad sizes");
+    td_loss_grad_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(q_s0_dev, action_dev, index_dev, y_dev, batch, n_actions, (float)grad_scale,
+                                                             dq_dev, metrics_dev);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n, double lr, double beta_1,
+                       double beta_2, double epsilon, uint64_t t, void* stream) {
+    DQ_REQUIRE(params_dev && grads_dev && m_dev && v_dev, DQ_ERR_INVALID, "dq_adam_step: null argument");
+    DQ_REQUIRE(t >= 1, DQ_ERR_INVALID, "dq_adam_step: t counts from 1");
+    const double lr_t = lr * sqrt(1.0 - pow(beta_2, (double)t)) / (1.0 - pow(beta_1, (double)t));
+    const size_t threads = (n + 3) / 4;
+    adam_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(params_dev, grads_dev, m_dev, v_dev, n, (float)lr_t,
+                                                                                  (float)beta_1, (float)beta_2, (float)epsilon);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,484 @@
+// Convolutional dueling Q-network: forward, backward and parameter bookkeeping on gfx950.
+//
+// Replaces the Keras model built by build_convolutional_nn
+// (/root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:61-90 == Function_Library.py:338-377
+// of the notebook copy) wrapped by keras-rl's dueling head (DQNAgent(enable_dueling_network=True), :119-127),
+// i.e. model.predict_on_batch / trainable_model.train_on_batch of the un-vendored keras-rl fork.
+// All contractions run on v_mfma_f32_32x32x2_f32 through the implicit-GEMM pieces of gemm.h.
+//
+// Device layouts
+//   parameters  one flat float buffer, Keras order and Keras shapes (conv kernels HWIO, dense (in,out)):
+//               [k1 b1 k2 b2 ... ]  -- the shipped .h5f tensors drop in without transposition;
+//   activations NHWC (row m = (sample, oy, ox), col = channel) == the row-major GEMM output; the Keras
+//               channels_first Flatten order is applied inside the first dense layer's loaders;
+//   observation uint8 NCHW as the environment writes it, optionally gathered through an index vector
+//               (replay minibatch rows) inside the first convolution's loader -- no minibatch copy.
+#include "gemm.h"
+#include <new>
+
+#define QN_MAX_LAYERS 12
+#define BM 128
+#define BK 32
+
+// C = A_gather * B (+ epilogue).  Block = 4 waves; wave w owns rows [32w, 32w+32) x BN columns.
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_fwd_kernel(Gather ga, BMap gb, Epilogue ep, int M, int N, int K) {
+    __shared__ float sA[BM][BK + 1];
+    __shared__ float sB[BK][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    constexpr int A_PER = BM * BK / 256, B_PER = BK * BN / 256, NT = BN / 32;
+
+    // this thread stages A rows (tid>>5)+8i at column tid&31 and B rows (tid / BN)+ (256/BN) i at column tid % BN
+    RowRef rows[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) rows[i] = gather_row(ga, m0 + (tid >> 5) + 8 * i, M);
+    const int acol = tid & 31, bcol = tid % BN, brow0 = tid / BN;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float ra[A_PER], rb[B_PER];
+    auto fetch = [&](int k0) {
+        const ColRef c = gather_col(ga, k0 + acol, K);
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) ra[i] = gather_load(ga, rows[i], c);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) rb[i] = bmap_load(gb, k0 + brow0 + (256 / BN) * i, n0 + bcol, K, N);
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();                       // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) sA[(tid >> 5) + 8 * i][acol] = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) sB[brow0 + (256 / BN) * i][bcol] = rb[i];
+        __syncthreads();
+        if (k0 + BK < K) fetch(k0 + BK);       // next tile's global loads fly under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = sA[wave * 32 + (lane & 31)][kk + (lane >> 5)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float b = sB[kk + (lane >> 5)][t * 32 + (lane & 31)];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + t * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < M && n < N) epilogue_store(ep, m, n, acc[t][r]);
+        }
+    }
+}
+
+// Weight gradient: dW[k, n] = sum_m A(m, k) * dZ[m, n]  (dZ row-major [M, N]) for m in this block's slice;
+// partial[slice][k][n] (+ partial bias sums when kt == 0) -- reduced in fixed order by reduce_partials_kernel.
+// Block = 4 waves; wave w owns output rows k in [k0 + 32w, k0 + 32w + 32) x BN columns.
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(Gather ga, const float* __restrict__ dz, float* __restrict__ partial,
+                                                         float* __restrict__ partial_bias, int M, int N, int K, int rows_per_slice) {
+    __shared__ float sA[BK][BM + 1];           // [m][k]: read transposed by the MFMA A operand
+    __shared__ float sB[BK][BN];
+    __shared__ float sBias[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.x * BM, slice = blockIdx.y, n0 = blockIdx.z * BN;
+    const int m_begin = slice * rows_per_slice, m_end = min(M, m_begin + rows_per_slice);
+    constexpr int A_PER = BM * BK / 256, B_PER = BK * BN / 256, NT = BN / 32;
+
+    // A staging: this thread owns column (k) tid & 127 and rows (m) (tid >> 7) + 2i
+    const ColRef col = gather_col(ga, k0 + (tid & 127), K);
+    const int bcol = tid % BN, brow0 = tid / BN;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bias_acc = 0.f;
+
+    float ra[A_PER], rb[B_PER];
+    auto fetch = [&](int mb) {
+        RowIter it;
+        it.init(ga, mb + (tid >> 7));
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            ra[i] = gather_load(ga, it.ref(ga, mb + (tid >> 7) + 2 * i < m_end), col);
+            it.advance(ga, 2);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int m = mb + brow0 + (256 / BN) * i, n = n0 + bcol;
+            rb[i] = (m < m_end && n < N) ? dz[(size_t)m * N + n] : 0.f;
+        }
+    };
+    fetch(m_begin);
+    for (int mb = m_begin; mb < m_end; mb += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) sA[(tid >> 7) + 2 * i][tid & 127] = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) { sB[brow0 + (256 / BN) * i][bcol] = rb[i]; bias_acc += rb[i]; }
+        __syncthreads();
+        if (mb + BK < m_end) fetch(mb + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = sA[kk + (lane >> 5)][wave * 32 + (lane & 31)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float b = sB[kk + (lane >> 5)][t * 32 + (lane & 31)];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    float* out = partial + (size_t)slice * K * N;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + t * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (k < K && n < N) out[(size_t)k * N + n] = acc[t][r];
+        }
+    }
+    if (blockIdx.x == 0) {                     // bias gradient = column sums of dZ over this slice
+        sBias[tid] = bias_acc;
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f;
+            for (int r = 0; r < 256 / BN; ++r) s += sBias[r * BN + tid];
+            if (n0 + tid < N) partial_bias[(size_t)slice * N + n0 + tid] = s;
+        }
+    }
+}
+
+// out[i] = sum_s partial[s][i]  (fixed order => deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, int slices) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += partial[(size_t)k * n + i];
+    out[i] = s;
+}
+
+// Dueling head (keras-rl dueling_type 'avg'): Q[b,a] = y[b,0] + y[b,1+a] - mean_a' y[b,1+a']
+__global__ void dueling_fwd_kernel(const float* __restrict__ y, float* __restrict__ q, int B, int A) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float* row = y + (size_t)b * (A + 1);
+    float s = 0.f;
+    for (int a = lane; a < A; a += 64) s += row[1 + a];
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    const float base = row[0] - s / (float)A;
+    for (int a = lane; a < A; a += 64) q[(size_t)b * A + a] = base + row[1 + a];
+}
+
+// g[b,0] = sum_a dq[b,a];  g[b,1+a] = dq[b,a] - (1/A) sum_a' dq[b,a']
+__global__ void dueling_bwd_kernel(const float* __restrict__ dq, float* __restrict__ g, int B, int A) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float* row = dq + (size_t)b * A;
+    float s = 0.f;
+    for (int a = lane; a < A; a += 64) s += row[a];
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    float* o = g + (size_t)b * (A + 1);
+    if (lane == 0) o[0] = s;
+    for (int a = lane; a < A; a += 64) o[1 + a] = row[a] - s / (float)A;
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct Layer {
+    int kind;                    // 0 conv, 1 dense
+    int cin, cout, k, s, ih, iw, oh, ow;   // conv
+    int nin, nout, relu;         // dense
+    float dropout;
+    size_t w_off, b_off;         // into the flat parameter buffer
+    int K, N, rows;              // GEMM view: rows per sample (oh*ow or 1), K, N
+};
+
+struct dq_qnet {
+    dq_qnet_cfg cfg;
+    int n_layers;
+    Layer L[QN_MAX_LAYERS];
+    size_t n_params;
+    int flat_c, flat_hw;         // last conv: channels and oh*ow (Keras Flatten permutation)
+    float* act[2][QN_MAX_LAYERS];   // [set][layer] outputs; set 0 = training (kept for backward), 1 = inference
+    float* grad[2];              // ping-pong gradient buffers (max activation size)
+    float* partial;              // wgrad slices
+    size_t partial_floats;
+    int last_train_batch;
+    const uint8_t* last_obs;     // inputs of the last training forward (needed by conv1's weight gradient)
+    const int32_t* last_index;
+    int last_index_off, last_index_mod;
+};
+
+static void launch_fwd(const Gather& ga, const BMap& gb, const Epilogue& ep, int M, int N, int K, hipStream_t st) {
+    if (N <= 32) {
+        dim3 grid((M + BM - 1) / BM, 1);
+        gemm_fwd_kernel<32><<<grid, 256, 0, st>>>(ga, gb, ep, M, N, K);
+    } else {
+        dim3 grid((M + BM - 1) / BM, (N + 63) / 64);
+        gemm_fwd_kernel<64><<<grid, 256, 0, st>>>(ga, gb, ep, M, N, K);
+    }
+}
+
+static Gather dense_gather(const float* src, int K) {
+    Gather g;
+    memset(&g, 0, sizeof(g));
+    g.src = src; g.rows_per_sample = 1; g.RW = 1; g.sb = (unsigned)K;
+    g.KC = K > 0 ? K : 1; g.KW = 1 << 30; g.sc = 1;
+    return g;
+}
+
+static Epilogue plain_epilogue(float* out, int ldo) {
+    Epilogue e;
+    memset(&e, 0, sizeof(e));
+    e.out = out; e.ldo = ldo; e.PC = 1 << 30; e.s_lo = 1;
+    return e;
+}
+
+extern "C" {
+
+dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
+    DQ_REQUIRE(cfg && out, DQ_ERR_INVALID, "dq_qnet_create: null argument");
+    *out = nullptr;
+    DQ_REQUIRE(cfg->n_conv >= 1 && cfg->n_conv <= 4 && cfg->n_ff >= 0 && cfg->n_ff <= 4, DQ_ERR_UNSUPPORTED, "dq_qnet_create: 1..4 conv and 0..4 hidden dense layers");
+    DQ_REQUIRE(cfg->n_actions >= 1 && cfg->n_actions <= 128 && cfg->max_batch >= 1, DQ_ERR_INVALID, "dq_qnet_create: bad n_actions / max_batch");
+    dq_qnet* Q = new (std::nothrow) dq_qnet();
+    DQ_REQUIRE(Q, DQ_ERR_NOMEM, "out of host memory");
+    memset(Q, 0, sizeof(*Q));
+    Q->cfg = *cfg;
+    int c = cfg->in_c, h = cfg->in_h, w = cfg->in_w, n = 0;
+    size_t off = 0;
+    for (int i = 0; i < cfg->n_conv; ++i) {
+        Layer& L = Q->L[n++];
+        L.kind = 0; L.cin = c; L.cout = cfg->conv[i][0]; L.k = cfg->conv[i][1]; L.s = cfg->conv[i][2]; L.ih = h; L.iw = w;
+        if (L.k < 1 || L.s < 1 || L.k > h || L.k > w || L.cout < 1) { delete Q; dq_set_error("dq_qnet_create: bad conv layer %d", i); return DQ_ERR_INVALID; }
+        if (i > 0 && L.s != 1) { delete Q; dq_set_error("dq_qnet_create: stride > 1 is only implemented for the first convolution"); return DQ_ERR_UNSUPPORTED; }
+        L.oh = (h - L.k) / L.s + 1; L.ow = (w - L.k) / L.s + 1;
+        L.K = L.k * L.k * c; L.N = L.cout; L.rows = L.oh * L.ow; L.relu = 1;
+        L.w_off = off; off += (size_t)L.K * L.N; L.b_off = off; off += L.N;
+        c = L.cout; h = L.oh; w = L.ow;
+    }
+    Q->flat_c = c; Q->flat_hw = h * w;
+    int nin = c * h * w;
+    for (int i = 0; i <= cfg->n_ff + (cfg->dueling ? 1 : 0); ++i) {
+        Layer& L = Q->L[n++];
+        L.kind = 1; L.nin = nin; L.rows = 1;
+        if (i < cfg->n_ff) { L.nout = cfg->ff_units[i]; L.relu = 1; L.dropout = cfg->ff_dropout[i]; }
+        else if (i == cfg->n_ff) { L.nout = cfg->n_actions; }
+        else { L.nout = cfg->n_actions + 1; }
+        if (L.nout < 1 || L.dropout < 0.f || L.dropout >= 1.f) { delete Q; dq_set_error("dq_qnet_create: bad dense layer %d", i); return DQ_ERR_INVALID; }
+        L.K = L.nin; L.N = L.nout;
+        L.w_off = off; off += (size_t)L.K * L.N; L.b_off = off; off += L.N;
+        nin = L.nout;
+    }
+    Q->n_layers = n;
+    Q->n_params = off;
+    // workspaces
+    size_t max_act = 0, max_partial = 0;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; ++i) {
+        const Layer& L = Q->L[i];
+        const size_t floats = (size_t)cfg->max_batch * L.rows * L.N;
+        if (floats >= (1ull << 32)) { dq_qnet_destroy(Q); dq_set_error("dq_qnet_create: activation too large for 32-bit offsets"); return DQ_ERR_UNSUPPORTED; }
+        max_act = floats > max_act ? floats : max_act;
+        for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&Q->act[s][i], floats * sizeof(float));
+        const size_t M = (size_t)cfg->max_batch * L.rows;
+        const size_t slices = (M + 511) / 512 < 1024 ? (M + 511) / 512 : 1024;
+        const size_t p = slices * ((size_t)L.K * L.N + L.N);
+        max_partial = p > max_partial ? p : max_partial;
+    }
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&Q->grad[s], max_act * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&Q->partial, max_partial * sizeof(float));
+    Q->partial_floats = max_partial;
+    if (e != hipSuccess) { dq_set_error("dq_qnet_create: %s", hipGetErrorString(e)); dq_qnet_destroy(Q); return DQ_ERR_HIP; }
+    *out = Q;
+    return DQ_OK;
+}
+
+void dq_qnet_destroy(dq_qnet* Q) {
+    if (!Q) return;
+    for (int s = 0; s < 2; ++s) {
+        for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->act[s][i]) (void)hipFree(Q->act[s][i]);
+        if (Q->grad[s]) (void)hipFree(Q->grad[s]);
+    }
+    if (Q->partial) (void)hipFree(Q->partial);
+    delete Q;
+}
+
+size_t dq_qnet_param_count(const dq_qnet* Q) { return Q ? Q->n_params : 0; }
+
+dq_status dq_qnet_layer_info(const dq_qnet* Q, int layer, int64_t* kernel_offset, int64_t* bias_offset, int32_t shape[4], int32_t* n_dims) {
+    DQ_REQUIRE(Q && layer >= 0 && layer < Q->n_layers, DQ_ERR_INVALID, "dq_qnet_layer_info: bad layer");
+    const Layer& L = Q->L[layer];
+    if (kernel_offset) *kernel_offset = (int64_t)L.w_off;
+    if (bias_offset) *bias_offset = (int64_t)L.b_off;
+    if (shape && n_dims) {
+        if (L.kind == 0) { shape[0] = L.k; shape[1] = L.k; shape[2] = L.cin; shape[3] = L.cout; *n_dims = 4; }
+        else { shape[0] = L.nin; shape[1] = L.nout; shape[2] = shape[3] = 0; *n_dims = 2; }
+    }
+    return DQ_OK;
+}
+
+int dq_qnet_num_layers(const dq_qnet* Q) { return Q ? Q->n_layers : 0; }
+
+dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev, int index_off,
+                          int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t, uint32_t sample_base,
+                          float* q_dev, void* stream) {
+    DQ_REQUIRE(Q && params_dev && obs_dev && q_dev, DQ_ERR_INVALID, "dq_qnet_forward: null argument");
+    DQ_REQUIRE(batch >= 1 && batch <= Q->cfg.max_batch, DQ_ERR_INVALID, "dq_qnet_forward: batch %d outside 1..%d", batch, Q->cfg.max_batch);
+    DQ_REQUIRE(!training || seed, DQ_ERR_INVALID, "dq_qnet_forward: training forward needs a seed");
+    hipStream_t st = (hipStream_t)stream;
+    const int set = training ? 0 : 1;
+    const float* x = nullptr;
+    for (int i = 0; i < Q->n_layers; ++i) {
+        const Layer& L = Q->L[i];
+        const int M = batch * L.rows;
+        Gather ga;
+        memset(&ga, 0, sizeof(ga));
+        if (L.kind == 0) {
+            ga.rows_per_sample = L.rows; ga.RW = L.ow; ga.KC = L.cin; ga.KW = L.k;
+            if (i == 0) {               // uint8 NCHW observation, optional replay gather
+                ga.src = obs_dev; ga.is_u8 = 1;
+                ga.sb = (unsigned)(L.cin * L.ih * L.iw); ga.sy = (unsigned)(L.s * L.iw); ga.sx = (unsigned)L.s;
+                ga.sky = L.iw; ga.skx = 1; ga.sc = L.ih * L.iw;
+                ga.index = index_dev; ga.index_off = index_off; ga.index_mod = index_mod > 0 ? index_mod : 0x7fffffff;
+            } else {                    // NHWC activation
+                ga.src = x;
+                ga.sb = (unsigned)(L.ih * L.iw * L.cin); ga.sy = (unsigned)(L.s * L.iw * L.cin); ga.sx = (unsigned)(L.s * L.cin);
+                ga.sky = L.iw * L.cin; ga.skx = L.cin; ga.sc = 1;
+            }
+        } else {
+            ga = dense_gather(x, L.K);
+            if (i == Q->cfg.n_conv) {   // Keras Flatten (channels_first): k = c*HW + p  ->  NHWC offset p*C + c
+                ga.KC = Q->flat_hw; ga.KW = 1 << 30; ga.skx = 1; ga.sc = Q->flat_c;
+            }
+        }
+        BMap gb = {params_dev + L.w_off, 1 << 30, 0, L.N, 1};
+        Epilogue ep = plain_epilogue(Q->act[set][i], L.N);
+        ep.flags = EPI_BIAS | (L.relu ? EPI_RELU : 0);
+        ep.bias = params_dev + L.b_off;
+        if (training && L.dropout > 0.f) {
+            ep.flags |= EPI_DROPOUT;
+            ep.keep_scale = (float)(1.0 / (1.0 - (double)L.dropout));
+            ep.drop_T = dq_rate_threshold((double)L.dropout);
+            ep.seed0 = seed[0]; ep.seed1 = seed[1]; ep.t = t; ep.sample_base = sample_base;
+        }
+        launch_fwd(ga, gb, ep, M, L.N, L.K, st);
+        DQ_LAUNCH_CHECK();
+        x = Q->act[set][i];
+    }
+    if (Q->cfg.dueling) {
+        dueling_fwd_kernel<<<(batch + 3) / 4, 256, 0, st>>>(x, q_dev, batch, Q->cfg.n_actions);
+        DQ_LAUNCH_CHECK();
+    } else {
+        DQ_HIP(hipMemcpyAsync(q_dev, x, (size_t)batch * Q->cfg.n_actions * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (training) {
+        Q->last_train_batch = batch; Q->last_obs = obs_dev; Q->last_index = index_dev;
+        Q->last_index_off = index_off; Q->last_index_mod = index_mod;
+    }
+    return DQ_OK;
+}
+
+dq_status dq_qnet_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, void* stream) {
+    DQ_REQUIRE(Q && params_dev && dq_dev && grads_dev, DQ_ERR_INVALID, "dq_qnet_backward: null argument");
+    DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_backward: no training forward to differentiate");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = Q->last_train_batch, nl = Q->n_layers;
+    // gradient w.r.t. the last layer's (linear) output
+    float* g = Q->grad[0];
+    float* g_next = Q->grad[1];
+    if (Q->cfg.dueling) {
+        dueling_bwd_kernel<<<(B + 3) / 4, 256, 0, st>>>(dq_dev, g, B, Q->cfg.n_actions);
+        DQ_LAUNCH_CHECK();
+    } else {
+        DQ_HIP(hipMemcpyAsync(g, dq_dev, (size_t)B * Q->cfg.n_actions * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    for (int i = nl - 1; i >= 0; --i) {
+        const Layer& L = Q->L[i];
+        const int M = B * L.rows;
+        // ---- weight + bias gradient: dW = A^T g -----------------------------------------------------
+        Gather ga;
+        memset(&ga, 0, sizeof(ga));
+        const float* x = i > 0 ? Q->act[0][i - 1] : nullptr;
+        if (L.kind == 0) {
+            ga.rows_per_sample = L.rows; ga.RW = L.ow; ga.KC = L.cin; ga.KW = L.k;
+            if (i == 0) {
+                ga.src = Q->last_obs; ga.is_u8 = 1;
+                ga.sb = (unsigned)(L.cin * L.ih * L.iw); ga.sy = (unsigned)(L.s * L.iw); ga.sx = (unsigned)L.s;
+                ga.sky = L.iw; ga.skx = 1; ga.sc = L.ih * L.iw;
+                ga.index = Q->last_index; ga.index_off = Q->last_index_off; ga.index_mod = Q->last_index_mod > 0 ? Q->last_index_mod : 0x7fffffff;
+            } else {
+                ga.src = x;
+                ga.sb = (unsigned)(L.ih * L.iw * L.cin); ga.sy = (unsigned)(L.s * L.iw * L.cin); ga.sx = (unsigned)(L.s * L.cin);
+                ga.sky = L.iw * L.cin; ga.skx = L.cin; ga.sc = 1;
+            }
+        } else {
+            ga = dense_gather(x, L.K);
+            if (i == Q->cfg.n_conv) { ga.KC = Q->flat_hw; ga.KW = 1 << 30; ga.skx = 1; ga.sc = Q->flat_c; }
+        }
+        int rows_per_slice = 512;
+        int slices = (M + rows_per_slice - 1) / rows_per_slice;
+        if (slices > 1024) { slices = 1024; rows_per_slice = ((M + slices - 1) / slices + BK - 1) / BK * BK; slices = (M + rows_per_slice - 1) / rows_per_slice; }
+        float* pw = Q->partial;
+        float* pb = Q->partial + (size_t)slices * L.K * L.N;
+        DQ_REQUIRE((size_t)slices * ((size_t)L.K * L.N + L.N) <= Q->partial_floats, DQ_ERR_STATE, "dq_qnet_backward: workspace too small");
+        if (L.N <= 32) {
+            dim3 grid((L.K + BM - 1) / BM, slices, 1);
+            gemm_wgrad_kernel<32><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice);
+        } else {
+            dim3 grid((L.K + BM - 1) / BM, slices, (L.N + 63) / 64);
+            gemm_wgrad_kernel<64><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice);
+        }
+        DQ_LAUNCH_CHECK();
+        {
+            const int nw = L.K * L.N;
+            reduce_partials_kernel<<<(nw + 255) / 256, 256, 0, st>>>(pw, grads_dev + L.w_off, nw, slices);
+            reduce_partials_kernel<<<(L.N + 255) / 256, 256, 0, st>>>(pb, grads_dev + L.b_off, L.N, slices);
+            DQ_LAUNCH_CHECK();
+        }
+        if (i == 0) break;
+        // ---- data gradient, masked by the previous layer's activation: g_prev = (g W^T) * [y_prev > 0] * scale ----
+        const Layer& Pv = Q->L[i - 1];
+        Gather gd;
+        memset(&gd, 0, sizeof(gd));
+        BMap gb;
+        int Md, Nd, Kd;
+        Epilogue ep = plain_epilogue(g_next, 0);
+        if (L.kind == 1) {
+            gd = dense_gather(g, L.N);                       // A = g [B, N]
+            gb = {params_dev + L.w_off, 1 << 30, 0, 1, L.N}; // B(n, k) = W[k*N + n]
+            Md = B; Nd = L.K; Kd = L.N;
+            ep.ldo = L.K;
+            if (i == Q->cfg.n_conv) { ep.PC = Q->flat_hw; ep.s_lo = Q->flat_c; ep.s_hi = 1; }   // Flatten^-1: k = c*HW + p -> p*C + c
+        } else {
+            // transposed convolution as a gather: dx[b,iy,ix,c] = sum_{ky,kx,n} g[b,iy-ky,ix-kx,n] W[ky,kx,c,n]   (stride 1)
+            gd.src = g; gd.rows_per_sample = L.ih * L.iw; gd.RW = L.iw;
+            gd.sb = (unsigned)(L.oh * L.ow * L.N); gd.sy = (unsigned)(L.ow * L.N); gd.sx = (unsigned)L.N;
+            gd.KC = L.N; gd.KW = L.k; gd.sky = -(L.ow * L.N); gd.skx = -L.N; gd.sc = 1;
+            gd.check = 1; gd.ylim = L.oh; gd.xlim = L.ow;
+            gb = {params_dev + L.w_off, L.N, L.cin * L.N, 1, L.N};   // B((ky,kx,n), c) = W[((ky*k+kx)*Cin + c)*N + n]
+            Md = B * L.ih * L.iw; Nd = L.cin; Kd = L.k * L.k * L.N;
+            ep.ldo = L.cin;
+        }
+        ep.flags = EPI_MASK;
+        ep.mask_src = Q->act[0][i - 1];
+        ep.mask_scale = Pv.dropout > 0.f ? (float)(1.0 / (1.0 - (double)Pv.dropout)) : 1.f;
+        if (!Pv.relu) { ep.flags = EPI_NONE; }
+        launch_fwd(gd, gb, ep, Md, Nd, Kd, st);
+        DQ_LAUNCH_CHECK();
+        float* tmp = g; g = g_next; g_next = tmp;
+    }
+    return DQ_OK;
+}
+
+}  // extern "C"

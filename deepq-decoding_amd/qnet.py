@@ -1,0 +1,157 @@
+"""Host wrapper of the HIP Q-network and DQN-update kernels (include/deepq_hip.h: dq_qnet_*, dq_td_*,
+dq_adam_step, dq_replay_sample).  Mirrors what the reference gets from Keras + keras-rl:
+build_convolutional_nn (/root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:61-90),
+the dueling head and the double-DQN train_on_batch of DQNAgent (:119-130)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, _philox
+from ._lib import QNetCfg, check, ptr
+
+
+def _seed_arr(seed):
+    return (ctypes.c_uint32 * 2)(int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF)
+
+
+class QNetwork:
+    """Conv dueling Q-network with caller-owned flat parameter tensors (Keras order / shapes)."""
+
+    def __init__(self, input_shape, c_layers, ff_layers, n_actions, dueling=True, max_batch=4096, device=None):
+        _lib.require_gpu()
+        self.L = _lib.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.input_shape = tuple(int(x) for x in input_shape)
+        self.c_layers = [[int(x) for x in l] for l in c_layers]
+        self.ff_layers = [[int(l[0]), float(l[1])] for l in ff_layers]
+        self.n_actions, self.dueling, self.max_batch = int(n_actions), bool(dueling), int(max_batch)
+        cfg = QNetCfg()
+        cfg.in_c, cfg.in_h, cfg.in_w = self.input_shape
+        cfg.n_conv = len(self.c_layers)
+        for i, l in enumerate(self.c_layers):
+            for j in range(3):
+                cfg.conv[i][j] = l[j]
+        cfg.n_ff = len(self.ff_layers)
+        for i, l in enumerate(self.ff_layers):
+            cfg.ff_units[i], cfg.ff_dropout[i] = l[0], l[1]
+        cfg.n_actions, cfg.dueling, cfg.max_batch = self.n_actions, int(self.dueling), self.max_batch
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.L.dq_qnet_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self.n_params = int(self.L.dq_qnet_param_count(self._h))
+        self.layers = []
+        for i in range(self.L.dq_qnet_num_layers(self._h)):
+            ko, bo, shape, nd = ctypes.c_int64(), ctypes.c_int64(), (ctypes.c_int32 * 4)(), ctypes.c_int32()
+            check(self.L.dq_qnet_layer_info(self._h, i, ctypes.byref(ko), ctypes.byref(bo), ctypes.byref(shape), ctypes.byref(nd)))
+            kshape = tuple(shape[j] for j in range(nd.value))
+            self.layers.append(dict(kernel_offset=ko.value, bias_offset=bo.value, kernel_shape=kshape, bias_shape=(kshape[-1],)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.dq_qnet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # -- parameters ---------------------------------------------------------------------------------------
+    def init_params(self, seed, stream_id=_lib.STREAM_INIT):
+        """Keras defaults: glorot_uniform kernels, zero biases.  Element i of layer l uses
+        u = (word + 0.5)/2^32, word = Philox(key=seed, ctr=(i>>2, 0, l, INIT<<16))[i&3]."""
+        flat = np.zeros(self.n_params, dtype=np.float32)
+        for l, info in enumerate(self.layers):
+            k = info["kernel_shape"]
+            nk = int(np.prod(k))
+            fan_in, fan_out = (k[0] * k[1] * k[2], k[0] * k[1] * k[3]) if len(k) == 4 else k
+            limit = np.sqrt(6.0 / (fan_in + fan_out))
+            idx = np.arange(nk, dtype=np.uint64)
+            words = _philox.philox4x32((idx >> np.uint64(2)).astype(np.uint32), 0, l, stream_id << 16, seed)
+            w = np.stack(words, axis=1)[np.arange(nk), (idx & np.uint64(3)).astype(np.int64)]
+            u = (w.astype(np.float64) + 0.5) / 4294967296.0
+            flat[info["kernel_offset"]:info["kernel_offset"] + nk] = ((2.0 * u - 1.0) * limit).astype(np.float32)
+        return torch.from_numpy(flat).to(self.device)
+
+    def get_weights(self, params):
+        """List of numpy arrays [kernel, bias, ...] in Keras order (what model.get_weights() returns)."""
+        p = params.detach().cpu().numpy()
+        out = []
+        for info in self.layers:
+            nk = int(np.prod(info["kernel_shape"]))
+            out.append(p[info["kernel_offset"]:info["kernel_offset"] + nk].reshape(info["kernel_shape"]).copy())
+            out.append(p[info["bias_offset"]:info["bias_offset"] + info["bias_shape"][0]].copy())
+        return out
+
+    def set_weights(self, params, weights):
+        flat = params.detach().cpu().numpy().copy()
+        assert len(weights) == 2 * len(self.layers)
+        for i, info in enumerate(self.layers):
+            k, b = np.asarray(weights[2 * i], np.float32), np.asarray(weights[2 * i + 1], np.float32)
+            assert k.shape == info["kernel_shape"] and b.shape == info["bias_shape"], (k.shape, info["kernel_shape"])
+            flat[info["kernel_offset"]:info["kernel_offset"] + k.size] = k.reshape(-1)
+            flat[info["bias_offset"]:info["bias_offset"] + b.size] = b
+        params.copy_(torch.from_numpy(flat))
+
+    # -- compute ----------------------------------------------------------------------------------------------
+    def forward(self, params, obs, batch=None, index=None, index_off=0, index_mod=0, training=False, seed=(0, 0), t=0,
+                sample_base=0, out=None):
+        assert params.dtype == torch.float32 and params.is_cuda and params.numel() == self.n_params
+        assert obs.dtype == torch.uint8 and obs.is_cuda and obs.is_contiguous()
+        if batch is None:
+            batch = obs.shape[0] if index is None else index.shape[0]
+        if index is not None:
+            assert index.dtype == torch.int32 and index.is_cuda and index.is_contiguous()
+        if out is None:
+            out = torch.empty((batch, self.n_actions), dtype=torch.float32, device=self.device)
+        check(self.L.dq_qnet_forward(self._h, ptr(params), ptr(obs), ptr(index), int(index_off), int(index_mod), int(batch),
+                                     int(bool(training)), _seed_arr(seed), int(t), int(sample_base), ptr(out), self._stream()))
+        if training:
+            self._train_inputs = (obs, index)       # backward re-reads them (conv1 weight gradient): keep them alive
+        return out
+
+    def backward(self, params, dq, grads=None):
+        assert dq.dtype == torch.float32 and dq.is_cuda and dq.is_contiguous()
+        if grads is None:
+            grads = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        check(self.L.dq_qnet_backward(self._h, ptr(params), ptr(dq), ptr(grads), self._stream()))
+        return grads
+
+
+def td_target(q_online_s1, q_target_s1, reward, terminal, gamma, index=None, out=None):
+    B, A = q_online_s1.shape
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=q_online_s1.device)
+    check(_lib.lib().dq_td_target(ptr(q_online_s1), ptr(q_target_s1), ptr(reward), ptr(terminal), ptr(index), float(gamma), B, A,
+                                  ptr(out), _lib.current_stream(q_online_s1.device)))
+    return out
+
+
+def td_loss_grad(q_s0, action, y, grad_scale=None, index=None, dq=None, metrics=None):
+    B, A = q_s0.shape
+    if dq is None:
+        dq = torch.empty_like(q_s0)
+    if metrics is None:
+        metrics = torch.empty(2, dtype=torch.float32, device=q_s0.device)
+    check(_lib.lib().dq_td_loss_grad(ptr(q_s0), ptr(action), ptr(index), ptr(y), B, A, 1.0 / B if grad_scale is None else float(grad_scale),
+                                     ptr(dq), ptr(metrics), _lib.current_stream(q_s0.device)))
+    return dq, metrics
+
+
+def adam_step(params, grads, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    check(_lib.lib().dq_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), float(lr), float(beta_1), float(beta_2),
+                                  float(epsilon), int(t), _lib.current_stream(params.device)))
+
+
+def replay_sample(terminal_ring, n_envs, n_slots, head_slot, filled_slots, batch, seed, t, sample_base=0, out=None):
+    if out is None:
+        out = torch.empty(batch, dtype=torch.int32, device=terminal_ring.device)
+    check(_lib.lib().dq_replay_sample(ptr(terminal_ring), int(n_envs), int(n_slots), int(head_slot), int(filled_slots), int(batch),
+                                      _seed_arr(seed), int(t), int(sample_base), ptr(out), _lib.current_stream(terminal_ring.device)))
+    return out

@@ -155,6 +155,86 @@ dq_status dq_policy_select(const float* q_dev, const uint64_t* legal_dev, int n,
                            int masked_greedy, const uint32_t seed[2], uint32_t env_id_base, uint64_t t,
                            int32_t* action_dev, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Q-network: replaces the Keras model of build_convolutional_nn (Single_Point_Training_Script.py:61-90)
+ * under keras-rl's dueling head (DQNAgent(enable_dueling_network=True), :119-127):
+ *   Conv2D(valid, channels_first)+ReLU x n_conv -> Flatten -> [Dense+ReLU+Dropout] x n_ff -> Dense(n_actions)
+ *   -> (dueling) Dense(n_actions+1), Q = y0 + y[1:] - mean(y[1:]).
+ * Parameters live in ONE flat float buffer owned by the caller, in Keras order and Keras shapes (conv
+ * kernels HWIO, dense (in,out)), each layer kernel then bias -- the tensors of a Keras .h5f drop in as is.
+ * fp32 MFMA throughout (the reference is fp32 and the parity bound is 1e-5).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dq_qnet dq_qnet;
+
+typedef struct {
+    int32_t in_c, in_h, in_w;   /* env.observation_space.shape (Single_Point_Training_Script.py:108) */
+    int32_t n_conv;             /* 1..4 */
+    int32_t conv[4][3];         /* [filters, kernel, stride]  ("c_layers"); stride > 1 only on the first */
+    int32_t n_ff;               /* 0..4 hidden dense layers ("ff_layers") */
+    int32_t ff_units[4];
+    float ff_dropout[4];
+    int32_t n_actions;          /* env.num_actions */
+    int32_t dueling;            /* enable_dueling_network */
+    int32_t max_batch;          /* workspaces are sized for this many samples */
+} dq_qnet_cfg;
+
+dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out);
+void dq_qnet_destroy(dq_qnet* net);
+size_t dq_qnet_param_count(const dq_qnet* net);
+int dq_qnet_num_layers(const dq_qnet* net);
+/* Offsets (in floats) of layer `layer`'s kernel and bias in the flat buffer and the kernel's Keras shape. */
+dq_status dq_qnet_layer_info(const dq_qnet* net, int layer, int64_t* kernel_offset, int64_t* bias_offset,
+                             int32_t shape[4], int32_t* n_dims);
+
+/* model.predict_on_batch (training == 0) / the forward half of train_on_batch (training != 0: dropout
+ * active, activations kept for dq_qnet_backward).
+ *   obs_dev    uint8 [rows, C, H, W]; sample b reads row  b                         if index_dev == NULL,
+ *                                                     row (index_dev[b] + index_off) mod index_mod otherwise
+ *              (the replay-minibatch gather happens inside the first convolution's loader);
+ *   q_dev      float [batch, n_actions];
+ *   dropout    keep(b, j) <=> Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b, (j>>2) | DQ_STREAM_DROPOUT<<16))[j&3]
+ *              >= ceil(rate * 2^32);  kept units are scaled by 1/(1-rate) (Keras K.dropout). */
+dq_status dq_qnet_forward(dq_qnet* net, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev,
+                          int index_off, int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t,
+                          uint32_t sample_base, float* q_dev, void* stream);
+
+/* Backward half of train_on_batch: grads_dev[n_params] = d/dparams sum(dq * Q) for the last training forward
+ * (obs_dev / index_dev of that call must still be valid).  Deterministic (fixed-order reductions). */
+dq_status dq_qnet_backward(dq_qnet* net, const float* params_dev, const float* dq_dev, float* grads_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DQN update: replaces SequentialMemory.sample + DQNAgent.backward + keras Adam of the keras-rl fork
+ * (Single_Point_Training_Script.py:109,119-130).
+ * Device replay ring: row r = slot*n_envs + env stores (observation, action, reward, terminal) of the
+ * step taken from that observation; its successor observation is row r + n_envs (mod n_slots*n_envs).
+ * ------------------------------------------------------------------------------------------- */
+/* Uniform minibatch rows (with replacement) over complete transitions, skipping those whose predecessor
+ * entry was terminal (keras-rl SequentialMemory.sample's rule).  head_slot = slot of the newest observation,
+ * filled_slots = slots written so far (<= n_slots).  Draws: Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b,
+ * attempt | DQ_STREAM_REPLAY<<16)): slot back-offset = (w0 * (filled-1)) >> 32, env = (w1 * n_envs) >> 32. */
+dq_status dq_replay_sample(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots,
+                           int batch, const uint32_t seed[2], uint64_t t, uint32_t sample_base, int32_t* index_dev,
+                           void* stream);
+
+/* Double-DQN target: y_b = reward[r_b] + gamma * (1 - terminal[r_b]) * Q_target(s1_b)[argmax_a Q_online(s1_b)[a]],
+ * r_b = index_dev ? index_dev[b] : b. */
+dq_status dq_td_target(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* reward_dev,
+                       const uint8_t* terminal_dev, const int32_t* index_dev, double gamma, int batch, int n_actions,
+                       float* y_dev, void* stream);
+
+/* keras-rl clipped_masked_error with delta_clip = inf:  loss = mean_b 0.5 (Q[b,a_b] - y_b)^2.
+ *   dq_dev      float [batch, n_actions] = grad_scale * (Q[b,a_b] - y_b) at a_b, 0 elsewhere
+ *               (grad_scale = 1 / global batch, so an all-reduce SUM of gradients gives the global mean);
+ *   metrics_dev float [2] (nullable) = {loss, mean_q = mean_b max_a Q[b,a]} of this rank's minibatch. */
+dq_status dq_td_loss_grad(const float* q_s0_dev, const int32_t* action_dev, const int32_t* index_dev, const float* y_dev,
+                          int batch, int n_actions, double grad_scale, float* dq_dev, float* metrics_dev, void* stream);
+
+/* keras.optimizers.Adam (Keras 2.2): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMAs; p -= lr_t*m/(sqrt(v)+epsilon).
+ * t = 1 for the first update. */
+dq_status dq_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n, double lr,
+                       double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

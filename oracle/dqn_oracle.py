@@ -1,0 +1,240 @@
+"""float64 numpy restatement of the DQN half of the hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED at source level: the reference's
+agent is the un-vendored, modified keras-rl fork github.com/R-Sweke/keras-rl (README.md:33; no commit
+pinned) on Keras 2.2.2 / TensorFlow 1.x, none of which is importable here.  What is restated below is
+the published keras-rl 0.4.x ``DQNAgent`` / Keras 2.2 arithmetic as used by the reference's call sites
+(``TRAIN`` = /root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py):
+
+  network      TRAIN:61-90 build_convolutional_nn: Conv2D(valid, channels_first)+ReLU ..., Flatten,
+               Dense+ReLU+Dropout ..., Dense(nb_actions) linear; keras-rl dueling head
+               (enable_dueling_network=True, TRAIN:127; dueling_type 'avg'): Dense(nb_actions+1) then
+               Q = y[:,0:1] + y[:,1:] - mean(y[:,1:], axis=1).  Tensor shapes confirmed by the shipped
+               weights (trained_models/*/*/final_dqn_weights.h5f: (3,3,C,64) (2,2,64,32) (2,2,32,32)
+               (288,512) (512,A) (A,A+1); kernels HWIO, dense (in,out)).
+  update       double DQN (keras-rl default enable_double_dqn=True; paper TEX:493,632):
+               a* = argmax_a Q_online(s1);  y = r + gamma * (1 - terminal) * Q_target(s1)[a*];
+               loss = mean_b 0.5 * (y_b - Q_online(s0_b)[a_b])^2   (delta_clip = inf -> huber == 0.5 x^2);
+               metric mean_q = mean_b max_a Q_online(s0_b) of the TRAINING forward (dropout active).
+  optimizer    Keras Adam (TRAIN:130): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+1e-7).
+  policy       LinearAnnealedPolicy(EpsGreedyQPolicy) TRAIN:110-114: eps = max(min, max_ - (max_-min)*step/nb_steps).
+
+Flat parameter layout (shared with the HIP library): for each layer kernel then bias, Keras order.
+Activations are described in NHWC here only where noted; the math is layout-free.
+"""
+import numpy as np
+
+from . import philox
+
+
+class QNetSpec:
+    def __init__(self, input_shape, c_layers, ff_layers, n_actions, dueling=True):
+        self.input_shape = tuple(int(x) for x in input_shape)          # (C, H, W)
+        self.c_layers = [tuple(int(x) for x in l) for l in c_layers]   # [filters, kernel, stride]
+        self.ff_layers = [(int(l[0]), float(l[1])) for l in ff_layers]  # [units, dropout rate]
+        self.n_actions, self.dueling = int(n_actions), bool(dueling)
+        self.layers = []            # (kind, dict)
+        c, h, w = self.input_shape
+        for (f, k, s) in self.c_layers:
+            oh, ow = (h - k) // s + 1, (w - k) // s + 1
+            self.layers.append(("conv", dict(cin=c, cout=f, k=k, s=s, ih=h, iw=w, oh=oh, ow=ow)))
+            c, h, w = f, oh, ow
+        n = c * h * w
+        self.flat = n
+        for (u, rate) in self.ff_layers:
+            self.layers.append(("dense", dict(nin=n, nout=u, relu=True, dropout=rate)))
+            n = u
+        self.layers.append(("dense", dict(nin=n, nout=self.n_actions, relu=False, dropout=0.0)))
+        if self.dueling:
+            self.layers.append(("dense", dict(nin=self.n_actions, nout=self.n_actions + 1, relu=False, dropout=0.0)))
+
+    def param_shapes(self):
+        out = []
+        for kind, L in self.layers:
+            if kind == "conv":
+                out.append(((L["k"], L["k"], L["cin"], L["cout"]), (L["cout"],)))
+            else:
+                out.append(((L["nin"], L["nout"]), (L["nout"],)))
+        return out
+
+    @property
+    def n_params(self):
+        return sum(int(np.prod(k)) + int(np.prod(b)) for k, b in self.param_shapes())
+
+    def split(self, flat):
+        out, o = [], 0
+        for k, b in self.param_shapes():
+            nk, nb = int(np.prod(k)), int(np.prod(b))
+            out.append((flat[o:o + nk].reshape(k), flat[o + nk:o + nk + nb]))
+            o += nk + nb
+        assert o == len(flat)
+        return out
+
+    def forward_macs(self):
+        m = 0
+        for kind, L in self.layers:
+            m += L["oh"] * L["ow"] * L["cout"] * L["k"] * L["k"] * L["cin"] if kind == "conv" else L["nin"] * L["nout"]
+        return m
+
+
+def glorot_init(spec, seed, stream=philox.STREAM_INIT):
+    """Keras default initialisers (glorot_uniform kernels, zero biases) driven by the Philox INIT stream:
+    element i of layer l gets u = (word + 0.5) / 2^32 with word = Philox(key=seed, ctr=(i>>2, 0, l, stream<<16))[i&3]."""
+    flat = np.zeros(spec.n_params, dtype=np.float32)
+    o = 0
+    for l, (k, b) in enumerate(spec.param_shapes()):
+        nk = int(np.prod(k))
+        if len(k) == 4:
+            fan_in, fan_out = k[0] * k[1] * k[2], k[0] * k[1] * k[3]
+        else:
+            fan_in, fan_out = k
+        limit = np.sqrt(6.0 / (fan_in + fan_out))
+        idx = np.arange(nk, dtype=np.uint64)
+        words = philox.philox4x32_np((idx >> np.uint64(2)).astype(np.uint32), 0, l, stream << 16, seed)
+        w = np.stack(words, axis=1)[np.arange(nk), (idx & np.uint64(3)).astype(np.int64)]
+        u = (w.astype(np.float64) + 0.5) / 4294967296.0
+        flat[o:o + nk] = ((2.0 * u - 1.0) * limit).astype(np.float32)
+        o += nk + int(np.prod(b))
+    return flat
+
+
+def dropout_keep_mask(seed, t, sample_ids, n_units, rate):
+    """keep[b, j] for update counter t: word = Philox(key=seed, ctr=(t_lo, t_hi, sample_id, (j>>2) | DROPOUT<<16))[j&3];
+    dropped iff word < ceil(rate * 2^32)."""
+    sample_ids = np.asarray(sample_ids, dtype=np.uint32)
+    j = np.arange(n_units, dtype=np.uint32)
+    words = philox.philox4x32_np(int(t) & philox.MASK, (int(t) >> 32) & philox.MASK, sample_ids[:, None],
+                                 (j[None, :] >> 2) | (philox.STREAM_DROPOUT << 16), seed)
+    w = np.stack(words, axis=-1)
+    sel = np.take_along_axis(w, np.broadcast_to((j & 3)[None, :, None].astype(np.int64), w.shape[:2] + (1,)), axis=-1)[..., 0]
+    return sel.astype(np.uint64) >= np.uint64(philox.threshold(rate))
+
+
+def _im2col(x, k, s):
+    """x (B,C,H,W) -> (B, OH, OW, k*k*C) with the last axis ordered (ky, kx, c) = Keras HWIO flattening."""
+    B, C, H, W = x.shape
+    oh, ow = (H - k) // s + 1, (W - k) // s + 1
+    cols = np.zeros((B, oh, ow, k, k, C), dtype=x.dtype)
+    for ky in range(k):
+        for kx in range(k):
+            cols[:, :, :, ky, kx, :] = x[:, :, ky:ky + s * oh:s, kx:kx + s * ow:s].transpose(0, 2, 3, 1)
+    return cols.reshape(B, oh, ow, k * k * C)
+
+
+def forward(spec, flat_params, obs, training=False, keep_masks=None):
+    """Returns (Q (B,A) float64, cache).  keep_masks: list of boolean (B, units) arrays, one per dropout layer
+    with rate > 0 (training only)."""
+    P = spec.split(np.asarray(flat_params, dtype=np.float64))
+    x = np.asarray(obs, dtype=np.float64)
+    cache = dict(layers=[])
+    mi = 0
+    flat_done = False
+    for (kind, L), (Wk, bk) in zip(spec.layers, P):
+        if kind == "conv":
+            cols = _im2col(x, L["k"], L["s"])                                  # (B,OH,OW,K)
+            z = cols @ Wk.reshape(-1, L["cout"]) + bk                          # (B,OH,OW,Cout)
+            y = np.maximum(z, 0.0)
+            cache["layers"].append(dict(kind="conv", cols=cols, y=y, x_shape=x.shape))
+            x = y.transpose(0, 3, 1, 2)                                        # back to (B,C,H,W)
+        else:
+            if not flat_done:
+                x = x.reshape(x.shape[0], -1)                                  # Keras Flatten, channels_first order
+                flat_done = True
+            z = x @ Wk + bk
+            y = np.maximum(z, 0.0) if L["relu"] else z
+            keep = None
+            if training and L["dropout"] > 0.0:
+                keep = keep_masks[mi]
+                mi += 1
+                y_out = np.where(keep, y / (1.0 - L["dropout"]), 0.0)           # K.dropout: x / keep_prob * mask
+            else:
+                y_out = y
+            cache["layers"].append(dict(kind="dense", x=x, y=y, keep=keep, rate=L["dropout"], relu=L["relu"]))
+            x = y_out
+    if spec.dueling:
+        q = x[:, 0:1] + x[:, 1:] - x[:, 1:].mean(axis=1, keepdims=True)
+    else:
+        q = x
+    cache["head_in"] = x
+    return q, cache
+
+
+def backward(spec, flat_params, cache, dq):
+    """Gradient of sum(dq * Q) w.r.t. the flat parameters (float64)."""
+    P = spec.split(np.asarray(flat_params, dtype=np.float64))
+    dq = np.asarray(dq, dtype=np.float64)
+    if spec.dueling:
+        A = spec.n_actions
+        g = np.zeros((dq.shape[0], A + 1))
+        g[:, 0] = dq.sum(axis=1)
+        g[:, 1:] = dq - dq.sum(axis=1, keepdims=True) / A
+    else:
+        g = dq
+    grads = [None] * len(P)
+    for li in range(len(P) - 1, -1, -1):
+        (kind, L), (Wk, bk), C = spec.layers[li], P[li], cache["layers"][li]
+        if kind == "dense":
+            if C["keep"] is not None:
+                g = np.where(C["keep"], g / (1.0 - C["rate"]), 0.0)
+            if C["relu"]:
+                g = g * (C["y"] > 0.0)
+            grads[li] = (C["x"].T @ g, g.sum(axis=0))
+            g = g @ Wk.T
+        else:
+            B = C["y"].shape[0]
+            if g.ndim == 2:                                                    # coming from Flatten: (B, C*OH*OW)
+                g = g.reshape(B, L["cout"], L["oh"], L["ow"]).transpose(0, 2, 3, 1)
+            g = g * (C["y"] > 0.0)                                             # (B,OH,OW,Cout)
+            K = L["k"] * L["k"] * L["cin"]
+            grads[li] = ((C["cols"].reshape(-1, K).T @ g.reshape(-1, L["cout"])).reshape(Wk.shape), g.sum(axis=(0, 1, 2)))
+            if li > 0:
+                dcols = g @ Wk.reshape(K, L["cout"]).T                         # (B,OH,OW,K)
+                dcols = dcols.reshape(B, L["oh"], L["ow"], L["k"], L["k"], L["cin"])
+                dx = np.zeros((B, L["ih"], L["iw"], L["cin"]))
+                s = L["s"]
+                for ky in range(L["k"]):
+                    for kx in range(L["k"]):
+                        dx[:, ky:ky + s * L["oh"]:s, kx:kx + s * L["ow"]:s, :] += dcols[:, :, :, ky, kx, :]
+                g = dx                                                         # NHWC gradient w.r.t. previous y
+    return np.concatenate([np.concatenate([gk.reshape(-1), gb.reshape(-1)]) for gk, gb in grads])
+
+
+def td_targets(q_online_s1, q_target_s1, reward, terminal, gamma):
+    """Double-DQN target (keras-rl DQNAgent.backward, enable_double_dqn)."""
+    a_star = np.argmax(q_online_s1, axis=1)
+    q = q_target_s1[np.arange(len(a_star)), a_star]
+    return np.asarray(reward, dtype=np.float64) + gamma * q * (1.0 - np.asarray(terminal, dtype=np.float64))
+
+
+def loss_and_grad(q_s0, action, y):
+    """loss = mean_b 0.5 (y_b - Q[b,a_b])^2;  mean_q = mean_b max_a Q[b,a];  dQ = dloss/dQ."""
+    B = q_s0.shape[0]
+    idx = np.arange(B)
+    diff = q_s0[idx, action] - y
+    dq = np.zeros_like(q_s0)
+    dq[idx, action] = diff / B
+    return 0.5 * np.mean(diff ** 2), np.mean(q_s0.max(axis=1)), dq
+
+
+def adam_step(p, g, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    """Keras 2.2 Adam.get_updates; t = 1 for the first update.  Returns new (p, m, v)."""
+    lr_t = lr * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+    m = beta_1 * m + (1.0 - beta_1) * g
+    v = beta_2 * v + (1.0 - beta_2) * g * g
+    return p - lr_t * m / (np.sqrt(v) + epsilon), m, v
+
+
+def annealed_eps(step, value_max, value_min, nb_steps):
+    """keras-rl LinearAnnealedPolicy.get_current_value (training)."""
+    a = -float(value_max - value_min) / float(nb_steps)
+    return max(value_min, a * float(step) + float(value_max))
+
+
+def select_action(q, legal_mask, eps, masked_greedy, words):
+    """Restates dq_policy_select for one lattice (include/deepq_hip.h): words = 4 uint32 of the POLICY stream."""
+    legal = [a for a in range(len(q)) if (legal_mask >> a) & 1]
+    if q is None or int(words[1]) < philox.threshold(eps):
+        return legal[philox.bounded(words[0], len(legal))]
+    if masked_greedy:
+        return max(legal, key=lambda a: (q[a], -a))
+    return int(np.argmax(q))

@@ -1,0 +1,196 @@
+"""GPU parity tests of the HIP Q-network / DQN-update kernels (through the C ABI) against the float64
+oracle (oracle/dqn_oracle.py).  Tolerance: 1e-5 absolute on Q-values and loss (BASELINE.json north_star);
+gradients and Adam are checked relative to their scale."""
+import numpy as np
+import pytest
+
+from oracle import dqn_oracle as O, philox
+
+pytestmark = pytest.mark.gpu
+
+C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
+SHAPES = {"c1": ((4, 7, 7), 10), "c2": ((6, 11, 11), 26), "c3": ((7, 11, 11), 51), "c5": ((9, 15, 15), 99)}
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _setup(dq, torch, name, batch, seed=(11, 22), dueling=True, max_batch=None):
+    shape, A = SHAPES[name]
+    spec = O.QNetSpec(shape, C_LAYERS, FF_LAYERS, A, dueling=dueling)
+    net = dq.QNetwork(shape, C_LAYERS, FF_LAYERS, A, dueling=dueling, max_batch=max_batch or batch)
+    assert net.n_params == spec.n_params
+    params = net.init_params(seed)
+    assert np.array_equal(params.cpu().numpy(), O.glorot_init(spec, seed))
+    rng = np.random.RandomState(5)
+    flat = params.cpu().numpy().copy()
+    flat += (rng.randn(flat.size) * 0.02).astype(np.float32)        # non-zero biases, less symmetric weights
+    params.copy_(torch.from_numpy(flat))
+    obs = (rng.rand(batch, *shape) < 0.3).astype(np.uint8)
+    return spec, net, params, flat, obs, rng
+
+
+@pytest.mark.parametrize("name,batch", [("c1", 1), ("c1", 37), ("c2", 32), ("c3", 32), ("c3", 300), ("c5", 64)])
+def test_forward_inference(dq, torch_mod, name, batch):
+    torch = torch_mod
+    spec, net, params, flat, obs, _ = _setup(dq, torch, name, batch)
+    q = net.forward(params, torch.from_numpy(obs).cuda()).cpu().numpy()
+    q_ref, _ = O.forward(spec, flat, obs)
+    assert np.abs(q - q_ref).max() < TOL
+
+
+def test_forward_non_dueling_and_layer_layout(dq, torch_mod):
+    torch = torch_mod
+    spec, net, params, flat, obs, _ = _setup(dq, torch, "c3", 16, dueling=False)
+    q = net.forward(params, torch.from_numpy(obs).cuda()).cpu().numpy()
+    assert np.abs(q - O.forward(spec, flat, obs)[0]).max() < TOL
+    # Keras-shaped views of the flat buffer round-trip (what .h5f loading relies on)
+    w = net.get_weights(params)
+    assert [x.shape for x in w] == [s for pair in spec.param_shapes() for s in pair]
+    for (k, b), wk, wb in zip(spec.split(flat), w[0::2], w[1::2]):
+        assert np.array_equal(k, wk) and np.array_equal(b, wb)
+    net.set_weights(params, [x * 2 for x in w])
+    assert np.array_equal(params.cpu().numpy(), flat * 2)
+
+
+def test_forward_with_replay_gather(dq, torch_mod):
+    """Minibatch rows gathered inside conv1's loader: forward(index) == forward(obs[index]); wrap-around of s1 rows."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 64)
+    ring = (rng.rand(200, *SHAPES["c3"][0]) < 0.3).astype(np.uint8)
+    idx = rng.randint(0, 200, size=64).astype(np.int32)
+    ring_t, idx_t = torch.from_numpy(ring).cuda(), torch.from_numpy(idx).cuda()
+    q0 = net.forward(params, ring_t, index=idx_t).cpu().numpy()
+    assert np.abs(q0 - O.forward(spec, flat, ring[idx])[0]).max() < TOL
+    q1 = net.forward(params, ring_t, index=idx_t, index_off=40, index_mod=200).cpu().numpy()
+    assert np.abs(q1 - O.forward(spec, flat, ring[(idx + 40) % 200])[0]).max() < TOL
+
+
+@pytest.mark.parametrize("name,batch", [("c1", 8), ("c3", 32), ("c3", 257), ("c5", 48)])
+def test_training_forward_backward(dq, torch_mod, name, batch):
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, name, batch)
+    seed, t, base = (3, 4), 12345678901, 77
+    keep = O.dropout_keep_mask(seed, t, base + np.arange(batch), 512, 0.2)
+    q = net.forward(params, torch.from_numpy(obs).cuda(), training=True, seed=seed, t=t, sample_base=base).cpu().numpy()
+    q_ref, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    assert np.abs(q - q_ref).max() < TOL
+    dq_ = (rng.randn(batch, spec.n_actions) / batch).astype(np.float32)
+    g = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
+    g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
+    scale = np.abs(g_ref).max()
+    assert np.abs(g - g_ref).max() < 2e-5 * max(scale, 1.0), (np.abs(g - g_ref).max(), scale)
+    # per-layer relative check so that small-gradient layers are not hidden by large ones
+    for (gk, gb), (rk, rb) in zip(spec.split(g), spec.split(g_ref)):
+        for a, b in ((gk, rk), (gb, rb)):
+            assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-7
+    # deterministic: same call twice gives identical bits
+    g2 = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
+    assert np.array_equal(g, g2)
+
+
+def test_td_target_loss_adam(dq, torch_mod):
+    torch = torch_mod
+    rng = np.random.RandomState(9)
+    B, A, R = 500, 51, 3000
+    q1o, q1t, q0 = (rng.randn(B, A).astype(np.float32) for _ in range(3))
+    q1o[7, 3] = q1o[7, 9] = q1o[7].max() + 1.0                      # tie -> first maximum
+    reward = (rng.rand(R) < 0.4).astype(np.float32)
+    terminal = (rng.rand(R) < 0.2).astype(np.uint8)
+    action = rng.randint(0, A, size=R).astype(np.int32)
+    idx = rng.randint(0, R, size=B).astype(np.int32)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    y = dq.td_target(cu(q1o), cu(q1t), cu(reward), cu(terminal), 0.99, index=cu(idx)).cpu().numpy()
+    y_ref = O.td_targets(q1o.astype(np.float64), q1t.astype(np.float64), reward[idx], terminal[idx], 0.99)
+    assert np.abs(y - y_ref).max() < TOL
+    dq_, metrics = dq.td_loss_grad(cu(q0), cu(action), cu(y), index=cu(idx))
+    loss_ref, mq_ref, dq_ref = O.loss_and_grad(q0.astype(np.float64), action[idx], y.astype(np.float64))
+    m = metrics.cpu().numpy()
+    assert abs(m[0] - loss_ref) < TOL and abs(m[1] - mq_ref) < TOL
+    assert np.abs(dq_.cpu().numpy() - dq_ref).max() < 1e-7
+    # Adam, three consecutive updates, odd length (exercises the scalar tail)
+    n = 10007
+    p, g = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    pt, mt, vt = cu(p.copy()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pr, mr, vr = p.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in range(1, 4):
+        dq.adam_step(pt, cu(g), mt, vt, t, 1e-3)
+        pr, mr, vr = O.adam_step(pr, g.astype(np.float64), mr, vr, t, 1e-3)
+        assert np.abs(pt.cpu().numpy() - pr).max() < 1e-6
+    assert np.abs(mt.cpu().numpy() - mr).max() < 1e-6 and np.abs(vt.cpu().numpy() - vr).max() < 1e-6
+
+
+def test_replay_sample_rule(dq, torch_mod):
+    """Sampled rows are complete transitions, never start at a post-terminal entry, match the Philox definition,
+    and cover the ring roughly uniformly."""
+    torch = torch_mod
+    rng = np.random.RandomState(2)
+    n_envs, n_slots, head, filled, batch = 64, 50, 17, 50, 20000
+    term = (rng.rand(n_slots, n_envs) < 0.15).astype(np.uint8)
+    seed, t, base = (8, 9), 55, 1000
+    idx = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, batch, seed, t, sample_base=base).cpu().numpy()
+    slot, env = idx // n_envs, idx % n_envs
+    assert (slot != head).all()                                        # the newest observation has no successor yet
+    prev = (slot - 1) % n_slots
+    oldest = (head + 1) % n_slots
+    bad = (term[prev, env] == 1) & (slot != oldest)
+    assert not bad.any()
+    # first few samples against the scalar definition
+    for b in range(50):
+        for attempt in range(64):
+            w = philox.philox4x32((t, 0, base + b, attempt | (philox.STREAM_REPLAY << 16)), seed)
+            j, e = philox.bounded(w[0], filled - 1), philox.bounded(w[1], n_envs)
+            s = (head - 1 - j) % n_slots
+            if j + 1 >= filled - 1 or not term[(s - 1) % n_slots, e]:
+                break
+        assert idx[b] == s * n_envs + e
+    counts = np.bincount(slot, minlength=n_slots)
+    assert counts[head] == 0 and counts[np.arange(n_slots) != head].min() > 0.5 * batch / n_slots
+    # partially filled ring: only written slots are sampled
+    idx2 = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, 5, 6, 5000, seed, t).cpu().numpy()
+    assert set(np.unique(idx2 // n_envs)) <= {0, 1, 2, 3, 4}
+
+
+def test_one_full_update_matches_oracle(dq, torch_mod):
+    """One complete DQN update (double-DQN target from s1, training forward on s0, loss, backward, Adam) on c3,
+    batch 32, against the float64 oracle: loss / mean_q within 1e-5, updated weights within 1e-6."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 32, max_batch=64)
+    B, A, gamma, lr = 32, 51, 0.99, 1e-4
+    target = params.clone()
+    target += 0.01 * torch.randn_like(target)
+    flat_t = target.cpu().numpy()
+    s1 = (rng.rand(B, 7, 11, 11) < 0.3).astype(np.uint8)
+    reward = (rng.rand(B) < 0.5).astype(np.float32)
+    terminal = (rng.rand(B) < 0.2).astype(np.uint8)
+    action = rng.randint(0, A, size=B).astype(np.int32)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    seed, t = (1, 2), 1
+    q1o = net.forward(params, cu(s1))
+    q1t = net.forward(target, cu(s1))
+    y = dq.td_target(q1o, q1t, cu(reward), cu(terminal), gamma)
+    obs_t = cu(obs)
+    q0 = net.forward(params, obs_t, training=True, seed=seed, t=t)
+    dq_, metrics = dq.td_loss_grad(q0, cu(action), y)
+    grads = net.backward(params, dq_)
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    dq.adam_step(params, grads, m, v, 1, lr)
+    # oracle
+    keep = O.dropout_keep_mask(seed, t, np.arange(B), 512, 0.2)
+    y_ref = O.td_targets(O.forward(spec, flat, s1)[0], O.forward(spec, flat_t, s1)[0], reward, terminal, gamma)
+    q0_ref, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    loss_ref, mq_ref, dq_ref = O.loss_and_grad(q0_ref, action, y_ref)
+    g_ref = O.backward(spec, flat, cache, dq_ref)
+    p_ref, _, _ = O.adam_step(flat.astype(np.float64), g_ref, np.zeros_like(g_ref), np.zeros_like(g_ref), 1, lr)
+    mt = metrics.cpu().numpy()
+    assert abs(mt[0] - loss_ref) < TOL and abs(mt[1] - mq_ref) < TOL
+    assert np.abs(y.cpu().numpy() - y_ref).max() < TOL
+    # first Adam step moves every weight by ~lr * sign(g): compare where the gradient is not ~0
+    big = np.abs(g_ref) > 1e-6
+    assert np.abs(params.cpu().numpy() - p_ref)[big].max() < 1e-6
+    assert np.abs(grads.cpu().numpy() - g_ref).max() < 1e-5 * max(1.0, np.abs(g_ref).max())
