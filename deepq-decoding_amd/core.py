@@ -1,0 +1,136 @@
+"""Device-resident DQN loop over a batch of lattices: act -> environment step -> replay ring -> update.
+
+This is the vectorised form of the loop keras-rl runs one lattice / one minibatch at a time
+(`Agent.fit` + `DQNAgent.forward/backward`, call site
+/root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:138-152).  With one lattice it
+performs exactly that sequence per step; with N lattices every launch handles all of them and nothing is
+copied to the host inside a step.
+
+Replay ring (SequentialMemory(limit, window_length=1), :109): time-major device tensors
+    obs      uint8 [T, N, C, H, W]     action int32 [T, N]     reward float [T, N]     terminal uint8 [T, N]
+row (t, i) = what lattice i saw / did / received at vector step t; its successor observation is row (t+1, i).
+The environment kernel writes the new observation straight into slot t+1, so there is no append copy; a
+lattice that terminated spends its next step being reset (keras-rl's extra forward/backward on the terminal
+observation), which is what makes keras-rl's "skip entries whose predecessor was terminal" sampling rule carry
+over unchanged.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, qnet as _q
+from ._lib import check, ptr
+
+
+class DQNCore:
+    def __init__(self, env, net, batch_size=32, memory_limit=50000, gamma=0.99, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
+                 target_model_update=10000, enable_double_dqn=True, seed=None, rank=0, world_size=1, process_group=None,
+                 params=None):
+        self.env, self.net = env, net
+        self.N, self.A = env.n_envs, env.num_actions
+        assert net.n_actions == self.A and tuple(net.input_shape) == tuple(env.obs_shape)
+        self.device = env.device
+        self.batch_size = int(batch_size)
+        assert self.batch_size <= net.max_batch and self.N <= net.max_batch
+        self.gamma, self.lr, self.beta_1, self.beta_2, self.epsilon = gamma, lr, beta_1, beta_2, epsilon
+        self.target_model_update = target_model_update
+        self.enable_double_dqn = enable_double_dqn
+        self.seed = tuple(env.seed) if seed is None else tuple(seed)
+        self.rank, self.world_size, self.pg = rank, world_size, process_group
+        self.L = _lib.lib()
+        dev = self.device
+        # ring
+        self.T = max(2, int(memory_limit) // self.N + 1)
+        C, H, W = env.obs_shape
+        self.obs_ring = torch.zeros((self.T, self.N, C, H, W), dtype=torch.uint8, device=dev)
+        self.action_ring = torch.zeros((self.T, self.N), dtype=torch.int32, device=dev)
+        self.reward_ring = torch.zeros((self.T, self.N), dtype=torch.float32, device=dev)
+        self.terminal_ring = torch.zeros((self.T, self.N), dtype=torch.uint8, device=dev)
+        self.cur, self.filled = 0, 0
+        # parameters
+        self.params = net.init_params(self.seed) if params is None else params
+        if world_size > 1:
+            torch.distributed.broadcast(self.params, src=0, group=self.pg)
+        self.target = self.params.clone()
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.grads = torch.zeros_like(self.params)
+        # scratch
+        self.q_act = torch.zeros((self.N, self.A), dtype=torch.float32, device=dev)
+        B = self.batch_size
+        self.index = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.q1_online = torch.zeros((B, self.A), dtype=torch.float32, device=dev)
+        self.q1_target = torch.zeros((B, self.A), dtype=torch.float32, device=dev)
+        self.q0 = torch.zeros((B, self.A), dtype=torch.float32, device=dev)
+        self.y = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.dq = torch.zeros((B, self.A), dtype=torch.float32, device=dev)
+        self.metrics = torch.zeros(_q.TD_METRICS_FLOATS, dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.vector_steps = 0        # policy / environment counter
+        self.updates = 0             # optimizer steps taken
+        self.started = False
+
+    # ------------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def reset_env(self):
+        """env.reset() for every lattice; the first observation lands in ring slot `cur`."""
+        self.env.reset(out_obs=self.obs_ring[self.cur])
+        self.filled = 1
+        self.started = True
+
+    def act_and_step(self, eps, masked_greedy=False, use_q=True, record_stats=True):
+        """One vector step: Q forward on the current observations, epsilon-greedy over the legal set, environment
+        step with auto-reset; the transition is recorded in the ring by construction."""
+        env, cur = self.env, self.cur
+        nxt = cur + 1 if cur + 1 < self.T else 0
+        obs = self.obs_ring[cur]
+        q = None
+        if use_q:
+            q = self.net.forward(self.params, obs, batch=self.N, out=self.q_act)
+        env.select_actions(self.vector_steps, q=q, eps=eps, masked_greedy=masked_greedy, out=self.action_ring[cur])
+        check(self.L.dq_env_step(env._h, ptr(self.action_ring[cur]), 1, ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]),
+                                 ptr(self.terminal_ring[cur]), ptr(env.legal), ptr(env.lifetime), ptr(env.was_reset), self._stream()))
+        if record_stats:
+            check(self.L.dq_episode_stats(ptr(self.terminal_ring[cur]), ptr(env.was_reset), ptr(env.lifetime), ptr(self.reward_ring[cur]),
+                                          self.N, ptr(self.stats), self._stream()))
+        self.cur = nxt
+        self.filled = min(self.T, self.filled + 1)
+        self.vector_steps += 1
+
+    def update(self):
+        """One minibatch update (keras-rl DQNAgent.backward's training branch)."""
+        assert self.filled >= 2, "no complete transition in the replay ring yet"
+        B, N, T = self.batch_size, self.N, self.T
+        self.updates += 1
+        t = self.updates
+        sample_base = self.rank * B
+        rows = T * N
+        _q.replay_sample(self.terminal_ring, N, T, self.cur, self.filled, B, self.seed, t, sample_base=sample_base, out=self.index)
+        net, ring = self.net, self.obs_ring
+        # Q_online(s1) picks the action, Q_target(s1) values it (double DQN); without it Q_target does both
+        net.forward(self.target, ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target)
+        if self.enable_double_dqn:
+            net.forward(self.params, ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online)
+            q_sel = self.q1_online
+        else:
+            q_sel = self.q1_target
+        _q.td_target(q_sel, self.q1_target, self.reward_ring, self.terminal_ring, self.gamma, index=self.index, out=self.y)
+        net.forward(self.params, ring, batch=B, index=self.index, training=True, seed=self.seed, t=t, sample_base=sample_base, out=self.q0)
+        _q.td_loss_grad(self.q0, self.action_ring, self.y, grad_scale=1.0 / (B * self.world_size), index=self.index, dq=self.dq,
+                        metrics=self.metrics)
+        net.backward(self.params, self.dq, grads=self.grads)
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+
+    def update_target_hard(self):
+        self.target.copy_(self.params)
+
+    def read_stats(self, reset=True):
+        """(episodes ended, sum of their lifetimes, rewards earned, lattices stepped) since the last reset; syncs."""
+        s = [int(x) for x in self.stats.cpu().tolist()]
+        if reset:
+            self.stats.zero_()
+        return s

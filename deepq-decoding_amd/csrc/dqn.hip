@@ -60,31 +60,50 @@ __global__ void td_target_kernel(const float* __restrict__ q_online, const float
 }
 
 // dq[b, a] = grad_scale * (Q[b,a_b] - y_b) at a = a_b, else 0;  metrics[0] = mean_b 0.5 (Q[b,a_b]-y_b)^2,
-// metrics[1] = mean_b max_a Q[b,a].  Single block => fixed summation order.
-__global__ __launch_bounds__(1024) void td_loss_grad_kernel(const float* __restrict__ q, const int32_t* __restrict__ action,
-                                                            const int32_t* __restrict__ index, const float* __restrict__ y, int B,
-                                                            int A, float grad_scale, float* __restrict__ dq, float* __restrict__ metrics) {
-    __shared__ float s_loss[1024], s_q[1024];
+// metrics[1] = mean_b max_a Q[b,a].  One wave per sample; per-block partials land in metrics[2 + 2*block ...] and a
+// second single-block pass adds them in a fixed order (deterministic).
+#define TD_MAX_BLOCKS 1024
+__global__ __launch_bounds__(256) void td_loss_grad_kernel(const float* __restrict__ q, const int32_t* __restrict__ action,
+                                                           const int32_t* __restrict__ index, const float* __restrict__ y, int B,
+                                                           int A, float grad_scale, float* __restrict__ dq, float* __restrict__ metrics) {
+    __shared__ float s_loss[4], s_q[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float loss = 0.f, mq = 0.f;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
         const float* row = q + (size_t)b * A;
         float* drow = dq + (size_t)b * A;
         const int a_b = action[index ? index[b] : b];
         float mx = -INFINITY;
-        for (int a = 0; a < A; ++a) { mx = fmaxf(mx, row[a]); drow[a] = 0.f; }
+        for (int a = lane; a < A; a += 64) {
+            const float v = row[a];
+            mx = fmaxf(mx, v);
+            drow[a] = a == a_b ? (v - y[b]) * grad_scale : 0.f;
+        }
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
         const float diff = row[a_b] - y[b];
-        drow[a_b] = diff * grad_scale;
         loss += 0.5f * diff * diff;
         mq += mx;
     }
+    if (lane == 0) { s_loss[wave] = loss; s_q[wave] = mq; }
+    __syncthreads();
+    if (threadIdx.x == 0 && metrics) {
+        metrics[2 + 2 * blockIdx.x] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        metrics[3 + 2 * blockIdx.x] = (s_q[0] + s_q[1]) + (s_q[2] + s_q[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void td_metrics_kernel(float* __restrict__ metrics, int blocks, int B) {
+    __shared__ float s_loss[256], s_q[256];
+    float loss = 0.f, mq = 0.f;
+    for (int k = threadIdx.x; k < blocks; k += 256) { loss += metrics[2 + 2 * k]; mq += metrics[3 + 2 * k]; }
     s_loss[threadIdx.x] = loss;
     s_q[threadIdx.x] = mq;
     __syncthreads();
-    for (int s = blockDim.x >> 1; s >= 1; s >>= 1) {
+    for (int s = 128; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s) { s_loss[threadIdx.x] += s_loss[threadIdx.x + s]; s_q[threadIdx.x] += s_q[threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && metrics) { metrics[0] = s_loss[0] / (float)B; metrics[1] = s_q[0] / (float)B; }
+    if (threadIdx.x == 0) { metrics[0] = s_loss[0] / (float)B; metrics[1] = s_q[0] / (float)B; }
 }
 
 // Keras 2.2 Adam.get_updates: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps)
@@ -116,7 +135,34 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// stats[0] += #episodes that ended this step, stats[1] += sum of their lifetimes, stats[2] += #rewards == 1,
+// stats[3] += #lattices stepped (not reset).  Integer atomics => order-independent result.
+__global__ void episode_stats_kernel(const u8* __restrict__ done, const u8* __restrict__ was_reset, const u32* __restrict__ lifetime,
+                                     const float* __restrict__ reward, int n, unsigned long long* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const bool stepped = in && !(was_reset && was_reset[i]);
+    const bool ended = stepped && done[i];
+    const u64 m_end = __ballot(ended), m_rew = __ballot(stepped && reward[i] > 0.5f), m_step = __ballot(stepped);
+    unsigned long long life = ended ? lifetime[i] : 0;
+    for (int m = 32; m >= 1; m >>= 1) life += __shfl_xor(life, m);
+    if ((threadIdx.x & 63) == 0) {
+        if (m_end) { atomicAdd(&stats[0], (unsigned long long)__popcll(m_end)); atomicAdd(&stats[1], life); }
+        if (m_rew) atomicAdd(&stats[2], (unsigned long long)__popcll(m_rew));
+        if (m_step) atomicAdd(&stats[3], (unsigned long long)__popcll(m_step));
+    }
+}
+
 extern "C" {
+
+dq_status dq_episode_stats(const uint8_t* done_dev, const uint8_t* was_reset_dev, const uint32_t* lifetime_dev, const float* reward_dev,
+                           int n, uint64_t* stats_dev, void* stream) {
+    DQ_REQUIRE(done_dev && lifetime_dev && reward_dev && stats_dev && n >= 1, DQ_ERR_INVALID, "dq_episode_stats: bad argument");
+    episode_stats_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(done_dev, was_reset_dev, lifetime_dev, reward_dev, n,
+                                                                         reinterpret_cast<unsigned long long*>(stats_dev));
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
 
 dq_status dq_replay_sample(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots, int batch,
                            const uint32_t seed[2], uint64_t t, uint32_t sample_base, int32_t* index_dev, void* stream) {
@@ -144,8 +190,10 @@ dq_status dq_td_loss_grad(const float* q_s0_dev, const int32_t* action_dev, cons
                           int n_actions, double grad_scale, float* dq_dev, float* metrics_dev, void* stream) {
     DQ_REQUIRE(q_s0_dev && action_dev && y_dev && dq_dev, DQ_ERR_INVALID, "dq_td_loss_grad: null argument");
     DQ_REQUIRE(batch >= 1 && n_actions >= 1, DQ_ERR_INVALID, "dq_td_loss_grad: bad sizes");
-    td_loss_grad_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(q_s0_dev, action_dev, index_dev, y_dev, batch, n_actions, (float)grad_scale,
-                                                             dq_dev, metrics_dev);
+    const int blocks = (batch + 3) / 4 < TD_MAX_BLOCKS ? (batch + 3) / 4 : TD_MAX_BLOCKS;
+    td_loss_grad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(q_s0_dev, action_dev, index_dev, y_dev, batch, n_actions, (float)grad_scale,
+                                                                 dq_dev, metrics_dev);
+    if (metrics_dev) td_metrics_kernel<<<1, 256, 0, (hipStream_t)stream>>>(metrics_dev, blocks, batch);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

@@ -122,8 +122,13 @@ __device__ __forceinline__ float bmap_load(const BMap& b, int k, int n, int K, i
 }
 
 __device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, float v) {
-    const int hi = n / e.PC, lo = n - hi * e.PC;
-    const size_t off = (size_t)m * e.ldo + (size_t)hi * e.s_hi + (size_t)lo * e.s_lo;
+    size_t off;
+    if (e.PC >= (1 << 30)) {
+        off = (size_t)m * e.ldo + (size_t)n * e.s_lo;            // plain row-major: no division
+    } else {
+        const int hi = n / e.PC, lo = n - hi * e.PC;
+        off = (size_t)m * e.ldo + (size_t)hi * e.s_hi + (size_t)lo * e.s_lo;
+    }
     if (e.flags & EPI_BIAS) v += e.bias[n];
     if (e.flags & EPI_RELU) v = fmaxf(v, 0.f);
     if (e.flags & EPI_DROPOUT) {

@@ -20,19 +20,28 @@
 #define BM 128
 #define BK 32
 
-// C = A_gather * B (+ epilogue).  Block = 4 waves; wave w owns rows [32w, 32w+32) x BN columns.
-template <int BN>
-__global__ __launch_bounds__(256) void gemm_fwd_kernel(Gather ga, BMap gb, Epilogue ep, int M, int N, int K) {
-    __shared__ float sA[BM][BK + 1];
+// C = A_gather * B (+ epilogue).  Block = WAVES waves; wave w owns rows [32w, 32w+32) x BN columns.
+// WAVES = 4 for the big im2col GEMMs, WAVES = 1 when M is small (dense layers) so that the grid still fills the chip.
+template <int BN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gemm_fwd_kernel(Gather ga, BMap gb, Epilogue ep, int M, int N, int K) {
+    constexpr int TBM = 32 * WAVES, NTHR = 64 * WAVES;
+    __shared__ float sA[TBM][BK + 1];
     __shared__ float sB[BK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    constexpr int A_PER = BM * BK / 256, B_PER = BK * BN / 256, NT = BN / 32;
+    const int m0 = blockIdx.x * TBM, n0 = blockIdx.y * BN;
+    constexpr int A_PER = TBM * BK / NTHR, A_STEP = NTHR / 32, B_PER = BK * BN / NTHR, B_STEP = NTHR / BN, NT = BN / 32;
 
-    // this thread stages A rows (tid>>5)+8i at column tid&31 and B rows (tid / BN)+ (256/BN) i at column tid % BN
+    // this thread stages A rows (tid>>5) + A_STEP*i at column tid&31 and B rows (tid / BN) + B_STEP*i at column tid % BN
     RowRef rows[A_PER];
+    {
+        RowIter it;
+        it.init(ga, m0 + (tid >> 5));
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) rows[i] = gather_row(ga, m0 + (tid >> 5) + 8 * i, M);
+        for (int i = 0; i < A_PER; ++i) {
+            rows[i] = it.ref(ga, m0 + (tid >> 5) + A_STEP * i < M);
+            it.advance(ga, A_STEP);
+        }
+    }
     const int acol = tid & 31, bcol = tid % BN, brow0 = tid / BN;
 
     f32x16 acc[NT];
@@ -47,15 +56,15 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(Gather ga, BMap gb, Epilo
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) ra[i] = gather_load(ga, rows[i], c);
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) rb[i] = bmap_load(gb, k0 + brow0 + (256 / BN) * i, n0 + bcol, K, N);
+        for (int i = 0; i < B_PER; ++i) rb[i] = bmap_load(gb, k0 + brow0 + B_STEP * i, n0 + bcol, K, N);
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
         __syncthreads();                       // previous tile fully consumed
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) sA[(tid >> 5) + 8 * i][acol] = ra[i];
+        for (int i = 0; i < A_PER; ++i) sA[(tid >> 5) + A_STEP * i][acol] = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) sB[brow0 + (256 / BN) * i][bcol] = rb[i];
+        for (int i = 0; i < B_PER; ++i) sB[brow0 + B_STEP * i][bcol] = rb[i];
         __syncthreads();
         if (k0 + BK < K) fetch(k0 + BK);       // next tile's global loads fly under the MFMAs
 #pragma unroll
@@ -85,7 +94,8 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(Gather ga, BMap gb, Epilo
 // Block = 4 waves; wave w owns output rows k in [k0 + 32w, k0 + 32w + 32) x BN columns.
 template <int BN>
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(Gather ga, const float* __restrict__ dz, float* __restrict__ partial,
-                                                         float* __restrict__ partial_bias, int M, int N, int K, int rows_per_slice) {
+                                                         float* __restrict__ partial_bias, int M, int N, int K, int rows_per_slice,
+                                                         size_t pstride) {
     __shared__ float sA[BK][BM + 1];           // [m][k]: read transposed by the MFMA A operand
     __shared__ float sB[BK][BN];
     __shared__ float sBias[256];
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(Gather ga, const float*
             }
         }
     }
-    float* out = partial + (size_t)slice * K * N;
+    float* out = partial + (size_t)slice * pstride;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = n0 + t * 32 + (lane & 31);
@@ -154,18 +164,31 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(Gather ga, const float*
         if (tid < BN) {
             float s = 0.f;
             for (int r = 0; r < 256 / BN; ++r) s += sBias[r * BN + tid];
-            if (n0 + tid < N) partial_bias[(size_t)slice * N + n0 + tid] = s;
+            if (n0 + tid < N) partial_bias[(size_t)slice * pstride + n0 + tid] = s;
         }
     }
 }
 
-// out[i] = sum_s partial[s][i]  (fixed order => deterministic)
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, int slices) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += partial[(size_t)k * n + i];
-    out[i] = s;
+// out[i] = sum_s partial[s * stride + i]; the slices are split over 4 thread groups whose sums are combined in a
+// fixed order => deterministic.  block = (64, 4).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int n,
+                                                              int slices, size_t stride) {
+    __shared__ float sh[4][64];
+    const int i = blockIdx.x * 64 + threadIdx.x, g = threadIdx.y;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int k = g;
+        for (; k + 12 < slices; k += 16) {
+            s0 += partial[(size_t)k * stride + i];
+            s1 += partial[(size_t)(k + 4) * stride + i];
+            s2 += partial[(size_t)(k + 8) * stride + i];
+            s3 += partial[(size_t)(k + 12) * stride + i];
+        }
+        for (; k < slices; k += 4) s0 += partial[(size_t)k * stride + i];
+    }
+    sh[g][threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < n) out[i] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // Dueling head (keras-rl dueling_type 'avg'): Q[b,a] = y[b,0] + y[b,1+a] - mean_a' y[b,1+a']
@@ -220,13 +243,26 @@ struct dq_qnet {
 };
 
 static void launch_fwd(const Gather& ga, const BMap& gb, const Epilogue& ep, int M, int N, int K, hipStream_t st) {
+    const bool small = (M + BM - 1) / BM * ((N + 63) / 64) < 256;      // too few 128-row blocks to fill 256 CUs
     if (N <= 32) {
-        dim3 grid((M + BM - 1) / BM, 1);
-        gemm_fwd_kernel<32><<<grid, 256, 0, st>>>(ga, gb, ep, M, N, K);
+        if (small) gemm_fwd_kernel<32, 1><<<dim3((M + 31) / 32, 1), 64, 0, st>>>(ga, gb, ep, M, N, K);
+        else gemm_fwd_kernel<32, 4><<<dim3((M + BM - 1) / BM, 1), 256, 0, st>>>(ga, gb, ep, M, N, K);
     } else {
-        dim3 grid((M + BM - 1) / BM, (N + 63) / 64);
-        gemm_fwd_kernel<64><<<grid, 256, 0, st>>>(ga, gb, ep, M, N, K);
+        if (small) gemm_fwd_kernel<64, 1><<<dim3((M + 31) / 32, (N + 63) / 64), 64, 0, st>>>(ga, gb, ep, M, N, K);
+        else gemm_fwd_kernel<64, 4><<<dim3((M + BM - 1) / BM, (N + 63) / 64), 256, 0, st>>>(ga, gb, ep, M, N, K);
     }
+}
+
+// split of the weight-gradient reduction over M into slices (shared by create() for workspace sizing)
+static void wgrad_slices(int M, int K, int N, int* rows_per_slice, int* slices) {
+    const int tiles = ((K + BM - 1) / BM) * ((N + 63) / 64);
+    int want = (768 + tiles - 1) / tiles;                               // aim at >= ~768 blocks
+    if (want < 1) want = 1;
+    int rows = (M + want - 1) / want;
+    rows = (rows + BK - 1) / BK * BK;
+    if (rows < 2 * BK) rows = 2 * BK;
+    *rows_per_slice = rows;
+    *slices = (M + rows - 1) / rows;
 }
 
 static Gather dense_gather(const float* src, int K) {
@@ -291,9 +327,9 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         if (floats >= (1ull << 32)) { dq_qnet_destroy(Q); dq_set_error("dq_qnet_create: activation too large for 32-bit offsets"); return DQ_ERR_UNSUPPORTED; }
         max_act = floats > max_act ? floats : max_act;
         for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&Q->act[s][i], floats * sizeof(float));
-        const size_t M = (size_t)cfg->max_batch * L.rows;
-        const size_t slices = (M + 511) / 512 < 1024 ? (M + 511) / 512 : 1024;
-        const size_t p = slices * ((size_t)L.K * L.N + L.N);
+        int rps, slices;
+        wgrad_slices(cfg->max_batch * L.rows, L.K, L.N, &rps, &slices);
+        const size_t p = (size_t)slices * ((size_t)L.K * L.N + L.N);
         max_partial = p > max_partial ? p : max_partial;
     }
     for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&Q->grad[s], max_act * sizeof(float));
@@ -426,24 +462,24 @@ dq_status dq_qnet_backward(dq_qnet* Q, const float* params_dev, const float* dq_
             ga = dense_gather(x, L.K);
             if (i == Q->cfg.n_conv) { ga.KC = Q->flat_hw; ga.KW = 1 << 30; ga.skx = 1; ga.sc = Q->flat_c; }
         }
-        int rows_per_slice = 512;
-        int slices = (M + rows_per_slice - 1) / rows_per_slice;
-        if (slices > 1024) { slices = 1024; rows_per_slice = ((M + slices - 1) / slices + BK - 1) / BK * BK; slices = (M + rows_per_slice - 1) / rows_per_slice; }
+        int rows_per_slice, slices;
+        wgrad_slices(M, L.K, L.N, &rows_per_slice, &slices);
+        const size_t pstride = (size_t)L.K * L.N + L.N;                 // per slice: kernel partial then bias partial
+        DQ_REQUIRE((size_t)slices * pstride <= Q->partial_floats, DQ_ERR_STATE, "dq_qnet_backward: workspace too small");
         float* pw = Q->partial;
-        float* pb = Q->partial + (size_t)slices * L.K * L.N;
-        DQ_REQUIRE((size_t)slices * ((size_t)L.K * L.N + L.N) <= Q->partial_floats, DQ_ERR_STATE, "dq_qnet_backward: workspace too small");
+        float* pb = Q->partial + (size_t)L.K * L.N;
         if (L.N <= 32) {
             dim3 grid((L.K + BM - 1) / BM, slices, 1);
-            gemm_wgrad_kernel<32><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice);
+            gemm_wgrad_kernel<32><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice, pstride);
         } else {
             dim3 grid((L.K + BM - 1) / BM, slices, (L.N + 63) / 64);
-            gemm_wgrad_kernel<64><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice);
+            gemm_wgrad_kernel<64><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice, pstride);
         }
         DQ_LAUNCH_CHECK();
         {
-            const int nw = L.K * L.N;
-            reduce_partials_kernel<<<(nw + 255) / 256, 256, 0, st>>>(pw, grads_dev + L.w_off, nw, slices);
-            reduce_partials_kernel<<<(L.N + 255) / 256, 256, 0, st>>>(pb, grads_dev + L.b_off, L.N, slices);
+            // bias follows the kernel in the flat buffer (b_off == w_off + K*N): one reduction covers both
+            const int nw = L.K * L.N + L.N;
+            reduce_partials_kernel<<<(nw + 63) / 64, dim3(64, 4), 0, st>>>(Q->partial, grads_dev + L.w_off, nw, slices, pstride);
             DQ_LAUNCH_CHECK();
         }
         if (i == 0) break;

@@ -11,6 +11,9 @@ from . import _lib, _philox
 from ._lib import QNetCfg, check, ptr
 
 
+TD_METRICS_FLOATS = 2050      # include/deepq_hip.h DQ_TD_METRICS_FLOATS
+
+
 def _seed_arr(seed):
     return (ctypes.c_uint32 * 2)(int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF)
 
@@ -138,7 +141,7 @@ def td_loss_grad(q_s0, action, y, grad_scale=None, index=None, dq=None, metrics=
     if dq is None:
         dq = torch.empty_like(q_s0)
     if metrics is None:
-        metrics = torch.empty(2, dtype=torch.float32, device=q_s0.device)
+        metrics = torch.empty(TD_METRICS_FLOATS, dtype=torch.float32, device=q_s0.device)
     check(_lib.lib().dq_td_loss_grad(ptr(q_s0), ptr(action), ptr(index), ptr(y), B, A, 1.0 / B if grad_scale is None else float(grad_scale),
                                      ptr(dq), ptr(metrics), _lib.current_stream(q_s0.device)))
     return dq, metrics

@@ -226,9 +226,17 @@ dq_status dq_td_target(const float* q_online_s1_dev, const float* q_target_s1_de
 /* keras-rl clipped_masked_error with delta_clip = inf:  loss = mean_b 0.5 (Q[b,a_b] - y_b)^2.
  *   dq_dev      float [batch, n_actions] = grad_scale * (Q[b,a_b] - y_b) at a_b, 0 elsewhere
  *               (grad_scale = 1 / global batch, so an all-reduce SUM of gradients gives the global mean);
- *   metrics_dev float [2] (nullable) = {loss, mean_q = mean_b max_a Q[b,a]} of this rank's minibatch. */
+ *   metrics_dev float [DQ_TD_METRICS_FLOATS] (nullable): [0] = loss, [1] = mean_q = mean_b max_a Q[b,a] of this
+ *               rank's minibatch; the rest is scratch for the fixed-order two-stage reduction. */
+#define DQ_TD_METRICS_FLOATS 2050
 dq_status dq_td_loss_grad(const float* q_s0_dev, const int32_t* action_dev, const int32_t* index_dev, const float* y_dev,
                           int batch, int n_actions, double grad_scale, float* dq_dev, float* metrics_dev, void* stream);
+
+/* Episode bookkeeping the keras-rl fork does on the host per step (episode ends, env.lifetime of finished
+ * episodes -- Single_Point_Training_Script.py:207 reads their rolling average): accumulates into uint64 stats_dev[4]
+ * = {episodes ended, sum of their lifetimes, rewards earned, lattices stepped}.  was_reset_dev nullable. */
+dq_status dq_episode_stats(const uint8_t* done_dev, const uint8_t* was_reset_dev, const uint32_t* lifetime_dev,
+                           const float* reward_dev, int n, uint64_t* stats_dev, void* stream);
 
 /* keras.optimizers.Adam (Keras 2.2): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMAs; p -= lr_t*m/(sqrt(v)+epsilon).
  * t = 1 for the first update. */
