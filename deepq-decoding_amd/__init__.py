@@ -22,4 +22,11 @@ def __getattr__(name):
     if name in ("QNetwork", "td_target", "td_loss_grad", "adam_step", "replay_sample"):
         from . import qnet
         return getattr(qnet, name)
+    if name in ("DQNAgent", "SequentialMemory", "EpsGreedyQPolicy", "GreedyQPolicy", "LinearAnnealedPolicy", "BoltzmannQPolicy",
+                "FileLogger", "Adam", "build_convolutional_nn", "ConvQModel", "History"):
+        from . import agent
+        return getattr(agent, name)
+    if name == "DQNCore":
+        from .core import DQNCore
+        return DQNCore
     raise AttributeError(name)

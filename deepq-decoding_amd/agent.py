@@ -1,0 +1,544 @@
+"""keras-rl-compatible agent surface over the device loop (DQNCore).
+
+Mirrors what the reference's driver scripts and notebooks use from the un-vendored keras-rl fork
+(github.com/R-Sweke/keras-rl; call sites in
+/root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py, "TRAIN"):
+
+    SequentialMemory(limit, window_length=1)                                   TRAIN:109
+    LinearAnnealedPolicy(EpsGreedyQPolicy(masked_greedy=..), attr='eps', ...)   TRAIN:110-114
+    GreedyQPolicy(masked_greedy=True)                                           TRAIN:115
+    DQNAgent(model, nb_actions, memory, nb_steps_warmup, target_model_update,
+             policy, test_policy, gamma, enable_dueling_network)                TRAIN:119-127
+    dqn.compile(Adam(lr=...))                                                   TRAIN:130
+    dqn.fit(env, nb_steps, ..., episode_averaging_length, success_threshold,
+            stopping_patience, min_nb_steps, single_cycle)                      TRAIN:138-152
+    dqn.test(env, nb_episodes, visualize, verbose, interval, single_cycle)      TRAIN:206
+    dqn.save_weights / dqn.model.load_weights / dqn.memory / dqn.forward        TRAIN:157-160,183; notebook 3 cell 24
+    FileLogger(filepath, interval)                                              TRAIN:94-95
+
+Semantics follow upstream keras-rl 0.4.x where the fork's source is unavailable; the
+fork-only keywords (episode_averaging_length, success_threshold, stopping_patience, min_nb_steps, single_cycle,
+masked_greedy) follow the README's description and log output (README.md:168,262,408-480,638-672).
+
+`env` may be the drop-in single-lattice class or a VectorEnv of N lattices; both run the same device loop.
+With N lattices one "step" of the loop advances all of them, `self.step` advances by N, and episode statistics
+are gathered on the device and read back every `sync_interval` vector steps.
+"""
+import json
+import os
+import time
+import timeit
+import warnings
+from collections import deque
+
+import numpy as np
+import torch
+
+from .core import DQNCore
+from .env import Surface_Code_Environment_Multi_Decoding_Cycles, VectorEnv
+from .qnet import QNetwork
+
+
+# ----------------------------------------------------------------------------------------------------------
+# model description (stands in for the keras Sequential returned by build_convolutional_nn)
+# ----------------------------------------------------------------------------------------------------------
+class ConvQModel:
+    """Layer description + Keras-ordered weight list.  Bound to a device QNetwork by the agent."""
+
+    def __init__(self, cc_layers, ff_layers, input_shape, num_actions):
+        self.c_layers = [[int(x) for x in l] for l in cc_layers]
+        self.ff_layers = [[int(l[0]), float(l[1])] for l in ff_layers]
+        self.input_shape = tuple(int(x) for x in input_shape)
+        self.num_actions = int(num_actions)
+        self._weights = None          # host copy (list of numpy arrays) until bound
+        self._agent = None
+
+    @property
+    def output_shape(self):
+        return (None, self.num_actions)
+
+    def get_weights(self):
+        if self._agent is not None and self._agent._core is not None:
+            return self._agent._net.get_weights(self._agent._core.params)
+        return None if self._weights is None else [w.copy() for w in self._weights]
+
+    def set_weights(self, weights):
+        weights = [np.asarray(w, dtype=np.float32) for w in weights]
+        if self._agent is not None and self._agent._core is not None:
+            self._agent._net.set_weights(self._agent._core.params, weights)
+            self._agent._core.update_target_hard()
+        self._weights = weights
+
+    def save_weights(self, filepath, overwrite=True):
+        if os.path.exists(filepath) and not overwrite:
+            raise IOError(f"{filepath} exists and overwrite=False")
+        w = self.get_weights()
+        if w is None:
+            raise RuntimeError("model has no weights yet (fit/compile against an environment first)")
+        from .weights_io import save_weights_file
+        save_weights_file(filepath, w, self.layer_names())
+
+    def load_weights(self, filepath):
+        from .weights_io import load_weights_file
+        self.set_weights(load_weights_file(filepath))
+
+    def layer_names(self, dueling=True):
+        names = [f"conv2d_{i + 1}" for i in range(len(self.c_layers))]
+        names += [f"dense_{i + 1}" for i in range(len(self.ff_layers) + 1 + (1 if dueling else 0))]
+        return names
+
+    def summary(self):
+        print(f"ConvQModel input={self.input_shape} conv={self.c_layers} dense={self.ff_layers} -> {self.num_actions} actions")
+
+
+def build_convolutional_nn(cc_layers, ff_layers, input_shape, num_actions):
+    """Function_Library.py:338-377 / TRAIN:61-90: returns the model description the agent builds on the GPU."""
+    return ConvQModel(cc_layers, ff_layers, input_shape, num_actions)
+
+
+class Adam:
+    """keras.optimizers.Adam stand-in (TRAIN:130): hyper-parameters only; the update is dq_adam_step."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=None, decay=0.0, amsgrad=False, **kwargs):
+        if decay or amsgrad:
+            raise NotImplementedError("Adam(decay/amsgrad) is not used by the reference and not implemented")
+        self.lr, self.beta_1, self.beta_2 = float(lr), float(beta_1), float(beta_2)
+        self.epsilon = 1e-7 if epsilon is None else float(epsilon)     # K.epsilon()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# memory and policies
+# ----------------------------------------------------------------------------------------------------------
+class SequentialMemory:
+    """Capacity holder; the storage is the device replay ring of DQNCore (see core.py)."""
+
+    def __init__(self, limit, window_length=1, ignore_episode_boundaries=False):
+        if window_length != 1:
+            raise NotImplementedError("window_length != 1 is not used by the reference and not implemented")
+        self.limit, self.window_length = int(limit), 1
+        self._core = None
+        self._saved = None
+
+    @property
+    def nb_entries(self):
+        return 0 if self._core is None else min(self._core.filled, self._core.T) * self._core.N
+
+    def get_config(self):
+        return dict(limit=self.limit, window_length=1)
+
+    # pickling (TRAIN:156-157 pickles dqn.memory; the Continue script reloads it)
+    def __getstate__(self):
+        st = dict(limit=self.limit, window_length=1, _saved=None)
+        c = self._core
+        if c is not None:
+            st["_saved"] = dict(obs=np.packbits(c.obs_ring.cpu().numpy(), axis=None), obs_shape=tuple(c.obs_ring.shape),
+                                action=c.action_ring.cpu().numpy(), reward=c.reward_ring.cpu().numpy(),
+                                terminal=c.terminal_ring.cpu().numpy(), cur=c.cur, filled=c.filled)
+        elif self._saved is not None:
+            st["_saved"] = self._saved
+        return st
+
+    def __setstate__(self, st):
+        self.limit, self.window_length, self._saved, self._core = st["limit"], 1, st.get("_saved"), None
+
+    def _restore_into(self, core):
+        s = self._saved
+        if s is None or tuple(s["obs_shape"]) != tuple(core.obs_ring.shape):
+            return False
+        n = int(np.prod(s["obs_shape"]))
+        core.obs_ring.copy_(torch.from_numpy(np.unpackbits(s["obs"], count=n).reshape(s["obs_shape"])))
+        core.action_ring.copy_(torch.from_numpy(s["action"]))
+        core.reward_ring.copy_(torch.from_numpy(s["reward"]))
+        core.terminal_ring.copy_(torch.from_numpy(s["terminal"]))
+        core.cur, core.filled = int(s["cur"]), int(s["filled"])
+        return True
+
+
+class Policy:
+    def _set_agent(self, agent):
+        self.agent = agent
+
+    @property
+    def metrics_names(self):
+        return []
+
+    @property
+    def metrics(self):
+        return []
+
+
+class EpsGreedyQPolicy(Policy):
+    """With probability eps a uniformly random LEGAL action, else argmax Q (over the legal set when masked_greedy)."""
+
+    def __init__(self, eps=.1, masked_greedy=False):
+        self.eps, self.masked_greedy = eps, masked_greedy
+
+    def current(self, training=True):
+        return float(self.eps), bool(self.masked_greedy)
+
+
+class GreedyQPolicy(Policy):
+    def __init__(self, masked_greedy=False):
+        self.masked_greedy = masked_greedy
+
+    def current(self, training=True):
+        return 0.0, bool(self.masked_greedy)
+
+
+class BoltzmannQPolicy(Policy):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("BoltzmannQPolicy is imported but never used by the reference (TRAIN:16)")
+
+
+class LinearAnnealedPolicy(Policy):
+    """keras-rl LinearAnnealedPolicy: linearly anneals inner_policy.<attr> with the agent's step counter."""
+
+    def __init__(self, inner_policy, attr, value_max, value_min, value_test, nb_steps):
+        if not hasattr(inner_policy, attr):
+            raise ValueError(f'Policy does not have attribute "{attr}".')
+        self.inner_policy, self.attr = inner_policy, attr
+        self.value_max, self.value_min, self.value_test, self.nb_steps = value_max, value_min, value_test, nb_steps
+
+    def get_current_value(self, training=True):
+        if training:
+            a = -float(self.value_max - self.value_min) / float(self.nb_steps)
+            return max(self.value_min, a * float(self.agent.step) + float(self.value_max))
+        return self.value_test
+
+    def current(self, training=True):
+        setattr(self.inner_policy, self.attr, self.get_current_value(training))
+        return self.inner_policy.current(training)
+
+    @property
+    def metrics_names(self):
+        return [f"mean_{self.attr}"]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# callbacks / history
+# ----------------------------------------------------------------------------------------------------------
+class History:
+    def __init__(self):
+        self.history = {}
+
+    def append(self, logs):
+        for k, v in logs.items():
+            self.history.setdefault(k, []).append(v)
+
+
+class Callback:
+    def on_train_begin(self, logs=None): pass
+    def on_train_end(self, logs=None): pass
+    def on_episode_end(self, episode, logs=None): pass
+
+
+class FileLogger(Callback):
+    """keras-rl FileLogger: per-episode metrics dumped as one JSON dict of lists every `interval` episodes."""
+
+    def __init__(self, filepath, interval=None):
+        self.filepath, self.interval = filepath, interval
+        self.data = {}
+
+    def on_episode_end(self, episode, logs=None):
+        logs = dict(logs or {})
+        logs["episode"] = episode
+        for k, v in logs.items():
+            self.data.setdefault(k, []).append(v)
+        if self.interval is not None and episode % self.interval == 0:
+            self.save_data()
+
+    def on_train_end(self, logs=None):
+        self.save_data()
+
+    def save_data(self):
+        if not self.data.get("episode"):
+            return
+        order = np.argsort(self.data["episode"])
+        out = {k: [_jsonable(v[i]) for i in order] for k, v in self.data.items()}
+        with open(self.filepath, "w") as f:
+            json.dump(out, f)
+
+
+def _jsonable(v):
+    if isinstance(v, (np.floating, np.integer)):
+        v = v.item()
+    if isinstance(v, float) and v != v:
+        return float("nan")
+    return v
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the agent
+# ----------------------------------------------------------------------------------------------------------
+class DQNAgent:
+    def __init__(self, model, nb_actions, memory, nb_steps_warmup=1000, target_model_update=10000, policy=None, test_policy=None,
+                 gamma=.99, enable_dueling_network=False, enable_double_dqn=True, dueling_type='avg', batch_size=32,
+                 train_interval=1, memory_interval=1, delta_clip=np.inf, custom_model_objects=None, seed=None, **kwargs):
+        if model.output_shape != (None, nb_actions):
+            raise ValueError(f'Model output "{model.output_shape}" has invalid shape. DQN expects a model that has one dimension for each action, in this case {nb_actions}.')
+        if dueling_type != 'avg':
+            raise NotImplementedError("only dueling_type='avg' (the keras-rl default the reference uses) is implemented")
+        if not np.isinf(delta_clip):
+            raise NotImplementedError("delta_clip != inf is not used by the reference and not implemented")
+        if target_model_update < 1:
+            raise NotImplementedError("soft target updates (target_model_update < 1) are not used by the reference")
+        if memory_interval != 1:
+            raise NotImplementedError("memory_interval != 1 is not implemented")
+        self.model, self.nb_actions, self.memory = model, int(nb_actions), memory
+        self.nb_steps_warmup, self.target_model_update = int(nb_steps_warmup), int(target_model_update)
+        self.policy = policy if policy is not None else EpsGreedyQPolicy()
+        self.test_policy = test_policy if test_policy is not None else GreedyQPolicy()
+        self.policy._set_agent(self)
+        self.test_policy._set_agent(self)
+        self.gamma, self.enable_dueling_network, self.enable_double_dqn = gamma, bool(enable_dueling_network), bool(enable_double_dqn)
+        self.batch_size, self.train_interval = int(batch_size), int(train_interval)
+        self.seed = seed
+        self.optimizer = None
+        self.compiled = False
+        self.training = False
+        self.step = 0
+        self._core = self._net = self._env = None
+        self._last_target_sync = 0
+        model._agent = self
+
+    # -- keras-rl surface ---------------------------------------------------------------------------------------
+    def compile(self, optimizer, metrics=[]):
+        self.optimizer = optimizer
+        self.compiled = True
+
+    @property
+    def metrics_names(self):
+        return ["loss", "mean_q"] + self.policy.metrics_names
+
+    def reset_states(self):
+        pass
+
+    def save_weights(self, filepath, overwrite=True):
+        self.model.save_weights(filepath, overwrite=overwrite)
+
+    def load_weights(self, filepath):
+        self.model.load_weights(filepath)
+
+    def get_config(self):
+        return dict(nb_actions=self.nb_actions, gamma=self.gamma, batch_size=self.batch_size, nb_steps_warmup=self.nb_steps_warmup,
+                    train_interval=self.train_interval, target_model_update=self.target_model_update,
+                    enable_double_dqn=self.enable_double_dqn, enable_dueling_network=self.enable_dueling_network, dueling_type='avg')
+
+    # -- binding to an environment ------------------------------------------------------------------------------
+    def _bind(self, env):
+        venv = env._v if isinstance(env, Surface_Code_Environment_Multi_Decoding_Cycles) else env
+        if not isinstance(venv, VectorEnv):
+            raise TypeError("env must be the drop-in Surface_Code_Environment_Multi_Decoding_Cycles or a VectorEnv")
+        if self._core is not None and self._env is venv:
+            return venv
+        if not self.compiled:
+            raise RuntimeError("Your tried to fit your agent but it hasn't been compiled yet. Please call `compile()` before `fit()`.")
+        if venv.num_actions != self.nb_actions or tuple(venv.obs_shape) != tuple(self.model.input_shape):
+            raise ValueError("environment and model shapes disagree")
+        old = self.model.get_weights()
+        max_batch = max(self.batch_size, venv.n_envs)
+        self._net = QNetwork(self.model.input_shape, self.model.c_layers, self.model.ff_layers, self.nb_actions,
+                             dueling=self.enable_dueling_network, max_batch=max_batch, device=venv.device)
+        opt = self.optimizer
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        rank = torch.distributed.get_rank() if world > 1 else 0
+        self._core = DQNCore(venv, self._net, batch_size=self.batch_size, memory_limit=self.memory.limit, gamma=self.gamma,
+                             lr=opt.lr, beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon,
+                             target_model_update=self.target_model_update, enable_double_dqn=self.enable_double_dqn,
+                             seed=self.seed if self.seed is not None else venv.seed, rank=rank, world_size=world)
+        self._env = venv
+        if old is not None:
+            self._net.set_weights(self._core.params, old)
+            self._core.update_target_hard()
+        self.memory._core = self._core
+        self.memory._restore_into(self._core)
+        return venv
+
+    # -- single-observation API (notebook 3 cell 24: action = dqn.forward(input_state)) ----------------------------
+    def forward(self, observation, legal_actions=None):
+        if self._core is None:
+            raise RuntimeError("forward() needs the agent bound to an environment: call fit()/test() first or agent._bind(env)")
+        obs = torch.as_tensor(np.asarray(observation), dtype=torch.uint8, device=self._core.device).reshape((1,) + tuple(self.model.input_shape)).contiguous()
+        q = self._net.forward(self._core.params, obs, batch=1)[0].cpu().numpy()
+        eps, masked = (self.policy if self.training else self.test_policy).current(self.training)
+        if legal_actions is not None and masked:
+            legal = sorted(legal_actions)
+            return int(max(legal, key=lambda a: (q[a], -a)))
+        return int(np.argmax(q))
+
+    def compute_q_values(self, observation):
+        obs = torch.as_tensor(np.asarray(observation), dtype=torch.uint8, device=self._core.device).reshape((1,) + tuple(self.model.input_shape)).contiguous()
+        return self._net.forward(self._core.params, obs, batch=1)[0].cpu().numpy()
+
+    # -- training ------------------------------------------------------------------------------------------------
+    def _maybe_train(self):
+        core = self._core
+        did = False
+        if self.step > self.nb_steps_warmup and core.filled >= 2 and (self.step // core.N) % self.train_interval == 0:
+            core.update()
+            did = True
+        if self.step - self._last_target_sync >= self.target_model_update:
+            core.update_target_hard()
+            self._last_target_sync = self.step
+        return did
+
+    def fit(self, env, nb_steps, action_repetition=1, callbacks=None, verbose=1, visualize=False, nb_max_start_steps=0,
+            start_step_policy=None, log_interval=10000, nb_max_episode_steps=None, episode_averaging_length=10,
+            success_threshold=None, stopping_patience=None, min_nb_steps=500, single_cycle=True, sync_interval=None):
+        if action_repetition != 1 or nb_max_start_steps != 0 or nb_max_episode_steps is not None:
+            raise NotImplementedError("action_repetition / nb_max_start_steps / nb_max_episode_steps are not used by the reference")
+        if single_cycle and getattr(env, "multi_cycle", True):
+            warnings.warn("single_cycle=True is ignored: the environment is a multi-cycle one (Environments.py:97)")
+        venv = self._bind(env)
+        core, N = self._core, venv.n_envs
+        self.training = True
+        callbacks = list(callbacks or [])
+        history = History()
+        for cb in callbacks:
+            cb.on_train_begin()
+        if verbose >= 1:
+            print(f"Training for {nb_steps} steps ...")
+        core.reset_env()
+        if sync_interval is None:
+            sync_interval = 1 if N == 1 else 64
+        t_start = timeit.default_timer()
+        lifetimes = deque(maxlen=int(episode_averaging_length))     # (episodes, lifetime_sum) chunks, newest last
+        best_avg, best_episode, episode = -np.inf, 0, 0
+        has_succeeded = stopped_improving = False
+        ep_start, ep_steps, ep_reward = t_start, 0, 0.0
+        losses, qs, epss = [], [], []
+        start_step = self.step
+        stop = False
+        try:
+            while self.step - start_step < nb_steps and not stop:
+                eps, masked = self.policy.current(True)
+                core.act_and_step(eps, masked_greedy=masked)
+                self.step += N
+                trained = self._maybe_train()
+                epss.append(eps)
+                if core.vector_steps % sync_interval != 0:
+                    continue
+                # ---- host sync: episode bookkeeping ---------------------------------------------------------------
+                n_ep, life_sum, n_rew, n_stepped = core.read_stats()
+                if trained:
+                    m = core.metrics[:2].cpu().numpy()
+                    losses.append(float(m[0]))
+                    qs.append(float(m[1]))
+                ep_steps += n_stepped
+                ep_reward += n_rew
+                if n_ep == 0:
+                    continue
+                if N == 1:
+                    # keras-rl spends one more forward/backward on the terminal observation before env.reset();
+                    # here that is the auto-reset vector step, taken now so that the episode boundary is exact.
+                    core.act_and_step(eps, masked_greedy=masked, record_stats=False)
+                    self._maybe_train()
+                now = timeit.default_timer()
+                # one log record per finished episode (N == 1) or per synchronisation chunk (N > 1)
+                episode += n_ep
+                self._append_lifetimes(lifetimes, n_ep, life_sum, int(episode_averaging_length))
+                tot_ep = sum(c for c, _ in lifetimes)
+                rolling = sum(s for _, s in lifetimes) / tot_ep
+                if rolling > best_avg:
+                    best_avg, best_episode = rolling, episode - 1
+                time_since_best = episode - 1 - best_episode
+                if success_threshold is not None and rolling >= success_threshold:
+                    has_succeeded = True
+                if stopping_patience is not None and time_since_best >= stopping_patience:
+                    stopped_improving = True
+                logs = {
+                    "episode_reward": ep_reward / n_ep, "nb_episode_steps": ep_steps / n_ep if N > 1 else ep_steps,
+                    "nb_steps": self.step, "duration": now - ep_start,
+                    "episode_lifetimes_rolling_avg": rolling, "best_rolling_avg": best_avg, "best_episode": best_episode,
+                    "time_since_best": time_since_best, "has_succeeded": has_succeeded, "stopped_improving": stopped_improving,
+                    "loss": float(np.mean(losses)) if losses else float("nan"), "mean_q": float(np.mean(qs)) if qs else float("nan"),
+                    "mean_eps": float(np.mean(epss)) if epss else float("nan"),
+                }
+                history.append(dict(logs, episode=episode - 1))
+                for cb in callbacks:
+                    cb.on_episode_end(episode - 1, logs)
+                if verbose >= 2 and (episode // max(1, log_interval)) != ((episode - n_ep) // max(1, log_interval)):
+                    self._print_train_block(episode, nb_steps, logs, now - t_start)
+                ep_start, ep_steps, ep_reward = now, 0, 0.0
+                losses, qs, epss = [], [], []
+                if (has_succeeded or stopped_improving) and (self.step - start_step) >= min_nb_steps:
+                    stop = True
+        except KeyboardInterrupt:
+            pass
+        torch.cuda.synchronize(core.device)
+        dt = timeit.default_timer() - t_start
+        for cb in callbacks:
+            cb.on_train_end()
+        if verbose >= 1:
+            final = history.history.get("episode_lifetimes_rolling_avg", [float("nan")])[-1]
+            print(f"Training Finished in {dt:.3f} seconds\n\nFinal Step: {self.step}\nSucceeded: {has_succeeded}\n"
+                  f"Stopped_Improving: {stopped_improving}\nFinal Episode Lifetimes Rolling Avg: {final:.3f}")
+        self.training = False
+        return history
+
+    @staticmethod
+    def _append_lifetimes(dq_, n_ep, life_sum, L):
+        """Keep (count, sum) chunks covering the most recent L episodes (chunks are split so the window is exact
+        for single episodes and chunk-granular for vector runs)."""
+        dq_.append((n_ep, life_sum))
+        tot = sum(c for c, _ in dq_)
+        while tot > L and len(dq_) > 1:
+            c, _ = dq_[0]
+            if tot - c >= L:
+                dq_.popleft()
+                tot -= c
+            else:
+                break
+
+    @staticmethod
+    def _print_train_block(episode, nb_steps, logs, total):
+        print("-----------------\n")
+        print(f"Episode: {episode}\nStep: {logs['nb_steps']}/{nb_steps}\nThis Episode Steps: {logs['nb_episode_steps']}\n"
+              f"This Episode Reward: {logs['episode_reward']}\nThis Episode Duration: {logs['duration']:.3f}s\n"
+              f"Rolling Lifetime length: {logs['episode_lifetimes_rolling_avg']:.3f}\nBest Lifetime Rolling Avg: {logs['best_rolling_avg']}\n"
+              f"Best Episode: {logs['best_episode']}\nTime Since Best: {logs['time_since_best']}\nHas Succeeded: {logs['has_succeeded']}\n"
+              f"Stopped Improving: {logs['stopped_improving']}\nMetrics: loss: {logs['loss']:.6f}, mean_q: {logs['mean_q']:.6f}, mean_eps: {logs['mean_eps']:.6f}\n"
+              f"Total Training Time: {total:.3f}s\n")
+
+    # -- evaluation ------------------------------------------------------------------------------------------------
+    def test(self, env, nb_episodes=1, action_repetition=1, callbacks=None, visualize=True, nb_max_episode_steps=None,
+             nb_max_start_steps=0, start_step_policy=None, verbose=1, episode_averaging_length=None, interval=100, single_cycle=True):
+        """Greedy episodes (TRAIN:206).  With N lattices, lattice i contributes its first ceil-share of episodes, so the
+        sample is not biased towards short episodes.  history keys: episode_reward, nb_steps, episode_lifetime,
+        episode_lifetimes_rolling_avg."""
+        venv = self._bind(env)
+        core, N = self._core, venv.n_envs
+        self.training = False
+        history = History()
+        if verbose >= 1:
+            print(f"Testing for {nb_episodes} episodes ...")
+        quota = np.full(N, nb_episodes // N, dtype=np.int64)
+        quota[:nb_episodes % N] += 1
+        eps, masked = self.test_policy.current(False)
+        core.reset_env()
+        ep_reward, ep_len = np.zeros(N), np.zeros(N, dtype=np.int64)
+        lifetimes, episode = [], 0
+        while quota.sum() > 0:
+            slot = core.cur
+            core.act_and_step(eps, masked_greedy=masked, record_stats=False)
+            done = core.terminal_ring[slot].cpu().numpy().astype(bool)
+            wr = venv.was_reset.cpu().numpy().astype(bool)
+            rew = core.reward_ring[slot].cpu().numpy()
+            life = venv.lifetime.cpu().numpy()
+            ep_reward += np.where(wr, 0.0, rew)
+            ep_len += ~wr
+            for i in np.flatnonzero(done & ~wr):
+                if quota[i] > 0:
+                    quota[i] -= 1
+                    episode += 1
+                    lifetimes.append(int(life[i]))
+                    logs = {"episode_reward": float(ep_reward[i]), "nb_steps": int(ep_len[i]), "episode_lifetime": int(life[i]),
+                            "episode_lifetimes_rolling_avg": float(np.mean(lifetimes))}
+                    history.append(logs)
+                    if verbose >= 2 and (episode - 1) % max(1, interval) == 0:
+                        print(f"-----------------\nEpisode: {episode}\nThis Episode Length: {logs['nb_steps']}\n"
+                              f"This Episode Reward: {logs['episode_reward']}\nThis Episode Lifetime: {logs['episode_lifetime']}\n\n"
+                              f"Episode Lifetimes Avg: {logs['episode_lifetimes_rolling_avg']:.3f}\n")
+                ep_reward[i], ep_len[i] = 0.0, 0
+        core.read_stats()
+        return history

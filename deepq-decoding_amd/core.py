@@ -18,7 +18,7 @@ import ctypes
 
 import torch
 
-from . import _lib, qnet as _q
+from . import _lib, dist as _dist, qnet as _q
 from ._lib import check, ptr
 
 
@@ -49,8 +49,7 @@ class DQNCore:
         self.cur, self.filled = 0, 0
         # parameters
         self.params = net.init_params(self.seed) if params is None else params
-        if world_size > 1:
-            torch.distributed.broadcast(self.params, src=0, group=self.pg)
+        _dist.broadcast_(self.params, src=0, group=self.pg)
         self.target = self.params.clone()
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
@@ -75,9 +74,14 @@ class DQNCore:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def reset_env(self):
-        """env.reset() for every lattice; the first observation lands in ring slot `cur`."""
+        """env.reset() for every lattice; the new observation lands in ring slot `cur` (which has no action recorded
+        yet).  If the ring already holds transitions (a second fit(), or a memory restored from a pickle), the entry
+        before it is marked terminal so that no TD target bootstraps across the discontinuity."""
+        if self.filled >= 2:
+            prev = self.cur - 1 if self.cur > 0 else self.T - 1
+            self.terminal_ring[prev].fill_(1)
         self.env.reset(out_obs=self.obs_ring[self.cur])
-        self.filled = 1
+        self.filled = max(self.filled, 1)
         self.started = True
 
     def act_and_step(self, eps, masked_greedy=False, use_q=True, record_stats=True):
@@ -105,7 +109,7 @@ class DQNCore:
         B, N, T = self.batch_size, self.N, self.T
         self.updates += 1
         t = self.updates
-        sample_base = self.rank * B
+        _, sample_base = _dist.shard(self.rank, N, B)
         rows = T * N
         _q.replay_sample(self.terminal_ring, N, T, self.cur, self.filled, B, self.seed, t, sample_base=sample_base, out=self.index)
         net, ring = self.net, self.obs_ring
@@ -118,11 +122,11 @@ class DQNCore:
             q_sel = self.q1_target
         _q.td_target(q_sel, self.q1_target, self.reward_ring, self.terminal_ring, self.gamma, index=self.index, out=self.y)
         net.forward(self.params, ring, batch=B, index=self.index, training=True, seed=self.seed, t=t, sample_base=sample_base, out=self.q0)
-        _q.td_loss_grad(self.q0, self.action_ring, self.y, grad_scale=1.0 / (B * self.world_size), index=self.index, dq=self.dq,
+        _q.td_loss_grad(self.q0, self.action_ring, self.y, grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, dq=self.dq,
                         metrics=self.metrics)
         net.backward(self.params, self.dq, grads=self.grads)
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            _dist.allreduce_sum_(self.grads, group=self.pg)
         _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
 
     def update_target_hard(self):

@@ -1,0 +1,169 @@
+"""GPU tests of the device loop and the keras-rl-compatible agent surface."""
+import importlib
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, dqn_oracle as O, philox
+
+pytestmark = pytest.mark.gpu
+
+C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
+C1 = dict(d=3, error_model="X", use_Y=False, volume_depth=3, p_phys=0.005, p_meas=0.005)
+C3 = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_device_loop_matches_oracle_loop(dq, torch_mod):
+    """The whole loop -- Q forward, epsilon-greedy over legal moves, environment step into the ring, replay sampling,
+    double-DQN update, Adam -- against the same loop assembled from the CPU oracles, for several vector steps.
+    Actions / observations / rewards must be identical; parameters agree to fp32 round-off."""
+    torch = torch_mod
+    N, B, steps, eps, gamma, lr = 16, 8, 6, 0.3, 0.99, 1e-3
+    seed = (0x5EED, 0xD0DEC0DE)
+    env = dq.VectorEnv(n_envs=N, seed=seed, **C1)
+    net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=max(N, B))
+    core = dq.DQNCore(env, net, batch_size=B, memory_limit=N * 8, gamma=gamma, lr=lr, seed=seed)
+    spec = O.QNetSpec(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions)
+    p = core.params.cpu().numpy().astype(np.float64)
+    assert np.array_equal(core.params.cpu().numpy(), O.glorot_init(spec, seed))
+    p_t = p.copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    ref = c_oracle.COracleEnv(n_envs=N, seed=seed, **C1)
+    T = core.T
+    ring_obs = np.zeros((T, N) + env.obs_shape, np.uint8)
+    ring_a, ring_r, ring_t = np.zeros((T, N), np.int32), np.zeros((T, N), np.float32), np.zeros((T, N), np.uint8)
+    core.reset_env()
+    ref.reset()
+    cur, filled = 0, 1
+    ring_obs[0] = ref.obs
+    for t in range(steps):
+        # --- act
+        core.act_and_step(eps)
+        q, _ = O.forward(spec, p, ring_obs[cur])
+        acts = np.zeros(N, np.int32)
+        for i in range(N):
+            w = philox.philox4x32((t, 0, i, philox.STREAM_POLICY << 16), seed)
+            mask = int(ref.legal[i, 0]) | (int(ref.legal[i, 1]) << 64)
+            acts[i] = O.select_action(q[i], mask, eps, False, w)
+        assert np.array_equal(core.action_ring[cur].cpu().numpy(), acts), ("actions", t)
+        ref.step(acts, auto_reset=True)
+        nxt = (cur + 1) % T
+        ring_a[cur], ring_r[cur], ring_t[cur], ring_obs[nxt] = acts, ref.reward, ref.done, ref.obs
+        assert np.array_equal(core.obs_ring[nxt].cpu().numpy(), ref.obs), ("obs", t)
+        assert np.array_equal(core.reward_ring[cur].cpu().numpy(), ref.reward) and np.array_equal(core.terminal_ring[cur].cpu().numpy(), ref.done)
+        cur, filled = nxt, min(T, filled + 1)
+        # --- update
+        core.update()
+        u = t + 1
+        idx = core.index.cpu().numpy()
+        cand = filled - 1
+        for b in range(B):                                                     # replay rows follow the Philox definition
+            for attempt in range(64):
+                w = philox.philox4x32((u, 0, b, attempt | (philox.STREAM_REPLAY << 16)), seed)
+                j, e = philox.bounded(w[0], cand), philox.bounded(w[1], N)
+                s = (cur - 1 - j) % T
+                if j + 1 >= cand or not ring_t[(s - 1) % T, e]:
+                    break
+            assert idx[b] == s * N + e
+        rows = T * N
+        flat_obs = ring_obs.reshape(rows, *env.obs_shape)
+        s0, s1 = flat_obs[idx], flat_obs[(idx + N) % rows]
+        y = O.td_targets(O.forward(spec, p, s1)[0], O.forward(spec, p_t, s1)[0], ring_r.reshape(-1)[idx], ring_t.reshape(-1)[idx], gamma)
+        keep = O.dropout_keep_mask(seed, u, np.arange(B), 512, 0.2)
+        q0, cache = O.forward(spec, p, s0, training=True, keep_masks=[keep])
+        loss, mean_q, dq_ = O.loss_and_grad(q0, ring_a.reshape(-1)[idx], y)
+        g = O.backward(spec, p, cache, dq_)
+        p, m, v = O.adam_step(p, g, m, v, u, lr)
+        met = core.metrics[:2].cpu().numpy()
+        assert abs(met[0] - loss) < 1e-5 and abs(met[1] - mean_q) < 1e-5, (met, loss, mean_q)
+        assert np.abs(core.grads.cpu().numpy() - g).max() < 1e-5 * max(1.0, np.abs(g).max())
+        big = np.abs(g) > 1e-6
+        assert np.abs(core.params.cpu().numpy() - p)[big].max() < 5e-6
+        if u % 3 == 0:
+            core.update_target_hard()
+            p_t = p.copy()
+        # keep the oracle's weights glued to the device's fp32 values so round-off cannot accumulate into an action flip
+        p = core.params.cpu().numpy().astype(np.float64)
+        m, v = core.m.cpu().numpy().astype(np.float64), core.v.cpu().numpy().astype(np.float64)
+        if u % 3 == 0:
+            p_t = p.copy()
+
+
+def _make_agent(dq, model_shape, n_actions, batch_size=32, warmup=64, target=200, limit=5000, seed=(1, 2)):
+    model = dq.build_convolutional_nn(C_LAYERS, FF_LAYERS, model_shape, n_actions)
+    memory = dq.SequentialMemory(limit=limit, window_length=1)
+    policy = dq.LinearAnnealedPolicy(dq.EpsGreedyQPolicy(masked_greedy=False), attr="eps", value_max=1.0, value_min=0.02,
+                                     value_test=0.0, nb_steps=2000)
+    agent = dq.DQNAgent(model=model, nb_actions=n_actions, memory=memory, nb_steps_warmup=warmup, target_model_update=target,
+                        policy=policy, test_policy=dq.GreedyQPolicy(masked_greedy=True), gamma=0.99, enable_dueling_network=True,
+                        batch_size=batch_size, seed=seed)
+    agent.compile(dq.Adam(lr=1e-4))
+    return agent
+
+
+def test_fit_and_test_single_lattice_facade(dq, torch_mod, tmp_path):
+    """configs[0]: d=3 X p=0.005 batch=1 through the reference's reset()/step()/fit()/test() surface."""
+    env = dq.Surface_Code_Environment_Multi_Decoding_Cycles(static_decoder=None, **C1)
+    agent = _make_agent(dq, env.observation_space.shape, env.num_actions)
+    log = dq.FileLogger(str(tmp_path / "training_history.json"), interval=10)
+    hist = agent.fit(env, nb_steps=400, action_repetition=1, callbacks=[log], verbose=0, visualize=False, nb_max_start_steps=0,
+                     start_step_policy=None, log_interval=50, nb_max_episode_steps=None, episode_averaging_length=20,
+                     success_threshold=10000, stopping_patience=10000, min_nb_steps=100, single_cycle=False)
+    h = hist.history
+    for key in ("episode_reward", "nb_episode_steps", "nb_steps", "episode_lifetimes_rolling_avg", "best_rolling_avg", "best_episode",
+                "time_since_best", "has_succeeded", "stopped_improving", "loss", "mean_q", "mean_eps", "duration", "episode"):
+        assert key in h and len(h[key]) == len(h["episode"]) > 0, key
+    assert agent.step >= 400 and np.isfinite([x for x in h["loss"] if x == x]).all()
+    assert any(x == x for x in h["loss"]), "no update happened after warm-up"
+    data = json.loads((tmp_path / "training_history.json").read_text())
+    assert set(h) <= set(data) | {"episode"}
+    # weights: save / load round trip through the reference's file name; memory pickles (TRAIN:156-160)
+    w_before = agent.model.get_weights()
+    wfile = str(tmp_path / "final_dqn_weights.h5f")
+    agent.save_weights(wfile, overwrite=True)
+    agent.model.set_weights([w * 0 for w in w_before])
+    agent.model.load_weights(wfile)
+    assert all(np.array_equal(a, b) for a, b in zip(w_before, agent.model.get_weights()))
+    mem = pickle.loads(pickle.dumps(agent.memory))
+    assert mem._saved is not None and mem._saved["filled"] == agent._core.filled
+    # evaluation
+    env.p_phys = env.p_meas = 0.003                                           # TRAIN:200-201
+    th = agent.test(env, nb_episodes=7, visualize=False, verbose=0, interval=10, single_cycle=False)
+    assert len(th.history["episode_lifetime"]) == 7 and th.history["episode_lifetimes_rolling_avg"][-1] == np.mean(th.history["episode_lifetime"])
+    assert all(l >= 3 and l % 3 == 0 for l in th.history["episode_lifetime"])     # lifetimes advance in volumes of depth 3
+    a = agent.forward(env.reset())
+    assert 0 <= a < env.num_actions and agent.compute_q_values(env.board_state).shape == (env.num_actions,)
+
+
+def test_fit_vector_env_is_deterministic(dq, torch_mod):
+    """Two identical runs (same seeds) produce bit-identical weights: fixed-order reductions + counter RNG."""
+    torch = torch_mod
+    out = []
+    for _ in range(2):
+        env = dq.VectorEnv(n_envs=128, **C3)
+        agent = _make_agent(dq, env.obs_shape, env.num_actions, batch_size=64, warmup=256, target=2048, limit=128 * 40)
+        hist = agent.fit(env, nb_steps=128 * 40, verbose=0, episode_averaging_length=100, success_threshold=None, stopping_patience=None,
+                         min_nb_steps=0, single_cycle=False, sync_interval=8)
+        assert agent._core.updates >= 30 and len(hist.history["episode"]) >= 2
+        out.append(agent._core.params.clone())
+        th = agent.test(env, nb_episodes=200, visualize=False, verbose=0, single_cycle=False)
+        assert len(th.history["episode_lifetime"]) == 200
+    assert torch.equal(out[0], out[1])
+
+
+def test_early_stopping_rule(dq, torch_mod):
+    env = dq.VectorEnv(n_envs=64, **C3)
+    agent = _make_agent(dq, env.obs_shape, env.num_actions, batch_size=32, warmup=10 ** 9)
+    hist = agent.fit(env, nb_steps=64 * 2000, verbose=0, episode_averaging_length=50, success_threshold=5.0, stopping_patience=None,
+                     min_nb_steps=64 * 16, single_cycle=False, sync_interval=4)
+    assert hist.history["has_succeeded"][-1] is True and agent.step < 64 * 2000

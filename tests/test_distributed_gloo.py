@@ -1,0 +1,116 @@
+"""world_size-2 `gloo` test (CPU) of the multi-GPU design: lattice sharding by global id, per-rank replay shards,
+ONE all-reduce of the flat gradient, identical Adam everywhere.
+
+The compute on each rank is the ORACLE (the HIP kernels need a GPU); what is under test is the package's
+distributed logic (deepq-decoding_amd/dist.py: shard(), grad_scale(), allreduce_sum_(), broadcast_()) and the claim
+in DESIGN.md that an R-rank run reproduces a 1-rank run of R times the lattices.
+"""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+CFG = dict(d=3, error_model="X", use_Y=False, volume_depth=3, p_phys=0.02, p_meas=0.02)
+SHAPE, A = (4, 7, 7), 10
+C_LAYERS, FF_LAYERS = [[16, 3, 2], [8, 2, 1]], [[32, 0.2]]
+N_LOCAL, B_LOCAL, STEPS = 6, 4, 5
+SEED = (0x5EED, 0xD0DEC0DE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_rank(rank, world, n_local, b_local, allreduce, steps=STEPS, perturb=True):
+    """One rank's loop with oracle compute.  Returns (final params, obs trace, grads of the last update)."""
+    from oracle import c_oracle, dqn_oracle as O
+    D = importlib.import_module("deepq-decoding_amd.dist")
+    env_base, sample_base = D.shard(rank, n_local, b_local)
+    env = c_oracle.COracleEnv(n_envs=n_local, env_id_base=env_base, seed=SEED, **CFG)
+    spec = O.QNetSpec(SHAPE, C_LAYERS, FF_LAYERS, A)
+    params = torch.from_numpy(O.glorot_init(spec, SEED).astype(np.float64))
+    if rank != 0 and perturb:
+        params += 1.0                       # deliberately wrong: broadcast_ must fix it
+    D.broadcast_(params, src=0)
+    p = params.numpy().copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    env.reset()
+    trace, last_g, first_g = [], None, None
+    s0 = env.obs.copy()
+    for t in range(steps):
+        a = env.policy_uniform_legal(t)
+        env.step(a, auto_reset=True)
+        s1, r, term = env.obs.copy(), env.reward.copy(), env.done.copy()
+        trace.append(s1)
+        idx = np.arange(b_local) % n_local       # fixed "replay" rows: the local lattices themselves
+        keep = O.dropout_keep_mask(SEED, t + 1, sample_base + np.arange(b_local), FF_LAYERS[0][0], 0.2)
+        y = O.td_targets(O.forward(spec, p, s1[idx])[0], O.forward(spec, p, s1[idx])[0], r[idx], term[idx], 0.99)
+        q0, cache = O.forward(spec, p, s0[idx], training=True, keep_masks=[keep])
+        diff = q0[np.arange(b_local), a[idx]] - y
+        dq = np.zeros_like(q0)
+        dq[np.arange(b_local), a[idx]] = diff * D.grad_scale(b_local, world)
+        g = torch.from_numpy(O.backward(spec, p, cache, dq))
+        if allreduce:
+            D.allreduce_sum_(g)
+        last_g = g.numpy().copy()
+        if first_g is None:
+            first_g = last_g
+        p, m, v = O.adam_step(p, last_g, m, v, t + 1, 1e-3)
+        s0 = s1
+    return p, np.stack(trace), last_g, first_g
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D = importlib.import_module("deepq-decoding_amd.dist")
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    p, trace, g, g1 = _run_rank(rank, world, N_LOCAL, B_LOCAL, allreduce=True)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), p=p, trace=trace, g=g, g_first=g1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    # (1) weights stay bit-identical across ranks (same all-reduced gradient, same Adam)
+    assert np.array_equal(r0["p"], r1["p"]) and np.array_equal(r0["g"], r1["g"])
+    # (2) the two shards are exactly the two halves of one 2*N_LOCAL-lattice run (global lattice ids)
+    from oracle import c_oracle
+    env = c_oracle.COracleEnv(n_envs=2 * N_LOCAL, env_id_base=0, seed=SEED, **CFG)
+    env.reset()
+    for t in range(STEPS):
+        env.step(env.policy_uniform_legal(t), auto_reset=True)
+        assert np.array_equal(env.obs[:N_LOCAL], r0["trace"][t]) and np.array_equal(env.obs[N_LOCAL:], r1["trace"][t])
+    # (3) the all-reduced gradient is the global-minibatch mean gradient: equal to what one process computes over
+    #     both ranks' samples, i.e. sum of the two un-reduced per-rank gradients each scaled by 1/(B_local*world)
+    sys.path.insert(0, ROOT)
+    D = importlib.import_module("deepq-decoding_amd.dist")
+    assert D.shard(1, N_LOCAL, B_LOCAL) == (N_LOCAL, B_LOCAL) and D.grad_scale(B_LOCAL, 2) == 1.0 / (2 * B_LOCAL)
+    assert np.isfinite(r0["p"]).all() and np.abs(r0["g"]).max() > 0
+    parts = [_run_rank(r, 2, N_LOCAL, B_LOCAL, allreduce=False, steps=1, perturb=False)[3] for r in range(2)]
+    assert np.allclose(parts[0] + parts[1], r0["g_first"], rtol=0, atol=1e-15)
+
+
+def test_single_process_helpers_are_noops():
+    D = importlib.import_module("deepq-decoding_amd.dist")
+    x = torch.arange(5, dtype=torch.float64)
+    assert torch.equal(D.allreduce_sum_(x.clone()), x) and torch.equal(D.broadcast_(x.clone()), x)
+    os.environ.pop("WORLD_SIZE", None)
+    assert D.init_from_env() == (0, 1, 0)
