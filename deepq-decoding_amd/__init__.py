@@ -26,6 +26,9 @@ def __getattr__(name):
                 "FileLogger", "Adam", "build_convolutional_nn", "ConvQModel", "History"):
         from . import agent
         return getattr(agent, name)
+    if name in ("dist", "hdf5_reader", "weights_io", "function_library"):
+        import importlib
+        return importlib.import_module("." + name, __name__)
     if name == "DQNCore":
         from .core import DQNCore
         return DQNCore

@@ -167,3 +167,24 @@ def test_early_stopping_rule(dq, torch_mod):
     hist = agent.fit(env, nb_steps=64 * 2000, verbose=0, episode_averaging_length=50, success_threshold=5.0, stopping_patience=None,
                      min_nb_steps=64 * 16, single_cycle=False, sync_interval=4)
     assert hist.history["has_succeeded"][-1] is True and agent.step < 64 * 2000
+
+
+def test_shipped_keras_agent_decodes(dq, torch_mod):
+    """Behavioural pin of the Q-network semantics (HWIO kernels, channels_first Flatten, dueling head, masked greedy
+    test policy) against the REFERENCE'S OWN trained agent: tests/golden/keras_weights_d5_dp_0.007.npz holds the tensors
+    of trained_models/d5_dp/0.007/final_dqn_weights.h5f.  The reference reports mean lifetimes 270.4 @ p=0.007 and
+    81.2 @ p=0.011 for it (all_results.p; its NN referee, 101 episodes); a uniformly random legal policy lives ~20.
+    With the look-up referee the numbers differ somewhat, so the bounds are loose but far from random."""
+    from conftest import load_golden
+    fx = load_golden("keras_weights_d5_dp_0.007")
+    weights = [fx[f"w{i}"] for i in range(12)]
+    res = {}
+    for p in (0.011, 0.007):
+        env = dq.VectorEnv(n_envs=1024, **dict(C3, p_phys=p, p_meas=p))
+        agent = _make_agent(dq, env.obs_shape, env.num_actions)
+        agent._bind(env)
+        agent.model.set_weights(weights)
+        th = agent.test(env, nb_episodes=1024, visualize=False, verbose=0, single_cycle=False)
+        res[p] = float(np.mean(th.history["episode_lifetime"]))
+    print("shipped agent mean lifetimes:", res)
+    assert 45 < res[0.011] < 160 and 140 < res[0.007] < 520 and res[0.007] > 2 * res[0.011]

@@ -163,3 +163,22 @@ def test_dropin_module_tree():
         assert all(callable(x) for x in (DQNAgent, FileLogger, SequentialMemory, EpsGreedyQPolicy, GreedyQPolicy, LinearAnnealedPolicy, BoltzmannQPolicy))
     finally:
         sys.path.pop(0)
+
+
+REF_H5 = "/root/reference/trained_models/d5_dp/0.007/final_dqn_weights.h5f"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_H5), reason="reference checkout not present (GPU box)")
+def test_hdf5_reader_on_shipped_keras_weights():
+    """The pure-Python HDF5 reader returns the shipped agent's tensors in Keras order with the shapes SURVEY.md §8a-D1
+    lists; the committed fixture tests/golden/keras_weights_d5_dp_0.007.npz is exactly this file's content."""
+    h = importlib.import_module("deepq-decoding_amd.hdf5_reader")
+    w = h.read_keras_weights(REF_H5)
+    assert [x.shape for x in w] == [(3, 3, 7, 64), (64,), (2, 2, 64, 32), (32,), (2, 2, 32, 32), (32,), (288, 512), (512,),
+                                    (512, 51), (51,), (51, 52), (52,)]
+    fx = load_golden("keras_weights_d5_dp_0.007")
+    assert all(np.array_equal(fx[f"w{i}"], w[i]) for i in range(12))
+    wio = importlib.import_module("deepq-decoding_amd.weights_io")
+    assert all(np.array_equal(a, b) for a, b in zip(wio.load_weights_file(REF_H5), w))
+    names = sorted(h.read_datasets(REF_H5))
+    assert names[0] == "/conv2d_1/conv2d_1/bias:0" and names[-1] == "/dense_3/dense_3_1/kernel:0"
