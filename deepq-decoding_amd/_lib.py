@@ -64,6 +64,8 @@ SIGNATURES = {
     "dq_qnet_num_layers": (_i, [_vp]),
     "dq_qnet_layer_info": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                 ctypes.POINTER(ctypes.c_int32 * 4), ctypes.POINTER(ctypes.c_int32)]),
+    "dq_qnet_set_fused": (_i, [_vp, _i]),
+    "dq_qnet_fused_supported": (_i, [_vp]),
     "dq_qnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
     "dq_qnet_backward": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dq_replay_sample": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
@@ -71,6 +73,10 @@ SIGNATURES = {
     "dq_td_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _vp, _vp, _vp]),
     "dq_episode_stats": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dq_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
+    "dq_prof_kernel_count": (_i, []),
+    "dq_prof_kernel_name": (ctypes.c_char_p, [_i]),
+    "dq_prof_arm": (_i, [_i, _i]),
+    "dq_prof_collect": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_dbl)]),
 }
 
 _lib = None

@@ -536,7 +536,9 @@ static dq_status launch_env(dq_env* E, EnvParams& p, hipStream_t st) {
     p.T_phys = E->T_phys; p.T_meas = E->T_meas;
     const int blocks = (p.n_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     const size_t lds = ENVS_PER_BLOCK * DQ_MAX_DEPTH * 8 + 3 * 256 + (size_t)ENVS_PER_BLOCK * ((p.obs_size + 3) & ~3);
+    dq_prof_begin(DQ_K_ENV, st);
     env_kernel<<<blocks, 256, lds, st>>>(p);
+    dq_prof_end(DQ_K_ENV, st);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

@@ -1,0 +1,554 @@
+// Fused forward of the convolutional Q-network: two launches per forward, activations never leave the CU inside a chain.
+//
+// Same arithmetic as the per-layer path in qnet.hip (Keras model of build_convolutional_nn,
+// /root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:61-90, + keras-rl dueling head), laid out
+// for MI355X.  The network is tiny per sample (0.89 MFLOP and ~12 KB of activations at d=5), so a per-layer GEMM launch
+// is dominated by prologue, epilogue and HBM round trips.  f32-input MFMA is the bound (64 FLOP/clk/SIMD): one
+// v_mfma_f32_16x16x4_f32 occupies its SIMD for 32 cycles, so the kernels are organised to issue NOTHING but MFMAs and a
+// trickle of wide LDS reads in their inner loops:
+//
+//   conv_chain_kernel   workgroup = 4 waves = S samples (2 workgroups per CU).  uint8 observation rows (optionally
+//                       gathered from the replay ring) and every convolution's output live in LDS.  Each layer is an
+//                       im2col GEMM whose B operand -- the layer's whole weight matrix for the wave's columns -- is held
+//                       STATIONARY IN REGISTERS (<= 128 VGPRs) and whose A operand is one ds_read_b128 per four MFMA
+//                       k-steps, read straight out of the previous layer's LDS image.
+//   dense_chain_kernel  workgroup = 8 waves = 16 samples.  Flatten permutation, Dense(512)+ReLU(+Philox dropout) with
+//                       the weights streamed from L2 as float4 rows, double-buffered in registers; Dense(|A|) split over
+//                       K across the 8 waves and reduced in fixed order through LDS; the dueling layer and combination.
+//
+// Two index tricks make every operand access wide.  (1) The four k's of one MFMA need not be consecutive: lane (kq, i)
+// reads A[i][k0+4kq .. k0+4kq+3] as ONE float4 and MFMA s of the group consumes component s, i.e. covers
+// k in {k0+4kq+s}; B registers are loaded to match.  (2) The 16 columns of an MFMA tile need not be consecutive: with NT
+// tiles per wave, tile t lane j is column c0 + NT*j + t, so one float4/float2 load of a weight row feeds NT tiles and a
+// lane ends up owning NT consecutive output columns of a row -> vector stores.
+// The k order inside a dot product therefore differs from the per-layer kernels (both are exact-f32 fmaf chains, in
+// different orders): the two paths agree to f32 round-off, not bit for bit; each is deterministic.
+// Training forwards additionally write every layer's output to HBM in the layout qnet.hip's backward expects.
+#include "qnet.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define CONV_THREADS 256
+#define CONV_WAVES 4
+#define CONV_LDS_2PER_CU (80 * 1024)
+#define CONV_LDS_MAX (160 * 1024)
+#define DENSE_THREADS 512
+#define DENSE_WAVES 8
+#define DENSE_ROWS 16
+#define DENSE_HID 512                 // Dense(512): 8 waves x 64 columns; Dense(|A|) splits K = 512 into 8 x 64
+
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvChainArgs {
+    const float* params;
+    const u8* obs;
+    const int32_t* index;
+    int index_off, index_mod;
+    int batch, S;
+    int C, H, W, k1, st1, K1;          // first convolution: input planes, kernel, stride, K = k1*k1*C
+    int oh1, ow1, oh2, ow2, oh3, ow3;
+    int w_off[3], b_off[3];            // floats into params
+    float* act_out[3];                 // global NHWC [batch*oh*ow, cout]; [2] always written
+    int write_all;                     // training: write every layer
+    int slot;                          // bytes per sample slot in LDS (multiple of 4, >= C*H*W + 3)
+    int off_mis, off_a1, off_a2;       // LDS byte offsets (observations at 0)
+};
+
+// One stride-1 convolution whose input is an LDS image [pixel][CIN + 4] and whose weights sit in registers.
+// Each wave takes pairs of 16-row tiles (4 accumulators in flight).
+template <int CIN, int COUT, int KS>
+__device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int ih, int iw, int oh, int ow, int M,
+                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                              float* __restrict__ out_lds, float* __restrict__ out_g, int wave, int lane) {
+    constexpr int NT = COUT / 16, PSI = CIN + 4, PSO = COUT + 4, CG = CIN / 16, KG = KS * KS * CG;
+    static_assert(NT == 2, "column interleave below is written for two tiles");
+    const int j = lane & 15, kq = lane >> 4;
+    f32x2 b[KG][4];
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[g][s] = *reinterpret_cast<const f32x2*>(w + (size_t)(16 * g + 4 * kq + s) * COUT + 2 * j);
+    const f32x2 bias2 = *reinterpret_cast<const f32x2*>(bias + 2 * j);
+    const int rows = oh * ow, tiles = (M + 15) >> 4;
+    for (int t0 = 2 * wave; t0 < tiles; t0 += 2 * CONV_WAVES) {
+        const bool two = t0 + 1 < tiles;                            // wave-uniform
+        int abase[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int m = (t0 + u) * 16 + j;
+            if (m >= M) m = M - 1;                                  // padding rows recompute the last row; never stored
+            const int s = m / rows, pix = m - s * rows, oy = pix / ow, ox = pix - oy * ow;
+            abase[u] = ((s * ih + oy) * iw + ox) * PSI + 4 * kq;
+        }
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const int kyx = g / CG, c16 = g - kyx * CG, ky = kyx / KS, kx = kyx - ky * KS;
+            const int off = (ky * iw + kx) * PSI + 16 * c16;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(in + abase[0] + off);
+            f32x4 a1 = a0;
+            if (two) a1 = *reinterpret_cast<const f32x4*>(in + abase[1] + off);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[0][t] = MFMA16(a0[s], b[g][s][t], acc[0][t]);
+                if (two) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[1][t] = MFMA16(a1[s], b[g][s][t], acc[1][t]);
+                }
+            }
+        }
+        // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg; this lane owns columns 2j, 2j+1
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mo = (t0 + u) * 16 + 4 * kq + r;
+                if (mo >= M) continue;
+                f32x2 v = {fmaxf(acc[u][0][r] + bias2[0], 0.f), fmaxf(acc[u][1][r] + bias2[1], 0.f)};
+                if (out_lds) *reinterpret_cast<f32x2*>(out_lds + mo * PSO + 2 * j) = v;
+                if (out_g) *reinterpret_cast<f32x2*>(out_g + (size_t)mo * COUT + 2 * j) = v;
+            }
+        }
+    }
+}
+
+template <int KG1>      // first convolution's K padded to 16 * KG1
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u8* s_in = smem;
+    int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);
+    float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1);
+    float* s_a2 = reinterpret_cast<float*>(smem + a.off_a2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int b0 = blockIdx.x * a.S;
+    const int ns = min(a.S, a.batch - b0);
+    const int in_bytes = a.C * a.H * a.W;
+
+    // ---- first convolution's weights -> registers (the loads fly while the observations are staged) ----------------
+    const float* w1 = a.params + a.w_off[0];
+    f32x4 b1[KG1][4];
+    int ko[KG1][4];
+#pragma unroll
+    for (int g = 0; g < KG1; ++g)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * g + 4 * kq + s;
+            const bool valid = k < a.K1;
+            b1[g][s] = valid ? *reinterpret_cast<const f32x4*>(w1 + (size_t)k * 64 + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int t = k / a.C, c = k - t * a.C, ky = t / a.k1, kx = t - ky * a.k1;      // Keras HWIO: k = (ky*k1 + kx)*C + c
+            ko[g][s] = valid ? c * a.H * a.W + ky * a.W + kx : 0;                           // NCHW uint8 observation
+        }
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.params + a.b_off[0] + 4 * j);
+
+    // ---- stage the observations: one wave per sample, aligned dwords of the (arbitrarily aligned) row ---------------
+    for (int s = wave; s < ns; s += CONV_WAVES) {
+        int row = b0 + s;
+        if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
+        const u8* src = a.obs + (size_t)row * in_bytes;
+        const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
+        const u8* win = src - mis;
+        const int nd = (mis + in_bytes + 3) >> 2;
+        u32* dst = reinterpret_cast<u32*>(s_in + s * a.slot);
+        for (int d = lane; d < nd; d += 64) {
+            u32 v = 0;
+            if (4 * d >= mis && 4 * d + 4 <= mis + in_bytes) {
+                v = reinterpret_cast<const u32*>(win)[d];
+            } else {                                                // first / last partial dword: never read outside the row
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int o = 4 * d + bb;
+                    if (o >= mis && o < mis + in_bytes) v |= (u32)win[o] << (8 * bb);
+                }
+            }
+            dst[d] = v;
+        }
+        if (lane == 0) s_mis[s] = mis;
+    }
+    __syncthreads();
+
+    // ---- convolution 1: A gathered byte-wise from the uint8 image ---------------------------------------------------
+    {
+        const int r1 = a.oh1 * a.ow1, M1 = ns * r1, tiles = (M1 + 15) >> 4;
+        float* g1 = a.write_all ? a.act_out[0] + (size_t)b0 * r1 * 64 : nullptr;
+        for (int tile = wave; tile < tiles; tile += CONV_WAVES) {
+            int m = tile * 16 + j;
+            if (m >= M1) m = M1 - 1;
+            const int s = m / r1, pix = m - s * r1, oy = pix / a.ow1, ox = pix - oy * a.ow1;
+            const u8* ap = s_in + s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
+            f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < KG1; ++g) {
+                float av[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) av[s4] = (float)ap[ko[g][s4]];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[s4], b1[g][s4][t], acc[t]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mo = tile * 16 + 4 * kq + r;
+                if (mo >= M1) continue;
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[t][r] + bias1[t], 0.f);
+                *reinterpret_cast<f32x4*>(s_a1 + mo * 68 + 4 * j) = v;
+                if (g1) *reinterpret_cast<f32x4*>(g1 + (size_t)mo * 64 + 4 * j) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- convolution 2 (64 -> 32, 2x2) and 3 (32 -> 32, 2x2) --------------------------------------------------------
+    {
+        const int r2 = a.oh2 * a.ow2;
+        conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, a.params + a.w_off[1], a.params + a.b_off[1], s_a2,
+                                 a.write_all ? a.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane);
+    }
+    __syncthreads();
+    {
+        const int r3 = a.oh3 * a.ow3;
+        conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, a.params + a.w_off[2], a.params + a.b_off[2], nullptr,
+                                 a.act_out[2] + (size_t)b0 * r3 * 32, wave, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct DenseChainArgs {
+    const float* params;
+    const float* x;                     // [batch, K1]: NHWC flatten of the last convolution
+    int batch, K1, perm_hw, perm_c;     // Keras Flatten: k = c*hw + p reads x[p*perm_c + c]
+    int N2, N3, n_actions;              // Dense(|A|) width, dueling layer width (0 = no dueling layer)
+    int w_off[3], b_off[3];
+    float keep_scale;                   // > 0: dropout active on the hidden layer's output
+    u64 drop_T;
+    u32 seed0, seed1, sample_base;
+    u64 t;
+    float* h1_out;                      // training: [batch, 512] post-dropout; else NULL
+    float* y2_out;                      // training: [batch, N2]
+    float* y3_out;                      // training: [batch, N3]
+    float* q_out;                       // [batch, n_actions]
+    int ldx, ld2, ld3;                  // LDS row strides (floats)
+    int off_x, off_h, off_part, off_y2, off_y3;
+};
+
+template <int NT2, int KG3>             // N2 <= 16*NT2 (column tiles of Dense(|A|)); N2 <= 16*KG3 (k groups of the dueling layer)
+__global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    float* s_x = reinterpret_cast<float*>(smem + a.off_x);
+    float* s_h = reinterpret_cast<float*>(smem + a.off_h);
+    float* s_part = reinterpret_cast<float*>(smem + a.off_part);
+    float* s_y2 = reinterpret_cast<float*>(smem + a.off_y2);
+    float* s_y3 = reinterpret_cast<float*>(smem + a.off_y3);
+    constexpr int LDH = DENSE_HID + 4, PW = 16 * NT2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int b0 = blockIdx.x * DENSE_ROWS;
+    const int ns = min(DENSE_ROWS, a.batch - b0);
+    const int K1 = a.K1, KG = K1 >> 4;
+
+    // ---- hidden layer's first weight rows start flying before anything else ----------------------------------------
+    const float* w1 = a.params + a.w_off[0] + 64 * wave + 4 * j;
+    f32x4 bA[4], bB[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bA[s] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(4 * kq + s) * DENSE_HID);
+
+    // ---- input rows -> LDS in Keras Flatten order (zero-filled past the batch); clear the padded y2 image -----------
+    {
+        const int q4 = K1 >> 2;                                     // float4 per row
+        for (int i = tid; i < DENSE_ROWS * q4; i += DENSE_THREADS) {
+            const int r = i / q4, c4 = (i - r * q4) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < ns) v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(b0 + r) * K1 + c4);
+            if (a.perm_hw > 0) {
+                const int p = c4 / a.perm_c, c = c4 - p * a.perm_c;  // perm_c % 4 == 0: the four share p
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s_x[r * a.ldx + (c + e) * a.perm_hw + p] = v[e];
+            } else {
+                *reinterpret_cast<f32x4*>(s_x + r * a.ldx + c4) = v;
+            }
+        }
+        for (int i = tid; i < DENSE_ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- Dense(512): wave w owns columns [64w, 64w+64) as 4 interleaved tiles; weights double-buffered ------------------
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xrow = s_x + j * a.ldx + 4 * kq;
+    for (int g = 0; g < KG; g += 2) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bB[s] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(16 * (g + 1) + 4 * kq + s) * DENSE_HID);
+        f32x4 av = *reinterpret_cast<const f32x4*>(xrow + 16 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[s], bA[s][t], acc[t]);
+        if (g + 2 < KG) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bA[s] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(16 * (g + 2) + 4 * kq + s) * DENSE_HID);
+        }
+        av = *reinterpret_cast<const f32x4*>(xrow + 16 * (g + 1));
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[s], bB[s][t], acc[t]);
+    }
+
+    // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
+    const float* w2 = a.params + a.w_off[1];
+    const int kw0 = 64 * wave;
+    float b2[4][4][NT2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const int col = 16 * t + j;
+                b2[g][s][t] = col < a.N2 ? w2[(size_t)(kw0 + 16 * g + 4 * kq + s) * a.N2 + col] : 0.f;
+            }
+    const int NT3 = (a.N3 + 15) >> 4;
+    float b3[KG3][4];
+    if (wave < NT3) {
+        const float* w3 = a.params + a.w_off[2];
+        const int col = 16 * wave + j;
+#pragma unroll
+        for (int g = 0; g < KG3; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 16 * g + 4 * kq + s;
+                b3[g][s] = (k < a.N2 && col < a.N3) ? w3[(size_t)k * a.N3 + col] : 0.f;
+            }
+    }
+
+    // ---- hidden layer epilogue: bias, ReLU, dropout (one Philox call = this lane's 4 columns of a row) -----------------
+    {
+        const int c0 = 64 * wave + 4 * j;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.params + a.b_off[0] + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            f32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[t][r] + bias[t], 0.f);
+            if (a.keep_scale > 0.f) {
+                u32 wd[4];
+                philox4x32_10((u32)a.t, (u32)(a.t >> 32), a.sample_base + (u32)(b0 + row), ((u32)c0 >> 2) | ((u32)DQ_STREAM_DROPOUT << 16),
+                              a.seed0, a.seed1, wd);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = ((u64)wd[t] < a.drop_T) ? 0.f : v[t] * a.keep_scale;
+            }
+            *reinterpret_cast<f32x4*>(s_h + row * LDH + c0) = v;
+            if (a.h1_out && row < ns) *reinterpret_cast<f32x4*>(a.h1_out + (size_t)(b0 + row) * DENSE_HID + c0) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- Dense(|A|): K = 512 split over the 8 waves, partial tiles reduced in fixed order ---------------------------------
+    {
+        f32x4 acc2[NT2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* hrow = s_h + j * LDH + kw0 + 4 * kq;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 16 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) acc2[t] = MFMA16(av[s], b2[g][s][t], acc2[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_part[(wave * 16 + 4 * kq + r) * PW + 16 * t + j] = acc2[t][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < DENSE_ROWS * a.N2; e += DENSE_THREADS) {
+        const int row = e / a.N2, col = e - row * a.N2;
+        float v = a.params[a.b_off[1] + col];
+#pragma unroll
+        for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * 16 + row) * PW + col];
+        s_y2[row * a.ld2 + col] = v;
+        if (a.y2_out && row < ns) a.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
+    }
+    __syncthreads();
+
+    // ---- dueling layer Dense(|A|+1) and the combination Q = V + A - mean(A) ------------------------------------------------
+    const float* y = s_y2;
+    int ldy = a.ld2;
+    if (a.N3 > 0) {
+        if (wave < NT3) {
+            f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
+            const float* yrow = s_y2 + j * a.ld2 + 4 * kq;
+#pragma unroll
+            for (int g = 0; g < KG3; ++g) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(yrow + 16 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc3 = MFMA16(av[s], b3[g][s], acc3);
+            }
+            const int col = 16 * wave + j;
+            if (col < a.N3) {
+                const float bias = a.params[a.b_off[2] + col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * kq + r;
+                    const float v = acc3[r] + bias;
+                    s_y3[row * a.ld3 + col] = v;
+                    if (a.y3_out && row < ns) a.y3_out[(size_t)(b0 + row) * a.N3 + col] = v;
+                }
+            }
+        }
+        __syncthreads();
+        y = s_y3;
+        ldy = a.ld3;
+    }
+    const int A = a.n_actions;
+    for (int row = wave; row < ns; row += DENSE_WAVES) {
+        const float* yr = y + row * ldy;
+        if (a.N3 > 0) {
+            float s = 0.f;
+            for (int c = lane; c < A; c += 64) s += yr[1 + c];
+            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+            const float base = yr[0] - s / (float)A;
+            for (int c = lane; c < A; c += 64) a.q_out[(size_t)(b0 + row) * A + c] = base + yr[1 + c];
+        } else {
+            for (int c = lane; c < A; c += 64) a.q_out[(size_t)(b0 + row) * A + c] = yr[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvPlan { int S, slot, off_mis, off_a1, off_a2, KG1; size_t lds; };
+
+static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
+    if (Q->cfg.n_conv != 3) return false;
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    if (L1.cout != 64 || L1.K > 96) return false;
+    if (L2.cin != 64 || L2.cout != 32 || L2.k != 2 || L2.s != 1) return false;
+    if (L3.cin != 32 || L3.cout != 32 || L3.k != 2 || L3.s != 1) return false;
+    P->KG1 = (L1.K + 15) / 16;
+    if (P->KG1 < 3) P->KG1 = 3;
+    const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
+    P->slot = (in_bytes + 3 + 3) & ~3;
+    for (int pass = 0; pass < 2; ++pass) {                          // prefer two workgroups per CU; else the largest S that fits
+        const size_t budget = pass == 0 ? CONV_LDS_2PER_CU : CONV_LDS_MAX;
+        for (int S = 8; S >= 1; S >>= 1) {
+            size_t off = up16((size_t)S * P->slot);
+            const size_t mis = off; off += up16((size_t)S * 4);
+            const size_t a1 = off; off += up16((size_t)S * L1.rows * 68 * 4);
+            const size_t a2 = off; off += up16((size_t)S * L2.rows * 36 * 4);
+            if (off <= budget) {
+                P->S = S; P->off_mis = (int)mis; P->off_a1 = (int)a1; P->off_a2 = (int)a2; P->lds = off;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+struct DensePlan { int ldx, ld2, ld3, off_x, off_h, off_part, off_y2, off_y3, NT2; size_t lds; };
+
+static bool plan_dense(const dq_qnet* Q, DensePlan* P) {
+    const int nc = Q->cfg.n_conv;
+    if (Q->cfg.n_ff != 1) return false;
+    const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
+    if (D1.nout != DENSE_HID || (D1.nin & 31) || (Q->flat_c & 3)) return false;
+    const int N2 = D2.nout, N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0;
+    if (N2 > 112 || N3 > 128) return false;
+    P->NT2 = N2 <= 64 ? 4 : 7;
+    P->ldx = D1.nin + 4;
+    P->ld2 = 16 * P->NT2 + 4;
+    P->ld3 = 16 * ((N3 + 15) / 16) + 1;
+    size_t off = 0;
+    P->off_x = (int)off; off += up16((size_t)DENSE_ROWS * P->ldx * 4);
+    P->off_h = (int)off; off += up16((size_t)DENSE_ROWS * (DENSE_HID + 4) * 4);
+    P->off_part = (int)off; off += up16((size_t)DENSE_WAVES * 16 * 16 * P->NT2 * 4);
+    P->off_y2 = (int)off; off += up16((size_t)DENSE_ROWS * P->ld2 * 4);
+    P->off_y3 = (int)off; off += up16((size_t)DENSE_ROWS * P->ld3 * 4);
+    P->lds = off;
+    return off <= CONV_LDS_MAX;
+}
+
+bool fused_forward_supported(const dq_qnet* Q) {
+    ConvPlan cp;
+    DensePlan dp;
+    return plan_conv(Q, &cp) && plan_dense(Q, &dp);
+}
+
+typedef void (*conv_kernel_t)(ConvChainArgs);
+typedef void (*dense_kernel_t)(DenseChainArgs);
+
+dq_status fused_forward(dq_qnet* Q, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev, int index_off,
+                        int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t, uint32_t sample_base,
+                        float* q_dev, hipStream_t st) {
+    ConvPlan cp;
+    DensePlan dp;
+    DQ_REQUIRE(plan_conv(Q, &cp) && plan_dense(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_forward: configuration not covered");
+    DQ_REQUIRE((reinterpret_cast<uintptr_t>(params_dev) & 15) == 0, DQ_ERR_INVALID, "fused_forward: params_dev must be 16-byte aligned");
+    conv_kernel_t ck = cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
+    dense_kernel_t dk = dp.NT2 == 4 ? dense_chain_kernel<4, 4> : dense_chain_kernel<7, 7>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const conv_kernel_t cks[4] = {conv_chain_kernel<3>, conv_chain_kernel<4>, conv_chain_kernel<5>, conv_chain_kernel<6>};
+        for (int i = 0; i < 4; ++i)
+            DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain_kernel<7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
+        attr_set = true;
+    }
+    const int set = training ? 0 : 1, nc = Q->cfg.n_conv;
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    ConvChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.params = params_dev; ca.obs = obs_dev; ca.index = index_dev; ca.index_off = index_off;
+    ca.index_mod = index_mod > 0 ? index_mod : 0x7fffffff;
+    ca.batch = batch; ca.S = cp.S;
+    ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
+    ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
+    for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; ca.act_out[l] = Q->act[set][l]; }
+    ca.write_all = training ? 1 : 0;
+    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2;
+    dq_prof_begin(DQ_K_CONV_CHAIN, st);
+    ck<<<(batch + cp.S - 1) / cp.S, CONV_THREADS, cp.lds, st>>>(ca);
+    dq_prof_end(DQ_K_CONV_CHAIN, st);
+    DQ_LAUNCH_CHECK();
+
+    const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
+    DenseChainArgs da;
+    memset(&da, 0, sizeof(da));
+    da.params = params_dev; da.x = Q->act[set][nc - 1];
+    da.batch = batch; da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
+    da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
+    for (int l = 0; l < Q->n_layers - nc; ++l) { da.w_off[l] = (int)Q->L[nc + l].w_off; da.b_off[l] = (int)Q->L[nc + l].b_off; }
+    if (training && D1.dropout > 0.f) {
+        da.keep_scale = (float)(1.0 / (1.0 - (double)D1.dropout));
+        da.drop_T = dq_rate_threshold((double)D1.dropout);
+    }
+    if (seed) { da.seed0 = seed[0]; da.seed1 = seed[1]; }
+    da.sample_base = sample_base; da.t = t;
+    if (training) {
+        da.h1_out = Q->act[set][nc]; da.y2_out = Q->act[set][nc + 1];
+        da.y3_out = Q->cfg.dueling ? Q->act[set][nc + 2] : nullptr;
+    }
+    da.q_out = q_dev;
+    da.ldx = dp.ldx; da.ld2 = dp.ld2; da.ld3 = dp.ld3;
+    da.off_x = dp.off_x; da.off_h = dp.off_h; da.off_part = dp.off_part; da.off_y2 = dp.off_y2; da.off_y3 = dp.off_y3;
+    dq_prof_begin(DQ_K_DENSE_CHAIN, st);
+    dk<<<(batch + DENSE_ROWS - 1) / DENSE_ROWS, DENSE_THREADS, dp.lds, st>>>(da);
+    dq_prof_end(DQ_K_DENSE_CHAIN, st);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}

@@ -1,0 +1,74 @@
+// Live per-kernel timing with HIP events on the stream the kernel is launched on (bench.py's roofline object:
+// "achieved = algorithmic work per launch / that kernel's average launch duration, measured live").
+// One kernel family is armed at a time; every launch of it is bracketed by an event pair until the pool is full.
+// Nothing is recorded (and nothing costs anything beyond one compare) while no kernel is armed.
+#include "common.h"
+#include <vector>
+
+static const char* const kNames[DQ_K_COUNT] = {
+    "env_kernel", "policy_kernel", "conv_chain_kernel", "dense_chain_kernel", "gemm_fwd_kernel", "gemm_wgrad_kernel",
+    "reduce_partials_kernel", "td_kernels", "adam_kernel",
+};
+
+static int g_armed = -1;
+static int g_used = 0;
+static std::vector<hipEvent_t> g_events;      // 2 per launch
+
+void dq_prof_begin(int id, hipStream_t st) {
+    if (id != g_armed || 2 * g_used + 1 >= (int)g_events.size()) return;
+    (void)hipEventRecord(g_events[2 * g_used], st);
+}
+
+void dq_prof_end(int id, hipStream_t st) {
+    if (id != g_armed || 2 * g_used + 1 >= (int)g_events.size()) return;
+    (void)hipEventRecord(g_events[2 * g_used + 1], st);
+    ++g_used;
+}
+
+static void release_events() {
+    for (hipEvent_t e : g_events) (void)hipEventDestroy(e);
+    g_events.clear();
+    g_used = 0;
+}
+
+extern "C" {
+
+int dq_prof_kernel_count(void) { return DQ_K_COUNT; }
+
+const char* dq_prof_kernel_name(int id) { return id >= 0 && id < DQ_K_COUNT ? kNames[id] : ""; }
+
+dq_status dq_prof_arm(int kernel_id, int max_launches) {
+    release_events();
+    g_armed = -1;
+    if (kernel_id < 0) return DQ_OK;
+    DQ_REQUIRE(kernel_id < DQ_K_COUNT && max_launches > 0, DQ_ERR_INVALID, "dq_prof_arm: bad kernel id / capacity");
+    g_events.resize(2 * (size_t)max_launches);
+    for (size_t i = 0; i < g_events.size(); ++i) {
+        hipError_t e = hipEventCreate(&g_events[i]);
+        if (e != hipSuccess) {
+            g_events.resize(i);
+            release_events();
+            dq_set_error("dq_prof_arm: hipEventCreate: %s", hipGetErrorString(e));
+            return DQ_ERR_HIP;
+        }
+    }
+    g_armed = kernel_id;
+    return DQ_OK;
+}
+
+dq_status dq_prof_collect(int* launches, double* total_ms) {
+    DQ_REQUIRE(launches && total_ms, DQ_ERR_INVALID, "dq_prof_collect: null argument");
+    *launches = 0;
+    *total_ms = 0.0;
+    if (g_used > 0) DQ_HIP(hipEventSynchronize(g_events[2 * g_used - 1]));
+    for (int i = 0; i < g_used; ++i) {
+        float ms = 0.f;
+        DQ_HIP(hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]));
+        *total_ms += ms;
+    }
+    *launches = g_used;
+    g_used = 0;
+    return DQ_OK;
+}
+
+}  // extern "C"

@@ -16,7 +16,6 @@
 #include "gemm.h"
 #include <new>
 
-#define QN_MAX_LAYERS 12
 #define BM 128
 #define BK 32
 
@@ -217,33 +216,11 @@ __global__ void dueling_bwd_kernel(const float* __restrict__ dq, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct Layer {
-    int kind;                    // 0 conv, 1 dense
-    int cin, cout, k, s, ih, iw, oh, ow;   // conv
-    int nin, nout, relu;         // dense
-    float dropout;
-    size_t w_off, b_off;         // into the flat parameter buffer
-    int K, N, rows;              // GEMM view: rows per sample (oh*ow or 1), K, N
-};
-
-struct dq_qnet {
-    dq_qnet_cfg cfg;
-    int n_layers;
-    Layer L[QN_MAX_LAYERS];
-    size_t n_params;
-    int flat_c, flat_hw;         // last conv: channels and oh*ow (Keras Flatten permutation)
-    float* act[2][QN_MAX_LAYERS];   // [set][layer] outputs; set 0 = training (kept for backward), 1 = inference
-    float* grad[2];              // ping-pong gradient buffers (max activation size)
-    float* partial;              // wgrad slices
-    size_t partial_floats;
-    int last_train_batch;
-    const uint8_t* last_obs;     // inputs of the last training forward (needed by conv1's weight gradient)
-    const int32_t* last_index;
-    int last_index_off, last_index_mod;
-};
+#include "qnet.h"
 
 static void launch_fwd(const Gather& ga, const BMap& gb, const Epilogue& ep, int M, int N, int K, hipStream_t st) {
     const bool small = (M + BM - 1) / BM * ((N + 63) / 64) < 256;      // too few 128-row blocks to fill 256 CUs
+    dq_prof_begin(DQ_K_GEMM_FWD, st);
     if (N <= 32) {
         if (small) gemm_fwd_kernel<32, 1><<<dim3((M + 31) / 32, 1), 64, 0, st>>>(ga, gb, ep, M, N, K);
         else gemm_fwd_kernel<32, 4><<<dim3((M + BM - 1) / BM, 1), 256, 0, st>>>(ga, gb, ep, M, N, K);
@@ -251,6 +228,7 @@ static void launch_fwd(const Gather& ga, const BMap& gb, const Epilogue& ep, int
         if (small) gemm_fwd_kernel<64, 1><<<dim3((M + 31) / 32, (N + 63) / 64), 64, 0, st>>>(ga, gb, ep, M, N, K);
         else gemm_fwd_kernel<64, 4><<<dim3((M + BM - 1) / BM, (N + 63) / 64), 256, 0, st>>>(ga, gb, ep, M, N, K);
     }
+    dq_prof_end(DQ_K_GEMM_FWD, st);
 }
 
 // split of the weight-gradient reduction over M into slices (shared by create() for workspace sizing)
@@ -318,6 +296,7 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
     }
     Q->n_layers = n;
     Q->n_params = off;
+    Q->use_fused = 1;
     // workspaces
     size_t max_act = 0, max_partial = 0;
     hipError_t e = hipSuccess;
@@ -366,6 +345,14 @@ dq_status dq_qnet_layer_info(const dq_qnet* Q, int layer, int64_t* kernel_offset
 
 int dq_qnet_num_layers(const dq_qnet* Q) { return Q ? Q->n_layers : 0; }
 
+dq_status dq_qnet_set_fused(dq_qnet* Q, int enable) {
+    DQ_REQUIRE(Q, DQ_ERR_INVALID, "dq_qnet_set_fused: null handle");
+    Q->use_fused = enable ? 1 : 0;
+    return DQ_OK;
+}
+
+int dq_qnet_fused_supported(const dq_qnet* Q) { return Q && fused_forward_supported(Q) ? 1 : 0; }
+
 dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev, int index_off,
                           int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t, uint32_t sample_base,
                           float* q_dev, void* stream) {
@@ -375,6 +362,15 @@ dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* ob
     hipStream_t st = (hipStream_t)stream;
     const int set = training ? 0 : 1;
     const float* x = nullptr;
+    if (Q->use_fused && fused_forward_supported(Q)) {
+        const dq_status rc = fused_forward(Q, params_dev, obs_dev, index_dev, index_off, index_mod, batch, training, seed, t, sample_base, q_dev, st);
+        if (rc != DQ_OK) return rc;
+        if (training) {
+            Q->last_train_batch = batch; Q->last_obs = obs_dev; Q->last_index = index_dev;
+            Q->last_index_off = index_off; Q->last_index_mod = index_mod;
+        }
+        return DQ_OK;
+    }
     for (int i = 0; i < Q->n_layers; ++i) {
         const Layer& L = Q->L[i];
         const int M = batch * L.rows;
@@ -468,6 +464,7 @@ dq_status dq_qnet_backward(dq_qnet* Q, const float* params_dev, const float* dq_
         DQ_REQUIRE((size_t)slices * pstride <= Q->partial_floats, DQ_ERR_STATE, "dq_qnet_backward: workspace too small");
         float* pw = Q->partial;
         float* pb = Q->partial + (size_t)L.K * L.N;
+        dq_prof_begin(DQ_K_GEMM_WGRAD, st);
         if (L.N <= 32) {
             dim3 grid((L.K + BM - 1) / BM, slices, 1);
             gemm_wgrad_kernel<32><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice, pstride);
@@ -475,6 +472,7 @@ dq_status dq_qnet_backward(dq_qnet* Q, const float* params_dev, const float* dq_
             dim3 grid((L.K + BM - 1) / BM, slices, (L.N + 63) / 64);
             gemm_wgrad_kernel<64><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice, pstride);
         }
+        dq_prof_end(DQ_K_GEMM_WGRAD, st);
         DQ_LAUNCH_CHECK();
         {
             // bias follows the kernel in the flat buffer (b_off == w_off + K*N): one reduction covers both

@@ -51,6 +51,14 @@ class QNetwork:
             kshape = tuple(shape[j] for j in range(nd.value))
             self.layers.append(dict(kernel_offset=ko.value, bias_offset=bo.value, kernel_shape=kshape, bias_shape=(kshape[-1],)))
 
+    def set_fused(self, enable):
+        """Select the fused LDS-resident forward (default) or the per-layer implicit-GEMM forward."""
+        check(self.L.dq_qnet_set_fused(self._h, int(bool(enable))))
+
+    @property
+    def fused_supported(self):
+        return bool(self.L.dq_qnet_fused_supported(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self.L.dq_qnet_destroy(self._h)

@@ -187,6 +187,11 @@ int dq_qnet_num_layers(const dq_qnet* net);
 dq_status dq_qnet_layer_info(const dq_qnet* net, int layer, int64_t* kernel_offset, int64_t* bias_offset,
                              int32_t shape[4], int32_t* n_dims);
 
+/* Two forward implementations exist, both HIP: per-layer implicit GEMMs, and (default, when the configuration
+ * fits) the fused LDS-resident chains of csrc/fused.hip.  dq_qnet_set_fused(net, 0) selects the per-layer path. */
+dq_status dq_qnet_set_fused(dq_qnet* net, int enable);
+int dq_qnet_fused_supported(const dq_qnet* net);
+
 /* model.predict_on_batch (training == 0) / the forward half of train_on_batch (training != 0: dropout
  * active, activations kept for dq_qnet_backward).
  *   obs_dev    uint8 [rows, C, H, W]; sample b reads row  b                         if index_dev == NULL,
@@ -242,6 +247,18 @@ dq_status dq_episode_stats(const uint8_t* done_dev, const uint8_t* was_reset_dev
  * t = 1 for the first update. */
 dq_status dq_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n, double lr,
                        double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Live kernel timing (measurement only; no reference counterpart).  dq_prof_arm(id, n) brackets the next n
+ * launches of kernel family `id` (0 <= id < dq_prof_kernel_count(), names from dq_prof_kernel_name) with HIP
+ * events on the stream they are launched on; dq_prof_collect synchronises on the last recorded event and
+ * returns the number of launches recorded since the last collect and the sum of their durations.
+ * dq_prof_arm(-1, 0) disarms.  Not thread-safe; one family at a time.
+ * ------------------------------------------------------------------------------------------- */
+int dq_prof_kernel_count(void);
+const char* dq_prof_kernel_name(int kernel_id);
+dq_status dq_prof_arm(int kernel_id, int max_launches);
+dq_status dq_prof_collect(int* launches, double* total_ms);
 
 #ifdef __cplusplus
 }
