@@ -101,6 +101,9 @@ def main():
 
     for _ in range(args.warmup):
         runner.step(timed=False)
+    if hasattr(runner, "pick_dominant"):
+        runner.pick_dominant()          # untimed probe: which kernel family takes the most time per step
+        runner.arm(args.steps)          # ... that family's launches in the timed region are bracketed by HIP events
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
