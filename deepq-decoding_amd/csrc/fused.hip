@@ -26,19 +26,10 @@
 // Training forwards additionally write every layer's output to HBM in the layout qnet.hip's backward expects.
 #include "qnet.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
 #define CONV_THREADS 256
 #define CONV_WAVES 4
 #define CONV_LDS_2PER_CU (80 * 1024)
-#define CONV_LDS_MAX (160 * 1024)
-#define DENSE_THREADS 512
-#define DENSE_WAVES 8
-#define DENSE_ROWS 16
-#define DENSE_HID 512                 // Dense(512): 8 waves x 64 columns; Dense(|A|) splits K = 512 into 8 x 64
+#define CONV_LDS_MAX CHAIN_LDS_MAX
 
 // ---------------------------------------------------------------------------------------------------------------
 struct ConvChainArgs {
@@ -430,8 +421,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 
 // ---------------------------------------------------------------------------------------------------------------
 struct ConvPlan { int S, slot, off_mis, off_a1, off_a2, KG1; size_t lds; };
-
-static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
     if (Q->cfg.n_conv != 3) return false;

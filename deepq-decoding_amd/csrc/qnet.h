@@ -20,7 +20,7 @@ struct dq_qnet {
     size_t n_params;
     int flat_c, flat_hw;         // last conv: channels and oh*ow (Keras Flatten permutation)
     float* act[2][QN_MAX_LAYERS];   // [set][layer] outputs; set 0 = training (kept for backward), 1 = inference
-    float* grad[2];              // ping-pong gradient buffers (max activation size)
+    float* gz[QN_MAX_LAYERS];    // gradient w.r.t. each layer's pre-activation output (what its weight gradient consumes)
     float* partial;              // wgrad slices
     size_t partial_floats;
     int last_train_batch;
@@ -31,8 +31,25 @@ struct dq_qnet {
 };
 
 
+// ---- shared by the fused chains (fused.hip forward, fused_bwd.hip backward) ---------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define CHAIN_LDS_MAX (160 * 1024)
+#define DENSE_THREADS 512
+#define DENSE_WAVES 8
+#define DENSE_ROWS 16
+#define DENSE_HID 512                 // Dense(512): 8 waves x 64 columns; Dense(|A|) splits K = 512 into 8 x 64
+static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);
 dq_status fused_forward(dq_qnet* Q, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev, int index_off,
                         int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t, uint32_t sample_base,
                         float* q_dev, hipStream_t st);
+// qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
+dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
+dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_t st);
+// fused_bwd.hip: fused backward (data-gradient chains + all-layer weight gradients) for the same configurations
+bool fused_backward_supported(const dq_qnet* Q);
+dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, hipStream_t st);

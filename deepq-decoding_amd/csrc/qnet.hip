@@ -258,6 +258,90 @@ static Epilogue plain_epilogue(float* out, int ldo) {
     return e;
 }
 
+// Weight + bias gradient of layer i: dW = A^T g with g = Q->gz[i], A = the layer's (gathered) input of the last training forward.
+dq_status layer_wgrad(dq_qnet* Q, int i, float* grads_dev, hipStream_t st) {
+    const Layer& L = Q->L[i];
+    const int B = Q->last_train_batch, M = B * L.rows;
+    const float* g = Q->gz[i];
+    Gather ga;
+    memset(&ga, 0, sizeof(ga));
+    const float* x = i > 0 ? Q->act[0][i - 1] : nullptr;
+    if (L.kind == 0) {
+        ga.rows_per_sample = L.rows; ga.RW = L.ow; ga.KC = L.cin; ga.KW = L.k;
+        if (i == 0) {
+            ga.src = Q->last_obs; ga.is_u8 = 1;
+            ga.sb = (unsigned)(L.cin * L.ih * L.iw); ga.sy = (unsigned)(L.s * L.iw); ga.sx = (unsigned)L.s;
+            ga.sky = L.iw; ga.skx = 1; ga.sc = L.ih * L.iw;
+            ga.index = Q->last_index; ga.index_off = Q->last_index_off; ga.index_mod = Q->last_index_mod > 0 ? Q->last_index_mod : 0x7fffffff;
+        } else {
+            ga.src = x;
+            ga.sb = (unsigned)(L.ih * L.iw * L.cin); ga.sy = (unsigned)(L.s * L.iw * L.cin); ga.sx = (unsigned)(L.s * L.cin);
+            ga.sky = L.iw * L.cin; ga.skx = L.cin; ga.sc = 1;
+        }
+    } else {
+        ga = dense_gather(x, L.K);
+        if (i == Q->cfg.n_conv) { ga.KC = Q->flat_hw; ga.KW = 1 << 30; ga.skx = 1; ga.sc = Q->flat_c; }
+    }
+    int rows_per_slice, slices;
+    wgrad_slices(M, L.K, L.N, &rows_per_slice, &slices);
+    const size_t pstride = (size_t)L.K * L.N + L.N;                 // per slice: kernel partial then bias partial
+    DQ_REQUIRE((size_t)slices * pstride <= Q->partial_floats, DQ_ERR_STATE, "dq_qnet_backward: workspace too small");
+    float* pw = Q->partial;
+    float* pb = Q->partial + (size_t)L.K * L.N;
+    dq_prof_begin(DQ_K_GEMM_WGRAD, st);
+    if (L.N <= 32) {
+        dim3 grid((L.K + BM - 1) / BM, slices, 1);
+        gemm_wgrad_kernel<32><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice, pstride);
+    } else {
+        dim3 grid((L.K + BM - 1) / BM, slices, (L.N + 63) / 64);
+        gemm_wgrad_kernel<64><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice, pstride);
+    }
+    dq_prof_end(DQ_K_GEMM_WGRAD, st);
+    DQ_LAUNCH_CHECK();
+    // bias follows the kernel in the flat buffer (b_off == w_off + K*N): one reduction covers both
+    const int nw = L.K * L.N + L.N;
+    reduce_partials_kernel<<<(nw + 63) / 64, dim3(64, 4), 0, st>>>(Q->partial, grads_dev + L.w_off, nw, slices, pstride);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+// Data gradient through layer i (i >= 1), masked by the previous layer's activation:
+// Q->gz[i-1] = (Q->gz[i] W_i^T) * [y_{i-1} > 0] * scale.
+dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int i, hipStream_t st) {
+    const Layer& L = Q->L[i];
+    const Layer& Pv = Q->L[i - 1];
+    const int B = Q->last_train_batch;
+    const float* g = Q->gz[i];
+    Gather gd;
+    memset(&gd, 0, sizeof(gd));
+    BMap gb;
+    int Md, Nd, Kd;
+    Epilogue ep = plain_epilogue(Q->gz[i - 1], 0);
+    if (L.kind == 1) {
+        gd = dense_gather(g, L.N);                       // A = g [B, N]
+        gb = {params_dev + L.w_off, 1 << 30, 0, 1, L.N}; // B(n, k) = W[k*N + n]
+        Md = B; Nd = L.K; Kd = L.N;
+        ep.ldo = L.K;
+        if (i == Q->cfg.n_conv) { ep.PC = Q->flat_hw; ep.s_lo = Q->flat_c; ep.s_hi = 1; }   // Flatten^-1: k = c*HW + p -> p*C + c
+    } else {
+        // transposed convolution as a gather: dx[b,iy,ix,c] = sum_{ky,kx,n} g[b,iy-ky,ix-kx,n] W[ky,kx,c,n]   (stride 1)
+        gd.src = g; gd.rows_per_sample = L.ih * L.iw; gd.RW = L.iw;
+        gd.sb = (unsigned)(L.oh * L.ow * L.N); gd.sy = (unsigned)(L.ow * L.N); gd.sx = (unsigned)L.N;
+        gd.KC = L.N; gd.KW = L.k; gd.sky = -(L.ow * L.N); gd.skx = -L.N; gd.sc = 1;
+        gd.check = 1; gd.ylim = L.oh; gd.xlim = L.ow;
+        gb = {params_dev + L.w_off, L.N, L.cin * L.N, 1, L.N};   // B((ky,kx,n), c) = W[((ky*k+kx)*Cin + c)*N + n]
+        Md = B * L.ih * L.iw; Nd = L.cin; Kd = L.k * L.k * L.N;
+        ep.ldo = L.cin;
+    }
+    ep.flags = EPI_MASK;
+    ep.mask_src = Q->act[0][i - 1];
+    ep.mask_scale = Pv.dropout > 0.f ? (float)(1.0 / (1.0 - (double)Pv.dropout)) : 1.f;
+    if (!Pv.relu) { ep.flags = EPI_NONE; }
+    launch_fwd(gd, gb, ep, Md, Nd, Kd, st);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
 extern "C" {
 
 dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
@@ -298,20 +382,19 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
     Q->n_params = off;
     Q->use_fused = 1;
     // workspaces
-    size_t max_act = 0, max_partial = 0;
+    size_t max_partial = 0;
     hipError_t e = hipSuccess;
     for (int i = 0; i < n && e == hipSuccess; ++i) {
         const Layer& L = Q->L[i];
         const size_t floats = (size_t)cfg->max_batch * L.rows * L.N;
         if (floats >= (1ull << 32)) { dq_qnet_destroy(Q); dq_set_error("dq_qnet_create: activation too large for 32-bit offsets"); return DQ_ERR_UNSUPPORTED; }
-        max_act = floats > max_act ? floats : max_act;
         for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&Q->act[s][i], floats * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&Q->gz[i], floats * sizeof(float));
         int rps, slices;
         wgrad_slices(cfg->max_batch * L.rows, L.K, L.N, &rps, &slices);
         const size_t p = (size_t)slices * ((size_t)L.K * L.N + L.N);
         max_partial = p > max_partial ? p : max_partial;
     }
-    for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&Q->grad[s], max_act * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&Q->partial, max_partial * sizeof(float));
     Q->partial_floats = max_partial;
     if (e != hipSuccess) { dq_set_error("dq_qnet_create: %s", hipGetErrorString(e)); dq_qnet_destroy(Q); return DQ_ERR_HIP; }
@@ -321,10 +404,9 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
 
 void dq_qnet_destroy(dq_qnet* Q) {
     if (!Q) return;
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < 2; ++s)
         for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->act[s][i]) (void)hipFree(Q->act[s][i]);
-        if (Q->grad[s]) (void)hipFree(Q->grad[s]);
-    }
+    for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->gz[i]) (void)hipFree(Q->gz[i]);
     if (Q->partial) (void)hipFree(Q->partial);
     delete Q;
 }
@@ -426,9 +508,9 @@ dq_status dq_qnet_backward(dq_qnet* Q, const float* params_dev, const float* dq_
     DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_backward: no training forward to differentiate");
     hipStream_t st = (hipStream_t)stream;
     const int B = Q->last_train_batch, nl = Q->n_layers;
+    if (Q->use_fused && fused_backward_supported(Q)) return fused_backward(Q, params_dev, dq_dev, grads_dev, st);
     // gradient w.r.t. the last layer's (linear) output
-    float* g = Q->grad[0];
-    float* g_next = Q->grad[1];
+    float* g = Q->gz[nl - 1];
     if (Q->cfg.dueling) {
         dueling_bwd_kernel<<<(B + 3) / 4, 256, 0, st>>>(dq_dev, g, B, Q->cfg.n_actions);
         DQ_LAUNCH_CHECK();
@@ -436,81 +518,11 @@ dq_status dq_qnet_backward(dq_qnet* Q, const float* params_dev, const float* dq_
         DQ_HIP(hipMemcpyAsync(g, dq_dev, (size_t)B * Q->cfg.n_actions * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     for (int i = nl - 1; i >= 0; --i) {
-        const Layer& L = Q->L[i];
-        const int M = B * L.rows;
-        // ---- weight + bias gradient: dW = A^T g -----------------------------------------------------
-        Gather ga;
-        memset(&ga, 0, sizeof(ga));
-        const float* x = i > 0 ? Q->act[0][i - 1] : nullptr;
-        if (L.kind == 0) {
-            ga.rows_per_sample = L.rows; ga.RW = L.ow; ga.KC = L.cin; ga.KW = L.k;
-            if (i == 0) {
-                ga.src = Q->last_obs; ga.is_u8 = 1;
-                ga.sb = (unsigned)(L.cin * L.ih * L.iw); ga.sy = (unsigned)(L.s * L.iw); ga.sx = (unsigned)L.s;
-                ga.sky = L.iw; ga.skx = 1; ga.sc = L.ih * L.iw;
-                ga.index = Q->last_index; ga.index_off = Q->last_index_off; ga.index_mod = Q->last_index_mod > 0 ? Q->last_index_mod : 0x7fffffff;
-            } else {
-                ga.src = x;
-                ga.sb = (unsigned)(L.ih * L.iw * L.cin); ga.sy = (unsigned)(L.s * L.iw * L.cin); ga.sx = (unsigned)(L.s * L.cin);
-                ga.sky = L.iw * L.cin; ga.skx = L.cin; ga.sc = 1;
-            }
-        } else {
-            ga = dense_gather(x, L.K);
-            if (i == Q->cfg.n_conv) { ga.KC = Q->flat_hw; ga.KW = 1 << 30; ga.skx = 1; ga.sc = Q->flat_c; }
-        }
-        int rows_per_slice, slices;
-        wgrad_slices(M, L.K, L.N, &rows_per_slice, &slices);
-        const size_t pstride = (size_t)L.K * L.N + L.N;                 // per slice: kernel partial then bias partial
-        DQ_REQUIRE((size_t)slices * pstride <= Q->partial_floats, DQ_ERR_STATE, "dq_qnet_backward: workspace too small");
-        float* pw = Q->partial;
-        float* pb = Q->partial + (size_t)L.K * L.N;
-        dq_prof_begin(DQ_K_GEMM_WGRAD, st);
-        if (L.N <= 32) {
-            dim3 grid((L.K + BM - 1) / BM, slices, 1);
-            gemm_wgrad_kernel<32><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice, pstride);
-        } else {
-            dim3 grid((L.K + BM - 1) / BM, slices, (L.N + 63) / 64);
-            gemm_wgrad_kernel<64><<<grid, 256, 0, st>>>(ga, g, pw, pb, M, L.N, L.K, rows_per_slice, pstride);
-        }
-        dq_prof_end(DQ_K_GEMM_WGRAD, st);
-        DQ_LAUNCH_CHECK();
-        {
-            // bias follows the kernel in the flat buffer (b_off == w_off + K*N): one reduction covers both
-            const int nw = L.K * L.N + L.N;
-            reduce_partials_kernel<<<(nw + 63) / 64, dim3(64, 4), 0, st>>>(Q->partial, grads_dev + L.w_off, nw, slices, pstride);
-            DQ_LAUNCH_CHECK();
-        }
+        dq_status rc = layer_wgrad(Q, i, grads_dev, st);
+        if (rc != DQ_OK) return rc;
         if (i == 0) break;
-        // ---- data gradient, masked by the previous layer's activation: g_prev = (g W^T) * [y_prev > 0] * scale ----
-        const Layer& Pv = Q->L[i - 1];
-        Gather gd;
-        memset(&gd, 0, sizeof(gd));
-        BMap gb;
-        int Md, Nd, Kd;
-        Epilogue ep = plain_epilogue(g_next, 0);
-        if (L.kind == 1) {
-            gd = dense_gather(g, L.N);                       // A = g [B, N]
-            gb = {params_dev + L.w_off, 1 << 30, 0, 1, L.N}; // B(n, k) = W[k*N + n]
-            Md = B; Nd = L.K; Kd = L.N;
-            ep.ldo = L.K;
-            if (i == Q->cfg.n_conv) { ep.PC = Q->flat_hw; ep.s_lo = Q->flat_c; ep.s_hi = 1; }   // Flatten^-1: k = c*HW + p -> p*C + c
-        } else {
-            // transposed convolution as a gather: dx[b,iy,ix,c] = sum_{ky,kx,n} g[b,iy-ky,ix-kx,n] W[ky,kx,c,n]   (stride 1)
-            gd.src = g; gd.rows_per_sample = L.ih * L.iw; gd.RW = L.iw;
-            gd.sb = (unsigned)(L.oh * L.ow * L.N); gd.sy = (unsigned)(L.ow * L.N); gd.sx = (unsigned)L.N;
-            gd.KC = L.N; gd.KW = L.k; gd.sky = -(L.ow * L.N); gd.skx = -L.N; gd.sc = 1;
-            gd.check = 1; gd.ylim = L.oh; gd.xlim = L.ow;
-            gb = {params_dev + L.w_off, L.N, L.cin * L.N, 1, L.N};   // B((ky,kx,n), c) = W[((ky*k+kx)*Cin + c)*N + n]
-            Md = B * L.ih * L.iw; Nd = L.cin; Kd = L.k * L.k * L.N;
-            ep.ldo = L.cin;
-        }
-        ep.flags = EPI_MASK;
-        ep.mask_src = Q->act[0][i - 1];
-        ep.mask_scale = Pv.dropout > 0.f ? (float)(1.0 / (1.0 - (double)Pv.dropout)) : 1.f;
-        if (!Pv.relu) { ep.flags = EPI_NONE; }
-        launch_fwd(gd, gb, ep, Md, Nd, Kd, st);
-        DQ_LAUNCH_CHECK();
-        float* tmp = g; g = g_next; g_next = tmp;
+        rc = layer_dgrad(Q, params_dev, i, st);
+        if (rc != DQ_OK) return rc;
     }
     return DQ_OK;
 }
