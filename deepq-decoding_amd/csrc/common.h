@@ -44,7 +44,7 @@ void dq_set_error(const char* fmt, ...);
 
 // ---- live kernel timing (prof.hip; dq_prof_arm / dq_prof_collect in the C ABI) ------------------------
 enum { DQ_K_ENV = 0, DQ_K_POLICY, DQ_K_CONV_CHAIN, DQ_K_DENSE_CHAIN, DQ_K_GEMM_FWD, DQ_K_GEMM_WGRAD, DQ_K_REDUCE, DQ_K_TD, DQ_K_ADAM,
-       DQ_K_COUNT };
+       DQ_K_DENSE_BWD, DQ_K_DENSE_WGRAD, DQ_K_CONV_BWD, DQ_K_COUNT };
 void dq_prof_begin(int kernel_id, hipStream_t st);
 void dq_prof_end(int kernel_id, hipStream_t st);
 

@@ -197,6 +197,394 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients of the dense layers, all layers in ONE launch.  dW[k, n] = sum_b X[b, k] G[b, n]: the batch is the
+// reduction index.  One wave = one (16*TK x 64) output tile over one batch slice; both operands are loaded straight from
+// global memory in MFMA layout (lane (kq, i): X[b+kq][k0+i] / G[b+kq][n0+i], 64-byte segments), double-buffered in registers,
+// no LDS in the loop.  The four waves of a workgroup take the same tile over four consecutive slices and are summed through
+// LDS in fixed order, so only gridDim.y partials per weight reach HBM.  Bias gradients (column sums of G) ride along in the
+// waves of k-tile 0.
+#define WGRAD_THREADS 256
+#define WGRAD_WAVES 4
+
+struct WgradLayer {
+    const float* X;                     // [batch, K] the layer's input in the training forward
+    const float* G;                     // [batch, N] gradient w.r.t. the layer's pre-activation output
+    int K, N;
+    int out_w, out_b;                   // offsets into a partial (floats)
+    int perm_hw, perm_c;                // > 0: column idx = p*perm_c + c of X is weight row c*perm_hw + p (Keras Flatten)
+    int tile0, k_tiles, n_tiles, TK;    // first tile id of this layer, tiling, 16-row MFMA tiles per wave (3 or 4)
+};
+
+struct DenseWgradArgs {
+    WgradLayer L[3];
+    int n_layers, batch, rows_per_wave;
+    float* partial;                     // [gridDim.y][pstride]
+    size_t pstride;
+};
+
+template <int TK>
+__device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int batch, int rows_per_wave, float* __restrict__ out,
+                                           float* s_part, float* s_bias) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int kt = local / L.n_tiles, nt = local - kt * L.n_tiles;
+    const int kbase = kt * 16 * TK, nbase = nt * 64;
+    const int K = L.K, N = L.N;
+    const int m0 = (blockIdx.y * WGRAD_WAVES + wave) * rows_per_wave, m1 = min(batch, m0 + rows_per_wave);
+    int kcol[TK], ncol[4];
+    bool kok[TK], nok[4];
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti) { kcol[ti] = kbase + 16 * ti + j; kok[ti] = kcol[ti] < K; if (!kok[ti]) kcol[ti] = 0; }
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) { ncol[tj] = nbase + 16 * tj + j; nok[tj] = ncol[tj] < N; if (!nok[tj]) ncol[tj] = 0; }
+    f32x4 acc[TK][4];
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float xa0[TK], xa1[TK], gb0[4], gb1[4];
+    auto load = [&](int m, float (&xa)[TK], float (&gb)[4]) {
+        const int row = m + kq;
+        const bool rok = row < m1;
+        const float* xr = L.X + (size_t)(rok ? row : 0) * K;
+        const float* gr = L.G + (size_t)(rok ? row : 0) * N;
+#pragma unroll
+        for (int ti = 0; ti < TK; ++ti) xa[ti] = (rok && kok[ti]) ? xr[kcol[ti]] : 0.f;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) gb[tj] = (rok && nok[tj]) ? gr[ncol[tj]] : 0.f;
+    };
+    auto mma = [&](const float (&xa)[TK], const float (&gb)[4]) {
+#pragma unroll
+        for (int ti = 0; ti < TK; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = MFMA16(xa[ti], gb[tj], acc[ti][tj]);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) bsum[tj] += gb[tj];
+    };
+    load(m0, xa0, gb0);
+    for (int m = m0; m < m1; m += 8) {
+        load(m + 4, xa1, gb1);
+        mma(xa0, gb0);
+        load(m + 8, xa0, gb0);
+        mma(xa1, gb1);
+    }
+    // ---- combine the workgroup's four slices in fixed order, write one partial ---------------------------------------
+    float* sp = s_part + wave * (64 * 64);
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[(16 * ti + 4 * kq + r) * 64 + 16 * tj + j] = acc[ti][tj][r];
+    if (kt == 0) {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            float v = bsum[tj];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) s_bias[wave * 64 + 16 * tj + j] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * TK * 64; e += WGRAD_THREADS) {
+        const float v = (s_part[e] + s_part[4096 + e]) + (s_part[8192 + e] + s_part[12288 + e]);
+        const int kl = e >> 6, k = kbase + kl, n = nbase + (e & 63);
+        if (k < K && n < N) {
+            int row = k;
+            if (L.perm_hw > 0) { const int p = k / L.perm_c, c = k - p * L.perm_c; row = c * L.perm_hw + p; }
+            out[L.out_w + (size_t)row * N + n] = v;
+        }
+    }
+    if (kt == 0 && tid < 64 && nbase + tid < N)
+        out[L.out_b + nbase + tid] = (s_bias[tid] + s_bias[64 + tid]) + (s_bias[128 + tid] + s_bias[192 + tid]);
+}
+
+__global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    float* s_part = reinterpret_cast<float*>(smem);                  // [4][64*64]
+    float* s_bias = s_part + WGRAD_WAVES * 64 * 64;                 // [4][64]
+    int l = 0;
+    const int tile = blockIdx.x;
+    while (l + 1 < a.n_layers && tile >= a.L[l + 1].tile0) ++l;     // block-uniform
+    float* out = a.partial + (size_t)blockIdx.y * a.pstride;
+    if (a.L[l].TK == 3) wgrad_tile<3>(a.L[l], tile - a.L[l].tile0, a.batch, a.rows_per_wave, out, s_part, s_bias);
+    else wgrad_tile<4>(a.L[l], tile - a.L[l].tile0, a.batch, a.rows_per_wave, out, s_part, s_bias);
+}
+
+// out[i] = sum_s partial[s * stride + i] for i < n, slices summed in a fixed pairwise order (deterministic).
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, int slices,
+                                                            size_t stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < slices; k += 4) {
+        s0 += partial[(size_t)k * stride + i];
+        s1 += partial[(size_t)(k + 1) * stride + i];
+        s2 += partial[(size_t)(k + 2) * stride + i];
+        s3 += partial[(size_t)(k + 3) * stride + i];
+    }
+    for (; k < slices; ++k) s0 += partial[(size_t)k * stride + i];
+    out[i] = (s0 + s1) + (s2 + s3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Convolutional backward chain: both data gradients AND all three weight gradients of the convolutions in one persistent
+// launch.  Workgroup = 8 waves; it loops over groups of S samples.  Per group the saved activations a1 (conv1 output), a2
+// (conv2 output), the uint8 observations and the gradient g3 w.r.t. conv3's output are staged in LDS, then
+//   dW3 += im2col(a2)^T g3          g2 = (g3 (*) W3^T) * [a2 > 0]  -- written IN PLACE over a2
+//   dW2 += im2col(a1)^T g2          g1 = (g2 (*) W2^T) * [a1 > 0]  -- written IN PLACE over a1
+//   dW1 += im2col(obs)^T g1
+// so no convolutional gradient ever touches HBM.  Weight-gradient accumulators stay in registers across the workgroup's
+// groups; each workgroup writes ONE partial at the end (reduced in fixed order by reduce_slices_kernel).
+// Data gradients use the forward's operand tricks (weights for the wave's columns stationary in registers as float4 along
+// the reduction index n, A = one ds_read_b128 per four k-steps, a zero row standing in for out-of-range taps); weight
+// gradients reduce over pixels, so their operands are plain ds_read_b32 in MFMA layout (conflict-free: lanes = channels).
+#define CB_THREADS 512
+#define CB_WAVES 8
+
+struct ConvBwdArgs {
+    const float* params;
+    const u8* obs;
+    const int32_t* index;
+    int index_off, index_mod;
+    const float* a1;                    // saved activations of the training forward (global NHWC)
+    const float* a2;
+    const float* g3;                    // [batch*r3, 32] gradient w.r.t. conv3's pre-activation output
+    int batch, S, groups;
+    int C, H, W, k1, st1, K1;
+    int oh1, ow1, oh2, ow2, oh3, ow3;
+    int w_off[3], b_off[3];
+    float* partial;                     // [gridDim.x][pstride]
+    size_t pstride;
+    int slot;
+    int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3;
+};
+
+template <int CH, int PS>
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int rows, int tid) {
+    constexpr int Q4 = CH / 4;
+    for (int i = tid; i < rows * Q4; i += CB_THREADS) {
+        const int r = i / Q4, c4 = (i - r * Q4) * 4;
+        *reinterpret_cast<f32x4*>(dst + r * PS + c4) = *reinterpret_cast<const f32x4*>(src + (size_t)r * CH + c4);
+    }
+}
+
+// Data gradient of a 2x2 stride-1 convolution with 32 output channels, masked by the input activation, in place:
+//   act[(s,iy,ix), c] <- (sum_{ky,kx,n} g[(s,iy-ky,ix-kx), n] W[ky,kx,c,n]) * [act > 0]     for c in [c_lo, c_lo + 32)
+// g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA]; W = Keras HWIO [2][2][CIN][32].
+template <int CIN, int PSA>
+__device__ __forceinline__ void dgrad_inplace(const float* __restrict__ g, int zero_row, float* __restrict__ act, const float* __restrict__ w,
+                                              int c_lo, int ih, int iw, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
+    const int j = lane & 15, kq = lane >> 4;
+    f32x4 bw[8][2];                                                  // [(ky*2+kx)*2 + n16][t]: column c = c_lo + 2j + t
+#pragma unroll
+    for (int kyx = 0; kyx < 4; ++kyx)
+#pragma unroll
+        for (int n16 = 0; n16 < 2; ++n16)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                bw[kyx * 2 + n16][t] = *reinterpret_cast<const f32x4*>(w + (size_t)(kyx * CIN + c_lo + 2 * j + t) * 32 + 16 * n16 + 4 * kq);
+    const int rin = ih * iw, rout = oh * ow, tiles = (M + 15) >> 4;
+    for (int tile = tile_first; tile < tiles; tile += tile_step) {
+        int m = tile * 16 + j;
+        if (m >= M) m = M - 1;
+        const int s = m / rin, pix = m - s * rin, iy = pix / iw, ix = pix - iy * iw;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kyx = 0; kyx < 4; ++kyx) {
+            const int oy = iy - (kyx >> 1), ox = ix - (kyx & 1);
+            const bool valid = (unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow;
+            const float* gp = g + (valid ? s * rout + oy * ow + ox : zero_row) * 36 + 4 * kq;
+#pragma unroll
+            for (int n16 = 0; n16 < 2; ++n16) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(gp + 16 * n16);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = MFMA16(av[s4], bw[kyx * 2 + n16][t][s4], acc[t]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mo = tile * 16 + 4 * kq + r;
+            if (mo >= M) continue;
+            float* p = act + mo * PSA + c_lo + 2 * j;
+            const f32x2 old = *reinterpret_cast<const f32x2*>(p);
+            *reinterpret_cast<f32x2*>(p) = f32x2{old[0] > 0.f ? acc[0][r] : 0.f, old[1] > 0.f ? acc[1][r] : 0.f};
+        }
+    }
+}
+
+template <int KG1>                      // first convolution's K padded to 16 * KG1
+__global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u8* s_in = smem;
+    int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);
+    float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1);
+    float* s_a2 = reinterpret_cast<float*>(smem + a.off_a2);
+    float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
+    int* t1 = reinterpret_cast<int*>(smem + a.off_t1);
+    int* t2 = reinterpret_cast<int*>(smem + a.off_t2);
+    int* t3 = reinterpret_cast<int*>(smem + a.off_t3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int S = a.S, r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
+    const int in_bytes = a.C * a.H * a.W;
+    const int zero2 = S * r2, zero3 = S * r3;                        // all-zero rows of the g2 (= a2) and g3 images
+    constexpr int NW1 = (4 * KG1 + CB_WAVES - 1) / CB_WAVES;        // dW1 tiles (KG1 x 4) per wave
+
+    // ---- group-independent tables and zero rows ----------------------------------------------------------------
+    for (int m = tid; m < S * r3; m += CB_THREADS) { const int s = m / r3, p = m - s * r3, oy = p / a.ow3, ox = p - oy * a.ow3; t3[m] = s * r2 + oy * a.ow2 + ox; }
+    for (int m = tid; m < S * r2; m += CB_THREADS) { const int s = m / r2, p = m - s * r2, oy = p / a.ow2, ox = p - oy * a.ow2; t2[m] = s * r1 + oy * a.ow1 + ox; }
+    if (tid < 36) { s_a2[zero2 * 36 + tid] = 0.f; s_g3[zero3 * 36 + tid] = 0.f; }
+
+    // ---- per-lane constants of the weight-gradient phases ----------------------------------------------------------
+    // dW3 [128 x 32]: wave w owns k-tile w = (ky,kx) = w>>1, channels 16*(w&1)..; dW2 [256 x 32]: k-tiles 2w, 2w+1 = (ky,kx) = w>>1, channels 16*(2(w&1)+u)
+    const int kyx = wave >> 1, ky = kyx >> 1, kx = kyx & 1;
+    const int aoff3 = (ky * a.ow2 + kx) * 36 + 16 * (wave & 1) + j;
+    const int aoff2 = (ky * a.ow1 + kx) * 68 + 32 * (wave & 1) + j;
+    int ko1[NW1];                                                    // dW1: byte offset of weight row k = 16*kt + j inside an observation, -1 if k >= K1
+#pragma unroll
+    for (int u = 0; u < NW1; ++u) {
+        const int id = wave + CB_WAVES * u, kt = id >> 2, k = 16 * kt + j;
+        const int t = k / a.C, c = k - t * a.C, y = t / a.k1, x = t - y * a.k1;
+        ko1[u] = (id < 4 * KG1 && k < a.K1) ? c * a.H * a.W + y * a.W + x : -1;
+    }
+    f32x4 acc3[2], acc2[2][2], acc1[NW1];
+    float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1[NW1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[0][t] = acc3[t]; acc2[1][t] = acc3[t]; }
+#pragma unroll
+    for (int u = 0; u < NW1; ++u) { acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; bs1[u] = 0.f; }
+
+    for (int grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
+        const int b0 = grp * S, ns = min(S, a.batch - b0);
+        const int M1 = ns * r1, M2 = ns * r2, M3 = ns * r3;
+        __syncthreads();                                            // previous group's images are no longer read
+        // ---- stage observations (one wave per sample; aligned dwords of an arbitrarily aligned row), a1, a2, g3 -------
+        for (int s = wave; s < ns; s += CB_WAVES) {
+            int row = b0 + s;
+            if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
+            const u8* src = a.obs + (size_t)row * in_bytes;
+            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
+            const u8* win = src - mis;
+            const int nd = (mis + in_bytes + 3) >> 2;
+            u32* dst = reinterpret_cast<u32*>(s_in + s * a.slot);
+            for (int d = lane; d < nd; d += 64) {
+                u32 v = 0;
+                if (4 * d >= mis && 4 * d + 4 <= mis + in_bytes) {
+                    v = reinterpret_cast<const u32*>(win)[d];
+                } else {
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const int o = 4 * d + bb;
+                        if (o >= mis && o < mis + in_bytes) v |= (u32)win[o] << (8 * bb);
+                    }
+                }
+                dst[d] = v;
+            }
+            if (lane == 0) s_mis[s] = mis;
+        }
+        stage_rows<64, 68>(s_a1, a.a1 + (size_t)b0 * r1 * 64, M1, tid);
+        stage_rows<32, 36>(s_a2, a.a2 + (size_t)b0 * r2 * 32, M2, tid);
+        stage_rows<32, 36>(s_g3, a.g3 + (size_t)b0 * r3 * 32, M3, tid);
+        __syncthreads();
+        for (int m = tid; m < M1; m += CB_THREADS) {
+            const int s = m / r1, p = m - s * r1, oy = p / a.ow1, ox = p - oy * a.ow1;
+            t1[m] = s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
+        }
+
+        // ---- dW3 += im2col(a2)^T g3 ------------------------------------------------------------------------------
+        for (int m0 = 0; m0 < M3; m0 += 4) {
+            const int m = m0 + kq;
+            const bool ok = m < M3;
+            const int mc = ok ? m : 0;
+            const float av = ok ? s_a2[t3[mc] * 36 + aoff3] : 0.f;
+            const float g0 = ok ? s_g3[mc * 36 + j] : 0.f, g1 = ok ? s_g3[mc * 36 + 16 + j] : 0.f;
+            acc3[0] = MFMA16(av, g0, acc3[0]);
+            acc3[1] = MFMA16(av, g1, acc3[1]);
+            bs3[0] += g0; bs3[1] += g1;
+        }
+        __syncthreads();                                            // every wave is done reading a2
+        // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
+        dgrad_inplace<32, 36>(s_g3, zero3, s_a2, a.params + a.w_off[2], 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
+        __syncthreads();
+        // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
+        for (int m0 = 0; m0 < M2; m0 += 4) {
+            const int m = m0 + kq;
+            const bool ok = m < M2;
+            const int mc = ok ? m : 0;
+            const float* ap = s_a1 + t2[mc] * 68 + aoff2;
+            const float av0 = ok ? ap[0] : 0.f, av1 = ok ? ap[16] : 0.f;
+            const float g0 = ok ? s_a2[mc * 36 + j] : 0.f, g1 = ok ? s_a2[mc * 36 + 16 + j] : 0.f;
+            acc2[0][0] = MFMA16(av0, g0, acc2[0][0]);
+            acc2[0][1] = MFMA16(av0, g1, acc2[0][1]);
+            acc2[1][0] = MFMA16(av1, g0, acc2[1][0]);
+            acc2[1][1] = MFMA16(av1, g1, acc2[1][1]);
+            bs2[0] += g0; bs2[1] += g1;
+        }
+        __syncthreads();                                            // every wave is done reading a1
+        // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1: waves 0-3 channels 0..31, waves 4-7 channels 32..63 -------------
+        dgrad_inplace<64, 68>(s_a2, zero2, s_a1, a.params + a.w_off[1], 32 * (wave >> 2), a.oh1, a.ow1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
+        __syncthreads();
+        // ---- dW1 += im2col(obs)^T g1 ------------------------------------------------------------------------------------
+        for (int m0 = 0; m0 < M1; m0 += 4) {
+            const int m = m0 + kq;
+            const bool ok = m < M1;
+            const int mc = ok ? m : 0;
+            const u8* op = s_in + t1[mc];
+#pragma unroll
+            for (int u = 0; u < NW1; ++u) {
+                const int id = wave + CB_WAVES * u;
+                if (id < 4 * KG1) {                                 // wave-uniform
+                    const float av = (ok && ko1[u] >= 0) ? (float)op[ko1[u]] : 0.f;
+                    const float g = ok ? s_a1[mc * 68 + 16 * (id & 3) + j] : 0.f;
+                    acc1[u] = MFMA16(av, g, acc1[u]);
+                    bs1[u] += g;
+                }
+            }
+        }
+    }
+
+    // ---- one partial per workgroup -----------------------------------------------------------------------------------
+    float* out = a.partial + (size_t)blockIdx.x * a.pstride;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            out[a.w_off[2] + (16 * wave + 4 * kq + r) * 32 + 16 * t + j] = acc3[t][r];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) out[a.w_off[1] + (16 * (2 * wave + u) + 4 * kq + r) * 32 + 16 * t + j] = acc2[u][t][r];
+        }
+#pragma unroll
+    for (int u = 0; u < NW1; ++u) {
+        const int id = wave + CB_WAVES * u, kt = id >> 2, nt = id & 3;
+        if (id < 4 * KG1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * kt + 4 * kq + r;
+                if (k < a.K1) out[a.w_off[0] + k * 64 + 16 * nt + j] = acc1[u][r];
+            }
+            if (kt == 0) {                                          // bias gradient = column sums of g1
+                float v = bs1[u];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (kq == 0) out[a.b_off[0] + 16 * nt + j] = v;
+            }
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v3 = bs3[t], v2 = bs2[t];
+            v3 += __shfl_xor(v3, 16); v3 += __shfl_xor(v3, 32);
+            v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+            if (kq == 0) { out[a.b_off[2] + 16 * t + j] = v3; out[a.b_off[1] + 16 * t + j] = v2; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 struct DenseBwdPlan { int NT2, ldg, off_g3, off_gy2, off_gh1; size_t lds; };
 
@@ -218,17 +606,67 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     return true;
 }
 
+struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3; size_t lds; };
+
+static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
+    if (Q->cfg.n_conv != 3) return false;
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    if (L1.cout != 64 || L1.K > 96) return false;
+    if (L2.cin != 64 || L2.cout != 32 || L2.k != 2 || L2.s != 1) return false;
+    if (L3.cin != 32 || L3.cout != 32 || L3.k != 2 || L3.s != 1) return false;
+    P->KG1 = (L1.K + 15) / 16;
+    if (P->KG1 < 3) P->KG1 = 3;
+    const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
+    P->slot = (in_bytes + 3 + 3) & ~3;
+    for (int S = 8; S >= 1; S >>= 1) {
+        size_t off = up16((size_t)S * P->slot);
+        P->off_mis = (int)off; off += up16((size_t)S * 4);
+        P->off_a1 = (int)off; off += up16((size_t)S * L1.rows * 68 * 4);
+        P->off_a2 = (int)off; off += up16((size_t)(S * L2.rows + 1) * 36 * 4);
+        P->off_g3 = (int)off; off += up16((size_t)(S * L3.rows + 1) * 36 * 4);
+        P->off_t1 = (int)off; off += up16((size_t)S * L1.rows * 4);
+        P->off_t2 = (int)off; off += up16((size_t)S * L2.rows * 4);
+        P->off_t3 = (int)off; off += up16((size_t)S * L3.rows * 4);
+        if (off <= CHAIN_LDS_MAX) { P->S = S; P->lds = off; return true; }
+    }
+    return false;
+}
+
+#define CONV_BWD_MAX_WGS 256
+#define DENSE_WGRAD_SLICES 8
+#define DENSE_WGRAD_LDS ((WGRAD_WAVES * 64 * 64 + WGRAD_WAVES * 64) * 4)
+
 bool fused_backward_supported(const dq_qnet* Q) {
     DenseBwdPlan dp;
-    return fused_forward_supported(Q) && plan_dense_bwd(Q, &dp);
+    ConvBwdPlan cp;
+    return fused_forward_supported(Q) && plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp);
 }
+
+// floats of workspace the fused backward needs: [DENSE_WGRAD_SLICES][n_params] dense partials, then [CONV_BWD_MAX_WGS][conv params]
+size_t fused_backward_workspace_floats(const dq_qnet* Q) {
+    if (!fused_backward_supported(Q)) return 0;
+    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off;
+}
+
+typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
 
 dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, hipStream_t st) {
     DenseBwdPlan dp;
-    DQ_REQUIRE(plan_dense_bwd(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_backward: configuration not covered");
+    ConvBwdPlan cp;
+    DQ_REQUIRE(plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp), DQ_ERR_UNSUPPORTED, "fused_backward: configuration not covered");
     DQ_REQUIRE((reinterpret_cast<uintptr_t>(params_dev) & 15) == 0, DQ_ERR_INVALID, "fused_backward: params_dev must be 16-byte aligned");
+    DQ_REQUIRE(Q->fpartial, DQ_ERR_STATE, "fused_backward: workspace missing");
+    static bool attr_set = false;
+    if (!attr_set) {
+        const conv_bwd_kernel_t cks[4] = {conv_bwd_chain_kernel<3>, conv_bwd_chain_kernel<4>, conv_bwd_chain_kernel<5>, conv_bwd_chain_kernel<6>};
+        for (int i = 0; i < 4; ++i)
+            DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_MAX));
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_WGRAD_LDS));
+        attr_set = true;
+    }
     const int B = Q->last_train_batch, nc = Q->cfg.n_conv, nl = Q->n_layers;
     const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
+    // ---- 1. dense data gradients ----------------------------------------------------------------------------------
     DenseBwdArgs da;
     memset(&da, 0, sizeof(da));
     da.params = params_dev; da.dq = dq_dev; da.h1 = Q->act[0][nc]; da.x = Q->act[0][nc - 1];
@@ -238,16 +676,66 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     da.mask_scale = D1.dropout > 0.f ? (float)(1.0 / (1.0 - (double)D1.dropout)) : 1.f;
     da.g3 = Q->cfg.dueling ? Q->gz[nc + 2] : nullptr; da.gy2 = Q->gz[nc + 1]; da.gh1 = Q->gz[nc]; da.gx = Q->gz[nc - 1];
     da.ldg = dp.ldg; da.off_g3 = dp.off_g3; da.off_gy2 = dp.off_gy2; da.off_gh1 = dp.off_gh1;
+    dq_prof_begin(DQ_K_DENSE_BWD, st);
     if (dp.NT2 == 4) dense_bwd_chain_kernel<4><<<(B + DENSE_ROWS - 1) / DENSE_ROWS, DENSE_THREADS, dp.lds, st>>>(da);
     else dense_bwd_chain_kernel<7><<<(B + DENSE_ROWS - 1) / DENSE_ROWS, DENSE_THREADS, dp.lds, st>>>(da);
+    dq_prof_end(DQ_K_DENSE_BWD, st);
     DQ_LAUNCH_CHECK();
-    for (int i = nl - 1; i >= 0; --i) {
-        dq_status rc = layer_wgrad(Q, i, grads_dev, st);
-        if (rc != DQ_OK) return rc;
-        if (i > 0 && i < nc) {                                      // convolutional data gradients: per-layer kernels
-            rc = layer_dgrad(Q, params_dev, i, st);
-            if (rc != DQ_OK) return rc;
-        }
+
+    // ---- 2. dense weight gradients: all layers, one launch -----------------------------------------------------------
+    float* dense_partial = Q->fpartial;
+    float* conv_partial = Q->fpartial + (size_t)DENSE_WGRAD_SLICES * Q->n_params;
+    DenseWgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.n_layers = nl - nc; wa.batch = B;
+    int tiles = 0;
+    for (int l = 0; l < nl - nc; ++l) {
+        const Layer& L = Q->L[nc + l];
+        WgradLayer& W = wa.L[l];
+        W.X = Q->act[0][nc + l - 1]; W.G = Q->gz[nc + l]; W.K = L.K; W.N = L.N;
+        W.out_w = (int)L.w_off; W.out_b = (int)L.b_off;
+        if (l == 0) { W.perm_hw = Q->flat_hw; W.perm_c = Q->flat_c; }
+        W.TK = (L.K % 48 == 0) ? 3 : 4;
+        W.k_tiles = (L.K + 16 * W.TK - 1) / (16 * W.TK); W.n_tiles = (L.N + 63) / 64;
+        W.tile0 = tiles; tiles += W.k_tiles * W.n_tiles;
     }
+    int rpw = (B + DENSE_WGRAD_SLICES * WGRAD_WAVES - 1) / (DENSE_WGRAD_SLICES * WGRAD_WAVES);
+    rpw = (rpw + 7) & ~7;
+    const int sy = (B + rpw * WGRAD_WAVES - 1) / (rpw * WGRAD_WAVES);
+    wa.rows_per_wave = rpw; wa.partial = dense_partial; wa.pstride = Q->n_params;
+    dq_prof_begin(DQ_K_DENSE_WGRAD, st);
+    dense_wgrad_kernel<<<dim3(tiles, sy), WGRAD_THREADS, DENSE_WGRAD_LDS, st>>>(wa);
+    dq_prof_end(DQ_K_DENSE_WGRAD, st);
+    DQ_LAUNCH_CHECK();
+
+    // ---- 3. convolutions: data + weight gradients, one persistent launch -----------------------------------------------
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    ConvBwdArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.params = params_dev; ca.obs = Q->last_obs; ca.index = Q->last_index; ca.index_off = Q->last_index_off;
+    ca.index_mod = Q->last_index_mod > 0 ? Q->last_index_mod : 0x7fffffff;
+    ca.a1 = Q->act[0][0]; ca.a2 = Q->act[0][1]; ca.g3 = Q->gz[nc - 1];
+    ca.batch = B; ca.S = cp.S; ca.groups = (B + cp.S - 1) / cp.S;
+    ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
+    ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
+    for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
+    const size_t conv_floats = D1.w_off;
+    ca.partial = conv_partial; ca.pstride = conv_floats;
+    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
+    ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3;
+    const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
+    conv_bwd_kernel_t ck = cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
+                         : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;
+    dq_prof_begin(DQ_K_CONV_BWD, st);
+    ck<<<wgs, CB_THREADS, cp.lds, st>>>(ca);
+    dq_prof_end(DQ_K_CONV_BWD, st);
+    DQ_LAUNCH_CHECK();
+
+    // ---- 4. fixed-order reductions of the partials into the flat gradient ------------------------------------------------
+    const int n_dense = (int)(Q->n_params - conv_floats);
+    reduce_slices_kernel<<<(n_dense + 255) / 256, 256, 0, st>>>(dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params);
+    DQ_LAUNCH_CHECK();
+    reduce_slices_kernel<<<((int)conv_floats + 255) / 256, 256, 0, st>>>(conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats);
+    DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

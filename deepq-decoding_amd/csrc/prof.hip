@@ -7,7 +7,7 @@
 
 static const char* const kNames[DQ_K_COUNT] = {
     "env_kernel", "policy_kernel", "conv_chain_kernel", "dense_chain_kernel", "gemm_fwd_kernel", "gemm_wgrad_kernel",
-    "reduce_partials_kernel", "td_kernels", "adam_kernel",
+    "reduce_partials_kernel", "td_kernels", "adam_kernel", "dense_bwd_chain_kernel", "dense_wgrad_kernel", "conv_bwd_chain_kernel",
 };
 
 static int g_armed = -1;

@@ -27,6 +27,7 @@ struct dq_qnet {
     const uint8_t* last_obs;     // inputs of the last training forward (needed by conv1's weight gradient)
     const int32_t* last_index;
     int last_index_off, last_index_mod;
+    float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
     int use_fused;               // 1: fused LDS-resident forward when the configuration allows it
 };
 
@@ -52,4 +53,5 @@ dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
 dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_t st);
 // fused_bwd.hip: fused backward (data-gradient chains + all-layer weight gradients) for the same configurations
 bool fused_backward_supported(const dq_qnet* Q);
+size_t fused_backward_workspace_floats(const dq_qnet* Q);
 dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, hipStream_t st);

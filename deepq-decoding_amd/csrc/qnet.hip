@@ -396,6 +396,8 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         max_partial = p > max_partial ? p : max_partial;
     }
     if (e == hipSuccess) e = hipMalloc(&Q->partial, max_partial * sizeof(float));
+    const size_t fws = fused_backward_workspace_floats(Q);
+    if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));
     Q->partial_floats = max_partial;
     if (e != hipSuccess) { dq_set_error("dq_qnet_create: %s", hipGetErrorString(e)); dq_qnet_destroy(Q); return DQ_ERR_HIP; }
     *out = Q;
@@ -408,6 +410,7 @@ void dq_qnet_destroy(dq_qnet* Q) {
         for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->act[s][i]) (void)hipFree(Q->act[s][i]);
     for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->gz[i]) (void)hipFree(Q->gz[i]);
     if (Q->partial) (void)hipFree(Q->partial);
+    if (Q->fpartial) (void)hipFree(Q->fpartial);
     delete Q;
 }
 
