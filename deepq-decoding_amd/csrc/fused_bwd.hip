@@ -313,21 +313,31 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     else wgrad_tile<4>(a.L[l], tile - a.L[l].tile0, a.batch, a.rows_per_wave, out, s_part, s_bias);
 }
 
-// out[i] = sum_s partial[s * stride + i] for i < n, slices summed in a fixed pairwise order (deterministic).
-__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, int slices,
-                                                            size_t stride) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < slices; k += 4) {
-        s0 += partial[(size_t)k * stride + i];
-        s1 += partial[(size_t)(k + 1) * stride + i];
-        s2 += partial[(size_t)(k + 2) * stride + i];
-        s3 += partial[(size_t)(k + 3) * stride + i];
+// Fixed-order reduction of both partial sets in one launch: out[i] = sum_s partial[s * stride + i].
+// Block = 64 outputs x 8 slice groups (thread (x, g) sums slices g, g+8, ... in order; the 8 group sums are combined
+// pairwise in LDS) -- deterministic, and 8x the loads in flight of a one-thread-per-output loop.
+struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; };
+struct ReduceArgs { ReduceSeg seg[2]; };
+
+__global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
+    __shared__ float sh[8][64];
+    const ReduceSeg& S = a.seg[blockIdx.x >= (unsigned)a.seg[1].block0 ? 1 : 0];
+    const int i = (blockIdx.x - S.block0) * 64 + threadIdx.x, g = threadIdx.y;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < S.n) {
+        int k = g;
+        for (; k + 8 < S.slices; k += 16) {
+            s0 += S.partial[(size_t)k * S.stride + i];
+            s1 += S.partial[(size_t)(k + 8) * S.stride + i];
+        }
+        if (k < S.slices) s0 += S.partial[(size_t)k * S.stride + i];
     }
-    for (; k < slices; ++k) s0 += partial[(size_t)k * stride + i];
-    out[i] = (s0 + s1) + (s2 + s3);
+    sh[g][threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && i < S.n) {
+        const int x = threadIdx.x;
+        S.out[i] = ((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x])) + ((sh[4][x] + sh[5][x]) + (sh[6][x] + sh[7][x]));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -496,54 +506,79 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         }
 
         // ---- dW3 += im2col(a2)^T g3 ------------------------------------------------------------------------------
-        for (int m0 = 0; m0 < M3; m0 += 4) {
-            const int m = m0 + kq;
-            const bool ok = m < M3;
-            const int mc = ok ? m : 0;
-            const float av = ok ? s_a2[t3[mc] * 36 + aoff3] : 0.f;
-            const float g0 = ok ? s_g3[mc * 36 + j] : 0.f, g1 = ok ? s_g3[mc * 36 + 16 + j] : 0.f;
-            acc3[0] = MFMA16(av, g0, acc3[0]);
-            acc3[1] = MFMA16(av, g1, acc3[1]);
-            bs3[0] += g0; bs3[1] += g1;
+        for (int m0 = 0; m0 < M3; m0 += 16) {                         // 4 MFMA steps per trip: all LDS reads first, then the MFMAs
+            float av[4], g0[4], g1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + 4 * q + kq;
+                const bool ok = m < M3;
+                const int mc = ok ? m : 0;
+                av[q] = ok ? s_a2[t3[mc] * 36 + aoff3] : 0.f;
+                g0[q] = ok ? s_g3[mc * 36 + j] : 0.f;
+                g1[q] = ok ? s_g3[mc * 36 + 16 + j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc3[0] = MFMA16(av[q], g0[q], acc3[0]);
+                acc3[1] = MFMA16(av[q], g1[q], acc3[1]);
+                bs3[0] += g0[q]; bs3[1] += g1[q];
+            }
         }
         __syncthreads();                                            // every wave is done reading a2
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
         dgrad_inplace<32, 36>(s_g3, zero3, s_a2, a.params + a.w_off[2], 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
         __syncthreads();
         // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
-        for (int m0 = 0; m0 < M2; m0 += 4) {
-            const int m = m0 + kq;
-            const bool ok = m < M2;
-            const int mc = ok ? m : 0;
-            const float* ap = s_a1 + t2[mc] * 68 + aoff2;
-            const float av0 = ok ? ap[0] : 0.f, av1 = ok ? ap[16] : 0.f;
-            const float g0 = ok ? s_a2[mc * 36 + j] : 0.f, g1 = ok ? s_a2[mc * 36 + 16 + j] : 0.f;
-            acc2[0][0] = MFMA16(av0, g0, acc2[0][0]);
-            acc2[0][1] = MFMA16(av0, g1, acc2[0][1]);
-            acc2[1][0] = MFMA16(av1, g0, acc2[1][0]);
-            acc2[1][1] = MFMA16(av1, g1, acc2[1][1]);
-            bs2[0] += g0; bs2[1] += g1;
+        for (int m0 = 0; m0 < M2; m0 += 16) {
+            float av0[4], av1[4], g0[4], g1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + 4 * q + kq;
+                const bool ok = m < M2;
+                const int mc = ok ? m : 0;
+                const float* ap = s_a1 + t2[mc] * 68 + aoff2;
+                av0[q] = ok ? ap[0] : 0.f;
+                av1[q] = ok ? ap[16] : 0.f;
+                g0[q] = ok ? s_a2[mc * 36 + j] : 0.f;
+                g1[q] = ok ? s_a2[mc * 36 + 16 + j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc2[0][0] = MFMA16(av0[q], g0[q], acc2[0][0]);
+                acc2[0][1] = MFMA16(av0[q], g1[q], acc2[0][1]);
+                acc2[1][0] = MFMA16(av1[q], g0[q], acc2[1][0]);
+                acc2[1][1] = MFMA16(av1[q], g1[q], acc2[1][1]);
+                bs2[0] += g0[q]; bs2[1] += g1[q];
+            }
         }
         __syncthreads();                                            // every wave is done reading a1
         // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1: waves 0-3 channels 0..31, waves 4-7 channels 32..63 -------------
         dgrad_inplace<64, 68>(s_a2, zero2, s_a1, a.params + a.w_off[1], 32 * (wave >> 2), a.oh1, a.ow1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
         __syncthreads();
         // ---- dW1 += im2col(obs)^T g1 ------------------------------------------------------------------------------------
-        for (int m0 = 0; m0 < M1; m0 += 4) {
-            const int m = m0 + kq;
-            const bool ok = m < M1;
-            const int mc = ok ? m : 0;
-            const u8* op = s_in + t1[mc];
+        for (int m0 = 0; m0 < M1; m0 += 16) {
+            float av[4][NW1], g[4][NW1];
 #pragma unroll
-            for (int u = 0; u < NW1; ++u) {
-                const int id = wave + CB_WAVES * u;
-                if (id < 4 * KG1) {                                 // wave-uniform
-                    const float av = (ok && ko1[u] >= 0) ? (float)op[ko1[u]] : 0.f;
-                    const float g = ok ? s_a1[mc * 68 + 16 * (id & 3) + j] : 0.f;
-                    acc1[u] = MFMA16(av, g, acc1[u]);
-                    bs1[u] += g;
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + 4 * q + kq;
+                const bool ok = m < M1;
+                const int mc = ok ? m : 0;
+                const u8* op = s_in + t1[mc];
+#pragma unroll
+                for (int u = 0; u < NW1; ++u) {
+                    const int id = wave + CB_WAVES * u;
+                    av[q][u] = (ok && ko1[u] >= 0) ? (float)op[ko1[u]] : 0.f;
+                    g[q][u] = (ok && id < 4 * KG1) ? s_a1[mc * 68 + 16 * (id & 3) + j] : 0.f;
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < NW1; ++u)
+                    if (wave + CB_WAVES * u < 4 * KG1) {            // wave-uniform
+                        acc1[u] = MFMA16(av[q][u], g[q][u], acc1[u]);
+                        bs1[u] += g[q][u];
+                    }
         }
     }
 
@@ -732,10 +767,11 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     DQ_LAUNCH_CHECK();
 
     // ---- 4. fixed-order reductions of the partials into the flat gradient ------------------------------------------------
-    const int n_dense = (int)(Q->n_params - conv_floats);
-    reduce_slices_kernel<<<(n_dense + 255) / 256, 256, 0, st>>>(dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params);
-    DQ_LAUNCH_CHECK();
-    reduce_slices_kernel<<<((int)conv_floats + 255) / 256, 256, 0, st>>>(conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats);
+    ReduceArgs ra;
+    ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0};
+    const int blocks0 = ((int)conv_floats + 63) / 64, n_dense = (int)(Q->n_params - conv_floats);
+    ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, blocks0};
+    reduce_slices_kernel<<<blocks0 + (n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }
