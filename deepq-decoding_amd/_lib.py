@@ -36,6 +36,14 @@ class QNetCfg(ctypes.Structure):
                 ("max_batch", ctypes.c_int32)]
 
 
+class QNetJob(ctypes.Structure):
+    """dq_qnet_job (include/deepq_hip.h)."""
+    _fields_ = [("params_dev", ctypes.c_void_p), ("obs_dev", ctypes.c_void_p), ("index_dev", ctypes.c_void_p),
+                ("index_off", ctypes.c_int32), ("index_mod", ctypes.c_int32), ("batch", ctypes.c_int32), ("training", ctypes.c_int32),
+                ("seed", ctypes.c_uint32 * 2), ("t", ctypes.c_uint64), ("sample_base", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("q_dev", ctypes.c_void_p)]
+
+
 _vp, _i, _u32, _u64, _dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
 _sz = ctypes.c_size_t
 _seedp = ctypes.POINTER(ctypes.c_uint32)
@@ -67,6 +75,7 @@ SIGNATURES = {
     "dq_qnet_set_fused": (_i, [_vp, _i]),
     "dq_qnet_fused_supported": (_i, [_vp]),
     "dq_qnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
+    "dq_qnet_forward_multi": (_i, [_vp, _i, ctypes.POINTER(QNetJob), _vp]),
     "dq_qnet_backward": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dq_replay_sample": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
     "dq_td_target": (_i, [_vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _vp, _vp]),

@@ -57,20 +57,23 @@ class FullLoop:
         """family name -> (launches per vector step, algorithmic flops or bytes per vector step, bound).  One vector step =
         acting forward on n lattices + three forwards and one backward on the minibatch."""
         nc = len(C_LAYERS)
-        conv, dense = sum(self.layer_macs[:nc]), sum(self.layer_macs[nc:])
+        lm = self.layer_macs
+        conv, dense = sum(lm[:nc]), sum(lm[nc:])
         fwd_samples = self.n + 3 * self.B
-        fams = {
-            "conv_chain_kernel": (4, 2.0 * conv * fwd_samples, "mfma"),
-            "dense_chain_kernel": (4, 2.0 * dense * fwd_samples, "mfma"),
-            # backward: data gradients of every layer but the first, weight gradients of every layer
-            "gemm_fwd_kernel": (len(self.layer_macs) - 1, 2.0 * (self.macs - self.layer_macs[0]) * self.B, "mfma"),
-            "gemm_wgrad_kernel": (len(self.layer_macs), 2.0 * self.macs * self.B, "mfma"),
+        if self.net.fused_supported:
+            # two forward launch pairs per step (acting; the update's three forwards share one), one launch per backward kernel
+            return {
+                "conv_chain_kernel": (2, 2.0 * conv * fwd_samples, "mfma"),
+                "dense_chain_kernel": (2, 2.0 * dense * fwd_samples, "mfma"),
+                # conv weight gradients (= forward MACs) + data gradients through conv3 and conv2
+                "conv_bwd_chain_kernel": (1, 2.0 * (conv + sum(lm[1:nc])) * self.B, "mfma"),
+                "dense_bwd_chain_kernel": (1, 2.0 * dense * self.B, "mfma"),
+                "dense_wgrad_kernel": (1, 2.0 * dense * self.B, "mfma"),
+            }
+        return {
+            "gemm_fwd_kernel": (5 * len(lm) - 1, 2.0 * self.macs * fwd_samples + 2.0 * (self.macs - lm[0]) * self.B, "mfma"),
+            "gemm_wgrad_kernel": (len(lm), 2.0 * self.macs * self.B, "mfma"),
         }
-        if not self.net.fused_supported:
-            fams.pop("conv_chain_kernel"); fams.pop("dense_chain_kernel")
-            fams["gemm_fwd_kernel"] = (fams["gemm_fwd_kernel"][0] + 4 * len(self.layer_macs),
-                                       fams["gemm_fwd_kernel"][1] + 2.0 * self.macs * fwd_samples, "mfma")
-        return fams
 
     def _family_id(self, name):
         for i in range(self.L.dq_prof_kernel_count()):

@@ -113,15 +113,16 @@ class DQNCore:
         rows = T * N
         _q.replay_sample(self.terminal_ring, N, T, self.cur, self.filled, B, self.seed, t, sample_base=sample_base, out=self.index)
         net, ring = self.net, self.obs_ring
-        # Q_online(s1) picks the action, Q_target(s1) values it (double DQN); without it Q_target does both
-        net.forward(self.target, ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target)
+        # Q_online(s1) picks the action, Q_target(s1) values it (double DQN; without it Q_target does both); the training forward
+        # on s0 is independent of both, so the three share one pair of launches
+        jobs = [dict(params=self.target, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target)]
         if self.enable_double_dqn:
-            net.forward(self.params, ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online)
-            q_sel = self.q1_online
-        else:
-            q_sel = self.q1_target
+            jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online))
+        jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, training=True, seed=self.seed, t=t, sample_base=sample_base,
+                         out=self.q0))
+        net.forward_multi(jobs)
+        q_sel = self.q1_online if self.enable_double_dqn else self.q1_target
         _q.td_target(q_sel, self.q1_target, self.reward_ring, self.terminal_ring, self.gamma, index=self.index, out=self.y)
-        net.forward(self.params, ring, batch=B, index=self.index, training=True, seed=self.seed, t=t, sample_base=sample_base, out=self.q0)
         _q.td_loss_grad(self.q0, self.action_ring, self.y, grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, dq=self.dq,
                         metrics=self.metrics)
         net.backward(self.params, self.dq, grads=self.grads)

@@ -32,17 +32,25 @@
 #define CONV_LDS_MAX CHAIN_LDS_MAX
 
 // ---------------------------------------------------------------------------------------------------------------
-struct ConvChainArgs {
+// One launch serves up to FWD_MAX_JOBS independent forwards ("jobs": e.g. Q_target(s1), Q_online(s1) and the training forward
+// on s0 of one DQN update): with 16 samples per workgroup a single 4096-sample forward is one workgroup per CU, whose serial
+// phases (staging, epilogues, head layers) leave the matrix pipe idle; several jobs in one grid overlap them.
+struct ConvJob {
     const float* params;
     const u8* obs;
     const int32_t* index;
-    int index_off, index_mod;
-    int batch, S;
+    int index_off, index_mod, batch;
+    float* act_out[3];                 // global NHWC [batch*oh*ow, cout]; [2] always written
+    int write_all;                     // training: write every layer
+    int wg0;                           // first workgroup of this job
+};
+
+struct ConvChainArgs {
+    ConvJob job[FWD_MAX_JOBS];
+    int n_jobs, S;
     int C, H, W, k1, st1, K1;          // first convolution: input planes, kernel, stride, K = k1*k1*C
     int oh1, ow1, oh2, ow2, oh3, ow3;
     int w_off[3], b_off[3];            // floats into params
-    float* act_out[3];                 // global NHWC [batch*oh*ow, cout]; [2] always written
-    int write_all;                     // training: write every layer
     int slot;                          // bytes per sample slot in LDS (multiple of 4, >= C*H*W + 3)
     int off_mis, off_a1, off_a2;       // LDS byte offsets (observations at 0)
 };
@@ -119,12 +127,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1);
     float* s_a2 = reinterpret_cast<float*>(smem + a.off_a2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
-    const int b0 = blockIdx.x * a.S;
-    const int ns = min(a.S, a.batch - b0);
+    int jb = 0;
+    while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
+    const ConvJob& J = a.job[jb];
+    const int b0 = ((int)blockIdx.x - J.wg0) * a.S;
+    const int ns = min(a.S, J.batch - b0);
     const int in_bytes = a.C * a.H * a.W;
 
     // ---- first convolution's weights -> registers (the loads fly while the observations are staged) ----------------
-    const float* w1 = a.params + a.w_off[0];
+    const float* w1 = J.params + a.w_off[0];
     f32x4 b1[KG1][4];
     int ko[KG1][4];
 #pragma unroll
@@ -137,13 +148,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
             const int t = k / a.C, c = k - t * a.C, ky = t / a.k1, kx = t - ky * a.k1;      // Keras HWIO: k = (ky*k1 + kx)*C + c
             ko[g][s] = valid ? c * a.H * a.W + ky * a.W + kx : 0;                           // NCHW uint8 observation
         }
-    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.params + a.b_off[0] + 4 * j);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
 
     // ---- stage the observations: one wave per sample, aligned dwords of the (arbitrarily aligned) row ---------------
     for (int s = wave; s < ns; s += CONV_WAVES) {
         int row = b0 + s;
-        if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
-        const u8* src = a.obs + (size_t)row * in_bytes;
+        if (J.index) { row = J.index[row] + J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
+        const u8* src = J.obs + (size_t)row * in_bytes;
         const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
         const u8* win = src - mis;
         const int nd = (mis + in_bytes + 3) >> 2;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     // ---- convolution 1: A gathered byte-wise from the uint8 image ---------------------------------------------------
     {
         const int r1 = a.oh1 * a.ow1, M1 = ns * r1, tiles = (M1 + 15) >> 4;
-        float* g1 = a.write_all ? a.act_out[0] + (size_t)b0 * r1 * 64 : nullptr;
+        float* g1 = J.write_all ? J.act_out[0] + (size_t)b0 * r1 * 64 : nullptr;
         for (int tile = wave; tile < tiles; tile += CONV_WAVES) {
             int m = tile * 16 + j;
             if (m >= M1) m = M1 - 1;
@@ -202,24 +213,22 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     // ---- convolution 2 (64 -> 32, 2x2) and 3 (32 -> 32, 2x2) --------------------------------------------------------
     {
         const int r2 = a.oh2 * a.ow2;
-        conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, a.params + a.w_off[1], a.params + a.b_off[1], s_a2,
-                                 a.write_all ? a.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane);
+        conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, J.params + a.w_off[1], J.params + a.b_off[1], s_a2,
+                                 J.write_all ? J.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane);
     }
     __syncthreads();
     {
         const int r3 = a.oh3 * a.ow3;
-        conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, a.params + a.w_off[2], a.params + a.b_off[2], nullptr,
-                                 a.act_out[2] + (size_t)b0 * r3 * 32, wave, lane);
+        conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, J.params + a.w_off[2], J.params + a.b_off[2], nullptr,
+                                 J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct DenseChainArgs {
+struct DenseJob {
     const float* params;
     const float* x;                     // [batch, K1]: NHWC flatten of the last convolution
-    int batch, K1, perm_hw, perm_c;     // Keras Flatten: k = c*hw + p reads x[p*perm_c + c]
-    int N2, N3, n_actions;              // Dense(|A|) width, dueling layer width (0 = no dueling layer)
-    int w_off[3], b_off[3];
+    int batch;
     float keep_scale;                   // > 0: dropout active on the hidden layer's output
     u64 drop_T;
     u32 seed0, seed1, sample_base;
@@ -228,6 +237,15 @@ struct DenseChainArgs {
     float* y2_out;                      // training: [batch, N2]
     float* y3_out;                      // training: [batch, N3]
     float* q_out;                       // [batch, n_actions]
+    int wg0;                            // first workgroup of this job
+};
+
+struct DenseChainArgs {
+    DenseJob job[FWD_MAX_JOBS];
+    int n_jobs;
+    int K1, perm_hw, perm_c;            // Keras Flatten: k = c*hw + p reads x[p*perm_c + c]
+    int N2, N3, n_actions;              // Dense(|A|) width, dueling layer width (0 = no dueling layer)
+    int w_off[3], b_off[3];
     int ldx, ld2, ld3;                  // LDS row strides (floats)
     int off_x, off_h, off_part, off_y2, off_y3;
 };
@@ -242,12 +260,15 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     float* s_y3 = reinterpret_cast<float*>(smem + a.off_y3);
     constexpr int LDH = DENSE_HID + 4, PW = 16 * NT2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
-    const int b0 = blockIdx.x * DENSE_ROWS;
-    const int ns = min(DENSE_ROWS, a.batch - b0);
+    int jb = 0;
+    while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
+    const DenseJob& J = a.job[jb];
+    const int b0 = ((int)blockIdx.x - J.wg0) * DENSE_ROWS;
+    const int ns = min(DENSE_ROWS, J.batch - b0);
     const int K1 = a.K1, KG = K1 >> 4;
 
     // ---- hidden layer's first weight rows start flying before anything else ----------------------------------------
-    const float* w1 = a.params + a.w_off[0] + 64 * wave + 4 * j;
+    const float* w1 = J.params + a.w_off[0] + 64 * wave + 4 * j;
     f32x4 bA[4], bB[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) bA[s] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(4 * kq + s) * DENSE_HID);
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         for (int i = tid; i < DENSE_ROWS * q4; i += DENSE_THREADS) {
             const int r = i / q4, c4 = (i - r * q4) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < ns) v = *reinterpret_cast<const f32x4*>(a.x + (size_t)(b0 + r) * K1 + c4);
+            if (r < ns) v = *reinterpret_cast<const f32x4*>(J.x + (size_t)(b0 + r) * K1 + c4);
             if (a.perm_hw > 0) {
                 const int p = c4 / a.perm_c, c = c4 - p * a.perm_c;  // perm_c % 4 == 0: the four share p
 #pragma unroll
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     }
 
     // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
-    const float* w2 = a.params + a.w_off[1];
+    const float* w2 = J.params + a.w_off[1];
     const int kw0 = 64 * wave;
     float b2[4][4][NT2];
 #pragma unroll
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     const int NT3 = (a.N3 + 15) >> 4;
     float b3[KG3][4];
     if (wave < NT3) {
-        const float* w3 = a.params + a.w_off[2];
+        const float* w3 = J.params + a.w_off[2];
         const int col = 16 * wave + j;
 #pragma unroll
         for (int g = 0; g < KG3; ++g)
@@ -325,22 +346,22 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     // ---- hidden layer epilogue: bias, ReLU, dropout (one Philox call = this lane's 4 columns of a row) -----------------
     {
         const int c0 = 64 * wave + 4 * j;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.params + a.b_off[0] + c0);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + c0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * kq + r;
             f32x4 v;
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[t][r] + bias[t], 0.f);
-            if (a.keep_scale > 0.f) {
+            if (J.keep_scale > 0.f) {
                 u32 wd[4];
-                philox4x32_10((u32)a.t, (u32)(a.t >> 32), a.sample_base + (u32)(b0 + row), ((u32)c0 >> 2) | ((u32)DQ_STREAM_DROPOUT << 16),
-                              a.seed0, a.seed1, wd);
+                philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + row), ((u32)c0 >> 2) | ((u32)DQ_STREAM_DROPOUT << 16),
+                              J.seed0, J.seed1, wd);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = ((u64)wd[t] < a.drop_T) ? 0.f : v[t] * a.keep_scale;
+                for (int t = 0; t < 4; ++t) v[t] = ((u64)wd[t] < J.drop_T) ? 0.f : v[t] * J.keep_scale;
             }
             *reinterpret_cast<f32x4*>(s_h + row * LDH + c0) = v;
-            if (a.h1_out && row < ns) *reinterpret_cast<f32x4*>(a.h1_out + (size_t)(b0 + row) * DENSE_HID + c0) = v;
+            if (J.h1_out && row < ns) *reinterpret_cast<f32x4*>(J.h1_out + (size_t)(b0 + row) * DENSE_HID + c0) = v;
         }
     }
     __syncthreads();
@@ -367,11 +388,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     __syncthreads();
     for (int e = tid; e < DENSE_ROWS * a.N2; e += DENSE_THREADS) {
         const int row = e / a.N2, col = e - row * a.N2;
-        float v = a.params[a.b_off[1] + col];
+        float v = J.params[a.b_off[1] + col];
 #pragma unroll
         for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * 16 + row) * PW + col];
         s_y2[row * a.ld2 + col] = v;
-        if (a.y2_out && row < ns) a.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
+        if (J.y2_out && row < ns) J.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
     }
     __syncthreads();
 
@@ -390,13 +411,13 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             }
             const int col = 16 * wave + j;
             if (col < a.N3) {
-                const float bias = a.params[a.b_off[2] + col];
+                const float bias = J.params[a.b_off[2] + col];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * kq + r;
                     const float v = acc3[r] + bias;
                     s_y3[row * a.ld3 + col] = v;
-                    if (a.y3_out && row < ns) a.y3_out[(size_t)(b0 + row) * a.N3 + col] = v;
+                    if (J.y3_out && row < ns) J.y3_out[(size_t)(b0 + row) * a.N3 + col] = v;
                 }
             }
         }
@@ -412,9 +433,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             for (int c = lane; c < A; c += 64) s += yr[1 + c];
             for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
             const float base = yr[0] - s / (float)A;
-            for (int c = lane; c < A; c += 64) a.q_out[(size_t)(b0 + row) * A + c] = base + yr[1 + c];
+            for (int c = lane; c < A; c += 64) J.q_out[(size_t)(b0 + row) * A + c] = base + yr[1 + c];
         } else {
-            for (int c = lane; c < A; c += 64) a.q_out[(size_t)(b0 + row) * A + c] = yr[c];
+            for (int c = lane; c < A; c += 64) J.q_out[(size_t)(b0 + row) * A + c] = yr[c];
         }
     }
 }
@@ -480,13 +501,11 @@ bool fused_forward_supported(const dq_qnet* Q) {
 typedef void (*conv_kernel_t)(ConvChainArgs);
 typedef void (*dense_kernel_t)(DenseChainArgs);
 
-dq_status fused_forward(dq_qnet* Q, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev, int index_off,
-                        int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t, uint32_t sample_base,
-                        float* q_dev, hipStream_t st) {
+dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st) {
     ConvPlan cp;
     DensePlan dp;
     DQ_REQUIRE(plan_conv(Q, &cp) && plan_dense(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_forward: configuration not covered");
-    DQ_REQUIRE((reinterpret_cast<uintptr_t>(params_dev) & 15) == 0, DQ_ERR_INVALID, "fused_forward: params_dev must be 16-byte aligned");
+    DQ_REQUIRE(n_jobs >= 1 && n_jobs <= FWD_MAX_JOBS, DQ_ERR_INVALID, "fused_forward: 1..%d jobs per launch", FWD_MAX_JOBS);
     conv_kernel_t ck = cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
     dense_kernel_t dk = dp.NT2 == 4 ? dense_chain_kernel<4, 4> : dense_chain_kernel<7, 7>;
     static bool attr_set = false;
@@ -498,45 +517,61 @@ dq_status fused_forward(dq_qnet* Q, const float* params_dev, const uint8_t* obs_
         DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain_kernel<7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         attr_set = true;
     }
-    const int set = training ? 0 : 1, nc = Q->cfg.n_conv;
+    const int nc = Q->cfg.n_conv;
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
     ConvChainArgs ca;
+    DenseChainArgs da;
     memset(&ca, 0, sizeof(ca));
-    ca.params = params_dev; ca.obs = obs_dev; ca.index = index_dev; ca.index_off = index_off;
-    ca.index_mod = index_mod > 0 ? index_mod : 0x7fffffff;
-    ca.batch = batch; ca.S = cp.S;
+    memset(&da, 0, sizeof(da));
+    ca.n_jobs = da.n_jobs = n_jobs; ca.S = cp.S;
     ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
-    for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; ca.act_out[l] = Q->act[set][l]; }
-    ca.write_all = training ? 1 : 0;
+    for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2;
-    dq_prof_begin(DQ_K_CONV_CHAIN, st);
-    ck<<<(batch + cp.S - 1) / cp.S, CONV_THREADS, cp.lds, st>>>(ca);
-    dq_prof_end(DQ_K_CONV_CHAIN, st);
-    DQ_LAUNCH_CHECK();
-
-    const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
-    DenseChainArgs da;
-    memset(&da, 0, sizeof(da));
-    da.params = params_dev; da.x = Q->act[set][nc - 1];
-    da.batch = batch; da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
+    da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < Q->n_layers - nc; ++l) { da.w_off[l] = (int)Q->L[nc + l].w_off; da.b_off[l] = (int)Q->L[nc + l].b_off; }
-    if (training && D1.dropout > 0.f) {
-        da.keep_scale = (float)(1.0 / (1.0 - (double)D1.dropout));
-        da.drop_T = dq_rate_threshold((double)D1.dropout);
-    }
-    if (seed) { da.seed0 = seed[0]; da.seed1 = seed[1]; }
-    da.sample_base = sample_base; da.t = t;
-    if (training) {
-        da.h1_out = Q->act[set][nc]; da.y2_out = Q->act[set][nc + 1];
-        da.y3_out = Q->cfg.dueling ? Q->act[set][nc + 2] : nullptr;
-    }
-    da.q_out = q_dev;
     da.ldx = dp.ldx; da.ld2 = dp.ld2; da.ld3 = dp.ld3;
     da.off_x = dp.off_x; da.off_h = dp.off_h; da.off_part = dp.off_part; da.off_y2 = dp.off_y2; da.off_y3 = dp.off_y3;
+    int conv_wgs = 0, dense_wgs = 0, n_train = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const dq_qnet_job& jb = jobs[i];
+        DQ_REQUIRE(jb.params_dev && jb.obs_dev && jb.q_dev, DQ_ERR_INVALID, "dq_qnet_forward: null argument (job %d)", i);
+        DQ_REQUIRE(jb.batch >= 1 && jb.batch <= Q->cfg.max_batch, DQ_ERR_INVALID, "dq_qnet_forward: batch %d outside 1..%d", jb.batch, Q->cfg.max_batch);
+        DQ_REQUIRE((reinterpret_cast<uintptr_t>(jb.params_dev) & 15) == 0, DQ_ERR_INVALID, "fused_forward: params_dev must be 16-byte aligned");
+        const int training = jb.training ? 1 : 0;
+        n_train += training;
+        DQ_REQUIRE(n_train <= 1, DQ_ERR_INVALID, "dq_qnet_forward_multi: at most one training job per launch");
+        float* x = training ? Q->act[0][nc - 1] : Q->xinf[i];      // conv3 output: saved for backward / per-job scratch
+        ConvJob& C = ca.job[i];
+        C.params = jb.params_dev; C.obs = jb.obs_dev; C.index = jb.index_dev; C.index_off = jb.index_off;
+        C.index_mod = jb.index_mod > 0 ? jb.index_mod : 0x7fffffff;
+        C.batch = jb.batch; C.write_all = training; C.wg0 = conv_wgs;
+        C.act_out[0] = Q->act[0][0]; C.act_out[1] = Q->act[0][1]; C.act_out[2] = x;
+        conv_wgs += (jb.batch + cp.S - 1) / cp.S;
+        DenseJob& D = da.job[i];
+        D.params = jb.params_dev; D.x = x; D.batch = jb.batch; D.wg0 = dense_wgs;
+        if (training && D1.dropout > 0.f) {
+            D.keep_scale = (float)(1.0 / (1.0 - (double)D1.dropout));
+            D.drop_T = dq_rate_threshold((double)D1.dropout);
+        }
+        D.seed0 = jb.seed[0]; D.seed1 = jb.seed[1]; D.sample_base = jb.sample_base; D.t = jb.t;
+        if (training) {
+            D.h1_out = Q->act[0][nc]; D.y2_out = Q->act[0][nc + 1];
+            D.y3_out = Q->cfg.dueling ? Q->act[0][nc + 2] : nullptr;
+            Q->last_train_batch = jb.batch; Q->last_obs = jb.obs_dev; Q->last_index = jb.index_dev;
+            Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod;
+        }
+        D.q_out = jb.q_dev;
+        dense_wgs += (jb.batch + DENSE_ROWS - 1) / DENSE_ROWS;
+    }
+    dq_prof_begin(DQ_K_CONV_CHAIN, st);
+    ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
+    dq_prof_end(DQ_K_CONV_CHAIN, st);
+    DQ_LAUNCH_CHECK();
     dq_prof_begin(DQ_K_DENSE_CHAIN, st);
-    dk<<<(batch + DENSE_ROWS - 1) / DENSE_ROWS, DENSE_THREADS, dp.lds, st>>>(da);
+    dk<<<dense_wgs, DENSE_THREADS, dp.lds, st>>>(da);
     dq_prof_end(DQ_K_DENSE_CHAIN, st);
     DQ_LAUNCH_CHECK();
     return DQ_OK;

@@ -3,6 +3,7 @@
 #include "common.h"
 
 #define QN_MAX_LAYERS 12
+#define FWD_MAX_JOBS 4               // forwards served by one fused launch (dq_qnet_forward_multi)
 
 struct Layer {
     int kind;                    // 0 conv, 1 dense
@@ -27,6 +28,7 @@ struct dq_qnet {
     const uint8_t* last_obs;     // inputs of the last training forward (needed by conv1's weight gradient)
     const int32_t* last_index;
     int last_index_off, last_index_mod;
+    float* xinf[FWD_MAX_JOBS];   // fused inference forwards: last-convolution output per job slot [max_batch, flat]
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
     int use_fused;               // 1: fused LDS-resident forward when the configuration allows it
 };
@@ -45,9 +47,7 @@ static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);
-dq_status fused_forward(dq_qnet* Q, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev, int index_off,
-                        int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t, uint32_t sample_base,
-                        float* q_dev, hipStream_t st);
+dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
 dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_t st);

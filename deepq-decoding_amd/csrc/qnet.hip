@@ -396,6 +396,10 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         max_partial = p > max_partial ? p : max_partial;
     }
     if (e == hipSuccess) e = hipMalloc(&Q->partial, max_partial * sizeof(float));
+    if (fused_forward_supported(Q)) {
+        const size_t xf = (size_t)cfg->max_batch * Q->L[cfg->n_conv].nin;
+        for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->xinf[i], xf * sizeof(float));
+    }
     const size_t fws = fused_backward_workspace_floats(Q);
     if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));
     Q->partial_floats = max_partial;
@@ -411,6 +415,7 @@ void dq_qnet_destroy(dq_qnet* Q) {
     for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->gz[i]) (void)hipFree(Q->gz[i]);
     if (Q->partial) (void)hipFree(Q->partial);
     if (Q->fpartial) (void)hipFree(Q->fpartial);
+    for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->xinf[i]) (void)hipFree(Q->xinf[i]);
     delete Q;
 }
 
@@ -448,13 +453,13 @@ dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* ob
     const int set = training ? 0 : 1;
     const float* x = nullptr;
     if (Q->use_fused && fused_forward_supported(Q)) {
-        const dq_status rc = fused_forward(Q, params_dev, obs_dev, index_dev, index_off, index_mod, batch, training, seed, t, sample_base, q_dev, st);
-        if (rc != DQ_OK) return rc;
-        if (training) {
-            Q->last_train_batch = batch; Q->last_obs = obs_dev; Q->last_index = index_dev;
-            Q->last_index_off = index_off; Q->last_index_mod = index_mod;
-        }
-        return DQ_OK;
+        dq_qnet_job jb;
+        memset(&jb, 0, sizeof(jb));
+        jb.params_dev = params_dev; jb.obs_dev = obs_dev; jb.index_dev = index_dev; jb.index_off = index_off; jb.index_mod = index_mod;
+        jb.batch = batch; jb.training = training;
+        if (seed) { jb.seed[0] = seed[0]; jb.seed[1] = seed[1]; }
+        jb.t = t; jb.sample_base = sample_base; jb.q_dev = q_dev;
+        return fused_forward_multi(Q, 1, &jb, st);
     }
     for (int i = 0; i < Q->n_layers; ++i) {
         const Layer& L = Q->L[i];
@@ -502,6 +507,21 @@ dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* ob
     if (training) {
         Q->last_train_batch = batch; Q->last_obs = obs_dev; Q->last_index = index_dev;
         Q->last_index_off = index_off; Q->last_index_mod = index_mod;
+    }
+    return DQ_OK;
+}
+
+dq_status dq_qnet_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, void* stream) {
+    DQ_REQUIRE(Q && jobs && n_jobs >= 1, DQ_ERR_INVALID, "dq_qnet_forward_multi: null argument");
+    if (Q->use_fused && fused_forward_supported(Q) && n_jobs <= FWD_MAX_JOBS) return fused_forward_multi(Q, n_jobs, jobs, (hipStream_t)stream);
+    int n_train = 0;
+    for (int i = 0; i < n_jobs; ++i) n_train += jobs[i].training ? 1 : 0;
+    DQ_REQUIRE(n_train <= 1, DQ_ERR_INVALID, "dq_qnet_forward_multi: at most one training job per launch");
+    for (int i = 0; i < n_jobs; ++i) {                             // per-layer path: one forward after the other
+        const dq_qnet_job& jb = jobs[i];
+        const dq_status rc = dq_qnet_forward(Q, jb.params_dev, jb.obs_dev, jb.index_dev, jb.index_off, jb.index_mod, jb.batch, jb.training, jb.seed,
+                                             jb.t, jb.sample_base, jb.q_dev, stream);
+        if (rc != DQ_OK) return rc;
     }
     return DQ_OK;
 }

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib, _philox
-from ._lib import QNetCfg, check, ptr
+from ._lib import QNetCfg, QNetJob, check, ptr
 
 
 TD_METRICS_FLOATS = 2050      # include/deepq_hip.h DQ_TD_METRICS_FLOATS
@@ -126,6 +126,36 @@ class QNetwork:
         if training:
             self._train_inputs = (obs, index)       # backward re-reads them (conv1 weight gradient): keep them alive
         return out
+
+    def forward_multi(self, jobs):
+        """Several forwards in one pair of launches (dq_qnet_forward_multi).  `jobs`: list of dicts with the keyword arguments
+        of forward() (params, obs, batch, index, index_off, index_mod, training, seed, t, sample_base, out); at most one
+        training job.  Returns the list of outputs."""
+        arr = (QNetJob * len(jobs))()
+        outs = []
+        for jb, kw in zip(arr, jobs):
+            params, obs, index = kw["params"], kw["obs"], kw.get("index")
+            assert params.dtype == torch.float32 and params.is_cuda and params.numel() == self.n_params
+            assert obs.dtype == torch.uint8 and obs.is_cuda and obs.is_contiguous()
+            batch = kw.get("batch")
+            if batch is None:
+                batch = obs.shape[0] if index is None else index.shape[0]
+            if index is not None:
+                assert index.dtype == torch.int32 and index.is_cuda and index.is_contiguous()
+            out = kw.get("out")
+            if out is None:
+                out = torch.empty((batch, self.n_actions), dtype=torch.float32, device=self.device)
+            seed = kw.get("seed", (0, 0))
+            jb.params_dev, jb.obs_dev, jb.index_dev = ptr(params), ptr(obs), ptr(index)
+            jb.index_off, jb.index_mod, jb.batch = int(kw.get("index_off", 0)), int(kw.get("index_mod", 0)), int(batch)
+            jb.training = int(bool(kw.get("training", False)))
+            jb.seed[0], jb.seed[1] = int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF
+            jb.t, jb.sample_base, jb.q_dev = int(kw.get("t", 0)), int(kw.get("sample_base", 0)), ptr(out)
+            if jb.training:
+                self._train_inputs = (obs, index)
+            outs.append(out)
+        check(self.L.dq_qnet_forward_multi(self._h, len(jobs), arr, self._stream()))
+        return outs
 
     def backward(self, params, dq, grads=None):
         assert dq.dtype == torch.float32 and dq.is_cuda and dq.is_contiguous()

@@ -204,6 +204,21 @@ dq_status dq_qnet_forward(dq_qnet* net, const float* params_dev, const uint8_t* 
                           int index_off, int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t,
                           uint32_t sample_base, float* q_dev, void* stream);
 
+/* Several forwards in ONE pair of launches (e.g. Q_target(s1), Q_online(s1) and the training forward on s0 of one DQN
+ * update): each job has the meaning of one dq_qnet_forward call; at most 4 jobs, at most one of them training.  With the
+ * fused chains a lone 4096-sample forward is one workgroup per CU; sharing a grid lets the jobs' phases overlap. */
+typedef struct {
+    const float* params_dev;
+    const uint8_t* obs_dev;
+    const int32_t* index_dev;   /* nullable */
+    int32_t index_off, index_mod, batch, training;
+    uint32_t seed[2];
+    uint64_t t;
+    uint32_t sample_base, reserved;
+    float* q_dev;
+} dq_qnet_job;
+dq_status dq_qnet_forward_multi(dq_qnet* net, int n_jobs, const dq_qnet_job* jobs, void* stream);
+
 /* Backward half of train_on_batch: grads_dev[n_params] = d/dparams sum(dq * Q) for the last training forward
  * (obs_dev / index_dev of that call must still be valid).  Deterministic (fixed-order reductions). */
 dq_status dq_qnet_backward(dq_qnet* net, const float* params_dev, const float* dq_dev, float* grads_dev, void* stream);
