@@ -51,6 +51,7 @@ struct ConvChainArgs {
     int C, H, W, k1, st1, K1;          // first convolution: input planes, kernel, stride, K = k1*k1*C
     int oh1, ow1, oh2, ow2, oh3, ow3;
     int w_off[3], b_off[3];            // floats into params
+    const int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an observation, -1 past K1
     int slot;                          // bytes per sample slot in LDS (multiple of 4, >= C*H*W + 3)
     int off_mis, off_a1, off_a2;       // LDS byte offsets (observations at 0)
 };
@@ -143,35 +144,46 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = 16 * g + 4 * kq + s;
-            const bool valid = k < a.K1;
-            b1[g][s] = valid ? *reinterpret_cast<const f32x4*>(w1 + (size_t)k * 64 + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const int t = k / a.C, c = k - t * a.C, ky = t / a.k1, kx = t - ky * a.k1;      // Keras HWIO: k = (ky*k1 + kx)*C + c
-            ko[g][s] = valid ? c * a.H * a.W + ky * a.W + kx : 0;                           // NCHW uint8 observation
+            const int off = a.kofftab[k];                           // Keras HWIO row k = (ky*k1 + kx)*C + c -> NCHW uint8 offset
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + (size_t)(off >= 0 ? k : 0) * 64 + 4 * j);
+            b1[g][s] = off >= 0 ? wv : f32x4{0.f, 0.f, 0.f, 0.f};
+            ko[g][s] = off >= 0 ? off : 0;
         }
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
 
-    // ---- stage the observations: one wave per sample, aligned dwords of the (arbitrarily aligned) row ---------------
-    for (int s = wave; s < ns; s += CONV_WAVES) {
-        int row = b0 + s;
-        if (J.index) { row = J.index[row] + J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
-        const u8* src = J.obs + (size_t)row * in_bytes;
-        const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
-        const u8* win = src - mis;
-        const int nd = (mis + in_bytes + 3) >> 2;
-        u32* dst = reinterpret_cast<u32*>(s_in + s * a.slot);
-        for (int d = lane; d < nd; d += 64) {
-            u32 v = 0;
-            if (4 * d >= mis && 4 * d + 4 <= mis + in_bytes) {
-                v = reinterpret_cast<const u32*>(win)[d];
-            } else {                                                // first / last partial dword: never read outside the row
-                for (int bb = 0; bb < 4; ++bb) {
-                    const int o = 4 * d + bb;
-                    if (o >= mis && o < mis + in_bytes) v |= (u32)win[o] << (8 * bb);
-                }
-            }
-            dst[d] = v;
+    // ---- stage the observations: thread t copies aligned dword t (t + 256, ...) of every sample's (arbitrarily aligned) row;
+    //      all of a thread's loads are independent, so the gather costs one memory latency ---------------------------
+    {
+        int rows[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            int row = b0 + (s < ns ? s : 0);
+            if (J.index) { row = J.index[row] + J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
+            rows[s] = row;
         }
-        if (lane == 0) s_mis[s] = mis;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s < ns) {                                           // block-uniform
+                const u8* src = J.obs + (size_t)rows[s] * in_bytes;
+                const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
+                const u8* win = src - mis;
+                const int nd = (mis + in_bytes + 3) >> 2;
+                u32* dst = reinterpret_cast<u32*>(s_in + s * a.slot);
+                for (int d = tid; d < nd; d += CONV_THREADS) {
+                    u32 v = 0;
+                    if (4 * d >= mis && 4 * d + 4 <= mis + in_bytes) {
+                        v = reinterpret_cast<const u32*>(win)[d];
+                    } else {                                        // first / last partial dword: never read outside the row
+                        for (int bb = 0; bb < 4; ++bb) {
+                            const int o = 4 * d + bb;
+                            if (o >= mis && o < mis + in_bytes) v |= (u32)win[o] << (8 * bb);
+                        }
+                    }
+                    dst[d] = v;
+                }
+                if (tid == 0) s_mis[s] = mis;
+            }
+        }
     }
     __syncthreads();
 
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     float* s_y2 = reinterpret_cast<float*>(smem + a.off_y2);
     float* s_y3 = reinterpret_cast<float*>(smem + a.off_y3);
     constexpr int LDH = DENSE_HID + 4, PW = 16 * NT2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     int jb = 0;
     while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
     const DenseJob& J = a.job[jb];
@@ -318,28 +330,47 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 
     // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
     const float* w2 = J.params + a.w_off[1];
+    // Dense(|A|) splits K = 512 into 8 parts of 64 rows, one per wave, every column tile in each.  Tile t, lane j is column
+    // NT2*j + t, so a lane's NT2 weights of a row are NT2 consecutive floats: NT2/4 dwordx4 loads (rows are only 4-byte aligned,
+    // which global_load_dwordx4 accepts) instead of NT2 scalar gathers -- a wave can only have 63 loads in flight.
     const int kw0 = 64 * wave;
     float b2[4][4][NT2];
+    {
+        const float* wpart = w2 + (size_t)kw0 * a.N2;               // wave-uniform
+        int loff[NT2 / 4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+        for (int q = 0; q < NT2 / 4; ++q) {
+            const int c0 = NT2 * j + 4 * q;
+            loff[q] = 4 * kq * a.N2 + (c0 < a.N2 ? c0 : 0);
+        }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int t = 0; t < NT2; ++t) {
-                const int col = 16 * t + j;
-                b2[g][s][t] = col < a.N2 ? w2[(size_t)(kw0 + 16 * g + 4 * kq + s) * a.N2 + col] : 0.f;
+            for (int s = 0; s < 4; ++s) {
+                const float* wrow = wpart + (16 * g + s) * a.N2;       // uniform
+#pragma unroll
+                for (int q = 0; q < NT2 / 4; ++q) {
+                    const f32x4u v = *reinterpret_cast<const f32x4u*>(wrow + loff[q]);     // unconditional load, then select
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b2[g][s][4 * q + e] = (NT2 * j + 4 * q + e < a.N2) ? v[e] : 0.f;
+                }
             }
+    }
     const int NT3 = (a.N3 + 15) >> 4;
     float b3[KG3][4];
     if (wave < NT3) {
         const float* w3 = J.params + a.w_off[2];
         const int col = 16 * wave + j;
+        const bool cok = col < a.N3;
+        const int loff = 4 * kq * a.N3 + (cok ? col : 0);
 #pragma unroll
         for (int g = 0; g < KG3; ++g)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int k = 16 * g + 4 * kq + s;
-                b3[g][s] = (k < a.N2 && col < a.N3) ? w3[(size_t)k * a.N3 + col] : 0.f;
+                const bool okb = cok && k < a.N2;
+                const float v = w3[okb ? (16 * g + s) * a.N3 + loff : 0];
+                b3[g][s] = okb ? v : 0.f;
             }
     }
 
@@ -381,9 +412,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 for (int t = 0; t < NT2; ++t) acc2[t] = MFMA16(av[s], b2[g][s][t], acc2[t]);
         }
 #pragma unroll
-        for (int t = 0; t < NT2; ++t)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_part[(wave * 16 + 4 * kq + r) * PW + 16 * t + j] = acc2[t][r];
+            for (int q = 0; q < NT2 / 4; ++q)                       // this lane's columns NT2*j + 4q .. +3 of row 4kq + r
+                *reinterpret_cast<f32x4*>(s_part + (wave * 16 + 4 * kq + r) * PW + NT2 * j + 4 * q) =
+                    f32x4{acc2[4 * q][r], acc2[4 * q + 1][r], acc2[4 * q + 2][r], acc2[4 * q + 3][r]};
     }
     __syncthreads();
     for (int e = tid; e < DENSE_ROWS * a.N2; e += DENSE_THREADS) {
@@ -477,15 +510,15 @@ static bool plan_dense(const dq_qnet* Q, DensePlan* P) {
     const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
     if (D1.nout != DENSE_HID || (D1.nin & 31) || (Q->flat_c & 3)) return false;
     const int N2 = D2.nout, N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0;
-    if (N2 > 112 || N3 > 128) return false;
-    P->NT2 = N2 <= 64 ? 4 : 7;
+    if (N2 > 128 || N3 > 128) return false;
+    P->NT2 = N2 <= 64 ? 4 : 8;
     P->ldx = D1.nin + 4;
     P->ld2 = 16 * P->NT2 + 4;
     P->ld3 = 16 * ((N3 + 15) / 16) + 1;
     size_t off = 0;
-    P->off_x = (int)off; off += up16((size_t)DENSE_ROWS * P->ldx * 4);
+    const size_t xb = up16((size_t)DENSE_ROWS * P->ldx * 4), pb = up16((size_t)DENSE_WAVES * 16 * 16 * P->NT2 * 4);
+    P->off_x = P->off_part = (int)off; off += xb > pb ? xb : pb;   // the Dense(|A|) partials reuse the input image (dead by then)
     P->off_h = (int)off; off += up16((size_t)DENSE_ROWS * (DENSE_HID + 4) * 4);
-    P->off_part = (int)off; off += up16((size_t)DENSE_WAVES * 16 * 16 * P->NT2 * 4);
     P->off_y2 = (int)off; off += up16((size_t)DENSE_ROWS * P->ld2 * 4);
     P->off_y3 = (int)off; off += up16((size_t)DENSE_ROWS * P->ld3 * 4);
     P->lds = off;
@@ -507,14 +540,14 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     DQ_REQUIRE(plan_conv(Q, &cp) && plan_dense(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_forward: configuration not covered");
     DQ_REQUIRE(n_jobs >= 1 && n_jobs <= FWD_MAX_JOBS, DQ_ERR_INVALID, "fused_forward: 1..%d jobs per launch", FWD_MAX_JOBS);
     conv_kernel_t ck = cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
-    dense_kernel_t dk = dp.NT2 == 4 ? dense_chain_kernel<4, 4> : dense_chain_kernel<7, 7>;
+    dense_kernel_t dk = dp.NT2 == 4 ? dense_chain_kernel<4, 4> : dense_chain_kernel<8, 8>;
     static bool attr_set = false;
     if (!attr_set) {
         const conv_kernel_t cks[4] = {conv_chain_kernel<3>, conv_chain_kernel<4>, conv_chain_kernel<5>, conv_chain_kernel<6>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain_kernel<7, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         attr_set = true;
     }
     const int nc = Q->cfg.n_conv;
@@ -528,6 +561,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
+    ca.kofftab = Q->kofftab;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2;
     da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;

@@ -29,6 +29,7 @@ struct dq_qnet {
     const int32_t* last_index;
     int last_index_off, last_index_mod;
     float* xinf[FWD_MAX_JOBS];   // fused inference forwards: last-convolution output per job slot [max_batch, flat]
+    int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an NCHW uint8 observation, -1 past K
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
     int use_fused;               // 1: fused LDS-resident forward when the configuration allows it
 };
@@ -37,6 +38,7 @@ struct dq_qnet {
 // ---- shared by the fused chains (fused.hip forward, fused_bwd.hip backward) ---------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned: global_load_dwordx4 accepts it
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define CHAIN_LDS_MAX (160 * 1024)
 #define DENSE_THREADS 512

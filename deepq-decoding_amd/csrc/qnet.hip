@@ -396,7 +396,17 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         max_partial = p > max_partial ? p : max_partial;
     }
     if (e == hipSuccess) e = hipMalloc(&Q->partial, max_partial * sizeof(float));
-    if (fused_forward_supported(Q)) {
+    if (e == hipSuccess) {
+        int tab[96];
+        const Layer& L1 = Q->L[0];
+        for (int k = 0; k < 96; ++k) {
+            const int t = k / L1.cin, c = k - t * L1.cin, ky = t / L1.k, kx = t - ky * L1.k;
+            tab[k] = k < L1.K ? c * L1.ih * L1.iw + ky * L1.iw + kx : -1;
+        }
+        e = hipMalloc(&Q->kofftab, sizeof(tab));
+        if (e == hipSuccess) e = hipMemcpy(Q->kofftab, tab, sizeof(tab), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && fused_forward_supported(Q)) {
         const size_t xf = (size_t)cfg->max_batch * Q->L[cfg->n_conv].nin;
         for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->xinf[i], xf * sizeof(float));
     }
@@ -415,6 +425,7 @@ void dq_qnet_destroy(dq_qnet* Q) {
     for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->gz[i]) (void)hipFree(Q->gz[i]);
     if (Q->partial) (void)hipFree(Q->partial);
     if (Q->fpartial) (void)hipFree(Q->fpartial);
+    if (Q->kofftab) (void)hipFree(Q->kofftab);
     for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->xinf[i]) (void)hipFree(Q->xinf[i]);
     delete Q;
 }
