@@ -11,8 +11,39 @@
 // still run through qnet.hip's per-layer kernels (layer_wgrad / layer_dgrad).
 #include "qnet.h"
 
+// The data gradients multiply by W^T.  With W row-major, the 16 lanes of a quarter-wave that supply 16 different output
+// columns of an MFMA B operand would read 16 different rows of W -- 16 cache lines per quarter-wave request, which makes the
+// vector L1's tag path (not the matrix pipe) the bound.  So every backward first writes the transposes of the weights it
+// needs into a workspace (one small launch, ~0.8 MB), and the chains below read those with row-contiguous vector loads:
+//   W1T [512][K1], W2T [N2][512].
+#define TR_MAX_ITEMS 4
+struct TrItem { const float* src; float* dst; int R, C, tile0, tiles_c; };      // dst[c][r] = src[r][c]
+struct TrArgs { TrItem it[TR_MAX_ITEMS]; int n; };
+
+__global__ __launch_bounds__(256) void transpose_weights_kernel(TrArgs a) {
+    __shared__ float tile[32][33];
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.it[i + 1].tile0) ++i;            // block-uniform
+    const TrItem& T = a.it[i];
+    const int tl = (int)blockIdx.x - T.tile0, tr = tl / T.tiles_c, tc = tl - tr * T.tiles_c;
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = tr * 32 + y + 8 * k, c = tc * 32 + x;
+        if (r < T.R && c < T.C) tile[y + 8 * k][x] = T.src[(size_t)r * T.C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = tc * 32 + y + 8 * k, r = tr * 32 + x;
+        if (r < T.R && c < T.C) T.dst[(size_t)c * T.R + r] = tile[x][y + 8 * k];
+    }
+}
+
 struct DenseBwdArgs {
     const float* params;
+    const float* w1t;                   // [512][K1] transposed hidden-layer kernel
+    const float* w2t;                   // [N2][512] transposed Dense(|A|) kernel
     const float* dq;                    // [batch, n_actions]
     const float* h1;                    // saved hidden output (post ReLU + dropout): mask of gH1
     const float* x;                     // saved last-convolution output [batch, K1] (NHWC): mask of gX
@@ -27,6 +58,61 @@ struct DenseBwdArgs {
     int ldg;                            // LDS row stride of the g3 / gY2 images (floats)
     int off_g3, off_gy2, off_gh1;
 };
+
+// NTP adjacent column tiles [tile0, tile0 + NTP) of gX for this wave: tile t, lane j is column 16*tile0 + NTP*j + t, so the lane's
+// NTP weights of a W1T row are NTP consecutive floats (one dwordx2/x3 load, 4-byte aligned); weights double-buffered.
+template <int NTP>
+__device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const float* __restrict__ s_gh1, int tile0, int b0, int ns, int lane) {
+    typedef float vec_t __attribute__((ext_vector_type(NTP == 3 ? 3 : NTP == 2 ? 2 : 1), aligned(4)));
+    constexpr int LDH = DENSE_HID + 4, NG = DENSE_HID / 16;
+    const int j = lane & 15, kq = lane >> 4, K1 = a.K1;
+    const float* wp = a.w1t + (size_t)(4 * kq) * K1 + 16 * tile0 + NTP * j;
+    const float* hrow = s_gh1 + j * LDH + 4 * kq;
+    float bA[4][NTP], bB[4][NTP];
+    auto load = [&](int g, float (&bw)[4][NTP]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if constexpr (NTP == 1) {
+                bw[s][0] = wp[(size_t)(16 * g + s) * K1];
+            } else {
+                const vec_t v = *reinterpret_cast<const vec_t*>(wp + (size_t)(16 * g + s) * K1);
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) bw[s][t] = v[t];
+            }
+        }
+    };
+    f32x4 acc[NTP];
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load(0, bA);
+    for (int g = 0; g < NG; g += 2) {
+        load(g + 1, bB);
+        f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 16 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) acc[t] = MFMA16(av[s], bA[s][t], acc[t]);
+        load(g + 2 < NG ? g + 2 : g, bA);                           // unconditional (clamped): keeps the s_waitcnt counts static
+        av = *reinterpret_cast<const f32x4*>(hrow + 16 * (g + 1));
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) acc[t] = MFMA16(av[s], bB[s][t], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) {
+        const int k = 16 * tile0 + NTP * j + t;                     // Keras Flatten index c*hw + p  ->  NHWC offset p*C + c
+        int idx = k;
+        if (a.perm_hw > 0) { const int c = k / a.perm_hw, p = k - c * a.perm_hw; idx = p * a.perm_c + c; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            if (row >= ns) continue;
+            const size_t o = (size_t)(b0 + row) * K1 + idx;
+            a.gx[o] = a.x[o] > 0.f ? acc[t][r] : 0.f;
+        }
+    }
+}
 
 template <int NT2>                      // N2 <= 16*NT2 and N3 <= 16*NT2
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(DenseBwdArgs a) {
@@ -99,16 +185,15 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     }
     // ---- gH1 = (gY2 W2^T) * [h1 > 0] * scale  (K = N2; wave w owns columns 64w + 4j + t) ----------------------------------
     {
-        const float* w2 = a.params + a.w_off[1];
         const int c0 = 64 * wave + 4 * j;
-        float b[NT2][4][4];
+        f32x4 b[NT2][4];                                            // B(n2, n1) = W2T[n2][n1]: one float4 = this lane's 4 column tiles
 #pragma unroll
         for (int g = 0; g < NT2; ++g)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int k2 = 16 * g + 4 * kq + s;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) b[g][s][t] = k2 < N2 ? w2[(size_t)(c0 + t) * N2 + k2] : 0.f;      // B(n2, n1) = W2[n1][n2]
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.w2t + (size_t)(k2 < N2 ? k2 : 0) * DENSE_HID + c0);
+                b[g][s] = k2 < N2 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         f32x4 hv[4];
 #pragma unroll
@@ -139,64 +224,18 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         }
     }
     __syncthreads();
-    // ---- gX = (gH1 W1^T) * [x > 0]  (K = 512): column k = 16T + j of tile T is ROW k of W1 -> float4 along the reduction ----
+    // ---- gX = (gH1 W1T) * [x > 0]  (K = 512): each wave owns a run of adjacent column tiles (counts differ by at most one, the
+    //      longer runs on different SIMDs), taken up to three at a time with interleaved columns ---------------------------------
     {
-        const float* w1 = a.params + a.w_off[0];
-        const int tiles = a.K1 >> 4;
-        const float* hrow = s_gh1 + j * LDH + 4 * kq;
-        for (int T0 = wave; T0 < tiles; T0 += 3 * DENSE_WAVES) {
-            bool ok[3];
-            const float* wr[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int T = T0 + u * DENSE_WAVES;
-                ok[u] = T < tiles;                                  // wave-uniform
-                wr[u] = w1 + (size_t)(16 * (ok[u] ? T : T0) + j) * DENSE_HID + 4 * kq;
-            }
-            f32x4 acc[3], bA[3], bB[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bA[u] = *reinterpret_cast<const f32x4*>(wr[u]);
-            }
-            for (int g = 0; g < DENSE_HID / 16; g += 2) {
-#pragma unroll
-                for (int u = 0; u < 3; ++u) bB[u] = *reinterpret_cast<const f32x4*>(wr[u] + 16 * (g + 1));
-                f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 16 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int u = 0; u < 3; ++u)
-                        if (ok[u]) acc[u] = MFMA16(av[s], bA[u][s], acc[u]);
-                if (g + 2 < DENSE_HID / 16) {
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) bA[u] = *reinterpret_cast<const f32x4*>(wr[u] + 16 * (g + 2));
-                }
-                av = *reinterpret_cast<const f32x4*>(hrow + 16 * (g + 1));
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int u = 0; u < 3; ++u)
-                        if (ok[u]) acc[u] = MFMA16(av[s], bB[u][s], acc[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                if (!ok[u]) continue;
-                const int k = 16 * (T0 + u * DENSE_WAVES) + j;      // Keras Flatten index c*hw + p  ->  NHWC offset p*C + c
-                int idx = k;
-                if (a.perm_hw > 0) { const int c = k / a.perm_hw, p = k - c * a.perm_hw; idx = p * a.perm_c + c; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * kq + r;
-                    if (row >= ns) continue;
-                    const size_t o = (size_t)(b0 + row) * a.K1 + idx;
-                    a.gx[o] = a.x[o] > 0.f ? acc[u][r] : 0.f;
-                }
-            }
+        const int tiles = a.K1 >> 4, base = tiles / DENSE_WAVES, extra = tiles - base * DENSE_WAVES;
+        int t0 = wave * base + min(wave, extra), left = base + (wave < extra ? 1 : 0);
+        while (left > 0) {                                          // wave-uniform
+            if (left >= 3) { gx_pass<3>(a, s_gh1, t0, b0, ns, lane); t0 += 3; left -= 3; }
+            else if (left == 2) { gx_pass<2>(a, s_gh1, t0, b0, ns, lane); t0 += 2; left -= 2; }
+            else { gx_pass<1>(a, s_gh1, t0, b0, ns, lane); t0 += 1; left -= 1; }
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients of the dense layers, all layers in ONE launch.  dW[k, n] = sum_b X[b, k] G[b, n]: the batch is the
@@ -384,7 +423,8 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
 
 // Data gradient of a 2x2 stride-1 convolution with 32 output channels, masked by the input activation, in place:
 //   act[(s,iy,ix), c] <- (sum_{ky,kx,n} g[(s,iy-ky,ix-kx), n] W[ky,kx,c,n]) * [act > 0]     for c in [c_lo, c_lo + 32)
-// g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA]; W = Keras HWIO [2][2][CIN][32].
+// g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA]; W = Keras HWIO [2][2][CIN][32] (its rows are
+// exactly one 128-byte line, read once per sample group into stationary registers -- transposing it measured no gain).
 template <int CIN, int PSA>
 __device__ __forceinline__ void dgrad_inplace(const float* __restrict__ g, int zero_row, float* __restrict__ act, const float* __restrict__ w,
                                               int c_lo, int ih, int iw, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
@@ -677,10 +717,16 @@ bool fused_backward_supported(const dq_qnet* Q) {
     return fused_forward_supported(Q) && plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp);
 }
 
+// transposed weights: W1T, W2T
+static size_t transposed_floats(const dq_qnet* Q) {
+    const int nc = Q->cfg.n_conv;
+    return (size_t)Q->L[nc].K * Q->L[nc].N + (size_t)Q->L[nc + 1].K * Q->L[nc + 1].N;
+}
+
 // floats of workspace the fused backward needs: [DENSE_WGRAD_SLICES][n_params] dense partials, then [CONV_BWD_MAX_WGS][conv params]
 size_t fused_backward_workspace_floats(const dq_qnet* Q) {
     if (!fused_backward_supported(Q)) return 0;
-    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off;
+    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + transposed_floats(Q);
 }
 
 typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
@@ -701,9 +747,31 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     }
     const int B = Q->last_train_batch, nc = Q->cfg.n_conv, nl = Q->n_layers;
     const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
+    // ---- 0. transposed weights -------------------------------------------------------------------------------------
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    float* dense_partial = Q->fpartial;
+    float* conv_partial = dense_partial + (size_t)DENSE_WGRAD_SLICES * Q->n_params;
+    float* w1t = conv_partial + (size_t)CONV_BWD_MAX_WGS * D1.w_off;
+    float* w2t = w1t + (size_t)D1.K * D1.N;
+    {
+        TrArgs ta;
+        memset(&ta, 0, sizeof(ta));
+        int n = 0, tiles = 0;
+        auto add = [&](const float* src, float* dst, int R, int C) {
+            TrItem& T = ta.it[n++];
+            T.src = src; T.dst = dst; T.R = R; T.C = C; T.tile0 = tiles; T.tiles_c = (C + 31) / 32;
+            tiles += ((R + 31) / 32) * T.tiles_c;
+        };
+        add(params_dev + D1.w_off, w1t, D1.K, D1.N);
+        add(params_dev + D2.w_off, w2t, D2.K, D2.N);
+        ta.n = n;
+        transpose_weights_kernel<<<tiles, 256, 0, st>>>(ta);
+        DQ_LAUNCH_CHECK();
+    }
     // ---- 1. dense data gradients ----------------------------------------------------------------------------------
     DenseBwdArgs da;
     memset(&da, 0, sizeof(da));
+    da.w1t = w1t; da.w2t = w2t;
     da.params = params_dev; da.dq = dq_dev; da.h1 = Q->act[0][nc]; da.x = Q->act[0][nc - 1];
     da.batch = B; da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
@@ -718,8 +786,6 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     DQ_LAUNCH_CHECK();
 
     // ---- 2. dense weight gradients: all layers, one launch -----------------------------------------------------------
-    float* dense_partial = Q->fpartial;
-    float* conv_partial = Q->fpartial + (size_t)DENSE_WGRAD_SLICES * Q->n_params;
     DenseWgradArgs wa;
     memset(&wa, 0, sizeof(wa));
     wa.n_layers = nl - nc; wa.batch = B;
@@ -744,7 +810,6 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     DQ_LAUNCH_CHECK();
 
     // ---- 3. convolutions: data + weight gradients, one persistent launch -----------------------------------------------
-    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
     ConvBwdArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.params = params_dev; ca.obs = Q->last_obs; ca.index = Q->last_index; ca.index_off = Q->last_index_off;

@@ -1,12 +1,13 @@
+"""Per-layer gradient errors of the fused and per-layer paths against the float64 oracle (GPU box)."""
 import importlib, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import dqn_oracle as O
 dq = importlib.import_module("deepq-decoding_amd")
 C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
-name = sys.argv[1] if len(sys.argv) > 1 else "c1"
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-shape, A = {"c1": ((4, 7, 7), 10), "c3": ((7, 11, 11), 51)}[name]
+name = sys.argv[1] if len(sys.argv) > 1 else "c5"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+shape, A = {"c1": ((4, 7, 7), 10), "c2": ((6, 11, 11), 26), "c3": ((7, 11, 11), 51), "c5": ((9, 15, 15), 99)}[name]
 spec = O.QNetSpec(shape, C_LAYERS, FF_LAYERS, A)
 net = dq.QNetwork(shape, C_LAYERS, FF_LAYERS, A, max_batch=batch)
 params = net.init_params((11, 22))
@@ -16,11 +17,13 @@ params.copy_(torch.from_numpy(flat))
 obs = (rng.rand(batch, *shape) < 0.3).astype(np.uint8)
 seed, t, base = (3, 4), 5, 0
 keep = O.dropout_keep_mask(seed, t, base + np.arange(batch), 512, 0.2)
-q = net.forward(params, torch.from_numpy(obs).cuda(), training=True, seed=seed, t=t, sample_base=base).cpu().numpy()
 q_ref, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
-print("fwd err", np.abs(q - q_ref).max())
 dq_ = (rng.randn(batch, A) / batch).astype(np.float32)
-g = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
 g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
-for i, ((gk, gb), (rk, rb)) in enumerate(zip(spec.split(g), spec.split(g_ref))):
-    print(i, spec.layers[i][0], "kernel err", np.abs(gk - rk).max(), "scale", np.abs(rk).max(), "| bias err", np.abs(gb - rb).max(), "scale", np.abs(rb).max())
+for fused in (1, 0):
+    net.set_fused(fused)
+    q = net.forward(params, torch.from_numpy(obs).cuda(), training=True, seed=seed, t=t, sample_base=base).cpu().numpy()
+    g = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
+    print("fused" if fused else "layer", "fwd err", np.abs(q - q_ref).max())
+    for i, ((gk, gb), (rk, rb)) in enumerate(zip(spec.split(g), spec.split(g_ref))):
+        print("  ", i, spec.layers[i][0], "kernel err %.3e (scale %.3e) | bias err %.3e (scale %.3e)" % (np.abs(gk - rk).max(), np.abs(rk).max(), np.abs(gb - rb).max(), np.abs(rb).max()))
