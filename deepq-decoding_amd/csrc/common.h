@@ -102,4 +102,22 @@ __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
     return base + __ffsll((long long)m) - 1;
 }
 
+// ---- optional phase timestamps (development aid): build with DQ_EXTRA_FLAGS="-DDQ_STAMPS=<kernel tag>" and read them back with
+// tools/stamp_run.py.  Workgroup DQ_STAMP_BLOCK, lane 0 of every wave, records the shader cycle counter at phase boundaries.
+#define DQ_TAG_CONV_FWD 1
+#define DQ_TAG_DENSE_FWD 2
+#define DQ_TAG_DENSE_BWD 3
+#define DQ_TAG_CONV_BWD 4
+#ifdef DQ_STAMPS
+#define DQ_STAMP_BLOCK 9
+extern __device__ unsigned long long dq_dbg[512];
+#define DQ_STAMP(tag, i)                                                                                        \
+    do {                                                                                                        \
+        if ((tag) == DQ_STAMPS && blockIdx.x == DQ_STAMP_BLOCK && (threadIdx.x & 63) == 0)                      \
+            dq_dbg[(i) * 8 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();                                \
+    } while (0)
+#else
+#define DQ_STAMP(tag, i) do { } while (0)
+#endif
+
 #endif  // __HIPCC__

@@ -91,17 +91,16 @@ __device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int 
         for (int g = 0; g < KG; ++g) {
             const int kyx = g / CG, c16 = g - kyx * CG, ky = kyx / KS, kx = kyx - ky * KS;
             const int off = (ky * iw + kx) * PSI + 16 * c16;
+            // both tiles always: a missing second tile recomputes clamped rows and is never stored.  (A condition around an MFMA,
+            // even a wave-uniform one, makes hipcc copy the accumulators after every MFMA, each copy waiting for the result.)
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(in + abase[0] + off);
-            f32x4 a1 = a0;
-            if (two) a1 = *reinterpret_cast<const f32x4*>(in + abase[1] + off);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(in + abase[1] + off);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[0][t] = MFMA16(a0[s], b[g][s][t], acc[0][t]);
-                if (two) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[1][t] = MFMA16(a1[s], b[g][s][t], acc[1][t]);
-                }
+                for (int t = 0; t < NT; ++t) acc[1][t] = MFMA16(a1[s], b[g][s][t], acc[1][t]);
             }
         }
         // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg; this lane owns columns 2j, 2j+1
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);
     float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1);
     float* s_a2 = reinterpret_cast<float*>(smem + a.off_a2);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     int jb = 0;
     while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
     const ConvJob& J = a.job[jb];
@@ -135,6 +134,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     const int ns = min(a.S, J.batch - b0);
     const int in_bytes = a.C * a.H * a.W;
 
+    DQ_STAMP(DQ_TAG_CONV_FWD, 0);
     // ---- first convolution's weights -> registers (the loads fly while the observations are staged) ----------------
     const float* w1 = J.params + a.w_off[0];
     f32x4 b1[KG1][4];
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
         }
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
 
+    DQ_STAMP(DQ_TAG_CONV_FWD, 1);
     // ---- stage the observations: thread t copies aligned dword t (t + 256, ...) of every sample's (arbitrarily aligned) row;
     //      all of a thread's loads are independent, so the gather costs one memory latency ---------------------------
     {
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     }
     __syncthreads();
 
+    DQ_STAMP(DQ_TAG_CONV_FWD, 2);
     // ---- convolution 1: A gathered byte-wise from the uint8 image ---------------------------------------------------
     {
         const int r1 = a.oh1 * a.ow1, M1 = ns * r1, tiles = (M1 + 15) >> 4;
@@ -221,19 +223,24 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
             }
         }
     }
+    DQ_STAMP(DQ_TAG_CONV_FWD, 3);
     __syncthreads();
+    DQ_STAMP(DQ_TAG_CONV_FWD, 4);
     // ---- convolution 2 (64 -> 32, 2x2) and 3 (32 -> 32, 2x2) --------------------------------------------------------
     {
         const int r2 = a.oh2 * a.ow2;
         conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, J.params + a.w_off[1], J.params + a.b_off[1], s_a2,
                                  J.write_all ? J.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane);
     }
+    DQ_STAMP(DQ_TAG_CONV_FWD, 5);
     __syncthreads();
+    DQ_STAMP(DQ_TAG_CONV_FWD, 6);
     {
         const int r3 = a.oh3 * a.ow3;
         conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, J.params + a.w_off[2], J.params + a.b_off[2], nullptr,
                                  J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane);
     }
+    DQ_STAMP(DQ_TAG_CONV_FWD, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     float* s_gy2 = reinterpret_cast<float*>(smem + a.off_gy2);
     float* s_gh1 = reinterpret_cast<float*>(smem + a.off_gh1);
     constexpr int LDH = DENSE_HID + 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     const int b0 = blockIdx.x * DENSE_ROWS;
     const int ns = min(DENSE_ROWS, a.batch - b0);
     const int A = a.n_actions, N2 = a.N2, N3 = a.N3, ldg = a.ldg;
@@ -266,7 +266,7 @@ struct DenseWgradArgs {
 template <int TK>
 __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int batch, int rows_per_wave, float* __restrict__ out,
                                            float* s_part, float* s_bias) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     const int kt = local / L.n_tiles, nt = local - kt * L.n_tiles;
     const int kbase = kt * 16 * TK, nbase = nt * 64;
     const int K = L.K, N = L.N;
@@ -409,27 +409,38 @@ struct ConvBwdArgs {
     float* partial;                     // [gridDim.x][pstride]
     size_t pstride;
     int slot;
-    int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3;
+    int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko;
+    const int* kofftab;                 // [96] conv1 weight row k -> byte offset inside an observation, -1 past K1
 };
 
+// Copies `rows` rows of CH floats from global memory into an LDS image with row stride PS.  Loads are issued NB at a time before
+// the first store: a load -> store loop body costs one full memory latency per trip.
 template <int CH, int PS>
 __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int rows, int tid) {
-    constexpr int Q4 = CH / 4;
-    for (int i = tid; i < rows * Q4; i += CB_THREADS) {
-        const int r = i / Q4, c4 = (i - r * Q4) * 4;
-        *reinterpret_cast<f32x4*>(dst + r * PS + c4) = *reinterpret_cast<const f32x4*>(src + (size_t)r * CH + c4);
+    constexpr int Q4 = CH / 4, NB = 4;
+    const int total = rows * Q4;
+    for (int base = 0; base < total; base += NB * CB_THREADS) {
+        f32x4 v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = base + u * CB_THREADS + tid;
+            v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(i < total ? i : 0) * 4);      // contiguous source; clamped, unconditional
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = base + u * CB_THREADS + tid;
+            if (i < total) {
+                const int r = i / Q4, c4 = (i - r * Q4) * 4;
+                *reinterpret_cast<f32x4*>(dst + r * PS + c4) = v[u];
+            }
+        }
     }
 }
 
-// Data gradient of a 2x2 stride-1 convolution with 32 output channels, masked by the input activation, in place:
-//   act[(s,iy,ix), c] <- (sum_{ky,kx,n} g[(s,iy-ky,ix-kx), n] W[ky,kx,c,n]) * [act > 0]     for c in [c_lo, c_lo + 32)
-// g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA]; W = Keras HWIO [2][2][CIN][32] (its rows are
-// exactly one 128-byte line, read once per sample group into stationary registers -- transposing it measured no gain).
-template <int CIN, int PSA>
-__device__ __forceinline__ void dgrad_inplace(const float* __restrict__ g, int zero_row, float* __restrict__ act, const float* __restrict__ w,
-                                              int c_lo, int ih, int iw, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
+// Weights of one 2x2 data gradient for this lane: [(ky*2+kx)*2 + n16][t] = W[ky,kx, c_lo + 2j + t, 16 n16 + 4kq .. +3] (float4 along n).
+template <int CIN>
+__device__ __forceinline__ void dgrad_load_w(f32x4 (&bw)[8][2], const float* __restrict__ w, int c_lo, int lane) {
     const int j = lane & 15, kq = lane >> 4;
-    f32x4 bw[8][2];                                                  // [(ky*2+kx)*2 + n16][t]: column c = c_lo + 2j + t
 #pragma unroll
     for (int kyx = 0; kyx < 4; ++kyx)
 #pragma unroll
@@ -437,6 +448,12 @@ __device__ __forceinline__ void dgrad_inplace(const float* __restrict__ g, int z
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 bw[kyx * 2 + n16][t] = *reinterpret_cast<const f32x4*>(w + (size_t)(kyx * CIN + c_lo + 2 * j + t) * 32 + 16 * n16 + 4 * kq);
+}
+
+template <int PSA>
+__device__ __forceinline__ void dgrad_inplace(const f32x4 (&bw)[8][2], const float* __restrict__ g, int zero_row, float* __restrict__ act,
+                                              int c_lo, int ih, int iw, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
+    const int j = lane & 15, kq = lane >> 4;
     const int rin = ih * iw, rout = oh * ow, tiles = (M + 15) >> 4;
     for (int tile = tile_first; tile < tiles; tile += tile_step) {
         int m = tile * 16 + j;
@@ -476,75 +493,102 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1);
     float* s_a2 = reinterpret_cast<float*>(smem + a.off_a2);
     float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
-    int* t1 = reinterpret_cast<int*>(smem + a.off_t1);
+    u8* s_col = smem + a.off_t1;                                     // observation patch image [S*r1][16*KG1] bytes
+    int* s_ko = reinterpret_cast<int*>(smem + a.off_ko);
     int* t2 = reinterpret_cast<int*>(smem + a.off_t2);
     int* t3 = reinterpret_cast<int*>(smem + a.off_t3);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     const int S = a.S, r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
     const int in_bytes = a.C * a.H * a.W;
     const int zero2 = S * r2, zero3 = S * r3;                        // all-zero rows of the g2 (= a2) and g3 images
     constexpr int NW1 = (4 * KG1 + CB_WAVES - 1) / CB_WAVES;        // dW1 tiles (KG1 x 4) per wave
+    constexpr int KP = 16 * KG1;                                    // bytes per row of the observation patch image
 
     // ---- group-independent tables and zero rows ----------------------------------------------------------------
     for (int m = tid; m < S * r3; m += CB_THREADS) { const int s = m / r3, p = m - s * r3, oy = p / a.ow3, ox = p - oy * a.ow3; t3[m] = s * r2 + oy * a.ow2 + ox; }
     for (int m = tid; m < S * r2; m += CB_THREADS) { const int s = m / r2, p = m - s * r2, oy = p / a.ow2, ox = p - oy * a.ow2; t2[m] = s * r1 + oy * a.ow1 + ox; }
+    if (tid < 96) s_ko[tid] = a.kofftab[tid];
     if (tid < 36) { s_a2[zero2 * 36 + tid] = 0.f; s_g3[zero3 * 36 + tid] = 0.f; }
 
     // ---- per-lane constants of the weight-gradient phases ----------------------------------------------------------
     // dW3 [128 x 32]: wave w owns k-tile w = (ky,kx) = w>>1, channels 16*(w&1)..; dW2 [256 x 32]: k-tiles 2w, 2w+1 = (ky,kx) = w>>1, channels 16*(2(w&1)+u)
+    // dW1 [16 KG1 x 64]: tile id = wave + 8u -> k-tile id>>2, n-tile wave & 3 (the same for every u)
     const int kyx = wave >> 1, ky = kyx >> 1, kx = kyx & 1;
     const int aoff3 = (ky * a.ow2 + kx) * 36 + 16 * (wave & 1) + j;
     const int aoff2 = (ky * a.ow1 + kx) * 68 + 32 * (wave & 1) + j;
-    int ko1[NW1];                                                    // dW1: byte offset of weight row k = 16*kt + j inside an observation, -1 if k >= K1
-#pragma unroll
-    for (int u = 0; u < NW1; ++u) {
-        const int id = wave + CB_WAVES * u, kt = id >> 2, k = 16 * kt + j;
-        const int t = k / a.C, c = k - t * a.C, y = t / a.k1, x = t - y * a.k1;
-        ko1[u] = (id < 4 * KG1 && k < a.K1) ? c * a.H * a.W + y * a.W + x : -1;
-    }
     f32x4 acc3[2], acc2[2][2], acc1[NW1];
-    float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1[NW1];
+    float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1 = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[0][t] = acc3[t]; acc2[1][t] = acc3[t]; }
 #pragma unroll
-    for (int u = 0; u < NW1; ++u) { acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; bs1[u] = 0.f; }
+    for (int u = 0; u < NW1; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
         const int b0 = grp * S, ns = min(S, a.batch - b0);
         const int M1 = ns * r1, M2 = ns * r2, M3 = ns * r3;
+        const int sb = (grp == (int)blockIdx.x) ? 0 : 12;          // DQ_STAMP slots of the first / a later group
+        (void)sb;
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 0);
         __syncthreads();                                            // previous group's images are no longer read
-        // ---- stage observations (one wave per sample; aligned dwords of an arbitrarily aligned row), a1, a2, g3 -------
-        for (int s = wave; s < ns; s += CB_WAVES) {
-            int row = b0 + s;
-            if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
-            const u8* src = a.obs + (size_t)row * in_bytes;
-            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
-            const u8* win = src - mis;
-            const int nd = (mis + in_bytes + 3) >> 2;
-            u32* dst = reinterpret_cast<u32*>(s_in + s * a.slot);
-            for (int d = lane; d < nd; d += 64) {
-                u32 v = 0;
-                if (4 * d >= mis && 4 * d + 4 <= mis + in_bytes) {
-                    v = reinterpret_cast<const u32*>(win)[d];
-                } else {
+        // ---- stage: observations (thread t copies aligned dword t of every sample's arbitrarily aligned row; the loads of all
+        //      samples are issued before the first LDS store), a1, a2, g3 ----------------------------------------------------
+        {
+            u32 v[8];
+            int misv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                int row = b0 + (s < ns ? s : 0);
+                if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
+                const u8* src = a.obs + (size_t)row * in_bytes;
+                const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
+                const u8* win = src - mis;
+                const int lo = 4 * tid, last = mis + in_bytes;     // this thread's dword covers window bytes [lo, lo+4)
+                misv[s] = mis;
+                u32 w = 0;
+                if (lo >= mis && lo + 4 <= last) {
+                    w = reinterpret_cast<const u32*>(win)[tid];
+                } else if (lo < last && lo + 4 > mis) {             // first / last partial dword: never read outside the row
                     for (int bb = 0; bb < 4; ++bb) {
-                        const int o = 4 * d + bb;
-                        if (o >= mis && o < mis + in_bytes) v |= (u32)win[o] << (8 * bb);
+                        const int o = lo + bb;
+                        if (o >= mis && o < last) w |= (u32)win[o] << (8 * bb);
                     }
                 }
-                dst[d] = v;
+                v[s] = w;
             }
-            if (lane == 0) s_mis[s] = mis;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s < ns && 4 * tid < misv[s] + in_bytes) reinterpret_cast<u32*>(s_in + s * a.slot)[tid] = v[s];
+                if (tid == 0 && s < ns) s_mis[s] = misv[s];
+            }
         }
-        stage_rows<64, 68>(s_a1, a.a1 + (size_t)b0 * r1 * 64, M1, tid);
-        stage_rows<32, 36>(s_a2, a.a2 + (size_t)b0 * r2 * 32, M2, tid);
         stage_rows<32, 36>(s_g3, a.g3 + (size_t)b0 * r3 * 32, M3, tid);
+        stage_rows<32, 36>(s_a2, a.a2 + (size_t)b0 * r2 * 32, M2, tid);
+        stage_rows<64, 68>(s_a1, a.a1 + (size_t)b0 * r1 * 64, M1, tid);
+        f32x4 bw[8][2];                                             // data-gradient weights: loaded one phase ahead of their use
+        dgrad_load_w<32>(bw, a.params + a.w_off[2], 0, lane);
         __syncthreads();
-        for (int m = tid; m < M1; m += CB_THREADS) {
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 1);
+        // ---- observation patch image: row m = the K1 bytes conv1 multiplies for output pixel m (zeros past K1), so that dW1's A
+        //      operand is 16 consecutive bytes per quarter-wave instead of a scattered byte gather -------------------------------
+        for (int task = tid; task < M1 * (KP / 16); task += CB_THREADS) {
+            const int m = task / (KP / 16), q = task - m * (KP / 16);
             const int s = m / r1, p = m - s * r1, oy = p / a.ow1, ox = p - oy * a.ow1;
-            t1[m] = s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
+            const u8* op = s_in + s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
+            u32 wd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32 v = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int off = s_ko[16 * q + 4 * e + bb];
+                    v |= (off >= 0 ? (u32)op[off] : 0u) << (8 * bb);
+                }
+                wd[e] = v;
+            }
+            *reinterpret_cast<uint4*>(s_col + m * KP + 16 * q) = uint4{wd[0], wd[1], wd[2], wd[3]};
         }
 
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 2);
         // ---- dW3 += im2col(a2)^T g3 ------------------------------------------------------------------------------
         for (int m0 = 0; m0 < M3; m0 += 16) {                         // 4 MFMA steps per trip: all LDS reads first, then the MFMAs
             float av[4], g0[4], g1[4];
@@ -553,9 +597,12 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 const int m = m0 + 4 * q + kq;
                 const bool ok = m < M3;
                 const int mc = ok ? m : 0;
-                av[q] = ok ? s_a2[t3[mc] * 36 + aoff3] : 0.f;
-                g0[q] = ok ? s_g3[mc * 36 + j] : 0.f;
-                g1[q] = ok ? s_g3[mc * 36 + 16 + j] : 0.f;
+                // unconditional reads of a clamped row, masked by SELECT: a read under `ok ? .. : 0` becomes a branch with its own
+                // s_waitcnt, which serialises every LDS latency of the trip
+                const float ra = s_a2[t3[mc] * 36 + aoff3], r0 = s_g3[mc * 36 + j], r1 = s_g3[mc * 36 + 16 + j];
+                av[q] = ok ? ra : 0.f;
+                g0[q] = ok ? r0 : 0.f;
+                g1[q] = ok ? r1 : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -564,10 +611,15 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 bs3[0] += g0[q]; bs3[1] += g1[q];
             }
         }
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 3);
         __syncthreads();                                            // every wave is done reading a2
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 4);
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
-        dgrad_inplace<32, 36>(s_g3, zero3, s_a2, a.params + a.w_off[2], 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
+        dgrad_inplace<36>(bw, s_g3, zero3, s_a2, 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
+        dgrad_load_w<64>(bw, a.params + a.w_off[1], 32 * (wave >> 2), lane);     // next data gradient's weights fly under dW2
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
         __syncthreads();
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
         // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
         for (int m0 = 0; m0 < M2; m0 += 16) {
             float av0[4], av1[4], g0[4], g1[4];
@@ -577,10 +629,11 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 const bool ok = m < M2;
                 const int mc = ok ? m : 0;
                 const float* ap = s_a1 + t2[mc] * 68 + aoff2;
-                av0[q] = ok ? ap[0] : 0.f;
-                av1[q] = ok ? ap[16] : 0.f;
-                g0[q] = ok ? s_a2[mc * 36 + j] : 0.f;
-                g1[q] = ok ? s_a2[mc * 36 + 16 + j] : 0.f;
+                const float ra0 = ap[0], ra1 = ap[16], r0 = s_a2[mc * 36 + j], r1 = s_a2[mc * 36 + 16 + j];     // unconditional, then select
+                av0[q] = ok ? ra0 : 0.f;
+                av1[q] = ok ? ra1 : 0.f;
+                g0[q] = ok ? r0 : 0.f;
+                g1[q] = ok ? r1 : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -591,37 +644,47 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 bs2[0] += g0[q]; bs2[1] += g1[q];
             }
         }
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 7);
         __syncthreads();                                            // every wave is done reading a1
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 8);
         // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1: waves 0-3 channels 0..31, waves 4-7 channels 32..63 -------------
-        dgrad_inplace<64, 68>(s_a2, zero2, s_a1, a.params + a.w_off[1], 32 * (wave >> 2), a.oh1, a.ow1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
+        dgrad_inplace<68>(bw, s_a2, zero2, s_a1, 32 * (wave >> 2), a.oh1, a.ow1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 9);
         __syncthreads();
-        // ---- dW1 += im2col(obs)^T g1 ------------------------------------------------------------------------------------
-        for (int m0 = 0; m0 < M1; m0 += 16) {
-            float av[4][NW1], g[4][NW1];
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 10);
+        // ---- dW1 += patches^T g1 ----------------------------------------------------------------------------------------
+        {
+            const u8* cp = s_col + 16 * (wave >> 2) + j;           // + 32 per further tile of this wave (k-tile + 2)
+            const float* gp = s_a1 + 16 * (wave & 3) + j;
+            for (int m0 = 0; m0 < M1; m0 += 16) {
+                float av[4][NW1], g[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m0 + 4 * q + kq;
-                const bool ok = m < M1;
-                const int mc = ok ? m : 0;
-                const u8* op = s_in + t1[mc];
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + 4 * q + kq;
+                    const bool ok = m < M1;
+                    const int mc = ok ? m : 0;
 #pragma unroll
-                for (int u = 0; u < NW1; ++u) {
-                    const int id = wave + CB_WAVES * u;
-                    av[q][u] = (ok && ko1[u] >= 0) ? (float)op[ko1[u]] : 0.f;
-                    g[q][u] = (ok && id < 4 * KG1) ? s_a1[mc * 68 + 16 * (id & 3) + j] : 0.f;
+                    for (int u = 0; u < NW1; ++u) {
+                        const bool tv = wave + CB_WAVES * u < 4 * KG1;                                  // this wave has a u-th tile
+                        const u8 rb = cp[mc * KP + (tv ? 32 * u : 0)];                                  // unconditional, then select
+                        av[q][u] = (ok && tv) ? (float)rb : 0.f;
+                    }
+                    const float rg = gp[mc * 68];
+                    g[q] = ok ? rg : 0.f;
+                }
+                // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
+                // (each copy waits for the result) -- a tile this wave does not have just accumulates zeros and is never stored
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int u = 0; u < NW1; ++u) acc1[u] = MFMA16(av[q][u], g[q], acc1[u]);
+                    bs1 += g[q];
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int u = 0; u < NW1; ++u)
-                    if (wave + CB_WAVES * u < 4 * KG1) {            // wave-uniform
-                        acc1[u] = MFMA16(av[q][u], g[q][u], acc1[u]);
-                        bs1[u] += g[q][u];
-                    }
         }
     }
 
+    DQ_STAMP(DQ_TAG_CONV_BWD, 24);
     // ---- one partial per workgroup -----------------------------------------------------------------------------------
     float* out = a.partial + (size_t)blockIdx.x * a.pstride;
 #pragma unroll
@@ -642,7 +705,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 if (k < a.K1) out[a.w_off[0] + k * 64 + 16 * nt + j] = acc1[u][r];
             }
             if (kt == 0) {                                          // bias gradient = column sums of g1
-                float v = bs1[u];
+                float v = bs1;
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
                 if (kq == 0) out[a.b_off[0] + 16 * nt + j] = v;
@@ -681,7 +744,7 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     return true;
 }
 
-struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3; size_t lds; };
+struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko; size_t lds; };
 
 static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
     if (Q->cfg.n_conv != 3) return false;
@@ -693,15 +756,17 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
     if (P->KG1 < 3) P->KG1 = 3;
     const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
     P->slot = (in_bytes + 3 + 3) & ~3;
+    if (P->slot > 4 * CB_THREADS) return false;                      // one dword of an observation per thread
     for (int S = 8; S >= 1; S >>= 1) {
         size_t off = up16((size_t)S * P->slot);
         P->off_mis = (int)off; off += up16((size_t)S * 4);
         P->off_a1 = (int)off; off += up16((size_t)S * L1.rows * 68 * 4);
         P->off_a2 = (int)off; off += up16((size_t)(S * L2.rows + 1) * 36 * 4);
         P->off_g3 = (int)off; off += up16((size_t)(S * L3.rows + 1) * 36 * 4);
-        P->off_t1 = (int)off; off += up16((size_t)S * L1.rows * 4);
+        P->off_t1 = (int)off; off += up16((size_t)S * L1.rows * 16 * P->KG1);      // observation patch image (bytes)
         P->off_t2 = (int)off; off += up16((size_t)S * L2.rows * 4);
         P->off_t3 = (int)off; off += up16((size_t)S * L3.rows * 4);
+        P->off_ko = (int)off; off += 96 * 4;
         if (off <= CHAIN_LDS_MAX) { P->S = S; P->lds = off; return true; }
     }
     return false;
@@ -822,7 +887,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     const size_t conv_floats = D1.w_off;
     ca.partial = conv_partial; ca.pstride = conv_floats;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
-    ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3;
+    ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3; ca.off_ko = cp.off_ko; ca.kofftab = Q->kofftab;
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
     conv_bwd_kernel_t ck = cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;

@@ -1,7 +1,12 @@
-import importlib, os, sys, ctypes
+"""Phase timestamps of one fused kernel (development aid; GPU box).  Build with
+    DQ_EXTRA_FLAGS="-DDQ_STAMPS=<tag>" python deepq-decoding_amd/build.py --force      (tags: csrc/common.h DQ_TAG_*)
+then    python tools/stamp_run.py <tag>
+prints, per wave of workgroup DQ_STAMP_BLOCK, the shader cycles between consecutive DQ_STAMP points."""
+import ctypes, importlib, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 dq = importlib.import_module("deepq-decoding_amd")
+tag = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
 shape, A, batch = (7, 11, 11), 51, 4096
 net = dq.QNetwork(shape, C_LAYERS, FF_LAYERS, A, max_batch=batch)
@@ -13,8 +18,16 @@ for _ in range(5):
     net.forward(params, obs, training=True, seed=(1, 2), t=3)
     net.backward(params, dqt)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 512)()
 dq.lib().dq_dbg_read(buf)
-for w in range(2):
-    t = [buf[i * 2 + w] for i in range(7)]
-    print("wave", w, "dense_bwd phases: dueling, gY2, gH1, barrier, gX-loop, gX-epilogue:", [t[i + 1] - t[i] for i in range(6)], "total", t[6] - t[0])
+if tag == 4:
+    names = ["stage", "patch-image", "dW3", "bar", "g2(+next w)", "bar", "dW2", "bar", "g1", "bar", "dW1(to next/end)"]
+    for w in range(8):
+        t = [buf[i * 8 + w] for i in range(11)] + [buf[12 * 8 + w]]
+        t2 = [buf[(12 + i) * 8 + w] for i in range(11)] + [buf[24 * 8 + w]]
+        print("wave", w, "group 1:", [t[i + 1] - t[i] for i in range(11)], " group 2:", [t2[i + 1] - t2[i] for i in range(11)])
+    print(names)
+elif tag == 1:
+    for w in range(4):
+        t = [buf[i * 8 + w] for i in range(8)]
+        print("wave", w, "w1-issue, stage, conv1, bar, conv2, bar, conv3:", [t[i + 1] - t[i] for i in range(7)], "total", t[7] - t[0])
