@@ -110,7 +110,8 @@ __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
 #define DQ_TAG_CONV_BWD 4
 #ifdef DQ_STAMPS
 #define DQ_STAMP_BLOCK 9
-extern __device__ unsigned long long dq_dbg[512];
+static __device__ unsigned long long dq_dbg[512];            // one copy per translation unit (no relocatable device code)
+#define DQ_STAMP_READER(name) extern "C" void name(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dq_dbg), sizeof(dq_dbg)); }
 #define DQ_STAMP(tag, i)                                                                                        \
     do {                                                                                                        \
         if ((tag) == DQ_STAMPS && blockIdx.x == DQ_STAMP_BLOCK && (threadIdx.x & 63) == 0)                      \
@@ -118,6 +119,7 @@ extern __device__ unsigned long long dq_dbg[512];
     } while (0)
 #else
 #define DQ_STAMP(tag, i) do { } while (0)
+#define DQ_STAMP_READER(name)
 #endif
 
 #endif  // __HIPCC__

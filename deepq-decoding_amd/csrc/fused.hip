@@ -26,6 +26,8 @@
 // Training forwards additionally write every layer's output to HBM in the layout qnet.hip's backward expects.
 #include "qnet.h"
 
+DQ_STAMP_READER(dq_dbg_read_fwd)
+
 #define CONV_THREADS 256
 #define CONV_WAVES 4
 #define CONV_LDS_2PER_CU (80 * 1024)
@@ -155,40 +157,45 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     // ---- stage the observations: thread t copies aligned dword t (t + 256, ...) of every sample's (arbitrarily aligned) row;
     //      all of a thread's loads are independent, so the gather costs one memory latency ---------------------------
     {
-        int rows[8];
+        const u8* srcs[8];
+        int misv[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             int row = b0 + (s < ns ? s : 0);
             if (J.index) { row = J.index[row] + J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
-            rows[s] = row;
+            srcs[s] = J.obs + (size_t)row * in_bytes;
+            misv[s] = (int)(reinterpret_cast<uintptr_t>(srcs[s]) & 3);
         }
+        for (int d = tid; 4 * d < in_bytes + 3; d += CONV_THREADS) {       // 1 trip at d <= 5, 2 at d = 7
+            u32 v[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (s < ns) {                                           // block-uniform
-                const u8* src = J.obs + (size_t)rows[s] * in_bytes;
-                const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
-                const u8* win = src - mis;
-                const int nd = (mis + in_bytes + 3) >> 2;
-                u32* dst = reinterpret_cast<u32*>(s_in + s * a.slot);
-                for (int d = tid; d < nd; d += CONV_THREADS) {
-                    u32 v = 0;
-                    if (4 * d >= mis && 4 * d + 4 <= mis + in_bytes) {
-                        v = reinterpret_cast<const u32*>(win)[d];
-                    } else {                                        // first / last partial dword: never read outside the row
-                        for (int bb = 0; bb < 4; ++bb) {
-                            const int o = 4 * d + bb;
-                            if (o >= mis && o < mis + in_bytes) v |= (u32)win[o] << (8 * bb);
-                        }
+            for (int s = 0; s < 8; ++s) {                               // the loads of all samples, then the stores
+                const int mis = misv[s], lo = 4 * d, last = mis + in_bytes;
+                const u8* win = srcs[s] - mis;
+                u32 w = 0;
+                if (lo >= mis && lo + 4 <= last) {
+                    w = reinterpret_cast<const u32*>(win)[d];
+                } else if (lo < last && lo + 4 > mis) {                 // first / last partial dword: never read outside the row
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const int o = lo + bb;
+                        if (o >= mis && o < last) w |= (u32)win[o] << (8 * bb);
                     }
-                    dst[d] = v;
                 }
-                if (tid == 0) s_mis[s] = mis;
+                v[s] = w;
             }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < ns && 4 * d < misv[s] + in_bytes) reinterpret_cast<u32*>(s_in + s * a.slot)[d] = v[s];
+        }
+        if (tid < 8 && tid < ns) {
+            int mm = 0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) if (s == tid) mm = misv[s];
+            s_mis[tid] = mm;
         }
     }
     __syncthreads();
 
-    DQ_STAMP(DQ_TAG_CONV_FWD, 2);
     // ---- convolution 1: A gathered byte-wise from the uint8 image ---------------------------------------------------
     {
         const int r1 = a.oh1 * a.ow1, M1 = ns * r1, tiles = (M1 + 15) >> 4;

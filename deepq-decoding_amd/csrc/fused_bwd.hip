@@ -11,6 +11,8 @@
 // still run through qnet.hip's per-layer kernels (layer_wgrad / layer_dgrad).
 #include "qnet.h"
 
+DQ_STAMP_READER(dq_dbg_read_bwd)
+
 // The data gradients multiply by W^T.  With W row-major, the 16 lanes of a quarter-wave that supply 16 different output
 // columns of an MFMA B operand would read 16 different rows of W -- 16 cache lines per quarter-wave request, which makes the
 // vector L1's tag path (not the matrix pipe) the bound.  So every backward first writes the transposes of the weights it
@@ -561,9 +563,21 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 if (tid == 0 && s < ns) s_mis[s] = misv[s];
             }
         }
+        // a1 (the largest image) is only needed from dW2 on: its loads are issued now and land in LDS after g2, so their latency
+        // and bandwidth hide under dW3 and g2
+        constexpr int NA1 = 7;                                      // float4 of a1 per thread (plan: S*r1*16 <= NA1*512)
+        f32x4 a1v[NA1];
+        {
+            const float* src = a.a1 + (size_t)b0 * r1 * 64;
+            const int total = M1 * 16;
+#pragma unroll
+            for (int u = 0; u < NA1; ++u) {
+                const int i = u * CB_THREADS + tid;
+                a1v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(i < total ? i : 0) * 4);
+            }
+        }
         stage_rows<32, 36>(s_g3, a.g3 + (size_t)b0 * r3 * 32, M3, tid);
         stage_rows<32, 36>(s_a2, a.a2 + (size_t)b0 * r2 * 32, M2, tid);
-        stage_rows<64, 68>(s_a1, a.a1 + (size_t)b0 * r1 * 64, M1, tid);
         f32x4 bw[8][2];                                             // data-gradient weights: loaded one phase ahead of their use
         dgrad_load_w<32>(bw, a.params + a.w_off[2], 0, lane);
         __syncthreads();
@@ -617,6 +631,11 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
         dgrad_inplace<36>(bw, s_g3, zero3, s_a2, 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
         dgrad_load_w<64>(bw, a.params + a.w_off[1], 32 * (wave >> 2), lane);     // next data gradient's weights fly under dW2
+#pragma unroll
+        for (int u = 0; u < NA1; ++u) {                             // a1 -> LDS (issued at the top of the group)
+            const int i = u * CB_THREADS + tid;
+            if (i < M1 * 16) *reinterpret_cast<f32x4*>(s_a1 + (i >> 4) * 68 + (i & 15) * 4) = a1v[u];
+        }
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
@@ -767,7 +786,7 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
         P->off_t2 = (int)off; off += up16((size_t)S * L2.rows * 4);
         P->off_t3 = (int)off; off += up16((size_t)S * L3.rows * 4);
         P->off_ko = (int)off; off += 96 * 4;
-        if (off <= CHAIN_LDS_MAX) { P->S = S; P->lds = off; return true; }
+        if (off <= CHAIN_LDS_MAX && S * L1.rows * 16 <= 7 * CB_THREADS) { P->S = S; P->lds = off; return true; }
     }
     return false;
 }

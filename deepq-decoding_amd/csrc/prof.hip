@@ -31,11 +31,6 @@ static void release_events() {
     g_used = 0;
 }
 
-#ifdef DQ_STAMPS
-__device__ unsigned long long dq_dbg[512];
-extern "C" void dq_dbg_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dq_dbg), sizeof(dq_dbg)); }
-#endif
-
 extern "C" {
 
 int dq_prof_kernel_count(void) { return DQ_K_COUNT; }

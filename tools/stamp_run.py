@@ -19,7 +19,7 @@ for _ in range(5):
     net.backward(params, dqt)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 512)()
-dq.lib().dq_dbg_read(buf)
+getattr(dq.lib(), 'dq_dbg_read_fwd' if tag in (1, 2) else 'dq_dbg_read_bwd')(buf)
 if tag == 4:
     names = ["stage", "patch-image", "dW3", "bar", "g2(+next w)", "bar", "dW2", "bar", "g1", "bar", "dW1(to next/end)"]
     for w in range(8):
