@@ -17,6 +17,20 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_pmc_traffic.json, produced by
+    tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied); None if the
+    file or the kernel is missing.  PMC counters cannot be collected inside a timed run, so this is the last recorded value."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 class FullLoop:
     dtype = "f32"
 
@@ -130,8 +144,8 @@ class FullLoop:
                 per_launch = work / per_step
                 achieved = per_launch / avg_s / 1e12
                 roof = dict(kernel=self.prof_family, bound=bound, achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None, avg_launch_us=avg_s * 1e6, launches_timed=launches,
-                            algorithmic_flops_per_launch=per_launch)
+                            frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=_pmc_traffic(self.prof_family), avg_launch_us=avg_s * 1e6,
+                            launches_timed=launches, algorithmic_flops_per_launch=per_launch)
         out = {
             "roofline": roof,
             "dqn_updates_per_s": steps / dt,

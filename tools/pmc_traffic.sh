@@ -1,0 +1,33 @@
+#!/bin/bash
+# HBM-side traffic per kernel launch from the L2 fabric counters, as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE and WRITE_SIZE
+# in SEPARATE --pmc passes (they do not fit one pass), unit KB, gfx950 correction: FETCH_SIZE counts 128-byte requests at 64 bytes
+# -> doubled.  Usage (GPU box, repo root): tools/pmc_traffic.sh [bench args]  -> gpurun_out/pmc_traffic.json (copy into profiles/).
+root="${GRAFT_REPO_ROOT:-$PWD}"; cd "$root"; mkdir -p gpurun_out
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf "gpurun_out/pmc_$c"
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $c --kernel-trace -d "$root/gpurun_out/pmc_$c" -o pmc --output-format csv -- python "$root/bench.py" --steps 40 --warmup 5 --no-cpu-baseline "$@" > "$root/gpurun_out/pmc_$c.log" 2>&1)
+done
+python3 - <<'PY'
+import csv, glob, json, collections
+out = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg, cnt = collections.Counter(), collections.Counter()
+    for f in glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != c:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+            agg[k] += float(r["Counter_Value"]); cnt[k] += 1
+    for k in agg:
+        out[k][c + "_KB_per_launch"] = agg[k] / cnt[k]
+        out[k]["launches_" + c] = cnt[k]
+for k, v in out.items():
+    f, w = v.get("FETCH_SIZE_KB_per_launch", 0.0), v.get("WRITE_SIZE_KB_per_launch", 0.0)
+    v["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0       # gfx950: FETCH_SIZE reads half of a wide coalesced stream
+    v["hbm_bytes_per_launch_raw"] = (f + w) * 1024.0
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 40 --warmup 5 --no-cpu-baseline`",
+           "correction": "MI355X_MICROARCH.md HBM section: unit KB; gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B -> x2; WRITE_SIZE uncalibrated (used as is)",
+           "kernels": out}, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"])[:12]:
+    print(f"{k[:40]:40s} fetch {v.get('FETCH_SIZE_KB_per_launch', 0):10.1f} KB  write {v.get('WRITE_SIZE_KB_per_launch', 0):10.1f} KB  corrected {v['hbm_bytes_per_launch_corrected'] / 1e6:8.2f} MB/launch")
+PY
