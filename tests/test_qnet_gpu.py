@@ -20,10 +20,12 @@ def torch_mod():
     return torch
 
 
-def _setup(dq, torch, name, batch, seed=(11, 22), dueling=True, max_batch=None):
+def _setup(dq, torch, name, batch, seed=(11, 22), dueling=True, max_batch=None, fused=True):
     shape, A = SHAPES[name]
     spec = O.QNetSpec(shape, C_LAYERS, FF_LAYERS, A, dueling=dueling)
     net = dq.QNetwork(shape, C_LAYERS, FF_LAYERS, A, dueling=dueling, max_batch=max_batch or batch)
+    assert net.fused_supported                     # the reference architecture runs on the fused chains (csrc/fused*.hip)
+    net.set_fused(fused)                           # fused=False: the per-layer implicit-GEMM path (any architecture)
     assert net.n_params == spec.n_params
     params = net.init_params(seed)
     assert np.array_equal(params.cpu().numpy(), O.glorot_init(spec, seed))
@@ -35,10 +37,11 @@ def _setup(dq, torch, name, batch, seed=(11, 22), dueling=True, max_batch=None):
     return spec, net, params, flat, obs, rng
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
 @pytest.mark.parametrize("name,batch", [("c1", 1), ("c1", 37), ("c2", 32), ("c3", 32), ("c3", 300), ("c5", 64)])
-def test_forward_inference(dq, torch_mod, name, batch):
+def test_forward_inference(dq, torch_mod, name, batch, fused):
     torch = torch_mod
-    spec, net, params, flat, obs, _ = _setup(dq, torch, name, batch)
+    spec, net, params, flat, obs, _ = _setup(dq, torch, name, batch, fused=fused)
     q = net.forward(params, torch.from_numpy(obs).cuda()).cpu().numpy()
     q_ref, _ = O.forward(spec, flat, obs)
     assert np.abs(q - q_ref).max() < TOL
@@ -71,10 +74,11 @@ def test_forward_with_replay_gather(dq, torch_mod):
     assert np.abs(q1 - O.forward(spec, flat, ring[(idx + 40) % 200])[0]).max() < TOL
 
 
-@pytest.mark.parametrize("name,batch", [("c1", 8), ("c3", 32), ("c3", 257), ("c5", 48)])
-def test_training_forward_backward(dq, torch_mod, name, batch):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
+@pytest.mark.parametrize("name,batch", [("c1", 8), ("c2", 40), ("c3", 32), ("c3", 257), ("c5", 48)])
+def test_training_forward_backward(dq, torch_mod, name, batch, fused):
     torch = torch_mod
-    spec, net, params, flat, obs, rng = _setup(dq, torch, name, batch)
+    spec, net, params, flat, obs, rng = _setup(dq, torch, name, batch, fused=fused)
     seed, t, base = (3, 4), 12345678901, 77
     keep = O.dropout_keep_mask(seed, t, base + np.arange(batch), 512, 0.2)
     q = net.forward(params, torch.from_numpy(obs).cuda(), training=True, seed=seed, t=t, sample_base=base).cpu().numpy()
@@ -92,6 +96,50 @@ def test_training_forward_backward(dq, torch_mod, name, batch):
     # deterministic: same call twice gives identical bits
     g2 = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
     assert np.array_equal(g, g2)
+
+
+def test_forward_multi_equals_separate_forwards(dq, torch_mod):
+    """dq_qnet_forward_multi (the update's three forwards in one pair of launches) == three dq_qnet_forward calls, bit for bit;
+    the training job's saved activations drive the same backward."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 100, max_batch=128)
+    target = params.clone()
+    target += 0.01 * torch.randn_like(target)
+    ring = torch.from_numpy((rng.rand(500, *SHAPES["c3"][0]) < 0.3).astype(np.uint8)).cuda()
+    idx = torch.from_numpy(rng.randint(0, 500, size=100).astype(np.int32)).cuda()
+    seed, t, base = (5, 6), 77, 1000
+    single = [net.forward(target, ring, index=idx, index_off=60, index_mod=500).cpu().numpy(),
+              net.forward(params, ring, index=idx, index_off=60, index_mod=500).cpu().numpy(),
+              net.forward(params, ring, index=idx, training=True, seed=seed, t=t, sample_base=base).cpu().numpy()]
+    dq_ = torch.from_numpy((rng.randn(100, 51) / 100).astype(np.float32)).cuda()
+    g_single = net.backward(params, dq_).cpu().numpy()
+    multi = net.forward_multi([dict(params=target, obs=ring, index=idx, index_off=60, index_mod=500),
+                               dict(params=params, obs=ring, index=idx, index_off=60, index_mod=500),
+                               dict(params=params, obs=ring, index=idx, training=True, seed=seed, t=t, sample_base=base)])
+    for a, b in zip(single, multi):
+        assert np.array_equal(a, b.cpu().numpy())
+    assert np.array_equal(g_single, net.backward(params, dq_).cpu().numpy())
+    # two training jobs in one launch are refused (one set of saved activations)
+    with pytest.raises(dq.DeepQError):
+        net.forward_multi([dict(params=params, obs=ring, index=idx, training=True, seed=seed, t=t)] * 2)
+
+
+def test_fused_and_per_layer_paths_agree(dq, torch_mod):
+    """The two HIP forward/backward implementations order their dot products differently: same results to f32 round-off."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 200)
+    obs_t = torch.from_numpy(obs).cuda()
+    dq_ = torch.from_numpy((rng.randn(200, 51) / 200).astype(np.float32)).cuda()
+    out = {}
+    for fused in (True, False):
+        net.set_fused(fused)
+        q = net.forward(params, obs_t).cpu().numpy()
+        qt = net.forward(params, obs_t, training=True, seed=(1, 2), t=3).cpu().numpy()
+        out[fused] = (q, qt, net.backward(params, dq_).cpu().numpy())
+    assert np.abs(out[True][0] - out[False][0]).max() < 2e-6 and np.abs(out[True][1] - out[False][1]).max() < 2e-6
+    # a pre-activation within round-off of 0 may take different sides of the ReLU in the two summation orders: compare robustly
+    diff = np.abs(out[True][2] - out[False][2])
+    assert np.median(diff) < 1e-8 and (diff > 1e-5 * np.abs(out[False][2]).max()).mean() < 0.02
 
 
 def test_td_target_loss_adam(dq, torch_mod):
