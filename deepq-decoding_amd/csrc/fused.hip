@@ -170,17 +170,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
             u32 v[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) {                               // the loads of all samples, then the stores
-                const int mis = misv[s], lo = 4 * d, last = mis + in_bytes;
-                const u8* win = srcs[s] - mis;
-                u32 w = 0;
-                if (lo >= mis && lo + 4 <= last) {
-                    w = reinterpret_cast<const u32*>(win)[d];
-                } else if (lo < last && lo + 4 > mis) {                 // first / last partial dword: never read outside the row
-                    for (int bb = 0; bb < 4; ++bb) {
-                        const int o = lo + bb;
-                        if (o >= mis && o < last) w |= (u32)win[o] << (8 * bb);
-                    }
-                }
+                // whole aligned dwords, also where they straddle the neighbouring rows: the window never leaves the caller's
+                // allocation (dq_qnet_forward: obs_dev rows live in one 4-byte-aligned allocation whose size is a multiple of 4)
+                const int mis = misv[s];
+                const u32* win = reinterpret_cast<const u32*>(srcs[s] - mis);
+                const u32 w = win[4 * d < mis + in_bytes ? d : 0];          // unconditional, clamped
                 v[s] = w;
             }
 #pragma unroll
