@@ -190,6 +190,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     }
     __syncthreads();
 
+    DQ_STAMP(DQ_TAG_CONV_FWD, 2);
     // ---- convolution 1: A gathered byte-wise from the uint8 image ---------------------------------------------------
     {
         const int r1 = a.oh1 * a.ow1, M1 = ns * r1, tiles = (M1 + 15) >> 4;

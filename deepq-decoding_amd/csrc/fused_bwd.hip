@@ -638,10 +638,10 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
         // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
-        for (int m0 = 0; m0 < M2; m0 += 16) {
-            float av0[4], av1[4], g0[4], g1[4];
+        for (int m0 = 0; m0 < M2; m0 += 32) {                         // 8 MFMA steps per trip: two dependent LDS latencies per 32 MFMAs
+            float av0[8], av1[8], g0[8], g1[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 const int m = m0 + 4 * q + kq;
                 const bool ok = m < M2;
                 const int mc = ok ? m : 0;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 g1[q] = ok ? r1 : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 acc2[0][0] = MFMA16(av0[q], g0[q], acc2[0][0]);
                 acc2[0][1] = MFMA16(av0[q], g1[q], acc2[0][1]);
                 acc2[1][0] = MFMA16(av1[q], g0[q], acc2[1][0]);
@@ -673,10 +673,10 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         {
             const u8* cp = s_col + 16 * (wave >> 2) + j;           // + 32 per further tile of this wave (k-tile + 2)
             const float* gp = s_a1 + 16 * (wave & 3) + j;
-            for (int m0 = 0; m0 < M1; m0 += 16) {
-                float av[4][NW1], g[4];
+            for (int m0 = 0; m0 < M1; m0 += 32) {                     // 8 MFMA steps per trip
+                float av[8][NW1], g[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 8; ++q) {
                     const int m = m0 + 4 * q + kq;
                     const bool ok = m < M1;
                     const int mc = ok ? m : 0;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
                 // (each copy waits for the result) -- a tile this wave does not have just accumulates zeros and is never stored
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 8; ++q) {
 #pragma unroll
                     for (int u = 0; u < NW1; ++u) acc1[u] = MFMA16(av[q][u], g[q], acc1[u]);
                     bs1 += g[q];
