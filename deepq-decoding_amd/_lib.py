@@ -81,6 +81,9 @@ SIGNATURES = {
     "dq_td_target": (_i, [_vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _vp, _vp]),
     "dq_td_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _vp, _vp, _vp]),
     "dq_episode_stats": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "dq_td_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _dbl, _vp, _vp, _vp, _vp]),
+    "dq_td_metrics": (_i, [_vp, _i, _vp]),
+    "dq_post_step": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dq_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
     "dq_prof_kernel_count": (_i, []),
     "dq_prof_kernel_name": (ctypes.c_char_p, [_i]),

@@ -421,9 +421,9 @@ class DQNAgent:
                 # ---- host sync: episode bookkeeping ---------------------------------------------------------------
                 n_ep, life_sum, n_rew, n_stepped = core.read_stats()
                 if trained:
-                    m = core.metrics[:2].cpu().numpy()
-                    losses.append(float(m[0]))
-                    qs.append(float(m[1]))
+                    loss_v, mean_q_v = core.read_metrics()
+                    losses.append(loss_v)
+                    qs.append(mean_q_v)
                 ep_steps += n_stepped
                 ep_reward += n_rew
                 if n_ep == 0:

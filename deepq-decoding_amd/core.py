@@ -65,6 +65,9 @@ class DQNCore:
         self.dq = torch.zeros((B, self.A), dtype=torch.float32, device=dev)
         self.metrics = torch.zeros(_q.TD_METRICS_FLOATS, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        self._stats_pending = None   # episode bookkeeping not yet launched (slot,)
+        self.defer_stats = True      # act_and_step leaves the bookkeeping launch to the next update() (dq_post_step) / act / read_stats
+        self._metrics_stale = False
         self.vector_steps = 0        # policy / environment counter
         self.updates = 0             # optimizer steps taken
         self.started = False
@@ -87,6 +90,7 @@ class DQNCore:
     def act_and_step(self, eps, masked_greedy=False, use_q=True, record_stats=True):
         """One vector step: Q forward on the current observations, epsilon-greedy over the legal set, environment
         step with auto-reset; the transition is recorded in the ring by construction."""
+        self._flush_stats()          # bookkeeping of the previous step, if no update() took it along (env buffers are about to be reused)
         env, cur = self.env, self.cur
         nxt = cur + 1 if cur + 1 < self.T else 0
         obs = self.obs_ring[cur]
@@ -96,12 +100,21 @@ class DQNCore:
         env.select_actions(self.vector_steps, q=q, eps=eps, masked_greedy=masked_greedy, out=self.action_ring[cur])
         check(self.L.dq_env_step(env._h, ptr(self.action_ring[cur]), 1, ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]),
                                  ptr(self.terminal_ring[cur]), ptr(env.legal), ptr(env.lifetime), ptr(env.was_reset), self._stream()))
-        if record_stats:
-            check(self.L.dq_episode_stats(ptr(self.terminal_ring[cur]), ptr(env.was_reset), ptr(env.lifetime), ptr(self.reward_ring[cur]),
-                                          self.N, ptr(self.stats), self._stream()))
+        # episode bookkeeping of this step: launched together with the next update's replay sampling (dq_post_step) when an update
+        # follows, else on its own
+        self._stats_pending = (cur,) if record_stats else None
+        if record_stats and not self.defer_stats:
+            self._flush_stats()
         self.cur = nxt
         self.filled = min(self.T, self.filled + 1)
         self.vector_steps += 1
+
+    def _flush_stats(self):
+        if self._stats_pending is not None:
+            (slot,), env = self._stats_pending, self.env
+            check(self.L.dq_episode_stats(ptr(self.terminal_ring[slot]), ptr(env.was_reset), ptr(env.lifetime), ptr(self.reward_ring[slot]),
+                                          self.N, ptr(self.stats), self._stream()))
+            self._stats_pending = None
 
     def update(self):
         """One minibatch update (keras-rl DQNAgent.backward's training branch)."""
@@ -111,7 +124,14 @@ class DQNCore:
         t = self.updates
         _, sample_base = _dist.shard(self.rank, N, B)
         rows = T * N
-        _q.replay_sample(self.terminal_ring, N, T, self.cur, self.filled, B, self.seed, t, sample_base=sample_base, out=self.index)
+        if self._stats_pending is not None:          # replay sampling + the pending episode bookkeeping in one launch
+            (slot,), env = self._stats_pending, self.env
+            check(self.L.dq_post_step(ptr(self.terminal_ring), N, T, self.cur, self.filled, B, _q._seed_arr(self.seed), t, sample_base,
+                                      ptr(self.index), ptr(self.terminal_ring[slot]), ptr(env.was_reset), ptr(env.lifetime),
+                                      ptr(self.reward_ring[slot]), N, ptr(self.stats), self._stream()))
+            self._stats_pending = None
+        else:
+            _q.replay_sample(self.terminal_ring, N, T, self.cur, self.filled, B, self.seed, t, sample_base=sample_base, out=self.index)
         net, ring = self.net, self.obs_ring
         # Q_online(s1) picks the action, Q_target(s1) values it (double DQN; without it Q_target does both); the training forward
         # on s0 is independent of both, so the three share one pair of launches
@@ -122,19 +142,28 @@ class DQNCore:
                          out=self.q0))
         net.forward_multi(jobs)
         q_sel = self.q1_online if self.enable_double_dqn else self.q1_target
-        _q.td_target(q_sel, self.q1_target, self.reward_ring, self.terminal_ring, self.gamma, index=self.index, out=self.y)
-        _q.td_loss_grad(self.q0, self.action_ring, self.y, grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, dq=self.dq,
-                        metrics=self.metrics)
+        _q.td_update(q_sel, self.q1_target, self.q0, self.reward_ring, self.terminal_ring, self.action_ring, self.gamma,
+                     grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, y=self.y, dq=self.dq, metrics=self.metrics)
+        self._metrics_stale = True
         net.backward(self.params, self.dq, grads=self.grads)
         if self.world_size > 1:
             _dist.allreduce_sum_(self.grads, group=self.pg)
         _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+
+    def read_metrics(self):
+        """(loss, mean_q) of the last update on this rank; reduces the per-block partials first (syncs)."""
+        if self._metrics_stale:
+            _q.td_metrics(self.metrics, self.batch_size)
+            self._metrics_stale = False
+        m = self.metrics[:2].cpu().numpy()
+        return float(m[0]), float(m[1])
 
     def update_target_hard(self):
         self.target.copy_(self.params)
 
     def read_stats(self, reset=True):
         """(episodes ended, sum of their lifetimes, rewards earned, lattices stepped) since the last reset; syncs."""
+        self._flush_stats()
         s = [int(x) for x in self.stats.cpu().tolist()]
         if reset:
             self.stats.zero_()

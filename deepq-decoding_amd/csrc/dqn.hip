@@ -92,6 +92,55 @@ __global__ __launch_bounds__(256) void td_loss_grad_kernel(const float* __restri
     }
 }
 
+// The whole TD step of one update in one launch (one wave per sample): double-DQN target from Q_online(s1) / Q_target(s1), then the
+// masked squared-error loss and its gradient on Q(s0).  Same arithmetic and the same per-block metric partials as
+// td_target_kernel + td_loss_grad_kernel; y is also written (nullable) for tests / logging.
+__global__ __launch_bounds__(256) void td_update_kernel(const float* __restrict__ q_online, const float* __restrict__ q_target,
+                                                        const float* __restrict__ q, const float* __restrict__ reward,
+                                                        const u8* __restrict__ terminal, const int32_t* __restrict__ action,
+                                                        const int32_t* __restrict__ index, float gamma, int B, int A, float grad_scale,
+                                                        float* __restrict__ y_out, float* __restrict__ dq, float* __restrict__ metrics) {
+    __shared__ float s_loss[4], s_q[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float loss = 0.f, mq = 0.f;
+    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+        const float* row1 = q_online + (size_t)b * A;
+        float best = -INFINITY;
+        int best_a = 0x7fffffff;
+        for (int a = lane; a < A; a += 64) {
+            const float v = row1[a];
+            if (best_a == 0x7fffffff || v > best) { best = v; best_a = a; }
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best, m);
+            const int oa = __shfl_xor(best_a, m);
+            if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
+        }
+        const int r = index ? index[b] : b;
+        const float yb = reward[r] + (terminal[r] ? 0.f : gamma * q_target[(size_t)b * A + best_a]);
+        if (lane == 0 && y_out) y_out[b] = yb;
+        const float* row = q + (size_t)b * A;
+        float* drow = dq + (size_t)b * A;
+        const int a_b = action[r];
+        float mx = -INFINITY;
+        for (int a = lane; a < A; a += 64) {
+            const float v = row[a];
+            mx = fmaxf(mx, v);
+            drow[a] = a == a_b ? (v - yb) * grad_scale : 0.f;
+        }
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+        const float diff = row[a_b] - yb;
+        loss += 0.5f * diff * diff;
+        mq += mx;
+    }
+    if (lane == 0) { s_loss[wave] = loss; s_q[wave] = mq; }
+    __syncthreads();
+    if (threadIdx.x == 0 && metrics) {
+        metrics[2 + 2 * blockIdx.x] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        metrics[3 + 2 * blockIdx.x] = (s_q[0] + s_q[1]) + (s_q[2] + s_q[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void td_metrics_kernel(float* __restrict__ metrics, int blocks, int B) {
     __shared__ float s_loss[256], s_q[256];
     float loss = 0.f, mq = 0.f;
@@ -153,7 +202,89 @@ __global__ void episode_stats_kernel(const u8* __restrict__ done, const u8* __re
     }
 }
 
+// Replay sampling for the next update and the episode bookkeeping of the step just taken, in one launch: blocks
+// [0, sample_blocks) run replay_sample_kernel's rule, the rest episode_stats_kernel's.
+__global__ __launch_bounds__(256) void post_step_kernel(const u8* __restrict__ terminal, int n_envs, int n_slots, int head_slot, int filled,
+                                                        int batch, u32 seed0, u32 seed1, u64 t, u32 sample_base, int32_t* __restrict__ index,
+                                                        int sample_blocks, const u8* __restrict__ done, const u8* __restrict__ was_reset,
+                                                        const u32* __restrict__ lifetime, const float* __restrict__ reward, int n,
+                                                        unsigned long long* __restrict__ stats) {
+    if ((int)blockIdx.x < sample_blocks) {
+        const int b = blockIdx.x * blockDim.x + threadIdx.x;
+        if (b >= batch) return;
+        const int cand = filled - 1;
+        int row = 0;
+        for (u32 attempt = 0; attempt < 64; ++attempt) {
+            u32 w[4];
+            philox4x32_10((u32)t, (u32)(t >> 32), sample_base + (u32)b, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
+            const int j = (int)__umulhi(w[0], (u32)cand);
+            const int env = (int)__umulhi(w[1], (u32)n_envs);
+            int slot = head_slot - 1 - j;
+            if (slot < 0) slot += n_slots;
+            row = slot * n_envs + env;
+            if (j + 1 >= cand) break;
+            int prev = slot - 1;
+            if (prev < 0) prev += n_slots;
+            if (!terminal[(size_t)prev * n_envs + env]) break;
+        }
+        index[b] = row;
+        return;
+    }
+    const int i = ((int)blockIdx.x - sample_blocks) * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const bool stepped = in && !(was_reset && was_reset[i]);
+    const bool ended = stepped && done[i];
+    const u64 m_end = __ballot(ended), m_rew = __ballot(stepped && reward[i] > 0.5f), m_step = __ballot(stepped);
+    unsigned long long life = ended ? lifetime[i] : 0;
+    for (int m = 32; m >= 1; m >>= 1) life += __shfl_xor(life, m);
+    if ((threadIdx.x & 63) == 0) {
+        if (m_end) { atomicAdd(&stats[0], (unsigned long long)__popcll(m_end)); atomicAdd(&stats[1], life); }
+        if (m_rew) atomicAdd(&stats[2], (unsigned long long)__popcll(m_rew));
+        if (m_step) atomicAdd(&stats[3], (unsigned long long)__popcll(m_step));
+    }
+}
+
 extern "C" {
+
+dq_status dq_post_step(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots, int batch,
+                       const uint32_t seed[2], uint64_t t, uint32_t sample_base, int32_t* index_dev, const uint8_t* done_dev,
+                       const uint8_t* was_reset_dev, const uint32_t* lifetime_dev, const float* reward_dev, int n, uint64_t* stats_dev,
+                       void* stream) {
+    DQ_REQUIRE(terminal_ring_dev && index_dev && seed, DQ_ERR_INVALID, "dq_post_step: null argument");
+    DQ_REQUIRE(n_envs >= 1 && n_slots >= 2 && batch >= 1 && head_slot >= 0 && head_slot < n_slots, DQ_ERR_INVALID, "dq_post_step: bad sizes");
+    DQ_REQUIRE(filled_slots >= 2 && filled_slots <= n_slots, DQ_ERR_STATE, "dq_post_step: need at least one complete transition per lattice");
+    DQ_REQUIRE((long long)n_envs * n_slots < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_post_step: ring too large for 32-bit rows");
+    DQ_REQUIRE(done_dev && lifetime_dev && reward_dev && stats_dev && n >= 1, DQ_ERR_INVALID, "dq_post_step: bad statistics argument");
+    const int sb = (batch + 255) / 256;
+    post_step_kernel<<<sb + (n + 255) / 256, 256, 0, (hipStream_t)stream>>>(terminal_ring_dev, n_envs, n_slots, head_slot, filled_slots, batch,
+                                                                          seed[0], seed[1], t, sample_base, index_dev, sb, done_dev, was_reset_dev,
+                                                                          lifetime_dev, reward_dev, n, reinterpret_cast<unsigned long long*>(stats_dev));
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_td_update(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* q_s0_dev, const float* reward_dev,
+                       const uint8_t* terminal_dev, const int32_t* action_dev, const int32_t* index_dev, double gamma, int batch, int n_actions,
+                       double grad_scale, float* y_dev, float* dq_dev, float* metrics_dev, void* stream) {
+    DQ_REQUIRE(q_online_s1_dev && q_target_s1_dev && q_s0_dev && reward_dev && terminal_dev && action_dev && dq_dev, DQ_ERR_INVALID,
+               "dq_td_update: null argument");
+    DQ_REQUIRE(batch >= 1 && n_actions >= 1, DQ_ERR_INVALID, "dq_td_update: bad sizes");
+    const int blocks = (batch + 3) / 4 < TD_MAX_BLOCKS ? (batch + 3) / 4 : TD_MAX_BLOCKS;
+    dq_prof_begin(DQ_K_TD, (hipStream_t)stream);
+    td_update_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(q_online_s1_dev, q_target_s1_dev, q_s0_dev, reward_dev, terminal_dev, action_dev,
+                                                              index_dev, (float)gamma, batch, n_actions, (float)grad_scale, y_dev, dq_dev, metrics_dev);
+    dq_prof_end(DQ_K_TD, (hipStream_t)stream);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_td_metrics(float* metrics_dev, int batch, void* stream) {
+    DQ_REQUIRE(metrics_dev && batch >= 1, DQ_ERR_INVALID, "dq_td_metrics: bad argument");
+    const int blocks = (batch + 3) / 4 < TD_MAX_BLOCKS ? (batch + 3) / 4 : TD_MAX_BLOCKS;
+    td_metrics_kernel<<<1, 256, 0, (hipStream_t)stream>>>(metrics_dev, blocks, batch);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
 
 dq_status dq_episode_stats(const uint8_t* done_dev, const uint8_t* was_reset_dev, const uint32_t* lifetime_dev, const float* reward_dev,
                            int n, uint64_t* stats_dev, void* stream) {

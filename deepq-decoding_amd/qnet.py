@@ -185,6 +185,23 @@ def td_loss_grad(q_s0, action, y, grad_scale=None, index=None, dq=None, metrics=
     return dq, metrics
 
 
+def td_update(q_online_s1, q_target_s1, q_s0, reward, terminal, action, gamma, grad_scale=None, index=None, y=None, dq=None, metrics=None):
+    """td_target + td_loss_grad in one launch (dq_td_update); metrics[0..1] are valid only after td_metrics()."""
+    B, A = q_s0.shape
+    if dq is None:
+        dq = torch.empty_like(q_s0)
+    check(_lib.lib().dq_td_update(ptr(q_online_s1), ptr(q_target_s1), ptr(q_s0), ptr(reward), ptr(terminal), ptr(action), ptr(index), float(gamma),
+                                  B, A, 1.0 / B if grad_scale is None else float(grad_scale), ptr(y), ptr(dq), ptr(metrics),
+                                  _lib.current_stream(q_s0.device)))
+    return dq
+
+
+def td_metrics(metrics, batch):
+    """Final fixed-order reduction of the per-block loss / mean_q partials into metrics[0], metrics[1]."""
+    check(_lib.lib().dq_td_metrics(ptr(metrics), int(batch), _lib.current_stream(metrics.device)))
+    return metrics
+
+
 def adam_step(params, grads, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
     check(_lib.lib().dq_adam_step(ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), float(lr), float(beta_1), float(beta_2),
                                   float(epsilon), int(t), _lib.current_stream(params.device)))

@@ -255,6 +255,20 @@ dq_status dq_td_target(const float* q_online_s1_dev, const float* q_target_s1_de
 dq_status dq_td_loss_grad(const float* q_s0_dev, const int32_t* action_dev, const int32_t* index_dev, const float* y_dev,
                           int batch, int n_actions, double grad_scale, float* dq_dev, float* metrics_dev, void* stream);
 
+/* dq_td_target + dq_td_loss_grad in one launch (same arithmetic, same per-block metric partials), WITHOUT the final metric
+ * reduction: call dq_td_metrics(metrics_dev, batch) before reading metrics_dev[0..1] (the training loop only reads them at its
+ * logging interval).  y_dev nullable. */
+dq_status dq_td_update(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* q_s0_dev, const float* reward_dev,
+                       const uint8_t* terminal_dev, const int32_t* action_dev, const int32_t* index_dev, double gamma, int batch,
+                       int n_actions, double grad_scale, float* y_dev, float* dq_dev, float* metrics_dev, void* stream);
+dq_status dq_td_metrics(float* metrics_dev, int batch, void* stream);
+
+/* dq_replay_sample (for the next update) + dq_episode_stats (of the step just taken) in one launch. */
+dq_status dq_post_step(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots, int batch,
+                       const uint32_t seed[2], uint64_t t, uint32_t sample_base, int32_t* index_dev, const uint8_t* done_dev,
+                       const uint8_t* was_reset_dev, const uint32_t* lifetime_dev, const float* reward_dev, int n, uint64_t* stats_dev,
+                       void* stream);
+
 /* Episode bookkeeping the keras-rl fork does on the host per step (episode ends, env.lifetime of finished
  * episodes -- Single_Point_Training_Script.py:207 reads their rolling average): accumulates into uint64 stats_dev[4]
  * = {episodes ended, sum of their lifetimes, rewards earned, lattices stepped}.  was_reset_dev nullable. */

@@ -173,6 +173,40 @@ def test_td_target_loss_adam(dq, torch_mod):
     assert np.abs(mt.cpu().numpy() - mr).max() < 1e-6 and np.abs(vt.cpu().numpy() - vr).max() < 1e-6
 
 
+def test_fused_td_update_and_post_step_equal_the_separate_kernels(dq, torch_mod):
+    """dq_td_update == dq_td_target + dq_td_loss_grad (bit for bit); dq_post_step == dq_replay_sample + dq_episode_stats."""
+    torch = torch_mod
+    from importlib import import_module
+    qn, lib = import_module("deepq-decoding_amd.qnet"), import_module("deepq-decoding_amd._lib")
+    rng = np.random.RandomState(4)
+    B, A, R = 333, 51, 2000
+    cu = lambda a: torch.from_numpy(a).cuda()
+    q1o, q1t, q0 = (cu(rng.randn(B, A).astype(np.float32)) for _ in range(3))
+    reward, terminal = cu((rng.rand(R) < 0.4).astype(np.float32)), cu((rng.rand(R) < 0.2).astype(np.uint8))
+    action, idx = cu(rng.randint(0, A, size=R).astype(np.int32)), cu(rng.randint(0, R, size=B).astype(np.int32))
+    y = dq.td_target(q1o, q1t, reward, terminal, 0.99, index=idx)
+    dq_ref, met_ref = dq.td_loss_grad(q0, action, y, grad_scale=0.01, index=idx)
+    y2 = torch.empty_like(y)
+    met = torch.zeros(qn.TD_METRICS_FLOATS, dtype=torch.float32, device="cuda")
+    dq2 = qn.td_update(q1o, q1t, q0, reward, terminal, action, 0.99, grad_scale=0.01, index=idx, y=y2, metrics=met)
+    qn.td_metrics(met, B)
+    assert torch.equal(y, y2) and torch.equal(dq_ref, dq2) and torch.equal(met_ref[:2], met[:2])
+    # post-step
+    n_envs, n_slots, head, filled, batch = 64, 20, 7, 20, 500
+    term = cu((rng.rand(n_slots, n_envs) < 0.15).astype(np.uint8))
+    done, was_reset = cu((rng.rand(n_envs) < 0.3).astype(np.uint8)), cu((rng.rand(n_envs) < 0.1).astype(np.uint8))
+    life, rew = cu(rng.randint(1, 100, size=n_envs).astype(np.uint32)), cu((rng.rand(n_envs) < 0.5).astype(np.float32))
+    seed, t, base = (8, 9), 55, 1000
+    idx_ref = dq.replay_sample(term, n_envs, n_slots, head, filled, batch, seed, t, sample_base=base)
+    stats_ref, stats = torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros(4, dtype=torch.int64, device="cuda")
+    L, p = lib.lib(), lib.ptr
+    lib.check(L.dq_episode_stats(p(done), p(was_reset), p(life), p(rew), n_envs, p(stats_ref), lib.current_stream()))
+    idx2 = torch.empty_like(idx_ref)
+    lib.check(L.dq_post_step(p(term), n_envs, n_slots, head, filled, batch, qn._seed_arr(seed), t, base, p(idx2), p(done), p(was_reset), p(life),
+                             p(rew), n_envs, p(stats), lib.current_stream()))
+    assert torch.equal(idx_ref, idx2) and torch.equal(stats_ref, stats)
+
+
 def test_replay_sample_rule(dq, torch_mod):
     """Sampled rows are complete transitions, never start at a post-terminal entry, match the Philox definition,
     and cover the ring roughly uniformly."""
