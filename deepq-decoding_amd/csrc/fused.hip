@@ -135,22 +135,43 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     const int b0 = ((int)blockIdx.x - J.wg0) * a.S;
     const int ns = min(a.S, J.batch - b0);
     const int in_bytes = a.C * a.H * a.W;
+    constexpr int NH1 = (KG1 + 1) / 2;                              // first convolution's K in halves of 32
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 0);
     // ---- first convolution's weights -> registers (the loads fly while the observations are staged) ----------------
+    // The observation is binary, so conv1 runs on the bf16 matrix pipe (16x the f32 rate) WITHOUT losing a bit: 0/1 is exact in
+    // bf16, and every f32 weight is split exactly into three bf16 pieces w = hi + mid + lo (8 + 8 + 8 mantissa bits, by
+    // truncation); each product a*piece is exact and the pieces are accumulated in f32 by v_mfma_f32_16x16x32_bf16.  The result
+    // differs from an f32 fma chain only by the order of the f32 additions.  Layout of 16x16x32: lane (kb = lane >> 4, i = lane & 15)
+    // holds A[i][8kb .. 8kb+7] / B[8kb .. 8kb+7][i]; column tile t, lane j is column 4j + t (float4 weight loads).
     const float* w1 = J.params + a.w_off[0];
-    f32x4 b1[KG1][4];
-    int ko[KG1][4];
+    u32x4 wb[3][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 bf16 each
+    int ko[NH1][8];
 #pragma unroll
-    for (int g = 0; g < KG1; ++g)
+    for (int h = 0; h < NH1; ++h) {
+        f32x4 wv[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 16 * g + 4 * kq + s;
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * h + 8 * kq + e;
             const int off = a.kofftab[k];                           // Keras HWIO row k = (ky*k1 + kx)*C + c -> NCHW uint8 offset
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + (size_t)(off >= 0 ? k : 0) * 64 + 4 * j);
-            b1[g][s] = off >= 0 ? wv : f32x4{0.f, 0.f, 0.f, 0.f};
-            ko[g][s] = off >= 0 ? off : 0;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w1 + (size_t)(off >= 0 ? k : 0) * 64 + 4 * j);
+            wv[e] = off >= 0 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            ko[h][e] = off >= 0 ? off : 0;
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {                        // two k's per dword: element e in the low half
+                float x0 = wv[e][t], x1 = wv[e + 1][t];
+#pragma unroll
+                for (int piece = 0; piece < 3; ++piece) {
+                    const u32 b0 = __float_as_uint(x0) & 0xffff0000u, b1 = __float_as_uint(x1) & 0xffff0000u;
+                    wb[piece][h][t][e >> 1] = (b0 >> 16) | b1;
+                    x0 -= __uint_as_float(b0);                      // exact: the remainder has 8 fewer significant bits
+                    x1 -= __uint_as_float(b1);
+                }
+            }
+    }
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 1);
@@ -204,14 +225,19 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int g = 0; g < KG1; ++g) {
-                float av[4];
+            for (int h = 0; h < NH1; ++h) {
+                u32 ab[8];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) av[s4] = (float)ap[ko[g][s4]];
+                for (int e = 0; e < 8; ++e) ab[e] = ap[ko[h][e]];   // 0 or 1
+                u32x4 av;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
+                for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[e] | (ab[e + 1] << 16)) * 0x3f80u;       // bf16(1.0) = 0x3f80
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[s4], b1[g][s4][t], acc[t]);
+                for (int piece = 0; piece < 3; ++piece)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, wb[piece][h][t]),
+                                                                         acc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
