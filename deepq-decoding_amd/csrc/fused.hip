@@ -314,6 +314,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     const int ns = min(DENSE_ROWS, J.batch - b0);
     const int K1 = a.K1, KG = K1 >> 4;
 
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 0);
     // ---- hidden layer's first weight rows start flying before anything else ----------------------------------------
     const float* w1 = J.params + a.w_off[0] + 64 * wave + 4 * j;
     f32x4 bA[4], bB[4];
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     }
     __syncthreads();
 
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 1);
     // ---- Dense(512): wave w owns columns [64w, 64w+64) as 4 interleaved tiles; weights double-buffered ------------------
     f32x4 acc[4];
 #pragma unroll
@@ -363,6 +365,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[s], bB[s][t], acc[t]);
     }
 
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
     // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
     const float* w2 = J.params + a.w_off[1];
     // Dense(|A|) splits K = 512 into 8 parts of 64 rows, one per wave, every column tile in each.  Tile t, lane j is column
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             }
     }
 
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 3);
     // ---- hidden layer epilogue: bias, ReLU, dropout (one Philox call = this lane's 4 columns of a row) -----------------
     {
         const int c0 = 64 * wave + 4 * j;
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     }
     __syncthreads();
 
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 4);
     // ---- Dense(|A|): K = 512 split over the 8 waves, partial tiles reduced in fixed order ---------------------------------
     {
         f32x4 acc2[NT2];
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                     f32x4{acc2[4 * q][r], acc2[4 * q + 1][r], acc2[4 * q + 2][r], acc2[4 * q + 3][r]};
     }
     __syncthreads();
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 5);
     for (int e = tid; e < DENSE_ROWS * a.N2; e += DENSE_THREADS) {
         const int row = e / a.N2, col = e - row * a.N2;
         float v = J.params[a.b_off[1] + col];
@@ -464,6 +470,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     }
     __syncthreads();
 
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 6);
     // ---- dueling layer Dense(|A|+1) and the combination Q = V + A - mean(A) ------------------------------------------------
     const float* y = s_y2;
     int ldy = a.ld2;
@@ -493,6 +500,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         y = s_y3;
         ldy = a.ld3;
     }
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 7);
     const int A = a.n_actions;
     for (int row = wave; row < ns; row += DENSE_WAVES) {
         const float* yr = y + row * ldy;
@@ -506,6 +514,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             for (int c = lane; c < A; c += 64) J.q_out[(size_t)(b0 + row) * A + c] = yr[c];
         }
     }
+    DQ_STAMP(DQ_TAG_DENSE_FWD, 8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

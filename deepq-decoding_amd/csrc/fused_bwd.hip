@@ -70,36 +70,36 @@ __device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const float* __re
     const int j = lane & 15, kq = lane >> 4, K1 = a.K1;
     const float* wp = a.w1t + (size_t)(4 * kq) * K1 + 16 * tile0 + NTP * j;
     const float* hrow = s_gh1 + j * LDH + 4 * kq;
-    float bA[4][NTP], bB[4][NTP];
-    auto load = [&](int g, float (&bw)[4][NTP]) {
+    constexpr int RING = 4;                                         // k-groups in the ring, RING-1 in flight (L2 latency >> 12 MFMAs)
+    float bw[RING][4][NTP];
+    auto load = [&](int g, float (&b)[4][NTP]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if constexpr (NTP == 1) {
-                bw[s][0] = wp[(size_t)(16 * g + s) * K1];
+                b[s][0] = wp[(size_t)(16 * g + s) * K1];
             } else {
                 const vec_t v = *reinterpret_cast<const vec_t*>(wp + (size_t)(16 * g + s) * K1);
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) bw[s][t] = v[t];
+                for (int t = 0; t < NTP; ++t) b[s][t] = v[t];
             }
         }
     };
     f32x4 acc[NTP];
 #pragma unroll
     for (int t = 0; t < NTP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load(0, bA);
-    for (int g = 0; g < NG; g += 2) {
-        load(g + 1, bB);
-        f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 16 * g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+    for (int u = 0; u < RING - 1; ++u) load(u, bw[u]);
+    static_assert(NG % RING == 0, "whole rings");
+    for (int g = 0; g < NG; g += RING) {
 #pragma unroll
-            for (int t = 0; t < NTP; ++t) acc[t] = MFMA16(av[s], bA[s][t], acc[t]);
-        load(g + 2 < NG ? g + 2 : g, bA);                           // unconditional (clamped): keeps the s_waitcnt counts static
-        av = *reinterpret_cast<const f32x4*>(hrow + 16 * (g + 1));
+        for (int u = 0; u < RING; ++u) {
+            load(g + u + RING - 1 < NG ? g + u + RING - 1 : NG - 1, bw[(u + RING - 1) % RING]);     // unconditional (clamped): static s_waitcnt counts
+            const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 16 * (g + u));
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < NTP; ++t) acc[t] = MFMA16(av[s], bB[s][t], acc[t]);
+                for (int t = 0; t < NTP; ++t) acc[t] = MFMA16(av[s], bw[u][s][t], acc[t]);
+        }
     }
 #pragma unroll
     for (int t = 0; t < NTP; ++t) {
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     const int ns = min(DENSE_ROWS, a.batch - b0);
     const int A = a.n_actions, N2 = a.N2, N3 = a.N3, ldg = a.ldg;
 
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 0);
     for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) { s_g3[i] = 0.f; s_gy2[i] = 0.f; }
     __syncthreads();
     // ---- dueling backward: g3[b,0] = sum_a dq[b,a];  g3[b,1+a] = dq[b,a] - (1/A) sum_a' dq[b,a'] ----------------------
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         }
     }
     __syncthreads();
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 1);
     // ---- gY2 = g3 W3^T  (K = N3, one column tile per wave) -------------------------------------------------------------
     if (N3 > 0) {
         if (wave < NT2) {
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         }
         __syncthreads();
     }
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 2);
     // ---- gH1 = (gY2 W2^T) * [h1 > 0] * scale  (K = N2; wave w owns columns 64w + 4j + t) ----------------------------------
     {
         const int c0 = 64 * wave + 4 * j;
@@ -225,7 +228,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             if (row < ns) *reinterpret_cast<f32x4*>(a.gh1 + (size_t)(b0 + row) * DENSE_HID + c0) = v;
         }
     }
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 3);
     __syncthreads();
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 4);
     // ---- gX = (gH1 W1T) * [x > 0]  (K = 512): each wave owns a run of adjacent column tiles (counts differ by at most one, the
     //      longer runs on different SIMDs), taken up to three at a time with interleaved columns ---------------------------------
     {
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             else { gx_pass<1>(a, s_gh1, t0, b0, ns, lane); t0 += 1; left -= 1; }
         }
     }
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -279,22 +285,32 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
     for (int ti = 0; ti < TK; ++ti) { kcol[ti] = kbase + 16 * ti + j; kok[ti] = kcol[ti] < K; if (!kok[ti]) kcol[ti] = 0; }
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) { ncol[tj] = nbase + 16 * tj + j; nok[tj] = ncol[tj] < N; if (!nok[tj]) ncol[tj] = 0; }
+    float kmask[TK], nmask[4];
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti) kmask[ti] = kok[ti] ? 1.f : 0.f;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) nmask[tj] = nok[tj] ? 1.f : 0.f;
     f32x4 acc[TK][4];
 #pragma unroll
     for (int ti = 0; ti < TK; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    float xa0[TK], xa1[TK], gb0[4], gb1[4];
+    float xr[4][TK], gr4[4][4];                                     // ring of four 4-row steps, three in flight
     auto load = [&](int m, float (&xa)[TK], float (&gb)[4]) {
         const int row = m + kq;
         const bool rok = row < m1;
-        const float* xr = L.X + (size_t)(rok ? row : 0) * K;
-        const float* gr = L.G + (size_t)(rok ? row : 0) * N;
+        // unconditional loads of a clamped row / column, masked by select (a load under a condition gets its own branch and
+        // s_waitcnt, which drains the ring)
+        const int rc = rok ? row : m1 - 1;
+        const float* xp = L.X + (size_t)rc * K;
+        const float* gp = L.G + (size_t)rc * N;
+        // (masked by MULTIPLYING with 0/1: hipcc sinks a load whose only use is a select back under the condition)
+        const float rm = rok ? 1.f : 0.f;
 #pragma unroll
-        for (int ti = 0; ti < TK; ++ti) xa[ti] = (rok && kok[ti]) ? xr[kcol[ti]] : 0.f;
+        for (int ti = 0; ti < TK; ++ti) xa[ti] = xp[kcol[ti]] * (rm * kmask[ti]);
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) gb[tj] = (rok && nok[tj]) ? gr[ncol[tj]] : 0.f;
+        for (int tj = 0; tj < 4; ++tj) gb[tj] = gp[ncol[tj]] * (rm * nmask[tj]);
     };
     auto mma = [&](const float (&xa)[TK], const float (&gb)[4]) {
 #pragma unroll
@@ -304,12 +320,15 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) bsum[tj] += gb[tj];
     };
-    load(m0, xa0, gb0);
-    for (int m = m0; m < m1; m += 8) {
-        load(m + 4, xa1, gb1);
-        mma(xa0, gb0);
-        load(m + 8, xa0, gb0);
-        mma(xa1, gb1);
+    load(m0, xr[0], gr4[0]);
+    load(m0 + 4, xr[1], gr4[1]);
+    load(m0 + 8, xr[2], gr4[2]);
+    for (int m = m0; m < m1; m += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load(m + 4 * (u + 3), xr[(u + 3) & 3], gr4[(u + 3) & 3]);    // rows past the slice are masked to zero inside load()
+            mma(xr[u], gr4[u]);
+        }
     }
     // ---- combine the workgroup's four slices in fixed order, write one partial ---------------------------------------
     float* sp = s_part + wave * (64 * 64);

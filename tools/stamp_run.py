@@ -31,3 +31,11 @@ elif tag == 1:
     for w in range(4):
         t = [buf[i * 8 + w] for i in range(8)]
         print("wave", w, "w1-issue, stage, conv1, bar, conv2, bar, conv3:", [t[i + 1] - t[i] for i in range(7)], "total", t[7] - t[0])
+elif tag == 2:
+    for w in range(8):
+        t = [buf[i * 8 + w] for i in range(9)]
+        print("wave", w, "stage, dense1, w2-issue, epilogue+bar, dense2+bar, reduce+bar, dense3+bar, head:", [t[i + 1] - t[i] for i in range(8)], "total", t[8] - t[0])
+elif tag == 3:
+    for w in range(8):
+        t = [buf[i * 8 + w] for i in range(6)]
+        print("wave", w, "zero+dueling, gY2, gH1, bar, gX:", [t[i + 1] - t[i] for i in range(5)], "total", t[5] - t[0])
