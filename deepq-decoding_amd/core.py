@@ -145,9 +145,17 @@ class DQNCore:
         _q.td_update(q_sel, self.q1_target, self.q0, self.reward_ring, self.terminal_ring, self.action_ring, self.gamma,
                      grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, y=self.y, dq=self.dq, metrics=self.metrics)
         self._metrics_stale = True
-        net.backward(self.params, self.dq, grads=self.grads)
         if self.world_size > 1:
-            _dist.allreduce_sum_(self.grads, group=self.pg)
+            # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs
+            nconv = net.n_conv_params
+            net.backward_phase(self.params, self.dq, self.grads, 0)
+            work = _dist.allreduce_sum_async(self.grads[nconv:], group=self.pg)
+            net.backward_phase(self.params, self.dq, self.grads, 1)
+            _dist.allreduce_sum_(self.grads[:nconv], group=self.pg)
+            if work is not None:
+                work.wait()
+        else:
+            net.backward(self.params, self.dq, grads=self.grads)
         _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
 
     def read_metrics(self):

@@ -832,7 +832,9 @@ size_t fused_backward_workspace_floats(const dq_qnet* Q) {
 
 typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
 
-dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, hipStream_t st) {
+// phases: bit 0 = dense part (data gradients, dense weight gradients reduced into grads_dev[conv params ..)), bit 1 = convolutional
+// part (grads_dev[0 .. conv params)).  3 = whole backward with one reduction launch.
+dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st) {
     DenseBwdPlan dp;
     ConvBwdPlan cp;
     DQ_REQUIRE(plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp), DQ_ERR_UNSUPPORTED, "fused_backward: configuration not covered");
@@ -854,6 +856,9 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     float* conv_partial = dense_partial + (size_t)DENSE_WGRAD_SLICES * Q->n_params;
     float* w1t = conv_partial + (size_t)CONV_BWD_MAX_WGS * D1.w_off;
     float* w2t = w1t + (size_t)D1.K * D1.N;
+    const size_t conv_floats = D1.w_off;
+    const int n_dense = (int)(Q->n_params - conv_floats);
+    if (phases & 1) {
     {
         TrArgs ta;
         memset(&ta, 0, sizeof(ta));
@@ -911,6 +916,15 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     dq_prof_end(DQ_K_DENSE_WGRAD, st);
     DQ_LAUNCH_CHECK();
 
+    if (phases != 3) {                                              // phased: the dense gradients are complete (and reducible) now
+        ReduceArgs ra;
+        ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, 0};
+        ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
+        reduce_slices_kernel<<<(n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
+        DQ_LAUNCH_CHECK();
+    }
+    }
+    if (!(phases & 2)) return DQ_OK;
     // ---- 3. convolutions: data + weight gradients, one persistent launch -----------------------------------------------
     ConvBwdArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -921,7 +935,6 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
-    const size_t conv_floats = D1.w_off;
     ca.partial = conv_partial; ca.pstride = conv_floats;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
     ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3; ca.off_ko = cp.off_ko; ca.kofftab = Q->kofftab;
@@ -936,9 +949,17 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     // ---- 4. fixed-order reductions of the partials into the flat gradient ------------------------------------------------
     ReduceArgs ra;
     ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0};
-    const int blocks0 = ((int)conv_floats + 63) / 64, n_dense = (int)(Q->n_params - conv_floats);
-    ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, blocks0};
-    reduce_slices_kernel<<<blocks0 + (n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
+    const int blocks0 = ((int)conv_floats + 63) / 64;
+    if (phases == 3) {
+        int rpw = (B + DENSE_WGRAD_SLICES * WGRAD_WAVES - 1) / (DENSE_WGRAD_SLICES * WGRAD_WAVES);
+        rpw = (rpw + 7) & ~7;
+        const int sy = (B + rpw * WGRAD_WAVES - 1) / (rpw * WGRAD_WAVES);
+        ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, blocks0};
+        reduce_slices_kernel<<<blocks0 + (n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
+    } else {
+        ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
+        reduce_slices_kernel<<<blocks0, dim3(64, 8), 0, st>>>(ra);
+    }
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

@@ -58,4 +58,4 @@ dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_
 // fused_bwd.hip: fused backward (data-gradient chains + all-layer weight gradients) for the same configurations
 bool fused_backward_supported(const dq_qnet* Q);
 size_t fused_backward_workspace_floats(const dq_qnet* Q);
-dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, hipStream_t st);
+dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st);

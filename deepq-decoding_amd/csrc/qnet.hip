@@ -537,28 +537,46 @@ dq_status dq_qnet_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs,
     return DQ_OK;
 }
 
-dq_status dq_qnet_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, void* stream) {
-    DQ_REQUIRE(Q && params_dev && dq_dev && grads_dev, DQ_ERR_INVALID, "dq_qnet_backward: null argument");
+// phases: bit 0 = dense layers (+ dueling), bit 1 = convolutions; 3 = everything
+static dq_status backward_phases(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st) {
+    DQ_REQUIRE(Q && params_dev && grads_dev && ((phases & 1) == 0 || dq_dev), DQ_ERR_INVALID, "dq_qnet_backward: null argument");
     DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_backward: no training forward to differentiate");
-    hipStream_t st = (hipStream_t)stream;
-    const int B = Q->last_train_batch, nl = Q->n_layers;
-    if (Q->use_fused && fused_backward_supported(Q)) return fused_backward(Q, params_dev, dq_dev, grads_dev, st);
-    // gradient w.r.t. the last layer's (linear) output
-    float* g = Q->gz[nl - 1];
-    if (Q->cfg.dueling) {
-        dueling_bwd_kernel<<<(B + 3) / 4, 256, 0, st>>>(dq_dev, g, B, Q->cfg.n_actions);
-        DQ_LAUNCH_CHECK();
-    } else {
-        DQ_HIP(hipMemcpyAsync(g, dq_dev, (size_t)B * Q->cfg.n_actions * sizeof(float), hipMemcpyDeviceToDevice, st));
+    const int B = Q->last_train_batch, nl = Q->n_layers, nc = Q->cfg.n_conv;
+    if (Q->use_fused && fused_backward_supported(Q)) return fused_backward(Q, params_dev, dq_dev, grads_dev, phases, st);
+    if (phases & 1) {
+        // gradient w.r.t. the last layer's (linear) output
+        float* g = Q->gz[nl - 1];
+        if (Q->cfg.dueling) {
+            dueling_bwd_kernel<<<(B + 3) / 4, 256, 0, st>>>(dq_dev, g, B, Q->cfg.n_actions);
+            DQ_LAUNCH_CHECK();
+        } else {
+            DQ_HIP(hipMemcpyAsync(g, dq_dev, (size_t)B * Q->cfg.n_actions * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
     }
     for (int i = nl - 1; i >= 0; --i) {
+        const bool dense = i >= nc;
+        if (!(phases & (dense ? 1 : 2))) continue;
         dq_status rc = layer_wgrad(Q, i, grads_dev, st);
         if (rc != DQ_OK) return rc;
         if (i == 0) break;
-        rc = layer_dgrad(Q, params_dev, i, st);
-        if (rc != DQ_OK) return rc;
+        if (dense || (phases & 2)) {
+            if (i == nc && !(phases & 1)) continue;                 // (the dense phase already produced gz[nc-1])
+            rc = layer_dgrad(Q, params_dev, i, st);
+            if (rc != DQ_OK) return rc;
+        }
     }
     return DQ_OK;
 }
+
+dq_status dq_qnet_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, void* stream) {
+    return backward_phases(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream);
+}
+
+dq_status dq_qnet_backward_phase(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phase, void* stream) {
+    DQ_REQUIRE(phase == 0 || phase == 1, DQ_ERR_INVALID, "dq_qnet_backward_phase: phase is 0 (dense) or 1 (convolutions)");
+    return backward_phases(Q, params_dev, dq_dev, grads_dev, phase == 0 ? 1 : 2, (hipStream_t)stream);
+}
+
+size_t dq_qnet_conv_param_count(const dq_qnet* Q) { return Q ? Q->L[Q->cfg.n_conv].w_off : 0; }
 
 }  // extern "C"

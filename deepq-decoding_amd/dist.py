@@ -50,6 +50,15 @@ def allreduce_sum_(flat, group=None):
     return flat
 
 
+def allreduce_sum_async(flat, group=None):
+    """Starts the in-place sum and returns the work handle (None when there is nothing to do): the collective runs on the
+    communicator's stream, ordered after the work already queued on the current stream, while later kernels on the current
+    stream proceed; `handle.wait()` orders the current stream after it."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 def broadcast_(flat, src=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)

@@ -44,6 +44,7 @@ class QNetwork:
             check(self.L.dq_qnet_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
         self.n_params = int(self.L.dq_qnet_param_count(self._h))
+        self.n_conv_params = int(self.L.dq_qnet_conv_param_count(self._h))     # flat layout: convolutions first, then the dense layers
         self.layers = []
         for i in range(self.L.dq_qnet_num_layers(self._h)):
             ko, bo, shape, nd = ctypes.c_int64(), ctypes.c_int64(), (ctypes.c_int32 * 4)(), ctypes.c_int32()
@@ -163,6 +164,15 @@ class QNetwork:
             grads = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
         check(self.L.dq_qnet_backward(self._h, ptr(params), ptr(dq), ptr(grads), self._stream()))
         return grads
+
+
+def _backward_phase(self, params, dq, grads, phase):
+    """Phase 0: dueling + dense layers (grads[n_conv_params:] complete); phase 1: convolutions (grads[:n_conv_params])."""
+    check(self.L.dq_qnet_backward_phase(self._h, ptr(params), ptr(dq), ptr(grads), int(phase), self._stream()))
+    return grads
+
+
+QNetwork.backward_phase = _backward_phase
 
 
 def td_target(q_online_s1, q_target_s1, reward, terminal, gamma, index=None, out=None):

@@ -226,6 +226,13 @@ dq_status dq_qnet_forward_multi(dq_qnet* net, int n_jobs, const dq_qnet_job* job
  * (obs_dev / index_dev of that call must still be valid).  Deterministic (fixed-order reductions). */
 dq_status dq_qnet_backward(dq_qnet* net, const float* params_dev, const float* dq_dev, float* grads_dev, void* stream);
 
+/* The same backward in two phases, for overlapping the gradient all-reduce with compute on several GPUs (no reference
+ * counterpart): phase 0 = dueling + dense layers -> grads_dev[dq_qnet_conv_param_count(net) ..) complete; phase 1 = the
+ * convolutions -> grads_dev[0 .. dq_qnet_conv_param_count(net)).  Phase 0 must run first; dq_dev is only read by phase 0. */
+dq_status dq_qnet_backward_phase(dq_qnet* net, const float* params_dev, const float* dq_dev, float* grads_dev, int phase,
+                                 void* stream);
+size_t dq_qnet_conv_param_count(const dq_qnet* net);
+
 /* ---------------------------------------------------------------------------------------------
  * DQN update: replaces SequentialMemory.sample + DQNAgent.backward + keras Adam of the keras-rl fork
  * (Single_Point_Training_Script.py:109,119-130).

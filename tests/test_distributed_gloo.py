@@ -63,7 +63,13 @@ def _run_rank(rank, world, n_local, b_local, allreduce, steps=STEPS, perturb=Tru
         dq[np.arange(b_local), a[idx]] = diff * D.grad_scale(b_local, world)
         g = torch.from_numpy(O.backward(spec, p, cache, dq))
         if allreduce:
-            D.allreduce_sum_(g)
+            # the product's update all-reduces the gradient in two pieces: the dense range asynchronously (overlapped with the
+            # convolutional backward on the GPU), then the convolutional range (core.DQNCore.update)
+            ncut = g.numel() // 3
+            work = D.allreduce_sum_async(g[ncut:])
+            D.allreduce_sum_(g[:ncut])
+            if work is not None:
+                work.wait()
         last_g = g.numpy().copy()
         if first_g is None:
             first_g = last_g
@@ -112,5 +118,6 @@ def test_single_process_helpers_are_noops():
     D = importlib.import_module("deepq-decoding_amd.dist")
     x = torch.arange(5, dtype=torch.float64)
     assert torch.equal(D.allreduce_sum_(x.clone()), x) and torch.equal(D.broadcast_(x.clone()), x)
+    assert D.allreduce_sum_async(x.clone()) is None
     os.environ.pop("WORLD_SIZE", None)
     assert D.init_from_env() == (0, 1, 0)

@@ -124,6 +124,24 @@ def test_forward_multi_equals_separate_forwards(dq, torch_mod):
         net.forward_multi([dict(params=params, obs=ring, index=idx, training=True, seed=seed, t=t)] * 2)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
+def test_backward_in_two_phases_equals_one_call(dq, torch_mod, fused):
+    """dq_qnet_backward_phase 0 (dense) then 1 (convolutions) == dq_qnet_backward, bit for bit; after phase 0 the dense range of the
+    gradient is already final (it is all-reduced while phase 1 runs on several GPUs)."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 100, fused=fused)
+    dq_ = torch.from_numpy((rng.randn(100, 51) / 100).astype(np.float32)).cuda()
+    net.forward(params, torch.from_numpy(obs).cuda(), training=True, seed=(1, 2), t=3)
+    g_ref = net.backward(params, dq_).cpu().numpy()
+    g = torch.full_like(params, float("nan"))
+    net.backward_phase(params, dq_, g, 0)
+    nconv = net.n_conv_params
+    assert nconv == spec.n_params - sum(int(np.prod(k)) + int(np.prod(b)) for k, b in spec.param_shapes()[3:])
+    assert np.array_equal(g[nconv:].cpu().numpy(), g_ref[nconv:]) and torch.isnan(g[:nconv]).all()
+    net.backward_phase(params, dq_, g, 1)
+    assert np.array_equal(g.cpu().numpy(), g_ref)
+
+
 def test_fused_and_per_layer_paths_agree(dq, torch_mod):
     """The two HIP forward/backward implementations order their dot products differently: same results to f32 round-off."""
     torch = torch_mod
