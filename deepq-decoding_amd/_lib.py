@@ -62,6 +62,7 @@ SIGNATURES = {
     "dq_env_get_referee": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
     "dq_env_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dq_env_act_step": (_i, [_vp, _vp, _dbl, _i, _seedp, _u64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_export_state": (_i, [_vp, _vp, _vp]),
     "dq_env_import_state": (_i, [_vp, _vp, _vp]),
     "dq_env_get_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),

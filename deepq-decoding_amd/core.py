@@ -97,9 +97,11 @@ class DQNCore:
         q = None
         if use_q:
             q = self.net.forward(self.params, obs, batch=self.N, out=self.q_act)
-        env.select_actions(self.vector_steps, q=q, eps=eps, masked_greedy=masked_greedy, out=self.action_ring[cur])
-        check(self.L.dq_env_step(env._h, ptr(self.action_ring[cur]), 1, ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]),
-                                 ptr(self.terminal_ring[cur]), ptr(env.legal), ptr(env.lifetime), ptr(env.was_reset), self._stream()))
+        # action selection + environment step in one launch (dq_env_act_step == dq_policy_select then dq_env_step)
+        seed = (ctypes.c_uint32 * 2)(*env.seed)
+        check(self.L.dq_env_act_step(env._h, ptr(q), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
+                                     ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
+                                     ptr(env.lifetime), ptr(env.was_reset), self._stream()))
         # episode bookkeeping of this step: launched together with the next update's replay sampling (dq_post_step) when an update
         # follows, else on its own
         self._stats_pending = (cur,) if record_stats else None

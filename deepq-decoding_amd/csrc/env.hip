@@ -71,6 +71,13 @@ struct EnvParams {
     u64* legal;
     u32* lifetime;
     u8* was_reset;
+    // fused action selection (dq_env_act_step): the rule of policy.hip's policy_kernel, one lattice per wave
+    int policy;                    // 0: actions come from `action`; 1: selected here and written to action_out
+    const float* q;                // [n_envs, n_actions] or NULL (explore always)
+    u64 T_eps, pt;
+    int masked_greedy;
+    u32 pseed0, pseed1;
+    int32_t* action_out;
 };
 
 static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s) {
@@ -127,8 +134,35 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p) {
         if (do_reset) {                                                     // ENV:106-107, 211-213
             done = 0; lifetime = 0; xmask = 0; zmask = 0;
         }
+        int a_sel = 0;
+        if (p.policy) {                                                     // EpsGreedyQPolicy / GreedyQPolicy(masked_greedy), see policy.hip
+            u32 w[4];
+            philox4x32_10((u32)p.pt, (u32)(p.pt >> 32), p.env_id_base + (u32)i, (u32)DQ_STREAM_POLICY << 16, p.pseed0, p.pseed1, w);
+            if (p.q == nullptr || (u64)w[1] < p.T_eps) {                    // explore: k-th smallest legal action
+                const int n_legal = __popcll(legal0) + __popcll(legal1);
+                a_sel = kth_set_bit128(legal0, legal1, (int)__umulhi(w[0], (u32)n_legal));
+            } else {                                                        // first maximum of the Q row (optionally over the legal set)
+                const float* row = p.q + (size_t)i * p.n_actions;
+                float best = -INFINITY;
+                int best_a = 0x7fffffff;
+                for (int k = lane; k < p.n_actions; k += 64) {
+                    const bool ok = !p.masked_greedy || (((k < 64 ? legal0 : legal1) >> (k & 63)) & 1);
+                    const float v = row[k];
+                    if (ok && (v > best || best_a == 0x7fffffff)) { best = v; best_a = k; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const float ov = __shfl_xor(best, m);
+                    const int oa = __shfl_xor(best_a, m);
+                    if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
+                }
+                a_sel = best_a;
+            }
+            a_sel = __builtin_amdgcn_readfirstlane(a_sel);
+            if (lane == 0) p.action_out[i] = a_sel;
+        }
         if (do_step) {
-            int a = __builtin_amdgcn_readfirstlane(p.action[i]);
+            int a = p.policy ? a_sel : __builtin_amdgcn_readfirstlane(p.action[i]);
             if ((unsigned)a >= (unsigned)p.n_actions) a = p.identity;
             const u64 cw = a < 64 ? comp0 : comp1;
             const bool done_identity = a == p.identity || ((cw >> (a & 63)) & 1);      // ENV:131
@@ -561,6 +595,21 @@ dq_status dq_env_step(dq_env* E, const int32_t* action_dev, int auto_reset, uint
     memset(&p, 0, sizeof(p));
     p.mode = 1; p.auto_reset = auto_reset; p.action = action_dev; p.obs = obs_dev; p.reward = reward_dev;
     p.done = done_dev; p.legal = legal_dev; p.lifetime = lifetime_dev; p.was_reset = was_reset_dev;
+    return launch_env(E, p, (hipStream_t)stream);
+}
+
+dq_status dq_env_act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
+                          int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
+                          uint32_t* lifetime_dev, uint8_t* was_reset_dev, void* stream) {
+    DQ_REQUIRE(E && action_dev && seed, DQ_ERR_INVALID, "dq_env_act_step: null argument");
+    DQ_REQUIRE(E->lut_x, DQ_ERR_STATE, "dq_env_act_step: no referee installed (dq_env_build_referee / dq_env_set_referee)");
+    DQ_REQUIRE(eps >= 0.0 && eps <= 1.0, DQ_ERR_INVALID, "dq_env_act_step: eps must be in [0,1]");
+    EnvParams p;
+    memset(&p, 0, sizeof(p));
+    p.mode = 1; p.auto_reset = auto_reset; p.obs = obs_dev; p.reward = reward_dev;
+    p.done = done_dev; p.legal = legal_dev; p.lifetime = lifetime_dev; p.was_reset = was_reset_dev;
+    p.policy = 1; p.q = q_dev; p.T_eps = dq_rate_threshold(eps); p.masked_greedy = masked_greedy; p.pseed0 = seed[0]; p.pseed1 = seed[1];
+    p.pt = t; p.action_out = action_dev;
     return launch_env(E, p, (hipStream_t)stream);
 }
 

@@ -126,6 +126,13 @@ dq_status dq_env_step(dq_env* env, const int32_t* action_dev, int auto_reset, ui
                       float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev, uint32_t* lifetime_dev,
                       uint8_t* was_reset_dev, void* stream);
 
+/* dq_policy_select (declared below; same rule, same Philox stream, on the lattices' CURRENT legal sets) followed by dq_env_step,
+ * in one launch: keras-rl's `action = policy.select_action(q_values)` + `env.step(action)` of one agent step.  The selected
+ * actions are written to action_dev (the replay memory needs them); q_dev == NULL explores always. */
+dq_status dq_env_act_step(dq_env* env, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
+                          int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev,
+                          uint64_t* legal_dev, uint32_t* lifetime_dev, uint8_t* was_reset_dev, void* stream);
+
 /* Hidden state for tests / checkpointing: uint64 [n_envs, state_words], state_words = 11 + volume_depth:
  *   0 xmask (hidden_state codes 1,2)   1 zmask (codes 2,3)
  *   2 current_true_syndrome word       3 OR of the volume's faulty words (summed_syndrome_volume != 0)

@@ -268,3 +268,29 @@ def test_single_env_facade(dq, torch_mod):
             assert lo == int(g["legal"][e, t + 1, 0])
     with pytest.raises(Exception):
         dq.Surface_Code_Environment_Multi_Decoding_Cycles(d=4)
+
+
+@pytest.mark.parametrize("masked,eps", [(False, 0.3), (True, 0.0), (False, 1.0)])
+def test_fused_act_step_equals_policy_then_step(dq, torch_mod, masked, eps):
+    """dq_env_act_step == dq_policy_select followed by dq_env_step: same actions, observations, rewards, flags and hidden state."""
+    torch = torch_mod
+    import ctypes
+    from importlib import import_module
+    lib = import_module("deepq-decoding_amd._lib")
+    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    n = 777
+    a_env, b_env = dq.VectorEnv(n_envs=n, **cfg), dq.VectorEnv(n_envs=n, **cfg)
+    a_env.reset(); b_env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    L, p = lib.lib(), lib.ptr
+    seed = (ctypes.c_uint32 * 2)(*a_env.seed)
+    act_b = torch.empty(n, dtype=torch.int32, device="cuda")
+    for t in range(40):
+        q = torch.randn((n, a_env.num_actions), device="cuda", generator=g) if eps < 1.0 else None
+        act_a = a_env.select_actions(t, q=q, eps=eps, masked_greedy=masked)
+        a_env.step(act_a, auto_reset=True)
+        lib.check(L.dq_env_act_step(b_env._h, p(q), float(eps), int(masked), seed, t, p(act_b), 1, p(b_env.obs), p(b_env.reward), p(b_env.done),
+                                    p(b_env.legal), p(b_env.lifetime), p(b_env.was_reset), lib.current_stream()))
+        assert torch.equal(act_a, act_b) and torch.equal(a_env.obs, b_env.obs) and torch.equal(a_env.reward, b_env.reward)
+        assert torch.equal(a_env.done, b_env.done) and torch.equal(a_env.legal, b_env.legal) and torch.equal(a_env.was_reset, b_env.was_reset)
+    assert torch.equal(a_env.export_state(), b_env.export_state())
