@@ -463,50 +463,98 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
     }
 }
 
-// Weights of one 2x2 data gradient for this lane: [(ky*2+kx)*2 + n16][t] = W[ky,kx, c_lo + 2j + t, 16 n16 + 4kq .. +3] (float4 along n).
-template <int CIN>
-__device__ __forceinline__ void dgrad_load_w(f32x4 (&bw)[8][2], const float* __restrict__ w, int c_lo, int lane) {
-    const int j = lane & 15, kq = lane >> 4;
+// ---- f32-accurate contraction on the bf16 matrix pipe ("bf16x6") ----------------------------------------------------------
+// Every f32 value splits EXACTLY into three bf16 pieces x = hi + mid + lo (8+8+8 mantissa bits, by truncation).  A product a*b is then
+// the sum of nine exact piece products; the six with piece-index sum <= 4 carry it to ~2^-24 relative (the f32 rounding class), so
+//   a.b ~= aH.bH + aH.bM + aM.bH + aM.bM + aH.bL + aL.bH            (f32 accumulation inside v_mfma_f32_16x16x32_bf16)
+// costs 6 bf16 MFMAs of K = 32 (~17 cycles each) instead of 8 f32 MFMAs of K = 4 (32 cycles each): 2.5x the matrix-pipe rate at f32
+// accuracy.  The price is the VALU work of splitting the operands, so it is used where one operand (the weights) is split once per
+// phase and held in registers, and the other costs ~44 VALU per 8 values, issued in the MFMAs' shadow.
+struct Bf16x3 { u32x4 h, m, l; };       // 8 values: pieces packed two per dword (element e in the low half of dword e/2)
+
+__device__ __forceinline__ Bf16x3 split_bf16x3(const f32x4& x0, const f32x4& x1) {
+    Bf16x3 o;
+    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
-    for (int kyx = 0; kyx < 4; ++kyx)
-#pragma unroll
-        for (int n16 = 0; n16 < 2; ++n16)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                bw[kyx * 2 + n16][t] = *reinterpret_cast<const f32x4*>(w + (size_t)(kyx * CIN + c_lo + 2 * j + t) * 32 + 16 * n16 + 4 * kq);
+    for (int e = 0; e < 8; e += 2) {
+        const u32 a0 = __float_as_uint(v[e]), a1 = __float_as_uint(v[e + 1]);
+        o.h[e >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);                   // {a1.hi16, a0.hi16}
+        const float r0 = v[e] - __uint_as_float(a0 & 0xffff0000u), r1 = v[e + 1] - __uint_as_float(a1 & 0xffff0000u);     // exact
+        const u32 b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+        o.m[e >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(b0 & 0xffff0000u), s1 = r1 - __uint_as_float(b1 & 0xffff0000u);           // exact
+        o.l[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    return o;
 }
 
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// acc0 takes the three largest piece products, acc1 the three small ones (two independent accumulator chains; summed by the caller)
+__device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32x4& acc0, f32x4& acc1) {
+    acc0 = MFMA_BF16(a.h, b.h, acc0);
+    acc1 = MFMA_BF16(a.m, b.m, acc1);
+    acc0 = MFMA_BF16(a.h, b.m, acc0);
+    acc1 = MFMA_BF16(a.h, b.l, acc1);
+    acc0 = MFMA_BF16(a.m, b.h, acc0);
+    acc1 = MFMA_BF16(a.l, b.h, acc1);
+}
+
+// Weights of one 2x2 data gradient for this lane, split into bf16 pieces: [tap ky*2+kx][column tile t]: B(n = 8kb .. 8kb+7, c = c_lo + 16t + j)
+// = W[ky,kx, c, n] (Keras HWIO: 8 consecutive n are 32 contiguous bytes).  Lane (kb = lane >> 4, j = lane & 15).
+template <int CIN>
+__device__ __forceinline__ void dgrad_load_w(Bf16x3 (&bw)[4][2], const float* __restrict__ w, int c_lo, int lane) {
+    const int j = lane & 15, kb = lane >> 4;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* p = w + (size_t)(tap * CIN + c_lo + 16 * t + j) * 32 + 8 * kb;
+            bw[tap][t] = split_bf16x3(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+        }
+}
+
+// Data gradient of a 2x2 stride-1 convolution with 32 output channels, masked by the input activation, in place:
+//   act[(s,iy,ix), c] <- (sum_{ky,kx,n} g[(s,iy-ky,ix-kx), n] W[ky,kx,c,n]) * [act > 0]     for c in [c_lo, c_lo + 32)
+// g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA].  One tap = one K = 32 block of the bf16 MFMA:
+// A = the 32 channels of g at the tap's pixel (two ds_read_b128 per lane, split on the fly), B = the tap's weights (registers).
 template <int PSA>
-__device__ __forceinline__ void dgrad_inplace(const f32x4 (&bw)[8][2], const float* __restrict__ g, int zero_row, float* __restrict__ act,
+__device__ __forceinline__ void dgrad_inplace(const Bf16x3 (&bw)[4][2], const float* __restrict__ g, int zero_row, float* __restrict__ act,
                                               int c_lo, int ih, int iw, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
-    const int j = lane & 15, kq = lane >> 4;
+    const int j = lane & 15, kb = lane >> 4;
     const int rin = ih * iw, rout = oh * ow, tiles = (M + 15) >> 4;
     for (int tile = tile_first; tile < tiles; tile += tile_step) {
         int m = tile * 16 + j;
         if (m >= M) m = M - 1;
         const int s = m / rin, pix = m - s * rin, iy = pix / iw, ix = pix - iy * iw;
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[2][2];
 #pragma unroll
-        for (int kyx = 0; kyx < 4; ++kyx) {
-            const int oy = iy - (kyx >> 1), ox = ix - (kyx & 1);
+        for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+        f32x4 ga[4][2];
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {                         // all LDS reads first
+            const int oy = iy - (tap >> 1), ox = ix - (tap & 1);
             const bool valid = (unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow;
-            const float* gp = g + (valid ? s * rout + oy * ow + ox : zero_row) * 36 + 4 * kq;
-#pragma unroll
-            for (int n16 = 0; n16 < 2; ++n16) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(gp + 16 * n16);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = MFMA16(av[s4], bw[kyx * 2 + n16][t][s4], acc[t]);
-            }
+            const float* gp = g + (valid ? s * rout + oy * ow + ox : zero_row) * 36 + 8 * kb;
+            ga[tap][0] = *reinterpret_cast<const f32x4*>(gp);
+            ga[tap][1] = *reinterpret_cast<const f32x4*>(gp + 4);
         }
 #pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            const Bf16x3 av = split_bf16x3(ga[tap][0], ga[tap][1]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mma_bf16x6(av, bw[tap][t], acc[t][0], acc[t][1]);
+        }
+        // C/D layout: col = lane & 15 -> channel c_lo + 16t + j, row = (lane >> 4) * 4 + reg
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int mo = tile * 16 + 4 * kq + r;
+            const int mo = tile * 16 + 4 * kb + r;
             if (mo >= M) continue;
-            float* p = act + mo * PSA + c_lo + 2 * j;
-            const f32x2 old = *reinterpret_cast<const f32x2*>(p);
-            *reinterpret_cast<f32x2*>(p) = f32x2{old[0] > 0.f ? acc[0][r] : 0.f, old[1] > 0.f ? acc[1][r] : 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float* p = act + mo * PSA + c_lo + 16 * t + j;
+                *p = *p > 0.f ? acc[t][0][r] + acc[t][1][r] : 0.f;
+            }
         }
     }
 }
@@ -580,22 +628,10 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 if (tid == 0 && s < ns) s_mis[s] = misv[s];
             }
         }
-        // a1 (the largest image) is only needed from dW2 on: its loads are issued now and land in LDS after g2, so their latency
-        // and bandwidth hide under dW3 and g2
-        constexpr int NA1 = 7;                                      // float4 of a1 per thread (plan: S*r1*16 <= NA1*512)
-        f32x4 a1v[NA1];
-        {
-            const float* src = a.a1 + (size_t)b0 * r1 * 64;
-            const int total = M1 * 16;
-#pragma unroll
-            for (int u = 0; u < NA1; ++u) {
-                const int i = u * CB_THREADS + tid;
-                a1v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(i < total ? i : 0) * 4);
-            }
-        }
+        stage_rows<64, 68>(s_a1, a.a1 + (size_t)b0 * r1 * 64, M1, tid);
         stage_rows<32, 36>(s_g3, a.g3 + (size_t)b0 * r3 * 32, M3, tid);
         stage_rows<32, 36>(s_a2, a.a2 + (size_t)b0 * r2 * 32, M2, tid);
-        f32x4 bw[8][2];                                             // data-gradient weights: loaded one phase ahead of their use
+        Bf16x3 bw[4][2];                                            // data-gradient weights (bf16 pieces): loaded one phase ahead of their use
         dgrad_load_w<32>(bw, a.params + a.w_off[2], 0, lane);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 1);
@@ -647,12 +683,6 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 4);
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
         dgrad_inplace<36>(bw, s_g3, zero3, s_a2, 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
-        dgrad_load_w<64>(bw, a.params + a.w_off[1], 32 * (wave >> 2), lane);     // next data gradient's weights fly under dW2
-#pragma unroll
-        for (int u = 0; u < NA1; ++u) {                             // a1 -> LDS (issued at the top of the group)
-            const int i = u * CB_THREADS + tid;
-            if (i < M1 * 16) *reinterpret_cast<f32x4*>(s_a1 + (i >> 4) * 68 + (i & 15) * 4) = a1v[u];
-        }
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
@@ -680,6 +710,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 bs2[0] += g0[q]; bs2[1] += g1[q];
             }
         }
+        dgrad_load_w<64>(bw, a.params + a.w_off[1], 32 * (wave >> 2), lane);     // (96 registers of pieces: not held across dW2)
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 7);
         __syncthreads();                                            // every wave is done reading a1
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 8);
