@@ -41,7 +41,7 @@ class QNetJob(ctypes.Structure):
     _fields_ = [("params_dev", ctypes.c_void_p), ("obs_dev", ctypes.c_void_p), ("index_dev", ctypes.c_void_p),
                 ("index_off", ctypes.c_int32), ("index_mod", ctypes.c_int32), ("batch", ctypes.c_int32), ("training", ctypes.c_int32),
                 ("seed", ctypes.c_uint32 * 2), ("t", ctypes.c_uint64), ("sample_base", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
-                ("q_dev", ctypes.c_void_p)]
+                ("q_dev", ctypes.c_void_p), ("packed_dev", ctypes.c_void_p)]
 
 
 _vp, _i, _u32, _u64, _dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
@@ -77,6 +77,8 @@ SIGNATURES = {
     "dq_qnet_fused_supported": (_i, [_vp]),
     "dq_qnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
     "dq_qnet_forward_multi": (_i, [_vp, _i, ctypes.POINTER(QNetJob), _vp]),
+    "dq_qnet_packed_bytes": (_sz, [_vp]),
+    "dq_qnet_pack": (_i, [_vp, _vp, _vp, _vp]),
     "dq_qnet_backward": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "dq_qnet_backward_phase": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "dq_qnet_conv_param_count": (_sz, [_vp]),

@@ -66,6 +66,7 @@ class ConvQModel:
         weights = [np.asarray(w, dtype=np.float32) for w in weights]
         if self._agent is not None and self._agent._core is not None:
             self._agent._net.set_weights(self._agent._core.params, weights)
+            self._agent._core.repack()
             self._agent._core.update_target_hard()
         self._weights = weights
 
@@ -349,6 +350,7 @@ class DQNAgent:
         self._env = venv
         if old is not None:
             self._net.set_weights(self._core.params, old)
+            self._core.repack()
             self._core.update_target_hard()
         self.memory._core = self._core
         self.memory._restore_into(self._core)

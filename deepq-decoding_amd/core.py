@@ -51,6 +51,9 @@ class DQNCore:
         self.params = net.init_params(self.seed) if params is None else params
         _dist.broadcast_(self.params, src=0, group=self.pg)
         self.target = self.params.clone()
+        # bf16 pieces of the conv kernels for the fused chains: packed once per parameter change (repack()), shared by every forward
+        self.params_pk = net.pack(self.params)
+        self.target_pk = None if self.params_pk is None else self.params_pk.clone()
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.grads = torch.zeros_like(self.params)
@@ -96,7 +99,7 @@ class DQNCore:
         obs = self.obs_ring[cur]
         q = None
         if use_q:
-            q = self.net.forward(self.params, obs, batch=self.N, out=self.q_act)
+            q = self.net.forward(self.params, obs, batch=self.N, out=self.q_act, packed=self.params_pk)
         # action selection + environment step in one launch (dq_env_act_step == dq_policy_select then dq_env_step)
         seed = (ctypes.c_uint32 * 2)(*env.seed)
         check(self.L.dq_env_act_step(env._h, ptr(q), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
@@ -137,11 +140,12 @@ class DQNCore:
         net, ring = self.net, self.obs_ring
         # Q_online(s1) picks the action, Q_target(s1) values it (double DQN; without it Q_target does both); the training forward
         # on s0 is independent of both, so the three share one pair of launches
-        jobs = [dict(params=self.target, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target)]
+        jobs = [dict(params=self.target, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target, packed=self.target_pk)]
         if self.enable_double_dqn:
-            jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online))
+            jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online,
+                             packed=self.params_pk))
         jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, training=True, seed=self.seed, t=t, sample_base=sample_base,
-                         out=self.q0))
+                         out=self.q0, packed=self.params_pk))
         net.forward_multi(jobs)
         q_sel = self.q1_online if self.enable_double_dqn else self.q1_target
         _q.td_update(q_sel, self.q1_target, self.q0, self.reward_ring, self.terminal_ring, self.action_ring, self.gamma,
@@ -159,6 +163,7 @@ class DQNCore:
         else:
             net.backward(self.params, self.dq, grads=self.grads)
         _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+        self.repack()
 
     def read_metrics(self):
         """(loss, mean_q) of the last update on this rank; reduces the per-block partials first (syncs)."""
@@ -168,8 +173,15 @@ class DQNCore:
         m = self.metrics[:2].cpu().numpy()
         return float(m[0]), float(m[1])
 
+    def repack(self):
+        """Must follow every change of self.params (Adam step, weight loading): refreshes the packed conv kernels."""
+        if self.params_pk is not None:
+            self.net.pack(self.params, out=self.params_pk)
+
     def update_target_hard(self):
         self.target.copy_(self.params)
+        if self.target_pk is not None:
+            self.target_pk.copy_(self.params_pk)
 
     def read_stats(self, reset=True):
         """(episodes ended, sum of their lifetimes, rewards earned, lattices stepped) since the last reset; syncs."""

@@ -39,6 +39,7 @@ DQ_STAMP_READER(dq_dbg_read_fwd)
 // phases (staging, epilogues, head layers) leave the matrix pipe idle; several jobs in one grid overlap them.
 struct ConvJob {
     const float* params;
+    const u32x4* packed;               // bf16 pieces of the conv2 / conv3 kernels (qnet.h PK_*)
     const u8* obs;
     const int32_t* index;
     int index_off, index_mod, batch;
@@ -58,62 +59,67 @@ struct ConvChainArgs {
     int off_mis, off_a1, off_a2;       // LDS byte offsets (observations at 0)
 };
 
-// One stride-1 convolution whose input is an LDS image [pixel][CIN + 4] and whose weights sit in registers.
-// Each wave takes pairs of 16-row tiles (4 accumulators in flight).
+// One stride-1 convolution whose input is an LDS image [pixel][CIN + 4] (f32), on the bf16 matrix pipe at f32 accuracy (bf16x6,
+// qnet.h).  K = KS*KS*CIN is walked in blocks of 32 channels of one tap: A = 8 consecutive channels per lane (two ds_read_b128),
+// split into bf16 pieces on the fly; B = the block's weights as pieces in registers, HALF of K at a time (96 VGPRs).  Each wave
+// takes pairs of 16-row tiles x both column tiles (column tile t, lane j = column 2j + t), two accumulator chains per tile.
 template <int CIN, int COUT, int KS>
 __device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int ih, int iw, int oh, int ow, int M,
-                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                              const u32x4* __restrict__ pk, const float* __restrict__ bias,
                                               float* __restrict__ out_lds, float* __restrict__ out_g, int wave, int lane) {
-    constexpr int NT = COUT / 16, PSI = CIN + 4, PSO = COUT + 4, CG = CIN / 16, KG = KS * KS * CG;
-    static_assert(NT == 2, "column interleave below is written for two tiles");
-    const int j = lane & 15, kq = lane >> 4;
-    f32x2 b[KG][4];
-#pragma unroll
-    for (int g = 0; g < KG; ++g)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[g][s] = *reinterpret_cast<const f32x2*>(w + (size_t)(16 * g + 4 * kq + s) * COUT + 2 * j);
+    constexpr int NT = COUT / 16, PSI = CIN + 4, PSO = COUT + 4, CB = CIN / 32, NB = KS * KS * CB, HB = NB > 4 ? NB / 2 : NB;
+    static_assert(NT == 2 && CIN % 32 == 0 && NB % HB == 0, "written for 32 output channels, CIN a multiple of 32");
+    const int j = lane & 15, kb = lane >> 4;
     const f32x2 bias2 = *reinterpret_cast<const f32x2*>(bias + 2 * j);
     const int rows = oh * ow, tiles = (M + 15) >> 4;
     for (int t0 = 2 * wave; t0 < tiles; t0 += 2 * CONV_WAVES) {
-        const bool two = t0 + 1 < tiles;                            // wave-uniform
+        const bool two = t0 + 1 < tiles;                            // wave-uniform; a missing second tile recomputes clamped rows
         int abase[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             int m = (t0 + u) * 16 + j;
             if (m >= M) m = M - 1;                                  // padding rows recompute the last row; never stored
             const int s = m / rows, pix = m - s * rows, oy = pix / ow, ox = pix - oy * ow;
-            abase[u] = ((s * ih + oy) * iw + ox) * PSI + 4 * kq;
+            abase[u] = ((s * ih + oy) * iw + ox) * PSI + 8 * kb;
         }
-        f32x4 acc[2][NT];
+        f32x4 acc[2][NT][2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) { acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = acc[u][t][0]; }
 #pragma unroll
-        for (int g = 0; g < KG; ++g) {
-            const int kyx = g / CG, c16 = g - kyx * CG, ky = kyx / KS, kx = kyx - ky * KS;
-            const int off = (ky * iw + kx) * PSI + 16 * c16;
-            // both tiles always: a missing second tile recomputes clamped rows and is never stored.  (A condition around an MFMA,
-            // even a wave-uniform one, makes hipcc copy the accumulators after every MFMA, each copy waiting for the result.)
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(in + abase[0] + off);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(in + abase[1] + off);
+        for (int h0 = 0; h0 < NB; h0 += HB) {
+            // ---- this half's weights: ready-made bf16 pieces, one coalesced 16-byte load per lane per piece --------------------
+            Bf16x3 bw[HB][NT];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int bi = 0; bi < HB; ++bi)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[0][t] = MFMA16(a0[s], b[g][s][t], acc[0][t]);
+                for (int t = 0; t < NT; ++t) {
+                    const u32x4* pb = pk + ((h0 + bi) * NT + t) * PK_BLOCK + lane;
+                    bw[bi][t].h = pb[0]; bw[bi][t].m = pb[64]; bw[bi][t].l = pb[128];
+                }
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[1][t] = MFMA16(a1[s], b[g][s][t], acc[1][t]);
+            for (int bi = 0; bi < HB; ++bi) {
+                const int blk = h0 + bi, tap = blk / CB, c32 = blk - tap * CB, ky = tap / KS, kx = tap - ky * KS;
+                const int off = (ky * iw + kx) * PSI + 32 * c32;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float* ap = in + abase[u] + off;
+                    const Bf16x3 av = split_bf16x3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) mma_bf16x6(av, bw[bi][t], acc[u][t][0], acc[u][t][1]);
+                }
             }
         }
-        // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg; this lane owns columns 2j, 2j+1
+        // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg; this lane owns columns 2j, 2j+1
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int mo = (t0 + u) * 16 + 4 * kq + r;
+                const int mo = (t0 + u) * 16 + 4 * kb + r;
                 if (mo >= M) continue;
-                f32x2 v = {fmaxf(acc[u][0][r] + bias2[0], 0.f), fmaxf(acc[u][1][r] + bias2[1], 0.f)};
+                f32x2 v = {fmaxf(acc[u][0][0][r] + acc[u][0][1][r] + bias2[0], 0.f), fmaxf(acc[u][1][0][r] + acc[u][1][1][r] + bias2[1], 0.f)};
                 if (out_lds) *reinterpret_cast<f32x2*>(out_lds + mo * PSO + 2 * j) = v;
                 if (out_g) *reinterpret_cast<f32x2*>(out_g + (size_t)mo * COUT + 2 * j) = v;
             }
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     // ---- convolution 2 (64 -> 32, 2x2) and 3 (32 -> 32, 2x2) --------------------------------------------------------
     {
         const int r2 = a.oh2 * a.ow2;
-        conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, J.params + a.w_off[1], J.params + a.b_off[1], s_a2,
+        conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2,
                                  J.write_all ? J.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 5);
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 6);
     {
         const int r3 = a.oh3 * a.ow3;
-        conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, J.params + a.w_off[2], J.params + a.b_off[2], nullptr,
+        conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr,
                                  J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 7);
@@ -518,6 +524,40 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Packs the conv2 / conv3 kernels of one parameter buffer into bf16 pieces in MFMA B-operand order (qnet.h PK_*): one wave per
+// block, lane (kb, j) gathers its 8 weights, splits them exactly and writes 3 x 16 bytes.  ~0.2 MB, one launch per parameter change.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ params, u32x4* __restrict__ pk, int w2_off, int w3_off) {
+    const int lane = threadIdx.x & 63, blk_id = blockIdx.x * 4 + (threadIdx.x >> 6), j = lane & 15, kb = lane >> 4;
+    if (blk_id >= PK_TOTAL_BLOCKS) return;
+    float v[8];
+    if (blk_id < 16 + 8) {                                          // forward: B(k, col = 2j + t) = W[k][col], k = 32 blk + 8kb + e
+        const bool c2 = blk_id < 16;
+        const int b = c2 ? blk_id : blk_id - 16, blk = b >> 1, t = b & 1;
+        const float* w = params + (c2 ? w2_off : w3_off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[(size_t)(32 * blk + 8 * kb + e) * 32 + 2 * j + t];
+    } else {                                                        // data gradient: B(n = 8kb + e, c) = W[tap][c][n]
+        const bool c3 = blk_id < 32;
+        const int b = c3 ? blk_id - 24 : blk_id - 32;               // conv3: [tap][t]; conv2: [half][tap][t]
+        const int t = b & 1, tap = (b >> 1) & 3, half = b >> 3, cin = c3 ? 32 : 64;
+        const float* w = params + (c3 ? w3_off : w2_off) + (size_t)(tap * cin + 32 * half + 16 * t + j) * 32 + 8 * kb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[e];
+    }
+    const Bf16x3 o = split_bf16x3(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+    u32x4* dst = pk + (size_t)blk_id * PK_BLOCK + lane;
+    dst[0] = o.h; dst[64] = o.m; dst[128] = o.l;
+}
+
+dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* packed_dev, hipStream_t st) {
+    DQ_REQUIRE(Q && params_dev && packed_dev, DQ_ERR_INVALID, "dq_qnet_pack: null argument");
+    DQ_REQUIRE(fused_forward_supported(Q), DQ_ERR_UNSUPPORTED, "dq_qnet_pack: the fused chains do not cover this configuration");
+    pack_weights_kernel<<<(PK_TOTAL_BLOCKS + 3) / 4, 256, 0, st>>>(params_dev, static_cast<u32x4*>(packed_dev), (int)Q->L[1].w_off, (int)Q->L[2].w_off);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct ConvPlan { int S, slot, off_mis, off_a1, off_a2, KG1; size_t lds; };
 
 static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
@@ -623,7 +663,17 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         DQ_REQUIRE(n_train <= 1, DQ_ERR_INVALID, "dq_qnet_forward_multi: at most one training job per launch");
         float* x = training ? Q->act[0][nc - 1] : Q->xinf[i];      // conv3 output: saved for backward / per-job scratch
         ConvJob& C = ca.job[i];
-        C.params = jb.params_dev; C.obs = jb.obs_dev; C.index = jb.index_dev; C.index_off = jb.index_off;
+        const void* packed = jb.packed_dev;
+        if (!packed) {                                              // the caller did not pack: do it here (one small launch per job)
+            for (int k2 = 0; k2 < i && !packed; ++k2)
+                if (jobs[k2].params_dev == jb.params_dev && !jobs[k2].packed_dev) packed = Q->pk_scratch[k2];     // same weights as an earlier job
+            if (!packed) {
+                const dq_status rc = fused_pack_weights(Q, jb.params_dev, Q->pk_scratch[i], st);
+                if (rc != DQ_OK) return rc;
+                packed = Q->pk_scratch[i];
+            }
+        }
+        C.params = jb.params_dev; C.packed = static_cast<const u32x4*>(packed); C.obs = jb.obs_dev; C.index = jb.index_dev; C.index_off = jb.index_off;
         C.index_mod = jb.index_mod > 0 ? jb.index_mod : 0x7fffffff;
         C.batch = jb.batch; C.write_all = training; C.wg0 = conv_wgs;
         C.act_out[0] = Q->act[0][0]; C.act_out[1] = Q->act[0][1]; C.act_out[2] = x;
@@ -639,7 +689,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
             D.h1_out = Q->act[0][nc]; D.y2_out = Q->act[0][nc + 1];
             D.y3_out = Q->cfg.dueling ? Q->act[0][nc + 2] : nullptr;
             Q->last_train_batch = jb.batch; Q->last_obs = jb.obs_dev; Q->last_index = jb.index_dev;
-            Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod;
+            Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod; Q->last_train_packed = packed;
         }
         D.q_out = jb.q_dev;
         dense_wgs += (jb.batch + DENSE_ROWS - 1) / DENSE_ROWS;

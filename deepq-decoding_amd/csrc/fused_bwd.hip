@@ -428,6 +428,7 @@ struct ConvBwdArgs {
     const float* a1;                    // saved activations of the training forward (global NHWC)
     const float* a2;
     const float* g3;                    // [batch*r3, 32] gradient w.r.t. conv3's pre-activation output
+    const u32x4* packed;                // bf16 pieces of the conv kernels (qnet.h PK_*), those of the training forward
     int batch, S, groups;
     int C, H, W, k1, st1, K1;
     int oh1, ow1, oh2, ow2, oh3, ow3;
@@ -463,54 +464,15 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
     }
 }
 
-// ---- f32-accurate contraction on the bf16 matrix pipe ("bf16x6") ----------------------------------------------------------
-// Every f32 value splits EXACTLY into three bf16 pieces x = hi + mid + lo (8+8+8 mantissa bits, by truncation).  A product a*b is then
-// the sum of nine exact piece products; the six with piece-index sum <= 4 carry it to ~2^-24 relative (the f32 rounding class), so
-//   a.b ~= aH.bH + aH.bM + aM.bH + aM.bM + aH.bL + aL.bH            (f32 accumulation inside v_mfma_f32_16x16x32_bf16)
-// costs 6 bf16 MFMAs of K = 32 (~17 cycles each) instead of 8 f32 MFMAs of K = 4 (32 cycles each): 2.5x the matrix-pipe rate at f32
-// accuracy.  The price is the VALU work of splitting the operands, so it is used where one operand (the weights) is split once per
-// phase and held in registers, and the other costs ~44 VALU per 8 values, issued in the MFMAs' shadow.
-struct Bf16x3 { u32x4 h, m, l; };       // 8 values: pieces packed two per dword (element e in the low half of dword e/2)
-
-__device__ __forceinline__ Bf16x3 split_bf16x3(const f32x4& x0, const f32x4& x1) {
-    Bf16x3 o;
-    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const u32 a0 = __float_as_uint(v[e]), a1 = __float_as_uint(v[e + 1]);
-        o.h[e >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);                   // {a1.hi16, a0.hi16}
-        const float r0 = v[e] - __uint_as_float(a0 & 0xffff0000u), r1 = v[e + 1] - __uint_as_float(a1 & 0xffff0000u);     // exact
-        const u32 b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
-        o.m[e >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-        const float s0 = r0 - __uint_as_float(b0 & 0xffff0000u), s1 = r1 - __uint_as_float(b1 & 0xffff0000u);           // exact
-        o.l[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-    }
-    return o;
-}
-
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
-
-// acc0 takes the three largest piece products, acc1 the three small ones (two independent accumulator chains; summed by the caller)
-__device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32x4& acc0, f32x4& acc1) {
-    acc0 = MFMA_BF16(a.h, b.h, acc0);
-    acc1 = MFMA_BF16(a.m, b.m, acc1);
-    acc0 = MFMA_BF16(a.h, b.m, acc0);
-    acc1 = MFMA_BF16(a.h, b.l, acc1);
-    acc0 = MFMA_BF16(a.m, b.h, acc0);
-    acc1 = MFMA_BF16(a.l, b.h, acc1);
-}
-
-// Weights of one 2x2 data gradient for this lane, split into bf16 pieces: [tap ky*2+kx][column tile t]: B(n = 8kb .. 8kb+7, c = c_lo + 16t + j)
-// = W[ky,kx, c, n] (Keras HWIO: 8 consecutive n are 32 contiguous bytes).  Lane (kb = lane >> 4, j = lane & 15).
-template <int CIN>
-__device__ __forceinline__ void dgrad_load_w(Bf16x3 (&bw)[4][2], const float* __restrict__ w, int c_lo, int lane) {
-    const int j = lane & 15, kb = lane >> 4;
+// Weights of one 2x2 data gradient for this lane as bf16 pieces: [tap ky*2+kx][column tile t]: B(n = 8kb .. 8kb+7, c = c_lo + 16t + j)
+// = W[ky,kx, c, n], ready-made in the packed buffer (qnet.h PK_CONV3_DG / PK_CONV2_DG + 8 * PK_BLOCK * half).
+__device__ __forceinline__ void dgrad_load_w(Bf16x3 (&bw)[4][2], const u32x4* __restrict__ pk, int lane) {
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float* p = w + (size_t)(tap * CIN + c_lo + 16 * t + j) * 32 + 8 * kb;
-            bw[tap][t] = split_bf16x3(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+            const u32x4* pb = pk + (tap * 2 + t) * PK_BLOCK + lane;
+            bw[tap][t].h = pb[0]; bw[tap][t].m = pb[64]; bw[tap][t].l = pb[128];
         }
 }
 
@@ -632,7 +594,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         stage_rows<32, 36>(s_g3, a.g3 + (size_t)b0 * r3 * 32, M3, tid);
         stage_rows<32, 36>(s_a2, a.a2 + (size_t)b0 * r2 * 32, M2, tid);
         Bf16x3 bw[4][2];                                            // data-gradient weights (bf16 pieces): loaded one phase ahead of their use
-        dgrad_load_w<32>(bw, a.params + a.w_off[2], 0, lane);
+        dgrad_load_w(bw, a.packed + PK_CONV3_DG, lane);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 1);
         // ---- observation patch image: row m = the K1 bytes conv1 multiplies for output pixel m (zeros past K1), so that dW1's A
@@ -710,7 +672,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 bs2[0] += g0[q]; bs2[1] += g1[q];
             }
         }
-        dgrad_load_w<64>(bw, a.params + a.w_off[1], 32 * (wave >> 2), lane);     // (96 registers of pieces: not held across dW2)
+        dgrad_load_w(bw, a.packed + PK_CONV2_DG + 8 * PK_BLOCK * (wave >> 2), lane);      // (96 registers of pieces: not held across dW2)
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 7);
         __syncthreads();                                            // every wave is done reading a1
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 8);
@@ -962,6 +924,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.params = params_dev; ca.obs = Q->last_obs; ca.index = Q->last_index; ca.index_off = Q->last_index_off;
     ca.index_mod = Q->last_index_mod > 0 ? Q->last_index_mod : 0x7fffffff;
     ca.a1 = Q->act[0][0]; ca.a2 = Q->act[0][1]; ca.g3 = Q->gz[nc - 1];
+    DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
+    ca.packed = static_cast<const u32x4*>(Q->last_train_packed);
     ca.batch = B; ca.S = cp.S; ca.groups = (B + cp.S - 1) / cp.S;
     ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;

@@ -30,6 +30,8 @@ struct dq_qnet {
     int last_index_off, last_index_mod;
     float* xinf[FWD_MAX_JOBS];   // fused inference forwards: last-convolution output per job slot [max_batch, flat]
     int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an NCHW uint8 observation, -1 past K
+    void* pk_scratch[FWD_MAX_JOBS];  // packed weights of jobs that did not bring their own (dq_qnet_job.packed_dev == NULL)
+    const void* last_train_packed;   // packed weights of the last training forward (the backward's data gradients read them)
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
     int use_fused;               // 1: fused LDS-resident forward when the configuration allows it
 };
@@ -48,6 +50,62 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword
 #define DENSE_ROWS 16
 #define DENSE_HID 512                 // Dense(512): 8 waves x 64 columns; Dense(|A|) splits K = 512 into 8 x 64
 static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+#ifdef __HIPCC__
+// ---- f32-accurate contraction on the bf16 matrix pipe ("bf16x6") ----------------------------------------------------------
+// Every f32 value splits EXACTLY into three bf16 pieces x = hi + mid + lo (8+8+8 mantissa bits, by truncation).  A product a*b is then
+// the sum of nine exact piece products; the six with piece-index sum <= 4 carry it to ~2^-24 relative (the f32 rounding class), so
+//   a.b ~= aH.bH + aH.bM + aM.bH + aM.bM + aH.bL + aL.bH            (f32 accumulation inside v_mfma_f32_16x16x32_bf16)
+// costs 6 bf16 MFMAs of K = 32 (~17 cycles each) instead of 8 f32 MFMAs of K = 4 (32 cycles each): 2.5x the matrix-pipe rate at f32
+// accuracy.  The price is the VALU work of splitting the operands, so it is used where one operand (the weights) is split once per
+// phase and held in registers, and the other costs ~44 VALU per 8 values, issued in the MFMAs' shadow.
+struct Bf16x3 { u32x4 h, m, l; };       // 8 values: pieces packed two per dword (element e in the low half of dword e/2)
+
+__device__ __forceinline__ Bf16x3 split_bf16x3(const f32x4& x0, const f32x4& x1) {
+    Bf16x3 o;
+    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const u32 a0 = __float_as_uint(v[e]), a1 = __float_as_uint(v[e + 1]);
+        o.h[e >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);                   // {a1.hi16, a0.hi16}
+        const float r0 = v[e] - __uint_as_float(a0 & 0xffff0000u), r1 = v[e + 1] - __uint_as_float(a1 & 0xffff0000u);     // exact
+        const u32 b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
+        o.m[e >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+        const float s0 = r0 - __uint_as_float(b0 & 0xffff0000u), s1 = r1 - __uint_as_float(b1 & 0xffff0000u);           // exact
+        o.l[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    return o;
+}
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// acc0 takes the three largest piece products, acc1 the three small ones (two independent accumulator chains; summed by the caller)
+__device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32x4& acc0, f32x4& acc1) {
+    acc0 = MFMA_BF16(a.h, b.h, acc0);
+    acc1 = MFMA_BF16(a.m, b.m, acc1);
+    acc0 = MFMA_BF16(a.h, b.m, acc0);
+    acc1 = MFMA_BF16(a.h, b.l, acc1);
+    acc0 = MFMA_BF16(a.m, b.h, acc0);
+    acc1 = MFMA_BF16(a.l, b.h, acc1);
+}
+
+#endif  // __HIPCC__
+
+// ---- packed weights (fused.hip: pack_weights_kernel) --------------------------------------------------------------------------
+// The bf16x6 contractions read their weight operand as ready-made bf16 pieces in MFMA B-operand order: one "block" = 64 lanes x
+// 3 pieces x 16 bytes (lane (kb, j) holds the 8 reduction indices 8kb .. 8kb+7 of its column).  Sections, in u32x4 units:
+//   PK_CONV2_FWD  [8 k-blocks][2 column tiles]      B(k = 32 blk + 8kb + e, col = 2j + t)            = W2[k][col]
+//   PK_CONV3_FWD  [4][2]                            same for conv3
+//   PK_CONV3_DG   [4 taps][2]                       B(n = 8kb + e, c = 16t + j)                      = W3[tap][c][n]
+//   PK_CONV2_DG   [2 channel halves][4 taps][2]     B(n = 8kb + e, c = 32 half + 16t + j)            = W2[tap][c][n]
+#define PK_BLOCK 192                  // u32x4 per block (3 pieces x 64 lanes)
+#define PK_CONV2_FWD 0
+#define PK_CONV3_FWD (PK_CONV2_FWD + 16 * PK_BLOCK)
+#define PK_CONV3_DG (PK_CONV3_FWD + 8 * PK_BLOCK)
+#define PK_CONV2_DG (PK_CONV3_DG + 8 * PK_BLOCK)
+#define PK_TOTAL_BLOCKS 48
+#define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)
+dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* packed_dev, hipStream_t st);
 
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);

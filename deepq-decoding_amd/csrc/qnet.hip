@@ -406,6 +406,8 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         e = hipMalloc(&Q->kofftab, sizeof(tab));
         if (e == hipSuccess) e = hipMemcpy(Q->kofftab, tab, sizeof(tab), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && fused_forward_supported(Q))
+        for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->pk_scratch[i], (size_t)PK_TOTAL_U32X4 * 16);
     if (e == hipSuccess && fused_forward_supported(Q)) {
         const size_t xf = (size_t)cfg->max_batch * Q->L[cfg->n_conv].nin;
         for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->xinf[i], xf * sizeof(float));
@@ -426,6 +428,7 @@ void dq_qnet_destroy(dq_qnet* Q) {
     if (Q->partial) (void)hipFree(Q->partial);
     if (Q->fpartial) (void)hipFree(Q->fpartial);
     if (Q->kofftab) (void)hipFree(Q->kofftab);
+    for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->pk_scratch[i]) (void)hipFree(Q->pk_scratch[i]);
     for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->xinf[i]) (void)hipFree(Q->xinf[i]);
     delete Q;
 }
@@ -520,6 +523,12 @@ dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* ob
         Q->last_index_off = index_off; Q->last_index_mod = index_mod;
     }
     return DQ_OK;
+}
+
+size_t dq_qnet_packed_bytes(const dq_qnet* Q) { return Q && fused_forward_supported(Q) ? (size_t)PK_TOTAL_U32X4 * 16 : 0; }
+
+dq_status dq_qnet_pack(const dq_qnet* Q, const float* params_dev, void* packed_dev, void* stream) {
+    return fused_pack_weights(Q, params_dev, packed_dev, (hipStream_t)stream);
 }
 
 dq_status dq_qnet_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, void* stream) {

@@ -45,6 +45,7 @@ class QNetwork:
         self._h = h
         self.n_params = int(self.L.dq_qnet_param_count(self._h))
         self.n_conv_params = int(self.L.dq_qnet_conv_param_count(self._h))     # flat layout: convolutions first, then the dense layers
+        self.packed_bytes = int(self.L.dq_qnet_packed_bytes(self._h))          # 0 when the fused chains do not cover the architecture
         self.layers = []
         for i in range(self.L.dq_qnet_num_layers(self._h)):
             ko, bo, shape, nd = ctypes.c_int64(), ctypes.c_int64(), (ctypes.c_int32 * 4)(), ctypes.c_int32()
@@ -111,9 +112,22 @@ class QNetwork:
             flat[info["bias_offset"]:info["bias_offset"] + b.size] = b
         params.copy_(torch.from_numpy(flat))
 
+    def pack(self, params, out=None):
+        """bf16 pieces of the conv kernels in matrix-core operand order (dq_qnet_pack): pass the result as `packed=` to forward() /
+        forward_multi() jobs that use `params`, and call it again whenever `params` changes.  None if not applicable."""
+        if not self.packed_bytes:
+            return None
+        if out is None:
+            out = torch.empty(self.packed_bytes, dtype=torch.uint8, device=self.device)
+        check(self.L.dq_qnet_pack(self._h, ptr(params), ptr(out), self._stream()))
+        return out
+
     # -- compute ----------------------------------------------------------------------------------------------
     def forward(self, params, obs, batch=None, index=None, index_off=0, index_mod=0, training=False, seed=(0, 0), t=0,
-                sample_base=0, out=None):
+                sample_base=0, out=None, packed=None):
+        if packed is not None:
+            return self.forward_multi([dict(params=params, obs=obs, batch=batch, index=index, index_off=index_off, index_mod=index_mod,
+                                            training=training, seed=seed, t=t, sample_base=sample_base, out=out, packed=packed)])[0]
         assert params.dtype == torch.float32 and params.is_cuda and params.numel() == self.n_params
         assert obs.dtype == torch.uint8 and obs.is_cuda and obs.is_contiguous()
         if batch is None:
@@ -152,6 +166,7 @@ class QNetwork:
             jb.training = int(bool(kw.get("training", False)))
             jb.seed[0], jb.seed[1] = int(seed[0]) & 0xFFFFFFFF, int(seed[1]) & 0xFFFFFFFF
             jb.t, jb.sample_base, jb.q_dev = int(kw.get("t", 0)), int(kw.get("sample_base", 0)), ptr(out)
+            jb.packed_dev = ptr(kw.get("packed"))
             if jb.training:
                 self._train_inputs = (obs, index)
             outs.append(out)

@@ -226,8 +226,16 @@ typedef struct {
     uint64_t t;
     uint32_t sample_base, reserved;
     float* q_dev;
+    const void* packed_dev;     /* dq_qnet_pack(params_dev) output, or NULL: the call packs the weights itself (one extra small launch) */
 } dq_qnet_job;
 dq_status dq_qnet_forward_multi(dq_qnet* net, int n_jobs, const dq_qnet_job* jobs, void* stream);
+
+/* The fused chains read the conv2 / conv3 kernels as bf16 pieces in matrix-core operand order.  A caller that runs several
+ * forwards on the same weights packs them once per parameter change (dq_qnet_packed_bytes(net) bytes of device memory) and
+ * passes the buffer in dq_qnet_job.packed_dev; it MUST repack after every change of params_dev (dq_adam_step, weight loading).
+ * dq_qnet_forward and jobs with packed_dev == NULL pack on every call.  The backward reuses the training forward's pack. */
+size_t dq_qnet_packed_bytes(const dq_qnet* net);
+dq_status dq_qnet_pack(const dq_qnet* net, const float* params_dev, void* packed_dev, void* stream);
 
 /* Backward half of train_on_batch: grads_dev[n_params] = d/dparams sum(dq * Q) for the last training forward
  * (obs_dev / index_dev of that call must still be valid).  Deterministic (fixed-order reductions). */

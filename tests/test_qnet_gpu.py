@@ -98,6 +98,23 @@ def test_training_forward_backward(dq, torch_mod, name, batch, fused):
     assert np.array_equal(g, g2)
 
 
+def test_packed_weights_are_equivalent_and_must_follow_the_parameters(dq, torch_mod):
+    """forward(packed=net.pack(params)) == forward(params) (which packs on every call), bit for bit; the pack is a pure function
+    of the parameters (a stale pack gives the old weights' convolutions, which is why DQNCore repacks after every Adam step)."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 64)
+    obs_t = torch.from_numpy(obs).cuda()
+    pk = net.pack(params)
+    assert pk is not None and pk.numel() == net.packed_bytes
+    q_auto = net.forward(params, obs_t)
+    q_pk = net.forward(params, obs_t, packed=pk)
+    assert torch.equal(q_auto, q_pk)
+    p2 = params * 1.5
+    q2 = net.forward(p2, obs_t)
+    assert not torch.equal(q2, net.forward(p2, obs_t, packed=pk))          # stale pack: wrong on purpose
+    assert torch.equal(q2, net.forward(p2, obs_t, packed=net.pack(p2, out=pk)))
+
+
 def test_forward_multi_equals_separate_forwards(dq, torch_mod):
     """dq_qnet_forward_multi (the update's three forwards in one pair of launches) == three dq_qnet_forward calls, bit for bit;
     the training job's saved activations drive the same backward."""
