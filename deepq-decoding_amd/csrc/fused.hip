@@ -280,6 +280,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
 // ---------------------------------------------------------------------------------------------------------------
 struct DenseJob {
     const float* params;
+    const u32x4* packed;                // bf16 pieces (qnet.h); the hidden layer's blocks start at DenseChainArgs.pk_dense1
     const float* x;                     // [batch, K1]: NHWC flatten of the last convolution
     int batch;
     float keep_scale;                   // > 0: dropout active on the hidden layer's output
@@ -297,6 +298,7 @@ struct DenseChainArgs {
     DenseJob job[FWD_MAX_JOBS];
     int n_jobs;
     int K1, perm_hw, perm_c;            // Keras Flatten: k = c*hw + p reads x[p*perm_c + c]
+    int pk_dense1;                      // u32x4 offset of the hidden layer's packed blocks [K1/32][32 column tiles]
     int N2, N3, n_actions;              // Dense(|A|) width, dueling layer width (0 = no dueling layer)
     int w_off[3], b_off[3];
     int ldx, ld2, ld3;                  // LDS row strides (floats)
@@ -318,28 +320,39 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     const DenseJob& J = a.job[jb];
     const int b0 = ((int)blockIdx.x - J.wg0) * DENSE_ROWS;
     const int ns = min(DENSE_ROWS, J.batch - b0);
-    const int K1 = a.K1, KG = K1 >> 4;
+    const int K1 = a.K1;
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 0);
-    // ---- hidden layer's first weight rows start flying before anything else ----------------------------------------
-    const float* w1 = J.params + a.w_off[0] + 64 * wave + 4 * j;
-    f32x4 bA[4], bB[4];
+    // ---- hidden layer's first weight blocks start flying before anything else -------------------------------------------
+    // Dense(512) runs as bf16x6 (qnet.h): the weights come as packed bf16 pieces (block (kblk, column tile ct = 4*wave + t), column
+    // 64*wave + 4j + t), the input rows are split ONCE into three bf16 planes in LDS.
+    const int KB = K1 >> 5;                                          // k-blocks of 32
+    const u32x4* pkw = J.packed + a.pk_dense1 + (size_t)(4 * wave) * PK_BLOCK + lane;
+    Bf16x3 bw[2][4];                                                // two k-blocks in flight
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bA[s] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(4 * kq + s) * DENSE_HID);
+    for (int t = 0; t < 4; ++t) { bw[0][t].h = pkw[t * PK_BLOCK]; bw[0][t].m = pkw[t * PK_BLOCK + 64]; bw[0][t].l = pkw[t * PK_BLOCK + 128]; }
 
-    // ---- input rows -> LDS in Keras Flatten order (zero-filled past the batch); clear the padded y2 image -----------
+    // ---- input rows -> three bf16 planes in LDS, in Keras Flatten order (zero-filled past the batch); clear the padded y2 image --
+    const int LDP = K1 + 8;                                          // plane row stride in bf16 (rows stay 16-byte aligned)
+    unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [3][16][LDP]
     {
         const int q4 = K1 >> 2;                                     // float4 per row
         for (int i = tid; i < DENSE_ROWS * q4; i += DENSE_THREADS) {
             const int r = i / q4, c4 = (i - r * q4) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < ns) v = *reinterpret_cast<const f32x4*>(J.x + (size_t)(b0 + r) * K1 + c4);
-            if (a.perm_hw > 0) {
-                const int p = c4 / a.perm_c, c = c4 - p * a.perm_c;  // perm_c % 4 == 0: the four share p
+            const int p = a.perm_hw > 0 ? c4 / a.perm_c : 0, c = a.perm_hw > 0 ? c4 - p * a.perm_c : c4;   // perm_c % 4 == 0: the four share p
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s_x[r * a.ldx + (c + e) * a.perm_hw + p] = v[e];
-            } else {
-                *reinterpret_cast<f32x4*>(s_x + r * a.ldx + c4) = v;
+            for (int e = 0; e < 4; ++e) {
+                const int k = a.perm_hw > 0 ? (c + e) * a.perm_hw + p : c4 + e;
+                const u32 hb = __float_as_uint(v[e]) & 0xffff0000u;
+                const float r1 = v[e] - __uint_as_float(hb);                            // exact
+                const u32 mb = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(mb);                              // exact, <= 8 significant bits left
+                unsigned short* d = s_pl + r * LDP + k;
+                d[0] = (unsigned short)(hb >> 16);
+                d[DENSE_ROWS * LDP] = (unsigned short)(mb >> 16);
+                d[2 * DENSE_ROWS * LDP] = (unsigned short)(__float_as_uint(r2) >> 16);
             }
         }
         for (int i = tid; i < DENSE_ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
@@ -347,29 +360,32 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     __syncthreads();
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 1);
-    // ---- Dense(512): wave w owns columns [64w, 64w+64) as 4 interleaved tiles; weights double-buffered ------------------
+    // ---- Dense(512): wave w owns columns [64w, 64w+64) as 4 interleaved tiles; two accumulator chains per tile -----------------
+    f32x4 acc2c[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc2c[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2c[t][1] = acc2c[t][0]; }
+    const unsigned short* arow = s_pl + j * LDP + 8 * kq;
+    auto do_block = [&](int b, Bf16x3 (&cur)[4], Bf16x3 (&nxt)[4]) {
+        const u32x4* pn = pkw + (size_t)min(b + 1, KB - 1) * 32 * PK_BLOCK;      // next block: unconditional, clamped prefetch
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { nxt[t].h = pn[t * PK_BLOCK]; nxt[t].m = pn[t * PK_BLOCK + 64]; nxt[t].l = pn[t * PK_BLOCK + 128]; }
+        Bf16x3 av;
+        const unsigned short* ap = arow + 32 * b;
+        av.h = *reinterpret_cast<const u32x4*>(ap);
+        av.m = *reinterpret_cast<const u32x4*>(ap + DENSE_ROWS * LDP);
+        av.l = *reinterpret_cast<const u32x4*>(ap + 2 * DENSE_ROWS * LDP);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mma_bf16x6(av, cur[t], acc2c[t][0], acc2c[t][1]);
+    };
+    int blk = 0;
+    for (; blk + 1 < KB; blk += 2) {                                // no condition around the MFMAs inside the loop
+        do_block(blk, bw[0], bw[1]);
+        do_block(blk + 1, bw[1], bw[0]);
+    }
+    if (blk < KB) do_block(blk, bw[0], bw[1]);                       // odd block count (K1 = 288: 9 blocks)
     f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* xrow = s_x + j * a.ldx + 4 * kq;
-    for (int g = 0; g < KG; g += 2) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bB[s] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(16 * (g + 1) + 4 * kq + s) * DENSE_HID);
-        f32x4 av = *reinterpret_cast<const f32x4*>(xrow + 16 * g);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[s], bA[s][t], acc[t]);
-        if (g + 2 < KG) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) bA[s] = *reinterpret_cast<const f32x4*>(w1 + (size_t)(16 * (g + 2) + 4 * kq + s) * DENSE_HID);
-        }
-        av = *reinterpret_cast<const f32x4*>(xrow + 16 * (g + 1));
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[s], bB[s][t], acc[t]);
-    }
+    for (int t = 0; t < 4; ++t) acc[t] = acc2c[t][0] + acc2c[t][1];
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
     // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
@@ -526,11 +542,17 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 // ---------------------------------------------------------------------------------------------------------------
 // Packs the conv2 / conv3 kernels of one parameter buffer into bf16 pieces in MFMA B-operand order (qnet.h PK_*): one wave per
 // block, lane (kb, j) gathers its 8 weights, splits them exactly and writes 3 x 16 bytes.  ~0.2 MB, one launch per parameter change.
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ params, u32x4* __restrict__ pk, int w2_off, int w3_off) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ params, u32x4* __restrict__ pk, int w2_off, int w3_off,
+                                                           int d1_off, int d1_blocks) {
     const int lane = threadIdx.x & 63, blk_id = blockIdx.x * 4 + (threadIdx.x >> 6), j = lane & 15, kb = lane >> 4;
-    if (blk_id >= PK_TOTAL_BLOCKS) return;
+    if (blk_id >= PK_TOTAL_BLOCKS + d1_blocks) return;
     float v[8];
-    if (blk_id < 16 + 8) {                                          // forward: B(k, col = 2j + t) = W[k][col], k = 32 blk + 8kb + e
+    if (blk_id >= PK_TOTAL_BLOCKS) {                                // Dense(512): block (kblk, ct): B(k = 32 kblk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3))
+        const int b = blk_id - PK_TOTAL_BLOCKS, kblk = b >> 5, ct = b & 31;
+        const float* w = params + d1_off + (size_t)(32 * kblk + 8 * kb) * DENSE_HID + 64 * (ct >> 2) + 4 * j + (ct & 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[(size_t)e * DENSE_HID];
+    } else if (blk_id < 16 + 8) {                                          // forward: B(k, col = 2j + t) = W[k][col], k = 32 blk + 8kb + e
         const bool c2 = blk_id < 16;
         const int b = c2 ? blk_id : blk_id - 16, blk = b >> 1, t = b & 1;
         const float* w = params + (c2 ? w2_off : w3_off);
@@ -549,10 +571,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     dst[0] = o.h; dst[64] = o.m; dst[128] = o.l;
 }
 
+size_t fused_packed_u32x4(const dq_qnet* Q) { return (size_t)PK_TOTAL_U32X4 + (size_t)(Q->L[Q->cfg.n_conv].nin >> 5) * 32 * PK_BLOCK; }
+
 dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* packed_dev, hipStream_t st) {
     DQ_REQUIRE(Q && params_dev && packed_dev, DQ_ERR_INVALID, "dq_qnet_pack: null argument");
     DQ_REQUIRE(fused_forward_supported(Q), DQ_ERR_UNSUPPORTED, "dq_qnet_pack: the fused chains do not cover this configuration");
-    pack_weights_kernel<<<(PK_TOTAL_BLOCKS + 3) / 4, 256, 0, st>>>(params_dev, static_cast<u32x4*>(packed_dev), (int)Q->L[1].w_off, (int)Q->L[2].w_off);
+    const Layer& D1 = Q->L[Q->cfg.n_conv];
+    const int d1_blocks = (D1.nin >> 5) * 32;
+    pack_weights_kernel<<<(PK_TOTAL_BLOCKS + d1_blocks + 3) / 4, 256, 0, st>>>(params_dev, static_cast<u32x4*>(packed_dev), (int)Q->L[1].w_off,
+                                                                            (int)Q->L[2].w_off, (int)D1.w_off, d1_blocks);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }
@@ -600,7 +627,7 @@ static bool plan_dense(const dq_qnet* Q, DensePlan* P) {
     P->ld2 = 16 * P->NT2 + 4;
     P->ld3 = 16 * ((N3 + 15) / 16) + 1;
     size_t off = 0;
-    const size_t xb = up16((size_t)DENSE_ROWS * P->ldx * 4), pb = up16((size_t)DENSE_WAVES * 16 * 16 * P->NT2 * 4);
+    const size_t xb = up16((size_t)3 * DENSE_ROWS * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * 16 * 16 * P->NT2 * 4);   // bf16 planes | partials
     P->off_x = P->off_part = (int)off; off += xb > pb ? xb : pb;   // the Dense(|A|) partials reuse the input image (dead by then)
     P->off_h = (int)off; off += up16((size_t)DENSE_ROWS * (DENSE_HID + 4) * 4);
     P->off_y2 = (int)off; off += up16((size_t)DENSE_ROWS * P->ld2 * 4);
@@ -647,7 +674,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
     ca.kofftab = Q->kofftab;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2;
-    da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
+    da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = PK_TOTAL_U32X4;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < Q->n_layers - nc; ++l) { da.w_off[l] = (int)Q->L[nc + l].w_off; da.b_off[l] = (int)Q->L[nc + l].b_off; }
     da.ldx = dp.ldx; da.ld2 = dp.ld2; da.ld3 = dp.ld3;
@@ -679,7 +706,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         C.act_out[0] = Q->act[0][0]; C.act_out[1] = Q->act[0][1]; C.act_out[2] = x;
         conv_wgs += (jb.batch + cp.S - 1) / cp.S;
         DenseJob& D = da.job[i];
-        D.params = jb.params_dev; D.x = x; D.batch = jb.batch; D.wg0 = dense_wgs;
+        D.params = jb.params_dev; D.packed = static_cast<const u32x4*>(packed); D.x = x; D.batch = jb.batch; D.wg0 = dense_wgs;
         if (training && D1.dropout > 0.f) {
             D.keep_scale = (float)(1.0 / (1.0 - (double)D1.dropout));
             D.drop_T = dq_rate_threshold((double)D1.dropout);

@@ -104,7 +104,9 @@ __device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32
 #define PK_CONV3_DG (PK_CONV3_FWD + 8 * PK_BLOCK)
 #define PK_CONV2_DG (PK_CONV3_DG + 8 * PK_BLOCK)
 #define PK_TOTAL_BLOCKS 48
-#define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)
+#define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)     // the conv sections; then PK_DENSE1 [K1/32 k-blocks][32 column tiles]:
+//   B(k = 32 blk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3)) = W1[k][col]
+size_t fused_packed_u32x4(const dq_qnet* Q);
 dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* packed_dev, hipStream_t st);
 
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered

@@ -407,7 +407,7 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         if (e == hipSuccess) e = hipMemcpy(Q->kofftab, tab, sizeof(tab), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && fused_forward_supported(Q))
-        for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->pk_scratch[i], (size_t)PK_TOTAL_U32X4 * 16);
+        for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->pk_scratch[i], fused_packed_u32x4(Q) * 16);
     if (e == hipSuccess && fused_forward_supported(Q)) {
         const size_t xf = (size_t)cfg->max_batch * Q->L[cfg->n_conv].nin;
         for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->xinf[i], xf * sizeof(float));
@@ -525,7 +525,7 @@ dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* ob
     return DQ_OK;
 }
 
-size_t dq_qnet_packed_bytes(const dq_qnet* Q) { return Q && fused_forward_supported(Q) ? (size_t)PK_TOTAL_U32X4 * 16 : 0; }
+size_t dq_qnet_packed_bytes(const dq_qnet* Q) { return Q && fused_forward_supported(Q) ? fused_packed_u32x4(Q) * 16 : 0; }
 
 dq_status dq_qnet_pack(const dq_qnet* Q, const float* params_dev, void* packed_dev, void* stream) {
     return fused_pack_weights(Q, params_dev, packed_dev, (hipStream_t)stream);
