@@ -521,6 +521,8 @@ __device__ __forceinline__ void dgrad_inplace(const Bf16x3 (&bw)[4][2], const fl
     }
 }
 
+#define A1PS 64                         // row stride of the a1 image: unpadded, because it is filled by LDS-DMA (1 KB contiguous per wave instruction)
+
 template <int KG1>                      // first convolution's K padded to 16 * KG1
 __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     // dW1 [16 KG1 x 64]: tile id = wave + 8u -> k-tile id>>2, n-tile wave & 3 (the same for every u)
     const int kyx = wave >> 1, ky = kyx >> 1, kx = kyx & 1;
     const int aoff3 = (ky * a.ow2 + kx) * 36 + 16 * (wave & 1) + j;
-    const int aoff2 = (ky * a.ow1 + kx) * 68 + 32 * (wave & 1) + j;
+    const int aoff2 = (ky * a.ow1 + kx) * A1PS + 32 * (wave & 1) + j;
     f32x4 acc3[2], acc2[2][2], acc1[NW1];
     float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1 = 0.f;
 #pragma unroll
@@ -590,7 +592,16 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 if (tid == 0 && s < ns) s_mis[s] = misv[s];
             }
         }
-        stage_rows<64, 68>(s_a1, a.a1 + (size_t)b0 * r1 * 64, M1, tid);
+        {   // a1 (the largest image) goes global -> LDS directly, no registers: wave w copies 1 KB chunks w, w + 8, ...; it is first
+            // read by dW2, so the wait sits there and the copy overlaps the patch image, dW3 and g2
+            const char* src = reinterpret_cast<const char*>(a.a1 + (size_t)b0 * r1 * 64);
+            const int bytes = M1 * 256, chunks = (bytes + 1023) >> 10;
+            for (int ch = wave; ch < chunks; ch += CB_WAVES) {
+                int off = ch * 1024 + lane * 16;
+                if (off >= bytes) off = 0;                              // tail lanes: a valid address; they land in the image's padding
+                __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) u32*)(s_a1 + ch * 256), 16, 0, 0);
+            }
+        }
         stage_rows<32, 36>(s_g3, a.g3 + (size_t)b0 * r3 * 32, M3, tid);
         stage_rows<32, 36>(s_a2, a.a2 + (size_t)b0 * r2 * 32, M2, tid);
         Bf16x3 bw[4][2];                                            // data-gradient weights (bf16 pieces): loaded one phase ahead of their use
@@ -646,6 +657,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
         dgrad_inplace<36>(bw, s_g3, zero3, s_a2, 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's LDS-DMA chunks of a1 have landed
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
         // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 const int m = m0 + 4 * q + kq;
                 const bool ok = m < M2;
                 const int mc = ok ? m : 0;
-                const float* ap = s_a1 + t2[mc] * 68 + aoff2;
+                const float* ap = s_a1 + t2[mc] * A1PS + aoff2;
                 const float ra0 = ap[0], ra1 = ap[16], r0 = s_a2[mc * 36 + j], r1 = s_a2[mc * 36 + 16 + j];     // unconditional, then select
                 av0[q] = ok ? ra0 : 0.f;
                 av1[q] = ok ? ra1 : 0.f;
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         __syncthreads();                                            // every wave is done reading a1
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 8);
         // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1: waves 0-3 channels 0..31, waves 4-7 channels 32..63 -------------
-        dgrad_inplace<68>(bw, s_a2, zero2, s_a1, 32 * (wave >> 2), a.oh1, a.ow1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
+        dgrad_inplace<A1PS>(bw, s_a2, zero2, s_a1, 32 * (wave >> 2), a.oh1, a.ow1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 9);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 10);
@@ -698,7 +710,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                         const u8 rb = cp[mc * KP + (tv ? 32 * u : 0)];                                  // unconditional, then select
                         av[q][u] = (ok && tv) ? (float)rb : 0.f;
                     }
-                    const float rg = gp[mc * 68];
+                    const float rg = gp[mc * A1PS];
                     g[q] = ok ? rg : 0.f;
                 }
                 // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
@@ -789,7 +801,8 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
     for (int S = 8; S >= 1; S >>= 1) {
         size_t off = up16((size_t)S * P->slot);
         P->off_mis = (int)off; off += up16((size_t)S * 4);
-        P->off_a1 = (int)off; off += up16((size_t)S * L1.rows * 68 * 4);
+        off = (off + 1023) & ~(size_t)1023;                                            // LDS-DMA target: whole 1 KB chunks
+        P->off_a1 = (int)off; off += ((size_t)S * L1.rows * A1PS * 4 + 1023) & ~(size_t)1023;
         P->off_a2 = (int)off; off += up16((size_t)(S * L2.rows + 1) * 36 * 4);
         P->off_g3 = (int)off; off += up16((size_t)(S * L3.rows + 1) * 36 * 4);
         P->off_t1 = (int)off; off += up16((size_t)S * L1.rows * 16 * P->KG1);      // observation patch image (bytes)
