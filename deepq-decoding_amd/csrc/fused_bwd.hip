@@ -437,6 +437,7 @@ struct ConvBwdArgs {
     size_t pstride;
     int slot;
     int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko;
+    int a1_alt;                         // bytes from the a1 image to its second buffer, 0 = single-buffered
     const int* kofftab;                 // [96] conv1 weight row k -> byte offset inside an observation, -1 past K1
 };
 
@@ -467,6 +468,9 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
 // Weights of one 2x2 data gradient for this lane as bf16 pieces: [tap ky*2+kx][column tile t]: B(n = 8kb .. 8kb+7, c = c_lo + 16t + j)
 // = W[ky,kx, c, n], ready-made in the packed buffer (qnet.h PK_CONV3_DG / PK_CONV2_DG + 8 * PK_BLOCK * half).
 __device__ __forceinline__ void dgrad_load_w(Bf16x3 (&bw)[4][2], const u32x4* __restrict__ pk, int lane) {
+    // opaque base: otherwise hipcc hoists the 24 load addresses out of the caller's loop as invariants (48 VGPRs), spills them, and
+    // reloads each behind an s_waitcnt vmcnt(0) -- which serialises the loads (measured: 10K cycles for this function)
+    asm volatile("" : "+s"(pk));
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap)
 #pragma unroll
@@ -528,7 +532,6 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8* s_in = smem;
     int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);
-    float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1);
     float* s_a2 = reinterpret_cast<float*>(smem + a.off_a2);
     float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
     u8* s_col = smem + a.off_t1;                                     // observation patch image [S*r1][16*KG1] bytes
@@ -561,52 +564,74 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 #pragma unroll
     for (int u = 0; u < NW1; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
+    // ---- every input image goes global -> LDS by LDS-DMA (no registers), issued as early as its LDS target is free, so that group
+    //      k + 1's inputs land while group k computes.  (All workgroups run in lockstep: a load phase of its own is a burst on HBM
+    //      that nothing overlaps.)  One wave instruction writes 64 lanes x 16 B (or x 4 B) CONTIGUOUSLY in LDS from per-lane global
+    //      addresses; inactive lanes write nothing.
+    // a1 [M1][64]: wave w copies 1 KB chunks w, w + 8, ...  Double-buffered (a1 is live until the end of dW1).
+    auto issue_a1 = [&](int g, float* dst) {
+        const int gb0 = g * S, gM1 = min(S, a.batch - gb0) * r1;
+        const char* src = reinterpret_cast<const char*>(a.a1 + (size_t)gb0 * r1 * 64);
+        const int bytes = gM1 * 256, chunks = (bytes + 1023) >> 10;
+        for (int ch = wave; ch < chunks; ch += CB_WAVES) {
+            int off = ch * 1024 + lane * 16;
+            if (off >= bytes) off = 0;                                  // tail lanes: a valid address; they land in the image's padding
+            __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) u32*)(dst + ch * 256), 16, 0, 0);
+        }
+    };
+    // a2 / g3 [rows][32] -> LDS rows of 36 floats = 9 lane slots of 16 B: slot 8 of every row is padding (its lane stays inactive)
+    auto issue_rows36 = [&](const float* srcf, int rows, float* dst) {
+        const char* src = reinterpret_cast<const char*>(srcf);
+        const int slots = rows * 9, chunks = (slots + 63) >> 6;
+        for (int ch = wave; ch < chunks; ch += CB_WAVES) {
+            const int q = ch * 64 + lane, row = q / 9, part = q - row * 9;
+            if (q < slots && part < 8)
+                __builtin_amdgcn_global_load_lds(src + (size_t)row * 128 + part * 16, (__attribute__((address_space(3))) u32*)(dst + ch * 256), 16, 0, 0);
+        }
+    };
+    // observations: lane l copies aligned dword l of a 256-byte piece of a sample's arbitrarily aligned row -- whole aligned dwords, also
+    // where they straddle the neighbouring rows (see fused.hip: the window stays inside the caller's allocation)
+    auto issue_obs = [&](int g) {
+        const int gb0 = g * S, gns = min(S, a.batch - gb0);
+        const int pieces = (a.slot + 255) >> 8;
+        for (int task = wave; task < gns * pieces; task += CB_WAVES) {
+            const int s = task / pieces, pc = task - s * pieces;
+            int row = gb0 + s;
+            if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
+            const u8* src = a.obs + (size_t)row * in_bytes;
+            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
+            const int d = pc * 64 + lane;
+            if (4 * d < mis + in_bytes)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32*>(src - mis) + d,
+                                                 (__attribute__((address_space(3))) u32*)(s_in + s * a.slot + pc * 256), 4, 0, 0);
+            if (pc == 0 && lane == 0) s_mis[s] = mis;
+        }
+    };
+    if ((int)blockIdx.x < a.groups) {
+        const int g = blockIdx.x, gns = min(S, a.batch - g * S);
+        issue_obs(g);
+        issue_rows36(a.g3 + (size_t)g * S * r3 * 32, gns * r3, s_g3);
+        issue_rows36(a.a2 + (size_t)g * S * r2 * 32, gns * r2, s_a2);
+        if (a.a1_alt) issue_a1(g, reinterpret_cast<float*>(smem + a.off_a1));
+    }
+
+    Bf16x3 bw[4][2];                                                // data-gradient weights (bf16 pieces): loaded one phase ahead of their use
+    int it = 0;
+    for (int grp = blockIdx.x; grp < a.groups; grp += gridDim.x, ++it) {
+        float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1 + (it & 1) * a.a1_alt);
         const int b0 = grp * S, ns = min(S, a.batch - b0);
         const int M1 = ns * r1, M2 = ns * r2, M3 = ns * r3;
+        const int nxt = grp + (int)gridDim.x;
+        const int ns_nxt = min(S, a.batch - nxt * S);
         const int sb = (grp == (int)blockIdx.x) ? 0 : 12;          // DQ_STAMP slots of the first / a later group
         (void)sb;
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 0);
-        __syncthreads();                                            // previous group's images are no longer read
-        // ---- stage: observations (thread t copies aligned dword t of every sample's arbitrarily aligned row; the loads of all
-        //      samples are issued before the first LDS store), a1, a2, g3 ----------------------------------------------------
-        {
-            u32 v[8];
-            int misv[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                int row = b0 + (s < ns ? s : 0);
-                if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
-                const u8* src = a.obs + (size_t)row * in_bytes;
-                const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
-                // whole aligned dwords, also where they straddle the neighbouring rows (see fused.hip: the window stays inside the
-                // caller's allocation)
-                const u32* win = reinterpret_cast<const u32*>(src - mis);
-                misv[s] = mis;
-                const u32 w = win[4 * tid < mis + in_bytes ? tid : 0];     // unconditional, clamped
-                v[s] = w;
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s < ns && 4 * tid < misv[s] + in_bytes) reinterpret_cast<u32*>(s_in + s * a.slot)[tid] = v[s];
-                if (tid == 0 && s < ns) s_mis[s] = misv[s];
-            }
-        }
-        {   // a1 (the largest image) goes global -> LDS directly, no registers: wave w copies 1 KB chunks w, w + 8, ...; it is first
-            // read by dW2, so the wait sits there and the copy overlaps the patch image, dW3 and g2
-            const char* src = reinterpret_cast<const char*>(a.a1 + (size_t)b0 * r1 * 64);
-            const int bytes = M1 * 256, chunks = (bytes + 1023) >> 10;
-            for (int ch = wave; ch < chunks; ch += CB_WAVES) {
-                int off = ch * 1024 + lane * 16;
-                if (off >= bytes) off = 0;                              // tail lanes: a valid address; they land in the image's padding
-                __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) u32*)(s_a1 + ch * 256), 16, 0, 0);
-            }
-        }
-        stage_rows<32, 36>(s_g3, a.g3 + (size_t)b0 * r3 * 32, M3, tid);
-        stage_rows<32, 36>(s_a2, a.a2 + (size_t)b0 * r2 * 32, M2, tid);
-        Bf16x3 bw[4][2];                                            // data-gradient weights (bf16 pieces): loaded one phase ahead of their use
-        dgrad_load_w(bw, a.packed + PK_CONV3_DG, lane);
+        // ---- stage: nothing to copy -- wait for this wave's DMA pieces of the group's images, then meet ------------------------------
+        if (!a.a1_alt) { __syncthreads(); issue_a1(grp, s_a1); }    // single-buffered a1: free only when every wave has left dW1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DQ_STAMP(DQ_TAG_CONV_BWD, sb + 11);
         __syncthreads();
+        dgrad_load_w(bw, a.packed + PK_CONV3_DG, lane);             // first used by g2: lands during the patch image and dW3
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 1);
         // ---- observation patch image: row m = the K1 bytes conv1 multiplies for output pixel m (zeros past K1), so that dW1's A
         //      operand is 16 consecutive bytes per quarter-wave instead of a scattered byte gather -------------------------------
@@ -657,8 +682,12 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
         dgrad_inplace<36>(bw, s_g3, zero3, s_a2, 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's LDS-DMA chunks of a1 have landed
         __syncthreads();
+        if (nxt < a.groups) {                                       // the observation slots and g3 are dead now; so is the other a1 buffer
+            issue_obs(nxt);
+            issue_rows36(a.g3 + (size_t)nxt * S * r3 * 32, ns_nxt * r3, s_g3);
+            if (a.a1_alt) issue_a1(nxt, reinterpret_cast<float*>(smem + a.off_a1 + ((it + 1) & 1) * a.a1_alt));
+        }
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
         // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
         for (int m0 = 0; m0 < M2; m0 += 32) {                         // 8 MFMA steps per trip: two dependent LDS latencies per 32 MFMAs
@@ -693,12 +722,14 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 9);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 10);
+        if (nxt < a.groups) issue_rows36(a.a2 + (size_t)nxt * S * r2 * 32, ns_nxt * r2, s_a2);     // g2 (in a2) is dead; lands during dW1
         // ---- dW1 += patches^T g1 ----------------------------------------------------------------------------------------
         {
             const u8* cp = s_col + 16 * (wave >> 2) + j;           // + 32 per further tile of this wave (k-tile + 2)
             const float* gp = s_a1 + 16 * (wave & 3) + j;
-            for (int m0 = 0; m0 < M1; m0 += 32) {                     // 8 MFMA steps per trip
-                float av[8][NW1], g[8];
+            // 8 MFMA steps (32 rows) per trip, software-pipelined by hand: the LDS reads of trip t + 1 are issued before the MFMAs of
+            // trip t (with two waves per SIMD the read -> wait -> convert -> MFMA chain is otherwise exposed: pipe 39% busy)
+            auto rd = [&](int m0, float (&av)[8][NW1], float (&g)[8]) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int m = m0 + 4 * q + kq;
@@ -713,14 +744,22 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                     const float rg = gp[mc * A1PS];
                     g[q] = ok ? rg : 0.f;
                 }
-                // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
-                // (each copy waits for the result) -- a tile this wave does not have just accumulates zeros and is never stored
+            };
+            // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
+            // (each copy waits for the result) -- a tile this wave does not have just accumulates zeros and is never stored
+            auto mm = [&](const float (&av)[8][NW1], const float (&g)[8]) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
 #pragma unroll
                     for (int u = 0; u < NW1; ++u) acc1[u] = MFMA16(av[q][u], g[q], acc1[u]);
                     bs1 += g[q];
                 }
+            };
+            float avA[8][NW1], gA[8], avB[8][NW1], gB[8];
+            rd(0, avA, gA);
+            for (int m0 = 0;;) {
+                rd(m0 + 32, avB, gB); mm(avA, gA); m0 += 32; if (m0 >= M1) break;
+                rd(m0 + 32, avA, gA); mm(avB, gB); m0 += 32; if (m0 >= M1) break;
             }
         }
     }
@@ -785,7 +824,7 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     return true;
 }
 
-struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko; size_t lds; };
+struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, a1_alt; size_t lds; };
 
 static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
     if (Q->cfg.n_conv != 3) return false;
@@ -798,11 +837,14 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
     const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
     P->slot = (in_bytes + 3 + 3) & ~3;
     if (P->slot > 4 * CB_THREADS) return false;                      // one dword of an observation per thread
-    for (int S = 8; S >= 1; S >>= 1) {
+    for (int pass = 0; pass < 8; ++pass) {                             // S = 8 double-buffered, S = 8 single, S = 4 double, ...
+        const int S = 8 >> (pass >> 1), nbuf = 2 - (pass & 1);
         size_t off = up16((size_t)S * P->slot);
         P->off_mis = (int)off; off += up16((size_t)S * 4);
         off = (off + 1023) & ~(size_t)1023;                                            // LDS-DMA target: whole 1 KB chunks
-        P->off_a1 = (int)off; off += ((size_t)S * L1.rows * A1PS * 4 + 1023) & ~(size_t)1023;
+        const size_t a1_bytes = ((size_t)S * L1.rows * A1PS * 4 + 1023) & ~(size_t)1023;
+        P->off_a1 = (int)off; off += nbuf * a1_bytes;
+        P->a1_alt = nbuf == 2 ? (int)a1_bytes : 0;
         P->off_a2 = (int)off; off += up16((size_t)(S * L2.rows + 1) * 36 * 4);
         P->off_g3 = (int)off; off += up16((size_t)(S * L3.rows + 1) * 36 * 4);
         P->off_t1 = (int)off; off += up16((size_t)S * L1.rows * 16 * P->KG1);      // observation patch image (bytes)
@@ -944,7 +986,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
     ca.partial = conv_partial; ca.pstride = conv_floats;
-    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
+    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.a1_alt = cp.a1_alt; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
     ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3; ca.off_ko = cp.off_ko; ca.kofftab = Q->kofftab;
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
     conv_bwd_kernel_t ck = cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>

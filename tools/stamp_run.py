@@ -25,7 +25,8 @@ if tag == 4:
     for w in range(8):
         t = [buf[i * 8 + w] for i in range(11)] + [buf[12 * 8 + w]]
         t2 = [buf[(12 + i) * 8 + w] for i in range(11)] + [buf[24 * 8 + w]]
-        print("wave", w, "group 1:", [t[i + 1] - t[i] for i in range(11)], " group 2:", [t2[i + 1] - t2[i] for i in range(11)])
+        print("wave", w, "group 1:", [t[i + 1] - t[i] for i in range(11)], " group 2:", [t2[i + 1] - t2[i] for i in range(11)],
+              " wait part of stage:", buf[11 * 8 + w] - t[0], buf[23 * 8 + w] - t2[0])
     print(names)
 elif tag == 1:
     for w in range(4):
