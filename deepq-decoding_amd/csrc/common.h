@@ -110,15 +110,30 @@ __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
 #define DQ_TAG_CONV_BWD 4
 #ifdef DQ_STAMPS
 #define DQ_STAMP_BLOCK 9
-static __device__ unsigned long long dq_dbg[512];            // one copy per translation unit (no relocatable device code)
+static __device__ unsigned long long dq_dbg[4096];            // one copy per translation unit (no relocatable device code)
 #define DQ_STAMP_READER(name) extern "C" void name(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dq_dbg), sizeof(dq_dbg)); }
 #define DQ_STAMP(tag, i)                                                                                        \
     do {                                                                                                        \
         if ((tag) == DQ_STAMPS && blockIdx.x == DQ_STAMP_BLOCK && (threadIdx.x & 63) == 0)                      \
             dq_dbg[(i) * 8 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();                                \
     } while (0)
+// tag + 10: wall-clock (100 MHz) start / end of the first 256 workgroups instead (dispatch spread, launch ramp and drain)
+#define DQ_STAMP_WG(tag, end)                                                                                   \
+    do {                                                                                                        \
+        if ((tag) + 10 == DQ_STAMPS && blockIdx.x < 256 && threadIdx.x == 0)                                    \
+            dq_dbg[(end) * 256 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();                                \
+    } while (0)
+// DQ_STAMPS == 20: wall-clock start / end of workgroups 0..1023 of two consecutive kernels (quarter q = 2 * kernel + end): the gap
+// between one kernel's last workgroup and the next kernel's first
+#define DQ_STAMP_PAIR(q)                                                                                        \
+    do {                                                                                                        \
+        if (DQ_STAMPS == 20 && blockIdx.x < 1024 && threadIdx.x == 0)                                           \
+            dq_dbg[(q) * 1024 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();                                 \
+    } while (0)
 #else
 #define DQ_STAMP(tag, i) do { } while (0)
+#define DQ_STAMP_WG(tag, end) do { } while (0)
+#define DQ_STAMP_PAIR(q) do { } while (0)
 #define DQ_STAMP_READER(name)
 #endif
 

@@ -64,16 +64,42 @@ struct ConvChainArgs {
 // split into bf16 pieces on the fly; B = the block's weights as pieces in registers, HALF of K at a time (96 VGPRs).  Each wave
 // takes pairs of 16-row tiles x both column tiles (column tile t, lane j = column 2j + t), two accumulator chains per tile.
 template <int CIN, int COUT, int KS>
-__device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int ih, int iw, int oh, int ow, int M,
+struct ConvShape {
+    static constexpr int NT = COUT / 16, CB = CIN / 32, NB = KS * KS * CB, R = NB < 4 ? NB : 4;     // R: K = 32 weight blocks in flight
+};
+
+// One K = 32 block of packed weights (qnet.h) for this lane: NT column tiles x 3 bf16 pieces, one coalesced 16-byte load each.
+template <int NT>
+__device__ __forceinline__ void conv_w_load(Bf16x3 (&slot)[NT], const u32x4* __restrict__ pk, int blk, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const u32x4* pb = pk + (blk * NT + t) * PK_BLOCK + lane;
+        slot[t].h = pb[0]; slot[t].m = pb[64]; slot[t].l = pb[128];
+    }
+}
+
+// The first R blocks, issued by the caller BEFORE the barrier that publishes the input image.
+template <int R, int NT>
+__device__ __forceinline__ void conv_w_prefetch(Bf16x3 (&ring)[R][NT], const u32x4* __restrict__ pk, int lane) {
+    pk = opaque_global(pk);
+#pragma unroll
+    for (int b = 0; b < R; ++b) conv_w_load<NT>(ring[b], pk, b, lane);
+}
+
+template <int CIN, int COUT, int KS, int RR, int NTT>
+__device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int ih, int iw, int oh, int ow, int M, Bf16x3 (&ring)[RR][NTT],
                                               const u32x4* __restrict__ pk, const float* __restrict__ bias,
                                               float* __restrict__ out_lds, float* __restrict__ out_g, int wave, int lane) {
-    constexpr int NT = COUT / 16, PSI = CIN + 4, PSO = COUT + 4, CB = CIN / 32, NB = KS * KS * CB, HB = NB > 4 ? NB / 2 : NB;
-    static_assert(NT == 2 && CIN % 32 == 0 && NB % HB == 0, "written for 32 output channels, CIN a multiple of 32");
+    using SH = ConvShape<CIN, COUT, KS>;
+    constexpr int NT = SH::NT, PSI = CIN + 4, PSO = COUT + 4, CB = SH::CB, NB = SH::NB, R = SH::R;
+    static_assert(NT == 2 && CIN % 32 == 0 && RR == R && NTT == NT, "written for 32 output channels, CIN a multiple of 32");
     const int j = lane & 15, kb = lane >> 4;
     const f32x2 bias2 = *reinterpret_cast<const f32x2*>(bias + 2 * j);
     const int rows = oh * ow, tiles = (M + 15) >> 4;
     for (int t0 = 2 * wave; t0 < tiles; t0 += 2 * CONV_WAVES) {
+        pk = opaque_global(pk);                                     // per trip: see qnet.h
         const bool two = t0 + 1 < tiles;                            // wave-uniform; a missing second tile recomputes clamped rows
+        const bool more = t0 + 2 * CONV_WAVES < tiles;              // another pair of row tiles follows: keep the weight stream going
         int abase[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -87,29 +113,21 @@ __device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int 
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = acc[u][t][0]; }
+        // the weights stream through a ring of R blocks: block blk + R is requested as soon as block blk's MFMAs are issued, so the
+        // L1/L2 weight traffic (every wave reads the whole layer) overlaps the matrix pipe instead of alternating with it
 #pragma unroll
-        for (int h0 = 0; h0 < NB; h0 += HB) {
-            // ---- this half's weights: ready-made bf16 pieces, one coalesced 16-byte load per lane per piece --------------------
-            Bf16x3 bw[HB][NT];
+        for (int blk = 0; blk < NB; ++blk) {
+            const int tap = blk / CB, c32 = blk - tap * CB, ky = tap / KS, kx = tap - ky * KS;
+            const int off = (ky * iw + kx) * PSI + 32 * c32;
 #pragma unroll
-            for (int bi = 0; bi < HB; ++bi)
+            for (int u = 0; u < 2; ++u) {
+                const float* ap = in + abase[u] + off;
+                const Bf16x3 av = split_bf16x3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const u32x4* pb = pk + ((h0 + bi) * NT + t) * PK_BLOCK + lane;
-                    bw[bi][t].h = pb[0]; bw[bi][t].m = pb[64]; bw[bi][t].l = pb[128];
-                }
-#pragma unroll
-            for (int bi = 0; bi < HB; ++bi) {
-                const int blk = h0 + bi, tap = blk / CB, c32 = blk - tap * CB, ky = tap / KS, kx = tap - ky * KS;
-                const int off = (ky * iw + kx) * PSI + 32 * c32;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float* ap = in + abase[u] + off;
-                    const Bf16x3 av = split_bf16x3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) mma_bf16x6(av, bw[bi][t], acc[u][t][0], acc[u][t][1]);
-                }
+                for (int t = 0; t < NT; ++t) mma_bf16x6(av, ring[blk % R][t], acc[u][t][0], acc[u][t][1]);
             }
+            if (blk + R < NB) conv_w_load<NT>(ring[blk % R], pk, blk + R, lane);
+            else if (more) conv_w_load<NT>(ring[blk % R], pk, blk + R - NB, lane);
         }
         // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg; this lane owns columns 2j, 2j+1
 #pragma unroll
@@ -144,6 +162,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     constexpr int NH1 = (KG1 + 1) / 2;                              // first convolution's K in halves of 32
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 0);
+    DQ_STAMP_WG(DQ_TAG_CONV_FWD, 0);
+    DQ_STAMP_PAIR(0);
     // ---- first convolution's weights -> registers (the loads fly while the observations are staged) ----------------
     // The observation is binary, so conv1 runs on the bf16 matrix pipe (16x the f32 rate) WITHOUT losing a bit: 0/1 is exact in
     // bf16, and every f32 weight is split exactly into three bf16 pieces w = hi + mid + lo (8 + 8 + 8 mantissa bits, by
@@ -153,22 +173,55 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     const float* w1 = J.params + a.w_off[0];
     u32x4 wb[3][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 bf16 each
     int ko[NH1][8];
+    f32x4 wv[NH1][8];
 #pragma unroll
-    for (int h = 0; h < NH1; ++h) {
-        f32x4 wv[8];
+    for (int h = 0; h < NH1; ++h)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = 32 * h + 8 * kq + e;
             const int off = a.kofftab[k];                           // Keras HWIO row k = (ky*k1 + kx)*C + c -> NCHW uint8 offset
             const f32x4 v = *reinterpret_cast<const f32x4*>(w1 + (size_t)(off >= 0 ? k : 0) * 64 + 4 * j);
-            wv[e] = off >= 0 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            wv[h][e] = off >= 0 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             ko[h][e] = off >= 0 ? off : 0;
         }
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
+
+    DQ_STAMP(DQ_TAG_CONV_FWD, 1);
+    // ---- stage the observations by LDS-DMA (global -> LDS, no registers): lane l copies aligned dword l of a 256-byte piece of a
+    //      sample's arbitrarily aligned row -- whole aligned dwords, also where they straddle the neighbouring rows: the window never
+    //      leaves the caller's allocation (dq_qnet_forward: obs_dev rows live in one 4-byte-aligned allocation whose size is a
+    //      multiple of 4).  The copies fly while the weights are split below. ------------------------------------------------------
+    {
+        const int pieces = (a.slot + 255) >> 8;
+        for (int task = wave; task < ns * pieces; task += CONV_WAVES) {
+            const int s = task / pieces, pc = task - s * pieces;
+            int row = b0 + s;
+            if (J.index) { row = J.index[row] + J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
+            const u8* src = J.obs + (size_t)row * in_bytes;
+            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
+            const int d = pc * 64 + lane;
+            if (4 * d < mis + in_bytes)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32*>(src - mis) + d,
+                                                 (__attribute__((address_space(3))) u32*)(s_in + s * a.slot + pc * 256), 4, 0, 0);
+            if (pc == 0 && lane == 0) s_mis[s] = mis;
+        }
+    }
+    __syncthreads();                                                // s_mis
+    // byte offset of output pixel m's patch origin inside the staged observations (the a2 region is free until conv2 writes it)
+    const int r1 = a.oh1 * a.ow1, M1 = ns * r1;
+    int* s_t1 = reinterpret_cast<int*>(s_a2);
+    for (int m = tid; m < M1; m += CONV_THREADS) {
+        const int s = m / r1, pix = m - s * r1, oy = pix / a.ow1, ox = pix - oy * a.ow1;
+        s_t1[m] = s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
+    }
+    // ---- split the weights into bf16 pieces --------------------------------------------------------------------------------------
+#pragma unroll
+    for (int h = 0; h < NH1; ++h)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {                        // two k's per dword: element e in the low half
-                float x0 = wv[e][t], x1 = wv[e + 1][t];
+                float x0 = wv[h][e][t], x1 = wv[h][e + 1][t];
 #pragma unroll
                 for (int piece = 0; piece < 3; ++piece) {
                     const u32 b0 = __float_as_uint(x0) & 0xffff0000u, b1 = __float_as_uint(x1) & 0xffff0000u;
@@ -177,67 +230,32 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                     x1 -= __uint_as_float(b1);
                 }
             }
-    }
-    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
-
-    DQ_STAMP(DQ_TAG_CONV_FWD, 1);
-    // ---- stage the observations: thread t copies aligned dword t (t + 256, ...) of every sample's (arbitrarily aligned) row;
-    //      all of a thread's loads are independent, so the gather costs one memory latency ---------------------------
-    {
-        const u8* srcs[8];
-        int misv[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            int row = b0 + (s < ns ? s : 0);
-            if (J.index) { row = J.index[row] + J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
-            srcs[s] = J.obs + (size_t)row * in_bytes;
-            misv[s] = (int)(reinterpret_cast<uintptr_t>(srcs[s]) & 3);
-        }
-        for (int d = tid; 4 * d < in_bytes + 3; d += CONV_THREADS) {       // 1 trip at d <= 5, 2 at d = 7
-            u32 v[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {                               // the loads of all samples, then the stores
-                // whole aligned dwords, also where they straddle the neighbouring rows: the window never leaves the caller's
-                // allocation (dq_qnet_forward: obs_dev rows live in one 4-byte-aligned allocation whose size is a multiple of 4)
-                const int mis = misv[s];
-                const u32* win = reinterpret_cast<const u32*>(srcs[s] - mis);
-                const u32 w = win[4 * d < mis + in_bytes ? d : 0];          // unconditional, clamped
-                v[s] = w;
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (s < ns && 4 * d < misv[s] + in_bytes) reinterpret_cast<u32*>(s_in + s * a.slot)[d] = v[s];
-        }
-        if (tid < 8 && tid < ns) {
-            int mm = 0;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) if (s == tid) mm = misv[s];
-            s_mis[tid] = mm;
-        }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's DMA pieces have landed
     __syncthreads();
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 2);
-    // ---- convolution 1: A gathered byte-wise from the uint8 image ---------------------------------------------------
+    // ---- convolution 1: A gathered byte-wise from the uint8 image; the bytes of this wave's next tile are requested before the
+    //      MFMAs of the current one ----------------------------------------------------------------------------------------------
     {
-        const int r1 = a.oh1 * a.ow1, M1 = ns * r1, tiles = (M1 + 15) >> 4;
+        const int tiles = (M1 + 15) >> 4;
         float* g1 = J.write_all ? J.act_out[0] + (size_t)b0 * r1 * 64 : nullptr;
-        for (int tile = wave; tile < tiles; tile += CONV_WAVES) {
-            int m = tile * 16 + j;
-            if (m >= M1) m = M1 - 1;
-            const int s = m / r1, pix = m - s * r1, oy = pix / a.ow1, ox = pix - oy * a.ow1;
-            const u8* ap = s_in + s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
+        auto rd = [&](int tile, u32 (&ab)[NH1][8]) {
+            const int m = min(tile * 16 + j, M1 - 1);               // rows past the end (and whole tiles past it) reread the last row
+            const u8* ap = s_in + s_t1[m];
+#pragma unroll
+            for (int h = 0; h < NH1; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ab[h][e] = ap[ko[h][e]];        // 0 or 1
+        };
+        auto tile_out = [&](int tile, const u32 (&ab)[NH1][8]) {
             f32x4 acc[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < NH1; ++h) {
-                u32 ab[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ab[e] = ap[ko[h][e]];   // 0 or 1
                 u32x4 av;
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[e] | (ab[e + 1] << 16)) * 0x3f80u;       // bf16(1.0) = 0x3f80
+                for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[h][e] | (ab[h][e + 1] << 16)) * 0x3f80u;       // bf16(1.0) = 0x3f80
 #pragma unroll
                 for (int piece = 0; piece < 3; ++piece)
 #pragma unroll
@@ -255,26 +273,39 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 *reinterpret_cast<f32x4*>(s_a1 + mo * 68 + 4 * j) = v;
                 if (g1) *reinterpret_cast<f32x4*>(g1 + (size_t)mo * 64 + 4 * j) = v;
             }
+        };
+        u32 abA[NH1][8], abB[NH1][8];
+        if (wave < tiles) {
+            rd(wave, abA);
+            for (int tile = wave;;) {
+                rd(tile + CONV_WAVES, abB); tile_out(tile, abA); tile += CONV_WAVES; if (tile >= tiles) break;
+                rd(tile + CONV_WAVES, abA); tile_out(tile, abB); tile += CONV_WAVES; if (tile >= tiles) break;
+            }
         }
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 3);
+    // ---- convolution 2 (64 -> 32, 2x2) and 3 (32 -> 32, 2x2): the first weight blocks are requested before the barrier ------------
+    Bf16x3 ring[4][2];
+    conv_w_prefetch(ring, J.packed + PK_CONV2_FWD, lane);
     __syncthreads();
     DQ_STAMP(DQ_TAG_CONV_FWD, 4);
-    // ---- convolution 2 (64 -> 32, 2x2) and 3 (32 -> 32, 2x2) --------------------------------------------------------
     {
         const int r2 = a.oh2 * a.ow2;
-        conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2,
+        conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2,
                                  J.write_all ? J.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 5);
+    conv_w_prefetch(ring, J.packed + PK_CONV3_FWD, lane);
     __syncthreads();
     DQ_STAMP(DQ_TAG_CONV_FWD, 6);
     {
         const int r3 = a.oh3 * a.ow3;
-        conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr,
+        conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr,
                                  J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 7);
+    DQ_STAMP_WG(DQ_TAG_CONV_FWD, 1);
+    DQ_STAMP_PAIR(1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -323,6 +354,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     const int K1 = a.K1;
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 0);
+    DQ_STAMP_PAIR(2);
     // ---- hidden layer's first weight blocks start flying before anything else -------------------------------------------
     // Dense(512) runs as bf16x6 (qnet.h): the weights come as packed bf16 pieces (block (kblk, column tile ct = 4*wave + t), column
     // 64*wave + 4j + t), the input rows are split ONCE into three bf16 planes in LDS.
@@ -537,6 +569,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_FWD, 8);
+    DQ_STAMP_PAIR(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -470,7 +470,7 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
 __device__ __forceinline__ void dgrad_load_w(Bf16x3 (&bw)[4][2], const u32x4* __restrict__ pk, int lane) {
     // opaque base: otherwise hipcc hoists the 24 load addresses out of the caller's loop as invariants (48 VGPRs), spills them, and
     // reloads each behind an s_waitcnt vmcnt(0) -- which serialises the loads (measured: 10K cycles for this function)
-    asm volatile("" : "+s"(pk));
+    pk = opaque_global(pk);
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap)
 #pragma unroll

@@ -59,6 +59,14 @@ static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 // costs 6 bf16 MFMAs of K = 32 (~17 cycles each) instead of 8 f32 MFMAs of K = 4 (32 cycles each): 2.5x the matrix-pipe rate at f32
 // accuracy.  The price is the VALU work of splitting the operands, so it is used where one operand (the weights) is split once per
 // phase and held in registers, and the other costs ~44 VALU per 8 values, issued in the MFMAs' shadow.
+// A wave-uniform global pointer made opaque to the optimiser (so that the addresses computed from it are not hoisted out of the
+// enclosing loop as VGPR-pair invariants and spilled) and re-marked as global memory (so that the loads stay global_load, not flat).
+__device__ __forceinline__ const u32x4* opaque_global(const u32x4* p) {
+    const __attribute__((address_space(1))) u32x4* g = (const __attribute__((address_space(1))) u32x4*)p;
+    asm volatile("" : "+s"(g));
+    return (const u32x4*)g;
+}
+
 struct Bf16x3 { u32x4 h, m, l; };       // 8 values: pieces packed two per dword (element e in the low half of dword e/2)
 
 __device__ __forceinline__ Bf16x3 split_bf16x3(const f32x4& x0, const f32x4& x1) {

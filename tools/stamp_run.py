@@ -18,9 +18,37 @@ for _ in range(5):
     net.forward(params, obs, training=True, seed=(1, 2), t=3)
     net.backward(params, dqt)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 512)()
-getattr(dq.lib(), 'dq_dbg_read_fwd' if tag in (1, 2) else 'dq_dbg_read_bwd')(buf)
-if tag == 4:
+buf = (ctypes.c_ulonglong * 4096)()
+getattr(dq.lib(), 'dq_dbg_read_fwd' if tag % 10 in (1, 2) else 'dq_dbg_read_bwd')(buf)
+if tag == 20:
+    for _ in range(3): net.forward(params, obs)
+    torch.cuda.synchronize()
+    dq.lib().dq_dbg_read_fwd(buf)
+    q = [np.array([buf[k * 1024 + i] for i in range(512 if k < 2 else 256)], dtype=np.int64) for k in range(4)]
+    t0 = q[0].min()
+    print("conv: first start 0, last start %.2f, first end %.2f, last end %.2f us" % ((q[0].max() - t0) / 100, (q[1].min() - t0) / 100, (q[1].max() - t0) / 100))
+    print("dense: first start %.2f, last start %.2f, first end %.2f, last end %.2f us" % tuple((x - t0) / 100 for x in (q[2].min(), q[2].max(), q[3].min(), q[3].max())))
+elif tag > 10:
+    # wall-clock start / end (10 ns ticks) of workgroups 0..255 of the LAST launch of the kernel
+    def report(what):
+        getattr(dq.lib(), 'dq_dbg_read_fwd' if tag % 10 in (1, 2) else 'dq_dbg_read_bwd')(buf)
+        st = np.array([buf[i] for i in range(256)], dtype=np.int64); en = np.array([buf[256 + i] for i in range(256)], dtype=np.int64)
+        t0 = st.min()
+        print(what, "start spread %.2f us; end min %.2f median %.2f max %.2f us; per-workgroup duration median %.2f us" %
+              ((st - t0).max() / 100, (en - t0).min() / 100, np.median(en - t0) / 100, (en - t0).max() / 100, np.median(en - st) / 100))
+    def timed(fn, n=20):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+    if tag % 10 in (1, 2):
+        print("inference forward (conv + dense launches): %.1f us per call" % timed(lambda: net.forward(params, obs))); report("inference:")
+        print("training forward: %.1f us per call" % timed(lambda: net.forward(params, obs, training=True, seed=(1, 2), t=3))); report("training:")
+    else:
+        report("backward:")
+elif tag == 4:
     names = ["stage", "patch-image", "dW3", "bar", "g2(+next w)", "bar", "dW2", "bar", "g1", "bar", "dW1(to next/end)"]
     for w in range(8):
         t = [buf[i * 8 + w] for i in range(11)] + [buf[12 * 8 + w]]
