@@ -575,8 +575,37 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 // ---------------------------------------------------------------------------------------------------------------
 // Packs the conv2 / conv3 kernels of one parameter buffer into bf16 pieces in MFMA B-operand order (qnet.h PK_*): one wave per
 // block, lane (kb, j) gathers its 8 weights, splits them exactly and writes 3 x 16 bytes.  ~0.2 MB, one launch per parameter change.
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ params, u32x4* __restrict__ pk, int w2_off, int w3_off,
-                                                           int d1_off, int d1_blocks) {
+struct PackTr { const float* src; float* dst; int R, C, tile0, tiles_c; };      // dst[c][r] = src[r][c], 32 x 32 tiles
+struct PackArgs {
+    const float* params;
+    u32x4* pk;
+    int w2_off, w3_off, d1_off, d1_blocks;
+    int pack_wgs;                       // workgroups [0, pack_wgs) pack bf16 pieces, the rest transpose (tr[i].tile0 counts from pack_wgs)
+    PackTr tr[2];
+};
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
+    if ((int)blockIdx.x >= a.pack_wgs) {                            // ---- f32 transposes W1T, W2T (the backward's data gradients) ----
+        __shared__ float tile[32][33];
+        const PackTr& T = a.tr[(int)blockIdx.x >= a.tr[1].tile0 ? 1 : 0];
+        const int tl = (int)blockIdx.x - T.tile0, tr = tl / T.tiles_c, tc = tl - tr * T.tiles_c;
+        const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = tr * 32 + y + 8 * k, c = tc * 32 + x;
+            if (r < T.R && c < T.C) tile[y + 8 * k][x] = T.src[(size_t)r * T.C + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tc * 32 + y + 8 * k, r = tr * 32 + x;
+            if (r < T.R && c < T.C) T.dst[(size_t)c * T.R + r] = tile[x][y + 8 * k];
+        }
+        return;
+    }
+    const float* __restrict__ params = a.params;
+    u32x4* __restrict__ pk = a.pk;
+    const int w2_off = a.w2_off, w3_off = a.w3_off, d1_off = a.d1_off, d1_blocks = a.d1_blocks;
     const int lane = threadIdx.x & 63, blk_id = blockIdx.x * 4 + (threadIdx.x >> 6), j = lane & 15, kb = lane >> 4;
     if (blk_id >= PK_TOTAL_BLOCKS + d1_blocks) return;
     float v[8];
@@ -604,15 +633,37 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     dst[0] = o.h; dst[64] = o.m; dst[128] = o.l;
 }
 
-size_t fused_packed_u32x4(const dq_qnet* Q) { return (size_t)PK_TOTAL_U32X4 + (size_t)(Q->L[Q->cfg.n_conv].nin >> 5) * 32 * PK_BLOCK; }
+static size_t pk_dense1_end(const dq_qnet* Q) { return (size_t)PK_TOTAL_U32X4 + (size_t)(Q->L[Q->cfg.n_conv].nin >> 5) * 32 * PK_BLOCK; }
+size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return pk_dense1_end(Q); }
+size_t fused_packed_w2t_u32x4(const dq_qnet* Q) {
+    const Layer& D1 = Q->L[Q->cfg.n_conv];
+    return fused_packed_w1t_u32x4(Q) + ((size_t)D1.K * D1.N + 3) / 4;
+}
+size_t fused_packed_u32x4(const dq_qnet* Q) {
+    const Layer& D2 = Q->L[Q->cfg.n_conv + 1];
+    return fused_packed_w2t_u32x4(Q) + ((size_t)D2.K * D2.N + 3) / 4;
+}
 
 dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* packed_dev, hipStream_t st) {
     DQ_REQUIRE(Q && params_dev && packed_dev, DQ_ERR_INVALID, "dq_qnet_pack: null argument");
     DQ_REQUIRE(fused_forward_supported(Q), DQ_ERR_UNSUPPORTED, "dq_qnet_pack: the fused chains do not cover this configuration");
-    const Layer& D1 = Q->L[Q->cfg.n_conv];
-    const int d1_blocks = (D1.nin >> 5) * 32;
-    pack_weights_kernel<<<(PK_TOTAL_BLOCKS + d1_blocks + 3) / 4, 256, 0, st>>>(params_dev, static_cast<u32x4*>(packed_dev), (int)Q->L[1].w_off,
-                                                                            (int)Q->L[2].w_off, (int)D1.w_off, d1_blocks);
+    const int nc = Q->cfg.n_conv;
+    const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.params = params_dev; a.pk = static_cast<u32x4*>(packed_dev);
+    a.w2_off = (int)Q->L[1].w_off; a.w3_off = (int)Q->L[2].w_off; a.d1_off = (int)D1.w_off; a.d1_blocks = (D1.nin >> 5) * 32;
+    a.pack_wgs = (PK_TOTAL_BLOCKS + a.d1_blocks + 3) / 4;
+    int tiles = a.pack_wgs;
+    const Layer* Ls[2] = {&D1, &D2};
+    const size_t offs[2] = {fused_packed_w1t_u32x4(Q), fused_packed_w2t_u32x4(Q)};
+    for (int i = 0; i < 2; ++i) {
+        PackTr& T = a.tr[i];
+        T.src = params_dev + Ls[i]->w_off; T.dst = reinterpret_cast<float*>(a.pk + offs[i]);
+        T.R = Ls[i]->K; T.C = Ls[i]->N; T.tile0 = tiles; T.tiles_c = (T.C + 31) / 32;
+        tiles += ((T.R + 31) / 32) * T.tiles_c;
+    }
+    pack_weights_kernel<<<tiles, 256, 0, st>>>(a);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

@@ -15,33 +15,8 @@ DQ_STAMP_READER(dq_dbg_read_bwd)
 
 // The data gradients multiply by W^T.  With W row-major, the 16 lanes of a quarter-wave that supply 16 different output
 // columns of an MFMA B operand would read 16 different rows of W -- 16 cache lines per quarter-wave request, which makes the
-// vector L1's tag path (not the matrix pipe) the bound.  So every backward first writes the transposes of the weights it
-// needs into a workspace (one small launch, ~0.8 MB), and the chains below read those with row-contiguous vector loads:
-//   W1T [512][K1], W2T [N2][512].
-#define TR_MAX_ITEMS 4
-struct TrItem { const float* src; float* dst; int R, C, tile0, tiles_c; };      // dst[c][r] = src[r][c]
-struct TrArgs { TrItem it[TR_MAX_ITEMS]; int n; };
-
-__global__ __launch_bounds__(256) void transpose_weights_kernel(TrArgs a) {
-    __shared__ float tile[32][33];
-    int i = 0;
-    while (i + 1 < a.n && (int)blockIdx.x >= a.it[i + 1].tile0) ++i;            // block-uniform
-    const TrItem& T = a.it[i];
-    const int tl = (int)blockIdx.x - T.tile0, tr = tl / T.tiles_c, tc = tl - tr * T.tiles_c;
-    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = tr * 32 + y + 8 * k, c = tc * 32 + x;
-        if (r < T.R && c < T.C) tile[y + 8 * k][x] = T.src[(size_t)r * T.C + c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = tc * 32 + y + 8 * k, r = tr * 32 + x;
-        if (r < T.R && c < T.C) T.dst[(size_t)c * T.R + r] = tile[x][y + 8 * k];
-    }
-}
-
+// vector L1's tag path (not the matrix pipe) the bound.  So dq_qnet_pack also writes the f32 transposes W1T [512][K1] and
+// W2T [N2][512] behind the bf16 pieces (same launch), and the chains below read those with row-contiguous vector loads.
 struct DenseBwdArgs {
     const float* params;
     const float* w1t;                   // [512][K1] transposed hidden-layer kernel
@@ -866,16 +841,10 @@ bool fused_backward_supported(const dq_qnet* Q) {
     return fused_forward_supported(Q) && plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp);
 }
 
-// transposed weights: W1T, W2T
-static size_t transposed_floats(const dq_qnet* Q) {
-    const int nc = Q->cfg.n_conv;
-    return (size_t)Q->L[nc].K * Q->L[nc].N + (size_t)Q->L[nc + 1].K * Q->L[nc + 1].N;
-}
-
 // floats of workspace the fused backward needs: [DENSE_WGRAD_SLICES][n_params] dense partials, then [CONV_BWD_MAX_WGS][conv params]
 size_t fused_backward_workspace_floats(const dq_qnet* Q) {
     if (!fused_backward_supported(Q)) return 0;
-    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + transposed_floats(Q);
+    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off;
 }
 
 typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
@@ -902,26 +871,13 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
     float* dense_partial = Q->fpartial;
     float* conv_partial = dense_partial + (size_t)DENSE_WGRAD_SLICES * Q->n_params;
-    float* w1t = conv_partial + (size_t)CONV_BWD_MAX_WGS * D1.w_off;
-    float* w2t = w1t + (size_t)D1.K * D1.N;
+    DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
+    const u32x4* pkbase = static_cast<const u32x4*>(Q->last_train_packed);
+    const float* w1t = reinterpret_cast<const float*>(pkbase + fused_packed_w1t_u32x4(Q));       // transposed by dq_qnet_pack
+    const float* w2t = reinterpret_cast<const float*>(pkbase + fused_packed_w2t_u32x4(Q));
     const size_t conv_floats = D1.w_off;
     const int n_dense = (int)(Q->n_params - conv_floats);
     if (phases & 1) {
-    {
-        TrArgs ta;
-        memset(&ta, 0, sizeof(ta));
-        int n = 0, tiles = 0;
-        auto add = [&](const float* src, float* dst, int R, int C) {
-            TrItem& T = ta.it[n++];
-            T.src = src; T.dst = dst; T.R = R; T.C = C; T.tile0 = tiles; T.tiles_c = (C + 31) / 32;
-            tiles += ((R + 31) / 32) * T.tiles_c;
-        };
-        add(params_dev + D1.w_off, w1t, D1.K, D1.N);
-        add(params_dev + D2.w_off, w2t, D2.K, D2.N);
-        ta.n = n;
-        transpose_weights_kernel<<<tiles, 256, 0, st>>>(ta);
-        DQ_LAUNCH_CHECK();
-    }
     // ---- 1. dense data gradients ----------------------------------------------------------------------------------
     DenseBwdArgs da;
     memset(&da, 0, sizeof(da));

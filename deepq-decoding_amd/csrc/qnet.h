@@ -112,7 +112,8 @@ __device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32
 #define PK_CONV3_DG (PK_CONV3_FWD + 8 * PK_BLOCK)
 #define PK_CONV2_DG (PK_CONV3_DG + 8 * PK_BLOCK)
 #define PK_TOTAL_BLOCKS 48
-#define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)     // the conv sections; then PK_DENSE1 [K1/32 k-blocks][32 column tiles]:
+#define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)     // the conv sections; then PK_DENSE1 [K1/32 k-blocks][32 column tiles];
+// then (f32, for the backward's data gradients) W1T [512][K1] and W2T [N2][512], each section 16-byte aligned:
 //   B(k = 32 blk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3)) = W1[k][col]
 size_t fused_packed_u32x4(const dq_qnet* Q);
 dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* packed_dev, hipStream_t st);
@@ -126,4 +127,6 @@ dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_
 // fused_bwd.hip: fused backward (data-gradient chains + all-layer weight gradients) for the same configurations
 bool fused_backward_supported(const dq_qnet* Q);
 size_t fused_backward_workspace_floats(const dq_qnet* Q);
+size_t fused_packed_w1t_u32x4(const dq_qnet* Q);           // u32x4 offset of W1T inside a packed buffer
+size_t fused_packed_w2t_u32x4(const dq_qnet* Q);           // ... of W2T
 dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st);
