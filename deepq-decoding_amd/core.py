@@ -160,9 +160,9 @@ class DQNCore:
             _dist.allreduce_sum_(self.grads[:nconv], group=self.pg)
             if work is not None:
                 work.wait()
+            _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
         else:
-            net.backward(self.params, self.dq, grads=self.grads)
-        _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+            net.backward_adam(self.params, self.dq, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
         self.repack()
 
     def read_metrics(self):

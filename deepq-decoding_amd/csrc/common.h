@@ -102,6 +102,16 @@ __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
     return base + __ffsll((long long)m) - 1;
 }
 
+// Keras 2.2 Adam.get_updates for one parameter: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps).
+// One definition for adam_kernel (dqn.hip) and the fused backward's final reduction (fused_bwd.hip): the two give the same bits.
+// (No multiply-add contraction inside: whether hipcc fuses depends on the surrounding code, and the bits must not.)
+__device__ __forceinline__ void dq_adam1(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
+#pragma clang fp contract(off)
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p = p - lr_t * m / (sqrtf(v) + eps);
+}
+
 // ---- optional phase timestamps (development aid): build with DQ_EXTRA_FLAGS="-DDQ_STAMPS=<kernel tag>" and read them back with
 // tools/stamp_run.py.  Workgroup DQ_STAMP_BLOCK, lane 0 of every wave, records the shader cycle counter at phase boundaries.
 #define DQ_TAG_CONV_FWD 1

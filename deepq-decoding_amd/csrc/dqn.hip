@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void td_metrics_kernel(float* __restrict__ met
     if (threadIdx.x == 0) { metrics[0] = s_loss[0] / (float)B; metrics[1] = s_q[0] / (float)B; }
 }
 
-// Keras 2.2 Adam.get_updates: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps)
+// Keras 2.2 Adam.get_updates (common.h dq_adam1)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             size_t n, float lr_t, float b1, float b2, float eps) {
     const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -164,22 +164,18 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         float4 pp = *reinterpret_cast<float4*>(p + i4);
         const float4 gg = *reinterpret_cast<const float4*>(g + i4);
         float4 mm = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
-#define ADAM1(c)                                   \
-        mm.c = b1 * mm.c + (1.f - b1) * gg.c;      \
-        vv.c = b2 * vv.c + (1.f - b2) * gg.c * gg.c; \
-        pp.c = pp.c - lr_t * mm.c / (sqrtf(vv.c) + eps);
-        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
-#undef ADAM1
+        dq_adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
+        dq_adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
+        dq_adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);
+        dq_adam1(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps);
         *reinterpret_cast<float4*>(p + i4) = pp;
         *reinterpret_cast<float4*>(m + i4) = mm;
         *reinterpret_cast<float4*>(v + i4) = vv;
     } else {
         for (size_t i = i4; i < n && i < i4 + 4; ++i) {
-            const float gi = g[i];
-            const float mi = b1 * m[i] + (1.f - b1) * gi;
-            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-            m[i] = mi; v[i] = vi;
-            p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+            float pi = p[i], mi = m[i], vi = v[i];
+            dq_adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
+            p[i] = pi; m[i] = mi; v[i] = vi;
         }
     }
 }

@@ -356,8 +356,8 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
 // Fixed-order reduction of both partial sets in one launch: out[i] = sum_s partial[s * stride + i].
 // Block = 64 outputs x 8 slice groups (thread (x, g) sums slices g, g+8, ... in order; the 8 group sums are combined
 // pairwise in LDS) -- deterministic, and 8x the loads in flight of a one-thread-per-output loop.
-struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; };
-struct ReduceArgs { ReduceSeg seg[2]; };
+struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; int pidx0; };   // pidx0: flat index of out[0]
+struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; };
 
 __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __shared__ float sh[8][64];
@@ -376,7 +376,14 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __syncthreads();
     if (g == 0 && i < S.n) {
         const int x = threadIdx.x;
-        S.out[i] = ((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x])) + ((sh[4][x] + sh[5][x]) + (sh[6][x] + sh[7][x]));
+        const float gsum = ((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x])) + ((sh[4][x] + sh[5][x]) + (sh[6][x] + sh[7][x]));
+        S.out[i] = gsum;
+        if (a.adam) {                                               // the optimizer step rides on the reduction (dq_qnet_backward_adam)
+            const size_t k = (size_t)S.pidx0 + i;
+            float pk = a.opt.p[k], mk = a.opt.m[k], vk = a.opt.v[k];
+            dq_adam1(pk, gsum, mk, vk, a.opt.lr_t, a.opt.b1, a.opt.b2, a.opt.eps);
+            a.opt.p[k] = pk; a.opt.m[k] = mk; a.opt.v[k] = vk;
+        }
     }
 }
 
@@ -851,7 +858,9 @@ typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
 
 // phases: bit 0 = dense part (data gradients, dense weight gradients reduced into grads_dev[conv params ..)), bit 1 = convolutional
 // part (grads_dev[0 .. conv params)).  3 = whole backward with one reduction launch.
-dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st) {
+dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st,
+                         const AdamOpt* opt) {
+    DQ_REQUIRE(!opt || phases == 3, DQ_ERR_INVALID, "fused_backward: the fused optimizer step needs the whole backward in one call");
     DenseBwdPlan dp;
     ConvBwdPlan cp;
     DQ_REQUIRE(plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp), DQ_ERR_UNSUPPORTED, "fused_backward: configuration not covered");
@@ -922,7 +931,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
 
     if (phases != 3) {                                              // phased: the dense gradients are complete (and reducible) now
         ReduceArgs ra;
-        ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, 0};
+        memset(&ra, 0, sizeof(ra));
+        ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, 0, (int)conv_floats};
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
         reduce_slices_kernel<<<(n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
         DQ_LAUNCH_CHECK();
@@ -954,13 +964,15 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
 
     // ---- 4. fixed-order reductions of the partials into the flat gradient ------------------------------------------------
     ReduceArgs ra;
-    ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0};
+    memset(&ra, 0, sizeof(ra));
+    if (opt) { ra.opt = *opt; ra.adam = 1; }
+    ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0, 0};
     const int blocks0 = ((int)conv_floats + 63) / 64;
     if (phases == 3) {
         int rpw = (B + DENSE_WGRAD_SLICES * WGRAD_WAVES - 1) / (DENSE_WGRAD_SLICES * WGRAD_WAVES);
         rpw = (rpw + 7) & ~7;
         const int sy = (B + rpw * WGRAD_WAVES - 1) / (rpw * WGRAD_WAVES);
-        ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, blocks0};
+        ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, blocks0, (int)conv_floats};
         reduce_slices_kernel<<<blocks0 + (n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
     } else {
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;

@@ -129,4 +129,7 @@ bool fused_backward_supported(const dq_qnet* Q);
 size_t fused_backward_workspace_floats(const dq_qnet* Q);
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q);           // u32x4 offset of W1T inside a packed buffer
 size_t fused_packed_w2t_u32x4(const dq_qnet* Q);           // ... of W2T
-dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st);
+// opt != NULL (phases == 3 only): the final reduction also applies the Adam update to p/m/v (one launch fewer per update)
+struct AdamOpt { float* p; float* m; float* v; float lr_t, b1, b2, eps; };
+dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st,
+                         const AdamOpt* opt = nullptr);

@@ -588,4 +588,21 @@ dq_status dq_qnet_backward_phase(dq_qnet* Q, const float* params_dev, const floa
 
 size_t dq_qnet_conv_param_count(const dq_qnet* Q) { return Q ? Q->L[Q->cfg.n_conv].w_off : 0; }
 
+dq_status dq_qnet_backward_adam(dq_qnet* Q, float* params_dev, const float* dq_dev, float* grads_dev, float* m_dev, float* v_dev, double lr,
+                                double beta_1, double beta_2, double epsilon, uint64_t t, void* stream) {
+    DQ_REQUIRE(Q && params_dev && dq_dev && grads_dev && m_dev && v_dev, DQ_ERR_INVALID, "dq_qnet_backward_adam: null argument");
+    DQ_REQUIRE(t >= 1, DQ_ERR_INVALID, "dq_qnet_backward_adam: t counts from 1");
+    DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_backward_adam: no training forward to differentiate");
+    if (Q->use_fused && fused_backward_supported(Q)) {
+        AdamOpt opt;
+        opt.p = params_dev; opt.m = m_dev; opt.v = v_dev;
+        opt.lr_t = (float)(lr * sqrt(1.0 - pow(beta_2, (double)t)) / (1.0 - pow(beta_1, (double)t)));      // as dq_adam_step
+        opt.b1 = (float)beta_1; opt.b2 = (float)beta_2; opt.eps = (float)epsilon;
+        return fused_backward(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream, &opt);
+    }
+    dq_status rc = backward_phases(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream);
+    if (rc != DQ_OK) return rc;
+    return dq_adam_step(params_dev, grads_dev, m_dev, v_dev, Q->n_params, lr, beta_1, beta_2, epsilon, t, stream);
+}
+
 }  // extern "C"

@@ -190,6 +190,16 @@ def _backward_phase(self, params, dq, grads, phase):
 QNetwork.backward_phase = _backward_phase
 
 
+def _backward_adam(self, params, dq, grads, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    """backward() + adam_step() with the optimizer step applied by the backward's last launch (single-process training)."""
+    check(self.L.dq_qnet_backward_adam(self._h, ptr(params), ptr(dq), ptr(grads), ptr(m), ptr(v), float(lr), float(beta_1), float(beta_2),
+                                       float(epsilon), int(t), self._stream()))
+    return grads
+
+
+QNetwork.backward_adam = _backward_adam
+
+
 def td_target(q_online_s1, q_target_s1, reward, terminal, gamma, index=None, out=None):
     B, A = q_online_s1.shape
     if out is None:

@@ -248,6 +248,12 @@ dq_status dq_qnet_backward_phase(dq_qnet* net, const float* params_dev, const fl
                                  void* stream);
 size_t dq_qnet_conv_param_count(const dq_qnet* net);
 
+/* dq_qnet_backward followed by dq_adam_step on the whole parameter vector, with the optimizer step applied by the backward's
+ * final reduction launch (one launch fewer; same bits as the two separate calls).  Single-process training only: with several
+ * ranks the gradient has to be all-reduced between the two.  grads_dev still receives the gradient. */
+dq_status dq_qnet_backward_adam(dq_qnet* net, float* params_dev, const float* dq_dev, float* grads_dev, float* m_dev, float* v_dev,
+                                double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DQN update: replaces SequentialMemory.sample + DQNAgent.backward + keras Adam of the keras-rl fork
  * (Single_Point_Training_Script.py:109,119-130).

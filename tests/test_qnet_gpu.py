@@ -159,6 +159,30 @@ def test_backward_in_two_phases_equals_one_call(dq, torch_mod, fused):
     assert np.array_equal(g.cpu().numpy(), g_ref)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
+def test_backward_adam_equals_backward_then_adam(dq, torch_mod, fused):
+    """dq_qnet_backward_adam (optimizer step applied by the backward's last launch) == dq_qnet_backward + dq_adam_step, bit for bit:
+    gradient, parameters and both moment vectors, over three consecutive updates."""
+    torch = torch_mod
+    from importlib import import_module
+    Q = import_module("deepq-decoding_amd.qnet")
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 100, fused=fused)
+    obs_t = torch.from_numpy(obs).cuda()
+    dq_ = torch.from_numpy((rng.randn(100, 51) / 100).astype(np.float32)).cuda()
+    pa, pb = params.clone(), params.clone()
+    ma, va, mb, vb = (torch.zeros_like(params) for _ in range(4))
+    ga = torch.empty_like(params)
+    for t in (1, 2, 3):
+        net.forward(pa, obs_t, training=True, seed=(1, 2), t=t)
+        gb = net.backward(pb, dq_)
+        Q.adam_step(pb, gb, mb, vb, t, 1e-3)
+        net.forward(pa, obs_t, training=True, seed=(1, 2), t=t)
+        net.backward_adam(pa, dq_, ga, ma, va, t, 1e-3)
+        for x, y in ((ga, gb), (pa, pb), (ma, mb), (va, vb)):
+            assert torch.equal(x, y)
+    assert not torch.equal(pa, params)
+
+
 def test_fused_and_per_layer_paths_agree(dq, torch_mod):
     """The two HIP forward/backward implementations order their dot products differently: same results to f32 round-off."""
     torch = torch_mod
