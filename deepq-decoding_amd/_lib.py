@@ -44,6 +44,13 @@ class QNetJob(ctypes.Structure):
                 ("q_dev", ctypes.c_void_p), ("packed_dev", ctypes.c_void_p)]
 
 
+class SampleJob(ctypes.Structure):
+    """dq_sample_job (include/deepq_hip.h)."""
+    _fields_ = [("terminal_ring_dev", ctypes.c_void_p), ("n_slots", ctypes.c_int32), ("head_slot", ctypes.c_int32),
+                ("filled_slots", ctypes.c_int32), ("batch", ctypes.c_int32), ("seed", ctypes.c_uint32 * 2), ("t", ctypes.c_uint64),
+                ("sample_base", ctypes.c_uint32), ("index_dev", ctypes.c_void_p)]
+
+
 _vp, _i, _u32, _u64, _dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
 _sz = ctypes.c_size_t
 _seedp = ctypes.POINTER(ctypes.c_uint32)
@@ -63,6 +70,7 @@ SIGNATURES = {
     "dq_env_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_act_step": (_i, [_vp, _vp, _dbl, _i, _seedp, _u64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dq_env_act_step_sample": (_i, [_vp, _vp, _dbl, _i, _seedp, _u64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(SampleJob), _vp]),
     "dq_env_export_state": (_i, [_vp, _vp, _vp]),
     "dq_env_import_state": (_i, [_vp, _vp, _vp]),
     "dq_env_get_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
@@ -88,6 +96,7 @@ SIGNATURES = {
     "dq_td_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _vp, _vp, _vp]),
     "dq_episode_stats": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dq_td_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _dbl, _vp, _vp, _vp, _vp]),
+    "dq_td_update_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dq_td_metrics": (_i, [_vp, _i, _vp]),
     "dq_post_step": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dq_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),

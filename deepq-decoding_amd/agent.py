@@ -373,6 +373,11 @@ class DQNAgent:
         return self._net.forward(self._core.params, obs, batch=1)[0].cpu().numpy()
 
     # -- training ------------------------------------------------------------------------------------------------
+    def _will_train(self, step_after):
+        """Whether _maybe_train() will update once self.step has become step_after (the ring then holds one more slot)."""
+        core = self._core
+        return step_after > self.nb_steps_warmup and min(core.T, core.filled + 1) >= 2 and (step_after // core.N) % self.train_interval == 0
+
     def _maybe_train(self):
         core = self._core
         did = False
@@ -414,7 +419,7 @@ class DQNAgent:
         try:
             while self.step - start_step < nb_steps and not stop:
                 eps, masked = self.policy.current(True)
-                core.act_and_step(eps, masked_greedy=masked)
+                core.act_and_step(eps, masked_greedy=masked, presample=self._will_train(self.step + N))
                 self.step += N
                 trained = self._maybe_train()
                 epss.append(eps)

@@ -120,7 +120,7 @@ class FullLoop:
             _lib.check(self.L.dq_prof_arm(self._family_id(self.prof_family), steps * per_step + 8))
 
     def step(self, timed):
-        self.core.act_and_step(self.eps)
+        self.core.act_and_step(self.eps, presample=True)
         self.core.update()
         if self.core.updates % self.target_every == 0:
             self.core.update_target_hard()

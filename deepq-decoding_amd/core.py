@@ -69,6 +69,7 @@ class DQNCore:
         self.metrics = torch.zeros(_q.TD_METRICS_FLOATS, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(4, dtype=torch.int64, device=dev)
         self._stats_pending = None   # episode bookkeeping not yet launched (slot,)
+        self._presampled = 0
         self.defer_stats = True      # act_and_step leaves the bookkeeping launch to the next update() (dq_post_step) / act / read_stats
         self._metrics_stale = False
         self.vector_steps = 0        # policy / environment counter
@@ -90,9 +91,10 @@ class DQNCore:
         self.filled = max(self.filled, 1)
         self.started = True
 
-    def act_and_step(self, eps, masked_greedy=False, use_q=True, record_stats=True):
+    def act_and_step(self, eps, masked_greedy=False, use_q=True, record_stats=True, presample=False):
         """One vector step: Q forward on the current observations, epsilon-greedy over the legal set, environment
-        step with auto-reset; the transition is recorded in the ring by construction."""
+        step with auto-reset; the transition is recorded in the ring by construction.  presample=True when update() follows this
+        step: its replay sampling then rides on the environment launch (the rule never reads the slot this step writes)."""
         self._flush_stats()          # bookkeeping of the previous step, if no update() took it along (env buffers are about to be reused)
         env, cur = self.env, self.cur
         nxt = cur + 1 if cur + 1 < self.T else 0
@@ -102,16 +104,26 @@ class DQNCore:
             q = self.net.forward(self.params, obs, batch=self.N, out=self.q_act, packed=self.params_pk)
         # action selection + environment step in one launch (dq_env_act_step == dq_policy_select then dq_env_step)
         seed = (ctypes.c_uint32 * 2)(*env.seed)
-        check(self.L.dq_env_act_step(env._h, ptr(q), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
-                                     ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
-                                     ptr(env.lifetime), ptr(env.was_reset), self._stream()))
-        # episode bookkeeping of this step: launched together with the next update's replay sampling (dq_post_step) when an update
-        # follows, else on its own
+        args = (env._h, ptr(q), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
+                ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
+                ptr(env.lifetime), ptr(env.was_reset))
+        filled = min(self.T, self.filled + 1)
+        if presample and filled >= 2:
+            sj = _lib.SampleJob()
+            sj.terminal_ring_dev, sj.n_slots, sj.head_slot, sj.filled_slots, sj.batch = ptr(self.terminal_ring), self.T, nxt, filled, self.batch_size
+            sj.seed[0], sj.seed[1] = int(self.seed[0]) & 0xFFFFFFFF, int(self.seed[1]) & 0xFFFFFFFF
+            sj.t, sj.sample_base, sj.index_dev = self.updates + 1, _dist.shard(self.rank, self.N, self.batch_size)[1], ptr(self.index)
+            check(self.L.dq_env_act_step_sample(*args, ctypes.byref(sj), self._stream()))
+            self._presampled = self.updates + 1
+        else:
+            check(self.L.dq_env_act_step(*args, self._stream()))
+        # episode bookkeeping of this step: rides on the next update's TD launch (dq_td_update_stats) when an update follows, else
+        # launched on its own
         self._stats_pending = (cur,) if record_stats else None
         if record_stats and not self.defer_stats:
             self._flush_stats()
         self.cur = nxt
-        self.filled = min(self.T, self.filled + 1)
+        self.filled = filled
         self.vector_steps += 1
 
     def _flush_stats(self):
@@ -129,13 +141,7 @@ class DQNCore:
         t = self.updates
         _, sample_base = _dist.shard(self.rank, N, B)
         rows = T * N
-        if self._stats_pending is not None:          # replay sampling + the pending episode bookkeeping in one launch
-            (slot,), env = self._stats_pending, self.env
-            check(self.L.dq_post_step(ptr(self.terminal_ring), N, T, self.cur, self.filled, B, _q._seed_arr(self.seed), t, sample_base,
-                                      ptr(self.index), ptr(self.terminal_ring[slot]), ptr(env.was_reset), ptr(env.lifetime),
-                                      ptr(self.reward_ring[slot]), N, ptr(self.stats), self._stream()))
-            self._stats_pending = None
-        else:
+        if self._presampled != t:                    # (else act_and_step(presample=True) already drew this update's minibatch)
             _q.replay_sample(self.terminal_ring, N, T, self.cur, self.filled, B, self.seed, t, sample_base=sample_base, out=self.index)
         net, ring = self.net, self.obs_ring
         # Q_online(s1) picks the action, Q_target(s1) values it (double DQN; without it Q_target does both); the training forward
@@ -148,8 +154,14 @@ class DQNCore:
                          out=self.q0, packed=self.params_pk))
         net.forward_multi(jobs)
         q_sel = self.q1_online if self.enable_double_dqn else self.q1_target
+        step_stats = None
+        if self._stats_pending is not None:          # the pending episode bookkeeping rides on the TD launch
+            (slot,), env = self._stats_pending, self.env
+            step_stats = (self.terminal_ring[slot], env.was_reset, env.lifetime, self.reward_ring[slot], N, self.stats)
+            self._stats_pending = None
         _q.td_update(q_sel, self.q1_target, self.q0, self.reward_ring, self.terminal_ring, self.action_ring, self.gamma,
-                     grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, y=self.y, dq=self.dq, metrics=self.metrics)
+                     grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, y=self.y, dq=self.dq, metrics=self.metrics,
+                     step_stats=step_stats)
         self._metrics_stale = True
         if self.world_size > 1:
             # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs

@@ -102,6 +102,46 @@ __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
     return base + __ffsll((long long)m) - 1;
 }
 
+// Replay row of minibatch sample `sample_id` of update t (the rule of dqn.hip's replay_sample_kernel; shared by every launch
+// that carries the sampling along).
+__device__ __forceinline__ int dq_replay_row(const u8* __restrict__ terminal, int n_envs, int n_slots, int head_slot, int filled,
+                                             u32 seed0, u32 seed1, u64 t, u32 sample_id) {
+    const int cand = filled - 1;                        // slots that already have a successor
+    int row = 0;
+    for (u32 attempt = 0; attempt < 64; ++attempt) {
+        u32 w[4];
+        philox4x32_10((u32)t, (u32)(t >> 32), sample_id, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
+        const int j = (int)__umulhi(w[0], (u32)cand);   // 0 = newest complete transition
+        const int env = (int)__umulhi(w[1], (u32)n_envs);
+        int slot = head_slot - 1 - j;
+        if (slot < 0) slot += n_slots;
+        row = slot * n_envs + env;
+        if (j + 1 >= cand) break;                       // oldest stored slot: predecessor unknown -> accepted (keras-rl idx < 2)
+        int prev = slot - 1;
+        if (prev < 0) prev += n_slots;
+        if (!terminal[(size_t)prev * n_envs + env]) break;
+    }
+    return row;
+}
+
+// Episode bookkeeping of lattice i (one thread per lattice, whole waves): stats[0] += #episodes that ended this step, stats[1] +=
+// sum of their lifetimes, stats[2] += #rewards == 1, stats[3] += #lattices stepped (not reset).  Integer atomics => order-independent.
+__device__ __forceinline__ void dq_episode_stats_lane(const u8* __restrict__ done, const u8* __restrict__ was_reset,
+                                                      const u32* __restrict__ lifetime, const float* __restrict__ reward, int n, int i,
+                                                      unsigned long long* __restrict__ stats) {
+    const bool in = i < n;
+    const bool stepped = in && !(was_reset && was_reset[i]);
+    const bool ended = stepped && done[i];
+    const u64 m_end = __ballot(ended), m_rew = __ballot(stepped && reward[i] > 0.5f), m_step = __ballot(stepped);
+    unsigned long long life = ended ? lifetime[i] : 0;
+    for (int m = 32; m >= 1; m >>= 1) life += __shfl_xor(life, m);
+    if ((threadIdx.x & 63) == 0) {
+        if (m_end) { atomicAdd(&stats[0], (unsigned long long)__popcll(m_end)); atomicAdd(&stats[1], life); }
+        if (m_rew) atomicAdd(&stats[2], (unsigned long long)__popcll(m_rew));
+        if (m_step) atomicAdd(&stats[3], (unsigned long long)__popcll(m_step));
+    }
+}
+
 // Keras 2.2 Adam.get_updates for one parameter: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m / (sqrt(v) + eps).
 // One definition for adam_kernel (dqn.hip) and the fused backward's final reduction (fused_bwd.hip): the two give the same bits.
 // (No multiply-add contraction inside: whether hipcc fuses depends on the surrounding code, and the bits must not.)

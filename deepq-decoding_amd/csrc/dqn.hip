@@ -16,21 +16,7 @@ __global__ void replay_sample_kernel(const u8* __restrict__ terminal, int n_envs
                                      int batch, u32 seed0, u32 seed1, u64 t, u32 sample_base, int32_t* __restrict__ index) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    const int cand = filled - 1;                        // slots that already have a successor
-    int row = 0;
-    for (u32 attempt = 0; attempt < 64; ++attempt) {
-        u32 w[4];
-        philox4x32_10((u32)t, (u32)(t >> 32), sample_base + (u32)b, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
-        const int j = (int)__umulhi(w[0], (u32)cand);   // 0 = newest complete transition
-        const int env = (int)__umulhi(w[1], (u32)n_envs);
-        int slot = head_slot - 1 - j;
-        if (slot < 0) slot += n_slots;
-        row = slot * n_envs + env;
-        if (j + 1 >= cand) break;                       // oldest stored slot: predecessor unknown -> accepted (keras-rl idx < 2)
-        int prev = slot - 1;
-        if (prev < 0) prev += n_slots;
-        if (!terminal[(size_t)prev * n_envs + env]) break;
-    }
+    const int row = dq_replay_row(terminal, n_envs, n_slots, head_slot, filled, seed0, seed1, t, sample_base + (u32)b);
     index[b] = row;
 }
 
@@ -92,6 +78,8 @@ __global__ __launch_bounds__(256) void td_loss_grad_kernel(const float* __restri
     }
 }
 
+struct TdStats { const u8* done; const u8* was_reset; const u32* lifetime; const float* reward; int n; unsigned long long* stats; };
+
 // The whole TD step of one update in one launch (one wave per sample): double-DQN target from Q_online(s1) / Q_target(s1), then the
 // masked squared-error loss and its gradient on Q(s0).  Same arithmetic and the same per-block metric partials as
 // td_target_kernel + td_loss_grad_kernel; y is also written (nullable) for tests / logging.
@@ -99,11 +87,17 @@ __global__ __launch_bounds__(256) void td_update_kernel(const float* __restrict_
                                                         const float* __restrict__ q, const float* __restrict__ reward,
                                                         const u8* __restrict__ terminal, const int32_t* __restrict__ action,
                                                         const int32_t* __restrict__ index, float gamma, int B, int A, float grad_scale,
-                                                        float* __restrict__ y_out, float* __restrict__ dq, float* __restrict__ metrics) {
+                                                        float* __restrict__ y_out, float* __restrict__ dq, float* __restrict__ metrics,
+                                                        int td_blocks, TdStats st) {
+    if ((int)blockIdx.x >= td_blocks) {                             // the episode bookkeeping of the step just taken rides along
+        dq_episode_stats_lane(st.done, st.was_reset, st.lifetime, st.reward, st.n, ((int)blockIdx.x - td_blocks) * blockDim.x + threadIdx.x,
+                              st.stats);
+        return;
+    }
     __shared__ float s_loss[4], s_q[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float loss = 0.f, mq = 0.f;
-    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    for (int b = blockIdx.x * 4 + wave; b < B; b += td_blocks * 4) {
         const float* row1 = q_online + (size_t)b * A;
         float best = -INFINITY;
         int best_a = 0x7fffffff;
@@ -184,18 +178,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // stats[3] += #lattices stepped (not reset).  Integer atomics => order-independent result.
 __global__ void episode_stats_kernel(const u8* __restrict__ done, const u8* __restrict__ was_reset, const u32* __restrict__ lifetime,
                                      const float* __restrict__ reward, int n, unsigned long long* __restrict__ stats) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < n;
-    const bool stepped = in && !(was_reset && was_reset[i]);
-    const bool ended = stepped && done[i];
-    const u64 m_end = __ballot(ended), m_rew = __ballot(stepped && reward[i] > 0.5f), m_step = __ballot(stepped);
-    unsigned long long life = ended ? lifetime[i] : 0;
-    for (int m = 32; m >= 1; m >>= 1) life += __shfl_xor(life, m);
-    if ((threadIdx.x & 63) == 0) {
-        if (m_end) { atomicAdd(&stats[0], (unsigned long long)__popcll(m_end)); atomicAdd(&stats[1], life); }
-        if (m_rew) atomicAdd(&stats[2], (unsigned long long)__popcll(m_rew));
-        if (m_step) atomicAdd(&stats[3], (unsigned long long)__popcll(m_step));
-    }
+    dq_episode_stats_lane(done, was_reset, lifetime, reward, n, blockIdx.x * blockDim.x + threadIdx.x, stats);
 }
 
 // Replay sampling for the next update and the episode bookkeeping of the step just taken, in one launch: blocks
@@ -207,37 +190,10 @@ __global__ __launch_bounds__(256) void post_step_kernel(const u8* __restrict__ t
                                                         unsigned long long* __restrict__ stats) {
     if ((int)blockIdx.x < sample_blocks) {
         const int b = blockIdx.x * blockDim.x + threadIdx.x;
-        if (b >= batch) return;
-        const int cand = filled - 1;
-        int row = 0;
-        for (u32 attempt = 0; attempt < 64; ++attempt) {
-            u32 w[4];
-            philox4x32_10((u32)t, (u32)(t >> 32), sample_base + (u32)b, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
-            const int j = (int)__umulhi(w[0], (u32)cand);
-            const int env = (int)__umulhi(w[1], (u32)n_envs);
-            int slot = head_slot - 1 - j;
-            if (slot < 0) slot += n_slots;
-            row = slot * n_envs + env;
-            if (j + 1 >= cand) break;
-            int prev = slot - 1;
-            if (prev < 0) prev += n_slots;
-            if (!terminal[(size_t)prev * n_envs + env]) break;
-        }
-        index[b] = row;
+        if (b < batch) index[b] = dq_replay_row(terminal, n_envs, n_slots, head_slot, filled, seed0, seed1, t, sample_base + (u32)b);
         return;
     }
-    const int i = ((int)blockIdx.x - sample_blocks) * blockDim.x + threadIdx.x;
-    const bool in = i < n;
-    const bool stepped = in && !(was_reset && was_reset[i]);
-    const bool ended = stepped && done[i];
-    const u64 m_end = __ballot(ended), m_rew = __ballot(stepped && reward[i] > 0.5f), m_step = __ballot(stepped);
-    unsigned long long life = ended ? lifetime[i] : 0;
-    for (int m = 32; m >= 1; m >>= 1) life += __shfl_xor(life, m);
-    if ((threadIdx.x & 63) == 0) {
-        if (m_end) { atomicAdd(&stats[0], (unsigned long long)__popcll(m_end)); atomicAdd(&stats[1], life); }
-        if (m_rew) atomicAdd(&stats[2], (unsigned long long)__popcll(m_rew));
-        if (m_step) atomicAdd(&stats[3], (unsigned long long)__popcll(m_step));
-    }
+    dq_episode_stats_lane(done, was_reset, lifetime, reward, n, ((int)blockIdx.x - sample_blocks) * blockDim.x + threadIdx.x, stats);
 }
 
 extern "C" {
@@ -259,19 +215,42 @@ dq_status dq_post_step(const uint8_t* terminal_ring_dev, int n_envs, int n_slots
     return DQ_OK;
 }
 
-dq_status dq_td_update(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* q_s0_dev, const float* reward_dev,
-                       const uint8_t* terminal_dev, const int32_t* action_dev, const int32_t* index_dev, double gamma, int batch, int n_actions,
-                       double grad_scale, float* y_dev, float* dq_dev, float* metrics_dev, void* stream) {
+static dq_status launch_td_update(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* q_s0_dev, const float* reward_dev,
+                                  const uint8_t* terminal_dev, const int32_t* action_dev, const int32_t* index_dev, double gamma, int batch,
+                                  int n_actions, double grad_scale, float* y_dev, float* dq_dev, float* metrics_dev, const TdStats& ts,
+                                  void* stream) {
     DQ_REQUIRE(q_online_s1_dev && q_target_s1_dev && q_s0_dev && reward_dev && terminal_dev && action_dev && dq_dev, DQ_ERR_INVALID,
                "dq_td_update: null argument");
     DQ_REQUIRE(batch >= 1 && n_actions >= 1, DQ_ERR_INVALID, "dq_td_update: bad sizes");
     const int blocks = (batch + 3) / 4 < TD_MAX_BLOCKS ? (batch + 3) / 4 : TD_MAX_BLOCKS;
+    const int stat_blocks = ts.n > 0 ? (ts.n + 255) / 256 : 0;
     dq_prof_begin(DQ_K_TD, (hipStream_t)stream);
-    td_update_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(q_online_s1_dev, q_target_s1_dev, q_s0_dev, reward_dev, terminal_dev, action_dev,
-                                                              index_dev, (float)gamma, batch, n_actions, (float)grad_scale, y_dev, dq_dev, metrics_dev);
+    td_update_kernel<<<blocks + stat_blocks, 256, 0, (hipStream_t)stream>>>(q_online_s1_dev, q_target_s1_dev, q_s0_dev, reward_dev, terminal_dev,
+                                                                            action_dev, index_dev, (float)gamma, batch, n_actions,
+                                                                            (float)grad_scale, y_dev, dq_dev, metrics_dev, blocks, ts);
     dq_prof_end(DQ_K_TD, (hipStream_t)stream);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
+}
+
+dq_status dq_td_update(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* q_s0_dev, const float* reward_dev,
+                       const uint8_t* terminal_dev, const int32_t* action_dev, const int32_t* index_dev, double gamma, int batch, int n_actions,
+                       double grad_scale, float* y_dev, float* dq_dev, float* metrics_dev, void* stream) {
+    TdStats ts;
+    memset(&ts, 0, sizeof(ts));
+    return launch_td_update(q_online_s1_dev, q_target_s1_dev, q_s0_dev, reward_dev, terminal_dev, action_dev, index_dev, gamma, batch, n_actions,
+                            grad_scale, y_dev, dq_dev, metrics_dev, ts, stream);
+}
+
+dq_status dq_td_update_stats(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* q_s0_dev, const float* reward_dev,
+                             const uint8_t* terminal_dev, const int32_t* action_dev, const int32_t* index_dev, double gamma, int batch,
+                             int n_actions, double grad_scale, float* y_dev, float* dq_dev, float* metrics_dev, const uint8_t* done_dev,
+                             const uint8_t* was_reset_dev, const uint32_t* lifetime_dev, const float* step_reward_dev, int n,
+                             uint64_t* stats_dev, void* stream) {
+    DQ_REQUIRE(done_dev && lifetime_dev && step_reward_dev && stats_dev && n >= 1, DQ_ERR_INVALID, "dq_td_update_stats: bad statistics argument");
+    TdStats ts = {done_dev, was_reset_dev, lifetime_dev, step_reward_dev, n, reinterpret_cast<unsigned long long*>(stats_dev)};
+    return launch_td_update(q_online_s1_dev, q_target_s1_dev, q_s0_dev, reward_dev, terminal_dev, action_dev, index_dev, gamma, batch, n_actions,
+                            grad_scale, y_dev, dq_dev, metrics_dev, ts, stream);
 }
 
 dq_status dq_td_metrics(float* metrics_dev, int batch, void* stream) {

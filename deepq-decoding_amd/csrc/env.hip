@@ -78,6 +78,13 @@ struct EnvParams {
     int masked_greedy;
     u32 pseed0, pseed1;
     int32_t* action_out;
+    // replay sampling for the update that follows this step (dq_env_act_step_sample): workgroups [env_blocks, env_blocks + s_blocks)
+    int env_blocks, s_blocks;
+    const u8* s_terminal;          // the terminal ring; this step writes slot head - 1, the rule only reads older slots
+    int s_n_slots, s_head, s_filled, s_batch;
+    u32 s_seed0, s_seed1, s_base;
+    u64 s_t;
+    int32_t* s_index;
 };
 
 static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s) {
@@ -95,6 +102,12 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p) {
     u8* s_stage = s_qubit + 256;                                            // [4 * obs_size]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= p.env_blocks) {                                   // replay sampling rides along (independent of this step's results)
+        const int b = ((int)blockIdx.x - p.env_blocks) * 256 + tid;
+        if (b < p.s_batch)
+            p.s_index[b] = dq_replay_row(p.s_terminal, p.n_envs, p.s_n_slots, p.s_head, p.s_filled, p.s_seed0, p.s_seed1, p.s_t, p.s_base + (u32)b);
+        return;
+    }
     const int i = blockIdx.x * ENVS_PER_BLOCK + wave;
     const bool active = i < p.n_envs;                                        // wave-uniform
 
@@ -569,9 +582,10 @@ static dq_status launch_env(dq_env* E, EnvParams& p, hipStream_t st) {
     p.env_id_base = E->cfg.env_id_base; p.seed0 = E->cfg.seed[0]; p.seed1 = E->cfg.seed[1];
     p.T_phys = E->T_phys; p.T_meas = E->T_meas;
     const int blocks = (p.n_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    p.env_blocks = blocks;
     const size_t lds = ENVS_PER_BLOCK * DQ_MAX_DEPTH * 8 + 3 * 256 + (size_t)ENVS_PER_BLOCK * ((p.obs_size + 3) & ~3);
     dq_prof_begin(DQ_K_ENV, st);
-    env_kernel<<<blocks, 256, lds, st>>>(p);
+    env_kernel<<<blocks + p.s_blocks, 256, lds, st>>>(p);
     dq_prof_end(DQ_K_ENV, st);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
@@ -598,9 +612,9 @@ dq_status dq_env_step(dq_env* E, const int32_t* action_dev, int auto_reset, uint
     return launch_env(E, p, (hipStream_t)stream);
 }
 
-dq_status dq_env_act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
+static dq_status act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
                           int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
-                          uint32_t* lifetime_dev, uint8_t* was_reset_dev, void* stream) {
+                          uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sj, void* stream) {
     DQ_REQUIRE(E && action_dev && seed, DQ_ERR_INVALID, "dq_env_act_step: null argument");
     DQ_REQUIRE(E->lut_x, DQ_ERR_STATE, "dq_env_act_step: no referee installed (dq_env_build_referee / dq_env_set_referee)");
     DQ_REQUIRE(eps >= 0.0 && eps <= 1.0, DQ_ERR_INVALID, "dq_env_act_step: eps must be in [0,1]");
@@ -610,7 +624,34 @@ dq_status dq_env_act_step(dq_env* E, const float* q_dev, double eps, int masked_
     p.done = done_dev; p.legal = legal_dev; p.lifetime = lifetime_dev; p.was_reset = was_reset_dev;
     p.policy = 1; p.q = q_dev; p.T_eps = dq_rate_threshold(eps); p.masked_greedy = masked_greedy; p.pseed0 = seed[0]; p.pseed1 = seed[1];
     p.pt = t; p.action_out = action_dev;
+    if (sj) {
+        DQ_REQUIRE(sj->terminal_ring_dev && sj->index_dev, DQ_ERR_INVALID, "dq_env_act_step_sample: null argument");
+        DQ_REQUIRE(sj->n_slots >= 2 && sj->batch >= 1 && sj->head_slot >= 0 && sj->head_slot < sj->n_slots, DQ_ERR_INVALID,
+                   "dq_env_act_step_sample: bad sizes");
+        DQ_REQUIRE(sj->filled_slots >= 2 && sj->filled_slots <= sj->n_slots, DQ_ERR_STATE,
+                   "dq_env_act_step_sample: need at least one complete transition per lattice");
+        DQ_REQUIRE((long long)E->cfg.n_envs * sj->n_slots < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_env_act_step_sample: ring too large for 32-bit rows");
+        p.s_blocks = (sj->batch + 255) / 256; p.s_terminal = sj->terminal_ring_dev; p.s_n_slots = sj->n_slots; p.s_head = sj->head_slot;
+        p.s_filled = sj->filled_slots; p.s_batch = sj->batch; p.s_seed0 = sj->seed[0]; p.s_seed1 = sj->seed[1]; p.s_base = sj->sample_base;
+        p.s_t = sj->t; p.s_index = sj->index_dev;
+    }
     return launch_env(E, p, (hipStream_t)stream);
+}
+
+dq_status dq_env_act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
+                          int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
+                          uint32_t* lifetime_dev, uint8_t* was_reset_dev, void* stream) {
+    return act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev, lifetime_dev,
+                    was_reset_dev, nullptr, stream);
+}
+
+dq_status dq_env_act_step_sample(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
+                                 int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev,
+                                 uint64_t* legal_dev, uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sample,
+                                 void* stream) {
+    DQ_REQUIRE(sample, DQ_ERR_INVALID, "dq_env_act_step_sample: null sampling job");
+    return act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev, lifetime_dev,
+                    was_reset_dev, sample, stream);
 }
 
 dq_status dq_env_export_state(dq_env* E, uint64_t* state_dev, void* stream) {

@@ -220,11 +220,21 @@ def td_loss_grad(q_s0, action, y, grad_scale=None, index=None, dq=None, metrics=
     return dq, metrics
 
 
-def td_update(q_online_s1, q_target_s1, q_s0, reward, terminal, action, gamma, grad_scale=None, index=None, y=None, dq=None, metrics=None):
-    """td_target + td_loss_grad in one launch (dq_td_update); metrics[0..1] are valid only after td_metrics()."""
+def td_update(q_online_s1, q_target_s1, q_s0, reward, terminal, action, gamma, grad_scale=None, index=None, y=None, dq=None, metrics=None,
+              step_stats=None):
+    """td_target + td_loss_grad in one launch (dq_td_update); metrics[0..1] are valid only after td_metrics().
+    step_stats = (done, was_reset, lifetime, reward, n, stats): the episode bookkeeping of the step just taken rides along
+    (dq_td_update_stats)."""
     B, A = q_s0.shape
     if dq is None:
         dq = torch.empty_like(q_s0)
+    if step_stats is not None:
+        done, was_reset, lifetime, step_reward, n, stats = step_stats
+        check(_lib.lib().dq_td_update_stats(ptr(q_online_s1), ptr(q_target_s1), ptr(q_s0), ptr(reward), ptr(terminal), ptr(action), ptr(index),
+                                            float(gamma), B, A, 1.0 / B if grad_scale is None else float(grad_scale), ptr(y), ptr(dq),
+                                            ptr(metrics), ptr(done), ptr(was_reset), ptr(lifetime), ptr(step_reward), int(n), ptr(stats),
+                                            _lib.current_stream(q_s0.device)))
+        return dq
     check(_lib.lib().dq_td_update(ptr(q_online_s1), ptr(q_target_s1), ptr(q_s0), ptr(reward), ptr(terminal), ptr(action), ptr(index), float(gamma),
                                   B, A, 1.0 / B if grad_scale is None else float(grad_scale), ptr(y), ptr(dq), ptr(metrics),
                                   _lib.current_stream(q_s0.device)))

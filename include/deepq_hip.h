@@ -133,6 +133,22 @@ dq_status dq_env_act_step(dq_env* env, const float* q_dev, double eps, int maske
                           int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev,
                           uint64_t* legal_dev, uint32_t* lifetime_dev, uint8_t* was_reset_dev, void* stream);
 
+/* dq_env_act_step plus the replay sampling (dq_replay_sample's rule, same Philox stream) for the update that follows this step,
+ * in the same launch: the rule never reads the ring slot this step writes, so head_slot / filled_slots are the values AFTER the
+ * step (head_slot = the slot the successor observations go to). */
+typedef struct dq_sample_job {
+    const uint8_t* terminal_ring_dev;
+    int n_slots, head_slot, filled_slots, batch;
+    uint32_t seed[2];
+    uint64_t t;                 /* number of the update the minibatch is for (counts from 1) */
+    uint32_t sample_base;       /* first global sample id of this rank's minibatch */
+    int32_t* index_dev;         /* int32 [batch] out */
+} dq_sample_job;
+dq_status dq_env_act_step_sample(dq_env* env, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
+                                 int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev,
+                                 uint64_t* legal_dev, uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sample,
+                                 void* stream);
+
 /* Hidden state for tests / checkpointing: uint64 [n_envs, state_words], state_words = 11 + volume_depth:
  *   0 xmask (hidden_state codes 1,2)   1 zmask (codes 2,3)
  *   2 current_true_syndrome word       3 OR of the volume's faulty words (summed_syndrome_volume != 0)
@@ -289,6 +305,12 @@ dq_status dq_td_loss_grad(const float* q_s0_dev, const int32_t* action_dev, cons
 dq_status dq_td_update(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* q_s0_dev, const float* reward_dev,
                        const uint8_t* terminal_dev, const int32_t* action_dev, const int32_t* index_dev, double gamma, int batch,
                        int n_actions, double grad_scale, float* y_dev, float* dq_dev, float* metrics_dev, void* stream);
+/* dq_td_update plus dq_episode_stats of the environment step just taken, in one launch. */
+dq_status dq_td_update_stats(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* q_s0_dev, const float* reward_dev,
+                             const uint8_t* terminal_dev, const int32_t* action_dev, const int32_t* index_dev, double gamma, int batch,
+                             int n_actions, double grad_scale, float* y_dev, float* dq_dev, float* metrics_dev, const uint8_t* done_dev,
+                             const uint8_t* was_reset_dev, const uint32_t* lifetime_dev, const float* step_reward_dev, int n,
+                             uint64_t* stats_dev, void* stream);
 dq_status dq_td_metrics(float* metrics_dev, int batch, void* stream);
 
 /* dq_replay_sample (for the next update) + dq_episode_stats (of the step just taken) in one launch. */

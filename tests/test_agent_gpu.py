@@ -48,7 +48,7 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod):
     ring_obs[0] = ref.obs
     for t in range(steps):
         # --- act
-        core.act_and_step(eps)
+        core.act_and_step(eps, presample=(t % 2 == 0))          # the sampling rides on the env launch every other step: same draws
         q, _ = O.forward(spec, p, ring_obs[cur])
         acts = np.zeros(N, np.int32)
         for i in range(N):

@@ -294,3 +294,36 @@ def test_fused_act_step_equals_policy_then_step(dq, torch_mod, masked, eps):
         assert torch.equal(act_a, act_b) and torch.equal(a_env.obs, b_env.obs) and torch.equal(a_env.reward, b_env.reward)
         assert torch.equal(a_env.done, b_env.done) and torch.equal(a_env.legal, b_env.legal) and torch.equal(a_env.was_reset, b_env.was_reset)
     assert torch.equal(a_env.export_state(), b_env.export_state())
+
+
+def test_act_step_with_replay_sampling_equals_the_separate_calls(dq, torch_mod):
+    """dq_env_act_step_sample == dq_env_act_step + dq_replay_sample: the sampling blocks change nothing about the step, and draw the
+    same rows (also when the minibatch is larger than the number of lattices)."""
+    torch = torch_mod
+    import ctypes
+    from importlib import import_module
+    lib = import_module("deepq-decoding_amd._lib")
+    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    n, n_slots, batch = 300, 9, 1000
+    a_env, b_env = dq.VectorEnv(n_envs=n, **cfg), dq.VectorEnv(n_envs=n, **cfg)
+    a_env.reset(); b_env.reset()
+    L, p = lib.lib(), lib.ptr
+    seed = (ctypes.c_uint32 * 2)(*a_env.seed)
+    rng = np.random.RandomState(1)
+    term = torch.from_numpy((rng.rand(n_slots, n) < 0.2).astype(np.uint8)).cuda()
+    act_a, act_b = (torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(2))
+    idx_b = torch.empty(batch, dtype=torch.int32, device="cuda")
+    for t in range(12):
+        head, filled = (t + 3) % n_slots, min(n_slots, t + 2)
+        for env, act in ((a_env, act_a),):
+            lib.check(L.dq_env_act_step(env._h, None, 1.0, 0, seed, t, p(act), 1, p(env.obs), p(env.reward), p(env.done), p(env.legal),
+                                        p(env.lifetime), p(env.was_reset), lib.current_stream()))
+        idx_a = dq.replay_sample(term, n, n_slots, head, filled, batch, (5, 6), t + 1, sample_base=77)
+        sj = lib.SampleJob()
+        sj.terminal_ring_dev, sj.n_slots, sj.head_slot, sj.filled_slots, sj.batch = p(term), n_slots, head, filled, batch
+        sj.seed[0], sj.seed[1], sj.t, sj.sample_base, sj.index_dev = 5, 6, t + 1, 77, p(idx_b)
+        lib.check(L.dq_env_act_step_sample(b_env._h, None, 1.0, 0, seed, t, p(act_b), 1, p(b_env.obs), p(b_env.reward), p(b_env.done),
+                                           p(b_env.legal), p(b_env.lifetime), p(b_env.was_reset), ctypes.byref(sj), lib.current_stream()))
+        assert torch.equal(idx_a, idx_b) and torch.equal(act_a, act_b) and torch.equal(a_env.obs, b_env.obs)
+        assert torch.equal(a_env.reward, b_env.reward) and torch.equal(a_env.done, b_env.done) and torch.equal(a_env.legal, b_env.legal)
+    assert torch.equal(a_env.export_state(), b_env.export_state())

@@ -264,6 +264,12 @@ def test_fused_td_update_and_post_step_equal_the_separate_kernels(dq, torch_mod)
     lib.check(L.dq_post_step(p(term), n_envs, n_slots, head, filled, batch, qn._seed_arr(seed), t, base, p(idx2), p(done), p(was_reset), p(life),
                              p(rew), n_envs, p(stats), lib.current_stream()))
     assert torch.equal(idx_ref, idx2) and torch.equal(stats_ref, stats)
+    # the bookkeeping riding on the TD launch instead (dq_td_update_stats)
+    stats3, met3, y3 = torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros_like(met), torch.empty_like(y)
+    dq3 = qn.td_update(q1o, q1t, q0, reward, terminal, action, 0.99, grad_scale=0.01, index=idx, y=y3, metrics=met3,
+                       step_stats=(done, was_reset, life, rew, n_envs, stats3))
+    qn.td_metrics(met3, B)
+    assert torch.equal(y, y3) and torch.equal(dq_ref, dq3) and torch.equal(met_ref[:2], met3[:2]) and torch.equal(stats_ref, stats3)
 
 
 def test_replay_sample_rule(dq, torch_mod):
