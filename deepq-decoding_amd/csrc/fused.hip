@@ -369,22 +369,35 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [3][16][LDP]
     {
         const int q4 = K1 >> 2;                                     // float4 per row
-        for (int i = tid; i < DENSE_ROWS * q4; i += DENSE_THREADS) {
-            const int r = i / q4, c4 = (i - r * q4) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < ns) v = *reinterpret_cast<const f32x4*>(J.x + (size_t)(b0 + r) * K1 + c4);
-            const int p = a.perm_hw > 0 ? c4 / a.perm_c : 0, c = a.perm_hw > 0 ? c4 - p * a.perm_c : c4;   // perm_c % 4 == 0: the four share p
+        constexpr int NBS = 3;                                      // loads in flight per thread before the first split / LDS store
+        for (int i0 = tid; i0 < DENSE_ROWS * q4; i0 += NBS * DENSE_THREADS) {
+            f32x4 vv[NBS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = a.perm_hw > 0 ? (c + e) * a.perm_hw + p : c4 + e;
-                const u32 hb = __float_as_uint(v[e]) & 0xffff0000u;
-                const float r1 = v[e] - __uint_as_float(hb);                            // exact
-                const u32 mb = __float_as_uint(r1) & 0xffff0000u;
-                const float r2 = r1 - __uint_as_float(mb);                              // exact, <= 8 significant bits left
-                unsigned short* d = s_pl + r * LDP + k;
-                d[0] = (unsigned short)(hb >> 16);
-                d[DENSE_ROWS * LDP] = (unsigned short)(mb >> 16);
-                d[2 * DENSE_ROWS * LDP] = (unsigned short)(__float_as_uint(r2) >> 16);
+            for (int u = 0; u < NBS; ++u) {
+                const int i = i0 + u * DENSE_THREADS, r = i / q4, c4 = (i - r * q4) * 4;
+                const bool ok = i < DENSE_ROWS * q4 && r < ns;
+                // unconditional load of a clamped address, masked by multiplication (a select right behind the load serialises them)
+                vv[u] = *reinterpret_cast<const f32x4*>(J.x + (ok ? (size_t)(b0 + r) * K1 + c4 : 0)) * (ok ? 1.f : 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < NBS; ++u) {
+                const int i = i0 + u * DENSE_THREADS;
+                if (i >= DENSE_ROWS * q4) break;
+                const int r = i / q4, c4 = (i - r * q4) * 4;
+                const f32x4 v = vv[u];
+                const int p = a.perm_hw > 0 ? c4 / a.perm_c : 0, c = a.perm_hw > 0 ? c4 - p * a.perm_c : c4;   // perm_c % 4 == 0: the four share p
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = a.perm_hw > 0 ? (c + e) * a.perm_hw + p : c4 + e;
+                    const u32 hb = __float_as_uint(v[e]) & 0xffff0000u;
+                    const float r1 = v[e] - __uint_as_float(hb);                            // exact
+                    const u32 mb = __float_as_uint(r1) & 0xffff0000u;
+                    const float r2 = r1 - __uint_as_float(mb);                              // exact, <= 8 significant bits left
+                    unsigned short* d = s_pl + r * LDP + k;
+                    d[0] = (unsigned short)(hb >> 16);
+                    d[DENSE_ROWS * LDP] = (unsigned short)(mb >> 16);
+                    d[2 * DENSE_ROWS * LDP] = (unsigned short)(__float_as_uint(r2) >> 16);
+                }
             }
         }
         for (int i = tid; i < DENSE_ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
@@ -450,21 +463,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     }
     const int NT3 = (a.N3 + 15) >> 4;
     float b3[KG3][4];
-    if (wave < NT3) {
-        const float* w3 = J.params + a.w_off[2];
-        const int col = 16 * wave + j;
-        const bool cok = col < a.N3;
-        const int loff = 4 * kq * a.N3 + (cok ? col : 0);
-#pragma unroll
-        for (int g = 0; g < KG3; ++g)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = 16 * g + 4 * kq + s;
-                const bool okb = cok && k < a.N2;
-                const float v = w3[okb ? (16 * g + s) * a.N3 + loff : 0];
-                b3[g][s] = okb ? v : 0.f;
-            }
-    }
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 3);
     // ---- hidden layer epilogue: bias, ReLU, dropout (one Philox call = this lane's 4 columns of a row) -----------------
@@ -511,6 +509,23 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             for (int q = 0; q < NT2 / 4; ++q)                       // this lane's columns NT2*j + 4q .. +3 of row 4kq + r
                 *reinterpret_cast<f32x4*>(s_part + (wave * 16 + 4 * kq + r) * PW + NT2 * j + 4 * q) =
                     f32x4{acc2[4 * q][r], acc2[4 * q + 1][r], acc2[4 * q + 2][r], acc2[4 * q + 3][r]};
+    }
+    // the dueling layer's weights (waves 0 .. NT3-1): requested here, where Dense(|A|)'s 64 weight registers are free again, and used
+    // two barriers later.  All loads first, masked by MULTIPLICATION afterwards: under `ok ? v : 0` right after each load, with the
+    // 128-VGPR cap, hipcc reuses one register and waits for every load in turn (measured: 9K cycles on the critical path).
+    if (wave < NT3) {
+        const float* w3 = J.params + a.w_off[2];
+        const int col = 16 * wave + j;
+        const bool cok = col < a.N3;
+        const int loff = 4 * kq * a.N3 + (cok ? col : 0);
+#pragma unroll
+        for (int g = 0; g < KG3; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 16 * g + 4 * kq + s;
+                const bool okb = cok && k < a.N2;
+                b3[g][s] = w3[okb ? (16 * g + s) * a.N3 + loff : 0] * (okb ? 1.f : 0.f);
+            }
     }
     __syncthreads();
     DQ_STAMP(DQ_TAG_DENSE_FWD, 5);
