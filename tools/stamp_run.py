@@ -8,7 +8,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dir
 dq = importlib.import_module("deepq-decoding_amd")
 tag = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
-shape, A, batch = (7, 11, 11), 51, 4096
+shape, A, batch = (7, 11, 11), 51, int(os.environ.get("DQ_STAMP_BATCH", 4096))
 net = dq.QNetwork(shape, C_LAYERS, FF_LAYERS, A, max_batch=batch)
 params = net.init_params((11, 22))
 rng = np.random.RandomState(5)
