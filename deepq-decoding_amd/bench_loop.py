@@ -14,6 +14,7 @@ from .qnet import QNetwork
 C_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]]
 FF_LAYERS = [[512, 0.2]]
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 (MI355X_MICROARCH.md); the fused chains issue 3 (binary operand) or 6 bf16 MFMAs per f32 product
 HBM_PEAK_GBS = 8000.0
 
 
@@ -89,6 +90,14 @@ class FullLoop:
             "gemm_wgrad_kernel": (len(lm), 2.0 * self.macs * self.B, "mfma"),
         }
 
+    def bf16_pipe_factor(self):
+        """family -> bf16 MFMA flops issued per algorithmic f32 flop (work-weighted) for the kernels that run on the bf16 pipe."""
+        nc, lm = len(C_LAYERS), self.layer_macs
+        if not self.net.fused_supported:
+            return {}
+        conv = sum(lm[:nc])
+        return {"conv_chain_kernel": (3.0 * lm[0] + 6.0 * sum(lm[1:nc])) / conv}      # conv1's operand is binary: 3 pieces suffice
+
     def _family_id(self, name):
         for i in range(self.L.dq_prof_kernel_count()):
             if self.L.dq_prof_kernel_name(i).decode() == name:
@@ -146,6 +155,11 @@ class FullLoop:
                 roof = dict(kernel=self.prof_family, bound=bound, achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=_pmc_traffic(self.prof_family), avg_launch_us=avg_s * 1e6,
                             launches_timed=launches, algorithmic_flops_per_launch=per_launch)
+                issued = self.bf16_pipe_factor().get(self.prof_family)
+                if issued:
+                    # the same launch seen from the pipe it actually runs on: f32-accurate products issued as bf16 MFMAs
+                    roof["bf16_pipe"] = dict(issued_tflops=achieved * issued, peak=MFMA_BF16_PEAK_TFLOPS,
+                                             frac=achieved * issued / MFMA_BF16_PEAK_TFLOPS, mfmas_per_f32_product=issued)
         out = {
             "roofline": roof,
             "dqn_updates_per_s": steps / dt,
