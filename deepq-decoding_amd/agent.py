@@ -34,7 +34,7 @@ from collections import deque
 import numpy as np
 import torch
 
-from .core import DQNCore
+from .core import DQNCore, MIN_FILLED
 from .env import Surface_Code_Environment_Multi_Decoding_Cycles, VectorEnv
 from .qnet import QNetwork
 
@@ -376,18 +376,21 @@ class DQNAgent:
     def _will_train(self, step_after):
         """Whether _maybe_train() will update once self.step has become step_after (the ring then holds one more slot)."""
         core = self._core
-        return step_after > self.nb_steps_warmup and min(core.T, core.filled + 1) >= 2 and (step_after // core.N) % self.train_interval == 0
+        return step_after > self.nb_steps_warmup and min(core.T, core.filled + 1) >= MIN_FILLED and (step_after // core.N) % self.train_interval == 0
 
     def _maybe_train(self):
         core = self._core
         did = False
-        if self.step > self.nb_steps_warmup and core.filled >= 2 and (self.step // core.N) % self.train_interval == 0:
+        if self.step > self.nb_steps_warmup and core.filled >= MIN_FILLED and (self.step // core.N) % self.train_interval == 0:
             core.update()
             did = True
-        if self.step - self._last_target_sync >= self.target_model_update:
-            core.update_target_hard()
-            self._last_target_sync = self.step
+        self._sync_target()
         return did
+
+    def _sync_target(self):
+        if self.step - self._last_target_sync >= self.target_model_update:
+            self._core.update_target_hard()
+            self._last_target_sync = self.step
 
     def fit(self, env, nb_steps, action_repetition=1, callbacks=None, verbose=1, visualize=False, nb_max_start_steps=0,
             start_step_policy=None, log_interval=10000, nb_max_episode_steps=None, episode_averaging_length=10,
@@ -419,9 +422,16 @@ class DQNAgent:
         try:
             while self.step - start_step < nb_steps and not stop:
                 eps, masked = self.policy.current(True)
-                core.act_and_step(eps, masked_greedy=masked, presample=self._will_train(self.step + N))
-                self.step += N
-                trained = self._maybe_train()
+                if self._will_train(self.step + N):
+                    # acting forward + the update's forwards in one pair of launches; the environment launch draws the next minibatch
+                    core.step_and_update(eps, masked_greedy=masked, presample_next=self._will_train(self.step + 2 * N))
+                    self.step += N
+                    trained = True
+                    self._sync_target()
+                else:
+                    core.act_and_step(eps, masked_greedy=masked)
+                    self.step += N
+                    trained = self._maybe_train()
                 epss.append(eps)
                 if core.vector_steps % sync_interval != 0:
                     continue

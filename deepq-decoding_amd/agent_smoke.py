@@ -21,9 +21,11 @@ def run():
     core.reset_env()
     for _ in range(3):
         core.act_and_step(0.1)
-    for _ in range(3):
+    for _ in range(2):
         core.act_and_step(0.1)
         core.update()
+    for _ in range(2):
+        core.step_and_update(0.1)          # the same step with the four forwards in one pair of launches
     loss, mean_q = core.read_metrics()
     assert np.isfinite(loss) and np.isfinite(mean_q)
     # parity of one training forward + backward on the current observations

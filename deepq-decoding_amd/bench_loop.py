@@ -76,10 +76,11 @@ class FullLoop:
         conv, dense = sum(lm[:nc]), sum(lm[nc:])
         fwd_samples = self.n + 3 * self.B
         if self.net.fused_supported:
-            # two forward launch pairs per step (acting; the update's three forwards share one), one launch per backward kernel
+            # one forward launch pair per step (the acting forward and the update's three forwards share it), one launch per
+            # backward kernel
             return {
-                "conv_chain_kernel": (2, 2.0 * conv * fwd_samples, "mfma"),
-                "dense_chain_kernel": (2, 2.0 * dense * fwd_samples, "mfma"),
+                "conv_chain_kernel": (1, 2.0 * conv * fwd_samples, "mfma"),
+                "dense_chain_kernel": (1, 2.0 * dense * fwd_samples, "mfma"),
                 # conv weight gradients (= forward MACs) + data gradients through conv3 and conv2
                 "conv_bwd_chain_kernel": (1, 2.0 * (conv + sum(lm[1:nc])) * self.B, "mfma"),
                 "dense_bwd_chain_kernel": (1, 2.0 * dense * self.B, "mfma"),
@@ -129,8 +130,7 @@ class FullLoop:
             _lib.check(self.L.dq_prof_arm(self._family_id(self.prof_family), steps * per_step + 8))
 
     def step(self, timed):
-        self.core.act_and_step(self.eps, presample=True)
-        self.core.update()
+        self.core.step_and_update(self.eps)          # == act_and_step() + update(), the four forwards in one pair of launches
         if self.core.updates % self.target_every == 0:
             self.core.update_target_hard()
 

@@ -22,6 +22,9 @@ from . import _lib, dist as _dist, qnet as _q
 from ._lib import check, ptr
 
 
+MIN_FILLED = 4      # ring slots an update needs: keras-rl never samples the two newest transitions (csrc/common.h dq_replay_row)
+
+
 class DQNCore:
     def __init__(self, env, net, batch_size=32, memory_limit=50000, gamma=0.99, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
                  target_model_update=10000, enable_double_dqn=True, seed=None, rank=0, world_size=1, process_group=None,
@@ -40,7 +43,7 @@ class DQNCore:
         self.L = _lib.lib()
         dev = self.device
         # ring
-        self.T = max(2, int(memory_limit) // self.N + 1)
+        self.T = max(MIN_FILLED, int(memory_limit) // self.N + 1)
         C, H, W = env.obs_shape
         self.obs_ring = torch.zeros((self.T, self.N, C, H, W), dtype=torch.uint8, device=dev)
         self.action_ring = torch.zeros((self.T, self.N), dtype=torch.int32, device=dev)
@@ -60,7 +63,8 @@ class DQNCore:
         # scratch
         self.q_act = torch.zeros((self.N, self.A), dtype=torch.float32, device=dev)
         B = self.batch_size
-        self.index = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.index = torch.zeros(B, dtype=torch.int32, device=dev)         # rows of the update in progress
+        self._index_next = torch.zeros(B, dtype=torch.int32, device=dev)   # rows drawn ahead by an environment launch (_presampled)
         self.q1_online = torch.zeros((B, self.A), dtype=torch.float32, device=dev)
         self.q1_target = torch.zeros((B, self.A), dtype=torch.float32, device=dev)
         self.q0 = torch.zeros((B, self.A), dtype=torch.float32, device=dev)
@@ -69,7 +73,7 @@ class DQNCore:
         self.metrics = torch.zeros(_q.TD_METRICS_FLOATS, dtype=torch.float32, device=dev)
         self.stats = torch.zeros(4, dtype=torch.int64, device=dev)
         self._stats_pending = None   # episode bookkeeping not yet launched (slot,)
-        self._presampled = 0
+        self._presampled = None      # (update number, head slot, filled slots) the minibatch in self.index was drawn for
         self.defer_stats = True      # act_and_step leaves the bookkeeping launch to the next update() (dq_post_step) / act / read_stats
         self._metrics_stale = False
         self.vector_steps = 0        # policy / environment counter
@@ -108,15 +112,10 @@ class DQNCore:
                 ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
                 ptr(env.lifetime), ptr(env.was_reset))
         filled = min(self.T, self.filled + 1)
-        if presample and filled >= 2:
-            sj = _lib.SampleJob()
-            sj.terminal_ring_dev, sj.n_slots, sj.head_slot, sj.filled_slots, sj.batch = ptr(self.terminal_ring), self.T, nxt, filled, self.batch_size
-            sj.seed[0], sj.seed[1] = int(self.seed[0]) & 0xFFFFFFFF, int(self.seed[1]) & 0xFFFFFFFF
-            sj.t, sj.sample_base, sj.index_dev = self.updates + 1, _dist.shard(self.rank, self.N, self.batch_size)[1], ptr(self.index)
-            check(self.L.dq_env_act_step_sample(*args, ctypes.byref(sj), self._stream()))
-            self._presampled = self.updates + 1
+        if presample and filled >= MIN_FILLED:
+            self._launch_env(args, self._sample_job(self.updates + 1, nxt, filled))
         else:
-            check(self.L.dq_env_act_step(*args, self._stream()))
+            self._launch_env(args, None)
         # episode bookkeeping of this step: rides on the next update's TD launch (dq_td_update_stats) when an update follows, else
         # launched on its own
         self._stats_pending = (cur,) if record_stats else None
@@ -125,6 +124,22 @@ class DQNCore:
         self.cur = nxt
         self.filled = filled
         self.vector_steps += 1
+
+    def _sample_job(self, t, head, filled):
+        """dq_sample_job for update number t, to be run on a ring with `head` / `filled`, into the look-ahead buffer (the update in
+        progress may still be reading self.index)."""
+        sj = _lib.SampleJob()
+        sj.terminal_ring_dev, sj.n_slots, sj.head_slot, sj.filled_slots, sj.batch = ptr(self.terminal_ring), self.T, head, filled, self.batch_size
+        sj.seed[0], sj.seed[1] = int(self.seed[0]) & 0xFFFFFFFF, int(self.seed[1]) & 0xFFFFFFFF
+        sj.t, sj.sample_base, sj.index_dev = t, _dist.shard(self.rank, self.N, self.batch_size)[1], ptr(self._index_next)
+        self._presampled = (t, head, filled)
+        return sj
+
+    def _launch_env(self, args, sj):
+        if sj is not None:
+            check(self.L.dq_env_act_step_sample(*args, ctypes.byref(sj), self._stream()))
+        else:
+            check(self.L.dq_env_act_step(*args, self._stream()))
 
     def _flush_stats(self):
         if self._stats_pending is not None:
@@ -135,24 +150,41 @@ class DQNCore:
 
     def update(self):
         """One minibatch update (keras-rl DQNAgent.backward's training branch)."""
-        assert self.filled >= 2, "no complete transition in the replay ring yet"
+        assert self.filled >= MIN_FILLED, "fewer than three complete transitions in the replay ring"
         B, N, T = self.batch_size, self.N, self.T
         self.updates += 1
         t = self.updates
         _, sample_base = _dist.shard(self.rank, N, B)
-        rows = T * N
-        if self._presampled != t:                    # (else act_and_step(presample=True) already drew this update's minibatch)
-            _q.replay_sample(self.terminal_ring, N, T, self.cur, self.filled, B, self.seed, t, sample_base=sample_base, out=self.index)
-        net, ring = self.net, self.obs_ring
+        self._take_minibatch(t, self.cur, self.filled, sample_base)
+        self.net.forward_multi(self._update_jobs(t, sample_base))
+        self._learn(t)
+
+    def _take_minibatch(self, t, head, filled, sample_base):
+        """self.index <- rows of update t on a ring with `head` / `filled`: the look-ahead draw if an environment launch made exactly
+        that one, else a launch of its own."""
+        if self._presampled == (t, head, filled):
+            self.index, self._index_next = self._index_next, self.index
+        else:
+            _q.replay_sample(self.terminal_ring, self.N, self.T, head, filled, self.batch_size, self.seed, t, sample_base=sample_base,
+                             out=self.index)
+        self._presampled = None
+
+    def _update_jobs(self, t, sample_base):
         # Q_online(s1) picks the action, Q_target(s1) values it (double DQN; without it Q_target does both); the training forward
         # on s0 is independent of both, so the three share one pair of launches
+        B, N, ring = self.batch_size, self.N, self.obs_ring
+        rows = self.T * N
         jobs = [dict(params=self.target, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target, packed=self.target_pk)]
         if self.enable_double_dqn:
             jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online,
                              packed=self.params_pk))
         jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, training=True, seed=self.seed, t=t, sample_base=sample_base,
                          out=self.q0, packed=self.params_pk))
-        net.forward_multi(jobs)
+        return jobs
+
+    def _learn(self, t):
+        """TD step, backward, optimizer step, repack -- everything of an update behind its forwards."""
+        B, N, net = self.batch_size, self.N, self.net
         q_sel = self.q1_online if self.enable_double_dqn else self.q1_target
         step_stats = None
         if self._stats_pending is not None:          # the pending episode bookkeeping rides on the TD launch
@@ -176,6 +208,38 @@ class DQNCore:
         else:
             net.backward_adam(self.params, self.dq, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
         self.repack()
+
+    def step_and_update(self, eps, masked_greedy=False, record_stats=True, presample_next=True):
+        """act_and_step() followed by update(), with the acting forward and the update's forwards in ONE pair of launches -- same
+        results as the two calls.  Possible because the update's minibatch never contains the two newest transitions (keras-rl's
+        range), so it does not depend on this step's environment results: the parameters are the same for all four forwards.
+        With presample_next the environment launch also draws the NEXT step's minibatch (if that step does not update, update()
+        notices the stale draw and redraws)."""
+        self._flush_stats()
+        env, cur, B, N, T = self.env, self.cur, self.batch_size, self.N, self.T
+        nxt = cur + 1 if cur + 1 < T else 0
+        filled = min(T, self.filled + 1)
+        assert filled >= MIN_FILLED, "fewer than three complete transitions in the replay ring"
+        t = self.updates + 1
+        _, sample_base = _dist.shard(self.rank, N, B)
+        self._take_minibatch(t, nxt, filled, sample_base)        # (drawn from the ring as it WILL be after this step)
+        jobs = self._update_jobs(t, sample_base)
+        jobs.append(dict(params=self.params, obs=self.obs_ring[cur], batch=N, out=self.q_act, packed=self.params_pk))
+        self.net.forward_multi(jobs)
+        seed = (ctypes.c_uint32 * 2)(*env.seed)
+        args = (env._h, ptr(self.q_act), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
+                ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
+                ptr(env.lifetime), ptr(env.was_reset))
+        sj = None
+        if presample_next:
+            nxt2 = nxt + 1 if nxt + 1 < T else 0
+            sj = self._sample_job(t + 1, nxt2, min(T, filled + 1))
+        self._launch_env(args, sj)
+        self._stats_pending = (cur,) if record_stats else None
+        self.cur, self.filled = nxt, filled
+        self.vector_steps += 1
+        self.updates = t
+        self._learn(t)
 
     def read_metrics(self):
         """(loss, mean_q) of the last update on this rank; reduces the per-block partials first (syncs)."""

@@ -102,18 +102,24 @@ __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
     return base + __ffsll((long long)m) - 1;
 }
 
-// Replay row of minibatch sample `sample_id` of update t (the rule of dqn.hip's replay_sample_kernel; shared by every launch
-// that carries the sampling along).
+// Replay row of minibatch sample `sample_id` of update t (shared by every launch that carries the sampling along).
+// keras-rl's SequentialMemory.sample draws idx from [window_length, nb_entries - 1) and uses the transition idx - 1, with the entry
+// appended at this step already counted: the two newest transitions are never sampled (the newest has no successor observation in
+// keras-rl's memory yet, the one before falls to the exclusive bound).  Here `filled` slots hold observations, the newest in slot
+// head_slot; complete transitions are slots head-1 (the step just taken), head-2, ...: candidates are head-3 downwards, filled - 3 of
+// them.  A candidate whose PREVIOUS entry was terminal is redrawn (its s0 is the terminal observation the agent only looked at before
+// env.reset()).  Because the rule never looks at the two newest slots, an update's minibatch can be drawn one vector step early.
+#define DQ_REPLAY_SKIP 2
 __device__ __forceinline__ int dq_replay_row(const u8* __restrict__ terminal, int n_envs, int n_slots, int head_slot, int filled,
                                              u32 seed0, u32 seed1, u64 t, u32 sample_id) {
-    const int cand = filled - 1;                        // slots that already have a successor
+    const int cand = filled - 1 - DQ_REPLAY_SKIP;       // complete transitions minus the two newest
     int row = 0;
     for (u32 attempt = 0; attempt < 64; ++attempt) {
         u32 w[4];
         philox4x32_10((u32)t, (u32)(t >> 32), sample_id, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
-        const int j = (int)__umulhi(w[0], (u32)cand);   // 0 = newest complete transition
+        const int j = (int)__umulhi(w[0], (u32)cand);   // 0 = newest candidate
         const int env = (int)__umulhi(w[1], (u32)n_envs);
-        int slot = head_slot - 1 - j;
+        int slot = head_slot - 1 - DQ_REPLAY_SKIP - j;
         if (slot < 0) slot += n_slots;
         row = slot * n_envs + env;
         if (j + 1 >= cand) break;                       // oldest stored slot: predecessor unknown -> accepted (keras-rl idx < 2)

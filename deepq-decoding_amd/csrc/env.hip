@@ -626,10 +626,10 @@ static dq_status act_step(dq_env* E, const float* q_dev, double eps, int masked_
     p.pt = t; p.action_out = action_dev;
     if (sj) {
         DQ_REQUIRE(sj->terminal_ring_dev && sj->index_dev, DQ_ERR_INVALID, "dq_env_act_step_sample: null argument");
-        DQ_REQUIRE(sj->n_slots >= 2 && sj->batch >= 1 && sj->head_slot >= 0 && sj->head_slot < sj->n_slots, DQ_ERR_INVALID,
+        DQ_REQUIRE(sj->n_slots >= 4 && sj->batch >= 1 && sj->head_slot >= 0 && sj->head_slot < sj->n_slots, DQ_ERR_INVALID,
                    "dq_env_act_step_sample: bad sizes");
-        DQ_REQUIRE(sj->filled_slots >= 2 && sj->filled_slots <= sj->n_slots, DQ_ERR_STATE,
-                   "dq_env_act_step_sample: need at least one complete transition per lattice");
+        DQ_REQUIRE(sj->filled_slots >= 2 + DQ_REPLAY_SKIP && sj->filled_slots <= sj->n_slots, DQ_ERR_STATE,
+                   "dq_env_act_step_sample: need at least three complete transitions per lattice");
         DQ_REQUIRE((long long)E->cfg.n_envs * sj->n_slots < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_env_act_step_sample: ring too large for 32-bit rows");
         p.s_blocks = (sj->batch + 255) / 256; p.s_terminal = sj->terminal_ring_dev; p.s_n_slots = sj->n_slots; p.s_head = sj->head_slot;
         p.s_filled = sj->filled_slots; p.s_batch = sj->batch; p.s_seed0 = sj->seed[0]; p.s_seed1 = sj->seed[1]; p.s_base = sj->sample_base;

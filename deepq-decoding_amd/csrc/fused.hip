@@ -336,7 +336,8 @@ struct DenseChainArgs {
     int off_x, off_h, off_part, off_y2, off_y3;
 };
 
-template <int NT2, int KG3>             // N2 <= 16*NT2 (column tiles of Dense(|A|)); N2 <= 16*KG3 (k groups of the dueling layer)
+template <int NT2, int KG3, int RT>     // N2 <= 16*NT2 (column tiles of Dense(|A|)); N2 <= 16*KG3 (k groups of the dueling layer);
+                                        // RT row tiles of 16 samples per workgroup
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     float* s_x = reinterpret_cast<float*>(smem + a.off_x);
@@ -344,20 +345,22 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     float* s_part = reinterpret_cast<float*>(smem + a.off_part);
     float* s_y2 = reinterpret_cast<float*>(smem + a.off_y2);
     float* s_y3 = reinterpret_cast<float*>(smem + a.off_y3);
-    constexpr int LDH = DENSE_HID + 4, PW = 16 * NT2;
+    constexpr int LDH = DENSE_HID + 4, PW = 16 * NT2, ROWS = 16 * RT;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     int jb = 0;
     while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
     const DenseJob& J = a.job[jb];
-    const int b0 = ((int)blockIdx.x - J.wg0) * DENSE_ROWS;
-    const int ns = min(DENSE_ROWS, J.batch - b0);
+    const int b0 = ((int)blockIdx.x - J.wg0) * ROWS;
+    const int ns = min(ROWS, J.batch - b0);
     const int K1 = a.K1;
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 0);
     DQ_STAMP_PAIR(2);
     // ---- hidden layer's first weight blocks start flying before anything else -------------------------------------------
     // Dense(512) runs as bf16x6 (qnet.h): the weights come as packed bf16 pieces (block (kblk, column tile ct = 4*wave + t), column
-    // 64*wave + 4j + t), the input rows are split ONCE into three bf16 planes in LDS.
+    // 64*wave + 4j + t), the input rows are split ONCE into three bf16 planes in LDS.  The kernel is bound by the weight stream: the
+    // vector-memory path delivers ~64 B/clk/CU and every workgroup reads all 0.9 MB of pieces, so a workgroup takes RT = 2 row tiles
+    // (32 samples) per weight block when the batch is large enough to fill the chip that way -- half the bytes per sample.
     const int KB = K1 >> 5;                                          // k-blocks of 32
     const u32x4* pkw = J.packed + a.pk_dense1 + (size_t)(4 * wave) * PK_BLOCK + lane;
     Bf16x3 bw[2][4];                                                // two k-blocks in flight
@@ -366,23 +369,23 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 
     // ---- input rows -> three bf16 planes in LDS, in Keras Flatten order (zero-filled past the batch); clear the padded y2 image --
     const int LDP = K1 + 8;                                          // plane row stride in bf16 (rows stay 16-byte aligned)
-    unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [3][16][LDP]
+    unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [3][ROWS][LDP]
     {
         const int q4 = K1 >> 2;                                     // float4 per row
         constexpr int NBS = 3;                                      // loads in flight per thread before the first split / LDS store
-        for (int i0 = tid; i0 < DENSE_ROWS * q4; i0 += NBS * DENSE_THREADS) {
+        for (int i0 = tid; i0 < ROWS * q4; i0 += NBS * DENSE_THREADS) {
             f32x4 vv[NBS];
 #pragma unroll
             for (int u = 0; u < NBS; ++u) {
                 const int i = i0 + u * DENSE_THREADS, r = i / q4, c4 = (i - r * q4) * 4;
-                const bool ok = i < DENSE_ROWS * q4 && r < ns;
+                const bool ok = i < ROWS * q4 && r < ns;
                 // unconditional load of a clamped address, masked by multiplication (a select right behind the load serialises them)
                 vv[u] = *reinterpret_cast<const f32x4*>(J.x + (ok ? (size_t)(b0 + r) * K1 + c4 : 0)) * (ok ? 1.f : 0.f);
             }
 #pragma unroll
             for (int u = 0; u < NBS; ++u) {
                 const int i = i0 + u * DENSE_THREADS;
-                if (i >= DENSE_ROWS * q4) break;
+                if (i >= ROWS * q4) break;
                 const int r = i / q4, c4 = (i - r * q4) * 4;
                 const f32x4 v = vv[u];
                 const int p = a.perm_hw > 0 ? c4 / a.perm_c : 0, c = a.perm_hw > 0 ? c4 - p * a.perm_c : c4;   // perm_c % 4 == 0: the four share p
@@ -395,32 +398,37 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                     const float r2 = r1 - __uint_as_float(mb);                              // exact, <= 8 significant bits left
                     unsigned short* d = s_pl + r * LDP + k;
                     d[0] = (unsigned short)(hb >> 16);
-                    d[DENSE_ROWS * LDP] = (unsigned short)(mb >> 16);
-                    d[2 * DENSE_ROWS * LDP] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    d[ROWS * LDP] = (unsigned short)(mb >> 16);
+                    d[2 * ROWS * LDP] = (unsigned short)(__float_as_uint(r2) >> 16);
                 }
             }
         }
-        for (int i = tid; i < DENSE_ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
+        for (int i = tid; i < ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
     }
     __syncthreads();
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 1);
     // ---- Dense(512): wave w owns columns [64w, 64w+64) as 4 interleaved tiles; two accumulator chains per tile -----------------
-    f32x4 acc2c[4][2];
+    f32x4 acc2c[RT][4][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { acc2c[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2c[t][1] = acc2c[t][0]; }
+    for (int u = 0; u < RT; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc2c[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2c[u][t][1] = acc2c[u][t][0]; }
     const unsigned short* arow = s_pl + j * LDP + 8 * kq;
     auto do_block = [&](int b, Bf16x3 (&cur)[4], Bf16x3 (&nxt)[4]) {
         const u32x4* pn = pkw + (size_t)min(b + 1, KB - 1) * 32 * PK_BLOCK;      // next block: unconditional, clamped prefetch
 #pragma unroll
         for (int t = 0; t < 4; ++t) { nxt[t].h = pn[t * PK_BLOCK]; nxt[t].m = pn[t * PK_BLOCK + 64]; nxt[t].l = pn[t * PK_BLOCK + 128]; }
-        Bf16x3 av;
-        const unsigned short* ap = arow + 32 * b;
-        av.h = *reinterpret_cast<const u32x4*>(ap);
-        av.m = *reinterpret_cast<const u32x4*>(ap + DENSE_ROWS * LDP);
-        av.l = *reinterpret_cast<const u32x4*>(ap + 2 * DENSE_ROWS * LDP);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) mma_bf16x6(av, cur[t], acc2c[t][0], acc2c[t][1]);
+        for (int u = 0; u < RT; ++u) {
+            Bf16x3 av;
+            const unsigned short* ap = arow + 16 * u * LDP + 32 * b;
+            av.h = *reinterpret_cast<const u32x4*>(ap);
+            av.m = *reinterpret_cast<const u32x4*>(ap + ROWS * LDP);
+            av.l = *reinterpret_cast<const u32x4*>(ap + 2 * ROWS * LDP);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mma_bf16x6(av, cur[t], acc2c[u][t][0], acc2c[u][t][1]);
+        }
     };
     int blk = 0;
     for (; blk + 1 < KB; blk += 2) {                                // no condition around the MFMAs inside the loop
@@ -428,9 +436,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         do_block(blk + 1, bw[1], bw[0]);
     }
     if (blk < KB) do_block(blk, bw[0], bw[1]);                       // odd block count (K1 = 288: 9 blocks)
-    f32x4 acc[4];
+    f32x4 acc[RT][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = acc2c[t][0] + acc2c[t][1];
+    for (int u = 0; u < RT; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[u][t] = acc2c[u][t][0] + acc2c[u][t][1];
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
     // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
@@ -470,31 +480,34 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         const int c0 = 64 * wave + 4 * j;
         const f32x4 bias = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + c0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kq + r;
-            f32x4 v;
+        for (int u = 0; u < RT; ++u)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[t][r] + bias[t], 0.f);
-            if (J.keep_scale > 0.f) {
-                u32 wd[4];
-                philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + row), ((u32)c0 >> 2) | ((u32)DQ_STREAM_DROPOUT << 16),
-                              J.seed0, J.seed1, wd);
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * u + 4 * kq + r;
+                f32x4 v;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = ((u64)wd[t] < J.drop_T) ? 0.f : v[t] * J.keep_scale;
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[u][t][r] + bias[t], 0.f);
+                if (J.keep_scale > 0.f) {
+                    u32 wd[4];
+                    philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + row), ((u32)c0 >> 2) | ((u32)DQ_STREAM_DROPOUT << 16),
+                                  J.seed0, J.seed1, wd);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = ((u64)wd[t] < J.drop_T) ? 0.f : v[t] * J.keep_scale;
+                }
+                *reinterpret_cast<f32x4*>(s_h + row * LDH + c0) = v;
+                if (J.h1_out && row < ns) *reinterpret_cast<f32x4*>(J.h1_out + (size_t)(b0 + row) * DENSE_HID + c0) = v;
             }
-            *reinterpret_cast<f32x4*>(s_h + row * LDH + c0) = v;
-            if (J.h1_out && row < ns) *reinterpret_cast<f32x4*>(J.h1_out + (size_t)(b0 + row) * DENSE_HID + c0) = v;
-        }
     }
     __syncthreads();
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 4);
     // ---- Dense(|A|): K = 512 split over the 8 waves, partial tiles reduced in fixed order ---------------------------------
-    {
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
         f32x4 acc2[NT2];
 #pragma unroll
         for (int t = 0; t < NT2; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* hrow = s_h + j * LDH + kw0 + 4 * kq;
+        const float* hrow = s_h + (16 * u + j) * LDH + kw0 + 4 * kq;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 16 * g);
@@ -506,8 +519,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int q = 0; q < NT2 / 4; ++q)                       // this lane's columns NT2*j + 4q .. +3 of row 4kq + r
-                *reinterpret_cast<f32x4*>(s_part + (wave * 16 + 4 * kq + r) * PW + NT2 * j + 4 * q) =
+            for (int q = 0; q < NT2 / 4; ++q)                       // this lane's columns NT2*j + 4q .. +3 of row 16u + 4kq + r
+                *reinterpret_cast<f32x4*>(s_part + (wave * ROWS + 16 * u + 4 * kq + r) * PW + NT2 * j + 4 * q) =
                     f32x4{acc2[4 * q][r], acc2[4 * q + 1][r], acc2[4 * q + 2][r], acc2[4 * q + 3][r]};
     }
     // the dueling layer's weights (waves 0 .. NT3-1): requested here, where Dense(|A|)'s 64 weight registers are free again, and used
@@ -529,11 +542,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     }
     __syncthreads();
     DQ_STAMP(DQ_TAG_DENSE_FWD, 5);
-    for (int e = tid; e < DENSE_ROWS * a.N2; e += DENSE_THREADS) {
+    for (int e = tid; e < ROWS * a.N2; e += DENSE_THREADS) {
         const int row = e / a.N2, col = e - row * a.N2;
         float v = J.params[a.b_off[1] + col];
 #pragma unroll
-        for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * 16 + row) * PW + col];
+        for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * ROWS + row) * PW + col];
         s_y2[row * a.ld2 + col] = v;
         if (J.y2_out && row < ns) J.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
     }
@@ -545,23 +558,26 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     int ldy = a.ld2;
     if (a.N3 > 0) {
         if (wave < NT3) {
-            f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
-            const float* yrow = s_y2 + j * a.ld2 + 4 * kq;
 #pragma unroll
-            for (int g = 0; g < KG3; ++g) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(yrow + 16 * g);
+            for (int u = 0; u < RT; ++u) {
+                f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
+                const float* yrow = s_y2 + (16 * u + j) * a.ld2 + 4 * kq;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc3 = MFMA16(av[s], b3[g][s], acc3);
-            }
-            const int col = 16 * wave + j;
-            if (col < a.N3) {
-                const float bias = J.params[a.b_off[2] + col];
+                for (int g = 0; g < KG3; ++g) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(yrow + 16 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * kq + r;
-                    const float v = acc3[r] + bias;
-                    s_y3[row * a.ld3 + col] = v;
-                    if (J.y3_out && row < ns) J.y3_out[(size_t)(b0 + row) * a.N3 + col] = v;
+                    for (int s = 0; s < 4; ++s) acc3 = MFMA16(av[s], b3[g][s], acc3);
+                }
+                const int col = 16 * wave + j;
+                if (col < a.N3) {
+                    const float bias = J.params[a.b_off[2] + col];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * u + 4 * kq + r;
+                        const float v = acc3[r] + bias;
+                        s_y3[row * a.ld3 + col] = v;
+                        if (J.y3_out && row < ns) J.y3_out[(size_t)(b0 + row) * a.N3 + col] = v;
+                    }
                 }
             }
         }
@@ -714,23 +730,25 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
 
 struct DensePlan { int ldx, ld2, ld3, off_x, off_h, off_part, off_y2, off_y3, NT2; size_t lds; };
 
-static bool plan_dense(const dq_qnet* Q, DensePlan* P) {
+// rt = row tiles of 16 samples per workgroup (1 or 2)
+static bool plan_dense(const dq_qnet* Q, DensePlan* P, int rt = 1) {
     const int nc = Q->cfg.n_conv;
     if (Q->cfg.n_ff != 1) return false;
     const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
     if (D1.nout != DENSE_HID || (D1.nin & 31) || (Q->flat_c & 3)) return false;
     const int N2 = D2.nout, N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0;
     if (N2 > 128 || N3 > 128) return false;
+    const int rows = 16 * rt;
     P->NT2 = N2 <= 64 ? 4 : 8;
     P->ldx = D1.nin + 4;
     P->ld2 = 16 * P->NT2 + 4;
     P->ld3 = 16 * ((N3 + 15) / 16) + 1;
     size_t off = 0;
-    const size_t xb = up16((size_t)3 * DENSE_ROWS * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * 16 * 16 * P->NT2 * 4);   // bf16 planes | partials
+    const size_t xb = up16((size_t)3 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * rows * 16 * P->NT2 * 4);   // bf16 planes | partials
     P->off_x = P->off_part = (int)off; off += xb > pb ? xb : pb;   // the Dense(|A|) partials reuse the input image (dead by then)
-    P->off_h = (int)off; off += up16((size_t)DENSE_ROWS * (DENSE_HID + 4) * 4);
-    P->off_y2 = (int)off; off += up16((size_t)DENSE_ROWS * P->ld2 * 4);
-    P->off_y3 = (int)off; off += up16((size_t)DENSE_ROWS * P->ld3 * 4);
+    P->off_h = (int)off; off += up16((size_t)rows * (DENSE_HID + 4) * 4);
+    P->off_y2 = (int)off; off += up16((size_t)rows * P->ld2 * 4);
+    P->off_y3 = (int)off; off += up16((size_t)rows * P->ld3 * 4);
     P->lds = off;
     return off <= CONV_LDS_MAX;
 }
@@ -750,14 +768,14 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     DQ_REQUIRE(plan_conv(Q, &cp) && plan_dense(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_forward: configuration not covered");
     DQ_REQUIRE(n_jobs >= 1 && n_jobs <= FWD_MAX_JOBS, DQ_ERR_INVALID, "fused_forward: 1..%d jobs per launch", FWD_MAX_JOBS);
     conv_kernel_t ck = cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
-    dense_kernel_t dk = dp.NT2 == 4 ? dense_chain_kernel<4, 4> : dense_chain_kernel<8, 8>;
     static bool attr_set = false;
     if (!attr_set) {
         const conv_kernel_t cks[4] = {conv_chain_kernel<3>, conv_chain_kernel<4>, conv_chain_kernel<5>, conv_chain_kernel<6>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
+        const dense_kernel_t dks[4] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<8, 8, 2>};
+        for (int i = 0; i < 4; ++i)
+            DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         attr_set = true;
     }
     const int nc = Q->cfg.n_conv;
@@ -776,6 +794,31 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = PK_TOTAL_U32X4;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < Q->n_layers - nc; ++l) { da.w_off[l] = (int)Q->L[nc + l].w_off; da.b_off[l] = (int)Q->L[nc + l].b_off; }
+    // two row tiles (32 samples) per dense workgroup -- half the weight stream per sample -- when one-tile workgroups would
+    // outnumber the CUs anyway and the larger images fit in LDS
+    int tiles16 = 0;
+    for (int i = 0; i < n_jobs; ++i) tiles16 += (jobs[i].batch + 15) / 16;
+    int n_cu = 256;
+    {
+        static int cached_cus = 0;
+        if (!cached_cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached_cus = prop.multiProcessorCount;
+            if (cached_cus <= 0) cached_cus = 256;
+        }
+        n_cu = cached_cus;
+    }
+    DensePlan dp2;
+    // measured at c3 (us): one-tile workgroups cost ~20 for a launch of <= one per CU and ~15 per CU-ful beyond that (two share a
+    // CU and take turns on the vector-memory path); two-tile workgroups (one per CU) cost 23.6 per round of n_cu workgroups
+    const double cost1 = tiles16 <= n_cu ? 20.0 : 15.0 * tiles16 / n_cu;
+    const double cost2 = 23.6 * (((tiles16 + 1) / 2 + n_cu - 1) / n_cu);
+    const int RT = (cost2 < cost1 && plan_dense(Q, &dp2, 2)) ? 2 : 1;
+    if (RT == 2) dp = dp2;
+    const int dense_rows = 16 * RT;
+    const dense_kernel_t dk = dp.NT2 == 4 ? (RT == 2 ? dense_chain_kernel<4, 4, 2> : dense_chain_kernel<4, 4, 1>)
+                                          : (RT == 2 ? dense_chain_kernel<8, 8, 2> : dense_chain_kernel<8, 8, 1>);
     da.ldx = dp.ldx; da.ld2 = dp.ld2; da.ld3 = dp.ld3;
     da.off_x = dp.off_x; da.off_h = dp.off_h; da.off_part = dp.off_part; da.off_y2 = dp.off_y2; da.off_y3 = dp.off_y3;
     int conv_wgs = 0, dense_wgs = 0, n_train = 0;
@@ -818,7 +861,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
             Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod; Q->last_train_packed = packed;
         }
         D.q_out = jb.q_dev;
-        dense_wgs += (jb.batch + DENSE_ROWS - 1) / DENSE_ROWS;
+        dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
     }
     dq_prof_begin(DQ_K_CONV_CHAIN, st);
     ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);

@@ -28,7 +28,7 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod):
     double-DQN update, Adam -- against the same loop assembled from the CPU oracles, for several vector steps.
     Actions / observations / rewards must be identical; parameters agree to fp32 round-off."""
     torch = torch_mod
-    N, B, steps, eps, gamma, lr = 16, 8, 6, 0.3, 0.99, 1e-3
+    N, B, steps, eps, gamma, lr = 16, 8, 9, 0.3, 0.99, 1e-3
     seed = (0x5EED, 0xD0DEC0DE)
     env = dq.VectorEnv(n_envs=N, seed=seed, **C1)
     net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=max(N, B))
@@ -44,11 +44,16 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod):
     ring_a, ring_r, ring_t = np.zeros((T, N), np.int32), np.zeros((T, N), np.float32), np.zeros((T, N), np.uint8)
     core.reset_env()
     ref.reset()
-    cur, filled = 0, 1
+    cur, filled, n_updates = 0, 1, 0
     ring_obs[0] = ref.obs
     for t in range(steps):
-        # --- act
-        core.act_and_step(eps, presample=(t % 2 == 0))          # the sampling rides on the env launch every other step: same draws
+        # --- act (+ update): the three ways of driving the device loop give the same draws and the same arithmetic
+        will_update = min(T, filled + 1) >= 4                    # keras-rl never samples the two newest transitions
+        fused = will_update and t % 3 == 2                       # acting forward + the update's forwards in one pair of launches
+        if fused:
+            core.step_and_update(eps, presample_next=(t % 2 == 0))
+        else:
+            core.act_and_step(eps, presample=(t % 2 == 0))          # the sampling rides on the env launch every other step
         q, _ = O.forward(spec, p, ring_obs[cur])
         acts = np.zeros(N, np.int32)
         for i in range(N):
@@ -63,15 +68,20 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod):
         assert np.array_equal(core.reward_ring[cur].cpu().numpy(), ref.reward) and np.array_equal(core.terminal_ring[cur].cpu().numpy(), ref.done)
         cur, filled = nxt, min(T, filled + 1)
         # --- update
-        core.update()
-        u = t + 1
+        if not will_update:
+            continue
+        if not fused:
+            core.update()
+        n_updates += 1
+        u = n_updates
+        assert core.updates == u
         idx = core.index.cpu().numpy()
-        cand = filled - 1
+        cand = filled - 3
         for b in range(B):                                                     # replay rows follow the Philox definition
             for attempt in range(64):
                 w = philox.philox4x32((u, 0, b, attempt | (philox.STREAM_REPLAY << 16)), seed)
                 j, e = philox.bounded(w[0], cand), philox.bounded(w[1], N)
-                s = (cur - 1 - j) % T
+                s = (cur - 3 - j) % T
                 if j + 1 >= cand or not ring_t[(s - 1) % T, e]:
                     break
             assert idx[b] == s * N + e

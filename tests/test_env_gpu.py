@@ -314,7 +314,7 @@ def test_act_step_with_replay_sampling_equals_the_separate_calls(dq, torch_mod):
     act_a, act_b = (torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(2))
     idx_b = torch.empty(batch, dtype=torch.int32, device="cuda")
     for t in range(12):
-        head, filled = (t + 3) % n_slots, min(n_slots, t + 2)
+        head, filled = (t + 5) % n_slots, min(n_slots, t + 4)
         for env, act in ((a_env, act_a),):
             lib.check(L.dq_env_act_step(env._h, None, 1.0, 0, seed, t, p(act), 1, p(env.obs), p(env.reward), p(env.done), p(env.legal),
                                         p(env.lifetime), p(env.was_reset), lib.current_stream()))

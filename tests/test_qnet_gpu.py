@@ -273,8 +273,8 @@ def test_fused_td_update_and_post_step_equal_the_separate_kernels(dq, torch_mod)
 
 
 def test_replay_sample_rule(dq, torch_mod):
-    """Sampled rows are complete transitions, never start at a post-terminal entry, match the Philox definition,
-    and cover the ring roughly uniformly."""
+    """Sampled rows are the transitions keras-rl's SequentialMemory.sample can return (complete ones except the two newest), never
+    start at a post-terminal entry, match the Philox definition, and cover the ring roughly uniformly."""
     torch = torch_mod
     rng = np.random.RandomState(2)
     n_envs, n_slots, head, filled, batch = 64, 50, 17, 50, 20000
@@ -282,7 +282,8 @@ def test_replay_sample_rule(dq, torch_mod):
     seed, t, base = (8, 9), 55, 1000
     idx = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, batch, seed, t, sample_base=base).cpu().numpy()
     slot, env = idx // n_envs, idx % n_envs
-    assert (slot != head).all()                                        # the newest observation has no successor yet
+    newest3 = np.array([head, (head - 1) % n_slots, (head - 2) % n_slots])
+    assert not np.isin(slot, newest3).any()                            # newest observation (no successor yet) + the two newest transitions
     prev = (slot - 1) % n_slots
     oldest = (head + 1) % n_slots
     bad = (term[prev, env] == 1) & (slot != oldest)
@@ -291,16 +292,18 @@ def test_replay_sample_rule(dq, torch_mod):
     for b in range(50):
         for attempt in range(64):
             w = philox.philox4x32((t, 0, base + b, attempt | (philox.STREAM_REPLAY << 16)), seed)
-            j, e = philox.bounded(w[0], filled - 1), philox.bounded(w[1], n_envs)
-            s = (head - 1 - j) % n_slots
-            if j + 1 >= filled - 1 or not term[(s - 1) % n_slots, e]:
+            j, e = philox.bounded(w[0], filled - 3), philox.bounded(w[1], n_envs)
+            s = (head - 3 - j) % n_slots
+            if j + 1 >= filled - 3 or not term[(s - 1) % n_slots, e]:
                 break
         assert idx[b] == s * n_envs + e
     counts = np.bincount(slot, minlength=n_slots)
-    assert counts[head] == 0 and counts[np.arange(n_slots) != head].min() > 0.5 * batch / n_slots
+    assert counts[newest3].sum() == 0 and counts[~np.isin(np.arange(n_slots), newest3)].min() > 0.5 * batch / n_slots
     # partially filled ring: only written slots are sampled
     idx2 = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, 5, 6, 5000, seed, t).cpu().numpy()
-    assert set(np.unique(idx2 // n_envs)) <= {0, 1, 2, 3, 4}
+    assert set(np.unique(idx2 // n_envs)) == {0, 1, 2}
+    with pytest.raises(dq.DeepQError):                                 # fewer than three complete transitions
+        dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, 2, 3, 10, seed, t)
 
 
 def test_one_full_update_matches_oracle(dq, torch_mod):
