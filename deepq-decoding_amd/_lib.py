@@ -51,6 +51,16 @@ class SampleJob(ctypes.Structure):
                 ("sample_base", ctypes.c_uint32), ("index_dev", ctypes.c_void_p)]
 
 
+class TdJob(ctypes.Structure):
+    """dq_td_job (include/deepq_hip.h)."""
+    _fields_ = [("q_online_s1_dev", ctypes.c_void_p), ("q_target_s1_dev", ctypes.c_void_p), ("q_s0_dev", ctypes.c_void_p),
+                ("reward_dev", ctypes.c_void_p), ("terminal_dev", ctypes.c_void_p), ("action_dev", ctypes.c_void_p),
+                ("index_dev", ctypes.c_void_p), ("gamma", ctypes.c_double), ("grad_scale", ctypes.c_double), ("batch", ctypes.c_int32),
+                ("n_actions", ctypes.c_int32), ("y_dev", ctypes.c_void_p), ("dq_dev", ctypes.c_void_p), ("metrics_dev", ctypes.c_void_p),
+                ("done_dev", ctypes.c_void_p), ("was_reset_dev", ctypes.c_void_p), ("lifetime_dev", ctypes.c_void_p),
+                ("step_reward_dev", ctypes.c_void_p), ("n", ctypes.c_int32), ("stats_dev", ctypes.c_void_p)]
+
+
 _vp, _i, _u32, _u64, _dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
 _sz = ctypes.c_size_t
 _seedp = ctypes.POINTER(ctypes.c_uint32)
@@ -91,6 +101,7 @@ SIGNATURES = {
     "dq_qnet_backward_phase": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "dq_qnet_conv_param_count": (_sz, [_vp]),
     "dq_qnet_backward_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
+    "dq_qnet_td_backward_adam": (_i, [_vp, _vp, ctypes.POINTER(TdJob), _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
     "dq_replay_sample": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
     "dq_td_target": (_i, [_vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _vp, _vp]),
     "dq_td_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _vp, _vp, _vp]),

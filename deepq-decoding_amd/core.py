@@ -191,11 +191,13 @@ class DQNCore:
             (slot,), env = self._stats_pending, self.env
             step_stats = (self.terminal_ring[slot], env.was_reset, env.lifetime, self.reward_ring[slot], N, self.stats)
             self._stats_pending = None
-        _q.td_update(q_sel, self.q1_target, self.q0, self.reward_ring, self.terminal_ring, self.action_ring, self.gamma,
-                     grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, y=self.y, dq=self.dq, metrics=self.metrics,
-                     step_stats=step_stats)
+        td = dict(q_online_s1=q_sel, q_target_s1=self.q1_target, q_s0=self.q0, reward=self.reward_ring, terminal=self.terminal_ring,
+                  action=self.action_ring, gamma=self.gamma, grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, y=self.y,
+                  dq=self.dq, metrics=self.metrics, step_stats=step_stats)
         self._metrics_stale = True
         if self.world_size > 1:
+            _q.td_update(td["q_online_s1"], td["q_target_s1"], td["q_s0"], td["reward"], td["terminal"], td["action"], td["gamma"],
+                         grad_scale=td["grad_scale"], index=td["index"], y=td["y"], dq=td["dq"], metrics=td["metrics"], step_stats=step_stats)
             # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs
             nconv = net.n_conv_params
             net.backward_phase(self.params, self.dq, self.grads, 0)
@@ -206,7 +208,8 @@ class DQNCore:
                 work.wait()
             _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
         else:
-            net.backward_adam(self.params, self.dq, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+            # TD step in the backward's first launch, Adam on its last
+            net.td_backward_adam(self.params, td, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
         self.repack()
 
     def step_and_update(self, eps, masked_greedy=False, record_stats=True, presample_next=True):

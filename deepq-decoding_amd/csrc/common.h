@@ -130,14 +130,14 @@ __device__ __forceinline__ int dq_replay_row(const u8* __restrict__ terminal, in
     return row;
 }
 
-// Episode bookkeeping of lattice i (one thread per lattice, 256-thread workgroups, every thread calls): stats[0] += #episodes that ended
+// Episode bookkeeping of lattice i (one thread per lattice, workgroups of up to 8 waves, every thread calls): stats[0] += #episodes that ended
 // this step, stats[1] += sum of their lifetimes, stats[2] += #rewards == 1, stats[3] += #lattices stepped (not reset).  Ballots per
-// wave, the four waves combined through LDS, then at most four atomics per workgroup (atomics on one word serialise at ~10 ns each:
+// wave, the waves combined through LDS, then at most four atomics per workgroup (atomics on one word serialise at ~10 ns each:
 // per-wave atomics cost the TD launch 2.5 us).  Integer sums => order-independent.
 __device__ __forceinline__ void dq_episode_stats_lane(const u8* __restrict__ done, const u8* __restrict__ was_reset,
                                                       const u32* __restrict__ lifetime, const float* __restrict__ reward, int n, int i,
                                                       unsigned long long* __restrict__ stats) {
-    __shared__ unsigned long long s_st[4][4];
+    __shared__ unsigned long long s_st[8][4];
     const bool in = i < n;
     const bool stepped = in && !(was_reset && was_reset[i]);
     const bool ended = stepped && done[i];
@@ -145,7 +145,7 @@ __device__ __forceinline__ void dq_episode_stats_lane(const u8* __restrict__ don
     unsigned long long life = ended ? lifetime[i] : 0;
     for (int m = 32; m >= 1; m >>= 1) life += __shfl_xor(life, m);
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0 && wave < 4) {
+    if ((threadIdx.x & 63) == 0 && wave < 8) {
         s_st[wave][0] = (unsigned long long)__popcll(m_end); s_st[wave][1] = life;
         s_st[wave][2] = (unsigned long long)__popcll(m_rew); s_st[wave][3] = (unsigned long long)__popcll(m_step);
     }
@@ -153,7 +153,7 @@ __device__ __forceinline__ void dq_episode_stats_lane(const u8* __restrict__ don
     const int nw = (blockDim.x + 63) >> 6;
     if (threadIdx.x < 4) {
         unsigned long long v = 0;
-        for (int w = 0; w < nw && w < 4; ++w) v += s_st[w][threadIdx.x];
+        for (int w = 0; w < nw && w < 8; ++w) v += s_st[w][threadIdx.x];
         if (v) atomicAdd(&stats[threadIdx.x], v);
     }
 }

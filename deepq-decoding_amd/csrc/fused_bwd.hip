@@ -34,6 +34,8 @@ struct DenseBwdArgs {
     float* gx;                          // [batch, K1] NHWC
     int ldg;                            // LDS row stride of the g3 / gY2 images (floats)
     int off_g3, off_gy2, off_gh1;
+    int td_on, dense_wgs;               // td_on: dq is computed here from `td`; workgroups >= dense_wgs do the episode bookkeeping
+    TdFused td;
 };
 
 // NTP adjacent column tiles [tile0, tile0 + NTP) of gX for this wave: tile t, lane j is column 16*tile0 + NTP*j + t, so the lane's
@@ -103,32 +105,124 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     const int ns = min(DENSE_ROWS, a.batch - b0);
     const int A = a.n_actions, N2 = a.N2, N3 = a.N3, ldg = a.ldg;
 
+    if ((int)blockIdx.x >= a.dense_wgs) {                           // the episode bookkeeping of the step just taken rides along
+        dq_episode_stats_lane(a.td.st_done, a.td.st_was_reset, a.td.st_lifetime, a.td.st_reward, a.td.st_n,
+                              ((int)blockIdx.x - a.dense_wgs) * DENSE_THREADS + tid, a.td.st_stats);
+        return;
+    }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 0);
+    __shared__ float s_met[DENSE_WAVES][2];
     for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) { s_g3[i] = 0.f; s_gy2[i] = 0.f; }
     __syncthreads();
-    // ---- dueling backward: g3[b,0] = sum_a dq[b,a];  g3[b,1+a] = dq[b,a] - (1/A) sum_a' dq[b,a'] ----------------------
-    for (int row = wave; row < ns; row += DENSE_WAVES) {
-        const float* dr = a.dq + (size_t)(b0 + row) * A;
+    // ---- (TD step: y = r + gamma (1 - terminal) Q_target(s1)[argmax Q_online(s1)], dq = (Q(s0)[a] - y) * scale at the action taken,
+    //      dqn.hip td_update_kernel's arithmetic, one wave per sample) then the dueling backward:
+    //      g3[b,0] = sum_a dq[b,a];  g3[b,1+a] = dq[b,a] - (1/A) sum_a' dq[b,a'] ---------------------------------------------
+    float loss = 0.f, mq = 0.f;
+    constexpr int RPW = DENSE_ROWS / DENSE_WAVES;                   // rows per wave (2): their loads are issued together, in two dependent
+    static_assert(RPW == 2, "two rows per wave");                   // stages (a row at a time was ten serial latencies: +6 us)
+    float yb[RPW] = {0.f, 0.f}, qv[RPW][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    int a_b[RPW] = {-1, -1};
+    if (a.td_on) {
+        float q1[RPW][2];
+        int ridx[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {                             // stage 1: everything that needs only the sample number
+            const int b = b0 + min(wave + DENSE_WAVES * u, ns - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                const bool ok = c < A;
+                q1[u][h] = a.td.q1o[(size_t)b * A + (ok ? c : 0)];
+                qv[u][h] = a.td.q0[(size_t)b * A + (ok ? c : 0)];
+            }
+            ridx[u] = a.td.index ? a.td.index[b] : b;
+        }
+        float rw[RPW], qt[RPW];
+        int term[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {                             // stage 2: behind the replay row and the arg-max
+            const int b = b0 + min(wave + DENSE_WAVES * u, ns - 1);
+            float best = -INFINITY;
+            int best_a = 0x7fffffff;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                if (c < A && (best_a == 0x7fffffff || q1[u][h] > best)) { best = q1[u][h]; best_a = c; }
+            }
+            for (int m = 32; m >= 1; m >>= 1) {
+                const float ov = __shfl_xor(best, m);
+                const int oa = __shfl_xor(best_a, m);
+                if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
+            }
+            rw[u] = a.td.reward[ridx[u]];
+            term[u] = a.td.terminal[ridx[u]];
+            a_b[u] = a.td.action[ridx[u]];
+            qt[u] = a.td.q1t[(size_t)b * A + best_a];
+        }
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int row = wave + DENSE_WAVES * u;
+            if (row >= ns) continue;
+            const int b = b0 + row;
+            yb[u] = rw[u] + (term[u] ? 0.f : a.td.gamma * qt[u]);
+            if (lane == 0 && a.td.y_out) a.td.y_out[b] = yb[u];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) if (lane + 64 * h < A) mx = fmaxf(mx, qv[u][h]);
+            for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+            // Q(s0)[a_b] lives in lane a_b & 63, half a_b >> 6
+            const float qa0 = __shfl(qv[u][0], a_b[u] & 63), qa1 = __shfl(qv[u][1], a_b[u] & 63);
+            const float diff = (a_b[u] < 64 ? qa0 : qa1) - yb[u];
+            loss += 0.5f * diff * diff;
+            mq += mx;
+            if (a.td.dq_out)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = lane + 64 * h;
+                    if (c < A) a.td.dq_out[(size_t)b * A + c] = c == a_b[u] ? (qv[u][h] - yb[u]) * a.td.grad_scale : 0.f;
+                }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+        const int row = wave + DENSE_WAVES * u;
+        if (row >= ns) continue;
+        const int b = b0 + row;
+        const float* dr = a.dq + (size_t)b * A;
+        auto dval = [&](int h) {                                    // dq[b][lane + 64 h]
+            const int c = lane + 64 * h;
+            return a.td_on ? (c == a_b[u] ? (qv[u][h] - yb[u]) * a.td.grad_scale : 0.f) : dr[c];
+        };
         if (N3 > 0) {
             float s = 0.f;
-            for (int c = lane; c < A; c += 64) s += dr[c];
+            for (int h = 0; lane + 64 * h < A; ++h) s += dval(h);
             for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-            float* o = a.g3 + (size_t)(b0 + row) * N3;
+            float* o = a.g3 + (size_t)b * N3;
             if (lane == 0) { s_g3[row * ldg] = s; o[0] = s; }
-            for (int c = lane; c < A; c += 64) {
-                const float v = dr[c] - s / (float)A;
+            for (int h = 0; lane + 64 * h < A; ++h) {
+                const int c = lane + 64 * h;
+                const float v = dval(h) - s / (float)A;
                 s_g3[row * ldg + 1 + c] = v;
                 o[1 + c] = v;
             }
         } else {
-            for (int c = lane; c < A; c += 64) {
-                const float v = dr[c];
+            for (int h = 0; lane + 64 * h < A; ++h) {
+                const int c = lane + 64 * h;
+                const float v = dval(h);
                 s_gy2[row * ldg + c] = v;
-                a.gy2[(size_t)(b0 + row) * N2 + c] = v;
+                a.gy2[(size_t)b * N2 + c] = v;
             }
         }
     }
+    if (a.td_on && lane == 0) { s_met[wave][0] = loss; s_met[wave][1] = mq; }
     __syncthreads();
+    if (a.td_on && a.td.metrics && tid == 0) {                      // this workgroup's partial, and zeros in the slots nobody owns
+        float l = 0.f, q = 0.f;
+        for (int w = 0; w < DENSE_WAVES; ++w) { l += s_met[w][0]; q += s_met[w][1]; }
+        a.td.metrics[2 + 2 * blockIdx.x] = l;
+        a.td.metrics[3 + 2 * blockIdx.x] = q;
+        for (int k = blockIdx.x + a.dense_wgs; k < a.td.metric_slots; k += a.dense_wgs) { a.td.metrics[2 + 2 * k] = 0.f; a.td.metrics[3 + 2 * k] = 0.f; }
+    }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 1);
     // ---- gY2 = g3 W3^T  (K = N3, one column tile per wave) -------------------------------------------------------------
     if (N3 > 0) {
@@ -859,7 +953,8 @@ typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
 // phases: bit 0 = dense part (data gradients, dense weight gradients reduced into grads_dev[conv params ..)), bit 1 = convolutional
 // part (grads_dev[0 .. conv params)).  3 = whole backward with one reduction launch.
 dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st,
-                         const AdamOpt* opt) {
+                         const AdamOpt* opt, const TdFused* td) {
+    DQ_REQUIRE(!td || (phases & 1), DQ_ERR_INVALID, "fused_backward: the TD step belongs to the dense phase");
     DQ_REQUIRE(!opt || phases == 3, DQ_ERR_INVALID, "fused_backward: the fused optimizer step needs the whole backward in one call");
     DenseBwdPlan dp;
     ConvBwdPlan cp;
@@ -898,9 +993,15 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     da.mask_scale = D1.dropout > 0.f ? (float)(1.0 / (1.0 - (double)D1.dropout)) : 1.f;
     da.g3 = Q->cfg.dueling ? Q->gz[nc + 2] : nullptr; da.gy2 = Q->gz[nc + 1]; da.gh1 = Q->gz[nc]; da.gx = Q->gz[nc - 1];
     da.ldg = dp.ldg; da.off_g3 = dp.off_g3; da.off_gy2 = dp.off_gy2; da.off_gh1 = dp.off_gh1;
+    da.dense_wgs = (B + DENSE_ROWS - 1) / DENSE_ROWS;
+    int stat_wgs = 0;
+    if (td) {
+        da.td_on = 1; da.td = *td;
+        if (td->st_n > 0) stat_wgs = (td->st_n + DENSE_THREADS - 1) / DENSE_THREADS;
+    }
     dq_prof_begin(DQ_K_DENSE_BWD, st);
-    if (dp.NT2 == 4) dense_bwd_chain_kernel<4><<<(B + DENSE_ROWS - 1) / DENSE_ROWS, DENSE_THREADS, dp.lds, st>>>(da);
-    else dense_bwd_chain_kernel<7><<<(B + DENSE_ROWS - 1) / DENSE_ROWS, DENSE_THREADS, dp.lds, st>>>(da);
+    if (dp.NT2 == 4) dense_bwd_chain_kernel<4><<<da.dense_wgs + stat_wgs, DENSE_THREADS, dp.lds, st>>>(da);
+    else dense_bwd_chain_kernel<7><<<da.dense_wgs + stat_wgs, DENSE_THREADS, dp.lds, st>>>(da);
     dq_prof_end(DQ_K_DENSE_BWD, st);
     DQ_LAUNCH_CHECK();
 

@@ -131,5 +131,20 @@ size_t fused_packed_w1t_u32x4(const dq_qnet* Q);           // u32x4 offset of W1
 size_t fused_packed_w2t_u32x4(const dq_qnet* Q);           // ... of W2T
 // opt != NULL (phases == 3 only): the final reduction also applies the Adam update to p/m/v (one launch fewer per update)
 struct AdamOpt { float* p; float* m; float* v; float lr_t, b1, b2, eps; };
+// td != NULL: the TD step (dq_td_update's arithmetic) runs in the dense backward's prologue instead of reading dq_dev, and the episode
+// bookkeeping of the step just taken (st_n > 0) rides on the same launch
+struct TdFused {
+    const float *q1o, *q1t, *q0, *reward;
+    const u8* terminal;
+    const int32_t *action, *index;
+    float gamma, grad_scale;
+    float *y_out, *dq_out, *metrics;    // nullable
+    int metric_slots;                   // partial slots dq_td_metrics will read for this batch
+    const u8 *st_done, *st_was_reset;
+    const u32* st_lifetime;
+    const float* st_reward;
+    int st_n;
+    unsigned long long* st_stats;
+};
 dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st,
-                         const AdamOpt* opt = nullptr);
+                         const AdamOpt* opt = nullptr, const TdFused* td = nullptr);

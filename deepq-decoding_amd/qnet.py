@@ -200,6 +200,29 @@ def _backward_adam(self, params, dq, grads, m, v, t, lr, beta_1=0.9, beta_2=0.99
 QNetwork.backward_adam = _backward_adam
 
 
+def _td_backward_adam(self, params, td, grads, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    """td_update() (+ episode bookkeeping) + backward() + adam_step() with the TD step computed by the backward's first kernel and the
+    optimizer step applied by its last one.  td: dict with q_online_s1, q_target_s1, q_s0, reward, terminal, action, index, gamma,
+    grad_scale and optional y, dq, metrics, step_stats = (done, was_reset, lifetime, reward, n, stats)."""
+    B, A = td["q_s0"].shape
+    j = _lib.TdJob()
+    j.q_online_s1_dev, j.q_target_s1_dev, j.q_s0_dev = ptr(td["q_online_s1"]), ptr(td["q_target_s1"]), ptr(td["q_s0"])
+    j.reward_dev, j.terminal_dev, j.action_dev, j.index_dev = ptr(td["reward"]), ptr(td["terminal"]), ptr(td["action"]), ptr(td.get("index"))
+    j.gamma, j.grad_scale, j.batch, j.n_actions = float(td["gamma"]), float(td.get("grad_scale") or 1.0 / B), B, A
+    j.y_dev, j.dq_dev, j.metrics_dev = ptr(td.get("y")), ptr(td.get("dq")), ptr(td.get("metrics"))
+    st = td.get("step_stats")
+    if st is not None:
+        done, was_reset, lifetime, step_reward, n, stats = st
+        j.done_dev, j.was_reset_dev, j.lifetime_dev, j.step_reward_dev, j.n, j.stats_dev = (ptr(done), ptr(was_reset), ptr(lifetime),
+                                                                                            ptr(step_reward), int(n), ptr(stats))
+    check(self.L.dq_qnet_td_backward_adam(self._h, ptr(params), ctypes.byref(j), ptr(grads), ptr(m), ptr(v), float(lr), float(beta_1),
+                                          float(beta_2), float(epsilon), int(t), self._stream()))
+    return grads
+
+
+QNetwork.td_backward_adam = _td_backward_adam
+
+
 def td_target(q_online_s1, q_target_s1, reward, terminal, gamma, index=None, out=None):
     B, A = q_online_s1.shape
     if out is None:

@@ -270,6 +270,33 @@ size_t dq_qnet_conv_param_count(const dq_qnet* net);
 dq_status dq_qnet_backward_adam(dq_qnet* net, float* params_dev, const float* dq_dev, float* grads_dev, float* m_dev, float* v_dev,
                                 double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
 
+/* The learner half of one DQNAgent.backward in the fewest launches: dq_td_update (+ dq_episode_stats when n > 0) computed in the
+ * dense backward's first kernel, then dq_qnet_backward, then dq_adam_step on the final reduction.  Same y / dq / gradient / parameter
+ * bits as the separate calls; the loss / mean_q partials are summed in a different order (dq_td_metrics reads them the same way).
+ * y_dev, dq_dev (needed only by the per-layer path), metrics_dev nullable. */
+typedef struct dq_td_job {
+    const float* q_online_s1_dev;
+    const float* q_target_s1_dev;
+    const float* q_s0_dev;
+    const float* reward_dev;        /* replay ring arrays, indexed through index_dev */
+    const uint8_t* terminal_dev;
+    const int32_t* action_dev;
+    const int32_t* index_dev;
+    double gamma, grad_scale;
+    int batch, n_actions;
+    float* y_dev;
+    float* dq_dev;
+    float* metrics_dev;
+    const uint8_t* done_dev;        /* episode bookkeeping of the step just taken (dq_episode_stats arguments); n == 0: none */
+    const uint8_t* was_reset_dev;
+    const uint32_t* lifetime_dev;
+    const float* step_reward_dev;
+    int n;
+    uint64_t* stats_dev;
+} dq_td_job;
+dq_status dq_qnet_td_backward_adam(dq_qnet* net, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev,
+                                   double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DQN update: replaces SequentialMemory.sample + DQNAgent.backward + keras Adam of the keras-rl fork
  * (Single_Point_Training_Script.py:109,119-130).

@@ -183,6 +183,49 @@ def test_backward_adam_equals_backward_then_adam(dq, torch_mod, fused):
     assert not torch.equal(pa, params)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
+def test_td_backward_adam_equals_the_separate_calls(dq, torch_mod, fused):
+    """dq_qnet_td_backward_adam == dq_td_update_stats + dq_qnet_backward + dq_adam_step: y, dq, gradient, parameters, moments and the
+    episode counters bit for bit; loss / mean_q to round-off (their partials are summed in another order)."""
+    torch = torch_mod
+    from importlib import import_module
+    Q = import_module("deepq-decoding_amd.qnet")
+    B, A, R = 100, 51, 700
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", B, fused=fused)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    obs_t = cu(obs)
+    q1o, q1t = (cu(rng.randn(B, A).astype(np.float32)) for _ in range(2))
+    reward, terminal = cu((rng.rand(R) < 0.4).astype(np.float32)), cu((rng.rand(R) < 0.2).astype(np.uint8))
+    action, idx = cu(rng.randint(0, A, size=R).astype(np.int32)), cu(rng.randint(0, R, size=B).astype(np.int32))
+    n_envs = 900
+    done, was_reset = cu((rng.rand(n_envs) < 0.3).astype(np.uint8)), cu((rng.rand(n_envs) < 0.1).astype(np.uint8))
+    life, rew = cu(rng.randint(1, 100, size=n_envs).astype(np.uint32)), cu((rng.rand(n_envs) < 0.5).astype(np.float32))
+    out = {}
+    for name in ("separate", "one"):
+        p_, m_, v_ = params.clone(), torch.zeros_like(params), torch.zeros_like(params)
+        g_ = torch.empty_like(params)
+        stats = torch.zeros(4, dtype=torch.int64, device="cuda")
+        met = torch.full((Q.TD_METRICS_FLOATS,), 7.0, dtype=torch.float32, device="cuda")
+        y, dq_ = torch.empty(B, device="cuda"), torch.empty((B, A), device="cuda")
+        for t in (1, 2):
+            q0 = net.forward(p_, obs_t, training=True, seed=(1, 2), t=t)
+            td = dict(q_online_s1=q1o, q_target_s1=q1t, q_s0=q0, reward=reward, terminal=terminal, action=action, gamma=0.99,
+                      grad_scale=1.0 / B, index=idx, y=y, dq=dq_, metrics=met, step_stats=(done, was_reset, life, rew, n_envs, stats))
+            if name == "separate":
+                Q.td_update(q1o, q1t, q0, reward, terminal, action, 0.99, grad_scale=1.0 / B, index=idx, y=y, dq=dq_, metrics=met,
+                            step_stats=td["step_stats"])
+                net.backward(p_, dq_, grads=g_)
+                Q.adam_step(p_, g_, m_, v_, t, 1e-3)
+            else:
+                net.td_backward_adam(p_, td, g_, m_, v_, t, 1e-3)
+            Q.td_metrics(met, B)
+        out[name] = [x.clone() for x in (y, dq_, g_, p_, m_, v_, stats, met[:2])]
+    for a, b in zip(out["separate"][:7], out["one"][:7]):
+        assert torch.equal(a, b)
+    assert torch.allclose(out["separate"][7], out["one"][7], rtol=1e-5, atol=1e-7)
+    assert out["one"][6].tolist()[3] == 2 * int((was_reset == 0).sum())
+
+
 def test_fused_and_per_layer_paths_agree(dq, torch_mod):
     """The two HIP forward/backward implementations order their dot products differently: same results to f32 round-off."""
     torch = torch_mod
