@@ -77,7 +77,8 @@ class ConvQModel:
         if w is None:
             raise RuntimeError("model has no weights yet (fit/compile against an environment first)")
         from .weights_io import save_weights_file
-        save_weights_file(filepath, w, self.layer_names())
+        dueling = len(w) // 2 == len(self.c_layers) + len(self.ff_layers) + 2      # Dense(|A|) + keras-rl's Dense(|A|+1)
+        save_weights_file(filepath, w, self.layer_names(dueling), dueling=dueling)
 
     def load_weights(self, filepath):
         from .weights_io import load_weights_file

@@ -104,6 +104,31 @@ class _File:
         n = int(np.prod(dims)) if dims else 1
         return np.frombuffer(self.b, dtype="<f4", count=n, offset=addr).reshape(dims).copy()
 
+    def attributes(self, header_addr):
+        """{name: list of bytes | bytes | None} for the attribute messages (version 1) of an object: fixed-length string arrays and
+        scalars are decoded, anything else (the shipped files keep `backend` / `keras_version` as variable-length strings in a
+        global heap) is reported as None."""
+        out = {}
+        for mtype, data, _ in self.messages(header_addr):
+            if mtype != 0x0C or self.b[data] != 1:
+                continue
+            nsz, tsz, ssz = self.u16(data + 2), self.u16(data + 4), self.u16(data + 6)
+            pad = lambda n: (n + 7) & ~7
+            o = data + 8
+            name = self.b[o:o + nsz].split(b"\x00")[0].decode()
+            o += pad(nsz)
+            cls, width = self.b[o] & 0x0F, self.u32(o + 4)
+            o += pad(tsz)
+            rank = self.b[o + 1]
+            count = self.u64(o + 8) if rank == 1 else 1
+            o += pad(ssz)
+            if cls != 3 or rank > 1:
+                out[name] = None
+                continue
+            vals = [self.b[o + i * width:o + (i + 1) * width].rstrip(b"\x00") for i in range(count)]
+            out[name] = vals if rank == 1 else vals[0]
+        return out
+
     def walk(self, header_addr=None, prefix=""):
         header_addr = self.root_header if header_addr is None else header_addr
         for name, child in self.children(header_addr):
@@ -113,6 +138,20 @@ class _File:
                 yield path, arr
             else:
                 yield from self.walk(child, path)
+
+
+def read_attributes(path):
+    """{group path: {attribute: value}} for the root group and every group below it."""
+    f = _File(path)
+    out = {}
+
+    def rec(addr, prefix):
+        out[prefix or "/"] = f.attributes(addr)
+        for name, child in f.children(addr):
+            if f.dataset(child) is None:
+                rec(child, f"{prefix}/{name}")
+    rec(f.root_header, "")
+    return out
 
 
 def read_datasets(path):

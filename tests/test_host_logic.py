@@ -143,6 +143,42 @@ def test_weights_file_roundtrip(agent_mod, tmp_path):
     assert len(back) == 4 and all(np.array_equal(a, b) for a, b in zip(w, back))
 
 
+def test_hdf5_writer_produces_the_shipped_files_structure(tmp_path):
+    """save_weights writes a Keras 2.x HDF5 file: the shipped agent's tensors (golden fixture) survive the trip bit for bit, the tree
+    and the attributes Keras' load_weights reads (layer_names, weight_names, keras_version, backend) are as in the shipped files,
+    and the container obeys the format's bookkeeping (superblock, end-of-file address, 8-byte alignment, sorted symbol tables)."""
+    import struct
+    h = importlib.import_module("deepq-decoding_amd.hdf5_reader")
+    wio = importlib.import_module("deepq-decoding_amd.weights_io")
+    fx = load_golden("keras_weights_d5_dp_0.007")
+    w = [fx[f"w{i}"] for i in range(12)]
+    names = ["conv2d_1", "conv2d_2", "conv2d_3", "dense_1", "dense_2", "dense_3"]
+    p = str(tmp_path / "final_dqn_weights.h5f")
+    wio.save_weights_file(p, w, names)
+    raw = open(p, "rb").read()
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n" and raw[8:16] == bytes([0, 0, 0, 0, 0, 8, 8, 0])        # superblock v0, 8-byte offsets / lengths
+    assert struct.unpack_from("<HH", raw, 16) == (4, 16)                                            # group leaf / internal K, as shipped
+    base, free, eof, drv = struct.unpack_from("<QQQQ", raw, 24)
+    assert base == 0 and eof == len(raw) and free == drv == 0xFFFFFFFFFFFFFFFF and len(raw) % 8 == 0
+    back = wio.load_weights_file(p)
+    assert all(np.array_equal(a, b) and b.dtype == np.float32 for a, b in zip(w, back))
+    ds = h.read_datasets(p)
+    assert sorted(ds) == sorted([f"/{n}/{n}/{t}:0" for n in names[:-1] for t in ("kernel", "bias")] +
+                                ["/dense_3/dense_3_1/kernel:0", "/dense_3/dense_3_1/bias:0"])               # keras-rl's dueling layer scope
+    at = h.read_attributes(p)
+    assert at["/"] == {"layer_names": [n.encode() for n in names], "backend": b"tensorflow", "keras_version": b"2.2.2"}
+    assert at["/conv2d_2"] == {"weight_names": [b"conv2d_2/kernel:0", b"conv2d_2/bias:0"]}
+    assert at["/dense_3"] == {"weight_names": [b"dense_3_1/kernel:0", b"dense_3_1/bias:0"]}
+    f = h._File(p)
+    for addr in [f.root_header] + [c for _, c in f.children(f.root_header)]:
+        kids = [n for n, _ in f.children(addr)]
+        assert kids == sorted(kids) and addr % 8 == 0
+    # a non-dueling network keeps the plain scope for its last layer
+    p2 = str(tmp_path / "w.h5")
+    wio.save_weights_file(p2, w[:10], names[:5], dueling=False)
+    assert "/dense_2/dense_2/kernel:0" in h.read_datasets(p2)
+
+
 def test_dropin_module_tree():
     """`from Environments import *`, `from rl.agents.dqn import DQNAgent` ... resolve to the GPU-backed classes."""
     sys.path.insert(0, os.path.join(ROOT, "deepq-decoding_amd", "dropin"))
@@ -182,3 +218,5 @@ def test_hdf5_reader_on_shipped_keras_weights():
     assert all(np.array_equal(a, b) for a, b in zip(wio.load_weights_file(REF_H5), w))
     names = sorted(h.read_datasets(REF_H5))
     assert names[0] == "/conv2d_1/conv2d_1/bias:0" and names[-1] == "/dense_3/dense_3_1/kernel:0"
+    at = h.read_attributes(REF_H5)                                   # the attribute parser the writer's test relies on, on a real file
+    assert at["/"]["layer_names"][:2] == [b"conv2d_1_input", b"conv2d_1"] and at["/dense_3"] == {"weight_names": [b"dense_3_1/kernel:0", b"dense_3_1/bias:0"]}
