@@ -276,6 +276,8 @@ class DQNAgent:
     def __init__(self, model, nb_actions, memory, nb_steps_warmup=1000, target_model_update=10000, policy=None, test_policy=None,
                  gamma=.99, enable_dueling_network=False, enable_double_dqn=True, dueling_type='avg', batch_size=32,
                  train_interval=1, memory_interval=1, delta_clip=np.inf, custom_model_objects=None, seed=None, **kwargs):
+        if hasattr(model, "_built"):                # a keras.models.Sequential stand-in (dropin/keras): resolve to the model description
+            model = model._built()
         if model.output_shape != (None, nb_actions):
             raise ValueError(f'Model output "{model.output_shape}" has invalid shape. DQN expects a model that has one dimension for each action, in this case {nb_actions}.')
         if dueling_type != 'avg':

@@ -222,3 +222,69 @@ def test_training_from_scratch_learns_to_decode(dq, torch_mod):
     life = float(np.mean(th.history["episode_lifetime"]))
     print("lifetime after 25 M steps:", life)
     assert life > 100.0, life
+
+
+def test_driver_style_script_on_the_dropin_tree(dq, torch_mod, tmp_path):
+    """The call sequence of the reference's single-point driver (build the network with keras.models.Sequential, SequentialMemory,
+    annealed epsilon-greedy policy, DQNAgent(...).compile(Adam), fit with the fork's keywords, pickle the memory, save_weights to
+    final_dqn_weights.h5f, a fresh agent that loads them, mutate env.p_phys / p_meas, test) through the reference-named modules under
+    dropin/ only -- what a maintainer gets by putting that directory on PYTHONPATH."""
+    import pickle
+    import sys
+    dropin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepq-decoding_amd", "dropin")
+    sys.path.insert(0, dropin)
+    try:
+        from keras.layers import Activation, Conv2D, Dense, Dropout, Flatten
+        from keras.models import Sequential
+        from keras.optimizers import Adam
+        from rl.agents.dqn import DQNAgent
+        from rl.callbacks import FileLogger
+        from rl.memory import SequentialMemory
+        from rl.policy import EpsGreedyQPolicy, GreedyQPolicy, LinearAnnealedPolicy
+        from Environments import Surface_Code_Environment_Multi_Decoding_Cycles
+
+        def network(cc, ff, input_shape, num_actions):
+            m = Sequential()
+            m.add(Conv2D(filters=cc[0][0], kernel_size=cc[0][1], strides=cc[0][2], input_shape=input_shape, data_format="channels_first"))
+            m.add(Activation("relu"))
+            for f, k, st in cc[1:]:
+                m.add(Conv2D(filters=f, kernel_size=k, strides=st, data_format="channels_first"))
+                m.add(Activation("relu"))
+            m.add(Flatten())
+            for units, rate in ff:
+                m.add(Dense(units))
+                m.add(Activation("relu"))
+                m.add(Dropout(rate=rate))
+            m.add(Dense(num_actions))
+            m.add(Activation("linear"))
+            return m
+
+        env = Surface_Code_Environment_Multi_Decoding_Cycles(d=3, p_phys=0.005, p_meas=0.005, error_model="X", use_Y=False, volume_depth=3,
+                                                             static_decoder=None)
+
+        def agent(policy):
+            a = DQNAgent(model=network(C_LAYERS, FF_LAYERS, env.observation_space.shape, env.num_actions), nb_actions=env.num_actions,
+                         memory=SequentialMemory(limit=5000, window_length=1), nb_steps_warmup=50, target_model_update=100, policy=policy,
+                         test_policy=GreedyQPolicy(masked_greedy=True), gamma=0.99, enable_dueling_network=True)
+            a.compile(Adam(lr=1e-4))
+            return a
+        dqn = agent(LinearAnnealedPolicy(EpsGreedyQPolicy(masked_greedy=False), attr="eps", value_max=1.0, value_min=0.02, value_test=0.0,
+                                         nb_steps=200))
+        log = FileLogger(filepath=str(tmp_path / "training_history.json"), interval=10)
+        hist = dqn.fit(env, nb_steps=300, action_repetition=1, callbacks=[log], verbose=0, visualize=False, nb_max_start_steps=0,
+                       start_step_policy=None, log_interval=10, nb_max_episode_steps=None, episode_averaging_length=10,
+                       success_threshold=10000, stopping_patience=1000, min_nb_steps=200, single_cycle=False)
+        assert "episode_lifetimes_rolling_avg" in hist.history
+        pickle.dump(dqn.memory, open(tmp_path / "memory.p", "wb"))
+        wfile = str(tmp_path / "final_dqn_weights.h5f")
+        dqn.save_weights(wfile, overwrite=True)
+        assert open(wfile, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+        dqn2 = agent(GreedyQPolicy(masked_greedy=True))
+        dqn2.model.load_weights(wfile)
+        assert all(np.array_equal(a, b) for a, b in zip(dqn.model.get_weights(), dqn2.model.get_weights()))
+        env.p_phys = 0.002
+        env.p_meas = 0.002
+        th = dqn2.test(env, nb_episodes=5, visualize=False, verbose=0, interval=10, single_cycle=False)
+        assert len(th.history["episode_lifetimes_rolling_avg"]) >= 1
+    finally:
+        sys.path.pop(0)

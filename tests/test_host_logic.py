@@ -201,6 +201,47 @@ def test_dropin_module_tree():
         sys.path.pop(0)
 
 
+def test_keras_and_gym_standins_recognise_the_reference_architecture():
+    """The driver scripts build their network with keras.models.Sequential + layer objects (Single_Point_Training_Script.py:61-90): the
+    stand-ins under dropin/ turn exactly that layer sequence into the model description, and refuse anything else loudly."""
+    sys.path.insert(0, os.path.join(ROOT, "deepq-decoding_amd", "dropin"))
+    try:
+        for m in [k for k in sys.modules if k == "keras" or k.startswith("keras.") or k == "gym" or k.startswith("gym.")]:
+            sys.modules.pop(m)
+        import gym
+        from keras.layers import Activation, Conv2D, Dense, Dropout, Flatten, MaxPooling2D
+        from keras.layers.advanced_activations import LeakyReLU                     # noqa: F401  (imported by the scripts, unused)
+        from keras.layers.normalization import BatchNormalization                   # noqa: F401
+        from keras.models import Sequential, load_model
+        from keras.optimizers import Adam
+        from keras.utils import np_utils
+        model = Sequential()
+        model.add(Conv2D(filters=64, kernel_size=3, strides=2, input_shape=(7, 11, 11), data_format="channels_first"))
+        model.add(Activation("relu"))
+        for f, k, st in ((32, 2, 1), (32, 2, 1)):
+            model.add(Conv2D(filters=f, kernel_size=k, strides=st, data_format="channels_first"))
+            model.add(Activation("relu"))
+        model.add(Flatten())
+        model.add(Dense(512))
+        model.add(Activation("relu"))
+        model.add(Dropout(rate=0.2))
+        model.add(Dense(51))
+        model.add(Activation("linear"))
+        assert model._describe() == ([[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]], (7, 11, 11), 51)
+        assert model.output_shape == (None, 51) and model.c_layers == [[64, 3, 2], [32, 2, 1], [32, 2, 1]]
+        assert Adam(lr=1e-4).lr == 1e-4 and gym.spaces.Box(low=0, high=1, shape=(7, 11, 11)).shape == (7, 11, 11)
+        assert gym.spaces.Discrete(51).n == 51 and np_utils.to_categorical([1, 0], 3).tolist() == [[0, 1, 0], [1, 0, 0]]
+        bad = Sequential([Conv2D(8, 3, input_shape=(4, 7, 7), data_format="channels_first"), Activation("relu"), MaxPooling2D()])
+        with pytest.raises(NotImplementedError):
+            bad._describe()
+        with pytest.raises(NotImplementedError):
+            Conv2D(8, 3, data_format="channels_last")
+        with pytest.raises(NotImplementedError):
+            load_model("static_decoder")
+    finally:
+        sys.path.pop(0)
+
+
 REF_H5 = "/root/reference/trained_models/d5_dp/0.007/final_dqn_weights.h5f"
 
 
