@@ -123,7 +123,12 @@ class SequentialMemory:
 
     @property
     def nb_entries(self):
-        return 0 if self._core is None else min(self._core.filled, self._core.T) * self._core.N
+        if self._core is not None:
+            return min(self._core.filled, self._core.T) * self._core.N
+        if self._saved is not None:                 # unpickled, not bound to an agent yet
+            T, N = self._saved["obs_shape"][:2]
+            return min(int(self._saved["filled"]), T) * N
+        return 0
 
     def get_config(self):
         return dict(limit=self.limit, window_length=1)

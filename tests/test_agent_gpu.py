@@ -286,5 +286,18 @@ def test_driver_style_script_on_the_dropin_tree(dq, torch_mod, tmp_path):
         env.p_meas = 0.002
         th = dqn2.test(env, nb_episodes=5, visualize=False, verbose=0, interval=10, single_cycle=False)
         assert len(th.history["episode_lifetimes_rolling_avg"]) >= 1
+        # the continue-training driver: unpickled memory + initial weights, then fit again
+        mem = pickle.load(open(tmp_path / "memory.p", "rb"))
+        entries = mem.nb_entries
+        assert entries >= 300
+        dqn3 = DQNAgent(model=network(C_LAYERS, FF_LAYERS, env.observation_space.shape, env.num_actions), nb_actions=env.num_actions,
+                        memory=mem, nb_steps_warmup=50, target_model_update=100, policy=EpsGreedyQPolicy(masked_greedy=False),
+                        test_policy=GreedyQPolicy(masked_greedy=True), gamma=0.99, enable_dueling_network=True)
+        dqn3.compile(Adam(lr=1e-4))
+        dqn3.model.load_weights(wfile)
+        dqn3.fit(env, nb_steps=120, action_repetition=1, callbacks=[], verbose=0, visualize=False, nb_max_start_steps=0,
+                 start_step_policy=None, log_interval=10, nb_max_episode_steps=None, episode_averaging_length=10,
+                 success_threshold=10000, stopping_patience=1000, min_nb_steps=50, single_cycle=False)
+        assert dqn3.memory.nb_entries >= entries + 100
     finally:
         sys.path.pop(0)
