@@ -367,7 +367,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
     for (int t = 0; t < 4; ++t) { bw[0][t].h = pkw[t * PK_BLOCK]; bw[0][t].m = pkw[t * PK_BLOCK + 64]; bw[0][t].l = pkw[t * PK_BLOCK + 128]; }
 
-    // ---- input rows -> three bf16 planes in LDS, in Keras Flatten order (zero-filled past the batch); clear the padded y2 image --
+    // ---- input rows -> three bf16 planes in LDS (zero-filled past the batch), in the rows' own NHWC order: Keras' channels_first
+    //      Flatten is a permutation of k, applied ONCE to the packed weight rows by pack_weights_kernel instead of to every input row
+    //      here (transposed 2-byte LDS writes: 12 per float4, against three 8-byte ones); clear the padded y2 image ---------------
     const int LDP = K1 + 8;                                          // plane row stride in bf16 (rows stay 16-byte aligned)
     unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [3][ROWS][LDP]
     {
@@ -388,19 +390,18 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 if (i >= ROWS * q4) break;
                 const int r = i / q4, c4 = (i - r * q4) * 4;
                 const f32x4 v = vv[u];
-                const int p = a.perm_hw > 0 ? c4 / a.perm_c : 0, c = a.perm_hw > 0 ? c4 - p * a.perm_c : c4;   // perm_c % 4 == 0: the four share p
+                u32 hb[4], mb[4], lb[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int k = a.perm_hw > 0 ? (c + e) * a.perm_hw + p : c4 + e;
-                    const u32 hb = __float_as_uint(v[e]) & 0xffff0000u;
-                    const float r1 = v[e] - __uint_as_float(hb);                            // exact
-                    const u32 mb = __float_as_uint(r1) & 0xffff0000u;
-                    const float r2 = r1 - __uint_as_float(mb);                              // exact, <= 8 significant bits left
-                    unsigned short* d = s_pl + r * LDP + k;
-                    d[0] = (unsigned short)(hb >> 16);
-                    d[ROWS * LDP] = (unsigned short)(mb >> 16);
-                    d[2 * ROWS * LDP] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    hb[e] = __float_as_uint(v[e]) & 0xffff0000u;
+                    const float r1 = v[e] - __uint_as_float(hb[e]);                         // exact
+                    mb[e] = __float_as_uint(r1) & 0xffff0000u;
+                    lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));                   // exact, <= 8 significant bits left
                 }
+                unsigned short* d = s_pl + r * LDP + c4;
+                *reinterpret_cast<uint2*>(d) = uint2{(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
+                *reinterpret_cast<uint2*>(d + ROWS * LDP) = uint2{(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
+                *reinterpret_cast<uint2*>(d + 2 * ROWS * LDP) = uint2{(lb[0] >> 16) | (lb[1] & 0xffff0000u), (lb[2] >> 16) | (lb[3] & 0xffff0000u)};
             }
         }
         for (int i = tid; i < ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
@@ -587,16 +588,36 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     }
     DQ_STAMP(DQ_TAG_DENSE_FWD, 7);
     const int A = a.n_actions;
-    for (int row = wave; row < ns; row += DENSE_WAVES) {
-        const float* yr = y + row * ldy;
+    {   // this wave's rows (wave, wave + 8, ...) together: their LDS reads and butterfly sums are independent chains
+        constexpr int RW = ROWS / DENSE_WAVES;
+        float yv[RW][2], sum[RW];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            const float* yr = y + min(wave + DENSE_WAVES * u, ROWS - 1) * ldy + (a.N3 > 0 ? 1 : 0);
+            sum[u] = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                yv[u][h] = c < A ? yr[c] : 0.f;
+                sum[u] += yv[u][h];
+            }
+        }
         if (a.N3 > 0) {
-            float s = 0.f;
-            for (int c = lane; c < A; c += 64) s += yr[1 + c];
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-            const float base = yr[0] - s / (float)A;
-            for (int c = lane; c < A; c += 64) J.q_out[(size_t)(b0 + row) * A + c] = base + yr[1 + c];
-        } else {
-            for (int c = lane; c < A; c += 64) J.q_out[(size_t)(b0 + row) * A + c] = yr[c];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                for (int u = 0; u < RW; ++u) sum[u] += __shfl_xor(sum[u], m);
+        }
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            const int row = wave + DENSE_WAVES * u;
+            if (row >= ns) continue;
+            const float base = a.N3 > 0 ? y[row * ldy] - sum[u] / (float)A : 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                if (c < A) J.q_out[(size_t)(b0 + row) * A + c] = base + yv[u][h];
+            }
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_FWD, 8);
@@ -611,6 +632,7 @@ struct PackArgs {
     const float* params;
     u32x4* pk;
     int w2_off, w3_off, d1_off, d1_blocks;
+    int perm_hw, perm_c;                // > 0: plane index k' = p*perm_c + c of the dense forward is Keras weight row c*perm_hw + p
     int pack_wgs;                       // workgroups [0, pack_wgs) pack bf16 pieces, the rest transpose (tr[i].tile0 counts from pack_wgs)
     PackTr tr[2];
 };
@@ -642,9 +664,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
     float v[8];
     if (blk_id >= PK_TOTAL_BLOCKS) {                                // Dense(512): block (kblk, ct): B(k = 32 kblk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3))
         const int b = blk_id - PK_TOTAL_BLOCKS, kblk = b >> 5, ct = b & 31;
-        const float* w = params + d1_off + (size_t)(32 * kblk + 8 * kb) * DENSE_HID + 64 * (ct >> 2) + 4 * j + (ct & 3);
+        const float* w = params + d1_off + 64 * (ct >> 2) + 4 * j + (ct & 3);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = w[(size_t)e * DENSE_HID];
+        for (int e = 0; e < 8; ++e) {
+            int k = 32 * kblk + 8 * kb + e;                         // the input rows' own (NHWC) order ...
+            if (a.perm_hw > 0) { const int pp = k / a.perm_c, c = k - pp * a.perm_c; k = c * a.perm_hw + pp; }      // ... -> Keras Flatten row
+            v[e] = w[(size_t)k * DENSE_HID];
+        }
     } else if (blk_id < 16 + 8) {                                          // forward: B(k, col = 2j + t) = W[k][col], k = 32 blk + 8kb + e
         const bool c2 = blk_id < 16;
         const int b = c2 ? blk_id : blk_id - 16, blk = b >> 1, t = b & 1;
@@ -684,6 +710,7 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     memset(&a, 0, sizeof(a));
     a.params = params_dev; a.pk = static_cast<u32x4*>(packed_dev);
     a.w2_off = (int)Q->L[1].w_off; a.w3_off = (int)Q->L[2].w_off; a.d1_off = (int)D1.w_off; a.d1_blocks = (D1.nin >> 5) * 32;
+    a.perm_hw = Q->flat_hw; a.perm_c = Q->flat_c;
     a.pack_wgs = (PK_TOTAL_BLOCKS + a.d1_blocks + 3) / 4;
     int tiles = a.pack_wgs;
     const Layer* Ls[2] = {&D1, &D2};
