@@ -239,9 +239,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     {
         const int tiles = (M1 + 15) >> 4;
         float* g1 = J.write_all ? J.act_out[0] + (size_t)b0 * r1 * 64 : nullptr;
-        auto rd = [&](int tile, u32 (&ab)[NH1][8]) {
-            const int m = min(tile * 16 + j, M1 - 1);               // rows past the end (and whole tiles past it) reread the last row
-            const u8* ap = s_in + s_t1[m];
+        auto origin = [&](int tile) { return s_t1[min(tile * 16 + j, M1 - 1)]; };     // rows past the end (and whole tiles past it) reread the last row
+        auto rd = [&](int org, u32 (&ab)[NH1][8]) {
+            const u8* ap = s_in + org;
 #pragma unroll
             for (int h = 0; h < NH1; ++h)
 #pragma unroll
@@ -276,10 +276,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
         };
         u32 abA[NH1][8], abB[NH1][8];
         if (wave < tiles) {
-            rd(wave, abA);
+            // two tiles ahead: the patch origin (one LDS read the byte gathers depend on); one tile ahead: the bytes
+            int orgB = origin(wave + CONV_WAVES), orgA;
+            rd(origin(wave), abA);
             for (int tile = wave;;) {
-                rd(tile + CONV_WAVES, abB); tile_out(tile, abA); tile += CONV_WAVES; if (tile >= tiles) break;
-                rd(tile + CONV_WAVES, abA); tile_out(tile, abB); tile += CONV_WAVES; if (tile >= tiles) break;
+                rd(orgB, abB); orgA = origin(tile + 2 * CONV_WAVES); tile_out(tile, abA); tile += CONV_WAVES; if (tile >= tiles) break;
+                rd(orgA, abA); orgB = origin(tile + 2 * CONV_WAVES); tile_out(tile, abB); tile += CONV_WAVES; if (tile >= tiles) break;
             }
         }
     }
