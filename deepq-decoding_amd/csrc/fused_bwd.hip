@@ -331,6 +331,7 @@ struct WgradLayer {
     int out_w, out_b;                   // offsets into a partial (floats)
     int perm_hw, perm_c;                // > 0: column idx = p*perm_c + c of X is weight row c*perm_hw + p (Keras Flatten)
     int tile0, k_tiles, n_tiles, TK;    // first tile id of this layer, tiling, 16-row MFMA tiles per wave (3 or 4)
+    int vec;                            // K and N multiples of 4: wgrad_tile_vec (one dwordx4 load per operand per step)
 };
 
 struct DenseWgradArgs {
@@ -366,22 +367,23 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
         for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     float xr[4][TK], gr4[4][4];                                     // ring of four 4-row steps, three in flight
+    // raw loads of clamped rows / columns into the ring; masks are applied when a step is consumed (see wgrad_tile_vec)
     auto load = [&](int m, float (&xa)[TK], float (&gb)[4]) {
-        const int row = m + kq;
-        const bool rok = row < m1;
-        // unconditional loads of a clamped row / column, masked by select (a load under a condition gets its own branch and
-        // s_waitcnt, which drains the ring)
-        const int rc = rok ? row : m1 - 1;
+        const int rc = min(m + kq, m1 - 1);
         const float* xp = L.X + (size_t)rc * K;
         const float* gp = L.G + (size_t)rc * N;
-        // (masked by MULTIPLYING with 0/1: hipcc sinks a load whose only use is a select back under the condition)
-        const float rm = rok ? 1.f : 0.f;
 #pragma unroll
-        for (int ti = 0; ti < TK; ++ti) xa[ti] = xp[kcol[ti]] * (rm * kmask[ti]);
+        for (int ti = 0; ti < TK; ++ti) xa[ti] = xp[kcol[ti]];
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) gb[tj] = gp[ncol[tj]] * (rm * nmask[tj]);
+        for (int tj = 0; tj < 4; ++tj) gb[tj] = gp[ncol[tj]];
     };
-    auto mma = [&](const float (&xa)[TK], const float (&gb)[4]) {
+    auto mma = [&](int m, const float (&xraw)[TK], const float (&graw)[4]) {
+        const float rm = m + kq < m1 ? 1.f : 0.f;
+        float xa[TK], gb[4];
+#pragma unroll
+        for (int ti = 0; ti < TK; ++ti) xa[ti] = xraw[ti] * rm;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) gb[tj] = graw[tj] * (rm * nmask[tj]);          // (the bias sums see every column of the tile)
 #pragma unroll
         for (int ti = 0; ti < TK; ++ti)
 #pragma unroll
@@ -395,8 +397,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
     for (int m = m0; m < m1; m += 16) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            load(m + 4 * (u + 3), xr[(u + 3) & 3], gr4[(u + 3) & 3]);    // rows past the slice are masked to zero inside load()
-            mma(xr[u], gr4[u]);
+            load(m + 4 * (u + 3), xr[(u + 3) & 3], gr4[(u + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);                       // keep the request three steps ahead of its use: left alone, the
+            mma(m + 4 * u, xr[u], gr4[u]);                           // scheduler sinks the loads to just before the MFMAs that need them
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- combine the workgroup's four slices in fixed order, write one partial ---------------------------------------
@@ -430,6 +434,82 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
         out[L.out_b + nbase + tid] = (s_bias[tid] + s_bias[64 + tid]) + (s_bias[128 + tid] + s_bias[192 + tid]);
 }
 
+// The same tile with the column tiles INTERLEAVED: k-tile ti, lane i is weight row kbase + 4i + ti and n-tile tj, lane j is column
+// nbase + 4j + tj, so a lane's four X values (and four G values) of a batch row are four consecutive floats -- ONE dwordx4 load per
+// operand per 4-row step instead of seven dword loads whose 64-byte quarter-wave segments each cost a cache access (the scalar
+// variant above spends 54 % of its wave cycles waiting with the matrix pipe 37 % busy).  Needs K and N to be multiples of 4.
+__device__ __forceinline__ void wgrad_tile_vec(const WgradLayer& L, int local, int slice, int batch, int rows_per_wave, float* __restrict__ out,
+                                               float* s_part, float* s_bias) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
+    const int kt = local / L.n_tiles, nt = local - kt * L.n_tiles;
+    const int kbase = kt * 64, nbase = nt * 64;
+    const int K = L.K, N = L.N;
+    const int m0 = (slice * WGRAD_WAVES + wave) * rows_per_wave, m1 = min(batch, m0 + rows_per_wave);
+    const int kcol = kbase + 4 * j < K ? kbase + 4 * j : 0, ncol = nbase + 4 * j < N ? nbase + 4 * j : 0;      // whole quads: K, N are multiples of 4
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 xr[4], gr4[4];                                            // ring of four 4-row steps, three in flight
+    // The ring holds RAW loads of clamped rows / columns; rows past the slice are masked when a step is CONSUMED.  (Masking inside the
+    // load -- `x = p[i] * mask` -- makes hipcc wait for every load right where it is issued: the ring degenerates into "issue a
+    // batch, wait for all of it, then MFMA", which is how this kernel spent 54 % of its cycles waiting.)  Columns past K / N need no
+    // mask at all: they only reach accumulators that the epilogue never stores.
+    auto load = [&](int m, f32x4& xa, f32x4& gb) {
+        const int rc = min(m + kq, m1 - 1);
+        xa = *reinterpret_cast<const f32x4*>(L.X + (size_t)rc * K + kcol);
+        gb = *reinterpret_cast<const f32x4*>(L.G + (size_t)rc * N + ncol);
+    };
+    auto mma = [&](int m, const f32x4& xraw, const f32x4& graw) {
+        const float rm = m + kq < m1 ? 1.f : 0.f;
+        const f32x4 xa = xraw * rm, gb = graw * rm;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = MFMA16(xa[ti], gb[tj], acc[ti][tj]);
+        bsum += gb;
+    };
+    load(m0, xr[0], gr4[0]);
+    load(m0 + 4, xr[1], gr4[1]);
+    load(m0 + 8, xr[2], gr4[2]);
+    for (int m = m0; m < m1; m += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load(m + 4 * (u + 3), xr[(u + 3) & 3], gr4[(u + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);                       // keep the request three steps ahead of its use: left alone, the
+            mma(m + 4 * u, xr[u], gr4[u]);                           // scheduler sinks the loads to just before the MFMAs that need them
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- combine the workgroup's four slices in fixed order, write one partial: local weight row 4 (4kq + r) + ti, column 4j + tj ----
+    float* sp = s_part + wave * (64 * 64);
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4*>(sp + (4 * (4 * kq + r) + ti) * 64 + 4 * j) = f32x4{acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
+    if (kt == 0) {
+        f32x4 v = bsum;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += __shfl_xor(v[e], 16); v[e] += __shfl_xor(v[e], 32); }
+        if (kq == 0) *reinterpret_cast<f32x4*>(s_bias + wave * 64 + 4 * j) = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += WGRAD_THREADS) {
+        const float v = (s_part[e] + s_part[4096 + e]) + (s_part[8192 + e] + s_part[12288 + e]);
+        const int k = kbase + (e >> 6), n = nbase + (e & 63);
+        if (k < K && n < N) {
+            int row = k;
+            if (L.perm_hw > 0) { const int p = k / L.perm_c, c = k - p * L.perm_c; row = c * L.perm_hw + p; }
+            out[L.out_w + (size_t)row * N + n] = v;
+        }
+    }
+    if (kt == 0 && tid < 64 && nbase + tid < N)
+        out[L.out_b + nbase + tid] = (s_bias[tid] + s_bias[64 + tid]) + (s_bias[128 + tid] + s_bias[192 + tid]);
+}
+
 __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     float* s_part = reinterpret_cast<float*>(smem);                  // [4][64*64]
@@ -443,7 +523,8 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     int l = 0;
     while (l + 1 < a.n_layers && tile >= a.L[l + 1].tile0) ++l;     // block-uniform
     float* out = a.partial + (size_t)slice * a.pstride;
-    if (a.L[l].TK == 3) wgrad_tile<3>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
+    if (a.L[l].vec) wgrad_tile_vec(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
+    else if (a.L[l].TK == 3) wgrad_tile<3>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
     else wgrad_tile<4>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
 }
 
@@ -1016,7 +1097,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         W.X = Q->act[0][nc + l - 1]; W.G = Q->gz[nc + l]; W.K = L.K; W.N = L.N;
         W.out_w = (int)L.w_off; W.out_b = (int)L.b_off;
         if (l == 0) { W.perm_hw = Q->flat_hw; W.perm_c = Q->flat_c; }
-        W.TK = (L.K % 48 == 0) ? 3 : 4;
+        W.vec = (L.K % 4 == 0 && L.N % 4 == 0) ? 1 : 0;
+        W.TK = W.vec ? 4 : (L.K % 48 == 0) ? 3 : 4;
         W.k_tiles = (L.K + 16 * W.TK - 1) / (16 * W.TK); W.n_tiles = (L.N + 63) / 64;
         W.tile0 = tiles; tiles += W.k_tiles * W.n_tiles;
     }
