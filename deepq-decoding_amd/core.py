@@ -212,11 +212,9 @@ class DQNCore:
                   dq=self.dq, metrics=self.metrics, step_stats=step_stats)
         self._metrics_stale = True
         if self.world_size > 1:
-            _q.td_update(td["q_online_s1"], td["q_target_s1"], td["q_s0"], td["reward"], td["terminal"], td["action"], td["gamma"],
-                         grad_scale=td["grad_scale"], index=td["index"], y=td["y"], dq=td["dq"], metrics=td["metrics"], step_stats=step_stats)
             # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs
             nconv = net.n_conv_params
-            net.backward_phase(self.params, self.dq, self.grads, 0)
+            net.td_backward_phase0(self.params, td, self.grads)           # TD step + dueling + dense layers
             work = _dist.allreduce_sum_async(self.grads[nconv:], group=self.pg)
             net.backward_phase(self.params, self.dq, self.grads, 1)
             _dist.allreduce_sum_(self.grads[:nconv], group=self.pg)

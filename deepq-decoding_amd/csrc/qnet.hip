@@ -588,19 +588,48 @@ dq_status dq_qnet_backward_phase(dq_qnet* Q, const float* params_dev, const floa
 
 size_t dq_qnet_conv_param_count(const dq_qnet* Q) { return Q ? Q->L[Q->cfg.n_conv].w_off : 0; }
 
+static TdFused td_fused_from(const dq_td_job* tdj) {
+    TdFused td;
+    memset(&td, 0, sizeof(td));
+    td.q1o = tdj->q_online_s1_dev; td.q1t = tdj->q_target_s1_dev; td.q0 = tdj->q_s0_dev; td.reward = tdj->reward_dev;
+    td.terminal = tdj->terminal_dev; td.action = tdj->action_dev; td.index = tdj->index_dev;
+    td.gamma = (float)tdj->gamma; td.grad_scale = (float)tdj->grad_scale;
+    td.y_out = tdj->y_dev; td.dq_out = tdj->dq_dev; td.metrics = tdj->metrics_dev;
+    td.metric_slots = (tdj->batch + 3) / 4 < 1024 ? (tdj->batch + 3) / 4 : 1024;      // what dq_td_metrics(batch) reads
+    td.st_done = tdj->done_dev; td.st_was_reset = tdj->was_reset_dev; td.st_lifetime = tdj->lifetime_dev;
+    td.st_reward = tdj->step_reward_dev; td.st_n = tdj->n; td.st_stats = reinterpret_cast<unsigned long long*>(tdj->stats_dev);
+    return td;
+}
+
+static dq_status check_td_job(const dq_qnet* Q, const dq_td_job* tdj) {
+    DQ_REQUIRE(tdj->q_online_s1_dev && tdj->q_target_s1_dev && tdj->q_s0_dev && tdj->reward_dev && tdj->terminal_dev && tdj->action_dev,
+               DQ_ERR_INVALID, "dq_qnet_td_backward: null argument");
+    DQ_REQUIRE(tdj->batch == Q->last_train_batch && tdj->n_actions == Q->cfg.n_actions, DQ_ERR_INVALID,
+               "dq_qnet_td_backward: the TD job does not match the training forward (batch %d x %d actions)", Q->last_train_batch,
+               Q->cfg.n_actions);
+    DQ_REQUIRE(tdj->n == 0 || (tdj->done_dev && tdj->lifetime_dev && tdj->step_reward_dev && tdj->stats_dev && tdj->n > 0), DQ_ERR_INVALID,
+               "dq_qnet_td_backward: bad statistics argument");
+    return DQ_OK;
+}
+
+static dq_status separate_td(const dq_td_job* tdj, void* stream) {
+    DQ_REQUIRE(tdj->dq_dev, DQ_ERR_INVALID, "dq_qnet_td_backward: the per-layer path needs dq_dev");
+    return tdj->n > 0
+        ? dq_td_update_stats(tdj->q_online_s1_dev, tdj->q_target_s1_dev, tdj->q_s0_dev, tdj->reward_dev, tdj->terminal_dev, tdj->action_dev,
+                             tdj->index_dev, tdj->gamma, tdj->batch, tdj->n_actions, tdj->grad_scale, tdj->y_dev, tdj->dq_dev, tdj->metrics_dev,
+                             tdj->done_dev, tdj->was_reset_dev, tdj->lifetime_dev, tdj->step_reward_dev, tdj->n, tdj->stats_dev, stream)
+        : dq_td_update(tdj->q_online_s1_dev, tdj->q_target_s1_dev, tdj->q_s0_dev, tdj->reward_dev, tdj->terminal_dev, tdj->action_dev,
+                       tdj->index_dev, tdj->gamma, tdj->batch, tdj->n_actions, tdj->grad_scale, tdj->y_dev, tdj->dq_dev, tdj->metrics_dev, stream);
+}
+
 static dq_status backward_adam(dq_qnet* Q, float* params_dev, const float* dq_dev, const dq_td_job* tdj, float* grads_dev, float* m_dev,
                                float* v_dev, double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream) {
     DQ_REQUIRE(Q && params_dev && (dq_dev || tdj) && grads_dev && m_dev && v_dev, DQ_ERR_INVALID, "dq_qnet_backward_adam: null argument");
     DQ_REQUIRE(t >= 1, DQ_ERR_INVALID, "dq_qnet_backward_adam: t counts from 1");
     DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_backward_adam: no training forward to differentiate");
     if (tdj) {
-        DQ_REQUIRE(tdj->q_online_s1_dev && tdj->q_target_s1_dev && tdj->q_s0_dev && tdj->reward_dev && tdj->terminal_dev && tdj->action_dev,
-                   DQ_ERR_INVALID, "dq_qnet_td_backward_adam: null argument");
-        DQ_REQUIRE(tdj->batch == Q->last_train_batch && tdj->n_actions == Q->cfg.n_actions, DQ_ERR_INVALID,
-                   "dq_qnet_td_backward_adam: the TD job does not match the training forward (batch %d x %d actions)", Q->last_train_batch,
-                   Q->cfg.n_actions);
-        DQ_REQUIRE(tdj->n == 0 || (tdj->done_dev && tdj->lifetime_dev && tdj->step_reward_dev && tdj->stats_dev && tdj->n > 0), DQ_ERR_INVALID,
-                   "dq_qnet_td_backward_adam: bad statistics argument");
+        dq_status rc = check_td_job(Q, tdj);
+        if (rc != DQ_OK) return rc;
     }
     if (Q->use_fused && fused_backward_supported(Q)) {
         AdamOpt opt;
@@ -608,26 +637,11 @@ static dq_status backward_adam(dq_qnet* Q, float* params_dev, const float* dq_de
         opt.lr_t = (float)(lr * sqrt(1.0 - pow(beta_2, (double)t)) / (1.0 - pow(beta_1, (double)t)));      // as dq_adam_step
         opt.b1 = (float)beta_1; opt.b2 = (float)beta_2; opt.eps = (float)epsilon;
         TdFused td;
-        if (tdj) {
-            memset(&td, 0, sizeof(td));
-            td.q1o = tdj->q_online_s1_dev; td.q1t = tdj->q_target_s1_dev; td.q0 = tdj->q_s0_dev; td.reward = tdj->reward_dev;
-            td.terminal = tdj->terminal_dev; td.action = tdj->action_dev; td.index = tdj->index_dev;
-            td.gamma = (float)tdj->gamma; td.grad_scale = (float)tdj->grad_scale;
-            td.y_out = tdj->y_dev; td.dq_out = tdj->dq_dev; td.metrics = tdj->metrics_dev;
-            td.metric_slots = (tdj->batch + 3) / 4 < 1024 ? (tdj->batch + 3) / 4 : 1024;      // what dq_td_metrics(batch) reads
-            td.st_done = tdj->done_dev; td.st_was_reset = tdj->was_reset_dev; td.st_lifetime = tdj->lifetime_dev;
-            td.st_reward = tdj->step_reward_dev; td.st_n = tdj->n; td.st_stats = reinterpret_cast<unsigned long long*>(tdj->stats_dev);
-        }
+        if (tdj) td = td_fused_from(tdj);
         return fused_backward(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream, &opt, tdj ? &td : nullptr);
     }
     if (tdj) {                                                      // per-layer path: the separate launches
-        DQ_REQUIRE(tdj->dq_dev, DQ_ERR_INVALID, "dq_qnet_td_backward_adam: the per-layer path needs dq_dev");
-        dq_status rc = tdj->n > 0
-            ? dq_td_update_stats(tdj->q_online_s1_dev, tdj->q_target_s1_dev, tdj->q_s0_dev, tdj->reward_dev, tdj->terminal_dev, tdj->action_dev,
-                                 tdj->index_dev, tdj->gamma, tdj->batch, tdj->n_actions, tdj->grad_scale, tdj->y_dev, tdj->dq_dev, tdj->metrics_dev,
-                                 tdj->done_dev, tdj->was_reset_dev, tdj->lifetime_dev, tdj->step_reward_dev, tdj->n, tdj->stats_dev, stream)
-            : dq_td_update(tdj->q_online_s1_dev, tdj->q_target_s1_dev, tdj->q_s0_dev, tdj->reward_dev, tdj->terminal_dev, tdj->action_dev,
-                           tdj->index_dev, tdj->gamma, tdj->batch, tdj->n_actions, tdj->grad_scale, tdj->y_dev, tdj->dq_dev, tdj->metrics_dev, stream);
+        dq_status rc = separate_td(tdj, stream);
         if (rc != DQ_OK) return rc;
         dq_dev = tdj->dq_dev;
     }
@@ -640,6 +654,20 @@ dq_status dq_qnet_backward_adam(dq_qnet* Q, float* params_dev, const float* dq_d
                                 double beta_1, double beta_2, double epsilon, uint64_t t, void* stream) {
     DQ_REQUIRE(dq_dev, DQ_ERR_INVALID, "dq_qnet_backward_adam: null argument");
     return backward_adam(Q, params_dev, dq_dev, nullptr, grads_dev, m_dev, v_dev, lr, beta_1, beta_2, epsilon, t, stream);
+}
+
+dq_status dq_qnet_td_backward_phase0(dq_qnet* Q, const float* params_dev, const dq_td_job* tdj, float* grads_dev, void* stream) {
+    DQ_REQUIRE(Q && params_dev && tdj && grads_dev, DQ_ERR_INVALID, "dq_qnet_td_backward_phase0: null argument");
+    DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_td_backward_phase0: no training forward to differentiate");
+    dq_status rc = check_td_job(Q, tdj);
+    if (rc != DQ_OK) return rc;
+    if (Q->use_fused && fused_backward_supported(Q)) {
+        const TdFused td = td_fused_from(tdj);
+        return fused_backward(Q, params_dev, nullptr, grads_dev, 1, (hipStream_t)stream, nullptr, &td);
+    }
+    rc = separate_td(tdj, stream);
+    if (rc != DQ_OK) return rc;
+    return backward_phases(Q, params_dev, tdj->dq_dev, grads_dev, 1, (hipStream_t)stream);
 }
 
 dq_status dq_qnet_td_backward_adam(dq_qnet* Q, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev, double lr,

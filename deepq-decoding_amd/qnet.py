@@ -200,10 +200,7 @@ def _backward_adam(self, params, dq, grads, m, v, t, lr, beta_1=0.9, beta_2=0.99
 QNetwork.backward_adam = _backward_adam
 
 
-def _td_backward_adam(self, params, td, grads, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
-    """td_update() (+ episode bookkeeping) + backward() + adam_step() with the TD step computed by the backward's first kernel and the
-    optimizer step applied by its last one.  td: dict with q_online_s1, q_target_s1, q_s0, reward, terminal, action, index, gamma,
-    grad_scale and optional y, dq, metrics, step_stats = (done, was_reset, lifetime, reward, n, stats)."""
+def _td_job(td):
     B, A = td["q_s0"].shape
     j = _lib.TdJob()
     j.q_online_s1_dev, j.q_target_s1_dev, j.q_s0_dev = ptr(td["q_online_s1"]), ptr(td["q_target_s1"]), ptr(td["q_s0"])
@@ -215,11 +212,27 @@ def _td_backward_adam(self, params, td, grads, m, v, t, lr, beta_1=0.9, beta_2=0
         done, was_reset, lifetime, step_reward, n, stats = st
         j.done_dev, j.was_reset_dev, j.lifetime_dev, j.step_reward_dev, j.n, j.stats_dev = (ptr(done), ptr(was_reset), ptr(lifetime),
                                                                                             ptr(step_reward), int(n), ptr(stats))
+    return j
+
+
+def _td_backward_adam(self, params, td, grads, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    """td_update() (+ episode bookkeeping) + backward() + adam_step() with the TD step computed by the backward's first kernel and the
+    optimizer step applied by its last one.  td: dict with q_online_s1, q_target_s1, q_s0, reward, terminal, action, index, gamma,
+    grad_scale and optional y, dq, metrics, step_stats = (done, was_reset, lifetime, reward, n, stats)."""
+    j = _td_job(td)
     check(self.L.dq_qnet_td_backward_adam(self._h, ptr(params), ctypes.byref(j), ptr(grads), ptr(m), ptr(v), float(lr), float(beta_1),
                                           float(beta_2), float(epsilon), int(t), self._stream()))
     return grads
 
 
+def _td_backward_phase0(self, params, td, grads):
+    """The several-GPU form: TD step + phase 0 (dueling + dense layers) of the backward; backward_phase(.., 1) follows."""
+    j = _td_job(td)
+    check(self.L.dq_qnet_td_backward_phase0(self._h, ptr(params), ctypes.byref(j), ptr(grads), self._stream()))
+    return grads
+
+
+QNetwork.td_backward_phase0 = _td_backward_phase0
 QNetwork.td_backward_adam = _td_backward_adam
 
 

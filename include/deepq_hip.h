@@ -296,6 +296,9 @@ typedef struct dq_td_job {
 } dq_td_job;
 dq_status dq_qnet_td_backward_adam(dq_qnet* net, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev,
                                    double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
+/* The several-GPU form: the TD step + phase 0 of dq_qnet_backward_phase (dueling + dense layers) in one call; phase 1, the gradient
+ * all-reduce and dq_adam_step follow as separate calls. */
+dq_status dq_qnet_td_backward_phase0(dq_qnet* net, const float* params_dev, const dq_td_job* td, float* grads_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DQN update: replaces SequentialMemory.sample + DQNAgent.backward + keras Adam of the keras-rl fork

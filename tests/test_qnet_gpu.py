@@ -222,6 +222,21 @@ def test_td_backward_adam_equals_the_separate_calls(dq, torch_mod, fused):
         out[name] = [x.clone() for x in (y, dq_, g_, p_, m_, v_, stats, met[:2])]
     for a, b in zip(out["separate"][:7], out["one"][:7]):
         assert torch.equal(a, b)
+    # the several-GPU form: TD + phase 0, then phase 1 and the optimizer step as separate calls
+    p_, m_, v_ = params.clone(), torch.zeros_like(params), torch.zeros_like(params)
+    g_ = torch.empty_like(params)
+    stats = torch.zeros(4, dtype=torch.int64, device="cuda")
+    met = torch.zeros(Q.TD_METRICS_FLOATS, dtype=torch.float32, device="cuda")
+    y, dq_ = torch.empty(B, device="cuda"), torch.empty((B, A), device="cuda")
+    for t in (1, 2):
+        q0 = net.forward(p_, obs_t, training=True, seed=(1, 2), t=t)
+        td = dict(q_online_s1=q1o, q_target_s1=q1t, q_s0=q0, reward=reward, terminal=terminal, action=action, gamma=0.99,
+                  grad_scale=1.0 / B, index=idx, y=y, dq=dq_, metrics=met, step_stats=(done, was_reset, life, rew, n_envs, stats))
+        net.td_backward_phase0(p_, td, g_)
+        net.backward_phase(p_, dq_, g_, 1)
+        Q.adam_step(p_, g_, m_, v_, t, 1e-3)
+    for a, b in zip(out["separate"][:7], (y, dq_, g_, p_, m_, v_, stats)):
+        assert torch.equal(a, b)
     assert torch.allclose(out["separate"][7], out["one"][7], rtol=1e-5, atol=1e-7)
     assert out["one"][6].tolist()[3] == 2 * int((was_reset == 0).sum())
 
