@@ -75,6 +75,7 @@ SIGNATURES = {
     "dq_env_get_info": (_i, [_vp, ctypes.POINTER(EnvInfo)]),
     "dq_env_set_rates": (_i, [_vp, _dbl, _dbl]),
     "dq_env_build_referee": (_i, [_vp, _vp]),
+    "dq_env_build_referee_ml": (_i, [_vp, _dbl, _vp]),
     "dq_env_set_referee": (_i, [_vp, _vp, _vp]),
     "dq_env_get_referee": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
     "dq_env_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -534,6 +534,64 @@ static dq_status build_one_lut(dq_env* E, int comp, u32** out, hipStream_t st) {
     return DQ_OK;
 }
 
+// ---- maximum-likelihood referee: for one Pauli component with independent flip probability q per qubit, the probability of every
+// (syndrome, logical class) state is the XOR-convolution of the single-qubit distributions: one pass per qubit,
+//   P'[s] = (1 - q) P[s] + q P[s ^ delta_q],
+// over the doubled space the minimum-weight search uses (2^(n+1) states, doubles).  The table predicts class 1 iff
+// P[s | class 1] > P[s | class 0] (ties -> class 0).  No contraction: the numpy restatement (oracle/referee.py) must give the same bits.
+__global__ void ml_init_kernel(double* p, size_t size) {
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < size; s += (size_t)gridDim.x * blockDim.x) p[s] = s == 0 ? 1.0 : 0.0;
+}
+
+__global__ void ml_step_kernel(const double* __restrict__ in, double* __restrict__ out, size_t size, u32 delta, double q) {
+#pragma clang fp contract(off)
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < size; s += (size_t)gridDim.x * blockDim.x)
+        out[s] = (1.0 - q) * in[s] + q * in[s ^ delta];
+}
+
+__global__ void ml_pack_kernel(const double* __restrict__ p, u32 half, u32* __restrict__ lut) {
+    const u32 wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= (half + 31) / 32) return;
+    u32 w = 0;
+    for (u32 b = 0; b < 32; ++b) {
+        const u32 s = wi * 32 + b;
+        if (s < half && p[(size_t)half + s] > p[s]) w |= 1u << b;
+    }
+    lut[wi] = w;
+}
+
+static dq_status build_one_ml_lut(dq_env* E, int comp, double q, u32** out, hipStream_t st) {
+    const int nh = E->info.n_stab / 2, nq = E->cfg.d * E->cfg.d;
+    const size_t size = (size_t)1 << (nh + 1), half = (size_t)1 << nh, words = (half + 31) / 32;
+    double* buf[2] = {nullptr, nullptr};
+    DQ_HIP(hipMalloc(&buf[0], size * sizeof(double)));
+    DQ_HIP(hipMalloc(&buf[1], size * sizeof(double)));
+    if (!*out) DQ_HIP(hipMalloc(out, words * sizeof(u32)));
+    const int blocks = (int)((size + 255) / 256 < 8192 ? (size + 255) / 256 : 8192);
+    ml_init_kernel<<<blocks, 256, 0, st>>>(buf[0], size);
+    for (int k = 0; k < nq; ++k)
+        ml_step_kernel<<<blocks, 256, 0, st>>>(buf[k & 1], buf[(k + 1) & 1], size, E->ref_delta[comp][k], q);
+    ml_pack_kernel<<<(int)((words + 255) / 256), 256, 0, st>>>(buf[nq & 1], (u32)half, *out);
+    DQ_LAUNCH_CHECK();
+    DQ_HIP(hipStreamSynchronize(st));
+    DQ_HIP(hipFree(buf[0]));
+    DQ_HIP(hipFree(buf[1]));
+    return DQ_OK;
+}
+
+dq_status dq_env_build_referee_ml(dq_env* E, double q_flip, void* stream) {
+    DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_build_referee_ml: null handle");
+    DQ_REQUIRE(q_flip > 0.0 && q_flip < 0.5, DQ_ERR_INVALID, "dq_env_build_referee_ml: the flip probability must be in (0, 0.5)");
+    hipStream_t st = (hipStream_t)stream;
+    dq_status rc = build_one_ml_lut(E, 0, q_flip, &E->d_lut_x, st);
+    if (rc != DQ_OK) return rc;
+    rc = build_one_ml_lut(E, 1, q_flip, &E->d_lut_z, st);
+    if (rc != DQ_OK) return rc;
+    E->lut_x = E->d_lut_x;
+    E->lut_z = E->d_lut_z;
+    return DQ_OK;
+}
+
 dq_status dq_env_build_referee(dq_env* E, void* stream) {
     DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_build_referee: null handle");
     hipStream_t st = (hipStream_t)stream;

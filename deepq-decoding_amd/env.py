@@ -68,6 +68,10 @@ class VectorEnv:
         if referee == "lut":
             with torch.cuda.device(self.device):
                 check(self.L.dq_env_build_referee(self._h, self._stream()))
+        elif referee == "ml" or (isinstance(referee, tuple) and len(referee) == 2 and referee[0] == "ml"):
+            # maximum-likelihood table for independent component flips; default rate = one round's marginal flip probability
+            q = float(referee[1]) if isinstance(referee, tuple) else (p_phys if error_model == "X" else 2.0 * p_phys / 3.0)
+            self.build_ml_referee(q)
         elif referee is not None:
             self.set_referee(*referee)
 
@@ -104,6 +108,12 @@ class VectorEnv:
     def p_meas(self, v):
         self._p_meas = float(v)
         check(self.L.dq_env_set_rates(self._h, self._p_phys, self._p_meas))
+
+    def build_ml_referee(self, q_flip):
+        """Installs the maximum-likelihood referee for independent X- / Z-component flips with probability q_flip per qubit."""
+        with torch.cuda.device(self.device):
+            check(self.L.dq_env_build_referee_ml(self._h, float(q_flip), self._stream()))
+        self._lut = None
 
     def set_referee(self, lut_x, lut_z=None):
         """Install caller tables: uint8 0/1 arrays of 2**((d*d-1)//2) entries (bit order: include/deepq_hip.h)."""
@@ -207,7 +217,8 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
     Differences from the reference, all forced by what the checkout lacks:
       * randomness comes from the site-indexed Philox stream (``seed``, ``env_id``) instead of numpy's
         unseeded global generator;
-      * ``static_decoder`` is the built-in minimum-weight look-up referee (None / "lut"), or a pair of
+      * ``static_decoder`` is the built-in minimum-weight look-up referee (None / "lut"), the maximum-likelihood one
+        ("ml" or ("ml", q_flip)), or a pair of
         0/1 tables; arbitrary ``.predict`` objects cannot run inside the kernel and are rejected.
     """
 
@@ -215,6 +226,8 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
                  seed=DEFAULT_SEED, env_id=0, device=None):
         if static_decoder is None or static_decoder == "lut" or static_decoder is True:
             referee = "lut"
+        elif static_decoder == "ml":
+            referee = "ml"
         elif isinstance(static_decoder, (tuple, list)):
             referee = tuple(static_decoder)
         else:

@@ -98,6 +98,9 @@ dq_status dq_env_set_rates(dq_env* env, double p_phys, double p_meas);
  * not in the checkout; the library builds the deterministic minimum-weight look-up referee defined
  * in oracle/referee.py ON THE GPU (level-synchronous BFS).  Synchronises `stream`. */
 dq_status dq_env_build_referee(dq_env* env, void* stream);
+/* ... or the maximum-likelihood referee for independent component flips with probability q_flip per qubit: exact
+ * class posteriors by one XOR-convolution pass per qubit over the (syndrome, class) space, same table format.  Synchronises `stream`. */
+dq_status dq_env_build_referee_ml(dq_env* env, double q_flip, void* stream);
 /* ... or installs caller-provided bit-packed tables (device pointers, 2^((d*d-1)/2) bits each; must
  * stay alive while the handle uses them).  lut_z_dev may be NULL for DQ_MODEL_X. */
 dq_status dq_env_set_referee(dq_env* env, const uint32_t* lut_x_dev, const uint32_t* lut_z_dev);

@@ -61,6 +61,22 @@ def build_lut(d, typ):
     return (dist[half:] < dist[:half]).astype(np.uint8)
 
 
+def build_ml_lut(d, typ, q):
+    """uint8[2**n] maximum-likelihood table for independent component flips with probability q per qubit: the (syndrome, class)
+    distribution is the XOR-convolution of the single-qubit ones, P'[s] = (1 - q) P[s] + q P[s ^ delta]; class 1 iff strictly more
+    likely (the same arithmetic, in the same order, as csrc/env.hip ml_step_kernel)."""
+    n, deltas = component_deltas(d, typ)
+    size = 1 << (n + 1)
+    p = np.zeros(size, dtype=np.float64)
+    p[0] = 1.0
+    idx = np.arange(size)
+    q = np.float64(q)
+    for dl in deltas:
+        p = (np.float64(1.0) - q) * p + q * p[idx ^ dl]
+    half = 1 << n
+    return (p[half:] > p[:half]).astype(np.uint8)
+
+
 class LutReferee:
     """Object with the ``predict`` signature the reference calls (Environments.py:144)."""
 

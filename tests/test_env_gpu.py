@@ -327,3 +327,29 @@ def test_act_step_with_replay_sampling_equals_the_separate_calls(dq, torch_mod):
         assert torch.equal(idx_a, idx_b) and torch.equal(act_a, act_b) and torch.equal(a_env.obs, b_env.obs)
         assert torch.equal(a_env.reward, b_env.reward) and torch.equal(a_env.done, b_env.done) and torch.equal(a_env.legal, b_env.legal)
     assert torch.equal(a_env.export_state(), b_env.export_state())
+
+
+@pytest.mark.parametrize("d,q", [(3, 0.1), (5, 0.007), (5, 0.1), (5, 0.25), (7, 0.05)])
+def test_maximum_likelihood_referee_on_the_gpu(dq, torch_mod, d, q):
+    """dq_env_build_referee_ml == the numpy restatement (oracle/referee.py), bit for bit, for both components; the environment then
+    terminates exactly where that table says (checked through a short run against the C oracle driven with the same tables)."""
+    from oracle import referee, c_oracle
+    cfg = dict(d=d, error_model="DP", use_Y=False, volume_depth=d, p_phys=0.02, p_meas=0.02)
+    env = dq.VectorEnv(n_envs=64, referee=("ml", q), **cfg)
+    lx, lz = env.get_referee()
+    if d <= 5:
+        assert np.array_equal(lx, referee.build_ml_lut(d, 3, q)) and np.array_equal(lz, referee.build_ml_lut(d, 1, q))
+    else:                                                           # 2^25 states: the single-flip property instead of the full table
+        for typ, lut in ((3, lx), (1, lz)):
+            n, deltas = referee.component_deltas(d, typ)
+            assert lut[0] == 0 and all(lut[dl & ((1 << n) - 1)] == dl >> n for dl in deltas)
+        return
+    ref = c_oracle.COracleEnv(n_envs=64, lut=(np.ascontiguousarray(lx), np.ascontiguousarray(lz)), **cfg)
+    env.reset(); ref.reset()
+    for t in range(40):
+        a = env.select_actions(t)
+        assert np.array_equal(a.cpu().numpy(), ref.policy_uniform_legal(t))
+        env.step(a, auto_reset=True)
+        ref.step(a.cpu().numpy(), auto_reset=True)
+        assert np.array_equal(env.done.cpu().numpy(), ref.done) and np.array_equal(env.reward.cpu().numpy(), ref.reward)
+        assert np.array_equal(env.obs.cpu().numpy(), ref.obs)

@@ -120,6 +120,34 @@ def test_referee_lut(d):
             assert lut[dl & ((1 << n) - 1)] == dl >> n
 
 
+@pytest.mark.parametrize("d", [3, 5])
+def test_maximum_likelihood_referee_table(d):
+    """The XOR-convolution restatement equals brute-force enumeration of every error pattern (d = 3), reduces to the minimum-weight
+    table in the low-rate limit, decodes single flips, and differs from min-weight only where heavier cosets are more numerous."""
+    n, deltas = referee.component_deltas(d, 3)
+    if d == 3:
+        q = 0.13
+        p = np.zeros(1 << (n + 1))
+        for e in range(1 << (d * d)):
+            s, w = 0, 0
+            for k in range(d * d):
+                if (e >> k) & 1:
+                    s ^= deltas[k]
+                    w += 1
+            p[s] += q ** w * (1 - q) ** (d * d - w)
+        half = 1 << n
+        assert np.array_equal(referee.build_ml_lut(d, 3, q), (p[half:] > p[:half] * (1 + 1e-12)).astype(np.uint8))
+    for typ in (3, 1):
+        mw = referee.build_lut(d, typ)
+        assert np.array_equal(referee.build_ml_lut(d, typ, 1e-3), mw)
+        ml = referee.build_ml_lut(d, typ, 0.1)
+        nn, dd = referee.component_deltas(d, typ)
+        for dl in dd:
+            assert ml[dl & ((1 << nn) - 1)] == dl >> nn
+        if d == 5:
+            assert 0 < int((ml != mw).sum()) < 400
+
+
 def _luts(d):
     from functools import lru_cache
     return _lut_cache(d)
