@@ -504,13 +504,20 @@ dq_status dq_env_set_rates(dq_env* E, double p_phys, double p_meas) {
     return DQ_OK;
 }
 
+// device scratch that is released on every exit path of the referee builders
+struct DevScratch {
+    void* p = nullptr;
+    ~DevScratch() { if (p) (void)hipFree(p); }
+};
+
 static dq_status build_one_lut(dq_env* E, int comp, u32** out, hipStream_t st) {
     const int nh = E->info.n_stab / 2;
     const size_t size = (size_t)1 << (nh + 1), half = (size_t)1 << nh;
-    u8* dist = nullptr;
-    u32* changed = nullptr;
-    DQ_HIP(hipMalloc(&dist, size));
-    DQ_HIP(hipMalloc(&changed, sizeof(u32)));
+    DevScratch sd, sc;
+    DQ_HIP(hipMalloc(&sd.p, size));
+    DQ_HIP(hipMalloc(&sc.p, sizeof(u32)));
+    u8* dist = static_cast<u8*>(sd.p);
+    u32* changed = static_cast<u32*>(sc.p);
     const size_t words = (half + 31) / 32;
     if (!*out) DQ_HIP(hipMalloc(out, words * sizeof(u32)));
     BfsDeltas dl;
@@ -529,8 +536,6 @@ static dq_status build_one_lut(dq_env* E, int comp, u32** out, hipStream_t st) {
     bfs_pack_kernel<<<(int)((words + 255) / 256), 256, 0, st>>>(dist, (u32)half, *out);
     DQ_LAUNCH_CHECK();
     DQ_HIP(hipStreamSynchronize(st));
-    DQ_HIP(hipFree(dist));
-    DQ_HIP(hipFree(changed));
     return DQ_OK;
 }
 
@@ -563,9 +568,10 @@ __global__ void ml_pack_kernel(const double* __restrict__ p, u32 half, u32* __re
 static dq_status build_one_ml_lut(dq_env* E, int comp, double q, u32** out, hipStream_t st) {
     const int nh = E->info.n_stab / 2, nq = E->cfg.d * E->cfg.d;
     const size_t size = (size_t)1 << (nh + 1), half = (size_t)1 << nh, words = (half + 31) / 32;
-    double* buf[2] = {nullptr, nullptr};
-    DQ_HIP(hipMalloc(&buf[0], size * sizeof(double)));
-    DQ_HIP(hipMalloc(&buf[1], size * sizeof(double)));
+    DevScratch s0, s1;
+    DQ_HIP(hipMalloc(&s0.p, size * sizeof(double)));
+    DQ_HIP(hipMalloc(&s1.p, size * sizeof(double)));
+    double* buf[2] = {static_cast<double*>(s0.p), static_cast<double*>(s1.p)};
     if (!*out) DQ_HIP(hipMalloc(out, words * sizeof(u32)));
     const int blocks = (int)((size + 255) / 256 < 8192 ? (size + 255) / 256 : 8192);
     ml_init_kernel<<<blocks, 256, 0, st>>>(buf[0], size);
@@ -574,8 +580,6 @@ static dq_status build_one_ml_lut(dq_env* E, int comp, double q, u32** out, hipS
     ml_pack_kernel<<<(int)((words + 255) / 256), 256, 0, st>>>(buf[nq & 1], (u32)half, *out);
     DQ_LAUNCH_CHECK();
     DQ_HIP(hipStreamSynchronize(st));
-    DQ_HIP(hipFree(buf[0]));
-    DQ_HIP(hipFree(buf[1]));
     return DQ_OK;
 }
 
