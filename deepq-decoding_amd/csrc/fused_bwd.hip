@@ -538,16 +538,18 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __shared__ float sh[8][64];
     const ReduceSeg& S = a.seg[blockIdx.x >= (unsigned)a.seg[1].block0 ? 1 : 0];
     const int i = (blockIdx.x - S.block0) * 64 + threadIdx.x, g = threadIdx.y;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                     // four independent chains: the loop is load-latency-bound
     if (i < S.n) {
         int k = g;
-        for (; k + 8 < S.slices; k += 16) {
+        for (; k + 24 < S.slices; k += 32) {
             s0 += S.partial[(size_t)k * S.stride + i];
             s1 += S.partial[(size_t)(k + 8) * S.stride + i];
+            s2 += S.partial[(size_t)(k + 16) * S.stride + i];
+            s3 += S.partial[(size_t)(k + 24) * S.stride + i];
         }
-        if (k < S.slices) s0 += S.partial[(size_t)k * S.stride + i];
+        for (; k < S.slices; k += 8) s0 += S.partial[(size_t)k * S.stride + i];
     }
-    sh[g][threadIdx.x] = s0 + s1;
+    sh[g][threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && i < S.n) {
         const int x = threadIdx.x;
