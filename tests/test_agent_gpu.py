@@ -301,3 +301,34 @@ def test_driver_style_script_on_the_dropin_tree(dq, torch_mod, tmp_path):
         assert dqn3.memory.nb_entries >= entries + 100
     finally:
         sys.path.pop(0)
+
+
+def test_fused_step_equals_separate_calls_at_baseline_size(dq, torch_mod):
+    """BASELINE.json size (c3, 4096 lattices, 4096-sample minibatch): DQNCore.step_and_update (four forwards in one pair of launches with
+    32-row dense workgroups, next minibatch drawn on the environment launch, TD step inside the backward, Adam on its reduction) leaves
+    exactly the state that act_and_step() + update() leave -- parameters, moments, replay ring, episode counters -- bit for bit."""
+    torch = torch_mod
+    N = B = 4096
+    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    cores = []
+    for _ in range(2):
+        env = dq.VectorEnv(n_envs=N, **cfg)
+        net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=N)
+        core = dq.DQNCore(env, net, batch_size=B, memory_limit=N * 12, gamma=0.99, lr=1e-3)
+        core.reset_env()
+        for _ in range(4):
+            core.act_and_step(0.2)
+        cores.append(core)
+    a, b = cores
+    for t in range(8):
+        a.step_and_update(0.2, presample_next=(t % 3 != 2))
+        b.act_and_step(0.2, presample=(t % 2 == 0))
+        b.update()
+        if t == 4:
+            a.update_target_hard(); b.update_target_hard()
+        assert torch.equal(a.params, b.params) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v), t
+        assert torch.equal(a.index, b.index) and torch.equal(a.q_act, b.q_act), t
+    for x, y in ((a.obs_ring, b.obs_ring), (a.action_ring, b.action_ring), (a.reward_ring, b.reward_ring), (a.terminal_ring, b.terminal_ring)):
+        assert torch.equal(x, y)
+    assert a.read_stats() == b.read_stats() and a.read_stats()[3] == 0
+    assert not torch.equal(a.params, a.target)
