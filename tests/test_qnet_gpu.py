@@ -402,3 +402,34 @@ def test_one_full_update_matches_oracle(dq, torch_mod):
     big = np.abs(g_ref) > 1e-6
     assert np.abs(params.cpu().numpy() - p_ref)[big].max() < 1e-6
     assert np.abs(grads.cpu().numpy() - g_ref).max() < 1e-5 * max(1.0, np.abs(g_ref).max())
+
+
+def test_qnet_at_baseline_size_properties(dq, torch_mod):
+    """c3 at the BASELINE.json batch (4096 samples, the shapes bench.py runs): (1) a strided subset of the rows equals the float64
+    oracle; (2) every row equals what the same row gives in a small batch (tiling independence: 16- and 32-row dense workgroups, single-
+    and four-job launches); (3) a gathered forward is the permutation of the direct one; (4) the weight gradient is linear in dq."""
+    torch = torch_mod
+    B = 4096
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", B)
+    obs_t = torch.from_numpy(obs).cuda()
+    q = net.forward(params, obs_t)
+    sub = np.arange(0, B, 97)
+    q_ref, _ = O.forward(spec, flat, obs[sub])
+    assert np.abs(q[sub].cpu().numpy() - q_ref).max() < 1e-5
+    q_small = net.forward(params, obs_t[1000:1048].contiguous(), batch=48)
+    assert torch.equal(q_small, q[1000:1048])
+    # four jobs in one launch (the fused step's shape: 32-row dense workgroups) == four single launches
+    outs = net.forward_multi([dict(params=params, obs=obs_t, batch=B) for _ in range(3)] +
+                             [dict(params=params, obs=obs_t, batch=B, training=True, seed=(1, 2), t=3)])
+    assert all(torch.equal(o, q) for o in outs[:3])
+    q_tr = net.forward(params, obs_t, training=True, seed=(1, 2), t=3)
+    assert torch.equal(outs[3], q_tr)
+    perm = torch.from_numpy(rng.permutation(B).astype(np.int32)).cuda()
+    assert torch.equal(net.forward(params, obs_t, index=perm), q[perm.long()])
+    d1 = torch.from_numpy((rng.randn(B, 51) / B).astype(np.float32)).cuda()
+    d2 = torch.from_numpy((rng.randn(B, 51) / B).astype(np.float32)).cuda()
+    g1 = net.backward(params, d1).clone()
+    g2 = net.backward(params, d2).clone()
+    g12 = net.backward(params, d1 + d2)
+    scale = float(g12.abs().max())
+    assert float((g12 - (g1 + g2)).abs().max()) < 2e-5 * scale
