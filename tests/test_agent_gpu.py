@@ -303,13 +303,16 @@ def test_driver_style_script_on_the_dropin_tree(dq, torch_mod, tmp_path):
         sys.path.pop(0)
 
 
-def test_fused_step_equals_separate_calls_at_baseline_size(dq, torch_mod):
-    """BASELINE.json size (c3, 4096 lattices, 4096-sample minibatch): DQNCore.step_and_update (four forwards in one pair of launches with
+@pytest.mark.parametrize("name", ["c3", "c5", "c2"])
+def test_fused_step_equals_separate_calls_at_baseline_size(dq, torch_mod, name):
+    """BASELINE.json sizes (c3 / c2: 4096 lattices and a 4096-sample minibatch; c5: d = 7, 1024 per GPU): DQNCore.step_and_update (four forwards in one pair of launches with
     32-row dense workgroups, next minibatch drawn on the environment launch, TD step inside the backward, Adam on its reduction) leaves
     exactly the state that act_and_step() + update() leave -- parameters, moments, replay ring, episode counters -- bit for bit."""
     torch = torch_mod
-    N = B = 4096
-    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    N, cfg = {"c3": (4096, dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)),
+              "c5": (1024, dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005)),
+              "c2": (4096, dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007))}[name]
+    B = N
     cores = []
     for _ in range(2):
         env = dq.VectorEnv(n_envs=N, **cfg)
