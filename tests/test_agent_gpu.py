@@ -303,7 +303,7 @@ def test_driver_style_script_on_the_dropin_tree(dq, torch_mod, tmp_path):
         sys.path.pop(0)
 
 
-@pytest.mark.parametrize("name", ["c3", "c5", "c2"])
+@pytest.mark.parametrize("name", ["c3", "c5", "c2", "c3-ragged"])
 def test_fused_step_equals_separate_calls_at_baseline_size(dq, torch_mod, name):
     """BASELINE.json sizes (c3 / c2: 4096 lattices and a 4096-sample minibatch; c5: d = 7, 1024 per GPU): DQNCore.step_and_update (four forwards in one pair of launches with
     32-row dense workgroups, next minibatch drawn on the environment launch, TD step inside the backward, Adam on its reduction) leaves
@@ -311,8 +311,9 @@ def test_fused_step_equals_separate_calls_at_baseline_size(dq, torch_mod, name):
     torch = torch_mod
     N, cfg = {"c3": (4096, dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)),
               "c5": (1024, dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005)),
-              "c2": (4096, dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007))}[name]
-    B = N
+              "c2": (4096, dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007)),
+              "c3-ragged": (1003, dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011))}[name]
+    B = 777 if name == "c3-ragged" else N                           # neither a multiple of the 8 / 16 / 32 samples a workgroup takes
     cores = []
     for _ in range(2):
         env = dq.VectorEnv(n_envs=N, **cfg)
