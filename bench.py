@@ -122,6 +122,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    replicas_identical = None
+    if world > 1 and hasattr(runner, "core"):
+        # outside the timed region: every rank must hold bit-identical parameters (same all-reduced gradient, same Adam step)
+        chk = runner.core.params.view(torch.int32).to(torch.int64).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(lo.item() == hi.item())
+        assert replicas_identical, "the ranks' parameters diverged"
+
     if rank == 0:
         out = {
             "metric": "env steps/sec + DQN updates/sec, d=5 depolarising, batch 4096, 1/2/4/8 GPU",
@@ -140,6 +150,8 @@ def main():
                                     f"{n_local} lattices/GPU, mode={mode}", **runner.config()),
         }
         out.update(runner.report(args.steps, dt, world))
+        if replicas_identical is not None:
+            out["replicas_identical"] = replicas_identical
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = runner.cpu_baseline(dict(cfg, n_envs=n_local))
         print(json.dumps(out))
