@@ -105,10 +105,16 @@ CONFIGS = {
     "c2": dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007),
     "c3": dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011),
     "c5": dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005),
+    # SURVEY §8d's labelled variant (perfect measurements), and the two ends of the rate range: almost every volume rejected
+    # (the rejection loop of initialize_state runs tens of trips) / errors on a third of the qubits every round
+    "c2-pm0": dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.0),
+    "rare": dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=2e-4, p_meas=2e-4),
+    "dense": dict(d=5, error_model="DP", use_Y=True, volume_depth=3, p_phys=0.3, p_meas=0.3),
 }
 
 
-@pytest.mark.parametrize("name,n_envs,steps", [("c2", 4096, 40), ("c3", 4096, 60), ("c5", 1024, 30), ("c3", 1027, 25)])
+@pytest.mark.parametrize("name,n_envs,steps", [("c2", 4096, 40), ("c3", 4096, 60), ("c5", 1024, 30), ("c3", 1027, 25),
+                                               ("c2-pm0", 4096, 30), ("rare", 512, 25), ("dense", 512, 25)])
 def test_full_size_vs_c_oracle(dq, torch_mod, name, n_envs, steps):
     """BASELINE.json batch sizes, device policy (uniform over legal) vs the C oracle, every output
     compared bit-exactly at every step; n_envs=1027 covers a ragged last workgroup."""

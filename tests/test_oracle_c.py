@@ -80,17 +80,24 @@ def test_c_sticky_traces(name):
     _replay(name, False)
 
 
-def test_c_vs_python_oracle_random_walk():
-    """Longer free-running cross-check of the two restatements (uniform-over-legal policy)."""
-    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.02, p_meas=0.02)
+@pytest.mark.parametrize("cfg,steps", [
+    (dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.02, p_meas=0.02), 150),
+    (dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.0), 60),       # perfect measurements
+    (dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=2e-4, p_meas=2e-4), 25),      # nearly every volume rejected
+    (dict(d=5, error_model="DP", use_Y=True, volume_depth=3, p_phys=0.3, p_meas=0.3), 40),         # Y moves, errors everywhere
+], ids=["c3-like", "p_meas=0", "rare", "dense-useY"])
+def test_c_vs_python_oracle_random_walk(cfg, steps):
+    """Longer free-running cross-check of the two restatements (uniform-over-legal policy), also at the edges of the rate range the GPU
+    parity tests use (tests/test_env_gpu.py::test_full_size_vs_c_oracle)."""
     n_envs, seed = 6, (7, 9)
     ce = c_oracle.COracleEnv(n_envs=n_envs, seed=seed, env_id_base=100, **cfg)
     lx, lz = c_oracle.luts(5)
-    pes = [env_oracle.OracleEnv(referee=referee.LutReferee(5, "DP", lx, lz), seed=seed, env_id=100 + e, **cfg) for e in range(n_envs)]
+    pes = [env_oracle.OracleEnv(referee=referee.LutReferee(5, cfg["error_model"], lx, lz), seed=seed, env_id=100 + e, **cfg)
+           for e in range(n_envs)]
     ce.reset()
     for p in pes:
         p.reset()
-    for t in range(150):
+    for t in range(steps):
         a = ce.policy_uniform_legal(t)
         for e, p in enumerate(pes):
             legal = sorted(p.legal_actions)
