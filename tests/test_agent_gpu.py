@@ -303,7 +303,7 @@ def test_driver_style_script_on_the_dropin_tree(dq, torch_mod, tmp_path):
         sys.path.pop(0)
 
 
-@pytest.mark.parametrize("name", ["c3", "c5", "c2", "c3-ragged"])
+@pytest.mark.parametrize("name", ["c3", "c5", "c2", "c3-ragged", "per-layer"])
 def test_fused_step_equals_separate_calls_at_baseline_size(dq, torch_mod, name):
     """BASELINE.json sizes (c3 / c2: 4096 lattices and a 4096-sample minibatch; c5: d = 7, 1024 per GPU): DQNCore.step_and_update (four forwards in one pair of launches with
     32-row dense workgroups, next minibatch drawn on the environment launch, TD step inside the backward, Adam on its reduction) leaves
@@ -312,12 +312,15 @@ def test_fused_step_equals_separate_calls_at_baseline_size(dq, torch_mod, name):
     N, cfg = {"c3": (4096, dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)),
               "c5": (1024, dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005)),
               "c2": (4096, dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007)),
-              "c3-ragged": (1003, dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011))}[name]
+              "c3-ragged": (1003, dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)),
+              # 18 input planes: outside what the fused chains cover -> the per-layer GEMM path behind the same calls
+              "per-layer": (96, dict(d=7, error_model="DP", use_Y=False, volume_depth=16, p_phys=0.004, p_meas=0.004))}[name]
     B = 777 if name == "c3-ragged" else N                           # neither a multiple of the 8 / 16 / 32 samples a workgroup takes
     cores = []
     for _ in range(2):
         env = dq.VectorEnv(n_envs=N, **cfg)
         net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=N)
+        assert net.fused_supported == (name != "per-layer")
         core = dq.DQNCore(env, net, batch_size=B, memory_limit=N * 12, gamma=0.99, lr=1e-3)
         core.reset_env()
         for _ in range(4):
