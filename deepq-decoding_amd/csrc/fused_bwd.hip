@@ -886,39 +886,47 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         {
             const u8* cp = s_col + 16 * (wave >> 2) + j;           // + 32 per further tile of this wave (k-tile + 2)
             const float* gp = s_a1 + 16 * (wave & 3) + j;
-            // 8 MFMA steps (32 rows) per trip, software-pipelined by hand: the LDS reads of trip t + 1 are issued before the MFMAs of
-            // trip t (with two waves per SIMD the read -> wait -> convert -> MFMA chain is otherwise exposed: pipe 39% busy)
-            auto rd = [&](int m0, float (&av)[8][NW1], float (&g)[8]) {
+            // On the bf16 pipe, exactly: the patch operand is binary (exact in bf16) and g1 is split into three bf16 pieces, so one K = 32
+            // MFMA per piece replaces eight f32 MFMAs (96 instead of 512 pipe cycles per 32 rows and two tiles) and the eight byte ->
+            // float conversions per tile become four multiplies.  Lane (j, kq) supplies rows m0 + 8kq .. + 7 of column j of both
+            // operands.  The LDS reads of trip t + 1 are issued before the MFMAs of trip t.
+            auto rd = [&](int m0, u32 (&ab)[NW1][8], float (&g)[8]) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int m = m0 + 4 * q + kq;
+                for (int e = 0; e < 8; ++e) {
+                    const int m = m0 + 8 * kq + e;
                     const bool ok = m < M1;
                     const int mc = ok ? m : 0;
 #pragma unroll
                     for (int u = 0; u < NW1; ++u) {
                         const bool tv = wave + CB_WAVES * u < 4 * KG1;                                  // this wave has a u-th tile
-                        const u8 rb = cp[mc * KP + (tv ? 32 * u : 0)];                                  // unconditional, then select
-                        av[q][u] = (ok && tv) ? (float)rb : 0.f;
+                        ab[u][e] = cp[mc * KP + (tv ? 32 * u : 0)];                                     // 0 or 1; rows past M1 are masked through g
                     }
                     const float rg = gp[mc * A1PS];
-                    g[q] = ok ? rg : 0.f;
+                    g[e] = ok ? rg : 0.f;
                 }
             };
             // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
-            // (each copy waits for the result) -- a tile this wave does not have just accumulates zeros and is never stored
-            auto mm = [&](const float (&av)[8][NW1], const float (&g)[8]) {
+            // (each copy waits for the result) -- a tile this wave does not have accumulates garbage that is never stored
+            auto mm = [&](const u32 (&ab)[NW1][8], const float (&g)[8]) {
+                const Bf16x3 gb = split_bf16x3(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int u = 0; u < NW1; ++u) {
+                    u32x4 av;
 #pragma unroll
-                    for (int u = 0; u < NW1; ++u) acc1[u] = MFMA16(av[q][u], g[q], acc1[u]);
-                    bs1 += g[q];
+                    for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[u][e] | (ab[u][e + 1] << 16)) * 0x3f80u;      // bf16(1.0) = 0x3f80
+                    acc1[u] = MFMA_BF16(av, gb.h, acc1[u]);
+                    acc1[u] = MFMA_BF16(av, gb.m, acc1[u]);
+                    acc1[u] = MFMA_BF16(av, gb.l, acc1[u]);
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bs1 += g[e];
             };
-            float avA[8][NW1], gA[8], avB[8][NW1], gB[8];
-            rd(0, avA, gA);
+            u32 abA[NW1][8], abB[NW1][8];
+            float gA[8], gB[8];
+            rd(0, abA, gA);
             for (int m0 = 0;;) {
-                rd(m0 + 32, avB, gB); mm(avA, gA); m0 += 32; if (m0 >= M1) break;
-                rd(m0 + 32, avA, gA); mm(avB, gB); m0 += 32; if (m0 >= M1) break;
+                rd(m0 + 32, abB, gB); mm(abA, gA); m0 += 32; if (m0 >= M1) break;
+                rd(m0 + 32, abA, gA); mm(abB, gB); m0 += 32; if (m0 >= M1) break;
             }
         }
     }
