@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the DeepQ-Decoding hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode loop|env] [--config c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode loop|act|learn|env] [--config c3] [--minibatch B]
 
 One "step" = one pass of the hot path over one batch: every lattice of the batch (4096 per GPU at the
 headline config c3: d=5 depolarising p=0.011 with faulty syndromes, depth 5) receives an action, the
@@ -10,11 +10,21 @@ batched environment kernel steps them, the transition lands in the device replay
 `value` = whole-job env steps/s with all inputs resident in HBM; `roofline` is for the dominant kernel;
 `cpu_baseline` times the CPU oracle (a port; the reference's Python cannot travel to the GPU box) on
 this host's cores for a bounded sample.
+
+Modes (SURVEY.md 8d "reported numbers"): `loop` (iv) full loop, the default and the headline; `env` (i) environment kernel
++ uniform-legal device policy; `act` (ii) Q forward + epsilon-greedy + environment step, no learning; `learn` (iii) the
+learner alone -- replay sampling, three forwards, TD step, backward, Adam on a pre-filled ring (value = trained samples/s).
+
+`--gpus N` with N > 1 and no torchrun environment re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU over RCCL);
+a run whose world size differs from --gpus fails instead of printing a line.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +39,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA dense peak
+METRIC = "env steps/sec + DQN updates/sec, d=5 depolarising, batch 4096, 1/2/4/8 GPU"
 
 
 def env_bytes_per_step(cfg):
@@ -40,6 +51,7 @@ def env_bytes_per_step(cfg):
     return 2 * S + 4 + 4 + 1 + 8 * ((n_act + 63) // 64) + (cfg["volume_depth"] + layers) * (2 * d + 1) ** 2
 
 
+# ---- CPU baselines (the only place the oracle is used here: as the thing TIMED beside the GPU, never as the product) ---------------
 def cpu_baseline_env(cfg, seconds=10.0):
     """C oracle (oracle/env_oracle.c, a port of the reference's Environments.py) on ONE host core:
     same lattices, same uniform-over-legal policy, bounded to ~`seconds`."""
@@ -58,26 +70,114 @@ def cpu_baseline_env(cfg, seconds=10.0):
                 sample=f"{steps} vector steps x {n} lattices, C oracle env + uniform-legal policy, {dt:.1f}s")
 
 
+def _cpu_learner(cfg, c_layers, ff_layers):
+    import numpy as np
+    from oracle import c_oracle, dqn_oracle as O, torch_dqn
+    kw = {k: v for k, v in cfg.items() if k != "n_envs"}
+    env = c_oracle.COracleEnv(n_envs=cfg["n_envs"], **kw)
+    spec = O.QNetSpec(env.obs_shape, c_layers, ff_layers, env.num_actions)
+    return env, spec, torch_dqn.TorchDQN(spec, O.glorot_init(spec, (1, 2)).astype(np.float32), lr=1e-4), np
+
+
+def cpu_baseline_loop(cfg, B, eps, c_layers, ff_layers, mode="loop", seconds=12.0, seconds_b32=6.0):
+    """The SAME loop on this host's cores, assembled from the oracles: C-oracle environment (a port of Environments.py, one core)
+    + the torch-CPU fp32 restatement of the keras-rl / Keras update (oracle/torch_dqn.py; oneDNN convolutions + autograd on all
+    cores -- the closest thing to the reference's TensorFlow-CPU learner that runs here).  Bounded: whole vector steps until
+    ~`seconds` have elapsed (at least 2).  A second leg times the learner alone at minibatch 32, the reference's own setting, to
+    set beside its recorded 38-42 updates/s."""
+    import torch
+    env, spec, learner, np = _cpu_learner(cfg, c_layers, ff_layers)
+    n, T = cfg["n_envs"], 6
+    ring_obs = np.zeros((T, n) + env.obs_shape, np.uint8)
+    ring_a, ring_r, ring_t = np.zeros((T, n), np.int64), np.zeros((T, n), np.float32), np.zeros((T, n), np.uint8)
+    rng = np.random.RandomState(0)
+    ring_obs[0] = env.reset()
+    units, rate = ff_layers[0]
+    cur, filled, steps, updates, t0 = 0, 1, 0, 0, time.perf_counter()
+
+    def one_update(batch):
+        back = rng.randint(2, max(3, filled), size=batch)                  # keras-rl's range: never the newest transition
+        e = rng.randint(0, n, size=batch)
+        s0 = (cur - back) % T
+        s1 = (s0 + 1) % T
+        keep = rng.rand(batch, units) >= rate
+        learner.update(ring_obs[s0, e], ring_a[s0, e], ring_r[s0, e], ring_t[s0, e], ring_obs[s1, e], keep)
+
+    while steps < 2 or time.perf_counter() - t0 < seconds:
+        if mode != "learn" or filled < T:
+            with torch.no_grad():
+                q = learner.forward(learner.params, ring_obs[cur]).numpy()
+            a = np.where(rng.rand(n) < eps, env.policy_uniform_legal(steps), q.argmax(axis=1)).astype(np.int32)
+            nxt = (cur + 1) % T
+            obs, r, done = env.step(a, auto_reset=True)
+            ring_obs[nxt], ring_a[cur], ring_r[cur], ring_t[cur] = obs, a, r, done
+            cur, filled = nxt, min(T, filled + 1)
+            if mode == "learn" and filled == T:
+                steps, t0 = 0, time.perf_counter()                         # ring filled: the learner-only clock starts here
+                continue
+        if mode != "act" and filled >= 4:
+            one_update(B)
+            updates += 1
+        steps += 1
+    dt = time.perf_counter() - t0
+    out = dict(value=(B if mode == "learn" else n) * steps / dt, unit="dqn_samples/s" if mode == "learn" else "env_steps/s",
+               cores=os.cpu_count(), kind="port", torch_threads=torch.get_num_threads(),
+               sample=f"{steps} vector steps x {n} lattices, mode={mode} (C-oracle env step on one core; Q forward"
+                      f"{'' if mode == 'act' else f' + one {B}-sample double-DQN update'} in torch-CPU fp32 on all cores), {dt:.1f}s",
+               dqn_updates_per_s=(updates / dt) if mode != "act" else None)
+    if mode != "act" and seconds_b32 > 0 and filled >= 4:
+        t1, k = time.perf_counter(), 0
+        while k < 3 or time.perf_counter() - t1 < seconds_b32:
+            one_update(32)
+            k += 1
+        out["minibatch32_updates_per_s"] = k / (time.perf_counter() - t1)
+        out["reference_recorded_updates_per_s"] = "38.4-41.6 (4 cores, TF-CPU, 2018; trained_models/d5_dp/*/training_history.json)"
+    return out
+
+
+# ---- launch plumbing -----------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """--gpus N > 1 without a torchrun environment: re-run this script under torch.distributed.run, one rank per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS="4")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--mode", default="auto", choices=["auto", "loop", "env"])
+    ap.add_argument("--mode", default="loop", choices=["loop", "act", "learn", "env"])
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--minibatch", type=int, default=0, help="DQN minibatch per rank (default: n_envs)")
+    ap.add_argument("--lattices", type=int, default=0, help="lattices per rank (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a run of a different size")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     # one rank per GPU; DQ_DIST_BACKEND=gloo (+ several ranks on one GPU) exists only to exercise the multi-rank code path on a
     # single-GPU box -- its numbers mean nothing
     backend = os.environ.get("DQ_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        sys.exit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node has {torch.cuda.device_count()}")
     device = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device)
     if world > 1:
@@ -86,20 +186,19 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        assert dist.get_world_size() == args.gpus
 
     dq = importlib.import_module("deepq-decoding_amd")
     cfg = dict(CONFIGS[args.config])
-    n_local = cfg.pop("n_envs")
+    n_local = args.lattices or cfg.pop("n_envs")
+    cfg.pop("n_envs", None)
     mode = args.mode
-    if mode == "auto":
-        mode = "loop" if hasattr(dq, "bench_loop") or _has_agent() else "env"
 
     if mode == "env":
         runner = EnvOnly(dq, cfg, n_local, rank)
     else:
         runner = importlib.import_module("deepq-decoding_amd.bench_loop").FullLoop(
-            dq, cfg, n_local, rank, world, args.minibatch or n_local)
+            dq, cfg, n_local, rank, world, args.minibatch or n_local, mode=mode, config_name=args.config)
 
     def sync():
         if world > 1:
@@ -122,7 +221,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    replicas_identical = None
+    replicas_identical, allreduce = None, None
     if world > 1 and hasattr(runner, "core"):
         # outside the timed region: every rank must hold bit-identical parameters (same all-reduced gradient, same Adam step)
         chk = runner.core.params.view(torch.int32).to(torch.int64).sum().reshape(1)
@@ -132,12 +231,14 @@ def main():
         replicas_identical = bool(lo.item() == hi.item())
         if not replicas_identical and rank == 0:
             print("WARNING: the ranks' parameters diverged", file=sys.stderr)
+        allreduce = allreduce_probe(torch, dist, runner.core, backend)
 
     if rank == 0:
+        units = runner.units_per_step() if hasattr(runner, "units_per_step") else n_local
         out = {
-            "metric": "env steps/sec + DQN updates/sec, d=5 depolarising, batch 4096, 1/2/4/8 GPU",
-            "value": n_local * world * args.steps / dt,
-            "unit": "env_steps/s",
+            "metric": METRIC,
+            "value": units * world * args.steps / dt,
+            "unit": getattr(runner, "unit", "env_steps/s"),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -151,21 +252,44 @@ def main():
                                     f"{n_local} lattices/GPU, mode={mode}", **runner.config()),
         }
         out.update(runner.report(args.steps, dt, world))
-        if replicas_identical is not None:
+        if world > 1:
+            out["rccl_ranks"] = world if backend == "nccl" else 0
+            out["dist_backend"] = "rccl" if backend == "nccl" else backend
             out["replicas_identical"] = replicas_identical
+            out["allreduce"] = allreduce
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = runner.cpu_baseline(dict(cfg, n_envs=n_local))
-        print(json.dumps(out))
+            full = dict(cfg, n_envs=n_local)
+            if mode == "env":
+                out["cpu_baseline"] = cpu_baseline_env(full)
+            else:
+                bl = importlib.import_module("deepq-decoding_amd.bench_loop")
+                out["cpu_baseline"] = cpu_baseline_loop(full, runner.B, runner.eps, bl.C_LAYERS, bl.FF_LAYERS, mode=mode)
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
-def _has_agent():
-    try:
-        importlib.import_module("deepq-decoding_amd.bench_loop")
-        return True
-    except ImportError:
-        return False
+def allreduce_probe(torch, dist, core, backend, iters=20):
+    """The step's two gradient all-reduces on their own (untimed region): bytes and average microseconds, HIP events on the current
+    stream around blocking-semantics collectives (the stream waits for the communicator's stream)."""
+    nconv = core.net.n_conv_params
+    parts = {"dense": core.grads[nconv:].clone(), "conv": core.grads[:nconv].clone()}
+    out = {"backend": "rccl" if backend == "nccl" else backend, "per_step": "dense range asynchronous behind the convolutional backward, "
+           "convolutional range on the critical path"}
+    for name, buf in parts.items():
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name + "_bytes"] = buf.numel() * 4
+        out[name + "_us"] = 1e3 * e0.elapsed_time(e1) / iters
+    return out
 
 
 class EnvOnly:
@@ -200,12 +324,10 @@ class EnvOnly:
         ms = sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
         bytes_per_launch = env_bytes_per_step(self.cfg) * self.n
         achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+        bl = importlib.import_module("deepq-decoding_amd.bench_loop")
         return {"roofline": dict(kernel="env_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                                 frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_us=ms * 1e3,
+                                 frac=achieved / HBM_PEAK_GBS, traffic=bl.pmc_traffic("env_kernel", "env", "c3"), avg_launch_us=ms * 1e3,
                                  algorithmic_bytes_per_launch=bytes_per_launch)}
-
-    def cpu_baseline(self, cfg):
-        return cpu_baseline_env(cfg)
 
 
 if __name__ == "__main__":

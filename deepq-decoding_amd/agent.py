@@ -248,7 +248,10 @@ class FileLogger(Callback):
 
     def on_episode_end(self, episode, logs=None):
         logs = dict(logs or {})
-        logs["episode"] = episode
+        duration = logs.pop("duration", None)
+        logs["episode"] = episode                       # keras-rl appends ('episode', ...) and ('duration', ...) behind the agent's log
+        if duration is not None:
+            logs["duration"] = duration
         for k, v in logs.items():
             self.data.setdefault(k, []).append(v)
         if self.interval is not None and episode % self.interval == 0:
@@ -345,6 +348,7 @@ class DQNAgent:
         if venv.num_actions != self.nb_actions or tuple(venv.obs_shape) != tuple(self.model.input_shape):
             raise ValueError("environment and model shapes disagree")
         old = self.model.get_weights()
+        prev = self._core
         max_batch = max(self.batch_size, venv.n_envs)
         self._net = QNetwork(self.model.input_shape, self.model.c_layers, self.model.ff_layers, self.nb_actions,
                              dueling=self.enable_dueling_network, max_batch=max_batch, device=venv.device)
@@ -360,8 +364,26 @@ class DQNAgent:
             self._net.set_weights(self._core.params, old)
             self._core.repack()
             self._core.update_target_hard()
+        if prev is not None:
+            # a different environment object (e.g. test() on a lattice with other rates): the learner's state moves over -- Adam
+            # moments, update counter, target network, and the replay ring when its shape still fits
+            c = self._core
+            c.m.copy_(prev.m); c.v.copy_(prev.v); c.target.copy_(prev.target)
+            if c.target_pk is not None and prev.target_pk is not None:
+                c.target_pk.copy_(prev.target_pk)
+            c.updates, c.vector_steps = prev.updates, prev.vector_steps
+            if tuple(prev.obs_ring.shape) == tuple(c.obs_ring.shape):
+                for a, b in ((c.obs_ring, prev.obs_ring), (c.action_ring, prev.action_ring), (c.reward_ring, prev.reward_ring),
+                             (c.terminal_ring, prev.terminal_ring)):
+                    a.copy_(b)
+                c.cur, c.filled = prev.cur, prev.filled
+            elif prev.filled > 1:
+                warnings.warn("the replay memory of the previous environment does not fit the new one (other lattice count or "
+                              "observation shape) and was dropped")
         self.memory._core = self._core
-        self.memory._restore_into(self._core)
+        if prev is None and self.memory._saved is not None and not self.memory._restore_into(self._core):
+            warnings.warn("the unpickled replay memory does not fit this environment (ring shape "
+                          f"{tuple(self.memory._saved['obs_shape'])} vs {tuple(self._core.obs_ring.shape)}) and was dropped")
         return venv
 
     # -- single-observation API (notebook 3 cell 24: action = dqn.forward(input_state)) ----------------------------
@@ -410,7 +432,12 @@ class DQNAgent:
         venv = self._bind(env)
         core, N = self._core, venv.n_envs
         self.training = True
-        callbacks = list(callbacks or [])
+        # several ranks: episode statistics are summed over the ranks at every synchronisation point so that all of them stop on the
+        # same step (a rank leaving alone would hang the others in the gradient all-reduce); callbacks and printing on rank 0 only
+        lead = core.rank == 0
+        callbacks = list(callbacks or []) if lead else []
+        if not lead:
+            verbose = 0
         history = History()
         for cb in callbacks:
             cb.on_train_begin()
@@ -444,7 +471,7 @@ class DQNAgent:
                 if core.vector_steps % sync_interval != 0:
                     continue
                 # ---- host sync: episode bookkeeping ---------------------------------------------------------------
-                n_ep, life_sum, n_rew, n_stepped = core.read_stats()
+                n_ep, life_sum, n_rew, n_stepped = core.read_stats(all_ranks=True)
                 if trained:
                     loss_v, mean_q_v = core.read_metrics()
                     losses.append(loss_v)
@@ -471,17 +498,20 @@ class DQNAgent:
                     has_succeeded = True
                 if stopping_patience is not None and time_since_best >= stopping_patience:
                     stopped_improving = True
+                # key order and value types of the reference's training_history.json (trained_models/*/*/training_history.json):
+                # the three metrics first, then the fork's episode log, then FileLogger's own 'episode' and 'duration'
                 logs = {
-                    "episode_reward": ep_reward / n_ep, "nb_episode_steps": ep_steps / n_ep if N > 1 else ep_steps,
-                    "nb_steps": self.step, "duration": now - ep_start,
-                    "episode_lifetimes_rolling_avg": rolling, "best_rolling_avg": best_avg, "best_episode": best_episode,
-                    "time_since_best": time_since_best, "has_succeeded": has_succeeded, "stopped_improving": stopped_improving,
                     "loss": float(np.mean(losses)) if losses else float("nan"), "mean_q": float(np.mean(qs)) if qs else float("nan"),
                     "mean_eps": float(np.mean(epss)) if epss else float("nan"),
+                    "episode_reward": float(ep_reward / n_ep), "nb_episode_steps": int(round(ep_steps / n_ep)),
+                    "nb_steps": int(self.step * core.world_size),
+                    "episode_lifetimes_rolling_avg": float(rolling), "best_rolling_avg": float(best_avg), "best_episode": int(best_episode),
+                    "time_since_best": int(time_since_best), "has_succeeded": has_succeeded, "stopped_improving": stopped_improving,
                 }
-                history.append(dict(logs, episode=episode - 1))
+                history.append(dict(logs, episode=episode - 1, duration=now - ep_start))
                 for cb in callbacks:
-                    cb.on_episode_end(episode - 1, logs)
+                    cb.on_episode_end(episode - 1, dict(logs, duration=now - ep_start))
+                logs["duration"] = now - ep_start
                 if verbose >= 2 and (episode // max(1, log_interval)) != ((episode - n_ep) // max(1, log_interval)):
                     self._print_train_block(episode, nb_steps, logs, now - t_start)
                 ep_start, ep_steps, ep_reward = now, 0, 0.0
@@ -496,7 +526,7 @@ class DQNAgent:
             cb.on_train_end()
         if verbose >= 1:
             final = history.history.get("episode_lifetimes_rolling_avg", [float("nan")])[-1]
-            print(f"Training Finished in {dt:.3f} seconds\n\nFinal Step: {self.step}\nSucceeded: {has_succeeded}\n"
+            print(f"Training Finished in {dt:.3f} seconds\n        \nFinal Step: {self.step * core.world_size}\nSucceeded: {has_succeeded}\n"
                   f"Stopped_Improving: {stopped_improving}\nFinal Episode Lifetimes Rolling Avg: {final:.3f}")
         self.training = False
         return history
@@ -517,7 +547,8 @@ class DQNAgent:
 
     @staticmethod
     def _print_train_block(episode, nb_steps, logs, total):
-        print("-----------------\n")
+        # README.md:411-427, character for character (the separator is followed by a line of 16 blanks)
+        print("-----------------\n                ")
         print(f"Episode: {episode}\nStep: {logs['nb_steps']}/{nb_steps}\nThis Episode Steps: {logs['nb_episode_steps']}\n"
               f"This Episode Reward: {logs['episode_reward']}\nThis Episode Duration: {logs['duration']:.3f}s\n"
               f"Rolling Lifetime length: {logs['episode_lifetimes_rolling_avg']:.3f}\nBest Lifetime Rolling Avg: {logs['best_rolling_avg']}\n"
@@ -540,6 +571,13 @@ class DQNAgent:
         quota = np.full(N, nb_episodes // N, dtype=np.int64)
         quota[:nb_episodes % N] += 1
         eps, masked = self.test_policy.current(False)
+        core.begin_eval()                           # nothing of the evaluation reaches the replay memory (keras-rl: training=False)
+        try:
+            return self._test_loop(core, venv, N, quota, eps, masked, history, verbose, interval)
+        finally:
+            core.end_eval()
+
+    def _test_loop(self, core, venv, N, quota, eps, masked, history, verbose, interval):
         core.reset_env()
         ep_reward, ep_len = np.zeros(N), np.zeros(N, dtype=np.int64)
         lifetimes, episode = [], 0

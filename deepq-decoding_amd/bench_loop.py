@@ -18,33 +18,53 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 (MI355X_MICROARCH.md); the fus
 HBM_PEAK_GBS = 8000.0
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_pmc_traffic.json, produced by
-    tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied); None if the
-    file or the kernel is missing.  PMC counters cannot be collected inside a timed run, so this is the last recorded value."""
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/deepq_hip.h): stamps a PMC pass with the code it measured."""
+    import glob
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h"))) + \
+            [os.path.join(here, "..", "include", "deepq_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel, mode="loop", config="c3"):
+    """HBM bytes per launch of `kernel` from the committed PMC pass profiles/pmc_traffic_<mode>_<config>.json (tools/pmc_traffic.sh:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied).  PMC counters cannot be collected
+    inside a timed run, so this is a recorded value -- valid only for the kernel sources it was taken with: the file carries their
+    sha256 (csrc_digest) and anything else (stale pass, missing file, unknown kernel) gives None."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"pmc_traffic_{mode}_{config}.json")
     try:
         with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
+            rec = json.load(f)
+        if rec.get("csrc_sha256") != csrc_digest():
+            return None
+        return rec["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         return None
 
 
 class FullLoop:
-    dtype = "f32"
+    # f32 results (1e-5 against the float64 oracle); the hot products are issued on the bf16 matrix pipe as exact 3-way splits
+    dtype = "f32 (operands split exactly into 3 bf16 pieces, 3 or 6 bf16 MFMAs per product, f32 accumulate)"
 
     def __init__(self, dq, cfg, n_local, rank, world, minibatch, eps=0.1, replay_transitions=1 << 20, lr=1e-4,
-                 target_every=32):
+                 target_every=32, mode="loop", config_name="c3"):
         self.cfg, self.n, self.rank, self.world, self.B = cfg, n_local, rank, world, minibatch
-        self.eps, self.target_every = eps, target_every
+        self.eps, self.target_every, self.mode, self.config_name = eps, target_every, mode, config_name
+        self.unit = "dqn_samples/s" if mode == "learn" else "env_steps/s"
         self.env = VectorEnv(n_envs=n_local, env_id_base=rank * n_local, **cfg)
         self.net = QNetwork(self.env.obs_shape, C_LAYERS, FF_LAYERS, self.env.num_actions, dueling=True, max_batch=max(n_local, minibatch))
         self.core = DQNCore(self.env, self.net, batch_size=minibatch, memory_limit=replay_transitions, gamma=0.99, lr=lr,
                             rank=rank, world_size=world)
         self.core.reset_env()
-        for _ in range(4):                      # a few transitions before the first update
+        for _ in range(32 if mode == "learn" else 4):      # a few transitions before the first update
             self.core.act_and_step(self.eps)
         self.layer_macs = self._layer_macs()
         self.macs = sum(self.layer_macs)
@@ -74,7 +94,10 @@ class FullLoop:
         nc = len(C_LAYERS)
         lm = self.layer_macs
         conv, dense = sum(lm[:nc]), sum(lm[nc:])
-        fwd_samples = self.n + 3 * self.B
+        fwd_samples = {"loop": self.n + 3 * self.B, "act": self.n, "learn": 3 * self.B}[self.mode]
+        if self.mode == "act":
+            assert self.net.fused_supported
+            return {"conv_chain_kernel": (1, 2.0 * conv * fwd_samples, "mfma"), "dense_chain_kernel": (1, 2.0 * dense * fwd_samples, "mfma")}
         if self.net.fused_supported:
             # one forward launch pair per step (the acting forward and the update's three forwards share it), one launch per
             # backward kernel
@@ -129,8 +152,17 @@ class FullLoop:
             per_step = self.kernel_families()[self.prof_family][0]
             _lib.check(self.L.dq_prof_arm(self._family_id(self.prof_family), steps * per_step + 8))
 
+    def units_per_step(self):
+        return self.B if self.mode == "learn" else self.n
+
     def step(self, timed):
-        self.core.step_and_update(self.eps)          # == act_and_step() + update(), the four forwards in one pair of launches
+        if self.mode == "act":
+            self.core.act_and_step(self.eps)
+            return
+        if self.mode == "learn":
+            self.core.update()
+        else:
+            self.core.step_and_update(self.eps)      # == act_and_step() + update(), the four forwards in one pair of launches
         if self.core.updates % self.target_every == 0:
             self.core.update_target_hard()
 
@@ -142,7 +174,8 @@ class FullLoop:
 
     def report(self, steps, dt, world):
         ep, life, rew, stepped = self.core.read_stats()
-        flops_per_step = 2 * self.macs * (self.n * 1 + self.B * 5)       # acting forward + update (3 fwd + bwd = 5x fwd)
+        # acting forward + update (3 fwd + bwd = 5x fwd)
+        flops_per_step = 2 * self.macs * {"loop": self.n + self.B * 5, "act": self.n, "learn": self.B * 5}[self.mode]
         roof = None
         if self.prof_family:
             launches, ms = self._collect()
@@ -153,7 +186,7 @@ class FullLoop:
                 per_launch = work / per_step
                 achieved = per_launch / avg_s / 1e12
                 roof = dict(kernel=self.prof_family, bound=bound, achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=_pmc_traffic(self.prof_family), avg_launch_us=avg_s * 1e6,
+                            frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=pmc_traffic(self.prof_family, self.mode, self.config_name), avg_launch_us=avg_s * 1e6,
                             launches_timed=launches, algorithmic_flops_per_launch=per_launch)
                 issued = self.bf16_pipe_factor().get(self.prof_family)
                 if issued:
@@ -162,57 +195,10 @@ class FullLoop:
                                              frac=achieved * issued / MFMA_BF16_PEAK_TFLOPS, mfmas_per_f32_product=issued)
         out = {
             "roofline": roof,
-            "dqn_updates_per_s": steps / dt,
-            "dqn_samples_per_s": steps * self.B * world / dt,
+            "dqn_updates_per_s": 0.0 if self.mode == "act" else steps / dt,
+            "dqn_samples_per_s": 0.0 if self.mode == "act" else steps * self.B * world / dt,
             "achieved_qnet_tflops_per_gpu": flops_per_step * steps / dt / 1e12,
             "episodes_finished_rank0": ep,
             "mean_lifetime_rank0": (life / ep) if ep else None,
         }
         return out
-
-    def cpu_baseline(self, cfg, seconds=15.0):
-        """The SAME loop on this host's cores, assembled from the oracles (test infrastructure, used here only as the timed
-        CPU baseline): C oracle environment (a port of Environments.py) + numpy float64 restatement of the keras-rl / Keras
-        update (BLAS-threaded im2col GEMMs).  Bounded: whole vector steps until ~`seconds` have elapsed (at least 2)."""
-        import os
-        import time
-
-        import numpy as np
-
-        from oracle import c_oracle, dqn_oracle as O
-        n, B, eps, gamma = cfg["n_envs"], self.B, self.eps, 0.99
-        kw = {k: v for k, v in cfg.items() if k != "n_envs"}
-        env = c_oracle.COracleEnv(n_envs=n, **kw)
-        spec = O.QNetSpec(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions)
-        flat = O.glorot_init(spec, (1, 2)).astype(np.float64)
-        target, m, v = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
-        T = 6
-        ring_obs = np.zeros((T, n) + env.obs_shape, np.uint8)
-        ring_a, ring_r, ring_t = np.zeros((T, n), np.int32), np.zeros((T, n), np.float32), np.zeros((T, n), np.uint8)
-        rng = np.random.RandomState(0)
-        ring_obs[0] = env.reset()
-        cur, filled, steps, t0 = 0, 1, 0, time.perf_counter()
-        while steps < 2 or time.perf_counter() - t0 < seconds:
-            q, _ = O.forward(spec, flat, ring_obs[cur])
-            a = np.where(rng.rand(n) < eps, env.policy_uniform_legal(steps), q.argmax(axis=1)).astype(np.int32)
-            nxt = (cur + 1) % T
-            obs, r, done = env.step(a, auto_reset=True)
-            ring_obs[nxt], ring_a[cur], ring_r[cur], ring_t[cur] = obs, a, r, done
-            cur, filled, steps = nxt, min(T, filled + 1), steps + 1
-            back = rng.randint(1, filled, size=B)                     # transition = (slot cur-back, slot cur-back+1)
-            e = rng.randint(0, n, size=B)
-            s0 = (cur - back) % T
-            s1 = (s0 + 1) % T
-            q1_t, _ = O.forward(spec, target, ring_obs[s1, e])
-            q1_o, _ = O.forward(spec, flat, ring_obs[s1, e])
-            y = O.td_targets(q1_o, q1_t, ring_r[s0, e], ring_t[s0, e], gamma)
-            keep = rng.rand(B, FF_LAYERS[0][0]) >= FF_LAYERS[0][1]
-            q0, cache = O.forward(spec, flat, ring_obs[s0, e], training=True, keep_masks=[keep])
-            _, _, dq = O.loss_and_grad(q0, ring_a[s0, e], y)
-            g = O.backward(spec, flat, cache, dq)
-            flat, m, v = O.adam_step(flat, g, m, v, steps, 1e-4)
-        dt = time.perf_counter() - t0
-        return dict(value=n * steps / dt, unit="env_steps/s", cores=os.cpu_count(), kind="port",
-                    sample=f"{steps} vector steps x {n} lattices (acting forward + C-oracle env step + one {B}-sample double-DQN update "
-                           f"in numpy float64, BLAS threads = all cores), {dt:.1f}s",
-                    dqn_updates_per_s=steps / dt)

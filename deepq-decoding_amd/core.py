@@ -23,7 +23,7 @@ from . import _lib, dist as _dist, qnet as _q
 from ._lib import check, ptr
 
 
-MIN_FILLED = 4      # ring slots an update needs: keras-rl never samples the two newest transitions (csrc/common.h dq_replay_row)
+MIN_FILLED = 4      # ring slots an update needs: keras-rl asserts nb_entries >= window_length + 2 (csrc/common.h dq_replay_row)
 
 
 class DQNCore:
@@ -228,8 +228,10 @@ class DQNCore:
 
     def step_and_update(self, eps, masked_greedy=False, record_stats=True, presample_next=True):
         """act_and_step() followed by update(), with the acting forward and the update's forwards in ONE pair of launches -- same
-        results as the two calls.  Possible because the update's minibatch never contains the two newest transitions (keras-rl's
-        range), so it does not depend on this step's environment results: the parameters are the same for all four forwards.
+        results as the two calls.  Possible because the update's minibatch never contains the newest transition (keras-rl's range:
+        its successor observation is not in the memory yet), so it does not depend on this step's environment results -- the newest
+        row it can hold is the previous step's, whose successor is the observation this step acts on: the parameters are the same
+        for all four forwards.
         With presample_next the environment launch also draws the NEXT step's minibatch (if that step does not update, update()
         notices the stale draw and redraws)."""
         self._flush_stats()
@@ -289,10 +291,43 @@ class DQNCore:
         if self.target_pk is not None:
             self.target_pk.copy_(self.params_pk)
 
-    def read_stats(self, reset=True):
-        """(episodes ended, sum of their lifetimes, rewards earned, lattices stepped) since the last reset; syncs."""
+    def read_stats(self, reset=True, all_ranks=False):
+        """(episodes ended, sum of their lifetimes, rewards earned, lattices stepped) since the last reset; syncs.  all_ranks: summed
+        over the process group, so that every rank takes the same decisions from them (early stopping in DQNAgent.fit: a rank that left
+        the loop alone would leave the others waiting in the gradient all-reduce)."""
         self._flush_stats()
-        s = [int(x) for x in self.stats.cpu().tolist()]
+        st = self.stats
+        if all_ranks and self.world_size > 1:
+            st = st.clone()
+            _dist.allreduce_sum_(st, group=self.pg)
+        s = [int(x) for x in st.cpu().tolist()]
         if reset:
             self.stats.zero_()
         return s
+
+    # -- evaluation on a scratch ring ---------------------------------------------------------------------------------------
+    def begin_eval(self):
+        """keras-rl stores nothing in test mode (memory.append(training=False) is a no-op): greedy evaluation steps run on a scratch
+        three-slot ring, so that fit -> test -> fit (or pickling the memory after test()) never trains on evaluation transitions."""
+        assert getattr(self, "_train_ring", None) is None
+        self._flush_stats()
+        self._join_env()
+        self._train_ring = (self.obs_ring, self.action_ring, self.reward_ring, self.terminal_ring, self.T, self.cur, self.filled,
+                            self._presampled, self.started)
+        T = 3
+        dev = self.device
+        self.obs_ring = torch.zeros((T,) + tuple(self.obs_ring.shape[1:]), dtype=torch.uint8, device=dev)
+        self.action_ring = torch.zeros((T, self.N), dtype=torch.int32, device=dev)
+        self.reward_ring = torch.zeros((T, self.N), dtype=torch.float32, device=dev)
+        self.terminal_ring = torch.zeros((T, self.N), dtype=torch.uint8, device=dev)
+        self.T, self.cur, self.filled, self._presampled = T, 0, 0, None
+
+    def end_eval(self):
+        self._flush_stats()
+        self._join_env()
+        (self.obs_ring, self.action_ring, self.reward_ring, self.terminal_ring, self.T, self.cur, self.filled, self._presampled,
+         self.started) = self._train_ring
+        self._train_ring = None
+        # the lattices were reset and stepped by the evaluation: the ring's newest observation no longer describes them, so the next
+        # fit() (which calls reset_env(): previous entry marked terminal, fresh observation into slot `cur`) must not skip its reset
+        self.started = False

@@ -103,27 +103,30 @@ __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
 }
 
 // Replay row of minibatch sample `sample_id` of update t (shared by every launch that carries the sampling along).
-// keras-rl's SequentialMemory.sample draws idx from [window_length, nb_entries - 1) and uses the transition idx - 1, with the entry
-// appended at this step already counted: the two newest transitions are never sampled (the newest has no successor observation in
-// keras-rl's memory yet, the one before falls to the exclusive bound).  Here `filled` slots hold observations, the newest in slot
-// head_slot; complete transitions are slots head-1 (the step just taken), head-2, ...: candidates are head-3 downwards, filled - 3 of
-// them.  A candidate whose PREVIOUS entry was terminal is redrawn (its s0 is the terminal observation the agent only looked at before
-// env.reset()).  Because the rule never looks at the two newest slots, an update's minibatch can be drawn one vector step early.
-#define DQ_REPLAY_SKIP 2
+// Upstream keras-rl 0.4.2 SequentialMemory.sample (restated in oracle/memory_oracle.py): idx = sample_batch_indexes(window_length,
+// nb_entries - 1) + 1, i.e. idx in [2, nb_entries - 1] for window_length 1; the experience is (obs[idx-1], action[idx-1],
+// reward[idx-1], obs[idx], terminal[idx-1]); an idx with terminals[idx-2] set is redrawn from the same range (its s0 would be the
+// terminal observation the agent only looked at before env.reset()).  The entry appended at this step is counted in nb_entries, its
+// successor observation is not in keras-rl's memory yet: the newest transition is never sampled, nor is entry 0 (whose predecessor's
+// terminal flag is unknown).  Here `filled` slots hold observations, the newest in slot head_slot, so nb_entries = filled - 1 and entry
+// k lives in slot oldest + k, oldest = head - (filled - 1).  Transition idx - 1 in [1, nb_entries - 2]  <=>  slot in [oldest + 1,
+// head - 2]: filled - 3 candidates, newest first.  The sampler reads terminal[] only at slots <= head - 3 and the newest row it can
+// return is head - 2, so an update's minibatch can be drawn one vector step early (on the environment launch that WRITES slot head - 2
+// of the ring as the update will see it) and does not depend on the environment step taken in the update's own vector step.
+#define DQ_REPLAY_MIN_FILLED 4                          // nb_entries >= window_length + 2
 __device__ __forceinline__ int dq_replay_row(const u8* __restrict__ terminal, int n_envs, int n_slots, int head_slot, int filled,
                                              u32 seed0, u32 seed1, u64 t, u32 sample_id) {
-    const int cand = filled - 1 - DQ_REPLAY_SKIP;       // complete transitions minus the two newest
+    const int cand = filled - 3;
     int row = 0;
     for (u32 attempt = 0; attempt < 64; ++attempt) {
         u32 w[4];
         philox4x32_10((u32)t, (u32)(t >> 32), sample_id, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
         const int j = (int)__umulhi(w[0], (u32)cand);   // 0 = newest candidate
         const int env = (int)__umulhi(w[1], (u32)n_envs);
-        int slot = head_slot - 1 - DQ_REPLAY_SKIP - j;
+        int slot = head_slot - 2 - j;
         if (slot < 0) slot += n_slots;
         row = slot * n_envs + env;
-        if (j + 1 >= cand) break;                       // oldest stored slot: predecessor unknown -> accepted (keras-rl idx < 2)
-        int prev = slot - 1;
+        int prev = slot - 1;                            // >= oldest: always a stored entry
         if (prev < 0) prev += n_slots;
         if (!terminal[(size_t)prev * n_envs + env]) break;
     }

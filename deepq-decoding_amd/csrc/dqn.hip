@@ -204,7 +204,7 @@ dq_status dq_post_step(const uint8_t* terminal_ring_dev, int n_envs, int n_slots
                        void* stream) {
     DQ_REQUIRE(terminal_ring_dev && index_dev && seed, DQ_ERR_INVALID, "dq_post_step: null argument");
     DQ_REQUIRE(n_envs >= 1 && n_slots >= 4 && batch >= 1 && head_slot >= 0 && head_slot < n_slots, DQ_ERR_INVALID, "dq_post_step: bad sizes");
-    DQ_REQUIRE(filled_slots >= 2 + DQ_REPLAY_SKIP && filled_slots <= n_slots, DQ_ERR_STATE, "dq_post_step: need at least three complete transitions per lattice");
+    DQ_REQUIRE(filled_slots >= DQ_REPLAY_MIN_FILLED && filled_slots <= n_slots, DQ_ERR_STATE, "dq_post_step: need at least three complete transitions per lattice");
     DQ_REQUIRE((long long)n_envs * n_slots < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_post_step: ring too large for 32-bit rows");
     DQ_REQUIRE(done_dev && lifetime_dev && reward_dev && stats_dev && n >= 1, DQ_ERR_INVALID, "dq_post_step: bad statistics argument");
     const int sb = (batch + 255) / 256;
@@ -274,7 +274,7 @@ dq_status dq_replay_sample(const uint8_t* terminal_ring_dev, int n_envs, int n_s
                            const uint32_t seed[2], uint64_t t, uint32_t sample_base, int32_t* index_dev, void* stream) {
     DQ_REQUIRE(terminal_ring_dev && index_dev && seed, DQ_ERR_INVALID, "dq_replay_sample: null argument");
     DQ_REQUIRE(n_envs >= 1 && n_slots >= 4 && batch >= 1 && head_slot >= 0 && head_slot < n_slots, DQ_ERR_INVALID, "dq_replay_sample: bad sizes");
-    DQ_REQUIRE(filled_slots >= 2 + DQ_REPLAY_SKIP && filled_slots <= n_slots, DQ_ERR_STATE, "dq_replay_sample: need at least three complete transitions per lattice");
+    DQ_REQUIRE(filled_slots >= DQ_REPLAY_MIN_FILLED && filled_slots <= n_slots, DQ_ERR_STATE, "dq_replay_sample: need at least three complete transitions per lattice");
     DQ_REQUIRE((long long)n_envs * n_slots < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_replay_sample: ring too large for 32-bit rows");
     replay_sample_kernel<<<(batch + 255) / 256, 256, 0, (hipStream_t)stream>>>(terminal_ring_dev, n_envs, n_slots, head_slot, filled_slots,
                                                                              batch, seed[0], seed[1], t, sample_base, index_dev);

@@ -690,7 +690,7 @@ static dq_status act_step(dq_env* E, const float* q_dev, double eps, int masked_
         DQ_REQUIRE(sj->terminal_ring_dev && sj->index_dev, DQ_ERR_INVALID, "dq_env_act_step_sample: null argument");
         DQ_REQUIRE(sj->n_slots >= 4 && sj->batch >= 1 && sj->head_slot >= 0 && sj->head_slot < sj->n_slots, DQ_ERR_INVALID,
                    "dq_env_act_step_sample: bad sizes");
-        DQ_REQUIRE(sj->filled_slots >= 2 + DQ_REPLAY_SKIP && sj->filled_slots <= sj->n_slots, DQ_ERR_STATE,
+        DQ_REQUIRE(sj->filled_slots >= DQ_REPLAY_MIN_FILLED && sj->filled_slots <= sj->n_slots, DQ_ERR_STATE,
                    "dq_env_act_step_sample: need at least three complete transitions per lattice");
         DQ_REQUIRE((long long)E->cfg.n_envs * sj->n_slots < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_env_act_step_sample: ring too large for 32-bit rows");
         p.s_blocks = (sj->batch + 255) / 256; p.s_terminal = sj->terminal_ring_dev; p.s_n_slots = sj->n_slots; p.s_head = sj->head_slot;

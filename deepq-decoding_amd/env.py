@@ -283,7 +283,27 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
         self._pull()
 
     def reset_legal_moves(self):
-        raise NotImplementedError("legal-move bookkeeping lives on the device; call reset()")
+        """ENV:238-258: forget the moves made in this volume; legal = identity + every action on a qubit that touches a stabilizer
+        which fired anywhere in the current (faulty) volume.  The bookkeeping lives on the device: the lattice record is exported,
+        rewritten and imported back (a helper call, not part of the stepped path -- reset() / step() do this inside the kernel)."""
+        v, d2 = self._v, self.d * self.d
+        st = v.export_state()
+        w = [_u64(x) for x in st[0].cpu().tolist()]
+        fired = 0
+        for x in w[11:11 + self.volume_depth]:
+            fired |= x
+        qubit_smask = v.tables()["qubit_smask"]
+        legal = 1 << self.identity_index
+        for q in range(d2):
+            if int(qubit_smask[q]) & fired:
+                for j in range(self.n_action_layers):
+                    legal |= 1 << (q + j * d2)
+        w[4] = w[6] = w[7] = 0
+        w[8], w[9] = legal & 0xFFFFFFFFFFFFFFFF, legal >> 64
+        signed = [x - (1 << 64) if x >= (1 << 63) else x for x in w]
+        v.import_state(torch.tensor([signed], dtype=torch.int64))
+        v.legal.copy_(torch.tensor([[signed[8], signed[9]]], dtype=torch.int64))
+        self._state = None
 
     # state views in the reference's data types ----------------------------------------------------------------
     def _words(self):

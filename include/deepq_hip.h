@@ -137,8 +137,9 @@ dq_status dq_env_act_step(dq_env* env, const float* q_dev, double eps, int maske
                           uint64_t* legal_dev, uint32_t* lifetime_dev, uint8_t* was_reset_dev, void* stream);
 
 /* dq_env_act_step plus the replay sampling (dq_replay_sample's rule, same Philox stream) for a later update, in the same launch: the
- * rule never reads the two newest ring slots, so the job may describe the update that follows this step (head_slot / filled_slots
- * AFTER this step; head_slot = the slot the successor observations go to) or the one after the NEXT step (one more slot). */
+ * rule reads terminal flags no newer than slot head_slot - 3, so the job may describe the update that follows this step (head_slot /
+ * filled_slots AFTER this step; head_slot = the slot the successor observations go to) or the one after the NEXT step (one more slot;
+ * its newest candidate row is then the transition this very launch records). */
 typedef struct dq_sample_job {
     const uint8_t* terminal_ring_dev;
     int n_slots, head_slot, filled_slots, batch;
@@ -309,12 +310,14 @@ dq_status dq_qnet_td_backward_phase0(dq_qnet* net, const float* params_dev, cons
  * Device replay ring: row r = slot*n_envs + env stores (observation, action, reward, terminal) of the
  * step taken from that observation; its successor observation is row r + n_envs (mod n_slots*n_envs).
  * ------------------------------------------------------------------------------------------- */
-/* Uniform minibatch rows (with replacement) over the transitions keras-rl's SequentialMemory.sample can return: all complete
- * ones except the two newest (idx is drawn from [window_length, nb_entries - 1) and the transition used is idx - 1), redrawing those
- * whose predecessor entry was terminal.  head_slot = slot of the newest observation, filled_slots = slots written so far
- * (4 <= filled_slots <= n_slots).  Draws: Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b, attempt | DQ_STREAM_REPLAY<<16)):
- * slot = head_slot - 3 - ((w0 * (filled_slots - 3)) >> 32), env = (w1 * n_envs) >> 32.  The rule never reads the two newest slots,
- * so an update's minibatch may be drawn one vector step early (with the head_slot / filled_slots it WILL have). */
+/* Uniform minibatch rows (with replacement -- a documented deviation from random.sample) over exactly the transitions upstream
+ * keras-rl 0.4.2 SequentialMemory.sample can return (oracle/memory_oracle.py): idx = sample_batch_indexes(window_length,
+ * nb_entries - 1) + 1 and the transition used is idx - 1, i.e. every stored transition except the newest (its successor observation
+ * is not in keras-rl's memory yet) and entry 0, redrawing those whose predecessor entry was terminal (terminals[idx - 2]).
+ * head_slot = slot of the newest observation, filled_slots = slots written so far (4 <= filled_slots <= n_slots; nb_entries =
+ * filled_slots - 1).  Draws: Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b, attempt | DQ_STREAM_REPLAY<<16)):
+ * slot = head_slot - 2 - ((w0 * (filled_slots - 3)) >> 32), env = (w1 * n_envs) >> 32.  Terminal flags are read no newer than slot
+ * head_slot - 3, so an update's minibatch may be drawn one vector step early (with the head_slot / filled_slots it WILL have). */
 dq_status dq_replay_sample(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots,
                            int batch, const uint32_t seed[2], uint64_t t, uint32_t sample_base, int32_t* index_dev,
                            void* stream);

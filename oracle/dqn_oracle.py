@@ -134,7 +134,7 @@ def forward(spec, flat_params, obs, training=False, keep_masks=None):
             cols = _im2col(x, L["k"], L["s"])                                  # (B,OH,OW,K)
             z = cols @ Wk.reshape(-1, L["cout"]) + bk                          # (B,OH,OW,Cout)
             y = np.maximum(z, 0.0)
-            cache["layers"].append(dict(kind="conv", cols=cols, y=y, x_shape=x.shape))
+            cache["layers"].append(dict(kind="conv", cols=cols, y=y, z=z, x_shape=x.shape))
             x = y.transpose(0, 3, 1, 2)                                        # back to (B,C,H,W)
         else:
             if not flat_done:
@@ -149,7 +149,7 @@ def forward(spec, flat_params, obs, training=False, keep_masks=None):
                 y_out = np.where(keep, y / (1.0 - L["dropout"]), 0.0)           # K.dropout: x / keep_prob * mask
             else:
                 y_out = y
-            cache["layers"].append(dict(kind="dense", x=x, y=y, keep=keep, rate=L["dropout"], relu=L["relu"]))
+            cache["layers"].append(dict(kind="dense", x=x, y=y, z=z, keep=keep, rate=L["dropout"], relu=L["relu"]))
             x = y_out
     if spec.dueling:
         q = x[:, 0:1] + x[:, 1:] - x[:, 1:].mean(axis=1, keepdims=True)
@@ -157,6 +157,18 @@ def forward(spec, flat_params, obs, training=False, keep_masks=None):
         q = x
     cache["head_in"] = x
     return q, cache
+
+
+def fragile_samples(cache, thr=2e-5):
+    """Samples with a ReLU pre-activation within `thr` of 0: an fp32 implementation may put it on the other side of the ReLU, which
+    changes that sample's gradient by a finite amount (not a round-off).  Tests on large batches give such samples dq = 0."""
+    bad = None
+    for C in cache["layers"]:
+        if C["kind"] == "conv" or C["relu"]:
+            z = np.abs(C["z"])
+            b = (z.reshape(z.shape[0], -1) < thr).any(axis=1)
+            bad = b if bad is None else (bad | b)
+    return bad
 
 
 def backward(spec, flat_params, cache, dq):

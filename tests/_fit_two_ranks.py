@@ -1,0 +1,46 @@
+"""Helper of tests/test_distributed_gpu.py (launched under torch.distributed.run, 2 ranks, gloo, both on the one GPU): DQNAgent.fit with
+the reference's early-stopping keywords on ranks whose LOCAL episode statistics differ wildly -- every rank must leave the loop on the
+same step (the decision is taken from the all-reduced statistics), with identical parameters; only rank 0 logs."""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    out_dir = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    dq = importlib.import_module("deepq-decoding_amd")
+    N = 64
+    # rank 1's lattices are almost noiseless: its episodes are ~100x rarer than rank 0's, so a patience counted in LOCAL episodes would run out
+    # on rank 0 long before rank 1
+    p = 0.011 if rank == 0 else 0.0005
+    env = dq.VectorEnv(n_envs=N, env_id_base=rank * N, d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=p, p_meas=p)
+    model = dq.build_convolutional_nn([[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]], env.obs_shape, env.num_actions)
+    policy = dq.LinearAnnealedPolicy(dq.EpsGreedyQPolicy(masked_greedy=False), attr="eps", value_max=1.0, value_min=0.02, value_test=0.0,
+                                     nb_steps=5000)
+    agent = dq.DQNAgent(model=model, nb_actions=env.num_actions, memory=dq.SequentialMemory(limit=N * 64, window_length=1),
+                        nb_steps_warmup=N * 6, target_model_update=N * 50, policy=policy, test_policy=dq.GreedyQPolicy(masked_greedy=True),
+                        gamma=0.99, enable_dueling_network=True, batch_size=32, seed=(1, 2))
+    agent.compile(dq.Adam(lr=1e-4))
+    log = dq.FileLogger(os.path.join(out_dir, "training_history.json"), interval=1)
+    hist = agent.fit(env, nb_steps=N * 400, callbacks=[log], verbose=0, log_interval=100, episode_averaging_length=30, success_threshold=None,
+                     stopping_patience=150, min_nb_steps=N * 20, single_cycle=False, sync_interval=4)
+    chk = int(agent._core.params.view(torch.int32).to(torch.int64).sum().item())
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(dict(step=agent.step, updates=agent._core.updates, params=chk, stopped=hist.history["stopped_improving"][-1],
+                       records=len(hist.history["episode"])), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,12 +23,20 @@ def torch_mod():
     return torch
 
 
-def test_device_loop_matches_oracle_loop(dq, torch_mod):
+C5 = dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005)
+C2 = dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007)
+
+
+@pytest.mark.parametrize("name,C1,N,B,steps", [("c1", C1, 16, 8, 13), ("c3", C3, 64, 32, 12), ("c5", C5, 32, 16, 11), ("c2", C2, 48, 40, 11)],
+                         ids=["c1", "c3", "c5", "c2"])
+def test_device_loop_matches_oracle_loop(dq, torch_mod, name, C1, N, B, steps):
     """The whole loop -- Q forward, epsilon-greedy over legal moves, environment step into the ring, replay sampling,
-    double-DQN update, Adam -- against the same loop assembled from the CPU oracles, for several vector steps.
-    Actions / observations / rewards must be identical; parameters agree to fp32 round-off."""
+    double-DQN update, Adam -- against the same loop assembled from the CPU oracles (C environment oracle, float64 network oracle,
+    keras-rl memory oracle for the validity of the sampled rows), for several vector steps incl. the ring wrapping around, at every
+    BASELINE.json lattice configuration.  Actions / observations / rewards must be identical; parameters agree to fp32 round-off."""
     torch = torch_mod
-    N, B, steps, eps, gamma, lr = 16, 8, 9, 0.3, 0.99, 1e-3
+    from oracle import memory_oracle as M
+    eps, gamma, lr = 0.3, 0.99, 1e-3
     seed = (0x5EED, 0xD0DEC0DE)
     env = dq.VectorEnv(n_envs=N, seed=seed, **C1)
     net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=max(N, B))
@@ -48,7 +56,7 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod):
     ring_obs[0] = ref.obs
     for t in range(steps):
         # --- act (+ update): the three ways of driving the device loop give the same draws and the same arithmetic
-        will_update = min(T, filled + 1) >= 4                    # keras-rl never samples the two newest transitions
+        will_update = min(T, filled + 1) >= 4                    # keras-rl: nb_entries >= window_length + 2
         fused = will_update and t % 3 == 2                       # acting forward + the update's forwards in one pair of launches
         if fused:
             core.step_and_update(eps, presample_next=(t % 2 == 0))
@@ -81,10 +89,11 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod):
             for attempt in range(64):
                 w = philox.philox4x32((u, 0, b, attempt | (philox.STREAM_REPLAY << 16)), seed)
                 j, e = philox.bounded(w[0], cand), philox.bounded(w[1], N)
-                s = (cur - 3 - j) % T
-                if j + 1 >= cand or not ring_t[(s - 1) % T, e]:
+                s = (cur - 2 - j) % T
+                if not ring_t[(s - 1) % T, e]:
                     break
             assert idx[b] == s * N + e
+        assert set(idx.tolist()) <= M.valid_transitions(ring_t, N, T, cur, filled)   # rows keras-rl's sample() can return
         rows = T * N
         flat_obs = ring_obs.reshape(rows, *env.obs_shape)
         s0, s1 = flat_obs[idx], flat_obs[(idx + N) % rows]
@@ -137,6 +146,14 @@ def test_fit_and_test_single_lattice_facade(dq, torch_mod, tmp_path):
     assert any(x == x for x in h["loss"]), "no update happened after warm-up"
     data = json.loads((tmp_path / "training_history.json").read_text())
     assert set(h) <= set(data) | {"episode"}
+    # key order and value types of the reference's own files (trained_models/d5_dp/0.007/training_history.json)
+    assert list(data) == ["loss", "mean_q", "mean_eps", "episode_reward", "nb_episode_steps", "nb_steps", "episode_lifetimes_rolling_avg",
+                          "best_rolling_avg", "best_episode", "time_since_best", "has_succeeded", "stopped_improving", "episode", "duration"]
+    for key, typ in (("episode_reward", float), ("nb_episode_steps", int), ("nb_steps", int), ("episode_lifetimes_rolling_avg", float),
+                     ("best_rolling_avg", float), ("best_episode", int), ("time_since_best", int), ("has_succeeded", bool),
+                     ("stopped_improving", bool), ("episode", int), ("duration", float)):
+        assert all(type(v) is typ for v in data[key]), key
+    assert data["episode"] == list(range(len(data["episode"])))
     # weights: save / load round trip through the reference's file name; memory pickles (TRAIN:156-160)
     w_before = agent.model.get_weights()
     wfile = str(tmp_path / "final_dqn_weights.h5f")
@@ -148,11 +165,52 @@ def test_fit_and_test_single_lattice_facade(dq, torch_mod, tmp_path):
     assert mem._saved is not None and mem._saved["filled"] == agent._core.filled
     # evaluation
     env.p_phys = env.p_meas = 0.003                                           # TRAIN:200-201
+    core = agent._core
+    before = (core.cur, core.filled, core.T, core.updates, core.obs_ring.clone(), core.action_ring.clone(), core.terminal_ring.clone())
     th = agent.test(env, nb_episodes=7, visualize=False, verbose=0, interval=10, single_cycle=False)
+    # keras-rl stores nothing in test mode: the replay memory is exactly what training left
+    assert (core.cur, core.filled, core.T, core.updates) == before[:4]
+    assert all(bool((a == b).all()) for a, b in zip((core.obs_ring, core.action_ring, core.terminal_ring), before[4:]))
     assert len(th.history["episode_lifetime"]) == 7 and th.history["episode_lifetimes_rolling_avg"][-1] == np.mean(th.history["episode_lifetime"])
     assert all(l >= 3 and l % 3 == 0 for l in th.history["episode_lifetime"])     # lifetimes advance in volumes of depth 3
     a = agent.forward(env.reset())
     assert 0 <= a < env.num_actions and agent.compute_q_values(env.board_state).shape == (env.num_actions,)
+
+
+def test_log_text_follows_the_readme(dq, torch_mod, capsys):
+    """verbose=2 output of fit() / test() against the transcript in the reference's README.md:408-480,638-672: same lines, same
+    labels, same number formats (values differ, so digits are masked)."""
+    import re
+    env = dq.Surface_Code_Environment_Multi_Decoding_Cycles(static_decoder=None, **C1)
+    agent = _make_agent(dq, env.observation_space.shape, env.num_actions, warmup=20)
+    agent.fit(env, nb_steps=150, action_repetition=1, callbacks=[], verbose=2, visualize=False, nb_max_start_steps=0, start_step_policy=None,
+              log_interval=5, nb_max_episode_steps=None, episode_averaging_length=20, success_threshold=10000, stopping_patience=10000,
+              min_nb_steps=100, single_cycle=False)
+    out = capsys.readouterr().out.split("\n")
+    assert out[0] == "Training for 150 steps ..."
+    num, f3, f6 = r"\d+", r"\d+\.\d{3}", r"(nan|-?\d+\.\d{6})"
+    block = [r"-----------------", r" {16}", rf"Episode: {num}", rf"Step: {num}/150", rf"This Episode Steps: {num}", r"This Episode Reward: \d+\.\d+",
+             rf"This Episode Duration: {f3}s", rf"Rolling Lifetime length: {f3}", r"Best Lifetime Rolling Avg: \d+\.\d+", rf"Best Episode: {num}",
+             rf"Time Since Best: {num}", r"Has Succeeded: False", r"Stopped Improving: False",
+             rf"Metrics: loss: {f6}, mean_q: {f6}, mean_eps: {f6}", rf"Total Training Time: {f3}s", r""]
+    n_blocks = 0
+    i = 1
+    while out[i] == "-----------------":
+        for pat, line in zip(block, out[i:i + len(block)]):
+            assert re.fullmatch(pat, line), (pat, line)
+        i += len(block)
+        n_blocks += 1
+    assert n_blocks >= 2
+    tail = out[i:]
+    assert re.fullmatch(rf"Training Finished in {f3} seconds", tail[0]) and tail[1] == " " * 8
+    assert re.fullmatch(r"Final Step: \d+", tail[2]) and tail[3] == "Succeeded: False" and tail[4] == "Stopped_Improving: False"
+    assert re.fullmatch(rf"Final Episode Lifetimes Rolling Avg: {f3}", tail[5]) and tail[6:] == [""]
+    agent.test(env, nb_episodes=3, visualize=False, verbose=2, interval=2, single_cycle=False)
+    out = capsys.readouterr().out.split("\n")
+    assert out[0] == "Testing for 3 episodes ..." and out[1] == "-----------------" and out[2] == "Episode: 1"
+    assert re.fullmatch(r"This Episode Length: \d+", out[3]) and re.fullmatch(r"This Episode Reward: \d+\.\d", out[4])
+    assert re.fullmatch(r"This Episode Lifetime: \d+", out[5]) and out[6] == "" and re.fullmatch(r"Episode Lifetimes Avg: \d+\.\d{3}", out[7])
+    assert out[8] == "" and out[9] == "-----------------" and out[10] == "Episode: 3"
 
 
 def test_fit_vector_env_is_deterministic(dq, torch_mod):

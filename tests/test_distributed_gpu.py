@@ -1,6 +1,7 @@
 """Two ranks through the whole bench.py path on the ONE GPU of the test box (gloo moves the gradient; RCCL needs one GPU per rank):
 the several-GPU branch of the learner -- TD step + dense backward, asynchronous all-reduce of the dense gradient behind the
-convolutional backward, all-reduce of the convolutional range, separate Adam -- keeps the replicas bit-identical."""
+convolutional backward, all-reduce of the convolutional range, separate Adam -- keeps the replicas bit-identical.  `python bench.py
+--gpus 2` launches its own ranks (no torchrun wrapper); a world size that differs from --gpus is refused."""
 import json
 import os
 import subprocess
@@ -11,14 +12,64 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
 @pytest.mark.gpu
-def test_two_ranks_stay_identical():
-    env = dict(os.environ, DQ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+def test_bench_self_launches_two_ranks_that_stay_identical():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(DQ_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
-    out = json.loads(line)
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1                                           # rank 0 only
+    out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["replicas_identical"] is True and out["scaling"] == "weak"
     assert out["config"]["grad_allreduce"].startswith("RCCL") and out["value"] > 0
+    assert out["dist_backend"] == "gloo" and out["rccl_ranks"] == 0
+    ar = out["allreduce"]
+    assert ar["dense_bytes"] + ar["conv_bytes"] == 4 * out["config"]["n_params"] and ar["dense_us"] > 0 and ar["conv_us"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    # one process that claims to be a 1-rank world while --gpus says 2: no JSON line, non-zero exit
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=_clean_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '{"metric"' not in r.stdout and "refusing" in r.stderr
+    # RCCL needs one GPU per rank: two RCCL ranks on the one-GPU box are refused rather than silently sharing the device
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                           cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and '{"metric"' not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["act", "learn", "env"])
+def test_bench_modes_print_one_contract_line(mode):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", mode, "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                       cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["unit"] == ("dqn_samples/s" if mode == "learn" else "env_steps/s")
+    assert f"mode={mode}" in out["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_fit_stops_on_the_same_step_on_every_rank(tmp_path):
+    """DQNAgent.fit under two ranks whose local lifetimes differ by orders of magnitude: the early-stopping decision comes from the
+    all-reduced episode statistics, so both leave on the same step with bit-identical parameters (a rank leaving alone would hang the
+    other in the gradient all-reduce -- the subprocess timeout catches that); FileLogger output comes from rank 0 only."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "_fit_two_ranks.py"), str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
+    assert a == b, (a, b)
+    assert a["stopped"] is True and a["step"] < 64 * 400 and a["updates"] > 0
+    data = json.load(open(tmp_path / "training_history.json"))
+    assert len(data["episode"]) == a["records"]

@@ -280,6 +280,58 @@ def test_single_env_facade(dq, torch_mod):
         dq.Surface_Code_Environment_Multi_Decoding_Cycles(d=4)
 
 
+@pytest.mark.parametrize("name", ["c1_d3_x", "c3_d5_dp", "c5_d7_dp"])
+def test_facade_tables_identity_indicator_and_reset_legal_moves(dq, torch_mod, name):
+    """The facade's own copies of the reference tables against golden G1 (E11, E18: identity_indicator / indicate_identity, ENV:316-324,
+    374-385) and reset_legal_moves() (ENV:238-258) against the reference's rule evaluated with the golden stabilizer lists."""
+    g = load_golden("trace_" + name)
+    tb = load_golden("tables")
+    cfg, n_envs, n_steps, seed = trace_config(g)
+    d = cfg["d"]
+    # a lattice of the trace that gets two flips on the books before its first reset
+    e, t_stop = next((e, t) for e in range(n_envs) for t in range(n_steps)
+                     if g["completed"][e, t + 1].sum() >= 2 and not g["was_reset"][e, :t + 1].any() and not g["done"][e, :t + 2].any())
+    env = dq.Surface_Code_Environment_Multi_Decoding_Cycles(seed=seed, env_id=e, **cfg)
+    assert np.array_equal(env.identity_indicator, tb[f"identity_indicator_d{d}"])
+    assert np.array_equal(env.generate_identity_indicator(d), tb[f"identity_indicator_d{d}"])
+    assert np.array_equal(env.qubits, tb[f"qubits_d{d}"])
+    stabs = [[tuple(int(v) for v in st) for st in row if st[0] >= 0] for row in tb[f"qubit_stabilizers_d{d}"]]
+    assert [sorted(tuple(int(v) for v in st) for st in row) for row in env.qubit_stabilizers] == [sorted(r) for r in stabs]
+    assert np.array_equal(env.padding_syndrome(np.zeros((d + 1, d + 1), int)), tb[f"static_plane_d{d}"])
+    board = np.zeros(env.observation_space.shape, np.int64)
+    out = env.indicate_identity(board)
+    assert out is board
+    for k in range(env.n_action_layers):
+        assert np.array_equal(board[env.volume_depth + k], tb[f"identity_indicator_d{d}"])
+    assert not board[:env.volume_depth].any()
+
+    def rule():
+        s = env.summed_syndrome_volume
+        legal = {env.identity_index}
+        for q in range(d * d):
+            if any(s[st] != 0 for st in stabs[q]):
+                legal |= {q + j * d * d for j in range(env.n_action_layers)}
+        return legal
+    obs = env.reset()
+    assert sum(1 << a for a in env.legal_actions) == int(g["legal"][e, 0, 0]) | (int(g["legal"][e, 0, 1]) << 64)
+    env.reset_legal_moves()                                             # right after reset(): nothing to forget
+    assert env.legal_actions == rule() and sum(1 << a for a in env.legal_actions) == int(g["legal"][e, 0, 0]) | (int(g["legal"][e, 0, 1]) << 64)
+    for t in range(t_stop + 1):                                         # follow the trace until two flips are on the books
+        env.step(int(g["action"][e, t]))
+        assert np.array_equal(env.board_state, g["obs"][e, t + 1])
+    assert env.completed_actions.sum() >= 2
+    grown = set(env.legal_actions)
+    hidden, life, board = env.hidden_state.copy(), env.lifetime, env.board_state.copy()
+    env.reset_legal_moves()
+    assert env.completed_actions.sum() == 0 and env.acted_on_qubits == set()
+    assert env.legal_actions == rule() and env.legal_actions <= grown
+    assert np.array_equal(env.hidden_state, hidden) and env.lifetime == life and np.array_equal(env.board_state, board)   # nothing else moves
+    # the device goes on from the rewritten record: the flip just forgotten is a first-time flip again (no new volume)
+    a = int(g["action"][e, t])
+    env.step(a)
+    assert env.completed_actions[a] == 1 and env.lifetime == life
+
+
 @pytest.mark.parametrize("masked,eps", [(False, 0.3), (True, 0.0), (False, 1.0)])
 def test_fused_act_step_equals_policy_then_step(dq, torch_mod, masked, eps):
     """dq_env_act_step == dq_policy_select followed by dq_env_step: same actions, observations, rewards, flags and hidden state."""

@@ -99,3 +99,101 @@ def test_policy_and_schedule():
     assert 0.75 < keep.mean() < 0.85
     assert (O.dropout_keep_mask((5, 6), 3, np.arange(64), 512, 0.2) == keep).all()
     assert (O.dropout_keep_mask((5, 6), 4, np.arange(64), 512, 0.2) != keep).any()
+
+
+# ---- keras-rl replay memory restatement (oracle/memory_oracle.py) -------------------------------------------------------------------
+def test_memory_oracle_ring_and_sampling_rule():
+    """RingBuffer drops the oldest entry; sample() returns experiences (entry idx-1 -> entry idx) with idx in [2, nb_entries-1], never
+    one whose predecessor entry is terminal; state1 is the next stored observation; terminal1 is entry idx-1's flag."""
+    import random
+    import warnings
+    from oracle import memory_oracle as M
+    rb = M.RingBuffer(4)
+    for i in range(7):
+        rb.append(i)
+    assert len(rb) == 4 and [rb[i] for i in range(4)] == [3, 4, 5, 6]
+    with pytest.raises(KeyError):
+        rb[4]
+    rng = random.Random(3)
+    nrng = np.random.RandomState(0)
+    mem = M.SequentialMemory(limit=40, window_length=1)
+    flags = []
+    for k in range(57):                                         # wraps: entries 17..56 survive
+        term = bool(nrng.rand() < 0.2)
+        mem.append(k, k % 5, float(k), term)
+        flags.append(term)
+    assert mem.nb_entries == 40 and mem.observations[0] == 17
+    kept = flags[17:]
+    expect = [i for i in range(2, 40) if not kept[i - 2]]
+    assert mem.valid_idxs() == expect and 1 not in expect and 39 in expect or kept[37]
+    seen = set()
+    for _ in range(300):
+        for e in mem.sample(8, rng=rng):
+            assert e["idx"] in expect
+            assert e["state0"] == [17 + e["idx"] - 1] and e["state1"] == [17 + e["idx"]]
+            assert e["action"] == (17 + e["idx"] - 1) % 5 and e["reward"] == float(17 + e["idx"] - 1)
+            assert e["terminal1"] == kept[e["idx"] - 1]
+            seen.add(e["idx"])
+    assert seen == set(expect)                                   # the support is exactly the valid set
+    # first draws are distinct when the range allows it (random.sample), with replacement + warning otherwise
+    idxs = M.sample_batch_indexes(1, 39, 38, rng=rng)
+    assert sorted(idxs) == list(range(1, 39))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        idxs = M.sample_batch_indexes(1, 4, 10, rng=rng, np_rng=nrng)
+        assert len(w) == 1 and len(idxs) == 10 and set(idxs) <= {1, 2, 3}
+    small = M.SequentialMemory(limit=10)
+    small.append(0, 0, 0.0, False)
+    small.append(1, 0, 0.0, False)
+    with pytest.raises(AssertionError):                          # nb_entries >= window_length + 2
+        small.sample(1)
+    small.append(2, 0, 0.0, False)
+    assert [e["idx"] for e in small.sample(1, rng=rng)] == [2]   # 3 entries: exactly one experience (entry 1 -> entry 2)
+
+
+def test_memory_oracle_ring_mapping():
+    """valid_transitions(): device ring (slots x lattices) -> the rows keras-rl could sample, for a wrapped and a partial ring."""
+    from oracle import memory_oracle as M
+    n_envs, n_slots = 3, 8
+    term = np.zeros((n_slots, n_envs), np.uint8)
+    term[4, 1] = 1                                               # lattice 1 ended its episode with the action taken in slot 4
+    # full ring, head (newest observation) in slot 6: entries = slots 7,0,1,2,3,4,5 (oldest first), nb_entries = 7
+    rows = M.valid_transitions(term, n_envs, n_slots, 6, 8)
+    slots = lambda e: sorted(r // n_envs for r in rows if r % n_envs == e)
+    assert slots(0) == [0, 1, 2, 3, 4]                           # not 7 (entry 0), not 5 (newest transition), not 6 (no action yet)
+    assert slots(1) == [0, 1, 2, 3, 4]                           # slot 5 would also be excluded as post-terminal -- it is the newest anyway
+    term[2, 2] = 1
+    rows = M.valid_transitions(term, n_envs, n_slots, 6, 8)
+    assert slots(2) == [0, 1, 2, 4]                              # slot 3 holds the terminal observation of the finished episode
+    # partial ring: 5 slots written (0..4), head 4 -> entries = slots 0..3; sampleable: slots 1, 2
+    rows = M.valid_transitions(np.zeros((n_slots, n_envs), np.uint8), n_envs, n_slots, 4, 5)
+    assert sorted(r // n_envs for r in rows if r % n_envs == 0) == [1, 2]
+
+
+def test_torch_fp32_learner_matches_float64_oracle():
+    """oracle/torch_dqn.py (the CPU baseline's learner: torch-CPU fp32, autograd) == the float64 oracle's update to fp32 round-off."""
+    from oracle import torch_dqn
+    rng = np.random.RandomState(1)
+    shape, A = SPECS["c3"]
+    spec = O.QNetSpec(shape, C_LAYERS, FF_LAYERS, A)
+    flat = O.glorot_init(spec, (5, 6)) + (rng.randn(spec.n_params) * 0.02).astype(np.float32)
+    B = 24
+    s0, s1 = ((rng.rand(B, *shape) < 0.3).astype(np.uint8) for _ in range(2))
+    a, r, term = rng.randint(0, A, B), (rng.rand(B) < 0.5).astype(np.float32), (rng.rand(B) < 0.2).astype(np.uint8)
+    keep = rng.rand(B, 512) >= 0.2
+    learner = torch_dqn.TorchDQN(spec, flat, lr=1e-3)
+    assert np.array_equal(learner.flat(), flat.astype(np.float64))                  # HWIO <-> OIHW round trip
+    q = learner.forward(learner.params, s0).detach().numpy()
+    assert np.abs(q - O.forward(spec, flat, s0)[0]).max() < 2e-5
+    loss, mean_q, grads = learner.update(s0, a, r, term, s1, keep)
+    f64 = flat.astype(np.float64)
+    y = O.td_targets(O.forward(spec, f64, s1)[0], O.forward(spec, f64, s1)[0], r, term, 0.99)
+    q0, cache = O.forward(spec, f64, s0, training=True, keep_masks=[keep])
+    loss_ref, mq_ref, dq = O.loss_and_grad(q0, a, y)
+    g_ref = O.backward(spec, f64, cache, dq)
+    p_ref, _, _ = O.adam_step(f64, g_ref, np.zeros_like(g_ref), np.zeros_like(g_ref), 1, 1e-3)
+    assert abs(loss - loss_ref) < 1e-5 and abs(mean_q - mq_ref) < 1e-5
+    g = learner.flat(list(grads))
+    assert np.abs(g - g_ref).max() < 1e-5 * max(1.0, np.abs(g_ref).max())
+    big = np.abs(g_ref) > 1e-5
+    assert np.abs(learner.flat() - p_ref)[big].max() < 2e-5

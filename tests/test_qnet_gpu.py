@@ -98,6 +98,55 @@ def test_training_forward_backward(dq, torch_mod, name, batch, fused):
     assert np.array_equal(g, g2)
 
 
+@pytest.mark.parametrize("name,batch", [("c3", 4096), ("c3", 2049), ("c3", 4091), ("c3", 2048 + 8 * 200 + 3), ("c2", 4096), ("c5", 1024), ("c5", 2500)])
+def test_backward_at_baseline_batch_matches_oracle(dq, torch_mod, name, batch):
+    """The fused training forward + backward at the BASELINE.json minibatch sizes against the float64 oracle on the FULL batch.  Only
+    batches above 2048 give a workgroup of the persistent convolutional backward more than one group of 8 samples (256 workgroups), i.e.
+    exercise its cross-group software pipeline (inputs fetched one group ahead, double-buffered a1, weight-gradient accumulators kept in
+    registers across groups) and the batch-slice map of the dense weight-gradient kernel; ragged sizes leave a partly filled last group
+    and workgroups with different group counts."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, name, batch)
+    seed, t, base = (3, 4), 99, 12345
+    keep = O.dropout_keep_mask(seed, t, base + np.arange(batch), 512, 0.2)
+    obs_t = torch.from_numpy(obs).cuda()
+    q = net.forward(params, obs_t, training=True, seed=seed, t=t, sample_base=base).cpu().numpy()
+    q_ref, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    assert np.abs(q - q_ref).max() < TOL
+    dq_ = (rng.randn(batch, spec.n_actions) / batch).astype(np.float32)
+    # A ReLU pre-activation within fp32 round-off of 0 may fall on the other side in another summation order, which changes that
+    # sample's gradient by a finite amount; with ~3000 units x thousands of samples some always are.  Such samples (a few per cent)
+    # get dq = 0: they still run through every kernel, but their masks cannot matter.
+    fragile = O.fragile_samples(cache)
+    assert fragile.mean() < 0.5
+    dq_[fragile] = 0.0
+    dq_t = torch.from_numpy(dq_).cuda()
+    g = net.backward(params, dq_t).cpu().numpy()
+    g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
+    assert np.abs(g - g_ref).max() < 1e-5 * max(np.abs(g_ref).max(), 1.0), (np.abs(g - g_ref).max(), np.abs(g_ref).max())
+    for li, ((gk, gb), (rk, rb)) in enumerate(zip(spec.split(g), spec.split(g_ref))):
+        for a, b in ((gk, rk), (gb, rb)):
+            assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-7, (li, np.abs(a - b).max(), np.abs(b).max())
+    # a gradient that lives in ONE late group only (samples of the last 8-sample group of a late workgroup round): a dropped or stale
+    # group cannot hide behind the sum
+    one = np.zeros_like(dq_)
+    lo = (batch - 1) // 8 * 8
+    one[lo:] = dq_[lo:] * 50 + 0.01
+    one[fragile] = 0.0
+    if not one.any():                                                    # (every sample of the last group fragile: take the group before)
+        one[lo - 8:lo] = 0.01
+        one[fragile] = 0.0
+    g1 = net.backward(params, torch.from_numpy(one).cuda()).cpu().numpy()
+    g1_ref = O.backward(spec, flat, cache, one.astype(np.float64))
+    assert np.abs(g1 - g1_ref).max() < 1e-5 * max(np.abs(g1_ref).max(), 1.0)
+    assert np.abs(g1_ref).max() > 0
+    # the per-layer implicit-GEMM path on the same batch (independent kernels) agrees with the oracle too
+    net.set_fused(False)
+    net.forward(params, obs_t, training=True, seed=seed, t=t, sample_base=base)
+    g_pl = net.backward(params, dq_t).cpu().numpy()
+    assert np.abs(g_pl - g_ref).max() < 1e-5 * max(np.abs(g_ref).max(), 1.0)
+
+
 def test_packed_weights_are_equivalent_and_must_follow_the_parameters(dq, torch_mod):
     """forward(packed=net.pack(params)) == forward(params) (which packs on every call), bit for bit; the pack is a pure function
     of the parameters (a stale pack gives the old weights' convolutions, which is why DQNCore repacks after every Adam step)."""
@@ -331,36 +380,43 @@ def test_fused_td_update_and_post_step_equal_the_separate_kernels(dq, torch_mod)
 
 
 def test_replay_sample_rule(dq, torch_mod):
-    """Sampled rows are the transitions keras-rl's SequentialMemory.sample can return (complete ones except the two newest), never
-    start at a post-terminal entry, match the Philox definition, and cover the ring roughly uniformly."""
+    """The device sampler against the restatement of upstream keras-rl 0.4.2 SequentialMemory (oracle/memory_oracle.py), lattice by
+    lattice: every sampled row is an experience sample() can return (never the newest transition, never entry 0, never one whose
+    predecessor entry was terminal), and with enough draws the SUPPORT is exactly keras-rl's -- full ring (wrapped) and partially
+    filled ring.  The device draws with replacement (documented deviation from random.sample)."""
     torch = torch_mod
+    from oracle import memory_oracle as M
     rng = np.random.RandomState(2)
-    n_envs, n_slots, head, filled, batch = 64, 50, 17, 50, 20000
-    term = (rng.rand(n_slots, n_envs) < 0.15).astype(np.uint8)
     seed, t, base = (8, 9), 55, 1000
-    idx = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, batch, seed, t, sample_base=base).cpu().numpy()
-    slot, env = idx // n_envs, idx % n_envs
-    newest3 = np.array([head, (head - 1) % n_slots, (head - 2) % n_slots])
-    assert not np.isin(slot, newest3).any()                            # newest observation (no successor yet) + the two newest transitions
-    prev = (slot - 1) % n_slots
-    oldest = (head + 1) % n_slots
-    bad = (term[prev, env] == 1) & (slot != oldest)
-    assert not bad.any()
-    # first few samples against the scalar definition
-    for b in range(50):
-        for attempt in range(64):
-            w = philox.philox4x32((t, 0, base + b, attempt | (philox.STREAM_REPLAY << 16)), seed)
-            j, e = philox.bounded(w[0], filled - 3), philox.bounded(w[1], n_envs)
-            s = (head - 3 - j) % n_slots
-            if j + 1 >= filled - 3 or not term[(s - 1) % n_slots, e]:
-                break
-        assert idx[b] == s * n_envs + e
-    counts = np.bincount(slot, minlength=n_slots)
-    assert counts[newest3].sum() == 0 and counts[~np.isin(np.arange(n_slots), newest3)].min() > 0.5 * batch / n_slots
-    # partially filled ring: only written slots are sampled
-    idx2 = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, 5, 6, 5000, seed, t).cpu().numpy()
-    assert set(np.unique(idx2 // n_envs)) == {0, 1, 2}
-    with pytest.raises(dq.DeepQError):                                 # fewer than three complete transitions
+    for n_envs, n_slots, head, filled, batch in ((64, 50, 17, 50, 60000), (64, 50, 49, 50, 60000), (16, 50, 5, 6, 4000), (7, 9, 3, 4, 500),
+                                                  (3, 40, 30, 31, 4000)):
+        term = (rng.rand(n_slots, n_envs) < 0.15).astype(np.uint8)
+        idx = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, batch, seed, t, sample_base=base).cpu().numpy()
+        allowed = M.valid_transitions(term, n_envs, n_slots, head, filled)
+        got = set(int(x) for x in idx)
+        assert got <= allowed, sorted(got - allowed)[:5]
+        assert got == allowed, (len(got), len(allowed))                # batch >> |allowed|: every allowed experience turns up
+        # the oracle's own sample() only ever returns members of that set too (its redraw loop included)
+        mem = M.lattice_memory(term, 0, n_slots, head, filled)
+        if mem.nb_entries - 2 >= 1:
+            ex = mem.sample(min(32, mem.nb_entries - 2)) if mem.valid_idxs() else []
+            assert all(e["state0"][0] * n_envs in allowed for e in ex)
+            assert all(e["state1"][0] == (e["state0"][0] + 1) % n_slots for e in ex)       # successor = next slot (row + n_envs)
+        # roughly uniform over the allowed rows
+        if batch >= 20 * len(allowed):
+            counts = np.bincount(idx, minlength=n_slots * n_envs)[sorted(allowed)]
+            assert counts.min() > 0.15 * batch / len(allowed) and counts.max() < 3.0 * batch / len(allowed)
+    # the newest sampleable transition is the PREVIOUS step's (slot head - 2); the step just taken (head - 1) never is
+    n_envs, n_slots, head, filled = 64, 50, 17, 50
+    term = np.zeros((n_slots, n_envs), np.uint8)
+    idx = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, 20000, seed, t).cpu().numpy()
+    slots = set(np.unique(idx // n_envs).tolist())
+    assert slots == set(range(n_slots)) - {head, head - 1, (head + 1) % n_slots}           # newest obs, newest transition, entry 0
+    # deterministic in (seed, t, sample id): a minibatch is the same whichever launch draws it and however it is sharded
+    a = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, 100, seed, t, sample_base=40).cpu().numpy()
+    b = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, 60, seed, t, sample_base=80).cpu().numpy()
+    assert np.array_equal(a[40:], b)
+    with pytest.raises(dq.DeepQError):                                 # keras-rl: nb_entries >= window_length + 2
         dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, 2, 3, 10, seed, t)
 
 

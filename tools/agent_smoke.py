@@ -1,12 +1,13 @@
 """DQN half of __graft_entry__.smoke(): a few vector steps of the full device loop (act, environment step, replay ring, one
 double-DQN update per step through the fused Q-network kernels) on a small batch, and one training forward/backward checked
 against the float64 oracle (oracle/ is test infrastructure: it is only the checker here)."""
+import importlib
+
 import numpy as np
 import torch
 
-from .core import DQNCore
-from .env import VectorEnv
-from .qnet import QNetwork
+_dq = importlib.import_module("deepq-decoding_amd")
+DQNCore, VectorEnv, QNetwork = _dq.DQNCore, _dq.VectorEnv, _dq.QNetwork
 
 C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
 
