@@ -26,7 +26,7 @@ def __getattr__(name):
                 "FileLogger", "Adam", "build_convolutional_nn", "ConvQModel", "History"):
         from . import agent
         return getattr(agent, name)
-    if name in ("dist", "hdf5_reader", "weights_io", "function_library"):
+    if name in ("dist", "hdf5_reader", "weights_io", "function_library", "runner"):
         import importlib
         return importlib.import_module("." + name, __name__)
     if name == "DQNCore":

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdeepq_hip.so")
 
-DQ_MODEL_X, DQ_MODEL_DP = 0, 1
+DQ_MODEL_X, DQ_MODEL_DP, DQ_MODEL_IIDXZ = 0, 1, 2
 STREAM_ENV, STREAM_POLICY, STREAM_REPLAY, STREAM_DROPOUT, STREAM_INIT = range(5)
 
 

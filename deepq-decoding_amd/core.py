@@ -198,18 +198,42 @@ class DQNCore:
                          out=self.q0, packed=self.params_pk))
         return jobs
 
+    def _td_job(self, step_stats=None):
+        q_sel = self.q1_online if self.enable_double_dqn else self.q1_target
+        return dict(q_online_s1=q_sel, q_target_s1=self.q1_target, q_s0=self.q0, reward=self.reward_ring, terminal=self.terminal_ring,
+                    action=self.action_ring, gamma=self.gamma, grad_scale=_dist.grad_scale(self.batch_size, self.world_size),
+                    index=self.index, y=self.y, dq=self.dq, metrics=self.metrics, step_stats=step_stats)
+
+    def local_gradient(self, index=None):
+        """This rank's contribution to the NEXT update's gradient, without the all-reduce and without the optimizer step: minibatch
+        draw (or the given ring rows), the three forwards, TD step, backward; scaled by 1 / (batch_size * world_size), so that the SUM
+        over the ranks is the gradient of the global-minibatch mean loss.  Leaves counters and parameters untouched (tests, diagnostics:
+        tests/test_agent_gpu.py compares the sum of eight shard gradients with the gradient of one eight-times-larger lattice batch)."""
+        assert self.filled >= MIN_FILLED
+        self._join_env()
+        t = self.updates + 1
+        _, sample_base = _dist.shard(self.rank, self.N, self.batch_size)
+        if index is None:
+            _q.replay_sample(self.terminal_ring, self.N, self.T, self.cur, self.filled, self.batch_size, self.seed, t, sample_base=sample_base,
+                             out=self.index)
+        else:
+            self.index.copy_(index)
+        self._presampled = None
+        self.net.forward_multi(self._update_jobs(t, sample_base))
+        self.net.td_backward_phase0(self.params, self._td_job(), self.grads)
+        self.net.backward_phase(self.params, self.dq, self.grads, 1)
+        self._metrics_stale = True
+        return self.grads
+
     def _learn(self, t):
         """TD step, backward, optimizer step, repack -- everything of an update behind its forwards."""
         B, N, net = self.batch_size, self.N, self.net
-        q_sel = self.q1_online if self.enable_double_dqn else self.q1_target
         step_stats = None
         if self._stats_pending is not None:          # the pending episode bookkeeping rides on the TD launch
             (slot,), env = self._stats_pending, self.env
             step_stats = (self.terminal_ring[slot], env.was_reset, env.lifetime, self.reward_ring[slot], N, self.stats)
             self._stats_pending = None
-        td = dict(q_online_s1=q_sel, q_target_s1=self.q1_target, q_s0=self.q0, reward=self.reward_ring, terminal=self.terminal_ring,
-                  action=self.action_ring, gamma=self.gamma, grad_scale=_dist.grad_scale(B, self.world_size), index=self.index, y=self.y,
-                  dq=self.dq, metrics=self.metrics, step_stats=step_stats)
+        td = self._td_job(step_stats)
         self._metrics_stale = True
         if self.world_size > 1:
             # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs

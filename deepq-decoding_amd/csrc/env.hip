@@ -215,8 +215,10 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p) {
                     philox4x32_10((u32)round, (u32)(round >> 32), p.env_id_base + (u32)i, (u32)lane, p.seed0, p.seed1, w);
                     const bool hit = lane < p.d2 && (u64)w[0] < p.T_phys;   // FL:99 / FL:119
                     const int typ = p.model == DQ_MODEL_X ? 1 : 1 + (int)__umulhi(w[1], 3u);   // FL:100
-                    const u64 ex = __ballot(hit && typ != 3);
-                    const u64 ez = __ballot(hit && typ != 1);
+                    // IIDXZ (FL:134-160): the qubit's second uniform decides an independent Z flip instead of the Pauli type
+                    const bool zhit = lane < p.d2 && (u64)w[1] < p.T_phys;
+                    const u64 ex = __ballot(p.model == DQ_MODEL_IIDXZ ? hit : hit && typ != 3);
+                    const u64 ez = __ballot(p.model == DQ_MODEL_IIDXZ ? zhit : hit && typ != 1);
                     const u64 flips = __ballot(lane < p.n_stab && (u64)w[2] < p.T_meas);      // FL:191-221
                     ++round;
                     xmask ^= ex;                                            // ENV:164, FL:226-241
@@ -447,7 +449,7 @@ dq_status dq_env_create(const dq_env_cfg* cfg, dq_env** out) {
     *out = nullptr;
     DQ_REQUIRE(cfg->d % 2 == 1, DQ_ERR_INVALID, "for the surface code d must be odd!");     // FL:28-29
     DQ_REQUIRE(cfg->d >= 3 && cfg->d <= 7, DQ_ERR_UNSUPPORTED, "d=%d unsupported: one lattice per 64-lane wavefront needs d*d <= 64", cfg->d);
-    DQ_REQUIRE(cfg->error_model == DQ_MODEL_X || cfg->error_model == DQ_MODEL_DP, DQ_ERR_UNSUPPORTED,
+    DQ_REQUIRE(cfg->error_model == DQ_MODEL_X || cfg->error_model == DQ_MODEL_DP || cfg->error_model == DQ_MODEL_IIDXZ, DQ_ERR_UNSUPPORTED,
                "specified error model not currently supported!");                              // ENV:66-67
     DQ_REQUIRE(cfg->volume_depth >= 1 && cfg->volume_depth <= DQ_MAX_DEPTH, DQ_ERR_UNSUPPORTED, "volume_depth must be in 1..%d", DQ_MAX_DEPTH);
     DQ_REQUIRE(cfg->n_envs >= 1, DQ_ERR_INVALID, "n_envs must be positive");

@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import EnvCfg, EnvInfo, check, ptr
 
 DEFAULT_SEED = (0x5EED, 0xD0DEC0DE)
-_MODELS = {"X": _lib.DQ_MODEL_X, "DP": _lib.DQ_MODEL_DP}
+_MODELS = {"X": _lib.DQ_MODEL_X, "DP": _lib.DQ_MODEL_DP, "IIDXZ": _lib.DQ_MODEL_IIDXZ}
 
 
 class _Space:

@@ -53,7 +53,11 @@ enum {
     DQ_ERR_STATE = -5        /* call made in the wrong state (e.g. step before referee is set) */
 };
 
-enum { DQ_MODEL_X = 0, DQ_MODEL_DP = 1 };
+/* DQ_MODEL_IIDXZ: independent X and Z flips per qubit (generate_IIDXZ_error, Function_Library.py:134-160: two uniforms per qubit, X
+ * first) -- the noise channel generate_error() offers besides "X" and "DP" (Function_Library.py:91-92).  The reference's environment
+ * constructor does not accept it (Environments.py:66-67 prints and then fails); here it runs with the depolarising model's action
+ * layers (X and Z, or X/Y/Z with use_Y) and four homology classes (Function_Library.py:329-330). */
+enum { DQ_MODEL_X = 0, DQ_MODEL_DP = 1, DQ_MODEL_IIDXZ = 2 };
 enum { DQ_STREAM_ENV = 0, DQ_STREAM_POLICY = 1, DQ_STREAM_REPLAY = 2, DQ_STREAM_DROPOUT = 3, DQ_STREAM_INIT = 4 };
 
 int dq_version(void);
@@ -69,7 +73,7 @@ typedef struct dq_env dq_env;
 
 typedef struct {
     int32_t d;            /* code distance: 3, 5 or 7 (Environments.py:45; odd, Function_Library.py:28-29) */
-    int32_t error_model;  /* DQ_MODEL_X / DQ_MODEL_DP (Environments.py:56-67) */
+    int32_t error_model;  /* DQ_MODEL_X / DQ_MODEL_DP (Environments.py:56-67) / DQ_MODEL_IIDXZ */
     int32_t use_Y;        /* Environments.py:60-65 */
     int32_t volume_depth; /* 1..16 (Environments.py:52) */
     int32_t n_envs;       /* lattices owned by this handle */

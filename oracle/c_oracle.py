@@ -71,7 +71,7 @@ class COracleEnv:
                  n_envs=1, env_id_base=0, seed=(0x5EED, 0xD0DEC0DE), lut=None):
         self.L = lib()
         self.d, self.n_envs, self.depth = d, n_envs, volume_depth
-        model = {"X": 0, "DP": 1}[error_model]
+        model = {"X": 0, "DP": 1, "IIDXZ": 2}[error_model]
         self.h = self.L.dqo_env_create(d, model, int(use_Y), volume_depth, n_envs, env_id_base, seed[0], seed[1])
         if not self.h:
             raise ValueError("unsupported configuration")

@@ -214,7 +214,10 @@ static void new_volume(dqo_env* E, env_state* S, u32 env_id) {       /* ENV:157-
             for (int lane = 0; lane < L->d2; ++lane) {
                 u32 ctr[4] = {(u32)S->round, (u32)(S->round >> 32), env_id, (u32)lane}, w[4];
                 philox4x32_10(ctr, E->seed, w);
-                if ((u64)w[0] < E->T_phys) {                          /* FL:99 / FL:119 */
+                if (E->model == 2) {                                  /* IIDXZ, FL:134-160: X flip, then an independent Z flip */
+                    if ((u64)w[0] < E->T_phys) ex |= 1ull << lane;
+                    if ((u64)w[1] < E->T_phys) ez |= 1ull << lane;
+                } else if ((u64)w[0] < E->T_phys) {                   /* FL:99 / FL:119 */
                     int t = E->model == 0 ? 1 : 1 + (int)(((u64)w[1] * 3) >> 32);   /* FL:100 */
                     if (t == 1 || t == 2) ex |= 1ull << lane;
                     if (t == 2 || t == 3) ez |= 1ull << lane;

@@ -81,6 +81,15 @@ def padding_actions(d, actions_in):
     return out
 
 
+def iidxz_error_from_words(d, words, p_phys):
+    """FL:134-160 generate_IIDXZ_error under injected 32-bit words: qubit q (row-major) draws words[2q] (X flip) then words[2q+1]
+    (Z flip); X and Z together give Y (code 2)."""
+    T = philox.threshold(p_phys)
+    w = np.asarray(words, dtype=np.uint64).reshape(d, d, 2)
+    x, z = w[..., 0] < T, w[..., 1] < T
+    return (x * 1) ^ (z * 3)
+
+
 def faulty_syndrome_from_words(d, true_grid, words, p_meas):
     """FL:176-223 generate_faulty_syndrome with the uniforms replaced by uint32 `words`
     (one per stabilizer, in measurement order)."""
@@ -134,7 +143,12 @@ class OracleEnv:
         w0, w1, w2, _ = philox.philox4x32_np(self.round & philox.MASK, (self.round >> 32) & philox.MASK, self.env_id,
                                              np.arange(d2, dtype=np.uint32), self.seed)
         for lane in range(d2):
-            if int(w0[lane]) < Tp:                          # FL:99 / FL:119
+            if self.error_model == "IIDXZ":                 # FL:134-160: two uniforms per qubit, X flip first, then Z flip
+                if int(w0[lane]) < Tp:
+                    ex |= 1 << lane
+                if int(w1[lane]) < Tp:
+                    ez |= 1 << lane
+            elif int(w0[lane]) < Tp:                        # FL:99 / FL:119
                 t = 1 if self.error_model == "X" else philox.pauli_type(w1[lane])   # FL:100
                 if t in (1, 2):
                     ex |= 1 << lane

@@ -110,7 +110,7 @@ def num_actions(d, error_model, use_Y):
     """ENV:55-65 -> (num_actions, n_action_layers)."""
     if error_model == "X":
         return d * d + 1, 1
-    if error_model == "DP":
+    if error_model in ("DP", "IIDXZ"):      # IIDXZ: the build's extension (the reference constructor rejects it) -- DP's action layers
         return (3 * d * d + 1, 3) if use_Y else (2 * d * d + 1, 2)
     raise ValueError("specified error model not currently supported!")
 

@@ -26,11 +26,11 @@ def dq():
     return importlib.import_module("deepq-decoding_amd")
 
 
-TRACES = ["c1_d3_x", "c2_d5_x", "c3_d5_dp", "c5_d7_dp", "x1_d5_dpy", "x2_d5_dp_hot", "x3_d3_x_nomeas", "x4_d7_x"]
+TRACES = ["c1_d3_x", "c2_d5_x", "c3_d5_dp", "c5_d7_dp", "x1_d5_dpy", "x2_d5_dp_hot", "x3_d3_x_nomeas", "x4_d7_x", "x5_d5_iidxz"]
 STICKY_TRACES = ["sticky_c3_d5_dp", "sticky_x2_d5_dp_hot"]
 
 
 def trace_config(g):
     d, model, use_Y, depth, n_envs, n_steps = (int(x) for x in g["config"])
-    return dict(d=d, error_model="X" if model == 0 else "DP", use_Y=bool(use_Y), volume_depth=depth,
+    return dict(d=d, error_model={0: "X", 1: "DP", 2: "IIDXZ"}[model], use_Y=bool(use_Y), volume_depth=depth,
                 p_phys=float(g["rates"][0]), p_meas=float(g["rates"][1])), n_envs, n_steps, tuple(int(x) for x in g["seed"])

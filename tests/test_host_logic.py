@@ -63,6 +63,19 @@ def test_error_generators(fl):
     e = fl.generate_error(5, 0.5, "IIDXZ")
     assert set(np.unique(e)) <= {0, 1, 2, 3}
     assert fl.generate_error(5, 0.0, "DP").sum() == 0
+    # the host helper generate_IIDXZ_error consumes numpy's stream like the reference's loop (two uniforms per qubit, X first):
+    # served the golden words, it returns the reference's own outputs (tests/golden/kats.npz kat_iidxz_*)
+    g = load_golden("kats")
+    saved = np.random.rand
+    try:
+        for d in (3, 5, 7):
+            for w, want in zip(g[f"kat_iidxz_words_d{d}"], g[f"kat_iidxz_err_d{d}"]):
+                stream = iter(w.astype(np.float64) / 4294967296.0)
+                np.random.rand = lambda *shape: (np.array([next(stream) for _ in range(int(np.prod(shape)))]).reshape(shape)
+                                                 if shape else next(stream))
+                assert np.array_equal(fl.generate_error(d, 0.3, "IIDXZ"), want)
+    finally:
+        np.random.rand = saved
     with pytest.raises(Exception):
         fl.generateSurfaceCodeLattice(4)
 
@@ -261,3 +274,79 @@ def test_hdf5_reader_on_shipped_keras_weights():
     assert names[0] == "/conv2d_1/conv2d_1/bias:0" and names[-1] == "/dense_3/dense_3_1/kernel:0"
     at = h.read_attributes(REF_H5)                                   # the attribute parser the writer's test relies on, on a real file
     assert at["/"]["layer_names"][:2] == [b"conv2d_1_input", b"conv2d_1"] and at["/dense_3"] == {"weight_names": [b"dense_3_1/kernel:0", b"dense_3_1/bias:0"]}
+
+
+@pytest.mark.skipif(not os.path.exists(REF_H5), reason="reference checkout not present (GPU box)")
+def test_weight_fixtures_regenerate_and_all_shipped_agents_load():
+    """tools/gen_weight_fixtures.py reproduces the committed fixtures array for array, and the pure-Python HDF5 reader loads every one
+    of the 14 shipped agents (trained_models/d5_x/*, d5_dp/*) with the tensor shapes of SURVEY.md 8a-D1."""
+    import glob
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    try:
+        import gen_weight_fixtures as gw
+    finally:
+        sys.path.pop(0)
+    for family, p in gw.AGENTS:
+        fx = load_golden(gw.fixture_name(family, p))
+        fresh = gw.build(family, p)
+        assert sorted(fx.files) == sorted(fresh)
+        for k in fresh:
+            assert np.array_equal(fx[k], fresh[k]), (family, p, k)
+    h = importlib.import_module("deepq-decoding_amd.hdf5_reader")
+    files = sorted(glob.glob("/root/reference/trained_models/*/*/final_dqn_weights.h5f"))
+    assert len(files) == 14
+    for f in files:
+        C, A = (6, 26) if "/d5_x/" in f else (7, 51)
+        w = h.read_keras_weights(f)
+        assert [x.shape for x in w] == [(3, 3, C, 64), (64,), (2, 2, 64, 32), (32,), (2, 2, 32, 32), (32,), (288, 512), (512,),
+                                        (512, A), (A,), (A, A + 1), (A + 1,)], f
+        assert all(x.dtype == np.float32 and np.isfinite(x).all() for x in w)
+
+
+def test_grid_files_follow_the_reference_schema(tmp_path):
+    """runner.write_grid reproduces the reference's config tree: the 36-point initial grid of
+    Generate_Base_Configs_and_Simulation_Scripts.py:36-74 in its loop order, dict keys of :10-27 / :54-63; load_configs merges them like
+    Single_Point_Training_Script.py:36-53; the Controller's selection rule (Controller.py:117-156) and spawning (:189-268)."""
+    import pickle
+    runner = importlib.import_module("deepq-decoding_amd.runner")
+    fixed = {"d": 5, "use_Y": False, "train_freq": 1, "batch_size": 32, "print_freq": 250, "rolling_average_length": 1000,
+             "stopping_patience": 1000, "error_model": "DP", "c_layers": [[64, 3, 2], [32, 2, 1], [32, 2, 1]], "ff_layers": [[512, 0.2]],
+             "max_timesteps": 1000000, "volume_depth": 5, "testing_length": 101, "buffer_size": 50000, "dueling": True,
+             "masked_greedy": False, "static_decoder": True}
+    fam = str(tmp_path / "d5_dp")
+    dirs = runner.write_grid(fam, fixed, 0.001, 100000)
+    assert len(dirs) == 36 and os.path.basename(dirs[0]) == "config_1" and os.path.isdir(os.path.join(fam, "0.001", "output_files"))
+    assert pickle.load(open(os.path.join(fam, "fixed_config.p"), "rb")) == fixed
+    v1 = pickle.load(open(os.path.join(dirs[0], "variable_config_1.p"), "rb"))
+    assert v1 == {"p_phys": 0.001, "p_meas": 0.001, "success_threshold": 100000, "learning_starts": 1000, "learning_rate": 0.0001,
+                  "exploration_fraction": 100000, "max_eps": 1.0, "target_network_update_freq": 2500, "gamma": 0.99, "final_eps": 0.04}
+    v2 = pickle.load(open(os.path.join(dirs[1], "variable_config_2.p"), "rb"))
+    v4 = pickle.load(open(os.path.join(dirs[3], "variable_config_4.p"), "rb"))
+    assert v2["final_eps"] == 0.02 and v4["target_network_update_freq"] == 5000 and v4["final_eps"] == 0.04     # innermost loops first
+    v36 = pickle.load(open(os.path.join(dirs[35], "variable_config_36.p"), "rb"))
+    assert (v36["learning_rate"], v36["exploration_fraction"], v36["final_eps"]) == (0.00001, 200000, 0.001)
+    cfg, number = runner.load_configs(dirs[6])
+    assert number == "7" and cfg["d"] == 5 and cfg["learning_rate"] == v1["learning_rate"] and set(cfg) == set(fixed) | set(v1)
+    if os.path.exists("/root/reference/trained_models/d5_dp/fixed_config.p"):        # the reference's own pickles carry the same keys
+        ref_fixed = pickle.load(open("/root/reference/trained_models/d5_dp/fixed_config.p", "rb"))
+        assert set(ref_fixed) == set(runner.FIXED_KEYS) and ref_fixed == fixed
+        ref_var = pickle.load(open("/root/reference/trained_models/d5_dp/0.011/variable_config_92.p", "rb"))
+        assert set(ref_var) == set(runner.VARIABLE_KEYS)
+    # Controller bookkeeping
+    assert runner.collect_results(os.path.join(fam, "0.001"))["3"] == "not started"
+    assert runner.select_best({"1": 900.0, "2": 1200.0, "3": "still running", "4": 1500.0}, 1000, 1) == {"4": 1500.0}
+    assert runner.select_best({"1": 900.0}, 1000, 1) == {}
+    for n, life in (("2", 1200.0), ("5", 1700.0)):
+        cdir = os.path.join(fam, "0.001", f"config_{n}")
+        pickle.dump([life / 2, life], open(os.path.join(cdir, "results.p"), "wb"))
+        open(os.path.join(cdir, "final_dqn_weights.h5f"), "wb").write(b"weights" + n.encode())
+        open(os.path.join(cdir, "memory.p"), "wb").write(b"memory" + n.encode())
+    new = runner.spawn_next(fam, fixed, 0.001, 0.003)
+    assert len(new) == 4 * 2 * 3 * 2 * 3                                          # Controller.py:27-33 grid from the ONE best point
+    assert open(os.path.join(new[0], "initial_dqn_weights.h5f"), "rb").read() == b"weights5"
+    assert open(os.path.join(new[-1], "memory.p"), "rb").read() == b"memory5"
+    assert pickle.load(open(os.path.join(new[0], "variable_config_1.p"), "rb"))["p_phys"] == 0.003
+    assert open(os.path.join(fam, "results", "best_results_from_0.001.txt")).read() == "5: 1700.0\n"
+    assert open(os.path.join(fam, "results", "results_from_0.001.txt")).read().splitlines()[1] == "2: 1200.0"

@@ -82,6 +82,10 @@ def test_helper_kats(d):
         want = g[f"kat_move_d{d}_{model}_{int(use_Y)}"]
         for a in range(want.shape[0]):
             assert np.array_equal(env_oracle.index_to_move(d, a, model, use_Y), want[a])
+    # E5: generate_error(d, p, "IIDXZ") of the reference under injected words (two draws per qubit, X first)
+    for w, e in zip(g[f"kat_iidxz_words_d{d}"], g[f"kat_iidxz_err_d{d}"]):
+        assert np.array_equal(env_oracle.iidxz_error_from_words(d, w, 0.3), e)
+    assert {0, 1, 2, 3} <= set(np.unique(g[f"kat_iidxz_err_d{d}"]).tolist())
 
 
 def test_readme_known_answer():

@@ -100,6 +100,26 @@ class SiteStream:
         return self.pos == 0
 
 
+class SiteStreamIIDXZ(SiteStream):
+    """generate_IIDXZ_error (FL:134-160) draws TWO uniforms per qubit (X flip, then Z flip) and no integer: per round 2 d*d `rand`
+    (qubit q: site words k0, k1), then d*d-1 `rand` in the generate_faulty_syndrome order (word k2)."""
+
+    def rand(self):
+        n_err = 2 * self.d2
+        if self.pos < n_err:
+            w = philox.site_words(self.seed, self.env_id, self.round, self.pos // 2)[self.pos % 2]
+        else:
+            w = philox.site_words(self.seed, self.env_id, self.round, self.pos - n_err)[2]
+        self.pos += 1
+        if self.pos == n_err + self.d2 - 1:
+            self.pos = 0
+            self.round += 1
+        return w / 4294967296.0
+
+    def randint(self, lo, hi):
+        raise AssertionError("the IIDXZ channel draws no integers")
+
+
 class ListStream:
     def __init__(self, words):
         self.words, self.i = list(words), 0
@@ -207,6 +227,20 @@ def gen_kats(FL, ENV, out):
             n_act = lattice.num_actions(d, model, use_Y)[0]
             out[f"kat_move_d{d}_{model}_{int(use_Y)}"] = np.array(
                 [FL.index_to_move(d, a, model, use_Y) for a in range(n_act + 1)]).astype(np.uint8)
+    # G9: generate_error(d, p, "IIDXZ") under injected words (pins: two draws per qubit, X first; both hits -> Y)
+    saved = np.random.rand
+    for d in (3, 5, 7):
+        words, errs_out = [], []
+        for i in range(24):
+            w = rng.randint(0, 2 ** 32, size=2 * d * d, dtype=np.uint64)
+            stream = ListStream(w)
+            np.random.rand = stream.rand
+            e = FL.generate_error(d, 0.3, "IIDXZ")
+            np.random.rand = saved
+            assert stream.i == 2 * d * d
+            words.append(w), errs_out.append(e)
+        out[f"kat_iidxz_words_d{d}"] = np.array(words, dtype=np.uint32)
+        out[f"kat_iidxz_err_d{d}"] = np.array(errs_out, dtype=np.uint8)
     # G7: the README known-answer vector (README.md:712-780): X on qubit (4,1) of d=5
     qubits = FL.generateSurfaceCodeLattice(5)
     e = np.zeros((5, 5), int)
@@ -244,11 +278,21 @@ TRACE_CONFIGS = {
     "x2_d5_dp_hot": (5, "DP", False, 0.08, 0.08, 5, 8, 96),    # many failures / resets
     "x3_d3_x_nomeas": (3, "X", False, 0.02, 0.0, 3, 8, 96),    # p_meas = 0: long rejection loops
     "x4_d7_x": (7, "X", False, 0.01, 0.01, 4, 4, 64),          # depth != d
+    # IIDXZ noise (generate_error(d, p, "IIDXZ"), FL:91-92,134-160).  The reference's environment constructor cannot be built with this
+    # model string (ENV:66-69), so the trace runs its "DP" environment (same action layers, same four homology classes, FL:329-330) with
+    # the name `generate_error` in the Environments module bound to the reference's own IIDXZ generator -- no reference code is changed.
+    "x5_d5_iidxz": (5, "IIDXZ", False, 0.02, 0.015, 5, 8, 96),
 }
 
 
 def run_trace(ENV, cfg, luts, auto_reset=True):
     d, model, use_Y, p_phys, p_meas, depth, n_envs, n_steps = cfg
+    iidxz = model == "IIDXZ"
+    env_model = "DP" if iidxz else model
+    saved_gen = ENV.generate_error
+    if iidxz:
+        import Function_Library as FL
+        ENV.generate_error = lambda d_, p_, m_: FL.generate_error(d_, p_, "IIDXZ")
     ref = referee.LutReferee(d, model, lut_x=luts[d][0], lut_z=luts[d][1])
     n_act = lattice.num_actions(d, model, use_Y)[0]
     C, n = depth + lattice.num_actions(d, model, use_Y)[1], 2 * d + 1
@@ -270,10 +314,10 @@ def run_trace(ENV, cfg, luts, auto_reset=True):
     saved = (np.random.rand, np.random.randint)
     try:
         for e in range(n_envs):
-            stream = SiteStream(d, SEED, e)
+            stream = (SiteStreamIIDXZ if iidxz else SiteStream)(d, SEED, e)
             np.random.rand, np.random.randint = stream.rand, stream.randint
             env = ENV.Surface_Code_Environment_Multi_Decoding_Cycles(
-                d=d, p_phys=p_phys, p_meas=p_meas, error_model=model, use_Y=use_Y, volume_depth=depth, static_decoder=ref)
+                d=d, p_phys=p_phys, p_meas=p_meas, error_model=env_model, use_Y=use_Y, volume_depth=depth, static_decoder=ref)
 
             def snap(t):
                 rec["obs"][e, t] = env.board_state
@@ -306,7 +350,8 @@ def run_trace(ENV, cfg, luts, auto_reset=True):
                 snap(t + 1)
     finally:
         np.random.rand, np.random.randint = saved
-    rec["config"] = np.array([d, {"X": 0, "DP": 1}[model], int(use_Y), depth, n_envs, n_steps], dtype=np.int32)
+        ENV.generate_error = saved_gen
+    rec["config"] = np.array([d, {"X": 0, "DP": 1, "IIDXZ": 2}[model], int(use_Y), depth, n_envs, n_steps], dtype=np.int32)
     rec["rates"] = np.array([p_phys, p_meas], dtype=np.float64)
     rec["seed"] = np.array(SEED, dtype=np.uint32)
     return rec
