@@ -126,11 +126,17 @@ def cpu_baseline_loop(cfg, B, eps, c_layers, ff_layers, mode="loop", seconds=12.
                       f"{'' if mode == 'act' else f' + one {B}-sample double-DQN update'} in torch-CPU fp32 on all cores), {dt:.1f}s",
                dqn_updates_per_s=(updates / dt) if mode != "act" else None)
     if mode != "act" and seconds_b32 > 0 and filled >= 4:
+        threads_all = torch.get_num_threads()
+        torch.set_num_threads(min(4, threads_all))                         # the reference's SLURM jobs had 4 cores (GEN:87)
+        for _ in range(3):
+            one_update(32)
         t1, k = time.perf_counter(), 0
         while k < 3 or time.perf_counter() - t1 < seconds_b32:
             one_update(32)
             k += 1
         out["minibatch32_updates_per_s"] = k / (time.perf_counter() - t1)
+        out["minibatch32_threads"] = torch.get_num_threads()
+        torch.set_num_threads(threads_all)
         out["reference_recorded_updates_per_s"] = "38.4-41.6 (4 cores, TF-CPU, 2018; trained_models/d5_dp/*/training_history.json)"
     return out
 

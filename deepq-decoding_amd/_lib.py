@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdeepq_hip.so")
+# DQ_LIB_PATH: development aid (instrumented builds of the SAME library, tools/build_stamps.sh); there is still no CPU fallback
+LIB_PATH = os.environ.get("DQ_LIB_PATH") or os.path.join(_HERE, "lib", "libdeepq_hip.so")
 
 DQ_MODEL_X, DQ_MODEL_DP, DQ_MODEL_IIDXZ = 0, 1, 2
 STREAM_ENV, STREAM_POLICY, STREAM_REPLAY, STREAM_DROPOUT, STREAM_INIT = range(5)

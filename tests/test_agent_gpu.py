@@ -459,21 +459,21 @@ def test_config_dict_driven_grid_on_one_gpu(dq, torch_mod, tmp_path):
              "stopping_patience": 100000, "error_model": "X", "c_layers": C_LAYERS, "ff_layers": FF_LAYERS, "max_timesteps": 64 * 60,
              "volume_depth": 3, "testing_length": 64, "buffer_size": 64 * 40, "dueling": True, "masked_greedy": False, "static_decoder": True}
     fam = str(tmp_path / "d3_x")
-    dirs = runner.write_grid(fam, fixed, 0.005, 100000, grid=dict(learning_rate=[1e-4, 5e-5], exploration_fraction=[64 * 30],
+    dirs = runner.write_grid(fam, fixed, 0.001, 100000, grid=dict(learning_rate=[1e-4, 5e-5], exploration_fraction=[64 * 30],
                                                                   target_network_update_freq=[640], final_eps=[0.02], learning_starts=[256]))
     assert len(dirs) == 2
-    codes = runner.run_grid(os.path.join(fam, "0.005"), gpus=[0], n_envs=64, extra_args=["--quiet", "--sync-interval", "4"])
-    assert codes == {1: 0, 2: 0}, open(os.path.join(fam, "0.005", "output_files", "err_0.005_1.err")).read()[-2000:]
+    codes = runner.run_grid(os.path.join(fam, "0.001"), gpus=[0], n_envs=64, extra_args=["--quiet", "--sync-interval", "4"])
+    assert codes == {1: 0, 2: 0}, open(os.path.join(fam, "0.001", "output_files", "err_0.001_1.err")).read()[-2000:]
     for cdir in dirs:
         files = set(os.listdir(cdir))
         assert {"started_at.p", "training_history.json", "memory.p", "final_dqn_weights.h5f", "results.p", "all_results.p"} <= files
         allr = pickle.load(open(os.path.join(cdir, "all_results.p"), "rb"))
-        assert list(allr)[0] == "0.001" and all(v > 0 for v in allr.values()) and "0.005" in allr or len(allr) < 5
+        assert list(allr)[0] == "0.001" and all(v > 0 for v in allr.values())
         assert len(json.load(open(os.path.join(cdir, "training_history.json")))["episode"]) > 0
-    res = runner.collect_results(os.path.join(fam, "0.005"))
+    res = runner.collect_results(os.path.join(fam, "0.001"))
     assert set(res) == {"1", "2"} and all(isinstance(v, float) for v in res.values())
     # the Controller pass: best point -> next error rate's grid, continuing from its weights and memory (in this process)
-    new = runner.spawn_next(fam, fixed, 0.005, 0.007, thresholds={"0.005": 0.0},
+    new = runner.spawn_next(fam, fixed, 0.001, 0.003, thresholds={"0.001": 0.0},
                             grid=dict(learning_rate=[1e-4], exploration_fraction=[64 * 20], max_eps=[0.5], target_network_update_freq=[640],
                                       final_eps=[0.02], learning_starts=[128]))
     assert len(new) == 1 and os.path.exists(os.path.join(new[0], "initial_dqn_weights.h5f"))

@@ -1,0 +1,25 @@
+#!/bin/bash
+# The round's measurement set (GPU box, repo root): tools/measure.sh <tag>  ->  gpurun_out/<tag>/
+#   bench_<config>_<mode>.json   one JSON line each: c3 loop (headline, with cpu_baseline), c2 / c5 loop, c3 act / learn / env,
+#                                c3 loop at minibatch 32 (the reference's replay ratio setting)
+#   loop_c3_kernel_stats.csv     rocprofv3 --kernel-trace --stats of the headline command
+#   pmc_traffic_loop_c3.json     FETCH_SIZE / WRITE_SIZE passes, stamped with the kernel sources' sha256
+tag="${1:-meas}"; root="${GRAFT_REPO_ROOT:-$PWD}"; cd "$root"; out="gpurun_out/$tag"; mkdir -p "$out"
+line() { grep '^{"metric"' | tail -1; }
+python bench.py 2>"$out/bench_c3_loop.err" | line > "$out/bench_c3_loop.json"
+for cfg in c2 c5; do python bench.py --config $cfg --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_${cfg}_loop.json"; done
+for mode in act learn env; do python bench.py --mode $mode --steps 1000 --warmup 50 2>/dev/null | line > "$out/bench_c3_${mode}.json"; done
+python bench.py --minibatch 32 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_mb32.json"
+rm -rf "$out/prof"
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -- python "$root/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$root/$out/prof.log" 2>&1)
+python tools/rocprof_summary.py $(ls $out/prof/*/*.db | head -1) "$out/loop_c3_kernel_stats.csv"
+rm -rf "$out/prof"
+tools/pmc_traffic.sh loop c3 > "$out/pmc.log" 2>&1; cp gpurun_out/pmc_traffic_loop_c3.json "$out/" 2>/dev/null
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+head -12 "$out/loop_c3_kernel_stats.csv" | cut -c1-120
+for f in $out/bench_*.json; do python - "$f" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); r = d.get("roofline") or {}
+print(sys.argv[1].split("/")[-1], "%.3g %s" % (d["value"], d["unit"]), "ms/step %.4f" % d["ms_per_step"], r.get("kernel"), "frac %.3f" % r.get("frac", 0), "avg_us %.1f" % r.get("avg_launch_us", 0))
+PY
+done
