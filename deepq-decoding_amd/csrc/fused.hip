@@ -33,21 +33,6 @@ DQ_STAMP_READER(dq_dbg_read_fwd)
 #define CONV_LDS_2PER_CU (80 * 1024)
 #define CONV_LDS_MAX CHAIN_LDS_MAX
 
-// ---------------------------------------------------------------------------------------------------------------
-// One launch serves up to FWD_MAX_JOBS independent forwards ("jobs": e.g. Q_target(s1), Q_online(s1) and the training forward
-// on s0 of one DQN update): with 16 samples per workgroup a single 4096-sample forward is one workgroup per CU, whose serial
-// phases (staging, epilogues, head layers) leave the matrix pipe idle; several jobs in one grid overlap them.
-struct ConvJob {
-    const float* params;
-    const u32x4* packed;               // bf16 pieces of the conv2 / conv3 kernels (qnet.h PK_*)
-    const u8* obs;
-    const int32_t* index;
-    int index_off, index_mod, batch;
-    float* act_out[3];                 // global NHWC [batch*oh*ow, cout]; [2] always written
-    int write_all;                     // training: write every layer
-    int wg0;                           // first workgroup of this job
-};
-
 struct ConvChainArgs {
     ConvJob job[FWD_MAX_JOBS];
     int n_jobs, S;
@@ -170,20 +155,22 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     // truncation); each product a*piece is exact and the pieces are accumulated in f32 by v_mfma_f32_16x16x32_bf16.  The result
     // differs from an f32 fma chain only by the order of the f32 additions.  Layout of 16x16x32: lane (kb = lane >> 4, i = lane & 15)
     // holds A[i][8kb .. 8kb+7] / B[8kb .. 8kb+7][i]; column tile t, lane j is column 4j + t (float4 weight loads).
-    const float* w1 = J.params + a.w_off[0];
+    // ready-made pieces from the packed buffer (PK_CONV1, zero past K1): splitting them here cost every workgroup ~350 VALU per wave
     u32x4 wb[3][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 bf16 each
     int ko[NH1][8];
-    f32x4 wv[NH1][8];
+    {
+        const u32x4* pk1 = J.packed + PK_CONV1 + lane;
 #pragma unroll
-    for (int h = 0; h < NH1; ++h)
+        for (int h = 0; h < NH1; ++h)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 32 * h + 8 * kq + e;
-            const int off = a.kofftab[k];                           // Keras HWIO row k = (ky*k1 + kx)*C + c -> NCHW uint8 offset
-            const f32x4 v = *reinterpret_cast<const f32x4*>(w1 + (size_t)(off >= 0 ? k : 0) * 64 + 4 * j);
-            wv[h][e] = off >= 0 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-            ko[h][e] = off >= 0 ? off : 0;
-        }
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int piece = 0; piece < 3; ++piece) wb[piece][h][t] = pk1[(h * 4 + t) * PK_BLOCK + 64 * piece];
+#pragma unroll
+        for (int h = 0; h < NH1; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ko[h][e] = max(a.kofftab[32 * h + 8 * kq + e], 0);      // Keras HWIO row k -> NCHW uint8 offset (-1 past K1: weights 0)
+    }
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 1);
@@ -214,22 +201,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
         const int s = m / r1, pix = m - s * r1, oy = pix / a.ow1, ox = pix - oy * a.ow1;
         s_t1[m] = s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
     }
-    // ---- split the weights into bf16 pieces --------------------------------------------------------------------------------------
-#pragma unroll
-    for (int h = 0; h < NH1; ++h)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {                        // two k's per dword: element e in the low half
-                float x0 = wv[h][e][t], x1 = wv[h][e + 1][t];
-#pragma unroll
-                for (int piece = 0; piece < 3; ++piece) {
-                    const u32 b0 = __float_as_uint(x0) & 0xffff0000u, b1 = __float_as_uint(x1) & 0xffff0000u;
-                    wb[piece][h][t][e >> 1] = (b0 >> 16) | b1;
-                    x0 -= __uint_as_float(b0);                      // exact: the remainder has 8 fewer significant bits
-                    x1 -= __uint_as_float(b1);
-                }
-            }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's DMA pieces have landed
     __syncthreads();
 
@@ -633,7 +604,7 @@ struct PackTr { const float* src; float* dst; int R, C, tile0, tiles_c; };      
 struct PackArgs {
     const float* params;
     u32x4* pk;
-    int w2_off, w3_off, d1_off, d1_blocks;
+    int w1_off, K1, w2_off, w3_off, d1_off, d1_blocks;
     int perm_hw, perm_c;                // > 0: plane index k' = p*perm_c + c of the dense forward is Keras weight row c*perm_hw + p
     int pack_wgs;                       // workgroups [0, pack_wgs) pack bf16 pieces, the rest transpose (tr[i].tile0 counts from pack_wgs)
     PackTr tr[2];
@@ -679,6 +650,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
         const float* w = params + (c2 ? w2_off : w3_off);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = w[(size_t)(32 * blk + 8 * kb + e) * 32 + 2 * j + t];
+    } else if (blk_id >= 48) {                                      // first convolution (conv_pipe.hip): B(k = 32 h + 8kb + e, col = 4j + t), 0 past K1
+        const int b = blk_id - 48, h = b >> 2, t = b & 3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * h + 8 * kb + e;
+            v[e] = k < a.K1 ? params[a.w1_off + (size_t)k * 64 + 4 * j + t] : 0.f;
+        }
     } else {                                                        // data gradient: B(n = 8kb + e, c) = W[tap][c][n]
         const bool c3 = blk_id < 32;
         const int b = c3 ? blk_id - 24 : blk_id - 32;               // conv3: [tap][t]; conv2: [half][tap][t]
@@ -711,7 +689,7 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     PackArgs a;
     memset(&a, 0, sizeof(a));
     a.params = params_dev; a.pk = static_cast<u32x4*>(packed_dev);
-    a.w2_off = (int)Q->L[1].w_off; a.w3_off = (int)Q->L[2].w_off; a.d1_off = (int)D1.w_off; a.d1_blocks = (D1.nin >> 5) * 32;
+    a.w1_off = (int)Q->L[0].w_off; a.K1 = Q->L[0].K; a.w2_off = (int)Q->L[1].w_off; a.w3_off = (int)Q->L[2].w_off; a.d1_off = (int)D1.w_off; a.d1_blocks = (D1.nin >> 5) * 32;
     a.perm_hw = Q->flat_hw; a.perm_c = Q->flat_c;
     a.pack_wgs = (PK_TOTAL_BLOCKS + a.d1_blocks + 3) / 4;
     int tiles = a.pack_wgs;
@@ -892,10 +870,15 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         D.q_out = jb.q_dev;
         dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
     }
-    dq_prof_begin(DQ_K_CONV_CHAIN, st);
-    ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
-    dq_prof_end(DQ_K_CONV_CHAIN, st);
-    DQ_LAUNCH_CHECK();
+    if ((Q->use_fused & 2) && conv_pipe_supported(Q)) {             // experimental persistent wave pipeline (conv_pipe.hip): opt-in
+        const dq_status rc = conv_pipe_launch(Q, n_jobs, ca.job, n_cu, st);
+        if (rc != DQ_OK) return rc;
+    } else {
+        dq_prof_begin(DQ_K_CONV_CHAIN, st);
+        ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
+        dq_prof_end(DQ_K_CONV_CHAIN, st);
+        DQ_LAUNCH_CHECK();
+    }
     dq_prof_begin(DQ_K_DENSE_CHAIN, st);
     dk<<<dense_wgs, DENSE_THREADS, dp.lds, st>>>(da);
     dq_prof_end(DQ_K_DENSE_CHAIN, st);

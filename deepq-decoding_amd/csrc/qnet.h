@@ -33,7 +33,8 @@ struct dq_qnet {
     void* pk_scratch[FWD_MAX_JOBS];  // packed weights of jobs that did not bring their own (dq_qnet_job.packed_dev == NULL)
     const void* last_train_packed;   // packed weights of the last training forward (the backward's data gradients read them)
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
-    int use_fused;               // 1: fused LDS-resident forward when the configuration allows it
+    int use_fused;               // bit 0: fused LDS-resident chains when the configuration allows it; bit 1: the forward's convolutions
+                                 // through the experimental wave pipeline (conv_pipe.hip) instead of conv_chain_kernel (fused.hip)
 };
 
 
@@ -99,6 +100,19 @@ __device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32
 
 #endif  // __HIPCC__
 
+// One launch serves up to FWD_MAX_JOBS independent forwards ("jobs": e.g. Q_target(s1), Q_online(s1) and the training forward
+// on s0 of one DQN update, plus the acting forward): their serial phases (staging, epilogues, head layers) overlap in one grid.
+struct ConvJob {
+    const float* params;
+    const u32x4* packed;               // bf16 pieces of the conv2 / conv3 kernels (PK_* below)
+    const u8* obs;
+    const int32_t* index;
+    int index_off, index_mod, batch;
+    float* act_out[3];                 // global NHWC [batch*oh*ow, cout]; [2] always written
+    int write_all;                     // training: write every layer
+    int wg0;                           // first workgroup of this job
+};
+
 // ---- packed weights (fused.hip: pack_weights_kernel) --------------------------------------------------------------------------
 // The bf16x6 contractions read their weight operand as ready-made bf16 pieces in MFMA B-operand order: one "block" = 64 lanes x
 // 3 pieces x 16 bytes (lane (kb, j) holds the 8 reduction indices 8kb .. 8kb+7 of its column).  Sections, in u32x4 units:
@@ -106,12 +120,14 @@ __device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32
 //   PK_CONV3_FWD  [4][2]                            same for conv3
 //   PK_CONV3_DG   [4 taps][2]                       B(n = 8kb + e, c = 16t + j)                      = W3[tap][c][n]
 //   PK_CONV2_DG   [2 channel halves][4 taps][2]     B(n = 8kb + e, c = 32 half + 16t + j)            = W2[tap][c][n]
+//   PK_CONV1      [3 k-blocks][4 column tiles]      B(k = 32 blk + 8kb + e, col = 4j + t)            = W1[k][col] (conv_pipe.hip)
 #define PK_BLOCK 192                  // u32x4 per block (3 pieces x 64 lanes)
 #define PK_CONV2_FWD 0
 #define PK_CONV3_FWD (PK_CONV2_FWD + 16 * PK_BLOCK)
 #define PK_CONV3_DG (PK_CONV3_FWD + 8 * PK_BLOCK)
 #define PK_CONV2_DG (PK_CONV3_DG + 8 * PK_BLOCK)
-#define PK_TOTAL_BLOCKS 48
+#define PK_CONV1 (PK_CONV2_DG + 16 * PK_BLOCK)      // [3 k-blocks][4 column tiles]: B(k = 32 blk + 8kb + e, col = 4j + t) = W1[k][col], 0 past K1
+#define PK_TOTAL_BLOCKS 60
 #define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)     // the conv sections; then PK_DENSE1 [K1/32 k-blocks][32 column tiles];
 // then (f32, for the backward's data gradients) W1T [512][K1] and W2T [N2][512], each section 16-byte aligned:
 //   B(k = 32 blk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3)) = W1[k][col]
@@ -121,6 +137,9 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
+// conv_pipe.hip: the convolutional forward chain as a persistent wave pipeline (jobs[i].wg0 is filled in by the launcher)
+bool conv_pipe_supported(const dq_qnet* Q);
+dq_status conv_pipe_launch(dq_qnet* Q, int n_jobs, const ConvJob* jobs, int n_cu, hipStream_t st);
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
 dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_t st);

@@ -451,7 +451,7 @@ int dq_qnet_num_layers(const dq_qnet* Q) { return Q ? Q->n_layers : 0; }
 
 dq_status dq_qnet_set_fused(dq_qnet* Q, int enable) {
     DQ_REQUIRE(Q, DQ_ERR_INVALID, "dq_qnet_set_fused: null handle");
-    Q->use_fused = enable ? 1 : 0;
+    Q->use_fused = enable & 3;
     return DQ_OK;
 }
 

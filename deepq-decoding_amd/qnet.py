@@ -53,9 +53,11 @@ class QNetwork:
             kshape = tuple(shape[j] for j in range(nd.value))
             self.layers.append(dict(kernel_offset=ko.value, bias_offset=bo.value, kernel_shape=kshape, bias_shape=(kshape[-1],)))
 
-    def set_fused(self, enable):
-        """Select the fused LDS-resident forward (default) or the per-layer implicit-GEMM forward."""
-        check(self.L.dq_qnet_set_fused(self._h, int(bool(enable))))
+    def set_fused(self, enable, conv_pipe=False):
+        """Select the fused LDS-resident chains (default) or the per-layer implicit-GEMM path; conv_pipe=True keeps the fused chains
+        but runs the forward's convolutions through the experimental persistent wave pipeline (csrc/conv_pipe.hip: measured equal to
+        conv_chain_kernel) -- A/B runs and its parity test."""
+        check(self.L.dq_qnet_set_fused(self._h, (1 if enable else 0) | (2 if conv_pipe else 0)))
 
     @property
     def fused_supported(self):
