@@ -62,6 +62,14 @@ class TdJob(ctypes.Structure):
                 ("step_reward_dev", ctypes.c_void_p), ("n", ctypes.c_int32), ("stats_dev", ctypes.c_void_p)]
 
 
+class EnvStepJob(ctypes.Structure):
+    """dq_env_step_job (include/deepq_hip.h)."""
+    _fields_ = [("q_dev", ctypes.c_void_p), ("eps", ctypes.c_double), ("masked_greedy", ctypes.c_int32), ("seed", ctypes.c_uint32 * 2),
+                ("t", ctypes.c_uint64), ("action_dev", ctypes.c_void_p), ("auto_reset", ctypes.c_int32), ("obs_dev", ctypes.c_void_p),
+                ("reward_dev", ctypes.c_void_p), ("done_dev", ctypes.c_void_p), ("legal_dev", ctypes.c_void_p), ("lifetime_dev", ctypes.c_void_p),
+                ("was_reset_dev", ctypes.c_void_p), ("sample", ctypes.POINTER(SampleJob)), ("stats_dev", ctypes.c_void_p)]
+
+
 _vp, _i, _u32, _u64, _dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
 _sz = ctypes.c_size_t
 _seedp = ctypes.POINTER(ctypes.c_uint32)
@@ -104,6 +112,8 @@ SIGNATURES = {
     "dq_qnet_conv_param_count": (_sz, [_vp]),
     "dq_qnet_backward_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
     "dq_qnet_td_backward_adam": (_i, [_vp, _vp, ctypes.POINTER(TdJob), _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
+    "dq_qnet_td_backward_adam_env": (_i, [_vp, _vp, ctypes.POINTER(TdJob), _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp,
+                                          ctypes.POINTER(EnvStepJob), _vp]),
     "dq_qnet_td_backward_phase0": (_i, [_vp, _vp, ctypes.POINTER(TdJob), _vp, _vp]),
     "dq_replay_sample": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
     "dq_td_target": (_i, [_vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _vp, _vp]),

@@ -1,0 +1,298 @@
+// Device side of the batched surface-code environment, shared by env.hip (env_kernel) and fused_bwd.hip (the step of the lattices riding
+// on the dense backward's launch): tables, launch parameters and the body of one block of lattices.  Formulation: see env.hip.
+#pragma once
+#include "common.h"
+
+#define DQ_MAX_DEPTH 16
+#define ENVS_PER_BLOCK 4
+#define STATE_FIXED 9      // internal record: xmask zmask acted round comp0 comp1 legal0 legal1 meta, then volume
+#define EXPORT_FIXED 11
+
+struct EnvTables {
+    u64 stab_qmask[64];    // qubits of stabilizer s (measurement order), 0 beyond n_stab
+    u64 qubit_smask[64];   // live stabilizers touched by qubit q (ENV:262-271)
+    u64 neigh_qmask[64];   // 8-neighbourhood of qubit q (ENV:349-372)
+    u8 stab_isx[64];       // 1: type-3 plaquette (parity of the X component), 0: type 1 (Z component)
+    u8 stab_type[64];
+    u8 ref_src[64];        // lane h <- stabilizer whose bit lands at referee position h (255: none)
+    u8 cell_static[256];   // padding_syndrome decoration (ENV:284-298)
+    u8 cell_stab[256];     // stabilizer shown at an even-even cell (ENV:292-294), 255: none
+    u8 cell_qubit[256];    // qubit shown at an odd-odd cell of an action plane (ENV:301-314), 255: none
+    u64 col0, row0;        // FL:312-317
+};
+
+struct EnvParams {
+    const EnvTables* tab;
+    u64* state;
+    const u32 *lut_x, *lut_z;
+    int n_envs, d2, n_stab, depth, layers, n_actions, identity, model, use_Y, sw, P, C, obs_size;
+    u32 env_id_base, seed0, seed1;
+    u64 T_phys, T_meas;
+    int mode, auto_reset;          // mode 0: reset, 1: step
+    const u8* which;
+    const int32_t* action;
+    u8* obs;
+    float* reward;
+    u8* done;
+    u64* legal;
+    u32* lifetime;
+    u8* was_reset;
+    // fused action selection (dq_env_act_step): the rule of policy.hip's policy_kernel, one lattice per wave
+    int policy;                    // 0: actions come from `action`; 1: selected here and written to action_out
+    const float* q;                // [n_envs, n_actions] or NULL (explore always)
+    u64 T_eps, pt;
+    int masked_greedy;
+    u32 pseed0, pseed1;
+    int32_t* action_out;
+    // replay sampling for the update that follows this step (dq_env_act_step_sample): workgroups [env_blocks, env_blocks + s_blocks)
+    int env_blocks, s_blocks;
+    const u8* s_terminal;          // the terminal ring; this step writes slot head - 1, the rule only reads older slots
+    int s_n_slots, s_head, s_filled, s_batch;
+    u32 s_seed0, s_seed1, s_base;
+    u64 s_t;
+    int32_t* s_index;
+    // episode bookkeeping of THIS step (dq_episode_stats' four sums), done by the blocks themselves when the step rides on a launch
+    // that runs before anything could read its results (fused_bwd.hip); NULL: not here
+    unsigned long long* stats;
+};
+
+static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s) {
+    if (s == 0) { lo |= v; }
+    else if (s < 64) { lo |= v << s; hi |= v >> (64 - s); }
+    else { hi |= v << (s - 64); }
+}
+
+// One block of EPB lattices (64 * EPB threads, one lattice per wave); `block` = the block's number inside the environment part of the
+// grid (env_kernel: blockIdx.x; as a rider on another kernel's launch -- fused_bwd.hip -- the offset is subtracted by the caller).
+// LDS: env_block_lds(EPB, obs_size) bytes at `smem`.
+static inline size_t env_block_lds(int epb, int obs_size) { return (size_t)epb * DQ_MAX_DEPTH * 8 + 3 * 256 + (size_t)epb * ((obs_size + 3) & ~3); }
+
+template <int EPB>
+static __device__ __forceinline__ void env_block(const EnvParams& p, const int block, u8* __restrict__ smem) {
+    constexpr int THREADS = 64 * EPB;
+    u64* s_vol = reinterpret_cast<u64*>(smem);                              // [EPB][16]
+    u8* s_static = smem + EPB * DQ_MAX_DEPTH * 8;                           // [256]
+    u8* s_stab = s_static + 256;
+    u8* s_qubit = s_stab + 256;
+    u8* s_stage = s_qubit + 256;                                            // [EPB * obs_size]
+    __shared__ unsigned long long s_est[EPB][4];                            // episode bookkeeping of the block's lattices (p.stats)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (block >= p.env_blocks) {                                            // replay sampling rides along (independent of this step's results)
+        const int b = (block - p.env_blocks) * THREADS + tid;
+        if (b < p.s_batch)
+            p.s_index[b] = dq_replay_row(p.s_terminal, p.n_envs, p.s_n_slots, p.s_head, p.s_filled, p.s_seed0, p.s_seed1, p.s_t, p.s_base + (u32)b);
+        return;
+    }
+    const int i = block * EPB + wave;
+    const bool active = i < p.n_envs;                                        // wave-uniform
+
+    if (tid < 256) {
+        s_static[tid] = p.tab->cell_static[tid];
+        s_stab[tid] = p.tab->cell_stab[tid];
+        s_qubit[tid] = p.tab->cell_qubit[tid];
+    }
+
+    const u64 sq = p.tab->stab_qmask[lane];
+    const u64 qs = p.tab->qubit_smask[lane];
+    const bool isx = p.tab->stab_isx[lane] != 0;
+    const int rsrc = p.tab->ref_src[lane];
+    volatile u64* vol = s_vol + wave * DQ_MAX_DEPTH;   // written by lane 0, read by other lanes of the same wave
+
+    u64 comp0 = 0, comp1 = 0;
+    if (p.stats && lane < 4) s_est[wave][lane] = 0;
+    if (active) {
+        u64* rec = p.state + (size_t)i * p.sw;
+        const u64 word = lane < p.sw ? rec[lane] : 0;
+        u64 xmask = wave_bcast64(word, 0), zmask = wave_bcast64(word, 1), acted = wave_bcast64(word, 2);
+        u64 round = wave_bcast64(word, 3);
+        comp0 = wave_bcast64(word, 4);
+        comp1 = wave_bcast64(word, 5);
+        u64 legal0 = wave_bcast64(word, 6), legal1 = wave_bcast64(word, 7);
+        const u64 meta = wave_bcast64(word, 8);
+        u32 lifetime = (u32)meta;
+        int done = (int)((meta >> 32) & 1);
+        if (lane >= STATE_FIXED && lane < STATE_FIXED + p.depth) vol[lane - STATE_FIXED] = word;
+
+        bool do_reset;
+        if (p.mode == 0) {
+            do_reset = p.which ? (__builtin_amdgcn_readfirstlane((int)p.which[i]) != 0) : true;
+        } else {
+            do_reset = p.auto_reset && done;
+        }
+        const bool do_step = p.mode == 1 && !do_reset;
+        float reward = 0.f;
+        bool need_volume = do_reset;
+        if (do_reset) {                                                     // ENV:106-107, 211-213
+            done = 0; lifetime = 0; xmask = 0; zmask = 0;
+        }
+        int a_sel = 0;
+        if (p.policy) {                                                     // EpsGreedyQPolicy / GreedyQPolicy(masked_greedy), see policy.hip
+            u32 w[4];
+            philox4x32_10((u32)p.pt, (u32)(p.pt >> 32), p.env_id_base + (u32)i, (u32)DQ_STREAM_POLICY << 16, p.pseed0, p.pseed1, w);
+            if (p.q == nullptr || (u64)w[1] < p.T_eps) {                    // explore: k-th smallest legal action
+                const int n_legal = __popcll(legal0) + __popcll(legal1);
+                a_sel = kth_set_bit128(legal0, legal1, (int)__umulhi(w[0], (u32)n_legal));
+            } else {                                                        // first maximum of the Q row (optionally over the legal set)
+                const float* row = p.q + (size_t)i * p.n_actions;
+                float best = -INFINITY;
+                int best_a = 0x7fffffff;
+                for (int k = lane; k < p.n_actions; k += 64) {
+                    const bool ok = !p.masked_greedy || (((k < 64 ? legal0 : legal1) >> (k & 63)) & 1);
+                    const float v = row[k];
+                    if (ok && (v > best || best_a == 0x7fffffff)) { best = v; best_a = k; }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const float ov = __shfl_xor(best, m);
+                    const int oa = __shfl_xor(best_a, m);
+                    if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
+                }
+                a_sel = best_a;
+            }
+            a_sel = __builtin_amdgcn_readfirstlane(a_sel);
+            if (lane == 0) p.action_out[i] = a_sel;
+        }
+        if (do_step) {
+            int a = p.policy ? a_sel : __builtin_amdgcn_readfirstlane(p.action[i]);
+            if ((unsigned)a >= (unsigned)p.n_actions) a = p.identity;
+            const u64 cw = a < 64 ? comp0 : comp1;
+            const bool done_identity = a == p.identity || ((cw >> (a & 63)) & 1);      // ENV:131
+            if (a != p.identity) {                                          // ENV:135-136, FL:243-294
+                const int layer = a / p.d2, q = a - layer * p.d2;
+                const int pauli = p.model == DQ_MODEL_X ? 1 : (p.use_Y ? layer + 1 : (layer == 0 ? 1 : 3));
+                if (pauli != 3) xmask ^= 1ull << q;
+                if (pauli != 1) zmask ^= 1ull << q;
+            }
+            const u64 true_word = __ballot(__popcll((isx ? xmask : zmask) & sq) & 1);   // ENV:139, FL:152-174
+            const int cls = (__popcll(xmask & p.tab->col0) & 1) + 2 * (__popcll(zmask & p.tab->row0) & 1);  // ENV:143
+            const u64 refw = __ballot(rsrc < 64 && ((true_word >> (rsrc & 63)) & 1));
+            const u32 ix = (u32)refw, iz = (u32)(refw >> 32);
+            int dec = (p.lut_x[ix >> 5] >> (ix & 31)) & 1;                  // ENV:144
+            if (p.model != DQ_MODEL_X) dec += 2 * ((p.lut_z[iz >> 5] >> (iz & 31)) & 1);
+            dec = __builtin_amdgcn_readfirstlane(dec);
+            if (cls == 0 && true_word == 0) reward = 1.f;                   // ENV:148-149
+            else if (dec != cls) done = 1;                                  // ENV:150-151
+            if (done_identity) {
+                need_volume = true;                                         // ENV:155
+            } else {                                                        // ENV:185-196
+                if (a < 64) comp0 |= 1ull << a; else comp1 |= 1ull << (a - 64);
+                const int q = a % p.d2;
+                if (!((acted >> q) & 1)) {
+                    acted |= 1ull << q;
+                    const u64 nm = p.tab->neigh_qmask[q];
+                    for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, nm, j * p.d2);
+                }
+            }
+        }
+        if (need_volume) {                                                  // ENV:157-172 == ENV:216-231
+            u64 summed;
+            do {
+                summed = 0;
+                for (int j = 0; j < p.depth; ++j) {
+                    u32 w[4];
+                    philox4x32_10((u32)round, (u32)(round >> 32), p.env_id_base + (u32)i, (u32)lane, p.seed0, p.seed1, w);
+                    const bool hit = lane < p.d2 && (u64)w[0] < p.T_phys;   // FL:99 / FL:119
+                    const int typ = p.model == DQ_MODEL_X ? 1 : 1 + (int)__umulhi(w[1], 3u);   // FL:100
+                    // IIDXZ (FL:134-160): the qubit's second uniform decides an independent Z flip instead of the Pauli type
+                    const bool zhit = lane < p.d2 && (u64)w[1] < p.T_phys;
+                    const u64 ex = __ballot(p.model == DQ_MODEL_IIDXZ ? hit : hit && typ != 3);
+                    const u64 ez = __ballot(p.model == DQ_MODEL_IIDXZ ? zhit : hit && typ != 1);
+                    const u64 flips = __ballot(lane < p.n_stab && (u64)w[2] < p.T_meas);      // FL:191-221
+                    ++round;
+                    xmask ^= ex;                                            // ENV:164, FL:226-241
+                    zmask ^= ez;
+                    const u64 tw = __ballot(__popcll((isx ? xmask : zmask) & sq) & 1);        // ENV:165
+                    const u64 v = tw ^ flips;                               // ENV:166
+                    if (lane == 0) vol[j] = v;
+                    summed |= v;                                            // ENV:168
+                    ++lifetime;                                             // ENV:169
+                }
+            } while (summed == 0);                                          // ENV:171
+            // reset_legal_moves, ENV:238-258
+            comp0 = comp1 = 0; acted = 0;
+            const u64 legal_q = __ballot(lane < p.d2 && (qs & summed) != 0);
+            legal0 = legal1 = 0;
+            or_shl128(legal0, legal1, 1ull, p.identity);
+            for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, legal_q, j * p.d2);
+        }
+
+        // ---- state record and scalar outputs ----------------------------------------------------
+        const u64 meta_out = (u64)lifetime | ((u64)done << 32);
+        u64 o = 0;
+        o = lane == 0 ? xmask : o;  o = lane == 1 ? zmask : o;  o = lane == 2 ? acted : o;
+        o = lane == 3 ? round : o;  o = lane == 4 ? comp0 : o;  o = lane == 5 ? comp1 : o;
+        o = lane == 6 ? legal0 : o; o = lane == 7 ? legal1 : o; o = lane == 8 ? meta_out : o;
+        if (lane >= STATE_FIXED && lane < STATE_FIXED + p.depth) o = vol[lane - STATE_FIXED];
+        if (lane < p.sw) rec[lane] = o;
+        if (lane == 0) {
+            if (p.reward) p.reward[i] = reward;
+            if (p.done) p.done[i] = (u8)done;
+            if (p.lifetime) p.lifetime[i] = lifetime;
+            if (p.was_reset) p.was_reset[i] = (u8)(p.mode == 1 && do_reset);
+            if (p.legal) { p.legal[2 * (size_t)i] = legal0; p.legal[2 * (size_t)i + 1] = legal1; }
+            if (p.stats) {                                                  // dq_episode_stats' sums for this lattice (common.h dq_episode_stats_lane)
+                const bool stepped = p.mode == 1 && !do_reset, ended = stepped && done;
+                s_est[wave][0] = ended; s_est[wave][1] = ended ? lifetime : 0;
+                s_est[wave][2] = stepped && reward > 0.5f; s_est[wave][3] = stepped;
+            }
+        }
+    }
+
+    if (!p.obs && !p.stats) return;                                         // block-uniform
+    __syncthreads();                                                        // cell tables (and bookkeeping words) visible
+    if (p.stats && tid < 4) {                                               // integer sums: order-independent; at most four atomics per block
+        unsigned long long v = 0;
+#pragma unroll
+        for (int w = 0; w < EPB; ++w) v += s_est[w][tid];
+        if (v) atomicAdd(&p.stats[tid], v);
+    }
+    if (!p.obs) return;
+    if (active) {
+        // observation planes into the LDS stage (ENV:174-175, 200-201, 273-314)
+        u8* st = s_stage + wave * p.obs_size;
+        for (int j = 0; j < p.depth; ++j) {
+            const u64 v = vol[j];
+            for (int c = lane; c < p.P; c += 64) {
+                const int sidx = s_stab[c];
+                st[j * p.P + c] = (u8)(s_static[c] | (sidx < 64 ? (u32)((v >> (sidx & 63)) & 1) : 0u));
+            }
+        }
+        for (int k = 0; k < p.layers; ++k) {
+            for (int c = lane; c < p.P; c += 64) {
+                const int qi = s_qubit[c];
+                u32 bit = 0;
+                if (qi < 64) {
+                    const int a = k * p.d2 + qi;
+                    bit = (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1);
+                }
+                st[(p.depth + k) * p.P + c] = (u8)bit;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int first = block * EPB;
+        const int n_valid = min(EPB, p.n_envs - first);
+        const int total = n_valid * p.obs_size;
+        u8* g = p.obs + (size_t)first * p.obs_size;
+        if ((reinterpret_cast<uintptr_t>(g) & 3) == 0) {
+            const u32* s32 = reinterpret_cast<const u32*>(s_stage);
+            u32* g32 = reinterpret_cast<u32*>(g);
+            const int ndw = total >> 2;
+            for (int k = tid; k < ndw; k += THREADS) g32[k] = s32[k];
+            for (int k = (ndw << 2) + tid; k < total; k += THREADS) g[k] = s_stage[k];
+        } else {
+            for (int k = tid; k < total; k += THREADS) g[k] = s_stage[k];
+        }
+    }
+}
+
+// env.hip: validates the arguments of dq_env_act_step(_sample) and fills the parameters of a step WITHOUT launching it: the caller
+// runs env_block<8> on blocks [0, p->env_blocks + p->s_blocks) of its own grid (p->env_blocks, p->s_blocks are set for 8 lattices /
+// 512 sampling threads per block); *lds = the dynamic LDS those blocks need.
+struct dq_env;
+dq_status env_fill_act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
+                            int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
+                            uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sj, uint64_t* stats_dev, EnvParams* p,
+                            size_t* lds);

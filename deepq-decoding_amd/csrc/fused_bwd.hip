@@ -10,6 +10,7 @@
 // Gradients w.r.t. pre-activations are stored per layer in Q->gz[layer]; weight gradients and the convolutional data gradients
 // still run through qnet.hip's per-layer kernels (layer_wgrad / layer_dgrad).
 #include "qnet.h"
+#include "env_dev.h"
 
 DQ_STAMP_READER(dq_dbg_read_bwd)
 
@@ -34,7 +35,8 @@ struct DenseBwdArgs {
     float* gx;                          // [batch, K1] NHWC
     int ldg;                            // LDS row stride of the g3 / gY2 images (floats)
     int off_g3, off_gy2, off_gh1;
-    int td_on, dense_wgs;               // td_on: dq is computed here from `td`; workgroups >= dense_wgs do the episode bookkeeping
+    int td_on, dense_wgs;               // td_on: dq is computed here from `td`; workgroups >= dense_wgs do the episode bookkeeping ...
+    int env_on;                         // ... or, with a rider, the environment step (+ its replay sampling and bookkeeping): env_block<8>
     TdFused td;
 };
 
@@ -94,8 +96,16 @@ __device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const float* __re
 }
 
 template <int NT2>                      // N2 <= 16*NT2 and N3 <= 16*NT2
-__global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(DenseBwdArgs a) {
+__global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(DenseBwdArgs a, EnvParams env) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    // The vector step's environment launch does not feed this update (the minibatch never holds the newest transition, common.h
+    // dq_replay_row) and this update does not feed it (it acts on Q-values the forward already wrote): the lattices' step rides on this
+    // launch as extra workgroups.  The dense chain is one 8-wave workgroup per CU with long dependent phases; the environment is a
+    // latency chain per lattice: together they fill each other's idle issue slots instead of taking 15 us of their own.
+    if (a.env_on && (int)blockIdx.x >= a.dense_wgs) {               // block-uniform
+        env_block<8>(env, (int)blockIdx.x - a.dense_wgs, smem);
+        return;
+    }
     float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
     float* s_gy2 = reinterpret_cast<float*>(smem + a.off_gy2);
     float* s_gh1 = reinterpret_cast<float*>(smem + a.off_gh1);
@@ -1044,7 +1054,8 @@ typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
 // phases: bit 0 = dense part (data gradients, dense weight gradients reduced into grads_dev[conv params ..)), bit 1 = convolutional
 // part (grads_dev[0 .. conv params)).  3 = whole backward with one reduction launch.
 dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st,
-                         const AdamOpt* opt, const TdFused* td) {
+                         const AdamOpt* opt, const TdFused* td, const EnvParams* rider, size_t rider_lds) {
+    DQ_REQUIRE(!rider || (td && (phases & 1)), DQ_ERR_INVALID, "fused_backward: the environment step rides on the TD launch");
     DQ_REQUIRE(!td || (phases & 1), DQ_ERR_INVALID, "fused_backward: the TD step belongs to the dense phase");
     DQ_REQUIRE(!opt || phases == 3, DQ_ERR_INVALID, "fused_backward: the fused optimizer step needs the whole backward in one call");
     DenseBwdPlan dp;
@@ -1090,9 +1101,17 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         da.td_on = 1; da.td = *td;
         if (td->st_n > 0) stat_wgs = (td->st_n + DENSE_THREADS - 1) / DENSE_THREADS;
     }
+    EnvParams ep;
+    memset(&ep, 0, sizeof(ep));
+    size_t lds = dp.lds;
+    if (rider) {                                                    // (its blocks do their own bookkeeping: no statistics workgroups)
+        DQ_REQUIRE(!td->st_n, DQ_ERR_INVALID, "fused_backward: the riding environment step does its own episode bookkeeping");
+        ep = *rider; da.env_on = 1; stat_wgs = ep.env_blocks + ep.s_blocks;
+        if (rider_lds > lds) lds = rider_lds;
+    }
     dq_prof_begin(DQ_K_DENSE_BWD, st);
-    if (dp.NT2 == 4) dense_bwd_chain_kernel<4><<<da.dense_wgs + stat_wgs, DENSE_THREADS, dp.lds, st>>>(da);
-    else dense_bwd_chain_kernel<7><<<da.dense_wgs + stat_wgs, DENSE_THREADS, dp.lds, st>>>(da);
+    if (dp.NT2 == 4) dense_bwd_chain_kernel<4><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
+    else dense_bwd_chain_kernel<7><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
     dq_prof_end(DQ_K_DENSE_BWD, st);
     DQ_LAUNCH_CHECK();
 

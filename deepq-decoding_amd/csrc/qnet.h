@@ -165,5 +165,8 @@ struct TdFused {
     int st_n;
     unsigned long long* st_stats;
 };
+// rider != NULL (needs td): the lattices' environment step (env_dev.h parameters, filled by env_fill_act_step) runs as extra
+// workgroups of the dense backward's first launch
+struct EnvParams;
 dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st,
-                         const AdamOpt* opt = nullptr, const TdFused* td = nullptr);
+                         const AdamOpt* opt = nullptr, const TdFused* td = nullptr, const EnvParams* rider = nullptr, size_t rider_lds = 0);

@@ -217,6 +217,7 @@ __global__ void dueling_bwd_kernel(const float* __restrict__ dq, float* __restri
 
 // ---------------------------------------------------------------------------------------------------
 #include "qnet.h"
+#include "env_dev.h"
 
 static void launch_fwd(const Gather& ga, const BMap& gb, const Epilogue& ep, int M, int N, int K, hipStream_t st) {
     const bool small = (M + BM - 1) / BM * ((N + 63) / 64) < 256;      // too few 128-row blocks to fill 256 CUs
@@ -623,7 +624,8 @@ static dq_status separate_td(const dq_td_job* tdj, void* stream) {
 }
 
 static dq_status backward_adam(dq_qnet* Q, float* params_dev, const float* dq_dev, const dq_td_job* tdj, float* grads_dev, float* m_dev,
-                               float* v_dev, double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream) {
+                               float* v_dev, double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream,
+                               const EnvParams* rider = nullptr, size_t rider_lds = 0) {
     DQ_REQUIRE(Q && params_dev && (dq_dev || tdj) && grads_dev && m_dev && v_dev, DQ_ERR_INVALID, "dq_qnet_backward_adam: null argument");
     DQ_REQUIRE(t >= 1, DQ_ERR_INVALID, "dq_qnet_backward_adam: t counts from 1");
     DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_backward_adam: no training forward to differentiate");
@@ -638,8 +640,9 @@ static dq_status backward_adam(dq_qnet* Q, float* params_dev, const float* dq_de
         opt.b1 = (float)beta_1; opt.b2 = (float)beta_2; opt.eps = (float)epsilon;
         TdFused td;
         if (tdj) td = td_fused_from(tdj);
-        return fused_backward(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream, &opt, tdj ? &td : nullptr);
+        return fused_backward(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream, &opt, tdj ? &td : nullptr, rider, rider_lds);
     }
+    DQ_REQUIRE(!rider, DQ_ERR_UNSUPPORTED, "dq_qnet_td_backward_adam_env: only the fused chains carry the environment step");
     if (tdj) {                                                      // per-layer path: the separate launches
         dq_status rc = separate_td(tdj, stream);
         if (rc != DQ_OK) return rc;
@@ -668,6 +671,22 @@ dq_status dq_qnet_td_backward_phase0(dq_qnet* Q, const float* params_dev, const 
     rc = separate_td(tdj, stream);
     if (rc != DQ_OK) return rc;
     return backward_phases(Q, params_dev, tdj->dq_dev, grads_dev, 1, (hipStream_t)stream);
+}
+
+dq_status dq_qnet_td_backward_adam_env(dq_qnet* Q, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev,
+                                       double lr, double beta_1, double beta_2, double epsilon, uint64_t t, dq_env* env,
+                                       const dq_env_step_job* sj, void* stream) {
+    DQ_REQUIRE(td && env && sj, DQ_ERR_INVALID, "dq_qnet_td_backward_adam_env: null argument");
+    DQ_REQUIRE(td->n == 0, DQ_ERR_INVALID, "dq_qnet_td_backward_adam_env: the step does its own bookkeeping (td->n must be 0)");
+    DQ_REQUIRE(Q && Q->use_fused && fused_backward_supported(Q), DQ_ERR_UNSUPPORTED,
+               "dq_qnet_td_backward_adam_env: only the fused chains carry the environment step");
+    EnvParams ep;
+    size_t lds = 0;
+    const dq_status rc = env_fill_act_step(env, sj->q_dev, sj->eps, sj->masked_greedy, sj->seed, sj->t, sj->action_dev, sj->auto_reset, sj->obs_dev,
+                                           sj->reward_dev, sj->done_dev, sj->legal_dev, sj->lifetime_dev, sj->was_reset_dev, sj->sample,
+                                           sj->stats_dev, &ep, &lds);
+    if (rc != DQ_OK) return rc;
+    return backward_adam(Q, params_dev, nullptr, td, grads_dev, m_dev, v_dev, lr, beta_1, beta_2, epsilon, t, stream, &ep, lds);
 }
 
 dq_status dq_qnet_td_backward_adam(dq_qnet* Q, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev, double lr,

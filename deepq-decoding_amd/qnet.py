@@ -43,6 +43,7 @@ class QNetwork:
         with torch.cuda.device(self.device):
             check(self.L.dq_qnet_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
+        self.fused_enabled = True
         self.n_params = int(self.L.dq_qnet_param_count(self._h))
         self.n_conv_params = int(self.L.dq_qnet_conv_param_count(self._h))     # flat layout: convolutions first, then the dense layers
         self.packed_bytes = int(self.L.dq_qnet_packed_bytes(self._h))          # 0 when the fused chains do not cover the architecture
@@ -58,6 +59,7 @@ class QNetwork:
         but runs the forward's convolutions through the experimental persistent wave pipeline (csrc/conv_pipe.hip: measured equal to
         conv_chain_kernel) -- A/B runs and its parity test."""
         check(self.L.dq_qnet_set_fused(self._h, (1 if enable else 0) | (2 if conv_pipe else 0)))
+        self.fused_enabled = bool(enable)
 
     @property
     def fused_supported(self):
@@ -225,6 +227,29 @@ def _td_backward_adam(self, params, td, grads, m, v, t, lr, beta_1=0.9, beta_2=0
     check(self.L.dq_qnet_td_backward_adam(self._h, ptr(params), ctypes.byref(j), ptr(grads), ptr(m), ptr(v), float(lr), float(beta_1),
                                           float(beta_2), float(epsilon), int(t), self._stream()))
     return grads
+
+
+def _td_backward_adam_env(self, params, td, grads, m, v, t, lr, beta_1, beta_2, epsilon, env_handle, step):
+    """td_backward_adam() with the SAME vector step's environment launch (dq_env_act_step(_sample) + its episode bookkeeping) riding on
+    the dense backward's first kernel (dq_qnet_td_backward_adam_env).  step: dict with q, eps, masked_greedy, seed, t, action,
+    auto_reset, obs, reward, done, legal, lifetime, was_reset and optional sample (a _lib.SampleJob), stats."""
+    j = _td_job(td)
+    assert j.n == 0, "the riding step does its own bookkeeping"
+    e = _lib.EnvStepJob()
+    e.q_dev, e.eps, e.masked_greedy = ptr(step["q"]), float(step["eps"]), int(step["masked_greedy"])
+    e.seed[0], e.seed[1] = int(step["seed"][0]) & 0xFFFFFFFF, int(step["seed"][1]) & 0xFFFFFFFF
+    e.t, e.action_dev, e.auto_reset = int(step["t"]), ptr(step["action"]), int(step.get("auto_reset", 1))
+    e.obs_dev, e.reward_dev, e.done_dev = ptr(step["obs"]), ptr(step["reward"]), ptr(step["done"])
+    e.legal_dev, e.lifetime_dev, e.was_reset_dev = ptr(step["legal"]), ptr(step["lifetime"]), ptr(step["was_reset"])
+    sj = step.get("sample")
+    e.sample = ctypes.pointer(sj) if sj is not None else None
+    e.stats_dev = ptr(step.get("stats"))
+    check(self.L.dq_qnet_td_backward_adam_env(self._h, ptr(params), ctypes.byref(j), ptr(grads), ptr(m), ptr(v), float(lr), float(beta_1),
+                                              float(beta_2), float(epsilon), int(t), env_handle, ctypes.byref(e), self._stream()))
+    return grads
+
+
+QNetwork.td_backward_adam_env = _td_backward_adam_env
 
 
 def _td_backward_phase0(self, params, td, grads):

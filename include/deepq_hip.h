@@ -304,6 +304,34 @@ typedef struct dq_td_job {
 } dq_td_job;
 dq_status dq_qnet_td_backward_adam(dq_qnet* net, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev,
                                    double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
+/* dq_env_act_step(_sample) of the SAME vector step riding on dq_qnet_td_backward_adam's first launch.  The update does not read what
+ * the step writes (its minibatch never holds the newest transition, dq_replay_sample's rule) and the step does not read what the
+ * update writes (it acts on q_dev, already computed), so the two are one launch: the lattices' blocks fill the idle issue slots of
+ * the dense backward chain instead of taking a launch of their own.  The step's episode bookkeeping (dq_episode_stats' sums into
+ * stats_dev, nullable) is done by the lattices' blocks themselves; td->n must be 0.  Same bits as the separate calls.  Fused chains
+ * only (DQ_ERR_UNSUPPORTED otherwise: make the separate calls).  Replaces, per vector step of the reference's loop,
+ * `action = policy.select_action(q)`, `env.step(action)`, `memory.append` and `DQNAgent.backward`
+ * (cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:138-152 -> keras-rl Agent.fit). */
+typedef struct dq_env_step_job {
+    const float* q_dev;             /* dq_env_act_step's arguments */
+    double eps;
+    int masked_greedy;
+    uint32_t seed[2];
+    uint64_t t;
+    int32_t* action_dev;
+    int auto_reset;
+    uint8_t* obs_dev;
+    float* reward_dev;
+    uint8_t* done_dev;
+    uint64_t* legal_dev;
+    uint32_t* lifetime_dev;
+    uint8_t* was_reset_dev;
+    const dq_sample_job* sample;    /* nullable: dq_env_act_step_sample's look-ahead draw */
+    uint64_t* stats_dev;            /* nullable: uint64 [4] accumulators of dq_episode_stats */
+} dq_env_step_job;
+dq_status dq_qnet_td_backward_adam_env(dq_qnet* net, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev,
+                                       double lr, double beta_1, double beta_2, double epsilon, uint64_t t, dq_env* env,
+                                       const dq_env_step_job* step, void* stream);
 /* The several-GPU form: the TD step + phase 0 of dq_qnet_backward_phase (dueling + dense layers) in one call; phase 1, the gradient
  * all-reduce and dq_adam_step follow as separate calls. */
 dq_status dq_qnet_td_backward_phase0(dq_qnet* net, const float* params_dev, const dq_td_job* td, float* grads_dev, void* stream);
