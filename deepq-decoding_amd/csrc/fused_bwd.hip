@@ -351,7 +351,16 @@ struct DenseWgradArgs {
     size_t pstride;
 };
 
-template <int TK>
+// One wave's tile on the bf16 matrix pipe at f32 accuracy (bf16x6, qnet.h).  The batch is the reduction index, so lane (kb, i)
+// supplies rows m + 8kb .. m + 8kb + 7 of its columns: eight loads per operand per 32 batch rows.  Each 16-column tile operand is
+// split ONCE into three bf16 pieces and used by every tile of the other operand: TK x 4 x 6 K = 32 MFMAs (1.5K pipe cycles at
+// TK = 4) per 32 rows instead of 8 x TK x 4 f32 K = 4 ones (4.1K).  Rows past the slice are clamped on load and zeroed in G only (a
+// zero factor kills the product; the bias sums need G anyway).
+//   VEC (K and N multiples of 4): column tiles INTERLEAVED -- k-tile ti, lane i is weight row kbase + 4i + ti and n-tile tj, lane j is
+//   column nbase + 4j + tj -- so a lane's four X values (and four G values) of a batch row are ONE dwordx4 load;
+//   otherwise: tile t, lane i is column base + 16t + i, scalar loads (clamped columns only reach accumulators that are never stored).
+// A block's raw rows are split into pieces first; the next block's loads then fly under the current block's MFMAs.
+template <int TK, bool VEC>
 __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int slice, int batch, int rows_per_wave, float* __restrict__ out,
                                            float* s_part, float* s_bias) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
@@ -359,155 +368,112 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
     const int kbase = kt * 16 * TK, nbase = nt * 64;
     const int K = L.K, N = L.N;
     const int m0 = (slice * WGRAD_WAVES + wave) * rows_per_wave, m1 = min(batch, m0 + rows_per_wave);
-    int kcol[TK], ncol[4];
-    bool kok[TK], nok[4];
+    static_assert(!VEC || TK == 4, "the interleaved layout takes four k-tiles");
+    int kcol[VEC ? 1 : TK], ncol[VEC ? 1 : 4];
+    if constexpr (VEC) {
+        kcol[0] = kbase + 4 * j < K ? kbase + 4 * j : 0;          // whole quads: K, N are multiples of 4
+        ncol[0] = nbase + 4 * j < N ? nbase + 4 * j : 0;
+    } else {
 #pragma unroll
-    for (int ti = 0; ti < TK; ++ti) { kcol[ti] = kbase + 16 * ti + j; kok[ti] = kcol[ti] < K; if (!kok[ti]) kcol[ti] = 0; }
+        for (int ti = 0; ti < TK; ++ti) kcol[ti] = kbase + 16 * ti + j < K ? kbase + 16 * ti + j : 0;
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj) { ncol[tj] = nbase + 16 * tj + j; nok[tj] = ncol[tj] < N; if (!nok[tj]) ncol[tj] = 0; }
-    float kmask[TK], nmask[4];
+        for (int tj = 0; tj < 4; ++tj) ncol[tj] = nbase + 16 * tj + j < N ? nbase + 16 * tj + j : 0;
+    }
+    float nmask[4];                                                 // scalar layout: the bias sums must not see a clamped column's values
 #pragma unroll
-    for (int ti = 0; ti < TK; ++ti) kmask[ti] = kok[ti] ? 1.f : 0.f;
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj) nmask[tj] = nok[tj] ? 1.f : 0.f;
+    for (int tj = 0; tj < 4; ++tj) nmask[tj] = (VEC || nbase + 16 * tj + j < N) ? 1.f : 0.f;
     f32x4 acc[TK][4];
 #pragma unroll
     for (int ti = 0; ti < TK; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    float xr[4][TK], gr4[4][4];                                     // ring of four 4-row steps, three in flight
-    // raw loads of clamped rows / columns into the ring; masks are applied when a step is consumed (see wgrad_tile_vec)
-    auto load = [&](int m, float (&xa)[TK], float (&gb)[4]) {
-        const int rc = min(m + kq, m1 - 1);
-        const float* xp = L.X + (size_t)rc * K;
-        const float* gp = L.G + (size_t)rc * N;
+    float xr[TK][8], gr[4][8];                                      // raw values [tile][row] of one 32-row block
+    auto load = [&](int m) {
 #pragma unroll
-        for (int ti = 0; ti < TK; ++ti) xa[ti] = xp[kcol[ti]];
+        for (int e = 0; e < 8; ++e) {
+            const int rc = min(m + 8 * kq + e, m1 - 1);
+            if constexpr (VEC) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(L.X + (size_t)rc * K + kcol[0]);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(L.G + (size_t)rc * N + ncol[0]);
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) gb[tj] = gp[ncol[tj]];
+                for (int t = 0; t < 4; ++t) { xr[t][e] = xv[t]; gr[t][e] = gv[t]; }
+            } else {
+                const float* xp = L.X + (size_t)rc * K;
+                const float* gp = L.G + (size_t)rc * N;
+#pragma unroll
+                for (int ti = 0; ti < TK; ++ti) xr[ti][e] = xp[kcol[ti]];
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) gr[tj][e] = gp[ncol[tj]];
+            }
+        }
     };
-    auto mma = [&](int m, const float (&xraw)[TK], const float (&graw)[4]) {
-        const float rm = m + kq < m1 ? 1.f : 0.f;
-        float xa[TK], gb[4];
-#pragma unroll
-        for (int ti = 0; ti < TK; ++ti) xa[ti] = xraw[ti] * rm;
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) gb[tj] = graw[tj] * (rm * nmask[tj]);          // (the bias sums see every column of the tile)
+    load(m0);
+    for (int m = m0; m < m1; m += 32) {
+        // split this block's raw rows into pieces (the raw registers are dead after that) ...
+        Bf16x3 xa[TK], gb[4];
 #pragma unroll
         for (int ti = 0; ti < TK; ++ti)
+            xa[ti] = split_bf16x3(f32x4{xr[ti][0], xr[ti][1], xr[ti][2], xr[ti][3]}, f32x4{xr[ti][4], xr[ti][5], xr[ti][6], xr[ti][7]});
+        const bool tail = m + 32 > m1;                              // wave-uniform
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = MFMA16(xa[ti], gb[tj], acc[ti][tj]);
+        for (int tj = 0; tj < 4; ++tj) {
+            float g[8];
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) bsum[tj] += gb[tj];
-    };
-    load(m0, xr[0], gr4[0]);
-    load(m0 + 4, xr[1], gr4[1]);
-    load(m0 + 8, xr[2], gr4[2]);
-    for (int m = m0; m < m1; m += 16) {
+            for (int e = 0; e < 8; ++e) g[e] = tail ? gr[tj][e] * (m + 8 * kq + e < m1 ? 1.f : 0.f) : gr[tj][e];
+            float bs = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            load(m + 4 * (u + 3), xr[(u + 3) & 3], gr4[(u + 3) & 3]);
-            __builtin_amdgcn_sched_barrier(0);                       // keep the request three steps ahead of its use: left alone, the
-            mma(m + 4 * u, xr[u], gr4[u]);                           // scheduler sinks the loads to just before the MFMAs that need them
-            __builtin_amdgcn_sched_barrier(0);
+            for (int e = 0; e < 8; ++e) bs += g[e];
+            bsum[tj] += VEC ? bs : bs * nmask[tj];
+            gb[tj] = split_bf16x3(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
         }
+        // ... request the next block's rows into them (past the slice: clamped rows, never multiplied) ...
+        __builtin_amdgcn_sched_barrier(0);
+        load(m + 32);
+        __builtin_amdgcn_sched_barrier(0);                           // (left alone, the scheduler sinks the loads to just before their use)
+        // ... and multiply: one accumulator per tile, 4 TK independent chains interleaved, six passes
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].h, gb[tj].h, c); }
+#pragma unroll
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].m, gb[tj].m, c); }
+#pragma unroll
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].h, gb[tj].m, c); }
+#pragma unroll
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].m, gb[tj].h, c); }
+#pragma unroll
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].h, gb[tj].l, c); }
+#pragma unroll
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].l, gb[tj].h, c); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- combine the workgroup's four slices in fixed order, write one partial ---------------------------------------
+    // ---- combine the workgroup's four slices in fixed order, write one partial.  C/D layout: this lane holds rows 4kq + r of each
+    //      16 x 16 tile; VEC: local weight row 4 (4kq + r) + ti, column 4j + tj; else row 16ti + 4kq + r, column 16tj + j ----------------
     float* sp = s_part + wave * (64 * 64);
 #pragma unroll
     for (int ti = 0; ti < TK; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (VEC) {
+                *reinterpret_cast<f32x4*>(sp + (4 * (4 * kq + r) + ti) * 64 + 4 * j) = f32x4{acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sp[(16 * ti + 4 * kq + r) * 64 + 16 * tj + j] = acc[ti][tj][r];
+                for (int tj = 0; tj < 4; ++tj) sp[(16 * ti + 4 * kq + r) * 64 + 16 * tj + j] = acc[ti][tj][r];
+            }
+        }
     if (kt == 0) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
             float v = bsum[tj];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (kq == 0) s_bias[wave * 64 + 16 * tj + j] = v;
+            if (kq == 0) s_bias[wave * 64 + (VEC ? 4 * j + tj : 16 * tj + j)] = v;
         }
     }
     __syncthreads();
     for (int e = tid; e < 16 * TK * 64; e += WGRAD_THREADS) {
-        const float v = (s_part[e] + s_part[4096 + e]) + (s_part[8192 + e] + s_part[12288 + e]);
-        const int kl = e >> 6, k = kbase + kl, n = nbase + (e & 63);
-        if (k < K && n < N) {
-            int row = k;
-            if (L.perm_hw > 0) { const int p = k / L.perm_c, c = k - p * L.perm_c; row = c * L.perm_hw + p; }
-            out[L.out_w + (size_t)row * N + n] = v;
-        }
-    }
-    if (kt == 0 && tid < 64 && nbase + tid < N)
-        out[L.out_b + nbase + tid] = (s_bias[tid] + s_bias[64 + tid]) + (s_bias[128 + tid] + s_bias[192 + tid]);
-}
-
-// The same tile with the column tiles INTERLEAVED: k-tile ti, lane i is weight row kbase + 4i + ti and n-tile tj, lane j is column
-// nbase + 4j + tj, so a lane's four X values (and four G values) of a batch row are four consecutive floats -- ONE dwordx4 load per
-// operand per 4-row step instead of seven dword loads whose 64-byte quarter-wave segments each cost a cache access (the scalar
-// variant above spends 54 % of its wave cycles waiting with the matrix pipe 37 % busy).  Needs K and N to be multiples of 4.
-__device__ __forceinline__ void wgrad_tile_vec(const WgradLayer& L, int local, int slice, int batch, int rows_per_wave, float* __restrict__ out,
-                                               float* s_part, float* s_bias) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
-    const int kt = local / L.n_tiles, nt = local - kt * L.n_tiles;
-    const int kbase = kt * 64, nbase = nt * 64;
-    const int K = L.K, N = L.N;
-    const int m0 = (slice * WGRAD_WAVES + wave) * rows_per_wave, m1 = min(batch, m0 + rows_per_wave);
-    const int kcol = kbase + 4 * j < K ? kbase + 4 * j : 0, ncol = nbase + 4 * j < N ? nbase + 4 * j : 0;      // whole quads: K, N are multiples of 4
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 xr[4], gr4[4];                                            // ring of four 4-row steps, three in flight
-    // The ring holds RAW loads of clamped rows / columns; rows past the slice are masked when a step is CONSUMED.  (Masking inside the
-    // load -- `x = p[i] * mask` -- makes hipcc wait for every load right where it is issued: the ring degenerates into "issue a
-    // batch, wait for all of it, then MFMA", which is how this kernel spent 54 % of its cycles waiting.)  Columns past K / N need no
-    // mask at all: they only reach accumulators that the epilogue never stores.
-    auto load = [&](int m, f32x4& xa, f32x4& gb) {
-        const int rc = min(m + kq, m1 - 1);
-        xa = *reinterpret_cast<const f32x4*>(L.X + (size_t)rc * K + kcol);
-        gb = *reinterpret_cast<const f32x4*>(L.G + (size_t)rc * N + ncol);
-    };
-    auto mma = [&](int m, const f32x4& xraw, const f32x4& graw) {
-        const float rm = m + kq < m1 ? 1.f : 0.f;
-        const f32x4 xa = xraw * rm, gb = graw * rm;
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = MFMA16(xa[ti], gb[tj], acc[ti][tj]);
-        bsum += gb;
-    };
-    load(m0, xr[0], gr4[0]);
-    load(m0 + 4, xr[1], gr4[1]);
-    load(m0 + 8, xr[2], gr4[2]);
-    for (int m = m0; m < m1; m += 16) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            load(m + 4 * (u + 3), xr[(u + 3) & 3], gr4[(u + 3) & 3]);
-            __builtin_amdgcn_sched_barrier(0);                       // keep the request three steps ahead of its use: left alone, the
-            mma(m + 4 * u, xr[u], gr4[u]);                           // scheduler sinks the loads to just before the MFMAs that need them
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // ---- combine the workgroup's four slices in fixed order, write one partial: local weight row 4 (4kq + r) + ti, column 4j + tj ----
-    float* sp = s_part + wave * (64 * 64);
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<f32x4*>(sp + (4 * (4 * kq + r) + ti) * 64 + 4 * j) = f32x4{acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
-    if (kt == 0) {
-        f32x4 v = bsum;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += __shfl_xor(v[e], 16); v[e] += __shfl_xor(v[e], 32); }
-        if (kq == 0) *reinterpret_cast<f32x4*>(s_bias + wave * 64 + 4 * j) = v;
-    }
-    __syncthreads();
-    for (int e = tid; e < 64 * 64; e += WGRAD_THREADS) {
         const float v = (s_part[e] + s_part[4096 + e]) + (s_part[8192 + e] + s_part[12288 + e]);
         const int k = kbase + (e >> 6), n = nbase + (e & 63);
         if (k < K && n < N) {
@@ -533,9 +499,9 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     int l = 0;
     while (l + 1 < a.n_layers && tile >= a.L[l + 1].tile0) ++l;     // block-uniform
     float* out = a.partial + (size_t)slice * a.pstride;
-    if (a.L[l].vec) wgrad_tile_vec(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
-    else if (a.L[l].TK == 3) wgrad_tile<3>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
-    else wgrad_tile<4>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
+    if (a.L[l].vec) wgrad_tile<4, true>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
+    else if (a.L[l].TK == 3) wgrad_tile<3, false>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
+    else wgrad_tile<4, false>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
 }
 
 // Fixed-order reduction of both partial sets in one launch: out[i] = sum_s partial[s * stride + i].
