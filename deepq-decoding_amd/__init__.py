@@ -29,6 +29,9 @@ def __getattr__(name):
     if name in ("dist", "hdf5_reader", "weights_io", "function_library", "runner"):
         import importlib
         return importlib.import_module("." + name, __name__)
+    if name == "FeedForwardReferee":
+        from .referee import FeedForwardReferee
+        return FeedForwardReferee
     if name == "DQNCore":
         from .core import DQNCore
         return DQNCore

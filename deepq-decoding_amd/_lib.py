@@ -86,6 +86,7 @@ SIGNATURES = {
     "dq_env_build_referee": (_i, [_vp, _vp]),
     "dq_env_build_referee_ml": (_i, [_vp, _dbl, _vp]),
     "dq_env_set_referee": (_i, [_vp, _vp, _vp]),
+    "dq_env_set_referee_joint": (_i, [_vp, _vp]),
     "dq_env_get_referee": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
     "dq_env_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

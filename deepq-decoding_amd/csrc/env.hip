@@ -34,6 +34,7 @@ struct dq_env {
     u64* d_state;
     u32 *d_lut_x, *d_lut_z;        // owned tables (dq_env_build_referee)
     const u32 *lut_x, *lut_z;      // tables in use
+    const u32* lut_joint;          // caller's joint table (dq_env_set_referee_joint), else NULL
     u32 ref_delta[2][64];          // BFS generators per component (x, z)
 };
 
@@ -340,6 +341,7 @@ dq_status dq_env_build_referee_ml(dq_env* E, double q_flip, void* stream) {
     if (rc != DQ_OK) return rc;
     E->lut_x = E->d_lut_x;
     E->lut_z = E->d_lut_z;
+    E->lut_joint = nullptr;
     return DQ_OK;
 }
 
@@ -352,6 +354,7 @@ dq_status dq_env_build_referee(dq_env* E, void* stream) {
     if (rc != DQ_OK) return rc;
     E->lut_x = E->d_lut_x;
     E->lut_z = E->d_lut_z;
+    E->lut_joint = nullptr;
     return DQ_OK;
 }
 
@@ -360,11 +363,22 @@ dq_status dq_env_set_referee(dq_env* E, const uint32_t* lut_x_dev, const uint32_
     DQ_REQUIRE(lut_z_dev || E->cfg.error_model == DQ_MODEL_X, DQ_ERR_INVALID, "dq_env_set_referee: the DP model needs a Z table");
     E->lut_x = lut_x_dev;
     E->lut_z = lut_z_dev ? lut_z_dev : lut_x_dev;
+    E->lut_joint = nullptr;
+    return DQ_OK;
+}
+
+dq_status dq_env_set_referee_joint(dq_env* E, const uint32_t* lut_dev) {
+    DQ_REQUIRE(E && lut_dev, DQ_ERR_INVALID, "dq_env_set_referee_joint: null argument");
+    DQ_REQUIRE(E->info.n_stab <= 24, DQ_ERR_UNSUPPORTED, "dq_env_set_referee_joint: a table over all %d stabilizers does not fit (d <= 5)",
+               E->info.n_stab);
+    E->lut_joint = lut_dev;
+    E->lut_x = E->lut_z = lut_dev;                                  // "a referee is installed"; the component tables are not read
     return DQ_OK;
 }
 
 dq_status dq_env_get_referee(dq_env* E, uint8_t* lut_x_host, uint8_t* lut_z_host, size_t entries) {
     DQ_REQUIRE(E && E->lut_x, DQ_ERR_STATE, "dq_env_get_referee: no referee installed");
+    DQ_REQUIRE(!E->lut_joint, DQ_ERR_STATE, "dq_env_get_referee: a joint table is installed (dq_env_set_referee_joint): it has no component tables");
     const size_t half = (size_t)1 << (E->info.n_stab / 2), words = (half + 31) / 32;
     DQ_REQUIRE(entries == half, DQ_ERR_INVALID, "dq_env_get_referee: expected %zu entries", half);
     u32* tmp = new (std::nothrow) u32[words];
@@ -383,7 +397,7 @@ dq_status dq_env_get_referee(dq_env* E, uint8_t* lut_x_host, uint8_t* lut_z_host
 
 static dq_status fill_common(dq_env* E, EnvParams& p, int epb) {
     DQ_REQUIRE(E->rates_set, DQ_ERR_STATE, "dq_env_set_rates has not been called");
-    p.tab = E->d_tab; p.state = E->d_state; p.lut_x = E->lut_x; p.lut_z = E->lut_z;
+    p.tab = E->d_tab; p.state = E->d_state; p.lut_x = E->lut_x; p.lut_z = E->lut_z; p.lut_joint = E->lut_joint;
     p.n_envs = E->cfg.n_envs; p.d2 = E->cfg.d * E->cfg.d; p.n_stab = E->info.n_stab; p.depth = E->cfg.volume_depth;
     p.layers = E->info.n_action_layers; p.n_actions = E->info.num_actions; p.identity = E->info.identity_index;
     p.model = E->cfg.error_model; p.use_Y = E->cfg.use_Y; p.sw = E->sw; p.P = E->P; p.C = E->info.obs_c;

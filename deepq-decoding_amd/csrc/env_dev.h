@@ -25,6 +25,7 @@ struct EnvParams {
     const EnvTables* tab;
     u64* state;
     const u32 *lut_x, *lut_z;
+    const u32* lut_joint;          // != NULL: ONE table over the whole syndrome word, 2 bits (class X + 2Z) per entry: any `.predict` referee
     int n_envs, d2, n_stab, depth, layers, n_actions, identity, model, use_Y, sw, P, C, obs_size;
     u32 env_id_base, seed0, seed1;
     u64 T_phys, T_meas;
@@ -168,8 +169,14 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
             const int cls = (__popcll(xmask & p.tab->col0) & 1) + 2 * (__popcll(zmask & p.tab->row0) & 1);  // ENV:143
             const u64 refw = __ballot(rsrc < 64 && ((true_word >> (rsrc & 63)) & 1));
             const u32 ix = (u32)refw, iz = (u32)(refw >> 32);
-            int dec = (p.lut_x[ix >> 5] >> (ix & 31)) & 1;                  // ENV:144
-            if (p.model != DQ_MODEL_X) dec += 2 * ((p.lut_z[iz >> 5] >> (iz & 31)) & 1);
+            int dec;
+            if (p.lut_joint) {                                              // an arbitrary static_decoder.predict, tabulated (ENV:144,150)
+                const u32 sw = (u32)true_word;                              // bit s = stabilizer s in measurement order (n_stab <= 24)
+                dec = (p.lut_joint[sw >> 4] >> (2 * (sw & 15))) & 3;
+            } else {
+                dec = (p.lut_x[ix >> 5] >> (ix & 31)) & 1;                  // ENV:144
+                if (p.model != DQ_MODEL_X) dec += 2 * ((p.lut_z[iz >> 5] >> (iz & 31)) & 1);
+            }
             dec = __builtin_amdgcn_readfirstlane(dec);
             if (cls == 0 && true_word == 0) reward = 1.f;                   // ENV:148-149
             else if (dec != cls) done = 1;                                  // ENV:150-151

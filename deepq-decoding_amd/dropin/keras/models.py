@@ -1,5 +1,5 @@
-"""`Sequential` that records layer descriptors and resolves to the GPU-backed model (ConvQModel) on first use; `load_model` only
-exists for the reference's static-decoder branch and refuses (the referee here is the built-in look-up table)."""
+"""`Sequential` that records layer descriptors and resolves to the GPU-backed model (ConvQModel) on first use; `load_model` exists
+for the reference's static-decoder branch: a Dense-stack weight file becomes a FeedForwardReferee."""
 from _bootstrap import package as _package
 
 from .layers import Activation, Conv2D, Dense, Dropout, Flatten
@@ -65,5 +65,11 @@ class Sequential:
 
 
 def load_model(path, *args, **kwargs):
-    raise NotImplementedError("Keras models cannot be loaded here; static_decoder=None selects the built-in look-up referee "
-                              "(set fixed_configs['static_decoder'] = False)")
+    """The reference loads its referee decoder with this (Single_Point_Training_Script.py:54-57).  A weight file holding a plain
+    Dense stack resolves to FeedForwardReferee (same .predict protocol; the environment tabulates it once, env.py
+    VectorEnv.set_referee_predict); anything else cannot be rebuilt without Keras."""
+    try:
+        return _package("referee").FeedForwardReferee.from_file(path)
+    except Exception as e:
+        raise NotImplementedError("Keras models cannot be rebuilt here (only a Dense-stack weight file resolves to a referee: %s); "
+                                  "static_decoder=None selects the built-in look-up referee" % (e,))

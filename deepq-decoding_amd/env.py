@@ -72,6 +72,8 @@ class VectorEnv:
             # maximum-likelihood table for independent component flips; default rate = one round's marginal flip probability
             q = float(referee[1]) if isinstance(referee, tuple) else (p_phys if error_model == "X" else 2.0 * p_phys / 3.0)
             self.build_ml_referee(q)
+        elif hasattr(referee, "predict"):
+            self.set_referee_predict(referee)
         elif referee is not None:
             self.set_referee(*referee)
 
@@ -123,6 +125,36 @@ class VectorEnv:
             return torch.from_numpy(bits.view(np.int32).copy()).to(self.device)
         self._lut = (pack(lut_x), None if lut_z is None else pack(lut_z))
         check(self.L.dq_env_set_referee(self._h, ptr(self._lut[0]), ptr(self._lut[1])))
+
+    def set_referee_predict(self, decoder, chunk=1 << 18):
+        """Install an arbitrary referee object with the reference's protocol -- ``decoder.predict(x[n, (d+1)**2], batch_size=..,
+        verbose=0) -> scores[n, n_classes]``, of which the environment only uses the argmax (ENV:144,150) -- by tabulating it ONCE over
+        all 2**n_stab syndromes (d <= 5: 16.8 M rows at d = 5, fed in chunks) into the kernel's joint look-up table
+        (dq_env_set_referee_joint).  Inside the step the referee then costs one table read, whatever the object computes."""
+        n = self.n_stab
+        if n > 24:
+            raise NotImplementedError("a .predict referee is tabulated over all syndromes: d <= 5 (use the built-in referees at d = 7)")
+        d = self.d
+        cells = np.array([a * (d + 1) + b for a, b in _measurement_order(d)], dtype=np.int64)     # stabilizer s -> cell of the (d+1)^2 vector
+        total = 1 << n
+        codes = np.zeros(total, dtype=np.uint8)
+        shifts = np.arange(n, dtype=np.uint32)
+        for lo in range(0, total, chunk):
+            idx = np.arange(lo, min(total, lo + chunk), dtype=np.uint32)
+            x = np.zeros((len(idx), (d + 1) ** 2), dtype=np.int64)
+            x[:, cells] = (idx[:, None] >> shifts[None, :]) & 1
+            try:
+                scores = decoder.predict(x, batch_size=len(idx), verbose=0)
+            except TypeError:
+                scores = decoder.predict(x)
+            codes[lo:lo + len(idx)] = np.argmax(np.asarray(scores), axis=1).astype(np.uint8)
+        if self.error_model == "X" and codes.max(initial=0) > 1:
+            raise ValueError("the bit-flip model has two homology classes; the referee predicted class %d" % codes.max())
+        pad = (-total) % 16
+        c = np.concatenate([codes, np.zeros(pad, np.uint8)]).astype(np.uint32).reshape(-1, 16)
+        words = (c << (2 * np.arange(16, dtype=np.uint32))[None, :]).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+        self._lut = (torch.from_numpy(words.view(np.int32).copy()).to(self.device), None)
+        check(self.L.dq_env_set_referee_joint(self._h, ptr(self._lut[0])))
 
     def get_referee(self):
         n = 1 << (self.n_stab // 2)
@@ -218,8 +250,8 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
       * randomness comes from the site-indexed Philox stream (``seed``, ``env_id``) instead of numpy's
         unseeded global generator;
       * ``static_decoder`` is the built-in minimum-weight look-up referee (None / "lut"), the maximum-likelihood one
-        ("ml" or ("ml", q_flip)), or a pair of
-        0/1 tables; arbitrary ``.predict`` objects cannot run inside the kernel and are rejected.
+        ("ml" or ("ml", q_flip)), a pair of 0/1 tables, or -- as in the reference -- any object with ``.predict`` (d <= 5): it is
+        tabulated once over all syndromes (VectorEnv.set_referee_predict), since only the argmax of its output is used (ENV:150).
     """
 
     def __init__(self, d=5, p_phys=0.01, p_meas=0.01, error_model="DP", use_Y=True, volume_depth=3, static_decoder=None,
@@ -230,9 +262,10 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
             referee = "ml"
         elif isinstance(static_decoder, (tuple, list)):
             referee = tuple(static_decoder)
+        elif hasattr(static_decoder, "predict"):
+            referee = static_decoder            # the reference's protocol (ENV:144): tabulated once over all syndromes (d <= 5)
         else:
-            raise NotImplementedError("static_decoder must be None/'lut' (built-in min-weight referee) or a (lut_x, lut_z) pair; "
-                                      "a Keras model cannot be evaluated inside the HIP kernel")
+            raise NotImplementedError("static_decoder must be None/'lut', 'ml', a (lut_x, lut_z) pair or an object with .predict")
         self._v = VectorEnv(d, p_phys, p_meas, error_model, use_Y, volume_depth, n_envs=1, seed=seed, env_id_base=env_id,
                             device=device, referee=referee)
         v = self._v

@@ -108,6 +108,12 @@ dq_status dq_env_build_referee_ml(dq_env* env, double q_flip, void* stream);
 /* ... or installs caller-provided bit-packed tables (device pointers, 2^((d*d-1)/2) bits each; must
  * stay alive while the handle uses them).  lut_z_dev may be NULL for DQ_MODEL_X. */
 dq_status dq_env_set_referee(dq_env* env, const uint32_t* lut_x_dev, const uint32_t* lut_z_dev);
+/* ... or ONE table over the whole syndrome: entry s (bit i of s = stabilizer i in generate_faulty_syndrome's draw order,
+ * Function_Library.py:189-221) holds the class the referee predicts, X + 2 Z (generate_one_hot_labels_surface_code's index,
+ * Function_Library.py:329-334), 2 bits per entry, 16 entries per word: 2^n_stab entries, n_stab <= 24 (d <= 5; 4 MB at d = 5).  This is
+ * how an arbitrary `static_decoder.predict` object (Environments.py:144,150 -- only argmax of its output is used) runs inside the
+ * kernel: the host tabulates it once (deepq-decoding_amd/env.py VectorEnv.set_referee_predict).  Device pointer, caller-owned. */
+dq_status dq_env_set_referee_joint(dq_env* env, const uint32_t* lut_dev);
 /* Copies the referee tables to host memory as one byte per entry (tests). Synchronises. */
 dq_status dq_env_get_referee(dq_env* env, uint8_t* lut_x_host, uint8_t* lut_z_host, size_t entries);
 

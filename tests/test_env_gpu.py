@@ -415,3 +415,87 @@ def test_maximum_likelihood_referee_on_the_gpu(dq, torch_mod, d, q):
         ref.step(a.cpu().numpy(), auto_reset=True)
         assert np.array_equal(env.done.cpu().numpy(), ref.done) and np.array_equal(env.reward.cpu().numpy(), ref.reward)
         assert np.array_equal(env.obs.cpu().numpy(), ref.obs)
+
+
+class _TablePredictor:
+    """A referee with the reference's .predict protocol (ENV:144) built from component tables, vectorised so that the product's
+    tabulation over all 2^24 syndromes of d = 5 takes seconds.  Uses only oracle/ code for the cell / bit conventions."""
+
+    def __init__(self, d, error_model, lut_x, lut_z):
+        from oracle import lattice
+        self.d, self.model = d, error_model
+        m = lattice.Masks(d)
+        n_cells = (d + 1) ** 2
+        self.cell_bit = np.full(n_cells, -1, dtype=np.int64)       # cell of the (d+1)^2 vector -> bit of the syndrome word
+        for c in range(n_cells):
+            g = np.zeros(n_cells, dtype=np.int64); g[c] = 1
+            w = m.grid_to_word(g.reshape(d + 1, d + 1))
+            if w:
+                self.cell_bit[c] = int(w).bit_length() - 1
+        n_stab = int((self.cell_bit >= 0).sum())
+        self.sel = {}
+        for typ in (3, 1):                                          # referee-index bit i of a component <- syndrome-word bit sel[i]
+            pos = {}
+            for s in range(n_stab):
+                idx = m.referee_index(1 << s, typ)
+                if idx:
+                    pos[int(idx).bit_length() - 1] = s
+            self.sel[typ] = np.array([pos[i] for i in range(len(pos))], dtype=np.int64)
+        self.lut = {3: np.asarray(lut_x, np.uint8), 1: np.asarray(lut_z, np.uint8)}
+        self.n_stab = n_stab
+
+    def predict(self, x, batch_size=1, verbose=0):
+        x = np.asarray(x)
+        cells = np.nonzero(self.cell_bit >= 0)[0]
+        bits = np.zeros((len(x), self.n_stab), dtype=np.int64)
+        bits[:, self.cell_bit[cells]] = x[:, cells]
+        cls = np.zeros(len(x), dtype=np.int64)
+        for typ, mult in ((3, 1), (1, 2)):
+            if self.model == "X" and typ == 1:
+                continue
+            idx = (bits[:, self.sel[typ]] << np.arange(len(self.sel[typ]))[None, :]).sum(axis=1)
+            cls += mult * self.lut[typ][idx]
+        out = np.zeros((len(x), 2 if self.model == "X" else 4), dtype=np.float32)
+        out[np.arange(len(x)), cls] = 1.0
+        return out
+
+
+@pytest.mark.parametrize("d,model", [(3, "X"), (3, "DP"), (5, "DP")])
+def test_arbitrary_predict_referee_runs_as_a_joint_table(dq, torch_mod, d, model):
+    """static_decoder with the reference's .predict protocol (ENV:53,144): the environment tabulates it once over all syndromes
+    (VectorEnv.set_referee_predict -> dq_env_set_referee_joint).  (1) The min-weight tables wrapped as a .predict object reproduce the
+    built-in referee's trajectories bit for bit.  (2) RANDOM component tables wrapped the same way reproduce the C oracle run with
+    those tables: the joint table carries any function of the syndrome, not just a decoder-shaped one."""
+    torch = torch_mod
+    from oracle import c_oracle, referee as oref
+    cfg = dict(d=d, error_model=model, use_Y=False, volume_depth=d, p_phys=0.02, p_meas=0.02)
+    n = 64
+    n_tab = 1 << ((d * d - 1) // 2)
+    rng = np.random.RandomState(17)
+    for kind in ("min-weight", "random"):
+        if kind == "min-weight":
+            lx, lz = c_oracle.luts(d)
+        else:
+            lx, lz = (rng.rand(n_tab) < 0.5).astype(np.uint8), (rng.rand(n_tab) < 0.5).astype(np.uint8)
+        pred = oref.LutReferee(d, model, lx, lz) if d == 3 else _TablePredictor(d, model, lx, lz)      # (the oracle's own .predict loops in Python)
+        env = dq.VectorEnv(n_envs=n, referee=pred, **cfg)
+        ref = c_oracle.COracleEnv(n_envs=n, lut=(lx, lz), **cfg)
+        env.reset(); ref.reset()
+        ended = 0
+        for t in range(60):
+            a = env.select_actions(t)
+            assert np.array_equal(a.cpu().numpy(), ref.policy_uniform_legal(t))
+            env.step(a, auto_reset=True)
+            ref.step(a.cpu().numpy(), auto_reset=True)
+            assert np.array_equal(env.obs.cpu().numpy(), ref.obs) and np.array_equal(env.reward.cpu().numpy(), ref.reward), (kind, t)
+            assert np.array_equal(env.done.cpu().numpy(), ref.done), (kind, t)
+            ended += int(ref.done.sum())
+        assert ended > 0                                            # the referee's verdict mattered
+    single = dq.Surface_Code_Environment_Multi_Decoding_Cycles(d=d, error_model=model, use_Y=False, volume_depth=d, p_phys=0.02, p_meas=0.02,
+                                                               static_decoder=pred)
+    obs = single.reset()
+    obs, r, done, _ = single.step(single.identity_index)
+    assert obs.shape == single.observation_space.shape
+    if d == 5:                                                      # (48 stabilizers at d = 7: no table)
+        with pytest.raises(NotImplementedError):
+            dq.VectorEnv(n_envs=1, d=7, error_model="DP", use_Y=False, volume_depth=3, referee=pred)

@@ -350,3 +350,37 @@ def test_grid_files_follow_the_reference_schema(tmp_path):
     assert pickle.load(open(os.path.join(new[0], "variable_config_1.p"), "rb"))["p_phys"] == 0.003
     assert open(os.path.join(fam, "results", "best_results_from_0.001.txt")).read() == "5: 1700.0\n"
     assert open(os.path.join(fam, "results", "results_from_0.001.txt")).read().splitlines()[1] == "2: 1200.0"
+
+
+def test_feed_forward_referee_from_a_keras_weight_file(tmp_path):
+    """The reference's static decoder is a Keras feed-forward classifier loaded with load_model (TRAIN:54-57) and used through
+    .predict (ENV:144).  FeedForwardReferee rebuilds a Dense stack from a Keras save_weights file (HDF5 written / read by the package's
+    own codecs, or .npz) and answers .predict with softmax scores; the drop-in keras.models.load_model resolves to it."""
+    ref_mod = importlib.import_module("deepq-decoding_amd.referee")
+    wio = importlib.import_module("deepq-decoding_amd.weights_io")
+    rng = np.random.RandomState(3)
+    sizes = [36, 48, 20, 4]
+    weights = []
+    for a, b in zip(sizes, sizes[1:]):
+        weights += [rng.randn(a, b).astype(np.float32) * 0.3, rng.randn(b).astype(np.float32) * 0.1]
+    x = (rng.rand(50, 36) < 0.2).astype(np.int64)
+    h = x.astype(np.float64)
+    for i in range(0, len(weights), 2):
+        h = h @ weights[i].astype(np.float64) + weights[i + 1]
+        if i + 2 < len(weights):
+            h = np.maximum(h, 0)
+    want = np.exp(h - h.max(1, keepdims=True)); want /= want.sum(1, keepdims=True)
+    for ext in ("h5f", "npz"):
+        path = str(tmp_path / f"referee.{ext}")
+        wio.save_weights_file(path, weights, ["dense_1", "dense_2", "dense_3"], dueling=False)
+        r = ref_mod.FeedForwardReferee.from_file(path)
+        assert (r.n_inputs, r.n_classes) == (36, 4)
+        got = r.predict(x, batch_size=1, verbose=0)
+        assert got.shape == (50, 4) and np.abs(got - want).max() < 1e-5 and np.allclose(got.sum(1), 1, atol=1e-5)
+    # through the reference-named module tree
+    dropin = os.path.join(ROOT, "deepq-decoding_amd", "dropin")
+    code = ("import sys; sys.path.insert(0, %r); from keras.models import load_model; import numpy as np; "
+            "m = load_model(%r); print(m.predict(np.zeros((1, 36)), batch_size=1, verbose=0).shape)") % (dropin, str(tmp_path / "referee.h5f"))
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0 and "(1, 4)" in out.stdout, out.stderr
