@@ -227,11 +227,13 @@ class DQNCore:
         self._metrics_stale = True
         return self.grads
 
-    def _learn(self, t):
-        """TD step, backward, optimizer step, repack -- everything of an update behind its forwards."""
+    def _learn(self, t, ride=None):
+        """TD step, backward, optimizer step, repack -- everything of an update behind its forwards.  ride: the vector step's
+        environment launch (qnet._env_step_job dict) to be carried by the dense backward's first kernel."""
         B, N, net = self.batch_size, self.N, self.net
         step_stats = None
         if self._stats_pending is not None:          # the pending episode bookkeeping rides on the TD launch
+            assert ride is None
             (slot,), env = self._stats_pending, self.env
             step_stats = (self.terminal_ring[slot], env.was_reset, env.lifetime, self.reward_ring[slot], N, self.stats)
             self._stats_pending = None
@@ -240,13 +242,19 @@ class DQNCore:
         if self.world_size > 1:
             # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs
             nconv = net.n_conv_params
-            net.td_backward_phase0(self.params, td, self.grads)           # TD step + dueling + dense layers
+            if ride is not None:
+                net.td_backward_phase0_env(self.params, td, self.grads, self.env._h, ride)
+            else:
+                net.td_backward_phase0(self.params, td, self.grads)       # TD step + dueling + dense layers
             work = _dist.allreduce_sum_async(self.grads[nconv:], group=self.pg)
             net.backward_phase(self.params, self.dq, self.grads, 1)
             _dist.allreduce_sum_(self.grads[:nconv], group=self.pg)
             if work is not None:
                 work.wait()
             _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+        elif ride is not None:
+            net.td_backward_adam_env(self.params, td, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon,
+                                     self.env._h, ride)
         else:
             # TD step in the backward's first launch, Adam on its last
             net.td_backward_adam(self.params, td, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
@@ -279,9 +287,9 @@ class DQNCore:
         if presample_next:
             nxt2 = nxt + 1 if nxt + 1 < T else 0
             sj = self._sample_job(t + 1, nxt2, min(T, filled + 1))
-        if self.ride_env and self.world_size == 1 and self._env_stream is None and self.net.fused_supported and self.net.fused_enabled:
-            # one launch fewer and ~15 us less per step: the environment step (+ look-ahead sampling + this step's episode bookkeeping)
-            # rides on the dense backward's first kernel (dq_qnet_td_backward_adam_env): neither needs the other's results
+        if self.ride_env and self._env_stream is None and self.net.fused_supported and self.net.fused_enabled:
+            # one launch fewer per step: the environment step (+ look-ahead sampling + this step's episode bookkeeping) rides on the
+            # dense backward's first kernel (dq_qnet_td_backward_adam_env / _phase0_env): neither needs the other's results
             step = dict(q=self.q_act, eps=eps, masked_greedy=masked_greedy, seed=env.seed, t=self.vector_steps, action=self.action_ring[cur],
                         auto_reset=1, obs=self.obs_ring[nxt], reward=self.reward_ring[cur], done=self.terminal_ring[cur], legal=env.legal,
                         lifetime=env.lifetime, was_reset=env.was_reset, sample=sj, stats=self.stats if record_stats else None)
@@ -289,10 +297,7 @@ class DQNCore:
             self.cur, self.filled = nxt, filled
             self.vector_steps += 1
             self.updates = t
-            self._metrics_stale = True
-            self.net.td_backward_adam_env(self.params, self._td_job(None), self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2,
-                                          self.epsilon, env._h, step)
-            self.repack()
+            self._learn(t, ride=step)
             return
         if self._env_stream is not None:
             main = torch.cuda.current_stream(self.device)

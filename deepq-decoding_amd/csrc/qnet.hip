@@ -659,32 +659,50 @@ dq_status dq_qnet_backward_adam(dq_qnet* Q, float* params_dev, const float* dq_d
     return backward_adam(Q, params_dev, dq_dev, nullptr, grads_dev, m_dev, v_dev, lr, beta_1, beta_2, epsilon, t, stream);
 }
 
-dq_status dq_qnet_td_backward_phase0(dq_qnet* Q, const float* params_dev, const dq_td_job* tdj, float* grads_dev, void* stream) {
+static dq_status fill_rider(dq_qnet* Q, const dq_td_job* td, dq_env* env, const dq_env_step_job* sj, EnvParams* ep, size_t* lds) {
+    DQ_REQUIRE(td && env && sj, DQ_ERR_INVALID, "dq_qnet_td_backward_*_env: null argument");
+    DQ_REQUIRE(td->n == 0, DQ_ERR_INVALID, "dq_qnet_td_backward_*_env: the step does its own bookkeeping (td->n must be 0)");
+    DQ_REQUIRE(Q && Q->use_fused && fused_backward_supported(Q), DQ_ERR_UNSUPPORTED,
+               "dq_qnet_td_backward_*_env: only the fused chains carry the environment step");
+    return env_fill_act_step(env, sj->q_dev, sj->eps, sj->masked_greedy, sj->seed, sj->t, sj->action_dev, sj->auto_reset, sj->obs_dev,
+                             sj->reward_dev, sj->done_dev, sj->legal_dev, sj->lifetime_dev, sj->was_reset_dev, sj->sample, sj->stats_dev, ep, lds);
+}
+
+static dq_status td_backward_phase0(dq_qnet* Q, const float* params_dev, const dq_td_job* tdj, float* grads_dev, void* stream,
+                                    const EnvParams* rider, size_t rider_lds) {
     DQ_REQUIRE(Q && params_dev && tdj && grads_dev, DQ_ERR_INVALID, "dq_qnet_td_backward_phase0: null argument");
     DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_td_backward_phase0: no training forward to differentiate");
     dq_status rc = check_td_job(Q, tdj);
     if (rc != DQ_OK) return rc;
     if (Q->use_fused && fused_backward_supported(Q)) {
         const TdFused td = td_fused_from(tdj);
-        return fused_backward(Q, params_dev, nullptr, grads_dev, 1, (hipStream_t)stream, nullptr, &td);
+        return fused_backward(Q, params_dev, nullptr, grads_dev, 1, (hipStream_t)stream, nullptr, &td, rider, rider_lds);
     }
+    DQ_REQUIRE(!rider, DQ_ERR_UNSUPPORTED, "dq_qnet_td_backward_phase0_env: only the fused chains carry the environment step");
     rc = separate_td(tdj, stream);
     if (rc != DQ_OK) return rc;
     return backward_phases(Q, params_dev, tdj->dq_dev, grads_dev, 1, (hipStream_t)stream);
 }
 
+dq_status dq_qnet_td_backward_phase0(dq_qnet* Q, const float* params_dev, const dq_td_job* tdj, float* grads_dev, void* stream) {
+    return td_backward_phase0(Q, params_dev, tdj, grads_dev, stream, nullptr, 0);
+}
+
+dq_status dq_qnet_td_backward_phase0_env(dq_qnet* Q, const float* params_dev, const dq_td_job* td, float* grads_dev, dq_env* env,
+                                         const dq_env_step_job* sj, void* stream) {
+    EnvParams ep;
+    size_t lds = 0;
+    const dq_status rc = fill_rider(Q, td, env, sj, &ep, &lds);
+    if (rc != DQ_OK) return rc;
+    return td_backward_phase0(Q, params_dev, td, grads_dev, stream, &ep, lds);
+}
+
 dq_status dq_qnet_td_backward_adam_env(dq_qnet* Q, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev,
                                        double lr, double beta_1, double beta_2, double epsilon, uint64_t t, dq_env* env,
                                        const dq_env_step_job* sj, void* stream) {
-    DQ_REQUIRE(td && env && sj, DQ_ERR_INVALID, "dq_qnet_td_backward_adam_env: null argument");
-    DQ_REQUIRE(td->n == 0, DQ_ERR_INVALID, "dq_qnet_td_backward_adam_env: the step does its own bookkeeping (td->n must be 0)");
-    DQ_REQUIRE(Q && Q->use_fused && fused_backward_supported(Q), DQ_ERR_UNSUPPORTED,
-               "dq_qnet_td_backward_adam_env: only the fused chains carry the environment step");
     EnvParams ep;
     size_t lds = 0;
-    const dq_status rc = env_fill_act_step(env, sj->q_dev, sj->eps, sj->masked_greedy, sj->seed, sj->t, sj->action_dev, sj->auto_reset, sj->obs_dev,
-                                           sj->reward_dev, sj->done_dev, sj->legal_dev, sj->lifetime_dev, sj->was_reset_dev, sj->sample,
-                                           sj->stats_dev, &ep, &lds);
+    const dq_status rc = fill_rider(Q, td, env, sj, &ep, &lds);
     if (rc != DQ_OK) return rc;
     return backward_adam(Q, params_dev, nullptr, td, grads_dev, m_dev, v_dev, lr, beta_1, beta_2, epsilon, t, stream, &ep, lds);
 }

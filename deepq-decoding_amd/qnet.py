@@ -229,12 +229,9 @@ def _td_backward_adam(self, params, td, grads, m, v, t, lr, beta_1=0.9, beta_2=0
     return grads
 
 
-def _td_backward_adam_env(self, params, td, grads, m, v, t, lr, beta_1, beta_2, epsilon, env_handle, step):
-    """td_backward_adam() with the SAME vector step's environment launch (dq_env_act_step(_sample) + its episode bookkeeping) riding on
-    the dense backward's first kernel (dq_qnet_td_backward_adam_env).  step: dict with q, eps, masked_greedy, seed, t, action,
-    auto_reset, obs, reward, done, legal, lifetime, was_reset and optional sample (a _lib.SampleJob), stats."""
-    j = _td_job(td)
-    assert j.n == 0, "the riding step does its own bookkeeping"
+def _env_step_job(step):
+    """dq_env_step_job from a dict with q, eps, masked_greedy, seed, t, action, auto_reset, obs, reward, done, legal, lifetime, was_reset
+    and optional sample (a _lib.SampleJob), stats."""
     e = _lib.EnvStepJob()
     e.q_dev, e.eps, e.masked_greedy = ptr(step["q"]), float(step["eps"]), int(step["masked_greedy"])
     e.seed[0], e.seed[1] = int(step["seed"][0]) & 0xFFFFFFFF, int(step["seed"][1]) & 0xFFFFFFFF
@@ -244,11 +241,30 @@ def _td_backward_adam_env(self, params, td, grads, m, v, t, lr, beta_1, beta_2, 
     sj = step.get("sample")
     e.sample = ctypes.pointer(sj) if sj is not None else None
     e.stats_dev = ptr(step.get("stats"))
+    return e
+
+
+def _td_backward_adam_env(self, params, td, grads, m, v, t, lr, beta_1, beta_2, epsilon, env_handle, step):
+    """td_backward_adam() with the SAME vector step's environment launch (dq_env_act_step(_sample) + its episode bookkeeping) riding on
+    the dense backward's first kernel (dq_qnet_td_backward_adam_env).  step: see _env_step_job."""
+    j = _td_job(td)
+    assert j.n == 0, "the riding step does its own bookkeeping"
+    e = _env_step_job(step)
     check(self.L.dq_qnet_td_backward_adam_env(self._h, ptr(params), ctypes.byref(j), ptr(grads), ptr(m), ptr(v), float(lr), float(beta_1),
                                               float(beta_2), float(epsilon), int(t), env_handle, ctypes.byref(e), self._stream()))
     return grads
 
 
+def _td_backward_phase0_env(self, params, td, grads, env_handle, step):
+    """The several-GPU form of td_backward_adam_env: td_backward_phase0() carrying the environment step."""
+    j = _td_job(td)
+    assert j.n == 0, "the riding step does its own bookkeeping"
+    e = _env_step_job(step)
+    check(self.L.dq_qnet_td_backward_phase0_env(self._h, ptr(params), ctypes.byref(j), ptr(grads), env_handle, ctypes.byref(e), self._stream()))
+    return grads
+
+
+QNetwork.td_backward_phase0_env = _td_backward_phase0_env
 QNetwork.td_backward_adam_env = _td_backward_adam_env
 
 

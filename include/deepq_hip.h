@@ -341,6 +341,9 @@ dq_status dq_qnet_td_backward_adam_env(dq_qnet* net, float* params_dev, const dq
 /* The several-GPU form: the TD step + phase 0 of dq_qnet_backward_phase (dueling + dense layers) in one call; phase 1, the gradient
  * all-reduce and dq_adam_step follow as separate calls. */
 dq_status dq_qnet_td_backward_phase0(dq_qnet* net, const float* params_dev, const dq_td_job* td, float* grads_dev, void* stream);
+/* ... with the vector step's environment launch riding on it (as dq_qnet_td_backward_adam_env). */
+dq_status dq_qnet_td_backward_phase0_env(dq_qnet* net, const float* params_dev, const dq_td_job* td, float* grads_dev, dq_env* env,
+                                         const dq_env_step_job* step, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DQN update: replaces SequentialMemory.sample + DQNAgent.backward + keras Adam of the keras-rl fork
