@@ -200,7 +200,9 @@ dq_status dq_policy_select(const float* q_dev, const uint64_t* legal_dev, int n,
  *   -> (dueling) Dense(n_actions+1), Q = y0 + y[1:] - mean(y[1:]).
  * Parameters live in ONE flat float buffer owned by the caller, in Keras order and Keras shapes (conv
  * kernels HWIO, dense (in,out)), each layer kernel then bias -- the tensors of a Keras .h5f drop in as is.
- * fp32 MFMA throughout (the reference is fp32 and the parity bound is 1e-5).
+ * f32 results throughout (the reference is fp32 and the parity bound is 1e-5).  The per-layer path multiplies on the f32-input MFMA;
+ * the fused chains issue every f32 product on the bf16 matrix pipe as an exact three-way split of both operands (six bf16 MFMAs with
+ * f32 accumulation, three where an operand is binary): same accuracy class, different summation order (csrc/qnet.h "bf16x6").
  * ------------------------------------------------------------------------------------------- */
 typedef struct dq_qnet dq_qnet;
 
