@@ -103,6 +103,7 @@ SIGNATURES = {
     "dq_qnet_layer_info": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                 ctypes.POINTER(ctypes.c_int32 * 4), ctypes.POINTER(ctypes.c_int32)]),
     "dq_qnet_set_fused": (_i, [_vp, _i]),
+    "dq_qnet_set_grad_scale": (_i, [_vp, _dbl]),
     "dq_qnet_fused_supported": (_i, [_vp]),
     "dq_qnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
     "dq_qnet_forward_multi": (_i, [_vp, _i, ctypes.POINTER(QNetJob), _vp]),

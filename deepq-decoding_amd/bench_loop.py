@@ -14,7 +14,7 @@ from .qnet import QNetwork
 C_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]]
 FF_LAYERS = [[512, 0.2]]
 MFMA_F32_PEAK_TFLOPS = 157.3
-MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 (MI355X_MICROARCH.md); the fused chains issue 3 (binary operand) or 6 bf16 MFMAs per f32 product
+MFMA_F16_PEAK_TFLOPS = 2500.0        # dense f16 / bf16 (MI355X_MICROARCH.md); the fused chains issue 2 (binary operand) or 3 f16 MFMAs per f32 product
 HBM_PEAK_GBS = 8000.0
 
 
@@ -51,8 +51,8 @@ def pmc_traffic(kernel, mode="loop", config="c3"):
 
 
 class FullLoop:
-    # f32 results (1e-5 against the float64 oracle); the hot products are issued on the bf16 matrix pipe as exact 3-way splits
-    dtype = "f32 (operands split exactly into 3 bf16 pieces, 3 or 6 bf16 MFMAs per product, f32 accumulate)"
+    # f32 results (1e-5 against the float64 oracle); the hot products are issued on the f16 matrix pipe, each operand as two f16 pieces
+    dtype = "f32 (operands as 2 f16 pieces = 22 significant bits, 2 or 3 f16 MFMAs per product, f32 accumulate)"
 
     def __init__(self, dq, cfg, n_local, rank, world, minibatch, eps=0.1, replay_transitions=1 << 20, lr=1e-4,
                  target_every=32, mode="loop", config_name="c3"):
@@ -114,13 +114,13 @@ class FullLoop:
             "gemm_wgrad_kernel": (len(lm), 2.0 * self.macs * self.B, "mfma"),
         }
 
-    def bf16_pipe_factor(self):
-        """family -> bf16 MFMA flops issued per algorithmic f32 flop (work-weighted) for the kernels that run on the bf16 pipe."""
+    def f16_pipe_factor(self):
+        """family -> f16 MFMA flops issued per algorithmic f32 flop (work-weighted) for the kernels that run on the f16 pipe."""
         nc, lm = len(C_LAYERS), self.layer_macs
         if not self.net.fused_supported:
             return {}
         conv = sum(lm[:nc])
-        return {"conv_chain_kernel": (3.0 * lm[0] + 6.0 * sum(lm[1:nc])) / conv}      # conv1's operand is binary: 3 pieces suffice
+        return {"conv_chain_kernel": (2.0 * lm[0] + 3.0 * sum(lm[1:nc])) / conv}      # conv1's operand is binary: the weight's 2 pieces suffice
 
     def _family_id(self, name):
         for i in range(self.L.dq_prof_kernel_count()):
@@ -185,14 +185,17 @@ class FullLoop:
                 avg_s = ms * 1e-3 / launches
                 per_launch = work / per_step
                 achieved = per_launch / avg_s / 1e12
-                roof = dict(kernel=self.prof_family, bound=bound, achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=pmc_traffic(self.prof_family, self.mode, self.config_name), avg_launch_us=avg_s * 1e6,
+                issued = self.f16_pipe_factor().get(self.prof_family)
+                # the peak is that of the pipe the kernel runs on: f32-class products cost `issued` f16 MFMA flops each, so the f16
+                # pipe's dense peak divided by that (frac = issued f16 flops / f16 peak); the f32-input MFMA peak is quoted beside it
+                peak = MFMA_F16_PEAK_TFLOPS / issued if issued else MFMA_F32_PEAK_TFLOPS
+                roof = dict(kernel=self.prof_family, bound=bound, achieved=achieved, peak=peak, unit="TFLOP/s",
+                            frac=achieved / peak, traffic=pmc_traffic(self.prof_family, self.mode, self.config_name), avg_launch_us=avg_s * 1e6,
                             launches_timed=launches, algorithmic_flops_per_launch=per_launch)
-                issued = self.bf16_pipe_factor().get(self.prof_family)
                 if issued:
-                    # the same launch seen from the pipe it actually runs on: f32-accurate products issued as bf16 MFMAs
-                    roof["bf16_pipe"] = dict(issued_tflops=achieved * issued, peak=MFMA_BF16_PEAK_TFLOPS,
-                                             frac=achieved * issued / MFMA_BF16_PEAK_TFLOPS, mfmas_per_f32_product=issued)
+                    roof["pipe"] = dict(name="f16 MFMA (v_mfma_f32_16x16x32_f16)", peak=MFMA_F16_PEAK_TFLOPS, issued_tflops=achieved * issued,
+                                        mfmas_per_f32_product=issued)
+                    roof["vs_f32_mfma_peak"] = dict(peak=MFMA_F32_PEAK_TFLOPS, ratio=achieved / MFMA_F32_PEAK_TFLOPS)
         out = {
             "roofline": roof,
             "dqn_updates_per_s": 0.0 if self.mode == "act" else steps / dt,

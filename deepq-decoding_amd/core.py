@@ -55,7 +55,7 @@ class DQNCore:
         self.params = net.init_params(self.seed) if params is None else params
         _dist.broadcast_(self.params, src=0, group=self.pg)
         self.target = self.params.clone()
-        # bf16 pieces of the conv kernels for the fused chains: packed once per parameter change (repack()), shared by every forward
+        # f16 pieces of the weights for the fused chains: packed once per parameter change (repack()), shared by every forward
         self.params_pk = net.pack(self.params)
         self.target_pk = None if self.params_pk is None else self.params_pk.clone()
         self.m = torch.zeros_like(self.params)

@@ -44,35 +44,35 @@ struct ConvChainArgs {
     int off_mis, off_a1, off_a2;       // LDS byte offsets (observations at 0)
 };
 
-// One stride-1 convolution whose input is an LDS image [pixel][CIN + 4] (f32), on the bf16 matrix pipe at f32 accuracy (bf16x6,
+// One stride-1 convolution whose input is an LDS image [pixel][CIN + 4] (f32), on the f16 matrix pipe at f32-class accuracy (f16x2,
 // qnet.h).  K = KS*KS*CIN is walked in blocks of 32 channels of one tap: A = 8 consecutive channels per lane (two ds_read_b128),
-// split into bf16 pieces on the fly; B = the block's weights as pieces in registers, HALF of K at a time (96 VGPRs).  Each wave
-// takes pairs of 16-row tiles x both column tiles (column tile t, lane j = column 2j + t), two accumulator chains per tile.
+// split into f16 pieces on the fly; B = the block's weights as pieces, streamed through a register ring.  Each wave takes pairs of
+// 16-row tiles x both column tiles (column tile t, lane j = column 2j + t), two accumulators per tile (leading / scaled cross terms).
 template <int CIN, int COUT, int KS>
 struct ConvShape {
     static constexpr int NT = COUT / 16, CB = CIN / 32, NB = KS * KS * CB, R = NB < 4 ? NB : 4;     // R: K = 32 weight blocks in flight
 };
 
-// One K = 32 block of packed weights (qnet.h) for this lane: NT column tiles x 3 bf16 pieces, one coalesced 16-byte load each.
+// One K = 32 block of packed weights (qnet.h) for this lane: NT column tiles x 2 f16 pieces, one coalesced 16-byte load each.
 template <int NT>
-__device__ __forceinline__ void conv_w_load(Bf16x3 (&slot)[NT], const u32x4* __restrict__ pk, int blk, int lane) {
+__device__ __forceinline__ void conv_w_load(F16x2 (&slot)[NT], const u32x4* __restrict__ pk, int blk, int lane) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const u32x4* pb = pk + (blk * NT + t) * PK_BLOCK + lane;
-        slot[t].h = pb[0]; slot[t].m = pb[64]; slot[t].l = pb[128];
+        slot[t].h = pb[0]; slot[t].l = pb[PK_LO];
     }
 }
 
 // The first R blocks, issued by the caller BEFORE the barrier that publishes the input image.
 template <int R, int NT>
-__device__ __forceinline__ void conv_w_prefetch(Bf16x3 (&ring)[R][NT], const u32x4* __restrict__ pk, int lane) {
+__device__ __forceinline__ void conv_w_prefetch(F16x2 (&ring)[R][NT], const u32x4* __restrict__ pk, int lane) {
     pk = opaque_global(pk);
 #pragma unroll
     for (int b = 0; b < R; ++b) conv_w_load<NT>(ring[b], pk, b, lane);
 }
 
 template <int CIN, int COUT, int KS, int RR, int NTT>
-__device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int ih, int iw, int oh, int ow, int M, Bf16x3 (&ring)[RR][NTT],
+__device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int ih, int iw, int oh, int ow, int M, F16x2 (&ring)[RR][NTT],
                                               const u32x4* __restrict__ pk, const float* __restrict__ bias,
                                               float* __restrict__ out_lds, float* __restrict__ out_g, int wave, int lane) {
     using SH = ConvShape<CIN, COUT, KS>;
@@ -107,9 +107,9 @@ __device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const float* ap = in + abase[u] + off;
-                const Bf16x3 av = split_bf16x3(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
+                const F16x2 av = split_f16x2(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
 #pragma unroll
-                for (int t = 0; t < NT; ++t) mma_bf16x6(av, ring[blk % R][t], acc[u][t][0], acc[u][t][1]);
+                for (int t = 0; t < NT; ++t) mma_f16x3(av, ring[blk % R][t], acc[u][t][0], acc[u][t][1]);
             }
             if (blk + R < NB) conv_w_load<NT>(ring[blk % R], pk, blk + R, lane);
             else if (more) conv_w_load<NT>(ring[blk % R], pk, blk + R - NB, lane);
@@ -122,7 +122,7 @@ __device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int 
             for (int r = 0; r < 4; ++r) {
                 const int mo = (t0 + u) * 16 + 4 * kb + r;
                 if (mo >= M) continue;
-                f32x2 v = {fmaxf(acc[u][0][0][r] + acc[u][0][1][r] + bias2[0], 0.f), fmaxf(acc[u][1][0][r] + acc[u][1][1][r] + bias2[1], 0.f)};
+                f32x2 v = {fmaxf(f16x2_sum(acc[u][0][0][r], acc[u][0][1][r]) + bias2[0], 0.f), fmaxf(f16x2_sum(acc[u][1][0][r], acc[u][1][1][r]) + bias2[1], 0.f)};
                 if (out_lds) *reinterpret_cast<f32x2*>(out_lds + mo * PSO + 2 * j) = v;
                 if (out_g) *reinterpret_cast<f32x2*>(out_g + (size_t)mo * COUT + 2 * j) = v;
             }
@@ -150,13 +150,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP_WG(DQ_TAG_CONV_FWD, 0);
     DQ_STAMP_PAIR(0);
     // ---- first convolution's weights -> registers (the loads fly while the observations are staged) ----------------
-    // The observation is binary, so conv1 runs on the bf16 matrix pipe (16x the f32 rate) WITHOUT losing a bit: 0/1 is exact in
-    // bf16, and every f32 weight is split exactly into three bf16 pieces w = hi + mid + lo (8 + 8 + 8 mantissa bits, by
-    // truncation); each product a*piece is exact and the pieces are accumulated in f32 by v_mfma_f32_16x16x32_bf16.  The result
-    // differs from an f32 fma chain only by the order of the f32 additions.  Layout of 16x16x32: lane (kb = lane >> 4, i = lane & 15)
-    // holds A[i][8kb .. 8kb+7] / B[8kb .. 8kb+7][i]; column tile t, lane j is column 4j + t (float4 weight loads).
+    // The observation is binary (0/1 is exact in f16), so conv1 needs only the weight's two f16 pieces (qnet.h): TWO MFMAs per
+    // product, each a*piece exact, accumulated in f32 by v_mfma_f32_16x16x32_f16 (leading and 2^11-scaled pieces in accumulators of
+    // their own).  Layout of 16x16x32: lane (kb = lane >> 4, i = lane & 15) holds A[i][8kb .. 8kb+7] / B[8kb .. 8kb+7][i]; column
+    // tile t, lane j is column 4j + t.
     // ready-made pieces from the packed buffer (PK_CONV1, zero past K1): splitting them here cost every workgroup ~350 VALU per wave
-    u32x4 wb[3][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 bf16 each
+    u32x4 wb[2][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 f16 each
     int ko[NH1][8];
     {
         const u32x4* pk1 = J.packed + PK_CONV1 + lane;
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int piece = 0; piece < 3; ++piece) wb[piece][h][t] = pk1[(h * 4 + t) * PK_BLOCK + 64 * piece];
+                for (int piece = 0; piece < 2; ++piece) wb[piece][h][t] = pk1[(h * 4 + t) * PK_BLOCK + PK_LO * piece];
 #pragma unroll
         for (int h = 0; h < NH1; ++h)
 #pragma unroll
@@ -219,20 +218,18 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 for (int e = 0; e < 8; ++e) ab[h][e] = ap[ko[h][e]];        // 0 or 1
         };
         auto tile_out = [&](int tile, const u32 (&ab)[NH1][8]) {
-            f32x4 acc[4];
+            f32x4 acc[4], accl[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[t] = acc[t]; }
 #pragma unroll
             for (int h = 0; h < NH1; ++h) {
                 u32x4 av;
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[h][e] | (ab[h][e + 1] << 16)) * 0x3f80u;       // bf16(1.0) = 0x3f80
+                for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[h][e] | (ab[h][e + 1] << 16)) * 0x3c00u;       // f16(1.0) = 0x3c00
 #pragma unroll
-                for (int piece = 0; piece < 3; ++piece)
+                for (int t = 0; t < 4; ++t) acc[t] = MFMA_F16(av, wb[0][h][t], acc[t]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, wb[piece][h][t]),
-                                                                         acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) accl[t] = MFMA_F16(av, wb[1][h][t], accl[t]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -240,7 +237,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 if (mo >= M1) continue;
                 f32x4 v;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[t][r] + bias1[t], 0.f);
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(f16x2_sum(acc[t][r], accl[t][r]) + bias1[t], 0.f);
                 *reinterpret_cast<f32x4*>(s_a1 + mo * 68 + 4 * j) = v;
                 if (g1) *reinterpret_cast<f32x4*>(g1 + (size_t)mo * 64 + 4 * j) = v;
             }
@@ -258,7 +255,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 3);
     // ---- convolution 2 (64 -> 32, 2x2) and 3 (32 -> 32, 2x2): the first weight blocks are requested before the barrier ------------
-    Bf16x3 ring[4][2];
+    F16x2 ring[4][2];
     conv_w_prefetch(ring, J.packed + PK_CONV2_FWD, lane);
     __syncthreads();
     DQ_STAMP(DQ_TAG_CONV_FWD, 4);
@@ -284,7 +281,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
 // ---------------------------------------------------------------------------------------------------------------
 struct DenseJob {
     const float* params;
-    const u32x4* packed;                // bf16 pieces (qnet.h); the hidden layer's blocks start at DenseChainArgs.pk_dense1
+    const u32x4* packed;                // f16 pieces (qnet.h); the hidden layer's blocks start at DenseChainArgs.pk_dense1
     const float* x;                     // [batch, K1]: NHWC flatten of the last convolution
     int batch;
     float keep_scale;                   // > 0: dropout active on the hidden layer's output
@@ -330,21 +327,21 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     DQ_STAMP(DQ_TAG_DENSE_FWD, 0);
     DQ_STAMP_PAIR(2);
     // ---- hidden layer's first weight blocks start flying before anything else -------------------------------------------
-    // Dense(512) runs as bf16x6 (qnet.h): the weights come as packed bf16 pieces (block (kblk, column tile ct = 4*wave + t), column
-    // 64*wave + 4j + t), the input rows are split ONCE into three bf16 planes in LDS.  The kernel is bound by the weight stream: the
-    // vector-memory path delivers ~64 B/clk/CU and every workgroup reads all 0.9 MB of pieces, so a workgroup takes RT = 2 row tiles
+    // Dense(512) runs as f16x2 (qnet.h): the weights come as packed f16 pieces (block (kblk, column tile ct = 4*wave + t), column
+    // 64*wave + 4j + t), the input rows are split ONCE into two f16 planes in LDS.  The kernel is bound by the weight stream: the
+    // vector-memory path delivers ~64 B/clk/CU and every workgroup reads all 0.6 MB of pieces, so a workgroup takes RT = 2 row tiles
     // (32 samples) per weight block when the batch is large enough to fill the chip that way -- half the bytes per sample.
     const int KB = K1 >> 5;                                          // k-blocks of 32
     const u32x4* pkw = J.packed + a.pk_dense1 + (size_t)(4 * wave) * PK_BLOCK + lane;
-    Bf16x3 bw[2][4];                                                // two k-blocks in flight
+    F16x2 bw[2][4];                                                 // two k-blocks in flight
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { bw[0][t].h = pkw[t * PK_BLOCK]; bw[0][t].m = pkw[t * PK_BLOCK + 64]; bw[0][t].l = pkw[t * PK_BLOCK + 128]; }
+    for (int t = 0; t < 4; ++t) { bw[0][t].h = pkw[t * PK_BLOCK]; bw[0][t].l = pkw[t * PK_BLOCK + PK_LO]; }
 
-    // ---- input rows -> three bf16 planes in LDS (zero-filled past the batch), in the rows' own NHWC order: Keras' channels_first
+    // ---- input rows -> two f16 planes in LDS (zero-filled past the batch), in the rows' own NHWC order: Keras' channels_first
     //      Flatten is a permutation of k, applied ONCE to the packed weight rows by pack_weights_kernel instead of to every input row
-    //      here (transposed 2-byte LDS writes: 12 per float4, against three 8-byte ones); clear the padded y2 image ---------------
-    const int LDP = K1 + 8;                                          // plane row stride in bf16 (rows stay 16-byte aligned)
-    unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [3][ROWS][LDP]
+    //      here (transposed 2-byte LDS writes: 8 per float4, against two 8-byte ones); clear the padded y2 image ---------------
+    const int LDP = K1 + 8;                                          // plane row stride in f16 (rows stay 16-byte aligned)
+    unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [2][ROWS][LDP]
     {
         const int q4 = K1 >> 2;                                     // float4 per row
         constexpr int NBS = 3;                                      // loads in flight per thread before the first split / LDS store
@@ -363,18 +360,12 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 if (i >= ROWS * q4) break;
                 const int r = i / q4, c4 = (i - r * q4) * 4;
                 const f32x4 v = vv[u];
-                u32 hb[4], mb[4], lb[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    hb[e] = __float_as_uint(v[e]) & 0xffff0000u;
-                    const float r1 = v[e] - __uint_as_float(hb[e]);                         // exact
-                    mb[e] = __float_as_uint(r1) & 0xffff0000u;
-                    lb[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));                   // exact, <= 8 significant bits left
-                }
+                u32 hb[2], lb[2];
+                split_f16x2_pair(v[0], v[1], hb[0], lb[0]);
+                split_f16x2_pair(v[2], v[3], hb[1], lb[1]);
                 unsigned short* d = s_pl + r * LDP + c4;
-                *reinterpret_cast<uint2*>(d) = uint2{(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
-                *reinterpret_cast<uint2*>(d + ROWS * LDP) = uint2{(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
-                *reinterpret_cast<uint2*>(d + 2 * ROWS * LDP) = uint2{(lb[0] >> 16) | (lb[1] & 0xffff0000u), (lb[2] >> 16) | (lb[3] & 0xffff0000u)};
+                *reinterpret_cast<uint2*>(d) = uint2{hb[0], hb[1]};
+                *reinterpret_cast<uint2*>(d + ROWS * LDP) = uint2{lb[0], lb[1]};
             }
         }
         for (int i = tid; i < ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
@@ -382,26 +373,25 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     __syncthreads();
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 1);
-    // ---- Dense(512): wave w owns columns [64w, 64w+64) as 4 interleaved tiles; two accumulator chains per tile -----------------
+    // ---- Dense(512): wave w owns columns [64w, 64w+64) as 4 interleaved tiles; two accumulators per tile (leading / cross terms) ----
     f32x4 acc2c[RT][4][2];
 #pragma unroll
     for (int u = 0; u < RT; ++u)
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc2c[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2c[u][t][1] = acc2c[u][t][0]; }
     const unsigned short* arow = s_pl + j * LDP + 8 * kq;
-    auto do_block = [&](int b, Bf16x3 (&cur)[4], Bf16x3 (&nxt)[4]) {
+    auto do_block = [&](int b, F16x2 (&cur)[4], F16x2 (&nxt)[4]) {
         const u32x4* pn = pkw + (size_t)min(b + 1, KB - 1) * 32 * PK_BLOCK;      // next block: unconditional, clamped prefetch
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { nxt[t].h = pn[t * PK_BLOCK]; nxt[t].m = pn[t * PK_BLOCK + 64]; nxt[t].l = pn[t * PK_BLOCK + 128]; }
+        for (int t = 0; t < 4; ++t) { nxt[t].h = pn[t * PK_BLOCK]; nxt[t].l = pn[t * PK_BLOCK + PK_LO]; }
 #pragma unroll
         for (int u = 0; u < RT; ++u) {
-            Bf16x3 av;
+            F16x2 av;
             const unsigned short* ap = arow + 16 * u * LDP + 32 * b;
             av.h = *reinterpret_cast<const u32x4*>(ap);
-            av.m = *reinterpret_cast<const u32x4*>(ap + ROWS * LDP);
-            av.l = *reinterpret_cast<const u32x4*>(ap + 2 * ROWS * LDP);
+            av.l = *reinterpret_cast<const u32x4*>(ap + ROWS * LDP);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) mma_bf16x6(av, cur[t], acc2c[u][t][0], acc2c[u][t][1]);
+            for (int t = 0; t < 4; ++t) mma_f16x3(av, cur[t], acc2c[u][t][0], acc2c[u][t][1]);
         }
     };
     int blk = 0;
@@ -414,7 +404,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
     for (int u = 0; u < RT; ++u)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[u][t] = acc2c[u][t][0] + acc2c[u][t][1];
+        for (int t = 0; t < 4; ++t) acc[u][t] = f16x2_sum(acc2c[u][t][0], acc2c[u][t][1]);
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
     // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
@@ -598,15 +588,15 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Packs the conv2 / conv3 kernels of one parameter buffer into bf16 pieces in MFMA B-operand order (qnet.h PK_*): one wave per
-// block, lane (kb, j) gathers its 8 weights, splits them exactly and writes 3 x 16 bytes.  ~0.2 MB, one launch per parameter change.
+// Packs the conv kernels and Dense(512) of one parameter buffer into f16 pieces in MFMA operand order (qnet.h PK_*): one wave per
+// block, lane (kb, j) gathers its 8 weights, splits them and writes 2 x 16 bytes.  One launch per parameter change.
 struct PackTr { const float* src; float* dst; int R, C, tile0, tiles_c; };      // dst[c][r] = src[r][c], 32 x 32 tiles
 struct PackArgs {
     const float* params;
     u32x4* pk;
     int w1_off, K1, w2_off, w3_off, d1_off, d1_blocks;
     int perm_hw, perm_c;                // > 0: plane index k' = p*perm_c + c of the dense forward is Keras weight row c*perm_hw + p
-    int pack_wgs;                       // workgroups [0, pack_wgs) pack bf16 pieces, the rest transpose (tr[i].tile0 counts from pack_wgs)
+    int pack_wgs;                       // workgroups [0, pack_wgs) pack f16 pieces, the rest transpose (tr[i].tile0 counts from pack_wgs)
     PackTr tr[2];
 };
 
@@ -650,7 +640,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
         const float* w = params + (c2 ? w2_off : w3_off);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = w[(size_t)(32 * blk + 8 * kb + e) * 32 + 2 * j + t];
-    } else if (blk_id >= 48) {                                      // first convolution (conv_pipe.hip): B(k = 32 h + 8kb + e, col = 4j + t), 0 past K1
+    } else if (blk_id >= 48) {                                      // first convolution: B(k = 32 h + 8kb + e, col = 4j + t), 0 past K1
         const int b = blk_id - 48, h = b >> 2, t = b & 3;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -665,9 +655,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = w[e];
     }
-    const Bf16x3 o = split_bf16x3(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+    const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
     u32x4* dst = pk + (size_t)blk_id * PK_BLOCK + lane;
-    dst[0] = o.h; dst[64] = o.m; dst[128] = o.l;
+    dst[0] = o.h; dst[PK_LO] = o.l;
 }
 
 static size_t pk_dense1_end(const dq_qnet* Q) { return (size_t)PK_TOTAL_U32X4 + (size_t)(Q->L[Q->cfg.n_conv].nin >> 5) * 32 * PK_BLOCK; }
@@ -751,7 +741,7 @@ static bool plan_dense(const dq_qnet* Q, DensePlan* P, int rt = 1) {
     P->ld2 = 16 * P->NT2 + 4;
     P->ld3 = 16 * ((N3 + 15) / 16) + 1;
     size_t off = 0;
-    const size_t xb = up16((size_t)3 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * rows * 16 * P->NT2 * 4);   // bf16 planes | partials
+    const size_t xb = up16((size_t)2 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * rows * 16 * P->NT2 * 4);   // f16 planes | partials
     P->off_x = P->off_part = (int)off; off += xb > pb ? xb : pb;   // the Dense(|A|) partials reuse the input image (dead by then)
     P->off_h = (int)off; off += up16((size_t)rows * (DENSE_HID + 4) * 4);
     P->off_y2 = (int)off; off += up16((size_t)rows * P->ld2 * 4);
@@ -870,15 +860,10 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         D.q_out = jb.q_dev;
         dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
     }
-    if ((Q->use_fused & 2) && conv_pipe_supported(Q)) {             // experimental persistent wave pipeline (conv_pipe.hip): opt-in
-        const dq_status rc = conv_pipe_launch(Q, n_jobs, ca.job, n_cu, st);
-        if (rc != DQ_OK) return rc;
-    } else {
-        dq_prof_begin(DQ_K_CONV_CHAIN, st);
-        ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
-        dq_prof_end(DQ_K_CONV_CHAIN, st);
-        DQ_LAUNCH_CHECK();
-    }
+    dq_prof_begin(DQ_K_CONV_CHAIN, st);
+    ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
+    dq_prof_end(DQ_K_CONV_CHAIN, st);
+    DQ_LAUNCH_CHECK();
     dq_prof_begin(DQ_K_DENSE_CHAIN, st);
     dk<<<dense_wgs, DENSE_THREADS, dp.lds, st>>>(da);
     dq_prof_end(DQ_K_DENSE_CHAIN, st);

@@ -35,10 +35,34 @@ struct DenseBwdArgs {
     float* gx;                          // [batch, K1] NHWC
     int ldg;                            // LDS row stride of the g3 / gY2 images (floats)
     int off_g3, off_gy2, off_gh1;
+    float gs;                           // every gradient of the fused backward is carried scaled by this power of two (GradScale below) ...
+    const float* gs_dev;                // ... or, when not NULL, by gs_dev[0] (computed on the device from max |dq|)
     int td_on, dense_wgs;               // td_on: dq is computed here from `td`; workgroups >= dense_wgs do the episode bookkeeping ...
     int env_on;                         // ... or, with a rider, the environment step (+ its replay sampling and bookkeeping): env_block<8>
     TdFused td;
 };
+
+// ---- gradient scale ----------------------------------------------------------------------------------------------------
+// The f16 pieces (qnet.h) carry 22 significant bits only for |x| in [2^-14, 65504), and loss gradients are small (dq = TD error / batch).
+// The backward is linear in dq, so the fused backward carries S * gradient everywhere, S a power of two (exact), and the final reduction
+// multiplies the weight gradient by 1/S.  With the TD step fused in, S = 2^k with S * grad_scale in [4, 8): TD errors between 1.5e-5 and
+// 8000 are carried at full precision (smaller ones at 2^-36 / 4 absolute).  With a caller-supplied dq, grad_scale_kernel reads max |dq|
+// and picks S with S * max |dq| in (128, 256].  S lives in kernel arguments (host-known) or in two floats behind the workspace.
+__global__ __launch_bounds__(1024) void grad_scale_kernel(const float* __restrict__ dq, int n, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(dq[i]));
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, sh[w]);
+        int e = 0;
+        float S = 1.f;
+        if (m > 0.f && m < INFINITY) { (void)frexpf(m, &e); S = ldexpf(1.f, max(-100, min(100, 8 - e))); }      // m = f 2^e, f in [0.5, 1)
+        out[0] = S; out[1] = 1.f / S;
+    }
+}
 
 // NTP adjacent column tiles [tile0, tile0 + NTP) of gX for this wave: tile t, lane j is column 16*tile0 + NTP*j + t, so the lane's
 // NTP weights of a W1T row are NTP consecutive floats (one dwordx2/x3 load, 4-byte aligned); weights double-buffered.
@@ -114,6 +138,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     const int b0 = blockIdx.x * DENSE_ROWS;
     const int ns = min(DENSE_ROWS, a.batch - b0);
     const int A = a.n_actions, N2 = a.N2, N3 = a.N3, ldg = a.ldg;
+    const float GS = a.gs_dev ? a.gs_dev[0] : a.gs;                  // gradient scale (a power of two), wave-uniform
 
     if ((int)blockIdx.x >= a.dense_wgs) {                           // the episode bookkeeping of the step just taken rides along
         dq_episode_stats_lane(a.td.st_done, a.td.st_was_reset, a.td.st_lifetime, a.td.st_reward, a.td.st_n,
@@ -201,7 +226,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         const float* dr = a.dq + (size_t)b * A;
         auto dval = [&](int h) {                                    // dq[b][lane + 64 h]
             const int c = lane + 64 * h;
-            return a.td_on ? (c == a_b[u] ? (qv[u][h] - yb[u]) * a.td.grad_scale : 0.f) : dr[c];
+            return a.td_on ? (c == a_b[u] ? (qv[u][h] - yb[u]) * a.td.grad_scale * GS : 0.f) : dr[c] * GS;
         };
         if (N3 > 0) {
             float s = 0.f;
@@ -351,9 +376,9 @@ struct DenseWgradArgs {
     size_t pstride;
 };
 
-// One wave's tile on the bf16 matrix pipe at f32 accuracy (bf16x6, qnet.h).  The batch is the reduction index, so lane (kb, i)
+// One wave's tile on the f16 matrix pipe at f32-class accuracy (f16x2, qnet.h).  The batch is the reduction index, so lane (kb, i)
 // supplies rows m + 8kb .. m + 8kb + 7 of its columns: eight loads per operand per 32 batch rows.  Each 16-column tile operand is
-// split ONCE into three bf16 pieces and used by every tile of the other operand: TK x 4 x 6 K = 32 MFMAs (1.5K pipe cycles at
+// split ONCE into two f16 pieces and used by every tile of the other operand: TK x 4 x 3 K = 32 MFMAs (0.8K pipe cycles at
 // TK = 4) per 32 rows instead of 8 x TK x 4 f32 K = 4 ones (4.1K).  Rows past the slice are clamped on load and zeroed in G only (a
 // zero factor kills the product; the bias sums need G anyway).
 //   VEC (K and N multiples of 4): column tiles INTERLEAVED -- k-tile ti, lane i is weight row kbase + 4i + ti and n-tile tj, lane j is
@@ -382,11 +407,11 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
     float nmask[4];                                                 // scalar layout: the bias sums must not see a clamped column's values
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) nmask[tj] = (VEC || nbase + 16 * tj + j < N) ? 1.f : 0.f;
-    f32x4 acc[TK][4];
+    f32x4 acc[TK][4], accx[TK][4];                                  // leading products / 2^11-scaled cross terms
 #pragma unroll
     for (int ti = 0; ti < TK; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tj = 0; tj < 4; ++tj) { acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[ti][tj] = acc[ti][tj]; }
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     float xr[TK][8], gr[4][8];                                      // raw values [tile][row] of one 32-row block
     auto load = [&](int m) {
@@ -411,10 +436,10 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
     load(m0);
     for (int m = m0; m < m1; m += 32) {
         // split this block's raw rows into pieces (the raw registers are dead after that) ...
-        Bf16x3 xa[TK], gb[4];
+        F16x2 xa[TK], gb[4];
 #pragma unroll
         for (int ti = 0; ti < TK; ++ti)
-            xa[ti] = split_bf16x3(f32x4{xr[ti][0], xr[ti][1], xr[ti][2], xr[ti][3]}, f32x4{xr[ti][4], xr[ti][5], xr[ti][6], xr[ti][7]});
+            xa[ti] = split_f16x2(f32x4{xr[ti][0], xr[ti][1], xr[ti][2], xr[ti][3]}, f32x4{xr[ti][4], xr[ti][5], xr[ti][6], xr[ti][7]});
         const bool tail = m + 32 > m1;                              // wave-uniform
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
@@ -425,33 +450,31 @@ __device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int s
 #pragma unroll
             for (int e = 0; e < 8; ++e) bs += g[e];
             bsum[tj] += VEC ? bs : bs * nmask[tj];
-            gb[tj] = split_bf16x3(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
+            gb[tj] = split_f16x2(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
         }
         // ... request the next block's rows into them (past the slice: clamped rows, never multiplied) ...
         __builtin_amdgcn_sched_barrier(0);
         load(m + 32);
         __builtin_amdgcn_sched_barrier(0);                           // (left alone, the scheduler sinks the loads to just before their use)
-        // ... and multiply: one accumulator per tile, 4 TK independent chains interleaved, six passes
+        // ... and multiply: two accumulators per tile, 4 TK independent chains interleaved, three passes
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
 #pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].h, gb[tj].h, c); }
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_F16(xa[ti].h, gb[tj].h, c); }
 #pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].m, gb[tj].m, c); }
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = accx[ti][tj]; c = MFMA_F16(xa[ti].h, gb[tj].l, c); }
 #pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].h, gb[tj].m, c); }
-#pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].m, gb[tj].h, c); }
-#pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].h, gb[tj].l, c); }
-#pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_BF16(xa[ti].l, gb[tj].h, c); }
+            for (int ti = 0; ti < TK; ++ti) { f32x4& c = accx[ti][tj]; c = MFMA_F16(xa[ti].l, gb[tj].h, c); }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     // ---- combine the workgroup's four slices in fixed order, write one partial.  C/D layout: this lane holds rows 4kq + r of each
     //      16 x 16 tile; VEC: local weight row 4 (4kq + r) + ti, column 4j + tj; else row 16ti + 4kq + r, column 16tj + j ----------------
     float* sp = s_part + wave * (64 * 64);
+#pragma unroll
+    for (int ti = 0; ti < TK; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f16x2_sum(acc[ti][tj], accx[ti][tj]);
 #pragma unroll
     for (int ti = 0; ti < TK; ++ti)
 #pragma unroll
@@ -508,7 +531,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
 // Block = 64 outputs x 8 slice groups (thread (x, g) sums slices g, g+8, ... in order; the 8 group sums are combined
 // pairwise in LDS) -- deterministic, and 8x the loads in flight of a one-thread-per-output loop.
 struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; int pidx0; };   // pidx0: flat index of out[0]
-struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; };
+struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; float inv_gs; const float* gs_dev; };     // partials carry the gradient scale: x 1/S
 
 __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __shared__ float sh[8][64];
@@ -529,7 +552,7 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __syncthreads();
     if (g == 0 && i < S.n) {
         const int x = threadIdx.x;
-        const float gsum = ((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x])) + ((sh[4][x] + sh[5][x]) + (sh[6][x] + sh[7][x]));
+        const float gsum = (((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x])) + ((sh[4][x] + sh[5][x]) + (sh[6][x] + sh[7][x]))) * (a.gs_dev ? a.gs_dev[1] : a.inv_gs);
         S.out[i] = gsum;
         if (a.adam) {                                               // the optimizer step rides on the reduction (dq_qnet_backward_adam)
             const size_t k = (size_t)S.pidx0 + i;
@@ -563,7 +586,7 @@ struct ConvBwdArgs {
     const float* a1;                    // saved activations of the training forward (global NHWC)
     const float* a2;
     const float* g3;                    // [batch*r3, 32] gradient w.r.t. conv3's pre-activation output
-    const u32x4* packed;                // bf16 pieces of the conv kernels (qnet.h PK_*), those of the training forward
+    const u32x4* packed;                // f16 pieces of the conv kernels (qnet.h PK_*), those of the training forward
     int batch, S, groups;
     int C, H, W, k1, st1, K1;
     int oh1, ow1, oh2, ow2, oh3, ow3;
@@ -600,10 +623,10 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
     }
 }
 
-// Weights of one 2x2 data gradient for this lane as bf16 pieces: [tap ky*2+kx][column tile t]: B(n = 8kb .. 8kb+7, c = c_lo + 16t + j)
+// Weights of one 2x2 data gradient for this lane as f16 pieces: [tap ky*2+kx][column tile t]: B(n = 8kb .. 8kb+7, c = c_lo + 16t + j)
 // = W[ky,kx, c, n], ready-made in the packed buffer (qnet.h PK_CONV3_DG / PK_CONV2_DG + 8 * PK_BLOCK * half).
-__device__ __forceinline__ void dgrad_load_w(Bf16x3 (&bw)[4][2], const u32x4* __restrict__ pk, int lane) {
-    // opaque base: otherwise hipcc hoists the 24 load addresses out of the caller's loop as invariants (48 VGPRs), spills them, and
+__device__ __forceinline__ void dgrad_load_w(F16x2 (&bw)[4][2], const u32x4* __restrict__ pk, int lane) {
+    // opaque base: otherwise hipcc hoists the load addresses out of the caller's loop as invariants (VGPR pairs), spills them, and
     // reloads each behind an s_waitcnt vmcnt(0) -- which serialises the loads (measured: 10K cycles for this function)
     pk = opaque_global(pk);
 #pragma unroll
@@ -611,16 +634,16 @@ __device__ __forceinline__ void dgrad_load_w(Bf16x3 (&bw)[4][2], const u32x4* __
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const u32x4* pb = pk + (tap * 2 + t) * PK_BLOCK + lane;
-            bw[tap][t].h = pb[0]; bw[tap][t].m = pb[64]; bw[tap][t].l = pb[128];
+            bw[tap][t].h = pb[0]; bw[tap][t].l = pb[PK_LO];
         }
 }
 
 // Data gradient of a 2x2 stride-1 convolution with 32 output channels, masked by the input activation, in place:
 //   act[(s,iy,ix), c] <- (sum_{ky,kx,n} g[(s,iy-ky,ix-kx), n] W[ky,kx,c,n]) * [act > 0]     for c in [c_lo, c_lo + 32)
-// g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA].  One tap = one K = 32 block of the bf16 MFMA:
+// g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA].  One tap = one K = 32 block of the f16 MFMA:
 // A = the 32 channels of g at the tap's pixel (two ds_read_b128 per lane, split on the fly), B = the tap's weights (registers).
 template <int PSA>
-__device__ __forceinline__ void dgrad_inplace(const Bf16x3 (&bw)[4][2], const float* __restrict__ g, int zero_row, float* __restrict__ act,
+__device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const float* __restrict__ g, int zero_row, float* __restrict__ act,
                                               int c_lo, int ih, int iw, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
     const int j = lane & 15, kb = lane >> 4;
     const int rin = ih * iw, rout = oh * ow, tiles = (M + 15) >> 4;
@@ -642,9 +665,9 @@ __device__ __forceinline__ void dgrad_inplace(const Bf16x3 (&bw)[4][2], const fl
         }
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) {
-            const Bf16x3 av = split_bf16x3(ga[tap][0], ga[tap][1]);
+            const F16x2 av = split_f16x2(ga[tap][0], ga[tap][1]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) mma_bf16x6(av, bw[tap][t], acc[t][0], acc[t][1]);
+            for (int t = 0; t < 2; ++t) mma_f16x3(av, bw[tap][t], acc[t][0], acc[t][1]);
         }
         // C/D layout: col = lane & 15 -> channel c_lo + 16t + j, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -654,7 +677,7 @@ __device__ __forceinline__ void dgrad_inplace(const Bf16x3 (&bw)[4][2], const fl
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float* p = act + mo * PSA + c_lo + 16 * t + j;
-                *p = *p > 0.f ? acc[t][0][r] + acc[t][1][r] : 0.f;
+                *p = *p > 0.f ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
             }
         }
     }
@@ -692,12 +715,12 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     const int kyx = wave >> 1, ky = kyx >> 1, kx = kyx & 1;
     const int aoff3 = (ky * a.ow2 + kx) * 36 + 16 * (wave & 1) + j;
     const int aoff2 = (ky * a.ow1 + kx) * A1PS + 32 * (wave & 1) + j;
-    f32x4 acc3[2], acc2[2][2], acc1[NW1];
+    f32x4 acc3[2], acc2[2][2], acc1[NW1], acc1l[NW1];
     float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1 = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[0][t] = acc3[t]; acc2[1][t] = acc3[t]; }
 #pragma unroll
-    for (int u = 0; u < NW1; ++u) acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NW1; ++u) { acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1l[u] = acc1[u]; }
 
     // ---- every input image goes global -> LDS by LDS-DMA (no registers), issued as early as its LDS target is free, so that group
     //      k + 1's inputs land while group k computes.  (All workgroups run in lockstep: a load phase of its own is a burst on HBM
@@ -750,7 +773,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         if (a.a1_alt) issue_a1(g, reinterpret_cast<float*>(smem + a.off_a1));
     }
 
-    Bf16x3 bw[4][2];                                                // data-gradient weights (bf16 pieces): loaded one phase ahead of their use
+    F16x2 bw[4][2];                                                 // data-gradient weights (f16 pieces): loaded one phase ahead of their use
     int it = 0;
     for (int grp = blockIdx.x; grp < a.groups; grp += gridDim.x, ++it) {
         float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1 + (it & 1) * a.a1_alt);
@@ -862,8 +885,8 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         {
             const u8* cp = s_col + 16 * (wave >> 2) + j;           // + 32 per further tile of this wave (k-tile + 2)
             const float* gp = s_a1 + 16 * (wave & 3) + j;
-            // On the bf16 pipe, exactly: the patch operand is binary (exact in bf16) and g1 is split into three bf16 pieces, so one K = 32
-            // MFMA per piece replaces eight f32 MFMAs (96 instead of 512 pipe cycles per 32 rows and two tiles) and the eight byte ->
+            // On the f16 pipe: the patch operand is binary (exact in f16) and g1 is split into two f16 pieces (qnet.h), so one K = 32
+            // MFMA per piece replaces eight f32 MFMAs (64 instead of 512 pipe cycles per 32 rows and two tiles) and the eight byte ->
             // float conversions per tile become four multiplies.  Lane (j, kq) supplies rows m0 + 8kq .. + 7 of column j of both
             // operands.  The LDS reads of trip t + 1 are issued before the MFMAs of trip t.
             auto rd = [&](int m0, u32 (&ab)[NW1][8], float (&g)[8]) {
@@ -884,15 +907,14 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
             // (each copy waits for the result) -- a tile this wave does not have accumulates garbage that is never stored
             auto mm = [&](const u32 (&ab)[NW1][8], const float (&g)[8]) {
-                const Bf16x3 gb = split_bf16x3(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
+                const F16x2 gb = split_f16x2(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
 #pragma unroll
                 for (int u = 0; u < NW1; ++u) {
                     u32x4 av;
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[u][e] | (ab[u][e + 1] << 16)) * 0x3f80u;      // bf16(1.0) = 0x3f80
-                    acc1[u] = MFMA_BF16(av, gb.h, acc1[u]);
-                    acc1[u] = MFMA_BF16(av, gb.m, acc1[u]);
-                    acc1[u] = MFMA_BF16(av, gb.l, acc1[u]);
+                    for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[u][e] | (ab[u][e + 1] << 16)) * 0x3c00u;      // f16(1.0) = 0x3c00
+                    acc1[u] = MFMA_F16(av, gb.h, acc1[u]);
+                    acc1l[u] = MFMA_F16(av, gb.l, acc1l[u]);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bs1 += g[e];
@@ -925,7 +947,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 16 * kt + 4 * kq + r;
-                if (k < a.K1) out[a.w_off[0] + k * 64 + 16 * nt + j] = acc1[u][r];
+                if (k < a.K1) out[a.w_off[0] + k * 64 + 16 * nt + j] = f16x2_sum(acc1[u][r], acc1l[u][r]);
             }
             if (kt == 0) {                                          // bias gradient = column sums of g1
                 float v = bs1;
@@ -1012,7 +1034,7 @@ bool fused_backward_supported(const dq_qnet* Q) {
 // floats of workspace the fused backward needs: [DENSE_WGRAD_SLICES][n_params] dense partials, then [CONV_BWD_MAX_WGS][conv params]
 size_t fused_backward_workspace_floats(const dq_qnet* Q) {
     if (!fused_backward_supported(Q)) return 0;
-    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off;
+    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + 4;     // + {S, 1/S}: GradScale
 }
 
 typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
@@ -1043,6 +1065,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
     float* dense_partial = Q->fpartial;
     float* conv_partial = dense_partial + (size_t)DENSE_WGRAD_SLICES * Q->n_params;
+    float* gs_slot = conv_partial + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off;       // device-computed {S, 1/S}
     DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
     const u32x4* pkbase = static_cast<const u32x4*>(Q->last_train_packed);
     const float* w1t = reinterpret_cast<const float*>(pkbase + fused_packed_w1t_u32x4(Q));       // transposed by dq_qnet_pack
@@ -1050,9 +1073,21 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     const size_t conv_floats = D1.w_off;
     const int n_dense = (int)(Q->n_params - conv_floats);
     if (phases & 1) {
+    // ---- gradient scale (see grad_scale_kernel): host-known with the TD step fused in, else from max |dq| on the device ----------
+    const float known = td ? td->grad_scale : Q->grad_scale_hint;  // the loss scale dq carries, when the host knows it
+    if (td || known > 0.f) {
+        int e = 0;
+        (void)frexp((double)known, &e);                             // grad_scale = f 2^e, f in [0.5, 1)
+        Q->bwd_scale = known > 0.f ? (float)ldexp(1.0, 3 - e) : 1.f;
+    } else {
+        Q->bwd_scale = 0.f;                                         // = read gs_slot
+        grad_scale_kernel<<<1, 1024, 0, st>>>(dq_dev, B * Q->cfg.n_actions, gs_slot);
+        DQ_LAUNCH_CHECK();
+    }
     // ---- 1. dense data gradients ----------------------------------------------------------------------------------
     DenseBwdArgs da;
     memset(&da, 0, sizeof(da));
+    da.gs = Q->bwd_scale; da.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
     da.w1t = w1t; da.w2t = w2t;
     da.params = params_dev; da.dq = dq_dev; da.h1 = Q->act[0][nc]; da.x = Q->act[0][nc - 1];
     da.batch = B; da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
@@ -1110,6 +1145,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     if (phases != 3) {                                              // phased: the dense gradients are complete (and reducible) now
         ReduceArgs ra;
         memset(&ra, 0, sizeof(ra));
+        ra.inv_gs = Q->bwd_scale > 0.f ? 1.f / Q->bwd_scale : 0.f; ra.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
         ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, 0, (int)conv_floats};
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
         reduce_slices_kernel<<<(n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
@@ -1143,6 +1179,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     // ---- 4. fixed-order reductions of the partials into the flat gradient ------------------------------------------------
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
+    ra.inv_gs = Q->bwd_scale > 0.f ? 1.f / Q->bwd_scale : 0.f; ra.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
     if (opt) { ra.opt = *opt; ra.adam = 1; }
     ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0, 0};
     const int blocks0 = ((int)conv_floats + 63) / 64;

@@ -33,8 +33,9 @@ struct dq_qnet {
     void* pk_scratch[FWD_MAX_JOBS];  // packed weights of jobs that did not bring their own (dq_qnet_job.packed_dev == NULL)
     const void* last_train_packed;   // packed weights of the last training forward (the backward's data gradients read them)
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
-    int use_fused;               // bit 0: fused LDS-resident chains when the configuration allows it; bit 1: the forward's convolutions
-                                 // through the experimental wave pipeline (conv_pipe.hip) instead of conv_chain_kernel (fused.hip)
+    float grad_scale_hint;       // dq_qnet_set_grad_scale: loss scale of caller-supplied dq (0 = unknown: measured on the device)
+    float bwd_scale;             // fused backward: power-of-two scale the gradients of the last dense phase carry (0: the device-computed one)
+    int use_fused;               // fused LDS-resident chains when the configuration allows it
 };
 
 
@@ -42,7 +43,6 @@ struct dq_qnet {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned: global_load_dwordx4 accepts it
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define CHAIN_LDS_MAX (160 * 1024)
@@ -53,13 +53,21 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword
 static inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 #ifdef __HIPCC__
-// ---- f32-accurate contraction on the bf16 matrix pipe ("bf16x6") ----------------------------------------------------------
-// Every f32 value splits EXACTLY into three bf16 pieces x = hi + mid + lo (8+8+8 mantissa bits, by truncation).  A product a*b is then
-// the sum of nine exact piece products; the six with piece-index sum <= 4 carry it to ~2^-24 relative (the f32 rounding class), so
-//   a.b ~= aH.bH + aH.bM + aM.bH + aM.bM + aH.bL + aL.bH            (f32 accumulation inside v_mfma_f32_16x16x32_bf16)
-// costs 6 bf16 MFMAs of K = 32 (~17 cycles each) instead of 8 f32 MFMAs of K = 4 (32 cycles each): 2.5x the matrix-pipe rate at f32
-// accuracy.  The price is the VALU work of splitting the operands, so it is used where one operand (the weights) is split once per
-// phase and held in registers, and the other costs ~44 VALU per 8 values, issued in the MFMAs' shadow.
+// ---- f32-class contraction on the f16 matrix pipe ("f16x2") ---------------------------------------------------------------
+// Every f32 operand x is carried as TWO f16 pieces: h = f16(x) (round to nearest even) and l = f16((x - h) * 2^11) -- the residual,
+// scaled so that it is a normal f16 wherever h is (x - h is exact in f32; |x - h| <= 2^-11 |x|), i.e. x = h + l 2^-11 + r with
+// |r| <= 2^-22 |x|: 22 significant bits and round-to-nearest in both pieces, so the representation error is unbiased and on average
+// below f32's own rounding unit.  A product is accumulated in f32 by v_mfma_f32_16x16x32_f16 as
+//   a.b ~= aH.bH + 2^-11 (aH.bL + aL.bH)                               (dropped: aL.bL 2^-22, relative 2^-22)
+// with the scaled terms in an accumulator of their own, combined once at the end (acc0 + 2^-11 acc1): THREE K = 32 MFMAs per product
+// (~16 cycles each) instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each), 5.3x the matrix-pipe rate of the f32 instruction.
+// Measured against float64 on this network's layers (tools/f16x2_error.py): max error 1.9e-7 / rms 3.8e-8 on outputs of magnitude ~2,
+// against 1.2e-6 / 1.3e-7 for an ordinary f32 GEMM (sgemm) of the same operands -- the scheme is inside the f32 rounding class; the
+// fused chains are tested against the float64 oracle at 1e-5 like the per-layer f32 path.  (Round 1 used three bf16 pieces and six
+// MFMAs per product; f16 pieces halve both the MFMAs and the splitting arithmetic: ~3 VALU per value.)
+// Range: operands must be finite with |x| < 65504 (weights, post-ReLU activations: always; gradients are carried scaled by a power of two
+// chosen from the loss scale, fused_bwd.hip).  f16 subnormals are honoured by the matrix pipe on gfx950 (tools/probe/f16_denorm.hip), so a
+// piece below 2^-14 only falls back from relative to absolute accuracy (2^-25 on h, 2^-36 on l).
 // A wave-uniform global pointer made opaque to the optimiser (so that the addresses computed from it are not hoisted out of the
 // enclosing loop as VGPR-pair invariants and spilled) and re-marked as global memory (so that the loads stay global_load, not flat).
 __device__ __forceinline__ const u32x4* opaque_global(const u32x4* p) {
@@ -68,35 +76,43 @@ __device__ __forceinline__ const u32x4* opaque_global(const u32x4* p) {
     return (const u32x4*)g;
 }
 
-struct Bf16x3 { u32x4 h, m, l; };       // 8 values: pieces packed two per dword (element e in the low half of dword e/2)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define F16_LO_SCALE 2048.f           // 2^11
+#define F16_LO_INV (1.f / 2048.f)
+struct F16x2 { u32x4 h, l; };         // 8 values: pieces packed two per dword (element e in the low half of dword e/2)
 
-__device__ __forceinline__ Bf16x3 split_bf16x3(const f32x4& x0, const f32x4& x1) {
-    Bf16x3 o;
+// two values -> {h pair, l pair}: v_cvt_pk_f16_f32, v_pk_mul_f32, 2 x v_cvt_f32_f16, v_pk_fma_f32, v_cvt_pk_f16_f32 (3 VALU per value)
+__device__ __forceinline__ void split_f16x2_pair(float x0, float x1, u32& h, u32& l) {
+    const f16x2 hp = {(_Float16)x0, (_Float16)x1};
+    u32 hu = __builtin_bit_cast(u32, hp);
+    asm volatile("" : "+v"(hu));                                    // (otherwise hipcc converts every value twice: packed and unpacked)
+    const f16x2 hq = __builtin_bit_cast(f16x2, hu);
+    const float r0 = __builtin_fmaf((float)hq[0], -F16_LO_SCALE, x0 * F16_LO_SCALE);      // (x - h) 2^11, exact
+    const float r1 = __builtin_fmaf((float)hq[1], -F16_LO_SCALE, x1 * F16_LO_SCALE);
+    const f16x2 lp = {(_Float16)r0, (_Float16)r1};
+    h = hu;
+    l = __builtin_bit_cast(u32, lp);
+}
+
+__device__ __forceinline__ F16x2 split_f16x2(const f32x4& x0, const f32x4& x1) {
+    F16x2 o;
     const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const u32 a0 = __float_as_uint(v[e]), a1 = __float_as_uint(v[e + 1]);
-        o.h[e >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);                   // {a1.hi16, a0.hi16}
-        const float r0 = v[e] - __uint_as_float(a0 & 0xffff0000u), r1 = v[e + 1] - __uint_as_float(a1 & 0xffff0000u);     // exact
-        const u32 b0 = __float_as_uint(r0), b1 = __float_as_uint(r1);
-        o.m[e >> 1] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-        const float s0 = r0 - __uint_as_float(b0 & 0xffff0000u), s1 = r1 - __uint_as_float(b1 & 0xffff0000u);           // exact
-        o.l[e >> 1] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-    }
+    for (int e = 0; e < 8; e += 2) { u32 h, l; split_f16x2_pair(v[e], v[e + 1], h, l); o.h[e >> 1] = h; o.l[e >> 1] = l; }
     return o;
 }
 
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+#define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
 
-// acc0 takes the three largest piece products, acc1 the three small ones (two independent accumulator chains; summed by the caller)
-__device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32x4& acc0, f32x4& acc1) {
-    acc0 = MFMA_BF16(a.h, b.h, acc0);
-    acc1 = MFMA_BF16(a.m, b.m, acc1);
-    acc0 = MFMA_BF16(a.h, b.m, acc0);
-    acc1 = MFMA_BF16(a.h, b.l, acc1);
-    acc0 = MFMA_BF16(a.m, b.h, acc0);
-    acc1 = MFMA_BF16(a.l, b.h, acc1);
+// acc0 takes the leading piece product, acc1 the two 2^11-scaled cross terms; the caller combines them with f16x2_sum
+__device__ __forceinline__ void mma_f16x3(const F16x2& a, const F16x2& b, f32x4& acc0, f32x4& acc1) {
+    acc0 = MFMA_F16(a.h, b.h, acc0);
+    acc1 = MFMA_F16(a.h, b.l, acc1);
+    acc1 = MFMA_F16(a.l, b.h, acc1);
 }
+__device__ __forceinline__ float f16x2_sum(float acc0, float acc1) { return __builtin_fmaf(acc1, F16_LO_INV, acc0); }
+__device__ __forceinline__ f32x4 f16x2_sum(const f32x4& acc0, const f32x4& acc1) { return acc1 * F16_LO_INV + acc0; }
 
 #endif  // __HIPCC__
 
@@ -104,7 +120,7 @@ __device__ __forceinline__ void mma_bf16x6(const Bf16x3& a, const Bf16x3& b, f32
 // on s0 of one DQN update, plus the acting forward): their serial phases (staging, epilogues, head layers) overlap in one grid.
 struct ConvJob {
     const float* params;
-    const u32x4* packed;               // bf16 pieces of the conv2 / conv3 kernels (PK_* below)
+    const u32x4* packed;               // f16 pieces of the conv kernels (PK_* below)
     const u8* obs;
     const int32_t* index;
     int index_off, index_mod, batch;
@@ -114,19 +130,21 @@ struct ConvJob {
 };
 
 // ---- packed weights (fused.hip: pack_weights_kernel) --------------------------------------------------------------------------
-// The bf16x6 contractions read their weight operand as ready-made bf16 pieces in MFMA B-operand order: one "block" = 64 lanes x
-// 3 pieces x 16 bytes (lane (kb, j) holds the 8 reduction indices 8kb .. 8kb+7 of its column).  Sections, in u32x4 units:
+// The f16x2 contractions read their weight operand as ready-made f16 pieces in MFMA operand order: one "block" = 64 lanes x
+// 2 pieces x 16 bytes (lane (kb, j) holds the 8 reduction indices 8kb .. 8kb+7 of its column; h pieces at +0, l pieces at +64).
+// Sections, in u32x4 units:
 //   PK_CONV2_FWD  [8 k-blocks][2 column tiles]      B(k = 32 blk + 8kb + e, col = 2j + t)            = W2[k][col]
 //   PK_CONV3_FWD  [4][2]                            same for conv3
 //   PK_CONV3_DG   [4 taps][2]                       B(n = 8kb + e, c = 16t + j)                      = W3[tap][c][n]
 //   PK_CONV2_DG   [2 channel halves][4 taps][2]     B(n = 8kb + e, c = 32 half + 16t + j)            = W2[tap][c][n]
-//   PK_CONV1      [3 k-blocks][4 column tiles]      B(k = 32 blk + 8kb + e, col = 4j + t)            = W1[k][col] (conv_pipe.hip)
-#define PK_BLOCK 192                  // u32x4 per block (3 pieces x 64 lanes)
+//   PK_CONV1      [3 k-blocks][4 column tiles]      B(k = 32 blk + 8kb + e, col = 4j + t)            = W1[k][col], 0 past K1
+#define PK_BLOCK 128                  // u32x4 per block (2 pieces x 64 lanes)
+#define PK_LO 64                      // the l pieces of a block
 #define PK_CONV2_FWD 0
 #define PK_CONV3_FWD (PK_CONV2_FWD + 16 * PK_BLOCK)
 #define PK_CONV3_DG (PK_CONV3_FWD + 8 * PK_BLOCK)
 #define PK_CONV2_DG (PK_CONV3_DG + 8 * PK_BLOCK)
-#define PK_CONV1 (PK_CONV2_DG + 16 * PK_BLOCK)      // [3 k-blocks][4 column tiles]: B(k = 32 blk + 8kb + e, col = 4j + t) = W1[k][col], 0 past K1
+#define PK_CONV1 (PK_CONV2_DG + 16 * PK_BLOCK)
 #define PK_TOTAL_BLOCKS 60
 #define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)     // the conv sections; then PK_DENSE1 [K1/32 k-blocks][32 column tiles];
 // then (f32, for the backward's data gradients) W1T [512][K1] and W2T [N2][512], each section 16-byte aligned:
@@ -137,9 +155,6 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
-// conv_pipe.hip: the convolutional forward chain as a persistent wave pipeline (jobs[i].wg0 is filled in by the launcher)
-bool conv_pipe_supported(const dq_qnet* Q);
-dq_status conv_pipe_launch(dq_qnet* Q, int n_jobs, const ConvJob* jobs, int n_cu, hipStream_t st);
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
 dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_t st);

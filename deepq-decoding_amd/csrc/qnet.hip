@@ -452,7 +452,13 @@ int dq_qnet_num_layers(const dq_qnet* Q) { return Q ? Q->n_layers : 0; }
 
 dq_status dq_qnet_set_fused(dq_qnet* Q, int enable) {
     DQ_REQUIRE(Q, DQ_ERR_INVALID, "dq_qnet_set_fused: null handle");
-    Q->use_fused = enable & 3;
+    Q->use_fused = enable ? 1 : 0;
+    return DQ_OK;
+}
+
+dq_status dq_qnet_set_grad_scale(dq_qnet* Q, double grad_scale) {
+    DQ_REQUIRE(Q && grad_scale >= 0.0 && grad_scale < 1e30, DQ_ERR_INVALID, "dq_qnet_set_grad_scale: bad argument");
+    Q->grad_scale_hint = (float)grad_scale;
     return DQ_OK;
 }
 

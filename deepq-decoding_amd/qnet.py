@@ -54,12 +54,15 @@ class QNetwork:
             kshape = tuple(shape[j] for j in range(nd.value))
             self.layers.append(dict(kernel_offset=ko.value, bias_offset=bo.value, kernel_shape=kshape, bias_shape=(kshape[-1],)))
 
-    def set_fused(self, enable, conv_pipe=False):
-        """Select the fused LDS-resident chains (default) or the per-layer implicit-GEMM path; conv_pipe=True keeps the fused chains
-        but runs the forward's convolutions through the experimental persistent wave pipeline (csrc/conv_pipe.hip: measured equal to
-        conv_chain_kernel) -- A/B runs and its parity test."""
-        check(self.L.dq_qnet_set_fused(self._h, (1 if enable else 0) | (2 if conv_pipe else 0)))
+    def set_fused(self, enable):
+        """Select the fused LDS-resident chains (default) or the per-layer implicit-GEMM path."""
+        check(self.L.dq_qnet_set_fused(self._h, 1 if enable else 0))
         self.fused_enabled = bool(enable)
+
+    def set_grad_scale(self, grad_scale):
+        """Declare the loss scale a caller-supplied dq was computed with (td_update's grad_scale); 0 = undeclared (the backward then
+        measures max |dq| on the device).  See include/deepq_hip.h dq_qnet_set_grad_scale."""
+        check(self.L.dq_qnet_set_grad_scale(self._h, float(grad_scale)))
 
     @property
     def fused_supported(self):
@@ -117,7 +120,7 @@ class QNetwork:
         params.copy_(torch.from_numpy(flat))
 
     def pack(self, params, out=None):
-        """bf16 pieces of the conv kernels in matrix-core operand order (dq_qnet_pack): pass the result as `packed=` to forward() /
+        """f16 pieces of the weights in matrix-core operand order (dq_qnet_pack): pass the result as `packed=` to forward() /
         forward_multi() jobs that use `params`, and call it again whenever `params` changes.  None if not applicable."""
         if not self.packed_bytes:
             return None

@@ -201,8 +201,9 @@ dq_status dq_policy_select(const float* q_dev, const uint64_t* legal_dev, int n,
  * Parameters live in ONE flat float buffer owned by the caller, in Keras order and Keras shapes (conv
  * kernels HWIO, dense (in,out)), each layer kernel then bias -- the tensors of a Keras .h5f drop in as is.
  * f32 results throughout (the reference is fp32 and the parity bound is 1e-5).  The per-layer path multiplies on the f32-input MFMA;
- * the fused chains issue every f32 product on the bf16 matrix pipe as an exact three-way split of both operands (six bf16 MFMAs with
- * f32 accumulation, three where an operand is binary): same accuracy class, different summation order (csrc/qnet.h "bf16x6").
+ * the fused chains carry every f32 operand as two f16 pieces (22 significant bits, round to nearest) and issue three f16 MFMAs per
+ * product with f32 accumulation (two where an operand is binary): error below that of an ordinary f32 GEMM's accumulation, different
+ * summation order (csrc/qnet.h "f16x2").  Operands of the fused chains must be finite and below 65504 in magnitude.
  * ------------------------------------------------------------------------------------------- */
 typedef struct dq_qnet dq_qnet;
 
@@ -262,7 +263,7 @@ typedef struct {
 } dq_qnet_job;
 dq_status dq_qnet_forward_multi(dq_qnet* net, int n_jobs, const dq_qnet_job* jobs, void* stream);
 
-/* The fused chains read the conv2 / conv3 kernels as bf16 pieces in matrix-core operand order.  A caller that runs several
+/* The fused chains read the conv kernels and Dense(512) as f16 pieces in matrix-core operand order.  A caller that runs several
  * forwards on the same weights packs them once per parameter change (dq_qnet_packed_bytes(net) bytes of device memory) and
  * passes the buffer in dq_qnet_job.packed_dev; it MUST repack after every change of params_dev (dq_adam_step, weight loading).
  * dq_qnet_forward and jobs with packed_dev == NULL pack on every call.  The backward reuses the training forward's pack. */
@@ -272,6 +273,13 @@ dq_status dq_qnet_pack(const dq_qnet* net, const float* params_dev, void* packed
 /* Backward half of train_on_batch: grads_dev[n_params] = d/dparams sum(dq * Q) for the last training forward
  * (obs_dev / index_dev of that call must still be valid).  Deterministic (fixed-order reductions). */
 dq_status dq_qnet_backward(dq_qnet* net, const float* params_dev, const float* dq_dev, float* grads_dev, void* stream);
+
+/* The fused backward carries its gradients multiplied by a power of two S (undone, exactly, by its final reduction) so that they sit in
+ * the f16 pieces' range (csrc/fused_bwd.hip "gradient scale").  With the TD step fused in (dq_qnet_td_backward_*), S follows from
+ * td->grad_scale.  A backward that is handed dq_dev measures max |dq| on the device first (one small extra launch) -- unless the caller
+ * declares here the loss scale its dq was computed with (dq = TD error x grad_scale, as dq_td_update's argument): then the same S as in
+ * the fused TD path is used, and the two paths give the same bits.  0 (default) = not declared.  No reference counterpart. */
+dq_status dq_qnet_set_grad_scale(dq_qnet* net, double grad_scale);
 
 /* The same backward in two phases, for overlapping the gradient all-reduce with compute on several GPUs (no reference
  * counterpart): phase 0 = dueling + dense layers -> grads_dev[dq_qnet_conv_param_count(net) ..) complete; phase 1 = the

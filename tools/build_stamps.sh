@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instrumented builds for tools/stamp_run.py: tools/probe/stamps/s<tag>.so = the library with -DDQ_STAMPS=<tag> in the file that
-# carries that tag's stamps (1, 2, 11, 12, 20: fused.hip; 3, 4, 13, 14: fused_bwd.hip; 5: conv_pipe.hip); the other objects are the regular build's.
+# carries that tag's stamps (1, 2, 11, 12, 20: fused.hip; 3, 4, 13, 14: fused_bwd.hip); the other objects are the regular build's.
 # Usage: tools/build_stamps.sh 1 2 3 4      then on the GPU box: DQ_LIB_PATH=tools/probe/stamps/s4.so python tools/stamp_run.py 4
 set -e
 root="$(cd "$(dirname "$0")/.." && pwd)"; cd "$root"
@@ -8,9 +8,9 @@ python deepq-decoding_amd/build.py > /dev/null
 mkdir -p tools/probe/stamps
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 for tag in "$@"; do
-  case $((tag % 10)) in 1|2|0) f=fused ;; 5) f=conv_pipe ;; *) f=fused_bwd ;; esac
+  case $((tag % 10)) in 1|2|0) f=fused ;; *) f=fused_bwd ;; esac
   ( /opt/rocm/bin/hipcc $FLAGS -DDQ_STAMPS=$tag -c deepq-decoding_amd/csrc/$f.hip -o /tmp/stamp_${f}_$tag.o
-    objs=""; for o in conv_pipe dqn env fused fused_bwd policy prof qnet; do if [ $o = $f ]; then objs="$objs /tmp/stamp_${f}_$tag.o"; else objs="$objs deepq-decoding_amd/lib/$o.o"; fi; done
+    objs=""; for o in dqn env fused fused_bwd policy prof qnet; do if [ $o = $f ]; then objs="$objs /tmp/stamp_${f}_$tag.o"; else objs="$objs deepq-decoding_amd/lib/$o.o"; fi; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/probe/stamps/s$tag.so $objs ) &
 done
 wait
