@@ -177,7 +177,7 @@ __device__ __forceinline__ void dq_adam1(float& p, float g, float& m, float& v, 
 #define DQ_TAG_DENSE_FWD 2
 #define DQ_TAG_DENSE_BWD 3
 #define DQ_TAG_CONV_BWD 4
-#define DQ_TAG_CONV_PIPE 5
+#define DQ_TAG_DENSE_WGRAD 5
 #ifdef DQ_STAMPS
 #define DQ_STAMP_BLOCK 9
 static __device__ unsigned long long dq_dbg[4096];            // one copy per translation unit (no relocatable device code)

@@ -41,13 +41,16 @@ struct ConvChainArgs {
     int w_off[3], b_off[3];            // floats into params
     const int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an observation, -1 past K1
     int slot;                          // bytes per sample slot in LDS (multiple of 4, >= C*H*W + 3)
-    int off_mis, off_a1, off_a2;       // LDS byte offsets (observations at 0)
+    int off_mis, off_t1, off_a1, off_a2;   // LDS byte offsets (observations at 0; a2 overlays observations + tables)
 };
 
-// One stride-1 convolution whose input is an LDS image [pixel][CIN + 4] (f32), on the f16 matrix pipe at f32-class accuracy (f16x2,
-// qnet.h).  K = KS*KS*CIN is walked in blocks of 32 channels of one tap: A = 8 consecutive channels per lane (two ds_read_b128),
-// split into f16 pieces on the fly; B = the block's weights as pieces, streamed through a register ring.  Each wave takes pairs of
-// 16-row tiles x both column tiles (column tile t, lane j = column 2j + t), two accumulators per tile (leading / scaled cross terms).
+// One stride-1 convolution on the f16 matrix pipe at f32-class accuracy (f16x2, qnet.h).  Its input is an LDS image of READY-MADE
+// pieces: two f16 planes [pixel][CIN + 8] (h plane, then the l plane `lo_in` halves further), written once by the producing layer's
+// epilogue ("split on write": every value is read by KS*KS taps, so splitting at the read would repeat the arithmetic four times).
+// K = KS*KS*CIN is walked in blocks of 32 channels of one tap: A = 8 consecutive channels per lane = one ds_read_b128 per piece (row
+// stride CIN + 8 halves: the quarter-wave's 16 rows fall into distinct banks); B = the block's weights as pieces, streamed through a
+// register ring.  Each wave takes pairs of 16-row tiles x both column tiles (column tile t, lane j = column 2j + t), two accumulators
+// per tile (leading / scaled cross terms).  The output goes to LDS as pieces again (out_lds) and / or to global memory as f32.
 template <int CIN, int COUT, int KS>
 struct ConvShape {
     static constexpr int NT = COUT / 16, CB = CIN / 32, NB = KS * KS * CB, R = NB < 4 ? NB : 4;     // R: K = 32 weight blocks in flight
@@ -72,11 +75,11 @@ __device__ __forceinline__ void conv_w_prefetch(F16x2 (&ring)[R][NT], const u32x
 }
 
 template <int CIN, int COUT, int KS, int RR, int NTT>
-__device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int ih, int iw, int oh, int ow, int M, F16x2 (&ring)[RR][NTT],
-                                              const u32x4* __restrict__ pk, const float* __restrict__ bias,
-                                              float* __restrict__ out_lds, float* __restrict__ out_g, int wave, int lane) {
+__device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__ in, int lo_in, int ih, int iw, int oh, int ow, int M,
+                                              F16x2 (&ring)[RR][NTT], const u32x4* __restrict__ pk, const float* __restrict__ bias,
+                                              unsigned short* __restrict__ out_lds, int lo_out, float* __restrict__ out_g, int wave, int lane) {
     using SH = ConvShape<CIN, COUT, KS>;
-    constexpr int NT = SH::NT, PSI = CIN + 4, PSO = COUT + 4, CB = SH::CB, NB = SH::NB, R = SH::R;
+    constexpr int NT = SH::NT, PSI = CIN + 8, PSO = COUT + 8, CB = SH::CB, NB = SH::NB, R = SH::R;
     static_assert(NT == 2 && CIN % 32 == 0 && RR == R && NTT == NT, "written for 32 output channels, CIN a multiple of 32");
     const int j = lane & 15, kb = lane >> 4;
     const f32x2 bias2 = *reinterpret_cast<const f32x2*>(bias + 2 * j);
@@ -106,8 +109,10 @@ __device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int 
             const int off = (ky * iw + kx) * PSI + 32 * c32;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float* ap = in + abase[u] + off;
-                const F16x2 av = split_f16x2(*reinterpret_cast<const f32x4*>(ap), *reinterpret_cast<const f32x4*>(ap + 4));
+                const unsigned short* ap = in + abase[u] + off;
+                F16x2 av;
+                av.h = *reinterpret_cast<const u32x4*>(ap);
+                av.l = *reinterpret_cast<const u32x4*>(ap + lo_in);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mma_f16x3(av, ring[blk % R][t], acc[u][t][0], acc[u][t][1]);
             }
@@ -123,7 +128,12 @@ __device__ __forceinline__ void conv_from_lds(const float* __restrict__ in, int 
                 const int mo = (t0 + u) * 16 + 4 * kb + r;
                 if (mo >= M) continue;
                 f32x2 v = {fmaxf(f16x2_sum(acc[u][0][0][r], acc[u][0][1][r]) + bias2[0], 0.f), fmaxf(f16x2_sum(acc[u][1][0][r], acc[u][1][1][r]) + bias2[1], 0.f)};
-                if (out_lds) *reinterpret_cast<f32x2*>(out_lds + mo * PSO + 2 * j) = v;
+                if (out_lds) {
+                    u32 h, l;
+                    split_f16x2_pair(v[0], v[1], h, l);
+                    *reinterpret_cast<u32*>(out_lds + mo * PSO + 2 * j) = h;
+                    *reinterpret_cast<u32*>(out_lds + mo * PSO + 2 * j + lo_out) = l;
+                }
                 if (out_g) *reinterpret_cast<f32x2*>(out_g + (size_t)mo * COUT + 2 * j) = v;
             }
         }
@@ -135,8 +145,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8* s_in = smem;
     int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);
-    float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1);
-    float* s_a2 = reinterpret_cast<float*>(smem + a.off_a2);
+    unsigned short* s_a1 = reinterpret_cast<unsigned short*>(smem + a.off_a1);      // f16 piece planes [2][S*r1][72]
+    unsigned short* s_a2 = reinterpret_cast<unsigned short*>(smem + a.off_a2);      // [2][S*r2][40]; overlays the observations (dead after conv1)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     int jb = 0;
     while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
@@ -193,9 +203,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
         }
     }
     __syncthreads();                                                // s_mis
-    // byte offset of output pixel m's patch origin inside the staged observations (the a2 region is free until conv2 writes it)
+    // byte offset of output pixel m's patch origin inside the staged observations
     const int r1 = a.oh1 * a.ow1, M1 = ns * r1;
-    int* s_t1 = reinterpret_cast<int*>(s_a2);
+    const int lo1 = a.S * r1 * 72, lo2 = a.S * a.oh2 * a.ow2 * 40;        // halves from an h plane to its l plane
+    int* s_t1 = reinterpret_cast<int*>(smem + a.off_t1);
     for (int m = tid; m < M1; m += CONV_THREADS) {
         const int s = m / r1, pix = m - s * r1, oy = pix / a.ow1, ox = pix - oy * a.ow1;
         s_t1[m] = s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
@@ -238,7 +249,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 f32x4 v;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = fmaxf(f16x2_sum(acc[t][r], accl[t][r]) + bias1[t], 0.f);
-                *reinterpret_cast<f32x4*>(s_a1 + mo * 68 + 4 * j) = v;
+                u32 hp[2], lp[2];                                   // split on write: this lane's 4 consecutive channels of pixel mo
+                split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
+                split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
+                *reinterpret_cast<uint2*>(s_a1 + mo * 72 + 4 * j) = uint2{hp[0], hp[1]};
+                *reinterpret_cast<uint2*>(s_a1 + mo * 72 + 4 * j + lo1) = uint2{lp[0], lp[1]};
                 if (g1) *reinterpret_cast<f32x4*>(g1 + (size_t)mo * 64 + 4 * j) = v;
             }
         };
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 4);
     {
         const int r2 = a.oh2 * a.ow2;
-        conv_from_lds<64, 32, 2>(s_a1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2,
+        conv_from_lds<64, 32, 2>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
                                  J.write_all ? J.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 5);
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 6);
     {
         const int r3 = a.oh3 * a.ow3;
-        conv_from_lds<32, 32, 2>(s_a2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr,
+        conv_from_lds<32, 32, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
                                  J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 7);
@@ -289,6 +304,9 @@ struct DenseJob {
     u32 seed0, seed1, sample_base;
     u64 t;
     float* h1_out;                      // training: [batch, 512] post-dropout; else NULL
+    unsigned short* x_pl;               // training: the input rows as f16 piece planes [2][plane_rows][K1] for the dense weight gradients
+    unsigned short* h1_pl;              // training: the hidden output as planes [2][plane_rows][512]
+    int plane_rows;
     float* y2_out;                      // training: [batch, N2]
     float* y3_out;                      // training: [batch, N3]
     float* q_out;                       // [batch, n_actions]
@@ -300,6 +318,7 @@ struct DenseChainArgs {
     int n_jobs;
     int K1, perm_hw, perm_c;            // Keras Flatten: k = c*hw + p reads x[p*perm_c + c]
     int pk_dense1;                      // u32x4 offset of the hidden layer's packed blocks [K1/32][32 column tiles]
+    int pk_dense2;                      // ... of Dense(|A|)'s [16][NT2]
     int N2, N3, n_actions;              // Dense(|A|) width, dueling layer width (0 = no dueling layer)
     int w_off[3], b_off[3];
     int ldx, ld2, ld3;                  // LDS row strides (floats)
@@ -311,11 +330,11 @@ template <int NT2, int KG3, int RT>     // N2 <= 16*NT2 (column tiles of Dense(|
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     float* s_x = reinterpret_cast<float*>(smem + a.off_x);
-    float* s_h = reinterpret_cast<float*>(smem + a.off_h);
+    unsigned short* s_hp = reinterpret_cast<unsigned short*>(smem + a.off_h);      // hidden output as f16 piece planes [2][ROWS][LDH]
     float* s_part = reinterpret_cast<float*>(smem + a.off_part);
     float* s_y2 = reinterpret_cast<float*>(smem + a.off_y2);
     float* s_y3 = reinterpret_cast<float*>(smem + a.off_y3);
-    constexpr int LDH = DENSE_HID + 4, PW = 16 * NT2, ROWS = 16 * RT;
+    constexpr int LDH = DENSE_HID + 8, PW = 16 * NT2, ROWS = 16 * RT;      // LDH: halves per plane row (16-byte aligned, bank-staggered)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     int jb = 0;
     while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
@@ -366,6 +385,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 unsigned short* d = s_pl + r * LDP + c4;
                 *reinterpret_cast<uint2*>(d) = uint2{hb[0], hb[1]};
                 *reinterpret_cast<uint2*>(d + ROWS * LDP) = uint2{lb[0], lb[1]};
+                if (J.x_pl && r < ns) {                             // the same pieces feed the weight gradient of this layer (fused_bwd.hip)
+                    unsigned short* gp = J.x_pl + (size_t)(b0 + r) * K1 + c4;
+                    *reinterpret_cast<uint2*>(gp) = uint2{hb[0], hb[1]};
+                    *reinterpret_cast<uint2*>(gp + (size_t)J.plane_rows * K1) = uint2{lb[0], lb[1]};
+                }
             }
         }
         for (int i = tid; i < ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
@@ -408,32 +432,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
     // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
-    const float* w2 = J.params + a.w_off[1];
-    // Dense(|A|) splits K = 512 into 8 parts of 64 rows, one per wave, every column tile in each.  Tile t, lane j is column
-    // NT2*j + t, so a lane's NT2 weights of a row are NT2 consecutive floats: NT2/4 dwordx4 loads (rows are only 4-byte aligned,
-    // which global_load_dwordx4 accepts) instead of NT2 scalar gathers -- a wave can only have 63 loads in flight.
+    // Dense(|A|) splits K = 512 into 8 parts of 64 rows (two K = 32 blocks), one per wave, every column tile in each, on the f16 pipe:
+    // packed pieces (qnet.h dense2: tile t, lane j is column NT2*j + t, so a lane's NT2 results of a row are consecutive floats)
     const int kw0 = 64 * wave;
-    float b2[4][4][NT2];
+    F16x2 b2[2][NT2];
     {
-        const float* wpart = w2 + (size_t)kw0 * a.N2;               // wave-uniform
-        int loff[NT2 / 4];
+        const u32x4* pk2 = J.packed + a.pk_dense2 + (size_t)(2 * wave) * NT2 * PK_BLOCK + lane;
 #pragma unroll
-        for (int q = 0; q < NT2 / 4; ++q) {
-            const int c0 = NT2 * j + 4 * q;
-            loff[q] = 4 * kq * a.N2 + (c0 < a.N2 ? c0 : 0);
-        }
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float* wrow = wpart + (16 * g + s) * a.N2;       // uniform
-#pragma unroll
-                for (int q = 0; q < NT2 / 4; ++q) {
-                    const f32x4u v = *reinterpret_cast<const f32x4u*>(wrow + loff[q]);     // unconditional load, then select
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) b2[g][s][4 * q + e] = (NT2 * j + 4 * q + e < a.N2) ? v[e] : 0.f;
-                }
-            }
+            for (int t = 0; t < NT2; ++t) { b2[b][t].h = pk2[(b * NT2 + t) * PK_BLOCK]; b2[b][t].l = pk2[(b * NT2 + t) * PK_BLOCK + PK_LO]; }
     }
     const int NT3 = (a.N3 + 15) >> 4;
     float b3[KG3][4];
@@ -458,8 +466,17 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = ((u64)wd[t] < J.drop_T) ? 0.f : v[t] * J.keep_scale;
                 }
-                *reinterpret_cast<f32x4*>(s_h + row * LDH + c0) = v;
-                if (J.h1_out && row < ns) *reinterpret_cast<f32x4*>(J.h1_out + (size_t)(b0 + row) * DENSE_HID + c0) = v;
+                u32 hp[2], lp[2];                                   // split on write: Dense(|A|) and the weight gradients read pieces
+                split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
+                split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
+                *reinterpret_cast<uint2*>(s_hp + row * LDH + c0) = uint2{hp[0], hp[1]};
+                *reinterpret_cast<uint2*>(s_hp + (ROWS + row) * LDH + c0) = uint2{lp[0], lp[1]};
+                if (J.h1_out && row < ns) {
+                    *reinterpret_cast<f32x4*>(J.h1_out + (size_t)(b0 + row) * DENSE_HID + c0) = v;
+                    unsigned short* gp = J.h1_pl + (size_t)(b0 + row) * DENSE_HID + c0;
+                    *reinterpret_cast<uint2*>(gp) = uint2{hp[0], hp[1]};
+                    *reinterpret_cast<uint2*>(gp + (size_t)J.plane_rows * DENSE_HID) = uint2{lp[0], lp[1]};
+                }
             }
     }
     __syncthreads();
@@ -468,18 +485,20 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     // ---- Dense(|A|): K = 512 split over the 8 waves, partial tiles reduced in fixed order ---------------------------------
 #pragma unroll
     for (int u = 0; u < RT; ++u) {
-        f32x4 acc2[NT2];
+        f32x4 acc2[NT2], acc2x[NT2];
 #pragma unroll
-        for (int t = 0; t < NT2; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* hrow = s_h + (16 * u + j) * LDH + kw0 + 4 * kq;
+        for (int t = 0; t < NT2; ++t) { acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2x[t] = acc2[t]; }
+        const unsigned short* hrow = s_hp + (16 * u + j) * LDH + kw0 + 8 * kq;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 16 * g);
+        for (int b = 0; b < 2; ++b) {
+            F16x2 av;
+            av.h = *reinterpret_cast<const u32x4*>(hrow + 32 * b);
+            av.l = *reinterpret_cast<const u32x4*>(hrow + 32 * b + ROWS * LDH);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < NT2; ++t) acc2[t] = MFMA16(av[s], b2[g][s][t], acc2[t]);
+            for (int t = 0; t < NT2; ++t) mma_f16x3(av, b2[b][t], acc2[t], acc2x[t]);
         }
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc2[t] = f16x2_sum(acc2[t], acc2x[t]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -595,6 +614,7 @@ struct PackArgs {
     const float* params;
     u32x4* pk;
     int w1_off, K1, w2_off, w3_off, d1_off, d1_blocks;
+    int d2_off, N2, NT2, KB2, d2_blocks, d2t_blocks, d1t_blocks, d1k;     // Dense(|A|) kernel offset / width, dense2 / dense2t / dense1t block counts, K1
     int perm_hw, perm_c;                // > 0: plane index k' = p*perm_c + c of the dense forward is Keras weight row c*perm_hw + p
     int pack_wgs;                       // workgroups [0, pack_wgs) pack f16 pieces, the rest transpose (tr[i].tile0 counts from pack_wgs)
     PackTr tr[2];
@@ -623,9 +643,28 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
     u32x4* __restrict__ pk = a.pk;
     const int w2_off = a.w2_off, w3_off = a.w3_off, d1_off = a.d1_off, d1_blocks = a.d1_blocks;
     const int lane = threadIdx.x & 63, blk_id = blockIdx.x * 4 + (threadIdx.x >> 6), j = lane & 15, kb = lane >> 4;
-    if (blk_id >= PK_TOTAL_BLOCKS + d1_blocks) return;
+    const int e_d1 = PK_TOTAL_BLOCKS + d1_blocks, e_d2 = e_d1 + a.d2_blocks, e_d2t = e_d2 + a.d2t_blocks, e_d1t = e_d2t + a.d1t_blocks;
+    if (blk_id >= e_d1t) return;
     float v[8];
-    if (blk_id >= PK_TOTAL_BLOCKS) {                                // Dense(512): block (kblk, ct): B(k = 32 kblk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3))
+    if (blk_id >= e_d2t) {                                          // dense1t (gX): B(n1 = 32 blk + 8kb + e, k' = 16 ct + j) = W1[row(k')][n1]
+        const int tiles = a.d1k >> 4, b = blk_id - e_d2t, blk = b / tiles, ct = b - blk * tiles;
+        int k = 16 * ct + j;
+        if (a.perm_hw > 0) { const int pp = k / a.perm_c, c = k - pp * a.perm_c; k = c * a.perm_hw + pp; }
+        const float* w = params + d1_off + (size_t)k * DENSE_HID + 32 * blk + 8 * kb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[e];
+    } else if (blk_id >= e_d2) {                                    // dense2t (gH1): B(n2 = 32 blk + 8kb + e, n1 = 64 (ct>>2) + 4j + (ct&3)) = W2[n1][n2]
+        const int b = blk_id - e_d2, blk = b >> 5, ct = b & 31, n1 = 64 * (ct >> 2) + 4 * j + (ct & 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n2 = 32 * blk + 8 * kb + e;
+            v[e] = n2 < a.N2 ? params[a.d2_off + (size_t)n1 * a.N2 + n2] : 0.f;
+        }
+    } else if (blk_id >= e_d1) {                                    // dense2 (forward): B(k = 32 blk + 8kb + e, col = NT2 j + t) = W2[k][col]
+        const int b = blk_id - e_d1, blk = b / a.NT2, t = b - blk * a.NT2, col = a.NT2 * j + t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = col < a.N2 ? params[a.d2_off + (size_t)(32 * blk + 8 * kb + e) * a.N2 + col] : 0.f;
+    } else if (blk_id >= PK_TOTAL_BLOCKS) {                         // Dense(512): block (kblk, ct): B(k = 32 kblk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3))
         const int b = blk_id - PK_TOTAL_BLOCKS, kblk = b >> 5, ct = b & 31;
         const float* w = params + d1_off + 64 * (ct >> 2) + 4 * j + (ct & 3);
 #pragma unroll
@@ -660,8 +699,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
     dst[0] = o.h; dst[PK_LO] = o.l;
 }
 
-static size_t pk_dense1_end(const dq_qnet* Q) { return (size_t)PK_TOTAL_U32X4 + (size_t)(Q->L[Q->cfg.n_conv].nin >> 5) * 32 * PK_BLOCK; }
-size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return pk_dense1_end(Q); }
+PackLayout fused_pack_layout(const dq_qnet* Q) {
+    const int nc = Q->cfg.n_conv;
+    const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
+    PackLayout P;
+    P.NT2 = D2.nout <= 64 ? 4 : 8;
+    P.KB2 = (D2.nout + 31) / 32;
+    P.d1_blocks = (D1.nin >> 5) * 32; P.d2_blocks = 16 * P.NT2; P.d2t_blocks = P.KB2 * 32; P.d1t_blocks = 16 * (D1.nin >> 4);
+    P.dense1 = PK_TOTAL_U32X4;
+    P.dense2 = P.dense1 + (size_t)P.d1_blocks * PK_BLOCK;
+    P.dense2t = P.dense2 + (size_t)P.d2_blocks * PK_BLOCK;
+    P.dense1t = P.dense2t + (size_t)P.d2t_blocks * PK_BLOCK;
+    P.total = P.dense1t + (size_t)P.d1t_blocks * PK_BLOCK;
+    return P;
+}
+size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return fused_pack_layout(Q).total; }
 size_t fused_packed_w2t_u32x4(const dq_qnet* Q) {
     const Layer& D1 = Q->L[Q->cfg.n_conv];
     return fused_packed_w1t_u32x4(Q) + ((size_t)D1.K * D1.N + 3) / 4;
@@ -681,7 +733,10 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     a.params = params_dev; a.pk = static_cast<u32x4*>(packed_dev);
     a.w1_off = (int)Q->L[0].w_off; a.K1 = Q->L[0].K; a.w2_off = (int)Q->L[1].w_off; a.w3_off = (int)Q->L[2].w_off; a.d1_off = (int)D1.w_off; a.d1_blocks = (D1.nin >> 5) * 32;
     a.perm_hw = Q->flat_hw; a.perm_c = Q->flat_c;
-    a.pack_wgs = (PK_TOTAL_BLOCKS + a.d1_blocks + 3) / 4;
+    const PackLayout PL = fused_pack_layout(Q);
+    a.d2_off = (int)D2.w_off; a.N2 = D2.nout; a.NT2 = PL.NT2; a.KB2 = PL.KB2; a.d2_blocks = PL.d2_blocks; a.d2t_blocks = PL.d2t_blocks;
+    a.d1t_blocks = PL.d1t_blocks; a.d1k = D1.nin;
+    a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + 3) / 4;
     int tiles = a.pack_wgs;
     const Layer* Ls[2] = {&D1, &D2};
     const size_t offs[2] = {fused_packed_w1t_u32x4(Q), fused_packed_w2t_u32x4(Q)};
@@ -697,7 +752,7 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct ConvPlan { int S, slot, off_mis, off_a1, off_a2, KG1; size_t lds; };
+struct ConvPlan { int S, slot, off_mis, off_t1, off_a1, off_a2, KG1; size_t lds; };
 
 static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
     if (Q->cfg.n_conv != 3) return false;
@@ -712,12 +767,16 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
     for (int pass = 0; pass < 2; ++pass) {                          // prefer two workgroups per CU; else the largest S that fits
         const size_t budget = pass == 0 ? CONV_LDS_2PER_CU : CONV_LDS_MAX;
         for (int S = 8; S >= 1; S >>= 1) {
+            // [observations | alignment offsets | patch origins] live until conv1 is done; conv2's output a2 (written after the
+            // barrier behind conv1) overlays them.  a1, a2: two f16 piece planes each, rows of 64 + 8 / 32 + 8 halves.
             size_t off = up16((size_t)S * P->slot);
             const size_t mis = off; off += up16((size_t)S * 4);
-            const size_t a1 = off; off += up16((size_t)S * L1.rows * 68 * 4);
-            const size_t a2 = off; off += up16((size_t)S * L2.rows * 36 * 4);
+            const size_t t1 = off; off += up16((size_t)S * L1.rows * 4);
+            const size_t a2_bytes = up16((size_t)2 * S * L2.rows * 40 * 2);
+            if (off < a2_bytes) off = a2_bytes;
+            const size_t a1 = off; off += up16((size_t)2 * S * L1.rows * 72 * 2);
             if (off <= budget) {
-                P->S = S; P->off_mis = (int)mis; P->off_a1 = (int)a1; P->off_a2 = (int)a2; P->lds = off;
+                P->S = S; P->off_mis = (int)mis; P->off_t1 = (int)t1; P->off_a1 = (int)a1; P->off_a2 = 0; P->lds = off;
                 return true;
             }
         }
@@ -743,7 +802,7 @@ static bool plan_dense(const dq_qnet* Q, DensePlan* P, int rt = 1) {
     size_t off = 0;
     const size_t xb = up16((size_t)2 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * rows * 16 * P->NT2 * 4);   // f16 planes | partials
     P->off_x = P->off_part = (int)off; off += xb > pb ? xb : pb;   // the Dense(|A|) partials reuse the input image (dead by then)
-    P->off_h = (int)off; off += up16((size_t)rows * (DENSE_HID + 4) * 4);
+    P->off_h = (int)off; off += up16((size_t)2 * rows * (DENSE_HID + 8) * 2);     // hidden output: two f16 planes
     P->off_y2 = (int)off; off += up16((size_t)rows * P->ld2 * 4);
     P->off_y3 = (int)off; off += up16((size_t)rows * P->ld3 * 4);
     P->lds = off;
@@ -787,8 +846,9 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
     ca.kofftab = Q->kofftab;
-    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2;
-    da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = PK_TOTAL_U32X4;
+    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_t1 = cp.off_t1; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2;
+    const PackLayout PL = fused_pack_layout(Q);
+    da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = (int)PL.dense1; da.pk_dense2 = (int)PL.dense2;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < Q->n_layers - nc; ++l) { da.w_off[l] = (int)Q->L[nc + l].w_off; da.b_off[l] = (int)Q->L[nc + l].b_off; }
     // two row tiles (32 samples) per dense workgroup -- half the weight stream per sample -- when one-tile workgroups would
@@ -853,6 +913,8 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         D.seed0 = jb.seed[0]; D.seed1 = jb.seed[1]; D.sample_base = jb.sample_base; D.t = jb.t;
         if (training) {
             D.h1_out = Q->act[0][nc]; D.y2_out = Q->act[0][nc + 1];
+            D.plane_rows = Q->cfg.max_batch;
+            D.x_pl = Q->planes; D.h1_pl = Q->planes + (size_t)2 * Q->cfg.max_batch * D1.nin;
             D.y3_out = Q->cfg.dueling ? Q->act[0][nc + 2] : nullptr;
             Q->last_train_batch = jb.batch; Q->last_obs = jb.obs_dev; Q->last_index = jb.index_dev;
             Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod; Q->last_train_packed = packed;

@@ -350,14 +350,22 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Weight gradients of the dense layers, all layers in ONE launch.  dW[k, n] = sum_b X[b, k] G[b, n]: the batch is the
-// reduction index.  One wave = one (16*TK x 64) output tile over one batch slice; both operands are loaded straight from
-// global memory in MFMA layout (lane (kq, i): X[b+kq][k0+i] / G[b+kq][n0+i], 64-byte segments), double-buffered in registers,
-// no LDS in the loop.  The four waves of a workgroup take the same tile over four consecutive slices and are summed through
-// LDS in fixed order, so only gridDim.y partials per weight reach HBM.  Bias gradients (column sums of G) ride along in the
-// waves of k-tile 0.
+// Weight gradients of the dense layers, all layers in ONE launch.  dW[k, n] = sum_b X[b, k] G[b, n]: the batch is the reduction index.
+// Workgroup = 4 waves = one 64 x 64 output tile over one batch slice; wave w owns the 32 x 32 quarter (k half w >> 1, n half w & 1) as
+// 2 x 2 MFMA tiles.  Both operands go through LDS as ready-made f16 pieces (qnet.h), TRANSPOSED -- [column][batch row] -- so that an
+// MFMA operand (lane (kb, i): 8 consecutive batch rows of column i) is ONE ds_read_b128 per piece: the rows of a 32-row block are
+// loaded from global memory, split and stored once per WORKGROUP.  (Until round 2 every wave loaded and split its own 64 + 64 columns:
+// four times the vector-memory traffic -- the kernel's bound -- and four times the splitting arithmetic, with 64 accumulator registers
+// per operand scheme.)  An iteration covers two blocks: waves 0 / 1 load X / G of the first (lane (g, i): rows 8g .. 8g+7 of columns
+// 4i .. 4i+3: eight dwordx4, every row 256 contiguous bytes), waves 2 / 3 of the second; the next iteration's rows are requested before
+// the current one's MFMAs; double-buffered LDS, one barrier per iteration.  Bias gradients (column sums of G) are accumulated by the
+// waves that load G, in the workgroups of k-tile 0.  Rows past the slice are clamped on load and zeroed in G only (a zero factor kills
+// the product); columns past K / N are clamped too and only reach accumulators that are never stored.
 #define WGRAD_THREADS 256
 #define WGRAD_WAVES 4
+#define WGRAD_LDT 40                    // halves per transposed column: 32 batch rows + 8 (80 bytes: a quarter-wave's 16 columns hit distinct banks)
+#define WGRAD_PIECE (64 * WGRAD_LDT)    // halves per piece plane [64 columns][WGRAD_LDT]
+#define DENSE_WGRAD_LDS (2 * 2 * 2 * 2 * WGRAD_PIECE * 2)      // [buffer][block][operand][piece] planes: 80 KB, two workgroups per CU
 
 struct WgradLayer {
     const float* X;                     // [batch, K] the layer's input in the training forward
@@ -365,166 +373,183 @@ struct WgradLayer {
     int K, N;
     int out_w, out_b;                   // offsets into a partial (floats)
     int perm_hw, perm_c;                // > 0: column idx = p*perm_c + c of X is weight row c*perm_hw + p (Keras Flatten)
-    int tile0, k_tiles, n_tiles, TK;    // first tile id of this layer, tiling, 16-row MFMA tiles per wave (3 or 4)
-    int vec;                            // K and N multiples of 4: wgrad_tile_vec (one dwordx4 load per operand per step)
+    int tile0, k_tiles, n_tiles;        // first tile id of this layer, tiling in 64 x 64 tiles
 };
 
 struct DenseWgradArgs {
     WgradLayer L[3];
-    int n_layers, batch, rows_per_wave, total_tiles, slices;
+    int n_layers, batch, rows_per_slice, total_tiles, slices;
     float* partial;                     // [slices][pstride]
     size_t pstride;
 };
 
-// One wave's tile on the f16 matrix pipe at f32-class accuracy (f16x2, qnet.h).  The batch is the reduction index, so lane (kb, i)
-// supplies rows m + 8kb .. m + 8kb + 7 of its columns: eight loads per operand per 32 batch rows.  Each 16-column tile operand is
-// split ONCE into two f16 pieces and used by every tile of the other operand: TK x 4 x 3 K = 32 MFMAs (0.8K pipe cycles at
-// TK = 4) per 32 rows instead of 8 x TK x 4 f32 K = 4 ones (4.1K).  Rows past the slice are clamped on load and zeroed in G only (a
-// zero factor kills the product; the bias sums need G anyway).
-//   VEC (K and N multiples of 4): column tiles INTERLEAVED -- k-tile ti, lane i is weight row kbase + 4i + ti and n-tile tj, lane j is
-//   column nbase + 4j + tj -- so a lane's four X values (and four G values) of a batch row are ONE dwordx4 load;
-//   otherwise: tile t, lane i is column base + 16t + i, scalar loads (clamped columns only reach accumulators that are never stored).
-// A block's raw rows are split into pieces first; the next block's loads then fly under the current block's MFMAs.
-template <int TK, bool VEC>
-__device__ __forceinline__ void wgrad_tile(const WgradLayer& L, int local, int slice, int batch, int rows_per_wave, float* __restrict__ out,
-                                           float* s_part, float* s_bias) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
-    const int kt = local / L.n_tiles, nt = local - kt * L.n_tiles;
-    const int kbase = kt * 16 * TK, nbase = nt * 64;
-    const int K = L.K, N = L.N;
-    const int m0 = (slice * WGRAD_WAVES + wave) * rows_per_wave, m1 = min(batch, m0 + rows_per_wave);
-    static_assert(!VEC || TK == 4, "the interleaved layout takes four k-tiles");
-    int kcol[VEC ? 1 : TK], ncol[VEC ? 1 : 4];
-    if constexpr (VEC) {
-        kcol[0] = kbase + 4 * j < K ? kbase + 4 * j : 0;          // whole quads: K, N are multiples of 4
-        ncol[0] = nbase + 4 * j < N ? nbase + 4 * j : 0;
-    } else {
-#pragma unroll
-        for (int ti = 0; ti < TK; ++ti) kcol[ti] = kbase + 16 * ti + j < K ? kbase + 16 * ti + j : 0;
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) ncol[tj] = nbase + 16 * tj + j < N ? nbase + 16 * tj + j : 0;
-    }
-    float nmask[4];                                                 // scalar layout: the bias sums must not see a clamped column's values
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj) nmask[tj] = (VEC || nbase + 16 * tj + j < N) ? 1.f : 0.f;
-    f32x4 acc[TK][4], accx[TK][4];                                  // leading products / 2^11-scaled cross terms
-#pragma unroll
-    for (int ti = 0; ti < TK; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) { acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[ti][tj] = acc[ti][tj]; }
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    float xr[TK][8], gr[4][8];                                      // raw values [tile][row] of one 32-row block
-    auto load = [&](int m) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int rc = min(m + 8 * kq + e, m1 - 1);
-            if constexpr (VEC) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(L.X + (size_t)rc * K + kcol[0]);
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(L.G + (size_t)rc * N + ncol[0]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { xr[t][e] = xv[t]; gr[t][e] = gv[t]; }
-            } else {
-                const float* xp = L.X + (size_t)rc * K;
-                const float* gp = L.G + (size_t)rc * N;
-#pragma unroll
-                for (int ti = 0; ti < TK; ++ti) xr[ti][e] = xp[kcol[ti]];
-#pragma unroll
-                for (int tj = 0; tj < 4; ++tj) gr[tj][e] = gp[ncol[tj]];
-            }
-        }
-    };
-    load(m0);
-    for (int m = m0; m < m1; m += 32) {
-        // split this block's raw rows into pieces (the raw registers are dead after that) ...
-        F16x2 xa[TK], gb[4];
-#pragma unroll
-        for (int ti = 0; ti < TK; ++ti)
-            xa[ti] = split_f16x2(f32x4{xr[ti][0], xr[ti][1], xr[ti][2], xr[ti][3]}, f32x4{xr[ti][4], xr[ti][5], xr[ti][6], xr[ti][7]});
-        const bool tail = m + 32 > m1;                              // wave-uniform
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-            float g[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = tail ? gr[tj][e] * (m + 8 * kq + e < m1 ? 1.f : 0.f) : gr[tj][e];
-            float bs = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bs += g[e];
-            bsum[tj] += VEC ? bs : bs * nmask[tj];
-            gb[tj] = split_f16x2(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
-        }
-        // ... request the next block's rows into them (past the slice: clamped rows, never multiplied) ...
-        __builtin_amdgcn_sched_barrier(0);
-        load(m + 32);
-        __builtin_amdgcn_sched_barrier(0);                           // (left alone, the scheduler sinks the loads to just before their use)
-        // ... and multiply: two accumulators per tile, 4 TK independent chains interleaved, three passes
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-#pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = acc[ti][tj]; c = MFMA_F16(xa[ti].h, gb[tj].h, c); }
-#pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = accx[ti][tj]; c = MFMA_F16(xa[ti].h, gb[tj].l, c); }
-#pragma unroll
-            for (int ti = 0; ti < TK; ++ti) { f32x4& c = accx[ti][tj]; c = MFMA_F16(xa[ti].l, gb[tj].h, c); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- combine the workgroup's four slices in fixed order, write one partial.  C/D layout: this lane holds rows 4kq + r of each
-    //      16 x 16 tile; VEC: local weight row 4 (4kq + r) + ti, column 4j + tj; else row 16ti + 4kq + r, column 16tj + j ----------------
-    float* sp = s_part + wave * (64 * 64);
-#pragma unroll
-    for (int ti = 0; ti < TK; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f16x2_sum(acc[ti][tj], accx[ti][tj]);
-#pragma unroll
-    for (int ti = 0; ti < TK; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if constexpr (VEC) {
-                *reinterpret_cast<f32x4*>(sp + (4 * (4 * kq + r) + ti) * 64 + 4 * j) = f32x4{acc[ti][0][r], acc[ti][1][r], acc[ti][2][r], acc[ti][3][r]};
-            } else {
-#pragma unroll
-                for (int tj = 0; tj < 4; ++tj) sp[(16 * ti + 4 * kq + r) * 64 + 16 * tj + j] = acc[ti][tj][r];
-            }
-        }
-    if (kt == 0) {
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-            float v = bsum[tj];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (kq == 0) s_bias[wave * 64 + (VEC ? 4 * j + tj : 16 * tj + j)] = v;
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < 16 * TK * 64; e += WGRAD_THREADS) {
-        const float v = (s_part[e] + s_part[4096 + e]) + (s_part[8192 + e] + s_part[12288 + e]);
-        const int k = kbase + (e >> 6), n = nbase + (e & 63);
-        if (k < K && n < N) {
-            int row = k;
-            if (L.perm_hw > 0) { const int p = k / L.perm_c, c = k - p * L.perm_c; row = c * L.perm_hw + p; }
-            out[L.out_w + (size_t)row * N + n] = v;
-        }
-    }
-    if (kt == 0 && tid < 64 && nbase + tid < N)
-        out[L.out_b + nbase + tid] = (s_bias[tid] + s_bias[64 + tid]) + (s_bias[128 + tid] + s_bias[192 + tid]);
+// rows per batch slice (a multiple of 64: whole iterations) and the number of slices, at most DENSE_WGRAD_SLICES
+#define DENSE_WGRAD_SLICES 8
+static void wgrad_slicing(int B, int* rows_per_slice, int* slices) {
+    int rps = (B + DENSE_WGRAD_SLICES - 1) / DENSE_WGRAD_SLICES;
+    rps = (rps + 63) & ~63;
+    *rows_per_slice = rps;
+    *slices = (B + rps - 1) / rps;
 }
 
 __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    float* s_part = reinterpret_cast<float*>(smem);                  // [4][64*64]
-    float* s_bias = s_part + WGRAD_WAVES * 64 * 64;                 // [4][64]
+    unsigned short* s_t = reinterpret_cast<unsigned short*>(smem);   // [buf][blk][op][piece][64][WGRAD_LDT]
     // XCD-aware block -> (tile, slice) map: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of one batch
     // slice are given to ONE XCD (slice = XCD + 8 i): the slice's rows of X and G are then fetched from HBM/MALL once instead of
-    // once per XCD (measured before: 31 MB fetched per launch for 15 MB of operands).
+    // once per XCD.
     const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
     const int slice = xcd + 8 * (within / a.total_tiles), tile = within % a.total_tiles;
     if (slice >= a.slices) return;                                  // block-uniform
     int l = 0;
     while (l + 1 < a.n_layers && tile >= a.L[l + 1].tile0) ++l;     // block-uniform
+    const WgradLayer& L = a.L[l];
+    const int local = tile - L.tile0, kt = local / L.n_tiles, nt = local - kt * L.n_tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kb = lane >> 4;
+    const int K = L.K, N = L.N, kbase = 64 * kt, nbase = 64 * nt;
+    const int m0 = slice * a.rows_per_slice, m1 = min(a.batch, m0 + a.rows_per_slice);
+    const int n_it = (m1 - m0 + 63) >> 6;
+    // ---- loader role of this wave: operand (0: X, 1: G) and block of the iteration -----------------------------------------
+    const int op = wave & 1, lblk = wave >> 1;
+    const float* src = op ? L.G : L.X;
+    const int ld = op ? N : K, cbase = (op ? nbase : kbase) + 4 * j, ncols = op ? N : K;
+    const bool vec = (ncols & 3) == 0;                              // whole quads inside or outside; rows 16-byte aligned relative to the base
+    int coff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) coff[c] = cbase + c < ncols ? cbase + c : 0;
+    float rawA[8][4], rawB[8][4];                                   // two iterations of rows in flight
+    auto load = [&](int it_, float (&raw)[8][4]) {
+        const int it = min(it_, n_it - 1);                          // past the end: re-read the last rows (unconditional loads: static wait counts)
+        const int r0 = m0 + 64 * it + 32 * lblk + 8 * kb;
+        if (vec) {                                                  // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(src + (size_t)min(r0 + e, m1 - 1) * ld + coff[0]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) raw[e][c] = v[c];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* rp = src + (size_t)min(r0 + e, m1 - 1) * ld;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) raw[e][c] = rp[coff[c]];
+            }
+        }
+    };
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto store = [&](int it, const float (&raw)[8][4]) {            // split this lane's 8 rows x 4 columns, transposed 16-byte stores
+        const int r0 = m0 + 64 * it + 32 * lblk + 8 * kb;
+        const bool tail = r0 + 8 > m1;
+        unsigned short* dst = s_t + ((((it & 1) * 2 + lblk) * 2 + op) * 2) * WGRAD_PIECE + (4 * j) * WGRAD_LDT + 8 * kb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (op && tail) ? raw[e][c] * (r0 + e < m1 ? 1.f : 0.f) : raw[e][c];
+            if (op) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bs[c] += v[e];
+            }
+            const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+            *reinterpret_cast<u32x4*>(dst + c * WGRAD_LDT) = o.h;
+            *reinterpret_cast<u32x4*>(dst + c * WGRAD_LDT + WGRAD_PIECE) = o.l;
+        }
+    };
+    f32x4 acc[2][2], accx[2][2];                                    // [k tile][n tile]: leading products / 2^11-scaled cross terms
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) { acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[ta][tb] = acc[ta][tb]; }
+    const int arow = (32 * (wave >> 1) + j) * WGRAD_LDT + 8 * kb, brow = (32 * (wave & 1) + j) * WGRAD_LDT + 8 * kb;
+    DQ_STAMP(DQ_TAG_DENSE_WGRAD, 0);
+    DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 0);
+    auto mm = [&](int it) {                                         // the iteration's two blocks: 8 ds_read_b128 + 12 MFMAs each
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const unsigned short* px = s_t + (((it & 1) * 2 + blk) * 2 + 0) * 2 * WGRAD_PIECE + arow;
+            const unsigned short* pg = s_t + (((it & 1) * 2 + blk) * 2 + 1) * 2 * WGRAD_PIECE + brow;
+            F16x2 xa[2], gb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xa[t].h = *reinterpret_cast<const u32x4*>(px + 16 * t * WGRAD_LDT);
+                xa[t].l = *reinterpret_cast<const u32x4*>(px + 16 * t * WGRAD_LDT + WGRAD_PIECE);
+                gb[t].h = *reinterpret_cast<const u32x4*>(pg + 16 * t * WGRAD_LDT);
+                gb[t].l = *reinterpret_cast<const u32x4*>(pg + 16 * t * WGRAD_LDT + WGRAD_PIECE);
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) mma_f16x3(xa[ta], gb[tb], acc[ta][tb], accx[ta][tb]);
+        }
+    };
+    // one step: this iteration's rows (requested two iterations ago) -> pieces in LDS; request the rows of iteration it + 2 into the
+    // registers just freed; meet; multiply.  (No condition around the MFMAs: the loop leaves between steps.)
+    auto step = [&](int it, float (&raw)[8][4]) {
+        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 1 + 3 * it);
+        store(it, raw);
+        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 2 + 3 * it);
+        __builtin_amdgcn_sched_barrier(0);
+        load(it + 2, raw);
+        __builtin_amdgcn_sched_barrier(0);                          // (left alone, the scheduler sinks the loads to just before their use)
+        __syncthreads();
+        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 3 + 3 * it);
+        mm(it);
+    };
+    load(0, rawA);
+    load(1, rawB);
+    for (int it = 0;;) {
+        step(it, rawA); if (++it >= n_it) break;
+        step(it, rawB); if (++it >= n_it) break;
+    }
+    DQ_STAMP(DQ_TAG_DENSE_WGRAD, 1 + 3 * n_it);
+    // ---- one partial per (slice, tile): the tile goes through LDS (C/D layout: this lane holds rows 4kb + r of column j of each 16 x 16
+    //      tile) so that it leaves as whole 256-byte weight rows ------------------------------------------------------------------
     float* out = a.partial + (size_t)slice * a.pstride;
-    if (a.L[l].vec) wgrad_tile<4, true>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
-    else if (a.L[l].TK == 3) wgrad_tile<3, false>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
-    else wgrad_tile<4, false>(a.L[l], tile - a.L[l].tile0, slice, a.batch, a.rows_per_wave, out, s_part, s_bias);
+    __syncthreads();                                                // every wave is done with the operand planes
+    float* s_o = reinterpret_cast<float*>(smem) + 128;              // [64][68] behind the bias scratch
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s_o[(32 * (wave >> 1) + 16 * ta + 4 * kb + r) * 68 + 32 * (wave & 1) + 16 * tb + j] = f16x2_sum(acc[ta][tb][r], accx[ta][tb][r]);
+    __syncthreads();
+    {
+        const int c4 = 4 * (tid & 15);
+        const bool nvec = (N & 3) == 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kr = (tid >> 4) + 16 * q, k = kbase + kr;
+            if (k >= K) continue;
+            int row = k;
+            if (L.perm_hw > 0) { const int pp = k / L.perm_c, c = k - pp * L.perm_c; row = c * L.perm_hw + pp; }
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_o + kr * 68 + c4);
+            float* o = out + L.out_w + (size_t)row * N + nbase + c4;
+            if (nvec) { if (nbase + c4 < N) *reinterpret_cast<f32x4u*>(o) = v; }
+            else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (nbase + c4 + c < N) o[c] = v[c];
+            }
+        }
+    }
+    if (kt == 0) {                                                  // block-uniform: bias gradient = column sums of G over the slice
+        float* s_bias = reinterpret_cast<float*>(smem);             // [2 loader waves][64] (free since the barrier above)
+        if (op) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = bs[c];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (kb == 0) s_bias[lblk * 64 + 4 * j + c] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < 64 && nbase + tid < N) out[L.out_b + nbase + tid] = s_bias[tid] + s_bias[64 + tid];
+    }
+    DQ_STAMP(DQ_TAG_DENSE_WGRAD, 2 + 3 * n_it);
+    DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 1);
 }
 
 // Fixed-order reduction of both partial sets in one launch: out[i] = sum_s partial[s * stride + i].
@@ -1022,8 +1047,6 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
 }
 
 #define CONV_BWD_MAX_WGS 256
-#define DENSE_WGRAD_SLICES 8
-#define DENSE_WGRAD_LDS ((WGRAD_WAVES * 64 * 64 + WGRAD_WAVES * 64) * 4)
 
 bool fused_backward_supported(const dq_qnet* Q) {
     DenseBwdPlan dp;
@@ -1127,15 +1150,12 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         W.X = Q->act[0][nc + l - 1]; W.G = Q->gz[nc + l]; W.K = L.K; W.N = L.N;
         W.out_w = (int)L.w_off; W.out_b = (int)L.b_off;
         if (l == 0) { W.perm_hw = Q->flat_hw; W.perm_c = Q->flat_c; }
-        W.vec = (L.K % 4 == 0 && L.N % 4 == 0) ? 1 : 0;
-        W.TK = W.vec ? 4 : (L.K % 48 == 0) ? 3 : 4;
-        W.k_tiles = (L.K + 16 * W.TK - 1) / (16 * W.TK); W.n_tiles = (L.N + 63) / 64;
+        W.k_tiles = (L.K + 63) / 64; W.n_tiles = (L.N + 63) / 64;
         W.tile0 = tiles; tiles += W.k_tiles * W.n_tiles;
     }
-    int rpw = (B + DENSE_WGRAD_SLICES * WGRAD_WAVES - 1) / (DENSE_WGRAD_SLICES * WGRAD_WAVES);
-    rpw = (rpw + 7) & ~7;
-    const int sy = (B + rpw * WGRAD_WAVES - 1) / (rpw * WGRAD_WAVES);
-    wa.rows_per_wave = rpw; wa.partial = dense_partial; wa.pstride = Q->n_params;
+    int rps, sy;
+    wgrad_slicing(B, &rps, &sy);
+    wa.rows_per_slice = rps; wa.partial = dense_partial; wa.pstride = Q->n_params;
     dq_prof_begin(DQ_K_DENSE_WGRAD, st);
     wa.total_tiles = tiles; wa.slices = sy;
     dense_wgrad_kernel<<<8 * tiles * ((sy + 7) / 8), WGRAD_THREADS, DENSE_WGRAD_LDS, st>>>(wa);
@@ -1184,9 +1204,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0, 0};
     const int blocks0 = ((int)conv_floats + 63) / 64;
     if (phases == 3) {
-        int rpw = (B + DENSE_WGRAD_SLICES * WGRAD_WAVES - 1) / (DENSE_WGRAD_SLICES * WGRAD_WAVES);
-        rpw = (rpw + 7) & ~7;
-        const int sy = (B + rpw * WGRAD_WAVES - 1) / (rpw * WGRAD_WAVES);
+        int rps, sy;
+        wgrad_slicing(B, &rps, &sy);
         ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, blocks0, (int)conv_floats};
         reduce_slices_kernel<<<blocks0 + (n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
     } else {

@@ -33,6 +33,8 @@ struct dq_qnet {
     void* pk_scratch[FWD_MAX_JOBS];  // packed weights of jobs that did not bring their own (dq_qnet_job.packed_dev == NULL)
     const void* last_train_packed;   // packed weights of the last training forward (the backward's data gradients read them)
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
+    unsigned short* planes;      // f16 piece planes (h plane, then l plane) of the training forward's / backward's operands of the dense
+                                 // weight gradients, row-major [max_batch][ld]: x (ld K1), h1 (512), gh1 (512), in this order
     float grad_scale_hint;       // dq_qnet_set_grad_scale: loss scale of caller-supplied dq (0 = unknown: measured on the device)
     float bwd_scale;             // fused backward: power-of-two scale the gradients of the last dense phase carry (0: the device-computed one)
     int use_fused;               // fused LDS-resident chains when the configuration allows it
@@ -146,10 +148,17 @@ struct ConvJob {
 #define PK_CONV2_DG (PK_CONV3_DG + 8 * PK_BLOCK)
 #define PK_CONV1 (PK_CONV2_DG + 16 * PK_BLOCK)
 #define PK_TOTAL_BLOCKS 60
-#define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)     // the conv sections; then PK_DENSE1 [K1/32 k-blocks][32 column tiles];
-// then (f32, for the backward's data gradients) W1T [512][K1] and W2T [N2][512], each section 16-byte aligned:
-//   B(k = 32 blk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3)) = W1[k][col]
+#define PK_TOTAL_U32X4 (PK_TOTAL_BLOCKS * PK_BLOCK)     // the conv sections; then the dense sections (PackLayout, blocks of PK_BLOCK):
+//   dense1   [K1/32 k-blocks][32 column tiles]   B(k' = 32 blk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3)) = W1[row(k')][col]     forward, Dense(512);
+//            k' runs in the input rows' own NHWC order, row(k') = the Keras Flatten row c*hw + p of k' = p*C + c
+//   dense2   [16][NT2]                           B(k = 32 blk + 8kb + e, col = NT2 j + t) = W2[k][col], 0 past N2                forward, Dense(|A|)
+//   dense2t  [KB2][32]                           B(n2 = 32 blk + 8kb + e, n1 = 64 (ct>>2) + 4j + (ct&3)) = W2[n1][n2], 0 past N2   backward, gH1
+//   dense1t  [16][K1/16]                         B(n1 = 32 blk + 8kb + e, k' = 16 ct + j) = W1[row(k')][n1]                         backward, gX
+struct PackLayout { size_t dense1, dense2, dense2t, dense1t, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2; };   // offsets in u32x4
+PackLayout fused_pack_layout(const dq_qnet* Q);
 size_t fused_packed_u32x4(const dq_qnet* Q);
+size_t fused_packed_w1t_u32x4(const dq_qnet* Q);           // u32x4 offset of the f32 transpose W1T behind the pieces
+size_t fused_packed_w2t_u32x4(const dq_qnet* Q);           // ... of W2T
 dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* packed_dev, hipStream_t st);
 
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
@@ -161,8 +170,6 @@ dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_
 // fused_bwd.hip: fused backward (data-gradient chains + all-layer weight gradients) for the same configurations
 bool fused_backward_supported(const dq_qnet* Q);
 size_t fused_backward_workspace_floats(const dq_qnet* Q);
-size_t fused_packed_w1t_u32x4(const dq_qnet* Q);           // u32x4 offset of W1T inside a packed buffer
-size_t fused_packed_w2t_u32x4(const dq_qnet* Q);           // ... of W2T
 // opt != NULL (phases == 3 only): the final reduction also applies the Adam update to p/m/v (one launch fewer per update)
 struct AdamOpt { float* p; float* m; float* v; float lr_t, b1, b2, eps; };
 // td != NULL: the TD step (dq_td_update's arithmetic) runs in the dense backward's prologue instead of reading dq_dev, and the episode

@@ -413,6 +413,10 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         const size_t xf = (size_t)cfg->max_batch * Q->L[cfg->n_conv].nin;
         for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->xinf[i], xf * sizeof(float));
     }
+    if (e == hipSuccess && fused_forward_supported(Q)) {            // piece planes x | h1 | gh1 (qnet.h)
+        const size_t halves = (size_t)2 * cfg->max_batch * (Q->L[cfg->n_conv].nin + 2 * DENSE_HID);
+        e = hipMalloc(&Q->planes, halves * sizeof(unsigned short));
+    }
     const size_t fws = fused_backward_workspace_floats(Q);
     if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));
     Q->partial_floats = max_partial;
@@ -428,6 +432,7 @@ void dq_qnet_destroy(dq_qnet* Q) {
     for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->gz[i]) (void)hipFree(Q->gz[i]);
     if (Q->partial) (void)hipFree(Q->partial);
     if (Q->fpartial) (void)hipFree(Q->fpartial);
+    if (Q->planes) (void)hipFree(Q->planes);
     if (Q->kofftab) (void)hipFree(Q->kofftab);
     for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->pk_scratch[i]) (void)hipFree(Q->pk_scratch[i]);
     for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->xinf[i]) (void)hipFree(Q->xinf[i]);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instrumented builds for tools/stamp_run.py: tools/probe/stamps/s<tag>.so = the library with -DDQ_STAMPS=<tag> in the file that
-# carries that tag's stamps (1, 2, 11, 12, 20: fused.hip; 3, 4, 13, 14: fused_bwd.hip); the other objects are the regular build's.
+# carries that tag's stamps (1, 2, 11, 12, 20: fused.hip; 3, 4, 5, 13, 14, 15: fused_bwd.hip); the other objects are the regular build's.
 # Usage: tools/build_stamps.sh 1 2 3 4      then on the GPU box: DQ_LIB_PATH=tools/probe/stamps/s4.so python tools/stamp_run.py 4
 set -e
 root="$(cd "$(dirname "$0")/.." && pwd)"; cd "$root"

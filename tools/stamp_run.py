@@ -56,6 +56,11 @@ elif tag == 4:
         print("wave", w, "group 1:", [t[i + 1] - t[i] for i in range(11)], " group 2:", [t2[i + 1] - t2[i] for i in range(11)],
               " wait part of stage:", buf[11 * 8 + w] - t[0], buf[23 * 8 + w] - t2[0])
     print(names)
+elif tag == 5:
+    for w in range(4):
+        t = [buf[i * 8 + w] for i in range(27)]
+        print("wave", w, "per iteration [wait+split+store, issue+barrier, mfma]:", [[t[1 + 3 * i + k + 1] - t[1 + 3 * i + k] for k in range(3)] for i in range(8)],
+              "first", t[1] - t[0], "epilogue", t[26] - t[25], "total", t[26] - t[0])
 elif tag == 1:
     for w in range(4):
         t = [buf[i * 8 + w] for i in range(8)]
