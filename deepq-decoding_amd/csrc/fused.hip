@@ -704,7 +704,7 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];
     PackLayout P;
     P.NT2 = D2.nout <= 64 ? 4 : 8;
-    P.KB2 = (D2.nout + 31) / 32;
+    P.KB2 = D2.nout <= 64 ? 2 : 4;                                  // gH1's K in blocks of 32, zero-padded (a compile-time count in the kernel)
     P.d1_blocks = (D1.nin >> 5) * 32; P.d2_blocks = 16 * P.NT2; P.d2t_blocks = P.KB2 * 32; P.d1t_blocks = 16 * (D1.nin >> 4);
     P.dense1 = PK_TOTAL_U32X4;
     P.dense2 = P.dense1 + (size_t)P.d1_blocks * PK_BLOCK;

@@ -14,14 +14,13 @@
 
 DQ_STAMP_READER(dq_dbg_read_bwd)
 
-// The data gradients multiply by W^T.  With W row-major, the 16 lanes of a quarter-wave that supply 16 different output
-// columns of an MFMA B operand would read 16 different rows of W -- 16 cache lines per quarter-wave request, which makes the
-// vector L1's tag path (not the matrix pipe) the bound.  So dq_qnet_pack also writes the f32 transposes W1T [512][K1] and
-// W2T [N2][512] behind the bf16 pieces (same launch), and the chains below read those with row-contiguous vector loads.
+// The data gradients multiply by W^T.  dq_qnet_pack writes W2^T and W1^T as f16 pieces in MFMA operand order (qnet.h dense2t / dense1t,
+// the Keras Flatten permutation folded into dense1t's columns), so both run on the f16 pipe (f16x2) with one coalesced 16-byte load per
+// lane, tile and piece; the gradients they multiply are split ONCE, when they are produced, into f16 piece planes in LDS.
 struct DenseBwdArgs {
     const float* params;
-    const float* w1t;                   // [512][K1] transposed hidden-layer kernel
-    const float* w2t;                   // [N2][512] transposed Dense(|A|) kernel
+    const u32x4* packed;                // f16 pieces of the training forward's weights (qnet.h)
+    int pk_dense2t, pk_dense1t, KB2;    // u32x4 offsets of the transposed dense sections; K = 32 blocks of gH1's reduction (N2 padded)
     const float* dq;                    // [batch, n_actions]
     const float* h1;                    // saved hidden output (post ReLU + dropout): mask of gH1
     const float* x;                     // saved last-convolution output [batch, K1] (NHWC): mask of gX
@@ -32,8 +31,10 @@ struct DenseBwdArgs {
     float* g3;                          // [batch, N3] (NULL without a dueling layer)
     float* gy2;                         // [batch, N2]
     float* gh1;                         // [batch, 512]
+    unsigned short* gh1_pl;             // the same as f16 piece planes [2][plane_rows][512] (the weight gradient's operand)
+    int plane_rows;
     float* gx;                          // [batch, K1] NHWC
-    int ldg;                            // LDS row stride of the g3 / gY2 images (floats)
+    int ldg;                            // LDS row stride of the g3 image (floats); the gY2 planes have rows of 32 KB2 + 8 halves
     int off_g3, off_gy2, off_gh1;
     float gs;                           // every gradient of the fused backward is carried scaled by this power of two (GradScale below) ...
     const float* gs_dev;                // ... or, when not NULL, by gs_dev[0] (computed on the device from max |dq|)
@@ -64,57 +65,104 @@ __global__ __launch_bounds__(1024) void grad_scale_kernel(const float* __restric
     }
 }
 
-// NTP adjacent column tiles [tile0, tile0 + NTP) of gX for this wave: tile t, lane j is column 16*tile0 + NTP*j + t, so the lane's
-// NTP weights of a W1T row are NTP consecutive floats (one dwordx2/x3 load, 4-byte aligned); weights double-buffered.
+// NTP adjacent column tiles [tile0, tile0 + NTP) of gX = (gH1 W1^T) * [x > 0] for this wave, on the f16 pipe: K = 512 in 16 blocks; A = the
+// gH1 piece planes in LDS (one ds_read_b128 per piece and block, shared by the tiles), B = dense1t pieces streamed through a ring of three
+// blocks (the kernel is bound by this stream: every workgroup reads all of W1^T through the CU's vector-memory path).  Column 16 tile + j
+// is the NHWC offset itself (the permutation lives in the packed columns), so masks and results are 64-byte row segments.
 template <int NTP>
-__device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const float* __restrict__ s_gh1, int tile0, int b0, int ns, int lane) {
-    typedef float vec_t __attribute__((ext_vector_type(NTP == 3 ? 3 : NTP == 2 ? 2 : 1), aligned(4)));
-    constexpr int LDH = DENSE_HID + 4, NG = DENSE_HID / 16;
-    const int j = lane & 15, kq = lane >> 4, K1 = a.K1;
-    const float* wp = a.w1t + (size_t)(4 * kq) * K1 + 16 * tile0 + NTP * j;
-    const float* hrow = s_gh1 + j * LDH + 4 * kq;
-    constexpr int RING = 4;                                         // k-groups in the ring, RING-1 in flight (L2 latency >> 12 MFMAs)
-    float bw[RING][4][NTP];
-    auto load = [&](int g, float (&b)[4][NTP]) {
+__device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const unsigned short* __restrict__ s_gh1p, int tile0, int b0, int ns, int lane) {
+    constexpr int LDH = DENSE_HID + 8, NB = DENSE_HID / 32, RING = 3;
+    const int j = lane & 15, kq = lane >> 4, K1 = a.K1, tiles = K1 >> 4;
+    const u32x4* pk = opaque_global(a.packed + a.pk_dense1t + (size_t)tile0 * PK_BLOCK) + lane;
+    const unsigned short* arow = s_gh1p + j * LDH + 8 * kq;
+    F16x2 bw[RING][NTP];
+    auto load = [&](int blk, F16x2 (&b)[NTP]) {
+        const u32x4* pb = pk + (size_t)blk * tiles * PK_BLOCK;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if constexpr (NTP == 1) {
-                b[s][0] = wp[(size_t)(16 * g + s) * K1];
-            } else {
-                const vec_t v = *reinterpret_cast<const vec_t*>(wp + (size_t)(16 * g + s) * K1);
-#pragma unroll
-                for (int t = 0; t < NTP; ++t) b[s][t] = v[t];
-            }
-        }
+        for (int t = 0; t < NTP; ++t) { b[t].h = pb[t * PK_BLOCK]; b[t].l = pb[t * PK_BLOCK + PK_LO]; }
     };
-    f32x4 acc[NTP];
-#pragma unroll
-    for (int t = 0; t < NTP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < RING - 1; ++u) load(u, bw[u]);
-    static_assert(NG % RING == 0, "whole rings");
-    for (int g = 0; g < NG; g += RING) {
+    float xm[NTP][4];                                               // the mask operand x (requested now, used in the epilogue)
 #pragma unroll
-        for (int u = 0; u < RING; ++u) {
-            load(g + u + RING - 1 < NG ? g + u + RING - 1 : NG - 1, bw[(u + RING - 1) % RING]);     // unconditional (clamped): static s_waitcnt counts
-            const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + 16 * (g + u));
+    for (int t = 0; t < NTP; ++t)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+        for (int r = 0; r < 4; ++r) xm[t][r] = a.x[(size_t)(b0 + min(4 * kq + r, ns - 1)) * K1 + 16 * (tile0 + t) + j];
+    f32x4 acc[NTP][2];
 #pragma unroll
-                for (int t = 0; t < NTP; ++t) acc[t] = MFMA16(av[s], bw[u][s][t], acc[t]);
-        }
+    for (int t = 0; t < NTP; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+    static_assert((NB - 1) % RING == 0, "the block loop is unrolled in whole rings plus one");
+    auto block = [&](int blk, int u) {
+        load(min(blk + RING - 1, NB - 1), bw[(u + RING - 1) % RING]);      // unconditional (clamped): static s_waitcnt counts
+        F16x2 av;
+        av.h = *reinterpret_cast<const u32x4*>(arow + 32 * blk);
+        av.l = *reinterpret_cast<const u32x4*>(arow + 32 * blk + DENSE_ROWS * LDH);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) mma_f16x3(av, bw[u][t], acc[t][0], acc[t][1]);
+    };
+    for (int blk = 0; blk + 1 < NB; blk += RING) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) block(blk + u, u);
     }
+    block(NB - 1, 0);
 #pragma unroll
-    for (int t = 0; t < NTP; ++t) {
-        const int k = 16 * tile0 + NTP * j + t;                     // Keras Flatten index c*hw + p  ->  NHWC offset p*C + c
-        int idx = k;
-        if (a.perm_hw > 0) { const int c = k / a.perm_hw, p = k - c * a.perm_hw; idx = p * a.perm_c + c; }
+    for (int t = 0; t < NTP; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * kq + r;
             if (row >= ns) continue;
-            const size_t o = (size_t)(b0 + row) * K1 + idx;
-            a.gx[o] = a.x[o] > 0.f ? acc[t][r] : 0.f;
+            a.gx[(size_t)(b0 + row) * K1 + 16 * (tile0 + t) + j] = xm[t][r] > 0.f ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
+        }
+}
+
+// gH1 = (gY2 W2^T) * [h1 > 0] * scale on the f16 pipe: K = N2 padded to KB2 blocks of 32 (a compile-time count: a register ring indexed by a
+// run-time block number would live in scratch memory); wave w owns columns 64w + 4j + t.  The result is split on write into the piece
+// planes gX and the weight gradients read.
+template <int KB2>
+__device__ __forceinline__ void gh1_phase(const DenseBwdArgs& a, const unsigned short* __restrict__ s_gy2p, unsigned short* __restrict__ s_gh1p,
+                                          int b0, int ns, int wave, int lane) {
+    constexpr int LDH = DENSE_HID + 8, LDY = 32 * KB2 + 8;
+    const int j = lane & 15, kq = lane >> 4;
+    const int c0 = 64 * wave + 4 * j;
+    const u32x4* pk = a.packed + a.pk_dense2t + (size_t)(4 * wave) * PK_BLOCK + lane;
+    F16x2 bw[2][4];                                                 // two blocks in flight (the loop below is fully unrolled: static indices)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { bw[0][t].h = pk[t * PK_BLOCK]; bw[0][t].l = pk[t * PK_BLOCK + PK_LO]; }
+    f32x4 hv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[r] = *reinterpret_cast<const f32x4*>(a.h1 + (size_t)(b0 + min(4 * kq + r, ns - 1)) * DENSE_HID + c0);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+    const unsigned short* grow = s_gy2p + j * LDY + 8 * kq;
+#pragma unroll
+    for (int b = 0; b < KB2; ++b) {
+        if (b + 1 < KB2) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { bw[(b + 1) & 1][t].h = pk[((b + 1) * 32 + t) * PK_BLOCK]; bw[(b + 1) & 1][t].l = pk[((b + 1) * 32 + t) * PK_BLOCK + PK_LO]; }
+        }
+        F16x2 av;
+        av.h = *reinterpret_cast<const u32x4*>(grow + 32 * b);
+        av.l = *reinterpret_cast<const u32x4*>(grow + 32 * b + DENSE_ROWS * LDY);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mma_f16x3(av, bw[b & 1][t], acc[t][0], acc[t][1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kq + r;
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = (hv[r][t] > 0.f && row < ns) ? f16x2_sum(acc[t][0][r], acc[t][1][r]) * a.mask_scale : 0.f;
+        u32 hp[2], lp[2];
+        split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
+        split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
+        *reinterpret_cast<uint2*>(s_gh1p + row * LDH + c0) = uint2{hp[0], hp[1]};
+        *reinterpret_cast<uint2*>(s_gh1p + (DENSE_ROWS + row) * LDH + c0) = uint2{lp[0], lp[1]};
+        if (row < ns) {
+            *reinterpret_cast<f32x4*>(a.gh1 + (size_t)(b0 + row) * DENSE_HID + c0) = v;
+            unsigned short* gp = a.gh1_pl + (size_t)(b0 + row) * DENSE_HID + c0;
+            *reinterpret_cast<uint2*>(gp) = uint2{hp[0], hp[1]};
+            *reinterpret_cast<uint2*>(gp + (size_t)a.plane_rows * DENSE_HID) = uint2{lp[0], lp[1]};
         }
     }
 }
@@ -131,9 +179,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         return;
     }
     float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
-    float* s_gy2 = reinterpret_cast<float*>(smem + a.off_gy2);
-    float* s_gh1 = reinterpret_cast<float*>(smem + a.off_gh1);
-    constexpr int LDH = DENSE_HID + 4;
+    unsigned short* s_gy2p = reinterpret_cast<unsigned short*>(smem + a.off_gy2);    // gY2 as f16 piece planes [2][16][LDY]
+    unsigned short* s_gh1p = reinterpret_cast<unsigned short*>(smem + a.off_gh1);    // gH1 as planes [2][16][LDH]
+    const int LDY = 32 * a.KB2 + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     const int b0 = blockIdx.x * DENSE_ROWS;
     const int ns = min(DENSE_ROWS, a.batch - b0);
@@ -147,7 +195,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 0);
     __shared__ float s_met[DENSE_WAVES][2];
-    for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) { s_g3[i] = 0.f; s_gy2[i] = 0.f; }
+    for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) s_g3[i] = 0.f;
+    for (int i = tid; i < DENSE_ROWS * LDY; i += DENSE_THREADS) reinterpret_cast<u32*>(s_gy2p)[i] = 0u;      // both planes (2 x 16 x LDY halves)
     __syncthreads();
     // ---- (TD step: y = r + gamma (1 - terminal) Q_target(s1)[argmax Q_online(s1)], dq = (Q(s0)[a] - y) * scale at the action taken,
     //      dqn.hip td_update_kernel's arithmetic, one wave per sample) then the dueling backward:
@@ -244,7 +293,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             for (int h = 0; lane + 64 * h < A; ++h) {
                 const int c = lane + 64 * h;
                 const float v = dval(h);
-                s_gy2[row * ldg + c] = v;
+                const _Float16 vh = (_Float16)v, vl = (_Float16)((v - (float)vh) * F16_LO_SCALE);
+                s_gy2p[row * LDY + c] = __builtin_bit_cast(unsigned short, vh);
+                s_gy2p[(DENSE_ROWS + row) * LDY + c] = __builtin_bit_cast(unsigned short, vl);
                 a.gy2[(size_t)b * N2 + c] = v;
             }
         }
@@ -284,7 +335,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * kq + r;
-                    s_gy2[row * ldg + n2] = acc[r];
+                    const _Float16 vh = (_Float16)acc[r], vl = (_Float16)((acc[r] - (float)vh) * F16_LO_SCALE);      // split on write (qnet.h)
+                    s_gy2p[row * LDY + n2] = __builtin_bit_cast(unsigned short, vh);
+                    s_gy2p[(DENSE_ROWS + row) * LDY + n2] = __builtin_bit_cast(unsigned short, vl);
                     if (row < ns) a.gy2[(size_t)(b0 + row) * N2 + n2] = acc[r];
                 }
             }
@@ -292,46 +345,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         __syncthreads();
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 2);
-    // ---- gH1 = (gY2 W2^T) * [h1 > 0] * scale  (K = N2; wave w owns columns 64w + 4j + t) ----------------------------------
-    {
-        const int c0 = 64 * wave + 4 * j;
-        f32x4 b[NT2][4];                                            // B(n2, n1) = W2T[n2][n1]: one float4 = this lane's 4 column tiles
-#pragma unroll
-        for (int g = 0; g < NT2; ++g)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k2 = 16 * g + 4 * kq + s;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a.w2t + (size_t)(k2 < N2 ? k2 : 0) * DENSE_HID + c0);
-                b[g][s] = k2 < N2 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        f32x4 hv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kq + r;
-            hv[r] = row < ns ? *reinterpret_cast<const f32x4*>(a.h1 + (size_t)(b0 + row) * DENSE_HID + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        f32x4 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* grow = s_gy2 + j * ldg + 4 * kq;
-#pragma unroll
-        for (int g = 0; g < NT2; ++g) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(grow + 16 * g);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = MFMA16(av[s], b[g][s][t], acc[t]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kq + r;
-            f32x4 v;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = hv[r][t] > 0.f ? acc[t][r] * a.mask_scale : 0.f;
-            *reinterpret_cast<f32x4*>(s_gh1 + row * LDH + c0) = v;
-            if (row < ns) *reinterpret_cast<f32x4*>(a.gh1 + (size_t)(b0 + row) * DENSE_HID + c0) = v;
-        }
-    }
+    // ---- gH1 (f16x2; K = N2 in 2 or 4 blocks) ---------------------------------------------------------------------------------------
+    if (a.KB2 == 2) gh1_phase<2>(a, s_gy2p, s_gh1p, b0, ns, wave, lane);       // block-uniform
+    else gh1_phase<4>(a, s_gy2p, s_gh1p, b0, ns, wave, lane);
     DQ_STAMP(DQ_TAG_DENSE_BWD, 3);
     __syncthreads();
     DQ_STAMP(DQ_TAG_DENSE_BWD, 4);
@@ -341,9 +357,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         const int tiles = a.K1 >> 4, base = tiles / DENSE_WAVES, extra = tiles - base * DENSE_WAVES;
         int t0 = wave * base + min(wave, extra), left = base + (wave < extra ? 1 : 0);
         while (left > 0) {                                          // wave-uniform
-            if (left >= 3) { gx_pass<3>(a, s_gh1, t0, b0, ns, lane); t0 += 3; left -= 3; }
-            else if (left == 2) { gx_pass<2>(a, s_gh1, t0, b0, ns, lane); t0 += 2; left -= 2; }
-            else { gx_pass<1>(a, s_gh1, t0, b0, ns, lane); t0 += 1; left -= 1; }
+            if (left >= 3) { gx_pass<3>(a, s_gh1p, t0, b0, ns, lane); t0 += 3; left -= 3; }
+            else if (left == 2) { gx_pass<2>(a, s_gh1p, t0, b0, ns, lane); t0 += 2; left -= 2; }
+            else { gx_pass<1>(a, s_gh1p, t0, b0, ns, lane); t0 += 1; left -= 1; }
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 5);
@@ -1008,8 +1024,8 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     P->ldg = 16 * P->NT2 + 4;
     size_t off = 0;
     P->off_g3 = (int)off; off += up16((size_t)DENSE_ROWS * P->ldg * 4);
-    P->off_gy2 = (int)off; off += up16((size_t)DENSE_ROWS * P->ldg * 4);
-    P->off_gh1 = (int)off; off += up16((size_t)DENSE_ROWS * (DENSE_HID + 4) * 4);
+    P->off_gy2 = (int)off; off += up16((size_t)2 * DENSE_ROWS * (32 * (N2 <= 64 ? 2 : 4) + 8) * 2);   // f16 piece planes (K padded to 2 or 4 blocks)
+    P->off_gh1 = (int)off; off += up16((size_t)2 * DENSE_ROWS * (DENSE_HID + 8) * 2);
     P->lds = off;
     return true;
 }
@@ -1091,8 +1107,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     float* gs_slot = conv_partial + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off;       // device-computed {S, 1/S}
     DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
     const u32x4* pkbase = static_cast<const u32x4*>(Q->last_train_packed);
-    const float* w1t = reinterpret_cast<const float*>(pkbase + fused_packed_w1t_u32x4(Q));       // transposed by dq_qnet_pack
-    const float* w2t = reinterpret_cast<const float*>(pkbase + fused_packed_w2t_u32x4(Q));
+    const PackLayout PL = fused_pack_layout(Q);
     const size_t conv_floats = D1.w_off;
     const int n_dense = (int)(Q->n_params - conv_floats);
     if (phases & 1) {
@@ -1111,7 +1126,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     DenseBwdArgs da;
     memset(&da, 0, sizeof(da));
     da.gs = Q->bwd_scale; da.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
-    da.w1t = w1t; da.w2t = w2t;
+    da.packed = pkbase; da.pk_dense2t = (int)PL.dense2t; da.pk_dense1t = (int)PL.dense1t; da.KB2 = PL.KB2;
+    da.plane_rows = Q->cfg.max_batch; da.gh1_pl = Q->planes + (size_t)2 * Q->cfg.max_batch * (D1.nin + DENSE_HID);
     da.params = params_dev; da.dq = dq_dev; da.h1 = Q->act[0][nc]; da.x = Q->act[0][nc - 1];
     da.batch = B; da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
