@@ -9,6 +9,7 @@
 //                            transposed operand's columns) are read as float4.
 // Gradients w.r.t. pre-activations are stored per layer in Q->gz[layer]; weight gradients and the convolutional data gradients
 // still run through qnet.hip's per-layer kernels (layer_wgrad / layer_dgrad).
+#include <type_traits>
 #include "qnet.h"
 #include "env_dev.h"
 
@@ -368,25 +369,43 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients of the dense layers, all layers in ONE launch.  dW[k, n] = sum_b X[b, k] G[b, n]: the batch is the reduction index.
 // Workgroup = 4 waves = one 64 x 64 output tile over one batch slice; wave w owns the 32 x 32 quarter (k half w >> 1, n half w & 1) as
-// 2 x 2 MFMA tiles.  Both operands go through LDS as ready-made f16 pieces (qnet.h), TRANSPOSED -- [column][batch row] -- so that an
-// MFMA operand (lane (kb, i): 8 consecutive batch rows of column i) is ONE ds_read_b128 per piece: the rows of a 32-row block are
-// loaded from global memory, split and stored once per WORKGROUP.  (Until round 2 every wave loaded and split its own 64 + 64 columns:
-// four times the vector-memory traffic -- the kernel's bound -- and four times the splitting arithmetic, with 64 accumulator registers
-// per operand scheme.)  An iteration covers two blocks: waves 0 / 1 load X / G of the first (lane (g, i): rows 8g .. 8g+7 of columns
-// 4i .. 4i+3: eight dwordx4, every row 256 contiguous bytes), waves 2 / 3 of the second; the next iteration's rows are requested before
-// the current one's MFMAs; double-buffered LDS, one barrier per iteration.  Bias gradients (column sums of G) are accumulated by the
-// waves that load G, in the workgroups of k-tile 0.  Rows past the slice are clamped on load and zeroed in G only (a zero factor kills
-// the product); columns past K / N are clamped too and only reach accumulators that are never stored.
+// 2 x 2 MFMA tiles.  Both operands go through LDS as f16 pieces (qnet.h), TRANSPOSED -- [column][batch row] -- so that an MFMA operand
+// (lane (kb, i): 8 consecutive batch rows of column i) is ONE ds_read_b128 per piece: the rows of a 32-row block are loaded from global
+// memory and transposed once per WORKGROUP.  The big operands (Dense(512)'s input x and its gradient gH1, the hidden output h1) arrive
+// as ready-made row-major piece planes, written by the kernels that produced them (fused.hip dense_chain_kernel, dense_bwd_chain_kernel
+// above): a lane loads 8 rows x 8 columns of one piece (eight 16-byte loads) and transposes them with 32 byte-permutes; the small ones
+// (gY2, g3, y2: <= 128 columns) are f32 and split here.  (Round 1: every wave loaded and split its own 64 + 64 columns of f32 from global
+// memory: four times the vector-memory traffic and ~250 VALU per 32 rows and wave.)
+// LDS is what bounds the kernel (SQ counters: with a plain [column][40 halves] image three quarters of its LDS cycles were bank conflicts
+// of the transposing stores -- the lanes of a store are 8 columns apart, a multiple of the 128-byte bank period whatever the padding).
+// The image is therefore SWIZZLED (wgrad_off): 64 bytes per column, two columns per 128-byte line, and the 16-byte slot of (column,
+// 8-row chunk) inside its line XOR-ed with column bits such that both the stores (lanes 8 columns apart) and the reads (16 consecutive
+// columns, one chunk) of any 8 consecutive lanes touch all eight slots: conflict-free both ways.
+// An iteration covers two 32-row blocks: waves 0 / 1 bring X / G of the first, waves 2 / 3 of the second; the rows of two iterations are
+// in flight; double-buffered LDS, one barrier per iteration.  Bias gradients (column sums of G) come out of the matrix pipe as well: a
+// tile whose A operand is all ones.  Rows past the slice are clamped on load and zeroed in G only (a zero factor kills the product);
+// columns past K / N are clamped too and only reach accumulators that are never stored.
 #define WGRAD_THREADS 256
 #define WGRAD_WAVES 4
-#define WGRAD_LDT 40                    // halves per transposed column: 32 batch rows + 8 (80 bytes: a quarter-wave's 16 columns hit distinct banks)
-#define WGRAD_PIECE (64 * WGRAD_LDT)    // halves per piece plane [64 columns][WGRAD_LDT]
-#define DENSE_WGRAD_LDS (2 * 2 * 2 * 2 * WGRAD_PIECE * 2)      // [buffer][block][operand][piece] planes: 80 KB, two workgroups per CU
+#define WGRAD_PIECE 2048                // halves per piece plane: 64 columns x 32 batch rows
+#define DENSE_WGRAD_LDS (2 * 2 * 2 * 2 * WGRAD_PIECE * 2)      // [buffer][block][operand][piece] planes: 64 KB
+
+// halves from a piece plane's start to the 8 rows of chunk `chunk` (0..3) of column `col` (0..63)
+__device__ __forceinline__ int wgrad_off(int col, int chunk) {
+    const int slot = ((((col & 1) ^ (col >> 5)) & 1) << 2) | ((chunk ^ (col >> 1) ^ (col >> 3)) & 3);
+    return (col >> 1) * 64 + slot * 8;
+}
+
+struct WgradOperand {
+    const float* f32;                   // [batch, cols] f32 (cols >= 4), or NULL when the operand comes as piece planes:
+    const unsigned short* planes;       // h plane [plane_rows][cols] then, plane_stride halves further, the l plane (cols a multiple of 8)
+    size_t plane_stride;
+    int cols;
+};
 
 struct WgradLayer {
-    const float* X;                     // [batch, K] the layer's input in the training forward
-    const float* G;                     // [batch, N] gradient w.r.t. the layer's pre-activation output
-    int K, N;
+    WgradOperand X;                     // the layer's input in the training forward
+    WgradOperand G;                     // gradient w.r.t. the layer's pre-activation output
     int out_w, out_b;                   // offsets into a partial (floats)
     int perm_hw, perm_c;                // > 0: column idx = p*perm_c + c of X is weight row c*perm_hw + p (Keras Flatten)
     int tile0, k_tiles, n_tiles;        // first tile id of this layer, tiling in 64 x 64 tiles
@@ -410,7 +429,7 @@ static void wgrad_slicing(int B, int* rows_per_slice, int* slices) {
 
 __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    unsigned short* s_t = reinterpret_cast<unsigned short*>(smem);   // [buf][blk][op][piece][64][WGRAD_LDT]
+    unsigned short* s_t = reinterpret_cast<unsigned short*>(smem);   // [buf][blk][op][piece] swizzled planes
     // XCD-aware block -> (tile, slice) map: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of one batch
     // slice are given to ONE XCD (slice = XCD + 8 i): the slice's rows of X and G are then fetched from HBM/MALL once instead of
     // once per XCD.
@@ -422,115 +441,164 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     const WgradLayer& L = a.L[l];
     const int local = tile - L.tile0, kt = local / L.n_tiles, nt = local - kt * L.n_tiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kb = lane >> 4;
-    const int K = L.K, N = L.N, kbase = 64 * kt, nbase = 64 * nt;
+    const int K = L.X.cols, N = L.G.cols, kbase = 64 * kt, nbase = 64 * nt;
     const int m0 = slice * a.rows_per_slice, m1 = min(a.batch, m0 + a.rows_per_slice);
     const int n_it = (m1 - m0 + 63) >> 6;
     // ---- loader role of this wave: operand (0: X, 1: G) and block of the iteration -----------------------------------------
     const int op = wave & 1, lblk = wave >> 1;
-    const float* src = op ? L.G : L.X;
-    const int ld = op ? N : K, cbase = (op ? nbase : kbase) + 4 * j, ncols = op ? N : K;
-    const bool vec = (ncols & 3) == 0;                              // whole quads inside or outside; rows 16-byte aligned relative to the base
-    int coff[4];
+    const WgradOperand& O = op ? L.G : L.X;
+    const int ld = O.cols, cb0 = op ? nbase : kbase;
+    const bool planes = O.f32 == nullptr;                           // wave-uniform
+    // f32 operand: lane (g = kb, i = j) takes rows 8g .. 8g+7 of columns 4i .. 4i+3;  piece planes: lane (piece = lane >> 5,
+    // g = (lane >> 3) & 3, i = lane & 7) takes rows 8g .. 8g+7 of columns 8i .. 8i+7 of its piece
+    const int lg = planes ? (lane >> 3) & 3 : kb, li = planes ? lane & 7 : j, lpiece = lane >> 5;
+    const float* fsrc = planes ? nullptr : O.f32 + (cb0 + 4 * li + 3 < ld ? cb0 + 4 * li : max(ld - 4, 0));      // a quad that straddles the row's end slides back
+    const int fshift = planes ? 0 : (cb0 + 4 * li + 3 < ld ? 0 : cb0 + 4 * li - max(ld - 4, 0));                  // ... by this many columns (>= 4: wholly outside)
+    const unsigned short* psrc = planes ? O.planes + (size_t)lpiece * O.plane_stride + (cb0 + 8 * li < ld ? cb0 + 8 * li : 0) : nullptr;
+    int woff[8];                                                    // swizzled store offsets of this lane's columns (chunk lg)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) coff[c] = cbase + c < ncols ? cbase + c : 0;
-    float rawA[8][4], rawB[8][4];                                   // two iterations of rows in flight
-    auto load = [&](int it_, float (&raw)[8][4]) {
-        const int it = min(it_, n_it - 1);                          // past the end: re-read the last rows (unconditional loads: static wait counts)
-        const int r0 = m0 + 64 * it + 32 * lblk + 8 * kb;
-        if (vec) {                                                  // wave-uniform
+    for (int c = 0; c < 8; ++c) woff[c] = wgrad_off(planes ? 8 * li + c : 4 * li + (c & 3), lg) + (planes ? lpiece * WGRAD_PIECE : 0);
+    int aoff[2], boff[2];                                           // read offsets of this wave's 2 + 2 tiles (chunk kb)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const f32x4u v = *reinterpret_cast<const f32x4u*>(src + (size_t)min(r0 + e, m1 - 1) * ld + coff[0]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) raw[e][c] = v[c];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float* rp = src + (size_t)min(r0 + e, m1 - 1) * ld;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) raw[e][c] = rp[coff[c]];
-            }
-        }
-    };
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    auto store = [&](int it, const float (&raw)[8][4]) {            // split this lane's 8 rows x 4 columns, transposed 16-byte stores
-        const int r0 = m0 + 64 * it + 32 * lblk + 8 * kb;
-        const bool tail = r0 + 8 > m1;
-        unsigned short* dst = s_t + ((((it & 1) * 2 + lblk) * 2 + op) * 2) * WGRAD_PIECE + (4 * j) * WGRAD_LDT + 8 * kb;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (op && tail) ? raw[e][c] * (r0 + e < m1 ? 1.f : 0.f) : raw[e][c];
-            if (op) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bs[c] += v[e];
-            }
-            const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
-            *reinterpret_cast<u32x4*>(dst + c * WGRAD_LDT) = o.h;
-            *reinterpret_cast<u32x4*>(dst + c * WGRAD_LDT + WGRAD_PIECE) = o.l;
-        }
-    };
-    f32x4 acc[2][2], accx[2][2];                                    // [k tile][n tile]: leading products / 2^11-scaled cross terms
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) { acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[ta][tb] = acc[ta][tb]; }
-    const int arow = (32 * (wave >> 1) + j) * WGRAD_LDT + 8 * kb, brow = (32 * (wave & 1) + j) * WGRAD_LDT + 8 * kb;
+    for (int t = 0; t < 2; ++t) { aoff[t] = wgrad_off(32 * (wave >> 1) + 16 * t + j, kb); boff[t] = wgrad_off(32 * (wave & 1) + 16 * t + j, kb); }
+    float* out = a.partial + (size_t)slice * a.pstride;
+    float* s_o = reinterpret_cast<float*>(smem);                    // the finished tile [64][68], staged for row-wise stores
     DQ_STAMP(DQ_TAG_DENSE_WGRAD, 0);
     DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 0);
-    auto mm = [&](int it) {                                         // the iteration's two blocks: 8 ds_read_b128 + 12 MFMAs each
+    // The whole loop is instantiated per operand format (FMT 0: piece planes, 1: f32) and the wave picks its copy once: with the format
+    // tested inside the loop, the branches' different load counts merge into an unknown number of loads in flight and hipcc waits for
+    // vmcnt(0) before every use -- no prefetch survives.
+    auto run = [&](auto fmt_tag) {
+        constexpr int FMT = decltype(fmt_tag)::value;
+        f32x4 acc[2][2], accx[2][2], accb[2], accbx[2];             // [k tile][n tile]: leading products / 2^11-scaled cross terms; bias tiles
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const unsigned short* px = s_t + (((it & 1) * 2 + blk) * 2 + 0) * 2 * WGRAD_PIECE + arow;
-            const unsigned short* pg = s_t + (((it & 1) * 2 + blk) * 2 + 1) * 2 * WGRAD_PIECE + brow;
-            F16x2 xa[2], gb[2];
+        for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                xa[t].h = *reinterpret_cast<const u32x4*>(px + 16 * t * WGRAD_LDT);
-                xa[t].l = *reinterpret_cast<const u32x4*>(px + 16 * t * WGRAD_LDT + WGRAD_PIECE);
-                gb[t].h = *reinterpret_cast<const u32x4*>(pg + 16 * t * WGRAD_LDT);
-                gb[t].l = *reinterpret_cast<const u32x4*>(pg + 16 * t * WGRAD_LDT + WGRAD_PIECE);
+            for (int tb = 0; tb < 2; ++tb) { acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[ta][tb] = acc[ta][tb]; }
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) { accb[tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accbx[tb] = accb[tb]; }
+        const u32x4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};     // f16 1.0 x 8
+        u32 rawA[8][4], rawB[8][4];                                 // two iterations of rows in flight (f32 values or 8 halves per row)
+        auto load = [&](int it_, u32 (&raw)[8][4]) {
+            const int it = min(it_, n_it - 1);                      // past the end: re-read the last rows (unconditional loads: static wait counts)
+            const int r0 = m0 + 64 * it + 32 * lblk + 8 * lg;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const size_t ro = (size_t)min(r0 + e, m1 - 1) * ld;
+                if constexpr (FMT == 0) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(psrc + ro);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) raw[e][c] = v[c];
+                } else {
+                    const f32x4u v = *reinterpret_cast<const f32x4u*>(fsrc + ro);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) raw[e][c] = __float_as_uint(v[c]);
+                }
             }
+        };
+        auto store_rows = [&](int it, const u32 (&raw)[8][4], auto tail_tag) {     // this lane's 8 rows, transposed: one 16-byte store per column and piece
+            constexpr bool tail = decltype(tail_tag)::value;        // rows of G past the slice are zeros
+            const int r0 = m0 + 64 * it + 32 * lblk + 8 * lg;
+            unsigned short* base = s_t + ((((it & 1) * 2 + lblk) * 2 + op) * 2) * WGRAD_PIECE;
+            if constexpr (FMT == 0) {
 #pragma unroll
-            for (int ta = 0; ta < 2; ++ta)
+                for (int c = 0; c < 8; ++c) {
+                    u32x4 o;
 #pragma unroll
-                for (int tb = 0; tb < 2; ++tb) mma_f16x3(xa[ta], gb[tb], acc[ta][tb], accx[ta][tb]);
+                    for (int d = 0; d < 4; ++d) {
+                        u32 lo = raw[2 * d][c >> 1], hi = raw[2 * d + 1][c >> 1];
+                        if constexpr (tail) { lo = r0 + 2 * d < m1 ? lo : 0u; hi = r0 + 2 * d + 1 < m1 ? hi : 0u; }
+                        o[d] = __builtin_amdgcn_perm(hi, lo, (c & 1) ? 0x07060302u : 0x05040100u);
+                    }
+                    *reinterpret_cast<u32x4*>(base + woff[c]) = o;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        // column c of this lane's quad; a quad that slid back holds it fshift places further (or not at all: zero)
+                        const int cs = c + fshift;
+                        float x = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x = cs == q ? __uint_as_float(raw[e][q]) : x;
+                        v[e] = (tail && r0 + e >= m1) ? 0.f : x;
+                    }
+                    const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+                    *reinterpret_cast<u32x4*>(base + woff[c]) = o.h;
+                    *reinterpret_cast<u32x4*>(base + woff[c] + WGRAD_PIECE) = o.l;
+                }
+            }
+        };
+        auto store = [&](int it, const u32 (&raw)[8][4]) {
+            // only the block that straddles the end of the slice masks rows -- a WAVE-uniform test (a per-lane one turns every select into a branch)
+            if (op && m0 + 64 * it + 32 * lblk + 32 > m1) store_rows(it, raw, std::true_type{});
+            else store_rows(it, raw, std::false_type{});
+        };
+        auto mm = [&](int it) {                                     // the iteration's two blocks: 8 ds_read_b128 + 16 MFMAs each
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const unsigned short* px = s_t + (((it & 1) * 2 + blk) * 2 + 0) * 2 * WGRAD_PIECE;
+                const unsigned short* pg = s_t + (((it & 1) * 2 + blk) * 2 + 1) * 2 * WGRAD_PIECE;
+                F16x2 xa[2], gb[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    xa[t].h = *reinterpret_cast<const u32x4*>(px + aoff[t]);
+                    xa[t].l = *reinterpret_cast<const u32x4*>(px + aoff[t] + WGRAD_PIECE);
+                    gb[t].h = *reinterpret_cast<const u32x4*>(pg + boff[t]);
+                    gb[t].l = *reinterpret_cast<const u32x4*>(pg + boff[t] + WGRAD_PIECE);
+                }
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb) mma_f16x3(xa[ta], gb[tb], acc[ta][tb], accx[ta][tb]);
+                // column sums of G (every wave: a condition around an MFMA makes hipcc copy accumulators; only k-tile 0 stores them)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) { accb[tb] = MFMA_F16(ones, gb[tb].h, accb[tb]); accbx[tb] = MFMA_F16(ones, gb[tb].l, accbx[tb]); }
+            }
+        };
+        // one step: this iteration's rows (requested two iterations ago) -> pieces in LDS; request the rows of iteration it + 2 into the
+        // registers just freed; meet; multiply.  (No condition around the MFMAs: the loop leaves between steps.)
+        auto step = [&](int it, u32 (&raw)[8][4]) {
+            DQ_STAMP(DQ_TAG_DENSE_WGRAD, 1 + 3 * min(it, 7));
+            store(it, raw);
+            DQ_STAMP(DQ_TAG_DENSE_WGRAD, 2 + 3 * min(it, 7));
+            __builtin_amdgcn_sched_barrier(0);
+            load(it + 2, raw);
+            __builtin_amdgcn_sched_barrier(0);                      // (left alone, the scheduler sinks the loads to just before their use)
+            __syncthreads();
+            DQ_STAMP(DQ_TAG_DENSE_WGRAD, 3 + 3 * min(it, 7));
+            mm(it);
+        };
+        load(0, rawA);
+        load(1, rawB);
+        for (int it = 0;;) {
+            step(it, rawA); if (++it >= n_it) break;
+            step(it, rawB); if (++it >= n_it) break;
+        }
+        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 25);
+        // ---- the tile goes through LDS (C/D layout: this lane holds rows 4kb + r of column j of each 16 x 16 tile) so that it leaves as
+        //      whole 256-byte weight rows ---------------------------------------------------------------------------------------------
+        __syncthreads();                                            // every wave is done with the operand planes
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s_o[(32 * (wave >> 1) + 16 * ta + 4 * kb + r) * 68 + 32 * (wave & 1) + 16 * tb + j] = f16x2_sum(acc[ta][tb][r], accx[ta][tb][r]);
+        if (kt == 0 && (wave >> 1) == 0 && kb == 0) {               // bias gradient: row 0 of the all-ones tiles
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int n = nbase + 32 * (wave & 1) + 16 * tb + j;
+                if (n < N) out[L.out_b + n] = f16x2_sum(accb[tb][0], accbx[tb][0]);
+            }
         }
     };
-    // one step: this iteration's rows (requested two iterations ago) -> pieces in LDS; request the rows of iteration it + 2 into the
-    // registers just freed; meet; multiply.  (No condition around the MFMAs: the loop leaves between steps.)
-    auto step = [&](int it, float (&raw)[8][4]) {
-        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 1 + 3 * it);
-        store(it, raw);
-        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 2 + 3 * it);
-        __builtin_amdgcn_sched_barrier(0);
-        load(it + 2, raw);
-        __builtin_amdgcn_sched_barrier(0);                          // (left alone, the scheduler sinks the loads to just before their use)
-        __syncthreads();
-        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 3 + 3 * it);
-        mm(it);
-    };
-    load(0, rawA);
-    load(1, rawB);
-    for (int it = 0;;) {
-        step(it, rawA); if (++it >= n_it) break;
-        step(it, rawB); if (++it >= n_it) break;
-    }
-    DQ_STAMP(DQ_TAG_DENSE_WGRAD, 1 + 3 * n_it);
-    // ---- one partial per (slice, tile): the tile goes through LDS (C/D layout: this lane holds rows 4kb + r of column j of each 16 x 16
-    //      tile) so that it leaves as whole 256-byte weight rows ------------------------------------------------------------------
-    float* out = a.partial + (size_t)slice * a.pstride;
-    __syncthreads();                                                // every wave is done with the operand planes
-    float* s_o = reinterpret_cast<float*>(smem) + 128;              // [64][68] behind the bias scratch
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                s_o[(32 * (wave >> 1) + 16 * ta + 4 * kb + r) * 68 + 32 * (wave & 1) + 16 * tb + j] = f16x2_sum(acc[ta][tb][r], accx[ta][tb][r]);
+    if (planes) run(std::integral_constant<int, 0>{});              // wave-uniform; every copy meets the same barriers
+    else run(std::integral_constant<int, 1>{});
+    // ---- one partial per (slice, tile) ------------------------------------------------------------------------------------------
     __syncthreads();
     {
         const int c4 = 4 * (tid & 15);
@@ -550,21 +618,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
             }
         }
     }
-    if (kt == 0) {                                                  // block-uniform: bias gradient = column sums of G over the slice
-        float* s_bias = reinterpret_cast<float*>(smem);             // [2 loader waves][64] (free since the barrier above)
-        if (op) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v = bs[c];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                if (kb == 0) s_bias[lblk * 64 + 4 * j + c] = v;
-            }
-        }
-        __syncthreads();
-        if (tid < 64 && nbase + tid < N) out[L.out_b + nbase + tid] = s_bias[tid] + s_bias[64 + tid];
-    }
-    DQ_STAMP(DQ_TAG_DENSE_WGRAD, 2 + 3 * n_it);
+    DQ_STAMP(DQ_TAG_DENSE_WGRAD, 26);
     DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 1);
 }
 
@@ -1163,7 +1217,14 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     for (int l = 0; l < nl - nc; ++l) {
         const Layer& L = Q->L[nc + l];
         WgradLayer& W = wa.L[l];
-        W.X = Q->act[0][nc + l - 1]; W.G = Q->gz[nc + l]; W.K = L.K; W.N = L.N;
+        W.X.f32 = Q->act[0][nc + l - 1]; W.X.cols = L.K; W.G.f32 = Q->gz[nc + l]; W.G.cols = L.N;
+        const size_t mb = (size_t)Q->cfg.max_batch;
+        if (l == 0) {                                               // Dense(512): x and gH1 as piece planes (qnet.h dq_qnet.planes)
+            W.X.f32 = nullptr; W.X.planes = Q->planes; W.X.plane_stride = mb * D1.nin;
+            W.G.f32 = nullptr; W.G.planes = Q->planes + 2 * mb * (D1.nin + DENSE_HID); W.G.plane_stride = mb * DENSE_HID;
+        } else if (l == 1) {                                        // Dense(|A|): its input h1 as planes
+            W.X.f32 = nullptr; W.X.planes = Q->planes + 2 * mb * D1.nin; W.X.plane_stride = mb * DENSE_HID;
+        }
         W.out_w = (int)L.w_off; W.out_b = (int)L.b_off;
         if (l == 0) { W.perm_hw = Q->flat_hw; W.perm_c = Q->flat_c; }
         W.k_tiles = (L.K + 63) / 64; W.n_tiles = (L.N + 63) / 64;
