@@ -200,7 +200,15 @@ static __device__ unsigned long long dq_dbg[4096];            // one copy per tr
         if (DQ_STAMPS == 20 && blockIdx.x < 1024 && threadIdx.x == 0)                                           \
             dq_dbg[(q) * 1024 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();                                 \
     } while (0)
+// DQ_STAMPS == 21: the same across the backward's launches (fused_bwd.hip): q = 0 dense data gradients end, 1 / 2 dense weight gradients
+// start / end, 3 convolutional backward start
+#define DQ_STAMP_PAIR2(q)                                                                                       \
+    do {                                                                                                        \
+        if (DQ_STAMPS == 21 && blockIdx.x < 1024 && threadIdx.x == 0)                                           \
+            dq_dbg[(q) * 1024 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();                                 \
+    } while (0)
 #else
+#define DQ_STAMP_PAIR2(q) do { } while (0)
 #define DQ_STAMP(tag, i) do { } while (0)
 #define DQ_STAMP_WG(tag, end) do { } while (0)
 #define DQ_STAMP_PAIR(q) do { } while (0)

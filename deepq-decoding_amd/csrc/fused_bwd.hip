@@ -33,7 +33,9 @@ struct DenseBwdArgs {
     float* gy2;                         // [batch, N2]
     float* gh1;                         // [batch, 512]
     unsigned short* gh1_pl;             // the same as f16 piece planes [2][plane_rows][512] (the weight gradient's operand)
-    int plane_rows;
+    unsigned short* gy2_pl;             // ... [2][plane_rows][small_ld]
+    unsigned short* g3_pl;              // ... [2][plane_rows][small_ld]
+    int plane_rows, small_ld;
     float* gx;                          // [batch, K1] NHWC
     int ldg;                            // LDS row stride of the g3 image (floats); the gY2 planes have rows of 32 KB2 + 8 halves
     int off_g3, off_gy2, off_gh1;
@@ -283,12 +285,17 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             for (int h = 0; lane + 64 * h < A; ++h) s += dval(h);
             for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
             float* o = a.g3 + (size_t)b * N3;
-            if (lane == 0) { s_g3[row * ldg] = s; o[0] = s; }
+            unsigned short* p3 = a.g3_pl + (size_t)b * a.small_ld;   // the same values as pieces: the dueling layer's weight gradient
+            const size_t lo3 = (size_t)a.plane_rows * a.small_ld;
+            unsigned short ph, pl;
+            if (lane == 0) { s_g3[row * ldg] = s; o[0] = s; split_f16x2_one(s, ph, pl); p3[0] = ph; p3[lo3] = pl; }
             for (int h = 0; lane + 64 * h < A; ++h) {
                 const int c = lane + 64 * h;
                 const float v = dval(h) - s / (float)A;
                 s_g3[row * ldg + 1 + c] = v;
                 o[1 + c] = v;
+                split_f16x2_one(v, ph, pl);
+                p3[1 + c] = ph; p3[lo3 + 1 + c] = pl;
             }
         } else {
             for (int h = 0; lane + 64 * h < A; ++h) {
@@ -306,9 +313,14 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     if (a.td_on && a.td.metrics && tid == 0) {                      // this workgroup's partial, and zeros in the slots nobody owns
         float l = 0.f, q = 0.f;
         for (int w = 0; w < DENSE_WAVES; ++w) { l += s_met[w][0]; q += s_met[w][1]; }
-        a.td.metrics[2 + 2 * blockIdx.x] = l;
-        a.td.metrics[3 + 2 * blockIdx.x] = q;
-        for (int k = blockIdx.x + a.dense_wgs; k < a.td.metric_slots; k += a.dense_wgs) { a.td.metrics[2 + 2 * k] = 0.f; a.td.metrics[3 + 2 * k] = 0.f; }
+        if (a.dense_wgs <= a.td.metric_slots) {
+            a.td.metrics[2 + 2 * blockIdx.x] = l;
+            a.td.metrics[3 + 2 * blockIdx.x] = q;
+            for (int k = blockIdx.x + a.dense_wgs; k < a.td.metric_slots; k += a.dense_wgs) { a.td.metrics[2 + 2 * k] = 0.f; a.td.metrics[3 + 2 * k] = 0.f; }
+        } else {                                                    // more workgroups than slots (batch > 16 384): the launcher zeroed the slots
+            atomicAdd(a.td.metrics + 2 + 2 * (blockIdx.x % a.td.metric_slots), l);
+            atomicAdd(a.td.metrics + 3 + 2 * (blockIdx.x % a.td.metric_slots), q);
+        }
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 1);
     // ---- gY2 = g3 W3^T  (K = N3, one column tile per wave) -------------------------------------------------------------
@@ -346,6 +358,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         __syncthreads();
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 2);
+    // ---- gY2's piece planes also leave for the weight gradient of Dense(|A|): 16 rows x 32 KB2 halves per plane, 16 bytes per thread ----
+    {
+        const int per_row = 4 * a.KB2, n16 = DENSE_ROWS * per_row;  // 16-byte pieces per row / per plane
+        for (int i = tid; i < 2 * n16; i += DENSE_THREADS) {
+            const int piece = i / n16, r = (i - piece * n16) / per_row, c8 = (i - piece * n16) - r * per_row;
+            if (r < ns)
+                *reinterpret_cast<u32x4*>(a.gy2_pl + ((size_t)piece * a.plane_rows + b0 + r) * a.small_ld + 8 * c8) =
+                    *reinterpret_cast<const u32x4*>(s_gy2p + (piece * DENSE_ROWS + r) * LDY + 8 * c8);
+        }
+    }
     // ---- gH1 (f16x2; K = N2 in 2 or 4 blocks) ---------------------------------------------------------------------------------------
     if (a.KB2 == 2) gh1_phase<2>(a, s_gy2p, s_gh1p, b0, ns, wave, lane);       // block-uniform
     else gh1_phase<4>(a, s_gy2p, s_gh1p, b0, ns, wave, lane);
@@ -364,6 +386,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 5);
+    DQ_STAMP_PAIR2(0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -397,10 +420,10 @@ __device__ __forceinline__ int wgrad_off(int col, int chunk) {
 }
 
 struct WgradOperand {
-    const float* f32;                   // [batch, cols] f32 (cols >= 4), or NULL when the operand comes as piece planes:
+    const float* f32;                   // [batch, cols] f32 (+ 16 bytes of slack), or NULL when the operand comes as piece planes:
     const unsigned short* planes;       // h plane [plane_rows][cols] then, plane_stride halves further, the l plane (cols a multiple of 8)
     size_t plane_stride;
-    int cols;
+    int cols, ld;                       // columns that exist / halves (floats) per row
 };
 
 struct WgradLayer {
@@ -447,14 +470,17 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     // ---- loader role of this wave: operand (0: X, 1: G) and block of the iteration -----------------------------------------
     const int op = wave & 1, lblk = wave >> 1;
     const WgradOperand& O = op ? L.G : L.X;
-    const int ld = O.cols, cb0 = op ? nbase : kbase;
+    const int ld = O.ld, ncols = O.cols, cb0 = op ? nbase : kbase;
     const bool planes = O.f32 == nullptr;                           // wave-uniform
     // f32 operand: lane (g = kb, i = j) takes rows 8g .. 8g+7 of columns 4i .. 4i+3;  piece planes: lane (piece = lane >> 5,
     // g = (lane >> 3) & 3, i = lane & 7) takes rows 8g .. 8g+7 of columns 8i .. 8i+7 of its piece
     const int lg = planes ? (lane >> 3) & 3 : kb, li = planes ? lane & 7 : j, lpiece = lane >> 5;
-    const float* fsrc = planes ? nullptr : O.f32 + (cb0 + 4 * li + 3 < ld ? cb0 + 4 * li : max(ld - 4, 0));      // a quad that straddles the row's end slides back
-    const int fshift = planes ? 0 : (cb0 + 4 * li + 3 < ld ? 0 : cb0 + 4 * li - max(ld - 4, 0));                  // ... by this many columns (>= 4: wholly outside)
+    // f32 rows are read as 4-byte-aligned dwordx4 wherever the quad starts inside the row: a quad that straddles the row's end takes the
+    // next row's first values with it (the buffers carry 16 bytes of slack behind their last row, qnet.hip) -- columns past N only reach
+    // accumulators that are never stored
+    const float* fsrc = planes ? nullptr : O.f32 + (cb0 + 4 * li < ncols ? cb0 + 4 * li : 0);
     const unsigned short* psrc = planes ? O.planes + (size_t)lpiece * O.plane_stride + (cb0 + 8 * li < ld ? cb0 + 8 * li : 0) : nullptr;
+    (void)ncols;
     int woff[8];                                                    // swizzled store offsets of this lane's columns (chunk lg)
 #pragma unroll
     for (int c = 0; c < 8; ++c) woff[c] = wgrad_off(planes ? 8 * li + c : 4 * li + (c & 3), lg) + (planes ? lpiece * WGRAD_PIECE : 0);
@@ -465,6 +491,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     float* s_o = reinterpret_cast<float*>(smem);                    // the finished tile [64][68], staged for row-wise stores
     DQ_STAMP(DQ_TAG_DENSE_WGRAD, 0);
     DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 0);
+    DQ_STAMP_PAIR2(1);
     // The whole loop is instantiated per operand format (FMT 0: piece planes, 1: f32) and the wave picks its copy once: with the format
     // tested inside the loop, the branches' different load counts merge into an unknown number of loads in flight and hipcc waits for
     // vmcnt(0) before every use -- no prefetch survives.
@@ -517,14 +544,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
                 for (int c = 0; c < 4; ++c) {
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        // column c of this lane's quad; a quad that slid back holds it fshift places further (or not at all: zero)
-                        const int cs = c + fshift;
-                        float x = 0.f;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) x = cs == q ? __uint_as_float(raw[e][q]) : x;
-                        v[e] = (tail && r0 + e >= m1) ? 0.f : x;
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] = (tail && r0 + e >= m1) ? 0.f : __uint_as_float(raw[e][c]);
                     const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
                     *reinterpret_cast<u32x4*>(base + woff[c]) = o.h;
                     *reinterpret_cast<u32x4*>(base + woff[c] + WGRAD_PIECE) = o.l;
@@ -620,6 +640,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     }
     DQ_STAMP(DQ_TAG_DENSE_WGRAD, 26);
     DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 1);
+    DQ_STAMP_PAIR2(2);
 }
 
 // Fixed-order reduction of both partial sets in one launch: out[i] = sum_s partial[s * stride + i].
@@ -798,6 +819,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     constexpr int NW1 = (4 * KG1 + CB_WAVES - 1) / CB_WAVES;        // dW1 tiles (KG1 x 4) per wave
     constexpr int KP = 16 * KG1;                                    // bytes per row of the observation patch image
 
+    DQ_STAMP_PAIR2(3);
     // ---- group-independent tables and zero rows ----------------------------------------------------------------
     for (int m = tid; m < S * r3; m += CB_THREADS) { const int s = m / r3, p = m - s * r3, oy = p / a.ow3, ox = p - oy * a.ow3; t3[m] = s * r2 + oy * a.ow2 + ox; }
     for (int m = tid; m < S * r2; m += CB_THREADS) { const int s = m / r2, p = m - s * r2, oy = p / a.ow2, ox = p - oy * a.ow2; t2[m] = s * r1 + oy * a.ow1 + ox; }
@@ -1181,7 +1203,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     memset(&da, 0, sizeof(da));
     da.gs = Q->bwd_scale; da.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
     da.packed = pkbase; da.pk_dense2t = (int)PL.dense2t; da.pk_dense1t = (int)PL.dense1t; da.KB2 = PL.KB2;
-    da.plane_rows = Q->cfg.max_batch; da.gh1_pl = Q->planes + (size_t)2 * Q->cfg.max_batch * (D1.nin + DENSE_HID);
+    da.plane_rows = Q->cfg.max_batch; da.small_ld = dq_planes_small_ld(Q);
+    da.gh1_pl = dq_plane(Q, 2); da.gy2_pl = dq_plane(Q, 3); da.g3_pl = dq_plane(Q, 4);
     da.params = params_dev; da.dq = dq_dev; da.h1 = Q->act[0][nc]; da.x = Q->act[0][nc - 1];
     da.batch = B; da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
@@ -1203,6 +1226,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         ep = *rider; da.env_on = 1; stat_wgs = ep.env_blocks + ep.s_blocks;
         if (rider_lds > lds) lds = rider_lds;
     }
+    if (td && td->metrics && da.dense_wgs > td->metric_slots)      // (the partials are then summed by atomics, in any order: diagnostics only)
+        DQ_HIP(hipMemsetAsync(td->metrics + 2, 0, (size_t)td->metric_slots * 2 * sizeof(float), st));
     dq_prof_begin(DQ_K_DENSE_BWD, st);
     if (dp.NT2 == 4) dense_bwd_chain_kernel<4><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
     else dense_bwd_chain_kernel<7><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
@@ -1217,13 +1242,17 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     for (int l = 0; l < nl - nc; ++l) {
         const Layer& L = Q->L[nc + l];
         WgradLayer& W = wa.L[l];
-        W.X.f32 = Q->act[0][nc + l - 1]; W.X.cols = L.K; W.G.f32 = Q->gz[nc + l]; W.G.cols = L.N;
+        W.X.cols = L.K; W.X.ld = L.K; W.G.cols = L.N; W.G.ld = L.N;
         const size_t mb = (size_t)Q->cfg.max_batch;
-        if (l == 0) {                                               // Dense(512): x and gH1 as piece planes (qnet.h dq_qnet.planes)
-            W.X.f32 = nullptr; W.X.planes = Q->planes; W.X.plane_stride = mb * D1.nin;
-            W.G.f32 = nullptr; W.G.planes = Q->planes + 2 * mb * (D1.nin + DENSE_HID); W.G.plane_stride = mb * DENSE_HID;
-        } else if (l == 1) {                                        // Dense(|A|): its input h1 as planes
-            W.X.f32 = nullptr; W.X.planes = Q->planes + 2 * mb * D1.nin; W.X.plane_stride = mb * DENSE_HID;
+        // every operand comes as piece planes (qnet.h dq_plane): x / gH1, h1 / gY2, y2 / g3; the small ones in rows of small_ld halves
+        const size_t sl = (size_t)dq_planes_small_ld(Q);
+        W.X.f32 = nullptr; W.G.f32 = nullptr;
+        if (l == 0) {
+            W.X.planes = dq_plane(Q, 0); W.X.plane_stride = mb * D1.nin; W.G.planes = dq_plane(Q, 2); W.G.plane_stride = mb * DENSE_HID;
+        } else if (l == 1) {
+            W.X.planes = dq_plane(Q, 1); W.X.plane_stride = mb * DENSE_HID; W.G.planes = dq_plane(Q, 3); W.G.plane_stride = mb * sl; W.G.ld = (int)sl;
+        } else {
+            W.X.planes = dq_plane(Q, 5); W.X.plane_stride = mb * sl; W.X.ld = (int)sl; W.G.planes = dq_plane(Q, 4); W.G.plane_stride = mb * sl; W.G.ld = (int)sl;
         }
         W.out_w = (int)L.w_off; W.out_b = (int)L.b_off;
         if (l == 0) { W.perm_hw = Q->flat_hw; W.perm_c = Q->flat_c; }

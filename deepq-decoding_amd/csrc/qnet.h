@@ -34,7 +34,9 @@ struct dq_qnet {
     const void* last_train_packed;   // packed weights of the last training forward (the backward's data gradients read them)
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
     unsigned short* planes;      // f16 piece planes (h plane, then l plane) of the training forward's / backward's operands of the dense
-                                 // weight gradients, row-major [max_batch][ld]: x (ld K1), h1 (512), gh1 (512), in this order
+                                 // weight gradients, row-major [max_batch][ld]: x (ld K1), h1 (512), gh1 (512), then gy2, g3, y2 (ld
+                                 // dq_planes_small_ld: 64 or 128; columns past the tensor's width hold anything finite or not -- they only
+                                 // reach weight-gradient accumulators that are never stored), in this order
     float grad_scale_hint;       // dq_qnet_set_grad_scale: loss scale of caller-supplied dq (0 = unknown: measured on the device)
     float bwd_scale;             // fused backward: power-of-two scale the gradients of the last dense phase carry (0: the device-computed one)
     int use_fused;               // fused LDS-resident chains when the configuration allows it
@@ -105,6 +107,13 @@ __device__ __forceinline__ F16x2 split_f16x2(const f32x4& x0, const f32x4& x1) {
     return o;
 }
 
+// one f32 value -> its two f16 pieces (qnet.h), as raw halves
+__device__ __forceinline__ void split_f16x2_one(float v, unsigned short& h, unsigned short& l) {
+    const _Float16 vh = (_Float16)v, vl = (_Float16)((v - (float)vh) * F16_LO_SCALE);
+    h = __builtin_bit_cast(unsigned short, vh);
+    l = __builtin_bit_cast(unsigned short, vl);
+}
+
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
 
 // acc0 takes the leading piece product, acc1 the two 2^11-scaled cross terms; the caller combines them with f16x2_sum
@@ -156,6 +165,16 @@ struct ConvJob {
 //   dense1t  [16][K1/16]                         B(n1 = 32 blk + 8kb + e, k' = 16 ct + j) = W1[row(k')][n1]                         backward, gX
 struct PackLayout { size_t dense1, dense2, dense2t, dense1t, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2; };   // offsets in u32x4
 PackLayout fused_pack_layout(const dq_qnet* Q);
+static inline int dq_planes_small_ld(const dq_qnet* Q) { return Q->cfg.n_actions + 1 <= 64 ? 64 : 128; }
+static inline size_t dq_planes_halves(const dq_qnet* Q) {      // total size of dq_qnet.planes
+    return (size_t)2 * Q->cfg.max_batch * (Q->L[Q->cfg.n_conv].nin + 2 * DENSE_HID + 3 * dq_planes_small_ld(Q));
+}
+// plane set i (0 x, 1 h1, 2 gh1, 3 gy2, 4 g3, 5 y2): first half (the h plane; the l plane follows max_batch * ld halves further)
+static inline unsigned short* dq_plane(const dq_qnet* Q, int i) {
+    const size_t mb = (size_t)Q->cfg.max_batch, k1 = Q->L[Q->cfg.n_conv].nin, sl = dq_planes_small_ld(Q);
+    const size_t off[6] = {0, k1, k1 + DENSE_HID, k1 + 2 * DENSE_HID, k1 + 2 * DENSE_HID + sl, k1 + 2 * DENSE_HID + 2 * sl};
+    return Q->planes + 2 * mb * off[i];
+}
 size_t fused_packed_u32x4(const dq_qnet* Q);
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q);           // u32x4 offset of the f32 transpose W1T behind the pieces
 size_t fused_packed_w2t_u32x4(const dq_qnet* Q);           // ... of W2T

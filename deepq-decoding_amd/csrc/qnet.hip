@@ -389,8 +389,9 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         const Layer& L = Q->L[i];
         const size_t floats = (size_t)cfg->max_batch * L.rows * L.N;
         if (floats >= (1ull << 32)) { dq_qnet_destroy(Q); dq_set_error("dq_qnet_create: activation too large for 32-bit offsets"); return DQ_ERR_UNSUPPORTED; }
-        for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&Q->act[s][i], floats * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&Q->gz[i], floats * sizeof(float));
+        // (+ 16 bytes: the dense weight gradient reads rows as dwordx4 that may straddle the last row's end, fused_bwd.hip)
+        for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(&Q->act[s][i], floats * sizeof(float) + 16);
+        if (e == hipSuccess) e = hipMalloc(&Q->gz[i], floats * sizeof(float) + 16);
         int rps, slices;
         wgrad_slices(cfg->max_batch * L.rows, L.K, L.N, &rps, &slices);
         const size_t p = (size_t)slices * ((size_t)L.K * L.N + L.N);
@@ -414,8 +415,7 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->xinf[i], xf * sizeof(float));
     }
     if (e == hipSuccess && fused_forward_supported(Q)) {            // piece planes x | h1 | gh1 (qnet.h)
-        const size_t halves = (size_t)2 * cfg->max_batch * (Q->L[cfg->n_conv].nin + 2 * DENSE_HID);
-        e = hipMalloc(&Q->planes, halves * sizeof(unsigned short));
+        e = hipMalloc(&Q->planes, dq_planes_halves(Q) * sizeof(unsigned short));
     }
     const size_t fws = fused_backward_workspace_floats(Q);
     if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));

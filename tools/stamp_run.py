@@ -19,8 +19,23 @@ for _ in range(5):
     net.backward(params, dqt)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()
-getattr(dq.lib(), 'dq_dbg_read_fwd' if tag % 10 in (1, 2) else 'dq_dbg_read_bwd')(buf)
-if tag == 20:
+getattr(dq.lib(), 'dq_dbg_read_fwd' if tag % 10 in (1, 2) and tag != 21 else 'dq_dbg_read_bwd')(buf)
+if tag == 21:
+    dq.lib().dq_dbg_read_bwd(buf)
+    n = [256, 392, 392, 256]
+    q = [np.array([buf[k * 1024 + i] for i in range(n[k])], dtype=np.int64) for k in range(4)]
+    t0 = q[0].min()
+    f = lambda x: "%.2f" % ((x - t0) / 100)
+    print("dense data gradients: ends first", f(q[0].min()), "median", f(np.median(q[0])), "last", f(q[0].max()), "us")
+    print("dense weight gradients: starts first", f(q[1].min()), "last", f(q[1].max()), "; ends first", f(q[2].min()), "median", f(np.median(q[2])), "last", f(q[2].max()), "us")
+    print("convolutional backward: starts first", f(q[3].min()), "last", f(q[3].max()), "us")
+    tiles = 49
+    dur = (q[2] - q[1]) / 100.0
+    by_tile = [dur[[b for b in range(392) if (b >> 3) % tiles == t]] for t in range(tiles)]
+    print("weight-gradient workgroup durations by tile (us, mean over slices):", " ".join("%d:%.1f" % (t, by_tile[t].mean()) for t in range(tiles)))
+    by_slice = [dur[[b for b in range(392) if (b & 7) == x]] for x in range(8)]
+    print("by slice:", " ".join("%.1f" % v.mean() for v in by_slice))
+elif tag == 20:
     for _ in range(3): net.forward(params, obs)
     torch.cuda.synchronize()
     dq.lib().dq_dbg_read_fwd(buf)
