@@ -331,11 +331,10 @@ template <int NT2, int KG3, int RT>     // N2 <= 16*NT2 (column tiles of Dense(|
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     float* s_x = reinterpret_cast<float*>(smem + a.off_x);
-    unsigned short* s_hp = reinterpret_cast<unsigned short*>(smem + a.off_h);      // hidden output as f16 piece planes [2][ROWS][LDH]
     float* s_part = reinterpret_cast<float*>(smem + a.off_part);
     float* s_y2 = reinterpret_cast<float*>(smem + a.off_y2);
     float* s_y3 = reinterpret_cast<float*>(smem + a.off_y3);
-    constexpr int LDH = DENSE_HID + 8, PW = 16 * NT2, ROWS = 16 * RT;      // LDH: halves per plane row (16-byte aligned, bank-staggered)
+    constexpr int PW = 16 * NT2, ROWS = 16 * RT, PR = ROWS < 32 ? ROWS : 32, UP = PR / 16;      // PR rows (UP row tiles) per reduction pass
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     int jb = 0;
     while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
@@ -347,19 +346,25 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     DQ_STAMP(DQ_TAG_DENSE_FWD, 0);
     DQ_STAMP_PAIR(2);
     // ---- hidden layer's first weight blocks start flying before anything else -------------------------------------------
-    // Dense(512) runs as f16x2 (qnet.h): the weights come as packed f16 pieces (block (kblk, column tile ct = 4*wave + t), column
-    // 64*wave + 4j + t), the input rows are split ONCE into two f16 planes in LDS.  The kernel is bound by the weight stream: the
-    // vector-memory path delivers ~64 B/clk/CU and every workgroup reads all 0.6 MB of pieces, so a workgroup takes RT = 2 row tiles
-    // (32 samples) per weight block when the batch is large enough to fill the chip that way -- half the bytes per sample.
+    // Both dense layers run TRANSPOSED on the f16 pipe (f16x2, qnet.h): out^T = W^T x^T, the packed weight pieces are the MFMA's FIRST
+    // operand and the samples are its columns.  The accumulator layout (lane (kq, j): rows 4kq .. 4kq+3 of column j) then hands every lane
+    // four consecutive hidden units of ONE sample, and with the tiles' rows numbered unit = 64 wave + 32 b + 8 (i >> 2) + 4 s + (i & 3)
+    // (tile (b, s), row i: a permutation that lives in the packed weights) the two tiles (b, 0), (b, 1) give lane (kq, j) exactly units
+    // 8kq .. 8kq+7 of block b of sample j -- the SECOND operand of Dense(|A|) for that K = 32 block.  So the hidden layer never goes
+    // through LDS: bias, ReLU, dropout and the split into pieces happen in registers, and Dense(|A|) (K = 512 split over the 8 waves,
+    // each over the 64 units it has just produced) consumes them in place.  LDS holds only the input rows' planes -- which is what lets a
+    // workgroup take RT = 4 row tiles (64 samples) per pass over the weights: the kernel is bound by the weight stream (every workgroup
+    // reads all 0.6 MB of Dense(512) pieces through the CU's 64 B/clk vector-memory path, and all workgroups together through L2), so
+    // bytes per sample are what counts.
     const int KB = K1 >> 5;                                          // k-blocks of 32
     const u32x4* pkw = J.packed + a.pk_dense1 + (size_t)(4 * wave) * PK_BLOCK + lane;
-    F16x2 bw[2][4];                                                 // two k-blocks in flight
+    F16x2 bw[2][4];                                                 // two k-blocks in flight; tile ct = 2 b + s
 #pragma unroll
     for (int t = 0; t < 4; ++t) { bw[0][t].h = pkw[t * PK_BLOCK]; bw[0][t].l = pkw[t * PK_BLOCK + PK_LO]; }
 
     // ---- input rows -> two f16 planes in LDS (zero-filled past the batch), in the rows' own NHWC order: Keras' channels_first
     //      Flatten is a permutation of k, applied ONCE to the packed weight rows by pack_weights_kernel instead of to every input row
-    //      here (transposed 2-byte LDS writes: 8 per float4, against two 8-byte ones); clear the padded y2 image ---------------
+    //      here; clear the padded y2 image ---------------------------------------------------------------------------------------
     const int LDP = K1 + 8;                                          // plane row stride in f16 (rows stay 16-byte aligned)
     unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [2][ROWS][LDP]
     {
@@ -398,25 +403,25 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     __syncthreads();
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 1);
-    // ---- Dense(512): wave w owns columns [64w, 64w+64) as 4 interleaved tiles; two accumulators per tile (leading / cross terms) ----
-    f32x4 acc2c[RT][4][2];
+    // ---- Dense(512)^T: wave w owns units [64w, 64w+64) as 4 tiles; two accumulators per tile (leading / cross terms) ---------------
+    f32x4 acc[RT][4][2];
 #pragma unroll
     for (int u = 0; u < RT; ++u)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { acc2c[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2c[u][t][1] = acc2c[u][t][0]; }
-    const unsigned short* arow = s_pl + j * LDP + 8 * kq;
+        for (int t = 0; t < 4; ++t) { acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = acc[u][t][0]; }
+    const unsigned short* xrow = s_pl + j * LDP + 8 * kq;
     auto do_block = [&](int b, F16x2 (&cur)[4], F16x2 (&nxt)[4]) {
         const u32x4* pn = pkw + (size_t)min(b + 1, KB - 1) * 32 * PK_BLOCK;      // next block: unconditional, clamped prefetch
 #pragma unroll
         for (int t = 0; t < 4; ++t) { nxt[t].h = pn[t * PK_BLOCK]; nxt[t].l = pn[t * PK_BLOCK + PK_LO]; }
 #pragma unroll
         for (int u = 0; u < RT; ++u) {
-            F16x2 av;
-            const unsigned short* ap = arow + 16 * u * LDP + 32 * b;
-            av.h = *reinterpret_cast<const u32x4*>(ap);
-            av.l = *reinterpret_cast<const u32x4*>(ap + ROWS * LDP);
+            F16x2 xv;
+            const unsigned short* xp = xrow + 16 * u * LDP + 32 * b;
+            xv.h = *reinterpret_cast<const u32x4*>(xp);
+            xv.l = *reinterpret_cast<const u32x4*>(xp + ROWS * LDP);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) mma_f16x3(av, cur[t], acc2c[u][t][0], acc2c[u][t][1]);
+            for (int t = 0; t < 4; ++t) mma_f16x3(cur[t], xv, acc[u][t][0], acc[u][t][1]);
         }
     };
     int blk = 0;
@@ -425,123 +430,110 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         do_block(blk + 1, bw[1], bw[0]);
     }
     if (blk < KB) do_block(blk, bw[0], bw[1]);                       // odd block count (K1 = 288: 9 blocks)
-    f32x4 acc[RT][4];
-#pragma unroll
-    for (int u = 0; u < RT; ++u)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[u][t] = f16x2_sum(acc2c[u][t][0], acc2c[u][t][1]);
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
-    // ---- the head layers' weights for this wave start flying under the hidden layer's epilogue -----------------------
-    // Dense(|A|) splits K = 512 into 8 parts of 64 rows (two K = 32 blocks), one per wave, every column tile in each, on the f16 pipe:
-    // packed pieces (qnet.h dense2: tile t, lane j is column NT2*j + t, so a lane's NT2 results of a row are consecutive floats)
-    const int kw0 = 64 * wave;
-    F16x2 b2[2][NT2];
+    // ---- Dense(|A|)^T's weights for this wave's 64 units (two K = 32 blocks x NT2 tiles of 16 outputs: qnet.h dense2) start flying
+    //      under the hidden layer's epilogue ---------------------------------------------------------------------------------------
+    F16x2 w2[2][NT2];
     {
         const u32x4* pk2 = J.packed + a.pk_dense2 + (size_t)(2 * wave) * NT2 * PK_BLOCK + lane;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int t = 0; t < NT2; ++t) { b2[b][t].h = pk2[(b * NT2 + t) * PK_BLOCK]; b2[b][t].l = pk2[(b * NT2 + t) * PK_BLOCK + PK_LO]; }
+            for (int t = 0; t < NT2; ++t) { w2[b][t].h = pk2[(b * NT2 + t) * PK_BLOCK]; w2[b][t].l = pk2[(b * NT2 + t) * PK_BLOCK + PK_LO]; }
     }
     const int NT3 = (a.N3 + 15) >> 4;
     float b3[KG3][4];
+    f32x4 bias1[4];                                                 // this lane's four units of tile ct: 64w + 32 (ct >> 1) + 8kq + 4 (ct & 1) + r
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+        bias1[ct] = *reinterpret_cast<const f32x4u*>(J.params + a.b_off[0] + 64 * wave + 32 * (ct >> 1) + 8 * kq + 4 * (ct & 1));
+    __syncthreads();                                                // every wave is done with the input planes: the partials overlay them
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 3);
-    // ---- hidden layer epilogue: bias, ReLU, dropout (one Philox call = this lane's 4 columns of a row) -----------------
-    {
-        const int c0 = 64 * wave + 4 * j;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + c0);
+    // ---- per reduction pass (32 rows): hidden epilogue in registers -> Dense(|A|)^T partial over this wave's units -> LDS; then the
+    //      fixed-order sum over the 8 waves ------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int u = 0; u < RT; ++u)
+    for (int pass = 0; pass < ROWS / PR; ++pass) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * u + 4 * kq + r;
-                f32x4 v;
+        for (int uu = 0; uu < UP; ++uu) {
+            const int u = pass * UP + uu, row = 16 * u + j;         // this lane's sample
+            F16x2 hb[2];                                            // the sample's units 8kq .. 8kq+7 of this wave's two blocks, as pieces
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(acc[u][t][r] + bias[t], 0.f);
-                if (J.keep_scale > 0.f) {
-                    u32 wd[4];
-                    philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + row), ((u32)c0 >> 2) | ((u32)DQ_STREAM_DROPOUT << 16),
-                                  J.seed0, J.seed1, wd);
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = ((u64)wd[t] < J.drop_T) ? 0.f : v[t] * J.keep_scale;
+                for (int s = 0; s < 2; ++s) {
+                    const int ct = 2 * b + s, unit0 = 64 * wave + 32 * b + 8 * kq + 4 * s;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(f16x2_sum(acc[u][ct][0][r], acc[u][ct][1][r]) + bias1[ct][r], 0.f);
+                    if (J.keep_scale > 0.f) {                       // (one Philox call = four consecutive units of a sample)
+                        u32 wd[4];
+                        philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + row), ((u32)unit0 >> 2) | ((u32)DQ_STREAM_DROPOUT << 16),
+                                      J.seed0, J.seed1, wd);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = ((u64)wd[r] < J.drop_T) ? 0.f : v[r] * J.keep_scale;
+                    }
+                    u32 hp[2], lp[2];
+                    split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
+                    split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
+                    hb[b].h[2 * s] = hp[0]; hb[b].h[2 * s + 1] = hp[1];
+                    hb[b].l[2 * s] = lp[0]; hb[b].l[2 * s + 1] = lp[1];
+                    if (J.h1_out && row < ns) {                     // training: kept for the backward (mask) and, as pieces, for the weight gradients
+                        *reinterpret_cast<f32x4*>(J.h1_out + (size_t)(b0 + row) * DENSE_HID + unit0) = v;
+                        unsigned short* gp = J.h1_pl + (size_t)(b0 + row) * DENSE_HID + unit0;
+                        *reinterpret_cast<uint2*>(gp) = uint2{hp[0], hp[1]};
+                        *reinterpret_cast<uint2*>(gp + (size_t)J.plane_rows * DENSE_HID) = uint2{lp[0], lp[1]};
+                    }
                 }
-                u32 hp[2], lp[2];                                   // split on write: Dense(|A|) and the weight gradients read pieces
-                split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
-                split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
-                *reinterpret_cast<uint2*>(s_hp + row * LDH + c0) = uint2{hp[0], hp[1]};
-                *reinterpret_cast<uint2*>(s_hp + (ROWS + row) * LDH + c0) = uint2{lp[0], lp[1]};
-                if (J.h1_out && row < ns) {
-                    *reinterpret_cast<f32x4*>(J.h1_out + (size_t)(b0 + row) * DENSE_HID + c0) = v;
-                    unsigned short* gp = J.h1_pl + (size_t)(b0 + row) * DENSE_HID + c0;
-                    *reinterpret_cast<uint2*>(gp) = uint2{hp[0], hp[1]};
-                    *reinterpret_cast<uint2*>(gp + (size_t)J.plane_rows * DENSE_HID) = uint2{lp[0], lp[1]};
+            f32x4 acc2[NT2][2];
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) { acc2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t][1] = acc2[t][0]; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) mma_f16x3(w2[b][t], hb[b], acc2[t][0], acc2[t][1]);
+            // C/D layout: this lane holds outputs 16t + 4kq .. + 3 of sample j: one 16-byte store per tile
+#pragma unroll
+            for (int t = 0; t < NT2; ++t)
+                *reinterpret_cast<f32x4*>(s_part + (wave * PR + 16 * uu + j) * PW + 16 * t + 4 * kq) = f16x2_sum(acc2[t][0], acc2[t][1]);
+        }
+        // the dueling layer's weights (waves 0 .. NT3-1): requested here and used two barriers later.  All loads first, masked by
+        // MULTIPLICATION afterwards: under `ok ? v : 0` right after each load hipcc reuses one register and waits for every load in turn
+        if (pass == ROWS / PR - 1 && wave < NT3) {
+            const float* w3 = J.params + a.w_off[2];
+            const int col = 16 * wave + j;
+            const bool cok = col < a.N3;
+            const int loff = 4 * kq * a.N3 + (cok ? col : 0);
+#pragma unroll
+            for (int g = 0; g < KG3; ++g)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int k = 16 * g + 4 * kq + s;
+                    const bool okb = cok && k < a.N2;
+                    b3[g][s] = w3[okb ? (16 * g + s) * a.N3 + loff : 0] * (okb ? 1.f : 0.f);
                 }
+        }
+        __syncthreads();
+        for (int e = tid; e < PR * a.N2; e += DENSE_THREADS) {
+            const int rr = e / a.N2, col = e - rr * a.N2, row = pass * PR + rr;
+            float v = J.params[a.b_off[1] + col];
+#pragma unroll
+            for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * PR + rr) * PW + col];
+            s_y2[row * a.ld2 + col] = v;
+            if (J.y2_out && row < ns) {
+                J.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
+                unsigned short h, l;
+                split_f16x2_one(v, h, l);
+                J.y2_pl[(size_t)(b0 + row) * J.small_ld + col] = h;
+                J.y2_pl[((size_t)J.plane_rows + b0 + row) * J.small_ld + col] = l;
             }
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 4);
-    // ---- Dense(|A|): K = 512 split over the 8 waves, partial tiles reduced in fixed order ---------------------------------
-#pragma unroll
-    for (int u = 0; u < RT; ++u) {
-        f32x4 acc2[NT2], acc2x[NT2];
-#pragma unroll
-        for (int t = 0; t < NT2; ++t) { acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2x[t] = acc2[t]; }
-        const unsigned short* hrow = s_hp + (16 * u + j) * LDH + kw0 + 8 * kq;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            F16x2 av;
-            av.h = *reinterpret_cast<const u32x4*>(hrow + 32 * b);
-            av.l = *reinterpret_cast<const u32x4*>(hrow + 32 * b + ROWS * LDH);
-#pragma unroll
-            for (int t = 0; t < NT2; ++t) mma_f16x3(av, b2[b][t], acc2[t], acc2x[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < NT2; ++t) acc2[t] = f16x2_sum(acc2[t], acc2x[t]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < NT2 / 4; ++q)                       // this lane's columns NT2*j + 4q .. +3 of row 16u + 4kq + r
-                *reinterpret_cast<f32x4*>(s_part + (wave * ROWS + 16 * u + 4 * kq + r) * PW + NT2 * j + 4 * q) =
-                    f32x4{acc2[4 * q][r], acc2[4 * q + 1][r], acc2[4 * q + 2][r], acc2[4 * q + 3][r]};
-    }
-    // the dueling layer's weights (waves 0 .. NT3-1): requested here, where Dense(|A|)'s 64 weight registers are free again, and used
-    // two barriers later.  All loads first, masked by MULTIPLICATION afterwards: under `ok ? v : 0` right after each load, with the
-    // 128-VGPR cap, hipcc reuses one register and waits for every load in turn (measured: 9K cycles on the critical path).
-    if (wave < NT3) {
-        const float* w3 = J.params + a.w_off[2];
-        const int col = 16 * wave + j;
-        const bool cok = col < a.N3;
-        const int loff = 4 * kq * a.N3 + (cok ? col : 0);
-#pragma unroll
-        for (int g = 0; g < KG3; ++g)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = 16 * g + 4 * kq + s;
-                const bool okb = cok && k < a.N2;
-                b3[g][s] = w3[okb ? (16 * g + s) * a.N3 + loff : 0] * (okb ? 1.f : 0.f);
-            }
-    }
-    __syncthreads();
     DQ_STAMP(DQ_TAG_DENSE_FWD, 5);
-    for (int e = tid; e < ROWS * a.N2; e += DENSE_THREADS) {
-        const int row = e / a.N2, col = e - row * a.N2;
-        float v = J.params[a.b_off[1] + col];
-#pragma unroll
-        for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * ROWS + row) * PW + col];
-        s_y2[row * a.ld2 + col] = v;
-        if (J.y2_out && row < ns) {
-            J.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
-            unsigned short h, l;
-            split_f16x2_one(v, h, l);
-            J.y2_pl[(size_t)(b0 + row) * J.small_ld + col] = h;
-            J.y2_pl[((size_t)J.plane_rows + b0 + row) * J.small_ld + col] = l;
-        }
-    }
-    __syncthreads();
-
     DQ_STAMP(DQ_TAG_DENSE_FWD, 6);
     // ---- dueling layer Dense(|A|+1) and the combination Q = V + A - mean(A) ------------------------------------------------
     const float* y = s_y2;
@@ -668,12 +660,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
             v[e] = n2 < a.N2 ? params[a.d2_off + (size_t)n1 * a.N2 + n2] : 0.f;
         }
     } else if (blk_id >= e_d1) {                                    // dense2 (forward): B(k = 32 blk + 8kb + e, col = NT2 j + t) = W2[k][col]
-        const int b = blk_id - e_d1, blk = b / a.NT2, t = b - blk * a.NT2, col = a.NT2 * j + t;
+        const int b = blk_id - e_d1, blk = b / a.NT2, t = b - blk * a.NT2, col = 16 * t + j;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = col < a.N2 ? params[a.d2_off + (size_t)(32 * blk + 8 * kb + e) * a.N2 + col] : 0.f;
     } else if (blk_id >= PK_TOTAL_BLOCKS) {                         // Dense(512): block (kblk, ct): B(k = 32 kblk + 8kb + e, col = 64 (ct>>2) + 4j + (ct&3))
+        // (rows of the transposed tile (b, s) = ct & 3: unit = 64 wave + 32 b + 8 (i >> 2) + 4 s + (i & 3), fused.hip dense_chain_kernel)
         const int b = blk_id - PK_TOTAL_BLOCKS, kblk = b >> 5, ct = b & 31;
-        const float* w = params + d1_off + 64 * (ct >> 2) + 4 * j + (ct & 3);
+        const float* w = params + d1_off + 64 * (ct >> 2) + 32 * ((ct >> 1) & 1) + 8 * (j >> 2) + 4 * (ct & 1) + (j & 3);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int k = 32 * kblk + 8 * kb + e;                         // the input rows' own (NHWC) order ...
@@ -803,13 +796,14 @@ static bool plan_dense(const dq_qnet* Q, DensePlan* P, int rt = 1) {
     if (N2 > 128 || N3 > 128) return false;
     const int rows = 16 * rt;
     P->NT2 = N2 <= 64 ? 4 : 8;
+    if (rt > 1 && P->NT2 != 4) return false;                        // (more than 16 samples: the registers only fit four Dense(|A|) tiles)
     P->ldx = D1.nin + 4;
     P->ld2 = 16 * P->NT2 + 4;
     P->ld3 = 16 * ((N3 + 15) / 16) + 1;
     size_t off = 0;
-    const size_t xb = up16((size_t)2 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * rows * 16 * P->NT2 * 4);   // f16 planes | partials
+    const size_t xb = up16((size_t)2 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * (rows < 32 ? rows : 32) * 16 * P->NT2 * 4);   // f16 planes | partials of one pass
     P->off_x = P->off_part = (int)off; off += xb > pb ? xb : pb;   // the Dense(|A|) partials reuse the input image (dead by then)
-    P->off_h = (int)off; off += up16((size_t)2 * rows * (DENSE_HID + 8) * 2);     // hidden output: two f16 planes
+    P->off_h = (int)off;                                            // (the hidden output stays in registers)
     P->off_y2 = (int)off; off += up16((size_t)rows * P->ld2 * 4);
     P->off_y3 = (int)off; off += up16((size_t)rows * P->ld3 * 4);
     P->lds = off;
@@ -836,7 +830,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         const conv_kernel_t cks[4] = {conv_chain_kernel<3>, conv_chain_kernel<4>, conv_chain_kernel<5>, conv_chain_kernel<6>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
-        const dense_kernel_t dks[4] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<8, 8, 2>};
+        const dense_kernel_t dks[4] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<4, 4, 4>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         attr_set = true;
@@ -873,16 +867,24 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         }
         n_cu = cached_cus;
     }
-    DensePlan dp2;
-    // measured at c3 (us): one-tile workgroups cost ~20 for a launch of <= one per CU and ~15 per CU-ful beyond that (two share a
-    // CU and take turns on the vector-memory path); two-tile workgroups (one per CU) cost 23.6 per round of n_cu workgroups
-    const double cost1 = tiles16 <= n_cu ? 20.0 : 15.0 * tiles16 / n_cu;
-    const double cost2 = 23.6 * (((tiles16 + 1) / 2 + n_cu - 1) / n_cu);
-    const int RT = (cost2 < cost1 && plan_dense(Q, &dp2, 2)) ? 2 : 1;
-    if (RT == 2) dp = dp2;
+    // Row tiles per workgroup by a cost model measured at c3 (us per round of n_cu workgroups, DQ_DENSE_RT overrides): the kernel is bound
+    // by the weight stream, so a workgroup's time grows slowly with its rows and the bytes per sample fall with them -- but a launch
+    // that does not fill the chip with the larger workgroups is better off with smaller ones.
+    auto rounds = [&](int rt, int per_cu) { return ((tiles16 + rt - 1) / rt + per_cu * n_cu - 1) / (per_cu * n_cu); };
+    const double cost[3] = {(tiles16 <= n_cu ? 11.0 : 15.0 * rounds(1, 2)), 14.5 * rounds(2, 1), 19.0 * rounds(4, 1)};
+    int RT = 1;
+    double best = cost[0];
+    DensePlan dpx;
+    if (cost[1] < best && plan_dense(Q, &dpx, 2)) { RT = 2; best = cost[1]; dp = dpx; }
+    if (cost[2] < best && plan_dense(Q, &dpx, 4)) { RT = 4; best = cost[2]; dp = dpx; }
+    {
+        static int forced = -1;
+        if (forced < 0) { const char* e = getenv("DQ_DENSE_RT"); forced = e ? atoi(e) : 0; }
+        if ((forced == 1 || forced == 2 || forced == 4) && plan_dense(Q, &dpx, forced)) { RT = forced; dp = dpx; }
+    }
     const int dense_rows = 16 * RT;
-    const dense_kernel_t dk = dp.NT2 == 4 ? (RT == 2 ? dense_chain_kernel<4, 4, 2> : dense_chain_kernel<4, 4, 1>)
-                                          : (RT == 2 ? dense_chain_kernel<8, 8, 2> : dense_chain_kernel<8, 8, 1>);
+    const dense_kernel_t dk = dp.NT2 == 4 ? (RT == 4 ? dense_chain_kernel<4, 4, 4> : RT == 2 ? dense_chain_kernel<4, 4, 2> : dense_chain_kernel<4, 4, 1>)
+                                          : dense_chain_kernel<8, 8, 1>;
     da.ldx = dp.ldx; da.ld2 = dp.ld2; da.ld3 = dp.ld3;
     da.off_x = dp.off_x; da.off_h = dp.off_h; da.off_part = dp.off_part; da.off_y2 = dp.off_y2; da.off_y3 = dp.off_y3;
     int conv_wgs = 0, dense_wgs = 0, n_train = 0;
