@@ -188,18 +188,31 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     //      leaves the caller's allocation (dq_qnet_forward: obs_dev rows live in one 4-byte-aligned allocation whose size is a
     //      multiple of 4).  The copies fly while the weights are split below. ------------------------------------------------------
     {
+        // wave w takes samples w, w + 4, ...: their ring rows (scalar loads) are all requested BEFORE the first copy -- one after the
+        // other, every sample's copy waited for its own index
         const int pieces = (a.slot + 255) >> 8;
-        for (int task = wave; task < ns * pieces; task += CONV_WAVES) {
-            const int s = task / pieces, pc = task - s * pieces;
-            int row = b0 + s;
-            if (J.index) { row = J.index[row] + J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
+        constexpr int SPW = 4;                                      // samples per wave at most (S <= 16)
+        int rows[SPW];
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            const int s = min(wave + CONV_WAVES * q, ns - 1);
+            rows[q] = J.index ? J.index[b0 + s] : b0 + s;
+        }
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            const int s = wave + CONV_WAVES * q;
+            if (s >= ns) break;                                     // wave-uniform
+            int row = rows[q];
+            if (J.index) { row += J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
             const u8* src = J.obs + (size_t)row * in_bytes;
             const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
-            const int d = pc * 64 + lane;
-            if (4 * d < mis + in_bytes)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32*>(src - mis) + d,
-                                                 (__attribute__((address_space(3))) u32*)(s_in + s * a.slot + pc * 256), 4, 0, 0);
-            if (pc == 0 && lane == 0) s_mis[s] = mis;
+            for (int pc = 0; pc < pieces; ++pc) {
+                const int d = pc * 64 + lane;
+                if (4 * d < mis + in_bytes)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32*>(src - mis) + d,
+                                                     (__attribute__((address_space(3))) u32*)(s_in + s * a.slot + pc * 256), 4, 0, 0);
+            }
+            if (lane == 0) s_mis[s] = mis;
         }
     }
     __syncthreads();                                                // s_mis

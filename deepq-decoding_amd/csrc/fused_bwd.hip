@@ -869,17 +869,18 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     auto issue_obs = [&](int g) {
         const int gb0 = g * S, gns = min(S, a.batch - gb0);
         const int pieces = (a.slot + 255) >> 8;
-        for (int task = wave; task < gns * pieces; task += CB_WAVES) {
-            const int s = task / pieces, pc = task - s * pieces;
+        for (int s = wave; s < gns; s += CB_WAVES) {                // one sample per wave (S <= 8): ONE ring-row lookup, then all its pieces
             int row = gb0 + s;
             if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
             const u8* src = a.obs + (size_t)row * in_bytes;
             const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
-            const int d = pc * 64 + lane;
-            if (4 * d < mis + in_bytes)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32*>(src - mis) + d,
-                                                 (__attribute__((address_space(3))) u32*)(s_in + s * a.slot + pc * 256), 4, 0, 0);
-            if (pc == 0 && lane == 0) s_mis[s] = mis;
+            for (int pc = 0; pc < pieces; ++pc) {
+                const int d = pc * 64 + lane;
+                if (4 * d < mis + in_bytes)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32*>(src - mis) + d,
+                                                     (__attribute__((address_space(3))) u32*)(s_in + s * a.slot + pc * 256), 4, 0, 0);
+            }
+            if (lane == 0) s_mis[s] = mis;
         }
     };
     if ((int)blockIdx.x < a.groups) {
