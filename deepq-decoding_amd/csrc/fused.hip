@@ -382,7 +382,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [2][ROWS][LDP]
     {
         const int q4 = K1 >> 2;                                     // float4 per row
-        constexpr int NBS = 3;                                      // loads in flight per thread before the first split / LDS store
+        constexpr int NBS = RT == 4 ? 9 : RT == 2 ? 5 : 3;           // loads in flight per thread before the first split / LDS store: the whole image
         for (int i0 = tid; i0 < ROWS * q4; i0 += NBS * DENSE_THREADS) {
             f32x4 vv[NBS];
 #pragma unroll
