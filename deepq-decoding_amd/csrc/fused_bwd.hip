@@ -710,7 +710,7 @@ struct ConvBwdArgs {
     float* partial;                     // [gridDim.x][pstride]
     size_t pstride;
     int slot;
-    int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko;
+    int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp;
     int a1_alt;                         // bytes from the a1 image to its second buffer, 0 = single-buffered
     const int* kofftab;                 // [96] conv1 weight row k -> byte offset inside an observation, -1 past K1
 };
@@ -812,6 +812,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     int* s_ko = reinterpret_cast<int*>(smem + a.off_ko);
     int* t2 = reinterpret_cast<int*>(smem + a.off_t2);
     int* t3 = reinterpret_cast<int*>(smem + a.off_t3);
+    int* t1 = reinterpret_cast<int*>(smem + a.off_tp);              // [S*r1]: sample << 16 | byte offset of the pixel's patch origin inside an observation
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     const int S = a.S, r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
     const int in_bytes = a.C * a.H * a.W;
@@ -821,8 +822,9 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 
     DQ_STAMP_PAIR2(3);
     // ---- group-independent tables and zero rows ----------------------------------------------------------------
-    for (int m = tid; m < S * r3; m += CB_THREADS) { const int s = m / r3, p = m - s * r3, oy = p / a.ow3, ox = p - oy * a.ow3; t3[m] = s * r2 + oy * a.ow2 + ox; }
-    for (int m = tid; m < S * r2; m += CB_THREADS) { const int s = m / r2, p = m - s * r2, oy = p / a.ow2, ox = p - oy * a.ow2; t2[m] = s * r1 + oy * a.ow1 + ox; }
+    for (int m = tid; m < S * r3; m += CB_THREADS) { const int s = m / r3, p = m - s * r3, oy = p / a.ow3, ox = p - oy * a.ow3; t3[m] = (s * r2 + oy * a.ow2 + ox) * 36; }     // float offset of the a2 row
+    for (int m = tid; m < S * r2; m += CB_THREADS) { const int s = m / r2, p = m - s * r2, oy = p / a.ow2, ox = p - oy * a.ow2; t2[m] = (s * r1 + oy * a.ow1 + ox) * A1PS; }   // float offset of the a1 row
+    for (int m = tid; m < S * r1; m += CB_THREADS) { const int s = m / r1, p = m - s * r1, oy = p / a.ow1, ox = p - oy * a.ow1; t1[m] = s << 16 | ((oy * a.st1) * a.W + ox * a.st1); }
     if (tid < 96) s_ko[tid] = a.kofftab[tid];
     if (tid < 36) { s_a2[zero2 * 36 + tid] = 0.f; s_g3[zero3 * 36 + tid] = 0.f; }
 
@@ -830,12 +832,12 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     // dW3 [128 x 32]: wave w owns k-tile w = (ky,kx) = w>>1, channels 16*(w&1)..; dW2 [256 x 32]: k-tiles 2w, 2w+1 = (ky,kx) = w>>1, channels 16*(2(w&1)+u)
     // dW1 [16 KG1 x 64]: tile id = wave + 8u -> k-tile id>>2, n-tile wave & 3 (the same for every u)
     const int kyx = wave >> 1, ky = kyx >> 1, kx = kyx & 1;
-    const int aoff3 = (ky * a.ow2 + kx) * 36 + 16 * (wave & 1) + j;
+    const int aoff3 = (ky * a.ow2 + kx) * 36 + 16 * (wave & 1) + j;       // (t3 / t2 hold float offsets of rows)
     const int aoff2 = (ky * a.ow1 + kx) * A1PS + 32 * (wave & 1) + j;
-    f32x4 acc3[2], acc2[2][2], acc1[NW1], acc1l[NW1];
+    f32x4 acc3[2], acc3l[2], acc2[2][2], acc2l[2][2], acc1[NW1], acc1l[NW1];
     float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[0][t] = acc3[t]; acc2[1][t] = acc3[t]; }
+    for (int t = 0; t < 2; ++t) { acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[0][t] = acc3[t]; acc2[1][t] = acc3[t]; acc2l[0][t] = acc3[t]; acc2l[1][t] = acc3[t]; acc3l[t] = acc3[t]; }
 #pragma unroll
     for (int u = 0; u < NW1; ++u) { acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1l[u] = acc1[u]; }
 
@@ -913,17 +915,26 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         //      operand is 16 consecutive bytes per quarter-wave instead of a scattered byte gather -------------------------------
         for (int task = tid; task < M1 * (KP / 16); task += CB_THREADS) {
             const int m = task / (KP / 16), q = task - m * (KP / 16);
-            const int s = m / r1, p = m - s * r1, oy = p / a.ow1, ox = p - oy * a.ow1;
-            const u8* op = s_in + s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
+            const int to = t1[m], s = to >> 16;                    // (sample, byte offset of the patch origin inside its observation)
+            const u8* op = s_in + s * a.slot + s_mis[s] + (to & 0xffff);
+            // the 16 offsets first (four ds_read_b128), then 16 UNCONDITIONAL byte reads at clamped offsets, masked by select afterwards:
+            // a read under `off >= 0 ? .. : 0` is a branch with its own s_waitcnt -- 32 serialised LDS latencies per task (measured:
+            // 3K cycles per task, 5.9K for this phase)
+            int ko[16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int4 k4 = *reinterpret_cast<const int4*>(s_ko + 16 * q + 4 * e);
+                ko[4 * e] = k4.x; ko[4 * e + 1] = k4.y; ko[4 * e + 2] = k4.z; ko[4 * e + 3] = k4.w;
+            }
+            u32 by[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) by[e] = op[max(ko[e], 0)];
             u32 wd[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 u32 v = 0;
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    const int off = s_ko[16 * q + 4 * e + bb];
-                    v |= (off >= 0 ? (u32)op[off] : 0u) << (8 * bb);
-                }
+                for (int bb = 0; bb < 4; ++bb) v |= (ko[4 * e + bb] >= 0 ? by[4 * e + bb] : 0u) << (8 * bb);
                 wd[e] = v;
             }
             *reinterpret_cast<uint4*>(s_col + m * KP + 16 * q) = uint4{wd[0], wd[1], wd[2], wd[3]};
@@ -931,25 +942,51 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 2);
         // ---- dW3 += im2col(a2)^T g3 ------------------------------------------------------------------------------
-        for (int m0 = 0; m0 < M3; m0 += 16) {                         // 4 MFMA steps per trip: all LDS reads first, then the MFMAs
-            float av[4], g0[4], g1[4];
+        {
+            // f16 pipe, as dW2 below: K = 32 rows per block, lane (j, kq) supplies rows m0 + 4kq + (e & 3) + 16 (e >> 2) of its column of each operand
+            // FULL: the block lies inside M3 -- no clamps, no selects, and every address is affine in e (immediate offsets)
+            auto rd = [&](int m0, float (&av)[8], float (&g0)[8], float (&g1)[8]) {
+                if (m0 + 32 <= M3) {                                  // wave-uniform
+                    const int* tp = t3 + m0 + 4 * kq;
+                    const float* gp = s_g3 + (m0 + 4 * kq) * 36 + j;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m0 + 4 * q + kq;
-                const bool ok = m < M3;
-                const int mc = ok ? m : 0;
-                // unconditional reads of a clamped row, masked by SELECT: a read under `ok ? .. : 0` becomes a branch with its own
-                // s_waitcnt, which serialises every LDS latency of the trip
-                const float ra = s_a2[t3[mc] * 36 + aoff3], r0 = s_g3[mc * 36 + j], r1 = s_g3[mc * 36 + 16 + j];
-                av[q] = ok ? ra : 0.f;
-                g0[q] = ok ? r0 : 0.f;
-                g1[q] = ok ? r1 : 0.f;
-            }
+                    for (int e = 0; e < 8; ++e) {
+                        const int ro = (e & 3) + 16 * (e >> 2);
+                        av[e] = s_a2[tp[ro] + aoff3];
+                        g0[e] = gp[ro * 36];
+                        g1[e] = gp[ro * 36 + 16];
+                    }
+                } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc3[0] = MFMA16(av[q], g0[q], acc3[0]);
-                acc3[1] = MFMA16(av[q], g1[q], acc3[1]);
-                bs3[0] += g0[q]; bs3[1] += g1[q];
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = m0 + 4 * kq + (e & 3) + 16 * (e >> 2);
+                        const bool ok = m < M3;
+                        const int mc = ok ? m : 0;
+                        // unconditional reads of a clamped row, masked by SELECT: a read under `ok ? .. : 0` becomes a branch with its
+                        // own s_waitcnt, which serialises every LDS latency of the trip
+                        const float ra = s_a2[t3[mc] + aoff3], r0 = s_g3[mc * 36 + j], r1 = s_g3[mc * 36 + 16 + j];
+                        av[e] = ra;                                 // rows past M3 are masked through g alone
+                        g0[e] = ok ? r0 : 0.f;
+                        g1[e] = ok ? r1 : 0.f;
+                    }
+                }
+            };
+            auto mm = [&](const float (&av)[8], const float (&g0)[8], const float (&g1)[8]) {
+                const F16x2 A = split_f16x2(f32x4{av[0], av[1], av[2], av[3]}, f32x4{av[4], av[5], av[6], av[7]});
+                const F16x2 G0 = split_f16x2(f32x4{g0[0], g0[1], g0[2], g0[3]}, f32x4{g0[4], g0[5], g0[6], g0[7]});
+                const F16x2 G1 = split_f16x2(f32x4{g1[0], g1[1], g1[2], g1[3]}, f32x4{g1[4], g1[5], g1[6], g1[7]});
+                mma_f16x3(A, G0, acc3[0], acc3l[0]);
+                mma_f16x3(A, G1, acc3[1], acc3l[1]);
+                if (wave == 1) {                                    // (the bias gradient is the same sum in every wave: one keeps it)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { bs3[0] += g0[e]; bs3[1] += g1[e]; }
+                }
+            };
+            float aA[8], g0A[8], g1A[8], aB[8], g0B[8], g1B[8];
+            rd(0, aA, g0A, g1A);
+            for (int m0 = 0;;) {
+                rd(m0 + 32, aB, g0B, g1B); mm(aA, g0A, g1A); m0 += 32; if (m0 >= M3) break;
+                rd(m0 + 32, aA, g0A, g1A); mm(aB, g0B, g1B); m0 += 32; if (m0 >= M3) break;
             }
         }
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 3);
@@ -966,27 +1003,61 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         }
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
         // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
-        for (int m0 = 0; m0 < M2; m0 += 32) {                         // 8 MFMA steps per trip: two dependent LDS latencies per 32 MFMAs
-            float av0[8], av1[8], g0[8], g1[8];
+        {
+            // On the f16 pipe (f16x2, qnet.h): one K = 32 block = 32 rows, lane (j, kq) supplies rows m0 + 4kq + (e & 3) + 16 (e >> 2) (e = 0 .. 7;
+            // any assignment of the block's rows to (kq, e) is a permutation of the reduction index as long as both operands use it; this one puts
+            // the g rows of lanes kq, kq + 1 -- one ds_read_b32 lane group -- 4 x 36 floats = 16 banks apart: conflict-free) of its
+            // column of each operand -- the same eight ds_read_b32 per operand tile the f32 MFMAs took, but 12 K = 32 MFMAs (192 pipe
+            // cycles) per trip instead of 32 K = 4 ones (1024), for 4 operand splits (~96 VALU).  The LDS reads of trip t + 1 are issued
+            // before the splits and MFMAs of trip t.
+            auto rd = [&](int m0, float (&av0)[8], float (&av1)[8], float (&g0)[8], float (&g1)[8]) {
+                if (m0 + 32 <= M2) {                                  // wave-uniform: no clamps, no selects, affine addresses
+                    const int* tp = t2 + m0 + 4 * kq;
+                    const float* gp = s_a2 + (m0 + 4 * kq) * 36 + j;
+                    const float* ab = s_a1 + aoff2;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int m = m0 + 4 * q + kq;
-                const bool ok = m < M2;
-                const int mc = ok ? m : 0;
-                const float* ap = s_a1 + t2[mc] * A1PS + aoff2;
-                const float ra0 = ap[0], ra1 = ap[16], r0 = s_a2[mc * 36 + j], r1 = s_a2[mc * 36 + 16 + j];     // unconditional, then select
-                av0[q] = ok ? ra0 : 0.f;
-                av1[q] = ok ? ra1 : 0.f;
-                g0[q] = ok ? r0 : 0.f;
-                g1[q] = ok ? r1 : 0.f;
-            }
+                    for (int e = 0; e < 8; ++e) {
+                        const int ro = (e & 3) + 16 * (e >> 2);
+                        const float* ap = ab + tp[ro];
+                        av0[e] = ap[0];
+                        av1[e] = ap[16];
+                        g0[e] = gp[ro * 36];
+                        g1[e] = gp[ro * 36 + 16];
+                    }
+                } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                acc2[0][0] = MFMA16(av0[q], g0[q], acc2[0][0]);
-                acc2[0][1] = MFMA16(av0[q], g1[q], acc2[0][1]);
-                acc2[1][0] = MFMA16(av1[q], g0[q], acc2[1][0]);
-                acc2[1][1] = MFMA16(av1[q], g1[q], acc2[1][1]);
-                bs2[0] += g0[q]; bs2[1] += g1[q];
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = m0 + 4 * kq + (e & 3) + 16 * (e >> 2);
+                        const bool ok = m < M2;
+                        const int mc = ok ? m : 0;
+                        const float* ap = s_a1 + t2[mc] + aoff2;
+                        const float ra0 = ap[0], ra1 = ap[16], r0 = s_a2[mc * 36 + j], r1 = s_a2[mc * 36 + 16 + j];     // unconditional, then select
+                        av0[e] = ra0;                               // rows past M2 are masked through g alone
+                        av1[e] = ra1;
+                        g0[e] = ok ? r0 : 0.f;
+                        g1[e] = ok ? r1 : 0.f;
+                    }
+                }
+            };
+            auto mm = [&](const float (&av0)[8], const float (&av1)[8], const float (&g0)[8], const float (&g1)[8]) {
+                const F16x2 A0 = split_f16x2(f32x4{av0[0], av0[1], av0[2], av0[3]}, f32x4{av0[4], av0[5], av0[6], av0[7]});
+                const F16x2 A1 = split_f16x2(f32x4{av1[0], av1[1], av1[2], av1[3]}, f32x4{av1[4], av1[5], av1[6], av1[7]});
+                const F16x2 G0 = split_f16x2(f32x4{g0[0], g0[1], g0[2], g0[3]}, f32x4{g0[4], g0[5], g0[6], g0[7]});
+                const F16x2 G1 = split_f16x2(f32x4{g1[0], g1[1], g1[2], g1[3]}, f32x4{g1[4], g1[5], g1[6], g1[7]});
+                mma_f16x3(A0, G0, acc2[0][0], acc2l[0][0]);
+                mma_f16x3(A0, G1, acc2[0][1], acc2l[0][1]);
+                mma_f16x3(A1, G0, acc2[1][0], acc2l[1][0]);
+                mma_f16x3(A1, G1, acc2[1][1], acc2l[1][1]);
+                if (wave == 0) {                                    // (the bias gradient is the same sum in every wave: one keeps it)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { bs2[0] += g0[e]; bs2[1] += g1[e]; }
+                }
+            };
+            float a0A[8], a1A[8], g0A[8], g1A[8], a0B[8], a1B[8], g0B[8], g1B[8];
+            rd(0, a0A, a1A, g0A, g1A);
+            for (int m0 = 0;;) {
+                rd(m0 + 32, a0B, a1B, g0B, g1B); mm(a0A, a1A, g0A, g1A); m0 += 32; if (m0 >= M2) break;
+                rd(m0 + 32, a0A, a1A, g0A, g1A); mm(a0B, a1B, g0B, g1B); m0 += 32; if (m0 >= M2) break;
             }
         }
         dgrad_load_w(bw, a.packed + PK_CONV2_DG + 8 * PK_BLOCK * (wave >> 2), lane);      // (96 registers of pieces: not held across dW2)
@@ -1005,21 +1076,32 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             const float* gp = s_a1 + 16 * (wave & 3) + j;
             // On the f16 pipe: the patch operand is binary (exact in f16) and g1 is split into two f16 pieces (qnet.h), so one K = 32
             // MFMA per piece replaces eight f32 MFMAs (64 instead of 512 pipe cycles per 32 rows and two tiles) and the eight byte ->
-            // float conversions per tile become four multiplies.  Lane (j, kq) supplies rows m0 + 8kq .. + 7 of column j of both
-            // operands.  The LDS reads of trip t + 1 are issued before the MFMAs of trip t.
+            // float conversions per tile become four multiplies.  Lane (j, kq) supplies rows m0 + kq + 4e of column j of both
+            // operands (lanes kq, kq + 1 read patch bytes 16 banks apart).  The LDS reads of trip t + 1 are issued before the MFMAs of trip t.
             auto rd = [&](int m0, u32 (&ab)[NW1][8], float (&g)[8]) {
+                if (m0 + 32 <= M1) {                                  // wave-uniform: no clamps, no selects, affine addresses
+                    const u8* cb = cp + (m0 + kq) * KP;
+                    const float* gb = gp + (m0 + kq) * A1PS;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int m = m0 + 8 * kq + e;
-                    const bool ok = m < M1;
-                    const int mc = ok ? m : 0;
+                    for (int e = 0; e < 8; ++e) {
 #pragma unroll
-                    for (int u = 0; u < NW1; ++u) {
-                        const bool tv = wave + CB_WAVES * u < 4 * KG1;                                  // this wave has a u-th tile
-                        ab[u][e] = cp[mc * KP + (tv ? 32 * u : 0)];                                     // 0 or 1; rows past M1 are masked through g
+                        for (int u = 0; u < NW1; ++u) ab[u][e] = cb[4 * e * KP + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)];
+                        g[e] = gb[4 * e * A1PS];
                     }
-                    const float rg = gp[mc * A1PS];
-                    g[e] = ok ? rg : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = m0 + kq + 4 * e;
+                        const bool ok = m < M1;
+                        const int mc = ok ? m : 0;
+#pragma unroll
+                        for (int u = 0; u < NW1; ++u) {
+                            const bool tv = wave + CB_WAVES * u < 4 * KG1;                              // this wave has a u-th tile
+                            ab[u][e] = cp[mc * KP + (tv ? 32 * u : 0)];                                 // 0 or 1; rows past M1 are masked through g
+                        }
+                        const float rg = gp[mc * A1PS];
+                        g[e] = ok ? rg : 0.f;
+                    }
                 }
             };
             // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
@@ -1030,12 +1112,14 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 for (int u = 0; u < NW1; ++u) {
                     u32x4 av;
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[u][e] | (ab[u][e + 1] << 16)) * 0x3c00u;      // f16(1.0) = 0x3c00
+                    for (int e = 0; e < 8; e += 2) av[e >> 1] = __umul24(ab[u][e] | (ab[u][e + 1] << 16), 0x3c00u);      // f16(1.0) = 0x3c00; v_mul_u32_u24 (a 32-bit multiply is quarter rate)
                     acc1[u] = MFMA_F16(av, gb.h, acc1[u]);
                     acc1l[u] = MFMA_F16(av, gb.l, acc1l[u]);
                 }
+                if (wave < 4) {                                     // (waves 0 .. 3 store the bias gradient of their column tile)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bs1 += g[e];
+                    for (int e = 0; e < 8; ++e) bs1 += g[e];
+                }
             };
             u32 abA[NW1][8], abB[NW1][8];
             float gA[8], gB[8];
@@ -1054,9 +1138,9 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            out[a.w_off[2] + (16 * wave + 4 * kq + r) * 32 + 16 * t + j] = acc3[t][r];
+            out[a.w_off[2] + (16 * wave + 4 * kq + r) * 32 + 16 * t + j] = f16x2_sum(acc3[t][r], acc3l[t][r]);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) out[a.w_off[1] + (16 * (2 * wave + u) + 4 * kq + r) * 32 + 16 * t + j] = acc2[u][t][r];
+            for (int u = 0; u < 2; ++u) out[a.w_off[1] + (16 * (2 * wave + u) + 4 * kq + r) * 32 + 16 * t + j] = f16x2_sum(acc2[u][t][r], acc2l[u][t][r]);
         }
 #pragma unroll
     for (int u = 0; u < NW1; ++u) {
@@ -1075,13 +1159,12 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             }
         }
     }
-    if (wave == 0) {
+    if (wave < 2) {                                                 // wave 0 kept the second convolution's bias sums, wave 1 the third's
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            float v3 = bs3[t], v2 = bs2[t];
-            v3 += __shfl_xor(v3, 16); v3 += __shfl_xor(v3, 32);
-            v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
-            if (kq == 0) { out[a.b_off[2] + 16 * t + j] = v3; out[a.b_off[1] + 16 * t + j] = v2; }
+            float v = wave ? bs3[t] : bs2[t];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (kq == 0) out[a.b_off[wave ? 2 : 1] + 16 * t + j] = v;
         }
     }
 }
@@ -1107,7 +1190,7 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     return true;
 }
 
-struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, a1_alt; size_t lds; };
+struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp, a1_alt; size_t lds; };
 
 static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
     if (Q->cfg.n_conv != 3) return false;
@@ -1134,6 +1217,7 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
         P->off_t2 = (int)off; off += up16((size_t)S * L2.rows * 4);
         P->off_t3 = (int)off; off += up16((size_t)S * L3.rows * 4);
         P->off_ko = (int)off; off += 96 * 4;
+        P->off_tp = (int)off; off += up16((size_t)S * L1.rows * 4);
         if (off <= CHAIN_LDS_MAX && S * L1.rows * 16 <= 7 * CB_THREADS) { P->S = S; P->lds = off; return true; }
     }
     return false;
@@ -1294,7 +1378,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
     ca.partial = conv_partial; ca.pstride = conv_floats;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.a1_alt = cp.a1_alt; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
-    ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3; ca.off_ko = cp.off_ko; ca.kofftab = Q->kofftab;
+    ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3; ca.off_ko = cp.off_ko; ca.off_tp = cp.off_tp; ca.kofftab = Q->kofftab;
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
     conv_bwd_kernel_t ck = cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;
