@@ -115,12 +115,15 @@ class FullLoop:
         }
 
     def f16_pipe_factor(self):
-        """family -> f16 MFMA flops issued per algorithmic f32 flop (work-weighted) for the kernels that run on the f16 pipe."""
+        """family -> f16 MFMA flops issued per algorithmic f32 flop (work-weighted): every fused kernel runs on the f16 pipe (f16x2,
+        csrc/qnet.h) -- 3 MFMAs per product, 2 where one operand is the binary observation (conv1 forward, its weight gradient)."""
         nc, lm = len(C_LAYERS), self.layer_macs
         if not self.net.fused_supported:
             return {}
-        conv = sum(lm[:nc])
-        return {"conv_chain_kernel": (2.0 * lm[0] + 3.0 * sum(lm[1:nc])) / conv}      # conv1's operand is binary: the weight's 2 pieces suffice
+        conv, rest = sum(lm[:nc]), sum(lm[1:nc])
+        return {"conv_chain_kernel": (2.0 * lm[0] + 3.0 * rest) / conv,
+                "conv_bwd_chain_kernel": (2.0 * lm[0] + 3.0 * rest + 3.0 * rest) / (conv + rest),     # weight gradients + data gradients
+                "dense_chain_kernel": 3.0, "dense_bwd_chain_kernel": 3.0, "dense_wgrad_kernel": 3.0}
 
     def _family_id(self, name):
         for i in range(self.L.dq_prof_kernel_count()):

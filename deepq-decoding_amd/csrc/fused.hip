@@ -1,29 +1,27 @@
-// Fused forward of the convolutional Q-network: two launches per forward, activations never leave the CU inside a chain.
+// Fused forward of the convolutional Q-network: two launches per forward (or per group of up to FWD_MAX_JOBS forwards), activations
+// never leave the CU inside a chain.
 //
 // Same arithmetic as the per-layer path in qnet.hip (Keras model of build_convolutional_nn,
-// /root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:61-90, + keras-rl dueling head), laid out
-// for MI355X.  The network is tiny per sample (0.89 MFLOP and ~12 KB of activations at d=5), so a per-layer GEMM launch
-// is dominated by prologue, epilogue and HBM round trips.  f32-input MFMA is the bound (64 FLOP/clk/SIMD): one
-// v_mfma_f32_16x16x4_f32 occupies its SIMD for 32 cycles, so the kernels are organised to issue NOTHING but MFMAs and a
-// trickle of wide LDS reads in their inner loops:
+// /root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:61-90, + keras-rl dueling head), laid out for MI355X.
+// The network is tiny per sample (0.89 MFLOP and ~12 KB of activations at d=5), so a per-layer GEMM launch is dominated by prologue,
+// epilogue and HBM round trips, and the f32-input MFMA (64 FLOP/clk/SIMD: one v_mfma_f32_16x16x4_f32 occupies its SIMD for 32 cycles)
+// would be the bound.  The chains therefore run on the f16 matrix pipe at f32-class accuracy ("f16x2", qnet.h: every operand as two
+// f16 pieces, three v_mfma_f32_16x16x32_f16 per product, f32 accumulation; results within 1e-5 of the float64 oracle like the per-layer
+// f32 path) and are organised around what then bounds them -- VALU / LDS issue on the SIMD that also issues the MFMAs:
 //
-//   conv_chain_kernel   workgroup = 4 waves = S samples (2 workgroups per CU).  uint8 observation rows (optionally
-//                       gathered from the replay ring) and every convolution's output live in LDS.  Each layer is an
-//                       im2col GEMM whose B operand -- the layer's whole weight matrix for the wave's columns -- is held
-//                       STATIONARY IN REGISTERS (<= 128 VGPRs) and whose A operand is one ds_read_b128 per four MFMA
-//                       k-steps, read straight out of the previous layer's LDS image.
-//   dense_chain_kernel  workgroup = 8 waves = 16 samples.  Flatten permutation, Dense(512)+ReLU(+Philox dropout) with
-//                       the weights streamed from L2 as float4 rows, double-buffered in registers; Dense(|A|) split over
-//                       K across the 8 waves and reduced in fixed order through LDS; the dueling layer and combination.
+//   conv_chain_kernel   workgroup = 4 waves = S samples (2 workgroups per CU).  uint8 observation rows (optionally gathered from the
+//                       replay ring) arrive by LDS-DMA; every convolution's output lives in LDS as READY-MADE f16 piece planes, written
+//                       once by the producing layer's epilogue ("split on write": each value is read by four taps).  conv1: binary
+//                       operand gathered byte-wise, the kernel's pieces pre-packed (two MFMAs per product are exact); conv2 / conv3:
+//                       A = one ds_read_b128 per piece, B = packed weight pieces streamed through a register ring.
+//   dense_chain_kernel  workgroup = 8 waves = 16 RT samples.  Both dense layers run TRANSPOSED (weights as the MFMA's first operand,
+//                       samples as columns): the hidden layer's accumulators ARE Dense(|A|)'s second operand, so bias, ReLU, dropout
+//                       and the split happen in registers and the hidden layer never goes through LDS; Dense(|A|) is split over K
+//                       across the 8 waves and reduced in fixed order through LDS; the dueling layer and combination follow.
 //
-// Two index tricks make every operand access wide.  (1) The four k's of one MFMA need not be consecutive: lane (kq, i)
-// reads A[i][k0+4kq .. k0+4kq+3] as ONE float4 and MFMA s of the group consumes component s, i.e. covers
-// k in {k0+4kq+s}; B registers are loaded to match.  (2) The 16 columns of an MFMA tile need not be consecutive: with NT
-// tiles per wave, tile t lane j is column c0 + NT*j + t, so one float4/float2 load of a weight row feeds NT tiles and a
-// lane ends up owning NT consecutive output columns of a row -> vector stores.
-// The k order inside a dot product therefore differs from the per-layer kernels (both are exact-f32 fmaf chains, in
-// different orders): the two paths agree to f32 round-off, not bit for bit; each is deterministic.
-// Training forwards additionally write every layer's output to HBM in the layout qnet.hip's backward expects.
+// The order of the reduction inside a dot product differs from the per-layer kernels: the two paths agree to f32 round-off, not bit for
+// bit; each is deterministic.  Training forwards additionally write every layer's output to HBM (f32, the layout qnet.hip's backward
+// expects) and the dense layers' inputs / outputs as f16 piece planes for the dense weight gradients (fused_bwd.hip).
 #include "qnet.h"
 
 DQ_STAMP_READER(dq_dbg_read_fwd)

@@ -1,14 +1,16 @@
 // Fused backward of the convolutional Q-network (the backward half of keras-rl's trainable_model.train_on_batch,
 // /root/reference/cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:119-130), for the configurations fused.hip covers.
 //
-//   dense_bwd_chain_kernel   workgroup = 8 waves = 16 samples: dueling backward, then the data gradients of the three dense
-//                            layers chained through LDS -- g3 -> gY2 = g3 W3^T -> gH1 = (gY2 W2^T) * [h1 > 0] * 1/(1-rate)
-//                            -> gX = (gH1 W1^T) * [x > 0], un-flattened to NHWC.  Every gradient is also written to HBM
-//                            (the weight gradients read them from there).  Operand tricks as in fused.hip: the reduction
-//                            index of an MFMA group is permuted so that A (LDS) and, for W1, B (global: rows of W1 ARE the
-//                            transposed operand's columns) are read as float4.
-// Gradients w.r.t. pre-activations are stored per layer in Q->gz[layer]; weight gradients and the convolutional data gradients
-// still run through qnet.hip's per-layer kernels (layer_wgrad / layer_dgrad).
+//   dense_bwd_chain_kernel   workgroup = 8 waves = 16 samples: (optionally the TD step first) dueling backward, then the data
+//                            gradients of the three dense layers chained through LDS -- g3 -> gY2 = g3 W3^T -> gH1 = (gY2 W2^T) *
+//                            [h1 > 0] * 1/(1-rate) -> gX = (gH1 W1^T) * [x > 0], un-flattened to NHWC -- on the f16 pipe (f16x2,
+//                            qnet.h): W^T as packed pieces, every gradient split once, on write, into f16 piece planes (LDS for the
+//                            next layer, HBM for the weight gradients).  Extra workgroups carry the episode bookkeeping or the whole
+//                            environment step of the vector step (env_dev.h).
+//   dense_wgrad_kernel       weight + bias gradients of all dense layers in one launch from the piece planes.
+//   conv_bwd_chain_kernel    persistent: data AND weight gradients of the three convolutions, no convolutional gradient touches HBM.
+//   reduce_slices_kernel     fixed-order sum of the partials (+ Adam).
+// Configurations the fused chains do not cover run through qnet.hip's per-layer kernels.
 #include <type_traits>
 #include "qnet.h"
 #include "env_dev.h"
@@ -688,9 +690,12 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
 //   dW1 += im2col(obs)^T g1
 // so no convolutional gradient ever touches HBM.  Weight-gradient accumulators stay in registers across the workgroup's
 // groups; each workgroup writes ONE partial at the end (reduced in fixed order by reduce_slices_kernel).
-// Data gradients use the forward's operand tricks (weights for the wave's columns stationary in registers as float4 along
-// the reduction index n, A = one ds_read_b128 per four k-steps, a zero row standing in for out-of-range taps); weight
-// gradients reduce over pixels, so their operands are plain ds_read_b32 in MFMA layout (conflict-free: lanes = channels).
+// Everything runs on the f16 pipe (f16x2, qnet.h).  Data gradients: one tap = one K = 32 block, A = the 32 channels of g at the tap's
+// pixel (two ds_read_b128, split on the fly), B = the tap's packed weight pieces (registers), a zero row standing in for out-of-range
+// taps.  Weight gradients reduce over pixels, so a lane supplies 8 ROWS of its column of each operand per K = 32 block: eight
+// ds_read_b32 per operand tile (the rows of a block are assigned to (lane group, element) so that the two 16-lane groups of a
+// ds_read_b32 lane group fall 16 banks apart), then one split per operand tile; the LDS reads of block t + 1 are issued before the splits
+// and MFMAs of block t; blocks that lie inside the group take a mask-free path whose addresses are affine (immediate offsets).
 #define CB_THREADS 512
 #define CB_WAVES 8
 
@@ -956,22 +961,27 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                         g0[e] = gp[ro * 36];
                         g1[e] = gp[ro * 36 + 16];
                     }
-                } else {
+                } else {                                              // the group's last block: clamped rows, raw values (masked in mm)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int m = m0 + 4 * kq + (e & 3) + 16 * (e >> 2);
-                        const bool ok = m < M3;
-                        const int mc = ok ? m : 0;
-                        // unconditional reads of a clamped row, masked by SELECT: a read under `ok ? .. : 0` becomes a branch with its
-                        // own s_waitcnt, which serialises every LDS latency of the trip
-                        const float ra = s_a2[t3[mc] + aoff3], r0 = s_g3[mc * 36 + j], r1 = s_g3[mc * 36 + 16 + j];
-                        av[e] = ra;                                 // rows past M3 are masked through g alone
-                        g0[e] = ok ? r0 : 0.f;
-                        g1[e] = ok ? r1 : 0.f;
+                        const int mc = min(m0 + 4 * kq + (e & 3) + 16 * (e >> 2), M3 - 1);
+                        av[e] = s_a2[t3[mc] + aoff3];
+                        g0[e] = s_g3[mc * 36 + j];
+                        g1[e] = s_g3[mc * 36 + 16 + j];
                     }
                 }
             };
-            auto mm = [&](const float (&av)[8], const float (&g0)[8], const float (&g1)[8]) {
+            // rows past M3 are masked HERE, a block after their reads were issued, and through g alone (a zero factor kills the product):
+            // selects next to the reads make hipcc wait for every read where it is issued (eight serialised LDS latencies per partial block)
+            auto mm = [&](int m0, const float (&av)[8], float (&g0)[8], float (&g1)[8]) {
+                if (m0 + 32 > M3) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bool ok = m0 + 4 * kq + (e & 3) + 16 * (e >> 2) < M3;
+                        g0[e] = ok ? g0[e] : 0.f;
+                        g1[e] = ok ? g1[e] : 0.f;
+                    }
+                }
                 const F16x2 A = split_f16x2(f32x4{av[0], av[1], av[2], av[3]}, f32x4{av[4], av[5], av[6], av[7]});
                 const F16x2 G0 = split_f16x2(f32x4{g0[0], g0[1], g0[2], g0[3]}, f32x4{g0[4], g0[5], g0[6], g0[7]});
                 const F16x2 G1 = split_f16x2(f32x4{g1[0], g1[1], g1[2], g1[3]}, f32x4{g1[4], g1[5], g1[6], g1[7]});
@@ -985,8 +995,10 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             float aA[8], g0A[8], g1A[8], aB[8], g0B[8], g1B[8];
             rd(0, aA, g0A, g1A);
             for (int m0 = 0;;) {
-                rd(m0 + 32, aB, g0B, g1B); mm(aA, g0A, g1A); m0 += 32; if (m0 >= M3) break;
-                rd(m0 + 32, aA, g0A, g1A); mm(aB, g0B, g1B); m0 += 32; if (m0 >= M3) break;
+                rd(m0 + 32, aB, g0B, g1B);
+                mm(m0, aA, g0A, g1A); m0 += 32; if (m0 >= M3) break;
+                rd(m0 + 32, aA, g0A, g1A);
+                mm(m0, aB, g0B, g1B); m0 += 32; if (m0 >= M3) break;
             }
         }
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 3);
@@ -1024,22 +1036,27 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                         g0[e] = gp[ro * 36];
                         g1[e] = gp[ro * 36 + 16];
                     }
-                } else {
+                } else {                                              // the group's last block: clamped rows, raw values (masked in mm)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int m = m0 + 4 * kq + (e & 3) + 16 * (e >> 2);
-                        const bool ok = m < M2;
-                        const int mc = ok ? m : 0;
+                        const int mc = min(m0 + 4 * kq + (e & 3) + 16 * (e >> 2), M2 - 1);
                         const float* ap = s_a1 + t2[mc] + aoff2;
-                        const float ra0 = ap[0], ra1 = ap[16], r0 = s_a2[mc * 36 + j], r1 = s_a2[mc * 36 + 16 + j];     // unconditional, then select
-                        av0[e] = ra0;                               // rows past M2 are masked through g alone
-                        av1[e] = ra1;
-                        g0[e] = ok ? r0 : 0.f;
-                        g1[e] = ok ? r1 : 0.f;
+                        av0[e] = ap[0];
+                        av1[e] = ap[16];
+                        g0[e] = s_a2[mc * 36 + j];
+                        g1[e] = s_a2[mc * 36 + 16 + j];
                     }
                 }
             };
-            auto mm = [&](const float (&av0)[8], const float (&av1)[8], const float (&g0)[8], const float (&g1)[8]) {
+            auto mm = [&](int m0, const float (&av0)[8], const float (&av1)[8], float (&g0)[8], float (&g1)[8]) {
+                if (m0 + 32 > M2) {                                   // rows past M2: masked through g alone, a block after the reads
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bool ok = m0 + 4 * kq + (e & 3) + 16 * (e >> 2) < M2;
+                        g0[e] = ok ? g0[e] : 0.f;
+                        g1[e] = ok ? g1[e] : 0.f;
+                    }
+                }
                 const F16x2 A0 = split_f16x2(f32x4{av0[0], av0[1], av0[2], av0[3]}, f32x4{av0[4], av0[5], av0[6], av0[7]});
                 const F16x2 A1 = split_f16x2(f32x4{av1[0], av1[1], av1[2], av1[3]}, f32x4{av1[4], av1[5], av1[6], av1[7]});
                 const F16x2 G0 = split_f16x2(f32x4{g0[0], g0[1], g0[2], g0[3]}, f32x4{g0[4], g0[5], g0[6], g0[7]});
@@ -1056,8 +1073,10 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             float a0A[8], a1A[8], g0A[8], g1A[8], a0B[8], a1B[8], g0B[8], g1B[8];
             rd(0, a0A, a1A, g0A, g1A);
             for (int m0 = 0;;) {
-                rd(m0 + 32, a0B, a1B, g0B, g1B); mm(a0A, a1A, g0A, g1A); m0 += 32; if (m0 >= M2) break;
-                rd(m0 + 32, a0A, a1A, g0A, g1A); mm(a0B, a1B, g0B, g1B); m0 += 32; if (m0 >= M2) break;
+                rd(m0 + 32, a0B, a1B, g0B, g1B);
+                mm(m0, a0A, a1A, g0A, g1A); m0 += 32; if (m0 >= M2) break;
+                rd(m0 + 32, a0A, a1A, g0A, g1A);
+                mm(m0, a0B, a1B, g0B, g1B); m0 += 32; if (m0 >= M2) break;
             }
         }
         dgrad_load_w(bw, a.packed + PK_CONV2_DG + 8 * PK_BLOCK * (wave >> 2), lane);      // (96 registers of pieces: not held across dW2)
@@ -1088,25 +1107,23 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                         for (int u = 0; u < NW1; ++u) ab[u][e] = cb[4 * e * KP + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)];
                         g[e] = gb[4 * e * A1PS];
                     }
-                } else {
+                } else {                                              // the group's last block: clamped rows, raw values (masked in mm)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int m = m0 + kq + 4 * e;
-                        const bool ok = m < M1;
-                        const int mc = ok ? m : 0;
+                        const int mc = min(m0 + kq + 4 * e, M1 - 1);
 #pragma unroll
-                        for (int u = 0; u < NW1; ++u) {
-                            const bool tv = wave + CB_WAVES * u < 4 * KG1;                              // this wave has a u-th tile
-                            ab[u][e] = cp[mc * KP + (tv ? 32 * u : 0)];                                 // 0 or 1; rows past M1 are masked through g
-                        }
-                        const float rg = gp[mc * A1PS];
-                        g[e] = ok ? rg : 0.f;
+                        for (int u = 0; u < NW1; ++u) ab[u][e] = cp[mc * KP + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)];     // 0 or 1
+                        g[e] = gp[mc * A1PS];
                     }
                 }
             };
             // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
             // (each copy waits for the result) -- a tile this wave does not have accumulates garbage that is never stored
-            auto mm = [&](const u32 (&ab)[NW1][8], const float (&g)[8]) {
+            auto mm = [&](int m0, const u32 (&ab)[NW1][8], float (&g)[8]) {
+                if (m0 + 32 > M1) {                                   // rows past M1: masked through g alone, a block after the reads
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = m0 + kq + 4 * e < M1 ? g[e] : 0.f;
+                }
                 const F16x2 gb = split_f16x2(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
 #pragma unroll
                 for (int u = 0; u < NW1; ++u) {
@@ -1125,8 +1142,10 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             float gA[8], gB[8];
             rd(0, abA, gA);
             for (int m0 = 0;;) {
-                rd(m0 + 32, abB, gB); mm(abA, gA); m0 += 32; if (m0 >= M1) break;
-                rd(m0 + 32, abA, gA); mm(abB, gB); m0 += 32; if (m0 >= M1) break;
+                rd(m0 + 32, abB, gB);
+                mm(m0, abA, gA); m0 += 32; if (m0 >= M1) break;
+                rd(m0 + 32, abA, gA);
+                mm(m0, abB, gB); m0 += 32; if (m0 >= M1) break;
             }
         }
     }
