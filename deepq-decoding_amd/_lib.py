@@ -95,6 +95,11 @@ SIGNATURES = {
     "dq_env_export_state": (_i, [_vp, _vp, _vp]),
     "dq_env_import_state": (_i, [_vp, _vp, _vp]),
     "dq_env_get_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "dq_match_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "dq_match_destroy": (None, [_vp]),
+    "dq_match_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "dq_match_get_tables": (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(_i)]),
+    "dq_match_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "dq_policy_select": (_i, [_vp, _vp, _i, _i, _dbl, _i, ctypes.POINTER(_u32), _u32, _u64, _vp, _vp]),
     "dq_qnet_create": (_i, [ctypes.POINTER(QNetCfg), ctypes.POINTER(_vp)]),
     "dq_qnet_destroy": (None, [_vp]),

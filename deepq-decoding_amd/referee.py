@@ -11,6 +11,8 @@ Nothing here runs inside the environment step: ``VectorEnv.set_referee_predict``
 2**n_stab syndromes into the kernel's joint look-up table, so on the device the referee is one table read whatever the
 network's size.  The tabulation itself is a handful of small matrix products at construction time (numpy, on the host).
 """
+import ctypes
+
 import numpy as np
 
 from .weights_io import load_weights_file
@@ -42,3 +44,76 @@ class FeedForwardReferee:
         h -= h.max(axis=1, keepdims=True)
         e = np.exp(h)
         return e / e.sum(axis=1, keepdims=True)
+
+
+class MatchingReferee:
+    """The exact minimum-weight referee for lattices too large for look-up tables (d >= 9; any odd 3 <= d <= 15), on the GPU:
+    include/deepq_hip.h ``dq_match_*`` (csrc/match.hip).  Same definition as the environment's built-in look-up referee -- class 1 iff the
+    lightest error with that syndrome and class 1 is strictly lighter than with class 0 -- and the same ``predict`` protocol the reference
+    calls (Environments.py:144): rows of flattened (d+1) x (d+1) syndromes in, one-hot class rows out."""
+
+    def __init__(self, d, error_model="DP"):
+        from . import _lib
+        import torch
+        self._lib, self._torch = _lib, torch
+        self.d, self.error_model = int(d), error_model
+        self.n_classes = 2 if error_model == "X" else 4
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().dq_match_create(self.d, ctypes.byref(h)))
+        self._h = h
+        n, k, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().dq_match_info(h, ctypes.byref(n), ctypes.byref(k), ctypes.byref(w)))
+        self.nodes, self.max_defects, self.distance = n.value, k.value, w.value
+        # plaquette (a, b) -> (component, bit) in row-major order per type (FL:32-35, 42-50: type 3 when a + b is odd)
+        self._where = {}
+        rank = [0, 0]
+        dd = self.d
+        for a in range(dd + 1):
+            for b in range(dd + 1):
+                if (a == 0 and b % 2 == 0) or (a == dd and b % 2 == 1) or (b == 0 and a % 2 == 1) or (b == dd and a % 2 == 0):
+                    continue
+                comp = 0 if (a + b) % 2 == 1 else 1
+                self._where[(a, b)] = (comp, rank[comp])
+                rank[comp] += 1
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.lib().dq_match_destroy(h)
+
+    def tables(self, component):
+        """(dist uint8 [n, n, 2], distB uint8 [n, 2], w10) of one component (0: X part, 1: Z part)."""
+        n = self.nodes
+        dist, distB, w = np.zeros((n, n, 2), np.uint8), np.zeros((n, 2), np.uint8), ctypes.c_int()
+        self._lib.check(self._lib.lib().dq_match_get_tables(self._h, int(component), dist.ctypes.data_as(ctypes.c_void_p),
+                                                           distB.ctypes.data_as(ctypes.c_void_p), ctypes.byref(w)))
+        return dist, distB, w.value
+
+    def decode(self, defects, both=None):
+        """defects: integer array [batch, 2 components, 2 words] (bit i = i-th plaquette of the component) -> (class uint8 [batch],
+        inexact uint8 [batch]) as torch CUDA tensors."""
+        torch = self._torch
+        dev = torch.as_tensor(np.ascontiguousarray(defects, dtype=np.uint64).view(np.int64)).cuda() if not torch.is_tensor(defects) else defects
+        batch = dev.shape[0]
+        cls = torch.empty(batch, dtype=torch.uint8, device="cuda")
+        flag = torch.empty(batch, dtype=torch.uint8, device="cuda")
+        both = (self.error_model != "X") if both is None else both
+        self._lib.check(self._lib.lib().dq_match_decode(self._h, dev.data_ptr(), batch, int(both), cls.data_ptr(), flag.data_ptr(),
+                                                       torch.cuda.current_stream().cuda_stream))
+        return cls, flag
+
+    def pack(self, grids):
+        """[batch, d+1, d+1] syndrome grids -> defects uint64 [batch, 2, 2]."""
+        grids = np.asarray(grids).reshape(-1, self.d + 1, self.d + 1)
+        out = np.zeros((len(grids), 2, 2), dtype=np.uint64)
+        for i, g in enumerate(grids):
+            for (a, b) in zip(*np.nonzero(g)):
+                comp, bit = self._where[(int(a), int(b))]
+                out[i, comp, bit >> 6] |= np.uint64(1) << np.uint64(bit & 63)
+        return out
+
+    def predict(self, x, batch_size=None, verbose=0):
+        cls, _ = self.decode(self.pack(x))
+        out = np.zeros((len(cls), self.n_classes), dtype=np.float32)
+        out[np.arange(len(cls)), cls.cpu().numpy()] = 1.0
+        return out

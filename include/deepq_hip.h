@@ -179,6 +179,28 @@ dq_status dq_env_get_tables(const dq_env* env, uint64_t* stab_qmask, uint64_t* q
                             uint64_t* neigh_qmask, uint8_t* stab_type);
 
 /* ---------------------------------------------------------------------------------------------
+ * Matching referee: the referee of Environments.py:53,144,150 for lattices whose syndrome space no longer fits
+ * a look-up table (d >= 9; README.md:278 allows "any perfect-measurement decoding algorithm").  Same definition as dq_env_build_referee's
+ * tables -- class 1 iff the lightest error with that syndrome and class 1 is strictly lighter than the lightest with class 0 -- computed
+ * per syndrome: minimum-weight perfect matching of the defects (with each other or a boundary) with class bookkeeping, solved exactly by
+ * dynamic programming over defect subsets, one wavefront per syndrome (csrc/match_dev.h; numpy restatement oracle/matching_referee.py).
+ * Equals the look-up referee at d <= 7 for every syndrome.  3 <= d <= 15, odd.
+ *   defects_dev  uint64 [batch][2 components][2 words]: bit i of a component = its i-th plaquette in row-major (a, b) order (the
+ *                look-up referee's index convention); component 0 = type-3 plaquettes (X part), 1 = type-1 plaquettes (Z part)
+ *   class_dev    uint8 [batch]: X part (+ 2 * Z part when both_components != 0) -- generate_one_hot_labels_surface_code's index
+ *   inexact_dev  uint8 [batch] or NULL: 1 where a component had more than max_defects defects (the lowest max_defects are matched
+ *                exactly, every further one goes to its nearer boundary)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dq_match dq_match;
+dq_status dq_match_create(int d, dq_match** out);
+void dq_match_destroy(dq_match* m);
+dq_status dq_match_info(const dq_match* m, int* nodes_per_component, int* max_defects, int* w10);
+/* host copies of one component's tables (tests): dist uint8 [n][n][2], distB uint8 [n][2] (255: no such path), w10 */
+dq_status dq_match_get_tables(const dq_match* m, int component, uint8_t* dist_host, uint8_t* distB_host, int* w10);
+dq_status dq_match_decode(const dq_match* m, const uint64_t* defects_dev, int batch, int both_components, uint8_t* class_dev,
+                          uint8_t* inexact_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Action selection: replaces EpsGreedyQPolicy / GreedyQPolicy(masked_greedy=...) of the keras-rl
  * fork (call sites Single_Point_Training_Script.py:110-115,166-167; README.md:168,262).
  *   q_dev      float [n, n_actions] or NULL (then every lattice explores: uniform over legal)

@@ -124,6 +124,31 @@ def test_referee_lut(d):
             assert lut[dl & ((1 << n) - 1)] == dl >> n
 
 
+@pytest.mark.parametrize("d", [3, 5, 7])
+def test_matching_referee_equals_the_lookup_referee(d):
+    """oracle/matching_referee.py (exact minimum weight by matching, no table) is pinned against build_lut: every syndrome of both
+    components at d = 3, 5; at d = 7 random syndromes of up to 9 defects of the X component (2^24 entries) plus all single / double defects."""
+    from oracle import matching_referee as M
+    rng = np.random.RandomState(7)
+    for typ in ((3, 1) if d < 7 else (3,)):
+        g = M.ComponentGraph(d, typ)
+        lut = referee.build_lut(d, typ)
+        assert g.w10 == d and g.n == (d * d - 1) // 2
+        if d < 7:
+            idx = range(1 << g.n)
+        else:
+            idx = [0] + [1 << i for i in range(g.n)] + [(1 << i) | (1 << j) for i in range(g.n) for j in range(i)]
+            for k in range(3, 10):
+                for _ in range(40):
+                    idx.append(sum(1 << int(b) for b in rng.choice(g.n, size=k, replace=False)))
+        bad = [i for i in idx if g.classify(i) != lut[i]]
+        assert not bad, (d, typ, bad[:5])
+    # beyond MAX_DEFECTS the rule is deterministic and flagged
+    g = M.ComponentGraph(7, 3)
+    w0, w1, exact = g.weights(list(range(M.MAX_DEFECTS + 3)))
+    assert not exact and min(w0, w1) < 255
+
+
 @pytest.mark.parametrize("d", [3, 5])
 def test_maximum_likelihood_referee_table(d):
     """The XOR-convolution restatement equals brute-force enumeration of every error pattern (d = 3), reduces to the minimum-weight
