@@ -100,6 +100,15 @@ SIGNATURES = {
     "dq_match_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "dq_match_get_tables": (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(_i)]),
     "dq_match_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "dq_envb_create": (_i, [ctypes.POINTER(EnvCfg), ctypes.POINTER(_vp)]),
+    "dq_envb_destroy": (None, [_vp]),
+    "dq_envb_get_info": (_i, [_vp, ctypes.POINTER(EnvInfo), ctypes.POINTER(_i)]),
+    "dq_envb_set_rates": (_i, [_vp, _dbl, _dbl]),
+    "dq_envb_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "dq_envb_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dq_envb_act_step": (_i, [_vp, _vp, _dbl, _i, _seedp, _u64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dq_envb_export_state": (_i, [_vp, _vp, _vp]),
+    "dq_policy_select_wide": (_i, [_vp, _vp, _i, _i, _i, _dbl, _i, ctypes.POINTER(_u32), _u32, _u64, _vp, _vp]),
     "dq_policy_select": (_i, [_vp, _vp, _i, _i, _dbl, _i, ctypes.POINTER(_u32), _u32, _u64, _vp, _vp]),
     "dq_qnet_create": (_i, [ctypes.POINTER(QNetCfg), ctypes.POINTER(_vp)]),
     "dq_qnet_destroy": (None, [_vp]),

@@ -31,7 +31,9 @@ class VectorEnv:
     """Batched environment: lattice i has global id ``env_id_base + i`` (its RNG stream)."""
 
     def __init__(self, d=5, p_phys=0.01, p_meas=0.01, error_model="DP", use_Y=True, volume_depth=3,
-                 n_envs=1, seed=DEFAULT_SEED, env_id_base=0, device=None, referee="lut"):
+                 n_envs=1, seed=DEFAULT_SEED, env_id_base=0, device=None, referee="lut", backend="auto"):
+        """backend: "auto" -- d <= 7: one 64-bit word per bit-plane, look-up referee (csrc/env.hip); d >= 9: the wide environment with the
+        matching referee (csrc/env_big.hip, include/deepq_hip.h dq_envb_*) --, or "wide" to force the latter at any d (tests)."""
         if d % 2 != 1:
             raise Exception("for the surface code d must be odd!")          # Function_Library.py:28-29
         if error_model not in _MODELS:
@@ -44,11 +46,19 @@ class VectorEnv:
         cfg = EnvCfg(d, _MODELS[error_model], int(bool(use_Y)), volume_depth, self.n_envs, self.env_id_base,
                      (ctypes.c_uint32 * 2)(*self.seed))
         h = ctypes.c_void_p()
+        self.wide = backend == "wide" or (backend == "auto" and d > 7)
+        self._pfx = "dq_envb_" if self.wide else "dq_env_"
         with torch.cuda.device(self.device):
-            check(self.L.dq_env_create(ctypes.byref(cfg), ctypes.byref(h)))
+            check(getattr(self.L, self._pfx + "create")(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
         info = EnvInfo()
-        check(self.L.dq_env_get_info(self._h, ctypes.byref(info)))
+        self.legal_words = 2
+        if self.wide:
+            lw = ctypes.c_int()
+            check(self.L.dq_envb_get_info(self._h, ctypes.byref(info), ctypes.byref(lw)))
+            self.legal_words = lw.value
+        else:
+            check(self.L.dq_env_get_info(self._h, ctypes.byref(info)))
         self.num_actions, self.n_action_layers = info.num_actions, info.n_action_layers
         self.identity_index = info.identity_index
         self.obs_shape = (info.obs_c, info.obs_h, info.obs_w)
@@ -56,16 +66,20 @@ class VectorEnv:
         self.observation_space = _Space(shape=self.obs_shape)
         self.action_space = _Space(n=self.num_actions)
         self._p_phys, self._p_meas = float(p_phys), float(p_meas)
-        check(self.L.dq_env_set_rates(self._h, self._p_phys, self._p_meas))
+        check(getattr(self.L, self._pfx + "set_rates")(self._h, self._p_phys, self._p_meas))
         dev, n = self.device, self.n_envs
         self.obs = torch.zeros((n,) + self.obs_shape, dtype=torch.uint8, device=dev)
         self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
         self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.legal = torch.zeros((n, 2), dtype=torch.int64, device=dev)     # uint64 bit masks
+        self.legal = torch.zeros((n, self.legal_words), dtype=torch.int64, device=dev)     # uint64 bit masks
         self.lifetime = torch.zeros(n, dtype=torch.int32, device=dev)
         self.was_reset = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._lut = None
-        if referee == "lut":
+        self.inexact = torch.zeros(n, dtype=torch.uint8, device=dev)         # wide backend: referee fallback used in the last step
+        if self.wide:
+            if referee not in ("lut", "matching", None):
+                raise NotImplementedError("the wide environment (d >= 9) decodes with the built-in matching referee")
+        elif referee == "lut":
             with torch.cuda.device(self.device):
                 check(self.L.dq_env_build_referee(self._h, self._stream()))
         elif referee == "ml" or (isinstance(referee, tuple) and len(referee) == 2 and referee[0] == "ml"):
@@ -83,7 +97,7 @@ class VectorEnv:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.L.dq_env_destroy(self._h)
+            getattr(self.L, self._pfx + "destroy")(self._h)
             self._h = None
 
     def __del__(self):
@@ -100,7 +114,7 @@ class VectorEnv:
     @p_phys.setter
     def p_phys(self, v):
         self._p_phys = float(v)
-        check(self.L.dq_env_set_rates(self._h, self._p_phys, self._p_meas))
+        check(getattr(self.L, self._pfx + "set_rates")(self._h, self._p_phys, self._p_meas))
 
     @property
     def p_meas(self):
@@ -109,7 +123,7 @@ class VectorEnv:
     @p_meas.setter
     def p_meas(self, v):
         self._p_meas = float(v)
-        check(self.L.dq_env_set_rates(self._h, self._p_phys, self._p_meas))
+        check(getattr(self.L, self._pfx + "set_rates")(self._h, self._p_phys, self._p_meas))
 
     def build_ml_referee(self, q_flip):
         """Installs the maximum-likelihood referee for independent X- / Z-component flips with probability q_flip per qubit."""
@@ -167,7 +181,7 @@ class VectorEnv:
         """ENV:99-115 for every lattice (or those with which[i] != 0).  Returns the uint8 observation tensor."""
         obs = self.obs if out_obs is None else out_obs
         w = None if which is None else torch.as_tensor(which, dtype=torch.uint8, device=self.device).contiguous()
-        check(self.L.dq_env_reset(self._h, ptr(w), ptr(obs), ptr(self.legal), ptr(self.lifetime), self._stream()))
+        check(getattr(self.L, self._pfx + "reset")(self._h, ptr(w), ptr(obs), ptr(self.legal), ptr(self.lifetime), self._stream()))
         if which is None:
             self.done.zero_()
         else:
@@ -179,27 +193,53 @@ class VectorEnv:
         if not (isinstance(action, torch.Tensor) and action.dtype == torch.int32 and action.is_cuda and action.is_contiguous()):
             action = torch.as_tensor(action, dtype=torch.int32, device=self.device).contiguous()
         obs = self.obs if out_obs is None else out_obs
-        check(self.L.dq_env_step(self._h, ptr(action), int(auto_reset), ptr(obs), ptr(self.reward), ptr(self.done),
-                                 ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), self._stream()))
+        if self.wide:
+            check(self.L.dq_envb_step(self._h, ptr(action), int(auto_reset), ptr(obs), ptr(self.reward), ptr(self.done),
+                                      ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), ptr(self.inexact), self._stream()))
+        else:
+            check(self.L.dq_env_step(self._h, ptr(action), int(auto_reset), ptr(obs), ptr(self.reward), ptr(self.done),
+                                     ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), self._stream()))
         return obs, self.reward, self.done
+
+    def act_step(self, t, q=None, eps=1.0, masked_greedy=False, auto_reset=True, out_obs=None, out_action=None):
+        """Action selection (the rule of select_actions) fused in front of the step: one launch.  Returns the actions taken."""
+        if out_action is None:
+            out_action = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        obs = self.obs if out_obs is None else out_obs
+        seed = (ctypes.c_uint32 * 2)(*self.seed)
+        if self.wide:
+            check(self.L.dq_envb_act_step(self._h, ptr(q), float(eps), int(masked_greedy), seed, int(t), ptr(out_action), int(auto_reset),
+                                          ptr(obs), ptr(self.reward), ptr(self.done), ptr(self.legal), ptr(self.lifetime),
+                                          ptr(self.was_reset), ptr(self.inexact), self._stream()))
+        else:
+            check(self.L.dq_env_act_step(self._h, ptr(q), float(eps), int(masked_greedy), seed, int(t), ptr(out_action), int(auto_reset),
+                                         ptr(obs), ptr(self.reward), ptr(self.done), ptr(self.legal), ptr(self.lifetime),
+                                         ptr(self.was_reset), self._stream()))
+        return out_action
 
     def select_actions(self, t, q=None, eps=1.0, masked_greedy=False, out=None):
         """Epsilon-greedy over the legal set on the device (include/deepq_hip.h: dq_policy_select)."""
         if out is None:
             out = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
         seed = (ctypes.c_uint32 * 2)(*self.seed)
-        check(self.L.dq_policy_select(ptr(q), ptr(self.legal), self.n_envs, self.num_actions, float(eps), int(masked_greedy),
-                                      seed, self.env_id_base, int(t), ptr(out), self._stream()))
+        if self.wide:
+            check(self.L.dq_policy_select_wide(ptr(q), ptr(self.legal), self.n_envs, self.num_actions, self.legal_words, float(eps),
+                                               int(masked_greedy), seed, self.env_id_base, int(t), ptr(out), self._stream()))
+        else:
+            check(self.L.dq_policy_select(ptr(q), ptr(self.legal), self.n_envs, self.num_actions, float(eps), int(masked_greedy),
+                                          seed, self.env_id_base, int(t), ptr(out), self._stream()))
         return out
 
     # -- state views --------------------------------------------------------------------------------------
     def export_state(self):
         """int64 tensor [n_envs, 11 + depth] of uint64 words (layout: include/deepq_hip.h)."""
         st = torch.zeros((self.n_envs, self.state_words), dtype=torch.int64, device=self.device)
-        check(self.L.dq_env_export_state(self._h, ptr(st), self._stream()))
+        check(getattr(self.L, self._pfx + "export_state")(self._h, ptr(st), self._stream()))
         return st
 
     def import_state(self, st):
+        if self.wide:
+            raise NotImplementedError("import_state: not offered by the wide environment")
         st = torch.as_tensor(st, dtype=torch.int64, device=self.device).contiguous()
         assert st.shape == (self.n_envs, self.state_words)
         check(self.L.dq_env_import_state(self._h, ptr(st), self._stream()))

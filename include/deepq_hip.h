@@ -201,6 +201,35 @@ dq_status dq_match_decode(const dq_match* m, const uint64_t* defects_dev, int ba
                           uint8_t* inexact_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Wide environment: the same Surface_Code_Environment_Multi_Decoding_Cycles (Environments.py:10-385) for lattices beyond one 64-bit word
+ * per bit-plane -- any odd 3 <= d <= 15, i.e. the d >= 9 the dq_env_* kernels (one word per plane, look-up referee) cannot hold
+ * (csrc/env_big.hip).  Same configuration struct, same call semantics and Philox streams as dq_env_*; differences:
+ *   - legal sets are legal_words = ceil(num_actions / 64) uint64 per lattice (dq_envb_get_info), legal_dev is uint64 [n_envs][legal_words];
+ *   - the referee is the matching referee above, built by dq_envb_create and evaluated inside every step (inexact_dev, uint8 [n_envs]
+ *     or NULL, reports where its more-than-max_defects fallback was used);
+ *   - dq_envb_export_state: uint64 [n_envs][state_words] = x[W] z[W] true_syndrome[W] summed_volume[W] acted[W] round completed[LW]
+ *     legal[LW] (lifetime | done << 32) volume[depth][W], W = ceil(d*d / 64), LW = legal_words.
+ * At d <= 7 every output equals dq_env_*'s (with its default look-up referee) bit for bit.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dq_envb dq_envb;
+dq_status dq_envb_create(const dq_env_cfg* cfg, dq_envb** out);
+void dq_envb_destroy(dq_envb* env);
+dq_status dq_envb_get_info(const dq_envb* env, dq_env_info* out, int* legal_words);
+dq_status dq_envb_set_rates(dq_envb* env, double p_phys, double p_meas);
+dq_status dq_envb_reset(dq_envb* env, const uint8_t* which_dev, uint8_t* obs_dev, uint64_t* legal_dev, uint32_t* lifetime_dev, void* stream);
+dq_status dq_envb_step(dq_envb* env, const int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev,
+                       uint64_t* legal_dev, uint32_t* lifetime_dev, uint8_t* was_reset_dev, uint8_t* inexact_dev, void* stream);
+/* dq_policy_select_wide on the lattices' current legal sets followed by dq_envb_step, in one launch (cf. dq_env_act_step) */
+dq_status dq_envb_act_step(dq_envb* env, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
+                           int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
+                           uint32_t* lifetime_dev, uint8_t* was_reset_dev, uint8_t* inexact_dev, void* stream);
+dq_status dq_envb_export_state(dq_envb* env, uint64_t* state_dev, void* stream);
+/* dq_policy_select (below) over legal sets of legal_words uint64 per lattice: same rule, same Philox words */
+dq_status dq_policy_select_wide(const float* q_dev, const uint64_t* legal_dev, int n, int n_actions, int legal_words, double eps,
+                                int masked_greedy, const uint32_t seed[2], uint32_t env_id_base, uint64_t t, int32_t* action_dev,
+                                void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Action selection: replaces EpsGreedyQPolicy / GreedyQPolicy(masked_greedy=...) of the keras-rl
  * fork (call sites Single_Point_Training_Script.py:110-115,166-167; README.md:168,262).
  *   q_dev      float [n, n_actions] or NULL (then every lattice explores: uniform over legal)

@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import load_golden, TRACES, STICKY_TRACES, trace_config
+from conftest import load_golden, TRACES, STICKY_TRACES, BIG_TRACES, trace_config
 
 pytestmark = pytest.mark.gpu
 U64 = np.uint64
@@ -66,6 +66,65 @@ def _replay(dq, torch, name, auto_reset):
 @pytest.mark.parametrize("name", TRACES)
 def test_golden_traces(dq, torch_mod, name):
     _replay(dq, torch_mod, name, True)
+
+
+def _big(words):
+    return sum(int(w) << (64 * k) for k, w in enumerate(words))
+
+
+def _replay_wide(dq, torch, name, auto_reset):
+    """The reference's traces through the WIDE environment (csrc/env_big.hip: W-word planes, matching referee): every output and the
+    whole hidden state at every step.  Traces of d <= 7 are the ones env.hip replays (the matching referee equals their look-up referee);
+    traces of d >= 9 (names b*) were generated from the reference with oracle/matching_referee.py as its static_decoder."""
+    from oracle import lattice, env_oracle
+    g = load_golden("trace_" + name)
+    cfg, n_envs, n_steps, seed = trace_config(g)
+    env = dq.VectorEnv(n_envs=n_envs, seed=seed, backend="wide", **cfg)
+    assert env.wide
+    d = cfg["d"]
+    W, LW, n_act = (d * d + 63) // 64, env.legal_words, env.num_actions
+    m = lattice.Masks(d)
+    actions = torch.from_numpy(g["action"].astype(np.int32)).cuda()
+
+    def check(t):
+        assert np.array_equal(env.obs.cpu().numpy(), g["obs"][:, t]), (name, "obs", t)
+        assert np.array_equal(env.done.cpu().numpy(), g["done"][:, t]), (name, "done", t)
+        assert np.array_equal(env.lifetime.cpu().numpy(), g["lifetime"][:, t]), (name, "lifetime", t)
+        st = _np_u64(env.export_state())
+        lg = _np_u64(env.legal)
+        for e in range(n_envs):
+            w = [int(v) for v in st[e]]
+            x, z, tw, sm, act = (_big(w[k * W:(k + 1) * W]) for k in range(5))
+            rnd, comp, legal, meta = w[5 * W], _big(w[5 * W + 1:5 * W + 1 + LW]), _big(w[5 * W + 1 + LW:5 * W + 1 + 2 * LW]), w[5 * W + 1 + 2 * LW]
+            assert np.array_equal(env_oracle.masks_to_codes(d, x, z), g["hidden"][e, t]), ("hidden", e, t)
+            assert np.array_equal(m.word_to_grid(tw), g["true_syndrome"][e, t]), ("true_syndrome", e, t)
+            assert np.array_equal(m.word_to_grid(sm), g["summed_nonzero"][e, t]), ("summed", e, t)
+            assert act == _big(np.atleast_1d(g["acted"][e, t])) and rnd == int(g["rounds"][e, t])
+            assert [(comp >> a) & 1 for a in range(n_act)] == list(g["completed"][e, t])
+            assert legal == _big(g["legal"][e, t]) == _big(lg[e]), ("legal", e, t)
+            assert (meta & 0xFFFFFFFF) == g["lifetime"][e, t] and (meta >> 32) == g["done"][e, t]
+
+    env.reset()
+    check(0)
+    for t in range(n_steps):
+        env.step(actions[:, t].contiguous(), auto_reset=auto_reset)
+        assert np.array_equal(env.reward.cpu().numpy(), g["reward"][:, t]), (name, "reward", t)
+        if d <= 7:                                                   # (the random walks of the d >= 9 traces do pile up more than 14 defects; the
+            assert not env.inexact.any().item()                      #  fallback is part of the definition and the reference ran with the same rule)
+        if auto_reset:
+            assert np.array_equal(env.was_reset.cpu().numpy(), g["was_reset"][:, t])
+        check(t + 1)
+    env.close()
+
+
+@pytest.mark.parametrize("name", TRACES + BIG_TRACES)
+def test_golden_traces_wide_environment(dq, torch_mod, name):
+    _replay_wide(dq, torch_mod, name, True)
+
+
+@pytest.mark.parametrize("name", STICKY_TRACES)
+def test_golden_sticky_traces_wide_environment(dq, torch_mod, name):
+    _replay_wide(dq, torch_mod, name, False)
 
 
 @pytest.mark.parametrize("name", STICKY_TRACES)

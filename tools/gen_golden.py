@@ -146,6 +146,11 @@ def set_to_mask2(s):
     return np.array([lo, hi], dtype=np.uint64)
 
 
+def set_to_words(s, n_words):
+    v = sum(1 << a for a in s)
+    return np.array([(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(n_words)], dtype=np.uint64)
+
+
 # ---------------------------------------------------------------------------------------------
 def gen_tables(FL, ENV, out):
     for d in (3, 5, 7):
@@ -285,6 +290,18 @@ TRACE_CONFIGS = {
 }
 
 
+# Lattices beyond one 64-bit word per bit-plane (the wide environment, csrc/env_big.hip): no look-up referee exists, the reference runs
+# with oracle/matching_referee.py (same definition, pinned against the tables at d <= 7) as its static_decoder.  `legal` / `acted` are
+# stored as little-endian 64-bit word arrays.
+BIG_TRACE_CONFIGS = {
+    "b1_d9_dp": (9, "DP", False, 0.004, 0.004, 9, 4, 64),       # planes of 2 words, 163 actions
+    "b2_d9_x": (9, "X", False, 0.008, 0.008, 4, 4, 64),
+    "b3_d11_dp": (11, "DP", False, 0.004, 0.003, 3, 3, 48),     # 121 qubits, 243 actions
+    "b4_d13_x": (13, "X", False, 0.006, 0.006, 3, 2, 40),       # planes of 3 words
+    "b5_d15_dpy": (15, "DP", True, 0.003, 0.003, 2, 2, 32),     # planes of 4 words, 676 actions
+}
+
+
 def run_trace(ENV, cfg, luts, auto_reset=True):
     d, model, use_Y, p_phys, p_meas, depth, n_envs, n_steps = cfg
     iidxz = model == "IIDXZ"
@@ -293,8 +310,14 @@ def run_trace(ENV, cfg, luts, auto_reset=True):
     if iidxz:
         import Function_Library as FL
         ENV.generate_error = lambda d_, p_, m_: FL.generate_error(d_, p_, "IIDXZ")
-    ref = referee.LutReferee(d, model, lut_x=luts[d][0], lut_z=luts[d][1])
+    big = d > 7
+    if big:
+        from oracle import matching_referee
+        ref = matching_referee.MatchingReferee(d, model)
+    else:
+        ref = referee.LutReferee(d, model, lut_x=luts[d][0], lut_z=luts[d][1])
     n_act = lattice.num_actions(d, model, use_Y)[0]
+    LW, W = ((n_act + 63) // 64, (d * d + 63) // 64) if big else (2, 1)
     C, n = depth + lattice.num_actions(d, model, use_Y)[1], 2 * d + 1
     rec = dict(
         obs=np.zeros((n_envs, n_steps + 1, C, n, n), np.uint8),
@@ -306,9 +329,9 @@ def run_trace(ENV, cfg, luts, auto_reset=True):
         hidden=np.zeros((n_envs, n_steps + 1, d, d), np.uint8),
         true_syndrome=np.zeros((n_envs, n_steps + 1, d + 1, d + 1), np.uint8),
         summed_nonzero=np.zeros((n_envs, n_steps + 1, d + 1, d + 1), np.uint8),
-        legal=np.zeros((n_envs, n_steps + 1, 2), np.uint64),
+        legal=np.zeros((n_envs, n_steps + 1, LW), np.uint64),
         completed=np.zeros((n_envs, n_steps + 1, n_act), np.uint8),
-        acted=np.zeros((n_envs, n_steps + 1), np.uint64),
+        acted=np.zeros((n_envs, n_steps + 1, W) if big else (n_envs, n_steps + 1), np.uint64),
         rounds=np.zeros((n_envs, n_steps + 1), np.int64),
     )
     saved = (np.random.rand, np.random.randint)
@@ -326,9 +349,9 @@ def run_trace(ENV, cfg, luts, auto_reset=True):
                 rec["hidden"][e, t] = env.hidden_state
                 rec["true_syndrome"][e, t] = env.current_true_syndrome
                 rec["summed_nonzero"][e, t] = env.summed_syndrome_volume != 0
-                rec["legal"][e, t] = set_to_mask2(env.legal_actions)
+                rec["legal"][e, t] = set_to_words(env.legal_actions, LW) if big else set_to_mask2(env.legal_actions)
                 rec["completed"][e, t] = env.completed_actions
-                rec["acted"][e, t] = sum(1 << q for q in env.acted_on_qubits)
+                rec["acted"][e, t] = set_to_words(env.acted_on_qubits, W) if big else sum(1 << q for q in env.acted_on_qubits)
                 rec["rounds"][e, t] = stream.round
                 assert stream.at_round_boundary()
 
@@ -381,9 +404,22 @@ def time_reference(ENV, luts, seconds=5.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--big-only", action="store_true", help="only the traces of the lattices beyond d = 7 (BIG_TRACE_CONFIGS)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     FL, ENV = import_reference()
+
+    def big_traces():
+        for name, cfg in BIG_TRACE_CONFIGS.items():
+            t0 = time.time()
+            rec = run_trace(ENV, cfg, None, auto_reset=True)
+            np.savez_compressed(os.path.join(OUT, f"trace_{name}.npz"), **rec)
+            print(f"trace {name}: {time.time() - t0:.1f}s  resets={int(rec['was_reset'].sum())} rewards={int((rec['reward'] > 0).sum())} "
+                  f"done-steps={int(rec['done'].sum())}")
+
+    if args.big_only:
+        big_traces()
+        return
 
     t0 = time.time()
     luts = {d: (referee.build_lut(d, 3), referee.build_lut(d, 1)) for d in (3, 5, 7)}
@@ -416,6 +452,8 @@ def main():
         cfg[6], cfg[7] = 4, 48
         rec = run_trace(ENV, tuple(cfg), luts, auto_reset=False)
         np.savez_compressed(os.path.join(OUT, f"trace_sticky_{name}.npz"), **rec)
+
+    big_traces()
 
     if args.time:
         print(json.dumps({"reference_env_steps_per_s_1proc": time_reference(ENV, luts), "cores": os.cpu_count()}))
