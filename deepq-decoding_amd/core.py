@@ -146,6 +146,12 @@ class DQNCore:
         return sj
 
     def _launch_env(self, args, sj):
+        if getattr(self.env, "wide", False):
+            # lattices beyond d = 7 (csrc/env_big.hip): selection + step in one launch; no replay sampling rides on it -- the update draws
+            # its own minibatch (_take_minibatch notices that no look-ahead draw was made)
+            self._presampled = None
+            check(self.L.dq_envb_act_step(*args, ptr(self.env.inexact), self._stream()))
+            return
         if sj is not None:
             check(self.L.dq_env_act_step_sample(*args, ctypes.byref(sj), self._stream()))
         else:
@@ -287,7 +293,7 @@ class DQNCore:
         if presample_next:
             nxt2 = nxt + 1 if nxt + 1 < T else 0
             sj = self._sample_job(t + 1, nxt2, min(T, filled + 1))
-        if self.ride_env and self._env_stream is None and self.net.fused_supported and self.net.fused_enabled:
+        if self.ride_env and self._env_stream is None and self.net.fused_supported and self.net.fused_enabled and not getattr(env, "wide", False):
             # one launch fewer per step: the environment step (+ look-ahead sampling + this step's episode bookkeeping) rides on the
             # dense backward's first kernel (dq_qnet_td_backward_adam_env / _phase0_env): neither needs the other's results
             step = dict(q=self.q_act, eps=eps, masked_greedy=masked_greedy, seed=env.seed, t=self.vector_steps, action=self.action_ring[cur],

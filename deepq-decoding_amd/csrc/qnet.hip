@@ -349,7 +349,7 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
     DQ_REQUIRE(cfg && out, DQ_ERR_INVALID, "dq_qnet_create: null argument");
     *out = nullptr;
     DQ_REQUIRE(cfg->n_conv >= 1 && cfg->n_conv <= 4 && cfg->n_ff >= 0 && cfg->n_ff <= 4, DQ_ERR_UNSUPPORTED, "dq_qnet_create: 1..4 conv and 0..4 hidden dense layers");
-    DQ_REQUIRE(cfg->n_actions >= 1 && cfg->n_actions <= 128 && cfg->max_batch >= 1, DQ_ERR_INVALID, "dq_qnet_create: bad n_actions / max_batch");
+    DQ_REQUIRE(cfg->n_actions >= 1 && cfg->n_actions <= 1024 && cfg->max_batch >= 1, DQ_ERR_INVALID, "dq_qnet_create: bad n_actions / max_batch");
     dq_qnet* Q = new (std::nothrow) dq_qnet();
     DQ_REQUIRE(Q, DQ_ERR_NOMEM, "out of host memory");
     memset(Q, 0, sizeof(*Q));

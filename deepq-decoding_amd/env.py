@@ -46,7 +46,7 @@ class VectorEnv:
         cfg = EnvCfg(d, _MODELS[error_model], int(bool(use_Y)), volume_depth, self.n_envs, self.env_id_base,
                      (ctypes.c_uint32 * 2)(*self.seed))
         h = ctypes.c_void_p()
-        self.wide = backend == "wide" or (backend == "auto" and d > 7)
+        self.wide = backend == "wide" or referee == "matching" or (backend == "auto" and d > 7)
         self._pfx = "dq_envb_" if self.wide else "dq_env_"
         with torch.cuda.device(self.device):
             check(getattr(self.L, self._pfx + "create")(ctypes.byref(cfg), ctypes.byref(h)))
@@ -304,6 +304,8 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
             referee = tuple(static_decoder)
         elif hasattr(static_decoder, "predict"):
             referee = static_decoder            # the reference's protocol (ENV:144): tabulated once over all syndromes (d <= 5)
+        elif static_decoder == "matching":
+            referee = "matching"
         else:
             raise NotImplementedError("static_decoder must be None/'lut', 'ml', a (lut_x, lut_z) pair or an object with .predict")
         self._v = VectorEnv(d, p_phys, p_meas, error_model, use_Y, volume_depth, n_envs=1, seed=seed, env_id_base=env_id,
@@ -360,6 +362,8 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
         which fired anywhere in the current (faulty) volume.  The bookkeeping lives on the device: the lattice record is exported,
         rewritten and imported back (a helper call, not part of the stepped path -- reset() / step() do this inside the kernel)."""
         v, d2 = self._v, self.d * self.d
+        if v.wide:
+            raise NotImplementedError("reset_legal_moves: not offered on lattices beyond d = 7 (reset() / step() do it inside the kernel)")
         st = v.export_state()
         w = [_u64(x) for x in st[0].cpu().tolist()]
         fired = 0
@@ -384,31 +388,45 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
             self._state = [_u64(x) for x in self._v.export_state()[0].cpu().tolist()]
         return self._state
 
+    def _fields(self):
+        """The exported record as Python integers (bit q / s / a = qubit / stabilizer / action), whatever the backend's word layout
+        (include/deepq_hip.h: dq_env_export_state, dq_envb_export_state)."""
+        w = self._words()
+
+        def big(words):
+            return sum(x << (64 * k) for k, x in enumerate(words))
+
+        if self._v.wide:
+            W, LW = (self.d * self.d + 63) // 64, self._v.legal_words
+            o = 5 * W + 1
+            return dict(x=big(w[0:W]), z=big(w[W:2 * W]), true=big(w[2 * W:3 * W]), acted=big(w[4 * W:5 * W]),
+                        comp=big(w[o:o + LW]), legal=big(w[o + LW:o + 2 * LW]),
+                        vol=[big(w[o + 2 * LW + 1 + j * W:o + 2 * LW + 1 + (j + 1) * W]) for j in range(self.volume_depth)])
+        return dict(x=w[0], z=w[1], true=w[2], acted=w[4], comp=big(w[6:8]), legal=big(w[8:10]), vol=w[11:11 + self.volume_depth])
+
     @staticmethod
-    def _mask_to_set(lo, hi):
-        return {a for a in range(128) if ((lo if a < 64 else hi) >> (a & 63)) & 1}
+    def _mask_to_set(mask):
+        return {a for a in range(mask.bit_length()) if (mask >> a) & 1}
 
     @property
     def legal_actions(self):
-        w = self._words()
-        return self._mask_to_set(w[8], w[9])
+        return self._mask_to_set(self._fields()["legal"])
 
     @property
     def acted_on_qubits(self):
-        return self._mask_to_set(self._words()[4], 0)
+        return self._mask_to_set(self._fields()["acted"])
 
     @property
     def completed_actions(self):
-        w = self._words()
-        done = self._mask_to_set(w[6], w[7])
-        return np.array([int(a in done) for a in range(self.num_actions)], dtype=int)
+        done = self._fields()["comp"]
+        return np.array([(done >> a) & 1 for a in range(self.num_actions)], dtype=int)
 
     @property
     def hidden_state(self):
-        w, d = self._words(), self.d
+        f, d = self._fields(), self.d
         out = np.zeros(d * d)
         for q in range(d * d):
-            out[q] = (1 if (w[0] >> q) & 1 else 0) ^ (3 if (w[1] >> q) & 1 else 0)
+            out[q] = (1 if (f["x"] >> q) & 1 else 0) ^ (3 if (f["z"] >> q) & 1 else 0)
         return out.reshape(d, d)
 
     def _word_to_grid(self, word):
@@ -419,12 +437,11 @@ class Surface_Code_Environment_Multi_Decoding_Cycles:
 
     @property
     def current_true_syndrome(self):
-        return self._word_to_grid(self._words()[2])
+        return self._word_to_grid(self._fields()["true"])
 
     @property
     def summed_syndrome_volume(self):
-        w = self._words()
-        return sum(self._word_to_grid(x) for x in w[11:11 + self.volume_depth])
+        return sum(self._word_to_grid(x) for x in self._fields()["vol"])
 
     def is_adjacent_to_syndrome(self, qubit_number):
         s = self.summed_syndrome_volume

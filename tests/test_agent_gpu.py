@@ -118,6 +118,105 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod, name, C1, N, B, steps):
             p_t = p.copy()
 
 
+class _PyVecEnv:
+    """N independent oracle lattices (oracle/env_oracle.py, any d) behind the batched C-oracle's interface: the CPU side of the d >= 9 loop."""
+
+    def __init__(self, n_envs, seed, **cfg):
+        from oracle import env_oracle, matching_referee
+        ref = matching_referee.MatchingReferee(cfg["d"], cfg["error_model"])
+        self.envs = [env_oracle.OracleEnv(referee=ref, seed=seed, env_id=i, **cfg) for i in range(n_envs)]
+        self.obs = np.zeros((n_envs,) + self.envs[0].board_state.shape, np.uint8)
+        self.reward, self.done = np.zeros(n_envs, np.float32), np.zeros(n_envs, np.uint8)
+
+    def _pull(self):
+        for i, e in enumerate(self.envs):
+            self.obs[i], self.done[i] = e.board_state, e.done
+
+    def reset(self):
+        for e in self.envs:
+            e.reset()
+        self._pull()
+
+    def legal_mask(self, i):
+        return self.envs[i].legal
+
+    def step(self, acts, auto_reset=True):
+        for i, e in enumerate(self.envs):
+            if auto_reset and e.done:
+                e.reset()
+                self.reward[i] = 0.0
+            else:
+                self.reward[i] = e.step(int(acts[i]))[1]
+        self._pull()
+
+
+def test_device_loop_at_distance_nine_matches_oracle_loop(dq, torch_mod):
+    """The loop of test_device_loop_matches_oracle_loop on a lattice beyond one 64-bit word per plane (d = 9: 81 qubits, 163 actions,
+    19 x 19 observations): wide environment with the matching referee inside the step (csrc/env_big.hip), wide action selection, the
+    Q-network on whichever path covers the architecture -- against the Python environment oracle + float64 network oracle."""
+    cfg = dict(d=9, error_model="DP", use_Y=False, volume_depth=3, p_phys=0.006, p_meas=0.006)
+    N, B, steps, eps, gamma, lr = 6, 4, 9, 0.4, 0.99, 1e-3
+    seed = (0x5EED, 0xD0DEC0DE)
+    env = dq.VectorEnv(n_envs=N, seed=seed, **cfg)
+    assert env.wide and env.legal_words == 3 and env.obs_shape == (5, 19, 19)
+    net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=max(N, B))
+    core = dq.DQNCore(env, net, batch_size=B, memory_limit=N * 6, gamma=gamma, lr=lr, seed=seed)
+    spec = O.QNetSpec(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions)
+    p = core.params.cpu().numpy().astype(np.float64)
+    p_t = p.copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    ref = _PyVecEnv(N, seed, **cfg)
+    T = core.T
+    ring_obs = np.zeros((T, N) + env.obs_shape, np.uint8)
+    ring_a, ring_r, ring_t = np.zeros((T, N), np.int32), np.zeros((T, N), np.float32), np.zeros((T, N), np.uint8)
+    core.reset_env()
+    ref.reset()
+    cur, filled, n_updates = 0, 1, 0
+    ring_obs[0] = ref.obs
+    assert np.array_equal(core.obs_ring[0].cpu().numpy(), ref.obs)
+    for t in range(steps):
+        will_update = min(T, filled + 1) >= 4
+        fused = will_update and t % 2 == 0
+        if fused:
+            core.step_and_update(eps)
+        else:
+            core.act_and_step(eps, presample=True)
+        q, _ = O.forward(spec, p, ring_obs[cur])
+        acts = np.zeros(N, np.int32)
+        for i in range(N):
+            w = philox.philox4x32((t, 0, i, philox.STREAM_POLICY << 16), seed)
+            acts[i] = O.select_action(q[i], ref.legal_mask(i), eps, False, w)
+        assert np.array_equal(core.action_ring[cur].cpu().numpy(), acts), ("actions", t)
+        ref.step(acts, auto_reset=True)
+        nxt = (cur + 1) % T
+        ring_a[cur], ring_r[cur], ring_t[cur], ring_obs[nxt] = acts, ref.reward, ref.done, ref.obs
+        assert np.array_equal(core.obs_ring[nxt].cpu().numpy(), ref.obs), ("obs", t)
+        assert np.array_equal(core.reward_ring[cur].cpu().numpy(), ref.reward) and np.array_equal(core.terminal_ring[cur].cpu().numpy(), ref.done)
+        cur, filled = nxt, min(T, filled + 1)
+        if not will_update:
+            continue
+        if not fused:
+            core.update()
+        n_updates += 1
+        u = n_updates
+        idx = core.index.cpu().numpy()
+        rows = T * N
+        flat_obs = ring_obs.reshape(rows, *env.obs_shape)
+        s0, s1 = flat_obs[idx], flat_obs[(idx + N) % rows]
+        y = O.td_targets(O.forward(spec, p, s1)[0], O.forward(spec, p_t, s1)[0], ring_r.reshape(-1)[idx], ring_t.reshape(-1)[idx], gamma)
+        keep = O.dropout_keep_mask(seed, u, np.arange(B), 512, 0.2)
+        q0, cache = O.forward(spec, p, s0, training=True, keep_masks=[keep])
+        loss, mean_q, dq_ = O.loss_and_grad(q0, ring_a.reshape(-1)[idx], y)
+        g = O.backward(spec, p, cache, dq_)
+        p, m, v = O.adam_step(p, g, m, v, u, lr)
+        met = np.array(core.read_metrics())
+        assert abs(met[0] - loss) < 1e-5 and abs(met[1] - mean_q) < 1e-5, (met, loss, mean_q)
+        assert np.abs(core.grads.cpu().numpy() - g).max() < 1e-5 * max(1.0, np.abs(g).max())
+        p = core.params.cpu().numpy().astype(np.float64)
+        m, v = core.m.cpu().numpy().astype(np.float64), core.v.cpu().numpy().astype(np.float64)
+    assert n_updates >= 5
+
+
 def _make_agent(dq, model_shape, n_actions, batch_size=32, warmup=64, target=200, limit=5000, seed=(1, 2)):
     model = dq.build_convolutional_nn(C_LAYERS, FF_LAYERS, model_shape, n_actions)
     memory = dq.SequentialMemory(limit=limit, window_length=1)
@@ -227,6 +326,24 @@ def test_fit_vector_env_is_deterministic(dq, torch_mod):
         th = agent.test(env, nb_episodes=200, visualize=False, verbose=0, single_cycle=False)
         assert len(th.history["episode_lifetime"]) == 200
     assert torch.equal(out[0], out[1])
+
+
+def test_fit_and_test_at_distance_nine(dq, torch_mod):
+    """DQNAgent.fit / test on 81-qubit lattices (wide environment, matching referee, 163 actions): runs, learns from its replay ring,
+    and two identical runs give bit-identical weights."""
+    torch = torch_mod
+    cfg = dict(d=9, error_model="DP", use_Y=False, volume_depth=3, p_phys=0.003, p_meas=0.003)
+    out = []
+    for _ in range(2):
+        env = dq.VectorEnv(n_envs=64, **cfg)
+        agent = _make_agent(dq, env.obs_shape, env.num_actions, batch_size=32, warmup=128, target=512, limit=64 * 30)
+        hist = agent.fit(env, nb_steps=64 * 30, verbose=0, episode_averaging_length=50, success_threshold=None, stopping_patience=None,
+                         min_nb_steps=0, single_cycle=False, sync_interval=8)
+        assert agent._core.updates >= 20 and len(hist.history["episode"]) >= 1
+        out.append(agent._core.params.clone())
+        th = agent.test(env, nb_episodes=64, visualize=False, verbose=0, single_cycle=False)
+        assert len(th.history["episode_lifetime"]) == 64 and min(th.history["episode_lifetime"]) >= 3
+    assert torch.equal(out[0], out[1]) and torch.isfinite(out[0]).all()
 
 
 def test_early_stopping_rule(dq, torch_mod):

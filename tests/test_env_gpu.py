@@ -339,6 +339,37 @@ def test_single_env_facade(dq, torch_mod):
         dq.Surface_Code_Environment_Multi_Decoding_Cycles(d=4)
 
 
+@pytest.mark.parametrize("name", ["b2_d9_x", "b3_d11_dp", "c3_d5_dp"])
+def test_single_env_facade_beyond_distance_seven(dq, torch_mod, name):
+    """The drop-in class on the wide backend (d = 9, 11; and d = 5 with static_decoder="matching"): the reference's trace through
+    reset() / step() with the reference's types and state views."""
+    g = load_golden("trace_" + name)
+    cfg, n_envs, n_steps, seed = trace_config(g)
+    extra = dict(static_decoder="matching") if cfg["d"] <= 7 else {}
+    env = dq.Surface_Code_Environment_Multi_Decoding_Cycles(seed=seed, env_id=1, **cfg, **extra)
+    assert env._v.wide
+    e = 1
+    obs = env.reset()
+    assert obs is env.board_state and np.array_equal(obs, g["obs"][e, 0])
+    for t in range(min(n_steps, 40)):
+        if env.done:
+            env.reset()
+            r = 0.0
+        else:
+            o, r, done, info = env.step(int(g["action"][e, t]))
+            assert o is obs and info == {} and isinstance(r, float) and isinstance(done, bool)
+        assert r == g["reward"][e, t] and env.lifetime == g["lifetime"][e, t + 1] and env.done == bool(g["done"][e, t + 1])
+        assert np.array_equal(env.board_state, g["obs"][e, t + 1])
+        assert np.array_equal(env.hidden_state, g["hidden"][e, t + 1])
+        assert np.array_equal(env.current_true_syndrome, g["true_syndrome"][e, t + 1])
+        assert np.array_equal(env.summed_syndrome_volume != 0, g["summed_nonzero"][e, t + 1])
+        assert np.array_equal(env.completed_actions, g["completed"][e, t + 1])
+        assert sum(1 << a for a in env.legal_actions) == _big(g["legal"][e, t + 1])
+        assert sum(1 << q for q in env.acted_on_qubits) == _big(np.atleast_1d(g["acted"][e, t + 1]))
+    with pytest.raises(IndexError):
+        env.step(env.num_actions)
+
+
 @pytest.mark.parametrize("name", ["c1_d3_x", "c3_d5_dp", "c5_d7_dp"])
 def test_facade_tables_identity_indicator_and_reset_legal_moves(dq, torch_mod, name):
     """The facade's own copies of the reference tables against golden G1 (E11, E18: identity_indicator / indicate_identity, ENV:316-324,
