@@ -36,6 +36,9 @@ CONFIGS = {
     "c2": dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007, n_envs=4096),
     "c3": dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011, n_envs=4096),
     "c5": dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005, n_envs=1024),
+    # beyond BASELINE.json's configs: 81-qubit lattices on the wide environment with the matching referee inside the step;
+    # the Q-network runs on the per-layer kernels (the fused chains cover |A| <= 127); use with --no-cpu-baseline
+    "d9": dict(d=9, error_model="DP", use_Y=False, volume_depth=9, p_phys=0.003, p_meas=0.003, n_envs=1024),
 }
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA dense peak

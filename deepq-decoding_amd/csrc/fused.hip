@@ -247,7 +247,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
             for (int h = 0; h < NH1; ++h) {
                 u32x4 av;
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) av[e >> 1] = (ab[h][e] | (ab[h][e + 1] << 16)) * 0x3c00u;       // f16(1.0) = 0x3c00
+                for (int e = 0; e < 8; e += 2) av[e >> 1] = __umul24(ab[h][e] | (ab[h][e + 1] << 16), 0x3c00u);      // f16(1.0) = 0x3c00; v_mul_u32_u24 (a 32-bit multiply is quarter rate)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] = MFMA_F16(av, wb[0][h][t], acc[t]);
 #pragma unroll

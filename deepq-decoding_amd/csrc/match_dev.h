@@ -7,15 +7,16 @@
 // ended edges go to the boundary, every edge carries the qubit's logical bit); an error is a set of paths pairing the defects with each other
 // or the boundary, so  w_c(D) = min over pairings of the summed shortest-path lengths whose classes XOR to c  -- minimum-weight perfect
 // matching with class bookkeeping, solved exactly by dynamic programming over the subsets of the (few) defects:
-//   f[S][c], S a subset of the defects in index order, lowest defect u of S -> boundary (class c') or -> partner v in S (class c')
+//   f[S][c], S a subset of the defects in index order, one distinguished defect u of S (the oracle: the lowest; here: the highest) ->
+//   boundary (class c') or -> partner v in S (class c')
 //   w_c = min(f[D][c], f[D][c^1] + w_1(0))        (w_1(0): lightest defect-free class-1 error = the code distance)
 // More than DQ_MATCH_MAX_DEFECTS defects: the lowest DQ_MATCH_MAX_DEFECTS are solved exactly, every further one goes to its nearer boundary
 // (ties: the class-0 path) and the result is flagged inexact.
 //
 // One wavefront per (syndrome, component).  The 2^k x 2 table lives in LDS as bytes (255 = unreachable; any reachable entry is below
 // 14 x (d + 1) / 2 + d <= 127 for d <= 15: every defect can be sent to a boundary within (d + 1) / 2 edges, and forcing the other class
-// costs at most one more crossing); subsets are visited in increasing order (both predecessors of S are smaller); for one S the 64 lanes
-// are the candidates (partner j or boundary) x (path class c') x (result class c), min-reduced by butterflies inside each half-wave.
+// costs at most one more crossing); subsets are visited level by level of their highest defect (both predecessors of S lie below 2^h), the
+// 2^h subsets of a level one per lane, each lane walking its subset's candidates (boundary or partner v, path class 0 / 1).
 #pragma once
 #include "common.h"
 
@@ -71,22 +72,29 @@ static __device__ __forceinline__ int match_classify(const MatchComp& T, u64 d0,
     }
     if (lane < k) { s_pb[2 * lane] = T.distB[2 * s_list[lane]]; s_pb[2 * lane + 1] = T.distB[2 * s_list[lane] + 1]; }
     if (lane == 0) { f[0] = 0; f[1] = 255; }
-    // ---- subsets in increasing order -----------------------------------------------------------------------------------------
-    const int j = lane & 15, cp = (lane >> 4) & 1, c = lane >> 5;
+    // ---- subsets by their HIGHEST defect h: every S in [2^h, 2^(h+1)) depends only on sets below 2^h, so the 2^h subsets of a level are
+    //      independent -- one subset per lane (the oracle recurses on the lowest defect; the minimum over all pairings is the same) ------
+    const int BIG = 1 << 20;
     const int full = (1 << k) - 1;
-    for (int S = 1; S <= full; ++S) {
-        const int i = __builtin_ctz(S), rest = S & (S - 1);
-        int cand = 1 << 20;
-        if (j == 15) {                                            // lowest defect -> boundary
-            const int dd = s_pb[2 * i + cp], fv = f[2 * rest + (c ^ cp)];
-            if (dd != 255 && fv != 255) cand = fv + dd;
-        } else if ((rest >> j) & 1) {                             // ... -> partner j
-            const int dd = s_pd[(i * 16 + j) * 2 + cp], fv = f[2 * (rest ^ (1 << j)) + (c ^ cp)];
-            if (dd != 255 && fv != 255) cand = fv + dd;
+    for (int h = 0; h < k; ++h) {
+        const int base = 1 << h;
+        const int b0 = s_pb[2 * h] == 255 ? BIG : s_pb[2 * h], b1 = s_pb[2 * h + 1] == 255 ? BIG : s_pb[2 * h + 1];
+        for (int r = lane; r < base; r += 64) {
+            int g0 = f[2 * r], g1 = f[2 * r + 1];
+            g0 = g0 == 255 ? BIG : g0; g1 = g1 == 255 ? BIG : g1;
+            int best0 = min(g0 + b0, g1 + b1), best1 = min(g1 + b0, g0 + b1);      // defect h -> boundary with path class 0 / 1
+            for (int m = r; m; m &= m - 1) {                          // ... -> partner v
+                const int v = __builtin_ctz(m), rr = r ^ (1 << v);
+                int d0 = s_pd[(h * 16 + v) * 2], d1 = s_pd[(h * 16 + v) * 2 + 1];
+                d0 = d0 == 255 ? BIG : d0; d1 = d1 == 255 ? BIG : d1;
+                int q0 = f[2 * rr], q1 = f[2 * rr + 1];
+                q0 = q0 == 255 ? BIG : q0; q1 = q1 == 255 ? BIG : q1;
+                best0 = min(best0, min(q0 + d0, q1 + d1));
+                best1 = min(best1, min(q1 + d0, q0 + d1));
+            }
+            f[2 * (base + r)] = (u8)(best0 < 255 ? best0 : 255);
+            f[2 * (base + r) + 1] = (u8)(best1 < 255 ? best1 : 255);
         }
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) cand = min(cand, __shfl_xor(cand, m));     // inside the half-wave that shares c
-        if ((lane & 31) == 0) f[2 * S + c] = (u8)(cand < 255 ? cand : 255);
     }
     int w0 = f[2 * full], w1 = f[2 * full + 1];
     w0 = w0 == 255 ? 1 << 20 : w0;

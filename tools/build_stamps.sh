@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 for tag in "$@"; do
   case $tag in 21) f=fused_bwd ;; *) case $((tag % 10)) in 1|2|0) f=fused ;; *) f=fused_bwd ;; esac ;; esac
   ( /opt/rocm/bin/hipcc $FLAGS -DDQ_STAMPS=$tag -c deepq-decoding_amd/csrc/$f.hip -o /tmp/stamp_${f}_$tag.o
-    objs=""; for o in dqn env fused fused_bwd policy prof qnet; do if [ $o = $f ]; then objs="$objs /tmp/stamp_${f}_$tag.o"; else objs="$objs deepq-decoding_amd/lib/$o.o"; fi; done
+    objs=""; for src in deepq-decoding_amd/csrc/*.hip; do o=$(basename $src .hip); if [ $o = $f ]; then objs="$objs /tmp/stamp_${f}_$tag.o"; else objs="$objs deepq-decoding_amd/lib/$o.o"; fi; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/probe/stamps/s$tag.so $objs ) &
 done
 wait
