@@ -339,6 +339,40 @@ def test_single_env_facade(dq, torch_mod):
         dq.Surface_Code_Environment_Multi_Decoding_Cycles(d=4)
 
 
+def test_wide_environment_policy_fusion_and_sharding(dq, torch_mod):
+    """On the wide backend: (i) at d = 5 the wide action selection draws the actions of dq_policy_select from the same legal sets, with and
+    without Q-values; (ii) dq_envb_act_step == dq_policy_select_wide then dq_envb_step; (iii) at d = 9 one batch of 96 lattices equals three
+    shards of 32 with env_id_base = 32 r (results depend on global lattice ids only)."""
+    torch = torch_mod
+    cfg5 = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.02, p_meas=0.02)
+    a, b = dq.VectorEnv(n_envs=200, **cfg5), dq.VectorEnv(n_envs=200, backend="wide", **cfg5)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(12):
+        q = torch.randn((200, a.num_actions), device="cuda", generator=g)
+        for kw in (dict(), dict(q=q, eps=0.0, masked_greedy=True), dict(q=q, eps=0.5)):
+            assert torch.equal(a.select_actions(t, **kw), b.select_actions(t, **kw))
+        act = a.select_actions(t, q=q, eps=0.3)
+        a.step(act, auto_reset=True); b.step(act, auto_reset=True)
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.done, b.done) and torch.equal(a.reward, b.reward)
+    cfg9 = dict(d=9, error_model="DP", use_Y=False, volume_depth=3, p_phys=0.01, p_meas=0.01)
+    one, two = dq.VectorEnv(n_envs=96, **cfg9), dq.VectorEnv(n_envs=96, **cfg9)
+    shards = [dq.VectorEnv(n_envs=32, env_id_base=32 * r, **cfg9) for r in range(3)]
+    for e in [one, two] + shards:
+        e.reset()
+    for t in range(10):
+        q = torch.randn((96, one.num_actions), device="cuda", generator=g)
+        act = one.select_actions(t, q=q, eps=0.5)
+        one.step(act, auto_reset=True)
+        fused = two.act_step(t, q=q, eps=0.5, auto_reset=True)
+        assert torch.equal(fused, act) and torch.equal(one.obs, two.obs) and torch.equal(one.done, two.done) and torch.equal(one.legal, two.legal)
+        for r, sh in enumerate(shards):
+            sl = slice(32 * r, 32 * r + 32)
+            assert torch.equal(sh.select_actions(t, q=q[sl].contiguous(), eps=0.5), act[sl])
+            sh.step(act[sl].contiguous(), auto_reset=True)
+            assert torch.equal(sh.obs, one.obs[sl]) and torch.equal(sh.reward, one.reward[sl]) and torch.equal(sh.lifetime, one.lifetime[sl])
+
+
 @pytest.mark.parametrize("name", ["b2_d9_x", "b3_d11_dp", "c3_d5_dp"])
 def test_single_env_facade_beyond_distance_seven(dq, torch_mod, name):
     """The drop-in class on the wide backend (d = 9, 11; and d = 5 with static_decoder="matching"): the reference's trace through
