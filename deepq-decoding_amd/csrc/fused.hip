@@ -149,7 +149,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     int jb = 0;
     while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
     const ConvJob& J = a.job[jb];
-    const int b0 = ((int)blockIdx.x - J.wg0) * a.S;
+    const int grp = (int)blockIdx.x - J.wg0;
+    const int b0 = grp * a.S;
     const int ns = min(a.S, J.batch - b0);
     const int in_bytes = a.C * a.H * a.W;
     constexpr int NH1 = (KG1 + 1) / 2;                              // first convolution's K in halves of 32
@@ -346,6 +347,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     float* s_y2 = reinterpret_cast<float*>(smem + a.off_y2);
     float* s_y3 = reinterpret_cast<float*>(smem + a.off_y3);
     constexpr int PW = 16 * NT2, ROWS = 16 * RT, PR = ROWS < 32 ? ROWS : 32, UP = PR / 16;      // PR rows (UP row tiles) per reduction pass
+    constexpr int PWP = PW + 4;                                     // row stride of the partials: the 8 lanes of a ds_write_b128 lane group are 8 ROWS -- unpadded (a
+                                                                    // multiple of 32 banks) every store was an 8-way conflict, 13K cycles of this kernel's LDS time
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     int jb = 0;
     while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
@@ -459,6 +462,31 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
         bias1[ct] = *reinterpret_cast<const f32x4u*>(J.params + a.b_off[0] + 64 * wave + 32 * (ct >> 1) + 8 * kq + 4 * (ct & 1));
+    // the dueling layer's weights (waves 0 .. NT3-1): requested here, raw, at clamped addresses, and used three barriers later; the
+    // masks (columns past N3, rows past N2) are applied where they are used -- a multiplication or select next to the load makes hipcc
+    // wait for the load right there (4K cycles of every workgroup under load)
+    // column tile ct3 of the dueling layer belongs to waves ct3, ct3 + NT3, ...: they share its row tiles (u = part, part + parts, ...)
+    const int nt3 = NT3 > 0 ? NT3 : 1, parts = DENSE_WAVES / nt3, ct3 = wave % nt3, part = wave / nt3;
+    const bool act3 = a.N3 > 0 && part < parts;
+    const int col3 = 16 * ct3 + j;
+    float bias3 = 0.f;
+    if (act3) {
+        bias3 = J.params[a.b_off[2] + min(col3, a.N3 - 1)];
+        const float* w3 = J.params + a.w_off[2];
+        const bool cok = col3 < a.N3;
+        const int loff = 4 * kq * a.N3 + (cok ? col3 : 0);
+#pragma unroll
+        for (int g = 0; g < KG3; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 16 * g + 4 * kq + s;
+                b3[g][s] = w3[(cok && k < a.N2) ? (16 * g + s) * a.N3 + loff : 0];
+            }
+    }
+    const int rcol = tid & 63;                                      // column (+ 64 cc) of the cross-wave reduction below
+    float bias2r[(PW + 63) / 64];
+#pragma unroll
+    for (int cc = 0; cc < (PW + 63) / 64; ++cc) bias2r[cc] = J.params[a.b_off[1] + min(rcol + 64 * cc, a.N2 - 1)];
     __syncthreads();                                                // every wave is done with the input planes: the partials overlay them
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 3);
@@ -507,69 +535,63 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             // C/D layout: this lane holds outputs 16t + 4kq .. + 3 of sample j: one 16-byte store per tile
 #pragma unroll
             for (int t = 0; t < NT2; ++t)
-                *reinterpret_cast<f32x4*>(s_part + (wave * PR + 16 * uu + j) * PW + 16 * t + 4 * kq) = f16x2_sum(acc2[t][0], acc2[t][1]);
+                *reinterpret_cast<f32x4*>(s_part + (wave * PR + 16 * uu + j) * PWP + 16 * t + 4 * kq) = f16x2_sum(acc2[t][0], acc2[t][1]);
         }
-        // the dueling layer's weights (waves 0 .. NT3-1): requested here and used two barriers later.  All loads first, masked by
-        // MULTIPLICATION afterwards: under `ok ? v : 0` right after each load hipcc reuses one register and waits for every load in turn
-        if (pass == ROWS / PR - 1 && wave < NT3) {
-            const float* w3 = J.params + a.w_off[2];
-            const int col = 16 * wave + j;
-            const bool cok = col < a.N3;
-            const int loff = 4 * kq * a.N3 + (cok ? col : 0);
-#pragma unroll
-            for (int g = 0; g < KG3; ++g)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int k = 16 * g + 4 * kq + s;
-                    const bool okb = cok && k < a.N2;
-                    b3[g][s] = w3[okb ? (16 * g + s) * a.N3 + loff : 0] * (okb ? 1.f : 0.f);
-                }
-        }
+        if (pass == 0) { DQ_STAMP(DQ_TAG_DENSE_FWD, 4); }
         __syncthreads();
-        for (int e = tid; e < PR * a.N2; e += DENSE_THREADS) {
-            const int rr = e / a.N2, col = e - rr * a.N2, row = pass * PR + rr;
-            float v = J.params[a.b_off[1] + col];
+        // thread (rr0 = tid >> 6, col = tid & 63) sums the 8 waves' partials of column col for rows rr0, rr0 + 8, ...: no division, the
+        // bias in a register since before the first barrier (a global load per element sat on this loop's critical path), LDS reads
+        // conflict-free (a lane group = 32 consecutive columns of one row)
 #pragma unroll
-            for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * PR + rr) * PW + col];
-            s_y2[row * a.ld2 + col] = v;
-            if (J.y2_out && row < ns) {
-                J.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
-                unsigned short h, l;
-                split_f16x2_one(v, h, l);
-                J.y2_pl[(size_t)(b0 + row) * J.small_ld + col] = h;
-                J.y2_pl[((size_t)J.plane_rows + b0 + row) * J.small_ld + col] = l;
+        for (int cc = 0; cc < (PW + 63) / 64; ++cc) {
+            const int col = rcol + 64 * cc;
+            if (col >= a.N2) continue;
+#pragma unroll
+            for (int rr = tid >> 6; rr < PR; rr += DENSE_THREADS / 64) {
+                const int row = pass * PR + rr;
+                float v = bias2r[cc];
+#pragma unroll
+                for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * PR + rr) * PWP + col];
+                s_y2[row * a.ld2 + col] = v;
+                if (J.y2_out && row < ns) {
+                    J.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
+                    unsigned short h, l;
+                    split_f16x2_one(v, h, l);
+                    J.y2_pl[(size_t)(b0 + row) * J.small_ld + col] = h;
+                    J.y2_pl[((size_t)J.plane_rows + b0 + row) * J.small_ld + col] = l;
+                }
             }
         }
         __syncthreads();
+        if (pass == 0) { DQ_STAMP(DQ_TAG_DENSE_FWD, 5); }
     }
 
-    DQ_STAMP(DQ_TAG_DENSE_FWD, 4);
-    DQ_STAMP(DQ_TAG_DENSE_FWD, 5);
     DQ_STAMP(DQ_TAG_DENSE_FWD, 6);
     // ---- dueling layer Dense(|A|+1) and the combination Q = V + A - mean(A) ------------------------------------------------
     const float* y = s_y2;
     int ldy = a.ld2;
     if (a.N3 > 0) {
-        if (wave < NT3) {
+        if (act3) {
 #pragma unroll
-            for (int u = 0; u < RT; ++u) {
-                f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < KG3; ++g)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b3[g][s] = (col3 < a.N3 && 16 * g + 4 * kq + s < a.N2) ? b3[g][s] : 0.f;
+            for (int u = part; u < RT; u += parts) {
+                f32x4 acc3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // two chains: a dependent f32 MFMA waits for its predecessor
                 const float* yrow = s_y2 + (16 * u + j) * a.ld2 + 4 * kq;
 #pragma unroll
                 for (int g = 0; g < KG3; ++g) {
                     const f32x4 av = *reinterpret_cast<const f32x4*>(yrow + 16 * g);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc3 = MFMA16(av[s], b3[g][s], acc3);
+                    for (int s = 0; s < 4; ++s) acc3[s & 1] = MFMA16(av[s], b3[g][s], acc3[s & 1]);
                 }
-                const int col = 16 * wave + j;
-                if (col < a.N3) {
-                    const float bias = J.params[a.b_off[2] + col];
+                if (col3 < a.N3) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * u + 4 * kq + r;
-                        const float v = acc3[r] + bias;
-                        s_y3[row * a.ld3 + col] = v;
-                        if (J.y3_out && row < ns) J.y3_out[(size_t)(b0 + row) * a.N3 + col] = v;
+                        const float v = (acc3[0][r] + acc3[1][r]) + bias3;
+                        s_y3[row * a.ld3 + col3] = v;
+                        if (J.y3_out && row < ns) J.y3_out[(size_t)(b0 + row) * a.N3 + col3] = v;
                     }
                 }
             }
@@ -812,7 +834,7 @@ static bool plan_dense(const dq_qnet* Q, DensePlan* P, int rt = 1) {
     P->ld2 = 16 * P->NT2 + 4;
     P->ld3 = 16 * ((N3 + 15) / 16) + 1;
     size_t off = 0;
-    const size_t xb = up16((size_t)2 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * (rows < 32 ? rows : 32) * 16 * P->NT2 * 4);   // f16 planes | partials of one pass
+    const size_t xb = up16((size_t)2 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * (rows < 32 ? rows : 32) * (16 * P->NT2 + 4) * 4);   // f16 planes | partials of one pass (rows padded by 4 floats)
     P->off_x = P->off_part = (int)off; off += xb > pb ? xb : pb;   // the Dense(|A|) partials reuse the input image (dead by then)
     P->off_h = (int)off;                                            // (the hidden output stays in registers)
     P->off_y2 = (int)off; off += up16((size_t)rows * P->ld2 * 4);

@@ -85,7 +85,7 @@ elif tag == 1:
 elif tag == 2:
     for w in range(8):
         t = [buf[i * 8 + w] for i in range(9)]
-        print("wave", w, "stage, dense1, w2-issue, epilogue+bar, dense2+bar, reduce+bar, dense3+bar, head:", [t[i + 1] - t[i] for i in range(8)], "total", t[8] - t[0])
+        print("wave", w, "stage, dense1, w2-issue, pass 0 (epilogue + Dense(|A|) partials), its reduction, pass 1, dueling layer + bar, head (the stamps themselves add waits: each is a global store):", [t[i + 1] - t[i] for i in range(8)], "total", t[8] - t[0])
 elif tag == 3:
     for w in range(8):
         t = [buf[i * 8 + w] for i in range(6)]
