@@ -26,6 +26,12 @@
 
 DQ_STAMP_READER(dq_dbg_read_fwd)
 
+#ifndef CONV_PIN
+#define CONV_PIN 1
+#endif
+#ifndef DENSE_PIN
+#define DENSE_PIN 1
+#endif
 #define CONV_THREADS 256
 #define CONV_WAVES 4
 #define CONV_LDS_2PER_CU (80 * 1024)
@@ -116,6 +122,7 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
             }
             if (blk + R < NB) conv_w_load<NT>(ring[blk % R], pk, blk + R, lane);
             else if (more) conv_w_load<NT>(ring[blk % R], pk, blk + R - NB, lane);
+            if (CONV_PIN) __builtin_amdgcn_sched_barrier(0);        // the requests stay R blocks ahead of their use
         }
         // C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg; this lane owns columns 2j, 2j+1
 #pragma unroll
@@ -428,6 +435,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         const u32x4* pn = pkw + (size_t)min(b + 1, KB - 1) * 32 * PK_BLOCK;      // next block: unconditional, clamped prefetch
 #pragma unroll
         for (int t = 0; t < 4; ++t) { nxt[t].h = pn[t * PK_BLOCK]; nxt[t].l = pn[t * PK_BLOCK + PK_LO]; }
+        if (DENSE_PIN) __builtin_amdgcn_sched_barrier(0);           // the requests stay HERE, a whole block of MFMAs ahead of their use (hipcc otherwise sinks
+                                                                    // each next to its use -- a few MFMAs ahead -- and the wave waits out one L2 latency per pair)
 #pragma unroll
         for (int u = 0; u < RT; ++u) {
             F16x2 xv;

@@ -15,6 +15,12 @@
 #include "qnet.h"
 #include "env_dev.h"
 
+#ifndef GX_PIN
+#define GX_PIN 0
+#endif
+#ifndef GX_RING
+#define GX_RING 3
+#endif
 DQ_STAMP_READER(dq_dbg_read_bwd)
 
 // The data gradients multiply by W^T.  dq_qnet_pack writes W2^T and W1^T as f16 pieces in MFMA operand order (qnet.h dense2t / dense1t,
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(1024) void grad_scale_kernel(const float* __restric
 // is the NHWC offset itself (the permutation lives in the packed columns), so masks and results are 64-byte row segments.
 template <int NTP>
 __device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const unsigned short* __restrict__ s_gh1p, int tile0, int b0, int ns, int lane) {
-    constexpr int LDH = DENSE_HID + 8, NB = DENSE_HID / 32, RING = 3;
+    constexpr int LDH = DENSE_HID + 8, NB = DENSE_HID / 32, RING = GX_RING;
     const int j = lane & 15, kq = lane >> 4, K1 = a.K1, tiles = K1 >> 4;
     const u32x4* pk = opaque_global(a.packed + a.pk_dense1t + (size_t)tile0 * PK_BLOCK) + lane;
     const unsigned short* arow = s_gh1p + j * LDH + 8 * kq;
@@ -96,20 +102,28 @@ __device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const unsigned sh
     f32x4 acc[NTP][2];
 #pragma unroll
     for (int t = 0; t < NTP; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-    static_assert((NB - 1) % RING == 0, "the block loop is unrolled in whole rings plus one");
+    static_assert((NB - 1) % RING == 0 || NB % RING == 0, "the block loop is unrolled in whole rings (plus one)");
     auto block = [&](int blk, int u) {
         load(min(blk + RING - 1, NB - 1), bw[(u + RING - 1) % RING]);      // unconditional (clamped): static s_waitcnt counts
+        if (GX_PIN) __builtin_amdgcn_sched_barrier(0);              // the requests stay RING - 1 blocks ahead of their use (hipcc sinks them next to it)
         F16x2 av;
         av.h = *reinterpret_cast<const u32x4*>(arow + 32 * blk);
         av.l = *reinterpret_cast<const u32x4*>(arow + 32 * blk + DENSE_ROWS * LDH);
 #pragma unroll
         for (int t = 0; t < NTP; ++t) mma_f16x3(av, bw[u][t], acc[t][0], acc[t][1]);
     };
-    for (int blk = 0; blk + 1 < NB; blk += RING) {
+    if constexpr (NB % RING == 0) {
+        for (int blk = 0; blk < NB; blk += RING) {
 #pragma unroll
-        for (int u = 0; u < RING; ++u) block(blk + u, u);
+            for (int u = 0; u < RING; ++u) block(blk + u, u);
+        }
+    } else {
+        for (int blk = 0; blk + 1 < NB; blk += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) block(blk + u, u);
+        }
+        block(NB - 1, 0);
     }
-    block(NB - 1, 0);
 #pragma unroll
     for (int t = 0; t < NTP; ++t)
 #pragma unroll
