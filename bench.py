@@ -189,7 +189,15 @@ def main():
         sys.exit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node has {torch.cuda.device_count()}")
     device = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device)
-    if world > 1:
+    # DQ_DIST_FORCE=1 at --gpus 1: a one-rank RCCL group, and the learner takes its several-GPU branch through it (communicator,
+    # asynchronous all-reduce behind the convolutional backward, separate Adam) -- the only way to run that code through the real
+    # backend on a one-GPU box; the line then carries the distributed fields with rccl_ranks = 1
+    force_dist = world == 1 and os.environ.get("DQ_DIST_FORCE") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -210,7 +218,7 @@ def main():
             dq, cfg, n_local, rank, world, args.minibatch or n_local, mode=mode, config_name=args.config)
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -225,13 +233,13 @@ def main():
         runner.step(timed=True)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     replicas_identical, allreduce = None, None
-    if world > 1 and hasattr(runner, "core"):
+    if (world > 1 or force_dist) and hasattr(runner, "core"):
         # outside the timed region: every rank must hold bit-identical parameters (same all-reduced gradient, same Adam step)
         chk = runner.core.params.view(torch.int32).to(torch.int64).sum().reshape(1)
         lo, hi = chk.clone(), chk.clone()
@@ -242,6 +250,9 @@ def main():
             print("WARNING: the ranks' parameters diverged", file=sys.stderr)
         allreduce = allreduce_probe(torch, dist, runner.core, backend)
 
+    params_checksum = None
+    if hasattr(runner, "core"):                     # outside the timed region: what the run left in the parameters (path-equivalence checks)
+        params_checksum = int(runner.core.params.view(torch.int32).to(torch.int64).sum().item())
     if rank == 0:
         units = runner.units_per_step() if hasattr(runner, "units_per_step") else n_local
         out = {
@@ -261,7 +272,9 @@ def main():
                                     f"{n_local} lattices/GPU, mode={mode}", **runner.config()),
         }
         out.update(runner.report(args.steps, dt, world))
-        if world > 1:
+        if params_checksum is not None:
+            out["params_checksum"] = params_checksum
+        if world > 1 or force_dist:
             out["rccl_ranks"] = world if backend == "nccl" else 0
             out["dist_backend"] = "rccl" if backend == "nccl" else backend
             out["replicas_identical"] = replicas_identical
@@ -274,7 +287,7 @@ def main():
                 bl = importlib.import_module("deepq-decoding_amd.bench_loop")
                 out["cpu_baseline"] = cpu_baseline_loop(full, runner.B, runner.eps, bl.C_LAYERS, bl.FF_LAYERS, mode=mode)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -245,7 +245,7 @@ class DQNCore:
             self._stats_pending = None
         td = self._td_job(step_stats)
         self._metrics_stale = True
-        if self.world_size > 1:
+        if _dist.dist_path(self.world_size):
             # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs
             nconv = net.n_conv_params
             if ride is not None:

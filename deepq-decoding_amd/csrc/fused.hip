@@ -23,6 +23,7 @@
 // bit; each is deterministic.  Training forwards additionally write every layer's output to HBM (f32, the layout qnet.hip's backward
 // expects) and the dense layers' inputs / outputs as f16 piece planes for the dense weight gradients (fused_bwd.hip).
 #include "qnet.h"
+#include <type_traits>
 
 DQ_STAMP_READER(dq_dbg_read_fwd)
 
@@ -31,6 +32,12 @@ DQ_STAMP_READER(dq_dbg_read_fwd)
 #endif
 #ifndef DENSE_PIN
 #define DENSE_PIN 1
+#endif
+#ifndef CONV_APIPE
+#define CONV_APIPE 1
+#endif
+#ifndef DENSE_XPIPE
+#define DENSE_XPIPE 1
 #endif
 #define CONV_THREADS 256
 #define CONV_WAVES 4
@@ -44,6 +51,8 @@ struct ConvChainArgs {
     int oh1, ow1, oh2, ow2, oh3, ow3;
     int w_off[3], b_off[3];            // floats into params
     const int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an observation, -1 past K1
+    const int* rowtab;                 // [3][CONV_ROWTAB] output row m of a workgroup -> where its input patch starts (fused_conv_row_tables): the
+                                       // kernel never divides (every m -> (sample, y, x) was ~30 VALU, ten of them quarter-rate multiplies)
     int slot;                          // bytes per sample slot in LDS (multiple of 4, >= C*H*W + 3)
     int off_mis, off_t1, off_a1, off_a2;   // LDS byte offsets (observations at 0; a2 overlays observations + tables)
 };
@@ -81,24 +90,25 @@ __device__ __forceinline__ void conv_w_prefetch(F16x2 (&ring)[R][NT], const u32x
 template <int CIN, int COUT, int KS, int RR, int NTT>
 __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__ in, int lo_in, int ih, int iw, int oh, int ow, int M,
                                               F16x2 (&ring)[RR][NTT], const u32x4* __restrict__ pk, const float* __restrict__ bias,
-                                              unsigned short* __restrict__ out_lds, int lo_out, float* __restrict__ out_g, int wave, int lane) {
+                                              unsigned short* __restrict__ out_lds, int lo_out, float* __restrict__ out_g, int wave, int lane,
+                                              const int* __restrict__ rowtab, int pre0, int pre1) {
     using SH = ConvShape<CIN, COUT, KS>;
     constexpr int NT = SH::NT, PSI = CIN + 8, PSO = COUT + 8, CB = SH::CB, NB = SH::NB, R = SH::R;
     static_assert(NT == 2 && CIN % 32 == 0 && RR == R && NTT == NT, "written for 32 output channels, CIN a multiple of 32");
     const int j = lane & 15, kb = lane >> 4;
     const f32x2 bias2 = *reinterpret_cast<const f32x2*>(bias + 2 * j);
-    const int rows = oh * ow, tiles = (M + 15) >> 4;
+    const int tiles = (M + 15) >> 4;
+    (void)ih; (void)oh; (void)ow;
     for (int t0 = 2 * wave; t0 < tiles; t0 += 2 * CONV_WAVES) {
         pk = opaque_global(pk);                                     // per trip: see qnet.h
         const bool two = t0 + 1 < tiles;                            // wave-uniform; a missing second tile recomputes clamped rows
         const bool more = t0 + 2 * CONV_WAVES < tiles;              // another pair of row tiles follows: keep the weight stream going
-        int abase[2];
+        // patch origins of this lane's two rows: halves into the input image, from the host-built table (rows past M re-read row M - 1:
+        // padding rows recompute the last row and are never stored); the first trip's entries were requested by the caller before its barrier
+        int abase[2] = {pre0 + 8 * kb, pre1 + 8 * kb};
+        if (t0 != 2 * wave) {                                       // wave-uniform
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            int m = (t0 + u) * 16 + j;
-            if (m >= M) m = M - 1;                                  // padding rows recompute the last row; never stored
-            const int s = m / rows, pix = m - s * rows, oy = pix / ow, ox = pix - oy * ow;
-            abase[u] = ((s * ih + oy) * iw + ox) * PSI + 8 * kb;
+            for (int u = 0; u < 2; ++u) abase[u] = rowtab[min((t0 + u) * 16 + j, M - 1)] + 8 * kb;
         }
         f32x4 acc[2][NT][2];
 #pragma unroll
@@ -107,19 +117,29 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
             for (int t = 0; t < NT; ++t) { acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = acc[u][t][0]; }
         // the weights stream through a ring of R blocks: block blk + R is requested as soon as block blk's MFMAs are issued, so the
         // L1/L2 weight traffic (every wave reads the whole layer) overlaps the matrix pipe instead of alternating with it
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
+        // ... and the A pieces of block blk + 1 are read from LDS BEFORE block blk's MFMAs are issued (CONV_APIPE): read next to their use,
+        // every block waited out two LDS latencies (one per row tile) with the matrix pipe idle
+        auto a_read = [&](int blk, F16x2 (&av)[2]) {
             const int tap = blk / CB, c32 = blk - tap * CB, ky = tap / KS, kx = tap - ky * KS;
             const int off = (ky * iw + kx) * PSI + 32 * c32;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const unsigned short* ap = in + abase[u] + off;
-                F16x2 av;
-                av.h = *reinterpret_cast<const u32x4*>(ap);
-                av.l = *reinterpret_cast<const u32x4*>(ap + lo_in);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) mma_f16x3(av, ring[blk % R][t], acc[u][t][0], acc[u][t][1]);
+                av[u].h = *reinterpret_cast<const u32x4*>(ap);
+                av[u].l = *reinterpret_cast<const u32x4*>(ap + lo_in);
             }
+        };
+        F16x2 avr[2][2];
+        if (CONV_APIPE) a_read(0, avr[0]);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            if (CONV_APIPE) {
+                if (blk + 1 < NB) { a_read(blk + 1, avr[(blk + 1) & 1]); __builtin_amdgcn_sched_barrier(0); }
+            } else a_read(blk, avr[blk & 1]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mma_f16x3(avr[blk & 1][u], ring[blk % R][t], acc[u][t][0], acc[u][t][1]);
             if (blk + R < NB) conv_w_load<NT>(ring[blk % R], pk, blk + R, lane);
             else if (more) conv_w_load<NT>(ring[blk % R], pk, blk + R - NB, lane);
             if (CONV_PIN) __builtin_amdgcn_sched_barrier(0);        // the requests stay R blocks ahead of their use
@@ -128,11 +148,15 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) break;
+            // pieces' sum and bias as packed operations along an accumulator's own registers (v_pk_fma_f32 / v_pk_add_f32 take adjacent pairs)
+            f32x4 vs[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) vs[t] = f16x2_sum(acc[u][t][0], acc[u][t][1]) + f32x4{bias2[t], bias2[t], bias2[t], bias2[t]};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int mo = (t0 + u) * 16 + 4 * kb + r;
                 if (mo >= M) continue;
-                f32x2 v = {fmaxf(f16x2_sum(acc[u][0][0][r], acc[u][0][1][r]) + bias2[0], 0.f), fmaxf(f16x2_sum(acc[u][1][0][r], acc[u][1][1][r]) + bias2[1], 0.f)};
+                const f32x2 v = {relu1(vs[0][r]), relu1(vs[1][r])};
                 if (out_lds) {
                     u32 h, l;
                     split_f16x2_pair(v[0], v[1], h, l);
@@ -187,6 +211,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
             for (int e = 0; e < 8; ++e) ko[h][e] = max(a.kofftab[32 * h + 8 * kq + e], 0);      // Keras HWIO row k -> NCHW uint8 offset (-1 past K1: weights 0)
     }
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
+    // row tables (requested here, used behind the barriers): this thread's first-convolution row, this lane's two rows of the wave's first
+    // tile pair of the second and third convolution
+    const int r1 = a.oh1 * a.ow1, M1 = ns * r1, M2 = ns * a.oh2 * a.ow2, M3 = ns * a.oh3 * a.ow3;
+    const int tab1 = a.rowtab[min(tid, M1 - 1)];
+    int tab2[2], tab3[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        tab2[u] = a.rowtab[CONV_ROWTAB + min((2 * wave + u) * 16 + j, M2 - 1)];
+        tab3[u] = a.rowtab[2 * CONV_ROWTAB + min((2 * wave + u) * 16 + j, M3 - 1)];
+    }
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 1);
     // ---- stage the observations by LDS-DMA (global -> LDS, no registers): lane l copies aligned dword l of a 256-byte piece of a
@@ -223,12 +257,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     }
     __syncthreads();                                                // s_mis
     // byte offset of output pixel m's patch origin inside the staged observations
-    const int r1 = a.oh1 * a.ow1, M1 = ns * r1;
     const int lo1 = a.S * r1 * 72, lo2 = a.S * a.oh2 * a.ow2 * 40;        // halves from an h plane to its l plane
     int* s_t1 = reinterpret_cast<int*>(smem + a.off_t1);
-    for (int m = tid; m < M1; m += CONV_THREADS) {
-        const int s = m / r1, pix = m - s * r1, oy = pix / a.ow1, ox = pix - oy * a.ow1;
-        s_t1[m] = s * a.slot + s_mis[s] + (oy * a.st1) * a.W + ox * a.st1;
+    for (int m = tid; m < M1; m += CONV_THREADS) {                  // table entry: sample << 20 | offset of the patch inside the observation
+        const int e = m == tid ? tab1 : a.rowtab[m], s = e >> 20;
+        s_t1[m] = s * a.slot + s_mis[s] + (e & 0xfffff);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's DMA pieces have landed
     __syncthreads();
@@ -261,13 +294,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
 #pragma unroll
                 for (int t = 0; t < 4; ++t) accl[t] = MFMA_F16(av, wb[1][h][t], accl[t]);
             }
+            f32x4 vs[4];                                            // pieces' sum and bias, packed along each accumulator's own registers
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vs[t] = f16x2_sum(acc[t], accl[t]) + f32x4{bias1[t], bias1[t], bias1[t], bias1[t]};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int mo = tile * 16 + 4 * kq + r;
                 if (mo >= M1) continue;
                 f32x4 v;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(f16x2_sum(acc[t][r], accl[t][r]) + bias1[t], 0.f);
+                for (int t = 0; t < 4; ++t) v[t] = relu1(vs[t][r]);
                 u32 hp[2], lp[2];                                   // split on write: this lane's 4 consecutive channels of pixel mo
                 split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                 split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -295,8 +331,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 4);
     {
         const int r2 = a.oh2 * a.ow2;
-        conv_from_lds<64, 32, 2>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, ns * r2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
-                                 J.write_all ? J.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane);
+        conv_from_lds<64, 32, 2>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
+                                 J.write_all ? J.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1]);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 5);
     conv_w_prefetch(ring, J.packed + PK_CONV3_FWD, lane);
@@ -304,8 +340,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 6);
     {
         const int r3 = a.oh3 * a.ow3;
-        conv_from_lds<32, 32, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, ns * r3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
-                                 J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane);
+        conv_from_lds<32, 32, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, M3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
+                                 J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane, a.rowtab + 2 * CONV_ROWTAB, tab3[0], tab3[1]);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 7);
     DQ_STAMP_WG(DQ_TAG_CONV_FWD, 1);
@@ -431,7 +467,17 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc[u][t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[u][t][1] = acc[u][t][0]; }
     const unsigned short* xrow = s_pl + j * LDP + 8 * kq;
-    auto do_block = [&](int b, F16x2 (&cur)[4], F16x2 (&nxt)[4]) {
+    auto x_read = [&](int b, int u, F16x2& xv) {
+        const unsigned short* xp = xrow + 16 * u * LDP + 32 * b;
+        xv.h = *reinterpret_cast<const u32x4*>(xp);
+        xv.l = *reinterpret_cast<const u32x4*>(xp + ROWS * LDP);
+    };
+    // the input pieces of step (b, u) + 1 are read from LDS BEFORE step (b, u)'s MFMAs are issued (DENSE_XPIPE; xq[parity of the step]):
+    // read next to their use, every row tile of every block waited out one LDS latency with the matrix pipe idle
+    F16x2 xq[2];
+    if (DENSE_XPIPE) x_read(0, 0, xq[0]);
+    auto do_block = [&](int b, F16x2 (&cur)[4], F16x2 (&nxt)[4], auto ptag) {
+        constexpr int P0 = decltype(ptag)::value;                   // parity of step (b, 0)
         const u32x4* pn = pkw + (size_t)min(b + 1, KB - 1) * 32 * PK_BLOCK;      // next block: unconditional, clamped prefetch
 #pragma unroll
         for (int t = 0; t < 4; ++t) { nxt[t].h = pn[t * PK_BLOCK]; nxt[t].l = pn[t * PK_BLOCK + PK_LO]; }
@@ -439,20 +485,24 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                                                                     // each next to its use -- a few MFMAs ahead -- and the wave waits out one L2 latency per pair)
 #pragma unroll
         for (int u = 0; u < RT; ++u) {
-            F16x2 xv;
-            const unsigned short* xp = xrow + 16 * u * LDP + 32 * b;
-            xv.h = *reinterpret_cast<const u32x4*>(xp);
-            xv.l = *reinterpret_cast<const u32x4*>(xp + ROWS * LDP);
+            const int pp = (P0 + u) & 1;
+            if (DENSE_XPIPE) {
+                if (u + 1 < RT) x_read(b, u + 1, xq[pp ^ 1]);
+                else x_read(min(b + 1, KB - 1), 0, xq[pp ^ 1]);     // (past the last block: re-reads it, unused)
+                __builtin_amdgcn_sched_barrier(0);
+            } else x_read(b, u, xq[pp]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) mma_f16x3(cur[t], xv, acc[u][t][0], acc[u][t][1]);
+            for (int t = 0; t < 4; ++t) mma_f16x3(cur[t], xq[pp], acc[u][t][0], acc[u][t][1]);
         }
     };
+    using par0 = std::integral_constant<int, 0>;
+    using par1 = std::integral_constant<int, (RT & 1)>;             // an odd RT alternates the parity from block to block
     int blk = 0;
     for (; blk + 1 < KB; blk += 2) {                                // no condition around the MFMAs inside the loop
-        do_block(blk, bw[0], bw[1]);
-        do_block(blk + 1, bw[1], bw[0]);
+        do_block(blk, bw[0], bw[1], par0{});
+        do_block(blk + 1, bw[1], bw[0], par1{});
     }
-    if (blk < KB) do_block(blk, bw[0], bw[1]);                       // odd block count (K1 = 288: 9 blocks)
+    if (blk < KB) do_block(blk, bw[0], bw[1], par0{});               // odd block count (K1 = 288: 9 blocks)
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
     // ---- Dense(|A|)^T's weights for this wave's 64 units (two K = 32 blocks x NT2 tiles of 16 outputs: qnet.h dense2) start flying
@@ -805,6 +855,7 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
     P->KG1 = (L1.K + 15) / 16;
     if (P->KG1 < 3) P->KG1 = 3;
     const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
+    if (in_bytes >= (1 << 20)) return false;                        // (first row table: sample << 20 | offset inside the observation)
     P->slot = (in_bytes + 3 + 3) & ~3;
     for (int pass = 0; pass < 2; ++pass) {                          // prefer two workgroups per CU; else the largest S that fits
         const size_t budget = pass == 0 ? CONV_LDS_2PER_CU : CONV_LDS_MAX;
@@ -817,13 +868,34 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
             const size_t a2_bytes = up16((size_t)2 * S * L2.rows * 40 * 2);
             if (off < a2_bytes) off = a2_bytes;
             const size_t a1 = off; off += up16((size_t)2 * S * L1.rows * 72 * 2);
-            if (off <= budget) {
+            if (off <= budget && S * L1.rows <= CONV_ROWTAB) {      // (rows per workgroup: the row tables' capacity)
                 P->S = S; P->off_mis = (int)mis; P->off_t1 = (int)t1; P->off_a1 = (int)a1; P->off_a2 = 0; P->lds = off;
                 return true;
             }
         }
     }
     return false;
+}
+
+// Row tables of the fused conv forward for this network (CONV_ROWTAB ints each; qnet.hip uploads them behind kofftab at creation):
+//   [0] first convolution, row m = s * r1 + oy * ow1 + ox of a workgroup's S samples:  s << 20 | (oy * stride * W + ox * stride)
+//   [1] / [2] second / third convolution: halves from the input image's start to row m's patch, ((s * ih + oy) * iw + ox) * (CIN + 8)
+bool fused_conv_row_tables(const dq_qnet* Q, int* tab) {
+    ConvPlan P;
+    if (!plan_conv(Q, &P)) return false;
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    memset(tab, 0, sizeof(int) * 3 * CONV_ROWTAB);
+    for (int m = 0; m < P.S * L1.rows; ++m) {
+        const int s = m / L1.rows, pix = m % L1.rows, oy = pix / L1.ow, ox = pix % L1.ow;
+        tab[m] = s << 20 | (oy * L1.s * L1.iw + ox * L1.s);
+    }
+    const Layer* Ls[2] = {&L2, &L3};
+    for (int l = 0; l < 2; ++l)
+        for (int m = 0; m < P.S * Ls[l]->rows; ++m) {
+            const int s = m / Ls[l]->rows, pix = m % Ls[l]->rows, oy = pix / Ls[l]->ow, ox = pix % Ls[l]->ow;
+            tab[(1 + l) * CONV_ROWTAB + m] = ((s * Ls[l]->ih + oy) * Ls[l]->iw + ox) * (Ls[l]->cin + 8);
+        }
+    return true;
 }
 
 struct DensePlan { int ldx, ld2, ld3, off_x, off_h, off_part, off_y2, off_y3, NT2; size_t lds; };
@@ -888,7 +960,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
-    ca.kofftab = Q->kofftab;
+    ca.kofftab = Q->kofftab; ca.rowtab = Q->kofftab + 96;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_t1 = cp.off_t1; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2;
     const PackLayout PL = fused_pack_layout(Q);
     da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = (int)PL.dense1; da.pk_dense2 = (int)PL.dense2;

@@ -4,6 +4,7 @@
 
 #define QN_MAX_LAYERS 12
 #define FWD_MAX_JOBS 4               // forwards served by one fused launch (dq_qnet_forward_multi)
+#define CONV_ROWTAB 512              // rows per workgroup and layer of the fused conv forward, at most
 
 struct Layer {
     int kind;                    // 0 conv, 1 dense
@@ -29,7 +30,8 @@ struct dq_qnet {
     const int32_t* last_index;
     int last_index_off, last_index_mod;
     float* xinf[FWD_MAX_JOBS];   // fused inference forwards: last-convolution output per job slot [max_batch, flat]
-    int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an NCHW uint8 observation, -1 past K
+    int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an NCHW uint8 observation, -1 past K;
+                                 // then [3][CONV_ROWTAB] the fused conv forward's row tables (fused_conv_row_tables)
     void* pk_scratch[FWD_MAX_JOBS];  // packed weights of jobs that did not bring their own (dq_qnet_job.packed_dev == NULL)
     const void* last_train_packed;   // packed weights of the last training forward (the backward's data gradients read them)
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
@@ -122,6 +124,8 @@ __device__ __forceinline__ void mma_f16x3(const F16x2& a, const F16x2& b, f32x4&
     acc1 = MFMA_F16(a.h, b.l, acc1);
     acc1 = MFMA_F16(a.l, b.h, acc1);
 }
+// max(x, 0) as ONE instruction whatever produced x (fmaxf behind a packed operation costs a second v_max_f32 that canonicalises its operand)
+__device__ __forceinline__ float relu1(float x) { float y; asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x)); return y; }
 __device__ __forceinline__ float f16x2_sum(float acc0, float acc1) { return __builtin_fmaf(acc1, F16_LO_INV, acc0); }
 __device__ __forceinline__ f32x4 f16x2_sum(const f32x4& acc0, const f32x4& acc1) { return acc1 * F16_LO_INV + acc0; }
 
@@ -182,6 +186,7 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);
+bool fused_conv_row_tables(const dq_qnet* Q, int* tab);      // tab: int[3 * CONV_ROWTAB]
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);

@@ -33,6 +33,20 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def _active(group=None):
+    """A collective has something to do: more than one rank -- or DQ_DIST_FORCE=1 with an initialised one-rank group, which drives the
+    several-GPU code path (RCCL communicator, asynchronous all-reduce on the communicator's stream, split backward, separate Adam)
+    through the real backend on a one-GPU box (tests/test_distributed_gpu.py; the collective itself is then a copy onto itself)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("DQ_DIST_FORCE") == "1"
+
+
+def dist_path(world_size):
+    """True when the learner takes its several-GPU branch (DQNCore._learn)."""
+    return world_size > 1 or (os.environ.get("DQ_DIST_FORCE") == "1" and dist.is_available() and dist.is_initialized())
+
+
 def shard(rank, n_local, batch_local):
     """(env_id_base, sample_base) of a rank: global lattice ids and global minibatch-sample ids are contiguous per rank,
     so an R-rank run reproduces the lattices / dropout masks / replay draws of a 1-rank run of R*n_local lattices."""
@@ -45,7 +59,7 @@ def grad_scale(batch_local, world):
 
 def allreduce_sum_(flat, group=None):
     """In-place sum of the flat gradient over all ranks (RCCL ring/tree over xGMI on the GPU box; 0.77 MB at c3)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
@@ -54,12 +68,12 @@ def allreduce_sum_async(flat, group=None):
     """Starts the in-place sum and returns the work handle (None when there is nothing to do): the collective runs on the
     communicator's stream, ordered after the work already queued on the current stream, while later kernels on the current
     stream proceed; `handle.wait()` orders the current stream after it."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
 
 
 def broadcast_(flat, src=0, group=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.broadcast(flat, src=src, group=group)
     return flat

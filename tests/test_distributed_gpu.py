@@ -34,6 +34,25 @@ def test_bench_self_launches_two_ranks_that_stay_identical():
 
 
 @pytest.mark.gpu
+def test_one_rank_rccl_group_drives_the_several_gpu_branch():
+    """The several-GPU learner branch through the REAL backend on the one-GPU box: DQ_DIST_FORCE=1 makes bench.py create a one-rank RCCL
+    process group and DQNCore take the split backward (dense gradient all-reduced asynchronously on the communicator's stream behind the
+    convolutional backward, convolutional range on the critical path, separate Adam launch).  With one rank the sum is the identity, so
+    the parameters after the run must be the bits the one-GPU branch (Adam fused on the reduction) leaves."""
+    def run(**extra):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4", "--no-cpu-baseline"]
+        r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(**extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    forced, plain = run(DQ_DIST_FORCE="1"), run()
+    assert forced["rccl_ranks"] == 1 and forced["dist_backend"] == "rccl" and forced["replicas_identical"] is True
+    ar = forced["allreduce"]
+    assert ar["backend"] == "rccl" and ar["dense_us"] > 0 and ar["conv_us"] > 0
+    assert "rccl_ranks" not in plain
+    assert forced["params_checksum"] == plain["params_checksum"]
+
+
+@pytest.mark.gpu
 def test_bench_refuses_a_world_that_differs_from_gpus():
     # one process that claims to be a 1-rank world while --gpus says 2: no JSON line, non-zero exit
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],

@@ -19,6 +19,11 @@ for _ in range(5):
     net.backward(params, dqt)
 if os.environ.get("DQ_STAMP_INFER"):                  # the LAST forward launch (whose stamps are read) is an inference forward
     net.forward(params, obs)
+if os.environ.get("DQ_STAMP_LOOP"):                   # the LAST forward launch pair has the vector step's shape: 3 inference jobs + the training job
+    pk = net.pack(params)
+    for _ in range(3):
+        net.forward_multi([dict(params=params, obs=obs, packed=pk), dict(params=params, obs=obs, packed=pk),
+                           dict(params=params, obs=obs, training=True, seed=(1, 2), t=3, packed=pk), dict(params=params, obs=obs, packed=pk)])
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()
 getattr(dq.lib(), 'dq_dbg_read_fwd' if tag % 10 in (1, 2) and tag != 21 else 'dq_dbg_read_bwd')(buf)
