@@ -24,6 +24,7 @@
 // expects) and the dense layers' inputs / outputs as f16 piece planes for the dense weight gradients (fused_bwd.hip).
 #include "qnet.h"
 #include <type_traits>
+#include <utility>
 
 DQ_STAMP_READER(dq_dbg_read_fwd)
 
@@ -53,7 +54,7 @@ struct ConvChainArgs {
     const int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an observation, -1 past K1
     const int* rowtab;                 // [3][CONV_ROWTAB] output row m of a workgroup -> where its input patch starts (fused_conv_row_tables): the
                                        // kernel never divides (every m -> (sample, y, x) was ~30 VALU, ten of them quarter-rate multiplies)
-    int slot;                          // bytes per sample slot in LDS (multiple of 4, >= C*H*W + 3)
+    int slot;                          // bytes per sample slot in LDS (multiple of 16, >= C*H*W + 30)
     int off_mis, off_t1, off_a1, off_a2;   // LDS byte offsets (observations at 0; a2 overlays observations + tables)
 };
 
@@ -223,14 +224,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     }
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 1);
-    // ---- stage the observations by LDS-DMA (global -> LDS, no registers): lane l copies aligned dword l of a 256-byte piece of a
-    //      sample's arbitrarily aligned row -- whole aligned dwords, also where they straddle the neighbouring rows: the window never
-    //      leaves the caller's allocation (dq_qnet_forward: obs_dev rows live in one 4-byte-aligned allocation whose size is a
-    //      multiple of 4).  The copies fly while the weights are split below. ------------------------------------------------------
+    // ---- stage the observations by LDS-DMA (global -> LDS, no registers): lane l copies aligned 16-byte word l of a 1 KB piece of a
+    //      sample's arbitrarily aligned row -- whole aligned words, also where they straddle the neighbouring rows: the window never
+    //      leaves the caller's allocation (dq_qnet_forward: obs_dev rows live in one 16-byte-aligned allocation whose allocated size
+    //      is a multiple of 16). ---------------------------------------------------------------------------------------------------
     {
         // wave w takes samples w, w + 4, ...: their ring rows (scalar loads) are all requested BEFORE the first copy -- one after the
         // other, every sample's copy waited for its own index
-        const int pieces = (a.slot + 255) >> 8;
         constexpr int SPW = 4;                                      // samples per wave at most (S <= 16)
         int rows[SPW];
 #pragma unroll
@@ -245,13 +245,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
             int row = rows[q];
             if (J.index) { row += J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
             const u8* src = J.obs + (size_t)row * in_bytes;
-            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
-            for (int pc = 0; pc < pieces; ++pc) {
-                const int d = pc * 64 + lane;
-                if (4 * d < mis + in_bytes)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32*>(src - mis) + d,
-                                                     (__attribute__((address_space(3))) u32*)(s_in + s * a.slot + pc * 256), 4, 0, 0);
-            }
+            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 15);
+            // 16 bytes per lane: ONE instruction copies up to 1 KB (a whole d = 5 observation; four dword copies before)
+            const u32x4* gp = reinterpret_cast<const u32x4*>(src - mis) + lane;
+            u8* lp = s_in + s * a.slot;
+            const int nq = (mis + in_bytes + 15) >> 4;                          // 16-byte pieces of the window
+            for (int pc = 0; 64 * pc < nq; ++pc)
+                if (64 * pc + lane < nq) __builtin_amdgcn_global_load_lds(gp + 64 * pc, (__attribute__((address_space(3))) u32*)(lp + 1024 * pc), 16, 0, 0);
             if (lane == 0) s_mis[s] = mis;
         }
     }
@@ -856,7 +856,7 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
     if (P->KG1 < 3) P->KG1 = 3;
     const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
     if (in_bytes >= (1 << 20)) return false;                        // (first row table: sample << 20 | offset inside the observation)
-    P->slot = (in_bytes + 3 + 3) & ~3;
+    P->slot = (in_bytes + 15 + 15 + 15) & ~15;                       // the 16-byte-aligned window around an arbitrarily aligned row
     for (int pass = 0; pass < 2; ++pass) {                          // prefer two workgroups per CU; else the largest S that fits
         const size_t budget = pass == 0 ? CONV_LDS_2PER_CU : CONV_LDS_MAX;
         for (int S = 8; S >= 1; S >>= 1) {

@@ -88,17 +88,19 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define F16_LO_INV (1.f / 2048.f)
 struct F16x2 { u32x4 h, l; };         // 8 values: pieces packed two per dword (element e in the low half of dword e/2)
 
-// two values -> {h pair, l pair}: v_cvt_pk_f16_f32, v_pk_mul_f32, 2 x v_cvt_f32_f16, v_pk_fma_f32, v_cvt_pk_f16_f32 (3 VALU per value)
+// two values -> {h pair, l pair} in FOUR instructions: v_cvt_pk_f16_f32 (h pair), v_pk_mul_f32 (x 2^11), then v_fma_mixlo_f16 /
+// v_fma_mixhi_f16 = f16(fma(h as f32, -2^11, x 2^11)) straight from the packed h into the two halves of l -- the same roundings as the
+// plain form (convert h back, fma, convert: six instructions, which is what hipcc emits for it), so the same bits
 __device__ __forceinline__ void split_f16x2_pair(float x0, float x1, u32& h, u32& l) {
     const f16x2 hp = {(_Float16)x0, (_Float16)x1};
-    u32 hu = __builtin_bit_cast(u32, hp);
-    asm volatile("" : "+v"(hu));                                    // (otherwise hipcc converts every value twice: packed and unpacked)
-    const f16x2 hq = __builtin_bit_cast(f16x2, hu);
-    const float r0 = __builtin_fmaf((float)hq[0], -F16_LO_SCALE, x0 * F16_LO_SCALE);      // (x - h) 2^11, exact
-    const float r1 = __builtin_fmaf((float)hq[1], -F16_LO_SCALE, x1 * F16_LO_SCALE);
-    const f16x2 lp = {(_Float16)r0, (_Float16)r1};
+    const u32 hu = __builtin_bit_cast(u32, hp);
+    const f32x2 sc = f32x2{x0, x1} * F16_LO_SCALE;
+    const float ns = -F16_LO_SCALE;
+    u32 lu;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "v"(ns), "v"(sc[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "v"(ns), "v"(sc[1]));
     h = hu;
-    l = __builtin_bit_cast(u32, lp);
+    l = lu;
 }
 
 __device__ __forceinline__ F16x2 split_f16x2(const f32x4& x0, const f32x4& x1) {

@@ -288,9 +288,9 @@ int dq_qnet_fused_supported(const dq_qnet* net);
  *   obs_dev    uint8 [rows, C, H, W]; sample b reads row  b                         if index_dev == NULL,
  *                                                     row (index_dev[b] + index_off) mod index_mod otherwise
  *              (the replay-minibatch gather happens inside the first convolution's loader).  Rows are copied as whole
- *              aligned 4-byte words, so the words that straddle a row's ends are read too: obs_dev must point into an
- *              allocation that starts 4-byte aligned and whose size is a multiple of 4 (any hipMalloc / torch
- *              allocation; views at arbitrary byte offsets inside it are fine);
+ *              aligned 16-byte words, so the words that straddle a row's ends are read too: obs_dev must point into an
+ *              allocation that starts 16-byte aligned and whose allocated size is a multiple of 16 (any hipMalloc / torch
+ *              allocation: both round sizes up to at least 256 bytes; views at arbitrary byte offsets inside it are fine);
  *   q_dev      float [batch, n_actions];
  *   dropout    keep(b, j) <=> Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b, (j>>2) | DQ_STREAM_DROPOUT<<16))[j&3]
  *              >= ceil(rate * 2^32);  kept units are scaled by 1/(1-rate) (Keras K.dropout). */
