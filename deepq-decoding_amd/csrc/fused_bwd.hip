@@ -729,9 +729,10 @@ struct ConvBwdArgs {
     float* partial;                     // [gridDim.x][pstride]
     size_t pstride;
     int slot;
-    int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp;
+    int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp, off_d2, off_d1;
     int a1_alt;                         // bytes from the a1 image to its second buffer, 0 = single-buffered
     const int* kofftab;                 // [96] conv1 weight row k -> byte offset inside an observation, -1 past K1
+    const int* rowtab;                  // [5][CONV_ROWTAB] host-built row tables (fused_conv_bwd_row_tables): the kernel copies them into LDS and never divides
 };
 
 // Copies `rows` rows of CH floats from global memory into an LDS image with row stride PS.  Loads are issued NB at a time before
@@ -777,15 +778,15 @@ __device__ __forceinline__ void dgrad_load_w(F16x2 (&bw)[4][2], const u32x4* __r
 //   act[(s,iy,ix), c] <- (sum_{ky,kx,n} g[(s,iy-ky,ix-kx), n] W[ky,kx,c,n]) * [act > 0]     for c in [c_lo, c_lo + 32)
 // g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA].  One tap = one K = 32 block of the f16 MFMA:
 // A = the 32 channels of g at the tap's pixel (two ds_read_b128 per lane, split on the fly), B = the tap's weights (registers).
+// dtab[m] (LDS, host-built): row of g under input pixel m's own position, s * oh * ow + iy * ow + ix, | iy << 16 | ix << 24.
 template <int PSA>
 __device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const float* __restrict__ g, int zero_row, float* __restrict__ act,
-                                              int c_lo, int ih, int iw, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
+                                              int c_lo, const int* __restrict__ dtab, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
     const int j = lane & 15, kb = lane >> 4;
-    const int rin = ih * iw, rout = oh * ow, tiles = (M + 15) >> 4;
+    const int tiles = (M + 15) >> 4;
     for (int tile = tile_first; tile < tiles; tile += tile_step) {
-        int m = tile * 16 + j;
-        if (m >= M) m = M - 1;
-        const int s = m / rin, pix = m - s * rin, iy = pix / iw, ix = pix - iy * iw;
+        const int de = dtab[min(tile * 16 + j, M - 1)];
+        const int gbase = de & 0xffff, iy = (de >> 16) & 0xff, ix = (de >> 24) & 0xff;
         f32x4 acc[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
@@ -794,7 +795,7 @@ __device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const flo
         for (int tap = 0; tap < 4; ++tap) {                         // all LDS reads first
             const int oy = iy - (tap >> 1), ox = ix - (tap & 1);
             const bool valid = (unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow;
-            const float* gp = g + (valid ? s * rout + oy * ow + ox : zero_row) * 36 + 8 * kb;
+            const float* gp = g + (valid ? gbase - (tap >> 1) * ow - (tap & 1) : zero_row) * 36 + 8 * kb;
             ga[tap][0] = *reinterpret_cast<const f32x4*>(gp);
             ga[tap][1] = *reinterpret_cast<const f32x4*>(gp + 4);
         }
@@ -831,6 +832,8 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     int* s_ko = reinterpret_cast<int*>(smem + a.off_ko);
     int* t2 = reinterpret_cast<int*>(smem + a.off_t2);
     int* t3 = reinterpret_cast<int*>(smem + a.off_t3);
+    int* d2 = reinterpret_cast<int*>(smem + a.off_d2);              // dgrad_inplace's tables of the g2 / g1 phases
+    int* d1 = reinterpret_cast<int*>(smem + a.off_d1);
     int* t1 = reinterpret_cast<int*>(smem + a.off_tp);              // [S*r1]: sample << 16 | byte offset of the pixel's patch origin inside an observation
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     const int S = a.S, r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
@@ -841,9 +844,15 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 
     DQ_STAMP_PAIR2(3);
     // ---- group-independent tables and zero rows ----------------------------------------------------------------
-    for (int m = tid; m < S * r3; m += CB_THREADS) { const int s = m / r3, p = m - s * r3, oy = p / a.ow3, ox = p - oy * a.ow3; t3[m] = (s * r2 + oy * a.ow2 + ox) * 36; }     // float offset of the a2 row
-    for (int m = tid; m < S * r2; m += CB_THREADS) { const int s = m / r2, p = m - s * r2, oy = p / a.ow2, ox = p - oy * a.ow2; t2[m] = (s * r1 + oy * a.ow1 + ox) * A1PS; }   // float offset of the a1 row
-    for (int m = tid; m < S * r1; m += CB_THREADS) { const int s = m / r1, p = m - s * r1, oy = p / a.ow1, ox = p - oy * a.ow1; t1[m] = s << 16 | ((oy * a.st1) * a.W + ox * a.st1); }
+    // (copied from the host-built tables: computing them here took two integer divisions per entry)
+    for (int m = tid; m < S * r1; m += CB_THREADS) {
+        const int e1 = a.rowtab[m], e2 = a.rowtab[CONV_ROWTAB + min(m, S * r2 - 1)], e3 = a.rowtab[2 * CONV_ROWTAB + min(m, S * r3 - 1)];
+        const int e4 = a.rowtab[3 * CONV_ROWTAB + min(m, S * r2 - 1)], e5 = a.rowtab[4 * CONV_ROWTAB + m];
+        t1[m] = e1;                                                 // sample << 16 | byte offset of the patch origin inside an observation
+        d1[m] = e5;
+        if (m < S * r2) { t2[m] = e2; d2[m] = e4; }                 // t2: float offset of the a1 row under output pixel m of the second convolution
+        if (m < S * r3) t3[m] = e3;                                 // t3: float offset of the a2 row
+    }
     if (tid < 96) s_ko[tid] = a.kofftab[tid];
     if (tid < 36) { s_a2[zero2 * 36 + tid] = 0.f; s_g3[zero3 * 36 + tid] = 0.f; }
 
@@ -1019,7 +1028,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         __syncthreads();                                            // every wave is done reading a2
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 4);
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
-        dgrad_inplace<36>(bw, s_g3, zero3, s_a2, 0, a.oh2, a.ow2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
+        dgrad_inplace<36>(bw, s_g3, zero3, s_a2, 0, d2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
         __syncthreads();
         if (nxt < a.groups) {                                       // the observation slots and g3 are dead now; so is the other a1 buffer
@@ -1098,7 +1107,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         __syncthreads();                                            // every wave is done reading a1
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 8);
         // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1: waves 0-3 channels 0..31, waves 4-7 channels 32..63 -------------
-        dgrad_inplace<A1PS>(bw, s_a2, zero2, s_a1, 32 * (wave >> 2), a.oh1, a.ow1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
+        dgrad_inplace<A1PS>(bw, s_a2, zero2, s_a1, 32 * (wave >> 2), d1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 9);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 10);
@@ -1223,7 +1232,7 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     return true;
 }
 
-struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp, a1_alt; size_t lds; };
+struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp, off_d2, off_d1, a1_alt; size_t lds; };
 
 static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
     if (Q->cfg.n_conv != 3) return false;
@@ -1251,9 +1260,39 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
         P->off_t3 = (int)off; off += up16((size_t)S * L3.rows * 4);
         P->off_ko = (int)off; off += 96 * 4;
         P->off_tp = (int)off; off += up16((size_t)S * L1.rows * 4);
-        if (off <= CHAIN_LDS_MAX && S * L1.rows * 16 <= 7 * CB_THREADS) { P->S = S; P->lds = off; return true; }
+        P->off_d2 = (int)off; off += up16((size_t)S * L2.rows * 4);
+        P->off_d1 = (int)off; off += up16((size_t)S * L1.rows * 4);
+        if (off <= CHAIN_LDS_MAX && S * L1.rows * 16 <= 7 * CB_THREADS && S * L1.rows <= CONV_ROWTAB && S * L2.rows < 65536 && L1.oh < 256 && L1.ow < 256) {
+            P->S = S; P->lds = off; return true;
+        }
     }
     return false;
+}
+
+// Row tables of the fused conv backward (5 x CONV_ROWTAB ints; qnet.hip uploads them behind the forward's at creation), rows m of a
+// group of S samples:  [0] first-convolution output pixel: s << 16 | byte offset of its patch inside the observation;  [1] second-
+// convolution output pixel: float offset of the a1 row under it;  [2] third: float offset of the a2 row;  [3] / [4] dgrad_inplace's
+// tables of the g2 / g1 phases: row of the gradient image at the input pixel's own position | iy << 16 | ix << 24.
+bool fused_conv_bwd_row_tables(const dq_qnet* Q, int* tab) {
+    ConvBwdPlan P;
+    if (!plan_conv_bwd(Q, &P)) return false;
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    memset(tab, 0, sizeof(int) * 5 * CONV_ROWTAB);
+    for (int m = 0; m < P.S * L1.rows; ++m) {
+        const int s = m / L1.rows, p = m % L1.rows, oy = p / L1.ow, ox = p % L1.ow;
+        tab[m] = s << 16 | (oy * L1.s * L1.iw + ox * L1.s);
+        tab[4 * CONV_ROWTAB + m] = (s * L2.rows + oy * L2.ow + ox) | oy << 16 | ox << 24;      // a1 pixel (oy, ox): row of g2 at its own position
+    }
+    for (int m = 0; m < P.S * L2.rows; ++m) {
+        const int s = m / L2.rows, p = m % L2.rows, oy = p / L2.ow, ox = p % L2.ow;
+        tab[CONV_ROWTAB + m] = (s * L1.rows + oy * L1.ow + ox) * A1PS;
+        tab[3 * CONV_ROWTAB + m] = (s * L3.rows + oy * L3.ow + ox) | oy << 16 | ox << 24;       // a2 pixel: row of g3
+    }
+    for (int m = 0; m < P.S * L3.rows; ++m) {
+        const int s = m / L3.rows, p = m % L3.rows, oy = p / L3.ow, ox = p % L3.ow;
+        tab[2 * CONV_ROWTAB + m] = (s * L2.rows + oy * L2.ow + ox) * 36;
+    }
+    return true;
 }
 
 #define CONV_BWD_MAX_WGS 256
@@ -1412,6 +1451,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.partial = conv_partial; ca.pstride = conv_floats;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.a1_alt = cp.a1_alt; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
     ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3; ca.off_ko = cp.off_ko; ca.off_tp = cp.off_tp; ca.kofftab = Q->kofftab;
+    ca.off_d2 = cp.off_d2; ca.off_d1 = cp.off_d1; ca.rowtab = Q->kofftab + 96 + 3 * CONV_ROWTAB;
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
     conv_bwd_kernel_t ck = cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;

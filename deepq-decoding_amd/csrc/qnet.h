@@ -31,7 +31,8 @@ struct dq_qnet {
     int last_index_off, last_index_mod;
     float* xinf[FWD_MAX_JOBS];   // fused inference forwards: last-convolution output per job slot [max_batch, flat]
     int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an NCHW uint8 observation, -1 past K;
-                                 // then [3][CONV_ROWTAB] the fused conv forward's row tables (fused_conv_row_tables)
+                                 // then [3][CONV_ROWTAB] the fused conv forward's row tables (fused_conv_row_tables) and [5][CONV_ROWTAB]
+                                 // the fused conv backward's (fused_conv_bwd_row_tables)
     void* pk_scratch[FWD_MAX_JOBS];  // packed weights of jobs that did not bring their own (dq_qnet_job.packed_dev == NULL)
     const void* last_train_packed;   // packed weights of the last training forward (the backward's data gradients read them)
     float* fpartial;             // fused backward workspace (fused_backward_workspace_floats)
@@ -189,6 +190,7 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);
 bool fused_conv_row_tables(const dq_qnet* Q, int* tab);      // tab: int[3 * CONV_ROWTAB]
+bool fused_conv_bwd_row_tables(const dq_qnet* Q, int* tab);  // tab: int[5 * CONV_ROWTAB] (fused_bwd.hip)
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
