@@ -56,6 +56,14 @@ static inline u64 dq_rate_threshold(double p) {
     u64 f = (u64)t;
     return ((double)f < t) ? f + 1 : f;
 }
+// the same for a 16-bit draw (dropout: eight decisions per Philox call):  H / 2^16 < p  <=>  H < ceil(p * 2^16)
+static inline u32 dq_rate_threshold16(double p) {
+    double t = p * 65536.0;
+    if (!(t > 0.0)) return 0;
+    if (t >= 65536.0) return 65536u;
+    u32 f = (u32)t;
+    return ((double)f < t) ? f + 1 : f;
+}
 
 // ---- device helpers -----------------------------------------------------------------------------
 #ifdef __HIPCC__
@@ -64,8 +72,10 @@ static inline u64 dq_rate_threshold(double p) {
 __device__ __forceinline__ void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32): __umulhi and the low product as two expressions compile to two
+        // quarter-rate multiplies each (the dense forward's dropout spent 11K cycles per wave in them)
+        const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;
+        const u32 hi0 = (u32)(p0 >> 32), lo0 = (u32)p0, hi1 = (u32)(p1 >> 32), lo1 = (u32)p1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
@@ -179,7 +189,9 @@ __device__ __forceinline__ void dq_adam1(float& p, float g, float& m, float& v, 
 #define DQ_TAG_CONV_BWD 4
 #define DQ_TAG_DENSE_WGRAD 5
 #ifdef DQ_STAMPS
+#ifndef DQ_STAMP_BLOCK
 #define DQ_STAMP_BLOCK 9
+#endif
 static __device__ unsigned long long dq_dbg[4096];            // one copy per translation unit (no relocatable device code)
 #define DQ_STAMP_READER(name) extern "C" void name(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dq_dbg), sizeof(dq_dbg)); }
 #define DQ_STAMP(tag, i)                                                                                        \

@@ -37,6 +37,12 @@ DQ_STAMP_READER(dq_dbg_read_fwd)
 #ifndef CONV_APIPE
 #define CONV_APIPE 1
 #endif
+#ifndef DQ_EXP_NODROP
+#define DQ_EXP_NODROP 0
+#endif
+#ifndef DQ_EXP_NOSTORE
+#define DQ_EXP_NOSTORE 0
+#endif
 #ifndef DENSE_XPIPE
 #define DENSE_XPIPE 1
 #endif
@@ -355,10 +361,9 @@ struct DenseJob {
     const float* x;                     // [batch, K1]: NHWC flatten of the last convolution
     int batch;
     float keep_scale;                   // > 0: dropout active on the hidden layer's output
-    u64 drop_T;
+    u32 drop_T;                         // a unit is dropped iff its 16-bit draw < drop_T (dq_rate_threshold16)
     u32 seed0, seed1, sample_base;
     u64 t;
-    float* h1_out;                      // training: [batch, 512] post-dropout; else NULL
     unsigned short* x_pl;               // training: the input rows as f16 piece planes [2][plane_rows][K1] for the dense weight gradients
     unsigned short* h1_pl;              // training: the hidden output as planes [2][plane_rows][512]
     unsigned short* y2_pl;              // training: Dense(|A|)'s output as planes [2][plane_rows][small_ld] (the dueling layer's weight gradient)
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 unsigned short* d = s_pl + r * LDP + c4;
                 *reinterpret_cast<uint2*>(d) = uint2{hb[0], hb[1]};
                 *reinterpret_cast<uint2*>(d + ROWS * LDP) = uint2{lb[0], lb[1]};
-                if (J.x_pl && r < ns) {                             // the same pieces feed the weight gradient of this layer (fused_bwd.hip)
+                if (J.x_pl && r < ns && !DQ_EXP_NOSTORE) {                             // the same pieces feed the weight gradient of this layer (fused_bwd.hip)
                     unsigned short* gp = J.x_pl + (size_t)(b0 + r) * K1 + c4;
                     *reinterpret_cast<uint2*>(gp) = uint2{hb[0], hb[1]};
                     *reinterpret_cast<uint2*>(gp + (size_t)J.plane_rows * K1) = uint2{lb[0], lb[1]};
@@ -558,32 +563,38 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             const int u = pass * UP + uu, row = 16 * u + j;         // this lane's sample
             F16x2 hb[2];                                            // the sample's units 8kq .. 8kq+7 of this wave's two blocks, as pieces
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b) {
+                // one Philox call = the lane's eight consecutive units 64 wave + 32 b + 8 kq .. + 7 of its sample: 16 bits per decision
+                // (unit n draws half-word n & 7 of the call (n >> 3), low half of a word first)
+                u32 wd[4] = {0u, 0u, 0u, 0u};
+                if (J.keep_scale > 0.f && !DQ_EXP_NODROP)
+                    philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + row),
+                                  ((u32)(64 * wave + 32 * b + 8 * kq) >> 3) | ((u32)DQ_STREAM_DROPOUT << 16), J.seed0, J.seed1, wd);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int ct = 2 * b + s, unit0 = 64 * wave + 32 * b + 8 * kq + 4 * s;
                     f32x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(f16x2_sum(acc[u][ct][0][r], acc[u][ct][1][r]) + bias1[ct][r], 0.f);
-                    if (J.keep_scale > 0.f) {                       // (one Philox call = four consecutive units of a sample)
-                        u32 wd[4];
-                        philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + row), ((u32)unit0 >> 2) | ((u32)DQ_STREAM_DROPOUT << 16),
-                                      J.seed0, J.seed1, wd);
+                    if (J.keep_scale > 0.f) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = ((u64)wd[r] < J.drop_T) ? 0.f : v[r] * J.keep_scale;
+                        for (int r = 0; r < 4; ++r) v[r] = (((wd[2 * s + (r >> 1)] >> (16 * (r & 1))) & 0xffffu) < J.drop_T) ? 0.f : v[r] * J.keep_scale;
                     }
                     u32 hp[2], lp[2];
                     split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                     split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
                     hb[b].h[2 * s] = hp[0]; hb[b].h[2 * s + 1] = hp[1];
                     hb[b].l[2 * s] = lp[0]; hb[b].l[2 * s + 1] = lp[1];
-                    if (J.h1_out && row < ns) {                     // training: kept for the backward (mask) and, as pieces, for the weight gradients
-                        *reinterpret_cast<f32x4*>(J.h1_out + (size_t)(b0 + row) * DENSE_HID + unit0) = v;
-                        unsigned short* gp = J.h1_pl + (size_t)(b0 + row) * DENSE_HID + unit0;
-                        *reinterpret_cast<uint2*>(gp) = uint2{hp[0], hp[1]};
-                        *reinterpret_cast<uint2*>(gp + (size_t)J.plane_rows * DENSE_HID) = uint2{lp[0], lp[1]};
-                    }
                 }
+                // training: the hidden output is kept as its piece planes ONLY (the weight gradients' operand; the backward takes its ReLU /
+                // dropout mask from them too: an f32 copy beside them made the 64 training workgroups' stores the dense forward's critical
+                // path, +7 us) -- one 16-byte store per piece for the lane's eight units
+                if (J.h1_pl && row < ns && !DQ_EXP_NOSTORE) {
+                    unsigned short* gp = J.h1_pl + (size_t)(b0 + row) * DENSE_HID + 64 * wave + 32 * b + 8 * kq;
+                    *reinterpret_cast<u32x4*>(gp) = hb[b].h;
+                    *reinterpret_cast<u32x4*>(gp + (size_t)J.plane_rows * DENSE_HID) = hb[b].l;
+                }
+            }
             f32x4 acc2[NT2][2];
 #pragma unroll
             for (int t = 0; t < NT2; ++t) { acc2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t][1] = acc2[t][0]; }
@@ -1031,15 +1042,15 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         D.params = jb.params_dev; D.packed = static_cast<const u32x4*>(packed); D.x = x; D.batch = jb.batch; D.wg0 = dense_wgs;
         if (training && D1.dropout > 0.f) {
             D.keep_scale = (float)(1.0 / (1.0 - (double)D1.dropout));
-            D.drop_T = dq_rate_threshold((double)D1.dropout);
+            D.drop_T = dq_rate_threshold16((double)D1.dropout);
         }
         D.seed0 = jb.seed[0]; D.seed1 = jb.seed[1]; D.sample_base = jb.sample_base; D.t = jb.t;
         if (training) {
-            D.h1_out = Q->act[0][nc]; D.y2_out = Q->act[0][nc + 1];
+            D.y2_out = Q->act[0][nc + 1];
             D.plane_rows = Q->cfg.max_batch; D.small_ld = dq_planes_small_ld(Q);
             D.x_pl = dq_plane(Q, 0); D.h1_pl = dq_plane(Q, 1); D.y2_pl = dq_plane(Q, 5);
             D.y3_out = Q->cfg.dueling ? Q->act[0][nc + 2] : nullptr;
-            Q->last_train_batch = jb.batch; Q->last_obs = jb.obs_dev; Q->last_index = jb.index_dev;
+            Q->last_train_batch = jb.batch; Q->last_train_fused = 1; Q->last_obs = jb.obs_dev; Q->last_index = jb.index_dev;
             Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod; Q->last_train_packed = packed;
         }
         D.q_out = jb.q_dev;

@@ -31,7 +31,7 @@ struct DenseBwdArgs {
     const u32x4* packed;                // f16 pieces of the training forward's weights (qnet.h)
     int pk_dense2t, pk_dense1t, KB2;    // u32x4 offsets of the transposed dense sections; K = 32 blocks of gH1's reduction (N2 padded)
     const float* dq;                    // [batch, n_actions]
-    const float* h1;                    // saved hidden output (post ReLU + dropout): mask of gH1
+    const unsigned short* h1_pl;        // saved hidden output (post ReLU + dropout) as f16 piece planes [2][plane_rows][512]: mask of gH1
     const float* x;                     // saved last-convolution output [batch, K1] (NHWC): mask of gX
     int batch, K1, perm_hw, perm_c;
     int N2, N3, n_actions;
@@ -147,9 +147,20 @@ __device__ __forceinline__ void gh1_phase(const DenseBwdArgs& a, const unsigned 
     F16x2 bw[2][4];                                                 // two blocks in flight (the loop below is fully unrolled: static indices)
 #pragma unroll
     for (int t = 0; t < 4; ++t) { bw[0][t].h = pk[t * PK_BLOCK]; bw[0][t].l = pk[t * PK_BLOCK + PK_LO]; }
-    f32x4 hv[4];
+    // the mask operand: the saved hidden output's pieces (h > 0 or, for values below f16's range, l > 0  <=>  the f32 value was > 0)
+    // (rows past the batch are read unclamped -- two base addresses + immediate offsets; eight clamped addresses cost 16 registers and
+    // with them the fourth wave per SIMD, i.e. the co-residence of the riding environment workgroups -- and ignored: they lie inside the
+    // plane buffer, whose sets follow each other, qnet.h)
+    uint2 hvh[4], hvl[4];
+    {
+        const unsigned short* hp = a.h1_pl + (size_t)(b0 + 4 * kq) * DENSE_HID + c0;
+        const unsigned short* lp = hp + (size_t)a.plane_rows * DENSE_HID;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hv[r] = *reinterpret_cast<const f32x4*>(a.h1 + (size_t)(b0 + min(4 * kq + r, ns - 1)) * DENSE_HID + c0);
+        for (int r = 0; r < 4; ++r) {
+            hvh[r] = *reinterpret_cast<const uint2*>(hp + r * DENSE_HID);
+            hvl[r] = *reinterpret_cast<const uint2*>(lp + r * DENSE_HID);
+        }
+    }
     f32x4 acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
@@ -171,7 +182,11 @@ __device__ __forceinline__ void gh1_phase(const DenseBwdArgs& a, const unsigned 
         const int row = 4 * kq + r;
         f32x4 v;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = (hv[r][t] > 0.f && row < ns) ? f16x2_sum(acc[t][0][r], acc[t][1][r]) * a.mask_scale : 0.f;
+        for (int t = 0; t < 4; ++t) {
+            const u32 hw = t < 2 ? hvh[r].x : hvh[r].y, lw = t < 2 ? hvl[r].x : hvl[r].y;
+            const u32 pos = ((hw | lw) >> (16 * (t & 1))) & 0x7fffu;               // (pieces of a value >= 0: any magnitude bit set)
+            v[t] = (pos != 0u && row < ns) ? f16x2_sum(acc[t][0][r], acc[t][1][r]) * a.mask_scale : 0.f;
+        }
         u32 hp[2], lp[2];
         split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
         split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -1362,7 +1377,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     da.packed = pkbase; da.pk_dense2t = (int)PL.dense2t; da.pk_dense1t = (int)PL.dense1t; da.KB2 = PL.KB2;
     da.plane_rows = Q->cfg.max_batch; da.small_ld = dq_planes_small_ld(Q);
     da.gh1_pl = dq_plane(Q, 2); da.gy2_pl = dq_plane(Q, 3); da.g3_pl = dq_plane(Q, 4);
-    da.params = params_dev; da.dq = dq_dev; da.h1 = Q->act[0][nc]; da.x = Q->act[0][nc - 1];
+    da.params = params_dev; da.dq = dq_dev; da.h1_pl = dq_plane(Q, 1); da.x = Q->act[0][nc - 1];
     da.batch = B; da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < nl - nc; ++l) da.w_off[l] = (int)Q->L[nc + l].w_off;

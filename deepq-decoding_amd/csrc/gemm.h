@@ -46,7 +46,7 @@ struct Epilogue {
     const float* mask_src;            // EPI_MASK: multiply by (mask_src[same offset] > 0) * mask_scale
     float mask_scale;
     float keep_scale;                 // EPI_DROPOUT: y = keep ? y * keep_scale : 0  (keep_scale = 1/(1-rate))
-    u64 drop_T;                       //   dropped iff word < drop_T
+    u32 drop_T;                       //   dropped iff the unit's 16-bit draw < drop_T (dq_rate_threshold16)
     u32 seed0, seed1;                 //   word = Philox(key=seed, ctr=(t_lo, t_hi, sample_base + m, (n>>2) | DROPOUT<<16))[n&3]
     u64 t;
     u32 sample_base;
@@ -133,9 +133,11 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, 
     if (e.flags & EPI_RELU) v = fmaxf(v, 0.f);
     if (e.flags & EPI_DROPOUT) {
         u32 w[4];
-        philox4x32_10((u32)e.t, (u32)(e.t >> 32), e.sample_base + (u32)m, ((u32)n >> 2) | ((u32)DQ_STREAM_DROPOUT << 16), e.seed0, e.seed1, w);
-        const u32 word = (n & 3) == 0 ? w[0] : (n & 3) == 1 ? w[1] : (n & 3) == 2 ? w[2] : w[3];
-        v = ((u64)word < e.drop_T) ? 0.f : v * e.keep_scale;
+        // one Philox call = eight consecutive units of a sample: unit n draws half-word n & 7 (word (n & 7) >> 1, low half first)
+        philox4x32_10((u32)e.t, (u32)(e.t >> 32), e.sample_base + (u32)m, ((u32)n >> 3) | ((u32)DQ_STREAM_DROPOUT << 16), e.seed0, e.seed1, w);
+        const int wi = (n & 7) >> 1;
+        const u32 word = wi == 0 ? w[0] : wi == 1 ? w[1] : wi == 2 ? w[2] : w[3];
+        v = (((word >> (16 * (n & 1))) & 0xffffu) < e.drop_T) ? 0.f : v * e.keep_scale;
     }
     if (e.flags & EPI_MASK) v = e.mask_src[off] > 0.f ? v * e.mask_scale : 0.f;
     e.out[off] = v;

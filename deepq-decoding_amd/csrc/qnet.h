@@ -26,6 +26,8 @@ struct dq_qnet {
     float* partial;              // wgrad slices
     size_t partial_floats;
     int last_train_batch;
+    int last_train_fused;        // the last training forward ran on the fused chains (1) / per-layer kernels (0): the backward must take the same path --
+                                 // each forward saves what ITS backward reads (the fused one keeps the hidden layer as piece planes only)
     const uint8_t* last_obs;     // inputs of the last training forward (needed by conv1's weight gradient)
     const int32_t* last_index;
     int last_index_off, last_index_mod;

@@ -418,7 +418,8 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->xinf[i], xf * sizeof(float));
     }
     if (e == hipSuccess && fused_forward_supported(Q)) {            // piece planes x | h1 | gh1 (qnet.h)
-        e = hipMalloc(&Q->planes, dq_planes_halves(Q) * sizeof(unsigned short));
+        // (+ 16 rows of slack: the dense backward reads the hidden planes' rows of a ragged last tile unclamped, fused_bwd.hip gh1_phase)
+        e = hipMalloc(&Q->planes, (dq_planes_halves(Q) + 16 * DENSE_HID) * sizeof(unsigned short));
     }
     const size_t fws = fused_backward_workspace_floats(Q);
     if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));
@@ -481,7 +482,8 @@ dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* ob
     hipStream_t st = (hipStream_t)stream;
     const int set = training ? 0 : 1;
     const float* x = nullptr;
-    if (Q->use_fused && fused_forward_supported(Q)) {
+    // (a training forward takes the fused chains only when its backward can too: each path saves what its own backward reads)
+    if (Q->use_fused && fused_forward_supported(Q) && (!training || fused_backward_supported(Q))) {
         dq_qnet_job jb;
         memset(&jb, 0, sizeof(jb));
         jb.params_dev = params_dev; jb.obs_dev = obs_dev; jb.index_dev = index_dev; jb.index_off = index_off; jb.index_mod = index_mod;
@@ -520,7 +522,7 @@ dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* ob
         if (training && L.dropout > 0.f) {
             ep.flags |= EPI_DROPOUT;
             ep.keep_scale = (float)(1.0 / (1.0 - (double)L.dropout));
-            ep.drop_T = dq_rate_threshold((double)L.dropout);
+            ep.drop_T = dq_rate_threshold16((double)L.dropout);
             ep.seed0 = seed[0]; ep.seed1 = seed[1]; ep.t = t; ep.sample_base = sample_base;
         }
         launch_fwd(ga, gb, ep, M, L.N, L.K, st);
@@ -534,7 +536,7 @@ dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* ob
         DQ_HIP(hipMemcpyAsync(q_dev, x, (size_t)batch * Q->cfg.n_actions * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     if (training) {
-        Q->last_train_batch = batch; Q->last_obs = obs_dev; Q->last_index = index_dev;
+        Q->last_train_batch = batch; Q->last_train_fused = 0; Q->last_obs = obs_dev; Q->last_index = index_dev;
         Q->last_index_off = index_off; Q->last_index_mod = index_mod;
     }
     return DQ_OK;
@@ -548,7 +550,10 @@ dq_status dq_qnet_pack(const dq_qnet* Q, const float* params_dev, void* packed_d
 
 dq_status dq_qnet_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, void* stream) {
     DQ_REQUIRE(Q && jobs && n_jobs >= 1, DQ_ERR_INVALID, "dq_qnet_forward_multi: null argument");
-    if (Q->use_fused && fused_forward_supported(Q) && n_jobs <= FWD_MAX_JOBS) return fused_forward_multi(Q, n_jobs, jobs, (hipStream_t)stream);
+    int any_train = 0;
+    for (int i = 0; i < n_jobs && jobs; ++i) any_train |= jobs[i].training ? 1 : 0;
+    if (Q->use_fused && fused_forward_supported(Q) && n_jobs <= FWD_MAX_JOBS && (!any_train || fused_backward_supported(Q)))
+        return fused_forward_multi(Q, n_jobs, jobs, (hipStream_t)stream);
     int n_train = 0;
     for (int i = 0; i < n_jobs; ++i) n_train += jobs[i].training ? 1 : 0;
     DQ_REQUIRE(n_train <= 1, DQ_ERR_INVALID, "dq_qnet_forward_multi: at most one training job per launch");
@@ -561,11 +566,19 @@ dq_status dq_qnet_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs,
     return DQ_OK;
 }
 
+// The backward runs on the path its training forward ran on (dq_qnet_set_fused between the two is refused: each forward saves what its
+// own backward reads).
+#define DQ_SAME_PATH(Q, fused_now)                                                                                          \
+    DQ_REQUIRE((Q)->last_train_fused == ((fused_now) ? 1 : 0), DQ_ERR_STATE,                                               \
+               "dq_qnet backward: the training forward ran on the %s path, the backward was asked for the other one (dq_qnet_set_fused between them)", \
+               (Q)->last_train_fused ? "fused" : "per-layer")
+
 // phases: bit 0 = dense layers (+ dueling), bit 1 = convolutions; 3 = everything
 static dq_status backward_phases(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st) {
     DQ_REQUIRE(Q && params_dev && grads_dev && ((phases & 1) == 0 || dq_dev), DQ_ERR_INVALID, "dq_qnet_backward: null argument");
     DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_backward: no training forward to differentiate");
     const int B = Q->last_train_batch, nl = Q->n_layers, nc = Q->cfg.n_conv;
+    DQ_SAME_PATH(Q, Q->use_fused && fused_backward_supported(Q));
     if (Q->use_fused && fused_backward_supported(Q)) return fused_backward(Q, params_dev, dq_dev, grads_dev, phases, st);
     if (phases & 1) {
         // gradient w.r.t. the last layer's (linear) output
@@ -647,6 +660,7 @@ static dq_status backward_adam(dq_qnet* Q, float* params_dev, const float* dq_de
         dq_status rc = check_td_job(Q, tdj);
         if (rc != DQ_OK) return rc;
     }
+    DQ_SAME_PATH(Q, Q->use_fused && fused_backward_supported(Q));
     if (Q->use_fused && fused_backward_supported(Q)) {
         AdamOpt opt;
         opt.p = params_dev; opt.m = m_dev; opt.v = v_dev;
@@ -688,6 +702,7 @@ static dq_status td_backward_phase0(dq_qnet* Q, const float* params_dev, const d
     DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_td_backward_phase0: no training forward to differentiate");
     dq_status rc = check_td_job(Q, tdj);
     if (rc != DQ_OK) return rc;
+    DQ_SAME_PATH(Q, Q->use_fused && fused_backward_supported(Q));
     if (Q->use_fused && fused_backward_supported(Q)) {
         const TdFused td = td_fused_from(tdj);
         return fused_backward(Q, params_dev, nullptr, grads_dev, 1, (hipStream_t)stream, nullptr, &td, rider, rider_lds);

@@ -292,8 +292,10 @@ int dq_qnet_fused_supported(const dq_qnet* net);
  *              allocation that starts 16-byte aligned and whose allocated size is a multiple of 16 (any hipMalloc / torch
  *              allocation: both round sizes up to at least 256 bytes; views at arbitrary byte offsets inside it are fine);
  *   q_dev      float [batch, n_actions];
- *   dropout    keep(b, j) <=> Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b, (j>>2) | DQ_STREAM_DROPOUT<<16))[j&3]
- *              >= ceil(rate * 2^32);  kept units are scaled by 1/(1-rate) (Keras K.dropout). */
+ *   dropout    one Philox call covers eight consecutive units of a sample, 16 bits per decision:
+ *              keep(b, j) <=> half-word (j & 7) of Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b, (j>>3) | DQ_STREAM_DROPOUT<<16))
+ *              >= ceil(rate * 2^16)   (half-word h = bits 16 (h & 1) .. + 15 of word h >> 1);  kept units are scaled by
+ *              1/(1-rate) (Keras K.dropout). */
 dq_status dq_qnet_forward(dq_qnet* net, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev,
                           int index_off, int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t,
                           uint32_t sample_base, float* q_dev, void* stream);

@@ -99,15 +99,18 @@ def glorot_init(spec, seed, stream=philox.STREAM_INIT):
 
 
 def dropout_keep_mask(seed, t, sample_ids, n_units, rate):
-    """keep[b, j] for update counter t: word = Philox(key=seed, ctr=(t_lo, t_hi, sample_id, (j>>2) | DROPOUT<<16))[j&3];
-    dropped iff word < ceil(rate * 2^32)."""
+    """keep[b, j] for update counter t.  One Philox call covers eight consecutive units, 16 bits per decision: unit j draws half-word
+    j & 7 (bits 16 (h & 1) .. + 15 of word h >> 1) of Philox(key=seed, ctr=(t_lo, t_hi, sample_id, (j>>3) | DROPOUT<<16)); dropped iff
+    the draw < ceil(rate * 2^16)."""
     sample_ids = np.asarray(sample_ids, dtype=np.uint32)
     j = np.arange(n_units, dtype=np.uint32)
     words = philox.philox4x32_np(int(t) & philox.MASK, (int(t) >> 32) & philox.MASK, sample_ids[:, None],
-                                 (j[None, :] >> 2) | (philox.STREAM_DROPOUT << 16), seed)
+                                 (j[None, :] >> 3) | (philox.STREAM_DROPOUT << 16), seed)
     w = np.stack(words, axis=-1)
-    sel = np.take_along_axis(w, np.broadcast_to((j & 3)[None, :, None].astype(np.int64), w.shape[:2] + (1,)), axis=-1)[..., 0]
-    return sel.astype(np.uint64) >= np.uint64(philox.threshold(rate))
+    h = (j & 7).astype(np.int64)
+    sel = np.take_along_axis(w, np.broadcast_to((h >> 1)[None, :, None], w.shape[:2] + (1,)), axis=-1)[..., 0]
+    draw = (sel.astype(np.uint64) >> (16 * (h & 1)).astype(np.uint64)[None, :]) & np.uint64(0xffff)
+    return draw >= np.uint64(philox.threshold16(rate))
 
 
 def _im2col(x, k, s):

@@ -78,6 +78,13 @@ def threshold(p):
     return max(0, min(t, 1 << 32))
 
 
+def threshold16(p):
+    """Integer T such that (H / 2**16 < p) <=> (H < T) for every 16-bit draw H (dropout: csrc/common.h dq_rate_threshold16)."""
+    import math
+    t = math.ceil(float(p) * 65536.0)
+    return max(0, min(t, 1 << 16))
+
+
 def pauli_type(word):
     """Map a uint32 to {1,2,3} (X,Y,Z); stands in for np.random.randint(1,4) (Function_Library.py:100)."""
     return 1 + ((int(word) * 3) >> 32)
