@@ -54,6 +54,8 @@ DQ_STAMP_READER(dq_dbg_read_fwd)
 struct ConvChainArgs {
     ConvJob job[FWD_MAX_JOBS];
     int n_jobs, S;
+    int wg_first[FWD_MAX_JOBS];        // first workgroup of job 1, 2, 3 (INT_MAX for jobs that do not exist; [0] unused): the job of a workgroup by
+                                       // three comparisons on one scalar load instead of a loop of dependent ones
     int C, H, W, k1, st1, K1;          // first convolution: input planes, kernel, stride, K = k1*k1*C
     int oh1, ow1, oh2, ow2, oh3, ow3;
     int w_off[3], b_off[3];            // floats into params
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     unsigned short* s_a1 = reinterpret_cast<unsigned short*>(smem + a.off_a1);      // f16 piece planes [2][S*r1][72]
     unsigned short* s_a2 = reinterpret_cast<unsigned short*>(smem + a.off_a2);      // [2][S*r2][40]; overlays the observations (dead after conv1)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
-    int jb = 0;
-    while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
+    static_assert(FWD_MAX_JOBS == 4, "three comparisons");
+    const int jb = ((int)blockIdx.x >= a.wg_first[1]) + ((int)blockIdx.x >= a.wg_first[2]) + ((int)blockIdx.x >= a.wg_first[3]);      // block-uniform
     const ConvJob& J = a.job[jb];
     const int grp = (int)blockIdx.x - J.wg0;
     const int b0 = grp * a.S;
@@ -377,6 +379,7 @@ struct DenseJob {
 struct DenseChainArgs {
     DenseJob job[FWD_MAX_JOBS];
     int n_jobs;
+    int wg_first[FWD_MAX_JOBS];         // as in ConvChainArgs
     int K1, perm_hw, perm_c;            // Keras Flatten: k = c*hw + p reads x[p*perm_c + c]
     int pk_dense1;                      // u32x4 offset of the hidden layer's packed blocks [K1/32][32 column tiles]
     int pk_dense2;                      // ... of Dense(|A|)'s [16][NT2]
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     constexpr int PWP = PW + 4;                                     // row stride of the partials: the 8 lanes of a ds_write_b128 lane group are 8 ROWS -- unpadded (a
                                                                     // multiple of 32 banks) every store was an 8-way conflict, 13K cycles of this kernel's LDS time
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
-    int jb = 0;
-    while (jb + 1 < a.n_jobs && (int)blockIdx.x >= a.job[jb + 1].wg0) ++jb;      // block-uniform
+    static_assert(FWD_MAX_JOBS == 4, "three comparisons");
+    const int jb = ((int)blockIdx.x >= a.wg_first[1]) + ((int)blockIdx.x >= a.wg_first[2]) + ((int)blockIdx.x >= a.wg_first[3]);      // block-uniform
     const DenseJob& J = a.job[jb];
     const int b0 = ((int)blockIdx.x - J.wg0) * ROWS;
     const int ns = min(ROWS, J.batch - b0);
@@ -1035,7 +1038,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         }
         C.params = jb.params_dev; C.packed = static_cast<const u32x4*>(packed); C.obs = jb.obs_dev; C.index = jb.index_dev; C.index_off = jb.index_off;
         C.index_mod = jb.index_mod > 0 ? jb.index_mod : 0x7fffffff;
-        C.batch = jb.batch; C.write_all = training; C.wg0 = conv_wgs;
+        C.batch = jb.batch; C.write_all = training; C.wg0 = conv_wgs; ca.wg_first[i] = conv_wgs; da.wg_first[i] = dense_wgs;
         C.act_out[0] = Q->act[0][0]; C.act_out[1] = Q->act[0][1]; C.act_out[2] = x;
         conv_wgs += (jb.batch + cp.S - 1) / cp.S;
         DenseJob& D = da.job[i];
@@ -1056,6 +1059,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         D.q_out = jb.q_dev;
         dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
     }
+    for (int i = n_jobs; i < FWD_MAX_JOBS; ++i) ca.wg_first[i] = da.wg_first[i] = 0x7fffffff;
     dq_prof_begin(DQ_K_CONV_CHAIN, st);
     ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
     dq_prof_end(DQ_K_CONV_CHAIN, st);
