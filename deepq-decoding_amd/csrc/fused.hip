@@ -100,7 +100,8 @@ template <int CIN, int COUT, int KS, int RR, int NTT>
 __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__ in, int lo_in, int ih, int iw, int oh, int ow, int M,
                                               F16x2 (&ring)[RR][NTT], const u32x4* __restrict__ pk, const float* __restrict__ bias,
                                               unsigned short* __restrict__ out_lds, int lo_out, float* __restrict__ out_g, int wave, int lane,
-                                              const int* __restrict__ rowtab, int pre0, int pre1) {
+                                              const int* __restrict__ rowtab, int pre0, int pre1, unsigned short* __restrict__ out_pl = nullptr,
+                                              size_t lo_pl = 0) {
     using SH = ConvShape<CIN, COUT, KS>;
     constexpr int NT = SH::NT, PSI = CIN + 8, PSO = COUT + 8, CB = SH::CB, NB = SH::NB, R = SH::R;
     static_assert(NT == 2 && CIN % 32 == 0 && RR == R && NTT == NT, "written for 32 output channels, CIN a multiple of 32");
@@ -171,6 +172,10 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
                     split_f16x2_pair(v[0], v[1], h, l);
                     *reinterpret_cast<u32*>(out_lds + mo * PSO + 2 * j) = h;
                     *reinterpret_cast<u32*>(out_lds + mo * PSO + 2 * j + lo_out) = l;
+                    if (out_pl) {                                   // the same pieces to global memory, rows of COUT halves (training: the backward's operand)
+                        *reinterpret_cast<u32*>(out_pl + (size_t)mo * COUT + 2 * j) = h;
+                        *reinterpret_cast<u32*>(out_pl + (size_t)mo * COUT + 2 * j + lo_pl) = l;
+                    }
                 }
                 if (out_g) *reinterpret_cast<f32x2*>(out_g + (size_t)mo * COUT + 2 * j) = v;
             }
@@ -340,7 +345,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     {
         const int r2 = a.oh2 * a.ow2;
         conv_from_lds<64, 32, 2>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
-                                 J.write_all ? J.act_out[1] + (size_t)b0 * r2 * 32 : nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1]);
+                                 nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1],
+                                 J.write_all ? J.a2_pl + (size_t)b0 * r2 * 32 : nullptr, J.a2_lo);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 5);
     conv_w_prefetch(ring, J.packed + PK_CONV3_FWD, lane);
@@ -1039,7 +1045,8 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         C.params = jb.params_dev; C.packed = static_cast<const u32x4*>(packed); C.obs = jb.obs_dev; C.index = jb.index_dev; C.index_off = jb.index_off;
         C.index_mod = jb.index_mod > 0 ? jb.index_mod : 0x7fffffff;
         C.batch = jb.batch; C.write_all = training; C.wg0 = conv_wgs; ca.wg_first[i] = conv_wgs; da.wg_first[i] = dense_wgs;
-        C.act_out[0] = Q->act[0][0]; C.act_out[1] = Q->act[0][1]; C.act_out[2] = x;
+        C.act_out[0] = Q->act[0][0]; C.act_out[1] = nullptr; C.act_out[2] = x;
+        C.a2_pl = reinterpret_cast<unsigned short*>(Q->act[0][1]); C.a2_lo = (size_t)Q->cfg.max_batch * L2.rows * 32;
         conv_wgs += (jb.batch + cp.S - 1) / cp.S;
         DenseJob& D = da.job[i];
         D.params = jb.params_dev; D.packed = static_cast<const u32x4*>(packed); D.x = x; D.batch = jb.batch; D.wg0 = dense_wgs;

@@ -734,7 +734,8 @@ struct ConvBwdArgs {
     const int32_t* index;
     int index_off, index_mod;
     const float* a1;                    // saved activations of the training forward (global NHWC)
-    const float* a2;
+    const unsigned short* a2p;          // saved second-convolution output [batch*r2][32] as f16 piece planes (h plane; the l plane a2_lo halves further)
+    size_t a2_lo;
     const float* g3;                    // [batch*r3, 32] gradient w.r.t. conv3's pre-activation output
     const u32x4* packed;                // f16 pieces of the conv kernels (qnet.h PK_*), those of the training forward
     int batch, S, groups;
@@ -789,14 +790,39 @@ __device__ __forceinline__ void dgrad_load_w(F16x2 (&bw)[4][2], const u32x4* __r
         }
 }
 
+// Row stride (halves) of an LDS piece-plane image of 32 channels: 64 data bytes + 16 of padding, filled by LDS-DMA in 16-byte slots
+#define PL32 40
+
+// Transposing LDS read (ds_read_b64_tr_b16, tools/probe/tr_probe.hip): within a 16-lane group, lanes 4r .. 4r+3 each point at a 4-half
+// segment of row r (r = 0 .. 3, any addresses); lane i receives column i of those four rows.  Two of them are the eight reduction
+// indices of a 16 x 16 x 32 MFMA operand held ROW-major in LDS -- what the weight gradients (a reduction over pixels) need.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr4(const unsigned short* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+// rows p0 (reduction indices 0 .. 3 of this lane group) and p1 (4 .. 7), both pieces (l plane `lo` halves further)
+__device__ __forceinline__ F16x2 lds_tr8(const unsigned short* p0, const unsigned short* p1, int lo) {
+    const uint2 a = lds_tr4(p0), b = lds_tr4(p1), c = lds_tr4(p0 + lo), d = lds_tr4(p1 + lo);
+    F16x2 o;
+    o.h = u32x4{a.x, a.y, b.x, b.y};
+    o.l = u32x4{c.x, c.y, d.x, d.y};
+    return o;
+}
+
 // Data gradient of a 2x2 stride-1 convolution with 32 output channels, masked by the input activation, in place:
 //   act[(s,iy,ix), c] <- (sum_{ky,kx,n} g[(s,iy-ky,ix-kx), n] W[ky,kx,c,n]) * [act > 0]     for c in [c_lo, c_lo + 32)
-// g image [rows][36] with an all-zero row at index `zero_row`; act image [pixels][PSA].  One tap = one K = 32 block of the f16 MFMA:
-// A = the 32 channels of g at the tap's pixel (two ds_read_b128 per lane, split on the fly), B = the tap's weights (registers).
+// One tap = one K = 32 block of the f16 MFMA: A = the 32 channels of g at the tap's pixel, B = the tap's weights (registers).
+//   GPL: g is a piece-plane image [rows][PL32] (l plane g_lo halves further): A = one ds_read_b128 per piece; else an f32 image
+//        [rows][36], split on the fly.  Both have an all-zero row at index `zero_row`.
+//   OPL: act is a piece-plane image [pixels][PL32] (l plane act_lo halves further; c_lo = 0): the mask is "a magnitude bit in either
+//        piece", the result is split on write -- same address as the activation it replaces, so in place; else f32 [pixels][PSA].
 // dtab[m] (LDS, host-built): row of g under input pixel m's own position, s * oh * ow + iy * ow + ix, | iy << 16 | ix << 24.
-template <int PSA>
-__device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const float* __restrict__ g, int zero_row, float* __restrict__ act,
-                                              int c_lo, const int* __restrict__ dtab, int oh, int ow, int M, int tile_first, int tile_step, int lane) {
+// colsum (OPL only): this lane's running column sums of the result (columns j, 16 + j) -- the bias gradient of the layer below.
+template <int PSA, bool GPL, bool OPL>
+__device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const void* __restrict__ gv, int g_lo, int zero_row, void* __restrict__ actv,
+                                              int act_lo, int c_lo, const int* __restrict__ dtab, int oh, int ow, int M, int tile_first,
+                                              int tile_step, int lane, float (&colsum)[2]) {
     const int j = lane & 15, kb = lane >> 4;
     const int tiles = (M + 15) >> 4;
     for (int tile = tile_first; tile < tiles; tile += tile_step) {
@@ -805,30 +831,53 @@ __device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const flo
         f32x4 acc[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+        F16x2 av[4];
         f32x4 ga[4][2];
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) {                         // all LDS reads first
             const int oy = iy - (tap >> 1), ox = ix - (tap & 1);
             const bool valid = (unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow;
-            const float* gp = g + (valid ? gbase - (tap >> 1) * ow - (tap & 1) : zero_row) * 36 + 8 * kb;
-            ga[tap][0] = *reinterpret_cast<const f32x4*>(gp);
-            ga[tap][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+            const int grow = valid ? gbase - (tap >> 1) * ow - (tap & 1) : zero_row;
+            if constexpr (GPL) {
+                const unsigned short* gp = static_cast<const unsigned short*>(gv) + grow * PL32 + 8 * kb;
+                av[tap].h = *reinterpret_cast<const u32x4*>(gp);
+                av[tap].l = *reinterpret_cast<const u32x4*>(gp + g_lo);
+            } else {
+                const float* gp = static_cast<const float*>(gv) + grow * 36 + 8 * kb;
+                ga[tap][0] = *reinterpret_cast<const f32x4*>(gp);
+                ga[tap][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+            }
         }
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) {
-            const F16x2 av = split_f16x2(ga[tap][0], ga[tap][1]);
+            if constexpr (!GPL) av[tap] = split_f16x2(ga[tap][0], ga[tap][1]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) mma_f16x3(av, bw[tap][t], acc[t][0], acc[t][1]);
+            for (int t = 0; t < 2; ++t) mma_f16x3(av[tap], bw[tap][t], acc[t][0], acc[t][1]);
         }
         // C/D layout: col = lane & 15 -> channel c_lo + 16t + j, row = (lane >> 4) * 4 + reg
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mo = tile * 16 + 4 * kb + r;
             if (mo >= M) continue;
+            if constexpr (OPL) {
+                unsigned short* ph = static_cast<unsigned short*>(actv) + mo * PL32 + j;
+                float v[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float* p = act + mo * PSA + c_lo + 16 * t + j;
-                *p = *p > 0.f ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
+                for (int t = 0; t < 2; ++t) {
+                    const u32 bits = (u32)ph[16 * t] | (u32)ph[16 * t + act_lo];
+                    v[t] = (bits & 0x7fffu) != 0u ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
+                    colsum[t] += v[t];
+                }
+                u32 h, l;
+                split_f16x2_pair(v[0], v[1], h, l);
+                ph[0] = (unsigned short)h; ph[16] = (unsigned short)(h >> 16);
+                ph[act_lo] = (unsigned short)l; ph[16 + act_lo] = (unsigned short)(l >> 16);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float* p = static_cast<float*>(actv) + mo * PSA + c_lo + 16 * t + j;
+                    *p = *p > 0.f ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
+                }
             }
         }
     }
@@ -841,7 +890,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8* s_in = smem;
     int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);
-    float* s_a2 = reinterpret_cast<float*>(smem + a.off_a2);
+    unsigned short* s_a2 = reinterpret_cast<unsigned short*>(smem + a.off_a2);      // a2, then g2 in place: piece planes [2][S*r2 + 1][PL32]
     float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
     u8* s_col = smem + a.off_t1;                                     // observation patch image [S*r1][16*KG1] bytes
     int* s_ko = reinterpret_cast<int*>(smem + a.off_ko);
@@ -854,6 +903,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     const int S = a.S, r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
     const int in_bytes = a.C * a.H * a.W;
     const int zero2 = S * r2, zero3 = S * r3;                        // all-zero rows of the g2 (= a2) and g3 images
+    const int LA2 = (S * r2 + 1) * PL32;                             // halves from a2's h plane to its l plane
     constexpr int NW1 = (4 * KG1 + CB_WAVES - 1) / CB_WAVES;        // dW1 tiles (KG1 x 4) per wave
     constexpr int KP = 16 * KG1;                                    // bytes per row of the observation patch image
 
@@ -869,16 +919,17 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         if (m < S * r3) t3[m] = e3;                                 // t3: float offset of the a2 row
     }
     if (tid < 96) s_ko[tid] = a.kofftab[tid];
-    if (tid < 36) { s_a2[zero2 * 36 + tid] = 0.f; s_g3[zero3 * 36 + tid] = 0.f; }
+    if (tid < 36) s_g3[zero3 * 36 + tid] = 0.f;
+    if (tid < PL32) { s_a2[zero2 * PL32 + tid] = 0; s_a2[LA2 + zero2 * PL32 + tid] = 0; }
 
     // ---- per-lane constants of the weight-gradient phases ----------------------------------------------------------
     // dW3 [128 x 32]: wave w owns k-tile w = (ky,kx) = w>>1, channels 16*(w&1)..; dW2 [256 x 32]: k-tiles 2w, 2w+1 = (ky,kx) = w>>1, channels 16*(2(w&1)+u)
     // dW1 [16 KG1 x 64]: tile id = wave + 8u -> k-tile id>>2, n-tile wave & 3 (the same for every u)
     const int kyx = wave >> 1, ky = kyx >> 1, kx = kyx & 1;
-    const int aoff3 = (ky * a.ow2 + kx) * 36 + 16 * (wave & 1) + j;       // (t3 / t2 hold float offsets of rows)
+    const int aoff3 = (ky * a.ow2 + kx) * PL32 + 16 * (wave & 1);         // (t3: half offsets of a2's plane rows; t2: float offsets of a1's rows)
     const int aoff2 = (ky * a.ow1 + kx) * A1PS + 32 * (wave & 1) + j;
     f32x4 acc3[2], acc3l[2], acc2[2][2], acc2l[2][2], acc1[NW1], acc1l[NW1];
-    float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1 = 0.f;
+    float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1 = 0.f, bs_unused[2] = {0.f, 0.f};     // bs2: every wave's share of g2's column sums (its tiles' rows)
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[0][t] = acc3[t]; acc2[1][t] = acc3[t]; acc2l[0][t] = acc3[t]; acc2l[1][t] = acc3[t]; acc3l[t] = acc3[t]; }
 #pragma unroll
@@ -909,6 +960,18 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 __builtin_amdgcn_global_load_lds(src + (size_t)row * 128 + part * 16, (__attribute__((address_space(3))) u32*)(dst + ch * 256), 16, 0, 0);
         }
     };
+    // a2 piece planes [rows][32 halves] -> LDS rows of PL32 halves = 5 lane slots of 16 B (slot 4 of every row is padding), both planes
+    auto issue_a2 = [&](int g, int rows) {
+        const unsigned short* src = a.a2p + (size_t)g * S * r2 * 32;
+        const int slots = rows * 5, chunks = (slots + 63) >> 6;
+        for (int c = wave; c < 2 * chunks; c += CB_WAVES) {
+            const int piece = c >= chunks ? 1 : 0, ch = c - piece * chunks;
+            const int q = ch * 64 + lane, row = q / 5, part = q - row * 5;
+            if (q < slots && part < 4)
+                __builtin_amdgcn_global_load_lds(src + piece * a.a2_lo + (size_t)row * 32 + part * 8,
+                                                 (__attribute__((address_space(3))) u32*)(s_a2 + piece * LA2 + ch * 512), 16, 0, 0);
+        }
+    };
     // observations: lane l copies aligned dword l of a 256-byte piece of a sample's arbitrarily aligned row -- whole aligned dwords, also
     // where they straddle the neighbouring rows (see fused.hip: the window stays inside the caller's allocation)
     auto issue_obs = [&](int g) {
@@ -932,7 +995,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         const int g = blockIdx.x, gns = min(S, a.batch - g * S);
         issue_obs(g);
         issue_rows36(a.g3 + (size_t)g * S * r3 * 32, gns * r3, s_g3);
-        issue_rows36(a.a2 + (size_t)g * S * r2 * 32, gns * r2, s_a2);
+        issue_a2(g, gns * r2);
         if (a.a1_alt) issue_a1(g, reinterpret_cast<float*>(smem + a.off_a1));
     }
 
@@ -986,16 +1049,21 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 2);
         // ---- dW3 += im2col(a2)^T g3 ------------------------------------------------------------------------------
         {
-            // f16 pipe, as dW2 below: K = 32 rows per block, lane (j, kq) supplies rows m0 + 4kq + (e & 3) + 16 (e >> 2) of its column of each operand
-            // FULL: the block lies inside M3 -- no clamps, no selects, and every address is affine in e (immediate offsets)
-            auto rd = [&](int m0, float (&av)[8], float (&g0)[8], float (&g1)[8]) {
-                if (m0 + 32 <= M3) {                                  // wave-uniform
-                    const int* tp = t3 + m0 + 4 * kq;
+            // f16 pipe: K = 32 rows per block, lane group kq supplies rows m0 + 4kq + (e & 3) + 16 (e >> 2) (e = 0 .. 7) of both operands.
+            // A = the wave's 16 columns of a2 at its tap: ready-made pieces, fetched row-major -> operand order by two transposing reads
+            // per piece (this lane points at row ri, column segment cseg of each four-row read); G = g3's columns j, 16 + j: f32, eight
+            // ds_read_b32 per tile, split here.
+            const int ri = j >> 2, cseg = 4 * (j & 3);
+            auto rdA = [&](int m0, F16x2& A) {
+                const int r0 = min(m0 + 4 * kq + ri, M3 - 1), r1 = min(m0 + 16 + 4 * kq + ri, M3 - 1);      // (rows past M3: any valid row -- their g is zero)
+                A = lds_tr8(s_a2 + t3[r0] + aoff3 + cseg, s_a2 + t3[r1] + aoff3 + cseg, LA2);
+            };
+            auto rd = [&](int m0, float (&g0)[8], float (&g1)[8]) {
+                if (m0 + 32 <= M3) {                                  // wave-uniform: no clamps, no selects, affine addresses
                     const float* gp = s_g3 + (m0 + 4 * kq) * 36 + j;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int ro = (e & 3) + 16 * (e >> 2);
-                        av[e] = s_a2[tp[ro] + aoff3];
                         g0[e] = gp[ro * 36];
                         g1[e] = gp[ro * 36 + 16];
                     }
@@ -1003,15 +1071,14 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int mc = min(m0 + 4 * kq + (e & 3) + 16 * (e >> 2), M3 - 1);
-                        av[e] = s_a2[t3[mc] + aoff3];
-                        g0[e] = s_g3[mc * 36 + j];
-                        g1[e] = s_g3[mc * 36 + 16 + j];
+                        g0[e] = s_g3[__umul24(mc, 36) + j];
+                        g1[e] = s_g3[__umul24(mc, 36) + 16 + j];
                     }
                 }
             };
             // rows past M3 are masked HERE, a block after their reads were issued, and through g alone (a zero factor kills the product):
             // selects next to the reads make hipcc wait for every read where it is issued (eight serialised LDS latencies per partial block)
-            auto mm = [&](int m0, const float (&av)[8], float (&g0)[8], float (&g1)[8]) {
+            auto mm = [&](int m0, const F16x2& A, float (&g0)[8], float (&g1)[8]) {
                 if (m0 + 32 > M3) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -1020,7 +1087,6 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                         g1[e] = ok ? g1[e] : 0.f;
                     }
                 }
-                const F16x2 A = split_f16x2(f32x4{av[0], av[1], av[2], av[3]}, f32x4{av[4], av[5], av[6], av[7]});
                 const F16x2 G0 = split_f16x2(f32x4{g0[0], g0[1], g0[2], g0[3]}, f32x4{g0[4], g0[5], g0[6], g0[7]});
                 const F16x2 G1 = split_f16x2(f32x4{g1[0], g1[1], g1[2], g1[3]}, f32x4{g1[4], g1[5], g1[6], g1[7]});
                 mma_f16x3(A, G0, acc3[0], acc3l[0]);
@@ -1030,12 +1096,13 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                     for (int e = 0; e < 8; ++e) { bs3[0] += g0[e]; bs3[1] += g1[e]; }
                 }
             };
-            float aA[8], g0A[8], g1A[8], aB[8], g0B[8], g1B[8];
-            rd(0, aA, g0A, g1A);
+            float g0A[8], g1A[8], g0B[8], g1B[8];
+            F16x2 aA, aB;
+            rdA(0, aA); rd(0, g0A, g1A);
             for (int m0 = 0;;) {
-                rd(m0 + 32, aB, g0B, g1B);
+                rdA(m0 + 32, aB); rd(m0 + 32, g0B, g1B);
                 mm(m0, aA, g0A, g1A); m0 += 32; if (m0 >= M3) break;
-                rd(m0 + 32, aA, g0A, g1A);
+                rdA(m0 + 32, aA); rd(m0 + 32, g0A, g1A);
                 mm(m0, aB, g0B, g1B); m0 += 32; if (m0 >= M3) break;
             }
         }
@@ -1043,7 +1110,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         __syncthreads();                                            // every wave is done reading a2
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 4);
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
-        dgrad_inplace<36>(bw, s_g3, zero3, s_a2, 0, d2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane);
+        dgrad_inplace<PL32, false, true>(bw, s_g3, 0, zero3, s_a2, LA2, 0, d2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane, bs2);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
         __syncthreads();
         if (nxt < a.groups) {                                       // the observation slots and g3 are dead now; so is the other a1 buffer
@@ -1054,66 +1121,61 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
         // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
         {
-            // On the f16 pipe (f16x2, qnet.h): one K = 32 block = 32 rows, lane (j, kq) supplies rows m0 + 4kq + (e & 3) + 16 (e >> 2) (e = 0 .. 7;
-            // any assignment of the block's rows to (kq, e) is a permutation of the reduction index as long as both operands use it; this one puts
-            // the g rows of lanes kq, kq + 1 -- one ds_read_b32 lane group -- 4 x 36 floats = 16 banks apart: conflict-free) of its
-            // column of each operand -- the same eight ds_read_b32 per operand tile the f32 MFMAs took, but 12 K = 32 MFMAs (192 pipe
-            // cycles) per trip instead of 32 K = 4 ones (1024), for 4 operand splits (~96 VALU).  The LDS reads of trip t + 1 are issued
-            // before the splits and MFMAs of trip t.
-            auto rd = [&](int m0, float (&av0)[8], float (&av1)[8], float (&g0)[8], float (&g1)[8]) {
+            // One K = 32 block = 32 rows, lane group kq supplies rows m0 + 4kq + (e & 3) + 16 (e >> 2) of both operands (any assignment of the
+            // block's rows to (kq, e) is a permutation of the reduction index as long as both operands use it).  A = a1's columns (f32 image:
+            // eight ds_read_b32 per tile, split here); G = g2's columns j, 16 + j: ready-made pieces (the g2 phase split them on write),
+            // four transposing reads per tile and piece pair -- no arithmetic.  The reads of trip t + 1 are issued before the MFMAs of trip t.
+            const int ri = j >> 2, cseg = 4 * (j & 3);
+            auto rdG = [&](int m0, F16x2& G0, F16x2& G1) {
+                const int r0 = min(m0 + 4 * kq + ri, M2 - 1), r1 = min(m0 + 16 + 4 * kq + ri, M2 - 1);      // (rows past M2: masked in mm)
+                const unsigned short* p0 = s_a2 + r0 * PL32 + cseg;
+                const unsigned short* p1 = s_a2 + r1 * PL32 + cseg;
+                G0 = lds_tr8(p0, p1, LA2);
+                G1 = lds_tr8(p0 + 16, p1 + 16, LA2);
+            };
+            auto rd = [&](int m0, float (&av0)[8], float (&av1)[8]) {
                 if (m0 + 32 <= M2) {                                  // wave-uniform: no clamps, no selects, affine addresses
                     const int* tp = t2 + m0 + 4 * kq;
-                    const float* gp = s_a2 + (m0 + 4 * kq) * 36 + j;
                     const float* ab = s_a1 + aoff2;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int ro = (e & 3) + 16 * (e >> 2);
-                        const float* ap = ab + tp[ro];
+                        const float* ap = ab + tp[(e & 3) + 16 * (e >> 2)];
                         av0[e] = ap[0];
                         av1[e] = ap[16];
-                        g0[e] = gp[ro * 36];
-                        g1[e] = gp[ro * 36 + 16];
                     }
-                } else {                                              // the group's last block: clamped rows, raw values (masked in mm)
+                } else {                                              // the group's last block: clamped rows (their g is zeroed in mm)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int mc = min(m0 + 4 * kq + (e & 3) + 16 * (e >> 2), M2 - 1);
                         const float* ap = s_a1 + t2[mc] + aoff2;
                         av0[e] = ap[0];
                         av1[e] = ap[16];
-                        g0[e] = s_a2[mc * 36 + j];
-                        g1[e] = s_a2[mc * 36 + 16 + j];
                     }
                 }
             };
-            auto mm = [&](int m0, const float (&av0)[8], const float (&av1)[8], float (&g0)[8], float (&g1)[8]) {
-                if (m0 + 32 > M2) {                                   // rows past M2: masked through g alone, a block after the reads
+            auto mm = [&](int m0, const float (&av0)[8], const float (&av1)[8], F16x2& G0, F16x2& G1) {
+                if (m0 + 32 > M2) {                                   // rows past M2: their halves of g's pieces cleared (element e = half e of the operand)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const bool ok = m0 + 4 * kq + (e & 3) + 16 * (e >> 2) < M2;
-                        g0[e] = ok ? g0[e] : 0.f;
-                        g1[e] = ok ? g1[e] : 0.f;
+                    for (int d = 0; d < 4; ++d) {
+                        const u32 lo = m0 + 4 * kq + ((2 * d) & 3) + 16 * ((2 * d) >> 2) < M2 ? 0xffffu : 0u;
+                        const u32 hi = m0 + 4 * kq + ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < M2 ? 0xffff0000u : 0u;
+                        G0.h[d] &= lo | hi; G0.l[d] &= lo | hi; G1.h[d] &= lo | hi; G1.l[d] &= lo | hi;
                     }
                 }
                 const F16x2 A0 = split_f16x2(f32x4{av0[0], av0[1], av0[2], av0[3]}, f32x4{av0[4], av0[5], av0[6], av0[7]});
                 const F16x2 A1 = split_f16x2(f32x4{av1[0], av1[1], av1[2], av1[3]}, f32x4{av1[4], av1[5], av1[6], av1[7]});
-                const F16x2 G0 = split_f16x2(f32x4{g0[0], g0[1], g0[2], g0[3]}, f32x4{g0[4], g0[5], g0[6], g0[7]});
-                const F16x2 G1 = split_f16x2(f32x4{g1[0], g1[1], g1[2], g1[3]}, f32x4{g1[4], g1[5], g1[6], g1[7]});
                 mma_f16x3(A0, G0, acc2[0][0], acc2l[0][0]);
                 mma_f16x3(A0, G1, acc2[0][1], acc2l[0][1]);
                 mma_f16x3(A1, G0, acc2[1][0], acc2l[1][0]);
                 mma_f16x3(A1, G1, acc2[1][1], acc2l[1][1]);
-                if (wave == 0) {                                    // (the bias gradient is the same sum in every wave: one keeps it)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { bs2[0] += g0[e]; bs2[1] += g1[e]; }
-                }
             };
-            float a0A[8], a1A[8], g0A[8], g1A[8], a0B[8], a1B[8], g0B[8], g1B[8];
-            rd(0, a0A, a1A, g0A, g1A);
+            float a0A[8], a1A[8], a0B[8], a1B[8];
+            F16x2 g0A, g1A, g0B, g1B;
+            rdG(0, g0A, g1A); rd(0, a0A, a1A);
             for (int m0 = 0;;) {
-                rd(m0 + 32, a0B, a1B, g0B, g1B);
+                rdG(m0 + 32, g0B, g1B); rd(m0 + 32, a0B, a1B);
                 mm(m0, a0A, a1A, g0A, g1A); m0 += 32; if (m0 >= M2) break;
-                rd(m0 + 32, a0A, a1A, g0A, g1A);
+                rdG(m0 + 32, g0A, g1A); rd(m0 + 32, a0A, a1A);
                 mm(m0, a0B, a1B, g0B, g1B); m0 += 32; if (m0 >= M2) break;
             }
         }
@@ -1122,11 +1184,11 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         __syncthreads();                                            // every wave is done reading a1
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 8);
         // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1: waves 0-3 channels 0..31, waves 4-7 channels 32..63 -------------
-        dgrad_inplace<A1PS>(bw, s_a2, zero2, s_a1, 32 * (wave >> 2), d1, a.oh2, a.ow2, M1, wave & 3, 4, lane);
+        dgrad_inplace<A1PS, true, false>(bw, s_a2, LA2, zero2, s_a1, 0, 32 * (wave >> 2), d1, a.oh2, a.ow2, M1, wave & 3, 4, lane, bs_unused);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 9);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 10);
-        if (nxt < a.groups) issue_rows36(a.a2 + (size_t)nxt * S * r2 * 32, ns_nxt * r2, s_a2);     // g2 (in a2) is dead; lands during dW1
+        if (nxt < a.groups) issue_a2(nxt, ns_nxt * r2);            // g2 (in a2) is dead; lands during dW1
         // ---- dW1 += patches^T g1 ----------------------------------------------------------------------------------------
         {
             const u8* cp = s_col + 16 * (wave >> 2) + j;           // + 32 per further tile of this wave (k-tile + 2)
@@ -1216,12 +1278,29 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             }
         }
     }
-    if (wave < 2) {                                                 // wave 0 kept the second convolution's bias sums, wave 1 the third's
+    if (wave == 1) {                                                // wave 1 kept the third convolution's bias sums
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            float v = wave ? bs3[t] : bs2[t];
+            float v = bs3[t];
             v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            if (kq == 0) out[a.b_off[wave ? 2 : 1] + 16 * t + j] = v;
+            if (kq == 0) out[a.b_off[2] + 16 * t + j] = v;
+        }
+    }
+    {   // the second convolution's: every wave holds the column sums of the g2 tiles it produced -- combined in fixed order through LDS
+        __syncthreads();                                            // (every LDS image is dead)
+        float* s_b = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v = bs2[t];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (kq == 0) s_b[wave * 32 + 16 * t + j] = v;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < CB_WAVES; ++w) v += s_b[w * 32 + tid];
+            out[a.b_off[1] + tid] = v;
         }
     }
 }
@@ -1268,7 +1347,7 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
         const size_t a1_bytes = ((size_t)S * L1.rows * A1PS * 4 + 1023) & ~(size_t)1023;
         P->off_a1 = (int)off; off += nbuf * a1_bytes;
         P->a1_alt = nbuf == 2 ? (int)a1_bytes : 0;
-        P->off_a2 = (int)off; off += up16((size_t)(S * L2.rows + 1) * 36 * 4);
+        P->off_a2 = (int)off; off += up16((size_t)2 * (S * L2.rows + 1) * PL32 * 2);      // a2 / g2: two f16 piece planes, rows of PL32 halves
         P->off_g3 = (int)off; off += up16((size_t)(S * L3.rows + 1) * 36 * 4);
         P->off_t1 = (int)off; off += up16((size_t)S * L1.rows * 16 * P->KG1);      // observation patch image (bytes)
         P->off_t2 = (int)off; off += up16((size_t)S * L2.rows * 4);
@@ -1305,7 +1384,7 @@ bool fused_conv_bwd_row_tables(const dq_qnet* Q, int* tab) {
     }
     for (int m = 0; m < P.S * L3.rows; ++m) {
         const int s = m / L3.rows, p = m % L3.rows, oy = p / L3.ow, ox = p % L3.ow;
-        tab[2 * CONV_ROWTAB + m] = (s * L2.rows + oy * L2.ow + ox) * 36;
+        tab[2 * CONV_ROWTAB + m] = (s * L2.rows + oy * L2.ow + ox) * PL32;
     }
     return true;
 }
@@ -1456,7 +1535,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     memset(&ca, 0, sizeof(ca));
     ca.params = params_dev; ca.obs = Q->last_obs; ca.index = Q->last_index; ca.index_off = Q->last_index_off;
     ca.index_mod = Q->last_index_mod > 0 ? Q->last_index_mod : 0x7fffffff;
-    ca.a1 = Q->act[0][0]; ca.a2 = Q->act[0][1]; ca.g3 = Q->gz[nc - 1];
+    ca.a1 = Q->act[0][0]; ca.a2p = reinterpret_cast<const unsigned short*>(Q->act[0][1]); ca.a2_lo = (size_t)Q->cfg.max_batch * L2.rows * 32;
+    ca.g3 = Q->gz[nc - 1];
     DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
     ca.packed = static_cast<const u32x4*>(Q->last_train_packed);
     ca.batch = B; ca.S = cp.S; ca.groups = (B + cp.S - 1) / cp.S;

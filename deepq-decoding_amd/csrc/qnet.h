@@ -144,7 +144,9 @@ struct ConvJob {
     const u8* obs;
     const int32_t* index;
     int index_off, index_mod, batch;
-    float* act_out[3];                 // global NHWC [batch*oh*ow, cout]; [2] always written
+    float* act_out[3];                 // global NHWC [batch*oh*ow, cout]; [2] always written, [0] in training; [1] unused: in training the second
+    unsigned short* a2_pl;             // convolution's output is kept as f16 piece planes [batch*oh2*ow2][32] (h plane; the l plane a2_lo halves
+    size_t a2_lo;                      // further) -- the form the convolutional backward consumes it in (fused_bwd.hip)
     int write_all;                     // training: write every layer
     int wg0;                           // first workgroup of this job
 };
