@@ -44,7 +44,8 @@ struct DenseBwdArgs {
     unsigned short* gy2_pl;             // ... [2][plane_rows][small_ld]
     unsigned short* g3_pl;              // ... [2][plane_rows][small_ld]
     int plane_rows, small_ld;
-    float* gx;                          // [batch, K1] NHWC
+    unsigned short* gx_pl;              // gX [batch][K1] (NHWC) as f16 piece planes (h plane; the l plane gx_lo halves further): split on write --
+    size_t gx_lo;                       // it is the convolutional backward's g3 operand, staged there by LDS-DMA and read without arithmetic
     int ldg;                            // LDS row stride of the g3 image (floats); the gY2 planes have rows of 32 KB2 + 8 halves
     int off_g3, off_gy2, off_gh1;
     float gs;                           // every gradient of the fused backward is carried scaled by this power of two (GradScale below) ...
@@ -127,10 +128,14 @@ __device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const unsigned sh
 #pragma unroll
     for (int t = 0; t < NTP; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kq + r;
-            if (row >= ns) continue;
-            a.gx[(size_t)(b0 + row) * K1 + 16 * (tile0 + t) + j] = xm[t][r] > 0.f ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
+        for (int r = 0; r < 4; r += 2) {                            // rows 4kq + r, + 1 as one pair: four instructions split both (qnet.h)
+            const float v0 = xm[t][r] > 0.f ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
+            const float v1 = xm[t][r + 1] > 0.f ? f16x2_sum(acc[t][0][r + 1], acc[t][1][r + 1]) : 0.f;
+            u32 h, l;
+            split_f16x2_pair(v0, v1, h, l);
+            unsigned short* gp = a.gx_pl + (size_t)(b0 + 4 * kq + r) * K1 + 16 * (tile0 + t) + j;
+            if (4 * kq + r < ns) { gp[0] = (unsigned short)h; gp[a.gx_lo] = (unsigned short)l; }
+            if (4 * kq + r + 1 < ns) { gp[K1] = (unsigned short)(h >> 16); gp[K1 + a.gx_lo] = (unsigned short)(l >> 16); }
         }
 }
 
@@ -736,7 +741,8 @@ struct ConvBwdArgs {
     const float* a1;                    // saved activations of the training forward (global NHWC)
     const unsigned short* a2p;          // saved second-convolution output [batch*r2][32] as f16 piece planes (h plane; the l plane a2_lo halves further)
     size_t a2_lo;
-    const float* g3;                    // [batch*r3, 32] gradient w.r.t. conv3's pre-activation output
+    const unsigned short* g3p;          // [batch*r3][32] gradient w.r.t. conv3's pre-activation output, as f16 piece planes (l plane g3_lo halves further)
+    size_t g3_lo;
     const u32x4* packed;                // f16 pieces of the conv kernels (qnet.h PK_*), those of the training forward
     int batch, S, groups;
     int C, H, W, k1, st1, K1;
@@ -891,7 +897,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     u8* s_in = smem;
     int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);
     unsigned short* s_a2 = reinterpret_cast<unsigned short*>(smem + a.off_a2);      // a2, then g2 in place: piece planes [2][S*r2 + 1][PL32]
-    float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
+    unsigned short* s_g3 = reinterpret_cast<unsigned short*>(smem + a.off_g3);      // g3: piece planes [2][S*r3 + 1][PL32]
     u8* s_col = smem + a.off_t1;                                     // observation patch image [S*r1][16*KG1] bytes
     int* s_ko = reinterpret_cast<int*>(smem + a.off_ko);
     int* t2 = reinterpret_cast<int*>(smem + a.off_t2);
@@ -903,7 +909,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     const int S = a.S, r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
     const int in_bytes = a.C * a.H * a.W;
     const int zero2 = S * r2, zero3 = S * r3;                        // all-zero rows of the g2 (= a2) and g3 images
-    const int LA2 = (S * r2 + 1) * PL32;                             // halves from a2's h plane to its l plane
+    const int LA2 = (S * r2 + 1) * PL32, LG3 = (S * r3 + 1) * PL32;   // halves from a2's / g3's h plane to its l plane
     constexpr int NW1 = (4 * KG1 + CB_WAVES - 1) / CB_WAVES;        // dW1 tiles (KG1 x 4) per wave
     constexpr int KP = 16 * KG1;                                    // bytes per row of the observation patch image
 
@@ -919,8 +925,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         if (m < S * r3) t3[m] = e3;                                 // t3: float offset of the a2 row
     }
     if (tid < 96) s_ko[tid] = a.kofftab[tid];
-    if (tid < 36) s_g3[zero3 * 36 + tid] = 0.f;
-    if (tid < PL32) { s_a2[zero2 * PL32 + tid] = 0; s_a2[LA2 + zero2 * PL32 + tid] = 0; }
+    if (tid < PL32) { s_a2[zero2 * PL32 + tid] = 0; s_a2[LA2 + zero2 * PL32 + tid] = 0; s_g3[zero3 * PL32 + tid] = 0; s_g3[LG3 + zero3 * PL32 + tid] = 0; }
 
     // ---- per-lane constants of the weight-gradient phases ----------------------------------------------------------
     // dW3 [128 x 32]: wave w owns k-tile w = (ky,kx) = w>>1, channels 16*(w&1)..; dW2 [256 x 32]: k-tiles 2w, 2w+1 = (ky,kx) = w>>1, channels 16*(2(w&1)+u)
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     const int aoff3 = (ky * a.ow2 + kx) * PL32 + 16 * (wave & 1);         // (t3: half offsets of a2's plane rows; t2: float offsets of a1's rows)
     const int aoff2 = (ky * a.ow1 + kx) * A1PS + 32 * (wave & 1) + j;
     f32x4 acc3[2], acc3l[2], acc2[2][2], acc2l[2][2], acc1[NW1], acc1l[NW1];
-    float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs1 = 0.f, bs_unused[2] = {0.f, 0.f};     // bs2: every wave's share of g2's column sums (its tiles' rows)
+    float bs3 = 0.f, bs2[2] = {0.f, 0.f}, bs1 = 0.f, bs_unused[2] = {0.f, 0.f};     // bs2: every wave's share of g2's column sums (its tiles' rows); bs3: this thread's share of g3's column tid & 31
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[0][t] = acc3[t]; acc2[1][t] = acc3[t]; acc2l[0][t] = acc3[t]; acc2l[1][t] = acc3[t]; acc3l[t] = acc3[t]; }
 #pragma unroll
@@ -950,28 +955,19 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) u32*)(dst + ch * 256), 16, 0, 0);
         }
     };
-    // a2 / g3 [rows][32] -> LDS rows of 36 floats = 9 lane slots of 16 B: slot 8 of every row is padding (its lane stays inactive)
-    auto issue_rows36 = [&](const float* srcf, int rows, float* dst) {
-        const char* src = reinterpret_cast<const char*>(srcf);
-        const int slots = rows * 9, chunks = (slots + 63) >> 6;
-        for (int ch = wave; ch < chunks; ch += CB_WAVES) {
-            const int q = ch * 64 + lane, row = q / 9, part = q - row * 9;
-            if (q < slots && part < 8)
-                __builtin_amdgcn_global_load_lds(src + (size_t)row * 128 + part * 16, (__attribute__((address_space(3))) u32*)(dst + ch * 256), 16, 0, 0);
-        }
-    };
-    // a2 piece planes [rows][32 halves] -> LDS rows of PL32 halves = 5 lane slots of 16 B (slot 4 of every row is padding), both planes
-    auto issue_a2 = [&](int g, int rows) {
-        const unsigned short* src = a.a2p + (size_t)g * S * r2 * 32;
+    // piece planes [rows][32 halves] (a2, g3) -> LDS rows of PL32 halves = 5 lane slots of 16 B (slot 4 of every row is padding), both planes
+    auto issue_pl32 = [&](const unsigned short* src, size_t src_lo, int rows, unsigned short* dst, int dst_lo) {
         const int slots = rows * 5, chunks = (slots + 63) >> 6;
         for (int c = wave; c < 2 * chunks; c += CB_WAVES) {
             const int piece = c >= chunks ? 1 : 0, ch = c - piece * chunks;
             const int q = ch * 64 + lane, row = q / 5, part = q - row * 5;
             if (q < slots && part < 4)
-                __builtin_amdgcn_global_load_lds(src + piece * a.a2_lo + (size_t)row * 32 + part * 8,
-                                                 (__attribute__((address_space(3))) u32*)(s_a2 + piece * LA2 + ch * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(src + piece * src_lo + (size_t)row * 32 + part * 8,
+                                                 (__attribute__((address_space(3))) u32*)(dst + piece * dst_lo + ch * 512), 16, 0, 0);
         }
     };
+    auto issue_a2 = [&](int g, int rows) { issue_pl32(a.a2p + (size_t)g * S * r2 * 32, a.a2_lo, rows, s_a2, LA2); };
+    auto issue_g3 = [&](int g, int rows) { issue_pl32(a.g3p + (size_t)g * S * r3 * 32, a.g3_lo, rows, s_g3, LG3); };
     // observations: lane l copies aligned dword l of a 256-byte piece of a sample's arbitrarily aligned row -- whole aligned dwords, also
     // where they straddle the neighbouring rows (see fused.hip: the window stays inside the caller's allocation)
     auto issue_obs = [&](int g) {
@@ -994,7 +990,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     if ((int)blockIdx.x < a.groups) {
         const int g = blockIdx.x, gns = min(S, a.batch - g * S);
         issue_obs(g);
-        issue_rows36(a.g3 + (size_t)g * S * r3 * 32, gns * r3, s_g3);
+        issue_g3(g, gns * r3);
         issue_a2(g, gns * r2);
         if (a.a1_alt) issue_a1(g, reinterpret_cast<float*>(smem + a.off_a1));
     }
@@ -1046,63 +1042,50 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             *reinterpret_cast<uint4*>(s_col + m * KP + 16 * q) = uint4{wd[0], wd[1], wd[2], wd[3]};
         }
 
+        // the third convolution's bias gradient = column sums of g3, from its pieces: thread (column tid & 31, row class tid >> 5) adds its
+        // rows here (one pass per group; the classes are combined at the kernel's end)
+        for (int row = tid >> 5; row < M3; row += CB_THREADS / 32) {
+            const unsigned short* gp = s_g3 + row * PL32 + (tid & 31);
+            bs3 += (float)__builtin_bit_cast(_Float16, gp[0]) + (float)__builtin_bit_cast(_Float16, gp[LG3]) * F16_LO_INV;
+        }
+
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 2);
         // ---- dW3 += im2col(a2)^T g3 ------------------------------------------------------------------------------
         {
             // f16 pipe: K = 32 rows per block, lane group kq supplies rows m0 + 4kq + (e & 3) + 16 (e >> 2) (e = 0 .. 7) of both operands.
-            // A = the wave's 16 columns of a2 at its tap: ready-made pieces, fetched row-major -> operand order by two transposing reads
-            // per piece (this lane points at row ri, column segment cseg of each four-row read); G = g3's columns j, 16 + j: f32, eight
-            // ds_read_b32 per tile, split here.
+            // A = the wave's 16 columns of a2 at its tap, G = g3's columns j, 16 + j: both ready-made pieces (the forward saved a2 that way,
+            // the dense backward writes gX = g3 that way), fetched row-major -> operand order by two transposing reads per piece and tile
+            // (this lane points at row ri, column segment cseg of each four-row read) -- no arithmetic beside the MFMAs.
             const int ri = j >> 2, cseg = 4 * (j & 3);
             auto rdA = [&](int m0, F16x2& A) {
                 const int r0 = min(m0 + 4 * kq + ri, M3 - 1), r1 = min(m0 + 16 + 4 * kq + ri, M3 - 1);      // (rows past M3: any valid row -- their g is zero)
                 A = lds_tr8(s_a2 + t3[r0] + aoff3 + cseg, s_a2 + t3[r1] + aoff3 + cseg, LA2);
             };
-            auto rd = [&](int m0, float (&g0)[8], float (&g1)[8]) {
-                if (m0 + 32 <= M3) {                                  // wave-uniform: no clamps, no selects, affine addresses
-                    const float* gp = s_g3 + (m0 + 4 * kq) * 36 + j;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int ro = (e & 3) + 16 * (e >> 2);
-                        g0[e] = gp[ro * 36];
-                        g1[e] = gp[ro * 36 + 16];
-                    }
-                } else {                                              // the group's last block: clamped rows, raw values (masked in mm)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int mc = min(m0 + 4 * kq + (e & 3) + 16 * (e >> 2), M3 - 1);
-                        g0[e] = s_g3[__umul24(mc, 36) + j];
-                        g1[e] = s_g3[__umul24(mc, 36) + 16 + j];
-                    }
-                }
+            auto rdG = [&](int m0, F16x2& G0, F16x2& G1) {
+                const int r0 = min(m0 + 4 * kq + ri, M3 - 1), r1 = min(m0 + 16 + 4 * kq + ri, M3 - 1);      // (rows past M3: cleared in mm)
+                const unsigned short* p0 = s_g3 + r0 * PL32 + cseg;
+                const unsigned short* p1 = s_g3 + r1 * PL32 + cseg;
+                G0 = lds_tr8(p0, p1, LG3);
+                G1 = lds_tr8(p0 + 16, p1 + 16, LG3);
             };
-            // rows past M3 are masked HERE, a block after their reads were issued, and through g alone (a zero factor kills the product):
-            // selects next to the reads make hipcc wait for every read where it is issued (eight serialised LDS latencies per partial block)
-            auto mm = [&](int m0, const F16x2& A, float (&g0)[8], float (&g1)[8]) {
-                if (m0 + 32 > M3) {
+            auto mm = [&](int m0, const F16x2& A, F16x2& G0, F16x2& G1) {
+                if (m0 + 32 > M3) {                                   // rows past M3: their halves of g's pieces cleared (element e = half e of the operand)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const bool ok = m0 + 4 * kq + (e & 3) + 16 * (e >> 2) < M3;
-                        g0[e] = ok ? g0[e] : 0.f;
-                        g1[e] = ok ? g1[e] : 0.f;
+                    for (int d = 0; d < 4; ++d) {
+                        const u32 lo = m0 + 4 * kq + ((2 * d) & 3) + 16 * ((2 * d) >> 2) < M3 ? 0xffffu : 0u;
+                        const u32 hi = m0 + 4 * kq + ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < M3 ? 0xffff0000u : 0u;
+                        G0.h[d] &= lo | hi; G0.l[d] &= lo | hi; G1.h[d] &= lo | hi; G1.l[d] &= lo | hi;
                     }
                 }
-                const F16x2 G0 = split_f16x2(f32x4{g0[0], g0[1], g0[2], g0[3]}, f32x4{g0[4], g0[5], g0[6], g0[7]});
-                const F16x2 G1 = split_f16x2(f32x4{g1[0], g1[1], g1[2], g1[3]}, f32x4{g1[4], g1[5], g1[6], g1[7]});
                 mma_f16x3(A, G0, acc3[0], acc3l[0]);
                 mma_f16x3(A, G1, acc3[1], acc3l[1]);
-                if (wave == 1) {                                    // (the bias gradient is the same sum in every wave: one keeps it)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { bs3[0] += g0[e]; bs3[1] += g1[e]; }
-                }
             };
-            float g0A[8], g1A[8], g0B[8], g1B[8];
-            F16x2 aA, aB;
-            rdA(0, aA); rd(0, g0A, g1A);
+            F16x2 aA, aB, g0A, g1A, g0B, g1B;
+            rdA(0, aA); rdG(0, g0A, g1A);
             for (int m0 = 0;;) {
-                rdA(m0 + 32, aB); rd(m0 + 32, g0B, g1B);
+                rdA(m0 + 32, aB); rdG(m0 + 32, g0B, g1B);
                 mm(m0, aA, g0A, g1A); m0 += 32; if (m0 >= M3) break;
-                rdA(m0 + 32, aA); rd(m0 + 32, g0A, g1A);
+                rdA(m0 + 32, aA); rdG(m0 + 32, g0A, g1A);
                 mm(m0, aB, g0B, g1B); m0 += 32; if (m0 >= M3) break;
             }
         }
@@ -1110,12 +1093,12 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         __syncthreads();                                            // every wave is done reading a2
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 4);
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 -------------------------------------------------------------
-        dgrad_inplace<PL32, false, true>(bw, s_g3, 0, zero3, s_a2, LA2, 0, d2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane, bs2);
+        dgrad_inplace<PL32, true, true>(bw, s_g3, LG3, zero3, s_a2, LA2, 0, d2, a.oh3, a.ow3, M2, wave, CB_WAVES, lane, bs2);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
         __syncthreads();
         if (nxt < a.groups) {                                       // the observation slots and g3 are dead now; so is the other a1 buffer
             issue_obs(nxt);
-            issue_rows36(a.g3 + (size_t)nxt * S * r3 * 32, ns_nxt * r3, s_g3);
+            issue_g3(nxt, ns_nxt * r3);
             if (a.a1_alt) issue_a1(nxt, reinterpret_cast<float*>(smem + a.off_a1 + ((it + 1) & 1) * a.a1_alt));
         }
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
@@ -1278,17 +1261,10 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             }
         }
     }
-    if (wave == 1) {                                                // wave 1 kept the third convolution's bias sums
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float v = bs3[t];
-            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            if (kq == 0) out[a.b_off[2] + 16 * t + j] = v;
-        }
-    }
     {   // the second convolution's: every wave holds the column sums of the g2 tiles it produced -- combined in fixed order through LDS
         __syncthreads();                                            // (every LDS image is dead)
         float* s_b = reinterpret_cast<float*>(smem);
+        s_b[256 + tid] = bs3;                                       // the third's: thread (column tid & 31, row class tid >> 5)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float v = bs2[t];
@@ -1301,6 +1277,11 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 #pragma unroll
             for (int w = 0; w < CB_WAVES; ++w) v += s_b[w * 32 + tid];
             out[a.b_off[1] + tid] = v;
+        } else if (tid < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int cl = 0; cl < CB_THREADS / 32; ++cl) v += s_b[256 + cl * 32 + (tid - 32)];
+            out[a.b_off[2] + tid - 32] = v;
         }
     }
 }
@@ -1348,7 +1329,7 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
         P->off_a1 = (int)off; off += nbuf * a1_bytes;
         P->a1_alt = nbuf == 2 ? (int)a1_bytes : 0;
         P->off_a2 = (int)off; off += up16((size_t)2 * (S * L2.rows + 1) * PL32 * 2);      // a2 / g2: two f16 piece planes, rows of PL32 halves
-        P->off_g3 = (int)off; off += up16((size_t)(S * L3.rows + 1) * 36 * 4);
+        P->off_g3 = (int)off; off += up16((size_t)2 * (S * L3.rows + 1) * PL32 * 2);      // g3: two f16 piece planes
         P->off_t1 = (int)off; off += up16((size_t)S * L1.rows * 16 * P->KG1);      // observation patch image (bytes)
         P->off_t2 = (int)off; off += up16((size_t)S * L2.rows * 4);
         P->off_t3 = (int)off; off += up16((size_t)S * L3.rows * 4);
@@ -1461,7 +1442,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < nl - nc; ++l) da.w_off[l] = (int)Q->L[nc + l].w_off;
     da.mask_scale = D1.dropout > 0.f ? (float)(1.0 / (1.0 - (double)D1.dropout)) : 1.f;
-    da.g3 = Q->cfg.dueling ? Q->gz[nc + 2] : nullptr; da.gy2 = Q->gz[nc + 1]; da.gh1 = Q->gz[nc]; da.gx = Q->gz[nc - 1];
+    da.g3 = Q->cfg.dueling ? Q->gz[nc + 2] : nullptr; da.gy2 = Q->gz[nc + 1]; da.gh1 = Q->gz[nc]; da.gx_pl = reinterpret_cast<unsigned short*>(Q->gz[nc - 1]); da.gx_lo = (size_t)Q->cfg.max_batch * D1.nin;
     da.ldg = dp.ldg; da.off_g3 = dp.off_g3; da.off_gy2 = dp.off_gy2; da.off_gh1 = dp.off_gh1;
     da.dense_wgs = (B + DENSE_ROWS - 1) / DENSE_ROWS;
     int stat_wgs = 0;
@@ -1536,7 +1517,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.params = params_dev; ca.obs = Q->last_obs; ca.index = Q->last_index; ca.index_off = Q->last_index_off;
     ca.index_mod = Q->last_index_mod > 0 ? Q->last_index_mod : 0x7fffffff;
     ca.a1 = Q->act[0][0]; ca.a2p = reinterpret_cast<const unsigned short*>(Q->act[0][1]); ca.a2_lo = (size_t)Q->cfg.max_batch * L2.rows * 32;
-    ca.g3 = Q->gz[nc - 1];
+    ca.g3p = reinterpret_cast<const unsigned short*>(Q->gz[nc - 1]); ca.g3_lo = (size_t)Q->cfg.max_batch * L3.rows * 32;
     DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
     ca.packed = static_cast<const u32x4*>(Q->last_train_packed);
     ca.batch = B; ca.S = cp.S; ca.groups = (B + cp.S - 1) / cp.S;
