@@ -100,8 +100,7 @@ template <int CIN, int COUT, int KS, int RR, int NTT>
 __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__ in, int lo_in, int ih, int iw, int oh, int ow, int M,
                                               F16x2 (&ring)[RR][NTT], const u32x4* __restrict__ pk, const float* __restrict__ bias,
                                               unsigned short* __restrict__ out_lds, int lo_out, float* __restrict__ out_g, int wave, int lane,
-                                              const int* __restrict__ rowtab, int pre0, int pre1, unsigned short* __restrict__ out_pl = nullptr,
-                                              size_t lo_pl = 0) {
+                                              const int* __restrict__ rowtab, int pre0, int pre1) {
     using SH = ConvShape<CIN, COUT, KS>;
     constexpr int NT = SH::NT, PSI = CIN + 8, PSO = COUT + 8, CB = SH::CB, NB = SH::NB, R = SH::R;
     static_assert(NT == 2 && CIN % 32 == 0 && RR == R && NTT == NT, "written for 32 output channels, CIN a multiple of 32");
@@ -172,10 +171,6 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
                     split_f16x2_pair(v[0], v[1], h, l);
                     *reinterpret_cast<u32*>(out_lds + mo * PSO + 2 * j) = h;
                     *reinterpret_cast<u32*>(out_lds + mo * PSO + 2 * j + lo_out) = l;
-                    if (out_pl) {                                   // the same pieces to global memory, rows of COUT halves (training: the backward's operand)
-                        *reinterpret_cast<u32*>(out_pl + (size_t)mo * COUT + 2 * j) = h;
-                        *reinterpret_cast<u32*>(out_pl + (size_t)mo * COUT + 2 * j + lo_pl) = l;
-                    }
                 }
                 if (out_g) *reinterpret_cast<f32x2*>(out_g + (size_t)mo * COUT + 2 * j) = v;
             }
@@ -284,7 +279,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     //      MFMAs of the current one ----------------------------------------------------------------------------------------------
     {
         const int tiles = (M1 + 15) >> 4;
-        float* g1 = J.write_all ? J.act_out[0] + (size_t)b0 * r1 * 64 : nullptr;
         auto origin = [&](int tile) { return s_t1[min(tile * 16 + j, M1 - 1)]; };     // rows past the end (and whole tiles past it) reread the last row
         auto rd = [&](int org, u32 (&ab)[NH1][8]) {
             const u8* ap = s_in + org;
@@ -322,7 +316,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
                 *reinterpret_cast<uint2*>(s_a1 + mo * 72 + 4 * j) = uint2{hp[0], hp[1]};
                 *reinterpret_cast<uint2*>(s_a1 + mo * 72 + 4 * j + lo1) = uint2{lp[0], lp[1]};
-                if (g1) *reinterpret_cast<f32x4*>(g1 + (size_t)mo * 64 + 4 * j) = v;
             }
         };
         u32 abA[NH1][8], abB[NH1][8];
@@ -345,8 +338,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     {
         const int r2 = a.oh2 * a.ow2;
         conv_from_lds<64, 32, 2>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
-                                 nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1],
-                                 J.write_all ? J.a2_pl + (size_t)b0 * r2 * 32 : nullptr, J.a2_lo);
+                                 nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1]);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 5);
     conv_w_prefetch(ring, J.packed + PK_CONV3_FWD, lane);
@@ -356,6 +348,24 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
         const int r3 = a.oh3 * a.ow3;
         conv_from_lds<32, 32, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, M3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
                                  J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane, a.rowtab + 2 * CONV_ROWTAB, tab3[0], tab3[1]);
+    }
+    // ---- training: a1 and a2 leave as the piece planes they are in LDS (the convolutional backward's operands, fused_bwd.hip) in ONE burst of
+    //      16-byte copies at the very end: stores from the layers' epilogues sat in front of the next layer's weight requests (loads and
+    //      stores retire in order), +2.5 us on the training workgroups, which set the kernel's duration --------------------------------
+    if (J.write_all) {                                              // block-uniform; a1 is dead but intact since conv2, a2 since conv3
+        __syncthreads();
+        const int r2 = a.oh2 * a.ow2;
+        // a1: LDS rows of 72 halves -> global rows of 64 (8 slots of 16 B per row and plane); a2: rows of 40 -> 32 (4 slots)
+        for (int i = tid; i < 2 * M1 * 8; i += CONV_THREADS) {
+            const int piece = i >= M1 * 8 ? 1 : 0, q = i - piece * M1 * 8, row = q >> 3, part = q & 7;
+            *reinterpret_cast<u32x4*>(J.a1_pl + piece * J.a1_lo + ((size_t)b0 * r1 + row) * 64 + 8 * part) =
+                *reinterpret_cast<const u32x4*>(s_a1 + piece * lo1 + row * 72 + 8 * part);
+        }
+        for (int i = tid; i < 2 * M2 * 4; i += CONV_THREADS) {
+            const int piece = i >= M2 * 4 ? 1 : 0, q = i - piece * M2 * 4, row = q >> 2, part = q & 3;
+            *reinterpret_cast<u32x4*>(J.a2_pl + piece * J.a2_lo + ((size_t)b0 * r2 + row) * 32 + 8 * part) =
+                *reinterpret_cast<const u32x4*>(s_a2 + piece * lo2 + row * 40 + 8 * part);
+        }
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 7);
     DQ_STAMP_WG(DQ_TAG_CONV_FWD, 1);
@@ -798,11 +808,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
             const int k = 32 * h + 8 * kb + e;
             v[e] = k < a.K1 ? params[a.w1_off + (size_t)k * 64 + 4 * j + t] : 0.f;
         }
-    } else {                                                        // data gradient: B(n = 8kb + e, c) = W[tap][c][n]
+    } else {                                                        // data gradient: B(n = 8kb + e, c) = W[tap][c][n], tile t lane j: c = 2j + t
         const bool c3 = blk_id < 32;
         const int b = c3 ? blk_id - 24 : blk_id - 32;               // conv3: [tap][t]; conv2: [half][tap][t]
         const int t = b & 1, tap = (b >> 1) & 3, half = b >> 3, cin = c3 ? 32 : 64;
-        const float* w = params + (c3 ? w3_off : w2_off) + (size_t)(tap * cin + 32 * half + 16 * t + j) * 32 + 8 * kb;
+        const float* w = params + (c3 ? w3_off : w2_off) + (size_t)(tap * cin + 32 * half + 2 * j + t) * 32 + 8 * kb;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = w[e];
     }
@@ -1045,7 +1055,8 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         C.params = jb.params_dev; C.packed = static_cast<const u32x4*>(packed); C.obs = jb.obs_dev; C.index = jb.index_dev; C.index_off = jb.index_off;
         C.index_mod = jb.index_mod > 0 ? jb.index_mod : 0x7fffffff;
         C.batch = jb.batch; C.write_all = training; C.wg0 = conv_wgs; ca.wg_first[i] = conv_wgs; da.wg_first[i] = dense_wgs;
-        C.act_out[0] = Q->act[0][0]; C.act_out[1] = nullptr; C.act_out[2] = x;
+        C.act_out[0] = nullptr; C.act_out[1] = nullptr; C.act_out[2] = x;
+        C.a1_pl = reinterpret_cast<unsigned short*>(Q->act[0][0]); C.a1_lo = (size_t)Q->cfg.max_batch * L1.rows * 64;
         C.a2_pl = reinterpret_cast<unsigned short*>(Q->act[0][1]); C.a2_lo = (size_t)Q->cfg.max_batch * L2.rows * 32;
         conv_wgs += (jb.batch + cp.S - 1) / cp.S;
         DenseJob& D = da.job[i];

@@ -738,7 +738,8 @@ struct ConvBwdArgs {
     const u8* obs;
     const int32_t* index;
     int index_off, index_mod;
-    const float* a1;                    // saved activations of the training forward (global NHWC)
+    const unsigned short* a1p;          // saved first-convolution output [batch*r1][64] as f16 piece planes (h plane; the l plane a1_lo halves further)
+    size_t a1_lo;
     const unsigned short* a2p;          // saved second-convolution output [batch*r2][32] as f16 piece planes (h plane; the l plane a2_lo halves further)
     size_t a2_lo;
     const unsigned short* g3p;          // [batch*r3][32] gradient w.r.t. conv3's pre-activation output, as f16 piece planes (l plane g3_lo halves further)
@@ -821,10 +822,10 @@ __device__ __forceinline__ F16x2 lds_tr8(const unsigned short* p0, const unsigne
 // One tap = one K = 32 block of the f16 MFMA: A = the 32 channels of g at the tap's pixel, B = the tap's weights (registers).
 //   GPL: g is a piece-plane image [rows][PL32] (l plane g_lo halves further): A = one ds_read_b128 per piece; else an f32 image
 //        [rows][36], split on the fly.  Both have an all-zero row at index `zero_row`.
-//   OPL: act is a piece-plane image [pixels][PL32] (l plane act_lo halves further; c_lo = 0): the mask is "a magnitude bit in either
+//   OPL: act is a piece-plane image [pixels][PSA halves] (l plane act_lo halves further): the mask is "a magnitude bit in either
 //        piece", the result is split on write -- same address as the activation it replaces, so in place; else f32 [pixels][PSA].
 // dtab[m] (LDS, host-built): row of g under input pixel m's own position, s * oh * ow + iy * ow + ix, | iy << 16 | ix << 24.
-// colsum (OPL only): this lane's running column sums of the result (columns j, 16 + j) -- the bias gradient of the layer below.
+// colsum (OPL only): this lane's running column sums of the result (columns c_lo + 2j, c_lo + 2j + 1) -- the bias gradient of the layer below.
 template <int PSA, bool GPL, bool OPL>
 __device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const void* __restrict__ gv, int g_lo, int zero_row, void* __restrict__ actv,
                                               int act_lo, int c_lo, const int* __restrict__ dtab, int oh, int ow, int M, int tile_first,
@@ -860,28 +861,26 @@ __device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const voi
 #pragma unroll
             for (int t = 0; t < 2; ++t) mma_f16x3(av[tap], bw[tap][t], acc[t][0], acc[t][1]);
         }
-        // C/D layout: col = lane & 15 -> channel c_lo + 16t + j, row = (lane >> 4) * 4 + reg
+        // C/D layout: col = lane & 15 -> channel c_lo + 2j + t (the packed weights' column order), row = (lane >> 4) * 4 + reg
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mo = tile * 16 + 4 * kb + r;
             if (mo >= M) continue;
             if constexpr (OPL) {
-                unsigned short* ph = static_cast<unsigned short*>(actv) + mo * PL32 + j;
-                float v[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const u32 bits = (u32)ph[16 * t] | (u32)ph[16 * t + act_lo];
-                    v[t] = (bits & 0x7fffu) != 0u ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
-                    colsum[t] += v[t];
-                }
+                // this lane's two results are ADJACENT channels c_lo + 2j, + 1 (the packed weights' column order, qnet.h PK_CONV*_DG): the
+                // activation's pieces and the result's are one 4-byte LDS access per plane
+                u32* ph = reinterpret_cast<u32*>(static_cast<unsigned short*>(actv) + mo * PSA + c_lo + 2 * j);
+                const u32 bits = ph[0] | ph[act_lo >> 1];
+                const float v0 = (bits & 0x7fffu) != 0u ? f16x2_sum(acc[0][0][r], acc[0][1][r]) : 0.f;
+                const float v1 = (bits & 0x7fff0000u) != 0u ? f16x2_sum(acc[1][0][r], acc[1][1][r]) : 0.f;
+                colsum[0] += v0; colsum[1] += v1;
                 u32 h, l;
-                split_f16x2_pair(v[0], v[1], h, l);
-                ph[0] = (unsigned short)h; ph[16] = (unsigned short)(h >> 16);
-                ph[act_lo] = (unsigned short)l; ph[16 + act_lo] = (unsigned short)(l >> 16);
+                split_f16x2_pair(v0, v1, h, l);
+                ph[0] = h; ph[act_lo >> 1] = l;
             } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    float* p = static_cast<float*>(actv) + mo * PSA + c_lo + 16 * t + j;
+                    float* p = static_cast<float*>(actv) + mo * PSA + c_lo + 2 * j + t;
                     *p = *p > 0.f ? f16x2_sum(acc[t][0][r], acc[t][1][r]) : 0.f;
                 }
             }
@@ -889,7 +888,7 @@ __device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const voi
     }
 }
 
-#define A1PS 64                         // row stride of the a1 image: unpadded, because it is filled by LDS-DMA (1 KB contiguous per wave instruction)
+#define A1PS 64                         // row stride (halves) of the a1 piece planes: unpadded, because they are filled by LDS-DMA (1 KB contiguous per wave instruction)
 
 template <int KG1>                      // first convolution's K padded to 16 * KG1
 __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdArgs a) {
@@ -932,9 +931,9 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     // dW1 [16 KG1 x 64]: tile id = wave + 8u -> k-tile id>>2, n-tile wave & 3 (the same for every u)
     const int kyx = wave >> 1, ky = kyx >> 1, kx = kyx & 1;
     const int aoff3 = (ky * a.ow2 + kx) * PL32 + 16 * (wave & 1);         // (t3: half offsets of a2's plane rows; t2: float offsets of a1's rows)
-    const int aoff2 = (ky * a.ow1 + kx) * A1PS + 32 * (wave & 1) + j;
+    const int aoff2 = (ky * a.ow1 + kx) * A1PS + 32 * (wave & 1);          // (t2: half offsets of a1's plane rows)
     f32x4 acc3[2], acc3l[2], acc2[2][2], acc2l[2][2], acc1[NW1], acc1l[NW1];
-    float bs3 = 0.f, bs2[2] = {0.f, 0.f}, bs1 = 0.f, bs_unused[2] = {0.f, 0.f};     // bs2: every wave's share of g2's column sums (its tiles' rows); bs3: this thread's share of g3's column tid & 31
+    float bs3 = 0.f, bs2[2] = {0.f, 0.f}, bs1[2] = {0.f, 0.f};     // bs2 / bs1: every wave's share of g2's / g1's column sums (its tiles' rows); bs3: this thread's share of g3's column tid & 31
 #pragma unroll
     for (int t = 0; t < 2; ++t) { acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[0][t] = acc3[t]; acc2[1][t] = acc3[t]; acc2l[0][t] = acc3[t]; acc2l[1][t] = acc3[t]; acc3l[t] = acc3[t]; }
 #pragma unroll
@@ -944,15 +943,18 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     //      k + 1's inputs land while group k computes.  (All workgroups run in lockstep: a load phase of its own is a burst on HBM
     //      that nothing overlaps.)  One wave instruction writes 64 lanes x 16 B (or x 4 B) CONTIGUOUSLY in LDS from per-lane global
     //      addresses; inactive lanes write nothing.
-    // a1 [M1][64]: wave w copies 1 KB chunks w, w + 8, ...  Double-buffered (a1 is live until the end of dW1).
-    auto issue_a1 = [&](int g, float* dst) {
+    // a1 piece planes [M1][64 halves] each: wave w copies 1 KB chunks w, w + 8, ... of the h plane, then of the l plane (LA1 halves further in
+    // LDS).  Double-buffered (a1, then g1 in place, is live until the end of dW1).
+    const int LA1 = (S * r1 * A1PS + 511) & ~511;                    // halves from a1's h plane to its l plane (whole 1 KB chunks)
+    auto issue_a1 = [&](int g, unsigned short* dst) {
         const int gb0 = g * S, gM1 = min(S, a.batch - gb0) * r1;
-        const char* src = reinterpret_cast<const char*>(a.a1 + (size_t)gb0 * r1 * 64);
-        const int bytes = gM1 * 256, chunks = (bytes + 1023) >> 10;
-        for (int ch = wave; ch < chunks; ch += CB_WAVES) {
+        const int bytes = gM1 * A1PS * 2, chunks = (bytes + 1023) >> 10;
+        for (int c = wave; c < 2 * chunks; c += CB_WAVES) {
+            const int piece = c >= chunks ? 1 : 0, ch = c - piece * chunks;
+            const char* src = reinterpret_cast<const char*>(a.a1p + piece * a.a1_lo + (size_t)gb0 * r1 * A1PS);
             int off = ch * 1024 + lane * 16;
             if (off >= bytes) off = 0;                                  // tail lanes: a valid address; they land in the image's padding
-            __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) u32*)(dst + ch * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) u32*)(dst + piece * LA1 + ch * 512), 16, 0, 0);
         }
     };
     // piece planes [rows][32 halves] (a2, g3) -> LDS rows of PL32 halves = 5 lane slots of 16 B (slot 4 of every row is padding), both planes
@@ -992,13 +994,13 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         issue_obs(g);
         issue_g3(g, gns * r3);
         issue_a2(g, gns * r2);
-        if (a.a1_alt) issue_a1(g, reinterpret_cast<float*>(smem + a.off_a1));
+        if (a.a1_alt) issue_a1(g, reinterpret_cast<unsigned short*>(smem + a.off_a1));
     }
 
     F16x2 bw[4][2];                                                 // data-gradient weights (f16 pieces): loaded one phase ahead of their use
     int it = 0;
     for (int grp = blockIdx.x; grp < a.groups; grp += gridDim.x, ++it) {
-        float* s_a1 = reinterpret_cast<float*>(smem + a.off_a1 + (it & 1) * a.a1_alt);
+        unsigned short* s_a1 = reinterpret_cast<unsigned short*>(smem + a.off_a1 + (it & 1) * a.a1_alt);      // a1, then g1 in place: piece planes
         const int b0 = grp * S, ns = min(S, a.batch - b0);
         const int M1 = ns * r1, M2 = ns * r2, M3 = ns * r3;
         const int nxt = grp + (int)gridDim.x;
@@ -1099,15 +1101,16 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         if (nxt < a.groups) {                                       // the observation slots and g3 are dead now; so is the other a1 buffer
             issue_obs(nxt);
             issue_g3(nxt, ns_nxt * r3);
-            if (a.a1_alt) issue_a1(nxt, reinterpret_cast<float*>(smem + a.off_a1 + ((it + 1) & 1) * a.a1_alt));
+            if (a.a1_alt) issue_a1(nxt, reinterpret_cast<unsigned short*>(smem + a.off_a1 + ((it + 1) & 1) * a.a1_alt));
         }
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 6);
         // ---- dW2 += im2col(a1)^T g2 -----------------------------------------------------------------------------------
         {
             // One K = 32 block = 32 rows, lane group kq supplies rows m0 + 4kq + (e & 3) + 16 (e >> 2) of both operands (any assignment of the
-            // block's rows to (kq, e) is a permutation of the reduction index as long as both operands use it).  A = a1's columns (f32 image:
-            // eight ds_read_b32 per tile, split here); G = g2's columns j, 16 + j: ready-made pieces (the g2 phase split them on write),
-            // four transposing reads per tile and piece pair -- no arithmetic.  The reads of trip t + 1 are issued before the MFMAs of trip t.
+            // block's rows to (kq, e) is a permutation of the reduction index as long as both operands use it).  A = a1's columns of the wave's tap,
+            // G = g2's columns j, 16 + j: both ready-made pieces (the forward saved a1 as pieces, the g2 phase split g2 on write), four
+            // transposing reads per tile and piece pair -- no arithmetic at all beside the MFMAs.  The reads of trip t + 1 are issued before the
+            // MFMAs of trip t.
             const int ri = j >> 2, cseg = 4 * (j & 3);
             auto rdG = [&](int m0, F16x2& G0, F16x2& G1) {
                 const int r0 = min(m0 + 4 * kq + ri, M2 - 1), r1 = min(m0 + 16 + 4 * kq + ri, M2 - 1);      // (rows past M2: masked in mm)
@@ -1116,27 +1119,14 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 G0 = lds_tr8(p0, p1, LA2);
                 G1 = lds_tr8(p0 + 16, p1 + 16, LA2);
             };
-            auto rd = [&](int m0, float (&av0)[8], float (&av1)[8]) {
-                if (m0 + 32 <= M2) {                                  // wave-uniform: no clamps, no selects, affine addresses
-                    const int* tp = t2 + m0 + 4 * kq;
-                    const float* ab = s_a1 + aoff2;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float* ap = ab + tp[(e & 3) + 16 * (e >> 2)];
-                        av0[e] = ap[0];
-                        av1[e] = ap[16];
-                    }
-                } else {                                              // the group's last block: clamped rows (their g is zeroed in mm)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int mc = min(m0 + 4 * kq + (e & 3) + 16 * (e >> 2), M2 - 1);
-                        const float* ap = s_a1 + t2[mc] + aoff2;
-                        av0[e] = ap[0];
-                        av1[e] = ap[16];
-                    }
-                }
+            auto rdA = [&](int m0, F16x2& A0, F16x2& A1) {
+                const int r0 = min(m0 + 4 * kq + ri, M2 - 1), r1 = min(m0 + 16 + 4 * kq + ri, M2 - 1);
+                const unsigned short* p0 = s_a1 + t2[r0] + aoff2 + cseg;
+                const unsigned short* p1 = s_a1 + t2[r1] + aoff2 + cseg;
+                A0 = lds_tr8(p0, p1, LA1);
+                A1 = lds_tr8(p0 + 16, p1 + 16, LA1);
             };
-            auto mm = [&](int m0, const float (&av0)[8], const float (&av1)[8], F16x2& G0, F16x2& G1) {
+            auto mm = [&](int m0, const F16x2& A0, const F16x2& A1, F16x2& G0, F16x2& G1) {
                 if (m0 + 32 > M2) {                                   // rows past M2: their halves of g's pieces cleared (element e = half e of the operand)
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -1145,20 +1135,17 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                         G0.h[d] &= lo | hi; G0.l[d] &= lo | hi; G1.h[d] &= lo | hi; G1.l[d] &= lo | hi;
                     }
                 }
-                const F16x2 A0 = split_f16x2(f32x4{av0[0], av0[1], av0[2], av0[3]}, f32x4{av0[4], av0[5], av0[6], av0[7]});
-                const F16x2 A1 = split_f16x2(f32x4{av1[0], av1[1], av1[2], av1[3]}, f32x4{av1[4], av1[5], av1[6], av1[7]});
                 mma_f16x3(A0, G0, acc2[0][0], acc2l[0][0]);
                 mma_f16x3(A0, G1, acc2[0][1], acc2l[0][1]);
                 mma_f16x3(A1, G0, acc2[1][0], acc2l[1][0]);
                 mma_f16x3(A1, G1, acc2[1][1], acc2l[1][1]);
             };
-            float a0A[8], a1A[8], a0B[8], a1B[8];
-            F16x2 g0A, g1A, g0B, g1B;
-            rdG(0, g0A, g1A); rd(0, a0A, a1A);
+            F16x2 a0A, a1A, a0B, a1B, g0A, g1A, g0B, g1B;
+            rdG(0, g0A, g1A); rdA(0, a0A, a1A);
             for (int m0 = 0;;) {
-                rdG(m0 + 32, g0B, g1B); rd(m0 + 32, a0B, a1B);
+                rdG(m0 + 32, g0B, g1B); rdA(m0 + 32, a0B, a1B);
                 mm(m0, a0A, a1A, g0A, g1A); m0 += 32; if (m0 >= M2) break;
-                rdG(m0 + 32, g0A, g1A); rd(m0 + 32, a0A, a1A);
+                rdG(m0 + 32, g0A, g1A); rdA(m0 + 32, a0A, a1A);
                 mm(m0, a0B, a1B, g0B, g1B); m0 += 32; if (m0 >= M2) break;
             }
         }
@@ -1167,7 +1154,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         __syncthreads();                                            // every wave is done reading a1
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 8);
         // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1: waves 0-3 channels 0..31, waves 4-7 channels 32..63 -------------
-        dgrad_inplace<A1PS, true, false>(bw, s_a2, LA2, zero2, s_a1, 0, 32 * (wave >> 2), d1, a.oh2, a.ow2, M1, wave & 3, 4, lane, bs_unused);
+        dgrad_inplace<A1PS, true, true>(bw, s_a2, LA2, zero2, s_a1, LA1, 32 * (wave >> 2), d1, a.oh2, a.ow2, M1, wave & 3, 4, lane, bs1);
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 9);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 10);
@@ -1175,54 +1162,52 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         // ---- dW1 += patches^T g1 ----------------------------------------------------------------------------------------
         {
             const u8* cp = s_col + 16 * (wave >> 2) + j;           // + 32 per further tile of this wave (k-tile + 2)
-            const float* gp = s_a1 + 16 * (wave & 3) + j;
-            // On the f16 pipe: the patch operand is binary (exact in f16) and g1 is split into two f16 pieces (qnet.h), so one K = 32
-            // MFMA per piece replaces eight f32 MFMAs (64 instead of 512 pipe cycles per 32 rows and two tiles) and the eight byte ->
-            // float conversions per tile become four multiplies.  Lane (j, kq) supplies rows m0 + kq + 4e of column j of both
-            // operands (lanes kq, kq + 1 read patch bytes 16 banks apart).  The LDS reads of trip t + 1 are issued before the MFMAs of trip t.
-            auto rd = [&](int m0, u32 (&ab)[NW1][8], float (&g)[8]) {
+            // On the f16 pipe: the patch operand is binary (exact in f16: four multiplies make a tile's eight halves), g1 arrives as ready-made
+            // pieces (split on write by the g1 phase) through transposing reads: one K = 32 MFMA per piece.  Lane group kq supplies rows
+            // m0 + kq + 4 (e & 3) + 16 (e >> 2) of both operands (lanes kq, kq + 1 read patch bytes 16 banks apart; this lane points at row
+            // kq + 4 (j >> 2) (+ 16), column segment 4 (j & 3) of the transposing reads).  The LDS reads of trip t + 1 are issued before the
+            // MFMAs of trip t.
+            const int cseg = 16 * (wave & 3) + 4 * (j & 3), rj = kq + 4 * (j >> 2);
+            auto rd = [&](int m0, u32 (&ab)[NW1][8], F16x2& G) {
+                const int r0 = min(m0 + rj, M1 - 1), r1 = min(m0 + 16 + rj, M1 - 1);      // (rows past M1: masked in mm)
+                G = lds_tr8(s_a1 + r0 * A1PS + cseg, s_a1 + r1 * A1PS + cseg, LA1);
                 if (m0 + 32 <= M1) {                                  // wave-uniform: no clamps, no selects, affine addresses
                     const u8* cb = cp + (m0 + kq) * KP;
-                    const float* gb = gp + (m0 + kq) * A1PS;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+#pragma unroll
+                        for (int u = 0; u < NW1; ++u) ab[u][e] = cb[(4 * (e & 3) + 16 * (e >> 2)) * KP + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)];
+                } else {                                              // the group's last block: clamped rows (their g is cleared in mm)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-#pragma unroll
-                        for (int u = 0; u < NW1; ++u) ab[u][e] = cb[4 * e * KP + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)];
-                        g[e] = gb[4 * e * A1PS];
-                    }
-                } else {                                              // the group's last block: clamped rows, raw values (masked in mm)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int mc = min(m0 + kq + 4 * e, M1 - 1);
+                        const int mc = min(m0 + kq + 4 * (e & 3) + 16 * (e >> 2), M1 - 1);
 #pragma unroll
                         for (int u = 0; u < NW1; ++u) ab[u][e] = cp[mc * KP + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)];     // 0 or 1
-                        g[e] = gp[mc * A1PS];
                     }
                 }
             };
             // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
             // (each copy waits for the result) -- a tile this wave does not have accumulates garbage that is never stored
-            auto mm = [&](int m0, const u32 (&ab)[NW1][8], float (&g)[8]) {
-                if (m0 + 32 > M1) {                                   // rows past M1: masked through g alone, a block after the reads
+            auto mm = [&](int m0, const u32 (&ab)[NW1][8], F16x2& G) {
+                if (m0 + 32 > M1) {                                   // rows past M1: their halves of g's pieces cleared
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) g[e] = m0 + kq + 4 * e < M1 ? g[e] : 0.f;
+                    for (int d = 0; d < 4; ++d) {
+                        const u32 lo = m0 + kq + 4 * ((2 * d) & 3) + 16 * ((2 * d) >> 2) < M1 ? 0xffffu : 0u;
+                        const u32 hi = m0 + kq + 4 * ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < M1 ? 0xffff0000u : 0u;
+                        G.h[d] &= lo | hi; G.l[d] &= lo | hi;
+                    }
                 }
-                const F16x2 gb = split_f16x2(f32x4{g[0], g[1], g[2], g[3]}, f32x4{g[4], g[5], g[6], g[7]});
 #pragma unroll
                 for (int u = 0; u < NW1; ++u) {
                     u32x4 av;
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) av[e >> 1] = __umul24(ab[u][e] | (ab[u][e + 1] << 16), 0x3c00u);      // f16(1.0) = 0x3c00; v_mul_u32_u24 (a 32-bit multiply is quarter rate)
-                    acc1[u] = MFMA_F16(av, gb.h, acc1[u]);
-                    acc1l[u] = MFMA_F16(av, gb.l, acc1l[u]);
-                }
-                if (wave < 4) {                                     // (waves 0 .. 3 store the bias gradient of their column tile)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bs1 += g[e];
+                    acc1[u] = MFMA_F16(av, G.h, acc1[u]);
+                    acc1l[u] = MFMA_F16(av, G.l, acc1l[u]);
                 }
             };
             u32 abA[NW1][8], abB[NW1][8];
-            float gA[8], gB[8];
+            F16x2 gA, gB;
             rd(0, abA, gA);
             for (int m0 = 0;;) {
                 rd(m0 + 32, abB, gB);
@@ -1253,23 +1238,19 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 const int k = 16 * kt + 4 * kq + r;
                 if (k < a.K1) out[a.w_off[0] + k * 64 + 16 * nt + j] = f16x2_sum(acc1[u][r], acc1l[u][r]);
             }
-            if (kt == 0) {                                          // bias gradient = column sums of g1
-                float v = bs1;
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                if (kq == 0) out[a.b_off[0] + 16 * nt + j] = v;
-            }
         }
     }
-    {   // the second convolution's: every wave holds the column sums of the g2 tiles it produced -- combined in fixed order through LDS
+    {   // the second and first convolution's: every wave holds the column sums of the g2 / g1 tiles it produced (g2: columns 2j + t; g1:
+        // columns 32 (wave >> 2) + 2j + t) -- combined in fixed order through LDS
         __syncthreads();                                            // (every LDS image is dead)
         float* s_b = reinterpret_cast<float*>(smem);
         s_b[256 + tid] = bs3;                                       // the third's: thread (column tid & 31, row class tid >> 5)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            float v = bs2[t];
+            float v = bs2[t], w1 = bs1[t];
             v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            if (kq == 0) s_b[wave * 32 + 16 * t + j] = v;
+            w1 += __shfl_xor(w1, 16); w1 += __shfl_xor(w1, 32);
+            if (kq == 0) { s_b[wave * 32 + 2 * j + t] = v; s_b[768 + wave * 32 + 2 * j + t] = w1; }      // (dgrad_inplace: this lane's columns 2j + t)
         }
         __syncthreads();
         if (tid < 32) {
@@ -1282,6 +1263,12 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 #pragma unroll
             for (int cl = 0; cl < CB_THREADS / 32; ++cl) v += s_b[256 + cl * 32 + (tid - 32)];
             out[a.b_off[2] + tid - 32] = v;
+        } else if (tid < 128) {
+            const int c = tid - 64, half = c >> 5;                  // column c of g1: waves 4 half .. 4 half + 3
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += s_b[768 + (4 * half + w) * 32 + (c & 31)];
+            out[a.b_off[0] + c] = v;
         }
     }
 }
@@ -1325,7 +1312,7 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
         size_t off = up16((size_t)S * P->slot);
         P->off_mis = (int)off; off += up16((size_t)S * 4);
         off = (off + 1023) & ~(size_t)1023;                                            // LDS-DMA target: whole 1 KB chunks
-        const size_t a1_bytes = ((size_t)S * L1.rows * A1PS * 4 + 1023) & ~(size_t)1023;
+        const size_t a1_bytes = 2 * (((size_t)S * L1.rows * A1PS * 2 + 1023) & ~(size_t)1023);      // two piece planes, whole 1 KB chunks each
         P->off_a1 = (int)off; off += nbuf * a1_bytes;
         P->a1_alt = nbuf == 2 ? (int)a1_bytes : 0;
         P->off_a2 = (int)off; off += up16((size_t)2 * (S * L2.rows + 1) * PL32 * 2);      // a2 / g2: two f16 piece planes, rows of PL32 halves
@@ -1516,7 +1503,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     memset(&ca, 0, sizeof(ca));
     ca.params = params_dev; ca.obs = Q->last_obs; ca.index = Q->last_index; ca.index_off = Q->last_index_off;
     ca.index_mod = Q->last_index_mod > 0 ? Q->last_index_mod : 0x7fffffff;
-    ca.a1 = Q->act[0][0]; ca.a2p = reinterpret_cast<const unsigned short*>(Q->act[0][1]); ca.a2_lo = (size_t)Q->cfg.max_batch * L2.rows * 32;
+    ca.a1p = reinterpret_cast<const unsigned short*>(Q->act[0][0]); ca.a1_lo = (size_t)Q->cfg.max_batch * L1.rows * 64;
+    ca.a2p = reinterpret_cast<const unsigned short*>(Q->act[0][1]); ca.a2_lo = (size_t)Q->cfg.max_batch * L2.rows * 32;
     ca.g3p = reinterpret_cast<const unsigned short*>(Q->gz[nc - 1]); ca.g3_lo = (size_t)Q->cfg.max_batch * L3.rows * 32;
     DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
     ca.packed = static_cast<const u32x4*>(Q->last_train_packed);

@@ -145,6 +145,8 @@ struct ConvJob {
     const int32_t* index;
     int index_off, index_mod, batch;
     float* act_out[3];                 // global NHWC [batch*oh*ow, cout]; [2] always written, [0] in training; [1] unused: in training the second
+    unsigned short* a1_pl;             // (the first's the same way: [batch*oh1*ow1][64], l plane a1_lo halves further)
+    size_t a1_lo;
     unsigned short* a2_pl;             // convolution's output is kept as f16 piece planes [batch*oh2*ow2][32] (h plane; the l plane a2_lo halves
     size_t a2_lo;                      // further) -- the form the convolutional backward consumes it in (fused_bwd.hip)
     int write_all;                     // training: write every layer
@@ -157,8 +159,8 @@ struct ConvJob {
 // Sections, in u32x4 units:
 //   PK_CONV2_FWD  [8 k-blocks][2 column tiles]      B(k = 32 blk + 8kb + e, col = 2j + t)            = W2[k][col]
 //   PK_CONV3_FWD  [4][2]                            same for conv3
-//   PK_CONV3_DG   [4 taps][2]                       B(n = 8kb + e, c = 16t + j)                      = W3[tap][c][n]
-//   PK_CONV2_DG   [2 channel halves][4 taps][2]     B(n = 8kb + e, c = 32 half + 16t + j)            = W2[tap][c][n]
+//   PK_CONV3_DG   [4 taps][2]                       B(n = 8kb + e, c = 2j + t)                       = W3[tap][c][n]   (a lane's two results are
+//   PK_CONV2_DG   [2 channel halves][4 taps][2]     B(n = 8kb + e, c = 32 half + 2j + t)             = W2[tap][c][n]    adjacent channels)
 //   PK_CONV1      [3 k-blocks][4 column tiles]      B(k = 32 blk + 8kb + e, col = 4j + t)            = W1[k][col], 0 past K1
 #define PK_BLOCK 128                  // u32x4 per block (2 pieces x 64 lanes)
 #define PK_LO 64                      // the l pieces of a block
