@@ -159,6 +159,11 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python deepq-decoding_amd/build.py` "
                 "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
         try:
+            # torch's HIP runtime is initialised BEFORE this library is loaded: loaded first (e.g. build() and smoke() in one process),
+            # the library's hipGetDeviceCount then saw no device on the GPU box
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
             L = ctypes.CDLL(LIB_PATH)
         except OSError as e:
             raise DeepQError(f"cannot load {LIB_PATH}: {e}") from e
