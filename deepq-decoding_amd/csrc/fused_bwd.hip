@@ -444,10 +444,34 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
 // in flight; double-buffered LDS, one barrier per iteration.  Bias gradients (column sums of G) come out of the matrix pipe as well: a
 // tile whose A operand is all ones.  Rows past the slice are clamped on load and zeroed in G only (a zero factor kills the product);
 // columns past K / N are clamped too and only reach accumulators that are never stored.
+// Row stride (halves) of an LDS piece-plane image of 32 channels: 64 data bytes + 16 of padding, filled by LDS-DMA in 16-byte slots
+#define PL32 40
+
+// Transposing LDS read (ds_read_b64_tr_b16, tools/probe/tr_probe.hip): within a 16-lane group, lanes 4r .. 4r+3 each point at a 4-half
+// segment of row r (r = 0 .. 3, any addresses); lane i receives column i of those four rows.  Two of them are the eight reduction
+// indices of a 16 x 16 x 32 MFMA operand held ROW-major in LDS -- what the weight gradients (a reduction over pixels) need.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr4(const unsigned short* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+// rows p0 (reduction indices 0 .. 3 of this lane group) and p1 (4 .. 7), both pieces (l plane `lo` halves further)
+__device__ __forceinline__ F16x2 lds_tr8(const unsigned short* p0, const unsigned short* p1, int lo) {
+    const uint2 a = lds_tr4(p0), b = lds_tr4(p1), c = lds_tr4(p0 + lo), d = lds_tr4(p1 + lo);
+    F16x2 o;
+    o.h = u32x4{a.x, a.y, b.x, b.y};
+    o.l = u32x4{c.x, c.y, d.x, d.y};
+    return o;
+}
+
 #define WGRAD_THREADS 256
 #define WGRAD_WAVES 4
 #define WGRAD_PIECE 2048                // halves per piece plane: 64 columns x 32 batch rows
-#define DENSE_WGRAD_LDS (2 * 2 * 2 * 2 * WGRAD_PIECE * 2)      // [buffer][block][operand][piece] planes: 64 KB
+#define WG_PS 72                        // halves per LDS row of an operand image: 64 columns + one 16-byte padding slot (rows 36 dwords apart: the four rows of
+                                        // a transposing read fall into distinct banks)
+#define WG_IMG (64 * WG_PS)             // halves per image (64 rows of one operand and piece)
+#define WG_BUF (4 * WG_IMG)             // ... per buffer: [operand][piece]
+#define DENSE_WGRAD_LDS (2 * WG_BUF * 2)                       // two buffers: 72 KB
 
 // halves from a piece plane's start to the 8 rows of chunk `chunk` (0..3) of column `col` (0..63)
 __device__ __forceinline__ int wgrad_off(int col, int chunk) {
@@ -488,7 +512,7 @@ static void wgrad_slicing(int B, int* rows_per_slice, int* slices) {
 
 __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    unsigned short* s_t = reinterpret_cast<unsigned short*>(smem);   // [buf][blk][op][piece] swizzled planes
+    unsigned short* s_t = reinterpret_cast<unsigned short*>(smem);   // [buf][op][piece][64 rows][WG_PS] row-major piece planes
     // XCD-aware block -> (tile, slice) map: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of one batch
     // slice are given to ONE XCD (slice = XCD + 8 i): the slice's rows of X and G are then fetched from HBM/MALL once instead of
     // once per XCD.
@@ -503,157 +527,111 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     const int K = L.X.cols, N = L.G.cols, kbase = 64 * kt, nbase = 64 * nt;
     const int m0 = slice * a.rows_per_slice, m1 = min(a.batch, m0 + a.rows_per_slice);
     const int n_it = (m1 - m0 + 63) >> 6;
-    // ---- loader role of this wave: operand (0: X, 1: G) and block of the iteration -----------------------------------------
-    const int op = wave & 1, lblk = wave >> 1;
-    const WgradOperand& O = op ? L.G : L.X;
-    const int ld = O.ld, ncols = O.cols, cb0 = op ? nbase : kbase;
-    const bool planes = O.f32 == nullptr;                           // wave-uniform
-    // f32 operand: lane (g = kb, i = j) takes rows 8g .. 8g+7 of columns 4i .. 4i+3;  piece planes: lane (piece = lane >> 5,
-    // g = (lane >> 3) & 3, i = lane & 7) takes rows 8g .. 8g+7 of columns 8i .. 8i+7 of its piece
-    const int lg = planes ? (lane >> 3) & 3 : kb, li = planes ? lane & 7 : j, lpiece = lane >> 5;
-    // f32 rows are read as 4-byte-aligned dwordx4 wherever the quad starts inside the row: a quad that straddles the row's end takes the
-    // next row's first values with it (the buffers carry 16 bytes of slack behind their last row, qnet.hip) -- columns past N only reach
-    // accumulators that are never stored
-    const float* fsrc = planes ? nullptr : O.f32 + (cb0 + 4 * li < ncols ? cb0 + 4 * li : 0);
-    const unsigned short* psrc = planes ? O.planes + (size_t)lpiece * O.plane_stride + (cb0 + 8 * li < ld ? cb0 + 8 * li : 0) : nullptr;
-    (void)ncols;
-    int woff[8];                                                    // swizzled store offsets of this lane's columns (chunk lg)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) woff[c] = wgrad_off(planes ? 8 * li + c : 4 * li + (c & 3), lg) + (planes ? lpiece * WGRAD_PIECE : 0);
-    int aoff[2], boff[2];                                           // read offsets of this wave's 2 + 2 tiles (chunk kb)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) { aoff[t] = wgrad_off(32 * (wave >> 1) + 16 * t + j, kb); boff[t] = wgrad_off(32 * (wave & 1) + 16 * t + j, kb); }
     float* out = a.partial + (size_t)slice * a.pstride;
     float* s_o = reinterpret_cast<float*>(smem);                    // the finished tile [64][68], staged for row-wise stores
     DQ_STAMP(DQ_TAG_DENSE_WGRAD, 0);
     DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 0);
     DQ_STAMP_PAIR2(1);
-    // The whole loop is instantiated per operand format (FMT 0: piece planes, 1: f32) and the wave picks its copy once: with the format
-    // tested inside the loop, the branches' different load counts merge into an unknown number of loads in flight and hipcc waits for
-    // vmcnt(0) before every use -- no prefetch survives.
-    auto run = [&](auto fmt_tag) {
-        constexpr int FMT = decltype(fmt_tag)::value;
-        f32x4 acc[2][2], accx[2][2], accb[2], accbx[2];             // [k tile][n tile]: leading products / 2^11-scaled cross terms; bias tiles
+    // ---- staging: an iteration's 64 rows x 64 columns of both operands and both pieces = 4 images of 64 x 9 sixteen-byte slots (8 of data +
+    //      1 of padding, whose lane stays inactive) = 4 x 9 LDS-DMA instructions of 1 KB, nine per wave: instruction c = wave + 4k is chunk
+    //      c % 9 of image c / 9 (operand c / 18, piece (c / 9) & 1).  Per-lane constants of the wave's nine instructions: the row inside
+    //      the iteration and the global column offset (columns past the operand's row are clamped to 0: they only reach accumulators that
+    //      are never stored); -1 = padding slot.
+    int drow[9];
+    const unsigned short* dsrc[9];
 #pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
+    for (int k = 0; k < 9; ++k) {
+        const int c = wave + 4 * k, img = c / 9, ch = c - img * 9, q = ch * 64 + lane, row = q / 9, part = q - row * 9;
+        const WgradOperand& O = (img >> 1) ? L.G : L.X;
+        const int col = ((img >> 1) ? nbase : kbase) + 8 * part;
+        drow[k] = part < 8 ? row : -1;
+        dsrc[k] = O.planes + (size_t)(img & 1) * O.plane_stride + (col < O.ld ? col : 0);
+    }
+    const int ldx = L.X.ld, ldg = L.G.ld;
+    auto issue = [&](int it) {
+        unsigned short* dst = s_t + (it & 1) * WG_BUF;
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) { acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[ta][tb] = acc[ta][tb]; }
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) { accb[tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accbx[tb] = accb[tb]; }
-        const u32x4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};     // f16 1.0 x 8
-        u32 rawA[8][4], rawB[8][4];                                 // two iterations of rows in flight (f32 values or 8 halves per row)
-        auto load = [&](int it_, u32 (&raw)[8][4]) {
-            const int it = min(it_, n_it - 1);                      // past the end: re-read the last rows (unconditional loads: static wait counts)
-            const int r0 = m0 + 64 * it + 32 * lblk + 8 * lg;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const size_t ro = (size_t)min(r0 + e, m1 - 1) * ld;
-                if constexpr (FMT == 0) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(psrc + ro);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) raw[e][c] = v[c];
-                } else {
-                    const f32x4u v = *reinterpret_cast<const f32x4u*>(fsrc + ro);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) raw[e][c] = __float_as_uint(v[c]);
-                }
-            }
-        };
-        auto store_rows = [&](int it, const u32 (&raw)[8][4], auto tail_tag) {     // this lane's 8 rows, transposed: one 16-byte store per column and piece
-            constexpr bool tail = decltype(tail_tag)::value;        // rows of G past the slice are zeros
-            const int r0 = m0 + 64 * it + 32 * lblk + 8 * lg;
-            unsigned short* base = s_t + ((((it & 1) * 2 + lblk) * 2 + op) * 2) * WGRAD_PIECE;
-            if constexpr (FMT == 0) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    u32x4 o;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        u32 lo = raw[2 * d][c >> 1], hi = raw[2 * d + 1][c >> 1];
-                        if constexpr (tail) { lo = r0 + 2 * d < m1 ? lo : 0u; hi = r0 + 2 * d + 1 < m1 ? hi : 0u; }
-                        o[d] = __builtin_amdgcn_perm(hi, lo, (c & 1) ? 0x07060302u : 0x05040100u);
-                    }
-                    *reinterpret_cast<u32x4*>(base + woff[c]) = o;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (tail && r0 + e >= m1) ? 0.f : __uint_as_float(raw[e][c]);
-                    const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
-                    *reinterpret_cast<u32x4*>(base + woff[c]) = o.h;
-                    *reinterpret_cast<u32x4*>(base + woff[c] + WGRAD_PIECE) = o.l;
-                }
-            }
-        };
-        auto store = [&](int it, const u32 (&raw)[8][4]) {
-            // only the block that straddles the end of the slice masks rows -- a WAVE-uniform test (a per-lane one turns every select into a branch)
-            if (op && m0 + 64 * it + 32 * lblk + 32 > m1) store_rows(it, raw, std::true_type{});
-            else store_rows(it, raw, std::false_type{});
-        };
-        auto mm = [&](int it) {                                     // the iteration's two blocks: 8 ds_read_b128 + 16 MFMAs each
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const unsigned short* px = s_t + (((it & 1) * 2 + blk) * 2 + 0) * 2 * WGRAD_PIECE;
-                const unsigned short* pg = s_t + (((it & 1) * 2 + blk) * 2 + 1) * 2 * WGRAD_PIECE;
-                F16x2 xa[2], gb[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    xa[t].h = *reinterpret_cast<const u32x4*>(px + aoff[t]);
-                    xa[t].l = *reinterpret_cast<const u32x4*>(px + aoff[t] + WGRAD_PIECE);
-                    gb[t].h = *reinterpret_cast<const u32x4*>(pg + boff[t]);
-                    gb[t].l = *reinterpret_cast<const u32x4*>(pg + boff[t] + WGRAD_PIECE);
-                }
-#pragma unroll
-                for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < 2; ++tb) mma_f16x3(xa[ta], gb[tb], acc[ta][tb], accx[ta][tb]);
-                // column sums of G (every wave: a condition around an MFMA makes hipcc copy accumulators; only k-tile 0 stores them)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) { accb[tb] = MFMA_F16(ones, gb[tb].h, accb[tb]); accbx[tb] = MFMA_F16(ones, gb[tb].l, accbx[tb]); }
-            }
-        };
-        // one step: this iteration's rows (requested two iterations ago) -> pieces in LDS; request the rows of iteration it + 2 into the
-        // registers just freed; meet; multiply.  (No condition around the MFMAs: the loop leaves between steps.)
-        auto step = [&](int it, u32 (&raw)[8][4]) {
-            DQ_STAMP(DQ_TAG_DENSE_WGRAD, 1 + 3 * min(it, 7));
-            store(it, raw);
-            DQ_STAMP(DQ_TAG_DENSE_WGRAD, 2 + 3 * min(it, 7));
-            __builtin_amdgcn_sched_barrier(0);
-            load(it + 2, raw);
-            __builtin_amdgcn_sched_barrier(0);                      // (left alone, the scheduler sinks the loads to just before their use)
-            __syncthreads();
-            DQ_STAMP(DQ_TAG_DENSE_WGRAD, 3 + 3 * min(it, 7));
-            mm(it);
-        };
-        load(0, rawA);
-        load(1, rawB);
-        for (int it = 0;;) {
-            step(it, rawA); if (++it >= n_it) break;
-            step(it, rawB); if (++it >= n_it) break;
-        }
-        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 25);
-        // ---- the tile goes through LDS (C/D layout: this lane holds rows 4kb + r of column j of each 16 x 16 tile) so that it leaves as
-        //      whole 256-byte weight rows ---------------------------------------------------------------------------------------------
-        __syncthreads();                                            // every wave is done with the operand planes
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    s_o[(32 * (wave >> 1) + 16 * ta + 4 * kb + r) * 68 + 32 * (wave & 1) + 16 * tb + j] = f16x2_sum(acc[ta][tb][r], accx[ta][tb][r]);
-        if (kt == 0 && (wave >> 1) == 0 && kb == 0) {               // bias gradient: row 0 of the all-ones tiles
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                const int n = nbase + 32 * (wave & 1) + 16 * tb + j;
-                if (n < N) out[L.out_b + n] = f16x2_sum(accb[tb][0], accbx[tb][0]);
+        for (int k = 0; k < 9; ++k) {
+            const int c = wave + 4 * k, img = c / 9, ch = c - img * 9;      // wave-uniform
+            if (drow[k] >= 0) {
+                const size_t ro = (size_t)min(m0 + 64 * it + drow[k], m1 - 1) * ((img >> 1) ? ldg : ldx);      // rows past the slice: re-read its last row (G cleared in mm)
+                __builtin_amdgcn_global_load_lds(dsrc[k] + ro, (__attribute__((address_space(3))) u32*)(dst + img * WG_IMG + ch * 512), 16, 0, 0);
             }
         }
     };
-    if (planes) run(std::integral_constant<int, 0>{});              // wave-uniform; every copy meets the same barriers
-    else run(std::integral_constant<int, 1>{});
+    // ---- operands: row-major piece planes in LDS -> MFMA operand order by transposing reads (lds_tr8: this lane points at row ri, column
+    //      segment cseg of each four-row read; lane group kb supplies rows 4kb + (e & 3) + 16 (e >> 2) of a 32-row block) ------------------
+    const int ri = j >> 2, cseg = 4 * (j & 3);
+    f32x4 acc[2][2], accx[2][2], accb[2], accbx[2];                 // [k tile][n tile]: leading products / 2^11-scaled cross terms; bias tiles
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) { acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[ta][tb] = acc[ta][tb]; }
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) { accb[tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accbx[tb] = accb[tb]; }
+    const u32x4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};     // f16 1.0 x 8
+    auto mm = [&](int it) {                                         // the iteration's two blocks: 16 transposing reads + 16 MFMAs each
+        const unsigned short* base = s_t + (it & 1) * WG_BUF;
+        const bool tail = m0 + 64 * it + 64 > m1;                   // wave-uniform: only the slice's last iteration masks rows
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int r0 = (32 * blk + 4 * kb + ri) * WG_PS, r1 = r0 + 16 * WG_PS;
+            F16x2 xa[2], gb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int cx = 32 * (wave >> 1) + 16 * t + cseg, cg = 32 * (wave & 1) + 16 * t + cseg;
+                xa[t] = lds_tr8(base + r0 + cx, base + r1 + cx, WG_IMG);
+                gb[t] = lds_tr8(base + 2 * WG_IMG + r0 + cg, base + 2 * WG_IMG + r1 + cg, WG_IMG);
+            }
+            if (tail) {                                             // rows of G past the slice: their halves cleared (element e = half e of the operand)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int rb = m0 + 64 * it + 32 * blk + 4 * kb;
+                    const u32 lo = rb + ((2 * d) & 3) + 16 * ((2 * d) >> 2) < m1 ? 0xffffu : 0u;
+                    const u32 hi = rb + ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < m1 ? 0xffff0000u : 0u;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) { gb[t].h[d] &= lo | hi; gb[t].l[d] &= lo | hi; }
+                }
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) mma_f16x3(xa[ta], gb[tb], acc[ta][tb], accx[ta][tb]);
+            // column sums of G (every wave: a condition around an MFMA makes hipcc copy accumulators; only k-tile 0 stores them)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) { accb[tb] = MFMA_F16(ones, gb[tb].h, accb[tb]); accbx[tb] = MFMA_F16(ones, gb[tb].l, accbx[tb]); }
+        }
+    };
+    // one step: this wave's copies of iteration `it` have landed; meet (everybody's have, and everybody has left the other buffer); request
+    // iteration it + 1 into that buffer; multiply
+    issue(0);
+    for (int it = 0; it < n_it; ++it) {
+        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 1 + 3 * min(it, 7));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 2 + 3 * min(it, 7));
+        if (it + 1 < n_it) issue(it + 1);
+        DQ_STAMP(DQ_TAG_DENSE_WGRAD, 3 + 3 * min(it, 7));
+        mm(it);
+    }
+    DQ_STAMP(DQ_TAG_DENSE_WGRAD, 25);
+    // ---- the tile goes through LDS (C/D layout: this lane holds rows 4kb + r of column j of each 16 x 16 tile) so that it leaves as
+    //      whole 256-byte weight rows ---------------------------------------------------------------------------------------------
+    __syncthreads();                                                // every wave is done with the operand planes
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                s_o[(32 * (wave >> 1) + 16 * ta + 4 * kb + r) * 68 + 32 * (wave & 1) + 16 * tb + j] = f16x2_sum(acc[ta][tb][r], accx[ta][tb][r]);
+    if (kt == 0 && (wave >> 1) == 0 && kb == 0) {                   // bias gradient: row 0 of the all-ones tiles
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const int n = nbase + 32 * (wave & 1) + 16 * tb + j;
+            if (n < N) out[L.out_b + n] = f16x2_sum(accb[tb][0], accbx[tb][0]);
+        }
+    }
     // ---- one partial per (slice, tile) ------------------------------------------------------------------------------------------
     __syncthreads();
     {
@@ -795,26 +773,6 @@ __device__ __forceinline__ void dgrad_load_w(F16x2 (&bw)[4][2], const u32x4* __r
             const u32x4* pb = pk + (tap * 2 + t) * PK_BLOCK + lane;
             bw[tap][t].h = pb[0]; bw[tap][t].l = pb[PK_LO];
         }
-}
-
-// Row stride (halves) of an LDS piece-plane image of 32 channels: 64 data bytes + 16 of padding, filled by LDS-DMA in 16-byte slots
-#define PL32 40
-
-// Transposing LDS read (ds_read_b64_tr_b16, tools/probe/tr_probe.hip): within a 16-lane group, lanes 4r .. 4r+3 each point at a 4-half
-// segment of row r (r = 0 .. 3, any addresses); lane i receives column i of those four rows.  Two of them are the eight reduction
-// indices of a 16 x 16 x 32 MFMA operand held ROW-major in LDS -- what the weight gradients (a reduction over pixels) need.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 lds_tr4(const unsigned short* p) {
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
-    return __builtin_bit_cast(uint2, v);
-}
-// rows p0 (reduction indices 0 .. 3 of this lane group) and p1 (4 .. 7), both pieces (l plane `lo` halves further)
-__device__ __forceinline__ F16x2 lds_tr8(const unsigned short* p0, const unsigned short* p1, int lo) {
-    const uint2 a = lds_tr4(p0), b = lds_tr4(p1), c = lds_tr4(p0 + lo), d = lds_tr4(p1 + lo);
-    F16x2 o;
-    o.h = u32x4{a.x, a.y, b.x, b.y};
-    o.l = u32x4{c.x, c.y, d.x, d.y};
-    return o;
 }
 
 // Data gradient of a 2x2 stride-1 convolution with 32 output channels, masked by the input activation, in place:
