@@ -428,28 +428,23 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients of the dense layers, all layers in ONE launch.  dW[k, n] = sum_b X[b, k] G[b, n]: the batch is the reduction index.
 // Workgroup = 4 waves = one 64 x 64 output tile over one batch slice; wave w owns the 32 x 32 quarter (k half w >> 1, n half w & 1) as
-// 2 x 2 MFMA tiles.  Both operands go through LDS as f16 pieces (qnet.h), TRANSPOSED -- [column][batch row] -- so that an MFMA operand
-// (lane (kb, i): 8 consecutive batch rows of column i) is ONE ds_read_b128 per piece: the rows of a 32-row block are loaded from global
-// memory and transposed once per WORKGROUP.  The big operands (Dense(512)'s input x and its gradient gH1, the hidden output h1) arrive
-// as ready-made row-major piece planes, written by the kernels that produced them (fused.hip dense_chain_kernel, dense_bwd_chain_kernel
-// above): a lane loads 8 rows x 8 columns of one piece (eight 16-byte loads) and transposes them with 32 byte-permutes; the small ones
-// (gY2, g3, y2: <= 128 columns) are f32 and split here.  (Round 1: every wave loaded and split its own 64 + 64 columns of f32 from global
-// memory: four times the vector-memory traffic and ~250 VALU per 32 rows and wave.)
-// LDS is what bounds the kernel (SQ counters: with a plain [column][40 halves] image three quarters of its LDS cycles were bank conflicts
-// of the transposing stores -- the lanes of a store are 8 columns apart, a multiple of the 128-byte bank period whatever the padding).
-// The image is therefore SWIZZLED (wgrad_off): 64 bytes per column, two columns per 128-byte line, and the 16-byte slot of (column,
-// 8-row chunk) inside its line XOR-ed with column bits such that both the stores (lanes 8 columns apart) and the reads (16 consecutive
-// columns, one chunk) of any 8 consecutive lanes touch all eight slots: conflict-free both ways.
-// An iteration covers two 32-row blocks: waves 0 / 1 bring X / G of the first, waves 2 / 3 of the second; the rows of two iterations are
-// in flight; double-buffered LDS, one barrier per iteration.  Bias gradients (column sums of G) come out of the matrix pipe as well: a
-// tile whose A operand is all ones.  Rows past the slice are clamped on load and zeroed in G only (a zero factor kills the product);
-// columns past K / N are clamped too and only reach accumulators that are never stored.
+// 2 x 2 MFMA tiles.  Every operand (Dense(512)'s input x and its gradient gH1, the hidden output h1, gY2, y2, g3) arrives as ready-made
+// row-major f16 piece planes, written by the kernels that produced it (fused.hip dense_chain_kernel, dense_bwd_chain_kernel above).  An
+// iteration's 64 batch rows x 64 columns of both operands and pieces are copied global -> LDS by LDS-DMA (no registers, no arithmetic;
+// rows of 64 halves + one 16-byte padding slot whose lane stays inactive), and the MFMA operands -- 8 consecutive batch rows of one
+// column per lane: the TRANSPOSE of the staged rows -- come out of LDS by transposing reads (lds_tr8 above: two ds_read_b64_tr_b16 per
+// piece and tile).  Double-buffered, one barrier per iteration, the next iteration's copies fly under this iteration's MFMAs.
+// (Before: rows loaded into registers, transposed with 32 byte-permutes per lane and 8 rows, stored into a swizzled [column][batch row]
+// image and read back with ds_read_b128: 155 VALU per wave and iteration, 16.4 us; now 15.1 us.)
+// Bias gradients (column sums of G) come out of the matrix pipe as well: a tile whose A operand is all ones.  Rows past the slice are
+// re-reads of its last row, and zeroed in G only (a zero factor kills the product); columns past K / N are clamped too and only reach
+// accumulators that are never stored.
 // Row stride (halves) of an LDS piece-plane image of 32 channels: 64 data bytes + 16 of padding, filled by LDS-DMA in 16-byte slots
 #define PL32 40
 
 // Transposing LDS read (ds_read_b64_tr_b16, tools/probe/tr_probe.hip): within a 16-lane group, lanes 4r .. 4r+3 each point at a 4-half
 // segment of row r (r = 0 .. 3, any addresses); lane i receives column i of those four rows.  Two of them are the eight reduction
-// indices of a 16 x 16 x 32 MFMA operand held ROW-major in LDS -- what the weight gradients (a reduction over pixels) need.
+// indices of a 16 x 16 x 32 MFMA operand held ROW-major in LDS -- what the weight gradients (a reduction over pixels / batch rows) need.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_tr4(const unsigned short* p) {
     const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
@@ -466,18 +461,16 @@ __device__ __forceinline__ F16x2 lds_tr8(const unsigned short* p0, const unsigne
 
 #define WGRAD_THREADS 256
 #define WGRAD_WAVES 4
-#define WGRAD_PIECE 2048                // halves per piece plane: 64 columns x 32 batch rows
 #define WG_PS 72                        // halves per LDS row of an operand image: 64 columns + one 16-byte padding slot (rows 36 dwords apart: the four rows of
                                         // a transposing read fall into distinct banks)
-#define WG_IMG (64 * WG_PS)             // halves per image (64 rows of one operand and piece)
+#ifndef WG_ROWS
+#define WG_ROWS 64                      // batch rows per iteration (64: 72 KB of LDS per workgroup = two workgroups per CU; 32 -- four per CU -- measured 12 % slower)
+#endif
+#define WG_NCH ((WG_ROWS * 9 + 63) / 64)    // LDS-DMA instructions (1 KB chunks of 64 sixteen-byte slots) per image
+#define WG_NK ((4 * WG_NCH + 3) / 4)    // ... per wave and iteration
+#define WG_IMG (WG_ROWS * WG_PS)        // halves per image (WG_ROWS rows of one operand and piece)
 #define WG_BUF (4 * WG_IMG)             // ... per buffer: [operand][piece]
-#define DENSE_WGRAD_LDS (2 * WG_BUF * 2)                       // two buffers: 72 KB
-
-// halves from a piece plane's start to the 8 rows of chunk `chunk` (0..3) of column `col` (0..63)
-__device__ __forceinline__ int wgrad_off(int col, int chunk) {
-    const int slot = ((((col & 1) ^ (col >> 5)) & 1) << 2) | ((chunk ^ (col >> 1) ^ (col >> 3)) & 3);
-    return (col >> 1) * 64 + slot * 8;
-}
+#define DENSE_WGRAD_LDS ((2 * WG_BUF * 2) > 64 * 68 * 4 ? (2 * WG_BUF * 2) : 64 * 68 * 4)      // two buffers (the finished tile is staged over them)
 
 struct WgradOperand {
     const float* f32;                   // [batch, cols] f32 (+ 16 bytes of slack), or NULL when the operand comes as piece planes:
@@ -510,7 +503,7 @@ static void wgrad_slicing(int B, int* rows_per_slice, int* slices) {
     *slices = (B + rps - 1) / rps;
 }
 
-__global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgradArgs a) {
+__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wgrad_kernel(DenseWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     unsigned short* s_t = reinterpret_cast<unsigned short*>(smem);   // [buf][op][piece][64 rows][WG_PS] row-major piece planes
     // XCD-aware block -> (tile, slice) map: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of one batch
@@ -526,35 +519,35 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kb = lane >> 4;
     const int K = L.X.cols, N = L.G.cols, kbase = 64 * kt, nbase = 64 * nt;
     const int m0 = slice * a.rows_per_slice, m1 = min(a.batch, m0 + a.rows_per_slice);
-    const int n_it = (m1 - m0 + 63) >> 6;
+    const int n_it = (m1 - m0 + WG_ROWS - 1) / WG_ROWS;
     float* out = a.partial + (size_t)slice * a.pstride;
     float* s_o = reinterpret_cast<float*>(smem);                    // the finished tile [64][68], staged for row-wise stores
     DQ_STAMP(DQ_TAG_DENSE_WGRAD, 0);
     DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 0);
     DQ_STAMP_PAIR2(1);
-    // ---- staging: an iteration's 64 rows x 64 columns of both operands and both pieces = 4 images of 64 x 9 sixteen-byte slots (8 of data +
-    //      1 of padding, whose lane stays inactive) = 4 x 9 LDS-DMA instructions of 1 KB, nine per wave: instruction c = wave + 4k is chunk
-    //      c % 9 of image c / 9 (operand c / 18, piece (c / 9) & 1).  Per-lane constants of the wave's nine instructions: the row inside
+    // ---- staging: an iteration's WG_ROWS rows x 64 columns of both operands and both pieces = 4 images of WG_ROWS x 9 sixteen-byte slots (8 of data +
+    //      1 of padding, whose lane stays inactive) = 4 x WG_NCH LDS-DMA instructions of 1 KB, WG_NK per wave: instruction c = wave + 4k is
+    //      chunk c % WG_NCH of image c / WG_NCH (operand = image >> 1, piece = image & 1).  Per-lane constants of the wave's nine instructions: the row inside
     //      the iteration and the global column offset (columns past the operand's row are clamped to 0: they only reach accumulators that
     //      are never stored); -1 = padding slot.
-    int drow[9];
-    const unsigned short* dsrc[9];
+    int drow[WG_NK];
+    const unsigned short* dsrc[WG_NK];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int c = wave + 4 * k, img = c / 9, ch = c - img * 9, q = ch * 64 + lane, row = q / 9, part = q - row * 9;
+    for (int k = 0; k < WG_NK; ++k) {
+        const int c = wave + 4 * k, img = min(c / WG_NCH, 3), ch = c - (c / WG_NCH) * WG_NCH, q = ch * 64 + lane, row = q / 9, part = q - row * 9;
         const WgradOperand& O = (img >> 1) ? L.G : L.X;
         const int col = ((img >> 1) ? nbase : kbase) + 8 * part;
-        drow[k] = part < 8 ? row : -1;
+        drow[k] = (part < 8 && row < WG_ROWS && c < 4 * WG_NCH) ? row : -1;
         dsrc[k] = O.planes + (size_t)(img & 1) * O.plane_stride + (col < O.ld ? col : 0);
     }
     const int ldx = L.X.ld, ldg = L.G.ld;
     auto issue = [&](int it) {
         unsigned short* dst = s_t + (it & 1) * WG_BUF;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int c = wave + 4 * k, img = c / 9, ch = c - img * 9;      // wave-uniform
+        for (int k = 0; k < WG_NK; ++k) {
+            const int c = wave + 4 * k, img = min(c / WG_NCH, 3), ch = c - (c / WG_NCH) * WG_NCH;      // wave-uniform
             if (drow[k] >= 0) {
-                const size_t ro = (size_t)min(m0 + 64 * it + drow[k], m1 - 1) * ((img >> 1) ? ldg : ldx);      // rows past the slice: re-read its last row (G cleared in mm)
+                const size_t ro = (size_t)min(m0 + WG_ROWS * it + drow[k], m1 - 1) * ((img >> 1) ? ldg : ldx);      // rows past the slice: re-read its last row (G cleared in mm)
                 __builtin_amdgcn_global_load_lds(dsrc[k] + ro, (__attribute__((address_space(3))) u32*)(dst + img * WG_IMG + ch * 512), 16, 0, 0);
             }
         }
@@ -572,9 +565,9 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
     const u32x4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};     // f16 1.0 x 8
     auto mm = [&](int it) {                                         // the iteration's two blocks: 16 transposing reads + 16 MFMAs each
         const unsigned short* base = s_t + (it & 1) * WG_BUF;
-        const bool tail = m0 + 64 * it + 64 > m1;                   // wave-uniform: only the slice's last iteration masks rows
+        const bool tail = m0 + WG_ROWS * it + WG_ROWS > m1;         // wave-uniform: only the slice's last iteration masks rows
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < WG_ROWS / 32; ++blk) {
             const int r0 = (32 * blk + 4 * kb + ri) * WG_PS, r1 = r0 + 16 * WG_PS;
             F16x2 xa[2], gb[2];
 #pragma unroll
@@ -586,7 +579,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, 2) void dense_wgrad_kernel(DenseWgra
             if (tail) {                                             // rows of G past the slice: their halves cleared (element e = half e of the operand)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const int rb = m0 + 64 * it + 32 * blk + 4 * kb;
+                    const int rb = m0 + WG_ROWS * it + 32 * blk + 4 * kb;
                     const u32 lo = rb + ((2 * d) & 3) + 16 * ((2 * d) >> 2) < m1 ? 0xffffu : 0u;
                     const u32 hi = rb + ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < m1 ? 0xffff0000u : 0u;
 #pragma unroll
