@@ -279,7 +279,9 @@ dq_status dq_qnet_layer_info(const dq_qnet* net, int layer, int64_t* kernel_offs
                              int32_t shape[4], int32_t* n_dims);
 
 /* Two forward implementations exist, both HIP: per-layer implicit GEMMs, and (default, when the configuration
- * fits) the fused LDS-resident chains of csrc/fused.hip.  dq_qnet_set_fused(net, 0) selects the per-layer path. */
+ * fits) the fused LDS-resident chains of csrc/fused.hip.  dq_qnet_set_fused(net, 0) selects the per-layer path.  Each path's
+ * training forward saves its activations in the form ITS backward reads (the fused one mostly as f16 piece planes), so a backward
+ * must run on the path its training forward ran on: switching between the two calls makes the backward return DQ_ERR_STATE. */
 dq_status dq_qnet_set_fused(dq_qnet* net, int enable);
 int dq_qnet_fused_supported(const dq_qnet* net);
 
