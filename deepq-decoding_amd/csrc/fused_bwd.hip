@@ -1112,34 +1112,30 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         if (nxt < a.groups) issue_a2(nxt, ns_nxt * r2);            // g2 (in a2) is dead; lands during dW1
         // ---- dW1 += patches^T g1 ----------------------------------------------------------------------------------------
         {
-            const u8* cp = s_col + 16 * (wave >> 2) + j;           // + 32 per further tile of this wave (k-tile + 2)
-            // On the f16 pipe: the patch operand is binary (exact in f16: four multiplies make a tile's eight halves), g1 arrives as ready-made
-            // pieces (split on write by the g1 phase) through transposing reads: one K = 32 MFMA per piece.  Lane group kq supplies rows
-            // m0 + kq + 4 (e & 3) + 16 (e >> 2) of both operands (lanes kq, kq + 1 read patch bytes 16 banks apart; this lane points at row
-            // kq + 4 (j >> 2) (+ 16), column segment 4 (j & 3) of the transposing reads).  The LDS reads of trip t + 1 are issued before the
-            // MFMAs of trip t.
+            // On the f16 pipe: the patch operand is binary (exact in f16), g1 arrives as ready-made pieces (split on write by the g1 phase):
+            // one K = 32 MFMA per piece.  Lane group kq supplies rows m0 + kq + 4 (e & 3) + 16 (e >> 2) of both operands (consecutive kq =
+            // consecutive patch rows, 16 banks apart).  Both come out of their row-major LDS images by TRANSPOSING reads: g1's columns by
+            // lds_tr8 (this lane points at row kq + 4 (j >> 2) (+ 16), column segment 4 (j & 3)), the patch bytes by ds_read_b64_tr_b8
+            // (tools/probe/tr8_probe.hip: lanes 2e, 2e+1 of a 16-lane group point at the two 8-byte halves of row e, lane i receives column
+            // i of the eight rows) -- ONE read per tile where eight ds_read_u8 were; four byte-permutes + four multiplies make its eight
+            // halves.  The LDS reads of trip t + 1 are issued before the MFMAs of trip t.
             const int cseg = 16 * (wave & 3) + 4 * (j & 3), rj = kq + 4 * (j >> 2);
-            auto rd = [&](int m0, u32 (&ab)[NW1][8], F16x2& G) {
+            const int re = j >> 1, rowb = kq + 4 * (re & 3) + 16 * (re >> 2);      // the patch row (inside a block) this lane points at
+            const u8* cp = s_col + 16 * (wave >> 2) + 8 * (j & 1);  // + 32 per further tile of this wave (k-tile + 2)
+            auto rd = [&](int m0, uint2 (&ab)[NW1], F16x2& G) {
                 const int r0 = min(m0 + rj, M1 - 1), r1 = min(m0 + 16 + rj, M1 - 1);      // (rows past M1: masked in mm)
                 G = lds_tr8(s_a1 + r0 * A1PS + cseg, s_a1 + r1 * A1PS + cseg, LA1);
-                if (m0 + 32 <= M1) {                                  // wave-uniform: no clamps, no selects, affine addresses
-                    const u8* cb = cp + (m0 + kq) * KP;
+                const u8* cb = cp + min(m0 + rowb, M1 - 1) * KP;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-#pragma unroll
-                        for (int u = 0; u < NW1; ++u) ab[u][e] = cb[(4 * (e & 3) + 16 * (e >> 2)) * KP + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)];
-                } else {                                              // the group's last block: clamped rows (their g is cleared in mm)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int mc = min(m0 + kq + 4 * (e & 3) + 16 * (e >> 2), M1 - 1);
-#pragma unroll
-                        for (int u = 0; u < NW1; ++u) ab[u][e] = cp[mc * KP + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)];     // 0 or 1
-                    }
+                for (int u = 0; u < NW1; ++u) {
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(cb + (wave + CB_WAVES * u < 4 * KG1 ? 32 * u : 0)));
+                    ab[u] = uint2{(u32)v[0], (u32)v[1]};
                 }
             };
             // NO condition around an MFMA, not even a wave-uniform one: hipcc then copies the accumulators after every MFMA
             // (each copy waits for the result) -- a tile this wave does not have accumulates garbage that is never stored
-            auto mm = [&](int m0, const u32 (&ab)[NW1][8], F16x2& G) {
+            auto mm = [&](int m0, const uint2 (&ab)[NW1], F16x2& G) {
                 if (m0 + 32 > M1) {                                   // rows past M1: their halves of g's pieces cleared
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -1150,14 +1146,18 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
                 }
 #pragma unroll
                 for (int u = 0; u < NW1; ++u) {
+                    // bytes (0 / 1) e, e + 1 -> one dword of two halves: byte-permute into the halves' low bytes, times f16(1.0) = 0x3c00
+                    // (v_mul_u32_u24: a 32-bit multiply is quarter rate)
                     u32x4 av;
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) av[e >> 1] = __umul24(ab[u][e] | (ab[u][e + 1] << 16), 0x3c00u);      // f16(1.0) = 0x3c00; v_mul_u32_u24 (a 32-bit multiply is quarter rate)
+                    av[0] = __umul24(__builtin_amdgcn_perm(0u, ab[u].x, 0x0c010c00u), 0x3c00u);
+                    av[1] = __umul24(__builtin_amdgcn_perm(0u, ab[u].x, 0x0c030c02u), 0x3c00u);
+                    av[2] = __umul24(__builtin_amdgcn_perm(0u, ab[u].y, 0x0c010c00u), 0x3c00u);
+                    av[3] = __umul24(__builtin_amdgcn_perm(0u, ab[u].y, 0x0c030c02u), 0x3c00u);
                     acc1[u] = MFMA_F16(av, G.h, acc1[u]);
                     acc1l[u] = MFMA_F16(av, G.l, acc1l[u]);
                 }
             };
-            u32 abA[NW1][8], abB[NW1][8];
+            uint2 abA[NW1], abB[NW1];
             F16x2 gA, gB;
             rd(0, abA, gA);
             for (int m0 = 0;;) {
