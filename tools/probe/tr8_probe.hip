@@ -1,4 +1,6 @@
 // ds_read_b64_tr_b8 lane map probe (GPU box): hipcc --offload-arch=gfx950 tools/probe/tr8_probe.hip -o tools/probe/tr/tr8_probe
+// Result: within a 16-lane group, lanes 2e, 2e+1 point at the two 8-byte halves of row e (e = 0 .. 7; addresses are aligned DOWN to 8 bytes); lane i
+// receives byte i of each of the eight rows (element e = row e).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef int i32x2 __attribute__((ext_vector_type(2)));

@@ -1,3 +1,6 @@
+// ds_read_b64_tr_b16 lane map probe (GPU box): hipcc --offload-arch=gfx950 tools/probe/tr_probe.hip -o tools/probe/tr/tr_probe
+// Result: within a 16-lane group, lanes 4r .. 4r+3 point at the four 4-half segments of row r (r = 0 .. 3, any 8-byte-aligned addresses); lane i
+// receives half i of each of the four rows (element r = row r).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef short s16x4 __attribute__((ext_vector_type(4)));
