@@ -28,6 +28,12 @@
 
 DQ_STAMP_READER(dq_dbg_read_fwd)
 
+// Build-time switches of the one-box A/B comparisons (tools/build_ab.sh; DESIGN.md section 4 records what each measured):
+//   CONV_PIN / DENSE_PIN   sched_barrier pins that keep the weight-ring requests a whole block of MFMAs ahead of their use (+1 %: on)
+//   CONV_APIPE             conv2 / conv3: the A pieces of K block b + 1 are read before block b's MFMAs (+0.4 us: on)
+//   DENSE_XPIPE            the same for the dense forward's input pieces (neutral: on)
+//   DQ_EXP_NODROP / DQ_EXP_NOSTORE   TIMING EXPERIMENTS ONLY -- the training forward without its dropout arithmetic / without its saved
+//                          activations: WRONG RESULTS, used to price those parts of the training workgroups (never set in a product build)
 #ifndef CONV_PIN
 #define CONV_PIN 1
 #endif
@@ -37,14 +43,17 @@ DQ_STAMP_READER(dq_dbg_read_fwd)
 #ifndef CONV_APIPE
 #define CONV_APIPE 1
 #endif
+#ifndef DENSE_XPIPE
+#define DENSE_XPIPE 1
+#endif
 #ifndef DQ_EXP_NODROP
 #define DQ_EXP_NODROP 0
 #endif
 #ifndef DQ_EXP_NOSTORE
 #define DQ_EXP_NOSTORE 0
 #endif
-#ifndef DENSE_XPIPE
-#define DENSE_XPIPE 1
+#if DQ_EXP_NODROP || DQ_EXP_NOSTORE
+#warning "timing-experiment build: the training forward's results are wrong"
 #endif
 #define CONV_THREADS 256
 #define CONV_WAVES 4
@@ -336,7 +345,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     __syncthreads();
     DQ_STAMP(DQ_TAG_CONV_FWD, 4);
     {
-        const int r2 = a.oh2 * a.ow2;
         conv_from_lds<64, 32, 2>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
                                  nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1]);
     }
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                                   ((u32)(64 * wave + 32 * b + 8 * kq) >> 3) | ((u32)DQ_STREAM_DROPOUT << 16), J.seed0, J.seed1, wd);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const int ct = 2 * b + s, unit0 = 64 * wave + 32 * b + 8 * kq + 4 * s;
+                    const int ct = 2 * b + s;
                     f32x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(f16x2_sum(acc[u][ct][0][r], acc[u][ct][1][r]) + bias1[ct][r], 0.f);

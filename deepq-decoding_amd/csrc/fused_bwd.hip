@@ -15,6 +15,8 @@
 #include "qnet.h"
 #include "env_dev.h"
 
+// Build-time switches of one-box A/B comparisons (tools/build_ab.sh): GX_PIN = a sched_barrier pin of the gX weight ring (measured -12 us:
+// off), GX_RING = its depth in K blocks; WG_ROWS (below) = batch rows per iteration of the dense weight gradients.
 #ifndef GX_PIN
 #define GX_PIN 0
 #endif
