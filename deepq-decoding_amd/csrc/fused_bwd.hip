@@ -39,10 +39,8 @@ struct DenseBwdArgs {
     int N2, N3, n_actions;
     int w_off[3];
     float mask_scale;                   // 1/(1-rate) of the hidden layer's dropout (1 if none)
-    float* g3;                          // [batch, N3] (NULL without a dueling layer)
-    float* gy2;                         // [batch, N2]
-    float* gh1;                         // [batch, 512]
-    unsigned short* gh1_pl;             // the same as f16 piece planes [2][plane_rows][512] (the weight gradient's operand)
+    // (the gradients leave as f16 piece planes only -- what the weight-gradient kernel reads; the per-layer path keeps f32 copies of its own)
+    unsigned short* gh1_pl;             // gH1 as f16 piece planes [2][plane_rows][512] (the weight gradient's operand)
     unsigned short* gy2_pl;             // ... [2][plane_rows][small_ld]
     unsigned short* g3_pl;              // ... [2][plane_rows][small_ld]
     int plane_rows, small_ld;
@@ -200,7 +198,6 @@ __device__ __forceinline__ void gh1_phase(const DenseBwdArgs& a, const unsigned 
         *reinterpret_cast<uint2*>(s_gh1p + row * LDH + c0) = uint2{hp[0], hp[1]};
         *reinterpret_cast<uint2*>(s_gh1p + (DENSE_ROWS + row) * LDH + c0) = uint2{lp[0], lp[1]};
         if (row < ns) {
-            *reinterpret_cast<f32x4*>(a.gh1 + (size_t)(b0 + row) * DENSE_HID + c0) = v;
             unsigned short* gp = a.gh1_pl + (size_t)(b0 + row) * DENSE_HID + c0;
             *reinterpret_cast<uint2*>(gp) = uint2{hp[0], hp[1]};
             *reinterpret_cast<uint2*>(gp + (size_t)a.plane_rows * DENSE_HID) = uint2{lp[0], lp[1]};
@@ -322,16 +319,14 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             float s = 0.f;
             for (int h = 0; lane + 64 * h < A; ++h) s += dval(h);
             for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-            float* o = a.g3 + (size_t)b * N3;
             unsigned short* p3 = a.g3_pl + (size_t)b * a.small_ld;   // the same values as pieces: the dueling layer's weight gradient
             const size_t lo3 = (size_t)a.plane_rows * a.small_ld;
             unsigned short ph, pl;
-            if (lane == 0) { s_g3[row * ldg] = s; o[0] = s; split_f16x2_one(s, ph, pl); p3[0] = ph; p3[lo3] = pl; }
+            if (lane == 0) { s_g3[row * ldg] = s; split_f16x2_one(s, ph, pl); p3[0] = ph; p3[lo3] = pl; }
             for (int h = 0; lane + 64 * h < A; ++h) {
                 const int c = lane + 64 * h;
                 const float v = dval(h) - s / (float)A;
                 s_g3[row * ldg + 1 + c] = v;
-                o[1 + c] = v;
                 split_f16x2_one(v, ph, pl);
                 p3[1 + c] = ph; p3[lo3 + 1 + c] = pl;
             }
@@ -342,7 +337,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
                 const _Float16 vh = (_Float16)v, vl = (_Float16)((v - (float)vh) * F16_LO_SCALE);
                 s_gy2p[row * LDY + c] = __builtin_bit_cast(unsigned short, vh);
                 s_gy2p[(DENSE_ROWS + row) * LDY + c] = __builtin_bit_cast(unsigned short, vl);
-                a.gy2[(size_t)b * N2 + c] = v;
             }
         }
     }
@@ -389,7 +383,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
                     const _Float16 vh = (_Float16)acc[r], vl = (_Float16)((acc[r] - (float)vh) * F16_LO_SCALE);      // split on write (qnet.h)
                     s_gy2p[row * LDY + n2] = __builtin_bit_cast(unsigned short, vh);
                     s_gy2p[(DENSE_ROWS + row) * LDY + n2] = __builtin_bit_cast(unsigned short, vl);
-                    if (row < ns) a.gy2[(size_t)(b0 + row) * N2 + n2] = acc[r];
                 }
             }
         }
@@ -1382,7 +1375,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < nl - nc; ++l) da.w_off[l] = (int)Q->L[nc + l].w_off;
     da.mask_scale = D1.dropout > 0.f ? (float)(1.0 / (1.0 - (double)D1.dropout)) : 1.f;
-    da.g3 = Q->cfg.dueling ? Q->gz[nc + 2] : nullptr; da.gy2 = Q->gz[nc + 1]; da.gh1 = Q->gz[nc]; da.gx_pl = reinterpret_cast<unsigned short*>(Q->gz[nc - 1]); da.gx_lo = (size_t)Q->cfg.max_batch * D1.nin;
+    da.gx_pl = reinterpret_cast<unsigned short*>(Q->gz[nc - 1]); da.gx_lo = (size_t)Q->cfg.max_batch * D1.nin;
     da.ldg = dp.ldg; da.off_g3 = dp.off_g3; da.off_gy2 = dp.off_gy2; da.off_gh1 = dp.off_gh1;
     da.dense_wgs = (B + DENSE_ROWS - 1) / DENSE_ROWS;
     int stat_wgs = 0;
