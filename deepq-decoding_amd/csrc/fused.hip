@@ -394,8 +394,6 @@ struct DenseJob {
     unsigned short* h1_pl;              // training: the hidden output as planes [2][plane_rows][512]
     unsigned short* y2_pl;              // training: Dense(|A|)'s output as planes [2][plane_rows][small_ld] (the dueling layer's weight gradient)
     int plane_rows, small_ld;
-    float* y2_out;                      // training: [batch, N2]
-    float* y3_out;                      // training: [batch, N3]
     float* q_out;                       // [batch, n_actions]
     int wg0;                            // first workgroup of this job
 };
@@ -650,8 +648,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                 for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * PR + rr) * PWP + col];
                 s_y2[row * a.ld2 + col] = v;
-                if (J.y2_out && row < ns) {
-                    J.y2_out[(size_t)(b0 + row) * a.N2 + col] = v;
+                if (J.y2_pl && row < ns) {                          // training: Dense(|A|)'s output as pieces (the dueling layer's weight gradient)
                     unsigned short h, l;
                     split_f16x2_one(v, h, l);
                     J.y2_pl[(size_t)(b0 + row) * J.small_ld + col] = h;
@@ -688,7 +685,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                         const int row = 16 * u + 4 * kq + r;
                         const float v = (acc3[0][r] + acc3[1][r]) + bias3;
                         s_y3[row * a.ld3 + col3] = v;
-                        if (J.y3_out && row < ns) J.y3_out[(size_t)(b0 + row) * a.N3 + col3] = v;
                     }
                 }
             }
@@ -1075,10 +1071,8 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         }
         D.seed0 = jb.seed[0]; D.seed1 = jb.seed[1]; D.sample_base = jb.sample_base; D.t = jb.t;
         if (training) {
-            D.y2_out = Q->act[0][nc + 1];
             D.plane_rows = Q->cfg.max_batch; D.small_ld = dq_planes_small_ld(Q);
             D.x_pl = dq_plane(Q, 0); D.h1_pl = dq_plane(Q, 1); D.y2_pl = dq_plane(Q, 5);
-            D.y3_out = Q->cfg.dueling ? Q->act[0][nc + 2] : nullptr;
             Q->last_train_batch = jb.batch; Q->last_train_fused = 1; Q->last_obs = jb.obs_dev; Q->last_index = jb.index_dev;
             Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod; Q->last_train_packed = packed;
         }
