@@ -734,36 +734,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 // ---------------------------------------------------------------------------------------------------------------
 // Packs the conv kernels and Dense(512) of one parameter buffer into f16 pieces in MFMA operand order (qnet.h PK_*): one wave per
 // block, lane (kb, j) gathers its 8 weights, splits them and writes 2 x 16 bytes.  One launch per parameter change.
-struct PackTr { const float* src; float* dst; int R, C, tile0, tiles_c; };      // dst[c][r] = src[r][c], 32 x 32 tiles
 struct PackArgs {
     const float* params;
     u32x4* pk;
     int w1_off, K1, w2_off, w3_off, d1_off, d1_blocks;
     int d2_off, N2, NT2, KB2, d2_blocks, d2t_blocks, d1t_blocks, d1k;     // Dense(|A|) kernel offset / width, dense2 / dense2t / dense1t block counts, K1
     int perm_hw, perm_c;                // > 0: plane index k' = p*perm_c + c of the dense forward is Keras weight row c*perm_hw + p
-    int pack_wgs;                       // workgroups [0, pack_wgs) pack f16 pieces, the rest transpose (tr[i].tile0 counts from pack_wgs)
-    PackTr tr[2];
+    int pack_wgs;
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
-    if ((int)blockIdx.x >= a.pack_wgs) {                            // ---- f32 transposes W1T, W2T (the backward's data gradients) ----
-        __shared__ float tile[32][33];
-        const PackTr& T = a.tr[(int)blockIdx.x >= a.tr[1].tile0 ? 1 : 0];
-        const int tl = (int)blockIdx.x - T.tile0, tr = tl / T.tiles_c, tc = tl - tr * T.tiles_c;
-        const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = tr * 32 + y + 8 * k, c = tc * 32 + x;
-            if (r < T.R && c < T.C) tile[y + 8 * k][x] = T.src[(size_t)r * T.C + c];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = tc * 32 + y + 8 * k, r = tr * 32 + x;
-            if (r < T.R && c < T.C) T.dst[(size_t)c * T.R + r] = tile[x][y + 8 * k];
-        }
-        return;
-    }
     const float* __restrict__ params = a.params;
     u32x4* __restrict__ pk = a.pk;
     const int w2_off = a.w2_off, w3_off = a.w3_off, d1_off = a.d1_off, d1_blocks = a.d1_blocks;
@@ -863,16 +843,8 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     a.d2_off = (int)D2.w_off; a.N2 = D2.nout; a.NT2 = PL.NT2; a.KB2 = PL.KB2; a.d2_blocks = PL.d2_blocks; a.d2t_blocks = PL.d2t_blocks;
     a.d1t_blocks = PL.d1t_blocks; a.d1k = D1.nin;
     a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + 3) / 4;
-    int tiles = a.pack_wgs;
-    const Layer* Ls[2] = {&D1, &D2};
-    const size_t offs[2] = {fused_packed_w1t_u32x4(Q), fused_packed_w2t_u32x4(Q)};
-    for (int i = 0; i < 2; ++i) {
-        PackTr& T = a.tr[i];
-        T.src = params_dev + Ls[i]->w_off; T.dst = reinterpret_cast<float*>(a.pk + offs[i]);
-        T.R = Ls[i]->K; T.C = Ls[i]->N; T.tile0 = tiles; T.tiles_c = (T.C + 31) / 32;
-        tiles += ((T.R + 31) / 32) * T.tiles_c;
-    }
-    pack_weights_kernel<<<tiles, 256, 0, st>>>(a);
+    // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
+    pack_weights_kernel<<<a.pack_wgs, 256, 0, st>>>(a);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }
