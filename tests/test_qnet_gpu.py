@@ -310,6 +310,23 @@ def test_fused_and_per_layer_paths_agree(dq, torch_mod):
     assert np.median(diff) < 1e-8 and (diff > 1e-5 * np.abs(out[False][2]).max()).mean() < 0.02
 
 
+def test_backward_is_refused_on_the_other_path_than_its_forward(dq, torch_mod):
+    """Each path's training forward saves its activations in the form ITS backward reads (the fused one mostly as f16 piece planes,
+    the per-layer one as f32): switching paths between the two calls is an error, not a silently wrong gradient."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 64)
+    obs_t = torch.from_numpy(obs).cuda()
+    dq_ = torch.from_numpy((rng.randn(64, 51) / 64).astype(np.float32)).cuda()
+    for first in (True, False):
+        net.set_fused(first)
+        net.forward(params, obs_t, training=True, seed=(1, 2), t=3)
+        net.set_fused(not first)
+        with pytest.raises(dq.DeepQError):
+            net.backward(params, dq_)
+        net.set_fused(first)
+        assert np.isfinite(net.backward(params, dq_).cpu().numpy()).all()      # the matching path still works
+
+
 def test_td_target_loss_adam(dq, torch_mod):
     torch = torch_mod
     rng = np.random.RandomState(9)
