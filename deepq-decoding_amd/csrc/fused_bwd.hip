@@ -16,12 +16,20 @@
 #include "env_dev.h"
 
 // Build-time switches of one-box A/B comparisons (tools/build_ab.sh): GX_PIN = a sched_barrier pin of the gX weight ring (measured -12 us:
-// off), GX_RING = its depth in K blocks; WG_ROWS (below) = batch rows per iteration of the dense weight gradients.
+// off), GX_RING = its depth in K blocks; WG_ROWS (below) = batch rows per iteration of the dense weight gradients; CB_PRIO / DB_PRIO = static
+// issue priority for the second-dispatched half of an 8-wave workgroup's waves (conv backward -0.55 us, dense backward -0.2 us: on; the same in the
+// dense forward measured nothing).
 #ifndef GX_PIN
 #define GX_PIN 0
 #endif
 #ifndef GX_RING
 #define GX_RING 3
+#endif
+#ifndef CB_PRIO
+#define CB_PRIO 1
+#endif
+#ifndef DB_PRIO
+#define DB_PRIO 1
 #endif
 DQ_STAMP_READER(dq_dbg_read_bwd)
 
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
                               ((int)blockIdx.x - a.dense_wgs) * DENSE_THREADS + tid, a.td.st_stats);
         return;
     }
+    if (DB_PRIO && wave >= DENSE_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // (as in the conv backward: the younger half of the workgroup's waves)
     DQ_STAMP(DQ_TAG_DENSE_BWD, 0);
     __shared__ float s_met[DENSE_WAVES][2];
     for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) s_g3[i] = 0.f;
@@ -858,6 +867,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     constexpr int NW1 = (4 * KG1 + CB_WAVES - 1) / CB_WAVES;        // dW1 tiles (KG1 x 4) per wave
     constexpr int KP = 16 * KG1;                                    // bytes per row of the observation patch image
 
+    if (CB_PRIO && wave >= CB_WAVES / 2) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses every issue arbitration by age: static priority evens the pair out
     DQ_STAMP_PAIR2(3);
     // ---- group-independent tables and zero rows ----------------------------------------------------------------
     // (copied from the host-built tables: computing them here took two integer divisions per entry)
