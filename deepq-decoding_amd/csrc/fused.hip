@@ -455,33 +455,34 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     const int LDP = K1 + 8;                                          // plane row stride in f16 (rows stay 16-byte aligned)
     unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [2][ROWS][LDP]
     {
-        const int q4 = K1 >> 2;                                     // float4 per row
-        constexpr int NBS = RT == 4 ? 9 : RT == 2 ? 5 : 3;           // loads in flight per thread before the first split / LDS store: the whole image
-        for (int i0 = tid; i0 < ROWS * q4; i0 += NBS * DENSE_THREADS) {
-            f32x4 vv[NBS];
+        // eight consecutive values per item: two 16-byte loads in, ONE 16-byte store per piece out (LDS plane, and in training the global
+        // plane: stores are issue-bound per instruction -- as pairs of 8-byte stores they were twice as many for the same bytes)
+        const int q8 = K1 >> 3;                                     // items per row (K1 is a multiple of 32)
+        constexpr int NBS = RT == 4 ? 5 : RT == 2 ? 3 : 2;           // items in flight per thread before the first split / LDS store: the whole image
+        for (int i0 = tid; i0 < ROWS * q8; i0 += NBS * DENSE_THREADS) {
+            f32x4 vv[NBS][2];
 #pragma unroll
             for (int u = 0; u < NBS; ++u) {
-                const int i = i0 + u * DENSE_THREADS, r = i / q4, c4 = (i - r * q4) * 4;
-                const bool ok = i < ROWS * q4 && r < ns;
-                // unconditional load of a clamped address, masked by multiplication (a select right behind the load serialises them)
-                vv[u] = *reinterpret_cast<const f32x4*>(J.x + (ok ? (size_t)(b0 + r) * K1 + c4 : 0)) * (ok ? 1.f : 0.f);
+                const int i = i0 + u * DENSE_THREADS, r = i / q8, c8 = (i - r * q8) * 8;
+                const bool ok = i < ROWS * q8 && r < ns;
+                // unconditional loads of a clamped address, masked by multiplication (a select right behind the load serialises them)
+                const float* xp = J.x + (ok ? (size_t)(b0 + r) * K1 + c8 : 0);
+                vv[u][0] = *reinterpret_cast<const f32x4*>(xp) * (ok ? 1.f : 0.f);
+                vv[u][1] = *reinterpret_cast<const f32x4*>(xp + 4) * (ok ? 1.f : 0.f);
             }
 #pragma unroll
             for (int u = 0; u < NBS; ++u) {
                 const int i = i0 + u * DENSE_THREADS;
-                if (i >= ROWS * q4) break;
-                const int r = i / q4, c4 = (i - r * q4) * 4;
-                const f32x4 v = vv[u];
-                u32 hb[2], lb[2];
-                split_f16x2_pair(v[0], v[1], hb[0], lb[0]);
-                split_f16x2_pair(v[2], v[3], hb[1], lb[1]);
-                unsigned short* d = s_pl + r * LDP + c4;
-                *reinterpret_cast<uint2*>(d) = uint2{hb[0], hb[1]};
-                *reinterpret_cast<uint2*>(d + ROWS * LDP) = uint2{lb[0], lb[1]};
+                if (i >= ROWS * q8) break;
+                const int r = i / q8, c8 = (i - r * q8) * 8;
+                const F16x2 o = split_f16x2(vv[u][0], vv[u][1]);
+                unsigned short* d = s_pl + r * LDP + c8;
+                *reinterpret_cast<u32x4*>(d) = o.h;
+                *reinterpret_cast<u32x4*>(d + ROWS * LDP) = o.l;
                 if (J.x_pl && r < ns && !DQ_EXP_NOSTORE) {                             // the same pieces feed the weight gradient of this layer (fused_bwd.hip)
-                    unsigned short* gp = J.x_pl + (size_t)(b0 + r) * K1 + c4;
-                    *reinterpret_cast<uint2*>(gp) = uint2{hb[0], hb[1]};
-                    *reinterpret_cast<uint2*>(gp + (size_t)J.plane_rows * K1) = uint2{lb[0], lb[1]};
+                    unsigned short* gp = J.x_pl + (size_t)(b0 + r) * K1 + c8;
+                    *reinterpret_cast<u32x4*>(gp) = o.h;
+                    *reinterpret_cast<u32x4*>(gp + (size_t)J.plane_rows * K1) = o.l;
                 }
             }
         }
