@@ -649,18 +649,26 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                 for (int w = 0; w < DENSE_WAVES; ++w) v += s_part[(w * PR + rr) * PWP + col];
                 s_y2[row * a.ld2 + col] = v;
-                if (J.y2_pl && row < ns) {                          // training: Dense(|A|)'s output as pieces (the dueling layer's weight gradient)
-                    unsigned short h, l;
-                    split_f16x2_one(v, h, l);
-                    J.y2_pl[(size_t)(b0 + row) * J.small_ld + col] = h;
-                    J.y2_pl[((size_t)J.plane_rows + b0 + row) * J.small_ld + col] = l;
-                }
             }
         }
         __syncthreads();
         if (pass == 0) { DQ_STAMP(DQ_TAG_DENSE_FWD, 5); }
     }
 
+    // ---- training: Dense(|A|)'s output leaves as pieces (the dueling layer's weight gradient), eight columns per thread = one 16-byte store
+    //      per piece (as single halves from the reduction loop these were 26 two-byte stores per thread); columns past N2 are the image's zeros
+    if (J.y2_pl) {                                                  // block-uniform
+        const int per_row = J.small_ld >> 3;
+        for (int i = tid; i < ROWS * per_row; i += DENSE_THREADS) {
+            const int row = i / per_row, c8 = (i - row * per_row) * 8;
+            if (row >= ns) continue;
+            const float* yp = s_y2 + row * a.ld2 + c8;
+            const F16x2 o = split_f16x2(f32x4{yp[0], yp[1], yp[2], yp[3]}, f32x4{yp[4], yp[5], yp[6], yp[7]});
+            unsigned short* gp = J.y2_pl + (size_t)(b0 + row) * J.small_ld + c8;
+            *reinterpret_cast<u32x4*>(gp) = o.h;
+            *reinterpret_cast<u32x4*>(gp + (size_t)J.plane_rows * J.small_ld) = o.l;
+        }
+    }
     DQ_STAMP(DQ_TAG_DENSE_FWD, 6);
     // ---- dueling layer Dense(|A|+1) and the combination Q = V + A - mean(A) ------------------------------------------------
     const float* y = s_y2;
