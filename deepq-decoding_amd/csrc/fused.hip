@@ -454,11 +454,35 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     //      here; clear the padded y2 image ---------------------------------------------------------------------------------------
     const int LDP = K1 + 8;                                          // plane row stride in f16 (rows stay 16-byte aligned)
     unsigned short* s_pl = reinterpret_cast<unsigned short*>(s_x);   // [2][ROWS][LDP]
+    // dropout keep bits of this lane's units (row 16u + j; byte b = the eight units 64 wave + 32 b + 8 kq .. + 7), drawn HERE, while the input rows
+    // are in flight: one Philox call = eight consecutive units of a sample, 16 bits per decision (unit n draws half-word n & 7 of call n >> 3,
+    // low half of a word first).  In the epilogue passes the 20 quarter-rate multiplies per call were on the training workgroups' critical
+    // path -- the workgroups that set this kernel's duration.
+    u32 keepb[RT];
+#pragma unroll
+    for (int u = 0; u < RT; ++u) keepb[u] = 0xffffu;
+    auto draw_keep_bits = [&]() {
+        if (!(J.keep_scale > 0.f) || DQ_EXP_NODROP) return;         // block-uniform
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            u32 bits = 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                u32 wd[4];
+                philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + 16 * u + j),
+                              ((u32)(64 * wave + 32 * b + 8 * kq) >> 3) | ((u32)DQ_STREAM_DROPOUT << 16), J.seed0, J.seed1, wd);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bits |= (((wd[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= J.drop_T ? 1u : 0u) << (8 * b + e);
+            }
+            keepb[u] = bits;
+        }
+    };
     {
         // eight consecutive values per item: two 16-byte loads in, ONE 16-byte store per piece out (LDS plane, and in training the global
         // plane: stores are issue-bound per instruction -- as pairs of 8-byte stores they were twice as many for the same bytes)
         const int q8 = K1 >> 3;                                     // items per row (K1 is a multiple of 32)
         constexpr int NBS = RT == 4 ? 5 : RT == 2 ? 3 : 2;           // items in flight per thread before the first split / LDS store: the whole image
+        bool drawn = false;
         for (int i0 = tid; i0 < ROWS * q8; i0 += NBS * DENSE_THREADS) {
             f32x4 vv[NBS][2];
 #pragma unroll
@@ -470,6 +494,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 vv[u][0] = *reinterpret_cast<const f32x4*>(xp) * (ok ? 1.f : 0.f);
                 vv[u][1] = *reinterpret_cast<const f32x4*>(xp + 4) * (ok ? 1.f : 0.f);
             }
+            if (i0 == tid) { draw_keep_bits(); drawn = true; }      // (NBS covers the whole image: the loop body runs at most once)
 #pragma unroll
             for (int u = 0; u < NBS; ++u) {
                 const int i = i0 + u * DENSE_THREADS;
@@ -486,6 +511,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 }
             }
         }
+        if (!drawn) draw_keep_bits();                               // (threads that hold no input item: small K1)
         for (int i = tid; i < ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
     }
     __syncthreads();
@@ -590,12 +616,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             F16x2 hb[2];                                            // the sample's units 8kq .. 8kq+7 of this wave's two blocks, as pieces
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                // one Philox call = the lane's eight consecutive units 64 wave + 32 b + 8 kq .. + 7 of its sample: 16 bits per decision
-                // (unit n draws half-word n & 7 of the call (n >> 3), low half of a word first)
-                u32 wd[4] = {0u, 0u, 0u, 0u};
-                if (J.keep_scale > 0.f && !DQ_EXP_NODROP)
-                    philox4x32_10((u32)J.t, (u32)(J.t >> 32), J.sample_base + (u32)(b0 + row),
-                                  ((u32)(64 * wave + 32 * b + 8 * kq) >> 3) | ((u32)DQ_STREAM_DROPOUT << 16), J.seed0, J.seed1, wd);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int ct = 2 * b + s;
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(f16x2_sum(acc[u][ct][0][r], acc[u][ct][1][r]) + bias1[ct][r], 0.f);
                     if (J.keep_scale > 0.f) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (((wd[2 * s + (r >> 1)] >> (16 * (r & 1))) & 0xffffu) < J.drop_T) ? 0.f : v[r] * J.keep_scale;
+                        for (int r = 0; r < 4; ++r) v[r] = ((keepb[u] >> (8 * b + 4 * s + r)) & 1u) ? v[r] * J.keep_scale : 0.f;
                     }
                     u32 hp[2], lp[2];
                     split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
