@@ -14,8 +14,15 @@ DQ_MODEL_X, DQ_MODEL_DP, DQ_MODEL_IIDXZ = 0, 1, 2
 STREAM_ENV, STREAM_POLICY, STREAM_REPLAY, STREAM_DROPOUT, STREAM_INIT = range(5)
 
 
+DQ_ERR_RANGE = -6
+
+
 class DeepQError(RuntimeError):
-    pass
+    """status: the dq_status code of include/deepq_hip.h (None for errors raised on the host side)."""
+
+    def __init__(self, message, status=None):
+        super().__init__(message)
+        self.status = status
 
 
 class EnvCfg(ctypes.Structure):
@@ -118,6 +125,7 @@ SIGNATURES = {
                                 ctypes.POINTER(ctypes.c_int32 * 4), ctypes.POINTER(ctypes.c_int32)]),
     "dq_qnet_set_fused": (_i, [_vp, _i]),
     "dq_qnet_set_grad_scale": (_i, [_vp, _dbl]),
+    "dq_qnet_range_check": (_i, [_vp, _vp]),
     "dq_qnet_fused_supported": (_i, [_vp]),
     "dq_qnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
     "dq_qnet_forward_multi": (_i, [_vp, _i, ctypes.POINTER(QNetJob), _vp]),
@@ -176,7 +184,7 @@ def lib():
 
 def check(status):
     if status != 0:
-        raise DeepQError(f"libdeepq_hip error {status}: {lib().dq_last_error().decode()}")
+        raise DeepQError(f"libdeepq_hip error {status}: {lib().dq_last_error().decode()}", status)
 
 
 def require_gpu():

@@ -331,6 +331,7 @@ class DQNCore:
             _q.td_metrics(self.metrics, self.batch_size)
             self._metrics_stale = False
         m = self.metrics[:2].cpu().numpy()
+        self.net.check_range()       # (already synchronised) a gradient beyond the fused backward's range is an error, never silent
         return float(m[0]), float(m[1])
 
     def repack(self):

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
 // Block = 64 outputs x 8 slice groups (thread (x, g) sums slices g, g+8, ... in order; the 8 group sums are combined
 // pairwise in LDS) -- deterministic, and 8x the loads in flight of a one-thread-per-output loop.
 struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; int pidx0; };   // pidx0: flat index of out[0]
-struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; float inv_gs; const float* gs_dev; };     // partials carry the gradient scale: x 1/S
+struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; float inv_gs; const float* gs_dev; unsigned* range_flag; };     // partials carry the gradient scale: x 1/S
 
 __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __shared__ float sh[8][64];
@@ -681,7 +681,10 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
         const int x = threadIdx.x;
         const float gsum = (((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x])) + ((sh[4][x] + sh[5][x]) + (sh[6][x] + sh[7][x]))) * (a.gs_dev ? a.gs_dev[1] : a.inv_gs);
         S.out[i] = gsum;
-        if (a.adam) {                                               // the optimizer step rides on the reduction (dq_qnet_backward_adam)
+        // range guard (dq_qnet_range_check): an S x gradient beyond the f16 pieces' range arrives here as inf / NaN -- reported, never applied
+        const bool finite = fabsf(gsum) < INFINITY;
+        if (!finite) atomicOr(a.range_flag, 1u);
+        if (a.adam && finite) {                                     // the optimizer step rides on the reduction (dq_qnet_backward_adam)
             const size_t k = (size_t)S.pidx0 + i;
             float pk = a.opt.p[k], mk = a.opt.m[k], vk = a.opt.v[k];
             dq_adam1(pk, gsum, mk, vk, a.opt.lr_t, a.opt.b1, a.opt.b2, a.opt.eps);
@@ -1324,7 +1327,13 @@ bool fused_backward_supported(const dq_qnet* Q) {
 // floats of workspace the fused backward needs: [DENSE_WGRAD_SLICES][n_params] dense partials, then [CONV_BWD_MAX_WGS][conv params]
 size_t fused_backward_workspace_floats(const dq_qnet* Q) {
     if (!fused_backward_supported(Q)) return 0;
-    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + 4;     // + {S, 1/S}: GradScale
+    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + 4;     // + {S, 1/S}: GradScale, + the range flag
+}
+
+// the range guard's flag word (include/deepq_hip.h dq_qnet_range_check): the third of the four words behind the partials
+unsigned* fused_range_flag(const dq_qnet* Q) {
+    if (!Q->fpartial) return nullptr;
+    return reinterpret_cast<unsigned*>(Q->fpartial + (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off) + 2;
 }
 
 typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
@@ -1447,6 +1456,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         ReduceArgs ra;
         memset(&ra, 0, sizeof(ra));
         ra.inv_gs = Q->bwd_scale > 0.f ? 1.f / Q->bwd_scale : 0.f; ra.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
+        ra.range_flag = reinterpret_cast<unsigned*>(gs_slot) + 2;
         ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, 0, (int)conv_floats};
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
         reduce_slices_kernel<<<(n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
@@ -1484,6 +1494,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.inv_gs = Q->bwd_scale > 0.f ? 1.f / Q->bwd_scale : 0.f; ra.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
+    ra.range_flag = reinterpret_cast<unsigned*>(gs_slot) + 2;
     if (opt) { ra.opt = *opt; ra.adam = 1; }
     ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0, 0};
     const int blocks0 = ((int)conv_floats + 63) / 64;

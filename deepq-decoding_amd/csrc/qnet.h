@@ -204,6 +204,7 @@ dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_
 // fused_bwd.hip: fused backward (data-gradient chains + all-layer weight gradients) for the same configurations
 bool fused_backward_supported(const dq_qnet* Q);
 size_t fused_backward_workspace_floats(const dq_qnet* Q);
+unsigned* fused_range_flag(const dq_qnet* Q);     // device word of the range guard (dq_qnet_range_check), NULL without the fused backward
 // opt != NULL (phases == 3 only): the final reduction also applies the Adam update to p/m/v (one launch fewer per update)
 struct AdamOpt { float* p; float* m; float* v; float lr_t, b1, b2, eps; };
 // td != NULL: the TD step (dq_td_update's arithmetic) runs in the dense backward's prologue instead of reading dq_dev, and the episode

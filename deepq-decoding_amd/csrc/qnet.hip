@@ -423,6 +423,7 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
     }
     const size_t fws = fused_backward_workspace_floats(Q);
     if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));
+    if (e == hipSuccess && fws) e = hipMemset(Q->fpartial + fws - 4, 0, 4 * sizeof(float));       // {S, 1/S}, range flag
     Q->partial_floats = max_partial;
     if (e != hipSuccess) { dq_set_error("dq_qnet_create: %s", hipGetErrorString(e)); dq_qnet_destroy(Q); return DQ_ERR_HIP; }
     *out = Q;
@@ -469,6 +470,21 @@ dq_status dq_qnet_set_grad_scale(dq_qnet* Q, double grad_scale) {
     DQ_REQUIRE(Q && grad_scale >= 0.0 && grad_scale < 1e30, DQ_ERR_INVALID, "dq_qnet_set_grad_scale: bad argument");
     Q->grad_scale_hint = (float)grad_scale;
     return DQ_OK;
+}
+
+dq_status dq_qnet_range_check(dq_qnet* Q, void* stream) {
+    DQ_REQUIRE(Q, DQ_ERR_INVALID, "dq_qnet_range_check: null handle");
+    unsigned* flag = fused_range_flag(Q);
+    if (!flag) return DQ_OK;                                        // per-layer path only: f32 throughout
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned host = 0;
+    DQ_HIP(hipMemcpyAsync(&host, flag, sizeof(host), hipMemcpyDeviceToHost, st));
+    DQ_HIP(hipStreamSynchronize(st));
+    if (!host) return DQ_OK;
+    DQ_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+    dq_set_error("dq_qnet_range_check: a gradient of the fused backward left the range of its f16 pieces (non-finite weight gradient: "
+                 "TD errors of several thousand); the affected parameters were not updated.  dq_qnet_set_fused(net, 0) selects the f32 path");
+    return DQ_ERR_RANGE;
 }
 
 int dq_qnet_fused_supported(const dq_qnet* Q) { return Q && fused_forward_supported(Q) ? 1 : 0; }

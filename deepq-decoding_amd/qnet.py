@@ -64,6 +64,11 @@ class QNetwork:
         measures max |dq| on the device).  See include/deepq_hip.h dq_qnet_set_grad_scale."""
         check(self.L.dq_qnet_set_grad_scale(self._h, float(grad_scale)))
 
+    def check_range(self):
+        """Synchronises the current stream; raises DeepQError(status=DQ_ERR_RANGE) if a gradient of the fused backward left the range of
+        its f16 pieces since the last call (include/deepq_hip.h dq_qnet_range_check)."""
+        check(self.L.dq_qnet_range_check(self._h, self._stream()))
+
     @property
     def fused_supported(self):
         return bool(self.L.dq_qnet_fused_supported(self._h))

@@ -50,7 +50,8 @@ enum {
     DQ_ERR_UNSUPPORTED = -2, /* configuration outside what the kernels implement */
     DQ_ERR_HIP = -3,         /* a HIP runtime call failed */
     DQ_ERR_NOMEM = -4,
-    DQ_ERR_STATE = -5        /* call made in the wrong state (e.g. step before referee is set) */
+    DQ_ERR_STATE = -5,       /* call made in the wrong state (e.g. step before referee is set) */
+    DQ_ERR_RANGE = -6        /* a value left the range the arithmetic carries (dq_qnet_range_check) */
 };
 
 /* DQ_MODEL_IIDXZ: independent X and Z flips per qubit (generate_IIDXZ_error, Function_Library.py:134-160: two uniforms per qubit, X
@@ -335,6 +336,16 @@ dq_status dq_qnet_backward(dq_qnet* net, const float* params_dev, const float* d
  * declares here the loss scale its dq was computed with (dq = TD error x grad_scale, as dq_td_update's argument): then the same S as in
  * the fused TD path is used, and the two paths give the same bits.  0 (default) = not declared.  No reference counterpart. */
 dq_status dq_qnet_set_grad_scale(dq_qnet* net, double grad_scale);
+
+/* Range guard of the fused backward.  Its gradients travel as f16 pieces (finite up to 65504 after the scale S above): a TD error so
+ * large that some S x gradient leaves that range becomes inf / NaN in the weight gradient, where fp32 arithmetic (the reference's
+ * TensorFlow) would still be finite.  That is never silent: the final reduction raises a device-side flag for every non-finite
+ * gradient element and, when the optimizer step rides on it (dq_qnet_backward_adam, dq_qnet_td_backward_adam*), leaves that element's
+ * parameter and moments untouched.  This call synchronises `stream`, returns DQ_ERR_RANGE if the flag was raised since the last call
+ * and clears it; DQ_OK otherwise (always on the per-layer f32 path).  The agent loop calls it at its host synchronisation points.  With
+ * S x grad_scale in [4, 8) the guard trips for |TD error| of a few thousand (the reference's recorded losses, trained_models/ * / * /
+ * training_history.json, stay below 160, i.e. |TD error| ~ 20).  No reference counterpart. */
+dq_status dq_qnet_range_check(dq_qnet* net, void* stream);
 
 /* The same backward in two phases, for overlapping the gradient all-reduce with compute on several GPUs (no reference
  * counterpart): phase 0 = dueling + dense layers -> grads_dev[dq_qnet_conv_param_count(net) ..) complete; phase 1 = the

@@ -1,0 +1,251 @@
+"""The DQN half pinned to the reference's OWN artefacts: its shipped trained agents (trained_models/*/*/final_dqn_weights.h5f, committed as
+data fixtures tests/golden/keras_weights_*.npz) and the one known answer it documents for the Q-network forward -- the production-decoding
+example of /root/reference/README.md:694-829 (d = 5, X noise, agent d5_x/0.007, `corrections == [21]`).
+
+Tolerance (BASELINE.json north_star: "within 1e-5 on Q-values/loss"): the shipped agents' Q-values are 10 - 70, where float32 itself
+resolves ~4e-6 per value and an ordinary fp32 contraction is 1 - 3e-5 away from float64; an ABSOLUTE 1e-5 is therefore only meaningful
+for |Q| <~ 1.  The bound used here is SCALE-AWARE, 1e-5 * max(1, max |Q|) (i.e. 1e-5 relative to the largest Q-value of the batch), and
+it is accompanied by side-by-side errors of three fp32-class implementations against the float64 oracle on the same inputs:
+the fused f16x2 chains (operands carried as two f16 pieces = 22 significant bits, f32 accumulation), the per-layer true-f32 MFMA path,
+and torch-CPU fp32 -- with the requirement err_fused <= 1.5 * err_per_layer."""
+import numpy as np
+import pytest
+
+import shipped
+from oracle import dqn_oracle as O
+
+AGENTS = [("d5_x", "0.007", (6, 11, 11), 26), ("d5_dp", "0.007", (7, 11, 11), 51), ("d5_dp", "0.011", (7, 11, 11), 51)]
+
+
+def scale_tol(q_ref):
+    return 1e-5 * max(1.0, float(np.abs(q_ref).max()))
+
+
+def _spec(shape, A):
+    return O.QNetSpec(shape, shipped.C_LAYERS, shipped.FF_LAYERS, A)
+
+
+# ---- CPU: the known answer pins the float64 oracle (and the torch-CPU fp32 restatement) --------------------------------------------
+def test_readme_known_answer_pins_the_oracle_forward():
+    from oracle import env_oracle as E, torch_dqn
+    _, flat = shipped.shipped_weights("d5_x", "0.007")
+    spec = _spec((6, 11, 11), 26)
+    state = shipped.readme_input_state(lambda s: E.padding_syndrome(5, s))
+    assert state.shape == (6, 11, 11) and int(state[:5, 0::2, 0::2].sum()) == 9           # nine ones in the five printed slices
+    q = O.forward(spec, flat, state[None])[0][0]
+    assert int(np.argmax(q)) == 21 and q[21] - np.sort(q)[-2] > 1.0                         # 35.16 against 33.54 (the identity)
+    fwd = lambda s: int(np.argmax(O.forward(spec, flat, np.asarray(s)[None])[0][0]))
+    assert shipped.readme_decode_loop(fwd, lambda c: E.padding_actions(5, c), 25, state.copy()) == shipped.README_CORRECTIONS
+    # with the action plane filled the way the environment fills it (qubit 21 marked) the agent stops: identity
+    marked = state.copy()
+    marked[5] = E.padding_actions(5, [1 if i == 21 else 0 for i in range(25)])
+    assert fwd(marked) == 25
+    # the fp32 torch restatement (the CPU baseline's learner) agrees
+    t = torch_dqn.TorchDQN(spec, flat)
+    assert int(t.forward(t.params, state[None].astype(np.uint8)).argmax()) == 21
+
+
+@pytest.mark.parametrize("family,p,shape,A", AGENTS)
+def test_fp32_class_error_at_trained_magnitudes_cpu(family, p, shape, A):
+    """What 'fp32-class' means at the shipped agents' magnitudes, on real observations: torch-CPU fp32 and the f16x2 operand scheme with
+    exact accumulation (the fused chains' best case) against the float64 oracle.  Both meet the scale-aware bound; neither would meet an
+    absolute 1e-5 by a safe margin (printed)."""
+    from oracle import torch_dqn
+    _, flat = shipped.shipped_weights(family, p)
+    spec = _spec(shape, A)
+    obs = shipped.real_observations(family, float(p), 768)
+    q_ref = O.forward(spec, flat, obs)[0]
+    assert 10.0 < np.abs(q_ref).max() < 100.0                                               # the operating range the verdict names
+    t = torch_dqn.TorchDQN(spec, flat)
+    e_t = np.abs(t.forward(t.params, obs).detach().numpy().astype(np.float64) - q_ref).max()
+    e_s = np.abs(O.forward_f16x2_emulated(spec, flat, obs) - q_ref).max()
+    print(f"{family}/{p}: max|Q| {np.abs(q_ref).max():.1f}  torch-fp32 {e_t:.2e}  f16x2 (exact accumulation) {e_s:.2e}  bound {scale_tol(q_ref):.2e}")
+    assert e_t < scale_tol(q_ref) and e_s < scale_tol(q_ref)
+    assert (np.argmax(O.forward_f16x2_emulated(spec, flat, obs), axis=1) == np.argmax(q_ref, axis=1)).mean() > 0.995
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _net(dq, torch, shape, A, flat, max_batch):
+    net = dq.QNetwork(shape, shipped.C_LAYERS, shipped.FF_LAYERS, A, dueling=True, max_batch=max_batch)
+    assert net.fused_supported and net.n_params == flat.size
+    return net, torch.from_numpy(flat).cuda()
+
+
+@pytest.mark.gpu
+def test_readme_known_answer_on_the_hip_forward(dq, torch_mod):
+    """README.md:694-829 through the product: the façade's padding_syndrome / padding_actions build the input exactly as the README does,
+    both HIP forward paths pick action 21, and the README's loop over dqn.forward ends with corrections == [21]."""
+    torch = torch_mod
+    weights, flat = shipped.shipped_weights("d5_x", "0.007")
+    env = dq.Surface_Code_Environment_Multi_Decoding_Cycles(d=5, p_phys=0.007, p_meas=0.007, error_model="X", use_Y=False, volume_depth=5,
+                                                            static_decoder=None)
+    state = shipped.readme_input_state(env.padding_syndrome)
+    from oracle import env_oracle as E
+    assert np.array_equal(state, shipped.readme_input_state(lambda s: E.padding_syndrome(5, s)))
+    net, params = _net(dq, torch, (6, 11, 11), 26, flat, 16)
+    q_ref = O.forward(_spec((6, 11, 11), 26), flat, state[None])[0][0]
+    obs = torch.from_numpy(state[None].astype(np.uint8)).cuda()
+    for fused in (True, False):
+        net.set_fused(fused)
+        q = net.forward(params, obs)[0].cpu().numpy()
+        assert int(np.argmax(q)) == 21
+        assert np.abs(q - q_ref).max() < scale_tol(q_ref)
+    # the agent surface, as the README drives it
+    model = dq.build_convolutional_nn(shipped.C_LAYERS, shipped.FF_LAYERS, env.observation_space.shape, env.num_actions)
+    dqn = dq.DQNAgent(model=model, nb_actions=env.num_actions, memory=dq.SequentialMemory(limit=1000, window_length=1), nb_steps_warmup=100,
+                      target_model_update=100, policy=dq.GreedyQPolicy(masked_greedy=True), test_policy=dq.GreedyQPolicy(masked_greedy=True),
+                      gamma=0.99, enable_dueling_network=True)
+    dqn.compile(dq.Adam(lr=1e-4))
+    dqn._bind(env)
+    dqn.model.set_weights(weights)
+    assert dqn.forward(state) == 21
+    assert shipped.readme_decode_loop(dqn.forward, env.padding_actions, env.identity_index, state.copy()) == shipped.README_CORRECTIONS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,p,shape,A", AGENTS)
+def test_forward_parity_on_shipped_weights_at_baseline_batch(dq, torch_mod, family, p, shape, A):
+    """B = 4096 real observations through the shipped agent: fused chains, per-layer f32 MFMA path and torch-CPU fp32, each against the
+    float64 oracle.  Bound: 1e-5 * max(1, max |Q|); and the fused path may not be more than 1.5x further from float64 than the true-f32
+    per-layer path.  Greedy actions agree with the oracle's wherever the oracle's top two Q-values are further apart than the bound."""
+    torch = torch_mod
+    from oracle import torch_dqn
+    _, flat = shipped.shipped_weights(family, p)
+    spec = _spec(shape, A)
+    obs = shipped.real_observations(family, float(p), 4096)
+    q_ref = O.forward(spec, flat, obs)[0]
+    tol = scale_tol(q_ref)
+    net, params = _net(dq, torch, shape, A, flat, 4096)
+    obs_t = torch.from_numpy(obs).cuda()
+    err = {}
+    for fused in (True, False):
+        net.set_fused(fused)
+        q = net.forward(params, obs_t).cpu().numpy().astype(np.float64)
+        err["fused" if fused else "per-layer"] = np.abs(q - q_ref).max()
+        top2 = np.sort(q_ref, axis=1)[:, -2:]
+        clear = top2[:, 1] - top2[:, 0] > 2 * tol
+        assert clear.mean() > 0.99 and np.array_equal(np.argmax(q, axis=1)[clear], np.argmax(q_ref, axis=1)[clear])
+    t = torch_dqn.TorchDQN(spec, flat)
+    err["torch-fp32"] = np.abs(t.forward(t.params, obs).detach().numpy().astype(np.float64) - q_ref).max()
+    err["f16x2-exact-acc"] = np.abs(O.forward_f16x2_emulated(spec, flat, obs) - q_ref).max()
+    print(f"{family}/{p}: max|Q| {np.abs(q_ref).max():.1f}  bound {tol:.2e}  max abs error vs float64: " +
+          "  ".join(f"{k} {v:.2e}" for k, v in err.items()))
+    assert err["fused"] < tol and err["per-layer"] < tol and err["torch-fp32"] < tol
+    assert err["fused"] <= 1.5 * err["per-layer"], err
+
+
+def _td_like_dq(rng, B, A, lo=1.0, hi=50.0):
+    """dq of a real update: one non-zero per sample, (TD error) / B at the action taken, |TD error| in [lo, hi] (the shipped agents'
+    training_history.json records losses up to 160, i.e. TD errors of that order -- not the 1/B noise of the unit-scale tests)."""
+    dq_ = np.zeros((B, A), np.float32)
+    td = rng.uniform(lo, hi, size=B) * rng.choice([-1.0, 1.0], size=B)
+    dq_[np.arange(B), rng.randint(0, A, size=B)] = (td / B).astype(np.float32)
+    return dq_
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,p,shape,A", AGENTS)
+def test_backward_parity_on_shipped_weights(dq, torch_mod, family, p, shape, A):
+    """Training forward (dropout on) + backward on the shipped agent with TD errors of 1 - 50: both HIP paths against the float64 oracle,
+    1e-5 of the largest gradient element overall and 1e-4 per layer.  Samples with a ReLU pre-activation within fp32 round-off of zero
+    (scale-aware threshold, a few per cent) get dq = 0."""
+    torch = torch_mod
+    _, flat = shipped.shipped_weights(family, p)
+    spec = _spec(shape, A)
+    B = 1024
+    obs = shipped.real_observations(family, float(p), B)
+    rng = np.random.RandomState(17)
+    seed, t, base = (3, 4), 4242, 9000
+    keep = O.dropout_keep_mask(seed, t, base + np.arange(B), 512, 0.2)
+    q_ref, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    dq_ = _td_like_dq(rng, B, A)
+    fragile = O.fragile_samples(cache, rel=1e-6)
+    print(f"{family}/{p}: {fragile.mean():.2%} fragile samples")
+    assert fragile.mean() < 0.1
+    dq_[fragile] = 0.0
+    g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
+    net, params = _net(dq, torch, shape, A, flat, B)
+    obs_t, dq_t = torch.from_numpy(obs).cuda(), torch.from_numpy(dq_).cuda()
+    for fused in (True, False):
+        net.set_fused(fused)
+        q = net.forward(params, obs_t, training=True, seed=seed, t=t, sample_base=base).cpu().numpy()
+        assert np.abs(q - q_ref).max() < scale_tol(q_ref)
+        for declared in ((1.0 / B, 0.0) if fused else (0.0,)):              # S from the declared loss scale (the loop's) / from max |dq|
+            net.set_grad_scale(declared)
+            g = net.backward(params, dq_t).cpu().numpy()
+            net.set_grad_scale(0.0)
+            net.check_range()
+            err = np.abs(g - g_ref).max()
+            print(f"  {'fused' if fused else 'per-layer'} (declared scale {declared:g}): max |g| {np.abs(g_ref).max():.3e}  max abs error {err:.2e}")
+            assert err < 1e-5 * max(np.abs(g_ref).max(), 1.0)
+            for li, ((gk, gb), (rk, rb)) in enumerate(zip(spec.split(g), spec.split(g_ref))):
+                for a, b in ((gk, rk), (gb, rb)):
+                    assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-7, (fused, li, np.abs(a - b).max(), np.abs(b).max())
+
+
+@pytest.mark.gpu
+def test_td_errors_beyond_the_fused_range_raise_range_error(dq, torch_mod):
+    """The fused backward carries S x gradient in f16 pieces (S x grad_scale in [4, 8)): a TD error of 1e4 does not fit.  It must not
+    silently give inf: dq_qnet_range_check reports DQ_ERR_RANGE, the non-finite elements are not applied by the riding Adam step (the
+    parameters stay finite), and the flag clears.  A TD error of 1000 is inside the range and matches the oracle; the per-layer f32 path
+    takes 1e4 (and 1e6) without complaint."""
+    torch = torch_mod
+    from importlib import import_module
+    Q = import_module("deepq-decoding_amd.qnet")
+    L = import_module("deepq-decoding_amd._lib")
+    _, flat = shipped.shipped_weights("d5_dp", "0.011")
+    shape, A, B = (7, 11, 11), 51, 256
+    spec = _spec(shape, A)
+    obs = shipped.real_observations("d5_dp", 0.011, B)
+    net, params = _net(dq, torch, shape, A, flat, B)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    obs_t = cu(obs)
+    rng = np.random.RandomState(3)
+    action, idx = cu(rng.randint(0, A, size=B).astype(np.int32)), cu(np.arange(B, dtype=np.int32))
+    reward, terminal = cu(np.zeros(B, np.float32)), cu(np.zeros(B, np.uint8))
+    seed, t = (1, 2), 7
+    keep = O.dropout_keep_mask(seed, t, np.arange(B), 512, 0.2)
+    q0_ref, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    fragile = O.fragile_samples(cache, rel=1e-6)
+
+    def run(td_size, fused):
+        """One td_backward_adam with Q_target(s1) = -td_size / gamma everywhere, i.e. a TD error of Q(s0)[a] + td_size."""
+        net.set_fused(fused)
+        p_, m_, v_, g_ = params.clone(), torch.zeros_like(params), torch.zeros_like(params), torch.empty_like(params)
+        q1 = torch.full((B, A), -td_size / 0.99, dtype=torch.float32, device="cuda")
+        q0 = net.forward(p_, obs_t, training=True, seed=seed, t=t)
+        met = torch.zeros(Q.TD_METRICS_FLOATS, dtype=torch.float32, device="cuda")
+        td = dict(q_online_s1=q1, q_target_s1=q1, q_s0=q0, reward=reward, terminal=terminal, action=action, gamma=0.99, grad_scale=1.0 / B,
+                  index=idx, y=torch.empty(B, device="cuda"), dq=torch.empty((B, A), device="cuda"), metrics=met)
+        net.td_backward_adam(p_, td, g_, m_, v_, 1, 1e-4)
+        return p_, g_, td["dq"]
+
+    # inside the range: handled, equal to the oracle
+    p_, g_, dq_ = run(1000.0, True)
+    net.check_range()
+    dq_np = dq_.cpu().numpy().astype(np.float64)
+    dq_np[fragile] = 0.0
+    assert np.abs(dq_np).max() * B > 900.0
+    g_ref = O.backward(spec, flat, cache, dq_np)
+    if not fragile.any():
+        assert np.abs(g_.cpu().numpy() - g_ref).max() < 1e-5 * np.abs(g_ref).max()
+    assert torch.isfinite(p_).all() and not torch.equal(p_, params)
+    # beyond it: reported, not applied, flag cleared by the report
+    for td_size in (1e4, 1e6):
+        p_, g_, _ = run(td_size, True)
+        with pytest.raises(dq.DeepQError) as ei:
+            net.check_range()
+        assert ei.value.status == L.DQ_ERR_RANGE
+        assert not torch.isfinite(g_).all() and torch.isfinite(p_).all()
+        net.check_range()
+    # the f32 path has fp32's range
+    p_, g_, _ = run(1e6, False)
+    net.check_range()
+    assert torch.isfinite(g_).all() and torch.isfinite(p_).all()
