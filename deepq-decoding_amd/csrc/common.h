@@ -123,16 +123,57 @@ __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
 // head - 2]: filled - 3 candidates, newest first.  The sampler reads terminal[] only at slots <= head - 3 and the newest row it can
 // return is head - 2, so an update's minibatch can be drawn one vector step early (on the environment launch that WRITES slot head - 2
 // of the ring as the update will see it) and does not depend on the environment step taken in the update's own vector step.
+// DISTINCT ROWS (round 3).  keras-rl's first draw is random.sample(range(low, high), batch_size) -- without replacement -- whenever the
+// range holds at least batch_size indexes (else np.random integers with replacement and a warning); only the REDRAW of an idx behind a
+// terminal is a fresh independent draw (which may repeat another sample's row).  Over the N lattices of the ring the candidates are the
+// M = (filled - 3) * n_envs rows (candidate j of lattice e = flat index j * n_envs + e).  With batch <= M the first draw of sample
+// `sample_id` is  pi_t(sample_id mod M),  pi_t a bijection of [0, M) keyed by (seed, t): a four-round unbalanced Feistel network over
+// the next power of two (round keys = the four Philox words of the update's key counter; round function = the murmur3 finaliser),
+// cycle-walked back into [0, M) -- a minibatch's first draws are distinct rows, each row equally likely, and the row still depends
+// only on (seed, t, global sample id).  Redraws (attempt >= 1), and every draw when batch > M, are the independent Philox draws of
+// rounds 1-2.  Restated in oracle/memory_oracle.py device_replay_rows.
 #define DQ_REPLAY_MIN_FILLED 4                          // nb_entries >= window_length + 2
-__device__ __forceinline__ int dq_replay_row(const u8* __restrict__ terminal, int n_envs, int n_slots, int head_slot, int filled,
+__device__ __forceinline__ u32 dq_mix32(u32 h) {        // murmur3 fmix32
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+// pi_t(x) for x in [0, M), M >= 1; k[4] = the round keys
+__device__ __forceinline__ u32 dq_replay_permute(u32 x, u32 M, const u32 k[4]) {
+    if (M < 2u) return 0u;
+    const int bits = 32 - __clz((int)(M - 1u));         // 2^(bits-1) < M <= 2^bits
+    const int a = bits >> 1, b = bits - a;              // low half: a bits, high half: b bits (a may be 0)
+    const u32 ma = (1u << a) - 1u, mb = (1u << b) - 1u;
+    u32 v = x;
+    do {
+        u32 hi = v >> a, lo = v & ma;
+        hi ^= dq_mix32(lo ^ k[0]) & mb;
+        lo ^= dq_mix32(hi ^ k[1]) & ma;
+        hi ^= dq_mix32(lo ^ k[2]) & mb;
+        lo ^= dq_mix32(hi ^ k[3]) & ma;
+        v = hi << a | lo;
+    } while (v >= M);                                   // cycle walking: x lies on the cycle, so this ends; < 2 trips on average
+    return v;
+}
+__device__ __forceinline__ int dq_replay_row(const u8* __restrict__ terminal, int n_envs, int n_slots, int head_slot, int filled, int batch,
                                              u32 seed0, u32 seed1, u64 t, u32 sample_id) {
     const int cand = filled - 3;
+    const u32 M = (u32)cand * (u32)n_envs;
+    const bool distinct = (u32)batch <= M;
     int row = 0;
     for (u32 attempt = 0; attempt < 64; ++attempt) {
-        u32 w[4];
-        philox4x32_10((u32)t, (u32)(t >> 32), sample_id, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
-        const int j = (int)__umulhi(w[0], (u32)cand);   // 0 = newest candidate
-        const int env = (int)__umulhi(w[1], (u32)n_envs);
+        int j, env;
+        if (attempt == 0 && distinct) {
+            u32 k[4];
+            philox4x32_10((u32)t, (u32)(t >> 32), 0xffffffffu, 0xffffu | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, k);
+            const u32 flat = dq_replay_permute(sample_id % M, M, k);
+            j = (int)(flat / (u32)n_envs);
+            env = (int)(flat - (u32)j * (u32)n_envs);
+        } else {
+            u32 w[4];
+            philox4x32_10((u32)t, (u32)(t >> 32), sample_id, attempt | ((u32)DQ_STREAM_REPLAY << 16), seed0, seed1, w);
+            j = (int)__umulhi(w[0], (u32)cand);         // 0 = newest candidate
+            env = (int)__umulhi(w[1], (u32)n_envs);
+        }
         int slot = head_slot - 2 - j;
         if (slot < 0) slot += n_slots;
         row = slot * n_envs + env;

@@ -16,7 +16,7 @@ __global__ void replay_sample_kernel(const u8* __restrict__ terminal, int n_envs
                                      int batch, u32 seed0, u32 seed1, u64 t, u32 sample_base, int32_t* __restrict__ index) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    const int row = dq_replay_row(terminal, n_envs, n_slots, head_slot, filled, seed0, seed1, t, sample_base + (u32)b);
+    const int row = dq_replay_row(terminal, n_envs, n_slots, head_slot, filled, batch, seed0, seed1, t, sample_base + (u32)b);
     index[b] = row;
 }
 
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void post_step_kernel(const u8* __restrict__ t
                                                         unsigned long long* __restrict__ stats) {
     if ((int)blockIdx.x < sample_blocks) {
         const int b = blockIdx.x * blockDim.x + threadIdx.x;
-        if (b < batch) index[b] = dq_replay_row(terminal, n_envs, n_slots, head_slot, filled, seed0, seed1, t, sample_base + (u32)b);
+        if (b < batch) index[b] = dq_replay_row(terminal, n_envs, n_slots, head_slot, filled, batch, seed0, seed1, t, sample_base + (u32)b);
         return;
     }
     dq_episode_stats_lane(done, was_reset, lifetime, reward, n, ((int)blockIdx.x - sample_blocks) * blockDim.x + threadIdx.x, stats);

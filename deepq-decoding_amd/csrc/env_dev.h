@@ -82,7 +82,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
     if (block >= p.env_blocks) {                                            // replay sampling rides along (independent of this step's results)
         const int b = (block - p.env_blocks) * THREADS + tid;
         if (b < p.s_batch)
-            p.s_index[b] = dq_replay_row(p.s_terminal, p.n_envs, p.s_n_slots, p.s_head, p.s_filled, p.s_seed0, p.s_seed1, p.s_t, p.s_base + (u32)b);
+            p.s_index[b] = dq_replay_row(p.s_terminal, p.n_envs, p.s_n_slots, p.s_head, p.s_filled, p.s_batch, p.s_seed0, p.s_seed1, p.s_t, p.s_base + (u32)b);
         return;
     }
     const int i = block * EPB + wave;

@@ -427,12 +427,17 @@ dq_status dq_qnet_td_backward_phase0_env(dq_qnet* net, const float* params_dev, 
  * Device replay ring: row r = slot*n_envs + env stores (observation, action, reward, terminal) of the
  * step taken from that observation; its successor observation is row r + n_envs (mod n_slots*n_envs).
  * ------------------------------------------------------------------------------------------- */
-/* Uniform minibatch rows (with replacement -- a documented deviation from random.sample) over exactly the transitions upstream
- * keras-rl 0.4.2 SequentialMemory.sample can return (oracle/memory_oracle.py): idx = sample_batch_indexes(window_length,
- * nb_entries - 1) + 1 and the transition used is idx - 1, i.e. every stored transition except the newest (its successor observation
- * is not in keras-rl's memory yet) and entry 0, redrawing those whose predecessor entry was terminal (terminals[idx - 2]).
- * head_slot = slot of the newest observation, filled_slots = slots written so far (4 <= filled_slots <= n_slots; nb_entries =
- * filled_slots - 1).  Draws: Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b, attempt | DQ_STREAM_REPLAY<<16)):
+/* Uniform minibatch rows over exactly the transitions upstream keras-rl 0.4.2 SequentialMemory.sample can return
+ * (oracle/memory_oracle.py): idx = sample_batch_indexes(window_length, nb_entries - 1) + 1 and the transition used is idx - 1, i.e.
+ * every stored transition except the newest (its successor observation is not in keras-rl's memory yet) and entry 0, redrawing those
+ * whose predecessor entry was terminal (terminals[idx - 2]).  head_slot = slot of the newest observation, filled_slots = slots written
+ * so far (4 <= filled_slots <= n_slots; nb_entries = filled_slots - 1).
+ * As in keras-rl (random.sample, Single_Point_Training_Script.py:109 -> SequentialMemory.sample), the FIRST draws of a minibatch are
+ * WITHOUT replacement whenever the M = (filled_slots - 3) * n_envs candidate rows are at least `batch`: sample b takes candidate
+ * pi_t((sample_base + b) mod M), pi_t a keyed bijection of [0, M) (four-round Feistel network + cycle walking; round keys =
+ * Philox(key=seed, ctr=(t_lo, t_hi, 0xffffffff, 0xffff | DQ_STREAM_REPLAY<<16)); csrc/common.h dq_replay_permute); candidate
+ * c = slot head_slot - 2 - c / n_envs, lattice c mod n_envs.  A redraw (attempt >= 1) -- and every draw when batch > M, keras-rl's
+ * with-replacement fallback -- is independent: Philox(key=seed, ctr=(t_lo, t_hi, sample_base + b, attempt | DQ_STREAM_REPLAY<<16)),
  * slot = head_slot - 2 - ((w0 * (filled_slots - 3)) >> 32), env = (w1 * n_envs) >> 32.  Terminal flags are read no newer than slot
  * head_slot - 3, so an update's minibatch may be drawn one vector step early (with the head_slot / filled_slots it WILL have). */
 dq_status dq_replay_sample(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots,

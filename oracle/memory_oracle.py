@@ -20,8 +20,9 @@ published upstream keras-rl 0.4.2 ``rl/memory.py`` algorithm, written from its d
   entry (its successor observation is not stored yet), never entry 0 (the flag before it is unknown), never an entry
   whose predecessor is terminal (that entry holds the terminal observation of the finished episode).
 
-The device sampler (csrc/common.h dq_replay_row) draws rows with replacement from a ring shared by N lattices; the GPU
-tests compare ITS SUPPORT AND VALIDITY with `valid_transitions` below, per lattice.
+The device sampler (csrc/common.h dq_replay_row) draws rows from a ring shared by N lattices -- first draws distinct (a keyed
+permutation of the candidate rows), redraws independent, as above; `device_replay_rows` restates it bit for bit, and the GPU tests
+compare its SUPPORT AND VALIDITY with `valid_transitions` below, per lattice.
 """
 import random
 import warnings
@@ -125,4 +126,68 @@ def valid_transitions(terminal_ring, n_envs, n_slots, head_slot, filled_slots):
         mem = lattice_memory(terminal_ring, e, n_slots, head_slot, filled_slots)
         for idx in mem.valid_idxs():
             rows.add(mem.observations[idx - 1] * n_envs + e)
+    return rows
+
+
+# ---- bit-exact restatement of the device sampler (csrc/common.h dq_replay_permute / dq_replay_row) -------------------------------------
+def _mix32(h):
+    h = np.asarray(h, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def replay_permute(x, M, keys):
+    """pi_t(x) for an array x of values in [0, M): four-round unbalanced Feistel network over the next power of two, cycle-walked."""
+    x = np.asarray(x, dtype=np.uint64)
+    if M < 2:
+        return np.zeros_like(x)
+    bits = int(M - 1).bit_length()
+    a = bits >> 1
+    b = bits - a
+    ma, mb = np.uint64((1 << a) - 1), np.uint64((1 << b) - 1)
+    k = [np.uint64(int(w)) for w in keys]
+    v = x.copy()
+    todo = np.ones(v.shape, dtype=bool)
+    while todo.any():
+        w = v[todo]
+        hi, lo = w >> np.uint64(a), w & ma
+        hi = hi ^ (_mix32(lo ^ k[0]) & mb)
+        lo = lo ^ (_mix32(hi ^ k[1]) & ma)
+        hi = hi ^ (_mix32(lo ^ k[2]) & mb)
+        lo = lo ^ (_mix32(hi ^ k[3]) & ma)
+        v[todo] = (hi << np.uint64(a)) | lo
+        todo &= v >= np.uint64(M)
+    return v
+
+
+def device_replay_rows(terminal_ring, n_envs, n_slots, head_slot, filled_slots, batch, seed, t, sample_base=0):
+    """Ring rows (slot * n_envs + env) the device draws for samples sample_base .. sample_base + batch - 1 of update t."""
+    from . import philox
+    term = np.asarray(terminal_ring).reshape(n_slots, n_envs)
+    cand = filled_slots - 3
+    M = cand * n_envs
+    distinct = batch <= M
+    ids = (sample_base + np.arange(batch, dtype=np.uint64)) & np.uint64(0xFFFFFFFF)
+    t_lo, t_hi = int(t) & philox.MASK, (int(t) >> 32) & philox.MASK
+    rows = np.zeros(batch, dtype=np.int64)
+    live = np.ones(batch, dtype=bool)
+    for attempt in range(64):
+        if not live.any():
+            break
+        sel = np.flatnonzero(live)
+        if attempt == 0 and distinct:
+            keys = philox.philox4x32((t_lo, t_hi, 0xFFFFFFFF, 0xFFFF | (philox.STREAM_REPLAY << 16)), seed)
+            flat = replay_permute(ids[sel] % np.uint64(M), M, keys).astype(np.int64)
+            j, e = flat // n_envs, flat % n_envs
+        else:
+            w = philox.philox4x32_np(t_lo, t_hi, ids[sel].astype(np.uint32), attempt | (philox.STREAM_REPLAY << 16), seed)
+            j = ((w[0].astype(np.uint64) * np.uint64(cand)) >> np.uint64(32)).astype(np.int64)
+            e = ((w[1].astype(np.uint64) * np.uint64(n_envs)) >> np.uint64(32)).astype(np.int64)
+        slot = (head_slot - 2 - j) % n_slots
+        rows[sel] = slot * n_envs + e
+        live[sel] = term[(slot - 1) % n_slots, e] != 0
     return rows

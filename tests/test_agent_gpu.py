@@ -84,15 +84,8 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod, name, C1, N, B, steps):
         u = n_updates
         assert core.updates == u
         idx = core.index.cpu().numpy()
-        cand = filled - 3
-        for b in range(B):                                                     # replay rows follow the Philox definition
-            for attempt in range(64):
-                w = philox.philox4x32((u, 0, b, attempt | (philox.STREAM_REPLAY << 16)), seed)
-                j, e = philox.bounded(w[0], cand), philox.bounded(w[1], N)
-                s = (cur - 2 - j) % T
-                if not ring_t[(s - 1) % T, e]:
-                    break
-            assert idx[b] == s * N + e
+        # replay rows follow the device sampler's definition (first draws: a keyed permutation of the candidate rows, redraws: Philox)
+        assert np.array_equal(idx, M.device_replay_rows(ring_t, N, T, cur, filled, B, seed, u))
         assert set(idx.tolist()) <= M.valid_transitions(ring_t, N, T, cur, filled)   # rows keras-rl's sample() can return
         rows = T * N
         flat_obs = ring_obs.reshape(rows, *env.obs_shape)

@@ -384,3 +384,28 @@ def test_feed_forward_referee_from_a_keras_weight_file(tmp_path):
     import subprocess
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
     assert out.returncode == 0 and "(1, 4)" in out.stdout, out.stderr
+
+
+def test_replay_permutation_restatement_is_a_uniform_bijection():
+    """oracle/memory_oracle.py replay_permute (the restatement of csrc/common.h dq_replay_permute, compared bit for bit with the device
+    in tests/test_qnet_gpu.py::test_replay_sample_rule): a bijection of [0, M) for any M, different for different keys, and a fixed
+    position is spread evenly over the range as the key changes."""
+    from oracle import memory_oracle as M, philox
+    for size in (1, 2, 3, 5, 136, 3008, 4096 * 254):
+        keys = philox.philox4x32((7, 0, 0xFFFFFFFF, 0xFFFF | (philox.STREAM_REPLAY << 16)), (1, 2))
+        n = min(size, 100000)
+        out = M.replay_permute(np.arange(n), size, keys)
+        assert out.max() < size and len(set(out.tolist())) == n
+    size = 97
+    hits = np.zeros(size, int)
+    perms = set()
+    for t in range(1, 2001):
+        keys = philox.philox4x32((t, 0, 0xFFFFFFFF, 0xFFFF | (philox.STREAM_REPLAY << 16)), (1, 2))
+        out = M.replay_permute(np.arange(size), size, keys)
+        hits[out[5]] += 1
+        perms.add(tuple(out[:6].tolist()))
+    assert hits.min() > 5 and hits.max() < 45 and len(perms) > 1990
+    # first draws of a minibatch: distinct rows; the whole candidate set when batch == M
+    z = np.zeros((20, 8), np.uint8)
+    rows = M.device_replay_rows(z, 8, 20, 5, 20, 136, (8, 9), 3)
+    assert set(rows.tolist()) == M.valid_transitions(z, 8, 20, 5, 20)

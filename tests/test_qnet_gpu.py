@@ -409,7 +409,9 @@ def test_replay_sample_rule(dq, torch_mod):
     """The device sampler against the restatement of upstream keras-rl 0.4.2 SequentialMemory (oracle/memory_oracle.py), lattice by
     lattice: every sampled row is an experience sample() can return (never the newest transition, never entry 0, never one whose
     predecessor entry was terminal), and with enough draws the SUPPORT is exactly keras-rl's -- full ring (wrapped) and partially
-    filled ring.  The device draws with replacement (documented deviation from random.sample)."""
+    filled ring.  First draws are WITHOUT replacement when the candidates suffice (keras-rl: random.sample), redraws and the
+    batch > candidates case with replacement (keras-rl's own fallback); every draw equals the bit-exact restatement
+    oracle/memory_oracle.py device_replay_rows."""
     torch = torch_mod
     from oracle import memory_oracle as M
     rng = np.random.RandomState(2)
@@ -418,6 +420,7 @@ def test_replay_sample_rule(dq, torch_mod):
                                                   (3, 40, 30, 31, 4000)):
         term = (rng.rand(n_slots, n_envs) < 0.15).astype(np.uint8)
         idx = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, batch, seed, t, sample_base=base).cpu().numpy()
+        assert np.array_equal(idx, M.device_replay_rows(term, n_envs, n_slots, head, filled, batch, seed, t, sample_base=base))
         allowed = M.valid_transitions(term, n_envs, n_slots, head, filled)
         got = set(int(x) for x in idx)
         assert got <= allowed, sorted(got - allowed)[:5]
@@ -432,6 +435,31 @@ def test_replay_sample_rule(dq, torch_mod):
         if batch >= 20 * len(allowed):
             counts = np.bincount(idx, minlength=n_slots * n_envs)[sorted(allowed)]
             assert counts.min() > 0.15 * batch / len(allowed) and counts.max() < 3.0 * batch / len(allowed)
+    # WITHOUT replacement (keras-rl random.sample) whenever the candidates suffice: no terminals -> every row of a minibatch distinct,
+    # up to the whole candidate set (batch == M: a permutation of it); with terminals the first draws that stand are distinct among
+    # themselves (only redraws may repeat a row).  Marginally uniform: over many updates a fixed sample position visits the rows evenly.
+    for n_envs, n_slots, head, filled, batch in ((64, 50, 17, 50, 3008), (64, 50, 17, 50, 512), (4096, 257, 100, 257, 4096), (5, 9, 3, 7, 20),
+                                                  (1, 40, 7, 40, 37), (3, 5, 1, 4, 3)):
+        zeros = np.zeros((n_slots, n_envs), np.uint8)
+        idx = dq.replay_sample(torch.from_numpy(zeros).cuda(), n_envs, n_slots, head, filled, batch, seed, t, sample_base=base).cpu().numpy()
+        assert len(set(idx.tolist())) == batch, (n_envs, n_slots, batch, len(set(idx.tolist())))
+        assert np.array_equal(idx, M.device_replay_rows(zeros, n_envs, n_slots, head, filled, batch, seed, t, sample_base=base))
+        if batch == (filled - 3) * n_envs:
+            assert set(idx.tolist()) == M.valid_transitions(zeros, n_envs, n_slots, head, filled)
+        term = (rng.rand(n_slots, n_envs) < 0.15).astype(np.uint8)
+        idx = dq.replay_sample(torch.from_numpy(term).cuda(), n_envs, n_slots, head, filled, batch, seed, t, sample_base=base).cpu().numpy()
+        first = M.device_replay_rows(zeros, n_envs, n_slots, head, filled, batch, seed, t, sample_base=base)        # the first draws
+        stood = idx == first
+        assert len(set(idx[stood].tolist())) == int(stood.sum()) and set(idx.tolist()) <= M.valid_transitions(term, n_envs, n_slots, head, filled)
+    n_envs, n_slots, head, filled = 8, 20, 5, 20
+    zeros = torch.zeros((n_slots, n_envs), dtype=torch.uint8, device="cuda")
+    draws = np.stack([dq.replay_sample(zeros, n_envs, n_slots, head, filled, 32, seed, tt).cpu().numpy() for tt in range(1, 1501)])
+    cand_rows = sorted(M.valid_transitions(np.zeros((n_slots, n_envs), np.uint8), n_envs, n_slots, head, filled))
+    for pos in (0, 13, 31):                                                # 1500 updates over 136 rows: ~11 visits per row
+        counts = np.bincount(draws[:, pos], minlength=n_slots * n_envs)[cand_rows]
+        assert counts.sum() == 1500 and counts.max() < 30 and (counts == 0).mean() < 0.01
+    chi = ((np.bincount(draws.reshape(-1), minlength=n_slots * n_envs)[cand_rows] - 1500 * 32 / len(cand_rows)) ** 2).sum() / (1500 * 32 / len(cand_rows))
+    assert chi < 2.0 * len(cand_rows), chi                                 # pooled over positions: no row favoured
     # the newest sampleable transition is the PREVIOUS step's (slot head - 2); the step just taken (head - 1) never is
     n_envs, n_slots, head, filled = 64, 50, 17, 50
     term = np.zeros((n_slots, n_envs), np.uint8)
