@@ -73,6 +73,48 @@ def cpu_baseline_env(cfg, seconds=10.0):
                 sample=f"{steps} vector steps x {n} lattices, C oracle env + uniform-legal policy, {dt:.1f}s")
 
 
+def cpu_env_worker(config, t_start, seconds):
+    """One process of the all-cores environment figure: the C oracle environment of `config` (4096 lattices, uniform-legal policy)
+    stepped from wall-clock time t_start for `seconds`; prints the lattice-steps done.  No torch import."""
+    from oracle import c_oracle
+    cfg = {k: v for k, v in CONFIGS[config].items() if k != "n_envs"}
+    env = c_oracle.COracleEnv(n_envs=4096, env_id_base=4096 * (os.getpid() & 0xffff), **cfg)
+    env.reset()
+    while time.time() < t_start:
+        time.sleep(0.01)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        env.step(env.policy_uniform_legal(steps), auto_reset=True)
+        steps += 1
+    print(json.dumps(dict(lattice_steps=4096 * steps, seconds=time.perf_counter() - t0)), flush=True)
+
+
+def cpu_baseline_env_all_cores(config, seconds=5.0):
+    """the C oracle environment on ALL host cores -- one process per core this process may run on, independent
+    lattices, started together, lattice-steps summed.  Returns (env steps/s, cores)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t_start = time.time() + 2.0 + 0.01 * cores
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-env-worker", config, repr(t_start), repr(seconds)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env) for _ in range(cores)]
+    total, longest = 0, 0.0
+    for p in procs:
+        out, _ = p.communicate(timeout=120 + seconds)
+        r = json.loads(out.decode().strip().splitlines()[-1])
+        total, longest = total + r["lattice_steps"], max(longest, r["seconds"])
+    return total / longest, cores
+
+
+def cpu_quota_cores():
+    """CPU quota of this container's cgroup in cores (None = unlimited / unknown): the affinity mask may list every host core while
+    the quota allows far fewer to run at once, which is what bounds the all-cores figure."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_learner(cfg, c_layers, ff_layers):
     import numpy as np
     from oracle import c_oracle, dqn_oracle as O, torch_dqn
@@ -160,6 +202,8 @@ def self_launch(n):
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-env-worker":
+        return cpu_env_worker(sys.argv[2], float(sys.argv[3]), float(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -227,6 +271,8 @@ def main():
     if hasattr(runner, "pick_dominant"):
         runner.pick_dominant()          # untimed probe: which kernel family takes the most time per step
         runner.arm(args.steps)          # ... that family's launches in the timed region are bracketed by HIP events
+    if (world > 1 or force_dist) and hasattr(runner, "core"):
+        runner.core.ar_events = []      # HIP events around the exposed part of the gradient all-reduce, inside the timed loop
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -249,6 +295,12 @@ def main():
         if not replicas_identical and rank == 0:
             print("WARNING: the ranks' parameters diverged", file=sys.stderr)
         allreduce = allreduce_probe(torch, dist, runner.core, backend)
+        ev = runner.core.ar_events or []
+        # inside the timed loop, per step: conv-range all-reduce + wait for the dense range's asynchronous one (core.py _learn), i.e.
+        # the time the step's critical path spends on communication (what N > 1 adds to the N = 1 step besides the separate Adam launch)
+        allreduce["exposed_us_per_step"] = (1e3 * sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if ev else None
+        allreduce["exposed_steps_timed"] = len(ev)
+        runner.core.ar_events = None
 
     params_checksum = None
     if hasattr(runner, "core"):                     # outside the timed region: what the run left in the parameters (path-equivalence checks)
@@ -286,6 +338,13 @@ def main():
             else:
                 bl = importlib.import_module("deepq-decoding_amd.bench_loop")
                 out["cpu_baseline"] = cpu_baseline_loop(full, runner.B, runner.eps, bl.C_LAYERS, bl.FF_LAYERS, mode=mode)
+            if args.config in ("c1", "c2", "c3", "c5"):
+                # the environment alone on one core and on all host cores (C oracle, a port of Environments.py)
+                one = cpu_baseline_env(dict(CONFIGS[args.config], n_envs=4096), seconds=3.0)
+                allc, cores = cpu_baseline_env_all_cores(args.config)
+                out["cpu_baseline"].update(env_only_1core_steps_per_s=one["value"], env_only_all_cores_steps_per_s=allc, env_only_cores=cores, env_only_cgroup_cpu_quota_cores=cpu_quota_cores(),
+                                           env_only_sample="C oracle environment + uniform-legal policy, 4096 lattices per process, one process per "
+                                                           "host core, 5 s, lattice-steps summed")
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.barrier()

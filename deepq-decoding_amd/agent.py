@@ -432,6 +432,9 @@ class DQNAgent:
         venv = self._bind(env)
         core, N = self._core, venv.n_envs
         self.training = True
+        # Several ranks (one per GPU): every step-counted hyper-parameter -- nb_steps, nb_steps_warmup, the epsilon schedule, min_nb_steps,
+        # target_model_update -- counts THIS RANK's environment steps (self.step); what is logged and printed ("Step: a/b", nb_steps in
+        # training_history.json, "Final Step") is global on both sides: self.step * world_size of nb_steps * world_size.
         # several ranks: episode statistics are summed over the ranks at every synchronisation point so that all of them stop on the
         # same step (a rank leaving alone would hang the others in the gradient all-reduce); callbacks and printing on rank 0 only
         lead = core.rank == 0
@@ -482,8 +485,11 @@ class DQNAgent:
                     continue
                 if N == 1:
                     # keras-rl spends one more forward/backward on the terminal observation before env.reset();
-                    # here that is the auto-reset vector step, taken now so that the episode boundary is exact.
-                    core.act_and_step(eps, masked_greedy=masked, record_stats=False)
+                    # here that is the auto-reset vector step, taken now so that the episode boundary is exact.  Several ranks: n_ep is
+                    # the all-reduced count -- only the ranks whose OWN lattice finished take the (uncounted) reset step, a rank whose
+                    # lattice is still alive must not step it; the update is collective (gradient all-reduce), so every rank trains.
+                    if core.local_stats[0] > 0:
+                        core.act_and_step(eps, masked_greedy=masked, record_stats=False)
                     self._maybe_train()
                 now = timeit.default_timer()
                 # one log record per finished episode (N == 1) or per synchronisation chunk (N > 1)
@@ -513,7 +519,7 @@ class DQNAgent:
                     cb.on_episode_end(episode - 1, dict(logs, duration=now - ep_start))
                 logs["duration"] = now - ep_start
                 if verbose >= 2 and (episode // max(1, log_interval)) != ((episode - n_ep) // max(1, log_interval)):
-                    self._print_train_block(episode, nb_steps, logs, now - t_start)
+                    self._print_train_block(episode, nb_steps * core.world_size, logs, now - t_start)
                 ep_start, ep_steps, ep_reward = now, 0, 0.0
                 losses, qs, epss = [], [], []
                 if (has_succeeded or stopped_improving) and (self.step - start_step) >= min_nb_steps:

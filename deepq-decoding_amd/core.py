@@ -86,6 +86,10 @@ class DQNCore:
         self._env_stream = torch.cuda.Stream(device=dev) if os.environ.get("DQ_ENV_STREAM", "0") == "1" else None
         # step_and_update on one GPU: the environment launch rides on the dense backward's first kernel (DQ_RIDE_ENV=0: separate launches)
         self.ride_env = os.environ.get("DQ_RIDE_ENV", "1") != "0"
+        self.local_stats = [0, 0, 0, 0]
+        self.inexact_total = 0
+        self._inexact_acc = torch.zeros((), dtype=torch.int64, device=dev) if getattr(env, "wide", False) else None
+        self.ar_events = None        # bench.py: a list here collects HIP-event pairs around the exposed part of the gradient all-reduce
         self._e_fwd, self._e_env = torch.cuda.Event(), torch.cuda.Event()
         self._env_inflight = False
 
@@ -151,6 +155,7 @@ class DQNCore:
             # its own minibatch (_take_minibatch notices that no look-ahead draw was made)
             self._presampled = None
             check(self.L.dq_envb_act_step(*args, ptr(self.env.inexact), self._stream()))
+            self._inexact_acc += self.env.inexact.sum()              # (read and reported at the next read_stats())
             return
         if sj is not None:
             check(self.L.dq_env_act_step_sample(*args, ctypes.byref(sj), self._stream()))
@@ -254,9 +259,16 @@ class DQNCore:
                 net.td_backward_phase0(self.params, td, self.grads)       # TD step + dueling + dense layers
             work = _dist.allreduce_sum_async(self.grads[nconv:], group=self.pg)
             net.backward_phase(self.params, self.dq, self.grads, 1)
+            # what the step WAITS for: the convolutional range's all-reduce (critical path) + whatever is left of the dense range's
+            if self.ar_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             _dist.allreduce_sum_(self.grads[:nconv], group=self.pg)
             if work is not None:
                 work.wait()
+            if self.ar_events is not None:
+                e1.record()
+                self.ar_events.append((e0, e1))
             _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
         elif ride is not None:
             net.td_backward_adam_env(self.params, td, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon,
@@ -350,12 +362,27 @@ class DQNCore:
         the loop alone would leave the others waiting in the gradient all-reduce)."""
         self._flush_stats()
         st = self.stats
+        self.local_stats = None
         if all_ranks and self.world_size > 1:
+            self.local_stats = [int(x) for x in st.cpu().tolist()]       # this rank's own share (DQNAgent.fit: the single-lattice episode end)
             st = st.clone()
             _dist.allreduce_sum_(st, group=self.pg)
         s = [int(x) for x in st.cpu().tolist()]
+        if self.local_stats is None:
+            self.local_stats = list(s)
         if reset:
             self.stats.zero_()
+        if self._inexact_acc is not None:
+            # wide environment: lattice-steps whose reward / done came from the matching referee's FALLBACK (more than 14 defects in a
+            # component: the rest go to their nearer boundary, csrc/match_dev.h) -- heuristic referee decisions must not enter the
+            # replay memory or the lifetime statistics silently
+            n = int(self._inexact_acc.item())
+            if n:
+                self.inexact_total += n
+                self._inexact_acc.zero_()
+                import warnings
+                warnings.warn(f"{n} lattice-steps since the last synchronisation were refereed by the matching decoder's inexact fallback "
+                              f"(> 14 defects in one component; {self.inexact_total} in total): their reward / done are heuristic")
         return s
 
     # -- evaluation on a scratch ring ---------------------------------------------------------------------------------------

@@ -99,6 +99,10 @@ __device__ __forceinline__ u64 wave_uniform64(u64 v) {
     return ((u64)hi << 32) | lo;
 }
 
+// Kernel attributes (hipFuncSetAttribute) are PER DEVICE: a process that uses several GPUs must set them on each.  Bit of the current
+// device in a call site's "already set" mask.
+static inline unsigned long long dq_device_bit() { int dev = 0; (void)hipGetDevice(&dev); return 1ull << (dev & 63); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 // index of the k-th (0-based) set bit of a 128-bit mask; -1 if fewer bits are set

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(64 * BIG_EPB) void env_big_kernel(BigParams p) {
     const int O_X = 0, O_Z = W, O_ACT = 2 * W, O_ROUND = 3 * W, O_META = 3 * W + 1, O_COMP = 3 * W + 2, O_LEGAL = O_COMP + LW, O_VOL = O_LEGAL + LW;
     u64* rec = p.state + (size_t)i * p.sw;
     for (int k = lane; k < p.sw; k += 64) st[k] = rec[k];
+    match_wave_sync();                                               // the record is handed between lanes through LDS: fences, not `volatile` alone (match_dev.h)
     u64 x[W], z[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) { x[w] = st[O_X + w]; z[w] = st[O_Z + w]; }
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(64 * BIG_EPB) void env_big_kernel(BigParams p) {
         } else {                                                     // ENV:185-196
             const int q = a % p.d2;
             const bool fresh = !((st[O_ACT + (q >> 6)] >> (q & 63)) & 1);
+            match_wave_sync();                                       // all lanes have read `acted` before lane 0 sets the bit
             if (lane == 0) {
                 st[O_COMP + (a >> 6)] = st[O_COMP + (a >> 6)] | (1ull << (a & 63));
                 if (fresh) st[O_ACT + (q >> 6)] = st[O_ACT + (q >> 6)] | (1ull << (q & 63));
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(64 * BIG_EPB) void env_big_kernel(BigParams p) {
         }
     }
     // ---- state record and scalar outputs ------------------------------------------------------------------------------------
+    match_wave_sync();                                               // every lane has read the old record before lane 0 overwrites it
     if (lane == 0) {
 #pragma unroll
         for (int w = 0; w < W; ++w) { st[O_X + w] = x[w]; st[O_Z + w] = z[w]; }
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(64 * BIG_EPB) void env_big_kernel(BigParams p) {
         if (p.was_reset) p.was_reset[i] = (u8)(p.mode == 1 && do_reset);
         if (p.inexact) p.inexact[i] = (u8)flag;
     }
+    match_wave_sync();                                               // lane 0's updates (and the action / volume sets written above) are visible to all lanes
     for (int k = lane; k < p.sw; k += 64) rec[k] = st[k];
     if (p.legal && lane < LW) p.legal[(size_t)i * LW + lane] = st[O_LEGAL + lane];
     if (!p.obs) return;
@@ -472,13 +476,19 @@ dq_status dq_envb_create(const dq_env_cfg* cfg, dq_envb** out) {
     E->tab.cell_qubit = reinterpret_cast<const unsigned short*>(E->d_blob + o_cq);
     const dq_status ms = dq_match_create(d, &E->match);
     if (ms != DQ_OK) { dq_envb_destroy(E); return ms; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(env_big_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(env_big_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(env_big_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(env_big_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    static unsigned long long attr_devs = 0;                          // per device (common.h dq_device_bit)
+    const unsigned long long dev_bit = dq_device_bit();
+    if (!(attr_devs & dev_bit)) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(env_big_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(env_big_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(env_big_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ae == hipSuccess) ae = hipFuncSetAttribute(reinterpret_cast<const void*>(env_big_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ae != hipSuccess) {
+            dq_set_error("dq_envb_create: hipFuncSetAttribute: %s", hipGetErrorString(ae));
+            dq_envb_destroy(E);                                         // (frees the tables and the matching referee)
+            return DQ_ERR_HIP;
+        }
+        attr_devs |= dev_bit;
     }
     *out = E;
     return DQ_OK;

@@ -974,15 +974,16 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     DQ_REQUIRE(plan_conv(Q, &cp) && plan_dense(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_forward: configuration not covered");
     DQ_REQUIRE(n_jobs >= 1 && n_jobs <= FWD_MAX_JOBS, DQ_ERR_INVALID, "fused_forward: 1..%d jobs per launch", FWD_MAX_JOBS);
     conv_kernel_t ck = cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;                          // per device (common.h dq_device_bit)
+    const unsigned long long dev_bit = dq_device_bit();
+    if (!(attr_devs & dev_bit)) {
         const conv_kernel_t cks[4] = {conv_chain_kernel<3>, conv_chain_kernel<4>, conv_chain_kernel<5>, conv_chain_kernel<6>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         const dense_kernel_t dks[4] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<4, 4, 4>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
-        attr_set = true;
+        attr_devs |= dev_bit;
     }
     const int nc = Q->cfg.n_conv;
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];

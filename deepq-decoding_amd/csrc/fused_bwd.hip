@@ -1350,13 +1350,14 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     DQ_REQUIRE(plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp), DQ_ERR_UNSUPPORTED, "fused_backward: configuration not covered");
     DQ_REQUIRE((reinterpret_cast<uintptr_t>(params_dev) & 15) == 0, DQ_ERR_INVALID, "fused_backward: params_dev must be 16-byte aligned");
     DQ_REQUIRE(Q->fpartial, DQ_ERR_STATE, "fused_backward: workspace missing");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;                          // per device (common.h dq_device_bit)
+    const unsigned long long dev_bit = dq_device_bit();
+    if (!(attr_devs & dev_bit)) {
         const conv_bwd_kernel_t cks[4] = {conv_bwd_chain_kernel<3>, conv_bwd_chain_kernel<4>, conv_bwd_chain_kernel<5>, conv_bwd_chain_kernel<6>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_MAX));
         DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_WGRAD_LDS));
-        attr_set = true;
+        attr_devs |= dev_bit;
     }
     const int B = Q->last_train_batch, nc = Q->cfg.n_conv, nl = Q->n_layers;
     const Layer &D1 = Q->L[nc], &D2 = Q->L[nc + 1];

@@ -32,6 +32,7 @@ void match_comp(const dq_match* M, int comp, MatchComp* out) {
 
 extern "C" {
 
+void dq_match_destroy(dq_match* M);
 dq_status dq_match_create(int d, dq_match** out) {
     DQ_REQUIRE(out, DQ_ERR_INVALID, "dq_match_create: null argument");
     DQ_REQUIRE(d >= 3 && d <= 15 && (d & 1), DQ_ERR_INVALID, "for the surface code d must be odd! (3 <= d <= 15)");
@@ -54,10 +55,16 @@ dq_status dq_match_create(int d, dq_match** out) {
             return DQ_ERR_HIP;
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(match_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_MATCH_LDS));
-        attr_set = true;
+    static unsigned long long attr_devs = 0;                          // per device (common.h dq_device_bit)
+    const unsigned long long dev_bit = dq_device_bit();
+    if (!(attr_devs & dev_bit)) {
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(match_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_MATCH_LDS);
+        if (ae != hipSuccess) {
+            dq_set_error("dq_match_create: hipFuncSetAttribute: %s", hipGetErrorString(ae));
+            dq_match_destroy(M);
+            return DQ_ERR_HIP;
+        }
+        attr_devs |= dev_bit;
     }
     *out = M;
     return DQ_OK;

@@ -33,6 +33,15 @@ struct MatchComp {
 // Class predicted for the defects `d0 | d1 << 64` (bit i = i-th plaquette of the component in row-major order: the look-up referee's index
 // convention).  All lanes of the wave call it with the same arguments; the result is wave-uniform.  `s` = DQ_MATCH_LDS bytes of LDS owned
 // by this wave.  *inexact is OR-ed with 1 when the fallback was used.
+// Lanes of ONE wave hand values to each other through LDS here (list -> distances -> DP levels -> result): a wave's DS operations retire
+// in order, but the ordering the C++ sees must not rest on `volatile` alone -- a wavefront-scope release / acquire fence pair plus a wave
+// barrier between producer and consumer phases (no cost: s_waitcnt lgkmcnt(0), which the consumer's first read needs anyway).
+static __device__ __forceinline__ void match_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 static __device__ __forceinline__ int match_classify(const MatchComp& T, u64 d0, u64 d1, u8* __restrict__ s, int lane, int* inexact) {
     volatile u8* s_list = s;                                      // [16] node of defect i
     volatile u8* s_pd = s + 16;                                   // [16][16][2] distance defect i -> defect j with class c
@@ -63,6 +72,7 @@ static __device__ __forceinline__ int match_classify(const MatchComp& T, u64 d0,
         for (int m = 32; m >= 1; m >>= 1) { extra_add += __shfl_xor(extra_add, m); extra_par ^= __shfl_xor(extra_par, m); }
         *inexact |= 1;
     }
+    match_wave_sync();                                            // (also orders this call's writes after a previous call's reads of `s`)
     // ---- distances among the k defects ---------------------------------------------------------------------------------------
     for (int t = lane; t < k * k; t += 64) {
         const int i = t / k, j = t - i * k;
@@ -72,6 +82,7 @@ static __device__ __forceinline__ int match_classify(const MatchComp& T, u64 d0,
     }
     if (lane < k) { s_pb[2 * lane] = T.distB[2 * s_list[lane]]; s_pb[2 * lane + 1] = T.distB[2 * s_list[lane] + 1]; }
     if (lane == 0) { f[0] = 0; f[1] = 255; }
+    match_wave_sync();
     // ---- subsets by their HIGHEST defect h: every S in [2^h, 2^(h+1)) depends only on sets below 2^h, so the 2^h subsets of a level are
     //      independent -- one subset per lane (the oracle recurses on the lowest defect; the minimum over all pairings is the same) ------
     const int BIG = 1 << 20;
@@ -95,6 +106,7 @@ static __device__ __forceinline__ int match_classify(const MatchComp& T, u64 d0,
             f[2 * (base + r)] = (u8)(best0 < 255 ? best0 : 255);
             f[2 * (base + r) + 1] = (u8)(best1 < 255 ? best1 : 255);
         }
+        match_wave_sync();                                        // level h complete before level h + 1 (and the final read) looks at it
     }
     int w0 = f[2 * full], w1 = f[2 * full + 1];
     w0 = w0 == 255 ? 1 << 20 : w0;
@@ -102,5 +114,6 @@ static __device__ __forceinline__ int match_classify(const MatchComp& T, u64 d0,
     if (extra_par) { const int t = w0; w0 = w1; w1 = t; }
     w0 += extra_add; w1 += extra_add;
     const int v0 = min(w0, w1 + T.w10), v1 = min(w1, w0 + T.w10);
+    match_wave_sync();                                            // every lane has read its result before a following call reuses `s`
     return __builtin_amdgcn_readfirstlane(v1 < v0);
 }

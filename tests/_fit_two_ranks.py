@@ -15,10 +15,13 @@ import torch.distributed as dist
 
 def main():
     out_dir = sys.argv[1]
+    single = len(sys.argv) > 2 and sys.argv[2] == "single"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     dq = importlib.import_module("deepq-decoding_amd")
+    if single:
+        return main_single(dq, out_dir, rank)
     N = 64
     # rank 1's lattices are almost noiseless: its episodes are ~100x rarer than rank 0's, so a patience counted in LOCAL episodes would run out
     # on rank 0 long before rank 1
@@ -38,6 +41,29 @@ def main():
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(dict(step=agent.step, updates=agent._core.updates, params=chk, stopped=hist.history["stopped_improving"][-1],
                        records=len(hist.history["episode"])), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main_single(dq, out_dir, rank):
+    """ONE lattice per rank (keras-rl's own shape) under two ranks: a rank whose lattice is still alive must not spend the extra
+    'forward/backward on the terminal observation' step when only the OTHER rank's episode ended -- its lattice's steps are all counted
+    (lifetime statistics) -- while the update stays collective.  Rank 1 is nearly noiseless, so its episodes practically never end."""
+    p = 0.05 if rank == 0 else 0.0002
+    env = dq.VectorEnv(n_envs=1, env_id_base=rank, d=3, error_model="X", use_Y=False, volume_depth=3, p_phys=p, p_meas=p)
+    model = dq.build_convolutional_nn([[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]], env.obs_shape, env.num_actions)
+    agent = dq.DQNAgent(model=model, nb_actions=env.num_actions, memory=dq.SequentialMemory(limit=500, window_length=1), nb_steps_warmup=20,
+                        target_model_update=50, policy=dq.EpsGreedyQPolicy(eps=0.3, masked_greedy=True), test_policy=dq.GreedyQPolicy(masked_greedy=True),
+                        gamma=0.99, enable_dueling_network=True, batch_size=8, seed=(1, 2))
+    agent.compile(dq.Adam(lr=1e-4))
+    hist = agent.fit(env, nb_steps=300, verbose=0, episode_averaging_length=10, success_threshold=None, stopping_patience=None,
+                     min_nb_steps=0, single_cycle=False)
+    core = agent._core
+    chk = int(core.params.view(torch.int32).to(torch.int64).sum().item())
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        # vector_steps counts every environment launch of this rank: the 300 counted steps + one uncounted reset step per LOCAL episode end
+        json.dump(dict(step=agent.step, updates=core.updates, params=chk, vector_steps=core.vector_steps,
+                       episodes_global=(hist.history["episode"][-1] + 1) if hist.history.get("episode") else 0), f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -92,3 +92,20 @@ def test_fit_stops_on_the_same_step_on_every_rank(tmp_path):
     assert a["stopped"] is True and a["step"] < 64 * 400 and a["updates"] > 0
     data = json.load(open(tmp_path / "training_history.json"))
     assert len(data["episode"]) == a["records"]
+
+
+@pytest.mark.gpu
+def test_single_lattice_fit_under_two_ranks_counts_every_step(tmp_path):
+    """N = 1 per rank, two ranks: the extra auto-reset step behind an episode end is taken only by the rank whose own lattice finished
+    (the noisy rank 0: one extra launch per local episode; the nearly noiseless rank 1: none), both ranks take the same number of
+    collective updates and hold identical parameters."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "tests", "_fit_two_ranks.py"), str(tmp_path), "single"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
+    assert a["step"] == b["step"] == 300 and a["updates"] == b["updates"] > 0 and a["params"] == b["params"]
+    # every episode end costs exactly ONE uncounted reset step, on the rank that owns the lattice (before the fix both ranks spent one
+    # whenever either finished: extra_a == extra_b == number of episode ends)
+    extra_a, extra_b = a["vector_steps"] - 300, b["vector_steps"] - 300
+    assert a["episodes_global"] == b["episodes_global"] == extra_a + extra_b and extra_a > extra_b > 0
