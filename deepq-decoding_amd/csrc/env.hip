@@ -40,7 +40,8 @@ struct dq_env {
 
 __global__ __launch_bounds__(256) void env_kernel(EnvParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    env_block<ENVS_PER_BLOCK>(p, (int)blockIdx.x, smem);
+    if (p.pair) env_block2<2 * ENVS_PER_BLOCK>(p, (int)blockIdx.x, smem);     // block-uniform (kernel argument): two lattices per wave, d <= 5
+    else env_block<ENVS_PER_BLOCK>(p, (int)blockIdx.x, smem);
 }
 
 // ---- state export / import (tests, checkpointing) ------------------------------------------------
@@ -395,7 +396,14 @@ dq_status dq_env_get_referee(dq_env* E, uint8_t* lut_x_host, uint8_t* lut_z_host
     return DQ_OK;
 }
 
-static dq_status fill_common(dq_env* E, EnvParams& p, int epb) {
+// epb = lattices per block at one lattice per wave; doubled when the lattices go two to a wave (env_dev.h env_block2: everything of
+// a lattice fits 32 lanes; DQ_ENV_PAIR=0 switches it off for A/B runs)
+static bool env_pairs(const dq_env* E) {
+    static const bool enabled = !(getenv("DQ_ENV_PAIR") && getenv("DQ_ENV_PAIR")[0] == '0');
+    return enabled && E->cfg.d * E->cfg.d <= 32 && E->info.n_stab <= 32 && E->sw <= 32;
+}
+
+static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = false) {
     DQ_REQUIRE(E->rates_set, DQ_ERR_STATE, "dq_env_set_rates has not been called");
     p.tab = E->d_tab; p.state = E->d_state; p.lut_x = E->lut_x; p.lut_z = E->lut_z; p.lut_joint = E->lut_joint;
     p.n_envs = E->cfg.n_envs; p.d2 = E->cfg.d * E->cfg.d; p.n_stab = E->info.n_stab; p.depth = E->cfg.volume_depth;
@@ -404,6 +412,10 @@ static dq_status fill_common(dq_env* E, EnvParams& p, int epb) {
     p.obs_size = E->info.obs_c * E->P;
     p.env_id_base = E->cfg.env_id_base; p.seed0 = E->cfg.seed[0]; p.seed1 = E->cfg.seed[1];
     p.T_phys = E->T_phys; p.T_meas = E->T_meas;
+    // two to a wave only where the step rides on the dense backward (there it halves the rounds of environment workgroups: -3.7 us per
+    // vector step); the stand-alone launch measured 17.4 us one per wave against 17.8 us two per wave (fewer, longer waves)
+    p.pair = rider && env_pairs(E) ? 1 : 0;
+    if (p.pair) epb *= 2;
     p.env_blocks = (p.n_envs + epb - 1) / epb;
     return DQ_OK;
 }
@@ -412,7 +424,7 @@ static dq_status launch_env(dq_env* E, EnvParams& p, hipStream_t st) {
     const dq_status rc = fill_common(E, p, ENVS_PER_BLOCK);
     if (rc != DQ_OK) return rc;
     dq_prof_begin(DQ_K_ENV, st);
-    env_kernel<<<p.env_blocks + p.s_blocks, 64 * ENVS_PER_BLOCK, env_block_lds(ENVS_PER_BLOCK, p.obs_size), st>>>(p);
+    env_kernel<<<p.env_blocks + p.s_blocks, 64 * ENVS_PER_BLOCK, env_block_lds((p.pair ? 2 : 1) * ENVS_PER_BLOCK, p.obs_size), st>>>(p);
     dq_prof_end(DQ_K_ENV, st);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
@@ -525,9 +537,9 @@ dq_status env_fill_act_step(dq_env* E, const float* q_dev, double eps, int maske
     dq_status rc = fill_act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev,
                                  lifetime_dev, was_reset_dev, sj, 512, *p);
     if (rc != DQ_OK) return rc;
-    rc = fill_common(E, *p, 8);
+    rc = fill_common(E, *p, 8, true);
     if (rc != DQ_OK) return rc;
     p->stats = reinterpret_cast<unsigned long long*>(stats_dev);
-    *lds = env_block_lds(8, p->obs_size);
+    *lds = env_block_lds(p->pair ? 16 : 8, p->obs_size);
     return DQ_OK;
 }

@@ -55,6 +55,7 @@ struct EnvParams {
     // episode bookkeeping of THIS step (dq_episode_stats' four sums), done by the blocks themselves when the step rides on a launch
     // that runs before anything could read its results (fused_bwd.hip); NULL: not here
     unsigned long long* stats;
+    int pair;                      // 1: two lattices per wave (env_block2; d <= 5: qubits, stabilizers and record words all fit 32 lanes)
 };
 
 static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s) {
@@ -295,9 +296,249 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
     }
 }
 
+// ---- two lattices per wave (round 3) ------------------------------------------------------------------------------------------------
+// At d <= 5 a lattice has at most 25 qubits, 24 stabilizers and 25 record words: it fits the 32 lanes of HALF a wavefront.  env_block2
+// runs env_block's arithmetic with lattice 2w + h of the block on half h of wave w -- half as many waves for the same lattices, and no
+// idle upper half in the Philox rounds.  That matters most where the step RIDES on the dense backward's launch (fused_bwd.hip): with
+// 125 VGPRs a CU holds one dense workgroup plus ONE 8-wave environment workgroup, so 4096 one-per-wave lattices took two rounds of
+// environment workgroups (27.7 us per launch); two per wave they take one (measured with half the lattices: 24.1 us).  Same words,
+// same bits: lane h*32 + l stands where lane l stood (Philox counters use l), every 64-bit ballot is read as its own 32-bit half,
+// wave-uniform values become half-uniform (shuffles of width 32 instead of v_readlane), and the two halves diverge freely (step /
+// reset / rejection loop: ordinary EXEC masking).  The referee index needs the second 32 positions of ref_src as a second ballot.
+// EPB = lattices per block (32 * EPB threads).  LDS: env_block_lds(EPB, obs_size).
+static __device__ __forceinline__ u64 half_bcast64(u64 v, int src) {
+    const u32 lo = (u32)__shfl((int)(u32)v, src, 32), hi = (u32)__shfl((int)(u32)(v >> 32), src, 32);
+    return ((u64)hi << 32) | lo;
+}
+
+template <int EPB>
+static __device__ __forceinline__ void env_block2(const EnvParams& p, const int block, u8* __restrict__ smem) {
+    constexpr int THREADS = 32 * EPB;
+    u64* s_vol = reinterpret_cast<u64*>(smem);                              // [EPB][16]
+    u8* s_static = smem + EPB * DQ_MAX_DEPTH * 8;                           // [256]
+    u8* s_stab = s_static + 256;
+    u8* s_qubit = s_stab + 256;
+    u8* s_stage = s_qubit + 256;                                            // [EPB * obs_size]
+    __shared__ unsigned long long s_est2[EPB][4];
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, hl = lane & 31, slot = tid >> 5;
+    const int hshift = 32 * half;
+    if (block >= p.env_blocks) {                                            // replay sampling rides along (independent of this step's results)
+        const int b = (block - p.env_blocks) * THREADS + tid;
+        if (b < p.s_batch)
+            p.s_index[b] = dq_replay_row(p.s_terminal, p.n_envs, p.s_n_slots, p.s_head, p.s_filled, p.s_batch, p.s_seed0, p.s_seed1, p.s_t, p.s_base + (u32)b);
+        return;
+    }
+    const int i = block * EPB + slot;
+    const bool active = i < p.n_envs;                                        // half-uniform
+    auto hb = [&](bool pred) -> u64 { return (u64)(u32)(__ballot(pred) >> hshift); };   // this lattice's 32 bits of a ballot
+
+    for (int k = tid; k < 256; k += THREADS) {
+        s_static[k] = p.tab->cell_static[k];
+        s_stab[k] = p.tab->cell_stab[k];
+        s_qubit[k] = p.tab->cell_qubit[k];
+    }
+    const u64 sq = p.tab->stab_qmask[hl];
+    const u64 qs = p.tab->qubit_smask[hl];
+    const bool isx = p.tab->stab_isx[hl] != 0;
+    const int rsrc_x = p.tab->ref_src[hl], rsrc_z = p.tab->ref_src[32 + hl];
+    volatile u64* vol = s_vol + slot * DQ_MAX_DEPTH;   // written by lane 0 of the half, read by its other lanes
+
+    u64 comp0 = 0, comp1 = 0;
+    if (p.stats && hl < 4) s_est2[slot][hl] = 0;
+    if (active) {
+        u64* rec = p.state + (size_t)i * p.sw;
+        const u64 word = hl < p.sw ? rec[hl] : 0;
+        u64 xmask = half_bcast64(word, 0), zmask = half_bcast64(word, 1), acted = half_bcast64(word, 2);
+        u64 round = half_bcast64(word, 3);
+        comp0 = half_bcast64(word, 4);
+        comp1 = half_bcast64(word, 5);
+        u64 legal0 = half_bcast64(word, 6), legal1 = half_bcast64(word, 7);
+        const u64 meta = half_bcast64(word, 8);
+        u32 lifetime = (u32)meta;
+        int done = (int)((meta >> 32) & 1);
+        if (hl >= STATE_FIXED && hl < STATE_FIXED + p.depth) vol[hl - STATE_FIXED] = word;
+
+        bool do_reset;
+        if (p.mode == 0) {
+            do_reset = p.which ? (p.which[i] != 0) : true;
+        } else {
+            do_reset = p.auto_reset && done;
+        }
+        const bool do_step = p.mode == 1 && !do_reset;
+        float reward = 0.f;
+        bool need_volume = do_reset;
+        if (do_reset) {                                                     // ENV:106-107, 211-213
+            done = 0; lifetime = 0; xmask = 0; zmask = 0;
+        }
+        int a_sel = 0;
+        if (p.policy) {                                                     // EpsGreedyQPolicy / GreedyQPolicy(masked_greedy), see policy.hip
+            u32 w[4];
+            philox4x32_10((u32)p.pt, (u32)(p.pt >> 32), p.env_id_base + (u32)i, (u32)DQ_STREAM_POLICY << 16, p.pseed0, p.pseed1, w);
+            if (p.q == nullptr || (u64)w[1] < p.T_eps) {                    // explore: k-th smallest legal action
+                const int n_legal = __popcll(legal0) + __popcll(legal1);
+                a_sel = kth_set_bit128(legal0, legal1, (int)__umulhi(w[0], (u32)n_legal));
+            } else {                                                        // first maximum of the Q row (optionally over the legal set)
+                const float* row = p.q + (size_t)i * p.n_actions;
+                float best = -INFINITY;
+                int best_a = 0x7fffffff;
+                for (int k = hl; k < p.n_actions; k += 32) {
+                    const bool ok = !p.masked_greedy || (((k < 64 ? legal0 : legal1) >> (k & 63)) & 1);
+                    const float v = row[k];
+                    if (ok && (v > best || best_a == 0x7fffffff)) { best = v; best_a = k; }
+                }
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) {                         // (the butterfly stays inside the half; every lane ends with the result)
+                    const float ov = __shfl_xor(best, m);
+                    const int oa = __shfl_xor(best_a, m);
+                    if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
+                }
+                a_sel = best_a;
+            }
+            if (hl == 0) p.action_out[i] = a_sel;
+        }
+        if (do_step) {
+            int a = p.policy ? a_sel : p.action[i];
+            if ((unsigned)a >= (unsigned)p.n_actions) a = p.identity;
+            const u64 cw = a < 64 ? comp0 : comp1;
+            const bool done_identity = a == p.identity || ((cw >> (a & 63)) & 1);      // ENV:131
+            if (a != p.identity) {                                          // ENV:135-136, FL:243-294
+                const int layer = a / p.d2, q = a - layer * p.d2;
+                const int pauli = p.model == DQ_MODEL_X ? 1 : (p.use_Y ? layer + 1 : (layer == 0 ? 1 : 3));
+                if (pauli != 3) xmask ^= 1ull << q;
+                if (pauli != 1) zmask ^= 1ull << q;
+            }
+            const u64 true_word = hb(__popcll((isx ? xmask : zmask) & sq) & 1);          // ENV:139, FL:152-174
+            const int cls = (__popcll(xmask & p.tab->col0) & 1) + 2 * (__popcll(zmask & p.tab->row0) & 1);  // ENV:143
+            const u32 ix = (u32)hb(rsrc_x < 64 && ((true_word >> (rsrc_x & 63)) & 1));
+            const u32 iz = (u32)hb(rsrc_z < 64 && ((true_word >> (rsrc_z & 63)) & 1));
+            int dec;
+            if (p.lut_joint) {                                              // an arbitrary static_decoder.predict, tabulated (ENV:144,150)
+                const u32 sw = (u32)true_word;                              // bit s = stabilizer s in measurement order (n_stab <= 24)
+                dec = (p.lut_joint[sw >> 4] >> (2 * (sw & 15))) & 3;
+            } else {
+                dec = (p.lut_x[ix >> 5] >> (ix & 31)) & 1;                  // ENV:144
+                if (p.model != DQ_MODEL_X) dec += 2 * ((p.lut_z[iz >> 5] >> (iz & 31)) & 1);
+            }
+            if (cls == 0 && true_word == 0) reward = 1.f;                   // ENV:148-149
+            else if (dec != cls) done = 1;                                  // ENV:150-151
+            if (done_identity) {
+                need_volume = true;                                         // ENV:155
+            } else {                                                        // ENV:185-196
+                if (a < 64) comp0 |= 1ull << a; else comp1 |= 1ull << (a - 64);
+                const int q = a % p.d2;
+                if (!((acted >> q) & 1)) {
+                    acted |= 1ull << q;
+                    const u64 nm = p.tab->neigh_qmask[q];
+                    for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, nm, j * p.d2);
+                }
+            }
+        }
+        if (need_volume) {                                                  // ENV:157-172 == ENV:216-231
+            u64 summed;
+            do {
+                summed = 0;
+                for (int j = 0; j < p.depth; ++j) {
+                    u32 w[4];
+                    philox4x32_10((u32)round, (u32)(round >> 32), p.env_id_base + (u32)i, (u32)hl, p.seed0, p.seed1, w);
+                    const bool hit = hl < p.d2 && (u64)w[0] < p.T_phys;     // FL:99 / FL:119
+                    const int typ = p.model == DQ_MODEL_X ? 1 : 1 + (int)__umulhi(w[1], 3u);   // FL:100
+                    const bool zhit = hl < p.d2 && (u64)w[1] < p.T_phys;    // IIDXZ (FL:134-160)
+                    const u64 ex = hb(p.model == DQ_MODEL_IIDXZ ? hit : hit && typ != 3);
+                    const u64 ez = hb(p.model == DQ_MODEL_IIDXZ ? zhit : hit && typ != 1);
+                    const u64 flips = hb(hl < p.n_stab && (u64)w[2] < p.T_meas);          // FL:191-221
+                    ++round;
+                    xmask ^= ex;                                            // ENV:164, FL:226-241
+                    zmask ^= ez;
+                    const u64 tw = hb(__popcll((isx ? xmask : zmask) & sq) & 1);           // ENV:165
+                    const u64 v = tw ^ flips;                               // ENV:166
+                    if (hl == 0) vol[j] = v;
+                    summed |= v;                                            // ENV:168
+                    ++lifetime;                                             // ENV:169
+                }
+            } while (summed == 0);                                          // ENV:171
+            // reset_legal_moves, ENV:238-258
+            comp0 = comp1 = 0; acted = 0;
+            const u64 legal_q = hb(hl < p.d2 && (qs & summed) != 0);
+            legal0 = legal1 = 0;
+            or_shl128(legal0, legal1, 1ull, p.identity);
+            for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, legal_q, j * p.d2);
+        }
+
+        // ---- state record and scalar outputs ----------------------------------------------------
+        const u64 meta_out = (u64)lifetime | ((u64)done << 32);
+        u64 o = 0;
+        o = hl == 0 ? xmask : o;  o = hl == 1 ? zmask : o;  o = hl == 2 ? acted : o;
+        o = hl == 3 ? round : o;  o = hl == 4 ? comp0 : o;  o = hl == 5 ? comp1 : o;
+        o = hl == 6 ? legal0 : o; o = hl == 7 ? legal1 : o; o = hl == 8 ? meta_out : o;
+        if (hl >= STATE_FIXED && hl < STATE_FIXED + p.depth) o = vol[hl - STATE_FIXED];
+        if (hl < p.sw) rec[hl] = o;
+        if (hl == 0) {
+            if (p.reward) p.reward[i] = reward;
+            if (p.done) p.done[i] = (u8)done;
+            if (p.lifetime) p.lifetime[i] = lifetime;
+            if (p.was_reset) p.was_reset[i] = (u8)(p.mode == 1 && do_reset);
+            if (p.legal) { p.legal[2 * (size_t)i] = legal0; p.legal[2 * (size_t)i + 1] = legal1; }
+            if (p.stats) {                                                  // dq_episode_stats' sums for this lattice
+                const bool stepped = p.mode == 1 && !do_reset, ended = stepped && done;
+                s_est2[slot][0] = ended; s_est2[slot][1] = ended ? lifetime : 0;
+                s_est2[slot][2] = stepped && reward > 0.5f; s_est2[slot][3] = stepped;
+            }
+        }
+    }
+
+    if (!p.obs && !p.stats) return;                                         // block-uniform
+    __syncthreads();                                                        // cell tables (and bookkeeping words) visible
+    if (p.stats && tid < 4) {                                               // integer sums: order-independent; at most four atomics per block
+        unsigned long long v = 0;
+#pragma unroll
+        for (int w = 0; w < EPB; ++w) v += s_est2[w][tid];
+        if (v) atomicAdd(&p.stats[tid], v);
+    }
+    if (!p.obs) return;
+    if (active) {
+        // observation planes into the LDS stage (ENV:174-175, 200-201, 273-314)
+        u8* st = s_stage + slot * p.obs_size;
+        for (int j = 0; j < p.depth; ++j) {
+            const u64 v = vol[j];
+            for (int c = hl; c < p.P; c += 32) {
+                const int sidx = s_stab[c];
+                st[j * p.P + c] = (u8)(s_static[c] | (sidx < 64 ? (u32)((v >> (sidx & 63)) & 1) : 0u));
+            }
+        }
+        for (int k = 0; k < p.layers; ++k) {
+            for (int c = hl; c < p.P; c += 32) {
+                const int qi = s_qubit[c];
+                u32 bit = 0;
+                if (qi < 64) {
+                    const int a = k * p.d2 + qi;
+                    bit = (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1);
+                }
+                st[(p.depth + k) * p.P + c] = (u8)bit;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int first = block * EPB;
+        const int n_valid = min(EPB, p.n_envs - first);
+        const int total = n_valid * p.obs_size;
+        u8* g = p.obs + (size_t)first * p.obs_size;
+        if ((reinterpret_cast<uintptr_t>(g) & 3) == 0) {
+            const u32* s32 = reinterpret_cast<const u32*>(s_stage);
+            u32* g32 = reinterpret_cast<u32*>(g);
+            const int ndw = total >> 2;
+            for (int k = tid; k < ndw; k += THREADS) g32[k] = s32[k];
+            for (int k = (ndw << 2) + tid; k < total; k += THREADS) g[k] = s_stage[k];
+        } else {
+            for (int k = tid; k < total; k += THREADS) g[k] = s_stage[k];
+        }
+    }
+}
+
 // env.hip: validates the arguments of dq_env_act_step(_sample) and fills the parameters of a step WITHOUT launching it: the caller
-// runs env_block<8> on blocks [0, p->env_blocks + p->s_blocks) of its own grid (p->env_blocks, p->s_blocks are set for 8 lattices /
-// 512 sampling threads per block); *lds = the dynamic LDS those blocks need.
+// runs env_block<8> -- or, with p->pair, env_block2<16> -- on blocks [0, p->env_blocks + p->s_blocks) of its own 512-thread grid
+// (p->env_blocks, p->s_blocks are set for that); *lds = the dynamic LDS those blocks need.
 struct dq_env;
 dq_status env_fill_act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
                             int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,

@@ -221,7 +221,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     // launch as extra workgroups.  The dense chain is one 8-wave workgroup per CU with long dependent phases; the environment is a
     // latency chain per lattice: together they fill each other's idle issue slots instead of taking 15 us of their own.
     if (a.env_on && (int)blockIdx.x >= a.dense_wgs) {               // block-uniform
-        env_block<8>(env, (int)blockIdx.x - a.dense_wgs, smem);
+        if (env.pair) env_block2<16>(env, (int)blockIdx.x - a.dense_wgs, smem);      // two lattices per wave (d <= 5): ONE round of environment workgroups
+        else env_block<8>(env, (int)blockIdx.x - a.dense_wgs, smem);
         return;
     }
     float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
