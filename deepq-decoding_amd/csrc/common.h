@@ -105,6 +105,54 @@ static inline unsigned long long dq_device_bit() { int dev = 0; (void)hipGetDevi
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// ---- cross-lane steps on the data-parallel-primitive path (DPP: a source-lane permutation inside the VALU instruction, ~one issue slot)
+// instead of ds_bpermute (__shfl_xor: a round trip through the LDS crossbar, ~100 cycles of latency per dependent step; hipcc emits 107 of
+// them in the dense backward).  Within a row of 16 lanes: quad_perm [1,0,3,2] and [2,3,0,1] are the xor-1 / xor-2 exchanges; after them
+// every quad is uniform, so row_half_mirror (i <-> 7 - i) pairs the quads of an 8-group and row_mirror (i <-> 15 - i) the 8-groups:
+// four steps make a row uniform.  The four rows are then combined from v_readlane (SGPR) copies.
+#define DQ_DPP_XOR1 0xB1
+#define DQ_DPP_XOR2 0x4E
+#define DQ_DPP_HALF_MIRROR 0x141
+#define DQ_DPP_MIRROR 0x140
+template <int CTRL> __device__ __forceinline__ int dq_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float dq_dpp_f(float v) { return __builtin_bit_cast(float, dq_dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+
+// max over the wave's 64 lanes (wave-uniform result)
+__device__ __forceinline__ float dq_wave_max(float v) {
+    v = fmaxf(v, dq_dpp_f<DQ_DPP_XOR1>(v));
+    v = fmaxf(v, dq_dpp_f<DQ_DPP_XOR2>(v));
+    v = fmaxf(v, dq_dpp_f<DQ_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dq_dpp_f<DQ_DPP_MIRROR>(v));
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// First maximum (value, index) over the candidates of a set of lanes; index 0x7fffffff = "no candidate".  The combination rule -- larger
+// value, the smaller index among equals -- is commutative and associative: any exchange order gives the bits of the butterfly it replaces.
+__device__ __forceinline__ void dq_argmax_take(float& best, int& best_a, float ov, int oa) {
+    if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
+}
+// ... within each row of 16 lanes (every lane of the row ends with the row's result)
+__device__ __forceinline__ void dq_row_argmax(float& best, int& best_a) {
+    dq_argmax_take(best, best_a, dq_dpp_f<DQ_DPP_XOR1>(best), dq_dpp_i<DQ_DPP_XOR1>(best_a));
+    dq_argmax_take(best, best_a, dq_dpp_f<DQ_DPP_XOR2>(best), dq_dpp_i<DQ_DPP_XOR2>(best_a));
+    dq_argmax_take(best, best_a, dq_dpp_f<DQ_DPP_HALF_MIRROR>(best), dq_dpp_i<DQ_DPP_HALF_MIRROR>(best_a));
+    dq_argmax_take(best, best_a, dq_dpp_f<DQ_DPP_MIRROR>(best), dq_dpp_i<DQ_DPP_MIRROR>(best_a));
+}
+// ... over the whole wave (wave-uniform result)
+__device__ __forceinline__ void dq_wave_argmax(float& best, int& best_a) {
+    dq_row_argmax(best, best_a);
+    const int ib = __builtin_bit_cast(int, best);
+    float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, 0));
+    int a = __builtin_amdgcn_readlane(best_a, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16)
+        dq_argmax_take(v, a, __builtin_bit_cast(float, __builtin_amdgcn_readlane(ib, r)), __builtin_amdgcn_readlane(best_a, r));
+    best = v; best_a = a;
+}
+
 // index of the k-th (0-based) set bit of a 128-bit mask; -1 if fewer bits are set
 __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
     const int nlo = __popcll(lo);
@@ -264,7 +312,14 @@ static __device__ unsigned long long dq_dbg[4096];            // one copy per tr
         if (DQ_STAMPS == 21 && blockIdx.x < 1024 && threadIdx.x == 0)                                           \
             dq_dbg[(q) * 1024 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();                                 \
     } while (0)
+// DQ_STAMPS == 23: wall-clock start / end of EVERY workgroup (< 1024) of the dense backward's launch, riders included (tools/stamp_loop.py)
+#define DQ_STAMP_ALL(end)                                                                                       \
+    do {                                                                                                        \
+        if (DQ_STAMPS == 23 && blockIdx.x < 1024 && threadIdx.x == 0)                                           \
+            dq_dbg[(end) * 1024 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();                               \
+    } while (0)
 #else
+#define DQ_STAMP_ALL(end) do { } while (0)
 #define DQ_STAMP_PAIR2(q) do { } while (0)
 #define DQ_STAMP(tag, i) do { } while (0)
 #define DQ_STAMP_WG(tag, end) do { } while (0)

@@ -417,6 +417,8 @@ static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = fals
     p.pair = rider && env_pairs(E) ? 1 : 0;
     if (p.pair) epb *= 2;
     p.env_blocks = (p.n_envs + epb - 1) / epb;
+    // the riding step's sampling is drawn by the lattices' own blocks when their threads cover the minibatch (env_dev.h env_inline_sampling)
+    if (rider && p.s_batch > 0 && (long long)p.env_blocks * 512 >= p.s_batch) p.s_blocks = 0;
     return DQ_OK;
 }
 

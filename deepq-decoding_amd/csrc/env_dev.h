@@ -46,7 +46,7 @@ struct EnvParams {
     u32 pseed0, pseed1;
     int32_t* action_out;
     // replay sampling for the update that follows this step (dq_env_act_step_sample): workgroups [env_blocks, env_blocks + s_blocks)
-    int env_blocks, s_blocks;
+    int env_blocks, s_blocks;      // s_blocks == 0 with s_batch > 0: the lattices' own blocks draw the samples behind their step (s_inline)
     const u8* s_terminal;          // the terminal ring; this step writes slot head - 1, the rule only reads older slots
     int s_n_slots, s_head, s_filled, s_batch;
     u32 s_seed0, s_seed1, s_base;
@@ -68,6 +68,18 @@ static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s)
 // grid (env_kernel: blockIdx.x; as a rider on another kernel's launch -- fused_bwd.hip -- the offset is subtracted by the caller).
 // LDS: env_block_lds(EPB, obs_size) bytes at `smem`.
 static inline size_t env_block_lds(int epb, int obs_size) { return (size_t)epb * DQ_MAX_DEPTH * 8 + 3 * 256 + (size_t)epb * ((obs_size + 3) & ~3); }
+
+// Replay sampling by the lattices' own blocks, behind their step (s_blocks == 0): where the step rides on the dense backward, separate
+// sampling workgroups found no free wave slots (one dense + one environment workgroup fill a CU) and started only when a dense
+// workgroup ended -- the launch's tail.  The first blocks were dispatched first and finish first: the extra microsecond is theirs.
+template <int THREADS>
+static __device__ __forceinline__ void env_inline_sampling(const EnvParams& p, const int block) {
+    if (p.s_blocks == 0 && p.s_batch > 0) {
+        const int b = block * THREADS + (int)threadIdx.x;
+        if (b < p.s_batch)
+            p.s_index[b] = dq_replay_row(p.s_terminal, p.n_envs, p.s_n_slots, p.s_head, p.s_filled, p.s_batch, p.s_seed0, p.s_seed1, p.s_t, p.s_base + (u32)b);
+    }
+}
 
 template <int EPB>
 static __device__ __forceinline__ void env_block(const EnvParams& p, const int block, u8* __restrict__ smem) {
@@ -144,12 +156,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
                     const float v = row[k];
                     if (ok && (v > best || best_a == 0x7fffffff)) { best = v; best_a = k; }
                 }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    const float ov = __shfl_xor(best, m);
-                    const int oa = __shfl_xor(best_a, m);
-                    if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
-                }
+                dq_wave_argmax(best, best_a);                               // DPP + v_readlane (common.h), the butterfly's result
                 a_sel = best_a;
             }
             a_sel = __builtin_amdgcn_readfirstlane(a_sel);
@@ -247,7 +254,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
         }
     }
 
-    if (!p.obs && !p.stats) return;                                         // block-uniform
+    if (!p.obs && !p.stats) { env_inline_sampling<THREADS>(p, block); return; }    // block-uniform
     __syncthreads();                                                        // cell tables (and bookkeeping words) visible
     if (p.stats && tid < 4) {                                               // integer sums: order-independent; at most four atomics per block
         unsigned long long v = 0;
@@ -255,7 +262,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
         for (int w = 0; w < EPB; ++w) v += s_est[w][tid];
         if (v) atomicAdd(&p.stats[tid], v);
     }
-    if (!p.obs) return;
+    if (!p.obs) { env_inline_sampling<THREADS>(p, block); return; }
     if (active) {
         // observation planes into the LDS stage (ENV:174-175, 200-201, 273-314)
         u8* st = s_stage + wave * p.obs_size;
@@ -294,6 +301,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
             for (int k = tid; k < total; k += THREADS) g[k] = s_stage[k];
         }
     }
+    env_inline_sampling<THREADS>(p, block);
 }
 
 // ---- two lattices per wave (round 3) ------------------------------------------------------------------------------------------------
@@ -387,12 +395,8 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
                     const float v = row[k];
                     if (ok && (v > best || best_a == 0x7fffffff)) { best = v; best_a = k; }
                 }
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) {                         // (the butterfly stays inside the half; every lane ends with the result)
-                    const float ov = __shfl_xor(best, m);
-                    const int oa = __shfl_xor(best_a, m);
-                    if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
-                }
+                dq_row_argmax(best, best_a);                                // the half's two rows of 16 lanes (DPP, common.h) ...
+                dq_argmax_take(best, best_a, __shfl_xor(best, 16), __shfl_xor(best_a, 16));   // ... combined: every lane of the half ends with the result
                 a_sel = best_a;
             }
             if (hl == 0) p.action_out[i] = a_sel;
@@ -487,7 +491,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
         }
     }
 
-    if (!p.obs && !p.stats) return;                                         // block-uniform
+    if (!p.obs && !p.stats) { env_inline_sampling<THREADS>(p, block); return; }    // block-uniform
     __syncthreads();                                                        // cell tables (and bookkeeping words) visible
     if (p.stats && tid < 4) {                                               // integer sums: order-independent; at most four atomics per block
         unsigned long long v = 0;
@@ -495,7 +499,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
         for (int w = 0; w < EPB; ++w) v += s_est2[w][tid];
         if (v) atomicAdd(&p.stats[tid], v);
     }
-    if (!p.obs) return;
+    if (!p.obs) { env_inline_sampling<THREADS>(p, block); return; }
     if (active) {
         // observation planes into the LDS stage (ENV:174-175, 200-201, 273-314)
         u8* st = s_stage + slot * p.obs_size;
@@ -534,6 +538,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
             for (int k = tid; k < total; k += THREADS) g[k] = s_stage[k];
         }
     }
+    env_inline_sampling<THREADS>(p, block);
 }
 
 // env.hip: validates the arguments of dq_env_act_step(_sample) and fills the parameters of a step WITHOUT launching it: the caller

@@ -15,21 +15,27 @@
 #include "qnet.h"
 #include "env_dev.h"
 
-// Build-time switches of one-box A/B comparisons (tools/build_ab.sh): GX_PIN = a sched_barrier pin of the gX weight ring (measured -12 us:
-// off), GX_RING = its depth in K blocks; WG_ROWS (below) = batch rows per iteration of the dense weight gradients; CB_PRIO / DB_PRIO = static
+// Build-time switches of one-box A/B comparisons (tools/build_ab.sh): GX_PIN = a sched_barrier pin of the gX weight ring, GX_RING = its
+// depth in K blocks.  (Round 2: ring 3 unpinned -- the ISA showed hipcc sinking every load next to its use, one or two in flight per wave, the
+// phase a chain of L2 latencies (20K cycles); ring 3 pinned = 139 VGPRs = three waves per SIMD = no room for the riding environment
+// workgroup beside the dense one.  Round 3: ring 2 PINNED = 117 VGPRs: next block's six loads issued before this block's MFMAs: gX 20K -> 11-14K
+// cycles, dense workgroups end 3.5 us earlier in the loop); WG_ROWS (below) = batch rows per iteration of the dense weight gradients; CB_PRIO / DB_PRIO = static
 // issue priority for the second-dispatched half of an 8-wave workgroup's waves (conv backward -0.55 us, dense backward -0.2 us: on; the same in the
 // dense forward measured nothing).
 #ifndef GX_PIN
-#define GX_PIN 0
+#define GX_PIN 1
 #endif
 #ifndef GX_RING
-#define GX_RING 3
+#define GX_RING 2
+#endif
+#ifndef ENV_PRIO
+#define ENV_PRIO 3                      // the riding environment workgroups (short latency chains) at top issue priority: they end at 14 us instead of 21
 #endif
 #ifndef CB_PRIO
 #define CB_PRIO 1
 #endif
 #ifndef DB_PRIO
-#define DB_PRIO 1
+#define DB_PRIO 0
 #endif
 DQ_STAMP_READER(dq_dbg_read_bwd)
 
@@ -150,30 +156,49 @@ __device__ __forceinline__ void gx_pass(const DenseBwdArgs& a, const unsigned sh
 // gH1 = (gY2 W2^T) * [h1 > 0] * scale on the f16 pipe: K = N2 padded to KB2 blocks of 32 (a compile-time count: a register ring indexed by a
 // run-time block number would live in scratch memory); wave w owns columns 64w + 4j + t.  The result is split on write into the piece
 // planes gX and the weight gradients read.
+// What gh1_phase needs that does NOT depend on the gradient -- its first K block of W2^T pieces and the mask operand (the saved hidden
+// output's pieces) -- is requested at the top of the kernel, under the TD step's own load latencies (round 3: in the loop the phase
+// spent most of its 7-10K cycles waiting for exactly these loads).
+#ifndef GH1_PRE_W
+#define GH1_PRE_W 0                     // 1: the first weight block too (+32 registers across the TD step: 155 VGPRs, three waves per SIMD -- off); 2: behind the TD step, before gY2
+#endif
+struct Gh1Pre { F16x2 bw0[4]; uint2 hvh[4], hvl[4]; };
+__device__ __forceinline__ void gh1_preload(const DenseBwdArgs& a, int b0, int wave, int lane, Gh1Pre& P) {
+    const int j = lane & 15, kq = lane >> 4;
+    const int c0 = 64 * wave + 4 * j;
+    const u32x4* pk = a.packed + a.pk_dense2t + (size_t)(4 * wave) * PK_BLOCK + lane;
+    if (GH1_PRE_W == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { P.bw0[t].h = pk[t * PK_BLOCK]; P.bw0[t].l = pk[t * PK_BLOCK + PK_LO]; }
+    }
+    // the mask operand: the saved hidden output's pieces (h > 0 or, for values below f16's range, l > 0  <=>  the f32 value was > 0)
+    // (rows past the batch are read unclamped -- two base addresses + immediate offsets; eight clamped addresses cost 16 registers and
+    // with them the fourth wave per SIMD, i.e. the co-residence of the riding environment workgroups -- and ignored: they lie inside the
+    // plane buffer, whose sets follow each other, qnet.h)
+    const unsigned short* hp = a.h1_pl + (size_t)(b0 + 4 * kq) * DENSE_HID + c0;
+    const unsigned short* lp = hp + (size_t)a.plane_rows * DENSE_HID;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        P.hvh[r] = *reinterpret_cast<const uint2*>(hp + r * DENSE_HID);
+        P.hvl[r] = *reinterpret_cast<const uint2*>(lp + r * DENSE_HID);
+    }
+}
+
 template <int KB2>
 __device__ __forceinline__ void gh1_phase(const DenseBwdArgs& a, const unsigned short* __restrict__ s_gy2p, unsigned short* __restrict__ s_gh1p,
-                                          int b0, int ns, int wave, int lane) {
+                                          int b0, int ns, int wave, int lane, const Gh1Pre& P) {
     constexpr int LDH = DENSE_HID + 8, LDY = 32 * KB2 + 8;
     const int j = lane & 15, kq = lane >> 4;
     const int c0 = 64 * wave + 4 * j;
     const u32x4* pk = a.packed + a.pk_dense2t + (size_t)(4 * wave) * PK_BLOCK + lane;
     F16x2 bw[2][4];                                                 // two blocks in flight (the loop below is fully unrolled: static indices)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { bw[0][t].h = pk[t * PK_BLOCK]; bw[0][t].l = pk[t * PK_BLOCK + PK_LO]; }
-    // the mask operand: the saved hidden output's pieces (h > 0 or, for values below f16's range, l > 0  <=>  the f32 value was > 0)
-    // (rows past the batch are read unclamped -- two base addresses + immediate offsets; eight clamped addresses cost 16 registers and
-    // with them the fourth wave per SIMD, i.e. the co-residence of the riding environment workgroups -- and ignored: they lie inside the
-    // plane buffer, whose sets follow each other, qnet.h)
-    uint2 hvh[4], hvl[4];
-    {
-        const unsigned short* hp = a.h1_pl + (size_t)(b0 + 4 * kq) * DENSE_HID + c0;
-        const unsigned short* lp = hp + (size_t)a.plane_rows * DENSE_HID;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            hvh[r] = *reinterpret_cast<const uint2*>(hp + r * DENSE_HID);
-            hvl[r] = *reinterpret_cast<const uint2*>(lp + r * DENSE_HID);
-        }
+    for (int t = 0; t < 4; ++t) {
+        if (GH1_PRE_W) bw[0][t] = P.bw0[t];
+        else { bw[0][t].h = pk[t * PK_BLOCK]; bw[0][t].l = pk[t * PK_BLOCK + PK_LO]; }
     }
+    const uint2 (&hvh)[4] = P.hvh;
+    const uint2 (&hvl)[4] = P.hvl;
     f32x4 acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
@@ -220,9 +245,12 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     // dq_replay_row) and this update does not feed it (it acts on Q-values the forward already wrote): the lattices' step rides on this
     // launch as extra workgroups.  The dense chain is one 8-wave workgroup per CU with long dependent phases; the environment is a
     // latency chain per lattice: together they fill each other's idle issue slots instead of taking 15 us of their own.
+    DQ_STAMP_ALL(0);
     if (a.env_on && (int)blockIdx.x >= a.dense_wgs) {               // block-uniform
+        if (ENV_PRIO) __builtin_amdgcn_s_setprio(ENV_PRIO);
         if (env.pair) env_block2<16>(env, (int)blockIdx.x - a.dense_wgs, smem);      // two lattices per wave (d <= 5): ONE round of environment workgroups
         else env_block<8>(env, (int)blockIdx.x - a.dense_wgs, smem);
+        DQ_STAMP_ALL(1);
         return;
     }
     float* s_g3 = reinterpret_cast<float*>(smem + a.off_g3);
@@ -242,38 +270,69 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     }
     if (DB_PRIO && wave >= DENSE_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // (as in the conv backward: the younger half of the workgroup's waves)
     DQ_STAMP(DQ_TAG_DENSE_BWD, 0);
+    constexpr int RPW = DENSE_ROWS / DENSE_WAVES;                   // rows per wave (2): their loads are issued together
+    static_assert(RPW == 2, "two rows per wave");
+    // ---- the TD step's replay rows first: everything else it reads hangs on them, and their latency hides under the start-up below ----
+    int ridx[RPW] = {0, 0};
+    if (a.td_on) {
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int b = b0 + min(wave + DENSE_WAVES * u, ns - 1);
+            ridx[u] = a.td.index ? a.td.index[b] : b;
+        }
+    }
+    // ---- requested now, used two / three phases later: Dense(|A|+1)'s kernel for gY2, gH1's first weight block and mask operand --------
+    float w3b[NT2][4];
+    if (N3 > 0 && wave < NT2) {
+        const float* w3 = a.params + a.w_off[2];
+        const int n2 = 16 * wave + j;
+#pragma unroll
+        for (int g = 0; g < NT2; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k3 = 16 * g + 4 * kq + s;
+                w3b[g][s] = (n2 < N2 && k3 < N3) ? w3[(size_t)n2 * N3 + k3] : 0.f;
+            }
+    }
+    Gh1Pre gh1_pre;
+    gh1_preload(a, b0, wave, lane, gh1_pre);
+    __builtin_amdgcn_sched_barrier(0);                              // (hipcc sinks a load next to its use: these stay up here)
     __shared__ float s_met[DENSE_WAVES][2];
     for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) s_g3[i] = 0.f;
     for (int i = tid; i < DENSE_ROWS * LDY; i += DENSE_THREADS) reinterpret_cast<u32*>(s_gy2p)[i] = 0u;      // both planes (2 x 16 x LDY halves)
     __syncthreads();
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 6);
     // ---- (TD step: y = r + gamma (1 - terminal) Q_target(s1)[argmax Q_online(s1)], dq = (Q(s0)[a] - y) * scale at the action taken,
     //      dqn.hip td_update_kernel's arithmetic, one wave per sample) then the dueling backward:
     //      g3[b,0] = sum_a dq[b,a];  g3[b,1+a] = dq[b,a] - (1/A) sum_a' dq[b,a'] ---------------------------------------------
     float loss = 0.f, mq = 0.f;
-    constexpr int RPW = DENSE_ROWS / DENSE_WAVES;                   // rows per wave (2): their loads are issued together, in two dependent
-    static_assert(RPW == 2, "two rows per wave");                   // stages (a row at a time was ten serial latencies: +6 us)
     float yb[RPW] = {0.f, 0.f}, qv[RPW][2] = {{0.f, 0.f}, {0.f, 0.f}};
     int a_b[RPW] = {-1, -1};
     if (a.td_on) {
-        float q1[RPW][2];
-        int ridx[RPW];
+        // ONE load stage (round 3; before: Q_target(s1)[a*] was fetched behind the arg-max and the replay-row fields behind the row
+        // number -- two dependent round trips of 3K and 6K cycles in the loop, where 512 workgroups start at once): the row numbers were
+        // requested at the top of the kernel, so reward / terminal / action go out together with the three Q rows; Q_target(s1) comes as the
+        // whole row and its a*-th entry is picked by a shuffle, like Q(s0)[a].
+        float q1[RPW][2], q1t[RPW][2], rw[RPW], qt[RPW];
+        int term[RPW];
 #pragma unroll
-        for (int u = 0; u < RPW; ++u) {                             // stage 1: everything that needs only the sample number
+        for (int u = 0; u < RPW; ++u) {
             const int b = b0 + min(wave + DENSE_WAVES * u, ns - 1);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
                 const bool ok = c < A;
                 q1[u][h] = a.td.q1o[(size_t)b * A + (ok ? c : 0)];
+                q1t[u][h] = a.td.q1t[(size_t)b * A + (ok ? c : 0)];
                 qv[u][h] = a.td.q0[(size_t)b * A + (ok ? c : 0)];
             }
-            ridx[u] = a.td.index ? a.td.index[b] : b;
+            rw[u] = a.td.reward[ridx[u]];
+            term[u] = a.td.terminal[ridx[u]];
+            a_b[u] = a.td.action[ridx[u]];
         }
-        float rw[RPW], qt[RPW];
-        int term[RPW];
+        DQ_STAMP(DQ_TAG_DENSE_BWD, 7);
 #pragma unroll
-        for (int u = 0; u < RPW; ++u) {                             // stage 2: behind the replay row and the arg-max
-            const int b = b0 + min(wave + DENSE_WAVES * u, ns - 1);
+        for (int u = 0; u < RPW; ++u) {
             float best = -INFINITY;
             int best_a = 0x7fffffff;
 #pragma unroll
@@ -281,16 +340,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
                 const int c = lane + 64 * h;
                 if (c < A && (best_a == 0x7fffffff || q1[u][h] > best)) { best = q1[u][h]; best_a = c; }
             }
-            for (int m = 32; m >= 1; m >>= 1) {
-                const float ov = __shfl_xor(best, m);
-                const int oa = __shfl_xor(best_a, m);
-                if (oa != 0x7fffffff && (best_a == 0x7fffffff || ov > best || (ov == best && oa < best_a))) { best = ov; best_a = oa; }
-            }
-            rw[u] = a.td.reward[ridx[u]];
-            term[u] = a.td.terminal[ridx[u]];
-            a_b[u] = a.td.action[ridx[u]];
-            qt[u] = a.td.q1t[(size_t)b * A + best_a];
+            dq_wave_argmax(best, best_a);                           // (DPP + v_readlane, common.h: no LDS round trips)
+            // Q_target(s1)[best_a] lives in lane best_a & 63, half best_a >> 6 (best_a is wave-uniform: v_readlane)
+            qt[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_a < 64 ? q1t[u][0] : q1t[u][1]), best_a & 63));
         }
+        DQ_STAMP(DQ_TAG_DENSE_BWD, 8);
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
             const int row = wave + DENSE_WAVES * u;
@@ -301,10 +355,10 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             float mx = -INFINITY;
 #pragma unroll
             for (int h = 0; h < 2; ++h) if (lane + 64 * h < A) mx = fmaxf(mx, qv[u][h]);
-            for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
-            // Q(s0)[a_b] lives in lane a_b & 63, half a_b >> 6
-            const float qa0 = __shfl(qv[u][0], a_b[u] & 63), qa1 = __shfl(qv[u][1], a_b[u] & 63);
-            const float diff = (a_b[u] < 64 ? qa0 : qa1) - yb[u];
+            mx = dq_wave_max(mx);
+            // Q(s0)[a_b] lives in lane a_b & 63, half a_b >> 6 (a_b: one replay row's action, the same in every lane)
+            const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
+            const float diff = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ab < 64 ? qv[u][0] : qv[u][1]), ab & 63)) - yb[u];
             loss += 0.5f * diff * diff;
             mq += mx;
             if (a.td.dq_out)
@@ -327,8 +381,14 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         };
         if (N3 > 0) {
             float s = 0.f;
-            for (int h = 0; lane + 64 * h < A; ++h) s += dval(h);
-            for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+            if (a.td_on) {                                              // one non-zero per row: its sum is that value (the butterfly's bits: x + 0 ... + 0)
+                const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
+                const float qa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ab < 64 ? qv[u][0] : qv[u][1]), ab & 63));
+                s = (unsigned)ab < (unsigned)A ? (qa - yb[u]) * a.td.grad_scale * GS : 0.f;
+            } else {
+                for (int h = 0; lane + 64 * h < A; ++h) s += dval(h);
+                for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+            }
             unsigned short* p3 = a.g3_pl + (size_t)b * a.small_ld;   // the same values as pieces: the dueling layer's weight gradient
             const size_t lo3 = (size_t)a.plane_rows * a.small_ld;
             unsigned short ph, pl;
@@ -350,6 +410,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             }
         }
     }
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 9);
     if (a.td_on && lane == 0) { s_met[wave][0] = loss; s_met[wave][1] = mq; }
     __syncthreads();
     if (a.td_on && a.td.metrics && tid == 0) {                      // this workgroup's partial, and zeros in the slots nobody owns
@@ -365,19 +426,17 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 1);
+    if (GH1_PRE_W == 2) {                                           // gH1's first weight block: in flight under gY2
+        const u32x4* pk = a.packed + a.pk_dense2t + (size_t)(4 * wave) * PK_BLOCK + lane;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { gh1_pre.bw0[t].h = pk[t * PK_BLOCK]; gh1_pre.bw0[t].l = pk[t * PK_BLOCK + PK_LO]; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- gY2 = g3 W3^T  (K = N3, one column tile per wave) -------------------------------------------------------------
     if (N3 > 0) {
         if (wave < NT2) {
-            const float* w3 = a.params + a.w_off[2];
             const int n2 = 16 * wave + j;
-            float b[NT2][4];
-#pragma unroll
-            for (int g = 0; g < NT2; ++g)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int k3 = 16 * g + 4 * kq + s;
-                    b[g][s] = (n2 < N2 && k3 < N3) ? w3[(size_t)n2 * N3 + k3] : 0.f;
-                }
+            float (&b)[NT2][4] = w3b;                               // (requested at the top of the kernel)
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* grow = s_g3 + j * ldg + 4 * kq;
 #pragma unroll
@@ -410,8 +469,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         }
     }
     // ---- gH1 (f16x2; K = N2 in 2 or 4 blocks) ---------------------------------------------------------------------------------------
-    if (a.KB2 == 2) gh1_phase<2>(a, s_gy2p, s_gh1p, b0, ns, wave, lane);       // block-uniform
-    else gh1_phase<4>(a, s_gy2p, s_gh1p, b0, ns, wave, lane);
+    if (a.KB2 == 2) gh1_phase<2>(a, s_gy2p, s_gh1p, b0, ns, wave, lane, gh1_pre);       // block-uniform
+    else gh1_phase<4>(a, s_gy2p, s_gh1p, b0, ns, wave, lane, gh1_pre);
     DQ_STAMP(DQ_TAG_DENSE_BWD, 3);
     __syncthreads();
     DQ_STAMP(DQ_TAG_DENSE_BWD, 4);
@@ -428,6 +487,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 5);
     DQ_STAMP_PAIR2(0);
+    DQ_STAMP_ALL(1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
