@@ -94,6 +94,8 @@ SIGNATURES = {
     "dq_env_build_referee_ml": (_i, [_vp, _dbl, _vp]),
     "dq_env_set_referee": (_i, [_vp, _vp, _vp]),
     "dq_env_set_referee_joint": (_i, [_vp, _vp]),
+    "dq_env_set_referee_mlp": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_int32), _vp]),
+    "dq_env_referee_classes": (_i, [_vp, _vp, _vp, _vp]),
     "dq_env_get_referee": (_i, [_vp, _vp, _vp, ctypes.c_size_t]),
     "dq_env_reset": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -144,6 +146,7 @@ SIGNATURES = {
     "dq_td_target": (_i, [_vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _vp, _vp]),
     "dq_td_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _vp, _vp, _vp]),
     "dq_episode_stats": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "dq_test_bookkeeping": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dq_td_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _dbl, _vp, _vp, _vp, _vp]),
     "dq_td_update_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dq_td_metrics": (_i, [_vp, _i, _vp]),

@@ -583,31 +583,42 @@ class DQNAgent:
         finally:
             core.end_eval()
 
-    def _test_loop(self, core, venv, N, quota, eps, masked, history, verbose, interval):
+    def _test_loop(self, core, venv, N, quota, eps, masked, history, verbose, interval, sync_interval=None):
+        """Device-resident: the episode records are appended on the device (dq_test_bookkeeping, one small launch per vector step); the host
+        looks at the record counter every `sync_interval` steps only, so a batched evaluation costs what its kernels cost (rounds 1-2 did
+        four device-to-host copies and a Python loop over the finished lattices per vector step)."""
+        from ._lib import check, ptr
+        dev = core.device
+        total = int(quota.sum())
+        quota_d = torch.from_numpy(quota.astype(np.int32)).to(dev)
+        ep_reward = torch.zeros(N, dtype=torch.float32, device=dev)
+        ep_len = torch.zeros(N, dtype=torch.int32, device=dev)
+        records = torch.zeros((max(total, 1), 5), dtype=torch.int32, device=dev)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
         core.reset_env()
-        ep_reward, ep_len = np.zeros(N), np.zeros(N, dtype=np.int64)
-        lifetimes, episode = [], 0
-        while quota.sum() > 0:
+        L = core.L
+        step = 0
+        if sync_interval is None:
+            sync_interval = 1 if N == 1 else 64
+        while total > 0:
             slot = core.cur
             core.act_and_step(eps, masked_greedy=masked, record_stats=False)
-            done = core.terminal_ring[slot].cpu().numpy().astype(bool)
-            wr = venv.was_reset.cpu().numpy().astype(bool)
-            rew = core.reward_ring[slot].cpu().numpy()
-            life = venv.lifetime.cpu().numpy()
-            ep_reward += np.where(wr, 0.0, rew)
-            ep_len += ~wr
-            for i in np.flatnonzero(done & ~wr):
-                if quota[i] > 0:
-                    quota[i] -= 1
-                    episode += 1
-                    lifetimes.append(int(life[i]))
-                    logs = {"episode_reward": float(ep_reward[i]), "nb_steps": int(ep_len[i]), "episode_lifetime": int(life[i]),
-                            "episode_lifetimes_rolling_avg": float(np.mean(lifetimes))}
-                    history.append(logs)
-                    if verbose >= 2 and (episode - 1) % max(1, interval) == 0:
-                        print(f"-----------------\nEpisode: {episode}\nThis Episode Length: {logs['nb_steps']}\n"
-                              f"This Episode Reward: {logs['episode_reward']}\nThis Episode Lifetime: {logs['episode_lifetime']}\n\n"
-                              f"Episode Lifetimes Avg: {logs['episode_lifetimes_rolling_avg']:.3f}\n")
-                ep_reward[i], ep_len[i] = 0.0, 0
+            check(L.dq_test_bookkeeping(ptr(core.terminal_ring[slot]), ptr(venv.was_reset), ptr(core.reward_ring[slot]), ptr(venv.lifetime), N, step,
+                                        ptr(quota_d), ptr(ep_reward), ptr(ep_len), ptr(records), total, ptr(counter), core._stream()))
+            step += 1
+            if step % sync_interval == 0 and int(counter.item()) >= total:
+                break
+        rec = records.cpu().numpy()[:total]
+        rec = rec[np.lexsort((rec[:, 1], rec[:, 0]))]                     # by vector step, then lattice: the serial loop's order
+        lifetimes, run = [], 0.0
+        for episode, (t, i, rbits, length, life) in enumerate(rec, 1):
+            run += int(life)
+            logs = {"episode_reward": float(np.int32(rbits).view(np.float32)), "nb_steps": int(length), "episode_lifetime": int(life),
+                    "episode_lifetimes_rolling_avg": run / episode}
+            history.append(logs)
+            if verbose >= 2 and (episode - 1) % max(1, interval) == 0:
+                print(f"-----------------\nEpisode: {episode}\nThis Episode Length: {logs['nb_steps']}\n"
+                      f"This Episode Reward: {logs['episode_reward']}\nThis Episode Lifetime: {logs['episode_lifetime']}\n\n"
+                      f"Episode Lifetimes Avg: {logs['episode_lifetimes_rolling_avg']:.3f}\n")
         core.read_stats()
         return history

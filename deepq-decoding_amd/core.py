@@ -305,7 +305,8 @@ class DQNCore:
         if presample_next:
             nxt2 = nxt + 1 if nxt + 1 < T else 0
             sj = self._sample_job(t + 1, nxt2, min(T, filled + 1))
-        if self.ride_env and self._env_stream is None and self.net.fused_supported and self.net.fused_enabled and not getattr(env, "wide", False):
+        if self.ride_env and self._env_stream is None and self.net.fused_supported and self.net.fused_enabled and not getattr(env, "wide", False) \
+                and not getattr(env, "mlp_referee", False):
             # one launch fewer per step: the environment step (+ look-ahead sampling + this step's episode bookkeeping) rides on the
             # dense backward's first kernel (dq_qnet_td_backward_adam_env / _phase0_env): neither needs the other's results
             step = dict(q=self.q_act, eps=eps, masked_greedy=masked_greedy, seed=env.seed, t=self.vector_steps, action=self.action_ring[cur],

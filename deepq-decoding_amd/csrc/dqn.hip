@@ -196,6 +196,34 @@ __global__ __launch_bounds__(256) void post_step_kernel(const u8* __restrict__ t
     dq_episode_stats_lane(done, was_reset, lifetime, reward, n, ((int)blockIdx.x - sample_blocks) * blockDim.x + threadIdx.x, stats);
 }
 
+// Episode records of a greedy evaluation (DQNAgent.test, Single_Point_Training_Script.py:206 -> keras-rl Agent.test), kept on the device:
+// per lattice the running episode reward / length and the episodes it still owes (its quota); a lattice that ends an episode while it
+// owes one appends a record {vector step, lattice, reward, length, lifetime} (slot taken with one atomic; the host sorts by (step,
+// lattice), the order keras-rl's serial loop would have produced) and its counters restart.  One thread per lattice.
+__global__ void test_bookkeeping_kernel(const u8* __restrict__ done, const u8* __restrict__ was_reset, const float* __restrict__ reward,
+                                        const u32* __restrict__ lifetime, int n, int step, int32_t* __restrict__ quota,
+                                        float* __restrict__ ep_reward, int32_t* __restrict__ ep_len, int32_t* __restrict__ records,
+                                        int capacity, int32_t* __restrict__ counter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool wr = was_reset[i] != 0;
+    float r = ep_reward[i];
+    int len = ep_len[i];
+    if (!wr) { r += reward[i]; len += 1; }
+    if (done[i] && !wr) {
+        if (quota[i] > 0) {
+            quota[i] -= 1;
+            const int slot = atomicAdd(counter, 1);
+            if (slot < capacity) {
+                int32_t* rec = records + 5 * (size_t)slot;
+                rec[0] = step; rec[1] = i; rec[2] = __float_as_int(r); rec[3] = len; rec[4] = (int32_t)lifetime[i];
+            }
+        }
+        r = 0.f; len = 0;
+    }
+    ep_reward[i] = r; ep_len[i] = len;
+}
+
 extern "C" {
 
 dq_status dq_post_step(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots, int batch,
@@ -266,6 +294,18 @@ dq_status dq_episode_stats(const uint8_t* done_dev, const uint8_t* was_reset_dev
     DQ_REQUIRE(done_dev && lifetime_dev && reward_dev && stats_dev && n >= 1, DQ_ERR_INVALID, "dq_episode_stats: bad argument");
     episode_stats_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(done_dev, was_reset_dev, lifetime_dev, reward_dev, n,
                                                                          reinterpret_cast<unsigned long long*>(stats_dev));
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_test_bookkeeping(const uint8_t* done_dev, const uint8_t* was_reset_dev, const float* reward_dev, const uint32_t* lifetime_dev, int n,
+                              int step, int32_t* quota_dev, float* ep_reward_dev, int32_t* ep_len_dev, int32_t* records_dev, int capacity,
+                              int32_t* counter_dev, void* stream) {
+    DQ_REQUIRE(done_dev && was_reset_dev && reward_dev && lifetime_dev && quota_dev && ep_reward_dev && ep_len_dev && records_dev && counter_dev,
+               DQ_ERR_INVALID, "dq_test_bookkeeping: null argument");
+    DQ_REQUIRE(n >= 1 && capacity >= 1, DQ_ERR_INVALID, "dq_test_bookkeeping: bad sizes");
+    test_bookkeeping_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(done_dev, was_reset_dev, reward_dev, lifetime_dev, n, step, quota_dev,
+                                                                            ep_reward_dev, ep_len_dev, records_dev, capacity, counter_dev);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

@@ -21,6 +21,16 @@
 #include "env_dev.h"
 #include <new>
 #include <stdarg.h>
+#include <vector>
+#include <algorithm>
+
+#define DQ_MLP_MAX_LAYERS 6
+// lanes of one wave hand activations to each other through LDS (referee_mlp_kernel): wavefront-scope release / acquire + wave barrier
+static __device__ __forceinline__ void match_wave_sync_env() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 struct dq_env {
     dq_env_cfg cfg;
@@ -36,7 +46,97 @@ struct dq_env {
     const u32 *lut_x, *lut_z;      // tables in use
     const u32* lut_joint;          // caller's joint table (dq_env_set_referee_joint), else NULL
     u32 ref_delta[2][64];          // BFS generators per component (x, z)
+    // Dense-stack referee evaluated on the device (dq_env_set_referee_mlp): layer sizes, the caller's flat weights, per-lattice result
+    int mlp_layers, mlp_dims[DQ_MLP_MAX_LAYERS + 1];
+    const float* mlp_w;
+    u8* d_dec;                     // [n_envs] class predicted for each lattice's post-action syndrome
+    int* d_mlp_cells;              // [2 * n_stab]: stabilizers in increasing cell order of the (d+1)^2 input vector, then their cells
 };
+
+// ---- Dense-stack referee on the device (round 3) ------------------------------------------------------------------------------------
+// The reference's referee is a Keras feed-forward network called once per step on the flattened (d+1)^2 syndrome of the state AFTER the
+// agent's move (ENV:139-144); only the arg-max of its output is used (ENV:150).  A joint table over all syndromes stops fitting at d = 7
+// (48 stabilizers), so there the stack itself is evaluated: one wavefront per lattice applies the move to the lattice's planes (the
+// arithmetic of env_block's step, without touching the record), forms the syndrome word, and runs the layers -- lane o owns outputs
+// o, o + 64, ...; the first layer ADDS the kernel rows of the set cells (the input is binary), later layers walk the previous layer's
+// activations out of LDS -- in a FIXED arithmetic: float32, bias first, then the inputs in increasing index order, one rounded multiply and
+// one rounded add per term (no fused multiply-add), ReLU between layers, first maximum of the last layer's outputs (softmax is monotone).
+// referee.py FeedForwardReferee.predict_exact restates exactly that on the host, so device and host classes agree bit for bit.
+#define DQ_MLP_THREADS 256
+struct RefMlpParams {
+    const u64* state; int sw, n_envs, d2, n_stab, n_actions, identity, model, use_Y, auto_reset;
+    const EnvTables* tab;
+    const int32_t* action;
+    const int* cells;                  // [n_stab] stabilizers in increasing cell order, then [n_stab] the cell of each of them
+    int layers, dims[DQ_MLP_MAX_LAYERS + 1];
+    const float* w;
+    int max_width;
+    u8* dec;
+};
+
+__global__ __launch_bounds__(DQ_MLP_THREADS) void referee_mlp_kernel(RefMlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * (DQ_MLP_THREADS / 64) + wave;
+    if (i >= p.n_envs) return;                                       // wave-uniform; no block-wide barrier below
+    float* h0 = reinterpret_cast<float*>(smem) + (size_t)wave * 2 * p.max_width;
+    float* h1 = h0 + p.max_width;
+    const u64* rec = p.state + (size_t)i * p.sw;
+    u64 xmask = rec[0], zmask = rec[1];
+    const u64 meta = rec[8];
+    if (p.auto_reset && ((meta >> 32) & 1)) { if (lane == 0) p.dec[i] = 0; return; }       // this lattice is reset, not stepped: no referee call
+    int a = p.action[i];
+    if ((unsigned)a >= (unsigned)p.n_actions) a = p.identity;
+    if (a != p.identity) {                                          // ENV:135-136, FL:243-294 (env_dev.h env_block)
+        const int layer = a / p.d2, q = a - layer * p.d2;
+        const int pauli = p.model == DQ_MODEL_X ? 1 : (p.use_Y ? layer + 1 : (layer == 0 ? 1 : 3));
+        if (pauli != 3) xmask ^= 1ull << q;
+        if (pauli != 1) zmask ^= 1ull << q;
+    }
+    const u64 sq = p.tab->stab_qmask[lane];
+    const bool isx = p.tab->stab_isx[lane] != 0;
+    const u64 true_word = __ballot(__popcll((isx ? xmask : zmask) & sq) & 1);   // ENV:139
+    // ---- first layer: bias + the kernel rows of the set cells, in increasing cell order -----------------------------------------
+    const float* w = p.w;
+    int n_in = p.dims[0], n_out = p.dims[1];
+    for (int o = lane; o < n_out; o += 64) {
+        float acc = w[(size_t)n_in * n_out + o];
+        for (int t = 0; t < p.n_stab; ++t) {
+            const int s = p.cells[t];
+            if ((true_word >> s) & 1) acc = __fadd_rn(acc, w[(size_t)p.cells[p.n_stab + t] * n_out + o]);      // x = 1: the product is the weight itself
+        }
+        h0[o] = p.layers > 1 ? fmaxf(acc, 0.f) : acc;
+    }
+    w += (size_t)n_in * n_out + n_out;
+    float* src = h0;
+    float* dst = h1;
+    for (int l = 1; l < p.layers; ++l) {
+        match_wave_sync_env();
+        n_in = p.dims[l]; n_out = p.dims[l + 1];
+        for (int o = lane; o < n_out; o += 64) {
+            float acc = w[(size_t)n_in * n_out + o];
+            int k = 0;
+            for (; k + 8 <= n_in; k += 8) {                           // eight kernel rows requested together; the adds stay in index order
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k + u) * n_out + o];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, __fmul_rn(src[k + u], wv[u]));
+            }
+            for (; k < n_in; ++k) acc = __fadd_rn(acc, __fmul_rn(src[k], w[(size_t)k * n_out + o]));
+            dst[o] = l + 1 < p.layers ? fmaxf(acc, 0.f) : acc;
+        }
+        w += (size_t)n_in * n_out + n_out;
+        float* t = src; src = dst; dst = t;
+    }
+    match_wave_sync_env();
+    // ---- first maximum of the outputs (np.argmax) ---------------------------------------------------------------------------------
+    const int nc = p.dims[p.layers];
+    float best = lane < nc ? src[lane] : -INFINITY;
+    int best_a = lane < nc ? lane : 0x7fffffff;
+    dq_wave_argmax(best, best_a);
+    if (lane == 0) p.dec[i] = (u8)best_a;
+}
 
 __global__ __launch_bounds__(256) void env_kernel(EnvParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -235,6 +335,8 @@ void dq_env_destroy(dq_env* E) {
     if (E->d_state) (void)hipFree(E->d_state);
     if (E->d_lut_x) (void)hipFree(E->d_lut_x);
     if (E->d_lut_z) (void)hipFree(E->d_lut_z);
+    if (E->d_dec) (void)hipFree(E->d_dec);
+    if (E->d_mlp_cells) (void)hipFree(E->d_mlp_cells);
     delete E;
 }
 
@@ -342,7 +444,7 @@ dq_status dq_env_build_referee_ml(dq_env* E, double q_flip, void* stream) {
     if (rc != DQ_OK) return rc;
     E->lut_x = E->d_lut_x;
     E->lut_z = E->d_lut_z;
-    E->lut_joint = nullptr;
+    E->lut_joint = nullptr; E->mlp_layers = 0;
     return DQ_OK;
 }
 
@@ -355,7 +457,7 @@ dq_status dq_env_build_referee(dq_env* E, void* stream) {
     if (rc != DQ_OK) return rc;
     E->lut_x = E->d_lut_x;
     E->lut_z = E->d_lut_z;
-    E->lut_joint = nullptr;
+    E->lut_joint = nullptr; E->mlp_layers = 0;
     return DQ_OK;
 }
 
@@ -364,7 +466,7 @@ dq_status dq_env_set_referee(dq_env* E, const uint32_t* lut_x_dev, const uint32_
     DQ_REQUIRE(lut_z_dev || E->cfg.error_model == DQ_MODEL_X, DQ_ERR_INVALID, "dq_env_set_referee: the DP model needs a Z table");
     E->lut_x = lut_x_dev;
     E->lut_z = lut_z_dev ? lut_z_dev : lut_x_dev;
-    E->lut_joint = nullptr;
+    E->lut_joint = nullptr; E->mlp_layers = 0;
     return DQ_OK;
 }
 
@@ -372,8 +474,71 @@ dq_status dq_env_set_referee_joint(dq_env* E, const uint32_t* lut_dev) {
     DQ_REQUIRE(E && lut_dev, DQ_ERR_INVALID, "dq_env_set_referee_joint: null argument");
     DQ_REQUIRE(E->info.n_stab <= 24, DQ_ERR_UNSUPPORTED, "dq_env_set_referee_joint: a table over all %d stabilizers does not fit (d <= 5)",
                E->info.n_stab);
-    E->lut_joint = lut_dev;
+    E->lut_joint = lut_dev; E->mlp_layers = 0;
     E->lut_x = E->lut_z = lut_dev;                                  // "a referee is installed"; the component tables are not read
+    return DQ_OK;
+}
+
+dq_status dq_env_set_referee_mlp(dq_env* E, int n_layers, const int32_t* dims, const float* weights_dev) {
+    DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_set_referee_mlp: null handle");
+    if (n_layers == 0) { E->mlp_layers = 0; E->mlp_w = nullptr; return DQ_OK; }      // uninstall: the table referee (if any) is in charge again
+    DQ_REQUIRE(dims && weights_dev && n_layers >= 1 && n_layers <= DQ_MLP_MAX_LAYERS, DQ_ERR_INVALID, "dq_env_set_referee_mlp: 1 .. %d Dense layers",
+               DQ_MLP_MAX_LAYERS);
+    const int d = E->cfg.d, ns = E->info.n_stab, classes = E->cfg.error_model == DQ_MODEL_X ? 2 : 4;
+    DQ_REQUIRE(dims[0] == (d + 1) * (d + 1), DQ_ERR_INVALID, "dq_env_set_referee_mlp: the first layer takes the flattened (d+1)^2 = %d syndrome, not %d inputs",
+               (d + 1) * (d + 1), dims[0]);
+    DQ_REQUIRE(dims[n_layers] == classes, DQ_ERR_INVALID, "dq_env_set_referee_mlp: %d homology classes for this error model, the stack ends in %d units",
+               classes, dims[n_layers]);
+    for (int l = 1; l <= n_layers; ++l) DQ_REQUIRE(dims[l] >= 1 && dims[l] <= 4096, DQ_ERR_UNSUPPORTED, "dq_env_set_referee_mlp: layer widths 1 .. 4096");
+    if (!E->d_dec) DQ_HIP(hipMalloc(&E->d_dec, (size_t)E->cfg.n_envs));
+    if (!E->d_mlp_cells) {
+        // stabilizer s (measurement order, FL:189-221) sits at cell a (d+1) + b of the flattened syndrome (ENV:144 reshape)
+        std::vector<std::pair<int, int>> byc;
+        const int half = (d + 1) / 2 - 1;
+        std::vector<int> sa, sb;
+        for (int a = 1; a < d; ++a) for (int b = 1; b < d; ++b) { sa.push_back(a); sb.push_back(b); }
+        for (int x = 0; x < half; ++x) { sa.push_back(0); sb.push_back(2 * x + 1); }
+        for (int x = 0; x < half; ++x) { sa.push_back(d); sb.push_back(2 * x + 2); }
+        for (int x = 0; x < half; ++x) { sa.push_back(2 * x + 2); sb.push_back(0); }
+        for (int x = 0; x < half; ++x) { sa.push_back(2 * x + 1); sb.push_back(d); }
+        DQ_REQUIRE((int)sa.size() == ns, DQ_ERR_STATE, "dq_env_set_referee_mlp: stabilizer count");
+        for (int st = 0; st < ns; ++st) byc.push_back({sa[st] * (d + 1) + sb[st], st});
+        std::sort(byc.begin(), byc.end());
+        std::vector<int> tab(2 * ns);
+        for (int t = 0; t < ns; ++t) { tab[t] = byc[t].second; tab[ns + t] = byc[t].first; }
+        DQ_HIP(hipMalloc(&E->d_mlp_cells, tab.size() * sizeof(int)));
+        DQ_HIP(hipMemcpy(E->d_mlp_cells, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    E->mlp_layers = n_layers;
+    for (int l = 0; l <= n_layers; ++l) E->mlp_dims[l] = dims[l];
+    E->mlp_w = weights_dev;
+    if (!E->lut_x) E->lut_x = E->lut_z = reinterpret_cast<const u32*>(weights_dev);      // "a referee is installed"; the tables are not read
+    return DQ_OK;
+}
+
+// the pre-pass of a step whose referee is the Dense stack: classes of the lattices' post-action syndromes into E->d_dec
+static dq_status launch_referee_mlp(dq_env* E, const int32_t* action_dev, int auto_reset, hipStream_t st) {
+    RefMlpParams r;
+    memset(&r, 0, sizeof(r));
+    r.state = E->d_state; r.sw = E->sw; r.n_envs = E->cfg.n_envs; r.d2 = E->cfg.d * E->cfg.d; r.n_stab = E->info.n_stab;
+    r.n_actions = E->info.num_actions; r.identity = E->info.identity_index; r.model = E->cfg.error_model; r.use_Y = E->cfg.use_Y;
+    r.auto_reset = auto_reset; r.tab = E->d_tab; r.action = action_dev; r.cells = E->d_mlp_cells; r.layers = E->mlp_layers; r.w = E->mlp_w;
+    r.dec = E->d_dec;
+    int mw = 1;
+    for (int l = 0; l <= E->mlp_layers; ++l) { r.dims[l] = E->mlp_dims[l]; if (l > 0 && E->mlp_dims[l] > mw) mw = E->mlp_dims[l]; }
+    r.max_width = (mw + 3) & ~3;
+    const int wpb = DQ_MLP_THREADS / 64;
+    referee_mlp_kernel<<<(r.n_envs + wpb - 1) / wpb, DQ_MLP_THREADS, (size_t)wpb * 2 * r.max_width * sizeof(float), st>>>(r);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_env_referee_classes(dq_env* E, const int32_t* action_dev, uint8_t* classes_dev, void* stream) {
+    DQ_REQUIRE(E && action_dev && classes_dev, DQ_ERR_INVALID, "dq_env_referee_classes: null argument");
+    DQ_REQUIRE(E->mlp_layers, DQ_ERR_STATE, "dq_env_referee_classes: no Dense-stack referee installed (dq_env_set_referee_mlp)");
+    const dq_status rc = launch_referee_mlp(E, action_dev, 0, (hipStream_t)stream);
+    if (rc != DQ_OK) return rc;
+    DQ_HIP(hipMemcpyAsync(classes_dev, E->d_dec, (size_t)E->cfg.n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DQ_OK;
 }
 
@@ -450,6 +615,11 @@ dq_status dq_env_step(dq_env* E, const int32_t* action_dev, int auto_reset, uint
     memset(&p, 0, sizeof(p));
     p.mode = 1; p.auto_reset = auto_reset; p.action = action_dev; p.obs = obs_dev; p.reward = reward_dev;
     p.done = done_dev; p.legal = legal_dev; p.lifetime = lifetime_dev; p.was_reset = was_reset_dev;
+    if (E->mlp_layers) {                                            // Dense-stack referee: its classes first (pre-pass), then the step reads them
+        const dq_status rc = launch_referee_mlp(E, action_dev, auto_reset, (hipStream_t)stream);
+        if (rc != DQ_OK) return rc;
+        p.dec_in = E->d_dec;
+    }
     return launch_env(E, p, (hipStream_t)stream);
 }
 
@@ -486,6 +656,17 @@ static dq_status act_step(dq_env* E, const float* q_dev, double eps, int masked_
     const dq_status rc = fill_act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev,
                                        lifetime_dev, was_reset_dev, sj, 64 * ENVS_PER_BLOCK, p);
     if (rc != DQ_OK) return rc;
+    if (E->mlp_layers) {
+        // Dense-stack referee: the selection (dq_policy_select: the same rule and Philox stream, on the legal sets the last reset / step
+        // left in legal_dev) runs first, then the referee's pre-pass on the selected actions, then the step with both handed in
+        DQ_REQUIRE(legal_dev, DQ_ERR_INVALID, "dq_env_act_step: a Dense-stack referee needs legal_dev (the selection reads the legal sets from it)");
+        dq_status r2 = dq_policy_select(q_dev, legal_dev, E->cfg.n_envs, E->info.num_actions, eps, masked_greedy, seed, E->cfg.env_id_base, t,
+                                        action_dev, stream);
+        if (r2 != DQ_OK) return r2;
+        r2 = launch_referee_mlp(E, action_dev, auto_reset, (hipStream_t)stream);
+        if (r2 != DQ_OK) return r2;
+        p.policy = 0; p.action = action_dev; p.dec_in = E->d_dec;
+    }
     return launch_env(E, p, (hipStream_t)stream);
 }
 
@@ -536,6 +717,7 @@ dq_status env_fill_act_step(dq_env* E, const float* q_dev, double eps, int maske
                             int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
                             uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sj, uint64_t* stats_dev, EnvParams* p,
                             size_t* lds) {
+    DQ_REQUIRE(E && !E->mlp_layers, DQ_ERR_UNSUPPORTED, "a step whose referee is the Dense stack (dq_env_set_referee_mlp) does not ride: make the separate calls");
     dq_status rc = fill_act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev,
                                  lifetime_dev, was_reset_dev, sj, 512, *p);
     if (rc != DQ_OK) return rc;

@@ -55,6 +55,8 @@ struct EnvParams {
     // episode bookkeeping of THIS step (dq_episode_stats' four sums), done by the blocks themselves when the step rides on a launch
     // that runs before anything could read its results (fused_bwd.hip); NULL: not here
     unsigned long long* stats;
+    const u8* dec_in;              // != NULL: the referee's class for each lattice's post-action syndrome, computed by a pre-pass
+                                   // (env.hip referee_mlp_kernel: a Dense-stack `static_decoder` evaluated on the device, ENV:144)
     int pair;                      // 1: two lattices per wave (env_block2; d <= 5: qubits, stabilizers and record words all fit 32 lanes)
 };
 
@@ -178,7 +180,9 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
             const u64 refw = __ballot(rsrc < 64 && ((true_word >> (rsrc & 63)) & 1));
             const u32 ix = (u32)refw, iz = (u32)(refw >> 32);
             int dec;
-            if (p.lut_joint) {                                              // an arbitrary static_decoder.predict, tabulated (ENV:144,150)
+            if (p.dec_in) {                                                 // a Dense-stack static_decoder, evaluated by the pre-pass (env.hip)
+                dec = p.dec_in[i];
+            } else if (p.lut_joint) {                                       // an arbitrary static_decoder.predict, tabulated (ENV:144,150)
                 const u32 sw = (u32)true_word;                              // bit s = stabilizer s in measurement order (n_stab <= 24)
                 dec = (p.lut_joint[sw >> 4] >> (2 * (sw & 15))) & 3;
             } else {
@@ -417,7 +421,9 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
             const u32 ix = (u32)hb(rsrc_x < 64 && ((true_word >> (rsrc_x & 63)) & 1));
             const u32 iz = (u32)hb(rsrc_z < 64 && ((true_word >> (rsrc_z & 63)) & 1));
             int dec;
-            if (p.lut_joint) {                                              // an arbitrary static_decoder.predict, tabulated (ENV:144,150)
+            if (p.dec_in) {
+                dec = p.dec_in[i];
+            } else if (p.lut_joint) {                                       // an arbitrary static_decoder.predict, tabulated (ENV:144,150)
                 const u32 sw = (u32)true_word;                              // bit s = stabilizer s in measurement order (n_stab <= 24)
                 dec = (p.lut_joint[sw >> 4] >> (2 * (sw & 15))) & 3;
             } else {

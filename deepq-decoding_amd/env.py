@@ -75,6 +75,7 @@ class VectorEnv:
         self.lifetime = torch.zeros(n, dtype=torch.int32, device=dev)
         self.was_reset = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._lut = None
+        self.mlp_referee, self._mlp_w = False, None
         self.inexact = torch.zeros(n, dtype=torch.uint8, device=dev)         # wide backend: referee fallback used in the last step
         if self.wide:
             if referee not in ("lut", "matching", None):
@@ -86,6 +87,8 @@ class VectorEnv:
             # maximum-likelihood table for independent component flips; default rate = one round's marginal flip probability
             q = float(referee[1]) if isinstance(referee, tuple) else (p_phys if error_model == "X" else 2.0 * p_phys / 3.0)
             self.build_ml_referee(q)
+        elif hasattr(referee, "flat_weights") and (self.n_stab > 24 or getattr(referee, "on_device", False)):
+            self.set_referee_mlp(referee)            # a Dense stack where no table fits (d = 7): evaluated on the device, every step
         elif hasattr(referee, "predict"):
             self.set_referee_predict(referee)
         elif referee is not None:
@@ -169,6 +172,28 @@ class VectorEnv:
         words = (c << (2 * np.arange(16, dtype=np.uint32))[None, :]).sum(axis=1, dtype=np.uint64).astype(np.uint32)
         self._lut = (torch.from_numpy(words.view(np.int32).copy()).to(self.device), None)
         check(self.L.dq_env_set_referee_joint(self._h, ptr(self._lut[0])))
+
+    def set_referee_mlp(self, referee):
+        """Install a Dense-stack referee (referee.FeedForwardReferee: .dims, .flat_weights()) to be EVALUATED on the device before every
+        step (dq_env_set_referee_mlp) -- the reference's own kind of static_decoder (ENV:53,144), for any d <= 7; None uninstalls."""
+        if self.wide:
+            raise NotImplementedError("the wide environment (d >= 9) decodes with the built-in matching referee")
+        if referee is None:
+            check(self.L.dq_env_set_referee_mlp(self._h, 0, None, None))
+            self.mlp_referee, self._mlp_w = False, None
+            return
+        dims = [int(x) for x in referee.dims]
+        self._mlp_w = torch.from_numpy(np.ascontiguousarray(referee.flat_weights(), dtype=np.float32)).to(self.device)
+        arr = (ctypes.c_int32 * len(dims))(*dims)
+        check(self.L.dq_env_set_referee_mlp(self._h, len(dims) - 1, arr, ptr(self._mlp_w)))
+        self.mlp_referee = True          # DQNCore: this environment's step does not ride on the dense backward
+
+    def referee_classes(self, action):
+        """Classes the installed Dense-stack referee predicts for the lattices as they stand after `action` (int32 tensor [n_envs]); the
+        lattices are not stepped (dq_env_referee_classes)."""
+        out = torch.empty(self.n_envs, dtype=torch.uint8, device=self.device)
+        check(self.L.dq_env_referee_classes(self._h, ptr(action), ptr(out), self._stream()))
+        return out
 
     def get_referee(self):
         n = 1 << (self.n_stab // 2)

@@ -7,9 +7,11 @@ cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:54-57) -- and calls
 (Environments.py:144,150).  The shipped blobs are missing (.MISSING_LARGE_BLOBS), so this module provides the same thing
 from a weight file: a stack of Dense layers (ReLU between, softmax on top) read from a Keras HDF5 / .npz weight file.
 
-Nothing here runs inside the environment step: ``VectorEnv.set_referee_predict`` tabulates ``predict`` once over all
-2**n_stab syndromes into the kernel's joint look-up table, so on the device the referee is one table read whatever the
-network's size.  The tabulation itself is a handful of small matrix products at construction time (numpy, on the host).
+On the device a referee is either tabulated -- ``VectorEnv.set_referee_predict`` calls ``predict`` once over all 2**n_stab
+syndromes and installs the kernel's joint look-up table (d <= 5: one table read per step whatever the network's size) -- or, where no
+table fits (d = 7: 48 stabilizers), EVALUATED there: ``VectorEnv.set_referee_mlp`` hands the Dense stack to
+``dq_env_set_referee_mlp`` (include/deepq_hip.h; csrc/env.hip referee_mlp_kernel, one wavefront per lattice, before every step).
+``FeedForwardReferee.predict_exact`` restates the device's fixed float32 arithmetic, so the two give the same classes bit for bit.
 """
 import ctypes
 
@@ -44,6 +46,37 @@ class FeedForwardReferee:
         h -= h.max(axis=1, keepdims=True)
         e = np.exp(h)
         return e / e.sum(axis=1, keepdims=True)
+
+    @property
+    def dims(self):
+        return [self.n_inputs] + [k.shape[1] for k, _ in self.layers]
+
+    def flat_weights(self):
+        """The stack as dq_env_set_referee_mlp takes it: per layer the kernel (in, out) row-major, then the bias; float32."""
+        return np.concatenate([np.concatenate([k.reshape(-1), b]) for k, b in self.layers]).astype(np.float32)
+
+    def logits_exact(self, x):
+        """The device kernel's arithmetic (csrc/env.hip referee_mlp_kernel), restated: float32 throughout, accumulator = bias, then the
+        inputs in increasing index order with one rounded multiply and one rounded add each, ReLU between layers.  (An exactly-zero
+        input contributes +0.0 * w = 0: skipping it, as the kernel does for the binary first layer, leaves the same bits.)"""
+        h = np.asarray(x, dtype=np.float32).reshape(len(x), -1)
+        assert h.shape[1] == self.n_inputs, (h.shape, self.n_inputs)
+        for i, (k, b) in enumerate(self.layers):
+            acc = np.broadcast_to(b, (len(h), len(b))).astype(np.float32).copy()
+            for j in range(k.shape[0]):
+                col = h[:, j]
+                if not col.any():
+                    continue
+                acc = acc + (col[:, None] * k[j][None, :]).astype(np.float32)      # float32 * float32 and float32 + float32: one rounding each
+            h = np.maximum(acc, np.float32(0.0)) if i + 1 < len(self.layers) else acc
+        return h
+
+    def predict_exact(self, x, batch_size=None, verbose=0):
+        """One-hot rows of the first maximum of logits_exact: what the device referee decides."""
+        z = self.logits_exact(x)
+        out = np.zeros_like(z)
+        out[np.arange(len(z)), np.argmax(z, axis=1)] = 1.0
+        return out
 
 
 class MatchingReferee:

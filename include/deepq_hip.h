@@ -115,6 +115,25 @@ dq_status dq_env_set_referee(dq_env* env, const uint32_t* lut_x_dev, const uint3
  * how an arbitrary `static_decoder.predict` object (Environments.py:144,150 -- only argmax of its output is used) runs inside the
  * kernel: the host tabulates it once (deepq-decoding_amd/env.py VectorEnv.set_referee_predict).  Device pointer, caller-owned. */
 dq_status dq_env_set_referee_joint(dq_env* env, const uint32_t* lut_dev);
+/* A Dense-stack referee evaluated ON THE DEVICE, for lattices whose syndromes no table holds (d = 7: 48 stabilizers) -- the reference's
+ * own referee is such a network, "a fast feed-forward NN homology class predictor" loaded with keras load_model and called once per
+ * step on the flattened (d+1)^2 syndrome of the state after the agent's move (Environments.py:53,139-144,
+ * Single_Point_Training_Script.py:54-57); only the arg-max of its output is used (Environments.py:150).
+ *   n_layers     1 .. 6 Dense layers, ReLU between them (the top layer's softmax is monotone and not evaluated)
+ *   dims         int32 [n_layers + 1]: (d+1)^2, the hidden widths (<= 4096), then 2 ("X") or 4 classes
+ *   weights_dev  float, caller-owned, must outlive its use: per layer the kernel [in][out] row-major (Keras shape), then the bias
+ * Arithmetic (fixed, so that a host restatement gives the same bits -- referee.py FeedForwardReferee.predict_exact): float32, bias
+ * first, inputs in increasing index order, one rounded multiply and one rounded add per term, first maximum of the outputs.
+ * Every step then runs a pre-pass (one wavefront per lattice) before the environment kernel; dq_env_act_step selects the actions with
+ * dq_policy_select first (legal_dev must hold the current legal sets, as every reset / step leaves them); the step does not ride on
+ * the dense backward (dq_qnet_td_backward_*_env: DQ_ERR_UNSUPPORTED).  n_layers = 0 uninstalls it; installing any table referee does
+ * too.  d <= 7. */
+dq_status dq_env_set_referee_mlp(dq_env* env, int n_layers, const int32_t* dims, const float* weights_dev);
+/* What the Dense-stack referee says about every lattice as it stands after action_dev[i] (int32 [n_envs]; the identity leaves the state as
+ * it is): classes_dev uint8 [n_envs] = arg-max class.  The lattices are not stepped.  Tests and diagnostics (the step runs the same
+ * pre-pass itself). */
+dq_status dq_env_referee_classes(dq_env* env, const int32_t* action_dev, uint8_t* classes_dev, void* stream);
+
 /* Copies the referee tables to host memory as one byte per entry (tests). Synchronises. */
 dq_status dq_env_get_referee(dq_env* env, uint8_t* lut_x_host, uint8_t* lut_z_host, size_t entries);
 
@@ -359,6 +378,16 @@ size_t dq_qnet_conv_param_count(const dq_qnet* net);
  * ranks the gradient has to be all-reduced between the two.  grads_dev still receives the gradient. */
 dq_status dq_qnet_backward_adam(dq_qnet* net, float* params_dev, const float* dq_dev, float* grads_dev, float* m_dev, float* v_dev,
                                 double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
+
+/* Episode records of a greedy evaluation -- keras-rl Agent.test's per-episode log (episode_reward, nb_steps, and the fork's
+ * episode_lifetime; Single_Point_Training_Script.py:206-207) -- kept on the device, one call per vector step behind the environment
+ * step: lattice i's running reward / length advance (not on a step spent being reset); a lattice that ends an episode while
+ * quota_dev[i] > 0 appends int32 {step, i, reward bits (float), length, lifetime} to records_dev [capacity][5] (slot = atomic increment
+ * of counter_dev[0]; sort by (step, lattice) for the serial loop's order) and pays one unit of quota.  The host only reads counter_dev
+ * every few dozen steps to see whether the evaluation is complete.  No reference counterpart. */
+dq_status dq_test_bookkeeping(const uint8_t* done_dev, const uint8_t* was_reset_dev, const float* reward_dev, const uint32_t* lifetime_dev, int n,
+                              int step, int32_t* quota_dev, float* ep_reward_dev, int32_t* ep_len_dev, int32_t* records_dev, int capacity,
+                              int32_t* counter_dev, void* stream);
 
 /* The learner half of one DQNAgent.backward in the fewest launches: dq_td_update (+ dq_episode_stats when n > 0) computed in the
  * dense backward's first kernel, then dq_qnet_backward, then dq_adam_step on the final reduction.  Same y / dq / gradient / parameter

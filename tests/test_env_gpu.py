@@ -1,6 +1,7 @@
 """GPU parity tests of the HIP environment (through the C ABI) against the golden vectors captured
 from the reference, the CPU oracle, and size-independent properties at BASELINE.json sizes."""
 import hashlib
+import importlib
 
 import numpy as np
 import pytest
@@ -675,3 +676,128 @@ def test_arbitrary_predict_referee_runs_as_a_joint_table(dq, torch_mod, d, model
     if d == 5:                                                      # (48 stabilizers at d = 7: no table)
         with pytest.raises(NotImplementedError):
             dq.VectorEnv(n_envs=1, d=7, error_model="DP", use_Y=False, volume_depth=3, referee=pred)
+
+
+class _ExactStackReferee:
+    """A Dense stack behind the oracle's `classify_word` protocol and the reference's `.predict` protocol, both through
+    FeedForwardReferee.predict_exact (the host restatement of the device kernel's arithmetic)."""
+
+    def __init__(self, ff, d):
+        from oracle import lattice
+        self.ff, self.m, self.d = ff, lattice.Masks(d), d
+
+    def classify_word(self, w):
+        return int(np.argmax(self.ff.logits_exact(self.m.word_to_grid(int(w)).reshape(1, -1))[0]))
+
+    def predict(self, x, batch_size=None, verbose=0):
+        return self.ff.predict_exact(x)
+
+
+def _random_stack(dq, rng, d, classes, hidden=(96, 40)):
+    R = importlib.import_module("deepq-decoding_amd.referee")
+    dims = [(d + 1) ** 2] + list(hidden) + [classes]
+    w = []
+    for a, b in zip(dims, dims[1:]):
+        w += [(rng.randn(a, b) * (1.5 / np.sqrt(a))).astype(np.float32), (rng.randn(b) * 0.3).astype(np.float32)]
+    return R.FeedForwardReferee(w)
+
+
+def test_dense_stack_referee_evaluated_on_the_device(dq, torch_mod):
+    """The reference's kind of static_decoder -- a feed-forward network called every step (ENV:53,144) -- where no table fits (d = 7,
+    48 stabilizers): dq_env_set_referee_mlp evaluates the stack on the device.  (1) On 10 000 lattices in diverse states the device's
+    class equals the host restatement FeedForwardReferee.predict_exact bit for bit, and the BLAS-ordered `.predict` arg-max wherever
+    its top two outputs are not within round-off.  (2) Whole trajectories (observation, reward, done, lifetime, hidden state) equal the
+    Python oracle environment run with the same referee, fused selection included.  (3) At d = 5, where a table DOES fit, the
+    device-evaluated stack and the same stack tabulated over all 2^24 syndromes give identical trajectories."""
+    torch = torch_mod
+    from oracle import env_oracle, lattice
+    rng = np.random.RandomState(23)
+    d = 7
+    cfg = dict(d=d, error_model="DP", use_Y=False, volume_depth=3, p_phys=0.03, p_meas=0.03)
+    ff = _random_stack(dq, rng, d, 4)
+    n = 10000
+    env = dq.VectorEnv(n_envs=n, referee=ff, **cfg)
+    assert env.mlp_referee
+    env.reset()
+    for t in range(6):
+        env.step(env.select_actions(t), auto_reset=True)
+    ident = torch.full((n,), env.identity_index, dtype=torch.int32, device="cuda")
+    cls_dev = env.referee_classes(ident).cpu().numpy()
+    st = _np_u64(env.export_state())
+    m = lattice.Masks(d)
+    words = np.array([m.syndrome_word(int(x), int(z)) for x, z in zip(st[:, 0], st[:, 1])], dtype=object)
+    x = np.stack([m.word_to_grid(int(w)).reshape(-1) for w in words])
+    assert len({int(w) for w in words}) > 2000                      # diverse syndromes
+    z = ff.logits_exact(x)
+    assert np.array_equal(cls_dev, np.argmax(z, axis=1))
+    blas = ff.predict(x)
+    top2 = np.sort(z, axis=1)[:, -2:]
+    clear = top2[:, 1] - top2[:, 0] > 1e-4
+    assert clear.mean() > 0.99 and np.array_equal(np.argmax(blas, axis=1)[clear], cls_dev[clear])
+    assert len(set(cls_dev.tolist())) == 4
+    # a flip first: the class is that of the state AFTER the move
+    a = env.select_actions(99)
+    cls_a = env.referee_classes(a).cpu().numpy()
+    a_np = a.cpu().numpy()
+    for i in range(0, n, 997):
+        xm, zm = int(st[i, 0]), int(st[i, 1])
+        if a_np[i] < 2 * d * d:
+            layer, q = divmod(int(a_np[i]), d * d)
+            if layer == 0:
+                xm ^= 1 << q
+            else:
+                zm ^= 1 << q
+        w = m.syndrome_word(xm, zm)
+        assert cls_a[i] == int(np.argmax(ff.logits_exact(m.word_to_grid(w).reshape(1, -1))[0]))
+    # (2) trajectories against the Python oracle environment, with the device's fused selection (dq_env_act_step: policy kernel, referee
+    #     pre-pass, step) on one side and the separate calls on the other
+    k = 6
+    ref_obj = _ExactStackReferee(ff, d)
+    for fused in (False, True):
+        dev = dq.VectorEnv(n_envs=k, referee=ff, **cfg)
+        refs = [env_oracle.OracleEnv(referee=ref_obj, seed=dev.seed, env_id=i, **cfg) for i in range(k)]
+        dev.reset()
+        obs_ref = np.stack([r.reset() for r in refs])
+        assert np.array_equal(dev.obs.cpu().numpy(), obs_ref)
+        done = np.zeros(k, bool)
+        ended = 0
+        for t in range(50):
+            if fused:
+                a = dev.act_step(t, auto_reset=True).cpu().numpy()
+            else:
+                a = dev.select_actions(t)
+                dev.step(a, auto_reset=True)
+                a = a.cpu().numpy()
+            rew, dn = np.zeros(k, np.float32), np.zeros(k, np.uint8)
+            for i, r in enumerate(refs):
+                if done[i]:                                          # auto-reset: the step is spent on the reset, the action ignored
+                    r.done, r.lifetime, r.xmask, r.zmask = False, 0, 0, 0
+                    r.reset()
+                    done[i] = False
+                else:
+                    _, rew[i], d_i, _ = r.step(int(a[i]))
+                    dn[i] = d_i
+                    done[i] = d_i
+            ended += int(dn.sum())
+            assert np.array_equal(dev.obs.cpu().numpy(), np.stack([r.board_state for r in refs])), (fused, t)
+            assert np.array_equal(dev.reward.cpu().numpy(), rew) and np.array_equal(dev.done.cpu().numpy(), dn), (fused, t)
+        assert ended > 0
+    # (3) d = 5: evaluated on the device == tabulated
+    for model, classes in (("X", 2), ("DP", 4)):
+        cfg5 = dict(d=5, error_model=model, use_Y=False, volume_depth=5, p_phys=0.02, p_meas=0.02)
+        ff5 = _random_stack(dq, rng, 5, classes, hidden=(64,))
+        ff5.on_device = True
+        a_env = dq.VectorEnv(n_envs=512, referee=ff5, **cfg5)
+        b_env = dq.VectorEnv(n_envs=512, referee=_ExactStackReferee(ff5, 5), **cfg5)
+        assert a_env.mlp_referee and not b_env.mlp_referee
+        a_env.reset(); b_env.reset()
+        for t in range(40):
+            a_env.act_step(t, auto_reset=True)
+            b_env.act_step(t, auto_reset=True)
+            assert torch.equal(a_env.obs, b_env.obs) and torch.equal(a_env.done, b_env.done) and torch.equal(a_env.reward, b_env.reward), (model, t)
+        assert torch.equal(a_env.export_state(), b_env.export_state())
+    # the façade takes the reference's static_decoder argument; the agent loop runs on such an environment (its step does not ride)
+    single = dq.Surface_Code_Environment_Multi_Decoding_Cycles(static_decoder=ff, **cfg)
+    obs = single.reset()
+    obs, r, dn, _ = single.step(single.identity_index)
+    assert obs.shape == single.observation_space.shape and single._v.mlp_referee

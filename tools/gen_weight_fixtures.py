@@ -20,9 +20,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REF = "/root/reference/trained_models"
-# (family, training error rate): the DP agent the round-1 behavioural test used, the X-noise agent at the same rate (the (6,11,11) /
-# 26-action network), and the DP agent trained at the headline rate of BASELINE.json's configs[2]
-AGENTS = [("d5_dp", "0.007"), ("d5_x", "0.007"), ("d5_dp", "0.011")]
+# (family, training error rate): every agent the reference ships (trained_models/d5_x/0.001 .. 0.015, d5_dp/0.001 .. 0.011): 14 weight sets,
+# each with the whole test-rate sweep the reference recorded for it (all_results.p).  Rounds 1-2 committed three of them.
+AGENTS = [(fam, p) for fam in ("d5_x", "d5_dp") for p in sorted(x for x in os.listdir(os.path.join(REF, fam)) if x[0] == "0")] \
+    if os.path.isdir(REF) else []
 
 
 def fixture_name(family, p):
