@@ -347,34 +347,6 @@ def test_early_stopping_rule(dq, torch_mod):
     assert hist.history["has_succeeded"][-1] is True and agent.step < 64 * 2000
 
 
-@pytest.mark.parametrize("family,p_train", [("d5_dp", "0.007"), ("d5_x", "0.007"), ("d5_dp", "0.011")])
-def test_shipped_keras_agent_decodes(dq, torch_mod, family, p_train):
-    """Behavioural pin of the Q-network semantics (HWIO kernels, channels_first Flatten, dueling head, masked greedy test policy)
-    against the REFERENCE'S OWN trained agents: tests/golden/keras_weights_<family>_<p>.npz hold the tensors of
-    trained_models/<family>/<p>/final_dqn_weights.h5f and the lifetimes the reference recorded for them (all_results.p; its NN referee,
-    101 episodes per rate) -- d5_dp/0.007: 270.4 @ 0.007, 81.2 @ 0.011; d5_x/0.007 (the (6,11,11) / 26-action network): 347.3 @ 0.007,
-    100.4 @ 0.011; d5_dp/0.011: 293.1 @ 0.007, 91.0 @ 0.011.  A uniformly random legal policy lives ~20 rounds.  The look-up referee
-    differs from the authors' NN referee, so the bounds are a factor ~1.7 either way -- far from random, and ordered like the
-    reference's numbers."""
-    from conftest import load_golden
-    fx = load_golden(f"keras_weights_{family}_{p_train}")
-    weights = [fx[f"w{i}"] for i in range(12)]
-    ref = dict(zip((round(float(x), 3) for x in fx["ref_test_p"]), (float(x) for x in fx["ref_lifetime"])))
-    cfg = dict(C3 if family == "d5_dp" else C2)
-    res = {}
-    for p in (0.011, 0.007):
-        env = dq.VectorEnv(n_envs=1024, **dict(cfg, p_phys=p, p_meas=p))
-        agent = _make_agent(dq, env.obs_shape, env.num_actions)
-        agent._bind(env)
-        agent.model.set_weights(weights)
-        th = agent.test(env, nb_episodes=1024, visualize=False, verbose=0, single_cycle=False)
-        res[p] = float(np.mean(th.history["episode_lifetime"]))
-    print(f"shipped agent {family}/{p_train} mean lifetimes:", res, "reference:", {p: ref[p] for p in res})
-    for p in res:
-        assert ref[p] / 1.7 < res[p] < ref[p] * 1.7, (p, res[p], ref[p])
-    assert res[0.007] > 2 * res[0.011]
-
-
 ALL_SHIPPED = [("d5_x", p) for p in ("0.001", "0.003", "0.005", "0.007", "0.009", "0.011", "0.013", "0.015")] + \
               [("d5_dp", p) for p in ("0.001", "0.003", "0.005", "0.007", "0.009", "0.011")]
 
@@ -386,11 +358,12 @@ def _spearman(a, b):
 
 def test_all_shipped_agents_over_the_reference_sweeps(dq, torch_mod):
     """Every agent the reference ships (trained_models/d5_x/0.001 .. 0.015, d5_dp/0.001 .. 0.011: 14 weight sets, committed as data
-    fixtures) over the test-rate sweep the reference recorded for it (all_results.p = the means of detailed_results/results_<p>.p, 101
-    episodes each with the authors' NN referee), rates >= 0.003 (below, single episodes last 10^4 - 10^5 rounds: the two 0.007 agents
+    fixtures) over the test-rate sweep the reference recorded for it (all_results.p = the final rolling
+    averages of detailed_results/results_<p>.p -- 130 episodes at p = 0.001 up to 75 000 at 0.011 in the shipped files -- with the authors' NN referee), rates >= 0.003 (below, single episodes last 10^4 - 10^5 rounds: the two 0.007 agents
     additionally run 0.002) -- 1024 lattices x 1 episode per point, one batched device-resident evaluation each (DQNAgent.test: the
-    episode records stay on the device, one host look per 64 vector steps).  Asserted: every point within x1.3 of the reference's mean
-    lifetime (the reference's own standard error is ~10 %: 101 geometric-ish episodes); the rank correlation of log-lifetimes over all
+    episode records stay on the device, one host look per 64 vector steps).  Asserted: every point within x1.2 of the reference's mean
+    lifetime and the median ratio within 3 % of 1 (measured, round 3: 125 points, ours / reference between 0.924 and 1.081, median 1.005 -- the
+    built-in minimum-weight referee and the authors' NN referee evidently agree on what a logical error is); the rank correlation of log-lifetimes over all
     points; per agent the lifetimes fall monotonically with the rate as the reference's do; and across the agents of a family at the
     common rate 0.005 (the highest every agent was swept to) the reference's clear ordering (the agent trained at 0.001 is far the worst) is reproduced."""
     from conftest import load_golden
@@ -425,7 +398,8 @@ def test_all_shipped_agents_over_the_reference_sweeps(dq, torch_mod):
     assert len(ours) >= 110
     assert _spearman(ours, theirs) > 0.99
     worst = int(np.argmax(np.abs(np.log(ratio))))
-    assert 1 / 1.3 < ratio.min() and ratio.max() < 1.3, (tags[worst], ours[worst], theirs[worst])
+    assert 1 / 1.2 < ratio.min() and ratio.max() < 1.2, (tags[worst], ours[worst], theirs[worst])
+    assert abs(np.median(ratio) - 1.0) < 0.03
     for family, n_agents in (("d5_x", 8), ("d5_dp", 6)):
         at = [(table[k][0], table[k][1], k[1]) for k in table if k[0] == family and abs(k[2] - 0.005) < 1e-9]
         assert len(at) == n_agents
