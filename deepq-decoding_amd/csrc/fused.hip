@@ -46,6 +46,11 @@ DQ_STAMP_READER(dq_dbg_read_fwd)
 #ifndef DENSE_XPIPE
 #define DENSE_XPIPE 1
 #endif
+#ifndef CONV_SWZ
+#define CONV_SWZ 0                 // 1: a1 planes unpadded with their 16-byte chunks XOR-swizzled by pixel column (conv2's A reads conflict-free at d = 5): LDS bank
+                                   // conflicts -59 %, LDS-active cycles -24 %, VALU +12 %, kernel +1.7 us -- off; 0: rows padded by 8 halves
+#endif
+#define A1_PS (CONV_SWZ ? 64 : 72)  // halves per a1 pixel row in LDS
 #ifndef DQ_EXP_NODROP
 #define DQ_EXP_NODROP 0
 #endif
@@ -73,6 +78,8 @@ struct ConvChainArgs {
                                        // kernel never divides (every m -> (sample, y, x) was ~30 VALU, ten of them quarter-rate multiplies)
     int slot;                          // bytes per sample slot in LDS (multiple of 16, >= C*H*W + 30)
     int off_mis, off_t1, off_a1, off_a2;   // LDS byte offsets (observations at 0; a2 overlays observations + tables)
+    int off_fx;                        // CONV_SWZ: byte per first-convolution output row = its chunk swizzle in halves (8 * f, f = 2 (ox & 3))
+    int total_groups, off_obs1, off_a2b;   // persistent kernel: groups of S samples over all jobs; second observation buffer; a2 when the group's observations are in it
 };
 
 // One stride-1 convolution on the f16 matrix pipe at f32-class accuracy (f16x2, qnet.h).  Its input is an LDS image of READY-MADE
@@ -105,14 +112,20 @@ __device__ __forceinline__ void conv_w_prefetch(F16x2 (&ring)[R][NT], const u32x
     for (int b = 0; b < R; ++b) conv_w_load<NT>(ring[b], pk, b, lane);
 }
 
-template <int CIN, int COUT, int KS, int RR, int NTT>
+// SWZ (the second convolution with CONV_SWZ): the input planes' rows are CIN halves, unpadded, and pixel (y, x)'s 16-byte chunk c sits at chunk
+// c ^ f(x), f(x) = 2 (x & 3).  With the lane groups ds_read_b128 is served in (MI355X_MICROARCH.md LDS table: rows 0-3, 12-15 of chunk kb together
+// with rows 4-11 of chunk kb + 1) the padded rows put two or three rows on the same banks in every group at d = 5 (12 LDS cycles per read against
+// 4; tools/probe/lds_swizzle.py enumerates it); the swizzle makes every group's 16 chunks hit 16 different bank quadruples for all four taps.
+// The row table then carries ox & 3 in bits 24+ and the lane keeps one address per (row tile, kx, channel half).
+template <int CIN, int COUT, int KS, int RR, int NTT, bool SWZ = false, int PADI = 8>
 __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__ in, int lo_in, int ih, int iw, int oh, int ow, int M,
                                               F16x2 (&ring)[RR][NTT], const u32x4* __restrict__ pk, const float* __restrict__ bias,
                                               unsigned short* __restrict__ out_lds, int lo_out, float* __restrict__ out_g, int wave, int lane,
                                               const int* __restrict__ rowtab, int pre0, int pre1) {
     using SH = ConvShape<CIN, COUT, KS>;
-    constexpr int NT = SH::NT, PSI = CIN + 8, PSO = COUT + 8, CB = SH::CB, NB = SH::NB, R = SH::R;
+    constexpr int NT = SH::NT, PSI = SWZ ? CIN : CIN + PADI, PSO = COUT + 8, CB = SH::CB, NB = SH::NB, R = SH::R;
     static_assert(NT == 2 && CIN % 32 == 0 && RR == R && NTT == NT, "written for 32 output channels, CIN a multiple of 32");
+    static_assert(!SWZ || (CIN == 64 && KS == 2), "the swizzle is laid out for 64 input channels (8 chunks per row) and 2 x 2 taps");
     const int j = lane & 15, kb = lane >> 4;
     const f32x2 bias2 = *reinterpret_cast<const f32x2*>(bias + 2 * j);
     const int tiles = (M + 15) >> 4;
@@ -123,10 +136,23 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
         const bool more = t0 + 2 * CONV_WAVES < tiles;              // another pair of row tiles follows: keep the weight stream going
         // patch origins of this lane's two rows: halves into the input image, from the host-built table (rows past M re-read row M - 1:
         // padding rows recompute the last row and are never stored); the first trip's entries were requested by the caller before its barrier
-        int abase[2] = {pre0 + 8 * kb, pre1 + 8 * kb};
+        int ent[2] = {pre0, pre1};
         if (t0 != 2 * wave) {                                       // wave-uniform
 #pragma unroll
-            for (int u = 0; u < 2; ++u) abase[u] = rowtab[min((t0 + u) * 16 + j, M - 1)] + 8 * kb;
+            for (int u = 0; u < 2; ++u) ent[u] = rowtab[min((t0 + u) * 16 + j, M - 1)];
+        }
+        int abase[2] = {ent[0] + 8 * kb, ent[1] + 8 * kb};
+        int sa[2][2][2];                                            // SWZ: [row tile][kx][channel half]: halves to this lane's chunk of tap (0, kx)
+        if (SWZ) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx) {
+                    const int f8 = (((ent[u] >> 24) + kx) & 3) << 4;                  // 8 f(x + kx) halves: 0, 16, 32, 48
+                    const int low = (ent[u] & 0xffffff) + kx * PSI + ((8 * kb) ^ (f8 & 16));
+                    sa[u][kx][0] = low + (f8 & 32);
+                    sa[u][kx][1] = low + (32 ^ (f8 & 32));
+                }
         }
         f32x4 acc[2][NT][2];
 #pragma unroll
@@ -142,7 +168,7 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
             const int off = (ky * iw + kx) * PSI + 32 * c32;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const unsigned short* ap = in + abase[u] + off;
+                const unsigned short* ap = SWZ ? in + sa[u][kx & 1][c32 & 1] + ky * iw * PSI : in + abase[u] + off;
                 av[u].h = *reinterpret_cast<const u32x4*>(ap);
                 av[u].l = *reinterpret_cast<const u32x4*>(ap + lo_in);
             }
@@ -192,7 +218,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8* s_in = smem;
     int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);
-    unsigned short* s_a1 = reinterpret_cast<unsigned short*>(smem + a.off_a1);      // f16 piece planes [2][S*r1][72]
+    unsigned short* s_a1 = reinterpret_cast<unsigned short*>(smem + a.off_a1);      // f16 piece planes [2][S*r1][A1_PS]
+    u8* s_fx = smem + a.off_fx;                                                     // CONV_SWZ: chunk swizzle of every a1 row, in halves
     unsigned short* s_a2 = reinterpret_cast<unsigned short*>(smem + a.off_a2);      // [2][S*r2][40]; overlays the observations (dead after conv1)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     static_assert(FWD_MAX_JOBS == 4, "three comparisons");
@@ -274,11 +301,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     }
     __syncthreads();                                                // s_mis
     // byte offset of output pixel m's patch origin inside the staged observations
-    const int lo1 = a.S * r1 * 72, lo2 = a.S * a.oh2 * a.ow2 * 40;        // halves from an h plane to its l plane
+    const int lo1 = a.S * r1 * A1_PS, lo2 = a.S * a.oh2 * a.ow2 * 40;     // halves from an h plane to its l plane
     int* s_t1 = reinterpret_cast<int*>(smem + a.off_t1);
-    for (int m = tid; m < M1; m += CONV_THREADS) {                  // table entry: sample << 20 | offset of the patch inside the observation
+    for (int m = tid; m < M1; m += CONV_THREADS) {                  // table entry: sample << 20 | swizzle f << 17 | offset of the patch inside the observation
         const int e = m == tid ? tab1 : a.rowtab[m], s = e >> 20;
-        s_t1[m] = s * a.slot + s_mis[s] + (e & 0xfffff);
+        s_t1[m] = s * a.slot + s_mis[s] + (e & 0x1ffff);
+        if (CONV_SWZ) s_fx[m] = (u8)(((e >> 17) & 7) << 3);         // 8 f halves
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's DMA pieces have landed
     __syncthreads();
@@ -297,6 +325,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 for (int e = 0; e < 8; ++e) ab[h][e] = ap[ko[h][e]];        // 0 or 1
         };
         auto tile_out = [&](int tile, const u32 (&ab)[NH1][8]) {
+            u32 fxh[4];                                             // CONV_SWZ: swizzles of this lane's four output rows (bytes past M1 belong to rows that are not stored)
+            if (CONV_SWZ) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fxh[r] = s_fx[tile * 16 + 4 * kq + r];
+            }
             f32x4 acc[4], accl[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[t] = acc[t]; }
@@ -323,8 +356,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 u32 hp[2], lp[2];                                   // split on write: this lane's 4 consecutive channels of pixel mo
                 split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                 split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
-                *reinterpret_cast<uint2*>(s_a1 + mo * 72 + 4 * j) = uint2{hp[0], hp[1]};
-                *reinterpret_cast<uint2*>(s_a1 + mo * 72 + 4 * j + lo1) = uint2{lp[0], lp[1]};
+                // this lane's 4 channels 4j .. 4j+3 = half (j & 1) of chunk j >> 1
+                unsigned short* dst = CONV_SWZ ? s_a1 + mo * 64 + (((j >> 1) << 3) ^ (int)fxh[r]) + ((j & 1) << 2) : s_a1 + mo * 72 + 4 * j;
+                *reinterpret_cast<uint2*>(dst) = uint2{hp[0], hp[1]};
+                *reinterpret_cast<uint2*>(dst + lo1) = uint2{lp[0], lp[1]};
             }
         };
         u32 abA[NH1][8], abB[NH1][8];
@@ -345,8 +380,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     __syncthreads();
     DQ_STAMP(DQ_TAG_CONV_FWD, 4);
     {
-        conv_from_lds<64, 32, 2>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
-                                 nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1]);
+        conv_from_lds<64, 32, 2, 4, 2, CONV_SWZ != 0>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
+                                                      nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1]);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 5);
     conv_w_prefetch(ring, J.packed + PK_CONV3_FWD, lane);
@@ -354,7 +389,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 6);
     {
         const int r3 = a.oh3 * a.ow3;
-        conv_from_lds<32, 32, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, M3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
+        conv_from_lds<32, 32, 2, 4, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, M3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
                                  J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane, a.rowtab + 2 * CONV_ROWTAB, tab3[0], tab3[1]);
     }
     // ---- training: a1 and a2 leave as the piece planes they are in LDS (the convolutional backward's operands, fused_bwd.hip) in ONE burst of
@@ -363,11 +398,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     if (J.write_all) {                                              // block-uniform; a1 is dead but intact since conv2, a2 since conv3
         __syncthreads();
         const int r2 = a.oh2 * a.ow2;
-        // a1: LDS rows of 72 halves -> global rows of 64 (8 slots of 16 B per row and plane); a2: rows of 40 -> 32 (4 slots)
+        // a1: LDS rows of A1_PS halves (chunks swizzled with CONV_SWZ) -> global rows of 64 (8 slots of 16 B per row and plane); a2: rows of 40 -> 32 (4 slots)
         for (int i = tid; i < 2 * M1 * 8; i += CONV_THREADS) {
             const int piece = i >= M1 * 8 ? 1 : 0, q = i - piece * M1 * 8, row = q >> 3, part = q & 7;
+            const int src = CONV_SWZ ? row * 64 + ((8 * part) ^ (int)s_fx[row]) : row * 72 + 8 * part;
             *reinterpret_cast<u32x4*>(J.a1_pl + piece * J.a1_lo + ((size_t)b0 * r1 + row) * 64 + 8 * part) =
-                *reinterpret_cast<const u32x4*>(s_a1 + piece * lo1 + row * 72 + 8 * part);
+                *reinterpret_cast<const u32x4*>(s_a1 + piece * lo1 + src);
         }
         for (int i = tid; i < 2 * M2 * 4; i += CONV_THREADS) {
             const int piece = i >= M2 * 4 ? 1 : 0, q = i - piece * M2 * 4, row = q >> 2, part = q & 3;
@@ -378,6 +414,246 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 7);
     DQ_STAMP_WG(DQ_TAG_CONV_FWD, 1);
     DQ_STAMP_PAIR(1);
+}
+
+// Four scalar loads issued together and waited for once.  (Inside the persistent loop hipcc no longer proves the replay index vector unclobbered --
+// the loop stores to global memory -- and turns each `index[i]` of a uniform i into a VECTOR load + s_waitcnt vmcnt(0) + v_readfirstlane, one
+// after the other: four serial memory latencies at the top of every group, and vmcnt(0) waits in front of the DMA.)
+__device__ __forceinline__ void scalar_load4(const int32_t* p0, const int32_t* p1, const int32_t* p2, const int32_t* p3, int (&r)[4]) {
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r[0]), "=&s"(r[1]), "=&s"(r[2]), "=&s"(r[3]) : "s"(p0), "s"(p1), "s"(p2), "s"(p3) : "memory");
+}
+
+// ---- persistent form (round 3) --------------------------------------------------------------------------------------------------
+// Phase stamps of conv_chain_kernel in the vector step's launch (2048 workgroups = 4 rounds of 2 per CU) showed every workgroup, in every
+// round, spending 1.8-3.0K of its ~20K cycles in chains of dependent scalar loads (kernel arguments -> job record -> pointers -> row tables,
+// first-layer weights) and another 1.7-2.6K waiting for its observations (replay-ring index -> LDS-DMA from HBM): a fifth of a workgroup's
+// life before the first MFMA, paid again by each of the 2048.  Here 2 workgroups per CU stay resident and walk the groups of S samples
+// (group g, g + grid, ...):
+//   * row tables and the first layer's byte offsets are read once;
+//   * the observations of group g + 1 are requested by LDS-DMA at the top of group g, a whole group ahead, into a second buffer (the a1 planes are
+//     unpadded here to make room: 64 halves per pixel; conv2's A reads then take 16 LDS cycles instead of 12, and the LDS has that slack --
+//     tools/probe/lds_swizzle.py);
+//   * the first layer's weight pieces of group g + 1 are requested when group g's last convolution is under way, and an explicit
+//     s_waitcnt vmcnt(0) BEFORE the next DMA is issued retires them: a wave's memory operations retire in order, so a register load waited for
+//     behind a younger DMA would wait for the DMA as well (hipcc cannot count the DMA's instructions and falls back to vmcnt(0)).
+// LDS: [obs A | core | obs B | a1 planes | alignment offsets]; a2 (conv2's output) overlays the CURRENT group's observation buffer and the core
+// (the patch-origin table lives there), never the buffer the next group's observations are landing in.
+template <int KG1>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);          // [2][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
+    static_assert(FWD_MAX_JOBS == 4, "three comparisons");
+    const int in_bytes = a.C * a.H * a.W;
+    constexpr int NH1 = (KG1 + 1) / 2;                              // first convolution's K in halves of 32
+    const int r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
+    const int lo1 = a.S * r1 * 64, lo2 = a.S * r2 * 40;             // halves from an h plane to its l plane
+    const int total = a.total_groups, gstride = (int)gridDim.x;
+    auto job_of = [&](int g) { return (g >= a.wg_first[1]) + (g >= a.wg_first[2]) + (g >= a.wg_first[3]); };     // block-uniform
+
+    DQ_STAMP(DQ_TAG_CONV_FWD, 0);
+    // ---- once per workgroup: byte offsets of the first layer's K, row tables of a FULL group (rows past a ragged group's end read stale rows
+    //      of LDS whose results are never stored: MFMA rows are independent) -----------------------------------------------------------
+    int ko[NH1][8];                                                 // (requested with the first layer's weights, per group: 16 registers that would
+                                                                    // otherwise stay live through the other two convolutions)
+    const int MF1 = a.S * r1, MF2 = a.S * r2, MF3 = a.S * r3;
+    const int tab1 = a.rowtab[min(tid, MF1 - 1)];
+    int tab2[2], tab3[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        tab2[u] = a.rowtab[3 * CONV_ROWTAB + min((2 * wave + u) * 16 + j, MF2 - 1)];       // (table 3: a1 rows of 64 halves)
+        tab3[u] = a.rowtab[2 * CONV_ROWTAB + min((2 * wave + u) * 16 + j, MF3 - 1)];
+    }
+    // first-layer weight pieces (PK_CONV1, zero past K1) and bias of a job
+    u32x4 wb[2][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 f16 each
+    f32x4 bias1;
+    auto load_w1 = [&](const ConvJob& Jn) {
+        const u32x4* pk1 = opaque_global(Jn.packed + PK_CONV1) + lane;
+#pragma unroll
+        for (int h = 0; h < NH1; ++h)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int piece = 0; piece < 2; ++piece) wb[piece][h][t] = pk1[(h * 4 + t) * PK_BLOCK + PK_LO * piece];
+        bias1 = *reinterpret_cast<const f32x4*>(Jn.params + a.b_off[0] + 4 * j);
+        const int* kt = reinterpret_cast<const int*>(opaque_global(reinterpret_cast<const u32x4*>(a.kofftab))) + 8 * kq;
+#pragma unroll
+        for (int h = 0; h < NH1; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ko[h][e] = kt[32 * h + e];      // Keras HWIO row k -> NCHW uint8 offset (-1 past K1: weights 0; clamped at the use)
+    };
+    // LDS-DMA of group g's observations into buffer buf (conv_chain_kernel's staging: whole aligned 16-byte words of arbitrarily aligned rows)
+    // Staging in two steps.  prep(g): the scalar part -- job record, this wave's replay rows of group g -- requested TWO groups ahead (at the tail of
+    // group g - 2) so that nothing waits for it: loaded at the top of the group that issues the copies, this chain of dependent scalar loads was
+    // 1.4K of every group's ~18K cycles (phase stamps).  The index vector is read through the constant address space: it is not written while this
+    // kernel runs, and inside the loop hipcc otherwise turns every index[uniform] into a vector load + s_waitcnt vmcnt(0) + v_readfirstlane.
+    // issue(P, buf): the copies, LDS-DMA of whole aligned 16-byte words of the arbitrarily aligned rows (conv_chain_kernel's staging).
+    constexpr int SPW = 4;                                          // samples per wave at most (S <= 16)
+    struct Prep { const u8* obs; int rows[SPW]; int ns, has_index, index_off, index_mod; };
+    auto prep = [&](int g) {
+        Prep P;
+        const ConvJob& Jn = a.job[job_of(g)];
+        const int b0n = (g - Jn.wg0) * a.S;
+        P.ns = min(a.S, Jn.batch - b0n); P.obs = Jn.obs; P.has_index = Jn.index != nullptr; P.index_off = Jn.index_off; P.index_mod = Jn.index_mod;
+        const __attribute__((address_space(4))) int32_t* idx = (const __attribute__((address_space(4))) int32_t*)(uintptr_t)Jn.index;
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            const int r = b0n + min(wave + CONV_WAVES * q, P.ns - 1);
+            P.rows[q] = P.has_index ? idx[r] : r;
+        }
+        return P;
+    };
+    auto issue = [&](const Prep& P, int buf) {
+        u8* dst = smem + (buf ? a.off_obs1 : 0);
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            const int s = wave + CONV_WAVES * q;
+            if (s >= P.ns) break;                                   // wave-uniform
+            int row = P.rows[q];
+            if (P.has_index) { row += P.index_off; if (row >= P.index_mod) row -= P.index_mod; }
+            const u8* src = P.obs + (size_t)row * in_bytes;
+            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 15);
+            const u32x4* gp = reinterpret_cast<const u32x4*>(src - mis) + lane;
+            u8* lp = dst + s * a.slot;
+            const int nq = (mis + in_bytes + 15) >> 4;              // 16-byte pieces of the window
+            // (lds_dma16, qnet.h: the copies must stay in flight across this whole group; the wave's own s_waitcnt vmcnt(0) at the top of the next
+            // group retires them)
+            const u32 lds0 = lds_addr(lp);
+            for (int pc = 0; 64 * pc < nq; ++pc)
+                if (64 * pc + lane < nq) lds_dma16(gp + 64 * pc, lds0 + 1024 * pc);
+            if (lane == 0) s_mis[buf * 16 + s] = mis;
+        }
+    };
+
+    int gid = (int)blockIdx.x, cur = 0;
+    int gk = 0; (void)gk;                                           // group count of this workgroup (stamps: 8 per group)
+    load_w1(a.job[job_of(gid)]);
+    issue(prep(gid), 0);
+    Prep pre = prep(min(gid + gstride, total - 1));                 // the group whose copies the first trip issues
+    for (;;) {
+        // LDS bases and table pointers re-derived per group from opaque copies: as loop invariants hipcc keeps every address computed from them
+        // in registers of its own across the whole group (spills)
+        int o_a1 = a.off_a1, o_t1 = a.off_t1, wv = wave;             // (wv: the row numbers of a wave's tiles, and everything computed from them)
+        asm volatile("" : "+s"(o_a1), "+s"(o_t1), "+s"(wv));
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int j = ln & 15, kq = ln >> 4;
+        int* s_t1 = reinterpret_cast<int*>(smem + o_t1);
+        unsigned short* s_a1 = reinterpret_cast<unsigned short*>(smem + o_a1);      // f16 piece planes [2][S*r1][64]
+        const int* rowtab = reinterpret_cast<const int*>(opaque_global(reinterpret_cast<const u32x4*>(a.rowtab)));
+        const ConvJob& J = a.job[job_of(gid)];
+        const int b0 = (gid - J.wg0) * a.S;
+        const int ns = min(a.S, J.batch - b0);
+        const int M1 = ns * r1, M2 = ns * r2, M3 = ns * r3;
+        const u8* s_in = smem + (cur ? a.off_obs1 : 0);
+        unsigned short* s_a2 = reinterpret_cast<unsigned short*>(smem + (cur ? a.off_a2b : 0));     // [2][S*r2][40]; overlays this group's observations (dead after conv1)
+        // this wave's older memory operations retire here: its pieces of this group's observations (requested a group ago) and this group's
+        // first-layer weights -- BEFORE the next group's DMA is issued (see the kernel's header)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+#pragma unroll
+        for (int h = 0; h < NH1; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ko[h][e] = max(ko[h][e], 0);
+        __syncthreads();                                            // every wave's pieces have landed; the previous group's LDS images are dead
+        DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 1);
+        const int nxt = gid + gstride;
+        if (nxt < total) issue(pre, cur ^ 1);                       // block-uniform
+        for (int m = tid; m < M1; m += CONV_THREADS) {              // table entry: sample << 20 | offset of the patch inside the observation
+            const int e = m == tid ? tab1 : rowtab[m], s = e >> 20;
+            s_t1[m] = s * a.slot + s_mis[cur * 16 + s] + (e & 0x1ffff);
+        }
+        __syncthreads();
+        DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 2);
+        // ---- convolution 1 (conv_chain_kernel's, on rows of 64 halves) ------------------------------------------------------------
+        {
+            const int tiles = (M1 + 15) >> 4;
+            auto origin = [&](int tile) { return s_t1[min(tile * 16 + j, M1 - 1)]; };
+            auto rd = [&](int org, u32 (&ab)[NH1][8]) {
+                const u8* ap = s_in + org;
+#pragma unroll
+                for (int h = 0; h < NH1; ++h)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ab[h][e] = ap[ko[h][e]];        // 0 or 1
+            };
+            auto tile_out = [&](int tile, const u32 (&ab)[NH1][8]) {
+                f32x4 acc[4], accl[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[t] = acc[t]; }
+#pragma unroll
+                for (int h = 0; h < NH1; ++h) {
+                    u32x4 av;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) av[e >> 1] = __umul24(ab[h][e] | (ab[h][e + 1] << 16), 0x3c00u);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = MFMA_F16(av, wb[0][h][t], acc[t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accl[t] = MFMA_F16(av, wb[1][h][t], accl[t]);
+                }
+                f32x4 vs[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) vs[t] = f16x2_sum(acc[t], accl[t]) + f32x4{bias1[t], bias1[t], bias1[t], bias1[t]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mo = tile * 16 + 4 * kq + r;
+                    if (mo >= M1) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = relu1(vs[t][r]);
+                    u32 hp[2], lp[2];                               // split on write: this lane's 4 consecutive channels of pixel mo
+                    split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
+                    split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
+                    unsigned short* dst = s_a1 + mo * 64 + 4 * j;
+                    *reinterpret_cast<uint2*>(dst) = uint2{hp[0], hp[1]};
+                    *reinterpret_cast<uint2*>(dst + lo1) = uint2{lp[0], lp[1]};
+                }
+            };
+            u32 abA[NH1][8], abB[NH1][8];
+            const int w1 = wv;                                      // (tiles to the waves in reverse order -- the odd 13th tile to the wave the last convolution leaves idle -- measured: +0.4 us)
+            if (w1 < tiles) {
+                int orgB = origin(w1 + CONV_WAVES), orgA;
+                rd(origin(w1), abA);
+                for (int tile = w1;;) {
+                    rd(orgB, abB); orgA = origin(tile + 2 * CONV_WAVES); tile_out(tile, abA); tile += CONV_WAVES; if (tile >= tiles) break;
+                    rd(orgA, abA); orgB = origin(tile + 2 * CONV_WAVES); tile_out(tile, abB); tile += CONV_WAVES; if (tile >= tiles) break;
+                }
+            }
+        }
+        DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 3);
+        // ---- convolutions 2 and 3 ----------------------------------------------------------------------------------------------------
+        F16x2 ring[4][2];
+        conv_w_prefetch(ring, J.packed + PK_CONV2_FWD, ln);
+        __syncthreads();
+        DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 4);
+        conv_from_lds<64, 32, 2, 4, 2, false, 0>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
+                                                 nullptr, wv, ln, rowtab + 3 * CONV_ROWTAB, tab2[0], tab2[1]);
+        DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 5);
+        conv_w_prefetch(ring, J.packed + PK_CONV3_FWD, ln);
+        __syncthreads();
+        DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 6);
+        conv_from_lds<32, 32, 2, 4, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, M3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
+                                       J.act_out[2] + (size_t)b0 * r3 * 32, wv, ln, rowtab + 2 * CONV_ROWTAB, tab3[0], tab3[1]);
+        // the next group's first-layer weights fly over the training stores and the next group's top barrier (unconditional -- after the last group
+        // the last job's again --: a conditional reload would keep these 84 registers live through the whole group)
+        load_w1(a.job[job_of(min(nxt, total - 1))]);
+        pre = prep(min(nxt + gstride, total - 1));                  // scalar loads only; consumed at the top of the next group
+        // ---- training: a1 and a2 leave as the piece planes they are in LDS, in one burst of 16-byte copies ---------------------------
+        if (J.write_all) {                                          // block-uniform; a1 is dead but intact since conv2, a2 since conv3
+            __syncthreads();
+            for (int i = tid; i < 2 * M1 * 8; i += CONV_THREADS) {
+                const int piece = i >= M1 * 8 ? 1 : 0, q = i - piece * M1 * 8;
+                *reinterpret_cast<u32x4*>(J.a1_pl + piece * J.a1_lo + (size_t)b0 * r1 * 64 + 8 * q) = *reinterpret_cast<const u32x4*>(s_a1 + piece * lo1 + 8 * q);
+            }
+            for (int i = tid; i < 2 * M2 * 4; i += CONV_THREADS) {
+                const int piece = i >= M2 * 4 ? 1 : 0, q = i - piece * M2 * 4, row = q >> 2, part = q & 3;
+                *reinterpret_cast<u32x4*>(J.a2_pl + piece * J.a2_lo + ((size_t)b0 * r2 + row) * 32 + 8 * part) =
+                    *reinterpret_cast<const u32x4*>(s_a2 + piece * lo2 + row * 40 + 8 * part);
+            }
+        }
+        DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 7);
+        if (nxt >= total) break;
+        gid = nxt; cur ^= 1; ++gk;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -879,7 +1155,7 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct ConvPlan { int S, slot, off_mis, off_t1, off_a1, off_a2, KG1; size_t lds; };
+struct ConvPlan { int S, slot, off_mis, off_t1, off_a1, off_a2, off_fx, KG1; size_t lds; };
 
 static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
     if (Q->cfg.n_conv != 3) return false;
@@ -890,7 +1166,7 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
     P->KG1 = (L1.K + 15) / 16;
     if (P->KG1 < 3) P->KG1 = 3;
     const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
-    if (in_bytes >= (1 << 20)) return false;                        // (first row table: sample << 20 | offset inside the observation)
+    if (in_bytes >= (1 << 17)) return false;                        // (first row table: sample << 20 | swizzle << 17 | offset inside the observation)
     P->slot = (in_bytes + 15 + 15 + 15) & ~15;                       // the 16-byte-aligned window around an arbitrarily aligned row
     for (int pass = 0; pass < 2; ++pass) {                          // prefer two workgroups per CU; else the largest S that fits
         const size_t budget = pass == 0 ? CONV_LDS_2PER_CU : CONV_LDS_MAX;
@@ -902,9 +1178,36 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
             const size_t t1 = off; off += up16((size_t)S * L1.rows * 4);
             const size_t a2_bytes = up16((size_t)2 * S * L2.rows * 40 * 2);
             if (off < a2_bytes) off = a2_bytes;
-            const size_t a1 = off; off += up16((size_t)2 * S * L1.rows * 72 * 2);
+            const size_t a1 = off; off += up16((size_t)2 * S * L1.rows * A1_PS * 2);
+            const size_t fx = off; off += CONV_SWZ ? up16((size_t)S * L1.rows + 16) : 0;      // (+ 16: the last tile's rows past the end are read, not used)
             if (off <= budget && S * L1.rows <= CONV_ROWTAB) {      // (rows per workgroup: the row tables' capacity)
-                P->S = S; P->off_mis = (int)mis; P->off_t1 = (int)t1; P->off_a1 = (int)a1; P->off_a2 = 0; P->lds = off;
+                P->S = S; P->off_mis = (int)mis; P->off_t1 = (int)t1; P->off_a1 = (int)a1; P->off_a2 = 0; P->off_fx = (int)fx; P->lds = off;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// Persistent conv chain (conv_chain_pkernel): [obs A | core | obs B | a1 planes (rows of 64 halves) | alignment offsets [2][16]]; a2 overlays the
+// current group's observation buffer and the core.  Two workgroups per CU where that fits, else one.
+struct ConvPlanP { int S, slot, off_t1, off_obs1, off_a2b, off_a1, off_mis, per_cu; size_t lds; };
+static bool plan_conv_persist(const dq_qnet* Q, ConvPlanP* P) {
+    ConvPlan base;
+    if (!plan_conv(Q, &base)) return false;
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1];
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t budget = pass == 0 ? CONV_LDS_2PER_CU : CONV_LDS_MAX;
+        for (int S = 8; S >= 1; S >>= 1) {
+            const size_t obs = up16((size_t)S * base.slot), t1b = up16((size_t)S * L1.rows * 4), a2b = up16((size_t)2 * S * L2.rows * 40 * 2);
+            size_t core = a2b > obs ? a2b - obs : 0;
+            if (core < t1b) core = t1b;
+            size_t off = 2 * obs + core;
+            const size_t a1 = off; off += up16((size_t)2 * S * L1.rows * 64 * 2);
+            const size_t mis = off; off += 2 * 16 * 4;
+            if (off <= budget && S * L1.rows <= CONV_ROWTAB) {
+                P->S = S; P->slot = base.slot; P->off_t1 = (int)obs; P->off_obs1 = (int)(obs + core); P->off_a2b = (int)(2 * obs + core - a2b);
+                P->off_a1 = (int)a1; P->off_mis = (int)mis; P->lds = off; P->per_cu = pass == 0 ? 2 : 1;
                 return true;
             }
         }
@@ -913,22 +1216,32 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
 }
 
 // Row tables of the fused conv forward for this network (CONV_ROWTAB ints each; qnet.hip uploads them behind kofftab at creation):
-//   [0] first convolution, row m = s * r1 + oy * ow1 + ox of a workgroup's S samples:  s << 20 | (oy * stride * W + ox * stride)
-//   [1] / [2] second / third convolution: halves from the input image's start to row m's patch, ((s * ih + oy) * iw + ox) * (CIN + 8)
+//   [0] first convolution, row m = s * r1 + oy * ow1 + ox of a workgroup's S samples:  s << 20 | f << 17 | (oy * stride * W + ox * stride), f = 2 (ox & 3)
+//       the chunk swizzle of the row's a1 planes (CONV_SWZ)
+//   [1] / [2] second / third convolution: halves from the input image's start to row m's patch, ((s * ih + oy) * iw + ox) * row stride (a1: A1_PS, and
+//       with CONV_SWZ ox & 3 in bits 24+; a2: 40)
+//   [3] the second convolution's over a1 rows of 64 halves (conv_chain_pkernel)
 bool fused_conv_row_tables(const dq_qnet* Q, int* tab) {
     ConvPlan P;
     if (!plan_conv(Q, &P)) return false;
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
-    memset(tab, 0, sizeof(int) * 3 * CONV_ROWTAB);
+    memset(tab, 0, sizeof(int) * CONV_FWD_TABS * CONV_ROWTAB);
+    ConvPlanP PP;                                                   // [3]: the second convolution's rows over UNPADDED a1 planes (the persistent kernel's)
+    if (plan_conv_persist(Q, &PP))
+        for (int m = 0; m < PP.S * L2.rows; ++m) {
+            const int s = m / L2.rows, pix = m % L2.rows, oy = pix / L2.ow, ox = pix % L2.ow;
+            tab[3 * CONV_ROWTAB + m] = ((s * L2.ih + oy) * L2.iw + ox) * 64;
+        }
     for (int m = 0; m < P.S * L1.rows; ++m) {
         const int s = m / L1.rows, pix = m % L1.rows, oy = pix / L1.ow, ox = pix % L1.ow;
-        tab[m] = s << 20 | (oy * L1.s * L1.iw + ox * L1.s);
+        tab[m] = s << 20 | (CONV_SWZ ? (2 * (ox & 3)) << 17 : 0) | (oy * L1.s * L1.iw + ox * L1.s);
     }
     const Layer* Ls[2] = {&L2, &L3};
     for (int l = 0; l < 2; ++l)
         for (int m = 0; m < P.S * Ls[l]->rows; ++m) {
             const int s = m / Ls[l]->rows, pix = m % Ls[l]->rows, oy = pix / Ls[l]->ow, ox = pix % Ls[l]->ow;
-            tab[(1 + l) * CONV_ROWTAB + m] = ((s * Ls[l]->ih + oy) * Ls[l]->iw + ox) * (Ls[l]->cin + 8);
+            tab[(1 + l) * CONV_ROWTAB + m] = l == 0 ? ((s * L2.ih + oy) * L2.iw + ox) * A1_PS | (CONV_SWZ ? (ox & 3) << 24 : 0)
+                                                    : ((s * L3.ih + oy) * L3.iw + ox) * (L3.cin + 8);
         }
     return true;
 }
@@ -974,12 +1287,21 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     DQ_REQUIRE(plan_conv(Q, &cp) && plan_dense(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_forward: configuration not covered");
     DQ_REQUIRE(n_jobs >= 1 && n_jobs <= FWD_MAX_JOBS, DQ_ERR_INVALID, "fused_forward: 1..%d jobs per launch", FWD_MAX_JOBS);
     conv_kernel_t ck = cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
+    // the persistent form (DQ_CONV_PERSIST=0 selects the one-group-per-workgroup kernel: A/B runs) when the launch has more groups than resident workgroups
+    ConvPlanP pp;
+    static int persist_env = -1;
+    if (persist_env < 0) { const char* e = getenv("DQ_CONV_PERSIST"); persist_env = e ? atoi(e) : 1; }
+    const bool can_persist = persist_env != 0 && plan_conv_persist(Q, &pp) && pp.S == cp.S;
+    const conv_kernel_t pk = cp.KG1 == 3 ? conv_chain_pkernel<3> : cp.KG1 == 4 ? conv_chain_pkernel<4> : cp.KG1 == 5 ? conv_chain_pkernel<5> : conv_chain_pkernel<6>;
     static unsigned long long attr_devs = 0;                          // per device (common.h dq_device_bit)
     const unsigned long long dev_bit = dq_device_bit();
     if (!(attr_devs & dev_bit)) {
         const conv_kernel_t cks[4] = {conv_chain_kernel<3>, conv_chain_kernel<4>, conv_chain_kernel<5>, conv_chain_kernel<6>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
+        const conv_kernel_t pks[4] = {conv_chain_pkernel<3>, conv_chain_pkernel<4>, conv_chain_pkernel<5>, conv_chain_pkernel<6>};
+        for (int i = 0; i < 4; ++i)
+            DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         const dense_kernel_t dks[4] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<4, 4, 4>};
         for (int i = 0; i < 4; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
@@ -997,7 +1319,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
     ca.kofftab = Q->kofftab; ca.rowtab = Q->kofftab + 96;
-    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_t1 = cp.off_t1; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2;
+    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_t1 = cp.off_t1; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2; ca.off_fx = cp.off_fx;
     const PackLayout PL = fused_pack_layout(Q);
     da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = (int)PL.dense1; da.pk_dense2 = (int)PL.dense2;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
@@ -1083,7 +1405,12 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     }
     for (int i = n_jobs; i < FWD_MAX_JOBS; ++i) ca.wg_first[i] = da.wg_first[i] = 0x7fffffff;
     dq_prof_begin(DQ_K_CONV_CHAIN, st);
-    ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
+    if (can_persist && conv_wgs > pp.per_cu * n_cu) {
+        ca.total_groups = conv_wgs; ca.off_t1 = pp.off_t1; ca.off_obs1 = pp.off_obs1; ca.off_a2b = pp.off_a2b; ca.off_a1 = pp.off_a1; ca.off_mis = pp.off_mis;
+        pk<<<pp.per_cu * n_cu, CONV_THREADS, pp.lds, st>>>(ca);
+    } else {
+        ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
+    }
     dq_prof_end(DQ_K_CONV_CHAIN, st);
     DQ_LAUNCH_CHECK();
     dq_prof_begin(DQ_K_DENSE_CHAIN, st);

@@ -613,7 +613,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
             const int c = wave + 4 * k, img = min(c / WG_NCH, 3), ch = c - (c / WG_NCH) * WG_NCH;      // wave-uniform
             if (drow[k] >= 0) {
                 const size_t ro = (size_t)min(m0 + WG_ROWS * it + drow[k], m1 - 1) * ((img >> 1) ? ldg : ldx);      // rows past the slice: re-read its last row (G cleared in mm)
-                __builtin_amdgcn_global_load_lds(dsrc[k] + ro, (__attribute__((address_space(3))) u32*)(dst + img * WG_IMG + ch * 512), 16, 0, 0);
+                lds_dma16(dsrc[k] + ro, lds_addr(dst + img * WG_IMG + ch * 512));      // (qnet.h: in flight until the loop's own s_waitcnt vmcnt(0))
             }
         }
     };
@@ -1543,7 +1543,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.partial = conv_partial; ca.pstride = conv_floats;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.a1_alt = cp.a1_alt; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
     ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3; ca.off_ko = cp.off_ko; ca.off_tp = cp.off_tp; ca.kofftab = Q->kofftab;
-    ca.off_d2 = cp.off_d2; ca.off_d1 = cp.off_d1; ca.rowtab = Q->kofftab + 96 + 3 * CONV_ROWTAB;
+    ca.off_d2 = cp.off_d2; ca.off_d1 = cp.off_d1; ca.rowtab = Q->kofftab + 96 + CONV_FWD_TABS * CONV_ROWTAB;
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
     conv_bwd_kernel_t ck = cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;

@@ -5,6 +5,7 @@
 #define QN_MAX_LAYERS 12
 #define FWD_MAX_JOBS 4               // forwards served by one fused launch (dq_qnet_forward_multi)
 #define CONV_ROWTAB 512              // rows per workgroup and layer of the fused conv forward, at most
+#define CONV_FWD_TABS 4              // row tables of the fused conv forward (fused_conv_row_tables); the backward's five follow
 
 struct Layer {
     int kind;                    // 0 conv, 1 dense
@@ -33,7 +34,7 @@ struct dq_qnet {
     int last_index_off, last_index_mod;
     float* xinf[FWD_MAX_JOBS];   // fused inference forwards: last-convolution output per job slot [max_batch, flat]
     int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an NCHW uint8 observation, -1 past K;
-                                 // then [3][CONV_ROWTAB] the fused conv forward's row tables (fused_conv_row_tables) and [5][CONV_ROWTAB]
+                                 // then [CONV_FWD_TABS][CONV_ROWTAB] the fused conv forward's row tables (fused_conv_row_tables) and [5][CONV_ROWTAB]
                                  // the fused conv backward's (fused_conv_bwd_row_tables)
     void* pk_scratch[FWD_MAX_JOBS];  // packed weights of jobs that did not bring their own (dq_qnet_job.packed_dev == NULL)
     const void* last_train_packed;   // packed weights of the last training forward (the backward's data gradients read them)
@@ -121,6 +122,28 @@ __device__ __forceinline__ void split_f16x2_one(float v, unsigned short& h, unsi
     l = __builtin_bit_cast(unsigned short, vl);
 }
 
+
+// ---- LDS-DMA the compiler does not see ---------------------------------------------------------------------------------------------
+// global -> LDS copies (per-lane global address, lane l lands at lds_base + size * l, inactive lanes copy nothing).  Behind the builtin
+// (__builtin_amdgcn_global_load_lds) hipcc inserts s_waitcnt vmcnt(0) in front of the NEXT LDS access of any kind -- it cannot tell that the
+// access does not touch the copy's destination -- so a copy issued "one stage ahead" was in fact waited for at once: round 3 found every
+// LDS-DMA pipeline of this library (dense weight gradients, convolutional backward, the persistent conv forward) serialised that way
+// (ISA: s_waitcnt vmcnt(0) right behind each global_load_lds; phase stamps: an iteration = copy latency + compute).  Written as inline assembly
+// the copy stays in flight until the kernel's OWN s_waitcnt vmcnt(0) (every pipeline has one, in front of the barrier that publishes the
+// stage).  hipcc's vmcnt bookkeeping for other loads stays correct: a wave's memory operations retire in order, so a wait it computes for
+// a load can only turn out stricter than needed (it does not count these copies), never weaker.
+__device__ __forceinline__ void lds_dma16(const void* gptr, u32 lds_base) {
+    u32 m0_saved;                                                   // (m0 = the copy's LDS base; restored: it is not an asm clobber hipcc honours)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "v"(gptr), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* gptr, u32 lds_base) {
+    u32 m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "v"(gptr), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ u32 lds_addr(const void* p) { return (u32)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+
 #define MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
 
 // acc0 takes the leading piece product, acc1 the two 2^11-scaled cross terms; the caller combines them with f16x2_sum
@@ -195,7 +218,7 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);
-bool fused_conv_row_tables(const dq_qnet* Q, int* tab);      // tab: int[3 * CONV_ROWTAB]
+bool fused_conv_row_tables(const dq_qnet* Q, int* tab);      // tab: int[CONV_FWD_TABS * CONV_ROWTAB]
 bool fused_conv_bwd_row_tables(const dq_qnet* Q, int* tab);  // tab: int[5 * CONV_ROWTAB] (fused_bwd.hip)
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)

@@ -399,15 +399,15 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
     }
     if (e == hipSuccess) e = hipMalloc(&Q->partial, max_partial * sizeof(float));
     if (e == hipSuccess) {
-        int tab[96 + 8 * CONV_ROWTAB];
+        int tab[96 + (CONV_FWD_TABS + 5) * CONV_ROWTAB];
         const Layer& L1 = Q->L[0];
         for (int k = 0; k < 96; ++k) {
             const int t = k / L1.cin, c = k - t * L1.cin, ky = t / L1.k, kx = t - ky * L1.k;
             tab[k] = k < L1.K ? c * L1.ih * L1.iw + ky * L1.iw + kx : -1;
         }
-        memset(tab + 96, 0, sizeof(int) * 8 * CONV_ROWTAB);
+        memset(tab + 96, 0, sizeof(int) * (CONV_FWD_TABS + 5) * CONV_ROWTAB);
         if (fused_forward_supported(Q)) (void)fused_conv_row_tables(Q, tab + 96);
-        if (fused_backward_supported(Q)) (void)fused_conv_bwd_row_tables(Q, tab + 96 + 3 * CONV_ROWTAB);
+        if (fused_backward_supported(Q)) (void)fused_conv_bwd_row_tables(Q, tab + 96 + CONV_FWD_TABS * CONV_ROWTAB);
         e = hipMalloc(&Q->kofftab, sizeof(tab));
         if (e == hipSuccess) e = hipMemcpy(Q->kofftab, tab, sizeof(tab), hipMemcpyHostToDevice);
     }

@@ -83,6 +83,13 @@ elif tag == 5:
         t = [buf[i * 8 + w] for i in range(27)]
         print("wave", w, "per iteration [wait+split+store, issue+barrier, mfma]:", [[t[1 + 3 * i + k + 1] - t[1 + 3 * i + k] for k in range(3)] for i in range(8)],
               "first", t[1] - t[0], "epilogue", t[26] - t[25], "total", t[26] - t[0])
+elif tag == 1 and os.environ.get("DQ_STAMP_PERSIST"):
+    # persistent conv chain: 8 stamps per group of the workgroup (1 top barrier passed, 2 table barrier, 3 conv1 done, 4 barrier, 5 conv2 done, 6 barrier, 7 group done)
+    for w in range(4):
+        for g in range(4):
+            t = [buf[(8 * g + i) * 8 + w] for i in range(1, 8)]
+            prev = buf[(8 * (g - 1) + 7) * 8 + w] if g else buf[0 * 8 + w]
+            print("wave", w, "group", g, "top wait+barrier", t[0] - prev, "| dma issue + table + bar, conv1, bar, conv2, bar, conv3 (+ w1 + burst):", [t[i + 1] - t[i] for i in range(6)], "group total", t[6] - prev)
 elif tag == 1:
     for w in range(4):
         t = [buf[i * 8 + w] for i in range(8)]
