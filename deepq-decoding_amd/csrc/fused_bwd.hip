@@ -498,7 +498,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
 // iteration's 64 batch rows x 64 columns of both operands and pieces are copied global -> LDS by LDS-DMA (no registers, no arithmetic;
 // rows of 64 halves + one 16-byte padding slot whose lane stays inactive), and the MFMA operands -- 8 consecutive batch rows of one
 // column per lane: the TRANSPOSE of the staged rows -- come out of LDS by transposing reads (lds_tr8 above: two ds_read_b64_tr_b16 per
-// piece and tile).  Double-buffered, one barrier per iteration, the next iteration's copies fly under this iteration's MFMAs.
+// piece and tile).  Double-buffered, one barrier per iteration, the next iteration's copies fly under this iteration's MFMAs (since round 3 for real:
+// lds_dma16, qnet.h -- 15.5 -> 13.7 us; the nine copies of an iteration issued BETWEEN the MFMA groups instead of in one run before them: 15.1 us, dropped).
 // (Before: rows loaded into registers, transposed with 32 byte-permutes per lane and 8 rows, stored into a swizzled [column][batch row]
 // image and read back with ds_read_b128: 155 VALU per wave and iteration, 16.4 us; now 15.1 us.)
 // Bias gradients (column sums of G) come out of the matrix pipe as well: a tile whose A operand is all ones.  Rows past the slice are
@@ -959,7 +960,8 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 #pragma unroll
     for (int u = 0; u < NW1; ++u) { acc1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1l[u] = acc1[u]; }
 
-    // ---- every input image goes global -> LDS by LDS-DMA (no registers), issued as early as its LDS target is free, so that group
+    // ---- every input image goes global -> LDS by LDS-DMA (no registers; lds_dma16 / lds_dma4, qnet.h: copies hipcc does not wait for behind our
+    //      back -- until round 3 it put an s_waitcnt vmcnt(0) behind every one of them), issued as early as its LDS target is free, so that group
     //      k + 1's inputs land while group k computes.  (All workgroups run in lockstep: a load phase of its own is a burst on HBM
     //      that nothing overlaps.)  One wave instruction writes 64 lanes x 16 B (or x 4 B) CONTIGUOUSLY in LDS from per-lane global
     //      addresses; inactive lanes write nothing.
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             const char* src = reinterpret_cast<const char*>(a.a1p + piece * a.a1_lo + (size_t)gb0 * r1 * A1PS);
             int off = ch * 1024 + lane * 16;
             if (off >= bytes) off = 0;                                  // tail lanes: a valid address; they land in the image's padding
-            __builtin_amdgcn_global_load_lds(src + off, (__attribute__((address_space(3))) u32*)(dst + piece * LA1 + ch * 512), 16, 0, 0);
+            lds_dma16(src + off, lds_addr(dst + piece * LA1 + ch * 512));
         }
     };
     // piece planes [rows][32 halves] (a2, g3) -> LDS rows of PL32 halves = 5 lane slots of 16 B (slot 4 of every row is padding), both planes
@@ -984,8 +986,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             const int piece = c >= chunks ? 1 : 0, ch = c - piece * chunks;
             const int q = ch * 64 + lane, row = q / 5, part = q - row * 5;
             if (q < slots && part < 4)
-                __builtin_amdgcn_global_load_lds(src + piece * src_lo + (size_t)row * 32 + part * 8,
-                                                 (__attribute__((address_space(3))) u32*)(dst + piece * dst_lo + ch * 512), 16, 0, 0);
+                lds_dma16(src + piece * src_lo + (size_t)row * 32 + part * 8, lds_addr(dst + piece * dst_lo + ch * 512));
         }
     };
     auto issue_a2 = [&](int g, int rows) { issue_pl32(a.a2p + (size_t)g * S * r2 * 32, a.a2_lo, rows, s_a2, LA2); };
@@ -1003,8 +1004,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             for (int pc = 0; pc < pieces; ++pc) {
                 const int d = pc * 64 + lane;
                 if (4 * d < mis + in_bytes)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32*>(src - mis) + d,
-                                                     (__attribute__((address_space(3))) u32*)(s_in + s * a.slot + pc * 256), 4, 0, 0);
+                    lds_dma4(reinterpret_cast<const u32*>(src - mis) + d, lds_addr(s_in + s * a.slot + pc * 256));
             }
             if (lane == 0) s_mis[s] = mis;
         }
