@@ -719,12 +719,64 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
 // Fixed-order reduction of both partial sets in one launch: out[i] = sum_s partial[s * stride + i].
 // Block = 64 outputs x 8 slice groups (thread (x, g) sums slices g, g+8, ... in order; the 8 group sums are combined
 // pairwise in LDS) -- deterministic, and 8x the loads in flight of a one-thread-per-output loop.
-struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; int pidx0; };   // pidx0: flat index of out[0]
+struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; int pidx0; int vec; };   // pidx0: flat index of out[0]; vec: see the kernel
 struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; float inv_gs; const float* gs_dev; unsigned* range_flag; };     // partials carry the gradient scale: x 1/S
+
+// one output's optimizer step and range guard
+__device__ __forceinline__ void reduce_finish(const ReduceArgs& a, const ReduceSeg& S, int i, float gsum) {
+    S.out[i] = gsum;
+    // range guard (dq_qnet_range_check): an S x gradient beyond the f16 pieces' range arrives here as inf / NaN -- reported, never applied
+    const bool finite = fabsf(gsum) < INFINITY;
+    if (!finite) atomicOr(a.range_flag, 1u);
+    if (a.adam && finite) {                                         // the optimizer step rides on the reduction (dq_qnet_backward_adam)
+        const size_t k = (size_t)S.pidx0 + i;
+        float pk = a.opt.p[k], mk = a.opt.m[k], vk = a.opt.v[k];
+        dq_adam1(pk, gsum, mk, vk, a.opt.lr_t, a.opt.b1, a.opt.b2, a.opt.eps);
+        a.opt.p[k] = pk; a.opt.m[k] = mk; a.opt.v[k] = vk;
+    }
+}
 
 __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __shared__ float sh[8][64];
     const ReduceSeg& S = a.seg[blockIdx.x >= (unsigned)a.seg[1].block0 ? 1 : 0];
+    const float inv = a.gs_dev ? a.gs_dev[1] : a.inv_gs;
+    if (S.vec) {
+        // at most 8 slices (the dense partials): thread = four consecutive outputs, all slices' 16-byte loads in flight together, summed in the
+        // order of the scalar form below (pairs, pairs of pairs: the same bits).  That form spent a 512-thread workgroup, a barrier and an LDS
+        // round trip on 64 outputs of 8 loads each: 2763 of this launch's 3020 workgroups.
+        const int i = 4 * ((blockIdx.x - S.block0) * 512 + threadIdx.y * 64 + threadIdx.x);      // block-uniform branch; slices start on 128-byte lines
+        if (i >= S.n) return;
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float* p = S.partial + (size_t)min(k, S.slices - 1) * S.stride + i;
+            if (i + 3 < S.n) v[k] = *reinterpret_cast<const f32x4*>(p);
+            else { v[k] = f32x4{p[0], i + 1 < S.n ? p[1] : 0.f, i + 2 < S.n ? p[2] : 0.f, 0.f}; }
+            if (k >= S.slices) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const f32x4 g4 = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * inv;
+        if (i + 3 < S.n) {                                          // whole quadruples: gradient, parameters and moments as 16-byte accesses (pidx0 is a multiple of 4)
+            *reinterpret_cast<f32x4*>(S.out + i) = g4;
+            bool finite = true;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) finite = finite && fabsf(g4[c]) < INFINITY;
+            if (!finite) {                                          // (rare: per element, as the scalar form does)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) reduce_finish(a, S, i + c, g4[c]);
+            } else if (a.adam) {
+                const size_t k = (size_t)S.pidx0 + i;
+                f32x4 pk = *reinterpret_cast<const f32x4*>(a.opt.p + k), mk = *reinterpret_cast<const f32x4*>(a.opt.m + k), vk = *reinterpret_cast<const f32x4*>(a.opt.v + k);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { float p1 = pk[c], m1 = mk[c], v1 = vk[c]; dq_adam1(p1, g4[c], m1, v1, a.opt.lr_t, a.opt.b1, a.opt.b2, a.opt.eps); pk[c] = p1; mk[c] = m1; vk[c] = v1; }
+                *reinterpret_cast<f32x4*>(a.opt.p + k) = pk; *reinterpret_cast<f32x4*>(a.opt.m + k) = mk; *reinterpret_cast<f32x4*>(a.opt.v + k) = vk;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (i + c < S.n) reduce_finish(a, S, i + c, g4[c]);
+        }
+        return;
+    }
     const int i = (blockIdx.x - S.block0) * 64 + threadIdx.x, g = threadIdx.y;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                     // four independent chains: the loop is load-latency-bound
     if (i < S.n) {
@@ -741,17 +793,7 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __syncthreads();
     if (g == 0 && i < S.n) {
         const int x = threadIdx.x;
-        const float gsum = (((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x])) + ((sh[4][x] + sh[5][x]) + (sh[6][x] + sh[7][x]))) * (a.gs_dev ? a.gs_dev[1] : a.inv_gs);
-        S.out[i] = gsum;
-        // range guard (dq_qnet_range_check): an S x gradient beyond the f16 pieces' range arrives here as inf / NaN -- reported, never applied
-        const bool finite = fabsf(gsum) < INFINITY;
-        if (!finite) atomicOr(a.range_flag, 1u);
-        if (a.adam && finite) {                                     // the optimizer step rides on the reduction (dq_qnet_backward_adam)
-            const size_t k = (size_t)S.pidx0 + i;
-            float pk = a.opt.p[k], mk = a.opt.m[k], vk = a.opt.v[k];
-            dq_adam1(pk, gsum, mk, vk, a.opt.lr_t, a.opt.b1, a.opt.b2, a.opt.eps);
-            a.opt.p[k] = pk; a.opt.m[k] = mk; a.opt.v[k] = vk;
-        }
+        reduce_finish(a, S, i, (((sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x])) + ((sh[4][x] + sh[5][x]) + (sh[6][x] + sh[7][x]))) * inv);
     }
 }
 
@@ -1385,16 +1427,19 @@ bool fused_backward_supported(const dq_qnet* Q) {
     return fused_forward_supported(Q) && plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp);
 }
 
+// stride (floats) between the dense weight-gradient partials: the parameter count rounded up to whole 128-byte lines, so that every slice starts
+// on one (the final reduction reads 16 bytes per lane)
+static inline size_t dense_pstride(const dq_qnet* Q) { return (Q->n_params + 31) & ~(size_t)31; }
 // floats of workspace the fused backward needs: [DENSE_WGRAD_SLICES][n_params] dense partials, then [CONV_BWD_MAX_WGS][conv params]
 size_t fused_backward_workspace_floats(const dq_qnet* Q) {
     if (!fused_backward_supported(Q)) return 0;
-    return (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + 4;     // + {S, 1/S}: GradScale, + the range flag
+    return (size_t)DENSE_WGRAD_SLICES * dense_pstride(Q) + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + 4;     // + {S, 1/S}: GradScale, + the range flag
 }
 
 // the range guard's flag word (include/deepq_hip.h dq_qnet_range_check): the third of the four words behind the partials
 unsigned* fused_range_flag(const dq_qnet* Q) {
     if (!Q->fpartial) return nullptr;
-    return reinterpret_cast<unsigned*>(Q->fpartial + (size_t)DENSE_WGRAD_SLICES * Q->n_params + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off) + 2;
+    return reinterpret_cast<unsigned*>(Q->fpartial + (size_t)DENSE_WGRAD_SLICES * dense_pstride(Q) + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off) + 2;
 }
 
 typedef void (*conv_bwd_kernel_t)(ConvBwdArgs);
@@ -1425,7 +1470,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     // ---- 0. transposed weights -------------------------------------------------------------------------------------
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
     float* dense_partial = Q->fpartial;
-    float* conv_partial = dense_partial + (size_t)DENSE_WGRAD_SLICES * Q->n_params;
+    float* conv_partial = dense_partial + (size_t)DENSE_WGRAD_SLICES * dense_pstride(Q);
     float* gs_slot = conv_partial + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off;       // device-computed {S, 1/S}
     DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
     const u32x4* pkbase = static_cast<const u32x4*>(Q->last_train_packed);
@@ -1507,7 +1552,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     }
     int rps, sy;
     wgrad_slicing(B, &rps, &sy);
-    wa.rows_per_slice = rps; wa.partial = dense_partial; wa.pstride = Q->n_params;
+    wa.rows_per_slice = rps; wa.partial = dense_partial; wa.pstride = dense_pstride(Q);
     dq_prof_begin(DQ_K_DENSE_WGRAD, st);
     wa.total_tiles = tiles; wa.slices = sy;
     dense_wgrad_kernel<<<8 * tiles * ((sy + 7) / 8), WGRAD_THREADS, DENSE_WGRAD_LDS, st>>>(wa);
@@ -1519,7 +1564,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         memset(&ra, 0, sizeof(ra));
         ra.inv_gs = Q->bwd_scale > 0.f ? 1.f / Q->bwd_scale : 0.f; ra.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
         ra.range_flag = reinterpret_cast<unsigned*>(gs_slot) + 2;
-        ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, 0, (int)conv_floats};
+        ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, dense_pstride(Q), 0, (int)conv_floats};
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
         reduce_slices_kernel<<<(n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
         DQ_LAUNCH_CHECK();
@@ -1563,8 +1608,10 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     if (phases == 3) {
         int rps, sy;
         wgrad_slicing(B, &rps, &sy);
-        ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, Q->n_params, blocks0, (int)conv_floats};
-        reduce_slices_kernel<<<blocks0 + (n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
+        ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, dense_pstride(Q), blocks0, (int)conv_floats};
+        ra.seg[1].vec = sy <= 8 && (conv_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(grads_dev) & 15) == 0 &&
+                        (!opt || ((reinterpret_cast<uintptr_t>(opt->p) | reinterpret_cast<uintptr_t>(opt->m) | reinterpret_cast<uintptr_t>(opt->v)) & 15) == 0);          // few slices: four outputs per thread, every slice's 16 bytes in flight at once
+        reduce_slices_kernel<<<blocks0 + (ra.seg[1].vec ? (n_dense + 2047) / 2048 : (n_dense + 63) / 64), dim3(64, 8), 0, st>>>(ra);
     } else {
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
         reduce_slices_kernel<<<blocks0, dim3(64, 8), 0, st>>>(ra);
