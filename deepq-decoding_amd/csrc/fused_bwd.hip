@@ -736,11 +736,35 @@ __device__ __forceinline__ void reduce_finish(const ReduceArgs& a, const ReduceS
     }
 }
 
+// four consecutive outputs (i a multiple of 4, pidx0 too, 16-byte-aligned buffers): gradient, parameters and moments as 16-byte accesses
+__device__ __forceinline__ void reduce_finish4(const ReduceArgs& a, const ReduceSeg& S, int i, const f32x4& g4) {
+    if (i + 3 < S.n) {
+        *reinterpret_cast<f32x4*>(S.out + i) = g4;
+        bool finite = true;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) finite = finite && fabsf(g4[c]) < INFINITY;
+        if (!finite) {                                              // (rare: per element, as the scalar form does)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) reduce_finish(a, S, i + c, g4[c]);
+        } else if (a.adam) {
+            const size_t k = (size_t)S.pidx0 + i;
+            f32x4 pk = *reinterpret_cast<const f32x4*>(a.opt.p + k), mk = *reinterpret_cast<const f32x4*>(a.opt.m + k), vk = *reinterpret_cast<const f32x4*>(a.opt.v + k);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { float p1 = pk[c], m1 = mk[c], v1 = vk[c]; dq_adam1(p1, g4[c], m1, v1, a.opt.lr_t, a.opt.b1, a.opt.b2, a.opt.eps); pk[c] = p1; mk[c] = m1; vk[c] = v1; }
+            *reinterpret_cast<f32x4*>(a.opt.p + k) = pk; *reinterpret_cast<f32x4*>(a.opt.m + k) = mk; *reinterpret_cast<f32x4*>(a.opt.v + k) = vk;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (i + c < S.n) reduce_finish(a, S, i + c, g4[c]);
+    }
+}
+
 __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __shared__ float sh[8][64];
     const ReduceSeg& S = a.seg[blockIdx.x >= (unsigned)a.seg[1].block0 ? 1 : 0];
     const float inv = a.gs_dev ? a.gs_dev[1] : a.inv_gs;
-    if (S.vec) {
+    if (S.vec == 1) {
         // at most 8 slices (the dense partials): thread = four consecutive outputs, all slices' 16-byte loads in flight together, summed in the
         // order of the scalar form below (pairs, pairs of pairs: the same bits).  That form spent a 512-thread workgroup, a barrier and an LDS
         // round trip on 64 outputs of 8 loads each: 2763 of this launch's 3020 workgroups.
@@ -755,28 +779,11 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
             if (k >= S.slices) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const f32x4 g4 = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * inv;
-        if (i + 3 < S.n) {                                          // whole quadruples: gradient, parameters and moments as 16-byte accesses (pidx0 is a multiple of 4)
-            *reinterpret_cast<f32x4*>(S.out + i) = g4;
-            bool finite = true;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) finite = finite && fabsf(g4[c]) < INFINITY;
-            if (!finite) {                                          // (rare: per element, as the scalar form does)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) reduce_finish(a, S, i + c, g4[c]);
-            } else if (a.adam) {
-                const size_t k = (size_t)S.pidx0 + i;
-                f32x4 pk = *reinterpret_cast<const f32x4*>(a.opt.p + k), mk = *reinterpret_cast<const f32x4*>(a.opt.m + k), vk = *reinterpret_cast<const f32x4*>(a.opt.v + k);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { float p1 = pk[c], m1 = mk[c], v1 = vk[c]; dq_adam1(p1, g4[c], m1, v1, a.opt.lr_t, a.opt.b1, a.opt.b2, a.opt.eps); pk[c] = p1; mk[c] = m1; vk[c] = v1; }
-                *reinterpret_cast<f32x4*>(a.opt.p + k) = pk; *reinterpret_cast<f32x4*>(a.opt.m + k) = mk; *reinterpret_cast<f32x4*>(a.opt.v + k) = vk;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (i + c < S.n) reduce_finish(a, S, i + c, g4[c]);
-        }
+        reduce_finish4(a, S, i, g4);
         return;
     }
+    // (the same treatment of the 256 convolutional partials -- 16 x 32 threads, four outputs each, eight 16-byte loads in flight per thread -- measured
+    // slower: 7.7 against 6.6 us for the launch)
     const int i = (blockIdx.x - S.block0) * 64 + threadIdx.x, g = threadIdx.y;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                     // four independent chains: the loop is load-latency-bound
     if (i < S.n) {
