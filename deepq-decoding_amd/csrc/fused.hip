@@ -1288,9 +1288,13 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     DQ_REQUIRE(n_jobs >= 1 && n_jobs <= FWD_MAX_JOBS, DQ_ERR_INVALID, "fused_forward: 1..%d jobs per launch", FWD_MAX_JOBS);
     conv_kernel_t ck = cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
     // the persistent form (DQ_CONV_PERSIST=0 selects the one-group-per-workgroup kernel: A/B runs) when the launch has more groups than resident workgroups
+    // (read per call: tests flip it.  0: never; 1 / unset: when the launch has more groups than resident workgroups; 2: always, with DQ_CONV_PERSIST_GRID
+    // workgroups if that is set -- a small grid makes every workgroup walk many groups)
     ConvPlanP pp;
-    static int persist_env = -1;
-    if (persist_env < 0) { const char* e = getenv("DQ_CONV_PERSIST"); persist_env = e ? atoi(e) : 1; }
+    const char* pe = getenv("DQ_CONV_PERSIST");
+    const int persist_env = pe ? atoi(pe) : 1;
+    const char* pg = getenv("DQ_CONV_PERSIST_GRID");
+    const int persist_grid = persist_env == 2 && pg ? atoi(pg) : 0;
     const bool can_persist = persist_env != 0 && plan_conv_persist(Q, &pp) && pp.S == cp.S;
     const conv_kernel_t pk = cp.KG1 == 3 ? conv_chain_pkernel<3> : cp.KG1 == 4 ? conv_chain_pkernel<4> : cp.KG1 == 5 ? conv_chain_pkernel<5> : conv_chain_pkernel<6>;
     static unsigned long long attr_devs = 0;                          // per device (common.h dq_device_bit)
@@ -1405,9 +1409,12 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     }
     for (int i = n_jobs; i < FWD_MAX_JOBS; ++i) ca.wg_first[i] = da.wg_first[i] = 0x7fffffff;
     dq_prof_begin(DQ_K_CONV_CHAIN, st);
-    if (can_persist && conv_wgs > pp.per_cu * n_cu) {
+    if (can_persist && (conv_wgs > pp.per_cu * n_cu || persist_env == 2)) {
         ca.total_groups = conv_wgs; ca.off_t1 = pp.off_t1; ca.off_obs1 = pp.off_obs1; ca.off_a2b = pp.off_a2b; ca.off_a1 = pp.off_a1; ca.off_mis = pp.off_mis;
-        pk<<<pp.per_cu * n_cu, CONV_THREADS, pp.lds, st>>>(ca);
+        int grid = pp.per_cu * n_cu;
+        if (persist_grid > 0) grid = persist_grid;
+        if (grid > conv_wgs) grid = conv_wgs;
+        pk<<<grid, CONV_THREADS, pp.lds, st>>>(ca);
     } else {
         ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
     }

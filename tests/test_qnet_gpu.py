@@ -197,6 +197,44 @@ def test_forward_multi_equals_separate_forwards(dq, torch_mod):
         net.forward_multi([dict(params=params, obs=ring, index=idx, training=True, seed=seed, t=t)] * 2)
 
 
+@pytest.mark.parametrize("name,big", [("c3", 1030), ("c5", 333), ("c1", 200), ("c2", 64)])
+def test_persistent_conv_forward_equals_the_one_group_kernel(dq, torch_mod, monkeypatch, name, big):
+    """The conv forward's persistent form (conv_chain_pkernel: resident workgroups walk the groups of 8 samples, the next group's observations
+    prefetched by LDS-DMA a group ahead, a1 planes unpadded) against the one-group-per-workgroup kernel it replaces above 2 workgroups per CU:
+    the same arithmetic in the same order, so the Q-values and the gradient computed from the saved activations must be IDENTICAL -- for ragged
+    batches, several jobs per launch with different weights, a replay-ring gather with wrap-around, and grids from 1 workgroup (every group
+    walked by the same workgroup) to one group each.  (DQ_CONV_PERSIST is read per launch: 0 never, 2 always; DQ_CONV_PERSIST_GRID workgroups.)"""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, name, big, fused=True)
+    params2 = (params + 0.05 * torch.randn_like(params)).contiguous()
+    T = 37
+    ring = torch.from_numpy((rng.rand(T * 64, *spec.input_shape) < 0.3).astype(np.uint8)).cuda()
+    index = torch.from_numpy(rng.randint(0, T * 64, size=300).astype(np.int32)).cuda()
+    obs_d = torch.from_numpy(obs).cuda()
+    dq_ = torch.from_numpy((rng.randn(big, spec.n_actions) / big).astype(np.float32)).cuda()
+
+    def run():
+        pk1, pk2 = net.pack(params), net.pack(params2)
+        jobs = [dict(params=params, obs=obs_d[:min(250, big)], packed=pk1), dict(params=params2, obs=obs_d[:9], packed=pk2),
+                dict(params=params, obs=obs_d, training=True, seed=(5, 6), t=77, packed=pk1),
+                dict(params=params2, obs=ring, index=index[:min(300, big)], index_off=T * 64 - 100, index_mod=T * 64, packed=pk2)]
+        qs = [q.clone() for q in net.forward_multi(jobs)]
+        g = net.backward(params, dq_).clone()
+        single = net.forward(params, obs_d[:1]).clone()
+        return qs, g, single
+
+    monkeypatch.setenv("DQ_CONV_PERSIST", "0")
+    q_ref, g_ref, s_ref = run()
+    assert torch.isfinite(g_ref).all() and float(g_ref.abs().max()) > 0
+    for grid in ("1", "3", "64", "100000"):
+        monkeypatch.setenv("DQ_CONV_PERSIST", "2")
+        monkeypatch.setenv("DQ_CONV_PERSIST_GRID", grid)
+        qs, g, single = run()
+        for a, b in zip(qs, q_ref):
+            assert torch.equal(a, b), grid
+        assert torch.equal(g, g_ref) and torch.equal(single, s_ref), grid
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
 def test_backward_in_two_phases_equals_one_call(dq, torch_mod, fused):
     """dq_qnet_backward_phase 0 (dense) then 1 (convolutions) == dq_qnet_backward, bit for bit; after phase 0 the dense range of the
