@@ -560,11 +560,18 @@ struct DenseWgradArgs {
     size_t pstride;
 };
 
-// rows per batch slice (a multiple of 64: whole iterations) and the number of slices, at most DENSE_WGRAD_SLICES
-#define DENSE_WGRAD_SLICES 8
+// rows per batch slice (a multiple of 64: whole iterations) and the number of slices, at most DENSE_WGRAD_SLICES.  WG_SLICES_TARGET slices are aimed
+// for: at c3 the launch is 49 tiles x slices workgroups on 256 CUs with room for two each -- 8 slices = 392 workgroups leave 120 CUs with one
+// workgroup and 136 with two (which set the kernel's duration: 8 iterations each); 10 slices of 448 rows = 490 workgroups of 7 iterations fill
+// nearly every CU twice.
+#define DENSE_WGRAD_SLICES 16
+#ifndef WG_SLICES_TARGET
+#define WG_SLICES_TARGET 10
+#endif
 static void wgrad_slicing(int B, int* rows_per_slice, int* slices) {
-    int rps = (B + DENSE_WGRAD_SLICES - 1) / DENSE_WGRAD_SLICES;
+    int rps = (B + WG_SLICES_TARGET - 1) / WG_SLICES_TARGET;
     rps = (rps + 63) & ~63;
+    while ((B + rps - 1) / rps > DENSE_WGRAD_SLICES) rps += 64;
     *rows_per_slice = rps;
     *slices = (B + rps - 1) / rps;
 }
@@ -575,8 +582,19 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
     // XCD-aware block -> (tile, slice) map: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of one batch
     // slice are given to ONE XCD (slice = XCD + 8 i): the slice's rows of X and G are then fetched from HBM/MALL once instead of
     // once per XCD.
-    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
-    const int slice = xcd + 8 * (within / a.total_tiles), tile = within % a.total_tiles;
+    // Whole groups of 8 slices are mapped that way; the slices left over (10 slices: two) go round the XCDs tile by tile, so that every XCD gets the
+    // same number of workgroups.
+    int slice, tile;
+    {
+        const int full = (a.slices >> 3) * 8 * a.total_tiles;       // workgroups of the whole groups of 8 slices
+        if ((int)blockIdx.x < full) {
+            const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+            slice = xcd + 8 * (within / a.total_tiles); tile = within % a.total_tiles;
+        } else {
+            const int e = (int)blockIdx.x - full;
+            slice = (a.slices & ~7) + e / a.total_tiles; tile = e % a.total_tiles;
+        }
+    }
     if (slice >= a.slices) return;                                  // block-uniform
     int l = 0;
     while (l + 1 < a.n_layers && tile >= a.L[l + 1].tile0) ++l;     // block-uniform
@@ -765,20 +783,21 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     const ReduceSeg& S = a.seg[blockIdx.x >= (unsigned)a.seg[1].block0 ? 1 : 0];
     const float inv = a.gs_dev ? a.gs_dev[1] : a.inv_gs;
     if (S.vec == 1) {
-        // at most 8 slices (the dense partials): thread = four consecutive outputs, all slices' 16-byte loads in flight together, summed in the
-        // order of the scalar form below (pairs, pairs of pairs: the same bits).  That form spent a 512-thread workgroup, a barrier and an LDS
+        // at most 16 slices (the dense partials): thread = four consecutive outputs, all slices' 16-byte loads in flight together, summed in fixed
+        // order (pairs, pairs of pairs, ...).  That form spent a 512-thread workgroup, a barrier and an LDS
         // round trip on 64 outputs of 8 loads each: 2763 of this launch's 3020 workgroups.
         const int i = 4 * ((blockIdx.x - S.block0) * 512 + threadIdx.y * 64 + threadIdx.x);      // block-uniform branch; slices start on 128-byte lines
         if (i >= S.n) return;
-        f32x4 v[8];
+        f32x4 v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const float* p = S.partial + (size_t)min(k, S.slices - 1) * S.stride + i;
             if (i + 3 < S.n) v[k] = *reinterpret_cast<const f32x4*>(p);
             else { v[k] = f32x4{p[0], i + 1 < S.n ? p[1] : 0.f, i + 2 < S.n ? p[2] : 0.f, 0.f}; }
             if (k >= S.slices) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const f32x4 g4 = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * inv;
+        const f32x4 g4 = ((((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                          (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])))) * inv;
         reduce_finish4(a, S, i, g4);
         return;
     }
@@ -1562,7 +1581,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     wa.rows_per_slice = rps; wa.partial = dense_partial; wa.pstride = dense_pstride(Q);
     dq_prof_begin(DQ_K_DENSE_WGRAD, st);
     wa.total_tiles = tiles; wa.slices = sy;
-    dense_wgrad_kernel<<<8 * tiles * ((sy + 7) / 8), WGRAD_THREADS, DENSE_WGRAD_LDS, st>>>(wa);
+    dense_wgrad_kernel<<<tiles * sy, WGRAD_THREADS, DENSE_WGRAD_LDS, st>>>(wa);
     dq_prof_end(DQ_K_DENSE_WGRAD, st);
     DQ_LAUNCH_CHECK();
 
@@ -1616,7 +1635,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         int rps, sy;
         wgrad_slicing(B, &rps, &sy);
         ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, dense_pstride(Q), blocks0, (int)conv_floats};
-        ra.seg[1].vec = sy <= 8 && (conv_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(grads_dev) & 15) == 0 &&
+        ra.seg[1].vec = sy <= 16 && (conv_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(grads_dev) & 15) == 0 &&
                         (!opt || ((reinterpret_cast<uintptr_t>(opt->p) | reinterpret_cast<uintptr_t>(opt->m) | reinterpret_cast<uintptr_t>(opt->v)) & 15) == 0);          // few slices: four outputs per thread, every slice's 16 bytes in flight at once
         reduce_slices_kernel<<<blocks0 + (ra.seg[1].vec ? (n_dense + 2047) / 2048 : (n_dense + 63) / 64), dim3(64, 8), 0, st>>>(ra);
     } else {

@@ -1,2 +1,2 @@
-python -m pytest tests/test_qnet_gpu.py tests/test_agent_gpu.py -m gpu -x -q -k "not shipped and not scratch" 2>&1 | tail -2
-tools/ab_run.sh dma base 2>&1 | grep rep
+python -m pytest tests/test_qnet_gpu.py -m gpu -x -q 2>&1 | tail -2
+tools/ab_run.sh dma base sl8 2>&1 | grep rep
