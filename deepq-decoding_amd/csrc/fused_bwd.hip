@@ -1061,12 +1061,25 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     auto issue_g3 = [&](int g, int rows) { issue_pl32(a.g3p + (size_t)g * S * r3 * 32, a.g3_lo, rows, s_g3, LG3); };
     // observations: lane l copies aligned dword l of a 256-byte piece of a sample's arbitrarily aligned row -- whole aligned dwords, also
     // where they straddle the neighbouring rows (see fused.hip: the window stays inside the caller's allocation)
-    auto issue_obs = [&](int g) {
+    // this wave's sample of group g (one sample per wave: S <= 8 = CB_WAVES): its replay-ring row, read through the CONSTANT address space -- a scalar
+    // load the compiler may issue early; as an ordinary load inside the group loop (which stores to global memory) hipcc made it a vector load +
+    // s_waitcnt vmcnt(0) + v_readfirstlane right in front of the copies: a memory latency in every group's prefetch
+    static_assert(CB_WAVES >= 8, "one observation per wave");
+    auto obs_row = [&](int g) {
+        const int gb0 = g * S, gns = min(S, a.batch - gb0);
+        int row = gb0 + min(wave, gns - 1);
+        if (a.index) {
+            const __attribute__((address_space(4))) int32_t* idx = (const __attribute__((address_space(4))) int32_t*)(uintptr_t)a.index;
+            row = idx[row] + a.index_off;
+            if (row >= a.index_mod) row -= a.index_mod;
+        }
+        return row;
+    };
+    auto issue_obs = [&](int g, int row) {
         const int gb0 = g * S, gns = min(S, a.batch - gb0);
         const int pieces = (a.slot + 255) >> 8;
-        for (int s = wave; s < gns; s += CB_WAVES) {                // one sample per wave (S <= 8): ONE ring-row lookup, then all its pieces
-            int row = gb0 + s;
-            if (a.index) { row = a.index[row] + a.index_off; if (row >= a.index_mod) row -= a.index_mod; }
+        const int s = wave;
+        if (s < gns) {                                              // wave-uniform
             const u8* src = a.obs + (size_t)row * in_bytes;
             const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
             for (int pc = 0; pc < pieces; ++pc) {
@@ -1079,7 +1092,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     };
     if ((int)blockIdx.x < a.groups) {
         const int g = blockIdx.x, gns = min(S, a.batch - g * S);
-        issue_obs(g);
+        issue_obs(g, obs_row(g));
         issue_g3(g, gns * r3);
         issue_a2(g, gns * r2);
         if (a.a1_alt) issue_a1(g, reinterpret_cast<unsigned short*>(smem + a.off_a1));
@@ -1093,6 +1106,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         const int M1 = ns * r1, M2 = ns * r2, M3 = ns * r3;
         const int nxt = grp + (int)gridDim.x;
         const int ns_nxt = min(S, a.batch - nxt * S);
+        const int row_nxt = nxt < a.groups ? obs_row(nxt) : 0;      // requested here, used behind g2 (block-uniform)
         const int sb = (grp == (int)blockIdx.x) ? 0 : 12;          // DQ_STAMP slots of the first / a later group
         (void)sb;
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 0);
@@ -1187,7 +1201,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 5);
         __syncthreads();
         if (nxt < a.groups) {                                       // the observation slots and g3 are dead now; so is the other a1 buffer
-            issue_obs(nxt);
+            issue_obs(nxt, row_nxt);
             issue_g3(nxt, ns_nxt * r3);
             if (a.a1_alt) issue_a1(nxt, reinterpret_cast<unsigned short*>(smem + a.off_a1 + ((it + 1) & 1) * a.a1_alt));
         }

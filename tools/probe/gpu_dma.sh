@@ -1,1 +1,2 @@
-tools/ab_run.sh dma base stg10 stg20 stg40 2>&1 | grep rep
+python -m pytest tests/test_qnet_gpu.py -m gpu -x -q 2>&1 | tail -2
+tools/ab_run.sh dma base 2>&1 | grep rep
