@@ -51,6 +51,7 @@ struct dq_env {
     const float* mlp_w;
     u8* d_dec;                     // [n_envs] class predicted for each lattice's post-action syndrome
     int* d_mlp_cells;              // [2 * n_stab]: stabilizers in increasing cell order of the (d+1)^2 input vector, then their cells
+    bool lut_marker;               // lut_x / lut_z only say "a referee is installed" (they point at the Dense stack's weights; never read)
 };
 
 // ---- Dense-stack referee on the device (round 3) ------------------------------------------------------------------------------------
@@ -444,7 +445,7 @@ dq_status dq_env_build_referee_ml(dq_env* E, double q_flip, void* stream) {
     if (rc != DQ_OK) return rc;
     E->lut_x = E->d_lut_x;
     E->lut_z = E->d_lut_z;
-    E->lut_joint = nullptr; E->mlp_layers = 0;
+    E->lut_joint = nullptr; E->mlp_layers = 0; E->lut_marker = false;
     return DQ_OK;
 }
 
@@ -457,7 +458,7 @@ dq_status dq_env_build_referee(dq_env* E, void* stream) {
     if (rc != DQ_OK) return rc;
     E->lut_x = E->d_lut_x;
     E->lut_z = E->d_lut_z;
-    E->lut_joint = nullptr; E->mlp_layers = 0;
+    E->lut_joint = nullptr; E->mlp_layers = 0; E->lut_marker = false;
     return DQ_OK;
 }
 
@@ -466,7 +467,7 @@ dq_status dq_env_set_referee(dq_env* E, const uint32_t* lut_x_dev, const uint32_
     DQ_REQUIRE(lut_z_dev || E->cfg.error_model == DQ_MODEL_X, DQ_ERR_INVALID, "dq_env_set_referee: the DP model needs a Z table");
     E->lut_x = lut_x_dev;
     E->lut_z = lut_z_dev ? lut_z_dev : lut_x_dev;
-    E->lut_joint = nullptr; E->mlp_layers = 0;
+    E->lut_joint = nullptr; E->mlp_layers = 0; E->lut_marker = false;
     return DQ_OK;
 }
 
@@ -474,14 +475,18 @@ dq_status dq_env_set_referee_joint(dq_env* E, const uint32_t* lut_dev) {
     DQ_REQUIRE(E && lut_dev, DQ_ERR_INVALID, "dq_env_set_referee_joint: null argument");
     DQ_REQUIRE(E->info.n_stab <= 24, DQ_ERR_UNSUPPORTED, "dq_env_set_referee_joint: a table over all %d stabilizers does not fit (d <= 5)",
                E->info.n_stab);
-    E->lut_joint = lut_dev; E->mlp_layers = 0;
+    E->lut_joint = lut_dev; E->mlp_layers = 0; E->lut_marker = false;
     E->lut_x = E->lut_z = lut_dev;                                  // "a referee is installed"; the component tables are not read
     return DQ_OK;
 }
 
 dq_status dq_env_set_referee_mlp(dq_env* E, int n_layers, const int32_t* dims, const float* weights_dev) {
     DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_set_referee_mlp: null handle");
-    if (n_layers == 0) { E->mlp_layers = 0; E->mlp_w = nullptr; return DQ_OK; }      // uninstall: the table referee (if any) is in charge again
+    if (n_layers == 0) {                                            // uninstall: the table referee (if any) is in charge again
+        if (E->lut_marker) { E->lut_x = E->lut_z = nullptr; E->lut_marker = false; }
+        E->mlp_layers = 0; E->mlp_w = nullptr;
+        return DQ_OK;
+    }
     DQ_REQUIRE(dims && weights_dev && n_layers >= 1 && n_layers <= DQ_MLP_MAX_LAYERS, DQ_ERR_INVALID, "dq_env_set_referee_mlp: 1 .. %d Dense layers",
                DQ_MLP_MAX_LAYERS);
     const int d = E->cfg.d, ns = E->info.n_stab, classes = E->cfg.error_model == DQ_MODEL_X ? 2 : 4;
@@ -489,7 +494,7 @@ dq_status dq_env_set_referee_mlp(dq_env* E, int n_layers, const int32_t* dims, c
                (d + 1) * (d + 1), dims[0]);
     DQ_REQUIRE(dims[n_layers] == classes, DQ_ERR_INVALID, "dq_env_set_referee_mlp: %d homology classes for this error model, the stack ends in %d units",
                classes, dims[n_layers]);
-    for (int l = 1; l <= n_layers; ++l) DQ_REQUIRE(dims[l] >= 1 && dims[l] <= 4096, DQ_ERR_UNSUPPORTED, "dq_env_set_referee_mlp: layer widths 1 .. 4096");
+    for (int l = 1; l <= n_layers; ++l) DQ_REQUIRE(dims[l] >= 1 && dims[l] <= 2048, DQ_ERR_UNSUPPORTED, "dq_env_set_referee_mlp: layer widths 1 .. 2048 (two activation vectors per wavefront in 64 KB of LDS)");
     if (!E->d_dec) DQ_HIP(hipMalloc(&E->d_dec, (size_t)E->cfg.n_envs));
     if (!E->d_mlp_cells) {
         // stabilizer s (measurement order, FL:189-221) sits at cell a (d+1) + b of the flattened syndrome (ENV:144 reshape)
@@ -512,7 +517,10 @@ dq_status dq_env_set_referee_mlp(dq_env* E, int n_layers, const int32_t* dims, c
     E->mlp_layers = n_layers;
     for (int l = 0; l <= n_layers; ++l) E->mlp_dims[l] = dims[l];
     E->mlp_w = weights_dev;
-    if (!E->lut_x) E->lut_x = E->lut_z = reinterpret_cast<const u32*>(weights_dev);      // "a referee is installed"; the tables are not read
+    if (!E->lut_x || E->lut_marker) {                               // "a referee is installed"; the tables are not read
+        E->lut_x = E->lut_z = reinterpret_cast<const u32*>(weights_dev);
+        E->lut_marker = true;
+    }
     return DQ_OK;
 }
 

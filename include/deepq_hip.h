@@ -120,7 +120,7 @@ dq_status dq_env_set_referee_joint(dq_env* env, const uint32_t* lut_dev);
  * step on the flattened (d+1)^2 syndrome of the state after the agent's move (Environments.py:53,139-144,
  * Single_Point_Training_Script.py:54-57); only the arg-max of its output is used (Environments.py:150).
  *   n_layers     1 .. 6 Dense layers, ReLU between them (the top layer's softmax is monotone and not evaluated)
- *   dims         int32 [n_layers + 1]: (d+1)^2, the hidden widths (<= 4096), then 2 ("X") or 4 classes
+ *   dims         int32 [n_layers + 1]: (d+1)^2, the hidden widths (<= 2048), then 2 ("X") or 4 classes
  *   weights_dev  float, caller-owned, must outlive its use: per layer the kernel [in][out] row-major (Keras shape), then the bias
  * Arithmetic (fixed, so that a host restatement gives the same bits -- referee.py FeedForwardReferee.predict_exact): float32, bias
  * first, inputs in increasing index order, one rounded multiply and one rounded add per term, first maximum of the outputs.

@@ -796,6 +796,27 @@ def test_dense_stack_referee_evaluated_on_the_device(dq, torch_mod):
             b_env.act_step(t, auto_reset=True)
             assert torch.equal(a_env.obs, b_env.obs) and torch.equal(a_env.done, b_env.done) and torch.equal(a_env.reward, b_env.reward), (model, t)
         assert torch.equal(a_env.export_state(), b_env.export_state())
+    # uninstalling: an environment that had no other referee has none afterwards (the step refuses), one with a table falls back to it; re-installing works
+    lib_mod = importlib.import_module("deepq-decoding_amd._lib")
+    bare = dq.VectorEnv(n_envs=8, referee=None, **cfg)
+    bare.set_referee_mlp(ff)
+    bare.reset()
+    bare.step(bare.select_actions(0), auto_reset=True)
+    bare.set_referee_mlp(None)
+    assert not bare.mlp_referee
+    with pytest.raises(lib_mod.DeepQError):
+        bare.step(bare.select_actions(1), auto_reset=True)
+    bare.set_referee_mlp(_random_stack(dq, rng, d, 4, hidden=(32,)))
+    bare.step(bare.select_actions(2), auto_reset=True)
+    tab = dq.VectorEnv(n_envs=8, **cfg)                              # built-in look-up referee
+    ref_tab = dq.VectorEnv(n_envs=8, **cfg)
+    tab.set_referee_mlp(ff); tab.set_referee_mlp(None)
+    tab.reset(); ref_tab.reset()
+    for t in range(10):
+        tab.act_step(t, auto_reset=True); ref_tab.act_step(t, auto_reset=True)
+        assert torch.equal(tab.obs, ref_tab.obs) and torch.equal(tab.done, ref_tab.done)
+    with pytest.raises(lib_mod.DeepQError):                          # widths beyond the kernel's LDS budget are refused, not mis-launched
+        dq.VectorEnv(n_envs=8, referee=_random_stack(dq, rng, d, 4, hidden=(4096,)), **cfg)
     # the façade takes the reference's static_decoder argument; the agent loop runs on such an environment (its step does not ride)
     single = dq.Surface_Code_Environment_Multi_Decoding_Cycles(static_decoder=ff, **cfg)
     obs = single.reset()

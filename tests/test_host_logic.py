@@ -386,6 +386,52 @@ def test_feed_forward_referee_from_a_keras_weight_file(tmp_path):
     assert out.returncode == 0 and "(1, 4)" in out.stdout, out.stderr
 
 
+def test_feed_forward_referee_exact_restatement_of_the_device_arithmetic():
+    """FeedForwardReferee.logits_exact / predict_exact restate the device referee's FIXED arithmetic (csrc/env.hip referee_mlp_kernel:
+    float32, bias first, inputs in increasing index order, one rounded multiply and one rounded add per term, ReLU between layers, first
+    maximum) -- checked here against an independent scalar loop in numpy float32, against the float64 / BLAS-ordered .predict wherever its top
+    two outputs are not within round-off, and for the flat weight layout dq_env_set_referee_mlp takes (kernel (in, out) row-major, then
+    the bias, per layer).  (The device side of the same equality: tests/test_env_gpu.py::test_dense_stack_referee_evaluated_on_the_device.)"""
+    ref_mod = importlib.import_module("deepq-decoding_amd.referee")
+    rng = np.random.RandomState(8)
+    dims = [64, 40, 24, 4]
+    weights = []
+    for a, b in zip(dims, dims[1:]):
+        weights += [(rng.randn(a, b) * (1.5 / np.sqrt(a))).astype(np.float32), (rng.randn(b) * 0.3).astype(np.float32)]
+    r = ref_mod.FeedForwardReferee(weights)
+    assert r.dims == dims
+    flat = r.flat_weights()
+    assert flat.dtype == np.float32 and flat.size == sum(a * b + b for a, b in zip(dims, dims[1:]))
+    off = 0
+    for (a, b), k, bias in zip(zip(dims, dims[1:]), weights[0::2], weights[1::2]):
+        assert np.array_equal(flat[off:off + a * b].reshape(a, b), k) and np.array_equal(flat[off + a * b:off + a * b + b], bias)
+        off += a * b + b
+    x = (rng.rand(300, 64) < 0.15).astype(np.float32)
+    z = r.logits_exact(x)
+    assert z.dtype == np.float32 and z.shape == (300, 4)
+
+    def scalar(row):                                                 # the kernel's loop, one output at a time
+        h = row.astype(np.float32)
+        for li, (k, bias) in enumerate(zip(weights[0::2], weights[1::2])):
+            out = np.empty(k.shape[1], np.float32)
+            for o in range(k.shape[1]):
+                acc = np.float32(bias[o])
+                for j in range(k.shape[0]):
+                    acc = np.float32(acc + np.float32(h[j] * k[j, o]))
+                out[o] = acc
+            h = np.maximum(out, np.float32(0)) if li + 1 < len(weights) // 2 else out
+        return h
+
+    for i in range(0, 300, 37):
+        assert np.array_equal(z[i], scalar(x[i])), i
+    p = r.predict(x)
+    top2 = np.sort(z, axis=1)[:, -2:]
+    clear = top2[:, 1] - top2[:, 0] > 1e-4
+    assert clear.mean() > 0.95 and np.array_equal(np.argmax(p, axis=1)[clear], np.argmax(z, axis=1)[clear])
+    pe = r.predict_exact(x)
+    assert np.array_equal(pe.sum(1), np.ones(300)) and np.array_equal(np.argmax(pe, axis=1), np.argmax(z, axis=1))
+
+
 def test_replay_permutation_restatement_is_a_uniform_bijection():
     """oracle/memory_oracle.py replay_permute (the restatement of csrc/common.h dq_replay_permute, compared bit for bit with the device
     in tests/test_qnet_gpu.py::test_replay_sample_rule): a bijection of [0, M) for any M, different for different keys, and a fixed
