@@ -416,14 +416,6 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP_PAIR(1);
 }
 
-// Four scalar loads issued together and waited for once.  (Inside the persistent loop hipcc no longer proves the replay index vector unclobbered --
-// the loop stores to global memory -- and turns each `index[i]` of a uniform i into a VECTOR load + s_waitcnt vmcnt(0) + v_readfirstlane, one
-// after the other: four serial memory latencies at the top of every group, and vmcnt(0) waits in front of the DMA.)
-__device__ __forceinline__ void scalar_load4(const int32_t* p0, const int32_t* p1, const int32_t* p2, const int32_t* p3, int (&r)[4]) {
-    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(r[0]), "=&s"(r[1]), "=&s"(r[2]), "=&s"(r[3]) : "s"(p0), "s"(p1), "s"(p2), "s"(p3) : "memory");
-}
-
 // ---- persistent form (round 3) --------------------------------------------------------------------------------------------------
 // Phase stamps of conv_chain_kernel in the vector step's launch (2048 workgroups = 4 rounds of 2 per CU) showed every workgroup, in every
 // round, spending 1.8-3.0K of its ~20K cycles in chains of dependent scalar loads (kernel arguments -> job record -> pointers -> row tables,
