@@ -783,8 +783,8 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     const ReduceSeg& S = a.seg[blockIdx.x >= (unsigned)a.seg[1].block0 ? 1 : 0];
     const float inv = a.gs_dev ? a.gs_dev[1] : a.inv_gs;
     if (S.vec == 1) {
-        // at most 16 slices (the dense partials): thread = four consecutive outputs, all slices' 16-byte loads in flight together, summed in fixed
-        // order (pairs, pairs of pairs, ...).  That form spent a 512-thread workgroup, a barrier and an LDS
+        // at most 16 slices (the dense partials): thread = four consecutive outputs, all slices' 16-byte loads in flight together, summed in the
+        // scalar form's order (the same bits).  That form spent a 512-thread workgroup, a barrier and an LDS
         // round trip on 64 outputs of 8 loads each: 2763 of this launch's 3020 workgroups.
         const int i = 4 * ((blockIdx.x - S.block0) * 512 + threadIdx.y * 64 + threadIdx.x);      // block-uniform branch; slices start on 128-byte lines
         if (i >= S.n) return;
@@ -796,8 +796,11 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
             else { v[k] = f32x4{p[0], i + 1 < S.n ? p[1] : 0.f, i + 2 < S.n ? p[2] : 0.f, 0.f}; }
             if (k >= S.slices) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const f32x4 g4 = ((((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-                          (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])))) * inv;
+        // the scalar form's order (the phased backward of the several-GPU path reduces through it and must give the same bits): slice group g =
+        // slices g, g + 8 in turn, then the groups pairwise
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] + v[k + 8];
+        const f32x4 g4 = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * inv;
         reduce_finish4(a, S, i, g4);
         return;
     }
