@@ -51,6 +51,11 @@ DQ_STAMP_READER(dq_dbg_read_fwd)
                                    // conflicts -59 %, LDS-active cycles -24 %, VALU +12 %, kernel +1.7 us -- off; 0: rows padded by 8 halves
 #endif
 #define A1_PS (CONV_SWZ ? 64 : 72)  // halves per a1 pixel row in LDS
+#ifndef CONV1_PIPE
+#define CONV1_PIPE 0               // persistent conv forward, EXPERIMENT (measured neutral): 1 = the first convolution software-pipelined across tiles (tile
+                                   // t + 4's MFMAs in one basic block with tile t's epilogue; a1 planes hold whole tiles, rows past the end are stored too), 2 = the same
+                                   // with sched_group_barrier interleaving (one MFMA, six VALU, one LDS read, ...)
+#endif
 #ifndef DQ_EXP_NODROP
 #define DQ_EXP_NODROP 0
 #endif
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     const int in_bytes = a.C * a.H * a.W;
     constexpr int NH1 = (KG1 + 1) / 2;                              // first convolution's K in halves of 32
     const int r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
-    const int lo1 = a.S * r1 * 64, lo2 = a.S * r2 * 40;             // halves from an h plane to its l plane
+    const int lo1 = (CONV1_PIPE ? (a.S * r1 + 15) & ~15 : a.S * r1) * 64, lo2 = a.S * r2 * 40;      // halves from an h plane to its l plane (CONV1_PIPE: whole 16-row tiles)
     const int total = a.total_groups, gstride = (int)gridDim.x;
     auto job_of = [&](int g) { return (g >= a.wg_first[1]) + (g >= a.wg_first[2]) + (g >= a.wg_first[3]); };     // block-uniform
 
@@ -602,6 +607,72 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
             };
             u32 abA[NH1][8], abB[NH1][8];
             const int w1 = wv;                                      // (tiles to the waves in reverse order -- the odd 13th tile to the wave the last convolution leaves idle -- measured: +0.4 us)
+#if CONV1_PIPE
+            // software pipeline across the wave's tiles: bytes two tiles ahead, MFMAs one tile ahead, epilogue of the current tile -- the MFMAs of tile
+            // t + 4 and the epilogue of tile t are independent and sit in ONE basic block (no row guards: the planes hold whole tiles)
+            auto mma = [&](const u32 (&ab)[NH1][8], f32x4 (&acc)[4], f32x4 (&accl)[4]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[t] = acc[t]; }
+#pragma unroll
+                for (int h = 0; h < NH1; ++h) {
+                    u32x4 av;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) av[e >> 1] = __umul24(ab[h][e] | (ab[h][e + 1] << 16), 0x3c00u);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = MFMA_F16(av, wb[0][h][t], acc[t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accl[t] = MFMA_F16(av, wb[1][h][t], accl[t]);
+                }
+            };
+            auto epi = [&](int tile, const f32x4 (&acc)[4], const f32x4 (&accl)[4]) {
+                f32x4 vs[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) vs[t] = f16x2_sum(acc[t], accl[t]) + f32x4{bias1[t], bias1[t], bias1[t], bias1[t]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mo = tile * 16 + 4 * kq + r;
+                    f32x4 v;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = relu1(vs[t][r]);
+                    u32 hp[2], lp[2];
+                    split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
+                    split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
+                    unsigned short* dst = s_a1 + mo * 64 + 4 * j;
+                    *reinterpret_cast<uint2*>(dst) = uint2{hp[0], hp[1]};
+                    *reinterpret_cast<uint2*>(dst + lo1) = uint2{lp[0], lp[1]};
+                }
+            };
+            auto interleave = [&]() {
+#if CONV1_PIPE == 2
+                // 16 MFMAs, ~110 VALU, 17 LDS reads, 8 LDS writes in the block: one MFMA, then what fits into its shadow
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                    if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+                }
+#endif
+            };
+            if (w1 < tiles) {
+                f32x4 accA[4], acclA[4], accB[4], acclB[4];
+                int tile = w1;
+                rd(origin(tile), abA);
+                rd(origin(tile + CONV_WAVES), abB);
+                int orgN = origin(tile + 2 * CONV_WAVES);
+                mma(abA, accA, acclA);
+                for (;;) {
+                    if (tile + CONV_WAVES >= tiles) { epi(tile, accA, acclA); break; }
+                    rd(orgN, abA); orgN = origin(tile + 3 * CONV_WAVES);
+                    mma(abB, accB, acclB); epi(tile, accA, acclA); interleave();
+                    tile += CONV_WAVES;
+                    if (tile + CONV_WAVES >= tiles) { epi(tile, accB, acclB); break; }
+                    rd(orgN, abB); orgN = origin(tile + 3 * CONV_WAVES);
+                    mma(abA, accA, acclA); epi(tile, accB, acclB); interleave();
+                    tile += CONV_WAVES;
+                }
+            }
+#else
             if (w1 < tiles) {
                 int orgB = origin(w1 + CONV_WAVES), orgA;
                 rd(origin(w1), abA);
@@ -610,6 +681,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
                     rd(orgA, abA); orgB = origin(tile + 2 * CONV_WAVES); tile_out(tile, abB); tile += CONV_WAVES; if (tile >= tiles) break;
                 }
             }
+#endif
         }
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 3);
         // ---- convolutions 2 and 3 ----------------------------------------------------------------------------------------------------
@@ -1195,7 +1267,7 @@ static bool plan_conv_persist(const dq_qnet* Q, ConvPlanP* P) {
             size_t core = a2b > obs ? a2b - obs : 0;
             if (core < t1b) core = t1b;
             size_t off = 2 * obs + core;
-            const size_t a1 = off; off += up16((size_t)2 * S * L1.rows * 64 * 2);
+            const size_t a1 = off; off += up16((size_t)2 * (CONV1_PIPE ? (S * L1.rows + 15) & ~15 : S * L1.rows) * 64 * 2);
             const size_t mis = off; off += 2 * 16 * 4;
             if (off <= budget && S * L1.rows <= CONV_ROWTAB) {
                 P->S = S; P->slot = base.slot; P->off_t1 = (int)obs; P->off_obs1 = (int)(obs + core); P->off_a2b = (int)(2 * obs + core - a2b);
