@@ -45,8 +45,9 @@ def pmc_traffic(kernel, mode="loop", config="c3"):
             rec = json.load(f)
         if rec.get("csrc_sha256") != csrc_digest():
             return None
-        ks = rec["kernels"]                      # (the conv forward's persistent form reports as conv_chain_pkernel)
-        return (ks.get(kernel) or ks[kernel.replace("_kernel", "_pkernel")])["hbm_bytes_per_launch_corrected"]
+        ks = rec["kernels"]                      # (the conv forward's persistent form -- the step's launch -- reports as conv_chain_pkernel; the
+        alt = kernel.replace("_kernel", "_pkernel")   #  one-group kernel of the same pass only ran the few small launches at start-up)
+        return (ks[alt] if alt in ks else ks[kernel])["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         return None
 
