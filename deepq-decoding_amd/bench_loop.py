@@ -66,7 +66,10 @@ class FullLoop:
         self.core = DQNCore(self.env, self.net, batch_size=minibatch, memory_limit=replay_transitions, gamma=0.99, lr=lr,
                             rank=rank, world_size=world)
         self.core.reset_env()
-        for _ in range(32 if mode == "learn" else 4):      # a few transitions before the first update
+        # untimed set-up: the replay ring is FILLED by acting (keras-rl's nb_steps_warmup phase: transitions are collected before learning
+        # starts), so that every update of the warm-up and of the timed region samples a full memory -- 2^20 transitions spread over the whole
+        # 0.9 GB ring, as in training -- instead of the handful of slots a cold start holds
+        for _ in range(max(4, self.core.T - 1)):
             self.core.act_and_step(self.eps)
         self.layer_macs = self._layer_macs()
         self.macs = sum(self.layer_macs)
