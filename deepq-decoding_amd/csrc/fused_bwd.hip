@@ -1608,8 +1608,9 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         ra.inv_gs = Q->bwd_scale > 0.f ? 1.f / Q->bwd_scale : 0.f; ra.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
         ra.range_flag = reinterpret_cast<unsigned*>(gs_slot) + 2;
         ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, dense_pstride(Q), 0, (int)conv_floats};
+        ra.seg[0].vec = sy <= 16 && (conv_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(grads_dev) & 15) == 0;      // (the vector path: same bits, see the kernel)
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
-        reduce_slices_kernel<<<(n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
+        reduce_slices_kernel<<<ra.seg[0].vec ? (n_dense + 2047) / 2048 : (n_dense + 63) / 64, dim3(64, 8), 0, st>>>(ra);
         DQ_LAUNCH_CHECK();
     }
     }
