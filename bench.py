@@ -273,6 +273,7 @@ def main():
         runner.arm(args.steps)          # ... that family's launches in the timed region are bracketed by HIP events
     if (world > 1 or force_dist) and hasattr(runner, "core"):
         runner.core.ar_events = []      # HIP events around the exposed part of the gradient all-reduce, inside the timed loop
+        runner.core.ar_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + 8)]
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -356,8 +357,13 @@ def allreduce_probe(torch, dist, core, backend, iters=20):
     stream around blocking-semantics collectives (the stream waits for the communicator's stream)."""
     nconv = core.net.n_conv_params
     parts = {"dense": core.grads[nconv:].clone(), "conv": core.grads[:nconv].clone()}
-    out = {"backend": "rccl" if backend == "nccl" else backend, "per_step": "dense range asynchronous behind the convolutional backward, "
-           "convolutional range on the critical path"}
+    mode = os.environ.get("DQ_DIST_MODE", "single")
+    native = getattr(core, "_rccl", None) is not None
+    out = {"backend": "rccl" if backend == "nccl" else backend,
+           "per_step": ("one all-reduce of the whole flat gradient behind the backward, " + ("on the step's own stream through the learner's RCCL communicator"
+                        if native else "through torch.distributed")) if mode == "single" else
+                       "dense range asynchronous behind the convolutional backward, convolutional range on the critical path (DQ_DIST_MODE=split)",
+           "in_stream_rccl": native}
     for name, buf in parts.items():
         for _ in range(3):
             dist.all_reduce(buf)

@@ -41,6 +41,7 @@ class DQNCore:
         self.enable_double_dqn = enable_double_dqn
         self.seed = tuple(env.seed) if seed is None else tuple(seed)
         self.rank, self.world_size, self.pg = rank, world_size, process_group
+        self._rccl, self._rccl_tried = None, False       # the learner's own RCCL communicator (dist.make_rccl), created at the first several-GPU update
         self.L = _lib.lib()
         dev = self.device
         # ring
@@ -90,6 +91,7 @@ class DQNCore:
         self.inexact_total = 0
         self._inexact_acc = torch.zeros((), dtype=torch.int64, device=dev) if getattr(env, "wide", False) else None
         self.ar_events = None        # bench.py: a list here collects HIP-event pairs around the exposed part of the gradient all-reduce
+        self.ar_pool = []            # ... taken from this pool of pre-created pairs (creating two timing events per step costs host time inside the timed region)
         self._e_fwd, self._e_env = torch.cuda.Event(), torch.cuda.Event()
         self._env_inflight = False
 
@@ -250,7 +252,30 @@ class DQNCore:
             self._stats_pending = None
         td = self._td_job(step_stats)
         self._metrics_stale = True
-        if _dist.dist_path(self.world_size):
+        if _dist.dist_path(self.world_size) and os.environ.get("DQ_DIST_MODE", "single") == "single":
+            # ONE all-reduce of the whole flat gradient behind the backward, on THIS stream through the learner's own RCCL communicator
+            # (dist.RcclComm; through torch.distributed for gloo groups): the communicator-stream hand-offs of the split form below cost
+            # more on a one-rank measurement than the 0.7 MB they hide
+            if ride is not None:
+                net.td_backward_phase0_env(self.params, td, self.grads, self.env._h, ride)
+            else:
+                net.td_backward_phase0(self.params, td, self.grads)
+            net.backward_phase(self.params, self.dq, self.grads, 1)
+            if self.ar_events is not None:
+                e0, e1 = self.ar_pool.pop() if self.ar_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                e0.record()
+            if self._rccl is None and not self._rccl_tried:
+                self._rccl_tried = True
+                self._rccl = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
+            if self._rccl is not None:
+                self._rccl.allreduce_sum_(self.grads)
+            else:
+                _dist.allreduce_sum_(self.grads, group=self.pg)
+            if self.ar_events is not None:
+                e1.record()
+                self.ar_events.append((e0, e1))
+            _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+        elif _dist.dist_path(self.world_size):
             # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs
             nconv = net.n_conv_params
             if ride is not None:
@@ -261,7 +286,7 @@ class DQNCore:
             net.backward_phase(self.params, self.dq, self.grads, 1)
             # what the step WAITS for: the convolutional range's all-reduce (critical path) + whatever is left of the dense range's
             if self.ar_events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = self.ar_pool.pop() if self.ar_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e0.record()
             _dist.allreduce_sum_(self.grads[:nconv], group=self.pg)
             if work is not None:

@@ -77,3 +77,68 @@ def broadcast_(flat, src=0, group=None):
     if _active(group):
         dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+# ---- RCCL on the caller's stream ---------------------------------------------------------------------------------------------------
+class RcclComm:
+    """A RCCL communicator of this build's own (librccl through ctypes), used for the one collective of the learner's hot path: the in-place
+    sum of the flat fp32 gradient, enqueued ON THE CALLER'S STREAM between the backward's final reduction and the Adam kernel -- one more
+    launch in the step's stream, no host synchronisation, no hand-off to a communicator stream.  (torch.distributed's RCCL collectives run on
+    the process group's internal stream: every call orders that stream behind the current one and the current one behind it again with
+    events, and costs ~30 us of host time; measured on a one-rank group, DESIGN.md section 7: the step's several-GPU branch 226 us with the
+    dense range all-reduced asynchronously through torch.distributed, 195-208 us with one synchronous torch.distributed all-reduce.)
+    torch.distributed still does the rendezvous: rank 0's ncclUniqueId travels through the default process group."""
+
+    class _UniqueId(__import__("ctypes").Structure):
+        _fields_ = [("internal", __import__("ctypes").c_char * 128)]
+
+    def __init__(self, rank, world, device, group=None):
+        import ctypes
+        libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+        path = os.path.join(libdir, "librccl.so")
+        self.lib = ctypes.CDLL(path if os.path.exists(path) else "librccl.so")       # the library torch itself is linked against
+        L = self.lib
+        L.ncclGetErrorString.restype = ctypes.c_char_p
+        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(self._UniqueId)]
+        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
+        L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        uid = self._UniqueId()
+        if rank == 0:
+            self._check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        if world > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.frombuffer(bytearray(bytes(uid.internal) if rank == 0 else bytes(128)), dtype=torch.uint8).clone()
+            t = t.to(self.device) if on_gpu else t
+            dist.broadcast(t, src=0, group=group)
+            ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        self.comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(L.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.ncclGetErrorString(rc).decode()} (rank {self.rank})")
+
+    def allreduce_sum_(self, flat):
+        """In-place float32 sum over the ranks, enqueued on the current stream of `flat`'s device."""
+        assert flat.dtype == torch.float32 and flat.is_cuda and flat.is_contiguous()
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        self._check(self.lib.ncclAllReduce(flat.data_ptr(), flat.data_ptr(), flat.numel(), 7, 0, self.comm, stream), "ncclAllReduce")   # ncclFloat32, ncclSum
+        return flat
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def make_rccl(rank, world, device, group=None):
+    """The learner's own communicator when the process group runs on RCCL (or DQ_DIST_FORCE drives the several-GPU branch on one GPU);
+    None for gloo groups (CPU tests, DQ_DIST_BACKEND=gloo) and when DQ_DIST_NATIVE=0."""
+    if os.environ.get("DQ_DIST_NATIVE", "1") == "0" or not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
+        return None
+    return RcclComm(rank, world, device, group)

@@ -36,20 +36,25 @@ def test_bench_self_launches_two_ranks_that_stay_identical():
 @pytest.mark.gpu
 def test_one_rank_rccl_group_drives_the_several_gpu_branch():
     """The several-GPU learner branch through the REAL backend on the one-GPU box: DQ_DIST_FORCE=1 makes bench.py create a one-rank RCCL
-    process group and DQNCore take the split backward (dense gradient all-reduced asynchronously on the communicator's stream behind the
-    convolutional backward, convolutional range on the critical path, separate Adam launch).  With one rank the sum is the identity, so
-    the parameters after the run must be the bits the one-GPU branch (Adam fused on the reduction) leaves."""
+    process group and DQNCore take its several-GPU branch -- split backward without the fused optimizer step, the flat gradient summed over the
+    ranks, separate Adam launch -- in each of its three forms: the default (ONE all-reduce on the step's own stream through the learner's own
+    RCCL communicator, dist.RcclComm), the same through torch.distributed (DQ_DIST_NATIVE=0), and the split form (DQ_DIST_MODE=split: dense
+    range asynchronously on the process group's stream behind the convolutional backward, convolutional range on the critical path).  With
+    one rank the sum is the identity, so the parameters after the run must be the bits the one-GPU branch (Adam fused on the reduction) leaves."""
     def run(**extra):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4", "--no-cpu-baseline"]
         r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(**extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
-    forced, plain = run(DQ_DIST_FORCE="1"), run()
-    assert forced["rccl_ranks"] == 1 and forced["dist_backend"] == "rccl" and forced["replicas_identical"] is True
-    ar = forced["allreduce"]
-    assert ar["backend"] == "rccl" and ar["dense_us"] > 0 and ar["conv_us"] > 0
+    plain = run()
     assert "rccl_ranks" not in plain
-    assert forced["params_checksum"] == plain["params_checksum"]
+    for extra, native, word in ((dict(), True, "own stream"), (dict(DQ_DIST_NATIVE="0"), False, "torch.distributed"), (dict(DQ_DIST_MODE="split"), False, "asynchronous")):
+        forced = run(DQ_DIST_FORCE="1", **extra)
+        assert forced["rccl_ranks"] == 1 and forced["dist_backend"] == "rccl" and forced["replicas_identical"] is True
+        ar = forced["allreduce"]
+        assert ar["backend"] == "rccl" and ar["dense_us"] > 0 and ar["conv_us"] > 0 and ar["exposed_us_per_step"] > 0
+        assert ar["in_stream_rccl"] is native and word in ar["per_step"], ar
+        assert forced["params_checksum"] == plain["params_checksum"], extra
 
 
 @pytest.mark.gpu
