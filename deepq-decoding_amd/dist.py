@@ -141,4 +141,17 @@ def make_rccl(rank, world, device, group=None):
         return None
     if dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
         return None
-    return RcclComm(rank, world, device, group)
+    comm = None
+    try:
+        comm = RcclComm(rank, world, device, group)
+    except (OSError, RuntimeError, AttributeError) as e:            # library or communicator unavailable here: the ranks agree on the fallback below
+        import warnings
+        warnings.warn(f"no RCCL communicator of our own ({e}); the gradient all-reduce goes through torch.distributed")
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)     # every rank takes the same path
+    if int(ok.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None
+    return comm
