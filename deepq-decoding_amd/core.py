@@ -256,11 +256,10 @@ class DQNCore:
             # ONE all-reduce of the whole flat gradient behind the backward, on THIS stream through the learner's own RCCL communicator
             # (dist.RcclComm; through torch.distributed for gloo groups): the communicator-stream hand-offs of the split form below cost
             # more on a one-rank measurement than the 0.7 MB they hide
-            if ride is not None:
-                net.td_backward_phase0_env(self.params, td, self.grads, self.env._h, ride)
+            if ride is not None:                          # the whole backward, gradient only (m = v = None): no optimizer step on the reduction
+                net.td_backward_adam_env(self.params, td, self.grads, None, None, t, self.lr, self.beta_1, self.beta_2, self.epsilon, self.env._h, ride)
             else:
-                net.td_backward_phase0(self.params, td, self.grads)
-            net.backward_phase(self.params, self.dq, self.grads, 1)
+                net.td_backward_adam(self.params, td, self.grads, None, None, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
             if self.ar_events is not None:
                 e0, e1 = self.ar_pool.pop() if self.ar_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e0.record()

@@ -669,7 +669,8 @@ static dq_status separate_td(const dq_td_job* tdj, void* stream) {
 static dq_status backward_adam(dq_qnet* Q, float* params_dev, const float* dq_dev, const dq_td_job* tdj, float* grads_dev, float* m_dev,
                                float* v_dev, double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream,
                                const EnvParams* rider = nullptr, size_t rider_lds = 0) {
-    DQ_REQUIRE(Q && params_dev && (dq_dev || tdj) && grads_dev && m_dev && v_dev, DQ_ERR_INVALID, "dq_qnet_backward_adam: null argument");
+    const bool no_opt = !m_dev && !v_dev;                           // gradient only (the several-GPU path: the all-reduce comes between backward and Adam)
+    DQ_REQUIRE(Q && params_dev && (dq_dev || tdj) && grads_dev && (no_opt || (m_dev && v_dev)), DQ_ERR_INVALID, "dq_qnet_backward_adam: null argument");
     DQ_REQUIRE(t >= 1, DQ_ERR_INVALID, "dq_qnet_backward_adam: t counts from 1");
     DQ_REQUIRE(Q->last_train_batch > 0, DQ_ERR_STATE, "dq_qnet_backward_adam: no training forward to differentiate");
     if (tdj) {
@@ -684,7 +685,7 @@ static dq_status backward_adam(dq_qnet* Q, float* params_dev, const float* dq_de
         opt.b1 = (float)beta_1; opt.b2 = (float)beta_2; opt.eps = (float)epsilon;
         TdFused td;
         if (tdj) td = td_fused_from(tdj);
-        return fused_backward(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream, &opt, tdj ? &td : nullptr, rider, rider_lds);
+        return fused_backward(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream, no_opt ? nullptr : &opt, tdj ? &td : nullptr, rider, rider_lds);
     }
     DQ_REQUIRE(!rider, DQ_ERR_UNSUPPORTED, "dq_qnet_td_backward_adam_env: only the fused chains carry the environment step");
     if (tdj) {                                                      // per-layer path: the separate launches
@@ -693,7 +694,7 @@ static dq_status backward_adam(dq_qnet* Q, float* params_dev, const float* dq_de
         dq_dev = tdj->dq_dev;
     }
     dq_status rc = backward_phases(Q, params_dev, dq_dev, grads_dev, 3, (hipStream_t)stream);
-    if (rc != DQ_OK) return rc;
+    if (rc != DQ_OK || no_opt) return rc;
     return dq_adam_step(params_dev, grads_dev, m_dev, v_dev, Q->n_params, lr, beta_1, beta_2, epsilon, t, stream);
 }
 

@@ -392,7 +392,10 @@ dq_status dq_test_bookkeeping(const uint8_t* done_dev, const uint8_t* was_reset_
 /* The learner half of one DQNAgent.backward in the fewest launches: dq_td_update (+ dq_episode_stats when n > 0) computed in the
  * dense backward's first kernel, then dq_qnet_backward, then dq_adam_step on the final reduction.  Same y / dq / gradient / parameter
  * bits as the separate calls; the loss / mean_q partials are summed in a different order (dq_td_metrics reads them the same way).
- * y_dev, dq_dev (needed only by the per-layer path), metrics_dev nullable. */
+ * y_dev, dq_dev (needed only by the per-layer path), metrics_dev nullable.
+ * m_dev == v_dev == NULL (dq_qnet_td_backward_adam, _adam_env, dq_qnet_backward_adam): the gradient only, no optimizer step -- the several-GPU
+ * path, where the all-reduce of grads_dev comes between the backward and dq_adam_step (one final reduction launch instead of the two of the
+ * phase calls). */
 typedef struct dq_td_job {
     const float* q_online_s1_dev;
     const float* q_target_s1_dev;
