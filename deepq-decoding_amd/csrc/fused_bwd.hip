@@ -238,7 +238,8 @@ __device__ __forceinline__ void gh1_phase(const DenseBwdArgs& a, const unsigned 
     }
 }
 
-template <int NT2>                      // N2 <= 16*NT2 and N3 <= 16*NT2
+template <int NT2, bool TD>             // N2 <= 16*NT2 and N3 <= 16*NT2; TD: the TD step in the prologue (a compile-time switch: around loads a run-time one
+                                        // is a branch whose merge hipcc guards with s_waitcnt vmcnt(0) -- every preload below was waited for at once)
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(DenseBwdArgs a, EnvParams env) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     // The vector step's environment launch does not feed this update (the minibatch never holds the newest transition, common.h
@@ -272,49 +273,14 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     DQ_STAMP(DQ_TAG_DENSE_BWD, 0);
     constexpr int RPW = DENSE_ROWS / DENSE_WAVES;                   // rows per wave (2): their loads are issued together
     static_assert(RPW == 2, "two rows per wave");
-    // ---- the TD step's replay rows first: everything else it reads hangs on them, and their latency hides under the start-up below ----
-    int ridx[RPW] = {0, 0};
-    if (a.td_on) {
-#pragma unroll
-        for (int u = 0; u < RPW; ++u) {
-            const int b = b0 + min(wave + DENSE_WAVES * u, ns - 1);
-            ridx[u] = a.td.index ? a.td.index[b] : b;
-        }
-    }
-    // ---- requested now, used two / three phases later: Dense(|A|+1)'s kernel for gY2, gH1's first weight block and mask operand --------
-    float w3b[NT2][4];
-    if (N3 > 0 && wave < NT2) {
-        const float* w3 = a.params + a.w_off[2];
-        const int n2 = 16 * wave + j;
-#pragma unroll
-        for (int g = 0; g < NT2; ++g)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k3 = 16 * g + 4 * kq + s;
-                w3b[g][s] = (n2 < N2 && k3 < N3) ? w3[(size_t)n2 * N3 + k3] : 0.f;
-            }
-    }
-    Gh1Pre gh1_pre;
-    gh1_preload(a, b0, wave, lane, gh1_pre);
-    __builtin_amdgcn_sched_barrier(0);                              // (hipcc sinks a load next to its use: these stay up here)
-    __shared__ float s_met[DENSE_WAVES][2];
-    for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) s_g3[i] = 0.f;
-    for (int i = tid; i < DENSE_ROWS * LDY; i += DENSE_THREADS) reinterpret_cast<u32*>(s_gy2p)[i] = 0u;      // both planes (2 x 16 x LDY halves)
-    __syncthreads();
-    DQ_STAMP(DQ_TAG_DENSE_BWD, 6);
-    // ---- (TD step: y = r + gamma (1 - terminal) Q_target(s1)[argmax Q_online(s1)], dq = (Q(s0)[a] - y) * scale at the action taken,
-    //      dqn.hip td_update_kernel's arithmetic, one wave per sample) then the dueling backward:
-    //      g3[b,0] = sum_a dq[b,a];  g3[b,1+a] = dq[b,a] - (1/A) sum_a' dq[b,a'] ---------------------------------------------
+    // ---- the TD step's three Q rows of this wave's two samples do not hang on the replay rows: requested first of all (round 3, second pass:
+    //      they used to go out behind the first barrier, a round trip of their own) ----
     float loss = 0.f, mq = 0.f;
     float yb[RPW] = {0.f, 0.f}, qv[RPW][2] = {{0.f, 0.f}, {0.f, 0.f}};
     int a_b[RPW] = {-1, -1};
-    if (a.td_on) {
-        // ONE load stage (round 3; before: Q_target(s1)[a*] was fetched behind the arg-max and the replay-row fields behind the row
-        // number -- two dependent round trips of 3K and 6K cycles in the loop, where 512 workgroups start at once): the row numbers were
-        // requested at the top of the kernel, so reward / terminal / action go out together with the three Q rows; Q_target(s1) comes as the
-        // whole row and its a*-th entry is picked by a shuffle, like Q(s0)[a].
-        float q1[RPW][2], q1t[RPW][2], rw[RPW], qt[RPW];
-        int term[RPW];
+    float q1[RPW][2] = {{0.f, 0.f}, {0.f, 0.f}}, q1t[RPW][2] = {{0.f, 0.f}, {0.f, 0.f}}, rw[RPW] = {0.f, 0.f};
+    int term[RPW] = {0, 0};
+    if constexpr (TD) {
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
             const int b = b0 + min(wave + DENSE_WAVES * u, ns - 1);
@@ -326,10 +292,64 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
                 q1t[u][h] = a.td.q1t[(size_t)b * A + (ok ? c : 0)];
                 qv[u][h] = a.td.q0[(size_t)b * A + (ok ? c : 0)];
             }
-            rw[u] = a.td.reward[ridx[u]];
-            term[u] = a.td.terminal[ridx[u]];
-            a_b[u] = a.td.action[ridx[u]];
         }
+    }
+    // ---- requested now, used two / three phases later: Dense(|A|+1)'s kernel for gY2, gH1's first weight block and mask operand --------
+    float w3b[NT2][4];
+    if (wave < NT2) {
+        // (every wave, unconditional loads at clamped addresses -- waves >= NT2 and networks without a dueling layer read valid parameters they
+        // never use --, masked where they are used: a condition around a load is a branch with its own s_waitcnt)
+        const float* w3 = a.params + a.w_off[2];
+        const int n2 = 16 * min(wave, NT2 - 1) + j;
+#pragma unroll
+        for (int g = 0; g < NT2; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k3 = 16 * g + 4 * kq + s;
+                w3b[g][s] = w3[(size_t)min(n2, N2 - 1) * N3 + max(min(k3, N3 - 1), 0)];
+            }
+    }
+    Gh1Pre gh1_pre;
+    gh1_preload(a, b0, wave, lane, gh1_pre);
+    __builtin_amdgcn_sched_barrier(0);                              // (hipcc sinks a load next to its use: these stay up here)
+    // (wave-uniform rows: SCALAR loads through the constant address space -- the index vector is not written while this kernel runs, the
+    // riders draw the next update's rows into the other buffer (core.py) --, both addresses formed first so that the two loads go out together,
+    // unconditional at a clamped address and selected at the use, BEHIND the vector preloads above and in front of the LDS clearing and the
+    // barrier that cover their latency: as `index ? index[b] : b` each was a vector load in a branch of its own with s_waitcnt vmcnt(0) behind
+    // it, two serialised round trips = 4K of the 5.4K cycles this workgroup spent in front of its first barrier)
+    int ridx[RPW] = {0, 0};
+    if constexpr (TD) {
+        const bool has_index = a.td.index != nullptr;
+        const __attribute__((address_space(4))) int32_t* ip =
+            (const __attribute__((address_space(4))) int32_t*)(uintptr_t)(has_index ? (const void*)a.td.index : (const void*)a.params);
+        const __attribute__((address_space(4))) int32_t* p0 = ip + (has_index ? b0 + min(wave, ns - 1) : 0);
+        const __attribute__((address_space(4))) int32_t* p1 = ip + (has_index ? b0 + min(wave + DENSE_WAVES, ns - 1) : 0);
+        asm volatile("" : "+s"(p0), "+s"(p1));
+        ridx[0] = *p0; ridx[1] = *p1;
+    }
+    __shared__ float s_met[DENSE_WAVES][2];
+    for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) s_g3[i] = 0.f;
+    for (int i = tid; i < DENSE_ROWS * LDY; i += DENSE_THREADS) reinterpret_cast<u32*>(s_gy2p)[i] = 0u;      // both planes (2 x 16 x LDY halves)
+    if constexpr (TD) {                                             // the replay rows' fields: in flight across the barrier
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int rr = a.td.index ? ridx[u] : b0 + min(wave + DENSE_WAVES * u, ns - 1);
+            rw[u] = a.td.reward[rr];
+            term[u] = a.td.terminal[rr];
+            a_b[u] = a.td.action[rr];
+        }
+    }
+    __syncthreads();
+    DQ_STAMP(DQ_TAG_DENSE_BWD, 6);
+    // ---- (TD step: y = r + gamma (1 - terminal) Q_target(s1)[argmax Q_online(s1)], dq = (Q(s0)[a] - y) * scale at the action taken,
+    //      dqn.hip td_update_kernel's arithmetic, one wave per sample) then the dueling backward:
+    //      g3[b,0] = sum_a dq[b,a];  g3[b,1+a] = dq[b,a] - (1/A) sum_a' dq[b,a'] ---------------------------------------------
+    if constexpr (TD) {
+        // No load stage of its own any more (round 3: the Q rows are requested at the top of the kernel, the replay rows behind the preloads and
+        // their fields in front of the barrier above; before: Q_target(s1)[a*] was fetched behind the arg-max and the replay-row fields behind
+        // the row number -- dependent round trips of 3K and 6K cycles in the loop, where 768 workgroups start at once); Q_target(s1) comes as the
+        // whole row and its a*-th entry is picked by a shuffle, like Q(s0)[a].
+        float qt[RPW];
         DQ_STAMP(DQ_TAG_DENSE_BWD, 7);
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
@@ -377,32 +397,37 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         const float* dr = a.dq + (size_t)b * A;
         auto dval = [&](int h) {                                    // dq[b][lane + 64 h]
             const int c = lane + 64 * h;
-            return a.td_on ? (c == a_b[u] ? (qv[u][h] - yb[u]) * a.td.grad_scale * GS : 0.f) : dr[c] * GS;
+            return TD ? (c == a_b[u] ? (qv[u][h] - yb[u]) * a.td.grad_scale * GS : 0.f) : dr[c] * GS;
         };
         if (N3 > 0) {
             float s = 0.f;
-            if (a.td_on) {                                              // one non-zero per row: its sum is that value (the butterfly's bits: x + 0 ... + 0)
+            if constexpr (TD) {                                         // one non-zero per row: its sum is that value (the butterfly's bits: x + 0 ... + 0)
                 const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
                 const float qa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ab < 64 ? qv[u][0] : qv[u][1]), ab & 63));
                 s = (unsigned)ab < (unsigned)A ? (qa - yb[u]) * a.td.grad_scale * GS : 0.f;
             } else {
-                for (int h = 0; lane + 64 * h < A; ++h) s += dval(h);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) if (lane + 64 * h < A) s += dval(h);      // (a run-time trip count would index qv dynamically: scratch memory)
                 for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
             }
             unsigned short* p3 = a.g3_pl + (size_t)b * a.small_ld;   // the same values as pieces: the dueling layer's weight gradient
             const size_t lo3 = (size_t)a.plane_rows * a.small_ld;
             unsigned short ph, pl;
             if (lane == 0) { s_g3[row * ldg] = s; split_f16x2_one(s, ph, pl); p3[0] = ph; p3[lo3] = pl; }
-            for (int h = 0; lane + 64 * h < A; ++h) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
+                if (c >= A) continue;
                 const float v = dval(h) - s / (float)A;
                 s_g3[row * ldg + 1 + c] = v;
                 split_f16x2_one(v, ph, pl);
                 p3[1 + c] = ph; p3[lo3 + 1 + c] = pl;
             }
         } else {
-            for (int h = 0; lane + 64 * h < A; ++h) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
+                if (c >= A) continue;
                 const float v = dval(h);
                 const _Float16 vh = (_Float16)v, vl = (_Float16)((v - (float)vh) * F16_LO_SCALE);
                 s_gy2p[row * LDY + c] = __builtin_bit_cast(unsigned short, vh);
@@ -411,9 +436,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 9);
-    if (a.td_on && lane == 0) { s_met[wave][0] = loss; s_met[wave][1] = mq; }
+    if (TD && lane == 0) { s_met[wave][0] = loss; s_met[wave][1] = mq; }
     __syncthreads();
-    if (a.td_on && a.td.metrics && tid == 0) {                      // this workgroup's partial, and zeros in the slots nobody owns
+    if (TD && a.td.metrics && tid == 0) {                      // this workgroup's partial, and zeros in the slots nobody owns
         float l = 0.f, q = 0.f;
         for (int w = 0; w < DENSE_WAVES; ++w) { l += s_met[w][0]; q += s_met[w][1]; }
         if (a.dense_wgs <= a.td.metric_slots) {
@@ -436,7 +461,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     if (N3 > 0) {
         if (wave < NT2) {
             const int n2 = 16 * wave + j;
-            float (&b)[NT2][4] = w3b;                               // (requested at the top of the kernel)
+            float (&b)[NT2][4] = w3b;                               // (requested at the top of the kernel, raw: masked here)
+#pragma unroll
+            for (int g = 0; g < NT2; ++g)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[g][s] = (n2 < N2 && 16 * g + 4 * kq + s < N3) ? b[g][s] : 0.f;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* grow = s_g3 + j * ldg + 4 * kq;
 #pragma unroll
@@ -1563,8 +1592,13 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     if (td && td->metrics && da.dense_wgs > td->metric_slots)      // (the partials are then summed by atomics, in any order: diagnostics only)
         DQ_HIP(hipMemsetAsync(td->metrics + 2, 0, (size_t)td->metric_slots * 2 * sizeof(float), st));
     dq_prof_begin(DQ_K_DENSE_BWD, st);
-    if (dp.NT2 == 4) dense_bwd_chain_kernel<4><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
-    else dense_bwd_chain_kernel<7><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
+    if (dp.NT2 == 4) {
+        if (td) dense_bwd_chain_kernel<4, true><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
+        else dense_bwd_chain_kernel<4, false><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
+    } else {
+        if (td) dense_bwd_chain_kernel<7, true><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
+        else dense_bwd_chain_kernel<7, false><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
+    }
     dq_prof_end(DQ_K_DENSE_BWD, st);
     DQ_LAUNCH_CHECK();
 
