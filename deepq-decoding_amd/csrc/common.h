@@ -281,6 +281,7 @@ __device__ __forceinline__ void dq_adam1(float& p, float g, float& m, float& v, 
 #define DQ_TAG_DENSE_BWD 3
 #define DQ_TAG_CONV_BWD 4
 #define DQ_TAG_DENSE_WGRAD 5
+#define DQ_TAG_ENV 6                     // env_block2 riding on the dense backward (fused_bwd.hip; build with -DDQ_STAMP_BLOCK=<a rider block>)
 #ifdef DQ_STAMPS
 #ifndef DQ_STAMP_BLOCK
 #define DQ_STAMP_BLOCK 9

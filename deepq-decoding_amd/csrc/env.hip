@@ -260,6 +260,7 @@ static void build_tables(dq_env* E) {
         if ((x & 1) && (y & 1) && ((x + y) % 4 == 0)) v = 1;
         T.cell_static[x * n + y] = v;
     }
+    for (int c = 0; c < 256; ++c) T.cell_pack[c] = (u32)T.cell_static[c] | (u32)T.cell_stab[c] << 8 | (u32)T.cell_qubit[c] << 16;
     // BFS generators: flipping component `comp` of qubit q toggles these referee-index bits (+ the logical bit)
     const int nh = n_stab / 2;
     for (int comp = 0; comp < 2; ++comp) {
@@ -589,6 +590,11 @@ static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = fals
     // vector step); the stand-alone launch measured 17.4 us one per wave against 17.8 us two per wave (fewer, longer waves)
     p.pair = rider && env_pairs(E) ? 1 : 0;
     if (p.pair) epb *= 2;
+    // the component referee tables go into LDS where they are small (d <= 5: 512 bytes each) and a step reads them
+    {
+        const size_t entries = (size_t)1 << (E->info.n_stab / 2), words = (entries + 31) / 32;
+        p.lut_words = (p.mode == 1 && E->lut_x && E->lut_z && !E->lut_joint && !E->lut_marker && !E->mlp_layers && words <= ENV_LUT_LDS_MAX) ? (int)words : 0;
+    }
     p.env_blocks = (p.n_envs + epb - 1) / epb;
     // the riding step's sampling is drawn by the lattices' own blocks when their threads cover the minibatch (env_dev.h env_inline_sampling)
     if (rider && p.s_batch > 0 && (long long)p.env_blocks * 512 >= p.s_batch) p.s_blocks = 0;
@@ -599,7 +605,7 @@ static dq_status launch_env(dq_env* E, EnvParams& p, hipStream_t st) {
     const dq_status rc = fill_common(E, p, ENVS_PER_BLOCK);
     if (rc != DQ_OK) return rc;
     dq_prof_begin(DQ_K_ENV, st);
-    env_kernel<<<p.env_blocks + p.s_blocks, 64 * ENVS_PER_BLOCK, env_block_lds((p.pair ? 2 : 1) * ENVS_PER_BLOCK, p.obs_size), st>>>(p);
+    env_kernel<<<p.env_blocks + p.s_blocks, 64 * ENVS_PER_BLOCK, env_block_lds((p.pair ? 2 : 1) * ENVS_PER_BLOCK, ENVS_PER_BLOCK, p.obs_size, p.lut_words), st>>>(p);
     dq_prof_end(DQ_K_ENV, st);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
@@ -732,6 +738,6 @@ dq_status env_fill_act_step(dq_env* E, const float* q_dev, double eps, int maske
     rc = fill_common(E, *p, 8, true);
     if (rc != DQ_OK) return rc;
     p->stats = reinterpret_cast<unsigned long long*>(stats_dev);
-    *lds = env_block_lds(p->pair ? 16 : 8, p->obs_size);
+    *lds = env_block_lds(p->pair ? 16 : 8, 8, p->obs_size, p->lut_words);
     return DQ_OK;
 }

@@ -4,6 +4,7 @@
 #include "common.h"
 
 #define DQ_MAX_DEPTH 16
+typedef u32 env_u32x4 __attribute__((ext_vector_type(4)));
 #define ENVS_PER_BLOCK 4
 #define STATE_FIXED 9      // internal record: xmask zmask acted round comp0 comp1 legal0 legal1 meta, then volume
 #define EXPORT_FIXED 11
@@ -18,6 +19,7 @@ struct EnvTables {
     u8 cell_static[256];   // padding_syndrome decoration (ENV:284-298)
     u8 cell_stab[256];     // stabilizer shown at an even-even cell (ENV:292-294), 255: none
     u8 cell_qubit[256];    // qubit shown at an odd-odd cell of an action plane (ENV:301-314), 255: none
+    u32 cell_pack[256];    // the three cell tables in one word: static | stab << 8 | qubit << 16 (a lane keeps its cells' words in registers)
     u64 col0, row0;        // FL:312-317
 };
 
@@ -58,6 +60,8 @@ struct EnvParams {
     const u8* dec_in;              // != NULL: the referee's class for each lattice's post-action syndrome, computed by a pre-pass
                                    // (env.hip referee_mlp_kernel: a Dense-stack `static_decoder` evaluated on the device, ENV:144)
     int pair;                      // 1: two lattices per wave (env_block2; d <= 5: qubits, stabilizers and record words all fit 32 lanes)
+    int lut_words;                 // > 0: lut_x / lut_z (this many words each; d <= 5: 128) are copied into LDS at the top of a block, so that the
+                                   // referee look-up behind the syndrome is an LDS read instead of a dependent round trip to L2
 };
 
 static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s) {
@@ -68,8 +72,16 @@ static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s)
 
 // One block of EPB lattices (64 * EPB threads, one lattice per wave); `block` = the block's number inside the environment part of the
 // grid (env_kernel: blockIdx.x; as a rider on another kernel's launch -- fused_bwd.hip -- the offset is subtracted by the caller).
-// LDS: env_block_lds(EPB, obs_size) bytes at `smem`.
-static inline size_t env_block_lds(int epb, int obs_size) { return (size_t)epb * DQ_MAX_DEPTH * 8 + 3 * 256 + (size_t)epb * ((obs_size + 3) & ~3); }
+// LDS: env_block_lds(EPB, waves, obs_size, lut_words) bytes at `smem`: [volumes | referee tables, one copy per wave | observation stage].
+// (the referee tables: one private copy per WAVE -- `waves` of them --, so that no barrier stands between the copy and the look-up; the stage starts
+// on a 16-byte boundary: it leaves by 16-byte stores where the block's rows in global memory are aligned that way)
+static inline size_t env_lut_lds(int lut_words) { return ((size_t)2 * lut_words * 4 + 15) & ~(size_t)15; }
+static inline size_t env_block_lds(int epb, int waves, int obs_size, int lut_words) {
+    return (size_t)epb * DQ_MAX_DEPTH * 8 + (size_t)waves * env_lut_lds(lut_words) + (((size_t)epb * obs_size + 15) & ~(size_t)15);
+}
+#define ENV_LUT_LDS_MAX 256             // words per table staged in LDS (1 KB: up to 13 stabilizers per type)
+#define ENV_CELLS 4                     // cells of an observation plane per lane: P <= 64 * 4 (one lattice per wave), P <= 32 * 4 (two per wave)
+#define ENV_QPRE 3                      // Q values per lane requested with the record: n_actions <= 64 * 3 / 32 * 3
 
 // Replay sampling by the lattices' own blocks, behind their step (s_blocks == 0): where the step rides on the dense backward, separate
 // sampling workgroups found no free wave slots (one dense + one environment workgroup fill a CU) and started only when a dense
@@ -87,13 +99,12 @@ template <int EPB>
 static __device__ __forceinline__ void env_block(const EnvParams& p, const int block, u8* __restrict__ smem) {
     constexpr int THREADS = 64 * EPB;
     u64* s_vol = reinterpret_cast<u64*>(smem);                              // [EPB][16]
-    u8* s_static = smem + EPB * DQ_MAX_DEPTH * 8;                           // [256]
-    u8* s_stab = s_static + 256;
-    u8* s_qubit = s_stab + 256;
-    u8* s_stage = s_qubit + 256;                                            // [EPB * obs_size]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lut_bytes = (2 * p.lut_words * 4 + 15) & ~15;
+    u32* s_lut = reinterpret_cast<u32*>(smem + EPB * DQ_MAX_DEPTH * 8 + wave * lut_bytes);     // this WAVE's copy of the component referee tables [2][lut_words]
+    u8* s_stage = smem + EPB * DQ_MAX_DEPTH * 8 + EPB * lut_bytes;          // [EPB * obs_size]
     __shared__ unsigned long long s_est[EPB][4];                            // episode bookkeeping of the block's lattices (p.stats)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (block >= p.env_blocks) {                                            // replay sampling rides along (independent of this step's results)
         const int b = (block - p.env_blocks) * THREADS + tid;
         if (b < p.s_batch)
@@ -103,23 +114,35 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
     const int i = block * EPB + wave;
     const bool active = i < p.n_envs;                                        // wave-uniform
 
-    if (tid < 256) {
-        s_static[tid] = p.tab->cell_static[tid];
-        s_stab[tid] = p.tab->cell_stab[tid];
-        s_qubit[tid] = p.tab->cell_qubit[tid];
-    }
-
-    const u64 sq = p.tab->stab_qmask[lane];
-    const u64 qs = p.tab->qubit_smask[lane];
-    const bool isx = p.tab->stab_isx[lane] != 0;
-    const int rsrc = p.tab->ref_src[lane];
+    // ---- everything the step reads from memory is requested HERE, in one batch: the lattice's record, the tables' per-lane entries (the cells of
+    //      the observation planes this lane composes: registers instead of three LDS tables read byte by byte per plane), the Q row of the greedy
+    //      choice (it used to go out behind the policy's Philox call and its explore / exploit branch: a round trip of its own for nine lattices in
+    //      ten), the referee tables (copied into LDS where they are small: the look-up behind the syndrome was a dependent round trip to L2).  The
+    //      step then is arithmetic and LDS traffic between one load latency at its top and its stores at the end.  (round 3, phase stamps of the
+    //      step riding on the dense backward: tables + record 4K, policy 4.5K, referee 2.8K, observation planes 6.3K of 32K cycles)
+    const EnvTables* __restrict__ T = p.tab;
+    u32 cpk[ENV_CELLS];
+#pragma unroll
+    for (int k = 0; k < ENV_CELLS; ++k) cpk[k] = T->cell_pack[lane + 64 * k];
+    const u64 sq = T->stab_qmask[lane];
+    const u64 qs = T->qubit_smask[lane];
+    const u64 nq = T->neigh_qmask[lane];
+    const bool isx = T->stab_isx[lane] != 0;
+    const int rsrc = T->ref_src[lane];
+    const u64 col0 = T->col0, row0 = T->row0;
     volatile u64* vol = s_vol + wave * DQ_MAX_DEPTH;   // written by lane 0, read by other lanes of the same wave
+    u64* rec = p.state + (size_t)(active ? i : 0) * p.sw;
+    const u64 word = lane < p.sw ? rec[lane] : 0;
+    float qpre[ENV_QPRE];
+    const bool have_q = p.policy && p.q != nullptr;
+#pragma unroll
+    for (int m = 0; m < ENV_QPRE; ++m) qpre[m] = have_q ? p.q[(size_t)(active ? i : 0) * p.n_actions + min(lane + 64 * m, p.n_actions - 1)] : 0.f;
+    // (a copy per wave: written and read by the same wave, whose LDS operations execute in order -- no barrier)
+    for (int k = lane; k < p.lut_words; k += 64) { s_lut[k] = p.lut_x[k]; s_lut[p.lut_words + k] = p.lut_z[k]; }
 
     u64 comp0 = 0, comp1 = 0;
     if (p.stats && lane < 4) s_est[wave][lane] = 0;
     if (active) {
-        u64* rec = p.state + (size_t)i * p.sw;
-        const u64 word = lane < p.sw ? rec[lane] : 0;
         u64 xmask = wave_bcast64(word, 0), zmask = wave_bcast64(word, 1), acted = wave_bcast64(word, 2);
         u64 round = wave_bcast64(word, 3);
         comp0 = wave_bcast64(word, 4);
@@ -153,7 +176,13 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
                 const float* row = p.q + (size_t)i * p.n_actions;
                 float best = -INFINITY;
                 int best_a = 0x7fffffff;
-                for (int k = lane; k < p.n_actions; k += 64) {
+#pragma unroll
+                for (int m = 0; m < ENV_QPRE; ++m) {                        // (the row's first 64 * ENV_QPRE entries were requested at the top)
+                    const int k = lane + 64 * m;
+                    const bool ok = k < p.n_actions && (!p.masked_greedy || (((k < 64 ? legal0 : legal1) >> (k & 63)) & 1));
+                    if (ok && (qpre[m] > best || best_a == 0x7fffffff)) { best = qpre[m]; best_a = k; }
+                }
+                for (int k = lane + 64 * ENV_QPRE; k < p.n_actions; k += 64) {
                     const bool ok = !p.masked_greedy || (((k < 64 ? legal0 : legal1) >> (k & 63)) & 1);
                     const float v = row[k];
                     if (ok && (v > best || best_a == 0x7fffffff)) { best = v; best_a = k; }
@@ -176,7 +205,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
                 if (pauli != 1) zmask ^= 1ull << q;
             }
             const u64 true_word = __ballot(__popcll((isx ? xmask : zmask) & sq) & 1);   // ENV:139, FL:152-174
-            const int cls = (__popcll(xmask & p.tab->col0) & 1) + 2 * (__popcll(zmask & p.tab->row0) & 1);  // ENV:143
+            const int cls = (__popcll(xmask & col0) & 1) + 2 * (__popcll(zmask & row0) & 1);  // ENV:143
             const u64 refw = __ballot(rsrc < 64 && ((true_word >> (rsrc & 63)) & 1));
             const u32 ix = (u32)refw, iz = (u32)(refw >> 32);
             int dec;
@@ -185,6 +214,9 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
             } else if (p.lut_joint) {                                       // an arbitrary static_decoder.predict, tabulated (ENV:144,150)
                 const u32 sw = (u32)true_word;                              // bit s = stabilizer s in measurement order (n_stab <= 24)
                 dec = (p.lut_joint[sw >> 4] >> (2 * (sw & 15))) & 3;
+            } else if (p.lut_words) {                                       // the component tables' copies in LDS
+                dec = (s_lut[ix >> 5] >> (ix & 31)) & 1;                    // ENV:144
+                if (p.model != DQ_MODEL_X) dec += 2 * ((s_lut[p.lut_words + (iz >> 5)] >> (iz & 31)) & 1);
             } else {
                 dec = (p.lut_x[ix >> 5] >> (ix & 31)) & 1;                  // ENV:144
                 if (p.model != DQ_MODEL_X) dec += 2 * ((p.lut_z[iz >> 5] >> (iz & 31)) & 1);
@@ -199,7 +231,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
                 const int q = a % p.d2;
                 if (!((acted >> q) & 1)) {
                     acted |= 1ull << q;
-                    const u64 nm = p.tab->neigh_qmask[q];
+                    const u64 nm = wave_bcast64(nq, q);                     // (neigh_qmask[q]: lane q holds it)
                     for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, nm, j * p.d2);
                 }
             }
@@ -256,10 +288,38 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
                 s_est[wave][2] = stepped && reward > 0.5f; s_est[wave][3] = stepped;
             }
         }
+
+        // ---- observation planes into the LDS stage (ENV:174-175, 200-201, 273-314): this lane's cells (lane, lane + 64, ...) of every plane, the
+        //      cells' table words from registers -- one LDS read (the plane's syndrome word) and ENV_CELLS byte stores per plane -----------------
+        if (p.obs) {
+            u8* st = s_stage + wave * p.obs_size;
+            for (int j = 0; j < p.depth; ++j) {
+                const u64 v = vol[j];
+#pragma unroll
+                for (int k = 0; k < ENV_CELLS; ++k) {
+                    const int c = lane + 64 * k;
+                    const u32 sidx = (cpk[k] >> 8) & 0xffu;
+                    if (c < p.P) st[j * p.P + c] = (u8)((cpk[k] & 0xffu) | (sidx < 64 ? (u32)((v >> (sidx & 63)) & 1) : 0u));
+                }
+            }
+            for (int k2 = 0; k2 < p.layers; ++k2) {
+#pragma unroll
+                for (int k = 0; k < ENV_CELLS; ++k) {
+                    const int c = lane + 64 * k;
+                    const u32 qi = (cpk[k] >> 16) & 0xffu;
+                    u32 bit = 0;
+                    if (qi < 64) {
+                        const int a = k2 * p.d2 + (int)qi;
+                        bit = (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1);
+                    }
+                    if (c < p.P) st[(p.depth + k2) * p.P + c] = (u8)bit;
+                }
+            }
+        }
     }
 
     if (!p.obs && !p.stats) { env_inline_sampling<THREADS>(p, block); return; }    // block-uniform
-    __syncthreads();                                                        // cell tables (and bookkeeping words) visible
+    __syncthreads();                                                        // the stage (and the bookkeeping words) visible
     if (p.stats && tid < 4) {                                               // integer sums: order-independent; at most four atomics per block
         unsigned long long v = 0;
 #pragma unroll
@@ -267,35 +327,18 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
         if (v) atomicAdd(&p.stats[tid], v);
     }
     if (!p.obs) { env_inline_sampling<THREADS>(p, block); return; }
-    if (active) {
-        // observation planes into the LDS stage (ENV:174-175, 200-201, 273-314)
-        u8* st = s_stage + wave * p.obs_size;
-        for (int j = 0; j < p.depth; ++j) {
-            const u64 v = vol[j];
-            for (int c = lane; c < p.P; c += 64) {
-                const int sidx = s_stab[c];
-                st[j * p.P + c] = (u8)(s_static[c] | (sidx < 64 ? (u32)((v >> (sidx & 63)) & 1) : 0u));
-            }
-        }
-        for (int k = 0; k < p.layers; ++k) {
-            for (int c = lane; c < p.P; c += 64) {
-                const int qi = s_qubit[c];
-                u32 bit = 0;
-                if (qi < 64) {
-                    const int a = k * p.d2 + qi;
-                    bit = (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1);
-                }
-                st[(p.depth + k) * p.P + c] = (u8)bit;
-            }
-        }
-    }
-    __syncthreads();
     {
         const int first = block * EPB;
         const int n_valid = min(EPB, p.n_envs - first);
         const int total = n_valid * p.obs_size;
         u8* g = p.obs + (size_t)first * p.obs_size;
-        if ((reinterpret_cast<uintptr_t>(g) & 3) == 0) {
+        if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {                   // 16-byte stores (a store instruction moves 1 KB instead of 256 bytes: as dwords
+            const env_u32x4* s128 = reinterpret_cast<const env_u32x4*>(s_stage);    // this copy was 5.6K of a riding block's 30K cycles)
+            env_u32x4* g128 = reinterpret_cast<env_u32x4*>(g);
+            const int nq = total >> 4;
+            for (int k = tid; k < nq; k += THREADS) g128[k] = s128[k];
+            for (int k = (nq << 4) + tid; k < total; k += THREADS) g[k] = s_stage[k];
+        } else if ((reinterpret_cast<uintptr_t>(g) & 3) == 0) {
             const u32* s32 = reinterpret_cast<const u32*>(s_stage);
             u32* g32 = reinterpret_cast<u32*>(g);
             const int ndw = total >> 2;
@@ -317,7 +360,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
 // same bits: lane h*32 + l stands where lane l stood (Philox counters use l), every 64-bit ballot is read as its own 32-bit half,
 // wave-uniform values become half-uniform (shuffles of width 32 instead of v_readlane), and the two halves diverge freely (step /
 // reset / rejection loop: ordinary EXEC masking).  The referee index needs the second 32 positions of ref_src as a second ballot.
-// EPB = lattices per block (32 * EPB threads).  LDS: env_block_lds(EPB, obs_size).
+// EPB = lattices per block (32 * EPB threads).  LDS: env_block_lds(EPB, EPB / 2, obs_size, lut_words).
 static __device__ __forceinline__ u64 half_bcast64(u64 v, int src) {
     const u32 lo = (u32)__shfl((int)(u32)v, src, 32), hi = (u32)__shfl((int)(u32)(v >> 32), src, 32);
     return ((u64)hi << 32) | lo;
@@ -327,13 +370,12 @@ template <int EPB>
 static __device__ __forceinline__ void env_block2(const EnvParams& p, const int block, u8* __restrict__ smem) {
     constexpr int THREADS = 32 * EPB;
     u64* s_vol = reinterpret_cast<u64*>(smem);                              // [EPB][16]
-    u8* s_static = smem + EPB * DQ_MAX_DEPTH * 8;                           // [256]
-    u8* s_stab = s_static + 256;
-    u8* s_qubit = s_stab + 256;
-    u8* s_stage = s_qubit + 256;                                            // [EPB * obs_size]
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, hl = lane & 31, slot = tid >> 5;
+    const int lut_bytes = (2 * p.lut_words * 4 + 15) & ~15;
+    u32* s_lut = reinterpret_cast<u32*>(smem + EPB * DQ_MAX_DEPTH * 8 + (tid >> 6) * lut_bytes);      // this WAVE's copy [2][lut_words]
+    u8* s_stage = smem + EPB * DQ_MAX_DEPTH * 8 + (EPB / 2) * lut_bytes;    // [EPB * obs_size]
     __shared__ unsigned long long s_est2[EPB][4];
 
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, hl = lane & 31, slot = tid >> 5;
     const int hshift = 32 * half;
     if (block >= p.env_blocks) {                                            // replay sampling rides along (independent of this step's results)
         const int b = (block - p.env_blocks) * THREADS + tid;
@@ -341,26 +383,34 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
             p.s_index[b] = dq_replay_row(p.s_terminal, p.n_envs, p.s_n_slots, p.s_head, p.s_filled, p.s_batch, p.s_seed0, p.s_seed1, p.s_t, p.s_base + (u32)b);
         return;
     }
+    DQ_STAMP(DQ_TAG_ENV, 0);
     const int i = block * EPB + slot;
     const bool active = i < p.n_envs;                                        // half-uniform
     auto hb = [&](bool pred) -> u64 { return (u64)(u32)(__ballot(pred) >> hshift); };   // this lattice's 32 bits of a ballot
 
-    for (int k = tid; k < 256; k += THREADS) {
-        s_static[k] = p.tab->cell_static[k];
-        s_stab[k] = p.tab->cell_stab[k];
-        s_qubit[k] = p.tab->cell_qubit[k];
-    }
-    const u64 sq = p.tab->stab_qmask[hl];
-    const u64 qs = p.tab->qubit_smask[hl];
-    const bool isx = p.tab->stab_isx[hl] != 0;
-    const int rsrc_x = p.tab->ref_src[hl], rsrc_z = p.tab->ref_src[32 + hl];
+    // ---- one batch of loads at the top (env_block's comment): record, per-lane table entries, Q row, referee tables -> LDS ------------------
+    const EnvTables* __restrict__ T = p.tab;
+    u32 cpk[ENV_CELLS];
+#pragma unroll
+    for (int k = 0; k < ENV_CELLS; ++k) cpk[k] = T->cell_pack[hl + 32 * k];
+    const u64 sq = T->stab_qmask[hl];
+    const u64 qs = T->qubit_smask[hl];
+    const u64 nq = T->neigh_qmask[hl];
+    const bool isx = T->stab_isx[hl] != 0;
+    const int rsrc_x = T->ref_src[hl], rsrc_z = T->ref_src[32 + hl];
+    const u64 col0 = T->col0, row0 = T->row0;
     volatile u64* vol = s_vol + slot * DQ_MAX_DEPTH;   // written by lane 0 of the half, read by its other lanes
+    u64* rec = p.state + (size_t)(active ? i : 0) * p.sw;
+    const u64 word = hl < p.sw ? rec[hl] : 0;
+    float qpre[ENV_QPRE];
+    const bool have_q = p.policy && p.q != nullptr;
+#pragma unroll
+    for (int m = 0; m < ENV_QPRE; ++m) qpre[m] = have_q ? p.q[(size_t)(active ? i : 0) * p.n_actions + min(hl + 32 * m, p.n_actions - 1)] : 0.f;
+    for (int k = lane; k < p.lut_words; k += 64) { s_lut[k] = p.lut_x[k]; s_lut[p.lut_words + k] = p.lut_z[k]; }      // (per wave: no barrier)
 
     u64 comp0 = 0, comp1 = 0;
     if (p.stats && hl < 4) s_est2[slot][hl] = 0;
     if (active) {
-        u64* rec = p.state + (size_t)i * p.sw;
-        const u64 word = hl < p.sw ? rec[hl] : 0;
         u64 xmask = half_bcast64(word, 0), zmask = half_bcast64(word, 1), acted = half_bcast64(word, 2);
         u64 round = half_bcast64(word, 3);
         comp0 = half_bcast64(word, 4);
@@ -370,6 +420,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
         u32 lifetime = (u32)meta;
         int done = (int)((meta >> 32) & 1);
         if (hl >= STATE_FIXED && hl < STATE_FIXED + p.depth) vol[hl - STATE_FIXED] = word;
+        DQ_STAMP(DQ_TAG_ENV, 1);
 
         bool do_reset;
         if (p.mode == 0) {
@@ -394,7 +445,13 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
                 const float* row = p.q + (size_t)i * p.n_actions;
                 float best = -INFINITY;
                 int best_a = 0x7fffffff;
-                for (int k = hl; k < p.n_actions; k += 32) {
+#pragma unroll
+                for (int m = 0; m < ENV_QPRE; ++m) {                        // (the row's first 32 * ENV_QPRE entries were requested at the top)
+                    const int k = hl + 32 * m;
+                    const bool ok = k < p.n_actions && (!p.masked_greedy || (((k < 64 ? legal0 : legal1) >> (k & 63)) & 1));
+                    if (ok && (qpre[m] > best || best_a == 0x7fffffff)) { best = qpre[m]; best_a = k; }
+                }
+                for (int k = hl + 32 * ENV_QPRE; k < p.n_actions; k += 32) {
                     const bool ok = !p.masked_greedy || (((k < 64 ? legal0 : legal1) >> (k & 63)) & 1);
                     const float v = row[k];
                     if (ok && (v > best || best_a == 0x7fffffff)) { best = v; best_a = k; }
@@ -405,6 +462,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
             }
             if (hl == 0) p.action_out[i] = a_sel;
         }
+        DQ_STAMP(DQ_TAG_ENV, 2);
         if (do_step) {
             int a = p.policy ? a_sel : p.action[i];
             if ((unsigned)a >= (unsigned)p.n_actions) a = p.identity;
@@ -417,7 +475,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
                 if (pauli != 1) zmask ^= 1ull << q;
             }
             const u64 true_word = hb(__popcll((isx ? xmask : zmask) & sq) & 1);          // ENV:139, FL:152-174
-            const int cls = (__popcll(xmask & p.tab->col0) & 1) + 2 * (__popcll(zmask & p.tab->row0) & 1);  // ENV:143
+            const int cls = (__popcll(xmask & col0) & 1) + 2 * (__popcll(zmask & row0) & 1);  // ENV:143
             const u32 ix = (u32)hb(rsrc_x < 64 && ((true_word >> (rsrc_x & 63)) & 1));
             const u32 iz = (u32)hb(rsrc_z < 64 && ((true_word >> (rsrc_z & 63)) & 1));
             int dec;
@@ -426,6 +484,9 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
             } else if (p.lut_joint) {                                       // an arbitrary static_decoder.predict, tabulated (ENV:144,150)
                 const u32 sw = (u32)true_word;                              // bit s = stabilizer s in measurement order (n_stab <= 24)
                 dec = (p.lut_joint[sw >> 4] >> (2 * (sw & 15))) & 3;
+            } else if (p.lut_words) {                                       // the component tables' copies in LDS
+                dec = (s_lut[ix >> 5] >> (ix & 31)) & 1;                    // ENV:144
+                if (p.model != DQ_MODEL_X) dec += 2 * ((s_lut[p.lut_words + (iz >> 5)] >> (iz & 31)) & 1);
             } else {
                 dec = (p.lut_x[ix >> 5] >> (ix & 31)) & 1;                  // ENV:144
                 if (p.model != DQ_MODEL_X) dec += 2 * ((p.lut_z[iz >> 5] >> (iz & 31)) & 1);
@@ -439,11 +500,12 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
                 const int q = a % p.d2;
                 if (!((acted >> q) & 1)) {
                     acted |= 1ull << q;
-                    const u64 nm = p.tab->neigh_qmask[q];
+                    const u64 nm = half_bcast64(nq, q);                     // (neigh_qmask[q]: lane q of the half holds it)
                     for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, nm, j * p.d2);
                 }
             }
         }
+        DQ_STAMP(DQ_TAG_ENV, 3);
         if (need_volume) {                                                  // ENV:157-172 == ENV:216-231
             u64 summed;
             do {
@@ -474,6 +536,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
             or_shl128(legal0, legal1, 1ull, p.identity);
             for (int j = 0; j < p.layers; ++j) or_shl128(legal0, legal1, legal_q, j * p.d2);
         }
+        DQ_STAMP(DQ_TAG_ENV, 4);
 
         // ---- state record and scalar outputs ----------------------------------------------------
         const u64 meta_out = (u64)lifetime | ((u64)done << 32);
@@ -495,10 +558,41 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
                 s_est2[slot][2] = stepped && reward > 0.5f; s_est2[slot][3] = stepped;
             }
         }
+        DQ_STAMP(DQ_TAG_ENV, 5);
+
+        // ---- observation planes into the LDS stage (ENV:174-175, 200-201, 273-314): this lane's cells (hl, hl + 32, ...) of every plane, their
+        //      table words from registers (env_block's comment) -------------------------------------------------------------------------------
+        if (p.obs) {
+            u8* st = s_stage + slot * p.obs_size;
+            for (int j = 0; j < p.depth; ++j) {
+                const u64 v = vol[j];
+#pragma unroll
+                for (int k = 0; k < ENV_CELLS; ++k) {
+                    const int c = hl + 32 * k;
+                    const u32 sidx = (cpk[k] >> 8) & 0xffu;
+                    if (c < p.P) st[j * p.P + c] = (u8)((cpk[k] & 0xffu) | (sidx < 64 ? (u32)((v >> (sidx & 63)) & 1) : 0u));
+                }
+            }
+            for (int k2 = 0; k2 < p.layers; ++k2) {
+#pragma unroll
+                for (int k = 0; k < ENV_CELLS; ++k) {
+                    const int c = hl + 32 * k;
+                    const u32 qi = (cpk[k] >> 16) & 0xffu;
+                    u32 bit = 0;
+                    if (qi < 64) {
+                        const int a = k2 * p.d2 + (int)qi;
+                        bit = (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1);
+                    }
+                    if (c < p.P) st[(p.depth + k2) * p.P + c] = (u8)bit;
+                }
+            }
+        }
+        DQ_STAMP(DQ_TAG_ENV, 6);
     }
 
     if (!p.obs && !p.stats) { env_inline_sampling<THREADS>(p, block); return; }    // block-uniform
-    __syncthreads();                                                        // cell tables (and bookkeeping words) visible
+    __syncthreads();                                                        // the stage (and the bookkeeping words) visible
+    DQ_STAMP(DQ_TAG_ENV, 7);
     if (p.stats && tid < 4) {                                               // integer sums: order-independent; at most four atomics per block
         unsigned long long v = 0;
 #pragma unroll
@@ -506,35 +600,18 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
         if (v) atomicAdd(&p.stats[tid], v);
     }
     if (!p.obs) { env_inline_sampling<THREADS>(p, block); return; }
-    if (active) {
-        // observation planes into the LDS stage (ENV:174-175, 200-201, 273-314)
-        u8* st = s_stage + slot * p.obs_size;
-        for (int j = 0; j < p.depth; ++j) {
-            const u64 v = vol[j];
-            for (int c = hl; c < p.P; c += 32) {
-                const int sidx = s_stab[c];
-                st[j * p.P + c] = (u8)(s_static[c] | (sidx < 64 ? (u32)((v >> (sidx & 63)) & 1) : 0u));
-            }
-        }
-        for (int k = 0; k < p.layers; ++k) {
-            for (int c = hl; c < p.P; c += 32) {
-                const int qi = s_qubit[c];
-                u32 bit = 0;
-                if (qi < 64) {
-                    const int a = k * p.d2 + qi;
-                    bit = (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1);
-                }
-                st[(p.depth + k) * p.P + c] = (u8)bit;
-            }
-        }
-    }
-    __syncthreads();
     {
         const int first = block * EPB;
         const int n_valid = min(EPB, p.n_envs - first);
         const int total = n_valid * p.obs_size;
         u8* g = p.obs + (size_t)first * p.obs_size;
-        if ((reinterpret_cast<uintptr_t>(g) & 3) == 0) {
+        if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {                   // 16-byte stores (a store instruction moves 1 KB instead of 256 bytes: as dwords
+            const env_u32x4* s128 = reinterpret_cast<const env_u32x4*>(s_stage);    // this copy was 5.6K of a riding block's 30K cycles)
+            env_u32x4* g128 = reinterpret_cast<env_u32x4*>(g);
+            const int nq = total >> 4;
+            for (int k = tid; k < nq; k += THREADS) g128[k] = s128[k];
+            for (int k = (nq << 4) + tid; k < total; k += THREADS) g[k] = s_stage[k];
+        } else if ((reinterpret_cast<uintptr_t>(g) & 3) == 0) {
             const u32* s32 = reinterpret_cast<const u32*>(s_stage);
             u32* g32 = reinterpret_cast<u32*>(g);
             const int ndw = total >> 2;
@@ -544,7 +621,9 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
             for (int k = tid; k < total; k += THREADS) g[k] = s_stage[k];
         }
     }
+    DQ_STAMP(DQ_TAG_ENV, 8);
     env_inline_sampling<THREADS>(p, block);
+    DQ_STAMP(DQ_TAG_ENV, 9);
 }
 
 // env.hip: validates the arguments of dq_env_act_step(_sample) and fills the parameters of a step WITHOUT launching it: the caller

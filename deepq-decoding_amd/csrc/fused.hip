@@ -771,6 +771,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     const int K1 = a.K1;
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 0);
+    DQ_STAMP_WG(DQ_TAG_DENSE_FWD, 0);
     DQ_STAMP_PAIR(2);
     // ---- hidden layer's first weight blocks start flying before anything else -------------------------------------------
     // Both dense layers run TRANSPOSED on the f16 pipe (f16x2, qnet.h): out^T = W^T x^T, the packed weight pieces are the MFMA's FIRST
@@ -1097,6 +1098,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_FWD, 8);
+    DQ_STAMP_WG(DQ_TAG_DENSE_FWD, 1);
     DQ_STAMP_PAIR(3);
 }
 

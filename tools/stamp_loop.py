@@ -15,7 +15,13 @@ for _ in range(60):
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()
 dq.lib().dq_dbg_read_bwd(buf)
-if tag == 3:
+if tag == 6:
+    names = ["tables+record", "policy", "step (referee look-ups)", "volume", "outputs", "barrier+stats", "obs compose", "barrier+obs write", "sampling"]
+    for w in range(8):
+        t = [buf[i * 8 + w] for i in range(10)]
+        print("wave", w, [t[i + 1] - t[i] for i in range(9)], "total", t[9] - t[0])
+    print(names)
+elif tag == 3:
     for w in range(8):
         t = [buf[i * 8 + w] for i in range(6)]
         print("wave", w, "zero+TD+dueling, gY2, gH1, bar, gX:", [t[i + 1] - t[i] for i in range(5)], "total", t[5] - t[0])
