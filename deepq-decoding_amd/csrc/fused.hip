@@ -728,6 +728,7 @@ struct DenseJob {
     int batch;
     float keep_scale;                   // > 0: dropout active on the hidden layer's output
     u32 drop_T;                         // a unit is dropped iff its 16-bit draw < drop_T (dq_rate_threshold16)
+    const u32* keep_bits;               // != NULL: the keep bits of this job's samples, drawn ahead ([batch][16] words, qnet.h keep_bits): loaded, not drawn
     u32 seed0, seed1, sample_base;
     u64 t;
     unsigned short* x_pl;               // training: the input rows as f16 piece planes [2][plane_rows][K1] for the dense weight gradients
@@ -802,8 +803,22 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     u32 keepb[RT];
 #pragma unroll
     for (int u = 0; u < RT; ++u) keepb[u] = 0xffffu;
+    // (drawn ahead by the previous backward's final reduction where the caller's loop lets it guess this forward -- qnet.h keep_bits --: then
+    // two words per row tile, requested with the input rows)
+    uint2 kbw[RT];
+    const bool kb_ahead = J.keep_scale > 0.f && J.keep_bits != nullptr;      // block-uniform
+    if (kb_ahead) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u)
+            kbw[u] = *reinterpret_cast<const uint2*>(J.keep_bits + (size_t)min(b0 + 16 * u + j, J.batch - 1) * 16 + 2 * wave);
+    }
     auto draw_keep_bits = [&]() {
         if (!(J.keep_scale > 0.f) || DQ_EXP_NODROP) return;         // block-uniform
+        if (kb_ahead) {                                             // word 2 wave + b: units 64 wave + 32 b .. + 31; this lane's eight: byte kq
+#pragma unroll
+            for (int u = 0; u < RT; ++u) keepb[u] = ((kbw[u].x >> (8 * kq)) & 0xffu) | (((kbw[u].y >> (8 * kq)) & 0xffu) << 8);
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < RT; ++u) {
             u32 bits = 0;
@@ -1462,6 +1477,16 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         if (training && D1.dropout > 0.f) {
             D.keep_scale = (float)(1.0 / (1.0 - (double)D1.dropout));
             D.drop_T = dq_rate_threshold16((double)D1.dropout);
+            // the draw this forward asks for; the bits the last backward drew ahead if they are exactly it (qnet.h keep_bits)
+            const dq_qnet::DropTag want = {jb.seed[0], jb.seed[1], jb.sample_base, D.drop_T, jb.t, jb.batch, 1};
+            const dq_qnet::DropTag& have = Q->kb_tag;
+            static const bool ahead_on = !(getenv("DQ_DROP_AHEAD") && getenv("DQ_DROP_AHEAD")[0] == '0');
+            if (ahead_on && Q->keep_bits && have.valid && have.seed0 == want.seed0 && have.seed1 == want.seed1 && have.sample_base == want.sample_base &&
+                have.drop_T == want.drop_T && have.t == want.t && have.batch == want.batch)
+                D.keep_bits = Q->keep_bits;
+            Q->last_drop = want;
+        } else if (training) {
+            Q->last_drop.valid = 0;
         }
         D.seed0 = jb.seed[0]; D.seed1 = jb.seed[1]; D.sample_base = jb.sample_base; D.t = jb.t;
         if (training) {

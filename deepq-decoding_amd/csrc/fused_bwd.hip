@@ -767,7 +767,25 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
 // Block = 64 outputs x 8 slice groups (thread (x, g) sums slices g, g+8, ... in order; the 8 group sums are combined
 // pairwise in LDS) -- deterministic, and 8x the loads in flight of a one-thread-per-output loop.
 struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; int pidx0; int vec; };   // pidx0: flat index of out[0]; vec: see the kernel
-struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; float inv_gs; const float* gs_dev; unsigned* range_flag; };     // partials carry the gradient scale: x 1/S
+// the hidden layer's dropout keep bits of the NEXT training forward, drawn by the first `wgs` workgroups of this launch (qnet.h keep_bits)
+struct DropAhead { u32* bits; u32 seed0, seed1, sample_base, drop_T; u64 t; int batch, wgs; };
+struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; float inv_gs; const float* gs_dev; unsigned* range_flag; DropAhead drop; };     // partials carry the gradient scale: x 1/S
+
+// Thread g of the drawing workgroups: word g & 15 of sample g >> 4 = the 32 units 32 (g & 15) .. + 31 = four Philox calls of eight 16-bit draws --
+// fused.hip dense_chain_kernel's draw (unit n: half-word n & 7 of call n >> 3, kept iff >= drop_T), the same bits.
+__device__ __forceinline__ void dropout_ahead(const DropAhead& d, int g) {
+    const int row = g >> 4, word = g & 15;
+    if (row >= d.batch) return;
+    u32 bits = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        u32 wd[4];
+        philox4x32_10((u32)d.t, (u32)(d.t >> 32), d.sample_base + (u32)row, (u32)(4 * word + c) | ((u32)DQ_STREAM_DROPOUT << 16), d.seed0, d.seed1, wd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bits |= (((wd[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= d.drop_T ? 1u : 0u) << (8 * c + e);
+    }
+    d.bits[(size_t)row * 16 + word] = bits;
+}
 
 // one output's optimizer step and range guard
 __device__ __forceinline__ void reduce_finish(const ReduceArgs& a, const ReduceSeg& S, int i, float gsum) {
@@ -809,13 +827,17 @@ __device__ __forceinline__ void reduce_finish4(const ReduceArgs& a, const Reduce
 
 __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     __shared__ float sh[8][64];
-    const ReduceSeg& S = a.seg[blockIdx.x >= (unsigned)a.seg[1].block0 ? 1 : 0];
+    // this launch waits for HBM with its vector ALUs idle: its FIRST workgroups (dispatched first, running beside the reduction's) draw the next
+    // training forward's dropout keep bits
+    if ((int)blockIdx.x < a.drop.wgs) { dropout_ahead(a.drop, (int)blockIdx.x * 512 + threadIdx.y * 64 + threadIdx.x); return; }
+    const unsigned bx = blockIdx.x - (unsigned)a.drop.wgs;
+    const ReduceSeg& S = a.seg[bx >= (unsigned)a.seg[1].block0 ? 1 : 0];
     const float inv = a.gs_dev ? a.gs_dev[1] : a.inv_gs;
     if (S.vec == 1) {
         // at most 16 slices (the dense partials): thread = four consecutive outputs, all slices' 16-byte loads in flight together, summed in the
         // scalar form's order (the same bits).  That form spent a 512-thread workgroup, a barrier and an LDS
         // round trip on 64 outputs of 8 loads each: 2763 of this launch's 3020 workgroups.
-        const int i = 4 * ((blockIdx.x - S.block0) * 512 + threadIdx.y * 64 + threadIdx.x);      // block-uniform branch; slices start on 128-byte lines
+        const int i = 4 * ((bx - S.block0) * 512 + threadIdx.y * 64 + threadIdx.x);      // block-uniform branch; slices start on 128-byte lines
         if (i >= S.n) return;
         f32x4 v[16];
 #pragma unroll
@@ -835,7 +857,7 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     }
     // (the same treatment of the 256 convolutional partials -- 16 x 32 threads, four outputs each, eight 16-byte loads in flight per thread -- measured
     // slower: 7.7 against 6.6 us for the launch)
-    const int i = (blockIdx.x - S.block0) * 64 + threadIdx.x, g = threadIdx.y;
+    const int i = (bx - S.block0) * 64 + threadIdx.x, g = threadIdx.y;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                     // four independent chains: the loop is load-latency-bound
     if (i < S.n) {
         int k = g;
@@ -1683,16 +1705,27 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     if (opt) { ra.opt = *opt; ra.adam = 1; }
     ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0, 0};
     const int blocks0 = ((int)conv_floats + 63) / 64;
+    // the next training forward's dropout keep bits, drawn ahead by this launch: the last one's draw at t + 1 (qnet.h keep_bits)
+    Q->kb_tag.valid = 0;
+    if (Q->keep_bits && Q->last_drop.valid && Q->last_drop.batch <= Q->cfg.max_batch) {
+        static const bool ahead_on = !(getenv("DQ_DROP_AHEAD") && getenv("DQ_DROP_AHEAD")[0] == '0');
+        if (ahead_on) {
+            dq_qnet::DropTag next = Q->last_drop;
+            next.t += 1;
+            ra.drop = {Q->keep_bits, next.seed0, next.seed1, next.sample_base, next.drop_T, next.t, next.batch, (next.batch * 16 + 511) / 512};
+            Q->kb_tag = next;
+        }
+    }
     if (phases == 3) {
         int rps, sy;
         wgrad_slicing(B, &rps, &sy);
         ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, dense_pstride(Q), blocks0, (int)conv_floats};
         ra.seg[1].vec = sy <= 16 && (conv_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(grads_dev) & 15) == 0 &&
                         (!opt || ((reinterpret_cast<uintptr_t>(opt->p) | reinterpret_cast<uintptr_t>(opt->m) | reinterpret_cast<uintptr_t>(opt->v)) & 15) == 0);          // few slices: four outputs per thread, every slice's 16 bytes in flight at once
-        reduce_slices_kernel<<<blocks0 + (ra.seg[1].vec ? (n_dense + 2047) / 2048 : (n_dense + 63) / 64), dim3(64, 8), 0, st>>>(ra);
+        reduce_slices_kernel<<<ra.drop.wgs + blocks0 + (ra.seg[1].vec ? (n_dense + 2047) / 2048 : (n_dense + 63) / 64), dim3(64, 8), 0, st>>>(ra);
     } else {
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
-        reduce_slices_kernel<<<blocks0, dim3(64, 8), 0, st>>>(ra);
+        reduce_slices_kernel<<<ra.drop.wgs + blocks0, dim3(64, 8), 0, st>>>(ra);
     }
     DQ_LAUNCH_CHECK();
     return DQ_OK;

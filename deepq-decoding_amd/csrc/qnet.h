@@ -43,6 +43,15 @@ struct dq_qnet {
                                  // weight gradients, row-major [max_batch][ld]: x (ld K1), h1 (512), gh1 (512), then gy2, g3, y2 (ld
                                  // dq_planes_small_ld: 64 or 128; columns past the tensor's width hold anything finite or not -- they only
                                  // reach weight-gradient accumulators that are never stored), in this order
+    // Dropout keep bits drawn AHEAD: the backward's final reduction (an HBM-bound launch whose vector ALUs idle) draws the hidden layer's keep bits
+    // of the training forward it expects NEXT -- the last one's seed, sample range and rate at t + 1 -- into keep_bits ([max_batch][16] words: bit
+    // unit & 31 of word unit >> 5 of a sample's row), and the next training forward that asks for exactly that (kb_tag) loads them instead of
+    // running eight Philox calls per lane in its 64 training workgroups -- the workgroups that set the dense forward's duration.  Any other
+    // request draws in the kernel as before: the same bits either way (fused.hip draw_keep_bits, fused_bwd.hip dropout_ahead).
+    struct DropTag { u32 seed0, seed1, sample_base, drop_T; u64 t; int batch, valid; };
+    u32* keep_bits;
+    DropTag kb_tag;              // what keep_bits holds (valid = 1)
+    DropTag last_drop;           // the last fused training forward's dropout draw (valid = 0: none)
     float grad_scale_hint;       // dq_qnet_set_grad_scale: loss scale of caller-supplied dq (0 = unknown: measured on the device)
     float bwd_scale;             // fused backward: power-of-two scale the gradients of the last dense phase carry (0: the device-computed one)
     int use_fused;               // fused LDS-resident chains when the configuration allows it

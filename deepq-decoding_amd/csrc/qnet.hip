@@ -422,6 +422,7 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         e = hipMalloc(&Q->planes, (dq_planes_halves(Q) + 16 * DENSE_HID) * sizeof(unsigned short));
     }
     const size_t fws = fused_backward_workspace_floats(Q);
+    if (e == hipSuccess && fused_forward_supported(Q)) e = hipMalloc(&Q->keep_bits, (size_t)Q->cfg.max_batch * 16 * sizeof(u32));
     if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));
     if (e == hipSuccess && fws) e = hipMemset(Q->fpartial + fws - 4, 0, 4 * sizeof(float));       // {S, 1/S}, range flag
     Q->partial_floats = max_partial;
@@ -436,6 +437,7 @@ void dq_qnet_destroy(dq_qnet* Q) {
         for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->act[s][i]) (void)hipFree(Q->act[s][i]);
     for (int i = 0; i < QN_MAX_LAYERS; ++i) if (Q->gz[i]) (void)hipFree(Q->gz[i]);
     if (Q->partial) (void)hipFree(Q->partial);
+    if (Q->keep_bits) (void)hipFree(Q->keep_bits);
     if (Q->fpartial) (void)hipFree(Q->fpartial);
     if (Q->planes) (void)hipFree(Q->planes);
     if (Q->kofftab) (void)hipFree(Q->kofftab);

@@ -104,6 +104,33 @@ def test_training_forward_backward(dq, torch_mod, name, batch, fused):
     assert np.array_equal(g, g2)
 
 
+@pytest.mark.parametrize("name,batch", [("c3", 4096), ("c3", 77), ("c1", 8)])
+def test_dropout_bits_drawn_ahead_equal_the_kernel_own_draw(dq, torch_mod, name, batch):
+    """The backward's final reduction draws the keep bits of the training forward it expects next (same seed and sample range, t + 1:
+    csrc/qnet.h keep_bits); a forward that asks for exactly that loads them, any other draws in its own kernel -- the same bits, hence the
+    same outputs and gradients, bit for bit, and equal to the oracle's mask."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, name, batch)
+    _, net2, params2, _, _, _ = _setup(dq, torch, name, batch)
+    obs_t = torch.from_numpy(obs).cuda()
+    dq_ = torch.from_numpy((rng.randn(batch, spec.n_actions) / batch).astype(np.float32)).cuda()
+    seed, t, base = (3, 4), 2 ** 32 - 1, 123                       # t + 1 carries into the counter's high word
+    net.forward(params, obs_t, training=True, seed=seed, t=t, sample_base=base)
+    net.backward(params, dq_)                                       # draws ahead for (seed, t + 1, base, batch)
+    q_ahead = net.forward(params, obs_t, training=True, seed=seed, t=t + 1, sample_base=base).cpu().numpy()
+    g_ahead = net.backward(params, dq_).cpu().numpy()
+    q_own = net2.forward(params2, obs_t, training=True, seed=seed, t=t + 1, sample_base=base).cpu().numpy()      # no backward before: its own draw
+    g_own = net2.backward(params2, dq_).cpu().numpy()
+    assert np.array_equal(q_ahead, q_own) and np.array_equal(g_ahead, g_own)
+    keep = O.dropout_keep_mask(seed, t + 1, base + np.arange(batch), 512, 0.2)
+    q_ref, _ = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    assert np.abs(q_ahead - q_ref).max() < tol(q_ref)
+    # a forward the guess does not cover (another sample range) draws for itself
+    q_other = net.forward(params, obs_t, training=True, seed=seed, t=t + 2, sample_base=base + 5).cpu().numpy()
+    keep = O.dropout_keep_mask(seed, t + 2, base + 5 + np.arange(batch), 512, 0.2)
+    assert np.abs(q_other - O.forward(spec, flat, obs, training=True, keep_masks=[keep])[0]).max() < tol(q_ref)
+
+
 @pytest.mark.parametrize("name,batch", [("c3", 4096), ("c3", 2049), ("c3", 4091), ("c3", 2048 + 8 * 200 + 3), ("c2", 4096), ("c5", 1024), ("c5", 2500)])
 def test_backward_at_baseline_batch_matches_oracle(dq, torch_mod, name, batch):
     """The fused training forward + backward at the BASELINE.json minibatch sizes against the float64 oracle on the FULL batch.  Only
