@@ -746,6 +746,7 @@ struct DenseChainArgs {
     int K1, perm_hw, perm_c;            // Keras Flatten: k = c*hw + p reads x[p*perm_c + c]
     int pk_dense1;                      // u32x4 offset of the hidden layer's packed blocks [K1/32][32 column tiles]
     int pk_dense2;                      // ... of Dense(|A|)'s [16][NT2]
+    int pk_w3q;                         // ... of the folded dueling layer W3' / b3' (f32, PackLayout.w3q)
     int N2, N3, n_actions;              // Dense(|A|) width, dueling layer width (0 = no dueling layer)
     int w_off[3], b_off[3];
     int ldx, ld2, ld3;                  // LDS row strides (floats)
@@ -759,7 +760,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     float* s_x = reinterpret_cast<float*>(smem + a.off_x);
     float* s_part = reinterpret_cast<float*>(smem + a.off_part);
     float* s_y2 = reinterpret_cast<float*>(smem + a.off_y2);
-    float* s_y3 = reinterpret_cast<float*>(smem + a.off_y3);
     constexpr int PW = 16 * NT2, ROWS = 16 * RT, PR = ROWS < 32 ? ROWS : 32, UP = PR / 16;      // PR rows (UP row tiles) per reduction pass
     constexpr int PWP = PW + 4;                                     // row stride of the partials: the 8 lanes of a ds_write_b128 lane group are 8 ROWS -- unpadded (a
                                                                     // multiple of 32 banks) every store was an 8-way conflict, 13K cycles of this kernel's LDS time
@@ -928,32 +928,28 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
             for (int t = 0; t < NT2; ++t) { w2[b][t].h = pk2[(b * NT2 + t) * PK_BLOCK]; w2[b][t].l = pk2[(b * NT2 + t) * PK_BLOCK + PK_LO]; }
     }
-    const int NT3 = (a.N3 + 15) >> 4;
+    // The dueling layer Dense(|A| + 1) and the combination Q = V + A - mean(A) are ONE linear map of Dense(|A|)'s output: pack_weights_kernel
+    // folds them into W3' [16 KG3][16 NT2] (zero past N2 / past |A|) and b3' (PackLayout.w3q), so that the last phase's MFMA accumulators ARE the
+    // Q-values (round 3: a separate combination -- every wave reading eight rows back from LDS, butterfly sums, a barrier in between -- was 5K of a
+    // workgroup's 48K cycles).  Waves 0 .. NTQ-1 x parts: column tile ct3 of Q belongs to waves ct3, ct3 + NTQ, ...: they share its row tiles.
+    const int A = a.n_actions;
+    const int NTQ = (A + 15) >> 4;
     float b3[KG3][4];
     f32x4 bias1[4];                                                 // this lane's four units of tile ct: 64w + 32 (ct >> 1) + 8kq + 4 (ct & 1) + r
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
         bias1[ct] = *reinterpret_cast<const f32x4u*>(J.params + a.b_off[0] + 64 * wave + 32 * (ct >> 1) + 8 * kq + 4 * (ct & 1));
-    // the dueling layer's weights (waves 0 .. NT3-1): requested here, raw, at clamped addresses, and used three barriers later; the
-    // masks (columns past N3, rows past N2) are applied where they are used -- a multiplication or select next to the load makes hipcc
-    // wait for the load right there (4K cycles of every workgroup under load)
-    // column tile ct3 of the dueling layer belongs to waves ct3, ct3 + NT3, ...: they share its row tiles (u = part, part + parts, ...)
-    const int nt3 = NT3 > 0 ? NT3 : 1, parts = DENSE_WAVES / nt3, ct3 = wave % nt3, part = wave / nt3;
+    const int nt3 = NTQ > 0 ? NTQ : 1, parts = DENSE_WAVES / nt3, ct3 = wave % nt3, part = wave / nt3;
     const bool act3 = a.N3 > 0 && part < parts;
     const int col3 = 16 * ct3 + j;
     float bias3 = 0.f;
-    if (act3) {
-        bias3 = J.params[a.b_off[2] + min(col3, a.N3 - 1)];
-        const float* w3 = J.params + a.w_off[2];
-        const bool cok = col3 < a.N3;
-        const int loff = 4 * kq * a.N3 + (cok ? col3 : 0);
+    if (act3) {                                                     // (requested here, used three barriers later; unconditional: the table is zero-padded)
+        const float* w3q = reinterpret_cast<const float*>(J.packed + a.pk_w3q);
+        bias3 = w3q[16 * KG3 * PW + col3];
 #pragma unroll
         for (int g = 0; g < KG3; ++g)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = 16 * g + 4 * kq + s;
-                b3[g][s] = w3[(cok && k < a.N2) ? (16 * g + s) * a.N3 + loff : 0];
-            }
+            for (int s = 0; s < 4; ++s) b3[g][s] = w3q[(16 * g + 4 * kq + s) * PW + col3];
     }
     const int rcol = tid & 63;                                      // column (+ 64 cc) of the cross-wave reduction below
     float bias2r[(PW + 63) / 64];
@@ -1046,15 +1042,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_FWD, 6);
-    // ---- dueling layer Dense(|A|+1) and the combination Q = V + A - mean(A) ------------------------------------------------
-    const float* y = s_y2;
-    int ldy = a.ld2;
+    // ---- Q = y2 W3' + b3' (the dueling layer and its combination, folded: see above), straight from the accumulators to global memory ----
     if (a.N3 > 0) {
         if (act3) {
-#pragma unroll
-            for (int g = 0; g < KG3; ++g)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) b3[g][s] = (col3 < a.N3 && 16 * g + 4 * kq + s < a.N2) ? b3[g][s] : 0.f;
             for (int u = part; u < RT; u += parts) {
                 f32x4 acc3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // two chains: a dependent f32 MFMA waits for its predecessor
                 const float* yrow = s_y2 + (16 * u + j) * a.ld2 + 4 * kq;
@@ -1064,51 +1054,28 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc3[s & 1] = MFMA16(av[s], b3[g][s], acc3[s & 1]);
                 }
-                if (col3 < a.N3) {
+                if (col3 < A) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * u + 4 * kq + r;
-                        const float v = (acc3[0][r] + acc3[1][r]) + bias3;
-                        s_y3[row * a.ld3 + col3] = v;
+                        if (row < ns) J.q_out[(size_t)(b0 + row) * A + col3] = (acc3[0][r] + acc3[1][r]) + bias3;
                     }
                 }
             }
         }
-        __syncthreads();
-        y = s_y3;
-        ldy = a.ld3;
-    }
-    DQ_STAMP(DQ_TAG_DENSE_FWD, 7);
-    const int A = a.n_actions;
-    {   // this wave's rows (wave, wave + 8, ...) together: their LDS reads and butterfly sums are independent chains
+        DQ_STAMP(DQ_TAG_DENSE_FWD, 7);
+    } else {
+        // no dueling layer: Q = Dense(|A|)'s output
+        DQ_STAMP(DQ_TAG_DENSE_FWD, 7);
         constexpr int RW = ROWS / DENSE_WAVES;
-        float yv[RW][2], sum[RW];
-#pragma unroll
-        for (int u = 0; u < RW; ++u) {
-            const float* yr = y + min(wave + DENSE_WAVES * u, ROWS - 1) * ldy + (a.N3 > 0 ? 1 : 0);
-            sum[u] = 0.f;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = lane + 64 * h;
-                yv[u][h] = c < A ? yr[c] : 0.f;
-                sum[u] += yv[u][h];
-            }
-        }
-        if (a.N3 > 0) {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-                for (int u = 0; u < RW; ++u) sum[u] += __shfl_xor(sum[u], m);
-        }
 #pragma unroll
         for (int u = 0; u < RW; ++u) {
             const int row = wave + DENSE_WAVES * u;
             if (row >= ns) continue;
-            const float base = a.N3 > 0 ? y[row * ldy] - sum[u] / (float)A : 0.f;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
-                if (c < A) J.q_out[(size_t)(b0 + row) * A + c] = base + yv[u][h];
+                if (c < A) J.q_out[(size_t)(b0 + row) * A + c] = s_y2[row * a.ld2 + c];
             }
         }
     }
@@ -1127,6 +1094,8 @@ struct PackArgs {
     int d2_off, N2, NT2, KB2, d2_blocks, d2t_blocks, d1t_blocks, d1k;     // Dense(|A|) kernel offset / width, dense2 / dense2t / dense1t block counts, K1
     int perm_hw, perm_c;                // > 0: plane index k' = p*perm_c + c of the dense forward is Keras weight row c*perm_hw + p
     int pack_wgs;
+    int w3q_off, w3q_rows;              // the folded dueling layer (qnet.h w3q): u32x4 offset, rows 16 KG3 (+ 1: the bias row); 0 rows = no dueling layer
+    int w3d_off, b3d_off, N3, n_actions;    // the dueling layer's kernel [N2][N3] and bias [N3] in params
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
@@ -1135,7 +1104,31 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
     const int w2_off = a.w2_off, w3_off = a.w3_off, d1_off = a.d1_off, d1_blocks = a.d1_blocks;
     const int lane = threadIdx.x & 63, blk_id = blockIdx.x * 4 + (threadIdx.x >> 6), j = lane & 15, kb = lane >> 4;
     const int e_d1 = PK_TOTAL_BLOCKS + d1_blocks, e_d2 = e_d1 + a.d2_blocks, e_d2t = e_d2 + a.d2t_blocks, e_d1t = e_d2t + a.d1t_blocks;
-    if (blk_id >= e_d1t) return;
+    if (blk_id >= e_d1t) {
+        // the dueling layer folded with its combination (qnet.h w3q): one wave per row k of the dueling kernel (row w3q_rows: its bias),
+        // lane = action a (+ 64): out[a] = (V + A_a) - mean_a' A_a', the mean by a fixed-order butterfly
+        const int r = blk_id - e_d1t;
+        if (r > a.w3q_rows || a.w3q_rows == 0) return;
+        const int pw = 16 * a.NT2, A = a.n_actions;
+        const bool live = r == a.w3q_rows || r < a.N2;
+        const float* src = r == a.w3q_rows ? params + a.b3d_off : params + a.w3d_off + (size_t)min(r, a.N2 - 1) * a.N3;
+        float va[2], sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h;
+            va[h] = (live && c < A) ? src[1 + c] : 0.f;
+            sum += va[h];
+        }
+        for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+        const float v0 = live ? src[0] : 0.f, mean = sum / (float)A;
+        float* dst = reinterpret_cast<float*>(pk + a.w3q_off) + (size_t)r * pw;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h;
+            if (c < pw) dst[c] = (live && c < A) ? (v0 + va[h]) - mean : 0.f;
+        }
+        return;
+    }
     float v[8];
     if (blk_id >= e_d2t) {                                          // dense1t (gX): B(n1 = 32 blk + 8kb + e, k' = 16 ct + j) = W1[row(k')][n1]
         const int tiles = a.d1k >> 4, b = blk_id - e_d2t, blk = b / tiles, ct = b - blk * tiles;
@@ -1202,7 +1195,9 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.dense2 = P.dense1 + (size_t)P.d1_blocks * PK_BLOCK;
     P.dense2t = P.dense2 + (size_t)P.d2_blocks * PK_BLOCK;
     P.dense1t = P.dense2t + (size_t)P.d2t_blocks * PK_BLOCK;
-    P.total = P.dense1t + (size_t)P.d1t_blocks * PK_BLOCK;
+    P.w3q = P.dense1t + (size_t)P.d1t_blocks * PK_BLOCK;
+    P.w3q_rows = Q->cfg.dueling ? (D2.nout <= 64 ? 64 : 128) : 0;  // 16 KG3 (dense_chain_kernel: KG3 = NT2 = 4 or 8)
+    P.total = P.w3q + ((size_t)(P.w3q_rows + 1) * 16 * P.NT2 + 3) / 4;
     return P;
 }
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return fused_pack_layout(Q).total; }
@@ -1228,7 +1223,9 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     const PackLayout PL = fused_pack_layout(Q);
     a.d2_off = (int)D2.w_off; a.N2 = D2.nout; a.NT2 = PL.NT2; a.KB2 = PL.KB2; a.d2_blocks = PL.d2_blocks; a.d2t_blocks = PL.d2t_blocks;
     a.d1t_blocks = PL.d1t_blocks; a.d1k = D1.nin;
-    a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + 3) / 4;
+    a.w3q_off = (int)PL.w3q; a.w3q_rows = PL.w3q_rows; a.n_actions = Q->cfg.n_actions;
+    if (Q->cfg.dueling) { const Layer& D3 = Q->L[nc + 2]; a.w3d_off = (int)D3.w_off; a.b3d_off = (int)D3.b_off; a.N3 = D3.nout; }
+    a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + 3) / 4;
     // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
     pack_weights_kernel<<<a.pack_wgs, 256, 0, st>>>(a);
     DQ_LAUNCH_CHECK();
@@ -1406,7 +1403,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     ca.kofftab = Q->kofftab; ca.rowtab = Q->kofftab + 96;
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_t1 = cp.off_t1; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2; ca.off_fx = cp.off_fx;
     const PackLayout PL = fused_pack_layout(Q);
-    da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = (int)PL.dense1; da.pk_dense2 = (int)PL.dense2;
+    da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = (int)PL.dense1; da.pk_dense2 = (int)PL.dense2; da.pk_w3q = (int)PL.w3q;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < Q->n_layers - nc; ++l) { da.w_off[l] = (int)Q->L[nc + l].w_off; da.b_off[l] = (int)Q->L[nc + l].b_off; }
     // two row tiles (32 samples) per dense workgroup -- half the weight stream per sample -- when one-tile workgroups would

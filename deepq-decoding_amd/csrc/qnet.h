@@ -208,7 +208,9 @@ struct ConvJob {
 //   dense2   [16][NT2]                           B(k = 32 blk + 8kb + e, col = NT2 j + t) = W2[k][col], 0 past N2                forward, Dense(|A|)
 //   dense2t  [KB2][32]                           B(n2 = 32 blk + 8kb + e, n1 = 64 (ct>>2) + 4j + (ct&3)) = W2[n1][n2], 0 past N2   backward, gH1
 //   dense1t  [16][K1/16]                         B(n1 = 32 blk + 8kb + e, k' = 16 ct + j) = W1[row(k')][n1]                         backward, gX
-struct PackLayout { size_t dense1, dense2, dense2t, dense1t, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2; };   // offsets in u32x4
+//   w3q      f32 [16 KG3 + 1][16 NT2]            the dueling layer folded with its combination (Q = y2 W3' + b3'): W3'[k][a] = W3[k][0] + W3[k][1 + a]
+//                                                - mean_a' W3[k][1 + a'], zero past N2 / |A|; the last row is b3' (the same map of the bias)                         forward, Q
+struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows; };   // offsets in u32x4
 PackLayout fused_pack_layout(const dq_qnet* Q);
 static inline int dq_planes_small_ld(const dq_qnet* Q) { return Q->cfg.n_actions + 1 <= 64 ? 64 : 128; }
 static inline size_t dq_planes_halves(const dq_qnet* Q) {      // total size of dq_qnet.planes
