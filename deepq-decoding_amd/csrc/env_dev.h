@@ -64,10 +64,13 @@ struct EnvParams {
                                    // referee look-up behind the syndrome is an LDS read instead of a dependent round trip to L2
 };
 
+// (lo, hi) |= v << s over 128 bits, 0 <= s < 128.  Branch-free on VALUES: written as three branches that update one word or the other, hipcc kept
+// the pair in SCRATCH memory and selected the word by address -- a load / wait / store round trip per call in the lattices' reset path.
 static __device__ __forceinline__ void or_shl128(u64& lo, u64& hi, u64 v, int s) {
-    if (s == 0) { lo |= v; }
-    else if (s < 64) { lo |= v << s; hi |= v >> (64 - s); }
-    else { hi |= v << (s - 64); }
+    const u64 l = s < 64 ? v << (s & 63) : 0ull;
+    const u64 h = s == 0 ? 0ull : (s < 64 ? v >> ((64 - s) & 63) : v << ((s - 64) & 63));
+    lo |= l;
+    hi |= h;
 }
 
 // One block of EPB lattices (64 * EPB threads, one lattice per wave); `block` = the block's number inside the environment part of the

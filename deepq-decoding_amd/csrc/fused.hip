@@ -1122,10 +1122,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
         for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
         const float v0 = live ? src[0] : 0.f, mean = sum / (float)A;
         float* dst = reinterpret_cast<float*>(pk + a.w3q_off) + (size_t)r * pw;
+        float* dstT = reinterpret_cast<float*>(pk + a.w3q_off) + (size_t)(a.w3q_rows + 1) * pw;      // W3'^T [a][k] (the dense backward's gY2 = dq W3'^T)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = lane + 64 * h;
-            if (c < pw) dst[c] = (live && c < A) ? (v0 + va[h]) - mean : 0.f;
+            const float o = (live && c < A) ? (v0 + va[h]) - mean : 0.f;
+            if (c < pw) { dst[c] = o; if (r < a.w3q_rows) dstT[(size_t)c * a.w3q_rows + r] = o; }
         }
         return;
     }
@@ -1197,7 +1199,7 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.dense1t = P.dense2t + (size_t)P.d2t_blocks * PK_BLOCK;
     P.w3q = P.dense1t + (size_t)P.d1t_blocks * PK_BLOCK;
     P.w3q_rows = Q->cfg.dueling ? (D2.nout <= 64 ? 64 : 128) : 0;  // 16 KG3 (dense_chain_kernel: KG3 = NT2 = 4 or 8)
-    P.total = P.w3q + ((size_t)(P.w3q_rows + 1) * 16 * P.NT2 + 3) / 4;
+    P.total = P.w3q + ((size_t)(2 * P.w3q_rows + 1) * 16 * P.NT2 + 3) / 4;   // W3' rows, the bias row, then W3'^T [16 NT2][w3q_rows]
     return P;
 }
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return fused_pack_layout(Q).total; }

@@ -60,8 +60,10 @@ struct DenseBwdArgs {
     int plane_rows, small_ld;
     unsigned short* gx_pl;              // gX [batch][K1] (NHWC) as f16 piece planes (h plane; the l plane gx_lo halves further): split on write --
     size_t gx_lo;                       // it is the convolutional backward's g3 operand, staged there by LDS-DMA and read without arithmetic
-    int ldg;                            // LDS row stride of the g3 image (floats); the gY2 planes have rows of 32 KB2 + 8 halves
+    int ldg;                            // LDS row stride of the dq image (floats); the gY2 planes have rows of 32 KB2 + 8 halves
     int off_g3, off_gy2, off_gh1;
+    int pk_w3q, w3q_rows, w3q_pw, off_w3t;  // the folded dueling layer (qnet.h w3q: W3' [w3q_rows + 1][w3q_pw], then W3'^T): u32x4 offset, rows, row stride
+                                        // (the FORWARD's tiling: 64 or 128); LDS offset of W3'^T
     float gs;                           // every gradient of the fused backward is carried scaled by this power of two (GradScale below) ...
     const float* gs_dev;                // ... or, when not NULL, by gs_dev[0] (computed on the device from max |dq|)
     int td_on, dense_wgs;               // td_on: dq is computed here from `td`; workgroups >= dense_wgs do the episode bookkeeping ...
@@ -294,20 +296,27 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             }
         }
     }
-    // ---- requested now, used two / three phases later: Dense(|A|+1)'s kernel for gY2, gH1's first weight block and mask operand --------
+    // ---- requested now, used two / three phases later: the folded dueling layer for gY2, gH1's first weight block and mask operand --------
+    // The dueling layer's backward and gY2 = g3 W3^T are ONE linear map of dq: gY2 = dq W3'^T, W3' the forward's folded matrix (qnet.h w3q).  With the
+    // TD step fused in, dq has one non-zero per row -- gY2[b] = dq[b][a_b] * W3'^T[a_b] --: a row of the 16 KB table, copied into LDS at the top, times
+    // a scalar; no dq image, no matrix phase, no barrier in between (SHORT: tables up to 64 x 64; round 3: that phase and its barrier were 3K of a
+    // workgroup's 34K cycles).  A caller's dense dq goes through the matrix pipe as before, K = |A|: the same bits where dq has one non-zero per row.
+    constexpr bool SHORT = TD && NT2 == 4;
+    constexpr int PW3 = 16 * NT2;
     float w3b[NT2][4];
-    if (wave < NT2) {
-        // (every wave, unconditional loads at clamped addresses -- waves >= NT2 and networks without a dueling layer read valid parameters they
-        // never use --, masked where they are used: a condition around a load is a branch with its own s_waitcnt)
-        const float* w3 = a.params + a.w_off[2];
-        const int n2 = 16 * min(wave, NT2 - 1) + j;
+    f32x4 wt3[2];
+    if constexpr (SHORT) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.packed + a.pk_w3q) + (size_t)(a.w3q_rows + 1) * PW3);
+        wt3[0] = N3 > 0 ? src[tid] : f32x4{0.f, 0.f, 0.f, 0.f};      // 64 x 64 floats = 2 x 16 bytes per thread
+        wt3[1] = N3 > 0 ? src[tid + DENSE_THREADS] : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (N3 > 0 && wave < NT2) {
+        const float* w3q = reinterpret_cast<const float*>(a.packed + a.pk_w3q);
+        const int n2 = 16 * wave + j;                               // (the table is zero-padded: rows past N2, columns past |A|)
 #pragma unroll
-        for (int g = 0; g < NT2; ++g)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k3 = 16 * g + 4 * kq + s;
-                w3b[g][s] = w3[(size_t)min(n2, N2 - 1) * N3 + max(min(k3, N3 - 1), 0)];
-            }
+        for (int g = 0; g < NT2; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w3q + (size_t)n2 * a.w3q_pw + 16 * g + 4 * kq);
+            w3b[g][0] = v[0]; w3b[g][1] = v[1]; w3b[g][2] = v[2]; w3b[g][3] = v[3];
+        }
     }
     Gh1Pre gh1_pre;
     gh1_preload(a, b0, wave, lane, gh1_pre);
@@ -328,7 +337,12 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         ridx[0] = *p0; ridx[1] = *p1;
     }
     __shared__ float s_met[DENSE_WAVES][2];
-    for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) s_g3[i] = 0.f;
+    if constexpr (SHORT) {
+        f32x4* s_w3t = reinterpret_cast<f32x4*>(smem + a.off_w3t);  // W3'^T [a][n2] (waited for here: the loads went out first of all)
+        s_w3t[tid] = wt3[0]; s_w3t[tid + DENSE_THREADS] = wt3[1];
+    } else {
+        for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) s_g3[i] = 0.f;
+    }
     for (int i = tid; i < DENSE_ROWS * LDY; i += DENSE_THREADS) reinterpret_cast<u32*>(s_gy2p)[i] = 0u;      // both planes (2 x 16 x LDY halves)
     if constexpr (TD) {                                             // the replay rows' fields: in flight across the barrier
 #pragma unroll
@@ -413,15 +427,23 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             unsigned short* p3 = a.g3_pl + (size_t)b * a.small_ld;   // the same values as pieces: the dueling layer's weight gradient
             const size_t lo3 = (size_t)a.plane_rows * a.small_ld;
             unsigned short ph, pl;
-            if (lane == 0) { s_g3[row * ldg] = s; split_f16x2_one(s, ph, pl); p3[0] = ph; p3[lo3] = pl; }
+            if (lane == 0) { split_f16x2_one(s, ph, pl); p3[0] = ph; p3[lo3] = pl; }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
                 if (c >= A) continue;
-                const float v = dval(h) - s / (float)A;
-                s_g3[row * ldg + 1 + c] = v;
+                const float dv = dval(h), v = dv - s / (float)A;    // g3 = the dueling layer's output gradient: its weight gradient's operand (pieces, HBM)
+                if constexpr (!SHORT) s_g3[row * ldg + c] = dv;     // the dq image: gY2's operand below
                 split_f16x2_one(v, ph, pl);
                 p3[1 + c] = ph; p3[lo3 + 1 + c] = pl;
+            }
+            if constexpr (SHORT) {                                  // gY2[row] = dq[row][a_b] * W3'^T[a_b]: lane = column n2 (zero past N2: the table's padding)
+                const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
+                const float* s_w3t = reinterpret_cast<const float*>(smem + a.off_w3t);
+                const float gy = s_w3t[min(max(ab, 0), PW3 - 1) * PW3 + lane] * s;
+                const _Float16 vh = (_Float16)gy, vl = (_Float16)((gy - (float)vh) * F16_LO_SCALE);      // split on write (qnet.h)
+                s_gy2p[row * LDY + lane] = __builtin_bit_cast(unsigned short, vh);
+                s_gy2p[(DENSE_ROWS + row) * LDY + lane] = __builtin_bit_cast(unsigned short, vl);
             }
         } else {
 #pragma unroll
@@ -457,15 +479,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         for (int t = 0; t < 4; ++t) { gh1_pre.bw0[t].h = pk[t * PK_BLOCK]; gh1_pre.bw0[t].l = pk[t * PK_BLOCK + PK_LO]; }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- gY2 = g3 W3^T  (K = N3, one column tile per wave) -------------------------------------------------------------
-    if (N3 > 0) {
+    // ---- gY2 = dq W3'^T  (K = |A|, one column tile per wave; SHORT: done above, row by row) ---------------------------------------
+    if (!SHORT && N3 > 0) {
         if (wave < NT2) {
             const int n2 = 16 * wave + j;
-            float (&b)[NT2][4] = w3b;                               // (requested at the top of the kernel, raw: masked here)
-#pragma unroll
-            for (int g = 0; g < NT2; ++g)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) b[g][s] = (n2 < N2 && 16 * g + 4 * kq + s < N3) ? b[g][s] : 0.f;
+            float (&b)[NT2][4] = w3b;                               // (requested at the top of the kernel; zero-padded)
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* grow = s_g3 + j * ldg + 4 * kq;
 #pragma unroll
@@ -1430,7 +1448,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct DenseBwdPlan { int NT2, ldg, off_g3, off_gy2, off_gh1; size_t lds; };
+struct DenseBwdPlan { int NT2, ldg, off_g3, off_gy2, off_gh1, off_w3t; size_t lds; };
 
 static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     const int nc = Q->cfg.n_conv;
@@ -1446,6 +1464,7 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     P->off_g3 = (int)off; off += up16((size_t)DENSE_ROWS * P->ldg * 4);
     P->off_gy2 = (int)off; off += up16((size_t)2 * DENSE_ROWS * (32 * (N2 <= 64 ? 2 : 4) + 8) * 2);   // f16 piece planes (K padded to 2 or 4 blocks)
     P->off_gh1 = (int)off; off += up16((size_t)2 * DENSE_ROWS * (DENSE_HID + 8) * 2);
+    P->off_w3t = (int)off; if (P->NT2 == 4 && N3 > 0) off += (size_t)64 * 64 * 4;      // W3'^T (the TD launch's gY2 shortcut, dense_bwd_chain_kernel SHORT)
     P->lds = off;
     return true;
 }
@@ -1596,7 +1615,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     for (int l = 0; l < nl - nc; ++l) da.w_off[l] = (int)Q->L[nc + l].w_off;
     da.mask_scale = D1.dropout > 0.f ? (float)(1.0 / (1.0 - (double)D1.dropout)) : 1.f;
     da.gx_pl = reinterpret_cast<unsigned short*>(Q->gz[nc - 1]); da.gx_lo = (size_t)Q->cfg.max_batch * D1.nin;
-    da.ldg = dp.ldg; da.off_g3 = dp.off_g3; da.off_gy2 = dp.off_gy2; da.off_gh1 = dp.off_gh1;
+    da.ldg = dp.ldg; da.off_g3 = dp.off_g3; da.off_gy2 = dp.off_gy2; da.off_gh1 = dp.off_gh1; da.off_w3t = dp.off_w3t;
+    da.pk_w3q = (int)PL.w3q; da.w3q_rows = PL.w3q_rows; da.w3q_pw = 16 * PL.NT2;
     da.dense_wgs = (B + DENSE_ROWS - 1) / DENSE_ROWS;
     int stat_wgs = 0;
     if (td) {

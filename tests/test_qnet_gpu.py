@@ -306,8 +306,11 @@ def test_backward_adam_equals_backward_then_adam(dq, torch_mod, fused):
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
 def test_td_backward_adam_equals_the_separate_calls(dq, torch_mod, fused):
-    """dq_qnet_td_backward_adam == dq_td_update_stats + dq_qnet_backward + dq_adam_step: y, dq, gradient, parameters, moments and the
-    episode counters bit for bit; loss / mean_q to round-off (their partials are summed in another order)."""
+    """dq_qnet_td_backward_adam == dq_td_update_stats + dq_qnet_backward + dq_adam_step: y, dq and the episode counters bit for bit; loss / mean_q
+    to round-off (their partials are summed in another order); gradient, parameters and moments bit for bit on the per-layer path and between the
+    two forms of the fused TD launch (one call / the several-GPU phases), and to round-off between the fused TD launch and the separate calls:
+    with the TD step fused in, dq has one non-zero per row and the fused backward forms gY2 = dq W3'^T as a scalar times a table row instead of on
+    the matrix pipe (csrc/fused_bwd.hip SHORT) -- the f32 MFMA does not round a lone product as the vector ALU's multiply does."""
     torch = torch_mod
     from importlib import import_module
     Q = import_module("deepq-decoding_amd.qnet")
@@ -343,8 +346,14 @@ def test_td_backward_adam_equals_the_separate_calls(dq, torch_mod, fused):
                 net.td_backward_adam(p_, td, g_, m_, v_, t, 1e-3)
             Q.td_metrics(met, B)
         out[name] = [x.clone() for x in (y, dq_, g_, p_, m_, v_, stats, met[:2])]
-    for a, b in zip(out["separate"][:7], out["one"][:7]):
-        assert torch.equal(a, b)
+    def same(a, b, k):
+        if fused and 1 <= k <= 5:                      # dq of the second step, gradient, parameters, moments: see the docstring
+            err, scale = float((a - b).abs().max()), float(a.abs().max())
+            # (parameters: Adam divides by sqrt(v) + 1e-7 -- where a gradient element is itself ~1e-8, a last-bit difference moves the step)
+            return err <= (5e-5 if k == 3 else 1e-6 * max(scale, 1e-30))
+        return torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(out["separate"][:7], out["one"][:7])):
+        assert same(a, b, k), k
     # the several-GPU form: TD + phase 0, then phase 1 and the optimizer step as separate calls
     p_, m_, v_ = params.clone(), torch.zeros_like(params), torch.zeros_like(params)
     g_ = torch.empty_like(params)
@@ -358,7 +367,7 @@ def test_td_backward_adam_equals_the_separate_calls(dq, torch_mod, fused):
         net.td_backward_phase0(p_, td, g_)
         net.backward_phase(p_, dq_, g_, 1)
         Q.adam_step(p_, g_, m_, v_, t, 1e-3)
-    for a, b in zip(out["separate"][:7], (y, dq_, g_, p_, m_, v_, stats)):
+    for a, b in zip(out["one"][:7], (y, dq_, g_, p_, m_, v_, stats)):      # both run the TD launch: bit for bit
         assert torch.equal(a, b)
     assert torch.allclose(out["separate"][7], out["one"][7], rtol=1e-5, atol=1e-7)
     assert out["one"][6].tolist()[3] == 2 * int((was_reset == 0).sum())
