@@ -523,6 +523,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
         }
     };
 
+    // the patch-origin table, ONCE per workgroup: entry m = sample << 20 | (sample * slot + offset of the patch inside the observation); what changes from
+    // group to group is only each sample's alignment offset (s_mis), added at the use.  (Rebuilt per group -- it lived in the core that a2 overlays --
+    // it cost every group a pass over the table and a barrier of its own: 0.7K of a group's 17K cycles.)
+    {
+        int* s_t1c = reinterpret_cast<int*>(smem + a.off_t1);
+        for (int m = tid; m < MF1; m += CONV_THREADS) {
+            const int e = m == tid ? tab1 : a.rowtab[m], s = e >> 20;
+            s_t1c[m] = (e & ~0x1ffff) | (s * a.slot + (e & 0x1ffff));
+        }
+    }
     int gid = (int)blockIdx.x, cur = 0;
     int gk = 0; (void)gk;                                           // group count of this workgroup (stamps: 8 per group)
     load_w1(a.job[job_of(gid)]);
@@ -556,16 +566,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 1);
         const int nxt = gid + gstride;
         if (nxt < total) issue(pre, cur ^ 1);                       // block-uniform
-        for (int m = tid; m < M1; m += CONV_THREADS) {              // table entry: sample << 20 | offset of the patch inside the observation
-            const int e = m == tid ? tab1 : rowtab[m], s = e >> 20;
-            s_t1[m] = s * a.slot + s_mis[cur * 16 + s] + (e & 0x1ffff);
-        }
-        __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 2);
         // ---- convolution 1 (conv_chain_kernel's, on rows of 64 halves) ------------------------------------------------------------
         {
             const int tiles = (M1 + 15) >> 4;
-            auto origin = [&](int tile) { return s_t1[min(tile * 16 + j, M1 - 1)]; };
+            auto origin = [&](int tile) {                           // (constant table entry + the sample's alignment offset of THIS group)
+                const int e = s_t1[min(tile * 16 + j, M1 - 1)];
+                return (e & 0x1ffff) + s_mis[cur * 16 + (e >> 20)];
+            };
             auto rd = [&](int org, u32 (&ab)[NH1][8]) {
                 const u8* ap = s_in + org;
 #pragma unroll
@@ -1285,8 +1293,9 @@ static bool plan_conv_persist(const dq_qnet* Q, ConvPlanP* P) {
             size_t off = 2 * obs + core;
             const size_t a1 = off; off += up16((size_t)2 * (CONV1_PIPE ? (S * L1.rows + 15) & ~15 : S * L1.rows) * 64 * 2);
             const size_t mis = off; off += 2 * 16 * 4;
+            const size_t t1c = off; off += t1b;                     // the patch-origin table, constant over the groups: a place of its own (a2 overlays the core)
             if (off <= budget && S * L1.rows <= CONV_ROWTAB) {
-                P->S = S; P->slot = base.slot; P->off_t1 = (int)obs; P->off_obs1 = (int)(obs + core); P->off_a2b = (int)(2 * obs + core - a2b);
+                P->S = S; P->slot = base.slot; P->off_t1 = (int)t1c; P->off_obs1 = (int)(obs + core); P->off_a2b = (int)(2 * obs + core - a2b);
                 P->off_a1 = (int)a1; P->off_mis = (int)mis; P->lds = off; P->per_cu = pass == 0 ? 2 : 1;
                 return true;
             }
