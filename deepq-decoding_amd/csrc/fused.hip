@@ -1104,6 +1104,7 @@ struct PackArgs {
     int pack_wgs;
     int w3q_off, w3q_rows;              // the folded dueling layer (qnet.h w3q): u32x4 offset, rows 16 KG3 (+ 1: the bias row); 0 rows = no dueling layer
     int w3d_off, b3d_off, N3, n_actions;    // the dueling layer's kernel [N2][N3] and bias [N3] in params
+    int wc_off, wc_waves;               // Wc (qnet.h wc: the dense backward's gH1 rows with the TD step fused in): u32x4 offset, waves that build it (0: none)
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
@@ -1116,7 +1117,28 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
         // the dueling layer folded with its combination (qnet.h w3q): one wave per row k of the dueling kernel (row w3q_rows: its bias),
         // lane = action a (+ 64): out[a] = (V + A_a) - mean_a' A_a', the mean by a fixed-order butterfly
         const int r = blk_id - e_d1t;
-        if (r > a.w3q_rows || a.w3q_rows == 0) return;
+        if (a.w3q_rows == 0) return;
+        if (r > a.w3q_rows) {
+            // Wc [|A|][512] = W3'^T W2^T: row a = what gH1 = gY2 W2^T is for a sample whose dq is 1 at action a (times its TD error: fused_bwd.hip).
+            // One wave per hidden unit n1: lane c forms P[c] = sum_n2 W2[n1][n2] W3[n2][c] (the plain product's row: W2's row through scalar loads, W3's
+            // rows coalesced, n2 in order), then the dueling fold ALONG the row -- Wc[a][n1] = P[0] + P[1 + a] - mean_a' P[1 + a'] -- by a butterfly.
+            const int n1 = r - a.w3q_rows - 1;
+            if (n1 >= a.wc_waves) return;
+            const int A = a.n_actions, N2 = a.N2, N3 = a.N3;
+            const __attribute__((address_space(4))) float* w2 = (const __attribute__((address_space(4))) float*)(uintptr_t)(params + a.d2_off + (size_t)n1 * N2);
+            const float* W3 = params + a.w3d_off;
+            const int c = min(lane, N3 - 1);
+            float acc = 0.f, wv[64];
+#pragma unroll
+            for (int n2 = 0; n2 < 64; ++n2) wv[n2] = W3[(size_t)min(n2, N2 - 1) * N3 + c];      // all in flight (a run-time trip count = one round trip per term)
+#pragma unroll
+            for (int n2 = 0; n2 < 64; ++n2) acc = fmaf(n2 < N2 ? w2[n2] : 0.f, wv[n2], acc);
+            float adv = (lane >= 1 && lane <= A) ? acc : 0.f;
+            for (int m = 32; m >= 1; m >>= 1) adv += __shfl_xor(adv, m);
+            const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc)));      // lane 0: the V column
+            if (lane >= 1 && lane <= A) reinterpret_cast<float*>(pk + a.wc_off)[(size_t)(lane - 1) * DENSE_HID + n1] = (v0 + acc) - adv / (float)A;
+            return;
+        }
         const int pw = 16 * a.NT2, A = a.n_actions;
         const bool live = r == a.w3q_rows || r < a.N2;
         const float* src = r == a.w3q_rows ? params + a.b3d_off : params + a.w3d_off + (size_t)min(r, a.N2 - 1) * a.N3;
@@ -1207,7 +1229,9 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.dense1t = P.dense2t + (size_t)P.d2t_blocks * PK_BLOCK;
     P.w3q = P.dense1t + (size_t)P.d1t_blocks * PK_BLOCK;
     P.w3q_rows = Q->cfg.dueling ? (D2.nout <= 64 ? 64 : 128) : 0;  // 16 KG3 (dense_chain_kernel: KG3 = NT2 = 4 or 8)
-    P.total = P.w3q + ((size_t)(2 * P.w3q_rows + 1) * 16 * P.NT2 + 3) / 4;   // W3' rows, the bias row, then W3'^T [16 NT2][w3q_rows]
+    P.wc = P.w3q + ((size_t)(2 * P.w3q_rows + 1) * 16 * P.NT2 + 3) / 4;      // W3' rows, the bias row, then W3'^T [16 NT2][w3q_rows]
+    P.wc_rows = (Q->cfg.dueling && P.NT2 == 4) ? Q->cfg.n_actions : 0;     // (the dense backward's shortcut: tables up to 64 x 64)
+    P.total = P.wc + (size_t)P.wc_rows * DENSE_HID / 4;
     return P;
 }
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return fused_pack_layout(Q).total; }
@@ -1235,7 +1259,8 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     a.d1t_blocks = PL.d1t_blocks; a.d1k = D1.nin;
     a.w3q_off = (int)PL.w3q; a.w3q_rows = PL.w3q_rows; a.n_actions = Q->cfg.n_actions;
     if (Q->cfg.dueling) { const Layer& D3 = Q->L[nc + 2]; a.w3d_off = (int)D3.w_off; a.b3d_off = (int)D3.b_off; a.N3 = D3.nout; }
-    a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + 3) / 4;
+    a.wc_off = (int)PL.wc; a.wc_waves = PL.wc_rows ? DENSE_HID : 0;
+    a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + a.wc_waves + 3) / 4;
     // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
     pack_weights_kernel<<<a.pack_wgs, 256, 0, st>>>(a);
     DQ_LAUNCH_CHECK();

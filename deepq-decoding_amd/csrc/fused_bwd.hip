@@ -62,6 +62,7 @@ struct DenseBwdArgs {
     size_t gx_lo;                       // it is the convolutional backward's g3 operand, staged there by LDS-DMA and read without arithmetic
     int ldg;                            // LDS row stride of the dq image (floats); the gY2 planes have rows of 32 KB2 + 8 halves
     int off_g3, off_gy2, off_gh1;
+    int pk_wc;                          // Wc (qnet.h wc), u32x4 offset
     int pk_w3q, w3q_rows, w3q_pw, off_w3t;  // the folded dueling layer (qnet.h w3q: W3' [w3q_rows + 1][w3q_pw], then W3'^T): u32x4 offset, rows, row stride
                                         // (the FORWARD's tiling: 64 or 128); LDS offset of W3'^T
     float gs;                           // every gradient of the fused backward is carried scaled by this power of two (GradScale below) ...
@@ -318,8 +319,22 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             w3b[g][0] = v[0]; w3b[g][1] = v[1]; w3b[g][2] = v[2]; w3b[g][3] = v[3];
         }
     }
+    // SHORT goes one step further: gH1 = gY2 W2^T = dq[b][a_b] * Wc[a_b], Wc = W3'^T W2^T [|A|][512] built by pack_weights_kernel -- a 2 KB row of an
+    // L2-resident table times a scalar, masked; every wave forms the gH1 rows of ITS two samples (whose TD error and action it holds): no matrix
+    // phase, no W2^T stream (64 KB per workgroup), no barrier (round 3: that phase was 5.5K of a workgroup's 30K cycles).  Its mask operand -- the
+    // saved hidden output's pieces of the wave's rows, eight units per lane -- is requested here.
     Gh1Pre gh1_pre;
-    gh1_preload(a, b0, wave, lane, gh1_pre);
+    u32x4 mkh[RPW], mkl[RPW];
+    if constexpr (SHORT) {
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const unsigned short* hp = a.h1_pl + (size_t)(b0 + min(wave + DENSE_WAVES * u, ns - 1)) * DENSE_HID + 8 * lane;
+            mkh[u] = *reinterpret_cast<const u32x4*>(hp);
+            mkl[u] = *reinterpret_cast<const u32x4*>(hp + (size_t)a.plane_rows * DENSE_HID);
+        }
+    } else {
+        gh1_preload(a, b0, wave, lane, gh1_pre);
+    }
     __builtin_amdgcn_sched_barrier(0);                              // (hipcc sinks a load next to its use: these stay up here)
     // (wave-uniform rows: SCALAR loads through the constant address space -- the index vector is not written while this kernel runs, the
     // riders draw the next update's rows into the other buffer (core.py) --, both addresses formed first so that the two loads go out together,
@@ -355,6 +370,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     }
     __syncthreads();
     DQ_STAMP(DQ_TAG_DENSE_BWD, 6);
+    f32x4 wcr[RPW][2];                                              // SHORT: this wave's rows of Wc, in flight under the TD arithmetic below
+    if constexpr (SHORT) {
+        const float* wc = reinterpret_cast<const float*>(a.packed + a.pk_wc);
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
+            const f32x4* row = reinterpret_cast<const f32x4*>(wc + (size_t)min(max(ab, 0), A - 1) * DENSE_HID + 8 * lane);
+            wcr[u][0] = row[0]; wcr[u][1] = row[1];
+        }
+    }
     // ---- (TD step: y = r + gamma (1 - terminal) Q_target(s1)[argmax Q_online(s1)], dq = (Q(s0)[a] - y) * scale at the action taken,
     //      dqn.hip td_update_kernel's arithmetic, one wave per sample) then the dueling backward:
     //      g3[b,0] = sum_a dq[b,a];  g3[b,1+a] = dq[b,a] - (1/A) sum_a' dq[b,a'] ---------------------------------------------
@@ -444,6 +469,25 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
                 const _Float16 vh = (_Float16)gy, vl = (_Float16)((gy - (float)vh) * F16_LO_SCALE);      // split on write (qnet.h)
                 s_gy2p[row * LDY + lane] = __builtin_bit_cast(unsigned short, vh);
                 s_gy2p[(DENSE_ROWS + row) * LDY + lane] = __builtin_bit_cast(unsigned short, vl);
+                // gH1[row] = dq[row][a_b] * Wc[a_b] * [h1 > 0] / (1 - rate): this lane's eight units, split on write into the planes gX reads
+                // (LDS) and the weight gradient reads (HBM)
+                constexpr int LDH = DENSE_HID + 8;
+                u32x4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32 mw = (e < 2 ? (e == 0 ? mkh[u][0] | mkl[u][0] : mkh[u][1] | mkl[u][1]) : (e == 2 ? mkh[u][2] | mkl[u][2] : mkh[u][3] | mkl[u][3]));
+                    const float w0 = wcr[u][e >> 1][2 * (e & 1)], w1 = wcr[u][e >> 1][2 * (e & 1) + 1];
+                    const float v0 = (mw & 0x7fffu) ? w0 * s * a.mask_scale : 0.f;          // (pieces of a value >= 0: any magnitude bit set <=> it was > 0)
+                    const float v1 = (mw & 0x7fff0000u) ? w1 * s * a.mask_scale : 0.f;
+                    u32 hq, lq;
+                    split_f16x2_pair(v0, v1, hq, lq);
+                    oh[e] = hq; ol[e] = lq;
+                }
+                *reinterpret_cast<u32x4*>(s_gh1p + row * LDH + 8 * lane) = oh;
+                *reinterpret_cast<u32x4*>(s_gh1p + (DENSE_ROWS + row) * LDH + 8 * lane) = ol;
+                unsigned short* gp = a.gh1_pl + (size_t)b * DENSE_HID + 8 * lane;
+                *reinterpret_cast<u32x4*>(gp) = oh;
+                *reinterpret_cast<u32x4*>(gp + (size_t)a.plane_rows * DENSE_HID) = ol;
             }
         } else {
 #pragma unroll
@@ -516,8 +560,10 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         }
     }
     // ---- gH1 (f16x2; K = N2 in 2 or 4 blocks) ---------------------------------------------------------------------------------------
-    if (a.KB2 == 2) gh1_phase<2>(a, s_gy2p, s_gh1p, b0, ns, wave, lane, gh1_pre);       // block-uniform
-    else gh1_phase<4>(a, s_gy2p, s_gh1p, b0, ns, wave, lane, gh1_pre);
+    if constexpr (!SHORT) {                                         // (SHORT: every wave wrote its rows above)
+        if (a.KB2 == 2) gh1_phase<2>(a, s_gy2p, s_gh1p, b0, ns, wave, lane, gh1_pre);       // block-uniform
+        else gh1_phase<4>(a, s_gy2p, s_gh1p, b0, ns, wave, lane, gh1_pre);
+    }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 3);
     __syncthreads();
     DQ_STAMP(DQ_TAG_DENSE_BWD, 4);
@@ -1616,7 +1662,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     da.mask_scale = D1.dropout > 0.f ? (float)(1.0 / (1.0 - (double)D1.dropout)) : 1.f;
     da.gx_pl = reinterpret_cast<unsigned short*>(Q->gz[nc - 1]); da.gx_lo = (size_t)Q->cfg.max_batch * D1.nin;
     da.ldg = dp.ldg; da.off_g3 = dp.off_g3; da.off_gy2 = dp.off_gy2; da.off_gh1 = dp.off_gh1; da.off_w3t = dp.off_w3t;
-    da.pk_w3q = (int)PL.w3q; da.w3q_rows = PL.w3q_rows; da.w3q_pw = 16 * PL.NT2;
+    da.pk_w3q = (int)PL.w3q; da.w3q_rows = PL.w3q_rows; da.w3q_pw = 16 * PL.NT2; da.pk_wc = (int)PL.wc;
     da.dense_wgs = (B + DENSE_ROWS - 1) / DENSE_ROWS;
     int stat_wgs = 0;
     if (td) {

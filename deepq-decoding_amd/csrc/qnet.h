@@ -211,7 +211,8 @@ struct ConvJob {
 //   w3q      f32 [16 KG3 + 1][16 NT2]            the dueling layer folded with its combination (Q = y2 W3' + b3'): W3'[k][a] = W3[k][0] + W3[k][1 + a]
 //                                                - mean_a' W3[k][1 + a'], zero past N2 / |A|; the last row is b3' (the same map of the bias)                         forward, Q
 //            then f32 [16 NT2][16 KG3]           its transpose W3'^T [a][k]: the dueling backward folded the same way, gY2 = dq W3'^T                             backward, gY2
-struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows; };   // offsets in u32x4
+//   wc       f32 [|A|][512]                      Wc = W3'^T W2^T (Dense(|A|) folded in as well): row a = gH1 of a sample whose dq is 1 at action a               backward, gH1 (TD launch)
+struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows; };   // offsets in u32x4
 PackLayout fused_pack_layout(const dq_qnet* Q);
 static inline int dq_planes_small_ld(const dq_qnet* Q) { return Q->cfg.n_actions + 1 <= 64 ? 64 : 128; }
 static inline size_t dq_planes_halves(const dq_qnet* Q) {      // total size of dq_qnet.planes
