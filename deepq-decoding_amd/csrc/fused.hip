@@ -1038,9 +1038,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     // ---- training: Dense(|A|)'s output leaves as pieces (the dueling layer's weight gradient), eight columns per thread = one 16-byte store
     //      per piece (as single halves from the reduction loop these were 26 two-byte stores per thread); columns past N2 are the image's zeros
     if (J.y2_pl) {                                                  // block-uniform
-        const int per_row = J.small_ld >> 3;
+        const int per_row = J.small_ld >> 3, prs = J.small_ld == 64 ? 3 : 4;        // (small_ld is 64 or 128: shifts, not a division)
         for (int i = tid; i < ROWS * per_row; i += DENSE_THREADS) {
-            const int row = i / per_row, c8 = (i - row * per_row) * 8;
+            const int row = i >> prs, c8 = (i - (row << prs)) * 8;
             if (row >= ns) continue;
             const float* yp = s_y2 + row * a.ld2 + c8;
             const F16x2 o = split_f16x2(f32x4{yp[0], yp[1], yp[2], yp[3]}, f32x4{yp[4], yp[5], yp[6], yp[7]});

@@ -552,8 +552,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     // ---- gY2's piece planes also leave for the weight gradient of Dense(|A|): 16 rows x 32 KB2 halves per plane, 16 bytes per thread ----
     {
         const int per_row = 4 * a.KB2, n16 = DENSE_ROWS * per_row;  // 16-byte pieces per row / per plane
+        const int prs = a.KB2 == 2 ? 3 : 4;                         // (KB2 is 2 or 4: shifts, not divisions)
         for (int i = tid; i < 2 * n16; i += DENSE_THREADS) {
-            const int piece = i / n16, r = (i - piece * n16) / per_row, c8 = (i - piece * n16) - r * per_row;
+            const int piece = i >> (prs + 4), r = (i >> prs) & (DENSE_ROWS - 1), c8 = i & (per_row - 1);
             if (r < ns)
                 *reinterpret_cast<u32x4*>(a.gy2_pl + ((size_t)piece * a.plane_rows + b0 + r) * a.small_ld + 8 * c8) =
                     *reinterpret_cast<const u32x4*>(s_gy2p + (piece * DENSE_ROWS + r) * LDY + 8 * c8);
