@@ -1069,22 +1069,35 @@ __device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const voi
             for (int t = 0; t < 2; ++t) mma_f16x3(av[tap], bw[tap][t], acc[t][0], acc[t][1]);
         }
         // C/D layout: col = lane & 15 -> channel c_lo + 2j + t (the packed weights' column order), row = (lane >> 4) * 4 + reg
+        if constexpr (OPL) {
+            // this lane's two results are ADJACENT channels c_lo + 2j, + 1 (the packed weights' column order, qnet.h PK_CONV*_DG): the
+            // activation's pieces and the result's are one 4-byte LDS access per plane.  The four rows' mask words are read TOGETHER, at
+            // clamped rows, before the first result is formed (round 3: under `if (mo >= M) continue` each row was a branch with its own
+            // s_waitcnt -- four LDS latencies in a row per tile); only the stores are guarded.
+            u32 bits[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const u32* ph = reinterpret_cast<const u32*>(static_cast<const unsigned short*>(actv) + min(tile * 16 + 4 * kb + r, M - 1) * PSA + c_lo + 2 * j);
+                bits[r] = ph[0] | ph[act_lo >> 1];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mo = tile * 16 + 4 * kb + r;
+                const bool in = mo < M;
+                const float v0 = (in && (bits[r] & 0x7fffu) != 0u) ? f16x2_sum(acc[0][0][r], acc[0][1][r]) : 0.f;
+                const float v1 = (in && (bits[r] & 0x7fff0000u) != 0u) ? f16x2_sum(acc[1][0][r], acc[1][1][r]) : 0.f;
+                colsum[0] += v0; colsum[1] += v1;
+                u32 h, l;
+                split_f16x2_pair(v0, v1, h, l);
+                u32* ph = reinterpret_cast<u32*>(static_cast<unsigned short*>(actv) + mo * PSA + c_lo + 2 * j);
+                if (in) { ph[0] = h; ph[act_lo >> 1] = l; }
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mo = tile * 16 + 4 * kb + r;
             if (mo >= M) continue;
-            if constexpr (OPL) {
-                // this lane's two results are ADJACENT channels c_lo + 2j, + 1 (the packed weights' column order, qnet.h PK_CONV*_DG): the
-                // activation's pieces and the result's are one 4-byte LDS access per plane
-                u32* ph = reinterpret_cast<u32*>(static_cast<unsigned short*>(actv) + mo * PSA + c_lo + 2 * j);
-                const u32 bits = ph[0] | ph[act_lo >> 1];
-                const float v0 = (bits & 0x7fffu) != 0u ? f16x2_sum(acc[0][0][r], acc[0][1][r]) : 0.f;
-                const float v1 = (bits & 0x7fff0000u) != 0u ? f16x2_sum(acc[1][0][r], acc[1][1][r]) : 0.f;
-                colsum[0] += v0; colsum[1] += v1;
-                u32 h, l;
-                split_f16x2_pair(v0, v1, h, l);
-                ph[0] = h; ph[act_lo >> 1] = l;
-            } else {
+            {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float* p = static_cast<float*>(actv) + mo * PSA + c_lo + 2 * j + t;
