@@ -1518,7 +1518,7 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     const int N2 = D2.nout, N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0;
     const int widest = N3 > N2 ? N3 : N2;
     if (widest > 112) return false;
-    P->NT2 = widest <= 64 ? 4 : 7;
+    P->NT2 = (widest <= 64 && N3 > 0) ? 4 : 7;                      // (the 4-tile kernel's TD form folds the dueling layer -- SHORT, below --: a network without one takes the general kernel)
     P->ldg = 16 * P->NT2 + 4;
     size_t off = 0;
     P->off_g3 = (int)off; off += up16((size_t)DENSE_ROWS * P->ldg * 4);

@@ -304,6 +304,46 @@ def test_backward_adam_equals_backward_then_adam(dq, torch_mod, fused):
     assert not torch.equal(pa, params)
 
 
+def test_td_backward_adam_without_a_dueling_layer(dq, torch_mod):
+    """A network without the dueling layer has nothing to fold: its fused TD launch takes the general dense backward and equals the separate calls
+    (TD kernel + backward + Adam) bit for bit; the gradient matches the oracle."""
+    torch = torch_mod
+    from importlib import import_module
+    Q = import_module("deepq-decoding_amd.qnet")
+    B, A, R = 40, 51, 300
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", B, dueling=False)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    obs_t = cu(obs)
+    q1o, q1t = (cu(rng.randn(B, A).astype(np.float32)) for _ in range(2))
+    reward, terminal = cu((rng.rand(R) < 0.4).astype(np.float32)), cu((rng.rand(R) < 0.2).astype(np.uint8))
+    action, idx = cu(rng.randint(0, A, size=R).astype(np.int32)), cu(rng.randint(0, R, size=B).astype(np.int32))
+    out = {}
+    for name in ("separate", "one"):
+        p_, m_, v_ = params.clone(), torch.zeros_like(params), torch.zeros_like(params)
+        g_ = torch.empty_like(params)
+        met = torch.zeros(Q.TD_METRICS_FLOATS, dtype=torch.float32, device="cuda")
+        y, dq_ = torch.empty(B, device="cuda"), torch.empty((B, A), device="cuda")
+        q0 = net.forward(p_, obs_t, training=True, seed=(1, 2), t=1)
+        td = dict(q_online_s1=q1o, q_target_s1=q1t, q_s0=q0, reward=reward, terminal=terminal, action=action, gamma=0.99,
+                  grad_scale=1.0 / B, index=idx, y=y, dq=dq_, metrics=met)
+        if name == "separate":
+            Q.td_update(q1o, q1t, q0, reward, terminal, action, 0.99, grad_scale=1.0 / B, index=idx, y=y, dq=dq_, metrics=met)
+            net.set_grad_scale(1.0 / B)
+            net.backward(p_, dq_, grads=g_)
+            net.set_grad_scale(0.0)
+            Q.adam_step(p_, g_, m_, v_, 1, 1e-3)
+        else:
+            net.td_backward_adam(p_, td, g_, m_, v_, 1, 1e-3)
+        out[name] = [x.clone() for x in (y, dq_, g_, p_, m_, v_)]
+    for a, b in zip(out["separate"], out["one"]):
+        assert torch.equal(a, b)
+    keep = O.dropout_keep_mask((1, 2), 1, np.arange(B), 512, 0.2)
+    _, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    g_ref = O.backward(spec, flat, cache, out["one"][1].cpu().numpy().astype(np.float64))
+    g = out["one"][2].cpu().numpy()
+    assert np.abs(g - g_ref).max() < 2e-5 * max(np.abs(g_ref).max(), 1.0)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
 def test_td_backward_adam_equals_the_separate_calls(dq, torch_mod, fused):
     """dq_qnet_td_backward_adam == dq_td_update_stats + dq_qnet_backward + dq_adam_step: y, dq and the episode counters bit for bit; loss / mean_q
