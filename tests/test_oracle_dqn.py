@@ -197,3 +197,40 @@ def test_torch_fp32_learner_matches_float64_oracle():
     assert np.abs(g - g_ref).max() < 1e-5 * max(1.0, np.abs(g_ref).max())
     big = np.abs(g_ref) > 1e-5
     assert np.abs(learner.flat() - p_ref)[big].max() < 2e-5
+
+
+@pytest.mark.parametrize("name", ["c1", "c3"])
+def test_dueling_layer_folds_into_one_matrix(name):
+    """The identities the HIP path rests on (csrc/qnet.h w3q / wc), checked on the oracle: keras-rl's dueling layer
+    Dense(|A| + 1) and its Lambda Q = V + A - mean(A) sit behind the model's last LINEAR layer, so with W3' = W3 C^T, b3' = C b3 (C the
+    combination) the forward is Q = y2 W3' + b3'; the backward of both is gY2 = dq W3'^T; and where dq has one non-zero per row (the TD
+    loss) gY2[b] = dq[b, a_b] W3'^T[a_b] and gH1[b] = dq[b, a_b] (W3'^T W2^T)[a_b] * mask."""
+    shape, A = SPECS[name]
+    spec = O.QNetSpec(shape, C_LAYERS, FF_LAYERS, A, dueling=True)
+    rng = np.random.RandomState(3)
+    flat = O.glorot_init(spec, (5, 6)).astype(np.float64) + rng.randn(spec.n_params) * 0.05
+    obs = (rng.rand(9, *shape) < 0.3).astype(np.uint8)
+    keep = rng.rand(9, 512) < 0.8
+    q, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    P = spec.split(flat)
+    (W2, b2), (W3, b3) = P[-2], P[-1]
+    fold = lambda M: M[..., 0:1] + M[..., 1:] - M[..., 1:].mean(axis=-1, keepdims=True)      # the combination along the last axis
+    W3q, b3q = fold(W3), fold(b3[None, :])[0]
+    y2 = cache["layers"][-1]["x"]                                                          # Dense(|A|)'s output = the dueling layer's input
+    assert np.abs(y2 @ W3q + b3q - q).max() < 1e-12
+    # backward: one non-zero per row of dq
+    a_b = rng.randint(0, A, size=9)
+    s = rng.randn(9)
+    dq = np.zeros((9, A))
+    dq[np.arange(9), a_b] = s
+    g3 = np.concatenate([dq.sum(axis=1, keepdims=True), dq - dq.sum(axis=1, keepdims=True) / A], axis=1)
+    gy2 = g3 @ W3.T
+    assert np.abs(gy2 - dq @ W3q.T).max() < 1e-12
+    assert np.abs(gy2 - s[:, None] * W3q.T[a_b]).max() < 1e-12
+    Wc = W3q.T @ W2.T                                                                    # [|A|, 512]
+    D1 = cache["layers"][-3]                                                             # Dense(512): ReLU + dropout
+    mask = np.where(keep, 1.0 / 0.8, 0.0) * (D1["y"] > 0.0)
+    gh1 = (gy2 @ W2.T) * mask
+    assert np.abs(gh1 - s[:, None] * Wc[a_b] * mask).max() < 1e-12
+    # Wc by the pack kernel's route: the plain product's row, folded along the row
+    assert np.abs(Wc - fold(W2 @ W3).T).max() < 1e-12
