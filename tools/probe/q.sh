@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_qnet_gpu.py -x -q -m gpu 2>&1 | tail -2
-timeout 400 bash tools/ab_run.sh xl base xearly
+for v in s_maxilp s_maxmem s_iter; do DQ_LIB_PATH=tools/probe/ab/$v.so timeout 120 python -m pytest tests/test_qnet_gpu.py -x -q -m gpu -k "training_forward_backward and c3" 2>&1 | tail -1; done
+timeout 600 bash tools/ab_run.sh sched base s_maxilp s_maxmem s_iter
