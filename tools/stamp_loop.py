@@ -1,6 +1,6 @@
 """Stamps of the dense backward's launch INSIDE the vector step (development aid; GPU box): the headline loop (bench_loop.FullLoop, c3) runs
 a few steps on a library built with -DDQ_STAMPS=3 (phase cycles of workgroup DQ_STAMP_BLOCK, TD prologue and riding environment step
-included) or -DDQ_STAMPS=23 (wall-clock start / end of every workgroup of the launch, riders included).
+included), -DDQ_STAMPS=6 -DDQ_STAMP_BLOCK=<a rider block, e.g. 300> (phases of a riding environment workgroup, env_dev.h env_block2) or -DDQ_STAMPS=23 (wall-clock start / end of every workgroup of the launch, riders included).
     DQ_LIB_PATH=tools/probe/stamps/s23.so python tools/stamp_loop.py 23"""
 import ctypes, importlib, os, sys
 import numpy as np, torch
@@ -16,7 +16,8 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()
 dq.lib().dq_dbg_read_bwd(buf)
 if tag == 6:
-    names = ["tables+record", "policy", "step (referee look-ups)", "volume", "outputs", "barrier+stats", "obs compose", "barrier+obs write", "sampling"]
+    names = ["loads at the top (tables, record, Q row, referee tables -> LDS)", "policy", "step (referee look-ups)", "noise rounds", "record + scalar outputs",
+             "observation planes -> LDS stage", "barrier", "bookkeeping atomics + stage -> global", "replay sampling"]
     for w in range(8):
         t = [buf[i * 8 + w] for i in range(10)]
         print("wave", w, [t[i + 1] - t[i] for i in range(9)], "total", t[9] - t[0])
