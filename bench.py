@@ -392,20 +392,25 @@ class EnvOnly:
         self.action = torch.zeros(n_local, dtype=torch.int32, device="cuda")
         self.t = 0
         self.events = []
+        # timing events from a pool made up front (creating two per step inside the timed loop was a third of this host-bound loop), ONE launch
+        # per step: the uniform-legal policy fused in front of the step (dq_env_act_step with no Q-values == dq_policy_select + dq_env_step)
+        self.pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(1024)]
+        self.timed_steps = 0
 
     def step(self, timed):
-        self.env.select_actions(self.t, out=self.action)
         if timed:
-            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0, e1 = self.pool[self.timed_steps % len(self.pool)]
             e0.record()
-        self.env.step(self.action, auto_reset=True)
+        self.env.act_step(self.t, q=None, eps=1.0, auto_reset=True, out_action=self.action)
         if timed:
             e1.record()
-            self.events.append((e0, e1))
+            if self.timed_steps < len(self.pool):
+                self.events.append((e0, e1))
+            self.timed_steps += 1
         self.t += 1
 
     def config(self):
-        return dict(policy="uniform over legal actions (device)", auto_reset=True)
+        return dict(policy="uniform over legal actions (device, fused in front of the step: one launch)", auto_reset=True)
 
     def report(self, steps, dt, world):
         ms = sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))

@@ -586,9 +586,12 @@ static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = fals
     p.obs_size = E->info.obs_c * E->P;
     p.env_id_base = E->cfg.env_id_base; p.seed0 = E->cfg.seed[0]; p.seed1 = E->cfg.seed[1];
     p.T_phys = E->T_phys; p.T_meas = E->T_meas;
-    // two to a wave only where the step rides on the dense backward (there it halves the rounds of environment workgroups: -3.7 us per
-    // vector step); the stand-alone launch measured 17.4 us one per wave against 17.8 us two per wave (fewer, longer waves)
-    p.pair = rider && env_pairs(E) ? 1 : 0;
+    // two to a wave where the lattice fits half a wave (d <= 5): where the step rides on the dense backward it halves the rounds of environment
+    // workgroups (-3.7 us per vector step); the stand-alone launch measured 17.4 us one per wave against 17.8 us two per wave in round 3's first pass
+    // (round 3, second pass: two to a wave in the stand-alone launch too -- with the step's loads in one batch and the planes composed from registers it
+    // measures 15.9 against 16.5 us per 4096-lattice launch, the acting-only loop 47.3 against 48.9 us per vector step; DQ_ENV_PAIR=1: riders only)
+    static const bool riders_only = getenv("DQ_ENV_PAIR") && getenv("DQ_ENV_PAIR")[0] == '1';
+    p.pair = (rider || !riders_only) && env_pairs(E) ? 1 : 0;
     if (p.pair) epb *= 2;
     // the component referee tables go into LDS where they are small (d <= 5: 512 bytes each) and a step reads them
     {
