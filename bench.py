@@ -7,7 +7,8 @@ One "step" = one pass of the hot path over one batch: every lattice of the batch
 headline config c3: d=5 depolarising p=0.011 with faulty syndromes, depth 5) receives an action, the
 batched environment kernel steps them, the transition lands in the device replay ring, and (mode
 `loop`) one DQN minibatch update runs.  Rank 0 prints ONE JSON line (contract in the task statement):
-`value` = whole-job env steps/s with all inputs resident in HBM; `roofline` is for the dominant kernel;
+`value` = whole-job env steps/s with all inputs resident in HBM; `roofline` is for the dominant kernel (its duration: HIP
+events bound to a sample of its launches inside the timed region -- the dispatch packets' own timestamps, csrc/prof.hip);
 `cpu_baseline` times the CPU oracle (a port; the reference's Python cannot travel to the GPU box) on
 this host's cores for a bounded sample.
 
@@ -270,7 +271,8 @@ def main():
         runner.step(timed=False)
     if hasattr(runner, "pick_dominant"):
         runner.pick_dominant()          # untimed probe: which kernel family takes the most time per step
-        runner.arm(args.steps)          # ... that family's launches in the timed region are bracketed by HIP events
+    if os.environ.get("DQ_BENCH_NO_ARM") != "1":     # (diagnostic: the timed region without any event, no roofline object)
+        runner.arm(args.steps)          # ... launches of that family inside the timed region carry a HIP event pair (prof.hip; a sample of them, see prof_stride)
     if (world > 1 or force_dist) and hasattr(runner, "core"):
         runner.core.ar_events = []      # HIP events around the exposed part of the gradient all-reduce, inside the timed loop
         runner.core.ar_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + 8)]
@@ -284,6 +286,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    if os.environ.get("DQ_BENCH_FAMILIES") == "1" and hasattr(runner, "family_times") and rank == 0:
+        extra = runner.report(args.steps, dt, world)       # (collects the timed region's events first)
+        fam = runner.family_times()
+        print("per-family launch durations in the free-running loop (us): " +
+              ", ".join(f"{k} {v['avg_us']:.2f} x{v['per_step']}" for k, v in fam.items()) +
+              f"; sum per step {sum(v['avg_us'] * v['per_step'] for v in fam.values()):.1f}", file=sys.stderr)
+        runner.report = lambda *a, _e=extra: _e
 
     replicas_identical, allreduce = None, None
     if (world > 1 or force_dist) and hasattr(runner, "core"):
@@ -391,35 +401,34 @@ class EnvOnly:
         self.env.reset()
         self.action = torch.zeros(n_local, dtype=torch.int32, device="cuda")
         self.t = 0
-        self.events = []
-        # timing events from a pool made up front (creating two per step inside the timed loop was a third of this host-bound loop), ONE launch
-        # per step: the uniform-legal policy fused in front of the step (dq_env_act_step with no Q-values == dq_policy_select + dq_env_step)
-        self.pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(1024)]
-        self.timed_steps = 0
+        self.bl = importlib.import_module("deepq-decoding_amd.bench_loop")
+        self.L = importlib.import_module("deepq-decoding_amd._lib").lib()
+        self.armed = False
+
+    def arm(self, steps):
+        # ONE launch per step: the uniform-legal policy fused in front of the step (dq_env_act_step with no Q-values == dq_policy_select + dq_env_step);
+        # a sample of the launches carries a HIP event pair (the dispatch's own timestamps, prof.hip)
+        self.armed = self.bl.prof_arm(self.L, "env_kernel", steps, 1)
 
     def step(self, timed):
-        if timed:
-            e0, e1 = self.pool[self.timed_steps % len(self.pool)]
-            e0.record()
         self.env.act_step(self.t, q=None, eps=1.0, auto_reset=True, out_action=self.action)
-        if timed:
-            e1.record()
-            if self.timed_steps < len(self.pool):
-                self.events.append((e0, e1))
-            self.timed_steps += 1
         self.t += 1
 
     def config(self):
         return dict(policy="uniform over legal actions (device, fused in front of the step: one launch)", auto_reset=True)
 
     def report(self, steps, dt, world):
-        ms = sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
+        if not self.armed:
+            return {"roofline": None}
+        launches, total_ms = self.bl.prof_collect(self.L)
+        if not launches:
+            return {"roofline": None}
+        ms = total_ms / launches
         bytes_per_launch = env_bytes_per_step(self.cfg) * self.n
         achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-        bl = importlib.import_module("deepq-decoding_amd.bench_loop")
         return {"roofline": dict(kernel="env_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                                 frac=achieved / HBM_PEAK_GBS, traffic=bl.pmc_traffic("env_kernel", "env", "c3"), avg_launch_us=ms * 1e3,
-                                 algorithmic_bytes_per_launch=bytes_per_launch)}
+                                 frac=achieved / HBM_PEAK_GBS, traffic=self.bl.pmc_traffic("env_kernel", "env", "c3"), avg_launch_us=ms * 1e3,
+                                 launches_timed=launches, algorithmic_bytes_per_launch=bytes_per_launch)}
 
 
 if __name__ == "__main__":

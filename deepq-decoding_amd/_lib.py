@@ -155,6 +155,7 @@ SIGNATURES = {
     "dq_prof_kernel_count": (_i, []),
     "dq_prof_kernel_name": (ctypes.c_char_p, [_i]),
     "dq_prof_arm": (_i, [_i, _i]),
+    "dq_prof_stride": (_i, [_i]),
     "dq_prof_collect": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_dbl)]),
 }
 

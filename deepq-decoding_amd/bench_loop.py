@@ -52,6 +52,32 @@ def pmc_traffic(kernel, mode="loop", config="c3"):
         return None
 
 
+def prof_stride(steps):
+    """A timed launch costs its stream a few microseconds (measured: the c3 loop 150.1 us per step with no launch timed, 154 with the dominant
+    kernel's launch timed in every step; the acting mode 41.4 against 45.8), so only a sample of the armed family's launches is timed: about 64 over
+    the timed region, every launch when the region is that short."""
+    samples = 64 if steps >= 256 else max(5, steps // 4)
+    return max(1, steps // samples)
+
+
+def prof_arm(L, family, steps, per_step):
+    """Arms `family` for the timed region of `steps` steps (per_step launches each); False if the library has no such family."""
+    for i in range(L.dq_prof_kernel_count()):
+        if L.dq_prof_kernel_name(i).decode() == family:
+            stride = prof_stride(steps)
+            _lib.check(L.dq_prof_arm(i, steps * per_step // stride + 8))
+            _lib.check(L.dq_prof_stride(stride))
+            return True
+    return False
+
+
+def prof_collect(L):
+    n, ms = ctypes.c_int(), ctypes.c_double()
+    _lib.check(L.dq_prof_collect(ctypes.byref(n), ctypes.byref(ms)))
+    _lib.check(L.dq_prof_arm(-1, 0))
+    return n.value, ms.value
+
+
 class FullLoop:
     # f32 results (1e-5 against the float64 oracle); the hot products are issued on the f16 matrix pipe, each operand as two f16 pieces
     dtype = "f32 (operands as 2 f16 pieces = 22 significant bits, 2 or 3 f16 MFMAs per product, f32 accumulate)"
@@ -155,10 +181,22 @@ class FullLoop:
         _lib.check(self.L.dq_prof_arm(-1, 0))
         return best
 
+    def family_times(self, steps=200):
+        """Diagnostic (DQ_BENCH_FAMILIES=1): every family's average launch duration in the free-running loop, one family timed at a time."""
+        out = {}
+        for name, (per_step, _, _) in self.kernel_families().items():
+            _lib.check(self.L.dq_prof_arm(self._family_id(name), steps * per_step + 8))
+            for _ in range(steps):
+                self.step(timed=False)
+            n, ms = self._collect()
+            if n:
+                out[name] = dict(launches=n, avg_us=ms * 1e3 / n, per_step=per_step)
+        _lib.check(self.L.dq_prof_arm(-1, 0))
+        return out
+
     def arm(self, steps):
         if self.prof_family:
-            per_step = self.kernel_families()[self.prof_family][0]
-            _lib.check(self.L.dq_prof_arm(self._family_id(self.prof_family), steps * per_step + 8))
+            prof_arm(self.L, self.prof_family, steps, self.kernel_families()[self.prof_family][0])
 
     def units_per_step(self):
         return self.B if self.mode == "learn" else self.n

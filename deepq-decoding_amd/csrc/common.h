@@ -47,6 +47,25 @@ enum { DQ_K_ENV = 0, DQ_K_POLICY, DQ_K_CONV_CHAIN, DQ_K_DENSE_CHAIN, DQ_K_GEMM_F
        DQ_K_DENSE_BWD, DQ_K_DENSE_WGRAD, DQ_K_CONV_BWD, DQ_K_COUNT };
 void dq_prof_begin(int kernel_id, hipStream_t st);
 void dq_prof_end(int kernel_id, hipStream_t st);
+// The exact form, for the launches of the fused chains and the environment step: the launch itself carries the event pair (hipExtLaunchKernelGGL: both
+// events are bound to the dispatch packet, so their distance is the packet's own start -> end timestamps -- the duration rocprofv3 reports; an event
+// recorded in front of and one behind the launch also measure the two marker packets, ~3.5 us on a 42 us kernel).
+int dq_prof_pair(int kernel_id, hipEvent_t* start, hipEvent_t* stop);      // 1: this launch is timed -> its pair (counted); 2: DQ_PROF_BRACKET=1, the bracketing
+                                                                            // form for comparison; 0: an ordinary launch
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+template <typename K, typename... A>
+static inline void dq_launch(int kernel_id, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+    hipEvent_t e0, e1;
+    const int how = dq_prof_pair(kernel_id, &e0, &e1);
+    if (how == 1) hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, args...);
+    else {
+        if (how == 2) dq_prof_begin(kernel_id, st);
+        kern<<<grid, block, lds, st>>>(args...);
+        if (how == 2) dq_prof_end(kernel_id, st);
+    }
+}
+#endif
 
 // W / 2^32 < p  <=>  W < ceil(p * 2^32)   (oracle/philox.py threshold())
 static inline u64 dq_rate_threshold(double p) {

@@ -1532,21 +1532,17 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
     }
     for (int i = n_jobs; i < FWD_MAX_JOBS; ++i) ca.wg_first[i] = da.wg_first[i] = 0x7fffffff;
-    dq_prof_begin(DQ_K_CONV_CHAIN, st);
     if (can_persist && (conv_wgs > pp.per_cu * n_cu || persist_env == 2)) {
         ca.total_groups = conv_wgs; ca.off_t1 = pp.off_t1; ca.off_obs1 = pp.off_obs1; ca.off_a2b = pp.off_a2b; ca.off_a1 = pp.off_a1; ca.off_mis = pp.off_mis;
         int grid = pp.per_cu * n_cu;
         if (persist_grid > 0) grid = persist_grid;
         if (grid > conv_wgs) grid = conv_wgs;
-        pk<<<grid, CONV_THREADS, pp.lds, st>>>(ca);
+        dq_launch(DQ_K_CONV_CHAIN, pk, dim3(grid), dim3(CONV_THREADS), pp.lds, st, ca);
     } else {
-        ck<<<conv_wgs, CONV_THREADS, cp.lds, st>>>(ca);
+        dq_launch(DQ_K_CONV_CHAIN, ck, dim3(conv_wgs), dim3(CONV_THREADS), cp.lds, st, ca);
     }
-    dq_prof_end(DQ_K_CONV_CHAIN, st);
     DQ_LAUNCH_CHECK();
-    dq_prof_begin(DQ_K_DENSE_CHAIN, st);
-    dk<<<dense_wgs, DENSE_THREADS, dp.lds, st>>>(da);
-    dq_prof_end(DQ_K_DENSE_CHAIN, st);
+    dq_launch(DQ_K_DENSE_CHAIN, dk, dim3(dense_wgs), dim3(DENSE_THREADS), dp.lds, st, da);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

@@ -1693,15 +1693,11 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     }
     if (td && td->metrics && da.dense_wgs > td->metric_slots)      // (the partials are then summed by atomics, in any order: diagnostics only)
         DQ_HIP(hipMemsetAsync(td->metrics + 2, 0, (size_t)td->metric_slots * 2 * sizeof(float), st));
-    dq_prof_begin(DQ_K_DENSE_BWD, st);
-    if (dp.NT2 == 4) {
-        if (td) dense_bwd_chain_kernel<4, true><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
-        else dense_bwd_chain_kernel<4, false><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
-    } else {
-        if (td) dense_bwd_chain_kernel<7, true><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
-        else dense_bwd_chain_kernel<7, false><<<da.dense_wgs + stat_wgs, DENSE_THREADS, lds, st>>>(da, ep);
+    {
+        void (*dbk)(DenseBwdArgs, EnvParams) = dp.NT2 == 4 ? (td ? dense_bwd_chain_kernel<4, true> : dense_bwd_chain_kernel<4, false>)
+                                                            : (td ? dense_bwd_chain_kernel<7, true> : dense_bwd_chain_kernel<7, false>);
+        dq_launch(DQ_K_DENSE_BWD, dbk, dim3(da.dense_wgs + stat_wgs), dim3(DENSE_THREADS), lds, st, da, ep);
     }
-    dq_prof_end(DQ_K_DENSE_BWD, st);
     DQ_LAUNCH_CHECK();
 
     // ---- 2. dense weight gradients: all layers, one launch -----------------------------------------------------------
@@ -1732,10 +1728,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     int rps, sy;
     wgrad_slicing(B, &rps, &sy);
     wa.rows_per_slice = rps; wa.partial = dense_partial; wa.pstride = dense_pstride(Q);
-    dq_prof_begin(DQ_K_DENSE_WGRAD, st);
     wa.total_tiles = tiles; wa.slices = sy;
-    dense_wgrad_kernel<<<tiles * sy, WGRAD_THREADS, DENSE_WGRAD_LDS, st>>>(wa);
-    dq_prof_end(DQ_K_DENSE_WGRAD, st);
+    dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_kernel, dim3(tiles * sy), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa);
     DQ_LAUNCH_CHECK();
 
     if (phases != 3) {                                              // phased: the dense gradients are complete (and reducible) now
@@ -1772,9 +1766,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
     conv_bwd_kernel_t ck = cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;
-    dq_prof_begin(DQ_K_CONV_BWD, st);
-    ck<<<wgs, CB_THREADS, cp.lds, st>>>(ca);
-    dq_prof_end(DQ_K_CONV_BWD, st);
+    dq_launch(DQ_K_CONV_BWD, ck, dim3(wgs), dim3(CB_THREADS), cp.lds, st, ca);
     DQ_LAUNCH_CHECK();
 
     // ---- 4. fixed-order reductions of the partials into the flat gradient ------------------------------------------------

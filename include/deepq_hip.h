@@ -523,15 +523,20 @@ dq_status dq_adam_step(float* params_dev, const float* grads_dev, float* m_dev, 
                        double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Live kernel timing (measurement only; no reference counterpart).  dq_prof_arm(id, n) brackets the next n
+ * Live kernel timing (measurement only; no reference counterpart).  dq_prof_arm(id, n) times up to n
  * launches of kernel family `id` (0 <= id < dq_prof_kernel_count(), names from dq_prof_kernel_name) with HIP
- * events on the stream they are launched on; dq_prof_collect synchronises on the last recorded event and
- * returns the number of launches recorded since the last collect and the sum of their durations.
+ * events on the stream they are launched on -- the fused chains and the environment step carry the event pair
+ * on the launch itself (the dispatch's own start / end timestamps), the small per-layer kernels are bracketed
+ * by one --; dq_prof_collect synchronises on the last recorded event and returns the number of launches
+ * recorded since the last collect and the sum of their durations.  dq_prof_stride(s) (s >= 1; reset to 1 by
+ * every dq_prof_arm) times only every s-th launch of the armed family: a timed launch costs the stream a few
+ * microseconds, a sample of the launches leaves the timed region undisturbed.
  * dq_prof_arm(-1, 0) disarms.  Not thread-safe; one family at a time.
  * ------------------------------------------------------------------------------------------- */
 int dq_prof_kernel_count(void);
 const char* dq_prof_kernel_name(int kernel_id);
 dq_status dq_prof_arm(int kernel_id, int max_launches);
+dq_status dq_prof_stride(int stride);
 dq_status dq_prof_collect(int* launches, double* total_ms);
 
 #ifdef __cplusplus

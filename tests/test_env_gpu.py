@@ -483,6 +483,40 @@ def test_fused_act_step_equals_policy_then_step(dq, torch_mod, masked, eps):
     assert torch.equal(a_env.export_state(), b_env.export_state())
 
 
+def test_live_kernel_timing_of_a_sample_of_the_launches(dq, torch_mod):
+    """dq_prof_arm / dq_prof_stride / dq_prof_collect (bench.py's roofline object): every third launch of the armed family carries an event pair on
+    the launch itself; the timed launches compute what the untimed ones do (same trajectory as an environment nobody times), their durations are
+    those of a kernel (microseconds, not the stream's), a second collect is empty and a disarmed library times nothing."""
+    torch = torch_mod
+    import ctypes
+    from importlib import import_module
+    lib = import_module("deepq-decoding_amd._lib")
+    L = lib.lib()
+    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    a_env, b_env = dq.VectorEnv(n_envs=512, **cfg), dq.VectorEnv(n_envs=512, **cfg)
+    a_env.reset(); b_env.reset()
+    fam = [L.dq_prof_kernel_name(i).decode() for i in range(L.dq_prof_kernel_count())].index("env_kernel")
+    for t in range(3):
+        a_env.act_step(t, q=None, eps=1.0, auto_reset=True)      # (first launches: module load, not timed)
+        b_env.act_step(t, q=None, eps=1.0, auto_reset=True)
+    lib.check(L.dq_prof_arm(fam, 64))
+    lib.check(L.dq_prof_stride(3))
+    for t in range(3, 15):
+        a_env.act_step(t, q=None, eps=1.0, auto_reset=True)
+    n, ms = ctypes.c_int(), ctypes.c_double()
+    lib.check(L.dq_prof_collect(ctypes.byref(n), ctypes.byref(ms)))
+    assert n.value == 4 and 0.0 < ms.value / n.value < 1.0, (n.value, ms.value)
+    lib.check(L.dq_prof_collect(ctypes.byref(n), ctypes.byref(ms)))
+    assert n.value == 0 and ms.value == 0.0
+    lib.check(L.dq_prof_arm(-1, 0))
+    for t in range(3, 15):
+        b_env.act_step(t, q=None, eps=1.0, auto_reset=True)
+    lib.check(L.dq_prof_collect(ctypes.byref(n), ctypes.byref(ms)))
+    assert n.value == 0
+    assert torch.equal(a_env.obs, b_env.obs) and torch.equal(a_env.export_state(), b_env.export_state())
+    assert L.dq_prof_stride(0) != 0                               # rejected
+
+
 def test_act_step_with_replay_sampling_equals_the_separate_calls(dq, torch_mod):
     """dq_env_act_step_sample == dq_env_act_step + dq_replay_sample: the sampling blocks change nothing about the step, and draw the
     same rows (also when the minibatch is larger than the number of lattices)."""

@@ -6,6 +6,10 @@
 #   pmc_traffic_loop_c3.json     FETCH_SIZE / WRITE_SIZE passes, stamped with the kernel sources' sha256
 tag="${1:-meas}"; root="${GRAFT_REPO_ROOT:-$PWD}"; cd "$root"; out="gpurun_out/$tag"; mkdir -p "$out"
 line() { grep '^{"metric"' | tail -1; }
+# the PMC passes first, copied into profiles/ on this box: the bench lines below then carry `roofline.traffic` of THESE sources
+tools/pmc_traffic.sh loop c3 > "$out/pmc.log" 2>&1; cp gpurun_out/pmc_traffic_loop_c3.json "$out/" 2>/dev/null; cp gpurun_out/pmc_traffic_loop_c3.json profiles/ 2>/dev/null
+tools/pmc_traffic.sh env c3 > "$out/pmc_env.log" 2>&1; cp gpurun_out/pmc_traffic_env_c3.json "$out/" 2>/dev/null; cp gpurun_out/pmc_traffic_env_c3.json profiles/ 2>/dev/null
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 python bench.py 2>"$out/bench_c3_loop.err" | line > "$out/bench_c3_loop.json"
 for cfg in c2 c5; do python bench.py --config $cfg --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_${cfg}_loop.json"; done
 for mode in act learn env; do python bench.py --mode $mode --steps 1000 --warmup 50 2>/dev/null | line > "$out/bench_c3_${mode}.json"; done
@@ -14,8 +18,6 @@ rm -rf "$out/prof"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -- python "$root/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$root/$out/prof.log" 2>&1)
 python tools/rocprof_summary.py $(ls $out/prof/*/*.db | head -1) "$out/loop_c3_kernel_stats.csv"
 rm -rf "$out/prof"
-tools/pmc_traffic.sh loop c3 > "$out/pmc.log" 2>&1; cp gpurun_out/pmc_traffic_loop_c3.json "$out/" 2>/dev/null
-rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 head -12 "$out/loop_c3_kernel_stats.csv" | cut -c1-120
 for f in $out/bench_*.json; do python - "$f" <<'PY'
 import json, sys
