@@ -275,7 +275,8 @@ def main():
         runner.arm(args.steps)          # ... launches of that family inside the timed region carry a HIP event pair (prof.hip; a sample of them, see prof_stride)
     if (world > 1 or force_dist) and hasattr(runner, "core"):
         runner.core.ar_events = []      # HIP events around the exposed part of the gradient all-reduce, inside the timed loop
-        runner.core.ar_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + 8)]
+        runner.core.ar_stride = importlib.import_module("deepq-decoding_amd.bench_loop").prof_stride(args.steps)      # (a sample of the steps, as the kernel timing)
+        runner.core.ar_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps // runner.core.ar_stride + 8)]
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

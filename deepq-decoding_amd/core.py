@@ -92,6 +92,7 @@ class DQNCore:
         self._inexact_acc = torch.zeros((), dtype=torch.int64, device=dev) if getattr(env, "wide", False) else None
         self.ar_events = None        # bench.py: a list here collects HIP-event pairs around the exposed part of the gradient all-reduce
         self.ar_pool = []            # ... taken from this pool of pre-created pairs (creating two timing events per step costs host time inside the timed region)
+        self.ar_stride, self._ar_seen = 1, 0     # ... in every ar_stride-th step only (two marker packets in the stream cost the step ~4 us)
         self._e_fwd, self._e_env = torch.cuda.Event(), torch.cuda.Event()
         self._env_inflight = False
 
@@ -260,7 +261,9 @@ class DQNCore:
                 net.td_backward_adam_env(self.params, td, self.grads, None, None, t, self.lr, self.beta_1, self.beta_2, self.epsilon, self.env._h, ride)
             else:
                 net.td_backward_adam(self.params, td, self.grads, None, None, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
-            if self.ar_events is not None:
+            probe = self.ar_events is not None and self._ar_seen % self.ar_stride == 0
+            self._ar_seen += 1
+            if probe:
                 e0, e1 = self.ar_pool.pop() if self.ar_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e0.record()
             if self._rccl is None and not self._rccl_tried:
@@ -270,7 +273,7 @@ class DQNCore:
                 self._rccl.allreduce_sum_(self.grads)
             else:
                 _dist.allreduce_sum_(self.grads, group=self.pg)
-            if self.ar_events is not None:
+            if probe:
                 e1.record()
                 self.ar_events.append((e0, e1))
             _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
@@ -284,13 +287,15 @@ class DQNCore:
             work = _dist.allreduce_sum_async(self.grads[nconv:], group=self.pg)
             net.backward_phase(self.params, self.dq, self.grads, 1)
             # what the step WAITS for: the convolutional range's all-reduce (critical path) + whatever is left of the dense range's
-            if self.ar_events is not None:
+            probe = self.ar_events is not None and self._ar_seen % self.ar_stride == 0
+            self._ar_seen += 1
+            if probe:
                 e0, e1 = self.ar_pool.pop() if self.ar_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e0.record()
             _dist.allreduce_sum_(self.grads[:nconv], group=self.pg)
             if work is not None:
                 work.wait()
-            if self.ar_events is not None:
+            if probe:
                 e1.record()
                 self.ar_events.append((e0, e1))
             _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
