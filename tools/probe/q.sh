@@ -1,8 +1,10 @@
 cd $GRAFT_REPO_ROOT
-echo "== dense fwd loop shape"; DQ_LIB_PATH=tools/probe/stamps/s2.so DQ_STAMP_LOOP=1 timeout 200 python tools/stamp_run.py 2 2>&1 | tail -10
-echo "== dense bwd in loop"; DQ_LIB_PATH=tools/probe/stamps/s3.so timeout 200 python tools/stamp_loop.py 3 2>&1 | tail -18
-echo "== dense bwd wg timeline"; DQ_LIB_PATH=tools/probe/stamps/s23.so timeout 200 python tools/stamp_loop.py 23 2>&1 | tail -6
-echo "== rider"; DQ_LIB_PATH=tools/probe/stamps/s6.so timeout 200 python tools/stamp_loop.py 6 2>&1 | tail -6
-echo "== learn-mode SQ counters"
-timeout 300 tools/pmc_any.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" sqL bench.py --mode learn --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -8
-rm -rf gpurun_out/sqL
+timeout 900 python -m pytest tests/test_qnet_gpu.py tests/test_shipped_weights.py -x -q -m gpu 2>&1 | tail -3
+DQ_LIB_PATH=tools/probe/stamps/s15.so timeout 200 python tools/stamp_run.py 15 2>&1 | grep -v amdgpu.ids | tail -9
+for rep in 1 2; do for v in 1 0; do
+echo "DQ_WGRAD_PC=$v: $(if [ $v = nopf ]; then export DQ_LIB_PATH=$PWD/tools/probe/ab/nopf.so; else unset DQ_LIB_PATH; fi; DQ_WGRAD_PC=$v timeout 200 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python -c 'import json,sys; d=json.loads(sys.stdin.readline()); print("%.2f M/s %.2f us" % (d["value"]/1e6, d["ms_per_step"]*1e3))')"
+done; done
+for v in 1 0; do
+rm -rf gpurun_out/pc_prof; (cd /tmp && export TMPDIR=/tmp && DQ_WGRAD_PC=$v timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/pc_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline > /dev/null 2>&1)
+python tools/rocprof_summary.py $(ls gpurun_out/pc_prof/*/*.db | head -1) gpurun_out/pc_$v.csv; echo "PC=$v"; grep -i "wgrad\|reduce" gpurun_out/pc_$v.csv | cut -c1-100
+done; rm -rf gpurun_out/pc_prof
