@@ -729,6 +729,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef DENSE_PR
+#define DENSE_PR 32                     // rows per reduction pass of the dense chain's Dense(|A|) partials (64 = one pass: measured)
+#endif
 struct DenseJob {
     const float* params;
     const u32x4* packed;                // f16 pieces (qnet.h); the hidden layer's blocks start at DenseChainArgs.pk_dense1
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     float* s_x = reinterpret_cast<float*>(smem + a.off_x);
     float* s_part = reinterpret_cast<float*>(smem + a.off_part);
     float* s_y2 = reinterpret_cast<float*>(smem + a.off_y2);
-    constexpr int PW = 16 * NT2, ROWS = 16 * RT, PR = ROWS < 32 ? ROWS : 32, UP = PR / 16;      // PR rows (UP row tiles) per reduction pass
+    constexpr int PW = 16 * NT2, ROWS = 16 * RT, PR = ROWS < DENSE_PR ? ROWS : DENSE_PR, UP = PR / 16;      // PR rows (UP row tiles) per reduction pass
     constexpr int PWP = PW + 4;                                     // row stride of the partials: the 8 lanes of a ds_write_b128 lane group are 8 ROWS -- unpadded (a
                                                                     // multiple of 32 banks) every store was an 8-way conflict, 13K cycles of this kernel's LDS time
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
@@ -1377,11 +1380,11 @@ static bool plan_dense(const dq_qnet* Q, DensePlan* P, int rt = 1) {
     P->ld2 = 16 * P->NT2 + 4;
     P->ld3 = 16 * ((N3 + 15) / 16) + 1;
     size_t off = 0;
-    const size_t xb = up16((size_t)2 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * (rows < 32 ? rows : 32) * (16 * P->NT2 + 4) * 4);   // f16 planes | partials of one pass (rows padded by 4 floats)
+    const size_t xb = up16((size_t)2 * rows * (D1.nin + 8) * 2), pb = up16((size_t)DENSE_WAVES * (rows < DENSE_PR ? rows : DENSE_PR) * (16 * P->NT2 + 4) * 4);   // f16 planes | partials of one pass (rows padded by 4 floats)
     P->off_x = P->off_part = (int)off; off += xb > pb ? xb : pb;   // the Dense(|A|) partials reuse the input image (dead by then)
     P->off_h = (int)off;                                            // (the hidden output stays in registers)
     P->off_y2 = (int)off; off += up16((size_t)rows * P->ld2 * 4);
-    P->off_y3 = (int)off; off += up16((size_t)rows * P->ld3 * 4);
+    P->off_y3 = (int)off;                                           // (unused since the dueling layer is folded: Q leaves from the accumulators)
     P->lds = off;
     return off <= CONV_LDS_MAX;
 }
