@@ -68,6 +68,7 @@ struct DenseBwdArgs {
     float gs;                           // every gradient of the fused backward is carried scaled by this power of two (GradScale below) ...
     const float* gs_dev;                // ... or, when not NULL, by gs_dev[0] (computed on the device from max |dq|)
     int td_on, dense_wgs;               // td_on: dq is computed here from `td`; workgroups >= dense_wgs do the episode bookkeeping ...
+    int dense_tiles, col_split;         // dense_wgs = dense_tiles (row tiles of 16 samples) x col_split (1, 2 or 4: small minibatches, see the kernel)
     int env_on;                         // ... or, with a rider, the environment step (+ its replay sampling and bookkeeping): env_block<8>
     TdFused td;
 };
@@ -262,7 +263,12 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     unsigned short* s_gh1p = reinterpret_cast<unsigned short*>(smem + a.off_gh1);    // gH1 as planes [2][16][LDH]
     const int LDY = 32 * a.KB2 + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
-    const int b0 = blockIdx.x * DENSE_ROWS;
+    // A minibatch of fewer row tiles than half the CUs (c5: 1024 samples = 64 workgroups on 256 CUs, each streaming all of W1^T -- 1.6 MB at d = 7 -- through
+    // its CU's vector-memory path: gX was 20 of that launch's 29 us) is spread further: col_split workgroups per row tile, each with the tile's whole
+    // prologue (the same values: its stores are duplicates of the same bits; the loss / mean-Q partial is written by the first only) and a quarter
+    // or half of gX's column tiles -- a quarter or half of the weight stream.  c3's 256 row tiles run as before (col_split 1).
+    const int bt = a.col_split > 1 ? (int)blockIdx.x % a.dense_tiles : (int)blockIdx.x, cs = a.col_split > 1 ? (int)blockIdx.x / a.dense_tiles : 0;
+    const int b0 = bt * DENSE_ROWS;
     const int ns = min(DENSE_ROWS, a.batch - b0);
     const int A = a.n_actions, N2 = a.N2, N3 = a.N3, ldg = a.ldg;
     const float GS = a.gs_dev ? a.gs_dev[0] : a.gs;                  // gradient scale (a power of two), wave-uniform
@@ -504,16 +510,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     DQ_STAMP(DQ_TAG_DENSE_BWD, 9);
     if (TD && lane == 0) { s_met[wave][0] = loss; s_met[wave][1] = mq; }
     __syncthreads();
-    if (TD && a.td.metrics && tid == 0) {                      // this workgroup's partial, and zeros in the slots nobody owns
+    if (TD && a.td.metrics && tid == 0 && cs == 0) {           // this row tile's partial, and zeros in the slots nobody owns
         float l = 0.f, q = 0.f;
         for (int w = 0; w < DENSE_WAVES; ++w) { l += s_met[w][0]; q += s_met[w][1]; }
-        if (a.dense_wgs <= a.td.metric_slots) {
-            a.td.metrics[2 + 2 * blockIdx.x] = l;
-            a.td.metrics[3 + 2 * blockIdx.x] = q;
-            for (int k = blockIdx.x + a.dense_wgs; k < a.td.metric_slots; k += a.dense_wgs) { a.td.metrics[2 + 2 * k] = 0.f; a.td.metrics[3 + 2 * k] = 0.f; }
-        } else {                                                    // more workgroups than slots (batch > 16 384): the launcher zeroed the slots
-            atomicAdd(a.td.metrics + 2 + 2 * (blockIdx.x % a.td.metric_slots), l);
-            atomicAdd(a.td.metrics + 3 + 2 * (blockIdx.x % a.td.metric_slots), q);
+        if (a.dense_tiles <= a.td.metric_slots) {
+            a.td.metrics[2 + 2 * bt] = l;
+            a.td.metrics[3 + 2 * bt] = q;
+            for (int k = bt + a.dense_tiles; k < a.td.metric_slots; k += a.dense_tiles) { a.td.metrics[2 + 2 * k] = 0.f; a.td.metrics[3 + 2 * k] = 0.f; }
+        } else {                                                    // more row tiles than slots (batch > 16 384): the launcher zeroed the slots
+            atomicAdd(a.td.metrics + 2 + 2 * (bt % a.td.metric_slots), l);
+            atomicAdd(a.td.metrics + 3 + 2 * (bt % a.td.metric_slots), q);
         }
     }
     DQ_STAMP(DQ_TAG_DENSE_BWD, 1);
@@ -571,8 +577,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     // ---- gX = (gH1 W1T) * [x > 0]  (K = 512): each wave owns a run of adjacent column tiles (counts differ by at most one, the
     //      longer runs on different SIMDs), taken up to three at a time with interleaved columns ---------------------------------
     {
-        const int tiles = a.K1 >> 4, base = tiles / DENSE_WAVES, extra = tiles - base * DENSE_WAVES;
-        int t0 = wave * base + min(wave, extra), left = base + (wave < extra ? 1 : 0);
+        const int all = a.K1 >> 4, per = (all + a.col_split - 1) / a.col_split, first = cs * per;      // this workgroup's column tiles [first, first + tiles)
+        const int tiles = max(0, min(per, all - first)), base = tiles / DENSE_WAVES, extra = tiles - base * DENSE_WAVES;
+        int t0 = first + wave * base + min(wave, extra), left = base + (wave < extra ? 1 : 0);
         while (left > 0) {                                          // wave-uniform
             if (left >= 3) { gx_pass<3>(a, s_gh1p, t0, b0, ns, lane); t0 += 3; left -= 3; }
             else if (left == 2) { gx_pass<2>(a, s_gh1p, t0, b0, ns, lane); t0 += 2; left -= 2; }
@@ -1677,7 +1684,20 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     da.gx_pl = reinterpret_cast<unsigned short*>(Q->gz[nc - 1]); da.gx_lo = (size_t)Q->cfg.max_batch * D1.nin;
     da.ldg = dp.ldg; da.off_g3 = dp.off_g3; da.off_gy2 = dp.off_gy2; da.off_gh1 = dp.off_gh1; da.off_w3t = dp.off_w3t;
     da.pk_w3q = (int)PL.w3q; da.w3q_rows = PL.w3q_rows; da.w3q_pw = 16 * PL.NT2; da.pk_wc = (int)PL.wc;
-    da.dense_wgs = (B + DENSE_ROWS - 1) / DENSE_ROWS;
+    da.dense_tiles = (B + DENSE_ROWS - 1) / DENSE_ROWS;
+    {
+        static const int forced = getenv("DQ_DENSE_BWD_SPLIT") ? atoi(getenv("DQ_DENSE_BWD_SPLIT")) : 0;      // (A/B runs: 1, 2, 4)
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu <= 0) n_cu = 256;
+        }
+        da.col_split = 4 * da.dense_tiles <= n_cu ? 4 : 2 * da.dense_tiles <= n_cu ? 2 : 1;          // (8 measured as 4)
+        if (forced == 1 || forced == 2 || forced == 4) da.col_split = forced;
+    }
+    da.dense_wgs = da.dense_tiles * da.col_split;
     int stat_wgs = 0;
     if (td) {
         da.td_on = 1; da.td = *td;
@@ -1691,7 +1711,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         ep = *rider; da.env_on = 1; stat_wgs = ep.env_blocks + ep.s_blocks;
         if (rider_lds > lds) lds = rider_lds;
     }
-    if (td && td->metrics && da.dense_wgs > td->metric_slots)      // (the partials are then summed by atomics, in any order: diagnostics only)
+    if (td && td->metrics && da.dense_tiles > td->metric_slots)    // (the partials are then summed by atomics, in any order: diagnostics only)
         DQ_HIP(hipMemsetAsync(td->metrics + 2, 0, (size_t)td->metric_slots * 2 * sizeof(float), st));
     {
         void (*dbk)(DenseBwdArgs, EnvParams) = dp.NT2 == 4 ? (td ? dense_bwd_chain_kernel<4, true> : dense_bwd_chain_kernel<4, false>)
