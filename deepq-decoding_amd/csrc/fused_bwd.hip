@@ -1775,7 +1775,16 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.g3p = reinterpret_cast<const unsigned short*>(Q->gz[nc - 1]); ca.g3_lo = (size_t)Q->cfg.max_batch * L3.rows * 32;
     DQ_REQUIRE(Q->last_train_packed, DQ_ERR_STATE, "fused_backward: the training forward left no packed weights");
     ca.packed = static_cast<const u32x4*>(Q->last_train_packed);
-    ca.batch = B; ca.S = cp.S; ca.groups = (B + cp.S - 1) / cp.S;
+    // samples per group: the plan's (8 where LDS allows) -- or fewer when that leaves most CUs without a group (a group is a chain of ten barrier-
+    // delimited phases: a lone workgroup per CU is latency-bound, so a small minibatch is better spread thin; the tables are sample-major
+    // and every loop runs over the group's own rows, so a smaller S is a prefix of the planned layout)
+    int S_run = cp.S;
+    {
+        static const int forced = getenv("DQ_CONV_BWD_S") ? atoi(getenv("DQ_CONV_BWD_S")) : 0;      // (A/B runs)
+        while (S_run > 2 && 2 * ((B + S_run - 1) / S_run) <= CONV_BWD_MAX_WGS) S_run >>= 1;
+        if (forced >= 1 && forced <= cp.S) S_run = forced;
+    }
+    ca.batch = B; ca.S = S_run; ca.groups = (B + S_run - 1) / S_run;
     ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
