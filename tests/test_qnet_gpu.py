@@ -131,13 +131,16 @@ def test_dropout_bits_drawn_ahead_equal_the_kernel_own_draw(dq, torch_mod, name,
     assert np.abs(q_other - O.forward(spec, flat, obs, training=True, keep_masks=[keep])[0]).max() < tol(q_ref)
 
 
-@pytest.mark.parametrize("name,batch", [("c3", 4096), ("c3", 2049), ("c3", 4091), ("c3", 2048 + 8 * 200 + 3), ("c2", 4096), ("c5", 1024), ("c5", 2500)])
+@pytest.mark.parametrize("name,batch", [("c3", 4096), ("c3", 2049), ("c3", 4091), ("c3", 2048 + 8 * 200 + 3), ("c2", 4096), ("c5", 1024), ("c5", 2500),
+                                        ("c3", 1500), ("c3", 1021)])
 def test_backward_at_baseline_batch_matches_oracle(dq, torch_mod, name, batch):
     """The fused training forward + backward at the BASELINE.json minibatch sizes against the float64 oracle on the FULL batch.  Only
     batches above 2048 give a workgroup of the persistent convolutional backward more than one group of 8 samples (256 workgroups), i.e.
     exercise its cross-group software pipeline (inputs fetched one group ahead, double-buffered a1, weight-gradient accumulators kept in
     registers across groups) and the batch-slice map of the dense weight-gradient kernel; ragged sizes leave a partly filled last group
-    and workgroups with different group counts."""
+    and workgroups with different group counts.  The sizes below 2048 are those where the small-minibatch forms take over: 1500 samples = 94 row
+    tiles of the dense backward, two workgroups each (col_split 2: half of gX's column tiles per workgroup); 1021 (and c5's 1024) = 64 row tiles, four
+    workgroups each, and groups of 4 instead of 8 samples in the convolutional backward, the last one ragged."""
     torch = torch_mod
     spec, net, params, flat, obs, rng = _setup(dq, torch, name, batch)
     seed, t, base = (3, 4), 99, 12345
