@@ -669,8 +669,17 @@ struct DenseWgradArgs {
 #ifndef WG_SLICES_TARGET
 #define WG_SLICES_TARGET 10
 #endif
-static void wgrad_slicing(int B, int* rows_per_slice, int* slices) {
-    int rps = (B + WG_SLICES_TARGET - 1) / WG_SLICES_TARGET;
+static void wgrad_slicing(const dq_qnet* Q, int B, int* rows_per_slice, int* slices) {
+    // as many slices as fill every CU twice -- 512 workgroup slots / the layers' 64 x 64 tiles: c3's 49 tiles -> 10 (WG_SLICES_TARGET, measured there);
+    // a wider first dense layer (d = 7: 122 tiles) takes fewer, so that the launch stays ONE round of workgroups and writes fewer partials
+    static const int forced = getenv("DQ_WGRAD_SLICES") ? atoi(getenv("DQ_WGRAD_SLICES")) : 0;      // (A/B runs)
+    int tiles = 0;
+    for (int l = Q->cfg.n_conv; l < Q->n_layers; ++l) tiles += ((Q->L[l].K + 63) / 64) * ((Q->L[l].N + 63) / 64);
+    int target = tiles > 0 ? 512 / tiles : WG_SLICES_TARGET;
+    if (target > WG_SLICES_TARGET) target = WG_SLICES_TARGET;
+    if (target < 2) target = 2;
+    if (forced >= 1 && forced <= DENSE_WGRAD_SLICES) target = forced;
+    int rps = (B + target - 1) / target;
     rps = (rps + 63) & ~63;
     while ((B + rps - 1) / rps > DENSE_WGRAD_SLICES) rps += 64;
     *rows_per_slice = rps;
@@ -1746,7 +1755,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         W.tile0 = tiles; tiles += W.k_tiles * W.n_tiles;
     }
     int rps, sy;
-    wgrad_slicing(B, &rps, &sy);
+    wgrad_slicing(Q, B, &rps, &sy);
     wa.rows_per_slice = rps; wa.partial = dense_partial; wa.pstride = dense_pstride(Q);
     wa.total_tiles = tiles; wa.slices = sy;
     dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_kernel, dim3(tiles * sy), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa);
@@ -1819,7 +1828,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     }
     if (phases == 3) {
         int rps, sy;
-        wgrad_slicing(B, &rps, &sy);
+        wgrad_slicing(Q, B, &rps, &sy);
         ra.seg[1] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, dense_pstride(Q), blocks0, (int)conv_floats};
         ra.seg[1].vec = sy <= 16 && (conv_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(grads_dev) & 15) == 0 &&
                         (!opt || ((reinterpret_cast<uintptr_t>(opt->p) | reinterpret_cast<uintptr_t>(opt->m) | reinterpret_cast<uintptr_t>(opt->v)) & 15) == 0);          // few slices: four outputs per thread, every slice's 16 bytes in flight at once
