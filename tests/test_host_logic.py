@@ -455,3 +455,14 @@ def test_replay_permutation_restatement_is_a_uniform_bijection():
     z = np.zeros((20, 8), np.uint8)
     rows = M.device_replay_rows(z, 8, 20, 5, 20, 136, (8, 9), 3)
     assert set(rows.tolist()) == M.valid_transitions(z, 8, 20, 5, 20)
+
+
+def test_live_timing_samples_the_launches():
+    """bench.py times a SAMPLE of the dominant kernel's launches inside the timed region (a timed launch costs its stream a few microseconds):
+    about 64 over a long region, every fourth launch of a 20-step run, every launch of a very short one."""
+    import importlib
+    bl = importlib.import_module("deepq-decoding_amd.bench_loop")
+    assert bl.prof_stride(2000) == 31 and 2000 // bl.prof_stride(2000) >= 64
+    assert bl.prof_stride(256) == 4
+    assert bl.prof_stride(20) == 4 and 20 // bl.prof_stride(20) == 5
+    assert bl.prof_stride(5) == 1 and bl.prof_stride(1) == 1
