@@ -21,6 +21,7 @@ learner alone -- replay sampling, three forwards, TD step, backward, Adam on a p
 a run whose world size differs from --gpus fails instead of printing a line.
 """
 import argparse
+import ctypes
 import importlib
 import json
 import os
@@ -242,7 +243,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.update(RANK="0", WORLD_SIZE="1")
+    json_out = sys.stdout
     if world > 1 or force_dist:
+        # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner through C stdio on file descriptor 1, buffered when that
+        # is a pipe and flushed at process exit -- i.e. BEHIND rank 0's line, once per rank.  Descriptor 1 is pointed at stderr for everything but
+        # the line itself (and the C buffers are flushed on every rank in front of it, below)
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -317,6 +325,10 @@ def main():
     params_checksum = None
     if hasattr(runner, "core"):                     # outside the timed region: what the run left in the parameters (path-equivalence checks)
         params_checksum = int(runner.core.params.view(torch.int32).to(torch.int64).sum().item())
+    if world > 1 or force_dist:
+        ctypes.CDLL(None).fflush(None)              # every rank's buffered library output leaves before rank 0's line does
+        sys.stdout.flush(); sys.stderr.flush()
+        dist.barrier()
     if rank == 0:
         units = runner.units_per_step() if hasattr(runner, "units_per_step") else n_local
         out = {
@@ -357,9 +369,11 @@ def main():
                 out["cpu_baseline"].update(env_only_1core_steps_per_s=one["value"], env_only_all_cores_steps_per_s=allc, env_only_cores=cores, env_only_cgroup_cpu_quota_cores=cpu_quota_cores(),
                                            env_only_sample="C oracle environment + uniform-legal policy, 4096 lattices per process, one process per "
                                                            "host core, 5 s, lattice-steps summed")
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1 or force_dist:
         dist.barrier()
+        if hasattr(runner, "core"):
+            runner.core.close_comm()            # the learner's own communicator first, on every rank, everything drained
         dist.destroy_process_group()
 
 

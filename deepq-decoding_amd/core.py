@@ -386,6 +386,14 @@ class DQNCore:
         if self.target_pk is not None:
             self.target_pk.copy_(self.params_pk)
 
+    def close_comm(self):
+        """Destroys the learner's own RCCL communicator (dist.RcclComm) -- every rank, behind a synchronisation, BEFORE the process group
+        that did its rendezvous is destroyed; a later several-GPU update would create a new one."""
+        if self._rccl is not None:
+            torch.cuda.synchronize(self.device)
+            self._rccl.close()
+        self._rccl, self._rccl_tried = None, False
+
     def read_stats(self, reset=True, all_ranks=False):
         """(episodes ended, sum of their lifetimes, rewards earned, lattices stepped) since the last reset; syncs.  all_ranks: summed
         over the process group, so that every rank takes the same decisions from them (early stopping in DQNAgent.fit: a rank that left

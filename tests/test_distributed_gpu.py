@@ -25,6 +25,7 @@ def test_bench_self_launches_two_ranks_that_stay_identical():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1                                           # rank 0 only
+    assert r.stdout.strip().splitlines() == line, r.stdout[-2000:]  # ... and nothing else on stdout, from any rank
     out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["replicas_identical"] is True and out["scaling"] == "weak"
     assert out["config"]["grad_allreduce"].startswith("RCCL") and out["value"] > 0
@@ -45,7 +46,10 @@ def test_one_rank_rccl_group_drives_the_several_gpu_branch():
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4", "--no-cpu-baseline"]
         r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(**extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        return json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+        lines = r.stdout.strip().splitlines()
+        # stdout is the ONE contract line, also with a RCCL communicator in the process (its version banner, C stdio flushed at exit, goes to stderr)
+        assert len(lines) == 1 and lines[0].startswith('{"metric"'), r.stdout[-2000:]
+        return json.loads(lines[0])
     plain = run()
     assert "rccl_ranks" not in plain
     for extra, native, word in ((dict(), True, "own stream"), (dict(DQ_DIST_NATIVE="0"), False, "torch.distributed"), (dict(DQ_DIST_MODE="split"), False, "asynchronous")):
