@@ -94,28 +94,38 @@ class RcclComm:
 
     def __init__(self, rank, world, device, group=None):
         import ctypes
-        libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
-        path = os.path.join(libdir, "librccl.so")
-        self.lib = ctypes.CDLL(path if os.path.exists(path) else "librccl.so")       # the library torch itself is linked against
-        L = self.lib
-        L.ncclGetErrorString.restype = ctypes.c_char_p
-        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(self._UniqueId)]
-        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
-        L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-        L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         self.rank, self.world, self.device = rank, world, torch.device(device)
-        uid = self._UniqueId()
-        if rank == 0:
-            self._check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        uid, err = self._UniqueId(), None
+        try:
+            libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+            path = os.path.join(libdir, "librccl.so")
+            self.lib = ctypes.CDLL(path if os.path.exists(path) else "librccl.so")       # the library torch itself is linked against
+            L = self.lib
+            L.ncclGetErrorString.restype = ctypes.c_char_p
+            L.ncclGetUniqueId.argtypes = [ctypes.POINTER(self._UniqueId)]
+            L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
+            L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            if rank == 0:
+                self._check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        except (OSError, RuntimeError, AttributeError) as e:
+            err = e
         if world > 1:
-            on_gpu = dist.get_backend(group) == "nccl"
-            t = torch.frombuffer(bytearray(bytes(uid.internal) if rank == 0 else bytes(128)), dtype=torch.uint8).clone()
-            t = t.to(self.device) if on_gpu else t
+            # every rank takes part in BOTH collectives whatever happened to it above (a rank that raised before them would leave the others
+            # waiting in the broadcast), and nobody enters ncclCommInitRank -- which blocks until all ranks have joined -- unless everybody is ready
+            dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            t = torch.frombuffer(bytearray(bytes(uid.internal) if rank == 0 else bytes(128)), dtype=torch.uint8).clone().to(dev)
             dist.broadcast(t, src=0, group=group)
+            ready = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ready, op=dist.ReduceOp.MIN, group=group)
+            if int(ready.item()) == 0:
+                raise RuntimeError(f"a rank could not prepare its RCCL communicator ({err if err is not None else 'another rank'})")
             ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        elif err is not None:
+            raise err
         self.comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            self._check(L.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+            self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), world, uid, rank), "ncclCommInitRank")
 
     def _check(self, rc, what):
         if rc != 0:

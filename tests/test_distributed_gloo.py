@@ -121,3 +121,36 @@ def test_single_process_helpers_are_noops():
     assert D.allreduce_sum_async(x.clone()) is None
     os.environ.pop("WORLD_SIZE", None)
     assert D.init_from_env() == (0, 1, 0)
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D = importlib.import_module("deepq-decoding_amd.dist")
+    D.init_from_env(backend="gloo")
+    if rank == 1:                               # this rank cannot even load the library
+        import ctypes
+
+        def no_library(*a, **k):
+            raise OSError("librccl.so: cannot open shared object file (test)")
+        ctypes.CDLL = no_library
+    try:
+        D.RcclComm(rank, world, "cpu")
+        outcome = "created"
+    except RuntimeError as e:
+        outcome = "RuntimeError: " + str(e)
+    with open(os.path.join(out_dir, f"rccl{rank}.txt"), "w") as f:
+        f.write(outcome)
+    dist.barrier()                              # the group is still in step: no rank is stuck in a collective the other one skipped
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_that_cannot_prepare_its_communicator_takes_every_rank_to_the_fallback(tmp_path):
+    """dist.RcclComm's rendezvous (rank 0's ncclUniqueId through the process group): a rank whose set-up fails BEFORE the collectives -- here
+    rank 1 cannot load librccl -- must neither leave the others waiting in the broadcast nor let them enter ncclCommInitRank (which blocks
+    until all ranks have joined): every rank raises RuntimeError, and dist.make_rccl then falls back to torch.distributed everywhere."""
+    world, port = 2, _free_port()
+    mp.spawn(_rccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    out = [(tmp_path / f"rccl{r}.txt").read_text() for r in range(world)]
+    assert all(o.startswith("RuntimeError: a rank could not prepare") for o in out), out
