@@ -10,7 +10,10 @@ from oracle import dqn_oracle as O, philox
 pytestmark = pytest.mark.gpu
 
 C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
-SHAPES = {"c1": ((4, 7, 7), 10), "c2": ((6, 11, 11), 26), "c3": ((7, 11, 11), 51), "c5": ((9, 15, 15), 99)}
+SHAPES = {"c1": ((4, 7, 7), 10), "c2": ((6, 11, 11), 26), "c3": ((7, 11, 11), 51), "c5": ((9, 15, 15), 99),
+          # combinations of lattice size and action count beside BASELINE.json's: d = 5 DP with Y moves (use_Y=True: 3 d^2 + 1 = 76 actions on the d = 5 planes),
+          # d = 7 X noise (d^2 + 1 = 50 actions on the d = 7 planes), d = 3 DP (2 d^2 + 1 = 19 actions, 5 planes)
+          "c3y": ((7, 11, 11), 76), "d7x": ((8, 15, 15), 50), "d3dp": ((5, 7, 7), 19)}
 
 
 def tol(ref):
@@ -43,7 +46,7 @@ def _setup(dq, torch, name, batch, seed=(11, 22), dueling=True, max_batch=None, 
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
-@pytest.mark.parametrize("name,batch", [("c1", 1), ("c1", 37), ("c2", 32), ("c3", 32), ("c3", 300), ("c5", 64)])
+@pytest.mark.parametrize("name,batch", [("c1", 1), ("c1", 37), ("c2", 32), ("c3", 32), ("c3", 300), ("c5", 64), ("c3y", 70), ("d7x", 45), ("d3dp", 130)])
 def test_forward_inference(dq, torch_mod, name, batch, fused):
     torch = torch_mod
     spec, net, params, flat, obs, _ = _setup(dq, torch, name, batch, fused=fused)
@@ -81,7 +84,7 @@ def test_forward_with_replay_gather(dq, torch_mod):
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
-@pytest.mark.parametrize("name,batch", [("c1", 8), ("c2", 40), ("c3", 32), ("c3", 257), ("c5", 48)])
+@pytest.mark.parametrize("name,batch", [("c1", 8), ("c2", 40), ("c3", 32), ("c3", 257), ("c5", 48), ("c3y", 70), ("d7x", 45), ("d3dp", 130)])
 def test_training_forward_backward(dq, torch_mod, name, batch, fused):
     torch = torch_mod
     spec, net, params, flat, obs, rng = _setup(dq, torch, name, batch, fused=fused)
