@@ -27,8 +27,16 @@ C5 = dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_me
 C2 = dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.007)
 
 
-@pytest.mark.parametrize("name,C1,N,B,steps", [("c1", C1, 16, 8, 13), ("c3", C3, 64, 32, 12), ("c5", C5, 32, 16, 11), ("c2", C2, 48, 40, 11)],
-                         ids=["c1", "c3", "c5", "c2"])
+# beside BASELINE.json's configurations: Y moves (use_Y=True: three action planes, 76 actions at d = 5 -- a 128-bit legal-move mask and the wider Dense(|A|) tiling),
+# the IIDXZ error model through the whole loop, and X noise at d = 7
+C3Y = dict(d=5, error_model="DP", use_Y=True, volume_depth=5, p_phys=0.011, p_meas=0.011)
+CXZ = dict(d=5, error_model="IIDXZ", use_Y=False, volume_depth=5, p_phys=0.008, p_meas=0.008)
+C7X = dict(d=7, error_model="X", use_Y=False, volume_depth=7, p_phys=0.006, p_meas=0.006)
+
+
+@pytest.mark.parametrize("name,C1,N,B,steps", [("c1", C1, 16, 8, 13), ("c3", C3, 64, 32, 12), ("c5", C5, 32, 16, 11), ("c2", C2, 48, 40, 11),
+                                               ("c3y", C3Y, 40, 24, 11), ("iidxz", CXZ, 40, 24, 11), ("d7x", C7X, 24, 16, 10)],
+                         ids=["c1", "c3", "c5", "c2", "c3y", "iidxz", "d7x"])
 def test_device_loop_matches_oracle_loop(dq, torch_mod, name, C1, N, B, steps):
     """The whole loop -- Q forward, epsilon-greedy over legal moves, environment step into the ring, replay sampling,
     double-DQN update, Adam -- against the same loop assembled from the CPU oracles (C environment oracle, float64 network oracle,
