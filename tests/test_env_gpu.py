@@ -173,12 +173,18 @@ CONFIGS = {
     # the largest supported volume (16 rounds: the 256-byte lattice record) and the smallest (1 round)
     "deep": dict(d=7, error_model="DP", use_Y=False, volume_depth=16, p_phys=0.004, p_meas=0.004),
     "flat": dict(d=3, error_model="X", use_Y=False, volume_depth=1, p_phys=0.05, p_meas=0.05),
+    # the error models / move sets beside BASELINE.json's, at its batch sizes: independent X and Z flips (generate_IIDXZ_error), Y moves at the headline
+    # rates, X noise at d = 7, depolarising noise at d = 3
+    "iidxz": dict(d=5, error_model="IIDXZ", use_Y=False, volume_depth=5, p_phys=0.008, p_meas=0.008),
+    "c3y": dict(d=5, error_model="DP", use_Y=True, volume_depth=5, p_phys=0.011, p_meas=0.011),
+    "d7x": dict(d=7, error_model="X", use_Y=False, volume_depth=7, p_phys=0.006, p_meas=0.006),
+    "d3dp": dict(d=3, error_model="DP", use_Y=False, volume_depth=3, p_phys=0.01, p_meas=0.01),
 }
 
 
 @pytest.mark.parametrize("name,n_envs,steps", [("c2", 4096, 40), ("c3", 4096, 60), ("c5", 1024, 30), ("c3", 1027, 25),
                                                ("c2-pm0", 4096, 30), ("rare", 512, 25), ("dense", 512, 25), ("deep", 300, 20),
-                                               ("flat", 300, 40)])
+                                               ("flat", 300, 40), ("iidxz", 4096, 40), ("c3y", 4096, 40), ("d7x", 1024, 30), ("d3dp", 4096, 40)])
 def test_full_size_vs_c_oracle(dq, torch_mod, name, n_envs, steps):
     """BASELINE.json batch sizes, device policy (uniform over legal) vs the C oracle, every output
     compared bit-exactly at every step; n_envs=1027 covers a ragged last workgroup."""
