@@ -85,14 +85,18 @@ def test_c_sticky_traces(name):
     (dict(d=5, error_model="X", use_Y=False, volume_depth=5, p_phys=0.007, p_meas=0.0), 60),       # perfect measurements
     (dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=2e-4, p_meas=2e-4), 25),      # nearly every volume rejected
     (dict(d=5, error_model="DP", use_Y=True, volume_depth=3, p_phys=0.3, p_meas=0.3), 40),         # Y moves, errors everywhere
-], ids=["c3-like", "p_meas=0", "rare", "dense-useY"])
+    (dict(d=5, error_model="IIDXZ", use_Y=False, volume_depth=5, p_phys=0.008, p_meas=0.008), 60),  # independent X and Z flips
+    (dict(d=5, error_model="DP", use_Y=True, volume_depth=5, p_phys=0.011, p_meas=0.011), 60),     # Y moves at the headline rates
+    (dict(d=7, error_model="X", use_Y=False, volume_depth=7, p_phys=0.006, p_meas=0.006), 40),
+    (dict(d=3, error_model="DP", use_Y=False, volume_depth=3, p_phys=0.01, p_meas=0.01), 80),
+], ids=["c3-like", "p_meas=0", "rare", "dense-useY", "iidxz", "c3y", "d7x", "d3dp"])
 def test_c_vs_python_oracle_random_walk(cfg, steps):
     """Longer free-running cross-check of the two restatements (uniform-over-legal policy), also at the edges of the rate range the GPU
     parity tests use (tests/test_env_gpu.py::test_full_size_vs_c_oracle)."""
     n_envs, seed = 6, (7, 9)
     ce = c_oracle.COracleEnv(n_envs=n_envs, seed=seed, env_id_base=100, **cfg)
-    lx, lz = c_oracle.luts(5)
-    pes = [env_oracle.OracleEnv(referee=referee.LutReferee(5, cfg["error_model"], lx, lz), seed=seed, env_id=100 + e, **cfg)
+    lx, lz = c_oracle.luts(cfg["d"])
+    pes = [env_oracle.OracleEnv(referee=referee.LutReferee(cfg["d"], cfg["error_model"], lx, lz), seed=seed, env_id=100 + e, **cfg)
            for e in range(n_envs)]
     ce.reset()
     for p in pes:
