@@ -135,7 +135,7 @@ def test_dropout_bits_drawn_ahead_equal_the_kernel_own_draw(dq, torch_mod, name,
 
 
 @pytest.mark.parametrize("name,batch", [("c3", 4096), ("c3", 2049), ("c3", 4091), ("c3", 2048 + 8 * 200 + 3), ("c2", 4096), ("c5", 1024), ("c5", 2500),
-                                        ("c3", 1500), ("c3", 1021)])
+                                        ("c3", 1500), ("c3", 1021), ("c3y", 4096), ("d7x", 1024), ("d3dp", 4096)])
 def test_backward_at_baseline_batch_matches_oracle(dq, torch_mod, name, batch):
     """The fused training forward + backward at the BASELINE.json minibatch sizes against the float64 oracle on the FULL batch.  Only
     batches above 2048 give a workgroup of the persistent convolutional backward more than one group of 8 samples (256 workgroups), i.e.
