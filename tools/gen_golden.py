@@ -299,6 +299,7 @@ BIG_TRACE_CONFIGS = {
     "b3_d11_dp": (11, "DP", False, 0.004, 0.003, 3, 3, 48),     # 121 qubits, 243 actions
     "b4_d13_x": (13, "X", False, 0.006, 0.006, 3, 2, 40),       # planes of 3 words
     "b5_d15_dpy": (15, "DP", True, 0.003, 0.003, 2, 2, 32),     # planes of 4 words, 676 actions
+    "b6_d9_iidxz": (9, "IIDXZ", False, 0.006, 0.005, 4, 4, 64),  # independent X and Z flips on the wide environment (the reference's generator, as x5)
 }
 
 
