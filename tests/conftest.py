@@ -26,7 +26,7 @@ def dq():
     return importlib.import_module("deepq-decoding_amd")
 
 
-TRACES = ["c1_d3_x", "c2_d5_x", "c3_d5_dp", "c5_d7_dp", "x1_d5_dpy", "x2_d5_dp_hot", "x3_d3_x_nomeas", "x4_d7_x", "x5_d5_iidxz"]
+TRACES = ["c1_d3_x", "c2_d5_x", "c3_d5_dp", "c5_d7_dp", "x1_d5_dpy", "x2_d5_dp_hot", "x3_d3_x_nomeas", "x4_d7_x", "x5_d5_iidxz", "x6_d7_iidxz", "x7_d3_dpy"]
 STICKY_TRACES = ["sticky_c3_d5_dp", "sticky_x2_d5_dp_hot"]
 # lattices beyond one 64-bit word per plane (wide environment + matching referee): legal / acted are stored as word arrays
 BIG_TRACES = ["b1_d9_dp", "b2_d9_x", "b3_d11_dp", "b4_d13_x", "b5_d15_dpy", "b6_d9_iidxz"]

@@ -110,8 +110,11 @@ def _replay_wide(dq, torch, name, auto_reset):
     for t in range(n_steps):
         env.step(actions[:, t].contiguous(), auto_reset=auto_reset)
         assert np.array_equal(env.reward.cpu().numpy(), g["reward"][:, t]), (name, "reward", t)
-        if d <= 7:                                                   # (the random walks of the d >= 9 traces do pile up more than 14 defects; the
-            assert not env.inexact.any().item()                      #  fallback is part of the definition and the reference ran with the same rule)
+        if d <= 7 and name != "x6_d7_iidxz":                         # (the random walks of the d >= 9 traces do pile up more than 14 defects; the
+            assert not env.inexact.any().item()                      #  fallback is part of the definition and the reference ran with the same rule.
+                                                                     #  x6: 24 plaquettes per type at d = 7 and independent X + Z flips under a random
+                                                                     #  walk -- the one d <= 7 trace that gets there; it was recorded with the TABLE
+                                                                     #  referee, so every reward / done below also checks the fallback's answers)
         if auto_reset:
             assert np.array_equal(env.was_reset.cpu().numpy(), g["was_reset"][:, t])
         check(t + 1)

@@ -287,6 +287,8 @@ TRACE_CONFIGS = {
     # model string (ENV:66-69), so the trace runs its "DP" environment (same action layers, same four homology classes, FL:329-330) with
     # the name `generate_error` in the Environments module bound to the reference's own IIDXZ generator -- no reference code is changed.
     "x5_d5_iidxz": (5, "IIDXZ", False, 0.02, 0.015, 5, 8, 96),
+    "x6_d7_iidxz": (7, "IIDXZ", False, 0.008, 0.008, 5, 4, 64),    # the same at d = 7 (table referee in L2, depth != d)
+    "x7_d3_dpy": (3, "DP", True, 0.02, 0.02, 3, 8, 96),            # Y moves on the smallest lattice (28 actions)
 }
 
 
