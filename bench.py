@@ -275,6 +275,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if (world > 1 or force_dist) and hasattr(runner, "core") and os.environ.get("DQ_DIST_MODE", "single") == "single":
+        runner.core.ensure_comm()       # the learner's own communicator: its rendezvous belongs to the set-up, also with --warmup 0
     for _ in range(args.warmup):
         runner.step(timed=False)
     if hasattr(runner, "pick_dominant"):

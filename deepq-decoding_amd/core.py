@@ -266,9 +266,7 @@ class DQNCore:
             if probe:
                 e0, e1 = self.ar_pool.pop() if self.ar_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 e0.record()
-            if self._rccl is None and not self._rccl_tried:
-                self._rccl_tried = True
-                self._rccl = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
+            self.ensure_comm()
             if self._rccl is not None:
                 self._rccl.allreduce_sum_(self.grads)
             else:
@@ -385,6 +383,14 @@ class DQNCore:
         self.target.copy_(self.params)
         if self.target_pk is not None:
             self.target_pk.copy_(self.params_pk)
+
+    def ensure_comm(self):
+        """Creates the learner's own RCCL communicator if the several-GPU branch will use one (dist.make_rccl: a collective call -- every rank, at the
+        same point; None for gloo groups / DQ_DIST_NATIVE=0).  Called by the first several-GPU update; bench.py calls it in front of its warm-up
+        steps so that the rendezvous (~1 s) can never fall into a timed region."""
+        if self._rccl is None and not self._rccl_tried and _dist.dist_path(self.world_size):
+            self._rccl_tried = True
+            self._rccl = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
 
     def close_comm(self):
         """Destroys the learner's own RCCL communicator (dist.RcclComm) -- every rank, behind a synchronisation, BEFORE the process group
