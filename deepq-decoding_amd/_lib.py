@@ -101,6 +101,7 @@ SIGNATURES = {
     "dq_env_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_act_step": (_i, [_vp, _vp, _dbl, _i, _seedp, _u64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_act_step_sample": (_i, [_vp, _vp, _dbl, _i, _seedp, _u64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(SampleJob), _vp]),
+    "dq_env_patch_output": (_i, [_vp, _vp, _i]),
     "dq_env_export_state": (_i, [_vp, _vp, _vp]),
     "dq_env_import_state": (_i, [_vp, _vp, _vp]),
     "dq_env_get_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
@@ -129,6 +130,7 @@ SIGNATURES = {
     "dq_qnet_set_grad_scale": (_i, [_vp, _dbl]),
     "dq_qnet_range_check": (_i, [_vp, _vp]),
     "dq_qnet_fused_supported": (_i, [_vp]),
+    "dq_qnet_set_patch_input": (_i, [_vp, _i, _i]),
     "dq_qnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
     "dq_qnet_forward_multi": (_i, [_vp, _i, ctypes.POINTER(QNetJob), _vp]),
     "dq_qnet_packed_bytes": (_sz, [_vp]),

@@ -138,9 +138,12 @@ class SequentialMemory:
         st = dict(limit=self.limit, window_length=1, _saved=None)
         c = self._core
         if c is not None:
-            st["_saved"] = dict(obs=np.packbits(c.obs_ring.cpu().numpy(), axis=None), obs_shape=tuple(c.obs_ring.shape),
-                                action=c.action_ring.cpu().numpy(), reward=c.reward_ring.cpu().numpy(),
+            st["_saved"] = dict(obs_shape=tuple(c.obs_ring.shape), action=c.action_ring.cpu().numpy(), reward=c.reward_ring.cpu().numpy(),
                                 terminal=c.terminal_ring.cpu().numpy(), cur=c.cur, filled=c.filled)
+            if getattr(c, "compact", False):     # the ring holds patch words (core.py): pickled as they are, d * d words per observation
+                st["_saved"]["patch"] = c.patch_ring.cpu().numpy()
+            else:
+                st["_saved"]["obs"] = np.packbits(c.obs_ring.cpu().numpy(), axis=None)
         elif self._saved is not None:
             st["_saved"] = self._saved
         return st
@@ -152,8 +155,15 @@ class SequentialMemory:
         s = self._saved
         if s is None or tuple(s["obs_shape"]) != tuple(core.obs_ring.shape):
             return False
-        n = int(np.prod(s["obs_shape"]))
-        core.obs_ring.copy_(torch.from_numpy(np.unpackbits(s["obs"], count=n).reshape(s["obs_shape"])))
+        if "patch" in s:                            # pickled from a compact ring
+            patch = torch.from_numpy(s["patch"]).to(core.device)
+            if getattr(core, "compact", False) and tuple(patch.shape) == tuple(core.patch_ring.shape):
+                core.patch_ring.copy_(patch)
+            else:
+                core.obs_ring.copy_(core.env.patch_to_obs(patch))
+        else:
+            n = int(np.prod(s["obs_shape"]))
+            core.obs_ring.copy_(torch.from_numpy(np.unpackbits(s["obs"], count=n).reshape(s["obs_shape"])))
         core.action_ring.copy_(torch.from_numpy(s["action"]))
         core.reward_ring.copy_(torch.from_numpy(s["reward"]))
         core.terminal_ring.copy_(torch.from_numpy(s["terminal"]))

@@ -26,10 +26,50 @@ from ._lib import check, ptr
 MIN_FILLED = 4      # ring slots an update needs: keras-rl asserts nb_entries >= window_length + 2 (csrc/common.h dq_replay_row)
 
 
+class ObsRingView:
+    """`DQNCore.obs_ring` where the ring holds PATCH WORDS (DQNCore.compact): the padded uint8 observations [T, N, C, H, W] the
+    reference's memory would hold (SequentialMemory stores the env's board_state, TRAIN:109), decoded on demand from
+    `DQNCore.patch_ring` (env.patch_to_obs: the image is a fixed function of the words).  Indexing returns decoded tensors; copy_()
+    encodes.  Tests, pickling and diagnostics only -- nothing in the loop touches it."""
+
+    def __init__(self, core):
+        self._c = core
+
+    @property
+    def shape(self):
+        p = self._c.patch_ring
+        return torch.Size(tuple(p.shape[:2]) + tuple(self._c.env.obs_shape))
+
+    dtype = torch.uint8
+
+    @property
+    def device(self):
+        return self._c.patch_ring.device
+
+    def __getitem__(self, idx):
+        return self._c.env.patch_to_obs(self._c.patch_ring[idx])
+
+    def clone(self):
+        return self._c.env.patch_to_obs(self._c.patch_ring)
+
+    def cpu(self):
+        return self.clone().cpu()
+
+    def copy_(self, src):
+        if isinstance(src, ObsRingView):
+            self._c.patch_ring.copy_(src._c.patch_ring)
+        else:
+            self._c.patch_ring.copy_(self._c.env.obs_to_patch(torch.as_tensor(src).to(self.device)))
+        return self
+
+    def __eq__(self, other):
+        return self.clone() == (other.clone() if isinstance(other, ObsRingView) else other)
+
+
 class DQNCore:
     def __init__(self, env, net, batch_size=32, memory_limit=50000, gamma=0.99, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
                  target_model_update=10000, enable_double_dqn=True, seed=None, rank=0, world_size=1, process_group=None,
-                 params=None):
+                 params=None, compact=None):
         self.env, self.net = env, net
         self.N, self.A = env.n_envs, env.num_actions
         assert net.n_actions == self.A and tuple(net.input_shape) == tuple(env.obs_shape)
@@ -47,7 +87,25 @@ class DQNCore:
         # ring
         self.T = max(MIN_FILLED, int(memory_limit) // self.N + 1)
         C, H, W = env.obs_shape
-        self.obs_ring = torch.zeros((self.T, self.N, C, H, W), dtype=torch.uint8, device=dev)
+        # Compact observations (include/deepq_hip.h dq_env_patch_output, dq_qnet_set_patch_input): the ring holds d * d patch words per
+        # transition (128 bytes at d = 5 instead of the 847-byte padded image; 2^20 transitions: 134 MB instead of 0.9 GB), the environment
+        # writes them, the first convolution reads them.  Where the fused chains and the one-word-per-plane environment cover the
+        # configuration; DQ_COMPACT_OBS=0 (or compact=False) keeps the uint8 ring.
+        if compact is None:
+            compact = os.environ.get("DQ_COMPACT_OBS", "1") != "0"
+        self.compact = bool(compact and not getattr(env, "wide", False) and getattr(env, "patch_supported", False) and net.fused_supported
+                            and net.fused_enabled and C == env.volume_depth + env.n_action_layers and net.c_layers[0][1:] == [3, 2])
+        if self.compact:
+            try:
+                net.set_patch_input(env.volume_depth, env.patch_stride)        # (before the first pack(): the packed buffer carries the compact kernel)
+            except _lib.DeepQError:
+                self.compact = False
+        if self.compact:
+            self.patch_ring = torch.zeros((self.T, self.N, env.patch_stride), dtype=torch.int32, device=dev)
+            self._obs_ring = None
+        else:
+            self.patch_ring = None
+            self._obs_ring = torch.zeros((self.T, self.N, C, H, W), dtype=torch.uint8, device=dev)
         self.action_ring = torch.zeros((self.T, self.N), dtype=torch.int32, device=dev)
         self.reward_ring = torch.zeros((self.T, self.N), dtype=torch.float32, device=dev)
         self.terminal_ring = torch.zeros((self.T, self.N), dtype=torch.uint8, device=dev)
@@ -100,6 +158,33 @@ class DQNCore:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    @property
+    def obs_ring(self):
+        """uint8 [T, N, C, H, W]: the tensor itself, or -- compact -- a view that decodes the patch words on demand (ObsRingView)."""
+        return ObsRingView(self) if self.compact else self._obs_ring
+
+    @obs_ring.setter
+    def obs_ring(self, value):
+        if self.compact:
+            raise AttributeError("compact ring: assign patch_ring")
+        self._obs_ring = value
+
+    def _obs_slot(self, slot):
+        """(obs pointer, ring slot to arm as patch output) of an environment launch that writes ring slot `slot`."""
+        if self.compact:
+            self.env.arm_patch_output(self.patch_ring[slot])
+            return None
+        return ptr(self._obs_ring[slot])
+
+    def _obs_job(self, **kw):
+        """A forward job on the ring (rows through kw['index']) or on one slot of it (kw['slot'])."""
+        slot = kw.pop("slot", None)
+        ring = self.patch_ring if self.compact else self._obs_ring
+        kw["obs"] = ring if slot is None else ring[slot]
+        if self.compact:
+            kw["patch"] = True
+        return kw
+
     def reset_env(self):
         """env.reset() for every lattice; the new observation lands in ring slot `cur` (which has no action recorded
         yet).  If the ring already holds transitions (a second fit(), or a memory restored from a pickle), the entry
@@ -108,7 +193,10 @@ class DQNCore:
         if self.filled >= 2:
             prev = self.cur - 1 if self.cur > 0 else self.T - 1
             self.terminal_ring[prev].fill_(1)
-        self.env.reset(out_obs=self.obs_ring[self.cur])
+        if self.compact:
+            self.env.reset(out_patch=self.patch_ring[self.cur], write_obs=False)
+        else:
+            self.env.reset(out_obs=self._obs_ring[self.cur])
         self.filled = max(self.filled, 1)
         self.started = True
 
@@ -119,14 +207,13 @@ class DQNCore:
         self._flush_stats()          # bookkeeping of the previous step, if no update() took it along (env buffers are about to be reused)
         env, cur = self.env, self.cur
         nxt = cur + 1 if cur + 1 < self.T else 0
-        obs = self.obs_ring[cur]
         q = None
         if use_q:
-            q = self.net.forward(self.params, obs, batch=self.N, out=self.q_act, packed=self.params_pk)
+            q = self.net.forward_multi([self._obs_job(params=self.params, slot=cur, batch=self.N, out=self.q_act, packed=self.params_pk)])[0]
         # action selection + environment step in one launch (dq_env_act_step == dq_policy_select then dq_env_step)
         seed = (ctypes.c_uint32 * 2)(*env.seed)
         args = (env._h, ptr(q), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
-                ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
+                self._obs_slot(nxt), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
                 ptr(env.lifetime), ptr(env.was_reset))
         filled = min(self.T, self.filled + 1)
         if presample and filled >= MIN_FILLED:
@@ -204,14 +291,14 @@ class DQNCore:
     def _update_jobs(self, t, sample_base):
         # Q_online(s1) picks the action, Q_target(s1) values it (double DQN; without it Q_target does both); the training forward
         # on s0 is independent of both, so the three share one pair of launches
-        B, N, ring = self.batch_size, self.N, self.obs_ring
+        B, N = self.batch_size, self.N
         rows = self.T * N
-        jobs = [dict(params=self.target, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target, packed=self.target_pk)]
+        jobs = [self._obs_job(params=self.target, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target, packed=self.target_pk)]
         if self.enable_double_dqn:
-            jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online,
-                             packed=self.params_pk))
-        jobs.append(dict(params=self.params, obs=ring, batch=B, index=self.index, training=True, seed=self.seed, t=t, sample_base=sample_base,
-                         out=self.q0, packed=self.params_pk))
+            jobs.append(self._obs_job(params=self.params, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online,
+                                      packed=self.params_pk))
+        jobs.append(self._obs_job(params=self.params, batch=B, index=self.index, training=True, seed=self.seed, t=t, sample_base=sample_base,
+                                  out=self.q0, packed=self.params_pk))
         return jobs
 
     def _td_job(self, step_stats=None):
@@ -322,12 +409,9 @@ class DQNCore:
         _, sample_base = _dist.shard(self.rank, N, B)
         self._take_minibatch(t, nxt, filled, sample_base)        # (drawn from the ring as it WILL be after this step)
         jobs = self._update_jobs(t, sample_base)
-        jobs.append(dict(params=self.params, obs=self.obs_ring[cur], batch=N, out=self.q_act, packed=self.params_pk))
+        jobs.append(self._obs_job(params=self.params, slot=cur, batch=N, out=self.q_act, packed=self.params_pk))
         self.net.forward_multi(jobs)
         seed = (ctypes.c_uint32 * 2)(*env.seed)
-        args = (env._h, ptr(self.q_act), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
-                ptr(self.obs_ring[nxt]), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
-                ptr(env.lifetime), ptr(env.was_reset))
         sj = None
         if presample_next:
             nxt2 = nxt + 1 if nxt + 1 < T else 0
@@ -336,15 +420,20 @@ class DQNCore:
                 and not getattr(env, "mlp_referee", False):
             # one launch fewer per step: the environment step (+ look-ahead sampling + this step's episode bookkeeping) rides on the
             # dense backward's first kernel (dq_qnet_td_backward_adam_env / _phase0_env): neither needs the other's results
+            if self.compact:
+                env.arm_patch_output(self.patch_ring[nxt])           # (consumed by the riding step's launch)
             step = dict(q=self.q_act, eps=eps, masked_greedy=masked_greedy, seed=env.seed, t=self.vector_steps, action=self.action_ring[cur],
-                        auto_reset=1, obs=self.obs_ring[nxt], reward=self.reward_ring[cur], done=self.terminal_ring[cur], legal=env.legal,
-                        lifetime=env.lifetime, was_reset=env.was_reset, sample=sj, stats=self.stats if record_stats else None)
+                        auto_reset=1, obs=None if self.compact else self._obs_ring[nxt], reward=self.reward_ring[cur], done=self.terminal_ring[cur],
+                        legal=env.legal, lifetime=env.lifetime, was_reset=env.was_reset, sample=sj, stats=self.stats if record_stats else None)
             self._stats_pending = None
             self.cur, self.filled = nxt, filled
             self.vector_steps += 1
             self.updates = t
             self._learn(t, ride=step)
             return
+        args = (env._h, ptr(self.q_act), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
+                self._obs_slot(nxt), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
+                ptr(env.lifetime), ptr(env.was_reset))
         if self._env_stream is not None:
             main = torch.cuda.current_stream(self.device)
             self._e_fwd.record(main)
@@ -436,11 +525,14 @@ class DQNCore:
         assert getattr(self, "_train_ring", None) is None
         self._flush_stats()
         self._join_env()
-        self._train_ring = (self.obs_ring, self.action_ring, self.reward_ring, self.terminal_ring, self.T, self.cur, self.filled,
-                            self._presampled, self.started)
+        self._train_ring = (self.patch_ring if self.compact else self._obs_ring, self.action_ring, self.reward_ring, self.terminal_ring, self.T,
+                            self.cur, self.filled, self._presampled, self.started)
         T = 3
         dev = self.device
-        self.obs_ring = torch.zeros((T,) + tuple(self.obs_ring.shape[1:]), dtype=torch.uint8, device=dev)
+        if self.compact:
+            self.patch_ring = torch.zeros((T,) + tuple(self.patch_ring.shape[1:]), dtype=torch.int32, device=dev)
+        else:
+            self._obs_ring = torch.zeros((T,) + tuple(self._obs_ring.shape[1:]), dtype=torch.uint8, device=dev)
         self.action_ring = torch.zeros((T, self.N), dtype=torch.int32, device=dev)
         self.reward_ring = torch.zeros((T, self.N), dtype=torch.float32, device=dev)
         self.terminal_ring = torch.zeros((T, self.N), dtype=torch.uint8, device=dev)
@@ -449,8 +541,12 @@ class DQNCore:
     def end_eval(self):
         self._flush_stats()
         self._join_env()
-        (self.obs_ring, self.action_ring, self.reward_ring, self.terminal_ring, self.T, self.cur, self.filled, self._presampled,
+        (ring, self.action_ring, self.reward_ring, self.terminal_ring, self.T, self.cur, self.filled, self._presampled,
          self.started) = self._train_ring
+        if self.compact:
+            self.patch_ring = ring
+        else:
+            self._obs_ring = ring
         self._train_ring = None
         # the lattices were reset and stepped by the evaluation: the ring's newest observation no longer describes them, so the next
         # fit() (which calls reset_env(): previous entry marked terminal, fresh observation into slot `cur`) must not skip its reset

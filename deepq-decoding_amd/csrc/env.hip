@@ -52,6 +52,8 @@ struct dq_env {
     u8* d_dec;                     // [n_envs] class predicted for each lattice's post-action syndrome
     int* d_mlp_cells;              // [2 * n_stab]: stabilizers in increasing cell order of the (d+1)^2 input vector, then their cells
     bool lut_marker;               // lut_x / lut_z only say "a referee is installed" (they point at the Dense stack's weights; never read)
+    u32* patch_next;               // dq_env_patch_output: where the NEXT launch writes the lattices' patch words (one call arms one launch)
+    int patch_stride;
 };
 
 // ---- Dense-stack referee on the device (round 3) ------------------------------------------------------------------------------------
@@ -261,6 +263,14 @@ static void build_tables(dq_env* E) {
         T.cell_static[x * n + y] = v;
     }
     for (int c = 0; c < 256; ++c) T.cell_pack[c] = (u32)T.cell_static[c] | (u32)T.cell_stab[c] << 8 | (u32)T.cell_qubit[c] << 16;
+    // compact observation: the data cells of conv1's 3 x 3 stride-2 patch of output pixel (oy, ox) are its four corners on the syndrome planes
+    // (even-even cells, ENV:292-294) and its centre on the action planes (the odd-odd cell of qubit oy d + ox, ENV:309-312)
+    memset(T.pix_stab, 255, sizeof(T.pix_stab));
+    for (int oy = 0; oy < d; ++oy) for (int ox = 0; ox < d; ++ox) {
+        u32 w = 0;
+        for (int c = 0; c < 4; ++c) w |= (u32)T.cell_stab[2 * (oy + (c >> 1)) * n + 2 * (ox + (c & 1))] << (8 * c);
+        T.pix_stab[oy * d + ox] = w;
+    }
     // BFS generators: flipping component `comp` of qubit q toggles these referee-index bits (+ the logical bit)
     const int nh = n_stab / 2;
     for (int comp = 0; comp < 2; ++comp) {
@@ -598,6 +608,8 @@ static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = fals
         const size_t entries = (size_t)1 << (E->info.n_stab / 2), words = (entries + 31) / 32;
         p.lut_words = (p.mode == 1 && E->lut_x && E->lut_z && !E->lut_joint && !E->lut_marker && !E->mlp_layers && words <= ENV_LUT_LDS_MAX) ? (int)words : 0;
     }
+    p.patch = E->patch_next; p.patch_stride = E->patch_stride;     // (armed by dq_env_patch_output for this one launch)
+    E->patch_next = nullptr;
     p.env_blocks = (p.n_envs + epb - 1) / epb;
     // the riding step's sampling is drawn by the lattices' own blocks when their threads cover the minibatch (env_dev.h env_inline_sampling)
     if (rider && p.s_batch > 0 && (long long)p.env_blocks * 512 >= p.s_batch) p.s_blocks = 0;
@@ -700,6 +712,16 @@ dq_status dq_env_act_step_sample(dq_env* E, const float* q_dev, double eps, int 
     DQ_REQUIRE(sample, DQ_ERR_INVALID, "dq_env_act_step_sample: null sampling job");
     return act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev, lifetime_dev,
                     was_reset_dev, sample, stream);
+}
+
+dq_status dq_env_patch_output(dq_env* E, uint32_t* patch_dev, int stride_words) {
+    DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_patch_output: null handle");
+    DQ_REQUIRE(4 * E->cfg.volume_depth + E->info.n_action_layers <= 32, DQ_ERR_UNSUPPORTED,
+               "dq_env_patch_output: 4 * volume_depth + action layers = %d data bits per pixel do not fit one word", 4 * E->cfg.volume_depth + E->info.n_action_layers);
+    DQ_REQUIRE(!patch_dev || stride_words >= E->cfg.d * E->cfg.d, DQ_ERR_INVALID, "dq_env_patch_output: stride_words must be at least d * d");
+    DQ_REQUIRE((reinterpret_cast<uintptr_t>(patch_dev) & 3) == 0, DQ_ERR_INVALID, "dq_env_patch_output: patch_dev must be 4-byte aligned");
+    E->patch_next = patch_dev; E->patch_stride = stride_words;
+    return DQ_OK;
 }
 
 dq_status dq_env_export_state(dq_env* E, uint64_t* state_dev, void* stream) {

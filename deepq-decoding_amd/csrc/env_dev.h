@@ -20,6 +20,8 @@ struct EnvTables {
     u8 cell_stab[256];     // stabilizer shown at an even-even cell (ENV:292-294), 255: none
     u8 cell_qubit[256];    // qubit shown at an odd-odd cell of an action plane (ENV:301-314), 255: none
     u32 cell_pack[256];    // the three cell tables in one word: static | stab << 8 | qubit << 16 (a lane keeps its cells' words in registers)
+    u32 pix_stab[64];      // compact observation: the stabilizers at the four corners (dy, dx) of conv1's 3 x 3 stride-2 patch of output pixel p = oy d + ox,
+                           // byte 2 dy + dx = stabilizer shown at padded cell (2 (oy + dy), 2 (ox + dx)), 255: none (a dead corner of the (d+1)^2 grid)
     u64 col0, row0;        // FL:312-317
 };
 
@@ -62,7 +64,42 @@ struct EnvParams {
     int pair;                      // 1: two lattices per wave (env_block2; d <= 5: qubits, stabilizers and record words all fit 32 lanes)
     int lut_words;                 // > 0: lut_x / lut_z (this many words each; d <= 5: 128) are copied into LDS at the top of a block, so that the
                                    // referee look-up behind the syndrome is an LDS read instead of a dependent round trip to L2
+    // compact observation (dq_env_patch_output): one u32 per lattice and conv1 output pixel p = oy d + ox -- the DATA bits of the pixel's 3 x 3
+    // stride-2 patch of the padded planes: bit 4 j + 2 dy + dx = faulty syndrome plane j at grid cell (oy + dy, ox + dx) (the patch's corners,
+    // ENV:292-294), bit 4 depth + l = action plane l at qubit p (its centre, ENV:309-312); every other cell of the patch is a constant of
+    // padding_syndrome / padding_actions (ENV:273-314).  Row i = lattice i, patch_stride words apart.  NULL: not written.
+    u32* patch;
+    int patch_stride;
 };
+
+// The lattice's patch words (EnvParams.patch): lane p < d2 composes pixel p's word from the volume words `vol` (LDS, lane-shared) and the
+// completed-actions mask.  ps = EnvTables.pix_stab[p].
+static __device__ __forceinline__ u32 env_patch_word(const EnvParams& p, const volatile u64* vol, u64 comp0, u64 comp1, u32 ps, int pix) {
+    u32 w = 0;
+    for (int j = 0; j < p.depth; ++j) {
+        const u64 v = vol[j];
+        const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32 s = (ps >> (8 * c)) & 0xffu;
+            const u32 src = (s & 32u) ? vhi : vlo;
+            w |= (s < 64u ? (src >> (s & 31u)) & 1u : 0u) << (4 * j + c);
+        }
+    }
+    for (int l = 0; l < p.layers; ++l) {
+        const int a = l * p.d2 + pix;
+        w |= (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1) << (4 * p.depth + l);
+    }
+    return w;
+}
+
+// lanes of one wave hand words to each other through LDS (the per-wave referee tables, the volume words): wavefront-scope release / acquire
+// + wave barrier, so that the ordering does not rest on the compiler's aliasing analysis (as match_dev.h match_wave_sync)
+static __device__ __forceinline__ void env_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // (lo, hi) |= v << s over 128 bits, 0 <= s < 128.  Branch-free on VALUES: written as three branches that update one word or the other, hipcc kept
 // the pair in SCRATCH memory and selected the word by address -- a load / wait / store round trip per call in the lattices' reset path.
@@ -132,6 +169,7 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
     const u64 nq = T->neigh_qmask[lane];
     const bool isx = T->stab_isx[lane] != 0;
     const int rsrc = T->ref_src[lane];
+    const u32 pstab = T->pix_stab[lane];                 // (unconditional: a guarded load is a branch with a wait of its own)
     const u64 col0 = T->col0, row0 = T->row0;
     volatile u64* vol = s_vol + wave * DQ_MAX_DEPTH;   // written by lane 0, read by other lanes of the same wave
     u64* rec = p.state + (size_t)(active ? i : 0) * p.sw;
@@ -140,8 +178,9 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
     const bool have_q = p.policy && p.q != nullptr;
 #pragma unroll
     for (int m = 0; m < ENV_QPRE; ++m) qpre[m] = have_q ? p.q[(size_t)(active ? i : 0) * p.n_actions + min(lane + 64 * m, p.n_actions - 1)] : 0.f;
-    // (a copy per wave: written and read by the same wave, whose LDS operations execute in order -- no barrier)
+    // (a copy per wave: written and read by the same wave -- no workgroup barrier, a wavefront fence)
     for (int k = lane; k < p.lut_words; k += 64) { s_lut[k] = p.lut_x[k]; s_lut[p.lut_words + k] = p.lut_z[k]; }
+    if (p.lut_words) env_wave_sync();
 
     u64 comp0 = 0, comp1 = 0;
     if (p.stats && lane < 4) s_est[wave][lane] = 0;
@@ -319,6 +358,12 @@ static __device__ __forceinline__ void env_block(const EnvParams& p, const int b
                 }
             }
         }
+        // ---- compact observation: this lane's pixel word, straight to global memory (no stage, no barrier) ----------------------------------
+        if (p.patch) {
+            env_wave_sync();                                                // (lane 0's volume words)
+            const u32 w = env_patch_word(p, vol, comp0, comp1, pstab, lane);
+            if (lane < p.d2) p.patch[(size_t)i * p.patch_stride + lane] = w;
+        }
     }
 
     if (!p.obs && !p.stats) { env_inline_sampling<THREADS>(p, block); return; }    // block-uniform
@@ -401,6 +446,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
     const u64 nq = T->neigh_qmask[hl];
     const bool isx = T->stab_isx[hl] != 0;
     const int rsrc_x = T->ref_src[hl], rsrc_z = T->ref_src[32 + hl];
+    const u32 pstab = T->pix_stab[hl];
     const u64 col0 = T->col0, row0 = T->row0;
     volatile u64* vol = s_vol + slot * DQ_MAX_DEPTH;   // written by lane 0 of the half, read by its other lanes
     u64* rec = p.state + (size_t)(active ? i : 0) * p.sw;
@@ -409,7 +455,8 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
     const bool have_q = p.policy && p.q != nullptr;
 #pragma unroll
     for (int m = 0; m < ENV_QPRE; ++m) qpre[m] = have_q ? p.q[(size_t)(active ? i : 0) * p.n_actions + min(hl + 32 * m, p.n_actions - 1)] : 0.f;
-    for (int k = lane; k < p.lut_words; k += 64) { s_lut[k] = p.lut_x[k]; s_lut[p.lut_words + k] = p.lut_z[k]; }      // (per wave: no barrier)
+    for (int k = lane; k < p.lut_words; k += 64) { s_lut[k] = p.lut_x[k]; s_lut[p.lut_words + k] = p.lut_z[k]; }      // (per wave: a wavefront fence, no barrier)
+    if (p.lut_words) env_wave_sync();
 
     u64 comp0 = 0, comp1 = 0;
     if (p.stats && hl < 4) s_est2[slot][hl] = 0;
@@ -589,6 +636,11 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
                     if (c < p.P) st[(p.depth + k2) * p.P + c] = (u8)bit;
                 }
             }
+        }
+        if (p.patch) {                                                      // compact observation (env_block's comment)
+            env_wave_sync();
+            const u32 w = env_patch_word(p, vol, comp0, comp1, pstab, hl);
+            if (hl < p.d2) p.patch[(size_t)i * p.patch_stride + hl] = w;
         }
         DQ_STAMP(DQ_TAG_ENV, 6);
     }

@@ -81,11 +81,25 @@ struct ConvChainArgs {
     const int* kofftab;                // [96] first convolution: weight row k -> byte offset inside an observation, -1 past K1
     const int* rowtab;                 // [3][CONV_ROWTAB] output row m of a workgroup -> where its input patch starts (fused_conv_row_tables): the
                                        // kernel never divides (every m -> (sample, y, x) was ~30 VALU, ten of them quarter-rate multiplies)
+    const int* rowtab0;                // the first convolution's table: rowtab, or with patch-word input qnet.h PT_FWD
     int slot;                          // bytes per sample slot in LDS (multiple of 16, >= C*H*W + 30)
     int off_mis, off_t1, off_a1, off_a2;   // LDS byte offsets (observations at 0; a2 overlays observations + tables)
     int off_fx;                        // CONV_SWZ: byte per first-convolution output row = its chunk swizzle in halves (8 * f, f = 2 (ox & 3))
     int total_groups, off_obs1, off_a2b;   // persistent kernel: groups of S samples over all jobs; second observation buffer; a2 when the group's observations are in it
+    // patch-word input (the kernels' KG1 == 0 instances; qnet.h PT_*, c1c, b1p): observation rows are `slot` bytes of u32 words, 16-byte aligned
+    int off_lut;                       // LDS: byte -> its eight bits as f16 0 / 1 (256 x 16 bytes), built by the workgroup
+    int pk_c1c, pk_b1p;                // u32x4 offsets of the compact first kernel and of the per-pixel bias table inside a job's packed buffer
 };
+
+// Patch-word input: the byte -> eight f16 (0 / 1) table every workgroup builds once (entry b, half e = bit e of b)
+__device__ __forceinline__ void conv_build_bit_lut(u32x4* s_lut, int tid, int threads) {
+    for (int b = tid; b < 256; b += threads) {
+        u32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (((u32)b >> (2 * q)) & 1u) * 0x3c00u | (((u32)b >> (2 * q + 1)) & 1u) * 0x3c000000u;
+        s_lut[b] = v;
+    }
+}
 
 // One stride-1 convolution on the f16 matrix pipe at f32-class accuracy (f16x2, qnet.h).  Its input is an LDS image of READY-MADE
 // pieces: two f16 planes [pixel][CIN + 8] (h plane, then the l plane `lo_in` halves further), written once by the producing layer's
@@ -218,7 +232,61 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
     }
 }
 
-template <int KG1>      // first convolution's K padded to 16 * KG1
+// ---- the first convolution over patch words (KG1 == 0 instances of both conv kernels) ---------------------------------------------------
+// Output pixel p of Conv2D(64, 3, strides=2) on the padded planes has K_data <= 32 DATA cells in its 3 x 3 patch (four corners per syndrome
+// plane, the centre per action plane: include/deepq_hip.h dq_env_patch_output); they arrive as ONE u32 per sample and pixel.  The A operand of
+// the single K = 32 block is therefore one byte per lane (lane (kq, j): bits 8kq .. 8kq+7 of row j's word) expanded through a 256-entry LDS table --
+// one ds_read_u8 + one ds_read_b128 where the uint8 image took 16 byte gathers, 8 packs and 8 multiplies -- and 8 MFMAs per tile instead of 16 / 24;
+// the patch's constant cells are a per-pixel bias (qnet.h b1p), read through L1 (6 KB at d = 5) before the tile's MFMAs.
+//   s_in    the group's staged rows (row s at s * slot);  s_t1[m] & 0x1ffff = s * slot + 4 p for row m = s * r1 + p, padded to whole tiles
+//   wb      [piece][column tile] the compact kernel's pieces (qnet.h c1c);  b1p  [r1][64] f32
+// Output: a1 piece planes, rows of 64 halves (l plane lo1 halves further), rows < M1 only.
+__device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, const int* __restrict__ s_t1, const u32x4* __restrict__ s_lut,
+                                                  const u32x4 (&wb)[2][1][4], const float* __restrict__ b1p, int slot, unsigned short* __restrict__ s_a1, int lo1,
+                                                  int M1, int wfirst, int j, int kq) {
+    const int tiles = (M1 + 15) >> 4;
+    if (wfirst >= tiles) return;                                    // wave-uniform
+    auto byte_of = [&](int tile) -> u32 { return s_in[(s_t1[min(tile * 16 + j, M1 - 1)] & 0x1ffff) + kq]; };      // (tiles past the end reread the last row)
+    auto tile_out = [&](int tile, u32 byte) {
+        const u32x4 av = s_lut[byte];
+        const int4 e4 = *reinterpret_cast<const int4*>(s_t1 + tile * 16 + 4 * kq);     // this lane's four output rows (the table is padded to whole tiles)
+        const int ent[4] = {e4.x, e4.y, e4.z, e4.w};
+        f32x4 bp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bp[r] = *reinterpret_cast<const f32x4*>(b1p + ((ent[r] & (slot - 1)) << 4) + 4 * j);     // 4 p -> p * 64 floats
+        f32x4 acc[4], accl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[t] = acc[t]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = MFMA_F16(av, wb[0][0][t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accl[t] = MFMA_F16(av, wb[1][0][t], accl[t]);
+        f32x4 vs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vs[t] = f16x2_sum(acc[t], accl[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mo = tile * 16 + 4 * kq + r;
+            if (mo >= M1) continue;
+            f32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = relu1(vs[t][r] + bp[r][t]);
+            u32 hp[2], lp[2];                                       // split on write: this lane's 4 consecutive channels of pixel mo
+            split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
+            split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
+            unsigned short* dst = s_a1 + mo * 64 + 4 * j;
+            *reinterpret_cast<uint2*>(dst) = uint2{hp[0], hp[1]};
+            *reinterpret_cast<uint2*>(dst + lo1) = uint2{lp[0], lp[1]};
+        }
+    };
+    u32 bA = byte_of(wfirst), bB;
+    for (int tile = wfirst;;) {
+        bB = byte_of(tile + CONV_WAVES); tile_out(tile, bA); tile += CONV_WAVES; if (tile >= tiles) break;
+        bA = byte_of(tile + CONV_WAVES); tile_out(tile, bB); tile += CONV_WAVES; if (tile >= tiles) break;
+    }
+}
+
+template <int KG1>      // first convolution's K padded to 16 * KG1; 0: patch-word input (conv1_patch_words)
 __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8* s_in = smem;
@@ -233,8 +301,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     const int grp = (int)blockIdx.x - J.wg0;
     const int b0 = grp * a.S;
     const int ns = min(a.S, J.batch - b0);
-    const int in_bytes = a.C * a.H * a.W;
-    constexpr int NH1 = (KG1 + 1) / 2;                              // first convolution's K in halves of 32
+    constexpr bool CP = KG1 == 0;                                   // patch-word input: one u32 per pixel instead of the padded uint8 image
+    const int in_bytes = CP ? a.slot : a.C * a.H * a.W;
+    constexpr int NH1 = CP ? 1 : (KG1 + 1) / 2;                     // first convolution's K in halves of 32
+    constexpr int A1S = CP ? 64 : A1_PS;                            // halves per a1 row in LDS (patch-word input: unpadded, which makes room for the bit table)
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 0);
     DQ_STAMP_WG(DQ_TAG_CONV_FWD, 0);
@@ -248,29 +318,33 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     u32x4 wb[2][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 f16 each
     int ko[NH1][8];
     {
-        const u32x4* pk1 = J.packed + PK_CONV1 + lane;
+        const u32x4* pk1 = J.packed + (CP ? a.pk_c1c : PK_CONV1) + lane;
 #pragma unroll
         for (int h = 0; h < NH1; ++h)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int piece = 0; piece < 2; ++piece) wb[piece][h][t] = pk1[(h * 4 + t) * PK_BLOCK + PK_LO * piece];
+        if constexpr (!CP) {
 #pragma unroll
-        for (int h = 0; h < NH1; ++h)
+            for (int h = 0; h < NH1; ++h)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ko[h][e] = max(a.kofftab[32 * h + 8 * kq + e], 0);      // Keras HWIO row k -> NCHW uint8 offset (-1 past K1: weights 0)
+                for (int e = 0; e < 8; ++e) ko[h][e] = max(a.kofftab[32 * h + 8 * kq + e], 0);      // Keras HWIO row k -> NCHW uint8 offset (-1 past K1: weights 0)
+        }
     }
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(J.params + a.b_off[0] + 4 * j);
     // row tables (requested here, used behind the barriers): this thread's first-convolution row, this lane's two rows of the wave's first
     // tile pair of the second and third convolution
     const int r1 = a.oh1 * a.ow1, M1 = ns * r1, M2 = ns * a.oh2 * a.ow2, M3 = ns * a.oh3 * a.ow3;
-    const int tab1 = a.rowtab[min(tid, M1 - 1)];
+    const int tab1 = a.rowtab0[min(tid, M1 - 1)];
     int tab2[2], tab3[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        tab2[u] = a.rowtab[CONV_ROWTAB + min((2 * wave + u) * 16 + j, M2 - 1)];
+        tab2[u] = a.rowtab[(CP ? 3 : 1) * CONV_ROWTAB + min((2 * wave + u) * 16 + j, M2 - 1)];      // (table 3: a1 rows of 64 halves)
         tab3[u] = a.rowtab[2 * CONV_ROWTAB + min((2 * wave + u) * 16 + j, M3 - 1)];
     }
+    u32x4* s_lut = reinterpret_cast<u32x4*>(smem + a.off_lut);
+    if constexpr (CP) conv_build_bit_lut(s_lut, tid, CONV_THREADS);
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 1);
     // ---- stage the observations by LDS-DMA (global -> LDS, no registers): lane l copies aligned 16-byte word l of a 1 KB piece of a
@@ -294,7 +368,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
             int row = rows[q];
             if (J.index) { row += J.index_off; if (row >= J.index_mod) row -= J.index_mod; }
             const u8* src = J.obs + (size_t)row * in_bytes;
-            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 15);
+            const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 15);  // (patch words: rows are 16-byte aligned, 0)
             // 16 bytes per lane: ONE instruction copies up to 1 KB (a whole d = 5 observation; four dword copies before)
             const u32x4* gp = reinterpret_cast<const u32x4*>(src - mis) + lane;
             u8* lp = s_in + s * a.slot;
@@ -306,10 +380,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     }
     __syncthreads();                                                // s_mis
     // byte offset of output pixel m's patch origin inside the staged observations
-    const int lo1 = a.S * r1 * A1_PS, lo2 = a.S * a.oh2 * a.ow2 * 40;     // halves from an h plane to its l plane
+    const int lo1 = a.S * r1 * A1S, lo2 = a.S * a.oh2 * a.ow2 * 40;     // halves from an h plane to its l plane
     int* s_t1 = reinterpret_cast<int*>(smem + a.off_t1);
-    for (int m = tid; m < M1; m += CONV_THREADS) {                  // table entry: sample << 20 | swizzle f << 17 | offset of the patch inside the observation
-        const int e = m == tid ? tab1 : a.rowtab[m], s = e >> 20;
+    for (int m = tid; m < (CP ? (M1 + 15) & ~15 : M1); m += CONV_THREADS) {     // table entry: sample << 20 | swizzle f << 17 | offset of the patch inside the observation
+        const int e = m == tid && m < M1 ? tab1 : a.rowtab0[min(m, M1 - 1)], s = e >> 20;      // (patch words: padded to whole tiles with the last row)
         s_t1[m] = s * a.slot + s_mis[s] + (e & 0x1ffff);
         if (CONV_SWZ) s_fx[m] = (u8)(((e >> 17) & 7) << 3);         // 8 f halves
     }
@@ -319,7 +393,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 2);
     // ---- convolution 1: A gathered byte-wise from the uint8 image; the bytes of this wave's next tile are requested before the
     //      MFMAs of the current one ----------------------------------------------------------------------------------------------
-    {
+    if constexpr (CP) {
+        conv1_patch_words(s_in, s_t1, s_lut, wb, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wave, j, kq);
+    } else {
         const int tiles = (M1 + 15) >> 4;
         auto origin = [&](int tile) { return s_t1[min(tile * 16 + j, M1 - 1)]; };     // rows past the end (and whole tiles past it) reread the last row
         auto rd = [&](int org, u32 (&ab)[NH1][8]) {
@@ -384,7 +460,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     conv_w_prefetch(ring, J.packed + PK_CONV2_FWD, lane);
     __syncthreads();
     DQ_STAMP(DQ_TAG_CONV_FWD, 4);
-    {
+    if constexpr (CP) {
+        conv_from_lds<64, 32, 2, 4, 2, false, 0>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
+                                                 nullptr, wave, lane, a.rowtab + 3 * CONV_ROWTAB, tab2[0], tab2[1]);
+    } else {
         conv_from_lds<64, 32, 2, 4, 2, CONV_SWZ != 0>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
                                                       nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1]);
     }
@@ -406,7 +485,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
         // a1: LDS rows of A1_PS halves (chunks swizzled with CONV_SWZ) -> global rows of 64 (8 slots of 16 B per row and plane); a2: rows of 40 -> 32 (4 slots)
         for (int i = tid; i < 2 * M1 * 8; i += CONV_THREADS) {
             const int piece = i >= M1 * 8 ? 1 : 0, q = i - piece * M1 * 8, row = q >> 3, part = q & 7;
-            const int src = CONV_SWZ ? row * 64 + ((8 * part) ^ (int)s_fx[row]) : row * 72 + 8 * part;
+            const int src = CP ? row * 64 + 8 * part : CONV_SWZ ? row * 64 + ((8 * part) ^ (int)s_fx[row]) : row * 72 + 8 * part;
             *reinterpret_cast<u32x4*>(J.a1_pl + piece * J.a1_lo + ((size_t)b0 * r1 + row) * 64 + 8 * part) =
                 *reinterpret_cast<const u32x4*>(s_a1 + piece * lo1 + src);
         }
@@ -442,8 +521,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);          // [2][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     static_assert(FWD_MAX_JOBS == 4, "three comparisons");
-    const int in_bytes = a.C * a.H * a.W;
-    constexpr int NH1 = (KG1 + 1) / 2;                              // first convolution's K in halves of 32
+    constexpr bool CP = KG1 == 0;                                   // patch-word input (conv1_patch_words)
+    const int in_bytes = CP ? a.slot : a.C * a.H * a.W;
+    constexpr int NH1 = CP ? 1 : (KG1 + 1) / 2;                     // first convolution's K in halves of 32
     const int r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
     const int lo1 = (CONV1_PIPE ? (a.S * r1 + 15) & ~15 : a.S * r1) * 64, lo2 = a.S * r2 * 40;      // halves from an h plane to its l plane (CONV1_PIPE: whole 16-row tiles)
     const int total = a.total_groups, gstride = (int)gridDim.x;
@@ -455,7 +535,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     int ko[NH1][8];                                                 // (requested with the first layer's weights, per group: 16 registers that would
                                                                     // otherwise stay live through the other two convolutions)
     const int MF1 = a.S * r1, MF2 = a.S * r2, MF3 = a.S * r3;
-    const int tab1 = a.rowtab[min(tid, MF1 - 1)];
+    const int tab1 = a.rowtab0[min(tid, MF1 - 1)];
+    u32x4* s_lut = reinterpret_cast<u32x4*>(smem + a.off_lut);
+    if constexpr (CP) conv_build_bit_lut(s_lut, tid, CONV_THREADS);     // (published by the first group's top barrier)
     int tab2[2], tab3[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -466,19 +548,21 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     u32x4 wb[2][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 f16 each
     f32x4 bias1;
     auto load_w1 = [&](const ConvJob& Jn) {
-        const u32x4* pk1 = opaque_global(Jn.packed + PK_CONV1) + lane;
+        const u32x4* pk1 = opaque_global(Jn.packed + (CP ? a.pk_c1c : PK_CONV1)) + lane;
 #pragma unroll
         for (int h = 0; h < NH1; ++h)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int piece = 0; piece < 2; ++piece) wb[piece][h][t] = pk1[(h * 4 + t) * PK_BLOCK + PK_LO * piece];
-        bias1 = *reinterpret_cast<const f32x4*>(Jn.params + a.b_off[0] + 4 * j);
-        const int* kt = reinterpret_cast<const int*>(opaque_global(reinterpret_cast<const u32x4*>(a.kofftab))) + 8 * kq;
+        if constexpr (!CP) {
+            bias1 = *reinterpret_cast<const f32x4*>(Jn.params + a.b_off[0] + 4 * j);
+            const int* kt = reinterpret_cast<const int*>(opaque_global(reinterpret_cast<const u32x4*>(a.kofftab))) + 8 * kq;
 #pragma unroll
-        for (int h = 0; h < NH1; ++h)
+            for (int h = 0; h < NH1; ++h)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ko[h][e] = kt[32 * h + e];      // Keras HWIO row k -> NCHW uint8 offset (-1 past K1: weights 0; clamped at the use)
+                for (int e = 0; e < 8; ++e) ko[h][e] = kt[32 * h + e];      // Keras HWIO row k -> NCHW uint8 offset (-1 past K1: weights 0; clamped at the use)
+        }
     };
     // LDS-DMA of group g's observations into buffer buf (conv_chain_kernel's staging: whole aligned 16-byte words of arbitrarily aligned rows)
     // Staging in two steps.  prep(g): the scalar part -- job record, this wave's replay rows of group g -- requested TWO groups ahead (at the tail of
@@ -528,8 +612,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     // it cost every group a pass over the table and a barrier of its own: 0.7K of a group's 17K cycles.)
     {
         int* s_t1c = reinterpret_cast<int*>(smem + a.off_t1);
-        for (int m = tid; m < MF1; m += CONV_THREADS) {
-            const int e = m == tid ? tab1 : a.rowtab[m], s = e >> 20;
+        for (int m = tid; m < (CP ? (MF1 + 15) & ~15 : MF1); m += CONV_THREADS) {      // (patch words: padded to whole tiles with the last row)
+            const int e = m == tid && m < MF1 ? tab1 : a.rowtab0[min(m, MF1 - 1)], s = e >> 20;
             s_t1c[m] = (e & ~0x1ffff) | (s * a.slot + (e & 0x1ffff));
         }
     }
@@ -558,17 +642,21 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
         // this wave's older memory operations retire here: its pieces of this group's observations (requested a group ago) and this group's
         // first-layer weights -- BEFORE the next group's DMA is issued (see the kernel's header)
         __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+        if constexpr (!CP) {
 #pragma unroll
-        for (int h = 0; h < NH1; ++h)
+            for (int h = 0; h < NH1; ++h)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ko[h][e] = max(ko[h][e], 0);
+                for (int e = 0; e < 8; ++e) ko[h][e] = max(ko[h][e], 0);
+        }
         __syncthreads();                                            // every wave's pieces have landed; the previous group's LDS images are dead
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 1);
         const int nxt = gid + gstride;
         if (nxt < total) issue(pre, cur ^ 1);                       // block-uniform
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 2);
         // ---- convolution 1 (conv_chain_kernel's, on rows of 64 halves) ------------------------------------------------------------
-        {
+        if constexpr (CP) {
+            conv1_patch_words(s_in, s_t1, s_lut, wb, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wv, j, kq);
+        } else {
             const int tiles = (M1 + 15) >> 4;
             auto origin = [&](int tile) {                           // (constant table entry + the sample's alignment offset of THIS group)
                 const int e = s_t1[min(tile * 16 + j, M1 - 1)];
@@ -1108,6 +1196,9 @@ struct PackArgs {
     int w3q_off, w3q_rows;              // the folded dueling layer (qnet.h w3q): u32x4 offset, rows 16 KG3 (+ 1: the bias row); 0 rows = no dueling layer
     int w3d_off, b3d_off, N3, n_actions;    // the dueling layer's kernel [N2][N3] and bias [N3] in params
     int wc_off, wc_waves;               // Wc (qnet.h wc: the dense backward's gH1 rows with the TD step fused in): u32x4 offset, waves that build it (0: none)
+    const int* ptab;                    // patch-word input (qnet.h PT_*), NULL: not configured -- the two sections below are left alone
+    int c1c_off, b1p_off, b1p_rows;     // u32x4 offsets of the compact first kernel (4 blocks) and of the per-pixel bias table; its rows (pixels)
+    int p_depth, p_C, b1_off;           // syndrome planes, input planes, the first bias in params
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
@@ -1120,6 +1211,35 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
         // the dueling layer folded with its combination (qnet.h w3q): one wave per row k of the dueling kernel (row w3q_rows: its bias),
         // lane = action a (+ 64): out[a] = (V + A_a) - mean_a' A_a', the mean by a fixed-order butterfly
         const int r = blk_id - e_d1t;
+        const int n_w3 = (a.w3q_rows ? a.w3q_rows + 1 : 0) + a.wc_waves;
+        if (r >= n_w3) {
+            // the first convolution over patch words (qnet.h c1c, b1p; include/deepq_hip.h dq_env_patch_output).  Output pixel (oy, ox) of
+            // Conv2D(64, 3, strides=2) on the padded planes sees 4 corner cells per syndrome plane + the centre cell per action plane as DATA;
+            // every other cell of its 3 x 3 patch is a constant of the embedding, 1 at position-dependent places (ENV:284-298) -- folded into a bias per pixel.
+            const int rc = r - n_w3;
+            if (!a.ptab) return;
+            if (rc < 4) {                                               // B(k = 8kb + e, col = 4j + rc) = W1[PT_KROW[k]][col]
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int row = a.ptab[PT_KROW + 8 * kb + e];
+                    v[e] = row >= 0 ? params[a.w1_off + (size_t)row * 64 + 4 * j + rc] : 0.f;
+                }
+                const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+                u32x4* dst = pk + a.c1c_off + (size_t)rc * PK_BLOCK + lane;
+                dst[0] = o.h; dst[PK_LO] = o.l;
+            } else if (rc - 4 < a.b1p_rows) {                           // one wave per pixel, lane = output channel
+                const int pix = rc - 4, mask = a.ptab[PT_CONST + pix];
+                double acc = (double)params[a.b1_off + lane];
+                for (int c = 0; c < 5; ++c) {
+                    if (!((mask >> c) & 1)) continue;
+                    const int pos = a.ptab[PT_CPOS + c];
+                    for (int pl = 0; pl < a.p_depth; ++pl) acc += (double)params[a.w1_off + (size_t)(pos * a.p_C + pl) * 64 + lane];
+                }
+                reinterpret_cast<float*>(pk + a.b1p_off)[(size_t)pix * 64 + lane] = (float)acc;
+            }
+            return;
+        }
         if (a.w3q_rows == 0) return;
         if (r > a.w3q_rows) {
             // Wc [|A|][512] = W3'^T W2^T: row a = what gH1 = gY2 W2^T is for a sample whose dq is 1 at action a (times its TD error: fused_bwd.hip).
@@ -1234,7 +1354,10 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.w3q_rows = Q->cfg.dueling ? (D2.nout <= 64 ? 64 : 128) : 0;  // 16 KG3 (dense_chain_kernel: KG3 = NT2 = 4 or 8)
     P.wc = P.w3q + ((size_t)(2 * P.w3q_rows + 1) * 16 * P.NT2 + 3) / 4;      // W3' rows, the bias row, then W3'^T [16 NT2][w3q_rows]
     P.wc_rows = (Q->cfg.dueling && P.NT2 == 4) ? Q->cfg.n_actions : 0;     // (the dense backward's shortcut: tables up to 64 x 64)
-    P.total = P.wc + (size_t)P.wc_rows * DENSE_HID / 4;
+    P.c1c = P.wc + (size_t)P.wc_rows * DENSE_HID / 4;
+    P.b1p_rows = Q->L[0].rows <= 64 ? Q->L[0].rows : 0;              // (patch-word input: one word per pixel and lane, d <= 7)
+    P.b1p = P.c1c + (P.b1p_rows ? 4 * PK_BLOCK : 0);
+    P.total = P.b1p + (size_t)P.b1p_rows * 64 / 4;
     return P;
 }
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return fused_pack_layout(Q).total; }
@@ -1263,7 +1386,10 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     a.w3q_off = (int)PL.w3q; a.w3q_rows = PL.w3q_rows; a.n_actions = Q->cfg.n_actions;
     if (Q->cfg.dueling) { const Layer& D3 = Q->L[nc + 2]; a.w3d_off = (int)D3.w_off; a.b3d_off = (int)D3.b_off; a.N3 = D3.nout; }
     a.wc_off = (int)PL.wc; a.wc_waves = PL.wc_rows ? DENSE_HID : 0;
-    a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + a.wc_waves + 3) / 4;
+    a.ptab = Q->patch_depth && PL.b1p_rows ? Q->ptab : nullptr;
+    a.c1c_off = (int)PL.c1c; a.b1p_off = (int)PL.b1p; a.b1p_rows = PL.b1p_rows; a.p_depth = Q->patch_depth; a.p_C = Q->L[0].cin; a.b1_off = (int)Q->L[0].b_off;
+    a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + a.wc_waves +
+                  (a.ptab ? 4 + PL.b1p_rows : 0) + 3) / 4;
     // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
     pack_weights_kernel<<<a.pack_wgs, 256, 0, st>>>(a);
     DQ_LAUNCH_CHECK();
@@ -1271,19 +1397,22 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct ConvPlan { int S, slot, off_mis, off_t1, off_a1, off_a2, off_fx, KG1; size_t lds; };
+struct ConvPlan { int S, slot, off_mis, off_t1, off_a1, off_a2, off_fx, off_lut, KG1; size_t lds; };
 
-static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
+// patch: the observations are patch words (dq_qnet_set_patch_input): rows of 4 * patch_stride bytes, a1 rows unpadded, a byte -> bits table behind a1
+static bool plan_conv(const dq_qnet* Q, ConvPlan* P, bool patch = false) {
     if (Q->cfg.n_conv != 3) return false;
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
     if (L1.cout != 64 || L1.K > 96) return false;
     if (L2.cin != 64 || L2.cout != 32 || L2.k != 2 || L2.s != 1) return false;
     if (L3.cin != 32 || L3.cout != 32 || L3.k != 2 || L3.s != 1) return false;
+    if (patch && !Q->patch_depth) return false;
     P->KG1 = (L1.K + 15) / 16;
     if (P->KG1 < 3) P->KG1 = 3;
     const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
     if (in_bytes >= (1 << 17)) return false;                        // (first row table: sample << 20 | swizzle << 17 | offset inside the observation)
-    P->slot = (in_bytes + 15 + 15 + 15) & ~15;                       // the 16-byte-aligned window around an arbitrarily aligned row
+    P->slot = patch ? 4 * Q->patch_stride : (in_bytes + 15 + 15 + 15) & ~15;      // the 16-byte-aligned window around an arbitrarily aligned row
+    const int a1ps = patch ? 64 : A1_PS;
     for (int pass = 0; pass < 2; ++pass) {                          // prefer two workgroups per CU; else the largest S that fits
         const size_t budget = pass == 0 ? CONV_LDS_2PER_CU : CONV_LDS_MAX;
         for (int S = 8; S >= 1; S >>= 1) {
@@ -1291,13 +1420,14 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
             // barrier behind conv1) overlays them.  a1, a2: two f16 piece planes each, rows of 64 + 8 / 32 + 8 halves.
             size_t off = up16((size_t)S * P->slot);
             const size_t mis = off; off += up16((size_t)S * 4);
-            const size_t t1 = off; off += up16((size_t)S * L1.rows * 4);
+            const size_t t1 = off; off += up16((size_t)(S * L1.rows + (patch ? 16 : 0)) * 4);      // (+ 16: the patch-word form pads the table to whole tiles)
             const size_t a2_bytes = up16((size_t)2 * S * L2.rows * 40 * 2);
             if (off < a2_bytes) off = a2_bytes;
-            const size_t a1 = off; off += up16((size_t)2 * S * L1.rows * A1_PS * 2);
+            const size_t a1 = off; off += up16((size_t)2 * S * L1.rows * a1ps * 2);
             const size_t fx = off; off += CONV_SWZ ? up16((size_t)S * L1.rows + 16) : 0;      // (+ 16: the last tile's rows past the end are read, not used)
+            const size_t lut = off; off += patch ? 4096 : 0;
             if (off <= budget && S * L1.rows <= CONV_ROWTAB) {      // (rows per workgroup: the row tables' capacity)
-                P->S = S; P->off_mis = (int)mis; P->off_t1 = (int)t1; P->off_a1 = (int)a1; P->off_a2 = 0; P->off_fx = (int)fx; P->lds = off;
+                P->S = S; P->off_mis = (int)mis; P->off_t1 = (int)t1; P->off_a1 = (int)a1; P->off_a2 = 0; P->off_fx = (int)fx; P->off_lut = (int)lut; P->lds = off;
                 return true;
             }
         }
@@ -1307,24 +1437,25 @@ static bool plan_conv(const dq_qnet* Q, ConvPlan* P) {
 
 // Persistent conv chain (conv_chain_pkernel): [obs A | core | obs B | a1 planes (rows of 64 halves) | alignment offsets [2][16]]; a2 overlays the
 // current group's observation buffer and the core.  Two workgroups per CU where that fits, else one.
-struct ConvPlanP { int S, slot, off_t1, off_obs1, off_a2b, off_a1, off_mis, per_cu; size_t lds; };
-static bool plan_conv_persist(const dq_qnet* Q, ConvPlanP* P) {
+struct ConvPlanP { int S, slot, off_t1, off_obs1, off_a2b, off_a1, off_mis, off_lut, per_cu; size_t lds; };
+static bool plan_conv_persist(const dq_qnet* Q, ConvPlanP* P, bool patch = false) {
     ConvPlan base;
-    if (!plan_conv(Q, &base)) return false;
+    if (!plan_conv(Q, &base, patch)) return false;
     const Layer &L1 = Q->L[0], &L2 = Q->L[1];
     for (int pass = 0; pass < 2; ++pass) {
         const size_t budget = pass == 0 ? CONV_LDS_2PER_CU : CONV_LDS_MAX;
         for (int S = 8; S >= 1; S >>= 1) {
-            const size_t obs = up16((size_t)S * base.slot), t1b = up16((size_t)S * L1.rows * 4), a2b = up16((size_t)2 * S * L2.rows * 40 * 2);
+            const size_t obs = up16((size_t)S * base.slot), t1b = up16((size_t)(S * L1.rows + (patch ? 16 : 0)) * 4), a2b = up16((size_t)2 * S * L2.rows * 40 * 2);
             size_t core = a2b > obs ? a2b - obs : 0;
             if (core < t1b) core = t1b;
             size_t off = 2 * obs + core;
             const size_t a1 = off; off += up16((size_t)2 * (CONV1_PIPE ? (S * L1.rows + 15) & ~15 : S * L1.rows) * 64 * 2);
             const size_t mis = off; off += 2 * 16 * 4;
             const size_t t1c = off; off += t1b;                     // the patch-origin table, constant over the groups: a place of its own (a2 overlays the core)
+            const size_t lut = off; off += patch ? 4096 : 0;
             if (off <= budget && S * L1.rows <= CONV_ROWTAB) {
                 P->S = S; P->slot = base.slot; P->off_t1 = (int)t1c; P->off_obs1 = (int)(obs + core); P->off_a2b = (int)(2 * obs + core - a2b);
-                P->off_a1 = (int)a1; P->off_mis = (int)mis; P->lds = off; P->per_cu = pass == 0 ? 2 : 1;
+                P->off_a1 = (int)a1; P->off_mis = (int)mis; P->off_lut = (int)lut; P->lds = off; P->per_cu = pass == 0 ? 2 : 1;
                 return true;
             }
         }
@@ -1343,24 +1474,78 @@ bool fused_conv_row_tables(const dq_qnet* Q, int* tab) {
     if (!plan_conv(Q, &P)) return false;
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
     memset(tab, 0, sizeof(int) * CONV_FWD_TABS * CONV_ROWTAB);
-    ConvPlanP PP;                                                   // [3]: the second convolution's rows over UNPADDED a1 planes (the persistent kernel's)
-    if (plan_conv_persist(Q, &PP))
-        for (int m = 0; m < PP.S * L2.rows; ++m) {
-            const int s = m / L2.rows, pix = m % L2.rows, oy = pix / L2.ow, ox = pix % L2.ow;
-            tab[3 * CONV_ROWTAB + m] = ((s * L2.ih + oy) * L2.iw + ox) * 64;
-        }
-    for (int m = 0; m < P.S * L1.rows; ++m) {
+    // (every table is filled for the largest group, 8 samples: row m's entry does not depend on the group size, so the plans of both kernels and
+    // both input forms read prefixes of the same tables)
+    auto rows_of = [](const Layer& L) { return 8 * L.rows < CONV_ROWTAB ? 8 * L.rows : CONV_ROWTAB; };
+    for (int m = 0; m < rows_of(L2); ++m) {                         // [3]: the second convolution's rows over UNPADDED a1 planes (persistent kernel; patch-word input)
+        const int s = m / L2.rows, pix = m % L2.rows, oy = pix / L2.ow, ox = pix % L2.ow;
+        tab[3 * CONV_ROWTAB + m] = ((s * L2.ih + oy) * L2.iw + ox) * 64;
+    }
+    for (int m = 0; m < rows_of(L1); ++m) {
         const int s = m / L1.rows, pix = m % L1.rows, oy = pix / L1.ow, ox = pix % L1.ow;
         tab[m] = s << 20 | (CONV_SWZ ? (2 * (ox & 3)) << 17 : 0) | (oy * L1.s * L1.iw + ox * L1.s);
     }
     const Layer* Ls[2] = {&L2, &L3};
     for (int l = 0; l < 2; ++l)
-        for (int m = 0; m < P.S * Ls[l]->rows; ++m) {
+        for (int m = 0; m < rows_of(*Ls[l]); ++m) {
             const int s = m / Ls[l]->rows, pix = m % Ls[l]->rows, oy = pix / Ls[l]->ow, ox = pix % Ls[l]->ow;
             tab[(1 + l) * CONV_ROWTAB + m] = l == 0 ? ((s * L2.ih + oy) * L2.iw + ox) * A1_PS | (CONV_SWZ ? (ox & 3) << 24 : 0)
                                                     : ((s * L3.ih + oy) * L3.iw + ox) * (L3.cin + 8);
         }
     return true;
+}
+
+// ---- patch-word input (include/deepq_hip.h dq_qnet_set_patch_input) ---------------------------------------------------------------------
+// Tables of qnet.h PT_*: which Keras rows of the first kernel the data bits multiply, which constant cells every pixel's patch holds
+// (padding_syndrome's decoration, /root/reference/example_notebooks/Environments.py:284-298, on the `depth` syndrome planes; the action
+// planes' other cells are 0, ENV:301-314), and the row tables of the two conv kernels over rows of `stride_words` words.
+bool fused_patch_supported(const dq_qnet* Q, int depth) {
+    ConvPlan P;
+    const Layer& L1 = Q->L[0];
+    if (!plan_conv(Q, &P)) return false;
+    if (L1.k != 3 || L1.s != 2 || L1.ih != L1.iw || !(L1.ih & 1) || L1.oh * L1.ow > 64) return false;     // Conv2D(64, 3, strides=2) on (2d+1)^2 planes, d <= 7
+    if (depth < 1 || depth >= L1.cin) return false;
+    return 4 * depth + (L1.cin - depth) <= 32;
+}
+void fused_patch_tables(const dq_qnet* Q, int depth, int stride_words, int* tab) {
+    const Layer& L1 = Q->L[0];
+    const int C = L1.cin, layers = C - depth, d = L1.oh, n = L1.ih, kd = 4 * depth + layers;
+    memset(tab, 0, sizeof(int) * PT_TOTAL);
+    for (int k = 0; k < 32; ++k) tab[PT_KROW + k] = -1;
+    for (int k = 0; k < 96; ++k) tab[PT_SRC + k] = -1;
+    for (int j = 0; j < depth; ++j)
+        for (int c = 0; c < 4; ++c) {                                // corner (dy, dx) = (c >> 1, c & 1) of the patch: kernel tap (2 dy, 2 dx)
+            const int row = ((2 * (c >> 1)) * 3 + 2 * (c & 1)) * C + j;
+            tab[PT_KROW + 4 * j + c] = row; tab[PT_SRC + row] = 4 * j + c;
+        }
+    for (int l = 0; l < layers; ++l) {                              // the centre tap (1, 1) of the action planes
+        const int row = (1 * 3 + 1) * C + depth + l;
+        tab[PT_KROW + 4 * depth + l] = row; tab[PT_SRC + row] = 4 * depth + l;
+    }
+    const int cpos[5] = {0 * 3 + 1, 2 * 3 + 1, 1 * 3 + 0, 1 * 3 + 2, 1 * 3 + 1};
+    for (int c = 0; c < 5; ++c) {
+        tab[PT_CPOS + c] = cpos[c];
+        for (int j = 0; j < depth; ++j) tab[PT_SRC + cpos[c] * C + j] = kd + c;      // the constant cells' kernel rows: one image column per position, every syndrome plane
+    }
+    auto decoration = [&](int x, int y) {                           // ENV:284-298 (the cells that do not hold a syndrome bit)
+        int v = 0;
+        if ((x == 0 || x == n - 1) && (y & 1)) v = 1;
+        if ((y == 0 || y == n - 1) && (x & 1)) v = 1;
+        if ((x & 1) && (y & 1) && ((x + y) % 4 == 0)) v = 1;
+        return v;
+    };
+    for (int oy = 0; oy < d; ++oy)
+        for (int ox = 0; ox < d; ++ox) {
+            int mask = 0;
+            for (int c = 0; c < 5; ++c) mask |= decoration(2 * oy + cpos[c] / 3, 2 * ox + cpos[c] % 3) << c;
+            tab[PT_CONST + oy * d + ox] = mask;
+        }
+    const int r1 = L1.rows, rows = 8 * r1 < CONV_ROWTAB ? 8 * r1 : CONV_ROWTAB;
+    for (int m = 0; m < rows; ++m) {
+        const int s = m / r1, pix = m % r1;
+        tab[PT_FWD + m] = s << 20 | 4 * pix;
+        tab[PT_BWD + m] = (s * stride_words + pix) | tab[PT_CONST + pix] << 16;
+    }
 }
 
 struct DensePlan { int ldx, ld2, ld3, off_x, off_h, off_part, off_y2, off_y3, NT2; size_t lds; };
@@ -1401,9 +1586,14 @@ typedef void (*dense_kernel_t)(DenseChainArgs);
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st) {
     ConvPlan cp;
     DensePlan dp;
-    DQ_REQUIRE(plan_conv(Q, &cp) && plan_dense(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_forward: configuration not covered");
     DQ_REQUIRE(n_jobs >= 1 && n_jobs <= FWD_MAX_JOBS, DQ_ERR_INVALID, "fused_forward: 1..%d jobs per launch", FWD_MAX_JOBS);
-    conv_kernel_t ck = cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
+    // every job of a launch reads its observations in the same form: padded uint8 images, or patch words (dq_qnet_job.reserved bit 0)
+    const bool patch = (jobs[0].reserved & 1u) != 0;
+    for (int i = 1; i < n_jobs; ++i)
+        DQ_REQUIRE(((jobs[i].reserved & 1u) != 0) == patch, DQ_ERR_INVALID, "dq_qnet_forward_multi: the jobs of one launch must all read uint8 images or all read patch words");
+    DQ_REQUIRE(!patch || Q->patch_depth, DQ_ERR_STATE, "dq_qnet_forward_multi: patch-word input without dq_qnet_set_patch_input");
+    DQ_REQUIRE(plan_conv(Q, &cp, patch) && plan_dense(Q, &dp), DQ_ERR_UNSUPPORTED, "fused_forward: configuration not covered");
+    conv_kernel_t ck = patch ? conv_chain_kernel<0> : cp.KG1 == 3 ? conv_chain_kernel<3> : cp.KG1 == 4 ? conv_chain_kernel<4> : cp.KG1 == 5 ? conv_chain_kernel<5> : conv_chain_kernel<6>;
     // the persistent form (DQ_CONV_PERSIST=0 selects the one-group-per-workgroup kernel: A/B runs) when the launch has more groups than resident workgroups
     // (read per call: tests flip it.  0: never; 1 / unset: when the launch has more groups than resident workgroups; 2: always, with DQ_CONV_PERSIST_GRID
     // workgroups if that is set -- a small grid makes every workgroup walk many groups)
@@ -1412,16 +1602,16 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     const int persist_env = pe ? atoi(pe) : 1;
     const char* pg = getenv("DQ_CONV_PERSIST_GRID");
     const int persist_grid = persist_env == 2 && pg ? atoi(pg) : 0;
-    const bool can_persist = persist_env != 0 && plan_conv_persist(Q, &pp) && pp.S == cp.S;
-    const conv_kernel_t pk = cp.KG1 == 3 ? conv_chain_pkernel<3> : cp.KG1 == 4 ? conv_chain_pkernel<4> : cp.KG1 == 5 ? conv_chain_pkernel<5> : conv_chain_pkernel<6>;
+    const bool can_persist = persist_env != 0 && plan_conv_persist(Q, &pp, patch) && pp.S == cp.S;
+    const conv_kernel_t pk = patch ? conv_chain_pkernel<0> : cp.KG1 == 3 ? conv_chain_pkernel<3> : cp.KG1 == 4 ? conv_chain_pkernel<4> : cp.KG1 == 5 ? conv_chain_pkernel<5> : conv_chain_pkernel<6>;
     static unsigned long long attr_devs = 0;                          // per device (common.h dq_device_bit)
     const unsigned long long dev_bit = dq_device_bit();
     if (!(attr_devs & dev_bit)) {
-        const conv_kernel_t cks[4] = {conv_chain_kernel<3>, conv_chain_kernel<4>, conv_chain_kernel<5>, conv_chain_kernel<6>};
-        for (int i = 0; i < 4; ++i)
+        const conv_kernel_t cks[5] = {conv_chain_kernel<3>, conv_chain_kernel<4>, conv_chain_kernel<5>, conv_chain_kernel<6>, conv_chain_kernel<0>};
+        for (int i = 0; i < 5; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
-        const conv_kernel_t pks[4] = {conv_chain_pkernel<3>, conv_chain_pkernel<4>, conv_chain_pkernel<5>, conv_chain_pkernel<6>};
-        for (int i = 0; i < 4; ++i)
+        const conv_kernel_t pks[5] = {conv_chain_pkernel<3>, conv_chain_pkernel<4>, conv_chain_pkernel<5>, conv_chain_pkernel<6>, conv_chain_pkernel<0>};
+        for (int i = 0; i < 5; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         const dense_kernel_t dks[4] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<4, 4, 4>};
         for (int i = 0; i < 4; ++i)
@@ -1439,9 +1629,10 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     ca.C = L1.cin; ca.H = L1.ih; ca.W = L1.iw; ca.k1 = L1.k; ca.st1 = L1.s; ca.K1 = L1.K;
     ca.oh1 = L1.oh; ca.ow1 = L1.ow; ca.oh2 = L2.oh; ca.ow2 = L2.ow; ca.oh3 = L3.oh; ca.ow3 = L3.ow;
     for (int l = 0; l < 3; ++l) { ca.w_off[l] = (int)Q->L[l].w_off; ca.b_off[l] = (int)Q->L[l].b_off; }
-    ca.kofftab = Q->kofftab; ca.rowtab = Q->kofftab + 96;
-    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_t1 = cp.off_t1; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2; ca.off_fx = cp.off_fx;
+    ca.kofftab = Q->kofftab; ca.rowtab = Q->kofftab + 96; ca.rowtab0 = patch ? Q->ptab + PT_FWD : ca.rowtab;
+    ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_t1 = cp.off_t1; ca.off_a1 = cp.off_a1; ca.off_a2 = cp.off_a2; ca.off_fx = cp.off_fx; ca.off_lut = cp.off_lut;
     const PackLayout PL = fused_pack_layout(Q);
+    ca.pk_c1c = (int)PL.c1c; ca.pk_b1p = (int)PL.b1p;
     da.K1 = D1.nin; da.perm_hw = Q->flat_hw; da.perm_c = Q->flat_c; da.pk_dense1 = (int)PL.dense1; da.pk_dense2 = (int)PL.dense2; da.pk_w3q = (int)PL.w3q;
     da.N2 = D2.nout; da.N3 = Q->cfg.dueling ? Q->L[nc + 2].nout : 0; da.n_actions = Q->cfg.n_actions;
     for (int l = 0; l < Q->n_layers - nc; ++l) { da.w_off[l] = (int)Q->L[nc + l].w_off; da.b_off[l] = (int)Q->L[nc + l].b_off; }
@@ -1486,6 +1677,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         DQ_REQUIRE(jb.params_dev && jb.obs_dev && jb.q_dev, DQ_ERR_INVALID, "dq_qnet_forward: null argument (job %d)", i);
         DQ_REQUIRE(jb.batch >= 1 && jb.batch <= Q->cfg.max_batch, DQ_ERR_INVALID, "dq_qnet_forward: batch %d outside 1..%d", jb.batch, Q->cfg.max_batch);
         DQ_REQUIRE((reinterpret_cast<uintptr_t>(jb.params_dev) & 15) == 0, DQ_ERR_INVALID, "fused_forward: params_dev must be 16-byte aligned");
+        DQ_REQUIRE(!patch || (reinterpret_cast<uintptr_t>(jb.obs_dev) & 15) == 0, DQ_ERR_INVALID, "fused_forward: patch-word rows must be 16-byte aligned");
         const int training = jb.training ? 1 : 0;
         n_train += training;
         DQ_REQUIRE(n_train <= 1, DQ_ERR_INVALID, "dq_qnet_forward_multi: at most one training job per launch");
@@ -1529,7 +1721,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
             D.plane_rows = Q->cfg.max_batch; D.small_ld = dq_planes_small_ld(Q);
             D.x_pl = dq_plane(Q, 0); D.h1_pl = dq_plane(Q, 1); D.y2_pl = dq_plane(Q, 5);
             Q->last_train_batch = jb.batch; Q->last_train_fused = 1; Q->last_obs = jb.obs_dev; Q->last_index = jb.index_dev;
-            Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod; Q->last_train_packed = packed;
+            Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod; Q->last_train_packed = packed; Q->last_patch = patch ? 1 : 0;
         }
         D.q_out = jb.q_dev;
         dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
@@ -1537,6 +1729,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     for (int i = n_jobs; i < FWD_MAX_JOBS; ++i) ca.wg_first[i] = da.wg_first[i] = 0x7fffffff;
     if (can_persist && (conv_wgs > pp.per_cu * n_cu || persist_env == 2)) {
         ca.total_groups = conv_wgs; ca.off_t1 = pp.off_t1; ca.off_obs1 = pp.off_obs1; ca.off_a2b = pp.off_a2b; ca.off_a1 = pp.off_a1; ca.off_mis = pp.off_mis;
+        ca.off_lut = pp.off_lut;
         int grid = pp.per_cu * n_cu;
         if (persist_grid > 0) grid = persist_grid;
         if (grid > conv_wgs) grid = conv_wgs;

@@ -999,6 +999,11 @@ struct ConvBwdArgs {
     int a1_alt;                         // bytes from the a1 image to its second buffer, 0 = single-buffered
     const int* kofftab;                 // [96] conv1 weight row k -> byte offset inside an observation, -1 past K1
     const int* rowtab;                  // [5][CONV_ROWTAB] host-built row tables (fused_conv_bwd_row_tables): the kernel copies them into LDS and never divides
+    // patch-word input (the kernel's CP instances; qnet.h PT_*, include/deepq_hip.h dq_env_patch_output): the observation rows are `slot` bytes of u32
+    // words (one per first-convolution output pixel), 16-byte aligned
+    const int* rowtab1;                 // the first table: rowtab, or qnet.h PT_BWD (row m -> word index s * stride + p | the pixel's constant-cell mask << 16)
+    const int* srctab;                  // qnet.h PT_SRC: Keras row of the first kernel -> column of the patch image, -1: gradient 0
+    int kd, off_lut;                    // data bits per pixel; LDS: byte -> its eight bits as bytes 0 / 1 (256 x 8 bytes), built by the workgroup
 };
 
 // Copies `rows` rows of CH floats from global memory into an LDS image with row stride PS.  Loads are issued NB at a time before
@@ -1126,7 +1131,12 @@ __device__ __forceinline__ void dgrad_inplace(const F16x2 (&bw)[4][2], const voi
 
 #define A1PS 64                         // row stride (halves) of the a1 piece planes: unpadded, because they are filled by LDS-DMA (1 KB contiguous per wave instruction)
 
-template <int KG1>                      // first convolution's K padded to 16 * KG1
+// CP: patch-word input.  The first convolution's patch image then has one column per DATA bit of a pixel's patch (K_data <= 32: four corners per
+// syndrome plane, the centre per action plane) plus one per constant POSITION (5: the places where padding_syndrome's decoration can put a 1 in a
+// 3 x 3 stride-2 patch -- the same on every syndrome plane, so their kernel rows share one gradient): 16 KG1 = 32 or 48 columns where the uint8 image has
+// 64 .. 96, built by expanding the pixel's word | its constant mask byte by byte through an LDS table; the result is scattered to the kernel's Keras
+// rows at the end (every other row's gradient is 0: its input cell is 0 in every observation).
+template <int KG1, bool CP = false>     // first convolution's K padded to 16 * KG1
 __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8* s_in = smem;
@@ -1142,7 +1152,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     int* t1 = reinterpret_cast<int*>(smem + a.off_tp);              // [S*r1]: sample << 16 | byte offset of the pixel's patch origin inside an observation
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     const int S = a.S, r1 = a.oh1 * a.ow1, r2 = a.oh2 * a.ow2, r3 = a.oh3 * a.ow3;
-    const int in_bytes = a.C * a.H * a.W;
+    const int in_bytes = CP ? a.slot : a.C * a.H * a.W;
     const int zero2 = S * r2, zero3 = S * r3;                        // all-zero rows of the g2 (= a2) and g3 images
     const int LA2 = (S * r2 + 1) * PL32, LG3 = (S * r3 + 1) * PL32;   // halves from a2's / g3's h plane to its l plane
     constexpr int NW1 = (4 * KG1 + CB_WAVES - 1) / CB_WAVES;        // dW1 tiles (KG1 x 4) per wave
@@ -1153,14 +1163,19 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     // ---- group-independent tables and zero rows ----------------------------------------------------------------
     // (copied from the host-built tables: computing them here took two integer divisions per entry)
     for (int m = tid; m < S * r1; m += CB_THREADS) {
-        const int e1 = a.rowtab[m], e2 = a.rowtab[CONV_ROWTAB + min(m, S * r2 - 1)], e3 = a.rowtab[2 * CONV_ROWTAB + min(m, S * r3 - 1)];
+        const int e1 = a.rowtab1[m], e2 = a.rowtab[CONV_ROWTAB + min(m, S * r2 - 1)], e3 = a.rowtab[2 * CONV_ROWTAB + min(m, S * r3 - 1)];
         const int e4 = a.rowtab[3 * CONV_ROWTAB + min(m, S * r2 - 1)], e5 = a.rowtab[4 * CONV_ROWTAB + m];
         t1[m] = e1;                                                 // sample << 16 | byte offset of the patch origin inside an observation
         d1[m] = e5;
         if (m < S * r2) { t2[m] = e2; d2[m] = e4; }                 // t2: float offset of the a1 row under output pixel m of the second convolution
         if (m < S * r3) t3[m] = e3;                                 // t3: float offset of the a2 row
     }
-    if (tid < 96) s_ko[tid] = a.kofftab[tid];
+    if (!CP && tid < 96) s_ko[tid] = a.kofftab[tid];
+    uint2* s_lut = reinterpret_cast<uint2*>(smem + a.off_lut);       // CP: byte -> its bits as eight bytes
+    if (CP && tid < 256) {
+        const u32 b = (u32)tid;
+        s_lut[tid] = uint2{(b & 1u) | (b & 2u) << 7 | (b & 4u) << 14 | (b & 8u) << 21, ((b >> 4) & 1u) | ((b >> 4) & 2u) << 7 | ((b >> 4) & 4u) << 14 | ((b >> 4) & 8u) << 21};
+    }
     if (tid < PL32) { s_a2[zero2 * PL32 + tid] = 0; s_a2[LA2 + zero2 * PL32 + tid] = 0; s_g3[zero3 * PL32 + tid] = 0; s_g3[LG3 + zero3 * PL32 + tid] = 0; }
 
     // ---- per-lane constants of the weight-gradient phases ----------------------------------------------------------
@@ -1227,7 +1242,9 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         const int gb0 = g * S, gns = min(S, a.batch - gb0);
         const int pieces = (a.slot + 255) >> 8;
         const int s = wave;
-        if (s < gns) {                                              // wave-uniform
+        if (CP) {                                                   // patch words: one aligned row of `slot` bytes, 16 bytes per lane
+            if (s < gns && lane < (a.slot >> 4)) lds_dma16(a.obs + (size_t)row * in_bytes + 16 * lane, lds_addr(s_in + s * a.slot));
+        } else if (s < gns) {                                       // wave-uniform
             const u8* src = a.obs + (size_t)row * in_bytes;
             const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3);
             for (int pc = 0; pc < pieces; ++pc) {
@@ -1267,6 +1284,16 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         DQ_STAMP(DQ_TAG_CONV_BWD, sb + 1);
         // ---- observation patch image: row m = the K1 bytes conv1 multiplies for output pixel m (zeros past K1), so that dW1's A
         //      operand is 16 consecutive bytes per quarter-wave instead of a scattered byte gather -------------------------------
+        if constexpr (CP) {
+            // row m = the bits of pixel m's word (data), then of its constant mask, one byte each: eight bytes per task from the byte table
+            const u32* s_w = reinterpret_cast<const u32*>(s_in);
+            for (int task = tid; task < M1 * (KP / 8); task += CB_THREADS) {
+                const int m = task / (KP / 8), g = task - m * (KP / 8);
+                const int e = t1[m];
+                const u64 bits = (u64)s_w[e & 0xffff] | (u64)(u32)(e >> 16) << a.kd;
+                *reinterpret_cast<uint2*>(s_col + m * KP + 8 * g) = s_lut[(u32)(bits >> (8 * g)) & 0xffu];
+            }
+        } else
         for (int task = tid; task < M1 * (KP / 16); task += CB_THREADS) {
             const int m = task / (KP / 16), q = task - m * (KP / 16);
             const int to = t1[m], s = to >> 16;                    // (sample, byte offset of the patch origin inside its observation)
@@ -1479,14 +1506,16 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 #pragma unroll
             for (int u = 0; u < 2; ++u) out[a.w_off[1] + (16 * (2 * wave + u) + 4 * kq + r) * 32 + 16 * t + j] = f16x2_sum(acc2[u][t][r], acc2l[u][t][r]);
         }
+    if constexpr (!CP) {
 #pragma unroll
-    for (int u = 0; u < NW1; ++u) {
-        const int id = wave + CB_WAVES * u, kt = id >> 2, nt = id & 3;
-        if (id < 4 * KG1) {
+        for (int u = 0; u < NW1; ++u) {
+            const int id = wave + CB_WAVES * u, kt = id >> 2, nt = id & 3;
+            if (id < 4 * KG1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = 16 * kt + 4 * kq + r;
-                if (k < a.K1) out[a.w_off[0] + k * 64 + 16 * nt + j] = f16x2_sum(acc1[u][r], acc1l[u][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * kt + 4 * kq + r;
+                    if (k < a.K1) out[a.w_off[0] + k * 64 + 16 * nt + j] = f16x2_sum(acc1[u][r], acc1l[u][r]);
+                }
             }
         }
     }
@@ -1494,6 +1523,17 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         // columns 32 (wave >> 2) + 2j + t) -- combined in fixed order through LDS
         __syncthreads();                                            // (every LDS image is dead)
         float* s_b = reinterpret_cast<float*>(smem);
+        float* s_res = s_b + 2048;                                  // CP: the patch image's gradient [16 KG1][64], then scattered to the kernel's Keras rows
+        if constexpr (CP) {
+#pragma unroll
+            for (int u = 0; u < NW1; ++u) {
+                const int id = wave + CB_WAVES * u, kt = id >> 2, nt = id & 3;
+                if (id < 4 * KG1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_res[(16 * kt + 4 * kq + r) * 64 + 16 * nt + j] = f16x2_sum(acc1[u][r], acc1l[u][r]);
+                }
+            }
+        }
         s_b[256 + tid] = bs3;                                       // the third's: thread (column tid & 31, row class tid >> 5)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -1520,6 +1560,12 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             for (int w = 0; w < 4; ++w) v += s_b[768 + (4 * half + w) * 32 + (c & 31)];
             out[a.b_off[0] + c] = v;
         }
+        if constexpr (CP) {
+            for (int i = tid; i < a.K1 * 64; i += CB_THREADS) {
+                const int src = a.srctab[i >> 6];
+                out[a.w_off[0] + i] = src >= 0 ? s_res[src * 64 + (i & 63)] : 0.f;
+            }
+        }
     }
 }
 
@@ -1545,18 +1591,21 @@ static bool plan_dense_bwd(const dq_qnet* Q, DenseBwdPlan* P) {
     return true;
 }
 
-struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp, off_d2, off_d1, a1_alt; size_t lds; };
+struct ConvBwdPlan { int S, KG1, slot, off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp, off_d2, off_d1, off_lut, a1_alt; size_t lds; };
 
-static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
+// patch: patch-word input (dq_qnet_set_patch_input): rows of 4 * patch_stride bytes, a patch image of 32 / 48 columns, the byte table behind the tables
+static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P, bool patch = false) {
     if (Q->cfg.n_conv != 3) return false;
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
     if (L1.cout != 64 || L1.K > 96) return false;
     if (L2.cin != 64 || L2.cout != 32 || L2.k != 2 || L2.s != 1) return false;
     if (L3.cin != 32 || L3.cout != 32 || L3.k != 2 || L3.s != 1) return false;
-    P->KG1 = (L1.K + 15) / 16;
-    if (P->KG1 < 3) P->KG1 = 3;
+    if (patch && !Q->patch_depth) return false;
+    P->KG1 = patch ? (Q->patch_kd + 5 + 15) / 16 : (L1.K + 15) / 16;
+    if (!patch && P->KG1 < 3) P->KG1 = 3;
+    if (patch && P->KG1 < 2) P->KG1 = 2;
     const int in_bytes = Q->cfg.in_c * Q->cfg.in_h * Q->cfg.in_w;
-    P->slot = (in_bytes + 3 + 3) & ~3;
+    P->slot = patch ? 4 * Q->patch_stride : (in_bytes + 3 + 3) & ~3;
     if (P->slot > 4 * CB_THREADS) return false;                      // one dword of an observation per thread
     for (int pass = 0; pass < 8; ++pass) {                             // S = 8 double-buffered, S = 8 single, S = 4 double, ...
         const int S = 8 >> (pass >> 1), nbuf = 2 - (pass & 1);
@@ -1575,6 +1624,8 @@ static bool plan_conv_bwd(const dq_qnet* Q, ConvBwdPlan* P) {
         P->off_tp = (int)off; off += up16((size_t)S * L1.rows * 4);
         P->off_d2 = (int)off; off += up16((size_t)S * L2.rows * 4);
         P->off_d1 = (int)off; off += up16((size_t)S * L1.rows * 4);
+        P->off_lut = (int)off; off += patch ? 2048 : 0;
+        if (off < 8192 + 48 * 64 * 4) off = 8192 + 48 * 64 * 4;     // (the end of the kernel reuses the first 20 KB for its reductions)
         if (off <= CHAIN_LDS_MAX && S * L1.rows * 16 <= 7 * CB_THREADS && S * L1.rows <= CONV_ROWTAB && S * L2.rows < 65536 && L1.oh < 256 && L1.ow < 256) {
             P->S = S; P->lds = off; return true;
         }
@@ -1591,17 +1642,19 @@ bool fused_conv_bwd_row_tables(const dq_qnet* Q, int* tab) {
     if (!plan_conv_bwd(Q, &P)) return false;
     const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
     memset(tab, 0, sizeof(int) * 5 * CONV_ROWTAB);
-    for (int m = 0; m < P.S * L1.rows; ++m) {
+    // (filled for the largest group, 8 samples: an entry does not depend on the group size, so every plan reads a prefix)
+    auto rows_of = [](const Layer& L) { return 8 * L.rows < CONV_ROWTAB ? 8 * L.rows : CONV_ROWTAB; };
+    for (int m = 0; m < rows_of(L1); ++m) {
         const int s = m / L1.rows, p = m % L1.rows, oy = p / L1.ow, ox = p % L1.ow;
         tab[m] = s << 16 | (oy * L1.s * L1.iw + ox * L1.s);
         tab[4 * CONV_ROWTAB + m] = (s * L2.rows + oy * L2.ow + ox) | oy << 16 | ox << 24;      // a1 pixel (oy, ox): row of g2 at its own position
     }
-    for (int m = 0; m < P.S * L2.rows; ++m) {
+    for (int m = 0; m < rows_of(L2); ++m) {
         const int s = m / L2.rows, p = m % L2.rows, oy = p / L2.ow, ox = p % L2.ow;
         tab[CONV_ROWTAB + m] = (s * L1.rows + oy * L1.ow + ox) * A1PS;
         tab[3 * CONV_ROWTAB + m] = (s * L3.rows + oy * L3.ow + ox) | oy << 16 | ox << 24;       // a2 pixel: row of g3
     }
-    for (int m = 0; m < P.S * L3.rows; ++m) {
+    for (int m = 0; m < rows_of(L3); ++m) {
         const int s = m / L3.rows, p = m % L3.rows, oy = p / L3.ow, ox = p % L3.ow;
         tab[2 * CONV_ROWTAB + m] = (s * L2.rows + oy * L2.ow + ox) * PL32;
     }
@@ -1642,14 +1695,17 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     DQ_REQUIRE(!opt || phases == 3, DQ_ERR_INVALID, "fused_backward: the fused optimizer step needs the whole backward in one call");
     DenseBwdPlan dp;
     ConvBwdPlan cp;
-    DQ_REQUIRE(plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp), DQ_ERR_UNSUPPORTED, "fused_backward: configuration not covered");
+    const bool patch = Q->last_patch != 0;                          // the training forward read patch words: so does the first kernel's weight gradient
+    DQ_REQUIRE(!patch || Q->patch_depth, DQ_ERR_STATE, "fused_backward: the training forward read patch words, dq_qnet_set_patch_input was reset since");
+    DQ_REQUIRE(plan_dense_bwd(Q, &dp) && plan_conv_bwd(Q, &cp, patch), DQ_ERR_UNSUPPORTED, "fused_backward: configuration not covered");
     DQ_REQUIRE((reinterpret_cast<uintptr_t>(params_dev) & 15) == 0, DQ_ERR_INVALID, "fused_backward: params_dev must be 16-byte aligned");
     DQ_REQUIRE(Q->fpartial, DQ_ERR_STATE, "fused_backward: workspace missing");
     static unsigned long long attr_devs = 0;                          // per device (common.h dq_device_bit)
     const unsigned long long dev_bit = dq_device_bit();
     if (!(attr_devs & dev_bit)) {
-        const conv_bwd_kernel_t cks[4] = {conv_bwd_chain_kernel<3>, conv_bwd_chain_kernel<4>, conv_bwd_chain_kernel<5>, conv_bwd_chain_kernel<6>};
-        for (int i = 0; i < 4; ++i)
+        const conv_bwd_kernel_t cks[6] = {conv_bwd_chain_kernel<3>, conv_bwd_chain_kernel<4>, conv_bwd_chain_kernel<5>, conv_bwd_chain_kernel<6>,
+                                          conv_bwd_chain_kernel<2, true>, conv_bwd_chain_kernel<3, true>};
+        for (int i = 0; i < 6; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_MAX));
         DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_WGRAD_LDS));
         attr_devs |= dev_bit;
@@ -1801,8 +1857,11 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.slot = cp.slot; ca.off_mis = cp.off_mis; ca.off_a1 = cp.off_a1; ca.a1_alt = cp.a1_alt; ca.off_a2 = cp.off_a2; ca.off_g3 = cp.off_g3;
     ca.off_t1 = cp.off_t1; ca.off_t2 = cp.off_t2; ca.off_t3 = cp.off_t3; ca.off_ko = cp.off_ko; ca.off_tp = cp.off_tp; ca.kofftab = Q->kofftab;
     ca.off_d2 = cp.off_d2; ca.off_d1 = cp.off_d1; ca.rowtab = Q->kofftab + 96 + CONV_FWD_TABS * CONV_ROWTAB;
+    ca.rowtab1 = patch ? Q->ptab + PT_BWD : ca.rowtab; ca.srctab = patch ? Q->ptab + PT_SRC : nullptr; ca.kd = Q->patch_kd; ca.off_lut = cp.off_lut;
+    DQ_REQUIRE(!patch || (reinterpret_cast<uintptr_t>(ca.obs) & 15) == 0, DQ_ERR_INVALID, "fused_backward: patch-word rows must be 16-byte aligned");
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
-    conv_bwd_kernel_t ck = cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
+    conv_bwd_kernel_t ck = patch ? (cp.KG1 == 2 ? conv_bwd_chain_kernel<2, true> : conv_bwd_chain_kernel<3, true>)
+                         : cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;
     dq_launch(DQ_K_CONV_BWD, ck, dim3(wgs), dim3(CB_THREADS), cp.lds, st, ca);
     DQ_LAUNCH_CHECK();

@@ -6,6 +6,14 @@
 #define FWD_MAX_JOBS 4               // forwards served by one fused launch (dq_qnet_forward_multi)
 #define CONV_ROWTAB 512              // rows per workgroup and layer of the fused conv forward, at most
 #define CONV_FWD_TABS 4              // row tables of the fused conv forward (fused_conv_row_tables); the backward's five follow
+// Patch-word input (dq_qnet_set_patch_input, include/deepq_hip.h dq_env_patch_output): device tables dq_qnet.ptab, in ints
+#define PT_KROW 0                    // [32] compact k -> Keras row of the first kernel ((ky * 3 + kx) * C + plane), -1 past the data bits
+#define PT_SRC 32                    // [96] Keras row -> column k' of the backward's patch image (data bits, then the 5 constant positions), -1: gradient 0
+#define PT_CPOS 128                  // [8]  constant position c -> ky * 3 + kx   (c = 0 .. 4: (0,1) (2,1) (1,0) (1,2) (1,1))
+#define PT_CONST 136                 // [64] pixel p -> 5-bit mask of its constant-1 positions on the syndrome planes
+#define PT_FWD 200                   // [CONV_ROWTAB] forward: row m of a workgroup's S samples -> s << 20 | 4 p
+#define PT_BWD (PT_FWD + CONV_ROWTAB)    // [CONV_ROWTAB] backward: row m -> (s * stride_words + p) | constant mask << 16
+#define PT_TOTAL (PT_BWD + CONV_ROWTAB)
 
 struct Layer {
     int kind;                    // 0 conv, 1 dense
@@ -55,6 +63,12 @@ struct dq_qnet {
     float grad_scale_hint;       // dq_qnet_set_grad_scale: loss scale of caller-supplied dq (0 = unknown: measured on the device)
     float bwd_scale;             // fused backward: power-of-two scale the gradients of the last dense phase carry (0: the device-computed one)
     int use_fused;               // fused LDS-resident chains when the configuration allows it
+    // patch-word input (dq_qnet_set_patch_input): observations as d * d words per sample instead of the padded uint8 image
+    int patch_depth;             // syndrome planes of the observation (0: not configured); the remaining input planes are action planes
+    int patch_kd;                // data bits per pixel = 4 patch_depth + action planes (<= 32)
+    int patch_stride;            // words per observation row
+    int* ptab;                   // device tables (PT_*)
+    int last_patch;              // the last training forward read patch words (the backward takes the same form)
 };
 
 
@@ -212,7 +226,9 @@ struct ConvJob {
 //                                                - mean_a' W3[k][1 + a'], zero past N2 / |A|; the last row is b3' (the same map of the bias)                         forward, Q
 //            then f32 [16 NT2][16 KG3]           its transpose W3'^T [a][k]: the dueling backward folded the same way, gY2 = dq W3'^T                             backward, gY2
 //   wc       f32 [|A|][512]                      Wc = W3'^T W2^T (Dense(|A|) folded in as well): row a = gH1 of a sample whose dq is 1 at action a               backward, gH1 (TD launch)
-struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows; };   // offsets in u32x4
+//   c1c      [1 k-block][4 column tiles]         the first convolution over patch words: B(k = 8kb + e, col = 4j + t) = W1[PT_KROW[k]][col], 0 past the data bits
+//   b1p      f32 [r1][64]                        its per-pixel bias: b1[c] + the kernel rows of the pixel's constant-1 cells (summed in double)
+struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, c1c, b1p, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows, b1p_rows; };   // offsets in u32x4
 PackLayout fused_pack_layout(const dq_qnet* Q);
 static inline int dq_planes_small_ld(const dq_qnet* Q) { return Q->cfg.n_actions + 1 <= 64 ? 64 : 128; }
 static inline size_t dq_planes_halves(const dq_qnet* Q) {      // total size of dq_qnet.planes
@@ -233,6 +249,8 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
 bool fused_forward_supported(const dq_qnet* Q);
 bool fused_conv_row_tables(const dq_qnet* Q, int* tab);      // tab: int[CONV_FWD_TABS * CONV_ROWTAB]
 bool fused_conv_bwd_row_tables(const dq_qnet* Q, int* tab);  // tab: int[5 * CONV_ROWTAB] (fused_bwd.hip)
+bool fused_patch_supported(const dq_qnet* Q, int depth);     // patch-word input possible for this network with `depth` syndrome planes
+void fused_patch_tables(const dq_qnet* Q, int depth, int stride_words, int* tab);      // tab: int[PT_TOTAL]
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);

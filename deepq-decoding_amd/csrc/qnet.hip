@@ -441,6 +441,7 @@ void dq_qnet_destroy(dq_qnet* Q) {
     if (Q->fpartial) (void)hipFree(Q->fpartial);
     if (Q->planes) (void)hipFree(Q->planes);
     if (Q->kofftab) (void)hipFree(Q->kofftab);
+    if (Q->ptab) (void)hipFree(Q->ptab);
     for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->pk_scratch[i]) (void)hipFree(Q->pk_scratch[i]);
     for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->xinf[i]) (void)hipFree(Q->xinf[i]);
     delete Q;
@@ -490,6 +491,22 @@ dq_status dq_qnet_range_check(dq_qnet* Q, void* stream) {
 }
 
 int dq_qnet_fused_supported(const dq_qnet* Q) { return Q && fused_forward_supported(Q) ? 1 : 0; }
+
+dq_status dq_qnet_set_patch_input(dq_qnet* Q, int n_syndrome_planes, int stride_words) {
+    DQ_REQUIRE(Q, DQ_ERR_INVALID, "dq_qnet_set_patch_input: null handle");
+    if (n_syndrome_planes == 0) { Q->patch_depth = 0; return DQ_OK; }
+    DQ_REQUIRE(fused_forward_supported(Q) && fused_backward_supported(Q) && fused_patch_supported(Q, n_syndrome_planes), DQ_ERR_UNSUPPORTED,
+               "dq_qnet_set_patch_input: needs the fused chains, Conv2D(64, 3, strides=2) on (2d+1)^2 planes with d <= 7, and 4 * syndrome planes + action planes <= 32");
+    const int r1 = Q->L[0].rows;
+    DQ_REQUIRE(stride_words >= r1 && stride_words <= 64 && (stride_words & (stride_words - 1)) == 0 && stride_words >= 4, DQ_ERR_INVALID,
+               "dq_qnet_set_patch_input: stride_words must be a power of two in [max(4, d * d), 64]");
+    int tab[PT_TOTAL];
+    fused_patch_tables(Q, n_syndrome_planes, stride_words, tab);
+    if (!Q->ptab) DQ_HIP(hipMalloc(&Q->ptab, sizeof(tab)));
+    DQ_HIP(hipMemcpy(Q->ptab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    Q->patch_depth = n_syndrome_planes; Q->patch_kd = 4 * n_syndrome_planes + (Q->L[0].cin - n_syndrome_planes); Q->patch_stride = stride_words;
+    return DQ_OK;
+}
 
 dq_status dq_qnet_forward(dq_qnet* Q, const float* params_dev, const uint8_t* obs_dev, const int32_t* index_dev, int index_off,
                           int index_mod, int batch, int training, const uint32_t seed[2], uint64_t t, uint32_t sample_base,
@@ -575,6 +592,8 @@ dq_status dq_qnet_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs,
     int n_train = 0;
     for (int i = 0; i < n_jobs; ++i) n_train += jobs[i].training ? 1 : 0;
     DQ_REQUIRE(n_train <= 1, DQ_ERR_INVALID, "dq_qnet_forward_multi: at most one training job per launch");
+    for (int i = 0; i < n_jobs; ++i)
+        DQ_REQUIRE(!(jobs[i].reserved & 1u), DQ_ERR_UNSUPPORTED, "dq_qnet_forward_multi: patch-word input is read by the fused chains only");
     for (int i = 0; i < n_jobs; ++i) {                             // per-layer path: one forward after the other
         const dq_qnet_job& jb = jobs[i];
         const dq_status rc = dq_qnet_forward(Q, jb.params_dev, jb.obs_dev, jb.index_dev, jb.index_off, jb.index_mod, jb.batch, jb.training, jb.seed,

@@ -27,6 +27,67 @@ class _Space:
         self.shape, self.n, self.dtype, self.low, self.high = shape, n, dtype, 0, 1
 
 
+def patch_stride_words(d):
+    """Words per row of a patch-word observation array (include/deepq_hip.h dq_env_patch_output): d * d words, rows padded to a power of
+    two so that they are 16-byte aligned."""
+    n = 4
+    while n < d * d:
+        n *= 2
+    return n
+
+
+def _static_plane(d):
+    """padding_syndrome's decoration (ENV:284-298): the cells of a padded plane that do not hold a syndrome bit."""
+    n = 2 * d + 1
+    x, y = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    v = (((x == 0) | (x == n - 1)) & (y % 2 == 1)) | (((y == 0) | (y == n - 1)) & (x % 2 == 1)) | ((x % 2 == 1) & (y % 2 == 1) & ((x + y) % 4 == 0))
+    return v.astype(np.uint8)
+
+
+def patch_to_obs(patch, d, depth, layers):
+    """Patch words (int32 tensor [..., stride >= d*d]: dq_env_patch_output) -> the padded uint8 observation [..., depth + layers, 2d+1, 2d+1]
+    the reference builds (padding_syndrome / padding_actions, ENV:273-314).  The image is a fixed function of the words: syndrome cell (a, b)
+    of plane j is bit 4 j + 2 dy + dx of pixel (a - dy, b - dx), action plane l's cell of qubit p is bit 4 depth + l of pixel p."""
+    n = 2 * d + 1
+    w = patch[..., :d * d].to(torch.int64) & 0xFFFFFFFF
+    lead = w.shape[:-1]
+    w = w.reshape(lead + (d, d))
+    out = torch.zeros(lead + (depth + layers, n, n), dtype=torch.uint8, device=patch.device)
+    static = torch.from_numpy(_static_plane(d)).to(patch.device)
+    for j in range(depth):
+        plane = out[..., j, :, :]
+        plane += static
+        for a_hi in (0, 1):                      # grid rows 0 .. d-1 from the pixel's upper corners, row d from the last pixel row's lower ones
+            for b_hi in (0, 1):
+                rows = slice(0, d) if not a_hi else slice(d - 1, d)
+                cols = slice(0, d) if not b_hi else slice(d - 1, d)
+                bit = (w[..., rows, cols] >> (4 * j + 2 * a_hi + b_hi)) & 1
+                ys = slice(0, 2 * d, 2) if not a_hi else slice(2 * d, 2 * d + 1)
+                xs = slice(0, 2 * d, 2) if not b_hi else slice(2 * d, 2 * d + 1)
+                plane[..., ys, xs] = bit.to(torch.uint8)
+    for l in range(layers):
+        out[..., depth + l, 1:2 * d:2, 1:2 * d:2] = ((w >> (4 * depth + l)) & 1).to(torch.uint8)
+    return out
+
+
+def obs_to_patch(obs, d, depth, layers, stride=None):
+    """The inverse of patch_to_obs on observations the environment can produce: uint8 [..., C, 2d+1, 2d+1] -> int32 [..., stride]."""
+    stride = patch_stride_words(d) if stride is None else stride
+    o = obs.to(torch.int64)
+    lead = o.shape[:-3]
+    w = torch.zeros(lead + (d, d), dtype=torch.int64, device=obs.device)
+    for j in range(depth):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                w |= o[..., j, 2 * dy:2 * dy + 2 * d:2, 2 * dx:2 * dx + 2 * d:2] << (4 * j + 2 * dy + dx)
+    for l in range(layers):
+        w |= o[..., depth + l, 1:2 * d:2, 1:2 * d:2] << (4 * depth + l)
+    out = torch.zeros(lead + (stride,), dtype=torch.int64, device=obs.device)
+    out[..., :d * d] = w.reshape(lead + (d * d,))
+    out = torch.where(out >= (1 << 31), out - (1 << 32), out)       # the words' bit patterns as int32
+    return out.to(torch.int32)
+
+
 class VectorEnv:
     """Batched environment: lattice i has global id ``env_id_base + i`` (its RNG stream)."""
 
@@ -201,11 +262,36 @@ class VectorEnv:
         check(self.L.dq_env_get_referee(self._h, lx.ctypes.data, lz.ctypes.data, n))
         return lx, lz
 
+    # -- compact observations (include/deepq_hip.h dq_env_patch_output) --------------------------------
+    @property
+    def patch_supported(self):
+        """d <= 7 (the one-word-per-plane kernel) and 4 * volume_depth + action layers <= 32 data bits per pixel."""
+        return not self.wide and 4 * self.volume_depth + self.n_action_layers <= 32
+
+    @property
+    def patch_stride(self):
+        return patch_stride_words(self.d)
+
+    def arm_patch_output(self, out_patch):
+        """The NEXT reset / step / act_step launch of this handle also writes the lattices' patch words into `out_patch`
+        (int32 [n_envs, patch_stride], 16-byte aligned); one call arms one launch."""
+        assert out_patch.dtype == torch.int32 and out_patch.is_cuda and out_patch.is_contiguous() and out_patch.shape == (self.n_envs, self.patch_stride)
+        check(self.L.dq_env_patch_output(self._h, ptr(out_patch), self.patch_stride))
+
+    def patch_to_obs(self, patch):
+        return patch_to_obs(patch, self.d, self.volume_depth, self.n_action_layers)
+
+    def obs_to_patch(self, obs):
+        return obs_to_patch(obs, self.d, self.volume_depth, self.n_action_layers, self.patch_stride)
+
     # -- gym protocol, batched ----------------------------------------------------------------------
-    def reset(self, which=None, out_obs=None):
-        """ENV:99-115 for every lattice (or those with which[i] != 0).  Returns the uint8 observation tensor."""
-        obs = self.obs if out_obs is None else out_obs
+    def reset(self, which=None, out_obs=None, out_patch=None, write_obs=True):
+        """ENV:99-115 for every lattice (or those with which[i] != 0).  Returns the uint8 observation tensor.  out_patch: the patch words
+        as well (arm_patch_output); write_obs=False: only them."""
+        obs = (self.obs if out_obs is None else out_obs) if write_obs else None
         w = None if which is None else torch.as_tensor(which, dtype=torch.uint8, device=self.device).contiguous()
+        if out_patch is not None:
+            self.arm_patch_output(out_patch)
         check(getattr(self.L, self._pfx + "reset")(self._h, ptr(w), ptr(obs), ptr(self.legal), ptr(self.lifetime), self._stream()))
         if which is None:
             self.done.zero_()
@@ -213,11 +299,13 @@ class VectorEnv:
             self.done.masked_fill_(w != 0, 0)
         return obs
 
-    def step(self, action, auto_reset=False, out_obs=None):
+    def step(self, action, auto_reset=False, out_obs=None, out_patch=None):
         """ENV:118-204 for every lattice.  `action`: int32 device tensor [n_envs].  Returns (obs, reward, done)."""
         if not (isinstance(action, torch.Tensor) and action.dtype == torch.int32 and action.is_cuda and action.is_contiguous()):
             action = torch.as_tensor(action, dtype=torch.int32, device=self.device).contiguous()
         obs = self.obs if out_obs is None else out_obs
+        if out_patch is not None:
+            self.arm_patch_output(out_patch)
         if self.wide:
             check(self.L.dq_envb_step(self._h, ptr(action), int(auto_reset), ptr(obs), ptr(self.reward), ptr(self.done),
                                       ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), ptr(self.inexact), self._stream()))
@@ -226,11 +314,13 @@ class VectorEnv:
                                      ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), self._stream()))
         return obs, self.reward, self.done
 
-    def act_step(self, t, q=None, eps=1.0, masked_greedy=False, auto_reset=True, out_obs=None, out_action=None):
+    def act_step(self, t, q=None, eps=1.0, masked_greedy=False, auto_reset=True, out_obs=None, out_action=None, out_patch=None):
         """Action selection (the rule of select_actions) fused in front of the step: one launch.  Returns the actions taken."""
         if out_action is None:
             out_action = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
         obs = self.obs if out_obs is None else out_obs
+        if out_patch is not None:
+            self.arm_patch_output(out_patch)
         seed = (ctypes.c_uint32 * 2)(*self.seed)
         if self.wide:
             check(self.L.dq_envb_act_step(self._h, ptr(q), float(eps), int(masked_greedy), seed, int(t), ptr(out_action), int(auto_reset),

@@ -64,6 +64,12 @@ class QNetwork:
         measures max |dq| on the device).  See include/deepq_hip.h dq_qnet_set_grad_scale."""
         check(self.L.dq_qnet_set_grad_scale(self._h, float(grad_scale)))
 
+    def set_patch_input(self, n_syndrome_planes, stride_words):
+        """Declare the observation's plane structure so that jobs may read patch words (include/deepq_hip.h dq_qnet_set_patch_input,
+        dq_env_patch_output; `patch=True` in a forward_multi job) instead of padded uint8 images.  Call before pack()."""
+        check(self.L.dq_qnet_set_patch_input(self._h, int(n_syndrome_planes), int(stride_words)))
+        self.patch_planes = int(n_syndrome_planes)
+
     def check_range(self):
         """Synchronises the current stream; raises DeepQError(status=DQ_ERR_RANGE) if a gradient of the fused backward left the range of
         its f16 pieces since the last call (include/deepq_hip.h dq_qnet_range_check)."""
@@ -156,19 +162,22 @@ class QNetwork:
 
     def forward_multi(self, jobs):
         """Several forwards in one pair of launches (dq_qnet_forward_multi).  `jobs`: list of dicts with the keyword arguments
-        of forward() (params, obs, batch, index, index_off, index_mod, training, seed, t, sample_base, out); at most one
-        training job.  Returns the list of outputs."""
+        of forward() (params, obs, batch, index, index_off, index_mod, training, seed, t, sample_base, out) and optionally
+        patch=True (obs = int32 patch words, set_patch_input(); all jobs of a call in the same form); at most one training job.
+        Returns the list of outputs."""
         arr = (QNetJob * len(jobs))()
         outs = []
         for jb, kw in zip(arr, jobs):
             params, obs, index = kw["params"], kw["obs"], kw.get("index")
             assert params.dtype == torch.float32 and params.is_cuda and params.numel() == self.n_params
-            assert obs.dtype == torch.uint8 and obs.is_cuda and obs.is_contiguous()
+            patch = bool(kw.get("patch", False))       # obs holds patch words (int32 [rows, stride]) instead of uint8 images
+            assert obs.dtype == (torch.int32 if patch else torch.uint8) and obs.is_cuda and obs.is_contiguous()
             batch = kw.get("batch")
             if batch is None:
                 batch = obs.shape[0] if index is None else index.shape[0]
             if index is not None:
                 assert index.dtype == torch.int32 and index.is_cuda and index.is_contiguous()
+            jb.reserved = 1 if patch else 0
             out = kw.get("out")
             if out is None:
                 out = torch.empty((batch, self.n_actions), dtype=torch.float32, device=self.device)

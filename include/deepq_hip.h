@@ -183,6 +183,22 @@ dq_status dq_env_act_step_sample(dq_env* env, const float* q_dev, double eps, in
                                  uint64_t* legal_dev, uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sample,
                                  void* stream);
 
+/* Compact observation ("patch words").  The observation the reference builds -- padding_syndrome / padding_actions,
+ * Environments.py:273-314 -- feeds Conv2D(64, 3, strides=2) (Function_Library.py:353): output pixel (oy, ox) of that convolution sees
+ * the 3 x 3 patch at padded cell (2 oy, 2 ox), of which only the four CORNERS of every syndrome plane (even-even cells: grid cells
+ * (oy + dy, ox + dx) of the faulty syndrome, Environments.py:292-294) and the CENTRE of every action plane (the odd-odd cell of qubit
+ * oy d + ox, Environments.py:309-312) are data; every other cell is a constant of the embedding (Environments.py:284-298).  A lattice's
+ * observation is therefore d * d words, one per output pixel p = oy d + ox:
+ *     bit 4 j + 2 dy + dx   = faulty syndrome plane j (j < volume_depth) at grid cell (oy + dy, ox + dx)
+ *     bit 4 volume_depth + l = action plane l (l < n_action_layers) at qubit p
+ * (the padded uint8 image is a fixed function of these words and back; 4 volume_depth + n_action_layers <= 32 required, else
+ * DQ_ERR_UNSUPPORTED).  This call ARMS the handle: the NEXT launch that resets or steps its lattices -- dq_env_reset, dq_env_step,
+ * dq_env_act_step(_sample), or the step riding on dq_qnet_td_backward_*_env -- ALSO writes uint32 patch_dev[i * stride_words + p] for every
+ * lattice i (stride_words >= d * d; the words between d * d and the stride are left alone); that launch's obs_dev may then be NULL.
+ * One call arms one launch; patch_dev == NULL disarms.  The Q-network reads such rows directly (dq_qnet_job.reserved bit 0,
+ * dq_qnet_set_patch_input).  No reference counterpart: the reference stores the padded int64 image (6.8 KB per d = 5 observation). */
+dq_status dq_env_patch_output(dq_env* env, uint32_t* patch_dev, int stride_words);
+
 /* Hidden state for tests / checkpointing: uint64 [n_envs, state_words], state_words = 11 + volume_depth:
  *   0 xmask (hidden_state codes 1,2)   1 zmask (codes 2,3)
  *   2 current_true_syndrome word       3 OR of the volume's faulty words (summed_syndrome_volume != 0)
@@ -332,11 +348,25 @@ typedef struct {
     int32_t index_off, index_mod, batch, training;
     uint32_t seed[2];
     uint64_t t;
-    uint32_t sample_base, reserved;
+    uint32_t sample_base;
+    uint32_t reserved;          /* bit 0: obs_dev holds PATCH WORDS (dq_env_patch_output) -- uint32 [rows, stride_words], 16-byte aligned rows -- instead
+                                 * of padded uint8 images (needs dq_qnet_set_patch_input; every job of a launch in the same form); other bits 0 */
     float* q_dev;
     const void* packed_dev;     /* dq_qnet_pack(params_dev) output, or NULL: the call packs the weights itself (one extra small launch) */
 } dq_qnet_job;
 dq_status dq_qnet_forward_multi(dq_qnet* net, int n_jobs, const dq_qnet_job* jobs, void* stream);
+
+/* Patch-word input.  Declares that the network's first `n_syndrome_planes` input planes are padding_syndrome planes and the rest
+ * padding_actions planes (Environments.py:273-314; the observation of Surface_Code_Environment_Multi_Decoding_Cycles with
+ * volume_depth = n_syndrome_planes), so that Conv2D(64, 3, strides=2) (Function_Library.py:353) can read an observation as the d * d
+ * patch words of dq_env_patch_output instead of the (2d+1)^2 uint8 planes: one K = 32 matrix block per tile from the words' bits, the
+ * embedding's constant cells folded into a per-pixel bias (forward) / five shared gradient columns (backward).  Same function of the
+ * same weights: Q-values and gradients agree with the uint8 path to f32 round-off (both meet the 1e-5 bound against the float64 oracle).
+ * stride_words = words per observation row (a power of two, max(4, d * d) <= stride_words <= 64).  Fused chains only, d <= 7,
+ * 4 * n_syndrome_planes + action planes <= 32 (DQ_ERR_UNSUPPORTED otherwise); n_syndrome_planes = 0 switches it off.  Call it BEFORE
+ * dq_qnet_pack: the packed buffer carries the compact first kernel and the per-pixel bias.  Jobs select the form per launch
+ * (dq_qnet_job.reserved bit 0); dq_qnet_forward always reads uint8 images.  No reference counterpart. */
+dq_status dq_qnet_set_patch_input(dq_qnet* net, int n_syndrome_planes, int stride_words);
 
 /* The fused chains read the conv kernels and Dense(512) as f16 pieces in matrix-core operand order.  A caller that runs several
  * forwards on the same weights packs them once per parameter change (dq_qnet_packed_bytes(net) bytes of device memory) and

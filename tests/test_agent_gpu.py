@@ -552,8 +552,8 @@ def test_fused_step_equals_separate_calls_at_baseline_size(dq, torch_mod, name):
             a.update_target_hard(); b.update_target_hard()
         assert torch.equal(a.params, b.params) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v), t
         assert torch.equal(a.index, b.index) and torch.equal(a.q_act, b.q_act), t
-    for x, y in ((a.obs_ring, b.obs_ring), (a.action_ring, b.action_ring), (a.reward_ring, b.reward_ring), (a.terminal_ring, b.terminal_ring)):
-        assert torch.equal(x, y)
+    for x, y in ((a.obs_ring[:], b.obs_ring[:]), (a.action_ring, b.action_ring), (a.reward_ring, b.reward_ring), (a.terminal_ring, b.terminal_ring)):
+        assert torch.equal(x, y)                # (obs_ring[:]: the tensor, or the compact ring's words decoded -- core.ObsRingView)
     assert a.read_stats() == b.read_stats() and a.read_stats()[3] == 0
     assert not torch.equal(a.params, a.target)
 
@@ -586,7 +586,7 @@ def test_one_large_batch_equals_the_concatenation_of_rank_shards(dq, torch_mod, 
         sh = make(n, r * n, r, R, n)
         assert sh.T == T and sh.cur == big.cur and torch.equal(sh.params, big.params)
         sl = slice(r * n, (r + 1) * n)
-        assert torch.equal(big.obs_ring[:, sl], sh.obs_ring) and torch.equal(big.action_ring[:, sl], sh.action_ring)
+        assert torch.equal(big.obs_ring[:, sl], sh.obs_ring[:]) and torch.equal(big.action_ring[:, sl], sh.action_ring)
         assert torch.equal(big.reward_ring[:, sl], sh.reward_ring) and torch.equal(big.terminal_ring[:, sl], sh.terminal_ring)
         assert torch.equal(big.env.export_state()[sl], sh.env.export_state())
         g_sum += sh.local_gradient().double()

@@ -1,0 +1,215 @@
+"""GPU parity tests of the COMPACT observation path (include/deepq_hip.h dq_env_patch_output, dq_qnet_set_patch_input): the environment
+writes d * d patch words per lattice instead of the padded uint8 image, the first convolution reads them (one K = 32 block from the words'
+bits, the embedding's constant cells folded into a per-pixel bias / five shared gradient columns).
+
+Checked here: (1) the words the environment writes are exactly the reference's observation (the golden traces recorded from
+/root/reference/example_notebooks/Environments.py: padding_syndrome / padding_actions, ENV:273-314), decoded and encoded; (2) Q-values from
+patch words meet the float64 oracle's 1e-5 bound like the uint8 path and agree with it; (3) gradients per layer at 1e-4 against the oracle
+and the uint8 path; (4) the whole loop on a compact ring equals the loop on a uint8 ring."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, TRACES, trace_config
+from oracle import dqn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
+# name -> (d, syndrome planes, action planes, actions): BASELINE.json's configurations and the combinations tests/test_qnet_gpu.py adds
+GEOM = {"c1": (3, 3, 1, 10), "c2": (5, 5, 1, 26), "c3": (5, 5, 2, 51), "c5": (7, 7, 2, 99), "c3y": (5, 4, 3, 76), "d7x": (7, 7, 1, 50), "d3dp": (3, 3, 2, 19)}
+
+
+def tol(ref):
+    return 1e-5 * max(1.0, float(np.abs(np.asarray(ref)).max()))
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def valid_observations(rng, d, depth, layers, batch, p=0.3):
+    """Random observations of the reference's form (ENV:273-314): random syndrome bits at the even-even cells over padding_syndrome's
+    decoration, random action bits at the odd-odd cells."""
+    n = 2 * d + 1
+    x, y = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    static = ((((x == 0) | (x == n - 1)) & (y % 2 == 1)) | (((y == 0) | (y == n - 1)) & (x % 2 == 1)) | ((x % 2 == 1) & (y % 2 == 1) & ((x + y) % 4 == 0))).astype(np.uint8)
+    obs = np.zeros((batch, depth + layers, n, n), np.uint8)
+    obs[:, :depth] = static
+    obs[:, :depth, 0::2, 0::2] = rng.rand(batch, depth, d + 1, d + 1) < p
+    obs[:, depth:, 1::2, 1::2] = rng.rand(batch, layers, d, d) < p
+    return obs
+
+
+def _setup(dq, torch, name, batch, seed=(11, 22)):
+    d, depth, layers, A = GEOM[name]
+    shape = (depth + layers, 2 * d + 1, 2 * d + 1)
+    spec = O.QNetSpec(shape, C_LAYERS, FF_LAYERS, A, dueling=True)
+    net = dq.QNetwork(shape, C_LAYERS, FF_LAYERS, A, dueling=True, max_batch=batch)
+    E = __import__("importlib").import_module("deepq-decoding_amd.env")
+    stride = E.patch_stride_words(d)
+    net.set_patch_input(depth, stride)
+    params = net.init_params(seed)
+    rng = np.random.RandomState(5)
+    flat = params.cpu().numpy().copy()
+    flat += (rng.randn(flat.size) * 0.02).astype(np.float32)        # non-zero biases, less symmetric weights
+    params.copy_(torch.from_numpy(flat))
+    obs = valid_observations(rng, d, depth, layers, batch)
+    patch = E.obs_to_patch(torch.from_numpy(obs), d, depth, layers, stride).cuda().contiguous()
+    assert torch.equal(E.patch_to_obs(patch, d, depth, layers).cpu(), torch.from_numpy(obs))
+    return spec, net, params, flat, obs, patch, rng
+
+
+@pytest.mark.parametrize("name", [n for n in TRACES])
+def test_environment_patch_words_are_the_reference_observation(dq, torch_mod, name):
+    """Replays the traces recorded from the reference's Environments.py with the patch output armed on every launch: the words decode to
+    the recorded observation (bit for bit), and equal the encoding of the uint8 observation the same launch wrote."""
+    torch = torch_mod
+    g = load_golden("trace_" + name)
+    cfg, n_envs, n_steps, seed = trace_config(g)
+    env = dq.VectorEnv(n_envs=n_envs, seed=seed, **cfg)
+    assert env.patch_supported
+    patch = torch.zeros((n_envs, env.patch_stride), dtype=torch.int32, device="cuda")
+    actions = torch.from_numpy(g["action"].astype(np.int32)).cuda()
+    env.reset(out_patch=patch)
+    for t in range(n_steps + 1):
+        assert np.array_equal(env.patch_to_obs(patch).cpu().numpy(), g["obs"][:, t]), (name, "decoded words", t)
+        assert torch.equal(env.obs_to_patch(env.obs)[:, :cfg["d"] ** 2], patch[:, :cfg["d"] ** 2]), (name, "encoded image", t)
+        if t < n_steps:
+            if t % 3 == 2:                      # words only (the loop's form: no uint8 image is written)
+                env.arm_patch_output(patch)
+                _lib = __import__("importlib").import_module("deepq-decoding_amd._lib")
+                _lib.check(env.L.dq_env_step(env._h, actions[:, t].contiguous().data_ptr(), 1, None, env.reward.data_ptr(), env.done.data_ptr(),
+                                             env.legal.data_ptr(), env.lifetime.data_ptr(), env.was_reset.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+                env.obs.copy_(env.patch_to_obs(patch))
+            else:
+                env.step(actions[:, t].contiguous(), auto_reset=True, out_patch=patch)
+            assert np.array_equal(env.reward.cpu().numpy(), g["reward"][:, t]), (name, "reward", t)
+    # one call arms ONE launch: the next step leaves the words alone
+    before = patch.clone()
+    env.step(actions[:, 0].contiguous(), auto_reset=True)
+    assert torch.equal(before, patch)
+    env.close()
+
+
+@pytest.mark.parametrize("name,batch", [("c1", 37), ("c2", 32), ("c3", 8), ("c3", 300), ("c3", 4096), ("c5", 64), ("c5", 1024), ("c3y", 70), ("d7x", 45), ("d3dp", 130)])
+def test_forward_from_patch_words(dq, torch_mod, name, batch):
+    torch = torch_mod
+    spec, net, params, flat, obs, patch, rng = _setup(dq, torch, name, batch)
+    q_u8 = net.forward(params, torch.from_numpy(obs).cuda()).cpu().numpy()
+    q_pw = net.forward_multi([dict(params=params, obs=patch, patch=True)])[0].cpu().numpy()
+    q_ref, _ = O.forward(spec, flat, obs)
+    assert np.abs(q_pw - q_ref).max() < tol(q_ref), ("patch words vs float64", np.abs(q_pw - q_ref).max())
+    assert np.abs(q_u8 - q_ref).max() < tol(q_ref)
+    assert np.abs(q_pw - q_u8).max() < tol(q_ref), ("patch words vs uint8 image", np.abs(q_pw - q_u8).max())
+    # the persistent kernel and the one-group kernel give the same bits (as for the uint8 form)
+    import os
+    old = os.environ.get("DQ_CONV_PERSIST")
+    try:
+        os.environ["DQ_CONV_PERSIST"] = "2"
+        q_p = net.forward_multi([dict(params=params, obs=patch, patch=True)])[0].cpu().numpy()
+        os.environ["DQ_CONV_PERSIST"] = "0"
+        q_1 = net.forward_multi([dict(params=params, obs=patch, patch=True)])[0].cpu().numpy()
+    finally:
+        if old is None:
+            os.environ.pop("DQ_CONV_PERSIST", None)
+        else:
+            os.environ["DQ_CONV_PERSIST"] = old
+    assert np.array_equal(q_p, q_1)
+
+
+def test_forward_from_patch_words_with_replay_gather_and_four_jobs(dq, torch_mod):
+    """Minibatch rows gathered from a ring of patch words inside conv1's loader (with the successor wrap-around), four jobs in one launch."""
+    torch = torch_mod
+    spec, net, params, flat, ring, ring_pw, rng = _setup(dq, torch, "c3", 600)
+    idx = rng.randint(0, 600, size=256).astype(np.int32)
+    idx_t = torch.from_numpy(idx).cuda()
+    params2 = params * 1.01
+    flat2 = params2.cpu().numpy()
+    jobs = [dict(params=params, obs=ring_pw, index=idx_t, patch=True),
+            dict(params=params2, obs=ring_pw, index=idx_t, index_off=40, index_mod=600, patch=True),
+            dict(params=params, obs=ring_pw[100:], batch=64, patch=True),
+            dict(params=params2, obs=ring_pw, index=idx_t, index_off=599, index_mod=600, patch=True)]
+    outs = [o.cpu().numpy() for o in net.forward_multi(jobs)]
+    refs = [O.forward(spec, flat, ring[idx])[0], O.forward(spec, flat2, ring[(idx + 40) % 600])[0], O.forward(spec, flat, ring[100:164])[0],
+            O.forward(spec, flat2, ring[(idx + 599) % 600])[0]]
+    for o, r in zip(outs, refs):
+        assert np.abs(o - r).max() < tol(r)
+    # each job alone gives the same bits as in the shared launch
+    for jb, o in zip(jobs, outs):
+        assert np.array_equal(net.forward_multi([jb])[0].cpu().numpy(), o)
+    # the two forms do not mix in one launch
+    with pytest.raises(Exception):
+        net.forward_multi([jobs[0], dict(params=params, obs=torch.from_numpy(ring).cuda(), batch=8)])
+
+
+@pytest.mark.parametrize("name,batch", [("c1", 8), ("c2", 40), ("c3", 32), ("c3", 257), ("c3", 4096), ("c5", 48), ("c5", 1024), ("c3y", 70), ("d7x", 45), ("d3dp", 130)])
+def test_training_forward_backward_from_patch_words(dq, torch_mod, name, batch):
+    torch = torch_mod
+    spec, net, params, flat, obs, patch, rng = _setup(dq, torch, name, batch)
+    seed, t, base = (3, 4), 12345678901, 77
+    keep = O.dropout_keep_mask(seed, t, base + np.arange(batch), 512, 0.2)
+    q = net.forward_multi([dict(params=params, obs=patch, patch=True, training=True, seed=seed, t=t, sample_base=base)])[0].cpu().numpy()
+    q_ref, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    assert np.abs(q - q_ref).max() < tol(q_ref)
+    dq_ = (rng.randn(batch, spec.n_actions) / batch).astype(np.float32)
+    g = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
+    g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
+    scale = np.abs(g_ref).max()
+    assert np.abs(g - g_ref).max() < 2e-5 * max(scale, 1.0), (np.abs(g - g_ref).max(), scale)
+    for (gk, gb), (rk, rb) in zip(spec.split(g), spec.split(g_ref)):
+        for a, b in ((gk, rk), (gb, rb)):
+            assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-7
+    # the first kernel's gradient row by row: rows no observation can excite are exactly 0 in both
+    k1 = spec.split(g)[0][0].reshape(-1, 64)
+    r1 = spec.split(g_ref)[0][0].reshape(-1, 64)
+    assert np.array_equal(np.abs(r1).max(axis=1) == 0, np.abs(k1).max(axis=1) == 0)
+    # deterministic
+    assert np.array_equal(g, net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy())
+    # ... and the uint8 form of the same observations: same function of the same weights
+    q8 = net.forward(params, torch.from_numpy(obs).cuda(), training=True, seed=seed, t=t, sample_base=base).cpu().numpy()
+    g8 = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
+    assert np.abs(q - q8).max() < tol(q_ref)
+    for (gk, gb), (rk, rb) in zip(spec.split(g), spec.split(g8)):
+        for a, b in ((gk, rk), (gb, rb)):
+            assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-7
+
+
+@pytest.mark.parametrize("cfg,n,batch", [(dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011), 512, 512),
+                                         (dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005), 128, 128),
+                                         (dict(d=3, error_model="X", use_Y=False, volume_depth=3, p_phys=0.005, p_meas=0.005), 1, 32)])
+def test_loop_on_a_compact_ring_equals_the_loop_on_a_uint8_ring(dq, torch_mod, cfg, n, batch):
+    """DQNCore with the ring as patch words against DQNCore with the uint8 ring (compact=False): same lattices, same minibatches; the
+    transitions (actions, rewards, terminals, observations) are identical, the parameters agree to f32 round-off."""
+    torch = torch_mod
+    seed = (7, 9)
+    cores = []
+    for compact in (True, False):
+        env = dq.VectorEnv(n_envs=n, seed=seed, **cfg)
+        net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=max(n, batch))
+        core = dq.DQNCore(env, net, batch_size=batch, memory_limit=n * 9, gamma=0.99, lr=1e-4, seed=seed, compact=compact)
+        assert core.compact == compact
+        core.reset_env()
+        for _ in range(5):
+            core.act_and_step(1.0, use_q=False)
+        cores.append(core)
+    a, b = cores
+    assert a.patch_ring is not None and b.patch_ring is None
+    lr, steps = 1e-4, 12
+    for t in range(steps):
+        for c in cores:
+            c.step_and_update(1.0)              # (eps = 1: the actions do not hang on a round-off-level tie between two Q-values)
+        assert torch.equal(a.index, b.index), t
+        qa, qb = a.q_act.cpu().numpy(), b.q_act.cpu().numpy()
+        assert np.abs(qa - qb).max() < tol(qb), t
+    assert torch.equal(a.action_ring, b.action_ring) and torch.equal(a.reward_ring, b.reward_ring) and torch.equal(a.terminal_ring, b.terminal_ring)
+    assert torch.equal(a.obs_ring[:], b.obs_ring[:])
+    la, lb = a.read_metrics(), b.read_metrics()
+    assert abs(la[0] - lb[0]) < 1e-5 * max(1.0, abs(lb[0])) and abs(la[1] - lb[1]) < 1e-5 * max(1.0, abs(lb[1]))
+    # Adam divides by sqrt(v): an element whose gradient is at round-off level moves by up to lr per step in either run; the bulk agrees closely
+    diff = (a.params - b.params).abs()
+    assert float(diff.max()) <= 2 * lr * steps and float(diff.mean()) < 2e-6, (float(diff.max()), float(diff.mean()))
+    assert a.read_stats() == b.read_stats()
