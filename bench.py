@@ -215,6 +215,10 @@ def main():
     ap.add_argument("--minibatch", type=int, default=0, help="DQN minibatch per rank (default: n_envs)")
     ap.add_argument("--lattices", type=int, default=0, help="lattices per rank (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--updates-per-step", type=int, default=1,
+                    help="minibatch updates per vector step (loop mode).  The reference trains 32 samples per environment step "
+                         "(one 32-sample update per step, Single_Point_Training_Script.py:119-127): --updates-per-step 32 at the default "
+                         "minibatch = lattices, or --minibatch 32 --updates-per-step <lattices>")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -268,7 +272,7 @@ def main():
         runner = EnvOnly(dq, cfg, n_local, rank)
     else:
         runner = importlib.import_module("deepq-decoding_amd.bench_loop").FullLoop(
-            dq, cfg, n_local, rank, world, args.minibatch or n_local, mode=mode, config_name=args.config)
+            dq, cfg, n_local, rank, world, args.minibatch or n_local, mode=mode, config_name=args.config, updates_per_step=max(1, args.updates_per_step))
 
     def sync():
         if world > 1 or force_dist:

@@ -293,7 +293,12 @@ def _jsonable(v):
 class DQNAgent:
     def __init__(self, model, nb_actions, memory, nb_steps_warmup=1000, target_model_update=10000, policy=None, test_policy=None,
                  gamma=.99, enable_dueling_network=False, enable_double_dqn=True, dueling_type='avg', batch_size=32,
-                 train_interval=1, memory_interval=1, delta_clip=np.inf, custom_model_objects=None, seed=None, **kwargs):
+                 train_interval=1, memory_interval=1, delta_clip=np.inf, custom_model_objects=None, seed=None, updates_per_vector_step=1,
+                 **kwargs):
+        """updates_per_vector_step (no keras-rl counterpart): minibatch updates per vector step of the N lattices.  keras-rl trains one
+        `batch_size` minibatch per ENVIRONMENT step (train_interval=1, TRAIN:119-127), i.e. batch_size samples per step; a vector step
+        advances N lattices, so the reference's replay ratio is updates_per_vector_step * batch_size / N = batch_size, reached with
+        updates_per_vector_step = N (batch_size 32) or N * 32 / batch_size for a larger minibatch.  Default 1: one update per vector step."""
         if hasattr(model, "_built"):                # a keras.models.Sequential stand-in (dropin/keras): resolve to the model description
             model = model._built()
         if model.output_shape != (None, nb_actions):
@@ -314,6 +319,9 @@ class DQNAgent:
         self.test_policy._set_agent(self)
         self.gamma, self.enable_dueling_network, self.enable_double_dqn = gamma, bool(enable_dueling_network), bool(enable_double_dqn)
         self.batch_size, self.train_interval = int(batch_size), int(train_interval)
+        self.updates_per_vector_step = int(updates_per_vector_step)
+        if self.updates_per_vector_step < 1:
+            raise ValueError("updates_per_vector_step must be at least 1")
         self.seed = seed
         self.optimizer = None
         self.compiled = False
@@ -422,7 +430,8 @@ class DQNAgent:
         core = self._core
         did = False
         if self.step > self.nb_steps_warmup and core.filled >= MIN_FILLED and (self.step // core.N) % self.train_interval == 0:
-            core.update()
+            for _ in range(self.updates_per_vector_step):
+                core.update()
             did = True
         self._sync_target()
         return did
@@ -459,6 +468,7 @@ class DQNAgent:
         core.reset_env()
         if sync_interval is None:
             sync_interval = 1 if N == 1 else 64
+        core.ensure_comm()              # several ranks: the learner's own RCCL communicator is created here, not inside the first update (~1 s rendezvous)
         t_start = timeit.default_timer()
         lifetimes = deque(maxlen=int(episode_averaging_length))     # (episodes, lifetime_sum) chunks, newest last
         best_avg, best_episode, episode = -np.inf, 0, 0
@@ -467,12 +477,17 @@ class DQNAgent:
         losses, qs, epss = [], [], []
         start_step = self.step
         stop = False
+        loop_iter = 0                   # counted steps of THIS fit() -- the same on every rank (core.vector_steps is not: with one lattice per
+                                        # rank only the ranks whose own lattice ended take the uncounted reset step), so the host synchronisations,
+                                        # which contain collectives, are gated on it
         try:
             while self.step - start_step < nb_steps and not stop:
+                loop_iter += 1
                 eps, masked = self.policy.current(True)
                 if self._will_train(self.step + N):
                     # acting forward + the update's forwards in one pair of launches; the environment launch draws the next minibatch
-                    core.step_and_update(eps, masked_greedy=masked, presample_next=self._will_train(self.step + 2 * N))
+                    core.step_and_update(eps, masked_greedy=masked, presample_next=self._will_train(self.step + 2 * N),
+                                         extra_updates=self.updates_per_vector_step - 1)
                     self.step += N
                     trained = True
                     self._sync_target()
@@ -481,7 +496,7 @@ class DQNAgent:
                     self.step += N
                     trained = self._maybe_train()
                 epss.append(eps)
-                if core.vector_steps % sync_interval != 0:
+                if loop_iter % sync_interval != 0:
                     continue
                 # ---- host sync: episode bookkeeping ---------------------------------------------------------------
                 n_ep, life_sum, n_rew, n_stepped = core.read_stats(all_ranks=True)
@@ -537,6 +552,7 @@ class DQNAgent:
         except KeyboardInterrupt:
             pass
         torch.cuda.synchronize(core.device)
+        core.close_comm()               # (every rank, everything drained: before the process group that did its rendezvous can be destroyed)
         dt = timeit.default_timer() - t_start
         for cb in callbacks:
             cb.on_train_end()

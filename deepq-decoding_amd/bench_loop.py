@@ -83,8 +83,10 @@ class FullLoop:
     dtype = "f32 (operands as 2 f16 pieces = 22 significant bits, 2 or 3 f16 MFMAs per product, f32 accumulate)"
 
     def __init__(self, dq, cfg, n_local, rank, world, minibatch, eps=0.1, replay_transitions=1 << 20, lr=1e-4,
-                 target_every=32, mode="loop", config_name="c3"):
+                 target_every=32, mode="loop", config_name="c3", updates_per_step=1):
         self.cfg, self.n, self.rank, self.world, self.B = cfg, n_local, rank, world, minibatch
+        self.k = int(updates_per_step)           # minibatch updates per vector step (DQNAgent.updates_per_vector_step): the reference's replay ratio of
+                                                 # 32 trained samples per environment step (TRAIN:119-127) is k * B / n = 32
         self.eps, self.target_every, self.mode, self.config_name = eps, target_every, mode, config_name
         self.unit = "dqn_samples/s" if mode == "learn" else "env_steps/s"
         self.env = VectorEnv(n_envs=n_local, env_id_base=rank * n_local, **cfg)
@@ -125,7 +127,9 @@ class FullLoop:
         nc = len(C_LAYERS)
         lm = self.layer_macs
         conv, dense = sum(lm[:nc]), sum(lm[nc:])
-        fwd_samples = {"loop": self.n + 3 * self.B, "act": self.n, "learn": 3 * self.B}[self.mode]
+        k = self.k if self.mode == "loop" else 1
+        fwd_samples = {"loop": self.n + 3 * self.B * k, "act": self.n, "learn": 3 * self.B}[self.mode]
+        B = self.B * k
         if self.mode == "act":
             assert self.net.fused_supported
             return {"conv_chain_kernel": (1, 2.0 * conv * fwd_samples, "mfma"), "dense_chain_kernel": (1, 2.0 * dense * fwd_samples, "mfma")}
@@ -133,12 +137,12 @@ class FullLoop:
             # one forward launch pair per step (the acting forward and the update's three forwards share it), one launch per
             # backward kernel
             return {
-                "conv_chain_kernel": (1, 2.0 * conv * fwd_samples, "mfma"),
-                "dense_chain_kernel": (1, 2.0 * dense * fwd_samples, "mfma"),
+                "conv_chain_kernel": (k, 2.0 * conv * fwd_samples, "mfma"),
+                "dense_chain_kernel": (k, 2.0 * dense * fwd_samples, "mfma"),
                 # conv weight gradients (= forward MACs) + data gradients through conv3 and conv2
-                "conv_bwd_chain_kernel": (1, 2.0 * (conv + sum(lm[1:nc])) * self.B, "mfma"),
-                "dense_bwd_chain_kernel": (1, 2.0 * dense * self.B, "mfma"),
-                "dense_wgrad_kernel": (1, 2.0 * dense * self.B, "mfma"),
+                "conv_bwd_chain_kernel": (k, 2.0 * (conv + sum(lm[1:nc])) * B, "mfma"),
+                "dense_bwd_chain_kernel": (k, 2.0 * dense * B, "mfma"),
+                "dense_wgrad_kernel": (k, 2.0 * dense * B, "mfma"),
             }
         return {
             "gemm_fwd_kernel": (5 * len(lm) - 1, 2.0 * self.macs * fwd_samples + 2.0 * (self.macs - lm[0]) * self.B, "mfma"),
@@ -152,8 +156,17 @@ class FullLoop:
         if not self.net.fused_supported:
             return {}
         conv, rest = sum(lm[:nc]), sum(lm[1:nc])
-        return {"conv_chain_kernel": (2.0 * lm[0] + 3.0 * rest) / conv,
-                "conv_bwd_chain_kernel": (2.0 * lm[0] + 3.0 * rest + 3.0 * rest) / (conv + rest),     # weight gradients + data gradients
+        # the first convolution's operand is binary: 2 MFMAs per product.  On the uint8 image its K = k*k*C is padded to whole blocks of 32 and every
+        # cell is multiplied, constants included; on patch words (DQNCore.compact) only the K_data <= 32 data cells are: ONE block of 32 in the
+        # forward, K_data + 5 columns (padded to 16s) in its weight gradient -- fewer ISSUED flops for the same algorithmic work
+        c1_fwd = c1_bwd = 2.0 * lm[0]
+        if getattr(self.core, "compact", False):
+            K1 = C_LAYERS[0][1] ** 2 * self.env.obs_shape[0]
+            kd = 4 * self.env.volume_depth + self.env.n_action_layers
+            c1_fwd = 2.0 * lm[0] * 32.0 / K1
+            c1_bwd = 2.0 * lm[0] * (16.0 * ((kd + 5 + 15) // 16)) / K1
+        return {"conv_chain_kernel": (c1_fwd + 3.0 * rest) / conv,
+                "conv_bwd_chain_kernel": (c1_bwd + 3.0 * rest + 3.0 * rest) / (conv + rest),     # weight gradients + data gradients
                 "dense_chain_kernel": 3.0, "dense_bwd_chain_kernel": 3.0, "dense_wgrad_kernel": 3.0}
 
     def _family_id(self, name):
@@ -208,20 +221,22 @@ class FullLoop:
         if self.mode == "learn":
             self.core.update()
         else:
-            self.core.step_and_update(self.eps)      # == act_and_step() + update(), the four forwards in one pair of launches
-        if self.core.updates % self.target_every == 0:
+            self.core.step_and_update(self.eps, extra_updates=self.k - 1)      # == act_and_step() + k update(), the first update's forwards with the acting forward
+        if self.core.updates % self.target_every < (self.k if self.mode == "loop" else 1):
             self.core.update_target_hard()
 
     def config(self):
         return dict(policy=f"eps-greedy over legal moves, eps={self.eps}, live Q-network", minibatch_per_gpu=self.B,
-                    updates_per_vector_step=1, replay_ratio_samples_per_env_step=self.B / self.n,
+                    updates_per_vector_step=self.k if self.mode == "loop" else (0 if self.mode == "act" else 1),
+                    replay_ratio_samples_per_env_step=(self.k * self.B / self.n) if self.mode == "loop" else None,
+                    reference_replay_ratio_samples_per_env_step=32, observations="patch words (d*d u32 per lattice)" if self.core.compact else "uint8 planes",
                     replay_ring_slots=self.core.T, network="conv 64x3s2-32x2-32x2, dense 512 (dropout .2), dueling",
                     n_params=self.net.n_params, grad_allreduce="RCCL sum of the flat fp32 gradient" if self.world > 1 else "none (1 GPU)")
 
     def report(self, steps, dt, world):
         ep, life, rew, stepped = self.core.read_stats()
         # acting forward + update (3 fwd + bwd = 5x fwd)
-        flops_per_step = 2 * self.macs * {"loop": self.n + self.B * 5, "act": self.n, "learn": self.B * 5}[self.mode]
+        flops_per_step = 2 * self.macs * {"loop": self.n + self.B * 5 * self.k, "act": self.n, "learn": self.B * 5}[self.mode]
         roof = None
         if self.prof_family:
             launches, ms = self._collect()
@@ -244,8 +259,8 @@ class FullLoop:
                     roof["vs_f32_mfma_peak"] = dict(peak=MFMA_F32_PEAK_TFLOPS, ratio=achieved / MFMA_F32_PEAK_TFLOPS)
         out = {
             "roofline": roof,
-            "dqn_updates_per_s": 0.0 if self.mode == "act" else steps / dt,
-            "dqn_samples_per_s": 0.0 if self.mode == "act" else steps * self.B * world / dt,
+            "dqn_updates_per_s": 0.0 if self.mode == "act" else steps * (self.k if self.mode == "loop" else 1) / dt,
+            "dqn_samples_per_s": 0.0 if self.mode == "act" else steps * (self.k if self.mode == "loop" else 1) * self.B * world / dt,
             "achieved_qnet_tflops_per_gpu": flops_per_step * steps / dt / 1e12,
             "episodes_finished_rank0": ep,
             "mean_lifetime_rank0": (life / ep) if ep else None,

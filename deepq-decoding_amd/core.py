@@ -392,9 +392,11 @@ class DQNCore:
             net.td_backward_adam(self.params, td, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
         self.repack()
 
-    def step_and_update(self, eps, masked_greedy=False, record_stats=True, presample_next=True):
+    def step_and_update(self, eps, masked_greedy=False, record_stats=True, presample_next=True, extra_updates=0):
         """act_and_step() followed by update(), with the acting forward and the update's forwards in ONE pair of launches -- same
-        results as the two calls.  Possible because the update's minibatch never contains the newest transition (keras-rl's range:
+        results as the two calls.  extra_updates: that many further update() calls on the same ring state (DQNAgent's
+        updates_per_vector_step - 1: the reference trains one 32-sample minibatch per environment step, TRAIN:119-127, i.e. N minibatches
+        per vector step of N lattices).  Possible because the update's minibatch never contains the newest transition (keras-rl's range:
         its successor observation is not in the memory yet), so it does not depend on this step's environment results -- the newest
         row it can hold is the previous step's, whose successor is the observation this step acts on: the parameters are the same
         for all four forwards.
@@ -413,7 +415,9 @@ class DQNCore:
         self.net.forward_multi(jobs)
         seed = (ctypes.c_uint32 * 2)(*env.seed)
         sj = None
-        if presample_next:
+        if extra_updates > 0:                    # the next update runs on THIS step's ring: the environment launch draws its minibatch
+            sj = self._sample_job(t + 1, nxt, filled)
+        elif presample_next:
             nxt2 = nxt + 1 if nxt + 1 < T else 0
             sj = self._sample_job(t + 1, nxt2, min(T, filled + 1))
         if self.ride_env and self._env_stream is None and self.net.fused_supported and self.net.fused_enabled and not getattr(env, "wide", False) \
@@ -430,6 +434,8 @@ class DQNCore:
             self.vector_steps += 1
             self.updates = t
             self._learn(t, ride=step)
+            for _ in range(extra_updates):
+                self.update()
             return
         args = (env._h, ptr(self.q_act), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
                 self._obs_slot(nxt), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
@@ -453,6 +459,8 @@ class DQNCore:
         self.vector_steps += 1
         self.updates = t
         self._learn(t)
+        for _ in range(extra_updates):
+            self.update()
 
     def read_metrics(self):
         """(loss, mean_q) of the last update on this rank; reduces the per-block partials first (syncs)."""
@@ -488,6 +496,16 @@ class DQNCore:
             torch.cuda.synchronize(self.device)
             self._rccl.close()
         self._rccl, self._rccl_tried = None, False
+
+    def close(self):
+        """Releases what outlives the Python objects: the learner's RCCL communicator (before torch.distributed.destroy_process_group)."""
+        self.close_comm()
+
+    def __del__(self):
+        try:
+            self.close_comm()
+        except Exception:
+            pass
 
     def read_stats(self, reset=True, all_ranks=False):
         """(episodes ended, sum of their lifetimes, rewards earned, lattices stepped) since the last reset; syncs.  all_ranks: summed

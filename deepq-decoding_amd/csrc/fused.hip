@@ -237,23 +237,32 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
 // plane, the centre per action plane: include/deepq_hip.h dq_env_patch_output); they arrive as ONE u32 per sample and pixel.  The A operand of
 // the single K = 32 block is therefore one byte per lane (lane (kq, j): bits 8kq .. 8kq+7 of row j's word) expanded through a 256-entry LDS table --
 // one ds_read_u8 + one ds_read_b128 where the uint8 image took 16 byte gathers, 8 packs and 8 multiplies -- and 8 MFMAs per tile instead of 16 / 24;
-// the patch's constant cells are a per-pixel bias (qnet.h b1p), read through L1 (6 KB at d = 5) before the tile's MFMAs.
+// the patch's constant cells are a per-pixel bias (qnet.h b1p).  A wave's tiles are the same rows of every group (tile = wave, wave + 4, ...: row m is
+// pixel m mod r1 whatever the group), so the bias vectors of its first PATCH_BT tiles are REGISTERS (conv1_patch_bias: loaded with the kernel pieces, far
+// ahead of their use; first version: four 16-byte loads per tile in front of its MFMAs -- an L2 round trip per tile that ate what the shorter gather
+// saved: 41.3 against 42.3 us); tiles beyond (a group of more than 16 PATCH_BT rows: one workgroup per CU at d = 7) read them per tile.
 //   s_in    the group's staged rows (row s at s * slot);  s_t1[m] & 0x1ffff = s * slot + 4 p for row m = s * r1 + p, padded to whole tiles
 //   wb      [piece][column tile] the compact kernel's pieces (qnet.h c1c);  b1p  [r1][64] f32
 // Output: a1 piece planes, rows of 64 halves (l plane lo1 halves further), rows < M1 only.
+#define PATCH_BT 4
+// ent(m): table entry of row m (any source); this lane's rows 4kq .. 4kq+3 of its wave's first PATCH_BT tiles
+template <typename EntFn>
+__device__ __forceinline__ void conv1_patch_bias(f32x4 (&bp)[PATCH_BT][4], const float* __restrict__ b1p, int slot, int wfirst, int j, int kq, EntFn ent) {
+#pragma unroll
+    for (int u = 0; u < PATCH_BT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            bp[u][r] = *reinterpret_cast<const f32x4*>(b1p + ((ent((wfirst + CONV_WAVES * u) * 16 + 4 * kq + r) & (slot - 1)) << 4) + 4 * j);     // 4 p -> p * 64 floats
+}
+
 __device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, const int* __restrict__ s_t1, const u32x4* __restrict__ s_lut,
-                                                  const u32x4 (&wb)[2][1][4], const float* __restrict__ b1p, int slot, unsigned short* __restrict__ s_a1, int lo1,
-                                                  int M1, int wfirst, int j, int kq) {
+                                                  const u32x4 (&wb)[2][1][4], const f32x4 (&bpr)[PATCH_BT][4], const float* __restrict__ b1p, int slot,
+                                                  unsigned short* __restrict__ s_a1, int lo1, int M1, int wfirst, int j, int kq) {
     const int tiles = (M1 + 15) >> 4;
     if (wfirst >= tiles) return;                                    // wave-uniform
     auto byte_of = [&](int tile) -> u32 { return s_in[(s_t1[min(tile * 16 + j, M1 - 1)] & 0x1ffff) + kq]; };      // (tiles past the end reread the last row)
-    auto tile_out = [&](int tile, u32 byte) {
+    auto tile_out = [&](int tile, u32 byte, const f32x4 (&bp)[4]) {
         const u32x4 av = s_lut[byte];
-        const int4 e4 = *reinterpret_cast<const int4*>(s_t1 + tile * 16 + 4 * kq);     // this lane's four output rows (the table is padded to whole tiles)
-        const int ent[4] = {e4.x, e4.y, e4.z, e4.w};
-        f32x4 bp[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bp[r] = *reinterpret_cast<const f32x4*>(b1p + ((ent[r] & (slot - 1)) << 4) + 4 * j);     // 4 p -> p * 64 floats
         f32x4 acc[4], accl[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[t] = acc[t]; }
@@ -279,10 +288,25 @@ __device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, c
             *reinterpret_cast<uint2*>(dst + lo1) = uint2{lp[0], lp[1]};
         }
     };
-    u32 bA = byte_of(wfirst), bB;
-    for (int tile = wfirst;;) {
-        bB = byte_of(tile + CONV_WAVES); tile_out(tile, bA); tile += CONV_WAVES; if (tile >= tiles) break;
-        bA = byte_of(tile + CONV_WAVES); tile_out(tile, bB); tile += CONV_WAVES; if (tile >= tiles) break;
+    u32 by[PATCH_BT + 1];
+    by[0] = byte_of(wfirst);
+#pragma unroll
+    for (int u = 0; u < PATCH_BT; ++u) {                            // (bytes one tile ahead)
+        const int tile = wfirst + CONV_WAVES * u;
+        if (tile >= tiles) return;                                  // wave-uniform
+        by[u + 1] = byte_of(tile + CONV_WAVES);
+        tile_out(tile, by[u], bpr[u]);
+    }
+    u32 bA = by[PATCH_BT];
+    for (int tile = wfirst + CONV_WAVES * PATCH_BT; tile < tiles; tile += CONV_WAVES) {     // larger groups: the bias through L1, per tile
+        const u32 bB = byte_of(tile + CONV_WAVES);
+        const int4 e4 = *reinterpret_cast<const int4*>(s_t1 + tile * 16 + 4 * kq);     // this lane's four output rows (the table is padded to whole tiles)
+        const int ent[4] = {e4.x, e4.y, e4.z, e4.w};
+        f32x4 bp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bp[r] = *reinterpret_cast<const f32x4*>(b1p + ((ent[r] & (slot - 1)) << 4) + 4 * j);
+        tile_out(tile, bA, bp);
+        bA = bB;
     }
 }
 
@@ -344,7 +368,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
         tab3[u] = a.rowtab[2 * CONV_ROWTAB + min((2 * wave + u) * 16 + j, M3 - 1)];
     }
     u32x4* s_lut = reinterpret_cast<u32x4*>(smem + a.off_lut);
-    if constexpr (CP) conv_build_bit_lut(s_lut, tid, CONV_THREADS);
+    f32x4 bp1[PATCH_BT][4];                                         // CP: per-pixel bias of this lane's rows (conv1_patch_words)
+    if constexpr (CP) {
+        conv_build_bit_lut(s_lut, tid, CONV_THREADS);
+        conv1_patch_bias(bp1, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, wave, j, kq, [&](int m) { return a.rowtab0[min(m, CONV_ROWTAB - 1)]; });
+    }
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 1);
     // ---- stage the observations by LDS-DMA (global -> LDS, no registers): lane l copies aligned 16-byte word l of a 1 KB piece of a
@@ -394,7 +422,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     // ---- convolution 1: A gathered byte-wise from the uint8 image; the bytes of this wave's next tile are requested before the
     //      MFMAs of the current one ----------------------------------------------------------------------------------------------
     if constexpr (CP) {
-        conv1_patch_words(s_in, s_t1, s_lut, wb, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wave, j, kq);
+        conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wave, j, kq);
     } else {
         const int tiles = (M1 + 15) >> 4;
         auto origin = [&](int tile) { return s_t1[min(tile * 16 + j, M1 - 1)]; };     // rows past the end (and whole tiles past it) reread the last row
@@ -547,6 +575,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     // first-layer weight pieces (PK_CONV1, zero past K1) and bias of a job
     u32x4 wb[2][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 f16 each
     f32x4 bias1;
+    f32x4 bp1[PATCH_BT][4];                                         // CP: per-pixel bias of this lane's rows (conv1_patch_words), reloaded with the pieces
     auto load_w1 = [&](const ConvJob& Jn) {
         const u32x4* pk1 = opaque_global(Jn.packed + (CP ? a.pk_c1c : PK_CONV1)) + lane;
 #pragma unroll
@@ -555,7 +584,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int piece = 0; piece < 2; ++piece) wb[piece][h][t] = pk1[(h * 4 + t) * PK_BLOCK + PK_LO * piece];
-        if constexpr (!CP) {
+        if constexpr (CP) {
+            const int* tc = reinterpret_cast<const int*>(smem + a.off_t1);      // (the constant table: row m -> sample, 4 p; padded to whole tiles)
+            conv1_patch_bias(bp1, reinterpret_cast<const float*>(opaque_global(Jn.packed + a.pk_b1p)), a.slot, wave, j, kq,
+                             [&](int m) { return tc[min(m, ((MF1 + 15) & ~15) - 1)]; });
+        } else {
             bias1 = *reinterpret_cast<const f32x4*>(Jn.params + a.b_off[0] + 4 * j);
             const int* kt = reinterpret_cast<const int*>(opaque_global(reinterpret_cast<const u32x4*>(a.kofftab))) + 8 * kq;
 #pragma unroll
@@ -619,6 +652,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     }
     int gid = (int)blockIdx.x, cur = 0;
     int gk = 0; (void)gk;                                           // group count of this workgroup (stamps: 8 per group)
+    if constexpr (CP) __syncthreads();                              // (load_w1 reads the table just built)
     load_w1(a.job[job_of(gid)]);
     issue(prep(gid), 0);
     Prep pre = prep(min(gid + gstride, total - 1));                 // the group whose copies the first trip issues
@@ -655,7 +689,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 2);
         // ---- convolution 1 (conv_chain_kernel's, on rows of 64 halves) ------------------------------------------------------------
         if constexpr (CP) {
-            conv1_patch_words(s_in, s_t1, s_lut, wb, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wv, j, kq);
+            conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wv, j, kq);
         } else {
             const int tiles = (M1 + 15) >> 4;
             auto origin = [&](int tile) {                           // (constant table entry + the sample's alignment offset of THIS group)
@@ -1706,11 +1740,11 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
             D.keep_scale = (float)(1.0 / (1.0 - (double)D1.dropout));
             D.drop_T = dq_rate_threshold16((double)D1.dropout);
             // the draw this forward asks for; the bits the last backward drew ahead if they are exactly it (qnet.h keep_bits)
-            const dq_qnet::DropTag want = {jb.seed[0], jb.seed[1], jb.sample_base, D.drop_T, jb.t, jb.batch, 1};
+            const dq_qnet::DropTag want = {jb.seed[0], jb.seed[1], jb.sample_base, D.drop_T, jb.t, jb.batch, 1, (void*)st};
             const dq_qnet::DropTag& have = Q->kb_tag;
             static const bool ahead_on = !(getenv("DQ_DROP_AHEAD") && getenv("DQ_DROP_AHEAD")[0] == '0');
             if (ahead_on && Q->keep_bits && have.valid && have.seed0 == want.seed0 && have.seed1 == want.seed1 && have.sample_base == want.sample_base &&
-                have.drop_T == want.drop_T && have.t == want.t && have.batch == want.batch)
+                have.drop_T == want.drop_T && have.t == want.t && have.batch == want.batch && have.stream == want.stream)
                 D.keep_bits = Q->keep_bits;
             Q->last_drop = want;
         } else if (training) {

@@ -1160,6 +1160,8 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
 
     if (CB_PRIO && wave >= CB_WAVES / 2) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses every issue arbitration by age: static priority evens the pair out
     DQ_STAMP_PAIR2(3);
+    DQ_STAMP_WG(DQ_TAG_CONV_BWD, 0);
+    DQ_STAMP(DQ_TAG_CONV_BWD, 25);
     // ---- group-independent tables and zero rows ----------------------------------------------------------------
     // (copied from the host-built tables: computing them here took two integer divisions per entry)
     for (int m = tid; m < S * r1; m += CB_THREADS) {
@@ -1170,13 +1172,15 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         if (m < S * r2) { t2[m] = e2; d2[m] = e4; }                 // t2: float offset of the a1 row under output pixel m of the second convolution
         if (m < S * r3) t3[m] = e3;                                 // t3: float offset of the a2 row
     }
-    if (!CP && tid < 96) s_ko[tid] = a.kofftab[tid];
+    if (tid < 96) s_ko[tid] = CP ? a.srctab[tid] : a.kofftab[tid];      // (CP: the scatter map of the kernel's end -- read there from LDS: a dependent global load per
+                                                                       // output row serialised eight round trips behind the last group, +2.4 us)
     uint2* s_lut = reinterpret_cast<uint2*>(smem + a.off_lut);       // CP: byte -> its bits as eight bytes
     if (CP && tid < 256) {
         const u32 b = (u32)tid;
         s_lut[tid] = uint2{(b & 1u) | (b & 2u) << 7 | (b & 4u) << 14 | (b & 8u) << 21, ((b >> 4) & 1u) | ((b >> 4) & 2u) << 7 | ((b >> 4) & 4u) << 14 | ((b >> 4) & 8u) << 21};
     }
     if (tid < PL32) { s_a2[zero2 * PL32 + tid] = 0; s_a2[LA2 + zero2 * PL32 + tid] = 0; s_g3[zero3 * PL32 + tid] = 0; s_g3[LG3 + zero3 * PL32 + tid] = 0; }
+    DQ_STAMP(DQ_TAG_CONV_BWD, 27);
 
     // ---- per-lane constants of the weight-gradient phases ----------------------------------------------------------
     // dW3 [128 x 32]: wave w owns k-tile w = (ky,kx) = w>>1, channels 16*(w&1)..; dW2 [256 x 32]: k-tiles 2w, 2w+1 = (ky,kx) = w>>1, channels 16*(2(w&1)+u)
@@ -1255,6 +1259,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
             if (lane == 0) s_mis[s] = mis;
         }
     };
+    DQ_STAMP(DQ_TAG_CONV_BWD, 28);
     if ((int)blockIdx.x < a.groups) {
         const int g = blockIdx.x, gns = min(S, a.batch - g * S);
         issue_obs(g, obs_row(g));
@@ -1262,6 +1267,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         issue_a2(g, gns * r2);
         if (a.a1_alt) issue_a1(g, reinterpret_cast<unsigned short*>(smem + a.off_a1));
     }
+    DQ_STAMP(DQ_TAG_CONV_BWD, 29);
 
     F16x2 bw[4][2];                                                 // data-gradient weights (f16 pieces): loaded one phase ahead of their use
     int it = 0;
@@ -1562,11 +1568,13 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
         }
         if constexpr (CP) {
             for (int i = tid; i < a.K1 * 64; i += CB_THREADS) {
-                const int src = a.srctab[i >> 6];
+                const int src = s_ko[i >> 6];
                 out[a.w_off[0] + i] = src >= 0 ? s_res[src * 64 + (i & 63)] : 0.f;
             }
         }
     }
+    DQ_STAMP(DQ_TAG_CONV_BWD, 26);
+    DQ_STAMP_WG(DQ_TAG_CONV_BWD, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1881,6 +1889,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         if (ahead_on) {
             dq_qnet::DropTag next = Q->last_drop;
             next.t += 1;
+            next.stream = (void*)st;                                  // (drawn by THIS launch: only a forward on the same stream is ordered behind it)
             ra.drop = {Q->keep_bits, next.seed0, next.seed1, next.sample_base, next.drop_T, next.t, next.batch, (next.batch * 16 + 511) / 512};
             Q->kb_tag = next;
         }

@@ -56,7 +56,8 @@ struct dq_qnet {
     // unit & 31 of word unit >> 5 of a sample's row), and the next training forward that asks for exactly that (kb_tag) loads them instead of
     // running eight Philox calls per lane in its 64 training workgroups -- the workgroups that set the dense forward's duration.  Any other
     // request draws in the kernel as before: the same bits either way (fused.hip draw_keep_bits, fused_bwd.hip dropout_ahead).
-    struct DropTag { u32 seed0, seed1, sample_base, drop_T; u64 t; int batch, valid; };
+    struct DropTag { u32 seed0, seed1, sample_base, drop_T; u64 t; int batch, valid; void* stream; };     // stream: the one the bits were drawn on -- a forward on
+                                 // another stream is not ordered behind the drawing launch and draws in its own kernel
     u32* keep_bits;
     DropTag kb_tag;              // what keep_bits holds (valid = 1)
     DropTag last_drop;           // the last fused training forward's dropout draw (valid = 0: none)

@@ -408,8 +408,11 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         memset(tab + 96, 0, sizeof(int) * (CONV_FWD_TABS + 5) * CONV_ROWTAB);
         if (fused_forward_supported(Q)) (void)fused_conv_row_tables(Q, tab + 96);
         if (fused_backward_supported(Q)) (void)fused_conv_bwd_row_tables(Q, tab + 96 + CONV_FWD_TABS * CONV_ROWTAB);
-        e = hipMalloc(&Q->kofftab, sizeof(tab));
+        // (+ PT_TOTAL: the patch-word tables of dq_qnet_set_patch_input live behind them in the SAME allocation -- as an allocation of their own their
+        // first touch cost every conv workgroup a translation miss of its own: +3K cycles in the conv backward's prologue)
+        e = hipMalloc(&Q->kofftab, sizeof(tab) + PT_TOTAL * sizeof(int));
         if (e == hipSuccess) e = hipMemcpy(Q->kofftab, tab, sizeof(tab), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(Q->kofftab + sizeof(tab) / sizeof(int), 0, PT_TOTAL * sizeof(int));
     }
     if (e == hipSuccess && fused_forward_supported(Q))
         for (int i = 0; i < FWD_MAX_JOBS && e == hipSuccess; ++i) e = hipMalloc(&Q->pk_scratch[i], fused_packed_u32x4(Q) * 16);
@@ -441,7 +444,6 @@ void dq_qnet_destroy(dq_qnet* Q) {
     if (Q->fpartial) (void)hipFree(Q->fpartial);
     if (Q->planes) (void)hipFree(Q->planes);
     if (Q->kofftab) (void)hipFree(Q->kofftab);
-    if (Q->ptab) (void)hipFree(Q->ptab);
     for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->pk_scratch[i]) (void)hipFree(Q->pk_scratch[i]);
     for (int i = 0; i < FWD_MAX_JOBS; ++i) if (Q->xinf[i]) (void)hipFree(Q->xinf[i]);
     delete Q;
@@ -502,7 +504,7 @@ dq_status dq_qnet_set_patch_input(dq_qnet* Q, int n_syndrome_planes, int stride_
                "dq_qnet_set_patch_input: stride_words must be a power of two in [max(4, d * d), 64]");
     int tab[PT_TOTAL];
     fused_patch_tables(Q, n_syndrome_planes, stride_words, tab);
-    if (!Q->ptab) DQ_HIP(hipMalloc(&Q->ptab, sizeof(tab)));
+    Q->ptab = Q->kofftab + 96 + (CONV_FWD_TABS + 5) * CONV_ROWTAB;  // (behind the row tables, same allocation: dq_qnet_create)
     DQ_HIP(hipMemcpy(Q->ptab, tab, sizeof(tab), hipMemcpyHostToDevice));
     Q->patch_depth = n_syndrome_planes; Q->patch_kd = 4 * n_syndrome_planes + (Q->L[0].cin - n_syndrome_planes); Q->patch_stride = stride_words;
     return DQ_OK;

@@ -119,6 +119,82 @@ def test_device_loop_matches_oracle_loop(dq, torch_mod, name, C1, N, B, steps):
             p_t = p.copy()
 
 
+def test_device_loop_with_three_updates_per_vector_step(dq, torch_mod):
+    """updates_per_vector_step = 3 (the knob that restores the reference's replay ratio: one minibatch per ENVIRONMENT step in keras-rl,
+    TRAIN:119-127, is N minibatches per vector step of N lattices): per vector step one acting step and three double-DQN updates on the
+    same ring state, update numbers u, u + 1, u + 2 -- against the same sequence assembled from the oracles."""
+    torch = torch_mod
+    from oracle import memory_oracle as M
+    cfg, N, B, steps, k = C3, 48, 32, 9, 3
+    eps, gamma, lr = 0.3, 0.99, 1e-3
+    seed = (0x5EED, 0xD0DEC0DE)
+    env = dq.VectorEnv(n_envs=N, seed=seed, **cfg)
+    net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=max(N, B))
+    core = dq.DQNCore(env, net, batch_size=B, memory_limit=N * 8, gamma=gamma, lr=lr, seed=seed)
+    spec = O.QNetSpec(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions)
+    p = core.params.cpu().numpy().astype(np.float64)
+    p_t = p.copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    ref = c_oracle.COracleEnv(n_envs=N, seed=seed, **cfg)
+    T = core.T
+    ring_obs = np.zeros((T, N) + env.obs_shape, np.uint8)
+    ring_a, ring_r, ring_t = np.zeros((T, N), np.int32), np.zeros((T, N), np.float32), np.zeros((T, N), np.uint8)
+    core.reset_env()
+    ref.reset()
+    cur, filled, u = 0, 1, 0
+    ring_obs[0] = ref.obs
+    for t in range(steps):
+        will_update = min(T, filled + 1) >= 4
+        # the parameters the acting forward sees: those before this step's updates
+        q, _ = O.forward(spec, p, ring_obs[cur])
+        if will_update and t % 2 == 0:
+            core.step_and_update(eps, extra_updates=k - 1)
+            seq = None                                               # (all three updates already ran)
+        else:
+            core.act_and_step(eps, presample=will_update)
+            seq = k if will_update else 0
+        acts = np.zeros(N, np.int32)
+        for i in range(N):
+            w = philox.philox4x32((t, 0, i, philox.STREAM_POLICY << 16), seed)
+            acts[i] = O.select_action(q[i], int(ref.legal[i, 0]) | (int(ref.legal[i, 1]) << 64), eps, False, w)
+        assert np.array_equal(core.action_ring[cur].cpu().numpy(), acts), ("actions", t)
+        ref.step(acts, auto_reset=True)
+        nxt = (cur + 1) % T
+        ring_a[cur], ring_r[cur], ring_t[cur], ring_obs[nxt] = acts, ref.reward, ref.done, ref.obs
+        assert np.array_equal(core.obs_ring[nxt].cpu().numpy(), ref.obs), ("obs", t)
+        cur, filled = nxt, min(T, filled + 1)
+        if not will_update:
+            continue
+        rows = T * N
+        flat_obs = ring_obs.reshape(rows, *env.obs_shape)
+        for j in range(k):
+            if seq:
+                core.update()
+            u += 1
+            idx = M.device_replay_rows(ring_t, N, T, cur, filled, B, seed, u)
+            s0, s1 = flat_obs[idx], flat_obs[(idx + N) % rows]
+            y = O.td_targets(O.forward(spec, p, s1)[0], O.forward(spec, p_t, s1)[0], ring_r.reshape(-1)[idx], ring_t.reshape(-1)[idx], gamma)
+            keep = O.dropout_keep_mask(seed, u, np.arange(B), 512, 0.2)
+            q0, cache = O.forward(spec, p, s0, training=True, keep_masks=[keep])
+            loss, mean_q, dq_ = O.loss_and_grad(q0, ring_a.reshape(-1)[idx], y)
+            g = O.backward(spec, p, cache, dq_)
+            p, m, v = O.adam_step(p, g, m, v, u, lr)
+            if seq:                                                  # update by update: glue the oracle to the device's fp32 state
+                assert np.array_equal(core.index.cpu().numpy(), idx)
+                met = np.array(core.read_metrics())
+                assert abs(met[0] - loss) < 1e-5 and abs(met[1] - mean_q) < 1e-5
+                p = core.params.cpu().numpy().astype(np.float64)
+                m, v = core.m.cpu().numpy().astype(np.float64), core.v.cpu().numpy().astype(np.float64)
+        assert core.updates == u
+        assert np.array_equal(core.index.cpu().numpy(), idx)        # the last update's rows
+        met = np.array(core.read_metrics())
+        assert abs(met[0] - loss) < 2e-5 and abs(met[1] - mean_q) < 2e-5, (met, loss, mean_q)
+        big = np.abs(g) > 1e-6
+        assert np.abs(core.params.cpu().numpy() - p)[big].max() < 2e-5     # three updates' round-off (Adam)
+        p = core.params.cpu().numpy().astype(np.float64)
+        m, v = core.m.cpu().numpy().astype(np.float64), core.v.cpu().numpy().astype(np.float64)
+
+
 class _PyVecEnv:
     """N independent oracle lattices (oracle/env_oracle.py, any d) behind the batched C-oracle's interface: the CPU side of the d >= 9 loop."""
 

@@ -14,6 +14,15 @@ params = net.init_params((11, 22))
 rng = np.random.RandomState(5)
 obs = torch.from_numpy((rng.rand(batch, *shape) < 0.3).astype(np.uint8)).cuda()
 dqt = torch.from_numpy((rng.randn(batch, A) / batch).astype(np.float32)).cuda()
+PATCH = bool(os.environ.get("DQ_STAMP_PATCH"))        # the observations as patch words (include/deepq_hip.h dq_env_patch_output)
+jkw = {}
+if PATCH:
+    E = importlib.import_module("deepq-decoding_amd.env")
+    net.set_patch_input(5, 32)
+    obs = E.obs_to_patch(E.patch_to_obs(torch.from_numpy(rng.randint(0, 1 << 22, size=(batch, 32)).astype(np.int32)), 5, 5, 2), 5, 5, 2).cuda().contiguous()
+    jkw = dict(patch=True)
+    _fwd = net.forward
+    net.forward = lambda p, o, **kw: net.forward_multi([dict(params=p, obs=o, **jkw, **kw)])[0]
 for _ in range(5):
     net.forward(params, obs, training=True, seed=(1, 2), t=3)
     net.backward(params, dqt)
@@ -22,8 +31,8 @@ if os.environ.get("DQ_STAMP_INFER"):                  # the LAST forward launch 
 if os.environ.get("DQ_STAMP_LOOP"):                   # the LAST forward launch pair has the vector step's shape: 3 inference jobs + the training job
     pk = net.pack(params)
     for _ in range(3):
-        net.forward_multi([dict(params=params, obs=obs, packed=pk), dict(params=params, obs=obs, packed=pk),
-                           dict(params=params, obs=obs, training=True, seed=(1, 2), t=3, packed=pk), dict(params=params, obs=obs, packed=pk)])
+        net.forward_multi([dict(params=params, obs=obs, packed=pk, **jkw), dict(params=params, obs=obs, packed=pk, **jkw),
+                           dict(params=params, obs=obs, training=True, seed=(1, 2), t=3, packed=pk, **jkw), dict(params=params, obs=obs, packed=pk, **jkw)])
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()
 getattr(dq.lib(), 'dq_dbg_read_fwd' if tag % 10 in (1, 2) and tag != 21 else 'dq_dbg_read_bwd')(buf)
@@ -78,6 +87,10 @@ elif tag == 4:
         print("wave", w, "group 1:", [t[i + 1] - t[i] for i in range(11)], " group 2:", [t2[i + 1] - t2[i] for i in range(11)],
               " wait part of stage:", buf[11 * 8 + w] - t[0], buf[23 * 8 + w] - t2[0])
     print(names)
+    for w in range(8):
+        print("wave", w, "kernel start -> first group", buf[0 * 8 + w] - buf[25 * 8 + w], "; last group's end -> kernel end", buf[26 * 8 + w] - buf[24 * 8 + w],
+              "; whole kernel", buf[26 * 8 + w] - buf[25 * 8 + w], "cycles; prologue: tables", buf[27 * 8 + w] - buf[25 * 8 + w], "constants", buf[28 * 8 + w] - buf[27 * 8 + w],
+              "first copies issued", buf[29 * 8 + w] - buf[28 * 8 + w], "to the loop", buf[0 * 8 + w] - buf[29 * 8 + w])
 elif tag == 5:
     for w in range(4):
         t = [buf[i * 8 + w] for i in range(27)]
