@@ -66,7 +66,7 @@ class TdJob(ctypes.Structure):
                 ("index_dev", ctypes.c_void_p), ("gamma", ctypes.c_double), ("grad_scale", ctypes.c_double), ("batch", ctypes.c_int32),
                 ("n_actions", ctypes.c_int32), ("y_dev", ctypes.c_void_p), ("dq_dev", ctypes.c_void_p), ("metrics_dev", ctypes.c_void_p),
                 ("done_dev", ctypes.c_void_p), ("was_reset_dev", ctypes.c_void_p), ("lifetime_dev", ctypes.c_void_p),
-                ("step_reward_dev", ctypes.c_void_p), ("n", ctypes.c_int32), ("stats_dev", ctypes.c_void_p)]
+                ("step_reward_dev", ctypes.c_void_p), ("n", ctypes.c_int32), ("stats_dev", ctypes.c_void_p), ("auto_scale", ctypes.c_int32)]
 
 
 class EnvStepJob(ctypes.Structure):
@@ -139,6 +139,7 @@ SIGNATURES = {
     "dq_qnet_backward_phase": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "dq_qnet_conv_param_count": (_sz, [_vp]),
     "dq_qnet_backward_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
+    "dq_qnet_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
     "dq_qnet_td_backward_adam": (_i, [_vp, _vp, ctypes.POINTER(TdJob), _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
     "dq_qnet_td_backward_adam_env": (_i, [_vp, _vp, ctypes.POINTER(TdJob), _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _u64, _vp,
                                           ctypes.POINTER(EnvStepJob), _vp]),

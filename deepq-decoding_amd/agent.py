@@ -421,15 +421,21 @@ class DQNAgent:
         return self._net.forward(self._core.params, obs, batch=1)[0].cpu().numpy()
 
     # -- training ------------------------------------------------------------------------------------------------
+    # keras-rl's step arithmetic (DQNAgent.backward runs with self.step = s, the 0-based number of the step just taken, and Agent.fit increments it
+    # afterwards): the update of step s happens iff s > nb_steps_warmup (and s % train_interval == 0), the hard target copy iff
+    # s % target_model_update == 0, behind that step's update.  Pinned by the reference's own records: every `mean_eps` entry of
+    # trained_models/d5_x/0.001/training_history.json equals, to 3e-16, the mean of the annealed epsilon over the episode's steps s > 1000 --
+    # its first trained step is s = 1001 (tests/test_host_logic.py::test_reference_mean_eps_records_pin_the_step_arithmetic).  Here self.step is
+    # incremented by N per vector step BEFORE these checks, so the vector step just taken covers s in [self.step - N, self.step).
     def _will_train(self, step_after):
         """Whether _maybe_train() will update once self.step has become step_after (the ring then holds one more slot)."""
         core = self._core
-        return step_after > self.nb_steps_warmup and min(core.T, core.filled + 1) >= MIN_FILLED and (step_after // core.N) % self.train_interval == 0
+        return step_after - 1 > self.nb_steps_warmup and min(core.T, core.filled + 1) >= MIN_FILLED and ((step_after - 1) // core.N) % self.train_interval == 0
 
     def _maybe_train(self):
         core = self._core
         did = False
-        if self.step > self.nb_steps_warmup and core.filled >= MIN_FILLED and (self.step // core.N) % self.train_interval == 0:
+        if self.step - 1 > self.nb_steps_warmup and core.filled >= MIN_FILLED and ((self.step - 1) // core.N) % self.train_interval == 0:
             for _ in range(self.updates_per_vector_step):
                 core.update()
             did = True
@@ -437,7 +443,9 @@ class DQNAgent:
         return did
 
     def _sync_target(self):
-        if self.step - self._last_target_sync >= self.target_model_update:
+        """Hard target copy when one of the steps just taken, s in [self.step - N, self.step), is a multiple of target_model_update."""
+        tmu, lo = self.target_model_update, self.step - self._core.N
+        if -(-lo // tmu) * tmu < self.step and self.step > self._last_target_sync:
             self._core.update_target_hard()
             self._last_target_sync = self.step
 
@@ -495,7 +503,8 @@ class DQNAgent:
                     core.act_and_step(eps, masked_greedy=masked)
                     self.step += N
                     trained = self._maybe_train()
-                epss.append(eps)
+                if trained:                     # keras-rl: a step without an update contributes NaN to every metric, mean_eps included (nanmean per episode)
+                    epss.append(eps)
                 if loop_iter % sync_interval != 0:
                     continue
                 # ---- host sync: episode bookkeeping ---------------------------------------------------------------

@@ -145,6 +145,11 @@ class DQNCore:
         self._env_stream = torch.cuda.Stream(device=dev) if os.environ.get("DQ_ENV_STREAM", "0") == "1" else None
         # step_and_update on one GPU: the environment launch rides on the dense backward's first kernel (DQ_RIDE_ENV=0: separate launches)
         self.ride_env = os.environ.get("DQ_RIDE_ENV", "1") != "0"
+        # DQ_TD_AUTOSCALE=1 (or auto_scale = True): the fused backward's gradient scale MEASURED from every minibatch's TD errors (dq_td_job.auto_scale: one
+        # small launch per update, +3 us; any finite TD error is carried -- keras-rl's delta_clip = inf).  Default: the host-known scale (TD errors up to
+        # several thousand -- the reference's recorded losses stay below 160 --; a larger one makes the WHOLE update a no-op on every rank and
+        # read_metrics() raise DQ_ERR_RANGE at the next synchronisation: nothing is ever partially applied)
+        self.auto_scale = os.environ.get("DQ_TD_AUTOSCALE", "0") == "1"
         self.local_stats = [0, 0, 0, 0]
         self.inexact_total = 0
         self._inexact_acc = torch.zeros((), dtype=torch.int64, device=dev) if getattr(env, "wide", False) else None
@@ -305,7 +310,7 @@ class DQNCore:
         q_sel = self.q1_online if self.enable_double_dqn else self.q1_target
         return dict(q_online_s1=q_sel, q_target_s1=self.q1_target, q_s0=self.q0, reward=self.reward_ring, terminal=self.terminal_ring,
                     action=self.action_ring, gamma=self.gamma, grad_scale=_dist.grad_scale(self.batch_size, self.world_size),
-                    index=self.index, y=self.y, dq=self.dq, metrics=self.metrics, step_stats=step_stats)
+                    index=self.index, y=self.y, dq=self.dq, metrics=self.metrics, step_stats=step_stats, auto_scale=self.auto_scale)
 
     def local_gradient(self, index=None):
         """This rank's contribution to the NEXT update's gradient, without the all-reduce and without the optimizer step: minibatch
@@ -361,7 +366,7 @@ class DQNCore:
             if probe:
                 e1.record()
                 self.ar_events.append((e0, e1))
-            _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+            net.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)     # (skips AND flags non-finite elements: every rank alike)
         elif _dist.dist_path(self.world_size):
             # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs
             nconv = net.n_conv_params
@@ -383,7 +388,7 @@ class DQNCore:
             if probe:
                 e1.record()
                 self.ar_events.append((e0, e1))
-            _q.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
+            net.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)     # (skips AND flags non-finite elements: every rank alike)
         elif ride is not None:
             net.td_backward_adam_env(self.params, td, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon,
                                      self.env._h, ride)

@@ -149,29 +149,38 @@ __global__ __launch_bounds__(256) void td_metrics_kernel(float* __restrict__ met
     if (threadIdx.x == 0) { metrics[0] = s_loss[0] / (float)B; metrics[1] = s_q[0] / (float)B; }
 }
 
-// Keras 2.2 Adam.get_updates (common.h dq_adam1)
+// Keras 2.2 Adam.get_updates (common.h dq_adam1).  A non-finite gradient element (the fused backward's range guard, include/deepq_hip.h
+// dq_qnet_range_check; behind an all-reduce every rank sees the same ones) leaves its parameter and moments untouched and raises *flag
+// (nullable) -- the rule of the optimizer step that rides on the fused backward's final reduction, so that the several-GPU branch, where
+// the all-reduce comes between backward and update, behaves the same on EVERY rank.
+__device__ __forceinline__ void dq_adam1_guarded(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps, bool& bad) {
+    if (__builtin_isfinite(g)) dq_adam1(p, g, m, v, lr_t, b1, b2, eps);
+    else bad = true;
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, float lr_t, float b1, float b2, float eps) {
+                            size_t n, float lr_t, float b1, float b2, float eps, unsigned* __restrict__ flag) {
     const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    bool bad = false;
     if (i4 + 3 < n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                         reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
         float4 pp = *reinterpret_cast<float4*>(p + i4);
         const float4 gg = *reinterpret_cast<const float4*>(g + i4);
         float4 mm = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
-        dq_adam1(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps);
-        dq_adam1(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps);
-        dq_adam1(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps);
-        dq_adam1(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps);
+        dq_adam1_guarded(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, bad);
+        dq_adam1_guarded(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, bad);
+        dq_adam1_guarded(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, bad);
+        dq_adam1_guarded(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps, bad);
         *reinterpret_cast<float4*>(p + i4) = pp;
         *reinterpret_cast<float4*>(m + i4) = mm;
         *reinterpret_cast<float4*>(v + i4) = vv;
     } else {
         for (size_t i = i4; i < n && i < i4 + 4; ++i) {
             float pi = p[i], mi = m[i], vi = v[i];
-            dq_adam1(pi, g[i], mi, vi, lr_t, b1, b2, eps);
+            dq_adam1_guarded(pi, g[i], mi, vi, lr_t, b1, b2, eps, bad);
             p[i] = pi; m[i] = mi; v[i] = vi;
         }
     }
+    if (bad && flag) atomicOr(flag, 1u);
 }
 
 // stats[0] += #episodes that ended this step, stats[1] += sum of their lifetimes, stats[2] += #rewards == 1,
@@ -351,9 +360,26 @@ dq_status dq_adam_step(float* params_dev, const float* grads_dev, float* m_dev, 
     const double lr_t = lr * sqrt(1.0 - pow(beta_2, (double)t)) / (1.0 - pow(beta_1, (double)t));
     const size_t threads = (n + 3) / 4;
     adam_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(params_dev, grads_dev, m_dev, v_dev, n, (float)lr_t,
-                                                                                  (float)beta_1, (float)beta_2, (float)epsilon);
+                                                                                  (float)beta_1, (float)beta_2, (float)epsilon, nullptr);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }
+
+}  // extern "C"
+
+// dq_qnet_adam_step (qnet.hip): dq_adam_step whose skipped elements raise `flag_dev` (the Q-network handle's range flag)
+dq_status adam_step_flagged(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n, double lr, double beta_1, double beta_2,
+                            double epsilon, uint64_t t, unsigned* flag_dev, hipStream_t st) {
+    DQ_REQUIRE(params_dev && grads_dev && m_dev && v_dev, DQ_ERR_INVALID, "dq_qnet_adam_step: null argument");
+    DQ_REQUIRE(t >= 1, DQ_ERR_INVALID, "dq_qnet_adam_step: t counts from 1");
+    const double lr_t = lr * sqrt(1.0 - pow(beta_2, (double)t)) / (1.0 - pow(beta_1, (double)t));
+    const size_t threads = (n + 3) / 4;
+    adam_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(params_dev, grads_dev, m_dev, v_dev, n, (float)lr_t, (float)beta_1, (float)beta_2,
+                                                                    (float)epsilon, flag_dev);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+extern "C" {
 
 }  // extern "C"

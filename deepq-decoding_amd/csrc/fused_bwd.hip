@@ -71,6 +71,11 @@ struct DenseBwdArgs {
     int dense_tiles, col_split;         // dense_wgs = dense_tiles (row tiles of 16 samples) x col_split (1, 2 or 4: small minibatches, see the kernel)
     int env_on;                         // ... or, with a rider, the environment step (+ its replay sampling and bookkeeping): env_block<8>
     TdFused td;
+    // range guard, early half (TD launches): a sample whose S x dq leaves the range the chain carries safely (|S dq| >= 2^15: TD errors of several
+    // thousand with the host-known scale) stamps this backward's number into *skip_word; the final reduction then discards the WHOLE update -- every
+    // gradient element becomes NaN, no parameter moves, the range flag is raised -- instead of applying the elements that happened to stay finite
+    unsigned* skip_word;
+    unsigned skip_tag;
 };
 
 // ---- gradient scale ----------------------------------------------------------------------------------------------------
@@ -92,6 +97,62 @@ __global__ __launch_bounds__(1024) void grad_scale_kernel(const float* __restric
         float S = 1.f;
         if (m > 0.f && m < INFINITY) { (void)frexpf(m, &e); S = ldexpf(1.f, max(-100, min(100, 8 - e))); }      // m = f 2^e, f in [0.5, 1)
         out[0] = S; out[1] = 1.f / S;
+    }
+}
+
+// The same choice with the TD step fused in and dq_td_job.auto_scale set: max |TD error x grad_scale| of THIS minibatch, measured by a small launch in
+// front of the dense backward (one wave per sample: dq_td_update's arithmetic without its stores; block maxima by one atomic each; the last block to
+// arrive turns the maximum into {S, 1/S} with S * max in (32, 64] and clears the two work words).  The host-known scale (S * grad_scale in [4, 8)) carries
+// TD errors up to a few thousand; with the measured one the backward takes ANY finite TD error fp32 can hold, like the reference's TensorFlow
+// (keras-rl delta_clip = inf): what is left to the range guard is a product of weights beyond 2^10, not a large loss.
+struct TdScaleArgs { TdFused td; int B, A; float* out; unsigned* work; };     // work[0]: bits of the running maximum, work[1]: blocks arrived
+#define TDS_ROWS 4                      // samples per wave (their loads in flight together); 16 waves per block: 64 samples, two atomics per block
+__global__ __launch_bounds__(1024) void td_scale_kernel(TdScaleArgs a) {
+    __shared__ float sh[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b0 = (blockIdx.x * 16 + wave) * TDS_ROWS;
+    float q1[TDS_ROWS];
+    int rr[TDS_ROWS];
+#pragma unroll
+    for (int u = 0; u < TDS_ROWS; ++u) {                            // (A <= 64 * 2 on the fused chains: two entries per lane would be needed beyond 64 -- folded below)
+        const int b = min(b0 + u, a.B - 1);
+        q1[u] = lane < a.A ? a.td.q1o[(size_t)b * a.A + lane] : -INFINITY;
+        rr[u] = a.td.index ? a.td.index[b] : b;
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int u = 0; u < TDS_ROWS; ++u) {
+        const int b = min(b0 + u, a.B - 1);
+        float best = q1[u];
+        int best_a = lane < a.A ? lane : 0x7fffffff;
+        for (int c = lane + 64; c < a.A; c += 64) {                 // (more than 64 actions: the rest of the row)
+            const float v = a.td.q1o[(size_t)b * a.A + c];
+            if (best_a == 0x7fffffff || v > best) { best = v; best_a = c; }
+        }
+        dq_wave_argmax(best, best_a);
+        const int r = rr[u];
+        const float qn = a.td.q1t[(size_t)b * a.A + best_a];
+        const float y = a.td.reward[r] + (a.td.terminal[r] ? 0.f : a.td.gamma * qn);
+        float v = fabsf((a.td.q0[(size_t)b * a.A + a.td.action[r]] - y) * a.td.grad_scale);
+        if (!(v < INFINITY)) v = INFINITY;                          // (NaN: the guard's business)
+        mine = fmaxf(mine, v);
+    }
+    if (lane == 0) sh[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = sh[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, sh[w]);
+        atomicMax(&a.work[0], __builtin_bit_cast(unsigned, m));     // (non-negative floats order as their bit patterns)
+        __threadfence();
+        if (atomicAdd(&a.work[1], 1u) == gridDim.x - 1) {
+            __threadfence();
+            const float mx = __builtin_bit_cast(float, atomicMax(&a.work[0], 0u));
+            int e = 0;
+            float S = 1.f;
+            if (mx > 0.f && mx < INFINITY) { (void)frexpf(mx, &e); S = ldexpf(1.f, max(-100, min(100, 6 - e))); }      // mx = f 2^e, f in [0.5, 1)
+            a.out[0] = S; a.out[1] = 1.f / S;
+            a.work[0] = 0u; a.work[1] = 0u;
+        }
     }
 }
 
@@ -426,6 +487,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             const float diff = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ab < 64 ? qv[u][0] : qv[u][1]), ab & 63)) - yb[u];
             loss += 0.5f * diff * diff;
             mq += mx;
+            if (!(fabsf(diff * a.td.grad_scale * GS) < 32768.f) && lane == 0) atomicMax(a.skip_word, a.skip_tag);      // (never taken in a healthy run)
             if (a.td.dq_out)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -850,7 +912,8 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
 struct ReduceSeg { const float* partial; float* out; int n, slices; size_t stride; int block0; int pidx0; int vec; };   // pidx0: flat index of out[0]; vec: see the kernel
 // the hidden layer's dropout keep bits of the NEXT training forward, drawn by the first `wgs` workgroups of this launch (qnet.h keep_bits)
 struct DropAhead { u32* bits; u32 seed0, seed1, sample_base, drop_T; u64 t; int batch, wgs; };
-struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; float inv_gs; const float* gs_dev; unsigned* range_flag; DropAhead drop; };     // partials carry the gradient scale: x 1/S
+struct ReduceArgs { ReduceSeg seg[2]; AdamOpt opt; int adam; float inv_gs; const float* gs_dev; unsigned* range_flag; DropAhead drop;
+                    const unsigned* skip_word; unsigned skip_tag; };     // partials carry the gradient scale: x 1/S; skip: DenseBwdArgs.skip_word
 
 // Thread g of the drawing workgroups: word g & 15 of sample g >> 4 = the 32 units 32 (g & 15) .. + 31 = four Philox calls of eight 16-bit draws --
 // fused.hip dense_chain_kernel's draw (unit n: half-word n & 7 of call n >> 3, kept iff >= drop_T), the same bits.
@@ -870,6 +933,8 @@ __device__ __forceinline__ void dropout_ahead(const DropAhead& d, int g) {
 
 // one output's optimizer step and range guard
 __device__ __forceinline__ void reduce_finish(const ReduceArgs& a, const ReduceSeg& S, int i, float gsum) {
+    // (the dense backward's TD step found a sample beyond the safe range: the whole update is discarded, on every rank once the NaNs are all-reduced)
+    if (a.skip_word && __builtin_nontemporal_load(a.skip_word) == a.skip_tag) gsum = __builtin_nanf("");
     S.out[i] = gsum;
     // range guard (dq_qnet_range_check): an S x gradient beyond the f16 pieces' range arrives here as inf / NaN -- reported, never applied
     const bool finite = fabsf(gsum) < INFINITY;
@@ -884,7 +949,8 @@ __device__ __forceinline__ void reduce_finish(const ReduceArgs& a, const ReduceS
 
 // four consecutive outputs (i a multiple of 4, pidx0 too, 16-byte-aligned buffers): gradient, parameters and moments as 16-byte accesses
 __device__ __forceinline__ void reduce_finish4(const ReduceArgs& a, const ReduceSeg& S, int i, const f32x4& g4) {
-    if (i + 3 < S.n) {
+    const bool skip = a.skip_word && __builtin_nontemporal_load(a.skip_word) == a.skip_tag;      // (the update is being discarded: the scalar form writes the NaNs)
+    if (i + 3 < S.n && !skip) {
         *reinterpret_cast<f32x4*>(S.out + i) = g4;
         bool finite = true;
 #pragma unroll
@@ -1683,7 +1749,7 @@ static inline size_t dense_pstride(const dq_qnet* Q) { return (Q->n_params + 31)
 // floats of workspace the fused backward needs: [DENSE_WGRAD_SLICES][n_params] dense partials, then [CONV_BWD_MAX_WGS][conv params]
 size_t fused_backward_workspace_floats(const dq_qnet* Q) {
     if (!fused_backward_supported(Q)) return 0;
-    return (size_t)DENSE_WGRAD_SLICES * dense_pstride(Q) + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + 4;     // + {S, 1/S}: GradScale, + the range flag
+    return (size_t)DENSE_WGRAD_SLICES * dense_pstride(Q) + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off + 8;     // + {S, 1/S}: GradScale, the range flag, a spare word, td_scale_kernel's two work words, two spare
 }
 
 // the range guard's flag word (include/deepq_hip.h dq_qnet_range_check): the third of the four words behind the partials
@@ -1733,7 +1799,13 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     if (phases & 1) {
     // ---- gradient scale (see grad_scale_kernel): host-known with the TD step fused in, else from max |dq| on the device ----------
     const float known = td ? td->grad_scale : Q->grad_scale_hint;  // the loss scale dq carries, when the host knows it
-    if (td || known > 0.f) {
+    if (td && td->auto_scale) {                                     // measured on the device from this minibatch's TD errors (td_scale_kernel)
+        Q->bwd_scale = 0.f;                                         // = read gs_slot
+        TdScaleArgs ta;
+        ta.td = *td; ta.B = B; ta.A = Q->cfg.n_actions; ta.out = gs_slot; ta.work = reinterpret_cast<unsigned*>(gs_slot) + 4;
+        td_scale_kernel<<<(B + 16 * TDS_ROWS - 1) / (16 * TDS_ROWS), 1024, 0, st>>>(ta);
+        DQ_LAUNCH_CHECK();
+    } else if (td || known > 0.f) {
         int e = 0;
         (void)frexp((double)known, &e);                             // grad_scale = f 2^e, f in [0.5, 1)
         Q->bwd_scale = known > 0.f ? (float)ldexp(1.0, 3 - e) : 1.f;
@@ -1771,6 +1843,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         if (forced == 1 || forced == 2 || forced == 4) da.col_split = forced;
     }
     da.dense_wgs = da.dense_tiles * da.col_split;
+    da.skip_word = reinterpret_cast<unsigned*>(gs_slot) + 3; da.skip_tag = ++Q->bwd_serial ? Q->bwd_serial : ++Q->bwd_serial;      // (never 0: the word's idle value)
     int stat_wgs = 0;
     if (td) {
         da.td_on = 1; da.td = *td;
@@ -1829,7 +1902,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         ReduceArgs ra;
         memset(&ra, 0, sizeof(ra));
         ra.inv_gs = Q->bwd_scale > 0.f ? 1.f / Q->bwd_scale : 0.f; ra.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
-        ra.range_flag = reinterpret_cast<unsigned*>(gs_slot) + 2;
+        ra.range_flag = reinterpret_cast<unsigned*>(gs_slot) + 2; ra.skip_word = reinterpret_cast<unsigned*>(gs_slot) + 3; ra.skip_tag = Q->bwd_serial;
         ra.seg[0] = {dense_partial + conv_floats, grads_dev + conv_floats, n_dense, sy, dense_pstride(Q), 0, (int)conv_floats};
         ra.seg[0].vec = sy <= 16 && (conv_floats & 3) == 0 && (reinterpret_cast<uintptr_t>(grads_dev) & 15) == 0;      // (the vector path: same bits, see the kernel)
         ra.seg[1] = ra.seg[0]; ra.seg[1].block0 = 0x7fffffff;
@@ -1878,7 +1951,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.inv_gs = Q->bwd_scale > 0.f ? 1.f / Q->bwd_scale : 0.f; ra.gs_dev = Q->bwd_scale > 0.f ? nullptr : gs_slot;
-    ra.range_flag = reinterpret_cast<unsigned*>(gs_slot) + 2;
+    ra.range_flag = reinterpret_cast<unsigned*>(gs_slot) + 2; ra.skip_word = reinterpret_cast<unsigned*>(gs_slot) + 3; ra.skip_tag = Q->bwd_serial;
     if (opt) { ra.opt = *opt; ra.adam = 1; }
     ra.seg[0] = {conv_partial, grads_dev, (int)conv_floats, wgs, conv_floats, 0, 0};
     const int blocks0 = ((int)conv_floats + 63) / 64;

@@ -70,6 +70,7 @@ struct dq_qnet {
     int patch_stride;            // words per observation row
     int* ptab;                   // device tables (PT_*)
     int last_patch;              // the last training forward read patch words (the backward takes the same form)
+    unsigned bwd_serial;         // fused backwards' dense phases launched so far: the tag of the range guard's early half (fused_bwd.hip skip_word)
 };
 
 
@@ -246,6 +247,9 @@ size_t fused_packed_w1t_u32x4(const dq_qnet* Q);           // u32x4 offset of th
 size_t fused_packed_w2t_u32x4(const dq_qnet* Q);           // ... of W2T
 dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* packed_dev, hipStream_t st);
 
+// dqn.hip: dq_adam_step whose skipped (non-finite) gradient elements raise *flag_dev (dq_qnet_adam_step)
+dq_status adam_step_flagged(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n, double lr, double beta_1, double beta_2,
+                            double epsilon, uint64_t t, unsigned* flag_dev, hipStream_t st);
 // fused.hip: LDS-resident forward (conv chain + dense chain); returns false when the configuration is not covered
 bool fused_forward_supported(const dq_qnet* Q);
 bool fused_conv_row_tables(const dq_qnet* Q, int* tab);      // tab: int[CONV_FWD_TABS * CONV_ROWTAB]
@@ -276,6 +280,7 @@ struct TdFused {
     const float* st_reward;
     int st_n;
     unsigned long long* st_stats;
+    int auto_scale;                     // dq_td_job.auto_scale: the gradient scale from this minibatch's max |TD error| (fused_bwd.hip td_scale_kernel)
 };
 // rider != NULL (needs td): the lattices' environment step (env_dev.h parameters, filled by env_fill_act_step) runs as extra
 // workgroups of the dense backward's first launch

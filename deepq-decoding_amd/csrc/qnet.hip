@@ -427,7 +427,7 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
     const size_t fws = fused_backward_workspace_floats(Q);
     if (e == hipSuccess && fused_forward_supported(Q)) e = hipMalloc(&Q->keep_bits, (size_t)Q->cfg.max_batch * 16 * sizeof(u32));
     if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));
-    if (e == hipSuccess && fws) e = hipMemset(Q->fpartial + fws - 4, 0, 4 * sizeof(float));       // {S, 1/S}, range flag
+    if (e == hipSuccess && fws) e = hipMemset(Q->fpartial + fws - 8, 0, 8 * sizeof(float));       // {S, 1/S}, range flag, spare; td_scale_kernel's work words, spare
     Q->partial_floats = max_partial;
     if (e != hipSuccess) { dq_set_error("dq_qnet_create: %s", hipGetErrorString(e)); dq_qnet_destroy(Q); return DQ_ERR_HIP; }
     *out = Q;
@@ -665,6 +665,7 @@ static TdFused td_fused_from(const dq_td_job* tdj) {
     td.metric_slots = (tdj->batch + 3) / 4 < 1024 ? (tdj->batch + 3) / 4 : 1024;      // what dq_td_metrics(batch) reads
     td.st_done = tdj->done_dev; td.st_was_reset = tdj->was_reset_dev; td.st_lifetime = tdj->lifetime_dev;
     td.st_reward = tdj->step_reward_dev; td.st_n = tdj->n; td.st_stats = reinterpret_cast<unsigned long long*>(tdj->stats_dev);
+    td.auto_scale = tdj->auto_scale ? 1 : 0;
     return td;
 }
 
@@ -774,6 +775,12 @@ dq_status dq_qnet_td_backward_adam_env(dq_qnet* Q, float* params_dev, const dq_t
     const dq_status rc = fill_rider(Q, td, env, sj, &ep, &lds);
     if (rc != DQ_OK) return rc;
     return backward_adam(Q, params_dev, nullptr, td, grads_dev, m_dev, v_dev, lr, beta_1, beta_2, epsilon, t, stream, &ep, lds);
+}
+
+dq_status dq_qnet_adam_step(dq_qnet* Q, float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, double lr, double beta_1, double beta_2,
+                            double epsilon, uint64_t t, void* stream) {
+    DQ_REQUIRE(Q, DQ_ERR_INVALID, "dq_qnet_adam_step: null handle");
+    return adam_step_flagged(params_dev, grads_dev, m_dev, v_dev, Q->n_params, lr, beta_1, beta_2, epsilon, t, fused_range_flag(Q), (hipStream_t)stream);
 }
 
 dq_status dq_qnet_td_backward_adam(dq_qnet* Q, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev, double lr,

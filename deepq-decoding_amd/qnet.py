@@ -228,6 +228,7 @@ def _td_job(td):
     j.reward_dev, j.terminal_dev, j.action_dev, j.index_dev = ptr(td["reward"]), ptr(td["terminal"]), ptr(td["action"]), ptr(td.get("index"))
     j.gamma, j.grad_scale, j.batch, j.n_actions = float(td["gamma"]), float(td.get("grad_scale") or 1.0 / B), B, A
     j.y_dev, j.dq_dev, j.metrics_dev = ptr(td.get("y")), ptr(td.get("dq")), ptr(td.get("metrics"))
+    j.auto_scale = int(bool(td.get("auto_scale", False)))
     st = td.get("step_stats")
     if st is not None:
         done, was_reset, lifetime, step_reward, n, stats = st
@@ -283,6 +284,16 @@ def _td_backward_phase0_env(self, params, td, grads, env_handle, step):
 
 QNetwork.td_backward_phase0_env = _td_backward_phase0_env
 QNetwork.td_backward_adam_env = _td_backward_adam_env
+
+
+def _net_adam_step(self, params, grads, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    """adam_step() whose skipped (non-finite) gradient elements raise this network's range flag (dq_qnet_adam_step): the several-GPU
+    branch's optimizer step behind the gradient all-reduce."""
+    check(self.L.dq_qnet_adam_step(self._h, ptr(params), ptr(grads), ptr(m), ptr(v), float(lr), float(beta_1), float(beta_2), float(epsilon),
+                                   int(t), self._stream()))
+
+
+QNetwork.adam_step = _net_adam_step
 
 
 def _td_backward_phase0(self, params, td, grads):

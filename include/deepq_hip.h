@@ -419,6 +419,13 @@ dq_status dq_test_bookkeeping(const uint8_t* done_dev, const uint8_t* was_reset_
                               int step, int32_t* quota_dev, float* ep_reward_dev, int32_t* ep_len_dev, int32_t* records_dev, int capacity,
                               int32_t* counter_dev, void* stream);
 
+/* dq_adam_step on the network's whole parameter vector, for the several-GPU branch (backward with m_dev == v_dev == NULL, all-reduce of
+ * grads_dev, then this): an element whose all-reduced gradient is not finite -- the fused backward's range guard, on whichever rank it
+ * tripped: the sum carries it to all of them -- is skipped AND raises this handle's range flag, so that dq_qnet_range_check reports
+ * DQ_ERR_RANGE on every rank at the same synchronisation point and the replicas stay identical.  No reference counterpart. */
+dq_status dq_qnet_adam_step(dq_qnet* net, float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, double lr, double beta_1,
+                            double beta_2, double epsilon, uint64_t t, void* stream);
+
 /* The learner half of one DQNAgent.backward in the fewest launches: dq_td_update (+ dq_episode_stats when n > 0) computed in the
  * dense backward's first kernel, then dq_qnet_backward, then dq_adam_step on the final reduction.  Same y / dq / gradient / parameter
  * bits as the separate calls; the loss / mean_q partials are summed in a different order (dq_td_metrics reads them the same way).
@@ -445,6 +452,10 @@ typedef struct dq_td_job {
     const float* step_reward_dev;
     int n;
     uint64_t* stats_dev;
+    int auto_scale;                 /* fused backward only.  0: its gradients are carried at the power-of-two scale that follows from grad_scale (TD errors up to
+                                     * a few thousand; beyond: dq_qnet_range_check).  1: the scale is MEASURED -- max |TD error x grad_scale| of this minibatch, by one
+                                     * small launch in front of the backward -- so that any finite TD error fp32 can hold is carried, as in the reference's
+                                     * TensorFlow arithmetic (keras-rl delta_clip = inf, Single_Point_Training_Script.py:119-127) */
 } dq_td_job;
 dq_status dq_qnet_td_backward_adam(dq_qnet* net, float* params_dev, const dq_td_job* td, float* grads_dev, float* m_dev, float* v_dev,
                                    double lr, double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
@@ -549,6 +560,7 @@ dq_status dq_episode_stats(const uint8_t* done_dev, const uint8_t* was_reset_dev
 
 /* keras.optimizers.Adam (Keras 2.2): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMAs; p -= lr_t*m/(sqrt(v)+epsilon).
  * t = 1 for the first update. */
+/* (A non-finite gradient element leaves its parameter and moments untouched -- as the optimizer step riding on the fused backward does.) */
 dq_status dq_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n, double lr,
                        double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
 

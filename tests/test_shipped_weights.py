@@ -192,7 +192,8 @@ def test_backward_parity_on_shipped_weights(dq, torch_mod, family, p, shape, A):
 
 @pytest.mark.gpu
 def test_td_errors_beyond_the_fused_range_raise_range_error(dq, torch_mod):
-    """The fused backward carries S x gradient in f16 pieces (S x grad_scale in [4, 8)): a TD error of 1e4 does not fit.  It must not
+    """With the gradient scale measured per minibatch (dq_td_job.auto_scale) the fused backward carries TD errors of 1e-3 .. 1e6 like fp32 does.
+    With the host-known scale it carries S x gradient in f16 pieces (S x grad_scale in [4, 8)): a TD error of 1e4 does not fit.  It must not
     silently give inf: dq_qnet_range_check reports DQ_ERR_RANGE, the non-finite elements are not applied by the riding Adam step (the
     parameters stay finite), and the flag clears.  A TD error of 1000 is inside the range and matches the oracle; the per-layer f32 path
     takes 1e4 (and 1e6) without complaint."""
@@ -215,7 +216,7 @@ def test_td_errors_beyond_the_fused_range_raise_range_error(dq, torch_mod):
     q0_ref, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
     fragile = O.fragile_samples(cache, rel=1e-6)
 
-    def run(td_size, fused):
+    def run(td_size, fused, auto_scale=False):
         """One td_backward_adam with Q_target(s1) = -td_size / gamma everywhere, i.e. a TD error of Q(s0)[a] + td_size."""
         net.set_fused(fused)
         p_, m_, v_, g_ = params.clone(), torch.zeros_like(params), torch.zeros_like(params), torch.empty_like(params)
@@ -223,9 +224,27 @@ def test_td_errors_beyond_the_fused_range_raise_range_error(dq, torch_mod):
         q0 = net.forward(p_, obs_t, training=True, seed=seed, t=t)
         met = torch.zeros(Q.TD_METRICS_FLOATS, dtype=torch.float32, device="cuda")
         td = dict(q_online_s1=q1, q_target_s1=q1, q_s0=q0, reward=reward, terminal=terminal, action=action, gamma=0.99, grad_scale=1.0 / B,
-                  index=idx, y=torch.empty(B, device="cuda"), dq=torch.empty((B, A), device="cuda"), metrics=met)
+                  index=idx, y=torch.empty(B, device="cuda"), dq=torch.empty((B, A), device="cuda"), metrics=met, auto_scale=auto_scale)
         net.td_backward_adam(p_, td, g_, m_, v_, 1, 1e-4)
         return p_, g_, td["dq"]
+
+    # The gradient scale MEASURED from the minibatch (dq_td_job.auto_scale, what DQNCore uses): every TD magnitude is carried -- no exception, gradients
+    # equal to the oracle's at 1e-5 of the largest element, like fp32 arithmetic (keras-rl delta_clip = inf)
+    for td_size in (1e-3, 1.0, 1000.0, 1e4, 1e6):
+        p_, g_, dq_ = run(td_size, True, auto_scale=True)
+        net.check_range()
+        dq_np = dq_.cpu().numpy().astype(np.float64)
+        dq_np[fragile] = 0.0
+        g_ref = O.backward(spec, flat, cache, dq_np)
+        assert torch.isfinite(g_).all() and torch.isfinite(p_).all() and not torch.equal(p_, params)
+        if not fragile.any():
+            err = np.abs(g_.cpu().numpy() - g_ref).max()
+            print(f"TD error ~{td_size:g}, measured scale: max |g| {np.abs(g_ref).max():.3e}, max abs error {err:.2e}")
+            assert err < 1e-5 * np.abs(g_ref).max()
+            for (gk, gb), (rk, rb) in zip(spec.split(g_.cpu().numpy()), spec.split(g_ref)):
+                for a_, b_ in ((gk, rk), (gb, rb)):
+                    assert np.abs(a_ - b_).max() <= 1e-4 * np.abs(b_).max() + 1e-7 * np.abs(g_ref).max()
+    # ... and with the HOST-KNOWN scale (auto_scale = 0, S x grad_scale in [4, 8)):
 
     # inside the range: handled, equal to the oracle
     p_, g_, dq_ = run(1000.0, True)
@@ -243,7 +262,8 @@ def test_td_errors_beyond_the_fused_range_raise_range_error(dq, torch_mod):
         with pytest.raises(dq.DeepQError) as ei:
             net.check_range()
         assert ei.value.status == L.DQ_ERR_RANGE
-        assert not torch.isfinite(g_).all() and torch.isfinite(p_).all()
+        assert not torch.isfinite(g_).any()             # the WHOLE update is discarded (the TD step sees the sample before any gradient is formed) ...
+        assert torch.equal(p_, params)                  # ... and no parameter has moved: nothing is ever partially applied
         net.check_range()
     # the f32 path has fp32's range
     p_, g_, _ = run(1e6, False)

@@ -45,7 +45,48 @@ def build(family, p):
     return out
 
 
+# The two agents the reference trained FROM SCRATCH (max_eps = 1, first error rate of their family): their training_history.json is the reference's
+# own record of a whole DQNAgent.fit run -- per episode: loss, mean_q, mean_eps (nan-means over the episode's trained steps), episode_reward,
+# nb_episode_steps, nb_steps (cumulative), episode_lifetimes_rolling_avg (over rolling_average_length = 1000 episodes) -- together with the
+# hyper-parameters that produced it (fixed_config.p, variable_config_N.p) and the lifetimes it tested at (all_results.p).  Committed as arrays
+# (float32 where the values allow; nb_steps exact) for tests/test_host_logic.py (step arithmetic) and tools/replay_reference_training.py.
+HISTORIES = [("d5_x", "0.001"), ("d5_dp", "0.001")]
+
+
+def history_fixture_name(family, p):
+    return f"training_history_{family}_{p}"
+
+
+def build_history(family, p):
+    import json
+    d = os.path.join(REF, family, p)
+    h = json.load(open(os.path.join(d, "training_history.json")))
+    out = {}
+    for k in ("loss", "mean_q", "episode_reward", "episode_lifetimes_rolling_avg", "best_rolling_avg", "duration"):
+        out[k] = np.array(h[k], dtype=np.float32)
+    out["mean_eps"] = np.array(h["mean_eps"], dtype=np.float64)             # (checked to 1e-12 against the annealing formula)
+    for k in ("nb_episode_steps", "nb_steps", "best_episode", "time_since_best", "episode"):
+        out[k] = np.array(h[k], dtype=np.int64)
+    for k in ("has_succeeded", "stopped_improving"):
+        out[k] = np.array(h[k], dtype=np.bool_)
+    out["key_order"] = np.array(list(h))
+    fixed = pickle.load(open(os.path.join(REF, family, "fixed_config.p"), "rb"))
+    var = pickle.load(open(glob.glob(os.path.join(d, "variable_config_*.p"))[0], "rb"))
+    out["fixed_config_json"] = np.array(json.dumps(fixed, sort_keys=True))
+    out["variable_config_json"] = np.array(json.dumps(var, sort_keys=True))
+    out["variable_config_file"] = np.array(os.path.basename(glob.glob(os.path.join(d, "variable_config_*.p"))[0]))
+    res = pickle.load(open(os.path.join(d, "all_results.p"), "rb"))
+    keys = sorted(res, key=float)
+    out["ref_test_p"] = np.array([float(k) for k in keys])
+    out["ref_lifetime"] = np.array([float(res[k]) for k in keys])
+    return out
+
+
 def main():
+    for family, p in HISTORIES:
+        path = os.path.join(ROOT, "tests", "golden", history_fixture_name(family, p) + ".npz")
+        np.savez_compressed(path, **build_history(family, p))
+        print(path, os.path.getsize(path))
     for family, p in AGENTS:
         path = os.path.join(ROOT, "tests", "golden", fixture_name(family, p) + ".npz")
         np.savez_compressed(path, **build(family, p))
