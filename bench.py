@@ -279,7 +279,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if (world > 1 or force_dist) and hasattr(runner, "core") and os.environ.get("DQ_DIST_MODE", "single") == "single":
+    if (world > 1 or force_dist) and hasattr(runner, "core") and os.environ.get("DQ_DIST_MODE", "single") in ("single", "overlap"):
         runner.core.ensure_comm()       # the learner's own communicator: its rendezvous belongs to the set-up, also with --warmup 0
     for _ in range(args.warmup):
         runner.step(timed=False)
@@ -393,6 +393,8 @@ def allreduce_probe(torch, dist, core, backend, iters=20):
     out = {"backend": "rccl" if backend == "nccl" else backend,
            "per_step": ("one all-reduce of the whole flat gradient behind the backward, " + ("on the step's own stream through the learner's RCCL communicator"
                         if native else "through torch.distributed")) if mode == "single" else
+                       ("dense range on a second stream through the learner's RCCL communicator while the convolutional backward runs, convolutional range "
+                        "in-stream (DQ_DIST_MODE=overlap)") if mode == "overlap" and native else
                        "dense range asynchronous behind the convolutional backward, convolutional range on the critical path (DQ_DIST_MODE=split)",
            "in_stream_rccl": native}
     for name, buf in parts.items():

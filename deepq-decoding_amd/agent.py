@@ -290,6 +290,20 @@ def _jsonable(v):
 # ----------------------------------------------------------------------------------------------------------
 # the agent
 # ----------------------------------------------------------------------------------------------------------
+def stopping_flags(has_succeeded, stopped_improving, rolling, time_since_best, steps_done, success_threshold, stopping_patience, min_nb_steps):
+    """The fork's early-stopping flags after an episode (fit keywords of TRAIN:138-152; the fork itself is not in the tree).  Pinned by the
+    fourteen training_history.json files the reference ships (tests/golden/training_history_tails.npz, tests/test_host_logic.py): `stopped_improving`
+    turns True at the first episode whose time_since_best EXCEEDS stopping_patience (1001 with patience 1000) once min_nb_steps steps have been
+    taken -- and that episode is the run's last; before min_nb_steps the counter runs far past the patience without effect (9426 in
+    d5_dp/0.001) and sets nothing.  `has_succeeded` (never True in any shipped record): rolling average >= success_threshold, as README.md:408-480
+    describes; the run ends once either flag is up and min_nb_steps have passed."""
+    if success_threshold is not None and rolling >= success_threshold:
+        has_succeeded = True
+    if stopping_patience is not None and time_since_best > stopping_patience and steps_done >= min_nb_steps:
+        stopped_improving = True
+    return has_succeeded, stopped_improving
+
+
 class DQNAgent:
     def __init__(self, model, nb_actions, memory, nb_steps_warmup=1000, target_model_update=10000, policy=None, test_policy=None,
                  gamma=.99, enable_dueling_network=False, enable_double_dqn=True, dueling_type='avg', batch_size=32,
@@ -534,10 +548,8 @@ class DQNAgent:
                 if rolling > best_avg:
                     best_avg, best_episode = rolling, episode - 1
                 time_since_best = episode - 1 - best_episode
-                if success_threshold is not None and rolling >= success_threshold:
-                    has_succeeded = True
-                if stopping_patience is not None and time_since_best >= stopping_patience:
-                    stopped_improving = True
+                has_succeeded, stopped_improving = stopping_flags(has_succeeded, stopped_improving, rolling, time_since_best, self.step - start_step,
+                                                                  success_threshold, stopping_patience, min_nb_steps)
                 # key order and value types of the reference's training_history.json (trained_models/*/*/training_history.json):
                 # the three metrics first, then the fork's episode log, then FileLogger's own 'episode' and 'duration'
                 logs = {

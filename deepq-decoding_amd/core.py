@@ -157,6 +157,7 @@ class DQNCore:
         self.ar_pool = []            # ... taken from this pool of pre-created pairs (creating two timing events per step costs host time inside the timed region)
         self.ar_stride, self._ar_seen = 1, 0     # ... in every ar_stride-th step only (two marker packets in the stream cost the step ~4 us)
         self._e_fwd, self._e_env = torch.cuda.Event(), torch.cuda.Event()
+        self._ar_stream = None       # DQ_DIST_MODE=overlap: the second stream of the dense range's all-reduce (created at its first use)
         self._env_inflight = False
 
     # ------------------------------------------------------------------------------------------------------
@@ -367,8 +368,41 @@ class DQNCore:
                 e1.record()
                 self.ar_events.append((e0, e1))
             net.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)     # (skips AND flags non-finite elements: every rank alike)
+        elif _dist.dist_path(self.world_size) and os.environ.get("DQ_DIST_MODE") == "overlap" and self._comm_ready():
+            # DQ_DIST_MODE=overlap: the dense layers' gradient (0.7 of the 0.77 MB at c3) is all-reduced on a SECOND stream through the learner's own
+            # RCCL communicator while the convolutional backward (32 us) runs on the step's stream -- one event each way, no torch.distributed
+            # hand-off --; the convolutional range (66 KB) follows in-stream, then the guarded Adam.  The same communicator serves both streams: the
+            # two collectives are issued in the same order on every rank.  What it costs beside the default: the backward in two phases (two final
+            # reductions instead of one) and the two events; what it hides: the wire time of the dense range.
+            nconv = net.n_conv_params
+            if ride is not None:
+                net.td_backward_phase0_env(self.params, td, self.grads, self.env._h, ride)
+            else:
+                net.td_backward_phase0(self.params, td, self.grads)
+            main = torch.cuda.current_stream(self.device)
+            if self._ar_stream is None:
+                self._ar_stream = torch.cuda.Stream(device=self.device)
+                self._e_dense, self._e_ar = torch.cuda.Event(), torch.cuda.Event()
+            self._e_dense.record(main)
+            with torch.cuda.stream(self._ar_stream):
+                self._ar_stream.wait_event(self._e_dense)
+                self._rccl.allreduce_sum_(self.grads[nconv:])
+                self._e_ar.record(self._ar_stream)
+            net.backward_phase(self.params, self.dq, self.grads, 1)
+            probe = self.ar_events is not None and self._ar_seen % self.ar_stride == 0
+            self._ar_seen += 1
+            if probe:
+                e0, e1 = self.ar_pool.pop() if self.ar_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                e0.record()
+            self._rccl.allreduce_sum_(self.grads[:nconv])
+            main.wait_event(self._e_ar)
+            if probe:
+                e1.record()
+                self.ar_events.append((e0, e1))
+            net.adam_step(self.params, self.grads, self.m, self.v, t, self.lr, self.beta_1, self.beta_2, self.epsilon)
         elif _dist.dist_path(self.world_size):
-            # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs
+            # the dense layers' gradient (most of the bytes) is all-reduced while the convolutional backward runs (DQ_DIST_MODE=split; =overlap on
+            # a process group without a RCCL communicator of our own: gloo)
             nconv = net.n_conv_params
             if ride is not None:
                 net.td_backward_phase0_env(self.params, td, self.grads, self.env._h, ride)
@@ -493,6 +527,10 @@ class DQNCore:
         if self._rccl is None and not self._rccl_tried and _dist.dist_path(self.world_size):
             self._rccl_tried = True
             self._rccl = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
+
+    def _comm_ready(self):
+        self.ensure_comm()
+        return self._rccl is not None
 
     def close_comm(self):
         """Destroys the learner's own RCCL communicator (dist.RcclComm) -- every rank, behind a synchronisation, BEFORE the process group

@@ -245,21 +245,32 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
 //   wb      [piece][column tile] the compact kernel's pieces (qnet.h c1c);  b1p  [r1][64] f32
 // Output: a1 piece planes, rows of 64 halves (l plane lo1 halves further), rows < M1 only.
 #define PATCH_BT 4
-// ent(m): table entry of row m (any source); this lane's rows 4kq .. 4kq+3 of its wave's first PATCH_BT tiles
+#ifndef PATCH_SPLIT
+#define PATCH_SPLIT 1                   // the odd last tile (13 tiles on 4 waves at 8 samples of d = 5) shared by waves 0 and 1, two column tiles each (below)
+#endif
+// ent(m): table entry of row m (any source); this lane's rows 4kq .. 4kq+3 of its wave's first PATCH_BT tiles, and (bpx) of the group's LAST tile
 template <typename EntFn>
-__device__ __forceinline__ void conv1_patch_bias(f32x4 (&bp)[PATCH_BT][4], const float* __restrict__ b1p, int slot, int wfirst, int j, int kq, EntFn ent) {
+__device__ __forceinline__ void conv1_patch_bias(f32x4 (&bp)[PATCH_BT][4], f32x4 (&bpx)[4], const float* __restrict__ b1p, int slot, int wfirst, int last_tile,
+                                                 int j, int kq, EntFn ent) {
 #pragma unroll
     for (int u = 0; u < PATCH_BT; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             bp[u][r] = *reinterpret_cast<const f32x4*>(b1p + ((ent((wfirst + CONV_WAVES * u) * 16 + 4 * kq + r) & (slot - 1)) << 4) + 4 * j);     // 4 p -> p * 64 floats
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bpx[r] = *reinterpret_cast<const f32x4*>(b1p + ((ent(last_tile * 16 + 4 * kq + r) & (slot - 1)) << 4) + 4 * j);
 }
 
+// Tile balance: M1 rows are ceil(M1 / 16) tiles on CONV_WAVES waves, tile t to wave t mod 4 -- 13 tiles at 8 samples of d = 5 (and at 4 of d = 7): wave 0
+// has four, the others three, and the barrier behind the phase waits for wave 0 (phase stamps: 6.6K cycles against 4.7K).  When the count is
+// 4 n + 1 the LAST tile is shared: wave 0 computes its column tiles 0, 1 (this lane's channels 4j, 4j + 1), wave 1 its column tiles 2, 3 -- half the MFMAs
+// and half the epilogue each: 3.5 tile times instead of 4 on the critical wave.
 __device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, const int* __restrict__ s_t1, const u32x4* __restrict__ s_lut,
-                                                  const u32x4 (&wb)[2][1][4], const f32x4 (&bpr)[PATCH_BT][4], const float* __restrict__ b1p, int slot,
-                                                  unsigned short* __restrict__ s_a1, int lo1, int M1, int wfirst, int j, int kq) {
+                                                  const u32x4 (&wb)[2][1][4], const f32x4 (&bpr)[PATCH_BT][4], const f32x4 (&bpx)[4], const float* __restrict__ b1p,
+                                                  int slot, unsigned short* __restrict__ s_a1, int lo1, int M1, int wfirst, int j, int kq, int bpx_tile) {
     const int tiles = (M1 + 15) >> 4;
     if (wfirst >= tiles) return;                                    // wave-uniform
+    const bool split = PATCH_SPLIT && (tiles & (CONV_WAVES - 1)) == 1 && tiles > CONV_WAVES;     // wave-uniform: the last tile belongs to wave 0 and is shared with wave 1
     auto byte_of = [&](int tile) -> u32 { return s_in[(s_t1[min(tile * 16 + j, M1 - 1)] & 0x1ffff) + kq]; };      // (tiles past the end reread the last row)
     auto tile_out = [&](int tile, u32 byte, const f32x4 (&bp)[4]) {
         const u32x4 av = s_lut[byte];
@@ -288,14 +299,52 @@ __device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, c
             *reinterpret_cast<uint2*>(dst + lo1) = uint2{lp[0], lp[1]};
         }
     };
+    // half of the shared last tile: column tiles 2 HALF, 2 HALF + 1 = this lane's channels 4j + 2 HALF, + 1 (one dword per plane and row)
+    auto tile_half = [&](int tile, u32 byte, const f32x4 (&bp)[4], auto half_c) {
+        constexpr int HALF = decltype(half_c)::value;
+        const u32x4 av = s_lut[byte];
+        f32x4 acc[2], accl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; accl[t] = acc[t]; }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = MFMA_F16(av, wb[0][0][2 * HALF + t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) accl[t] = MFMA_F16(av, wb[1][0][2 * HALF + t], accl[t]);
+        f32x4 vs[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) vs[t] = f16x2_sum(acc[t], accl[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mo = tile * 16 + 4 * kq + r;
+            if (mo >= M1) continue;
+            u32 hp, lp;
+            split_f16x2_pair(relu1(vs[0][r] + bp[r][2 * HALF]), relu1(vs[1][r] + bp[r][2 * HALF + 1]), hp, lp);
+            unsigned short* dst = s_a1 + mo * 64 + 4 * j + 2 * HALF;
+            *reinterpret_cast<u32*>(dst) = hp;
+            *reinterpret_cast<u32*>(dst + lo1) = lp;
+        }
+    };
     u32 by[PATCH_BT + 1];
     by[0] = byte_of(wfirst);
+    const u32 byx = byte_of(tiles - 1);                             // (the shared tile's byte: waves 0 and 1 use it when `split`)
 #pragma unroll
     for (int u = 0; u < PATCH_BT; ++u) {                            // (bytes one tile ahead)
         const int tile = wfirst + CONV_WAVES * u;
-        if (tile >= tiles) return;                                  // wave-uniform
+        if (tile >= tiles) break;                                   // wave-uniform
         by[u + 1] = byte_of(tile + CONV_WAVES);
-        tile_out(tile, by[u], bpr[u]);
+        if (split && tile == tiles - 1) tile_half(tile, by[u], bpr[u], std::integral_constant<int, 0>());      // (wave 0's last)
+        else tile_out(tile, by[u], bpr[u]);
+    }
+    if (split && wfirst == 1) {                                     // wave 1: the other half of wave 0's last tile
+        if (tiles - 1 == bpx_tile) tile_half(tiles - 1, byx, bpx, std::integral_constant<int, 1>());
+        else {                                                      // (a ragged group of the persistent kernel: bpx holds a full group's last tile -- this tile's bias through L1)
+            const int4 e4 = *reinterpret_cast<const int4*>(s_t1 + (tiles - 1) * 16 + 4 * kq);
+            const int ent[4] = {e4.x, e4.y, e4.z, e4.w};
+            f32x4 bp[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bp[r] = *reinterpret_cast<const f32x4*>(b1p + ((ent[r] & (slot - 1)) << 4) + 4 * j);
+            tile_half(tiles - 1, byx, bp, std::integral_constant<int, 1>());
+        }
     }
     u32 bA = by[PATCH_BT];
     for (int tile = wfirst + CONV_WAVES * PATCH_BT; tile < tiles; tile += CONV_WAVES) {     // larger groups: the bias through L1, per tile
@@ -305,7 +354,8 @@ __device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, c
         f32x4 bp[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bp[r] = *reinterpret_cast<const f32x4*>(b1p + ((ent[r] & (slot - 1)) << 4) + 4 * j);
-        tile_out(tile, bA, bp);
+        if (split && tile == tiles - 1) tile_half(tile, bA, bp, std::integral_constant<int, 0>());
+        else tile_out(tile, bA, bp);
         bA = bB;
     }
 }
@@ -368,10 +418,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
         tab3[u] = a.rowtab[2 * CONV_ROWTAB + min((2 * wave + u) * 16 + j, M3 - 1)];
     }
     u32x4* s_lut = reinterpret_cast<u32x4*>(smem + a.off_lut);
-    f32x4 bp1[PATCH_BT][4];                                         // CP: per-pixel bias of this lane's rows (conv1_patch_words)
+    f32x4 bp1[PATCH_BT][4], bpx[4];                                 // CP: per-pixel bias of this lane's rows (conv1_patch_words); bpx: of the group's last tile
     if constexpr (CP) {
         conv_build_bit_lut(s_lut, tid, CONV_THREADS);
-        conv1_patch_bias(bp1, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, wave, j, kq, [&](int m) { return a.rowtab0[min(m, CONV_ROWTAB - 1)]; });
+        conv1_patch_bias(bp1, bpx, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, wave, (M1 + 15) / 16 - 1, j, kq,
+                         [&](int m) { return a.rowtab0[min(m, CONV_ROWTAB - 1)]; });
     }
 
     DQ_STAMP(DQ_TAG_CONV_FWD, 1);
@@ -422,7 +473,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     // ---- convolution 1: A gathered byte-wise from the uint8 image; the bytes of this wave's next tile are requested before the
     //      MFMAs of the current one ----------------------------------------------------------------------------------------------
     if constexpr (CP) {
-        conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wave, j, kq);
+        conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, bpx, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wave, j, kq, (M1 + 15) / 16 - 1);
     } else {
         const int tiles = (M1 + 15) >> 4;
         auto origin = [&](int tile) { return s_t1[min(tile * 16 + j, M1 - 1)]; };     // rows past the end (and whole tiles past it) reread the last row
@@ -575,7 +626,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     // first-layer weight pieces (PK_CONV1, zero past K1) and bias of a job
     u32x4 wb[2][NH1][4];                                            // [piece][k-half of 32][column tile]: 8 f16 each
     f32x4 bias1;
-    f32x4 bp1[PATCH_BT][4];                                         // CP: per-pixel bias of this lane's rows (conv1_patch_words), reloaded with the pieces
+    f32x4 bp1[PATCH_BT][4], bpx[4];                                 // CP: per-pixel bias of this lane's rows (conv1_patch_words), reloaded with the pieces; bpx: of a
+                                                                    // FULL group's last tile (a ragged last group: its own last tile's rows are a prefix of the same pixels
+                                                                    // only when it ends on the same tile -- see the use)
     auto load_w1 = [&](const ConvJob& Jn) {
         const u32x4* pk1 = opaque_global(Jn.packed + (CP ? a.pk_c1c : PK_CONV1)) + lane;
 #pragma unroll
@@ -586,7 +639,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
                 for (int piece = 0; piece < 2; ++piece) wb[piece][h][t] = pk1[(h * 4 + t) * PK_BLOCK + PK_LO * piece];
         if constexpr (CP) {
             const int* tc = reinterpret_cast<const int*>(smem + a.off_t1);      // (the constant table: row m -> sample, 4 p; padded to whole tiles)
-            conv1_patch_bias(bp1, reinterpret_cast<const float*>(opaque_global(Jn.packed + a.pk_b1p)), a.slot, wave, j, kq,
+            conv1_patch_bias(bp1, bpx, reinterpret_cast<const float*>(opaque_global(Jn.packed + a.pk_b1p)), a.slot, wave, (MF1 + 15) / 16 - 1, j, kq,
                              [&](int m) { return tc[min(m, ((MF1 + 15) & ~15) - 1)]; });
         } else {
             bias1 = *reinterpret_cast<const f32x4*>(Jn.params + a.b_off[0] + 4 * j);
@@ -689,7 +742,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 2);
         // ---- convolution 1 (conv_chain_kernel's, on rows of 64 halves) ------------------------------------------------------------
         if constexpr (CP) {
-            conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wv, j, kq);
+            conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, bpx, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wv, j, kq, (MF1 + 15) / 16 - 1);
         } else {
             const int tiles = (M1 + 15) >> 4;
             auto origin = [&](int tile) {                           // (constant table entry + the sample's alignment offset of THIS group)

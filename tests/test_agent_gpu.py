@@ -728,3 +728,28 @@ def test_agent_loop_with_a_device_evaluated_network_referee(dq, torch_mod):
     assert agent._core.updates > 20 and len(hist.history["episode"]) > 0 and np.isfinite(hist.history["loss"][-1])
     th = agent.test(env, nb_episodes=64, visualize=False, verbose=0, single_cycle=False)
     assert len(th.history["episode_lifetime"]) == 64
+
+
+def test_reference_training_run_replayed_against_its_own_record(dq, torch_mod):
+    """The training half against a REFERENCE-HELD record (the keras-rl fork is not in the tree, so the update rule and the fit
+    loop have no source-level pin): the reference's from-scratch run trained_models/d5_x/0.001 (training_history.json + its two config
+    dicts, committed as data: tests/golden/training_history_d5_x_0.001.npz) replayed through runner.train_single_point -> DQNAgent.fit
+    with the same recipe -- one lattice, batch 32, Adam 1e-5, epsilon 1 -> 0.02 over 200 000 steps, target copy every 5000, warm-up 1000 --
+    for its first 120 000 steps (the whole 998 377-step run: tools/replay_reference_training.py, record in profiles/).  Random numbers
+    and referee differ by construction, so the comparison is statistical: mean_eps exact; mean_q within x2, loss within x4 and the
+    rolling lifetime within x3 of the reference's curve at 10 000 / 25 000 / 50 000 / 100 000 steps (measured: within 10 %)."""
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    try:
+        import replay_reference_training as R
+    finally:
+        sys.path.pop(0)
+    res = R.run("d5_x", "0.001", max_steps=120000, sweep_rates=[0.005])
+    rows, ok = R.compare(res)
+    for at, key, a, b, good in rows:
+        print(f"{str(at):>8} {key:<60} ours {a:12.5g} reference {b:12.5g} {'ok' if good else 'OUTSIDE'}")
+    assert ok, [r for r in rows if not r[4]]
+    assert int(res["ours"]["nb_steps"][-1]) >= 119000 and len(rows) >= 13
+    # keys and their order are the reference file's
+    assert list(res["ours"]) == [str(k) for k in res["record"]["key_order"]]

@@ -19,9 +19,11 @@ def _clean_env(**extra):
 
 
 @pytest.mark.gpu
-def test_bench_self_launches_two_ranks_that_stay_identical():
+@pytest.mark.parametrize("mode", ["single", "overlap"])
+def test_bench_self_launches_two_ranks_that_stay_identical(mode):
+    # (overlap: on a gloo group -- no RCCL communicator of the learner's own -- the mode takes the split form through torch.distributed)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(DQ_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(DQ_DIST_BACKEND="gloo", DQ_DIST_MODE=mode), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1                                           # rank 0 only
@@ -52,7 +54,8 @@ def test_one_rank_rccl_group_drives_the_several_gpu_branch():
         return json.loads(lines[0])
     plain = run()
     assert "rccl_ranks" not in plain
-    for extra, native, word in ((dict(), True, "own stream"), (dict(DQ_DIST_NATIVE="0"), False, "torch.distributed"), (dict(DQ_DIST_MODE="split"), False, "asynchronous")):
+    for extra, native, word in ((dict(), True, "own stream"), (dict(DQ_DIST_NATIVE="0"), False, "torch.distributed"), (dict(DQ_DIST_MODE="split"), False, "asynchronous"),
+                                (dict(DQ_DIST_MODE="overlap"), True, "second stream")):
         forced = run(DQ_DIST_FORCE="1", **extra)
         assert forced["rccl_ranks"] == 1 and forced["dist_backend"] == "rccl" and forced["replicas_identical"] is True
         ar = forced["allreduce"]

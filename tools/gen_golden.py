@@ -404,13 +404,34 @@ def time_reference(ENV, luts, seconds=5.0):
     return res
 
 
+_TIME_ARGS = None
+
+
+def _time_worker(seconds):
+    return time_reference(_TIME_ARGS[0], _TIME_ARGS[1], seconds)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--big-only", action="store_true", help="only the traces of the lattices beyond d = 7 (BIG_TRACE_CONFIGS)")
+    ap.add_argument("--time-only", type=int, default=0, metavar="N",
+                    help="no fixtures: only time the reference environment on N processes at once (independent lattices, steps summed: SURVEY.md 8d (1))")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     FL, ENV = import_reference()
+    if args.time_only:
+        import multiprocessing as mp
+        luts = {d: (referee.build_lut(d, 3), referee.build_lut(d, 1)) for d in (3, 5, 7)}
+        global _TIME_ARGS                                           # (forked workers inherit the imported reference module: it does not pickle)
+        _TIME_ARGS = (ENV, luts)
+        ctx = mp.get_context("fork")
+        with ctx.Pool(args.time_only) as pool:
+            per = pool.map(_time_worker, [8.0] * args.time_only)
+        total = {k: sum(r[k] for r in per) for k in per[0]}
+        print(json.dumps({"processes": args.time_only, "cores": os.cpu_count(), "reference_env_steps_per_s_total": total,
+                          "per_process_min": {k: min(r[k] for r in per) for k in per[0]}, "per_process_max": {k: max(r[k] for r in per) for k in per[0]}}))
+        return
 
     def big_traces():
         for name, cfg in BIG_TRACE_CONFIGS.items():

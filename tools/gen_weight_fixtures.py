@@ -82,7 +82,34 @@ def build_history(family, p):
     return out
 
 
+def build_history_tails():
+    """Of EVERY shipped training_history.json (14 runs): the last five episode rows of the early-stopping bookkeeping and the largest
+    time_since_best seen before min_nb_steps -- what pins the fork's stopping rule (tests/test_host_logic.py)."""
+    import json
+    out = {"agents": np.array([f"{fam}/{p}" for fam, p in AGENTS])}
+    rows = []
+    for fam, p in AGENTS:
+        d = os.path.join(REF, fam, p)
+        h = json.load(open(os.path.join(d, "training_history.json")))
+        fixed = pickle.load(open(os.path.join(REF, fam, "fixed_config.p"), "rb"))
+        var = pickle.load(open(glob.glob(os.path.join(d, "variable_config_*.p"))[0], "rb"))
+        S, tsb = np.array(h["nb_steps"]), np.array(h["time_since_best"])
+        pre = tsb[S < var["exploration_fraction"]]
+        rows.append(dict(patience=fixed["stopping_patience"], min_nb_steps=var["exploration_fraction"], max_timesteps=fixed["max_timesteps"],
+                         success_threshold=var["success_threshold"], max_tsb_before_min=int(pre.max()) if len(pre) else 0,
+                         max_tsb_after_min_before_last=int(tsb[S >= var["exploration_fraction"]][:-1].max()),
+                         tail_nb_steps=[int(x) for x in S[-5:]], tail_time_since_best=[int(x) for x in tsb[-5:]],
+                         tail_stopped_improving=[bool(x) for x in h["stopped_improving"][-5:]], tail_has_succeeded=[bool(x) for x in h["has_succeeded"][-5:]],
+                         any_stopped_before_last=bool(any(h["stopped_improving"][:-1])), episodes=len(S),
+                         max_rolling=float(max(h["episode_lifetimes_rolling_avg"]))))
+    out["rows_json"] = np.array(json.dumps(rows, sort_keys=True))
+    return out
+
+
 def main():
+    path = os.path.join(ROOT, "tests", "golden", "training_history_tails.npz")
+    np.savez_compressed(path, **build_history_tails())
+    print(path, os.path.getsize(path))
     for family, p in HISTORIES:
         path = os.path.join(ROOT, "tests", "golden", history_fixture_name(family, p) + ".npz")
         np.savez_compressed(path, **build_history(family, p))
