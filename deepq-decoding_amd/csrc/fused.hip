@@ -246,7 +246,10 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
 // Output: a1 piece planes, rows of 64 halves (l plane lo1 halves further), rows < M1 only.
 #define PATCH_BT 4
 #ifndef PATCH_SPLIT
-#define PATCH_SPLIT 1                   // the odd last tile (13 tiles on 4 waves at 8 samples of d = 5) shared by waves 0 and 1, two column tiles each (below)
+#define PATCH_SPLIT 0                   // 1: the odd last tile (13 tiles on 4 waves at 8 samples of d = 5) shared by waves 0 and 1, two column tiles each (below).
+                                        // Measured (one box, twice each, tools/ab_run.sh): conv forward 43.5-43.7 us with it against 42.0 without -- the critical wave
+                                        // does half a tile less, the kernel is 1.6 us SLOWER (four more live registers per lane, two more code paths in the unrolled
+                                        // tile loop): off; same bits either way (tests/test_compact_gpu.py passes with both)
 #endif
 // ent(m): table entry of row m (any source); this lane's rows 4kq .. 4kq+3 of its wave's first PATCH_BT tiles, and (bpx) of the group's LAST tile
 template <typename EntFn>

@@ -1228,6 +1228,19 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     DQ_STAMP_PAIR2(3);
     DQ_STAMP_WG(DQ_TAG_CONV_BWD, 0);
     DQ_STAMP(DQ_TAG_CONV_BWD, 25);
+    // this wave's replay row of the workgroup's FIRST group (obs_row below), requested before anything else: its round trip (the index vector was
+    // written by the launch before) then runs under the table copies instead of standing in front of the first group's copies
+    int row_first = 0;
+    if ((int)blockIdx.x < a.groups) {
+        const int gb0 = (int)blockIdx.x * a.S, gns = min(a.S, a.batch - gb0);
+        row_first = gb0 + min(wave, gns - 1);
+        if (a.index) {
+            const __attribute__((address_space(4))) int32_t* idx = (const __attribute__((address_space(4))) int32_t*)(uintptr_t)a.index;
+            row_first = idx[row_first] + a.index_off;
+            if (row_first >= a.index_mod) row_first -= a.index_mod;
+        }
+    }
+    row_first = __builtin_amdgcn_readfirstlane(row_first);          // (wave-uniform by construction; said so)
     // ---- group-independent tables and zero rows ----------------------------------------------------------------
     // (copied from the host-built tables: computing them here took two integer divisions per entry)
     for (int m = tid; m < S * r1; m += CB_THREADS) {
@@ -1328,7 +1341,7 @@ __global__ __launch_bounds__(CB_THREADS, 2) void conv_bwd_chain_kernel(ConvBwdAr
     DQ_STAMP(DQ_TAG_CONV_BWD, 28);
     if ((int)blockIdx.x < a.groups) {
         const int g = blockIdx.x, gns = min(S, a.batch - g * S);
-        issue_obs(g, obs_row(g));
+        issue_obs(g, row_first);
         issue_g3(g, gns * r3);
         issue_a2(g, gns * r2);
         if (a.a1_alt) issue_a1(g, reinterpret_cast<unsigned short*>(smem + a.off_a1));

@@ -14,6 +14,14 @@ python bench.py 2>"$out/bench_c3_loop.err" | line > "$out/bench_c3_loop.json"
 for cfg in c2 c5; do python bench.py --config $cfg --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_${cfg}_loop.json"; done
 for mode in act learn env; do python bench.py --mode $mode --steps 1000 --warmup 50 2>/dev/null | line > "$out/bench_c3_${mode}.json"; done
 python bench.py --minibatch 32 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_mb32.json"
+# the reference's replay ratio, 32 trained samples per environment step (one 32-sample update per step, TRAIN:119-127), three ways:
+# 32 updates of 4096 per vector step; 4 updates of 32768; and the reference's own schedule, 4096 updates of 32 (a few steps: 0.3 s each)
+python bench.py --updates-per-step 32 --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_ratio32.json"
+python bench.py --minibatch 32768 --updates-per-step 4 --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_ratio32_mb32768.json"
+python bench.py --minibatch 32 --updates-per-step 4096 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_ratio32_mb32.json"
+# the uint8 ring beside the patch-word ring (DQNCore.compact), same box
+DQ_COMPACT_OBS=0 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_uint8ring.json"
+DQ_COMPACT_OBS=0 python bench.py --config c5 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c5_loop_uint8ring.json"
 rm -rf "$out/prof"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -- python "$root/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$root/$out/prof.log" 2>&1)
 python tools/rocprof_summary.py $(ls $out/prof/*/*.db | head -1) "$out/loop_c3_kernel_stats.csv"
