@@ -13,9 +13,14 @@ import torch
 import torch.distributed as dist
 
 
+SYNC_INTERVAL = None
+
+
 def main():
     out_dir = sys.argv[1]
-    single = len(sys.argv) > 2 and sys.argv[2] == "single"
+    single = len(sys.argv) > 2 and sys.argv[2].startswith("single")
+    global SYNC_INTERVAL
+    SYNC_INTERVAL = 4 if len(sys.argv) > 2 and sys.argv[2] == "single4" else None
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
@@ -56,8 +61,10 @@ def main_single(dq, out_dir, rank):
                         target_model_update=50, policy=dq.EpsGreedyQPolicy(eps=0.3, masked_greedy=True), test_policy=dq.GreedyQPolicy(masked_greedy=True),
                         gamma=0.99, enable_dueling_network=True, batch_size=8, seed=(1, 2))
     agent.compile(dq.Adam(lr=1e-4))
+    # sync_interval > 1 with one lattice per rank: the ranks' launch counters diverge (only the rank whose lattice ended takes the uncounted
+    # reset step), so the host synchronisations -- which contain collectives -- must be gated on a rank-independent counter
     hist = agent.fit(env, nb_steps=300, verbose=0, episode_averaging_length=10, success_threshold=None, stopping_patience=None,
-                     min_nb_steps=0, single_cycle=False)
+                     min_nb_steps=0, single_cycle=False, **({} if SYNC_INTERVAL is None else dict(sync_interval=SYNC_INTERVAL)))
     core = agent._core
     chk = int(core.params.view(torch.int32).to(torch.int64).sum().item())
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:

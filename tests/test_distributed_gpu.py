@@ -121,3 +121,17 @@ def test_single_lattice_fit_under_two_ranks_counts_every_step(tmp_path):
     # whenever either finished: extra_a == extra_b == number of episode ends)
     extra_a, extra_b = a["vector_steps"] - 300, b["vector_steps"] - 300
     assert a["episodes_global"] == b["episodes_global"] == extra_a + extra_b and extra_a > extra_b > 0
+
+
+@pytest.mark.gpu
+def test_single_lattice_fit_under_two_ranks_with_a_longer_sync_interval(tmp_path):
+    """The same with sync_interval = 4: the ranks' environment-launch counters differ (one uncounted reset step per LOCAL episode end), the
+    synchronisation points -- statistics all-reduce, collective update -- are gated on the counted steps of this fit(), the same on every
+    rank: no deadlock (the subprocess timeout would catch it), same number of updates, identical parameters."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29545", os.path.join(ROOT, "tests", "_fit_two_ranks.py"), str(tmp_path), "single4"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
+    assert a["step"] == b["step"] == 300 and a["updates"] == b["updates"] > 0 and a["params"] == b["params"]
+    assert a["vector_steps"] != b["vector_steps"]            # (the situation the gate has to survive)

@@ -663,3 +663,36 @@ def test_qnet_at_baseline_size_properties(dq, torch_mod):
     g12 = net.backward(params, d1 + d2)
     scale = float(g12.abs().max())
     assert float((g12 - (g1 + g2)).abs().max()) < 2e-5 * scale
+
+
+def test_guarded_adam_step_skips_and_flags_non_finite_elements(dq, torch_mod):
+    """dq_qnet_adam_step (the several-GPU branch's optimizer step behind the gradient all-reduce): an element whose gradient is inf / NaN leaves
+    its parameter and moments untouched and raises the handle's range flag, every other element takes dq_adam_step's update bit for bit; dq_adam_step
+    itself skips such elements too (without a flag)."""
+    torch = torch_mod
+    from importlib import import_module
+    Q = import_module("deepq-decoding_amd.qnet")
+    L = import_module("deepq-decoding_amd._lib")
+    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", 8)
+    g = torch.from_numpy(rng.randn(net.n_params).astype(np.float32)).cuda()
+    bad = torch.tensor([0, 5, 1001, net.n_params - 1], device="cuda")
+    g_bad = g.clone()
+    g_bad[bad] = torch.tensor([float("inf"), float("nan"), float("-inf"), float("nan")], device="cuda")
+    ref_p, ref_m, ref_v = params.clone(), torch.full_like(params, 0.01), torch.full_like(params, 0.02)
+    Q.adam_step(ref_p, g, ref_m, ref_v, 3, 1e-3)
+    for guarded in (True, False):
+        p_, m_, v_ = params.clone(), torch.full_like(params, 0.01), torch.full_like(params, 0.02)
+        if guarded:
+            net.check_range()
+            net.adam_step(p_, g_bad, m_, v_, 3, 1e-3)
+            with pytest.raises(dq.DeepQError) as ei:
+                net.check_range()
+            assert ei.value.status == L.DQ_ERR_RANGE
+            net.check_range()                                    # cleared by the report
+        else:
+            Q.adam_step(p_, g_bad, m_, v_, 3, 1e-3)
+        ok = torch.ones(net.n_params, dtype=torch.bool, device="cuda")
+        ok[bad] = False
+        assert torch.equal(p_[ok], ref_p[ok]) and torch.equal(m_[ok], ref_m[ok]) and torch.equal(v_[ok], ref_v[ok])
+        assert torch.equal(p_[bad], params[bad]) and bool((m_[bad] == 0.01).all()) and bool((v_[bad] == 0.02).all())
+        assert torch.isfinite(p_).all()
