@@ -1109,14 +1109,21 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
     // ---- Dense(|A|)^T's weights for this wave's 64 units (two K = 32 blocks x NT2 tiles of 16 outputs: qnet.h dense2) start flying
     //      under the hidden layer's epilogue ---------------------------------------------------------------------------------------
-    F16x2 w2[2][NT2];
-    {
-        const u32x4* pk2 = J.packed + a.pk_dense2 + (size_t)(2 * wave) * NT2 * PK_BLOCK + lane;
+    // WIDE2 (|A| > 64 with 32-sample workgroups, round 4; selected by DQ_DENSE_RT=2 only: measured at c5 -- 4096 rows of d = 7 -- it is SLOWER than 16-sample
+    // workgroups, 29.1 against 25.9 us: 128 workgroups leave half the CUs idle and the launch is one round of latency-bound workgroups either way): all NT2 = 8 column tiles as pieces are 128 registers, beside the 64 of two row tiles' hidden
+    // accumulators they do not fit -- the passes below then form the hidden pieces of BOTH row tiles first (the accumulators die there) and walk
+    // Dense(|A|)'s column tiles in two halves of four, the second half's weights requested under the first half's MFMAs
+    constexpr bool WIDE2 = NT2 == 8 && RT == 2;
+    constexpr int NTW = WIDE2 ? 4 : NT2;                            // column tiles of Dense(|A|) held as pieces at a time
+    const u32x4* pk2 = J.packed + a.pk_dense2 + (size_t)(2 * wave) * NT2 * PK_BLOCK + lane;
+    F16x2 w2[2][NTW];
+    auto load_w2 = [&](F16x2 (&w)[2][NTW], int t0) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int t = 0; t < NT2; ++t) { w2[b][t].h = pk2[(b * NT2 + t) * PK_BLOCK]; w2[b][t].l = pk2[(b * NT2 + t) * PK_BLOCK + PK_LO]; }
-    }
+            for (int t = 0; t < NTW; ++t) { w[b][t].h = pk2[(b * NT2 + t0 + t) * PK_BLOCK]; w[b][t].l = pk2[(b * NT2 + t0 + t) * PK_BLOCK + PK_LO]; }
+    };
+    if constexpr (!WIDE2) load_w2(w2, 0);
     // The dueling layer Dense(|A| + 1) and the combination Q = V + A - mean(A) are ONE linear map of Dense(|A|)'s output: pack_weights_kernel
     // folds them into W3' [16 KG3][16 NT2] (zero past N2 / past |A|) and b3' (PackLayout.w3q), so that the last phase's MFMA accumulators ARE the
     // Q-values (round 3: a separate combination -- every wave reading eight rows back from LDS, butterfly sums, a barrier in between -- was 5K of a
@@ -1149,10 +1156,62 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     DQ_STAMP(DQ_TAG_DENSE_FWD, 3);
     // ---- per reduction pass (32 rows): hidden epilogue in registers -> Dense(|A|)^T partial over this wave's units -> LDS; then the
     //      fixed-order sum over the 8 waves ------------------------------------------------------------------------------------------
+    // the hidden epilogue of row tile u in registers: bias, ReLU, dropout, split -> this wave's two K = 32 blocks of Dense(|A|)'s operand
+    auto hidden_pieces = [&](int u, F16x2 (&hb)[2]) {
+        const int row = 16 * u + j;                                 // this lane's sample
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ct = 2 * b + s;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(f16x2_sum(acc[u][ct][0][r], acc[u][ct][1][r]) + bias1[ct][r], 0.f);
+                if (J.keep_scale > 0.f) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = ((keepb[u] >> (8 * b + 4 * s + r)) & 1u) ? v[r] * J.keep_scale : 0.f;
+                }
+                u32 hp[2], lp[2];
+                split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
+                split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
+                hb[b].h[2 * s] = hp[0]; hb[b].h[2 * s + 1] = hp[1];
+                hb[b].l[2 * s] = lp[0]; hb[b].l[2 * s + 1] = lp[1];
+            }
+            if (J.h1_pl && row < ns && !DQ_EXP_NOSTORE) {           // (training: the hidden output as piece planes, see below)
+                unsigned short* gp = J.h1_pl + (size_t)(b0 + row) * DENSE_HID + 64 * wave + 32 * b + 8 * kq;
+                *reinterpret_cast<u32x4*>(gp) = hb[b].h;
+                *reinterpret_cast<u32x4*>(gp + (size_t)J.plane_rows * DENSE_HID) = hb[b].l;
+            }
+        }
+    };
+    if constexpr (WIDE2) {
+        static_assert(!WIDE2 || (ROWS / PR == 1 && UP == 2), "one reduction pass over both row tiles");
+        F16x2 hbw[2][2];
+        F16x2 w2b[2][NTW];
+        load_w2(w2, 0);                                             // (both halves' weights fly under the epilogues)
+        load_w2(w2b, NTW);
+        hidden_pieces(0, hbw[0]);
+        hidden_pieces(1, hbw[1]);
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                f32x4 acc2[NTW][2];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) { acc2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t][1] = acc2[t][0]; }
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) mma_f16x3(hlf ? w2b[b][t] : w2[b][t], hbw[uu][b], acc2[t][0], acc2[t][1]);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    *reinterpret_cast<f32x4*>(s_part + (wave * PR + 16 * uu + j) * PWP + 16 * (NTW * hlf + t) + 4 * kq) = f16x2_sum(acc2[t][0], acc2[t][1]);
+            }
+    }
 #pragma unroll
     for (int pass = 0; pass < ROWS / PR; ++pass) {
 #pragma unroll
-        for (int uu = 0; uu < UP; ++uu) {
+        for (int uu = 0; uu < (WIDE2 ? 0 : UP); ++uu) {
             const int u = pass * UP + uu, row = 16 * u + j;         // this lane's sample
             F16x2 hb[2];                                            // the sample's units 8kq .. 8kq+7 of this wave's two blocks, as pieces
 #pragma unroll
@@ -1182,16 +1241,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                     *reinterpret_cast<u32x4*>(gp + (size_t)J.plane_rows * DENSE_HID) = hb[b].l;
                 }
             }
-            f32x4 acc2[NT2][2];
+            f32x4 acc2[NTW][2];                                      // (NTW == NT2 here: the WIDE2 form ran above)
 #pragma unroll
-            for (int t = 0; t < NT2; ++t) { acc2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t][1] = acc2[t][0]; }
+            for (int t = 0; t < NTW; ++t) { acc2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t][1] = acc2[t][0]; }
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int t = 0; t < NT2; ++t) mma_f16x3(w2[b][t], hb[b], acc2[t][0], acc2[t][1]);
+                for (int t = 0; t < NTW; ++t) mma_f16x3(w2[b][t], hb[b], acc2[t][0], acc2[t][1]);
             // C/D layout: this lane holds outputs 16t + 4kq .. + 3 of sample j: one 16-byte store per tile
 #pragma unroll
-            for (int t = 0; t < NT2; ++t)
+            for (int t = 0; t < NTW; ++t)
                 *reinterpret_cast<f32x4*>(s_part + (wave * PR + 16 * uu + j) * PWP + 16 * t + 4 * kq) = f16x2_sum(acc2[t][0], acc2[t][1]);
         }
         if (pass == 0) { DQ_STAMP(DQ_TAG_DENSE_FWD, 4); }
@@ -1650,7 +1709,7 @@ static bool plan_dense(const dq_qnet* Q, DensePlan* P, int rt = 1) {
     if (N2 > 128 || N3 > 128) return false;
     const int rows = 16 * rt;
     P->NT2 = N2 <= 64 ? 4 : 8;
-    if (rt > 1 && P->NT2 != 4) return false;                        // (more than 16 samples: the registers only fit four Dense(|A|) tiles)
+    if (rt > 2 && P->NT2 != 4) return false;                        // (64 samples: the registers only fit four Dense(|A|) tiles; 32 with eight: the WIDE2 form)
     P->ldx = D1.nin + 4;
     P->ld2 = 16 * P->NT2 + 4;
     P->ld3 = 16 * ((N3 + 15) / 16) + 1;
@@ -1703,8 +1762,9 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         const conv_kernel_t pks[5] = {conv_chain_pkernel<3>, conv_chain_pkernel<4>, conv_chain_pkernel<5>, conv_chain_pkernel<6>, conv_chain_pkernel<0>};
         for (int i = 0; i < 5; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
-        const dense_kernel_t dks[4] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<4, 4, 4>};
-        for (int i = 0; i < 4; ++i)
+        const dense_kernel_t dks[5] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<4, 4, 4>,
+                                       dense_chain_kernel<8, 8, 2>};
+        for (int i = 0; i < 5; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         attr_devs |= dev_bit;
     }
@@ -1758,7 +1818,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
     }
     const int dense_rows = 16 * RT;
     const dense_kernel_t dk = dp.NT2 == 4 ? (RT == 4 ? dense_chain_kernel<4, 4, 4> : RT == 2 ? dense_chain_kernel<4, 4, 2> : dense_chain_kernel<4, 4, 1>)
-                                          : dense_chain_kernel<8, 8, 1>;
+                                          : (RT == 2 ? dense_chain_kernel<8, 8, 2> : dense_chain_kernel<8, 8, 1>);
     da.ldx = dp.ldx; da.ld2 = dp.ld2; da.ld3 = dp.ld3;
     da.off_x = dp.off_x; da.off_h = dp.off_h; da.off_part = dp.off_part; da.off_y2 = dp.off_y2; da.off_y3 = dp.off_y3;
     int conv_wgs = 0, dense_wgs = 0, n_train = 0;
