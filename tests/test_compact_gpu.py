@@ -73,8 +73,13 @@ def test_environment_patch_words_are_the_reference_observation(dq, torch_mod, na
     assert env.patch_supported
     patch = torch.zeros((n_envs, env.patch_stride), dtype=torch.int32, device="cuda")
     actions = torch.from_numpy(g["action"].astype(np.int32)).cuda()
+    from oracle import patch_words as PW
+    d, depth, layers = cfg["d"], cfg["volume_depth"], env.n_action_layers
     env.reset(out_patch=patch)
     for t in range(n_steps + 1):
+        if t % 8 == 0 or t == n_steps:          # the oracle's cell-by-cell restatement (oracle/patch_words.py) of the RECORDED observation
+            want = PW.words_array(g["obs"][:, t].astype(np.uint8), d, depth, layers, env.patch_stride)
+            assert np.array_equal(patch.cpu().numpy()[:, :d * d], want[:, :d * d]), (name, "words vs oracle", t)
         assert np.array_equal(env.patch_to_obs(patch).cpu().numpy(), g["obs"][:, t]), (name, "decoded words", t)
         assert torch.equal(env.obs_to_patch(env.obs)[:, :cfg["d"] ** 2], patch[:, :cfg["d"] ** 2]), (name, "encoded image", t)
         if t < n_steps:

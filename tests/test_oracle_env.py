@@ -246,3 +246,37 @@ def test_episode_traces(name):
 @pytest.mark.parametrize("name", STICKY_TRACES)
 def test_sticky_done_traces(name):
     _replay_trace(name, auto_reset=False)
+
+
+@pytest.mark.parametrize("name", [n for n in __import__("conftest").TRACES])
+def test_patch_words_carry_the_whole_observation(name):
+    """oracle/patch_words.py against the observations recorded from the reference (ENV:273-314 through ENV:174-175, 200-201): every cell the
+    words do not carry holds padding_syndrome's decoration / zero in EVERY recorded observation, the words' round trip reproduces the
+    observation, and the package's vectorised host helpers (env.obs_to_patch / patch_to_obs, used for decoding rings and pickles) agree
+    with the loops."""
+    import importlib
+    import torch
+    from oracle import patch_words as PW
+    g = load_golden("trace_" + name)
+    cfg, n_envs, n_steps, seed = trace_config(g)
+    d, depth = cfg["d"], cfg["volume_depth"]
+    obs = g["obs"]
+    layers = obs.shape[2] - depth
+    assert 4 * depth + layers <= 32
+    flat = obs.reshape((-1,) + obs.shape[2:]).astype(np.uint8)
+    st = PW.static_plane(d)
+    data = np.zeros_like(st, dtype=bool)
+    data[0::2, 0::2] = True
+    for j in range(depth):                                          # syndrome planes: everything but the even-even cells is the decoration
+        assert np.array_equal(flat[:, j][:, ~data], np.broadcast_to(st[~data], (len(flat), (~data).sum())))
+    centre = np.zeros_like(st, dtype=bool)
+    centre[1::2, 1::2] = True
+    assert not flat[:, depth:][:, :, ~centre].any()                 # action planes: only the odd-odd cells are ever set
+    E = importlib.import_module("deepq-decoding_amd.env")
+    sample = flat[:: max(1, len(flat) // 64)]
+    words = PW.words_array(sample, d, depth, layers, E.patch_stride_words(d))
+    for o, w in zip(sample, words):
+        assert np.array_equal(PW.observation_of(w.view(np.uint32), d, depth, layers), o)
+    t = E.obs_to_patch(torch.from_numpy(flat), d, depth, layers).numpy()
+    assert np.array_equal(t[:: max(1, len(flat) // 64)], words)
+    assert np.array_equal(E.patch_to_obs(torch.from_numpy(t), d, depth, layers).numpy(), flat)

@@ -42,4 +42,15 @@ def run():
     g = net.backward(core.params, torch.from_numpy(dq_).cuda()).cpu().numpy()
     g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
     assert np.abs(g - g_ref).max() < 2e-5 * max(1.0, np.abs(g_ref).max()), np.abs(g - g_ref).max()
+    # the loop's own form of the observation: the ring holds patch words (core.compact) -- the words equal the oracle's cell-by-cell restatement
+    # of the decoded image, and the training forward / backward FROM THE WORDS meets the same bounds
+    assert core.compact, "the headline configuration runs on the compact ring"
+    from oracle import patch_words as PW
+    words = core.patch_ring[core.cur]
+    want = PW.words_array(obs.cpu().numpy(), env.d, env.volume_depth, env.n_action_layers, env.patch_stride)
+    assert np.array_equal(words.cpu().numpy()[:, :env.d ** 2], want[:, :env.d ** 2])
+    q2 = net.forward_multi([dict(params=core.params, obs=words.contiguous(), patch=True, training=True, seed=seed, t=t)])[0].cpu().numpy()
+    assert np.abs(q2 - q_ref).max() < 1e-5, np.abs(q2 - q_ref).max()
+    g2 = net.backward(core.params, torch.from_numpy(dq_).cuda()).cpu().numpy()
+    assert np.abs(g2 - g_ref).max() < 2e-5 * max(1.0, np.abs(g_ref).max()), np.abs(g2 - g_ref).max()
     print(f"agent smoke ok: loss {loss:.4g} mean_q {mean_q:.4g}")
