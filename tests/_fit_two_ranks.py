@@ -25,6 +25,8 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     dq = importlib.import_module("deepq-decoding_amd")
+    if len(sys.argv) > 2 and sys.argv[2] == "range":
+        return main_range(dq, out_dir, rank, world)
     if single:
         return main_single(dq, out_dir, rank)
     N = 64
@@ -46,6 +48,44 @@ def main():
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(dict(step=agent.step, updates=agent._core.updates, params=chk, stopped=hist.history["stopped_improving"][-1],
                        records=len(hist.history["episode"])), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main_range(dq, out_dir, rank, world):
+    """The range guard under several ranks: ONE rank's minibatch holds TD errors beyond the fused backward's range.  The whole update must
+    be discarded on EVERY rank (the overflowing rank turns its gradient into NaNs, the all-reduce carries them to the others, the guarded Adam step skips
+    and flags them), the replicas stay bit-identical, and every rank reports DQ_ERR_RANGE at the same synchronisation point."""
+    N = 64
+    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    env = dq.VectorEnv(n_envs=N, env_id_base=rank * N, **cfg)
+    net = dq.QNetwork(env.obs_shape, [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]], env.num_actions, max_batch=N)
+    core = dq.DQNCore(env, net, batch_size=N, memory_limit=N * 8, gamma=0.99, lr=1e-3, seed=(5, 6), rank=rank, world_size=world)
+    core.reset_env()
+    for _ in range(4):
+        core.act_and_step(1.0, use_q=False)
+    for _ in range(3):
+        core.step_and_update(0.5)
+    core.read_metrics()                                             # healthy so far: no error
+    before = core.params.clone()
+    if rank == 0:
+        core.reward_ring.fill_(1e6)                                 # TD errors of ~1e6 on this rank only
+    core.step_and_update(0.5)
+    torch.cuda.synchronize()
+    unchanged = bool(torch.equal(core.params, before))
+    raised = False
+    try:
+        core.read_metrics()
+    except dq.DeepQError as e:
+        raised = e.status == -6
+    if rank == 0:
+        core.reward_ring.zero_()
+    core.step_and_update(0.5)                                       # the loop carries on
+    core.read_metrics()
+    chk = int(core.params.view(torch.int32).to(torch.int64).sum().item())
+    finite = bool(torch.isfinite(core.params).all())
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(dict(unchanged=unchanged, raised=raised, params=chk, finite=finite, moved=not torch.equal(core.params, before)), f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -218,3 +218,25 @@ def test_loop_on_a_compact_ring_equals_the_loop_on_a_uint8_ring(dq, torch_mod, c
     diff = (a.params - b.params).abs()
     assert float(diff.max()) <= 2 * lr * steps and float(diff.mean()) < 2e-6, (float(diff.max()), float(diff.mean()))
     assert a.read_stats() == b.read_stats()
+
+
+def test_configurations_beyond_one_word_per_pixel_keep_the_uint8_ring(dq, torch_mod):
+    """4 volume_depth + action layers > 32 data bits per pixel (volume_depth 8 at d = 5) or the wide environment (d = 9): DQNCore stays on the
+    uint8 ring, dq_env_patch_output refuses, and the loop runs as before."""
+    torch = torch_mod
+    env = dq.VectorEnv(n_envs=32, d=5, error_model="DP", use_Y=False, volume_depth=8, p_phys=0.01, p_meas=0.01)
+    assert not env.patch_supported
+    with pytest.raises(dq.DeepQError):
+        env.arm_patch_output(torch.zeros((32, env.patch_stride), dtype=torch.int32, device="cuda"))
+    net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=32)
+    with pytest.raises(dq.DeepQError):
+        net.set_patch_input(8, 32)
+    core = dq.DQNCore(env, net, batch_size=32, memory_limit=32 * 8, gamma=0.99, lr=1e-4)
+    assert not core.compact and core.patch_ring is None and core.obs_ring.dtype == torch.uint8
+    core.reset_env()
+    for _ in range(4):
+        core.act_and_step(1.0, use_q=False)
+    for _ in range(3):
+        core.step_and_update(0.3)
+    loss, mean_q = core.read_metrics()
+    assert np.isfinite(loss) and np.isfinite(mean_q)

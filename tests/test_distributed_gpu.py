@@ -135,3 +135,16 @@ def test_single_lattice_fit_under_two_ranks_with_a_longer_sync_interval(tmp_path
     a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
     assert a["step"] == b["step"] == 300 and a["updates"] == b["updates"] > 0 and a["params"] == b["params"]
     assert a["vector_steps"] != b["vector_steps"]            # (the situation the gate has to survive)
+
+
+@pytest.mark.gpu
+def test_range_guard_discards_the_update_on_every_rank(tmp_path):
+    """Two ranks (gloo, one GPU), one of them with TD errors of ~1e6 in its minibatch: no parameter moves on either rank, both raise DQ_ERR_RANGE at
+    their next read_metrics(), the replicas stay bit-identical and the loop carries on afterwards."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "tests", "_fit_two_ranks.py"), str(tmp_path), "range"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
+    assert a == b, (a, b)
+    assert a["unchanged"] and a["raised"] and a["finite"] and a["moved"]
