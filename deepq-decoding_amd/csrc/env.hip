@@ -587,7 +587,7 @@ static bool env_pairs(const dq_env* E) {
     return enabled && E->cfg.d * E->cfg.d <= 32 && E->info.n_stab <= 32 && E->sw <= 32;
 }
 
-static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = false) {
+static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = false, int rider_threads = 512) {
     DQ_REQUIRE(E->rates_set, DQ_ERR_STATE, "dq_env_set_rates has not been called");
     p.tab = E->d_tab; p.state = E->d_state; p.lut_x = E->lut_x; p.lut_z = E->lut_z; p.lut_joint = E->lut_joint;
     p.n_envs = E->cfg.n_envs; p.d2 = E->cfg.d * E->cfg.d; p.n_stab = E->info.n_stab; p.depth = E->cfg.volume_depth;
@@ -612,7 +612,7 @@ static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = fals
     E->patch_next = nullptr;
     p.env_blocks = (p.n_envs + epb - 1) / epb;
     // the riding step's sampling is drawn by the lattices' own blocks when their threads cover the minibatch (env_dev.h env_inline_sampling)
-    if (rider && p.s_batch > 0 && (long long)p.env_blocks * 512 >= p.s_batch) p.s_blocks = 0;
+    if (rider && p.s_batch > 0 && (long long)p.env_blocks * rider_threads >= p.s_batch) p.s_blocks = 0;
     return DQ_OK;
 }
 
@@ -754,14 +754,16 @@ dq_status dq_env_get_tables(const dq_env* E, uint64_t* stab_qmask, uint64_t* qub
 dq_status env_fill_act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
                             int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
                             uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sj, uint64_t* stats_dev, EnvParams* p,
-                            size_t* lds) {
+                            size_t* lds, int threads) {
     DQ_REQUIRE(E && !E->mlp_layers, DQ_ERR_UNSUPPORTED, "a step whose referee is the Dense stack (dq_env_set_referee_mlp) does not ride: make the separate calls");
+    DQ_REQUIRE(threads == 512 || threads == 256, DQ_ERR_INVALID, "env_fill_act_step: 256 or 512 threads per carrying block");
     dq_status rc = fill_act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev,
-                                 lifetime_dev, was_reset_dev, sj, 512, *p);
+                                 lifetime_dev, was_reset_dev, sj, threads, *p);
     if (rc != DQ_OK) return rc;
-    rc = fill_common(E, *p, 8, true);
+    const int waves = threads / 64;
+    rc = fill_common(E, *p, waves, true, threads);
     if (rc != DQ_OK) return rc;
     p->stats = reinterpret_cast<unsigned long long*>(stats_dev);
-    *lds = env_block_lds(p->pair ? 16 : 8, 8, p->obs_size, p->lut_words);
+    *lds = env_block_lds(p->pair ? 2 * waves : waves, waves, p->obs_size, p->lut_words);
     return DQ_OK;
 }

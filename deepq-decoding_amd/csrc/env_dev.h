@@ -682,10 +682,10 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
 }
 
 // env.hip: validates the arguments of dq_env_act_step(_sample) and fills the parameters of a step WITHOUT launching it: the caller
-// runs env_block<8> -- or, with p->pair, env_block2<16> -- on blocks [0, p->env_blocks + p->s_blocks) of its own 512-thread grid
+// runs env_block<8> -- or, with p->pair, env_block2<16> -- on blocks [0, p->env_blocks + p->s_blocks) of its own 512-thread grid (256 threads: <4> / <8>)
 // (p->env_blocks, p->s_blocks are set for that); *lds = the dynamic LDS those blocks need.
 struct dq_env;
 dq_status env_fill_act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
                             int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
                             uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sj, uint64_t* stats_dev, EnvParams* p,
-                            size_t* lds);
+                            size_t* lds, int threads = 512);      // threads per block of the carrying launch: 512 (env_block<8> / env_block2<16>) or 256 (<4> / <8>)

@@ -689,6 +689,9 @@ __device__ __forceinline__ F16x2 lds_tr8(const unsigned short* p0, const unsigne
 }
 
 #define WGRAD_THREADS 256
+#ifndef DQ_RIDE_WGRAD_DEFAULT
+#define DQ_RIDE_WGRAD_DEFAULT 0        // 1: the environment step rides on the dense weight gradients' launch by default (fused_rider_threads)
+#endif
 #define WGRAD_WAVES 4
 #define WG_PS 72                        // halves per LDS row of an operand image: 64 columns + one 16-byte padding slot (rows 36 dwords apart: the four rows of
                                         // a transposing read fall into distinct banks)
@@ -721,7 +724,17 @@ struct DenseWgradArgs {
     int n_layers, batch, rows_per_slice, total_tiles, slices;
     float* partial;                     // [slices][pstride]
     size_t pstride;
+    int env_on, wg_count, env_wgs;               // env_on: workgroups >= wg_count run the vector step's environment launch (DQ_RIDE_ON=wgrad: env_block<4> / env_block2<8>)
 };
+
+// Where the riding environment step rides (round 4): on the dense data gradients' launch (rounds 2-3; DQ_RIDE_ON=dense_bwd) or on the dense weight
+// gradients' (DQ_RIDE_ON=wgrad): that launch has two 4-wave workgroups per CU at 121 registers -- issue slots and registers to spare -- while the data
+// gradients' workgroups are a latency chain that the riders lengthen (16.3 us alone, 20.2 with them, one box).
+static int ride_on_wgrad() {            // 0: dense_bwd_chain's launch; 1: behind the weight-gradient tiles; 2: in front of them
+    static const int on_wgrad = !getenv("DQ_RIDE_ON") ? DQ_RIDE_WGRAD_DEFAULT : strcmp(getenv("DQ_RIDE_ON"), "wgrad") == 0 ? 1 : strcmp(getenv("DQ_RIDE_ON"), "wgrad_first") == 0 ? 2 : 0;
+    return on_wgrad;
+}
+int fused_rider_threads() { return ride_on_wgrad() ? 256 : 512; }
 
 // rows per batch slice (a multiple of 64: whole iterations) and the number of slices, at most DENSE_WGRAD_SLICES.  WG_SLICES_TARGET slices are aimed
 // for: at c3 the launch is 49 tiles x slices workgroups on 256 CUs with room for two each -- 8 slices = 392 workgroups leave 120 CUs with one
@@ -748,8 +761,16 @@ static void wgrad_slicing(const dq_qnet* Q, int B, int* rows_per_slice, int* sli
     *slices = (B + rps - 1) / rps;
 }
 
-__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wgrad_kernel(DenseWgradArgs a) {
+__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wgrad_kernel(DenseWgradArgs a, EnvParams env) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    // the riding environment step (env_dev.h, 256 threads per block): behind the gradient tiles (env_on 1) or in front of them (env_on 2); block-uniform
+    const int wblock = (int)blockIdx.x - (a.env_on == 2 ? a.env_wgs : 0);
+    if (a.env_on && (a.env_on == 2 ? wblock < 0 : wblock >= a.wg_count)) {
+        const int eb = a.env_on == 2 ? (int)blockIdx.x : wblock - a.wg_count;
+        if (env.pair) env_block2<8>(env, eb, smem);
+        else env_block<4>(env, eb, smem);
+        return;
+    }
     unsigned short* s_t = reinterpret_cast<unsigned short*>(smem);   // [buf][op][piece][64 rows][WG_PS] row-major piece planes
     // XCD-aware block -> (tile, slice) map: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of one batch
     // slice are given to ONE XCD (slice = XCD + 8 i): the slice's rows of X and G are then fetched from HBM/MALL once instead of
@@ -759,11 +780,11 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
     int slice, tile;
     {
         const int full = (a.slices >> 3) * 8 * a.total_tiles;       // workgroups of the whole groups of 8 slices
-        if ((int)blockIdx.x < full) {
-            const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+        if (wblock < full) {
+            const int xcd = wblock & 7, within = wblock >> 3;
             slice = xcd + 8 * (within / a.total_tiles); tile = within % a.total_tiles;
         } else {
-            const int e = (int)blockIdx.x - full;
+            const int e = wblock - full;
             slice = (a.slices & ~7) + e / a.total_tiles; tile = e % a.total_tiles;
         }
     }
@@ -1865,10 +1886,13 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     EnvParams ep;
     memset(&ep, 0, sizeof(ep));
     size_t lds = dp.lds;
+    const bool ride_wgrad = rider && fused_rider_threads() == 256;  // the step rides on the dense weight gradients' launch instead (below)
     if (rider) {                                                    // (its blocks do their own bookkeeping: no statistics workgroups)
         DQ_REQUIRE(!td->st_n, DQ_ERR_INVALID, "fused_backward: the riding environment step does its own episode bookkeeping");
-        ep = *rider; da.env_on = 1; stat_wgs = ep.env_blocks + ep.s_blocks;
-        if (rider_lds > lds) lds = rider_lds;
+        if (!ride_wgrad) {
+            ep = *rider; da.env_on = 1; stat_wgs = ep.env_blocks + ep.s_blocks;
+            if (rider_lds > lds) lds = rider_lds;
+        }
     }
     if (td && td->metrics && da.dense_tiles > td->metric_slots)    // (the partials are then summed by atomics, in any order: diagnostics only)
         DQ_HIP(hipMemsetAsync(td->metrics + 2, 0, (size_t)td->metric_slots * 2 * sizeof(float), st));
@@ -1908,7 +1932,15 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     wgrad_slicing(Q, B, &rps, &sy);
     wa.rows_per_slice = rps; wa.partial = dense_partial; wa.pstride = dense_pstride(Q);
     wa.total_tiles = tiles; wa.slices = sy;
-    dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_kernel, dim3(tiles * sy), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa);
+    wa.wg_count = tiles * sy;
+    EnvParams wep;
+    memset(&wep, 0, sizeof(wep));
+    int ride_wgs = 0;
+    if (ride_wgrad) {
+        DQ_REQUIRE(rider_lds <= DENSE_WGRAD_LDS, DQ_ERR_UNSUPPORTED, "fused_backward: the riding environment step needs more LDS than the dense weight gradients' launch has");
+        wep = *rider; wa.env_on = ride_on_wgrad(); ride_wgs = wep.env_blocks + wep.s_blocks; wa.env_wgs = ride_wgs;
+    }
+    dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_kernel, dim3(tiles * sy + ride_wgs), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa, wep);
     DQ_LAUNCH_CHECK();
 
     if (phases != 3) {                                              // phased: the dense gradients are complete (and reducible) now

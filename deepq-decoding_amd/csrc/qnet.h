@@ -285,5 +285,6 @@ struct TdFused {
 // rider != NULL (needs td): the lattices' environment step (env_dev.h parameters, filled by env_fill_act_step) runs as extra
 // workgroups of the dense backward's first launch
 struct EnvParams;
+int fused_rider_threads();            // threads per block of the launch that carries the riding environment step: 512 (dense data gradients) or 256 (dense weight gradients)
 dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_dev, float* grads_dev, int phases, hipStream_t st,
                          const AdamOpt* opt = nullptr, const TdFused* td = nullptr, const EnvParams* rider = nullptr, size_t rider_lds = 0);

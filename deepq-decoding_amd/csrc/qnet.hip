@@ -734,7 +734,8 @@ static dq_status fill_rider(dq_qnet* Q, const dq_td_job* td, dq_env* env, const 
     DQ_REQUIRE(Q && Q->use_fused && fused_backward_supported(Q), DQ_ERR_UNSUPPORTED,
                "dq_qnet_td_backward_*_env: only the fused chains carry the environment step");
     return env_fill_act_step(env, sj->q_dev, sj->eps, sj->masked_greedy, sj->seed, sj->t, sj->action_dev, sj->auto_reset, sj->obs_dev,
-                             sj->reward_dev, sj->done_dev, sj->legal_dev, sj->lifetime_dev, sj->was_reset_dev, sj->sample, sj->stats_dev, ep, lds);
+                             sj->reward_dev, sj->done_dev, sj->legal_dev, sj->lifetime_dev, sj->was_reset_dev, sj->sample, sj->stats_dev, ep, lds,
+                             fused_rider_threads());
 }
 
 static dq_status td_backward_phase0(dq_qnet* Q, const float* params_dev, const dq_td_job* tdj, float* grads_dev, void* stream,
