@@ -1380,10 +1380,18 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
             } else if (rc - 4 < a.b1p_rows) {                           // one wave per pixel, lane = output channel
                 const int pix = rc - 4, mask = a.ptab[PT_CONST + pix];
                 double acc = (double)params[a.b1_off + lane];
+                float w[5][8];                                          // (all 40 loads in flight: a run-time trip count = one round trip per term; depth <= 8)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const int pos = a.ptab[PT_CPOS + c];
+#pragma unroll
+                    for (int pl = 0; pl < 8; ++pl) w[c][pl] = params[a.w1_off + (size_t)(pos * a.p_C + min(pl, a.p_depth - 1)) * 64 + lane];
+                }
+#pragma unroll
                 for (int c = 0; c < 5; ++c) {
                     if (!((mask >> c) & 1)) continue;
-                    const int pos = a.ptab[PT_CPOS + c];
-                    for (int pl = 0; pl < a.p_depth; ++pl) acc += (double)params[a.w1_off + (size_t)(pos * a.p_C + pl) * 64 + lane];
+#pragma unroll
+                    for (int pl = 0; pl < 8; ++pl) if (pl < a.p_depth) acc += (double)w[c][pl];
                 }
                 reinterpret_cast<float*>(pk + a.b1p_off)[(size_t)pix * 64 + lane] = (float)acc;
             }

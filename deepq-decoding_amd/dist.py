@@ -79,6 +79,23 @@ def broadcast_(flat, src=0, group=None):
     return flat
 
 
+def exchange_unique_id(raw, err, rank, dev, group=None):
+    """Rank 0's 128-byte ncclUniqueId to every rank through the process group.  Every rank takes part in BOTH collectives whatever happened
+    to it before (a rank that raised in front of them would leave the others waiting in the broadcast), and nobody enters ncclCommInitRank --
+    which blocks until all ranks have joined -- unless everybody is ready.  `raw`: the id's bytes on rank 0 (ALL 128 of them: the id is binary,
+    a ctypes char-array field read as an attribute stops at its first zero byte), None elsewhere; `err`: what went wrong on this rank so far."""
+    buf = bytearray(raw) if rank == 0 and raw is not None else bytearray(128)
+    if len(buf) != 128:
+        buf, err = bytearray(128), err or RuntimeError(f"ncclUniqueId of {len(buf)} bytes")
+    t = torch.frombuffer(buf, dtype=torch.uint8).clone().to(dev)
+    dist.broadcast(t, src=0, group=group)
+    ready = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(ready, op=dist.ReduceOp.MIN, group=group)
+    if int(ready.item()) == 0:
+        raise RuntimeError(f"a rank could not prepare its RCCL communicator ({err if err is not None else 'another rank'})")
+    return t.cpu().numpy().tobytes()
+
+
 # ---- RCCL on the caller's stream ---------------------------------------------------------------------------------------------------
 class RcclComm:
     """A RCCL communicator of this build's own (librccl through ctypes), used for the one collective of the learner's hot path: the in-place
@@ -111,16 +128,9 @@ class RcclComm:
         except (OSError, RuntimeError, AttributeError) as e:
             err = e
         if world > 1:
-            # every rank takes part in BOTH collectives whatever happened to it above (a rank that raised before them would leave the others
-            # waiting in the broadcast), and nobody enters ncclCommInitRank -- which blocks until all ranks have joined -- unless everybody is ready
             dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
-            t = torch.frombuffer(bytearray(bytes(uid.internal) if rank == 0 else bytes(128)), dtype=torch.uint8).clone().to(dev)
-            dist.broadcast(t, src=0, group=group)
-            ready = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(ready, op=dist.ReduceOp.MIN, group=group)
-            if int(ready.item()) == 0:
-                raise RuntimeError(f"a rank could not prepare its RCCL communicator ({err if err is not None else 'another rank'})")
-            ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+            raw = exchange_unique_id(ctypes.string_at(ctypes.byref(uid), 128) if rank == 0 else None, err, rank, dev, group)
+            ctypes.memmove(ctypes.byref(uid), raw, 128)
         elif err is not None:
             raise err
         self.comm = ctypes.c_void_p()

@@ -154,3 +154,59 @@ def test_a_rank_that_cannot_prepare_its_communicator_takes_every_rank_to_the_fal
     mp.spawn(_rccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     out = [(tmp_path / f"rccl{r}.txt").read_text() for r in range(world)]
     assert all(o.startswith("RuntimeError: a rank could not prepare") for o in out), out
+
+
+_FAKE_ID = bytes([7, 0, 0, 201] + [(37 * k) % 256 for k in range(124)])      # binary, zero bytes early on: as a real ncclUniqueId
+
+
+class _FakeRccl:
+    """Stands in for librccl in the rendezvous test: hands out _FAKE_ID on rank 0 and records the id every rank joins with."""
+    def __init__(self, *a, **k):
+        import ctypes
+
+        class _Fn:
+            def __init__(self, f):
+                self.f = f
+
+            def __call__(self, *args):
+                return self.f(*args)
+
+        def get_id(ref):
+            ctypes.memmove(ctypes.addressof(ref._obj), _FAKE_ID, 128)
+            return 0
+
+        def init_rank(comm_ref, world, uid, rank):
+            self.joined = (world, rank, ctypes.string_at(ctypes.addressof(uid), 128))
+            comm_ref._obj.value = 1
+            return 0
+        self.ncclGetErrorString, self.ncclGetUniqueId, self.ncclCommInitRank = _Fn(lambda rc: b"fake"), _Fn(get_id), _Fn(init_rank)
+        self.ncclAllReduce, self.ncclCommDestroy = _Fn(lambda *a: 0), _Fn(lambda c: 0)
+
+
+def _rccl_id_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D = importlib.import_module("deepq-decoding_amd.dist")
+    D.init_from_env(backend="gloo")
+    import ctypes
+    ctypes.CDLL = _FakeRccl
+    torch.cuda.device = lambda d: __import__("contextlib").nullcontext()         # (no GPU here; the communicator is the fake's)
+    comm = D.RcclComm(rank, world, "cpu")
+    w, r, raw = comm.lib.joined
+    with open(os.path.join(out_dir, f"id{rank}.bin"), "wb") as f:
+        f.write(bytes([w, r]) + raw)
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_every_rank_joins_with_all_128_bytes_of_rank_zeros_unique_id(tmp_path):
+    """The ncclUniqueId is binary: read as a ctypes char-array attribute it stops at its first zero byte (rank 0 then broadcast a few bytes and
+    the other ranks joined a different communicator id -- the N > 1 rendezvous could never have completed).  Two ranks, a stand-in library:
+    both call ncclCommInitRank(world, id, rank) with rank 0's 128 bytes."""
+    world, port = 2, _free_port()
+    mp.spawn(_rccl_id_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = (tmp_path / f"id{r}.bin").read_bytes()
+        assert got[0] == world and got[1] == r and got[2:] == _FAKE_ID, (r, got[:12])
