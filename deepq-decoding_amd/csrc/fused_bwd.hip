@@ -761,16 +761,8 @@ static void wgrad_slicing(const dq_qnet* Q, int B, int* rows_per_slice, int* sli
     *slices = (B + rps - 1) / rps;
 }
 
-__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wgrad_kernel(DenseWgradArgs a, EnvParams env) {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    // the riding environment step (env_dev.h, 256 threads per block): behind the gradient tiles (env_on 1) or in front of them (env_on 2); block-uniform
-    const int wblock = (int)blockIdx.x - (a.env_on == 2 ? a.env_wgs : 0);
-    if (a.env_on && (a.env_on == 2 ? wblock < 0 : wblock >= a.wg_count)) {
-        const int eb = a.env_on == 2 ? (int)blockIdx.x : wblock - a.wg_count;
-        if (env.pair) env_block2<8>(env, eb, smem);
-        else env_block<4>(env, eb, smem);
-        return;
-    }
+// (wblock: the workgroup's index among the gradient tiles' -- blockIdx.x, or less the riding environment blocks in front of them)
+__device__ __forceinline__ void dense_wgrad_body(const DenseWgradArgs& a, const int wblock, u8* smem) {
     unsigned short* s_t = reinterpret_cast<unsigned short*>(smem);   // [buf][op][piece][64 rows][WG_PS] row-major piece planes
     // XCD-aware block -> (tile, slice) map: workgroup b runs on XCD b % 8 and each XCD has its own L2, so all tiles of one batch
     // slice are given to ONE XCD (slice = XCD + 8 i): the slice's rows of X and G are then fetched from HBM/MALL once instead of
@@ -925,6 +917,26 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
     DQ_STAMP(DQ_TAG_DENSE_WGRAD, 26);
     DQ_STAMP_WG(DQ_TAG_DENSE_WGRAD, 1);
     DQ_STAMP_PAIR2(2);
+}
+
+__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wgrad_kernel(DenseWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    dense_wgrad_body(a, (int)blockIdx.x, smem);
+}
+
+// DQ_RIDE_ON=wgrad / wgrad_first (A/B runs; NOTEBOOK.md, Round 4 section 9: measured slower): the riding environment step (env_dev.h, 256 threads per
+// block) behind the gradient tiles (env_on 1) or in front of them (env_on 2); block-uniform.  A kernel of its own: the default launch keeps its
+// registers and its kernel-argument segment.
+__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wgrad_ride_kernel(DenseWgradArgs a, EnvParams env) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const int wblock = (int)blockIdx.x - (a.env_on == 2 ? a.env_wgs : 0);
+    if (a.env_on == 2 ? wblock < 0 : wblock >= a.wg_count) {
+        const int eb = a.env_on == 2 ? (int)blockIdx.x : wblock - a.wg_count;
+        if (env.pair) env_block2<8>(env, eb, smem);
+        else env_block<4>(env, eb, smem);
+        return;
+    }
+    dense_wgrad_body(a, wblock, smem);
 }
 
 // Fixed-order reduction of both partial sets in one launch: out[i] = sum_s partial[s * stride + i].
@@ -1816,6 +1828,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         for (int i = 0; i < 6; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_MAX));
         DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_WGRAD_LDS));
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wgrad_ride_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_WGRAD_LDS));
         attr_devs |= dev_bit;
     }
     const int B = Q->last_train_batch, nc = Q->cfg.n_conv, nl = Q->n_layers;
@@ -1940,7 +1953,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         DQ_REQUIRE(rider_lds <= DENSE_WGRAD_LDS, DQ_ERR_UNSUPPORTED, "fused_backward: the riding environment step needs more LDS than the dense weight gradients' launch has");
         wep = *rider; wa.env_on = ride_on_wgrad(); ride_wgs = wep.env_blocks + wep.s_blocks; wa.env_wgs = ride_wgs;
     }
-    dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_kernel, dim3(tiles * sy + ride_wgs), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa, wep);
+    if (ride_wgrad) dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_ride_kernel, dim3(tiles * sy + ride_wgs), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa, wep);
+    else dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_kernel, dim3(tiles * sy), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa);
     DQ_LAUNCH_CHECK();
 
     if (phases != 3) {                                              // phased: the dense gradients are complete (and reducible) now
