@@ -1341,7 +1341,7 @@ struct PackArgs {
     int w1_off, K1, w2_off, w3_off, d1_off, d1_blocks;
     int d2_off, N2, NT2, KB2, d2_blocks, d2t_blocks, d1t_blocks, d1k;     // Dense(|A|) kernel offset / width, dense2 / dense2t / dense1t block counts, K1
     int perm_hw, perm_c;                // > 0: plane index k' = p*perm_c + c of the dense forward is Keras weight row c*perm_hw + p
-    int pack_wgs;
+    int pack_wgs, wide_blocks;          // packing workgroups (four 64-lane blocks each); workgroups of pack_wide_wc_block in front of them
     int w3q_off, w3q_rows;              // the folded dueling layer (qnet.h w3q): u32x4 offset, rows 16 KG3 (+ 1: the bias row); 0 rows = no dueling layer
     int w3d_off, b3d_off, N3, n_actions;    // the dueling layer's kernel [N2][N3] and bias [N3] in params
     int wc_off, wc_waves;               // Wc (qnet.h wc: the dense backward's gH1 rows with the TD step fused in): u32x4 offset, waves that build it (0: none)
@@ -1350,11 +1350,84 @@ struct PackArgs {
     int p_depth, p_C, b1_off;           // syndrome planes, input planes, the first bias in params
 };
 
+// Wc for networks with more than 64 actions (N2, N3 <= 112; qnet.h wc): Wc[a][n1] = P[0] + P[1 + a] - mean_a' P[1 + a'],  P = W2[n1] W3 (the plain
+// product's row, n2 in order).  Workgroups of their own behind the packing ones: the dueling layer's kernel W3 (40 KB at d = 7) is staged in LDS once per
+// workgroup -- read from L2 by every wave it was 13 dependent round trips and the launch 15.6 instead of 6.3 us --; a wave forms WCW_R hidden units, two
+// columns per lane (c = lane, lane + 64), W2's rows through scalar loads.
+#define WCW_R 1
+__device__ __forceinline__ void pack_wide_wc_block(const PackArgs& a, int block, float* s_w3) {
+    const float* __restrict__ params = a.params;
+    const int A = a.n_actions, N2 = a.N2, N3 = a.N3, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // this wave's WCW_R rows of W2, two values per lane (n2 = lane, lane + 64; zero past N2), requested first of all
+    float w2v[WCW_R][2];
+    {
+        const int n1w = min(((block * 4 + wave) * WCW_R), DENSE_HID - WCW_R);
+#pragma unroll
+        for (int q = 0; q < WCW_R; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float v = params[a.d2_off + (size_t)(n1w + q) * N2 + min(lane + 64 * h, N2 - 1)];
+                w2v[q][h] = lane + 64 * h < N2 ? v : 0.f;
+            }
+    }
+    for (int base = 0; base < N2 * N3; base += 16 * 256) {          // (sixteen loads in flight per thread: one by one they are as many round trips)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = params[a.w3d_off + min(base + u * 256 + (int)threadIdx.x, N2 * N3 - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = base + u * 256 + (int)threadIdx.x;
+            if (i < N2 * N3) s_w3[i] = v[u];
+        }
+    }
+    __syncthreads();
+    const int n1_0 = (block * 4 + wave) * WCW_R;
+    if (n1_0 >= DENSE_HID) return;
+    const int c0 = min(lane, N3 - 1), c1 = min(lane + 64, N3 - 1);
+    float acc[WCW_R][2];
+#pragma unroll
+    for (int q = 0; q < WCW_R; ++q) acc[q][0] = acc[q][1] = 0.f;
+#pragma unroll 1
+    for (int n2c = 0; n2c < N2; n2c += 16) {                        // (a chunk of 16 rows lies inside one half of W2's row: its values come out of w2v by v_readlane)
+        float wv[16][2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int rowk = min(n2c + k, N2 - 1) * N3;
+            wv[k][0] = s_w3[rowk + c0]; wv[k][1] = s_w3[rowk + c1];
+        }
+        const int l0 = n2c & 63;
+#pragma unroll
+        for (int q = 0; q < WCW_R; ++q) {
+            const int src = __builtin_bit_cast(int, n2c < 64 ? w2v[q][0] : w2v[q][1]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(src, l0 + k));      // (zero past N2)
+                acc[q][0] = fmaf(w, wv[k][0], acc[q][0]);
+                acc[q][1] = fmaf(w, wv[k][1], acc[q][1]);
+            }
+        }
+    }
+    float* wc = reinterpret_cast<float*>(a.pk + a.wc_off);
+#pragma unroll
+    for (int q = 0; q < WCW_R; ++q) {
+        const bool in0 = lane >= 1 && lane <= A, in1 = lane + 64 <= A;      // columns 1 .. A hold the advantages
+        float adv = (in0 ? acc[q][0] : 0.f) + (in1 ? acc[q][1] : 0.f);
+        for (int m = 32; m >= 1; m >>= 1) adv += __shfl_xor(adv, m);
+        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[q][0])));      // lane 0: the V column
+        if (in0) wc[(size_t)(lane - 1) * DENSE_HID + n1_0 + q] = (v0 + acc[q][0]) - adv / (float)A;
+        if (in1) wc[(size_t)(lane + 63) * DENSE_HID + n1_0 + q] = (v0 + acc[q][1]) - adv / (float)A;
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pack_smem[];
+    // (block-uniform; the Wc workgroups come FIRST in the grid: theirs is the launch's longest chain -- stage, barrier, product, scattered stores)
+    if ((int)blockIdx.x < a.wide_blocks) { pack_wide_wc_block(a, (int)blockIdx.x, pack_smem); return; }
+    const int pblock = (int)blockIdx.x - a.wide_blocks;
     const float* __restrict__ params = a.params;
     u32x4* __restrict__ pk = a.pk;
     const int w2_off = a.w2_off, w3_off = a.w3_off, d1_off = a.d1_off, d1_blocks = a.d1_blocks;
-    const int lane = threadIdx.x & 63, blk_id = blockIdx.x * 4 + (threadIdx.x >> 6), j = lane & 15, kb = lane >> 4;
+    const int lane = threadIdx.x & 63, blk_id = pblock * 4 + (threadIdx.x >> 6), j = lane & 15, kb = lane >> 4;
     const int e_d1 = PK_TOTAL_BLOCKS + d1_blocks, e_d2 = e_d1 + a.d2_blocks, e_d2t = e_d2 + a.d2t_blocks, e_d1t = e_d2t + a.d1t_blocks;
     if (blk_id >= e_d1t) {
         // the dueling layer folded with its combination (qnet.h w3q): one wave per row k of the dueling kernel (row w3q_rows: its bias),
@@ -1510,7 +1583,8 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.w3q = P.dense1t + (size_t)P.d1t_blocks * PK_BLOCK;
     P.w3q_rows = Q->cfg.dueling ? (D2.nout <= 64 ? 64 : 128) : 0;  // 16 KG3 (dense_chain_kernel: KG3 = NT2 = 4 or 8)
     P.wc = P.w3q + ((size_t)(2 * P.w3q_rows + 1) * 16 * P.NT2 + 3) / 4;      // W3' rows, the bias row, then W3'^T [16 NT2][w3q_rows]
-    P.wc_rows = (Q->cfg.dueling && P.NT2 == 4) ? Q->cfg.n_actions : 0;     // (the dense backward's shortcut: tables up to 64 x 64)
+    // Wc (the dense backward's shortcut, fused_bwd.hip SHORT): up to 64 actions built wave by wave, wider ones through an LDS copy of the dueling kernel
+    P.wc_rows = Q->cfg.dueling && (P.NT2 == 4 || (size_t)D2.nout * Q->L[nc + 2].nout * 4 <= 60 * 1024) ? Q->cfg.n_actions : 0;
     P.c1c = P.wc + (size_t)P.wc_rows * DENSE_HID / 4;
     P.b1p_rows = Q->L[0].rows <= 64 ? Q->L[0].rows : 0;              // (patch-word input: one word per pixel and lane, d <= 7)
     P.b1p = P.c1c + (P.b1p_rows ? 4 * PK_BLOCK : 0);
@@ -1542,13 +1616,17 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     a.d1t_blocks = PL.d1t_blocks; a.d1k = D1.nin;
     a.w3q_off = (int)PL.w3q; a.w3q_rows = PL.w3q_rows; a.n_actions = Q->cfg.n_actions;
     if (Q->cfg.dueling) { const Layer& D3 = Q->L[nc + 2]; a.w3d_off = (int)D3.w_off; a.b3d_off = (int)D3.b_off; a.N3 = D3.nout; }
-    a.wc_off = (int)PL.wc; a.wc_waves = PL.wc_rows ? DENSE_HID : 0;
+    a.wc_off = (int)PL.wc; a.wc_waves = PL.wc_rows && PL.NT2 == 4 ? DENSE_HID : 0;      // (more than 64 actions: workgroups of their own, below)
     a.ptab = Q->patch_depth && PL.b1p_rows ? Q->ptab : nullptr;
     a.c1c_off = (int)PL.c1c; a.b1p_off = (int)PL.b1p; a.b1p_rows = PL.b1p_rows; a.p_depth = Q->patch_depth; a.p_C = Q->L[0].cin; a.b1_off = (int)Q->L[0].b_off;
     a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + a.wc_waves +
                   (a.ptab ? 4 + PL.b1p_rows : 0) + 3) / 4;
     // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
-    pack_weights_kernel<<<a.pack_wgs, 256, 0, st>>>(a);
+    // more than 64 actions: Wc by workgroups of their own behind the others, W3 staged in LDS (pack_wide_wc_block)
+    const bool wide_wc = PL.wc_rows && PL.NT2 == 8;
+    const int wide_blocks = wide_wc ? (DENSE_HID + 4 * WCW_R - 1) / (4 * WCW_R) : 0;
+    a.wide_blocks = wide_blocks;
+    pack_weights_kernel<<<a.pack_wgs + wide_blocks, 256, wide_wc ? (size_t)a.N2 * a.N3 * 4 : 0, st>>>(a);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

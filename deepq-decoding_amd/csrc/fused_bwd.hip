@@ -303,8 +303,12 @@ __device__ __forceinline__ void gh1_phase(const DenseBwdArgs& a, const unsigned 
     }
 }
 
-template <int NT2, bool TD>             // N2 <= 16*NT2 and N3 <= 16*NT2; TD: the TD step in the prologue (a compile-time switch: around loads a run-time one
-                                        // is a branch whose merge hipcc guards with s_waitcnt vmcnt(0) -- every preload below was waited for at once)
+#ifndef DB_SHORT_LEAN
+#define DB_SHORT_LEAN 0                 // 1: the shortcut without the LDS copy of W3'^T (its row from L2), without clearing gY2's image and without the first barrier
+#endif
+template <int NT2, bool TD, bool DUEL = true>      // N2 <= 16*NT2 and N3 <= 16*NT2; TD: the TD step in the prologue (a compile-time switch: around loads a run-time one
+                                        // is a branch whose merge hipcc guards with s_waitcnt vmcnt(0) -- every preload below was waited for at once); DUEL: a dueling layer
+                                        // whose tables pack_weights_kernel built (with TD: the shortcut SHORT below)
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(DenseBwdArgs a, EnvParams env) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     // The vector step's environment launch does not feed this update (the minibatch never holds the newest transition, common.h
@@ -369,15 +373,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
     // TD step fused in, dq has one non-zero per row -- gY2[b] = dq[b][a_b] * W3'^T[a_b] --: a row of the 16 KB table, copied into LDS at the top, times
     // a scalar; no dq image, no matrix phase, no barrier in between (SHORT: tables up to 64 x 64; round 3: that phase and its barrier were 3K of a
     // workgroup's 34K cycles).  A caller's dense dq goes through the matrix pipe as before, K = |A|: the same bits where dq has one non-zero per row.
-    constexpr bool SHORT = TD && NT2 == 4;
+    constexpr bool SHORT = TD && DUEL;
+    constexpr bool W3LDS = SHORT && NT2 == 4 && !DB_SHORT_LEAN;                       // W3'^T (64 x 64) copied into LDS; wider tables (|A| > 64): its row read from the L2-resident table
     constexpr int PW3 = 16 * NT2;
     float w3b[NT2][4];
     f32x4 wt3[2];
-    if constexpr (SHORT) {
+    if constexpr (W3LDS) {
         const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.packed + a.pk_w3q) + (size_t)(a.w3q_rows + 1) * PW3);
         wt3[0] = N3 > 0 ? src[tid] : f32x4{0.f, 0.f, 0.f, 0.f};      // 64 x 64 floats = 2 x 16 bytes per thread
         wt3[1] = N3 > 0 ? src[tid + DENSE_THREADS] : f32x4{0.f, 0.f, 0.f, 0.f};
-    } else if (N3 > 0 && wave < NT2) {
+    } else if (!SHORT && N3 > 0 && wave < NT2) {
         const float* w3q = reinterpret_cast<const float*>(a.packed + a.pk_w3q);
         const int n2 = 16 * wave + j;                               // (the table is zero-padded: rows past N2, columns past |A|)
 #pragma unroll
@@ -419,13 +424,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
         ridx[0] = *p0; ridx[1] = *p1;
     }
     __shared__ float s_met[DENSE_WAVES][2];
-    if constexpr (SHORT) {
+    if constexpr (W3LDS) {
         f32x4* s_w3t = reinterpret_cast<f32x4*>(smem + a.off_w3t);  // W3'^T [a][n2] (waited for here: the loads went out first of all)
         s_w3t[tid] = wt3[0]; s_w3t[tid + DENSE_THREADS] = wt3[1];
-    } else {
+    } else if constexpr (!SHORT) {
         for (int i = tid; i < DENSE_ROWS * ldg; i += DENSE_THREADS) s_g3[i] = 0.f;
     }
-    for (int i = tid; i < DENSE_ROWS * LDY; i += DENSE_THREADS) reinterpret_cast<u32*>(s_gy2p)[i] = 0u;      // both planes (2 x 16 x LDY halves)
+    // (SHORT writes whole rows of both gradient images, each wave its own: rows past the batch stay undefined -- they only reach MFMA output rows that
+    // are never stored --, so DB_SHORT_LEAN drops the clearing and the barrier behind it)
+    if (!(SHORT && DB_SHORT_LEAN))
+        for (int i = tid; i < DENSE_ROWS * LDY; i += DENSE_THREADS) reinterpret_cast<u32*>(s_gy2p)[i] = 0u;      // both planes (2 x 16 x LDY halves)
     if constexpr (TD) {                                             // the replay rows' fields: in flight across the barrier
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             a_b[u] = a.td.action[rr];
         }
     }
-    __syncthreads();
+    if (!(SHORT && DB_SHORT_LEAN)) __syncthreads();
     DQ_STAMP(DQ_TAG_DENSE_BWD, 6);
     f32x4 wcr[RPW][2];                                              // SHORT: this wave's rows of Wc, in flight under the TD arithmetic below
     if constexpr (SHORT) {
@@ -445,6 +453,17 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
             const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
             const f32x4* row = reinterpret_cast<const f32x4*>(wc + (size_t)min(max(ab, 0), A - 1) * DENSE_HID + 8 * lane);
             wcr[u][0] = row[0]; wcr[u][1] = row[1];
+        }
+    }
+    float w3r[RPW][2] = {{0.f, 0.f}, {0.f, 0.f}};                   // SHORT beyond 64 actions: row a_b of W3'^T [a][n2], columns lane and lane + 64 (zero past N2: the table's padding)
+    if constexpr (SHORT && !W3LDS) {
+        const float* w3t = reinterpret_cast<const float*>(a.packed + a.pk_w3q) + (size_t)(a.w3q_rows + 1) * a.w3q_pw;
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
+            const float* row = w3t + (size_t)min(max(ab, 0), A - 1) * a.w3q_rows;
+            w3r[u][0] = row[lane];
+            w3r[u][1] = lane + 64 < a.w3q_rows ? row[lane + 64] : 0.f;
         }
     }
     // ---- (TD step: y = r + gamma (1 - terminal) Q_target(s1)[argmax Q_online(s1)], dq = (Q(s0)[a] - y) * scale at the action taken,
@@ -531,12 +550,24 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
                 p3[1 + c] = ph; p3[lo3 + 1 + c] = pl;
             }
             if constexpr (SHORT) {                                  // gY2[row] = dq[row][a_b] * W3'^T[a_b]: lane = column n2 (zero past N2: the table's padding)
-                const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
-                const float* s_w3t = reinterpret_cast<const float*>(smem + a.off_w3t);
-                const float gy = s_w3t[min(max(ab, 0), PW3 - 1) * PW3 + lane] * s;
-                const _Float16 vh = (_Float16)gy, vl = (_Float16)((gy - (float)vh) * F16_LO_SCALE);      // split on write (qnet.h)
-                s_gy2p[row * LDY + lane] = __builtin_bit_cast(unsigned short, vh);
-                s_gy2p[(DENSE_ROWS + row) * LDY + lane] = __builtin_bit_cast(unsigned short, vl);
+                if constexpr (W3LDS) {
+                    const int ab = __builtin_amdgcn_readfirstlane(a_b[u]);
+                    const float* s_w3t = reinterpret_cast<const float*>(smem + a.off_w3t);
+                    const float gy = s_w3t[min(max(ab, 0), PW3 - 1) * PW3 + lane] * s;
+                    const _Float16 vh = (_Float16)gy, vl = (_Float16)((gy - (float)vh) * F16_LO_SCALE);      // split on write (qnet.h)
+                    s_gy2p[row * LDY + lane] = __builtin_bit_cast(unsigned short, vh);
+                    s_gy2p[(DENSE_ROWS + row) * LDY + lane] = __builtin_bit_cast(unsigned short, vl);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int n2 = lane + 64 * h;
+                        if (n2 >= 32 * a.KB2) continue;
+                        const float gy = w3r[u][h] * s;
+                        const _Float16 vh = (_Float16)gy, vl = (_Float16)((gy - (float)vh) * F16_LO_SCALE);
+                        s_gy2p[row * LDY + n2] = __builtin_bit_cast(unsigned short, vh);
+                        s_gy2p[(DENSE_ROWS + row) * LDY + n2] = __builtin_bit_cast(unsigned short, vl);
+                    }
+                }
                 // gH1[row] = dq[row][a_b] * Wc[a_b] * [h1 > 0] / (1 - rate): this lane's eight units, split on write into the planes gX reads
                 // (LDS) and the weight gradient reads (HBM)
                 constexpr int LDH = DENSE_HID + 8;
@@ -1910,8 +1941,13 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     if (td && td->metrics && da.dense_tiles > td->metric_slots)    // (the partials are then summed by atomics, in any order: diagnostics only)
         DQ_HIP(hipMemsetAsync(td->metrics + 2, 0, (size_t)td->metric_slots * 2 * sizeof(float), st));
     {
-        void (*dbk)(DenseBwdArgs, EnvParams) = dp.NT2 == 4 ? (td ? dense_bwd_chain_kernel<4, true> : dense_bwd_chain_kernel<4, false>)
-                                                            : (td ? dense_bwd_chain_kernel<7, true> : dense_bwd_chain_kernel<7, false>);
+        // (the TD launch of a dueling network takes the shortcut through the tables pack_weights_kernel built -- W3'^T, Wc --: |A| <= 64 with W3'^T in LDS,
+        // wider ones with its row read from L2)
+        static const bool wide_off = getenv("DQ_DENSE_BWD_WIDE_SHORT") && getenv("DQ_DENSE_BWD_WIDE_SHORT")[0] == '0';      // (A/B runs)
+        const bool wide_short = td && da.N3 > 0 && PL.wc_rows > 0 && !wide_off;
+        void (*dbk)(DenseBwdArgs, EnvParams) = dp.NT2 == 4 ? (td ? dense_bwd_chain_kernel<4, true, true> : dense_bwd_chain_kernel<4, false, true>)
+                                                            : (td ? (wide_short ? dense_bwd_chain_kernel<7, true, true> : dense_bwd_chain_kernel<7, true, false>)
+                                                                  : dense_bwd_chain_kernel<7, false, false>);
         dq_launch(DQ_K_DENSE_BWD, dbk, dim3(da.dense_wgs + stat_wgs), dim3(DENSE_THREADS), lds, st, da, ep);
     }
     DQ_LAUNCH_CHECK();

@@ -9,7 +9,10 @@ dq = importlib.import_module("deepq-decoding_amd")
 bl = importlib.import_module("deepq-decoding_amd.bench_loop")
 tag = int(sys.argv[1]) if len(sys.argv) > 1 else 23
 cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
-loop = bl.FullLoop(dq, cfg, 4096, 0, 1, 4096)
+n = 4096
+if os.environ.get("DQ_STAMP_CFG") == "c5":          # the d = 7 configuration at its per-GPU size
+    cfg, n = dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005), 1024
+loop = bl.FullLoop(dq, cfg, n, 0, 1, n)
 for _ in range(60):
     loop.step(timed=False)
 torch.cuda.synchronize()
