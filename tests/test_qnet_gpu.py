@@ -350,18 +350,20 @@ def test_td_backward_adam_without_a_dueling_layer(dq, torch_mod):
     assert np.abs(g - g_ref).max() < 2e-5 * max(np.abs(g_ref).max(), 1.0)
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
-def test_td_backward_adam_equals_the_separate_calls(dq, torch_mod, fused):
+@pytest.mark.parametrize("fused,shape", [(True, "c3"), (False, "c3"), (True, "c5"), (True, "c3y")], ids=["fused", "per-layer", "fused-99-actions", "fused-76-actions"])
+def test_td_backward_adam_equals_the_separate_calls(dq, torch_mod, fused, shape):
     """dq_qnet_td_backward_adam == dq_td_update_stats + dq_qnet_backward + dq_adam_step: y, dq and the episode counters bit for bit; loss / mean_q
     to round-off (their partials are summed in another order); gradient, parameters and moments bit for bit on the per-layer path and between the
     two forms of the fused TD launch (one call / the several-GPU phases), and to round-off between the fused TD launch and the separate calls:
     with the TD step fused in, dq has one non-zero per row and the fused backward forms gY2 = dq W3'^T as a scalar times a table row instead of on
-    the matrix pipe (csrc/fused_bwd.hip SHORT) -- the f32 MFMA does not round a lone product as the vector ALU's multiply does."""
+    the matrix pipe (csrc/fused_bwd.hip SHORT) -- the f32 MFMA does not round a lone product as the vector ALU's multiply does.  With more than 64
+    actions (c5: 99, c3y: 76) the shortcut reads its table rows from L2 and pack_weights_kernel builds Wc in workgroups of its own; the separate
+    calls' backward takes the matrix phases (gY2, gH1 on the f16 pipe)."""
     torch = torch_mod
     from importlib import import_module
     Q = import_module("deepq-decoding_amd.qnet")
-    B, A, R = 100, 51, 700
-    spec, net, params, flat, obs, rng = _setup(dq, torch, "c3", B, fused=fused)
+    B, A, R = 100, SHAPES[shape][1], 700
+    spec, net, params, flat, obs, rng = _setup(dq, torch, shape, B, fused=fused)
     cu = lambda a: torch.from_numpy(a).cuda()
     obs_t = cu(obs)
     q1o, q1t = (cu(rng.randn(B, A).astype(np.float32)) for _ in range(2))
