@@ -9,6 +9,10 @@ dq = importlib.import_module("deepq-decoding_amd")
 tag = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 C_LAYERS, FF_LAYERS = [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]]
 shape, A, batch = (7, 11, 11), 51, int(os.environ.get("DQ_STAMP_BATCH", 4096))
+PD, PDIST, PLAYERS = 5, 5, 2                 # patch words: syndrome planes, distance, action planes
+if os.environ.get("DQ_STAMP_CFG") == "c5":   # d = 7 depolarising, depth 7, at its per-GPU size
+    shape, A, batch = (9, 15, 15), 99, int(os.environ.get("DQ_STAMP_BATCH", 1024))
+    PD, PDIST, PLAYERS = 7, 7, 2
 net = dq.QNetwork(shape, C_LAYERS, FF_LAYERS, A, max_batch=batch)
 params = net.init_params((11, 22))
 rng = np.random.RandomState(5)
@@ -18,8 +22,9 @@ PATCH = bool(os.environ.get("DQ_STAMP_PATCH"))        # the observations as patc
 jkw = {}
 if PATCH:
     E = importlib.import_module("deepq-decoding_amd.env")
-    net.set_patch_input(5, 32)
-    obs = E.obs_to_patch(E.patch_to_obs(torch.from_numpy(rng.randint(0, 1 << 22, size=(batch, 32)).astype(np.int32)), 5, 5, 2), 5, 5, 2).cuda().contiguous()
+    stride = E.patch_stride_words(PDIST) if hasattr(E, "patch_stride_words") else 32
+    net.set_patch_input(PD, stride)
+    obs = E.obs_to_patch(E.patch_to_obs(torch.from_numpy(rng.randint(0, 1 << (4 * PD + PLAYERS), size=(batch, stride)).astype(np.int32)), PDIST, PD, PLAYERS), PDIST, PD, PLAYERS).cuda().contiguous()
     jkw = dict(patch=True)
     _fwd = net.forward
     net.forward = lambda p, o, **kw: net.forward_multi([dict(params=p, obs=o, **jkw, **kw)])[0]
