@@ -1351,25 +1351,26 @@ struct PackArgs {
 };
 
 // Wc for networks with more than 64 actions (N2, N3 <= 112; qnet.h wc): Wc[a][n1] = P[0] + P[1 + a] - mean_a' P[1 + a'],  P = W2[n1] W3 (the plain
-// product's row, n2 in order).  Workgroups of their own behind the packing ones: the dueling layer's kernel W3 (40 KB at d = 7) is staged in LDS once per
-// workgroup -- read from L2 by every wave it was 13 dependent round trips and the launch 15.6 instead of 6.3 us --; a wave forms WCW_R hidden units, two
-// columns per lane (c = lane, lane + 64), W2's rows through scalar loads.
-#define WCW_R 1
+// product's row).  Workgroups of their own, FIRST in the launch's grid (theirs is its longest chain): the dueling layer's kernel W3 (40 KB at d = 7) is
+// staged in LDS once per workgroup -- read from L2 by every wave it was 13 dependent round trips and the launch 15.6 instead of 6.3 us.  A workgroup forms
+// WCW_U = 4 hidden units; wave w takes the w-th quarter of W3's rows for ALL four (every wave reading all of W3 out of LDS, one unit each, was 160 KB of LDS
+// reads per workgroup: 9.2 us), two columns per lane (c = lane, lane + 64), W2's values by v_readlane; the four partial rows are summed in wave order through LDS
+// and wave u folds and stores unit u.
+#define WCW_U 4
 __device__ __forceinline__ void pack_wide_wc_block(const PackArgs& a, int block, float* s_w3) {
     const float* __restrict__ params = a.params;
     const int A = a.n_actions, N2 = a.N2, N3 = a.N3, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    // this wave's WCW_R rows of W2, two values per lane (n2 = lane, lane + 64; zero past N2), requested first of all
-    float w2v[WCW_R][2];
-    {
-        const int n1w = min(((block * 4 + wave) * WCW_R), DENSE_HID - WCW_R);
+    float* s_part = s_w3 + N2 * N3;                                 // [wave][unit][128]
+    const int n1_0 = min(block * WCW_U, DENSE_HID - WCW_U);
+    // the block's WCW_U rows of W2, two values per lane (n2 = lane, lane + 64; zero past N2), requested first of all
+    float w2v[WCW_U][2];
 #pragma unroll
-        for (int q = 0; q < WCW_R; ++q)
+    for (int q = 0; q < WCW_U; ++q)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float v = params[a.d2_off + (size_t)(n1w + q) * N2 + min(lane + 64 * h, N2 - 1)];
-                w2v[q][h] = lane + 64 * h < N2 ? v : 0.f;
-            }
-    }
+        for (int h = 0; h < 2; ++h) {
+            const float v = params[a.d2_off + (size_t)(n1_0 + q) * N2 + min(lane + 64 * h, N2 - 1)];
+            w2v[q][h] = lane + 64 * h < N2 ? v : 0.f;
+        }
     for (int base = 0; base < N2 * N3; base += 16 * 256) {          // (sixteen loads in flight per thread: one by one they are as many round trips)
         float v[16];
 #pragma unroll
@@ -1381,42 +1382,41 @@ __device__ __forceinline__ void pack_wide_wc_block(const PackArgs& a, int block,
         }
     }
     __syncthreads();
-    const int n1_0 = (block * 4 + wave) * WCW_R;
-    if (n1_0 >= DENSE_HID) return;
     const int c0 = min(lane, N3 - 1), c1 = min(lane + 64, N3 - 1);
-    float acc[WCW_R][2];
+    float acc[WCW_U][2];
 #pragma unroll
-    for (int q = 0; q < WCW_R; ++q) acc[q][0] = acc[q][1] = 0.f;
-#pragma unroll 1
-    for (int n2c = 0; n2c < N2; n2c += 16) {                        // (a chunk of 16 rows lies inside one half of W2's row: its values come out of w2v by v_readlane)
-        float wv[16][2];
+    for (int q = 0; q < WCW_U; ++q) acc[q][0] = acc[q][1] = 0.f;
+    const int quarter = (N2 + 3) >> 2, r0 = wave * quarter, r1 = min(N2, r0 + quarter);
+#pragma unroll 4
+    for (int n2 = r0; n2 < r1; ++n2) {                              // wave-uniform bounds
+        const float x0 = s_w3[n2 * N3 + c0], x1 = s_w3[n2 * N3 + c1];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int rowk = min(n2c + k, N2 - 1) * N3;
-            wv[k][0] = s_w3[rowk + c0]; wv[k][1] = s_w3[rowk + c1];
-        }
-        const int l0 = n2c & 63;
-#pragma unroll
-        for (int q = 0; q < WCW_R; ++q) {
-            const int src = __builtin_bit_cast(int, n2c < 64 ? w2v[q][0] : w2v[q][1]);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(src, l0 + k));      // (zero past N2)
-                acc[q][0] = fmaf(w, wv[k][0], acc[q][0]);
-                acc[q][1] = fmaf(w, wv[k][1], acc[q][1]);
-            }
+        for (int q = 0; q < WCW_U; ++q) {
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n2 < 64 ? w2v[q][0] : w2v[q][1]), n2 & 63));
+            acc[q][0] = fmaf(w, x0, acc[q][0]);
+            acc[q][1] = fmaf(w, x1, acc[q][1]);
         }
     }
+#pragma unroll
+    for (int q = 0; q < WCW_U; ++q) {
+        s_part[(wave * WCW_U + q) * 128 + lane] = acc[q][0];
+        s_part[(wave * WCW_U + q) * 128 + 64 + lane] = acc[q][1];
+    }
+    __syncthreads();
+    if (block * WCW_U + wave >= DENSE_HID) return;
+    const int n1 = block * WCW_U + wave;                            // this wave's unit: its four partial rows in wave order
+    float P[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        P[h] = ((s_part[(0 * WCW_U + wave) * 128 + 64 * h + lane] + s_part[(1 * WCW_U + wave) * 128 + 64 * h + lane]) +
+                s_part[(2 * WCW_U + wave) * 128 + 64 * h + lane]) + s_part[(3 * WCW_U + wave) * 128 + 64 * h + lane];
+    const bool in0 = lane >= 1 && lane <= A, in1 = lane + 64 <= A;  // columns 1 .. A hold the advantages
+    float adv = (in0 ? P[0] : 0.f) + (in1 ? P[1] : 0.f);
+    for (int m = 32; m >= 1; m >>= 1) adv += __shfl_xor(adv, m);
+    const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P[0])));      // lane 0: the V column
     float* wc = reinterpret_cast<float*>(a.pk + a.wc_off);
-#pragma unroll
-    for (int q = 0; q < WCW_R; ++q) {
-        const bool in0 = lane >= 1 && lane <= A, in1 = lane + 64 <= A;      // columns 1 .. A hold the advantages
-        float adv = (in0 ? acc[q][0] : 0.f) + (in1 ? acc[q][1] : 0.f);
-        for (int m = 32; m >= 1; m >>= 1) adv += __shfl_xor(adv, m);
-        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[q][0])));      // lane 0: the V column
-        if (in0) wc[(size_t)(lane - 1) * DENSE_HID + n1_0 + q] = (v0 + acc[q][0]) - adv / (float)A;
-        if (in1) wc[(size_t)(lane + 63) * DENSE_HID + n1_0 + q] = (v0 + acc[q][1]) - adv / (float)A;
-    }
+    if (in0) wc[(size_t)(lane - 1) * DENSE_HID + n1] = (v0 + P[0]) - adv / (float)A;
+    if (in1) wc[(size_t)(lane + 63) * DENSE_HID + n1] = (v0 + P[1]) - adv / (float)A;
 }
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
@@ -1584,7 +1584,7 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.w3q_rows = Q->cfg.dueling ? (D2.nout <= 64 ? 64 : 128) : 0;  // 16 KG3 (dense_chain_kernel: KG3 = NT2 = 4 or 8)
     P.wc = P.w3q + ((size_t)(2 * P.w3q_rows + 1) * 16 * P.NT2 + 3) / 4;      // W3' rows, the bias row, then W3'^T [16 NT2][w3q_rows]
     // Wc (the dense backward's shortcut, fused_bwd.hip SHORT): up to 64 actions built wave by wave, wider ones through an LDS copy of the dueling kernel
-    P.wc_rows = Q->cfg.dueling && (P.NT2 == 4 || (size_t)D2.nout * Q->L[nc + 2].nout * 4 <= 60 * 1024) ? Q->cfg.n_actions : 0;
+    P.wc_rows = Q->cfg.dueling && (P.NT2 == 4 || (size_t)D2.nout * Q->L[nc + 2].nout * 4 <= 52 * 1024) ? Q->cfg.n_actions : 0;
     P.c1c = P.wc + (size_t)P.wc_rows * DENSE_HID / 4;
     P.b1p_rows = Q->L[0].rows <= 64 ? Q->L[0].rows : 0;              // (patch-word input: one word per pixel and lane, d <= 7)
     P.b1p = P.c1c + (P.b1p_rows ? 4 * PK_BLOCK : 0);
@@ -1624,9 +1624,9 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
     // more than 64 actions: Wc by workgroups of their own behind the others, W3 staged in LDS (pack_wide_wc_block)
     const bool wide_wc = PL.wc_rows && PL.NT2 == 8;
-    const int wide_blocks = wide_wc ? (DENSE_HID + 4 * WCW_R - 1) / (4 * WCW_R) : 0;
+    const int wide_blocks = wide_wc ? (DENSE_HID + WCW_U - 1) / WCW_U : 0;
     a.wide_blocks = wide_blocks;
-    pack_weights_kernel<<<a.pack_wgs + wide_blocks, 256, wide_wc ? (size_t)a.N2 * a.N3 * 4 : 0, st>>>(a);
+    pack_weights_kernel<<<a.pack_wgs + wide_blocks, 256, wide_wc ? (size_t)a.N2 * a.N3 * 4 + 4 * WCW_U * 128 * 4 : 0, st>>>(a);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }
