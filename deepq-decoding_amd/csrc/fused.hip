@@ -1387,7 +1387,6 @@ __device__ __forceinline__ void pack_wide_wc_block(const PackArgs& a, int block,
 #pragma unroll
     for (int q = 0; q < WCW_U; ++q) acc[q][0] = acc[q][1] = 0.f;
     const int quarter = (N2 + 3) >> 2, r0 = wave * quarter, r1 = min(N2, r0 + quarter);
-#pragma unroll 4
     for (int n2 = r0; n2 < r1; ++n2) {                              // wave-uniform bounds
         const float x0 = s_w3[n2 * N3 + c0], x1 = s_w3[n2 * N3 + c1];
 #pragma unroll
