@@ -105,7 +105,7 @@ def compare(res):
     episode (against the annealing rule at OUR episode boundaries -- the reference's records obey the same rule to 3e-16, tests/test_host_logic.py);
     mean_q within a factor 2 of the reference's at every checkpoint up to the end of the run, loss within a factor 4 (it is a noisy per-episode
     mean of squared TD errors), the rolling lifetime within a factor 3 while it climbs (a learning curve's position in time varies run to run;
-    the reference has ONE run) and the greedy lifetime at the end of a full-length run within x2.2 of all_results.p (the spread of this build's own seeds is x1.8)."""
+    the reference has ONE run) and the greedy lifetime at the end of a full-length run within x2.2 of all_results.p (the spread of this build's own eight seeds is x2.6)."""
     ours, g, var = res["ours"], res["record"], res["var"]
     S = np.array(ours["nb_steps"])
     rows, ok = [], True
@@ -138,8 +138,8 @@ def compare(res):
             ok &= good
     ref_life = float(g["ref_lifetime"][np.argmin(np.abs(g["ref_test_p"] - float(res["p"])))])
     full = last >= 0.95 * res["fixed"]["max_timesteps"] and res["fixed"]["max_timesteps"] >= 900000
-    # (one run against one run: three seeds of THIS build's replay gave 13.7 k, 17.3 k and 25.0 k at p = 0.001 against the reference's 27.7 k --
-    # profiles/r04_replay_d5_x_0.001_*.json --, the same recipe's agents differ by x1.8 among themselves)
+    # (one run against one run: eight seeds of THIS build's replay gave 13.7 k ... 36.1 k, median 21.2 k, at p = 0.001 against the reference's 27.7 k --
+    # profiles/r04_replay_d5_x_0.001_*.json --, the same recipe's agents differ by x2.6 among themselves)
     good = (ref_life / 2.2 <= res["eval_lifetime"] <= ref_life * 2.2) if full else True
     rows.append((last, f"greedy lifetime at p = {res['p']} ({res['eval_episodes']} episodes; reference: all_results.p, 101 episodes)", res["eval_lifetime"], ref_life, good))
     ok &= good
