@@ -1348,6 +1348,7 @@ struct PackArgs {
     const int* ptab;                    // patch-word input (qnet.h PT_*), NULL: not configured -- the two sections below are left alone
     int c1c_off, b1p_off, b1p_rows;     // u32x4 offsets of the compact first kernel (4 blocks) and of the per-pixel bias table; its rows (pixels)
     int p_depth, p_C, b1_off;           // syndrome planes, input planes, the first bias in params
+    int c1w_off, c1w_blocks, p_kd;      // the wave-private conv forward's first kernel (qnet.h c1w): u32x4 offset, blocks (4 or 0), data bits per word
 };
 
 // Wc for networks with more than 64 actions (N2, N3 <= 112; qnet.h wc): Wc[a][n1] = P[0] + P[1 + a] - mean_a' P[1 + a'],  P = W2[n1] W3 (the plain
@@ -1466,6 +1467,37 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
                     for (int pl = 0; pl < 8; ++pl) if (pl < a.p_depth) acc += (double)w[c][pl];
                 }
                 reinterpret_cast<float*>(pk + a.b1p_off)[(size_t)pix * 64 + lane] = (float)acc;
+            } else if (rc - 4 - a.b1p_rows < a.c1w_blocks) {            // c1w block (half, t): B(k = 8kb + e, col = 32 half + 2j + t), bias folded in (qnet.h)
+                const int bq = rc - 4 - a.b1p_rows, col = 32 * (bq >> 1) + 2 * j + (bq & 1);
+                float v[8], wc[8][8];                                   // (all loads in flight: a run-time trip count = one round trip per term; depth <= 8)
+                int krow[8], cpos[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 8 * kb + e;
+                    krow[e] = a.ptab[PT_KROW + k];
+                    cpos[e] = a.ptab[PT_CPOS + min(max(k - a.p_kd, 0), 4)];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 8 * kb + e;
+                    const bool cst = k >= a.p_kd && k < a.p_kd + 5;
+                    v[e] = k < a.p_kd ? params[a.w1_off + (size_t)max(krow[e], 0) * 64 + col] : k == a.p_kd + 5 ? params[a.b1_off + col] : 0.f;
+#pragma unroll
+                    for (int pl = 0; pl < 8; ++pl) wc[e][pl] = params[a.w1_off + (size_t)((cst ? cpos[e] : 0) * a.p_C + min(pl, a.p_depth - 1)) * 64 + col];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 8 * kb + e;
+                    if (k >= a.p_kd && k < a.p_kd + 5) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int pl = 0; pl < 8; ++pl) if (pl < a.p_depth) acc += (double)wc[e][pl];
+                        v[e] = (float)acc;
+                    }
+                }
+                const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+                u32x4* dst = pk + a.c1w_off + (size_t)bq * PK_BLOCK + lane;
+                dst[0] = o.h; dst[PK_LO] = o.l;
             }
             return;
         }
@@ -1587,7 +1619,9 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.c1c = P.wc + (size_t)P.wc_rows * DENSE_HID / 4;
     P.b1p_rows = Q->L[0].rows <= 64 ? Q->L[0].rows : 0;              // (patch-word input: one word per pixel and lane, d <= 7)
     P.b1p = P.c1c + (P.b1p_rows ? 4 * PK_BLOCK : 0);
-    P.total = P.b1p + (size_t)P.b1p_rows * 64 / 4;
+    P.c1w = P.b1p + (size_t)P.b1p_rows * 64 / 4;
+    P.c1w_blocks = P.b1p_rows ? 4 : 0;                                // (filled when the patch input has K_data + 6 <= 32; the space is there either way)
+    P.total = P.c1w + (size_t)P.c1w_blocks * PK_BLOCK;
     return P;
 }
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return fused_pack_layout(Q).total; }
@@ -1618,8 +1652,9 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     a.wc_off = (int)PL.wc; a.wc_waves = PL.wc_rows && PL.NT2 == 4 ? DENSE_HID : 0;      // (more than 64 actions: workgroups of their own, below)
     a.ptab = Q->patch_depth && PL.b1p_rows ? Q->ptab : nullptr;
     a.c1c_off = (int)PL.c1c; a.b1p_off = (int)PL.b1p; a.b1p_rows = PL.b1p_rows; a.p_depth = Q->patch_depth; a.p_C = Q->L[0].cin; a.b1_off = (int)Q->L[0].b_off;
+    a.c1w_off = (int)PL.c1w; a.p_kd = Q->patch_kd; a.c1w_blocks = a.ptab && Q->patch_kd + 6 <= 32 ? PL.c1w_blocks : 0;
     a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + a.wc_waves +
-                  (a.ptab ? 4 + PL.b1p_rows : 0) + 3) / 4;
+                  (a.ptab ? 4 + PL.b1p_rows + a.c1w_blocks : 0) + 3) / 4;
     // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
     // more than 64 actions: Wc by workgroups of their own behind the others, W3 staged in LDS (pack_wide_wc_block)
     const bool wide_wc = PL.wc_rows && PL.NT2 == 8;
@@ -1962,7 +1997,18 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
     }
     for (int i = n_jobs; i < FWD_MAX_JOBS; ++i) ca.wg_first[i] = da.wg_first[i] = 0x7fffffff;
-    if (can_persist && (conv_wgs > pp.per_cu * n_cu || persist_env == 2)) {
+    // the wave-private form (conv_wave.hip) for patch words at d = 5; DQ_CONV_FORM=group keeps the workgroup-per-group kernels (read per call: tests flip it)
+    const char* cf = getenv("DQ_CONV_FORM");
+    if (patch && conv_wave_supported(Q) && !(cf && cf[0] == 'g')) {
+        ConvWaveArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        for (int i = 0; i < n_jobs; ++i) wa.job[i] = ca.job[i];
+        wa.n_jobs = n_jobs;
+        for (int l = 0; l < 3; ++l) wa.b_off[l] = ca.b_off[l];
+        wa.slot = cp.slot; wa.pk_c1w = (int)PL.c1w; wa.kd = Q->patch_kd; wa.ptab = Q->ptab;
+        const dq_status rc = conv_wave_launch(Q, wa, n_cu, st);
+        if (rc != DQ_OK) return rc;
+    } else if (can_persist && (conv_wgs > pp.per_cu * n_cu || persist_env == 2)) {
         ca.total_groups = conv_wgs; ca.off_t1 = pp.off_t1; ca.off_obs1 = pp.off_obs1; ca.off_a2b = pp.off_a2b; ca.off_a1 = pp.off_a1; ca.off_mis = pp.off_mis;
         ca.off_lut = pp.off_lut;
         int grid = pp.per_cu * n_cu;

@@ -230,7 +230,10 @@ struct ConvJob {
 //   wc       f32 [|A|][512]                      Wc = W3'^T W2^T (Dense(|A|) folded in as well): row a = gH1 of a sample whose dq is 1 at action a               backward, gH1 (TD launch)
 //   c1c      [1 k-block][4 column tiles]         the first convolution over patch words: B(k = 8kb + e, col = 4j + t) = W1[PT_KROW[k]][col], 0 past the data bits
 //   b1p      f32 [r1][64]                        its per-pixel bias: b1[c] + the kernel rows of the pixel's constant-1 cells (summed in double)
-struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, c1c, b1p, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows, b1p_rows; };   // offsets in u32x4
+//   c1w      [2 channel halves][2 column tiles]  the same kernel for conv_wave.hip, the per-pixel bias folded into the contraction: rows k < K_data as c1c; row K_data + c
+//                                                = the kernel rows of constant position c summed over the syndrome planes (in double); row K_data + 5 = b1; then 0.
+//                                                B(k = 8kb + e, col = 32 half + 2j + t).  Present when K_data + 6 <= 32 (c1w_blocks = 4, else 0)
+struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, c1c, b1p, c1w, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows, b1p_rows, c1w_blocks; };   // offsets in u32x4
 PackLayout fused_pack_layout(const dq_qnet* Q);
 static inline int dq_planes_small_ld(const dq_qnet* Q) { return Q->cfg.n_actions + 1 <= 64 ? 64 : 128; }
 static inline size_t dq_planes_halves(const dq_qnet* Q) {      // total size of dq_qnet.planes
@@ -257,6 +260,20 @@ bool fused_conv_bwd_row_tables(const dq_qnet* Q, int* tab);  // tab: int[5 * CON
 bool fused_patch_supported(const dq_qnet* Q, int depth);     // patch-word input possible for this network with `depth` syndrome planes
 void fused_patch_tables(const dq_qnet* Q, int depth, int stride_words, int* tab);      // tab: int[PT_TOTAL]
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
+// conv_wave.hip: the conv forward's wave-private form (one sample per wave, weights in LDS, no barriers): patch-word input, d = 5
+struct ConvWaveArgs {
+    ConvJob job[FWD_MAX_JOBS];
+    int n_jobs;
+    int cls_wg0[FWD_MAX_JOBS], cls_wgs[FWD_MAX_JOBS];   // per job: first workgroup / workgroups of its weight set (jobs with the same packed buffer share them)
+    int q[FWD_MAX_JOBS], m[FWD_MAX_JOBS];               // batch / cls_wgs, batch % cls_wgs: workgroup r of the set takes q + (r < m) samples from r q + min(r, m)
+    int b_off[3];                                       // floats into params: the three biases
+    int slot;                                           // bytes per observation row (4 * patch_stride)
+    int pk_c1w;                                         // u32x4 offset of the c1w section inside a packed buffer
+    int kd;                                             // data bits per patch word
+    const int* ptab;                                    // PT_* tables
+};
+bool conv_wave_supported(const dq_qnet* Q);
+dq_status conv_wave_launch(const dq_qnet* Q, ConvWaveArgs& a, int n_cu, hipStream_t st);
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
 dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_t st);
