@@ -1349,6 +1349,7 @@ struct PackArgs {
     int c1c_off, b1p_off, b1p_rows;     // u32x4 offsets of the compact first kernel (4 blocks) and of the per-pixel bias table; its rows (pixels)
     int p_depth, p_C, b1_off;           // syndrome planes, input planes, the first bias in params
     int c1w_off, c1w_blocks, p_kd;      // the wave-private conv forward's first kernel (qnet.h c1w): u32x4 offset, blocks (4 or 0), data bits per word
+    int c2w_off, c2w_blocks;            // ... and its second (qnet.h c2w): 16 blocks or 0
 };
 
 // Wc for networks with more than 64 actions (N2, N3 <= 112; qnet.h wc): Wc[a][n1] = P[0] + P[1 + a] - mean_a' P[1 + a'],  P = W2[n1] W3 (the plain
@@ -1467,8 +1468,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
                     for (int pl = 0; pl < 8; ++pl) if (pl < a.p_depth) acc += (double)w[c][pl];
                 }
                 reinterpret_cast<float*>(pk + a.b1p_off)[(size_t)pix * 64 + lane] = (float)acc;
-            } else if (rc - 4 - a.b1p_rows < a.c1w_blocks) {            // c1w block (half, t): B(k = 8kb + e, col = 32 half + 2j + t), bias folded in (qnet.h)
-                const int bq = rc - 4 - a.b1p_rows, col = 32 * (bq >> 1) + 2 * j + (bq & 1);
+            } else if (rc - 4 - a.b1p_rows < a.c1w_blocks) {            // c1w block (quarter): B(k = 8kb + e, col = 16 quarter + j), bias folded in (qnet.h)
+                const int bq = rc - 4 - a.b1p_rows, col = 16 * bq + j;
                 float v[8], wc[8][8];                                   // (all loads in flight: a run-time trip count = one round trip per term; depth <= 8)
                 int krow[8], cpos[8];
 #pragma unroll
@@ -1497,6 +1498,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
                 }
                 const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
                 u32x4* dst = pk + a.c1w_off + (size_t)bq * PK_BLOCK + lane;
+                dst[0] = o.h; dst[PK_LO] = o.l;
+            } else if (rc - 4 - a.b1p_rows - a.c1w_blocks < a.c2w_blocks) {    // c2w block (quarter, ky, t) (qnet.h)
+                const int b = rc - 4 - a.b1p_rows - a.c1w_blocks, t = b & 1, ky = (b >> 1) & 1, qt = b >> 2;
+                const float* w = params + w2_off + (size_t)((2 * ky + (kb >> 1)) * 64 + 16 * qt + 8 * (kb & 1)) * 32 + 2 * j + t;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = w[(size_t)e * 32];
+                const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+                u32x4* dst = pk + a.c2w_off + (size_t)b * PK_BLOCK + lane;
                 dst[0] = o.h; dst[PK_LO] = o.l;
             }
             return;
@@ -1621,7 +1631,9 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.b1p = P.c1c + (P.b1p_rows ? 4 * PK_BLOCK : 0);
     P.c1w = P.b1p + (size_t)P.b1p_rows * 64 / 4;
     P.c1w_blocks = P.b1p_rows ? 4 : 0;                                // (filled when the patch input has K_data + 6 <= 32; the space is there either way)
-    P.total = P.c1w + (size_t)P.c1w_blocks * PK_BLOCK;
+    P.c2w = P.c1w + (size_t)P.c1w_blocks * PK_BLOCK;
+    P.c2w_blocks = P.c1w_blocks ? 16 : 0;
+    P.total = P.c2w + (size_t)P.c2w_blocks * PK_BLOCK;
     return P;
 }
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return fused_pack_layout(Q).total; }
@@ -1653,8 +1665,9 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     a.ptab = Q->patch_depth && PL.b1p_rows ? Q->ptab : nullptr;
     a.c1c_off = (int)PL.c1c; a.b1p_off = (int)PL.b1p; a.b1p_rows = PL.b1p_rows; a.p_depth = Q->patch_depth; a.p_C = Q->L[0].cin; a.b1_off = (int)Q->L[0].b_off;
     a.c1w_off = (int)PL.c1w; a.p_kd = Q->patch_kd; a.c1w_blocks = a.ptab && Q->patch_kd + 6 <= 32 ? PL.c1w_blocks : 0;
+    a.c2w_off = (int)PL.c2w; a.c2w_blocks = a.c1w_blocks ? PL.c2w_blocks : 0;
     a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + a.wc_waves +
-                  (a.ptab ? 4 + PL.b1p_rows + a.c1w_blocks : 0) + 3) / 4;
+                  (a.ptab ? 4 + PL.b1p_rows + a.c1w_blocks + a.c2w_blocks : 0) + 3) / 4;
     // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
     // more than 64 actions: Wc by workgroups of their own behind the others, W3 staged in LDS (pack_wide_wc_block)
     const bool wide_wc = PL.wc_rows && PL.NT2 == 8;
@@ -1815,6 +1828,7 @@ void fused_patch_tables(const dq_qnet* Q, int depth, int stride_words, int* tab)
         tab[PT_FWD + m] = s << 20 | 4 * pix;
         tab[PT_BWD + m] = (s * stride_words + pix) | tab[PT_CONST + pix] << 16;
     }
+    conv_wave_lane_table(Q, kd, tab + PT_CONST, tab + PT_WAVE);
 }
 
 struct DensePlan { int ldx, ld2, ld3, off_x, off_h, off_part, off_y2, off_y3, NT2; size_t lds; };
@@ -2005,7 +2019,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         for (int i = 0; i < n_jobs; ++i) wa.job[i] = ca.job[i];
         wa.n_jobs = n_jobs;
         for (int l = 0; l < 3; ++l) wa.b_off[l] = ca.b_off[l];
-        wa.slot = cp.slot; wa.pk_c1w = (int)PL.c1w; wa.kd = Q->patch_kd; wa.ptab = Q->ptab;
+        wa.slot = cp.slot; wa.pk_c1w = (int)PL.c1w; wa.pk_c2w = (int)PL.c2w; wa.kd = Q->patch_kd; wa.ptab = Q->ptab;
         const dq_status rc = conv_wave_launch(Q, wa, n_cu, st);
         if (rc != DQ_OK) return rc;
     } else if (can_persist && (conv_wgs > pp.per_cu * n_cu || persist_env == 2)) {

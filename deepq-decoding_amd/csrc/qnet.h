@@ -13,7 +13,9 @@
 #define PT_CONST 136                 // [64] pixel p -> 5-bit mask of its constant-1 positions on the syndrome planes
 #define PT_FWD 200                   // [CONV_ROWTAB] forward: row m of a workgroup's S samples -> s << 20 | 4 p
 #define PT_BWD (PT_FWD + CONV_ROWTAB)    // [CONV_ROWTAB] backward: row m -> (s * stride_words + p) | constant mask << 16
-#define PT_TOTAL (PT_BWD + CONV_ROWTAB)
+#define PT_WAVE (PT_BWD + CONV_ROWTAB)    // [64][PT_WAVE_LD] conv_wave.hip: the per-lane constants of its prologue (conv_wave_lane_table), 16-byte aligned rows
+#define PT_WAVE_LD 20
+#define PT_TOTAL (PT_WAVE + 64 * PT_WAVE_LD)
 
 struct Layer {
     int kind;                    // 0 conv, 1 dense
@@ -230,10 +232,13 @@ struct ConvJob {
 //   wc       f32 [|A|][512]                      Wc = W3'^T W2^T (Dense(|A|) folded in as well): row a = gH1 of a sample whose dq is 1 at action a               backward, gH1 (TD launch)
 //   c1c      [1 k-block][4 column tiles]         the first convolution over patch words: B(k = 8kb + e, col = 4j + t) = W1[PT_KROW[k]][col], 0 past the data bits
 //   b1p      f32 [r1][64]                        its per-pixel bias: b1[c] + the kernel rows of the pixel's constant-1 cells (summed in double)
-//   c1w      [2 channel halves][2 column tiles]  the same kernel for conv_wave.hip, the per-pixel bias folded into the contraction: rows k < K_data as c1c; row K_data + c
+//   c1w      [4 channel quarters]                the same kernel for conv_wave.hip, the per-pixel bias folded into the contraction: rows k < K_data as c1c; row K_data + c
 //                                                = the kernel rows of constant position c summed over the syndrome planes (in double); row K_data + 5 = b1; then 0.
-//                                                B(k = 8kb + e, col = 32 half + 2j + t).  Present when K_data + 6 <= 32 (c1w_blocks = 4, else 0)
-struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, c1c, b1p, c1w, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows, b1p_rows, c1w_blocks; };   // offsets in u32x4
+//                                                B(k = 8kb + e, col = 16 quarter + j) -- read as the FIRST operand there (rows = channels: the transposed product).
+//                                                Present when K_data + 6 <= 32 (c1w_blocks = 4, else 0)
+//   c2w      [4 quarters][2 ky][2 column tiles]  the second convolution for conv_wave.hip: a K block = the taps (ky, 0), (ky, 1) x 16 input channels:
+//                                                B(slot (kb, e), col = 2j + t) = W2[(2 ky + (kb >> 1)) * 64 + 16 quarter + 8 (kb & 1) + e][col]
+struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, c1c, b1p, c1w, c2w, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows, b1p_rows, c1w_blocks, c2w_blocks; };   // offsets in u32x4
 PackLayout fused_pack_layout(const dq_qnet* Q);
 static inline int dq_planes_small_ld(const dq_qnet* Q) { return Q->cfg.n_actions + 1 <= 64 ? 64 : 128; }
 static inline size_t dq_planes_halves(const dq_qnet* Q) {      // total size of dq_qnet.planes
@@ -264,16 +269,28 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
 struct ConvWaveArgs {
     ConvJob job[FWD_MAX_JOBS];
     int n_jobs;
-    int cls_wg0[FWD_MAX_JOBS], cls_wgs[FWD_MAX_JOBS];   // per job: first workgroup / workgroups of its weight set (jobs with the same packed buffer share them)
-    int q[FWD_MAX_JOBS], m[FWD_MAX_JOBS];               // batch / cls_wgs, batch % cls_wgs: workgroup r of the set takes q + (r < m) samples from r q + min(r, m)
+    // weight sets: jobs with the same packed buffer and parameters.  A set's pairs of samples -- job after job, a job's pairs (2 i, 2 i + 1) -- form ONE list of
+    // end[3] pairs; workgroup r of the set's `wgs` takes the pairs r, r + wgs, ...: every workgroup gets the same number (+- 1) and the same share of every job
+    // (the training job's stores are spread over all of them)
+    struct Set {
+        const u32x4* packed;
+        const float* params;
+        int wg0, wgs;                                   // first workgroup (INT_MAX: no such set), workgroups
+        int job[FWD_MAX_JOBS];                          // its jobs in list order (padded with the last)
+        int end[FWD_MAX_JOBS];                          // end of each job's pairs in the list (padded with the total)
+        int batch[FWD_MAX_JOBS];                        // the jobs' sample counts
+    } set[FWD_MAX_JOBS];
+    int set_wg0[FWD_MAX_JOBS];                          // = set[c].wg0: the set of a workgroup by three comparisons on one scalar load ...
+    const u32x4* set_packed[FWD_MAX_JOBS];              // ... which also brings the sets' packed buffers: the weight copies go out one round trip after entry
     int b_off[3];                                       // floats into params: the three biases
     int slot;                                           // bytes per observation row (4 * patch_stride)
-    int pk_c1w;                                         // u32x4 offset of the c1w section inside a packed buffer
+    int pk_c1w, pk_c2w;                                 // u32x4 offsets of the c1w / c2w sections inside a packed buffer
     int kd;                                             // data bits per patch word
     const int* ptab;                                    // PT_* tables
 };
 bool conv_wave_supported(const dq_qnet* Q);
 dq_status conv_wave_launch(const dq_qnet* Q, ConvWaveArgs& a, int n_cu, hipStream_t st);
+void conv_wave_lane_table(const dq_qnet* Q, int kd, const int* pt_const, int* out);      // out: int[64 * PT_WAVE_LD] (qnet.h PT_WAVE)
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
 dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_t st);
