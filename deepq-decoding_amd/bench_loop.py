@@ -1,6 +1,7 @@
 """Full hot-path loop used by bench.py: per vector step every lattice acts (Q forward + epsilon-greedy over
 legal moves), the environment kernel steps them into the replay ring, and one DQN minibatch update runs."""
 import ctypes
+import os
 
 import torch
 
@@ -165,7 +166,14 @@ class FullLoop:
             kd = 4 * self.env.volume_depth + self.env.n_action_layers
             c1_fwd = 2.0 * lm[0] * 32.0 / K1
             c1_bwd = 2.0 * lm[0] * (16.0 * ((kd + 5 + 15) // 16)) / K1
-        return {"conv_chain_kernel": (c1_fwd + 3.0 * rest) / conv,
+        conv_fwd = (c1_fwd + 3.0 * rest) / conv
+        d = self.env.d
+        if getattr(self.core, "compact", False) and d == 5 and 4 * self.env.volume_depth + self.env.n_action_layers + 6 <= 32 \
+                and os.environ.get("DQ_CONV_FORM", "w")[:1] != "g":
+            # the wave-private form (csrc/conv_wave.hip): whole 16-row tiles per sample -- 2 tiles for conv1's 25 pixels, one for conv2's 16 and for
+            # conv3's 9 -- so the ISSUED count includes the padding rows: 2 x 32 x 64 x 32 + 3 x 16 x 32 x 256 + 3 x 16 x 32 x 128 MACs per sample
+            conv_fwd = (2.0 * 32 * 64 * 32 + 3.0 * 16 * 32 * 256 + 3.0 * 16 * 32 * 128) / conv
+        return {"conv_chain_kernel": conv_fwd,
                 "conv_bwd_chain_kernel": (c1_bwd + 3.0 * rest + 3.0 * rest) / (conv + rest),     # weight gradients + data gradients
                 "dense_chain_kernel": 3.0, "dense_bwd_chain_kernel": 3.0, "dense_wgrad_kernel": 3.0}
 

@@ -110,20 +110,25 @@ def test_forward_from_patch_words(dq, torch_mod, name, batch):
     assert np.abs(q_pw - q_ref).max() < tol(q_ref), ("patch words vs float64", np.abs(q_pw - q_ref).max())
     assert np.abs(q_u8 - q_ref).max() < tol(q_ref)
     assert np.abs(q_pw - q_u8).max() < tol(q_ref), ("patch words vs uint8 image", np.abs(q_pw - q_u8).max())
-    # the persistent kernel and the one-group kernel give the same bits (as for the uint8 form)
+    # the workgroup-per-group kernels (DQ_CONV_FORM=group; the default at d = 5 is the wave-private form, csrc/conv_wave.hip): the persistent kernel and
+    # the one-group kernel give the same bits (as for the uint8 form), and the same Q-values as the default form to round-off
     import os
-    old = os.environ.get("DQ_CONV_PERSIST")
+    old = {k: os.environ.get(k) for k in ("DQ_CONV_PERSIST", "DQ_CONV_FORM")}
     try:
+        os.environ["DQ_CONV_FORM"] = "group"
         os.environ["DQ_CONV_PERSIST"] = "2"
         q_p = net.forward_multi([dict(params=params, obs=patch, patch=True)])[0].cpu().numpy()
         os.environ["DQ_CONV_PERSIST"] = "0"
         q_1 = net.forward_multi([dict(params=params, obs=patch, patch=True)])[0].cpu().numpy()
     finally:
-        if old is None:
-            os.environ.pop("DQ_CONV_PERSIST", None)
-        else:
-            os.environ["DQ_CONV_PERSIST"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     assert np.array_equal(q_p, q_1)
+    assert np.abs(q_p - q_ref).max() < tol(q_ref)
+    assert np.abs(q_p - q_pw).max() < 0.2 * tol(q_ref), ("the two forms of the conv forward", np.abs(q_p - q_pw).max())
 
 
 def test_forward_from_patch_words_with_replay_gather_and_four_jobs(dq, torch_mod):
@@ -149,6 +154,57 @@ def test_forward_from_patch_words_with_replay_gather_and_four_jobs(dq, torch_mod
     # the two forms do not mix in one launch
     with pytest.raises(Exception):
         net.forward_multi([jobs[0], dict(params=params, obs=torch.from_numpy(ring).cuda(), batch=8)])
+
+
+@pytest.mark.parametrize("name", ["c3", "c2", "c3y"])
+def test_wave_private_conv_forward(dq, torch_mod, monkeypatch, name):
+    """csrc/conv_wave.hip (the default conv forward for patch words at d = 5: one workgroup of 16 waves per CU, two samples of one job per wave at a
+    time, packed weights in LDS, a job's samples dealt over the workgroups of its weight set) against the float64 oracle and against the
+    workgroup-per-group kernels: batches of 1, 2, 3 and odd counts (a wave's second sample missing), four jobs with two weight sets of very different
+    sizes, a replay gather with wrap-around, more pairs than waves (several trips per wave) and fewer; the training job's saved activations
+    through the gradient the backward computes from them; every job alone gives the bits it gives in the shared launch."""
+    torch = torch_mod
+    spec, net, params, flat, obs, patch, rng = _setup(dq, torch, name, 4099)
+    params2 = (params + 0.03 * torch.randn_like(params)).contiguous()
+    flat2 = params2.cpu().numpy()
+    obs_t = patch
+    idx = rng.randint(0, 4099, size=777).astype(np.int32)
+    idx_t = torch.from_numpy(idx).cuda()
+    dq_ = torch.from_numpy((rng.randn(333, spec.n_actions) / 333).astype(np.float32)).cuda()
+    pk1, pk2 = net.pack(params), net.pack(params2)
+
+    def run():
+        jobs = [dict(params=params, obs=obs_t[:4099], packed=pk1, patch=True),
+                dict(params=params2, obs=obs_t[:3], packed=pk2, patch=True),
+                dict(params=params, obs=obs_t[500:], batch=333, training=True, seed=(5, 6), t=77, packed=pk1, patch=True),
+                dict(params=params2, obs=obs_t, index=idx_t, index_off=4099 - 50, index_mod=4099, packed=pk2, patch=True)]
+        qs = [q.clone() for q in net.forward_multi(jobs)]
+        g = net.backward(params, dq_).clone()
+        alone = [net.forward_multi([jb])[0].clone() for jb in (jobs[0], jobs[1], jobs[3])]
+        tiny = [net.forward_multi([dict(params=params, obs=obs_t[7:7 + n], packed=pk1, patch=True)])[0].clone() for n in (1, 2, 3, 31, 33)]
+        return qs, g, alone, tiny
+
+    monkeypatch.delenv("DQ_CONV_FORM", raising=False)
+    qs, g, alone, tiny = run()
+    refs = [O.forward(spec, flat, obs[:4099])[0], O.forward(spec, flat2, obs[:3])[0], None, O.forward(spec, flat2, obs[(idx + 4099 - 50) % 4099])[0]]
+    for q, r in zip(qs, refs):
+        if r is not None:
+            assert np.abs(q.cpu().numpy() - r).max() < tol(r)
+    for a, q in zip(alone, (qs[0], qs[1], qs[3])):
+        assert torch.equal(a, q)
+    for n, q in zip((1, 2, 3, 31, 33), tiny):
+        assert torch.equal(q, qs[0][7:7 + n]), n
+    monkeypatch.setenv("DQ_CONV_FORM", "group")
+    qs_g, g_g, _, tiny_g = run()
+    for a, b, r in zip(qs, qs_g, refs):
+        scale = tol(b.cpu().numpy())
+        assert (a - b).abs().max().item() < 0.2 * scale
+    # the gradient from the wave form's saved a1 / a2 planes against the one from the group form's
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    assert (g - g_g).abs().max().item() <= 2e-6 * max(1.0, float(g_g.abs().max()))
+    for (gk, gb), (rk, rb) in zip(spec.split(g.cpu().numpy()), spec.split(g_g.cpu().numpy())):
+        for a, b in ((gk, rk), (gb, rb)):
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 1e-8
 
 
 @pytest.mark.parametrize("name,batch", [("c1", 8), ("c2", 40), ("c3", 32), ("c3", 257), ("c3", 4096), ("c5", 48), ("c5", 1024), ("c3y", 70), ("d7x", 45), ("d3dp", 130)])
