@@ -273,6 +273,7 @@ def main():
     else:
         runner = importlib.import_module("deepq-decoding_amd.bench_loop").FullLoop(
             dq, cfg, n_local, rank, world, args.minibatch or n_local, mode=mode, config_name=args.config, updates_per_step=max(1, args.updates_per_step))
+        runner.pmc_minibatch, runner.pmc_lattices = int(args.minibatch or 0), int(args.lattices or 0)
 
     def sync():
         if world > 1 or force_dist:
@@ -281,6 +282,21 @@ def main():
 
     if (world > 1 or force_dist) and hasattr(runner, "core") and os.environ.get("DQ_DIST_MODE", "single") in ("single", "overlap"):
         runner.core.ensure_comm()       # the learner's own communicator: its rendezvous belongs to the set-up, also with --warmup 0
+    rccl_ranks = 0
+    if world > 1 or force_dist:
+        # pre-flight (untimed): one all-reduce of a rank-stamped vector, checked against what `world` ranks must give, so that a mis-joined communicator
+        # fails loudly here instead of producing a plausible line; rccl_ranks is ncclCommCount's answer, not WORLD_SIZE
+        comm = getattr(getattr(runner, "core", None), "_rccl", None)
+        if comm is not None:
+            rccl_ranks = comm.preflight()
+        else:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            v = (float(rank) + torch.arange(64, dtype=torch.float32, device=dev) / 8.0)
+            dist.all_reduce(v)
+            want = world * (world - 1) / 2.0 + world * torch.arange(64, dtype=torch.float32, device=dev) / 8.0
+            if not torch.equal(v, want):
+                raise RuntimeError(f"pre-flight all-reduce over {world} ranks returned {v[:4].tolist()} ..., expected {want[:4].tolist()} ... (rank {rank})")
+            rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
     for _ in range(args.warmup):
         runner.step(timed=False)
     if hasattr(runner, "pick_dominant"):
@@ -357,7 +373,7 @@ def main():
         if params_checksum is not None:
             out["params_checksum"] = params_checksum
         if world > 1 or force_dist:
-            out["rccl_ranks"] = world if backend == "nccl" else 0
+            out["rccl_ranks"] = rccl_ranks                            # (from ncclCommCount behind a checked pre-flight all-reduce, above)
             out["dist_backend"] = "rccl" if backend == "nccl" else backend
             out["replicas_identical"] = replicas_identical
             out["allreduce"] = allreduce

@@ -366,7 +366,8 @@ class DQNAgent:
     def get_config(self):
         return dict(nb_actions=self.nb_actions, gamma=self.gamma, batch_size=self.batch_size, nb_steps_warmup=self.nb_steps_warmup,
                     train_interval=self.train_interval, target_model_update=self.target_model_update,
-                    enable_double_dqn=self.enable_double_dqn, enable_dueling_network=self.enable_dueling_network, dueling_type='avg')
+                    enable_double_dqn=self.enable_double_dqn, enable_dueling_network=self.enable_dueling_network, dueling_type='avg',
+                    updates_per_vector_step=self.updates_per_vector_step)
 
     # -- binding to an environment ------------------------------------------------------------------------------
     def _bind(self, env):
@@ -572,6 +573,12 @@ class DQNAgent:
                     stop = True
         except KeyboardInterrupt:
             pass
+        except BaseException:
+            # (a DeepQError -- e.g. DQ_ERR_RANGE, raised on every rank at the same synchronisation --, or anything else: the communicator does not outlive
+            # fit(); aborted, not destroyed: a destroy may wait for peers that are inside a collective this rank will never join)
+            core.close_comm(abort=True)
+            self.training = False
+            raise
         torch.cuda.synchronize(core.device)
         core.close_comm()               # (every rank, everything drained: before the process group that did its rendezvous can be destroyed)
         dt = timeit.default_timer() - t_start

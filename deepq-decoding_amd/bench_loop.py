@@ -33,11 +33,12 @@ def csrc_digest():
     return h.hexdigest()
 
 
-def pmc_traffic(kernel, mode="loop", config="c3"):
+def pmc_traffic(kernel, mode="loop", config="c3", minibatch=0, updates_per_step=1, lattices=0):
     """HBM bytes per launch of `kernel` from the committed PMC pass profiles/pmc_traffic_<mode>_<config>.json (tools/pmc_traffic.sh:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied).  PMC counters cannot be collected
-    inside a timed run, so this is a recorded value -- valid only for the kernel sources it was taken with: the file carries their
-    sha256 (csrc_digest) and anything else (stale pass, missing file, unknown kernel) gives None."""
+    inside a timed run, so this is a recorded value -- valid only for the kernel sources it was taken with AND for the launch shape it was
+    taken at: the file carries the sources' sha256 (csrc_digest) and the pass's minibatch / updates per step / lattices (0 = the
+    configuration's default); anything else (stale pass, another shape, missing file, unknown kernel) gives None."""
     import json
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"pmc_traffic_{mode}_{config}.json")
@@ -46,9 +47,16 @@ def pmc_traffic(kernel, mode="loop", config="c3"):
             rec = json.load(f)
         if rec.get("csrc_sha256") != csrc_digest():
             return None
-        ks = rec["kernels"]                      # (the conv forward's persistent form -- the step's launch -- reports as conv_chain_pkernel; the
-        alt = kernel.replace("_kernel", "_pkernel")   #  one-group kernel of the same pass only ran the few small launches at start-up)
-        return (ks[alt] if alt in ks else ks[kernel])["hbm_bytes_per_launch_corrected"]
+        shape = rec.get("shape", {"minibatch": 0, "updates_per_step": 1, "lattices": 0})
+        if (int(shape.get("minibatch", 0)), int(shape.get("updates_per_step", 1)), int(shape.get("lattices", 0))) != (int(minibatch), int(updates_per_step), int(lattices)):
+            return None
+        ks = rec["kernels"]
+        # the conv forward family's step launch is conv_wave_kernel (patch words, d = 5), else the persistent conv_chain_pkernel, else conv_chain_kernel
+        names = ("conv_wave_kernel", "conv_chain_pkernel", "conv_chain_kernel") if kernel == "conv_chain_kernel" else (kernel,)
+        for name in names:
+            if name in ks:
+                return ks[name]["hbm_bytes_per_launch_corrected"]
+        return None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -104,6 +112,7 @@ class FullLoop:
         self.macs = sum(self.layer_macs)
         self.L = _lib.lib()
         self.prof_family = None
+        self.pmc_minibatch = self.pmc_lattices = 0    # what bench.py was ASKED for (0 = the configuration's default): the key of the recorded PMC pass (pmc_traffic)
 
     def _layer_macs(self):
         """Multiply-accumulates per sample of each layer (conv1 100800, conv2 131072, conv3 36864, dense 147456,
@@ -259,7 +268,7 @@ class FullLoop:
                 # pipe's dense peak divided by that (frac = issued f16 flops / f16 peak); the f32-input MFMA peak is quoted beside it
                 peak = MFMA_F16_PEAK_TFLOPS / issued if issued else MFMA_F32_PEAK_TFLOPS
                 roof = dict(kernel=self.prof_family, bound=bound, achieved=achieved, peak=peak, unit="TFLOP/s",
-                            frac=achieved / peak, traffic=pmc_traffic(self.prof_family, self.mode, self.config_name), avg_launch_us=avg_s * 1e6,
+                            frac=achieved / peak, traffic=pmc_traffic(self.prof_family, self.mode, self.config_name, self.pmc_minibatch, self.k, self.pmc_lattices), avg_launch_us=avg_s * 1e6,
                             launches_timed=launches, algorithmic_flops_per_launch=per_launch)
                 if issued:
                     roof["pipe"] = dict(name="f16 MFMA (v_mfma_f32_16x16x32_f16)", peak=MFMA_F16_PEAK_TFLOPS, issued_tflops=achieved * issued,

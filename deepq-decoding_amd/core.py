@@ -81,7 +81,7 @@ class DQNCore:
         self.enable_double_dqn = enable_double_dqn
         self.seed = tuple(env.seed) if seed is None else tuple(seed)
         self.rank, self.world_size, self.pg = rank, world_size, process_group
-        self._rccl, self._rccl_tried = None, False       # the learner's own RCCL communicator (dist.make_rccl), created at the first several-GPU update
+        self._rccl, self._rccl2, self._rccl_tried = None, None, False       # the learner's own RCCL communicator (dist.make_rccl), created at the first several-GPU update
         self.L = _lib.lib()
         dev = self.device
         # ring
@@ -148,7 +148,8 @@ class DQNCore:
         # DQ_TD_AUTOSCALE=1 (or auto_scale = True): the fused backward's gradient scale MEASURED from every minibatch's TD errors (dq_td_job.auto_scale: one
         # small launch per update, +3 us; any finite TD error is carried -- keras-rl's delta_clip = inf).  Default: the host-known scale (TD errors up to
         # several thousand -- the reference's recorded losses stay below 160 --; a larger one makes the WHOLE update a no-op on every rank and
-        # read_metrics() raise DQ_ERR_RANGE at the next synchronisation: nothing is ever partially applied)
+        # read_metrics() at the next synchronisation switches this on for good, with a warning (DQ_TD_AUTOSCALE=0: raises DQ_ERR_RANGE instead):
+        # nothing is ever partially applied)
         self.auto_scale = os.environ.get("DQ_TD_AUTOSCALE", "0") == "1"
         self.local_stats = [0, 0, 0, 0]
         self.inexact_total = 0
@@ -253,10 +254,14 @@ class DQNCore:
             check(self.L.dq_envb_act_step(*args, ptr(self.env.inexact), self._stream()))
             self._inexact_acc += self.env.inexact.sum()              # (read and reported at the next read_stats())
             return
-        if sj is not None:
-            check(self.L.dq_env_act_step_sample(*args, ctypes.byref(sj), self._stream()))
-        else:
-            check(self.L.dq_env_act_step(*args, self._stream()))
+        try:
+            if sj is not None:
+                check(self.L.dq_env_act_step_sample(*args, ctypes.byref(sj), self._stream()))
+            else:
+                check(self.L.dq_env_act_step(*args, self._stream()))
+        except BaseException:
+            self.env.disarm_patch_output()                           # (_obs_slot armed a ring slot for this launch)
+            raise
 
     def _join_env(self):
         """Orders the current stream behind an environment launch still running on the side stream."""
@@ -386,8 +391,8 @@ class DQNCore:
             self._e_dense.record(main)
             with torch.cuda.stream(self._ar_stream):
                 self._ar_stream.wait_event(self._e_dense)
-                self._rccl.allreduce_sum_(self.grads[nconv:])
-                self._e_ar.record(self._ar_stream)
+                (self._rccl2 or self._rccl).allreduce_sum_(self.grads[nconv:])      # (the side stream's OWN communicator: two collectives of one communicator
+                self._e_ar.record(self._ar_stream)                                 #  in flight on two streams rest on RCCL's implicit serialisation)
             net.backward_phase(self.params, self.dq, self.grads, 1)
             probe = self.ar_events is not None and self._ar_seen % self.ar_stride == 0
             self._ar_seen += 1
@@ -472,7 +477,11 @@ class DQNCore:
             self.cur, self.filled = nxt, filled
             self.vector_steps += 1
             self.updates = t
-            self._learn(t, ride=step)
+            try:
+                self._learn(t, ride=step)
+            except BaseException:
+                env.disarm_patch_output()                           # (an error in front of the riding launch: no armed ring slot outlives the call)
+                raise
             for _ in range(extra_updates):
                 self.update()
             return
@@ -507,7 +516,19 @@ class DQNCore:
             _q.td_metrics(self.metrics, self.batch_size)
             self._metrics_stale = False
         m = self.metrics[:2].cpu().numpy()
-        self.net.check_range()       # (already synchronised) a gradient beyond the fused backward's range is an error, never silent
+        try:
+            self.net.check_range()   # (already synchronised) a gradient beyond the fused backward's range is never silent ...
+        except _lib.DeepQError as e:
+            # ... and with the default settings it is not fatal either: the updates that met it were discarded WHOLE on every rank (nothing partially
+            # applied), and from here on the gradient scale is MEASURED per minibatch (dq_td_job.auto_scale, +3 us per update), which carries any finite
+            # TD error -- keras-rl's delta_clip = inf without a user switch.  Sticky.  DQ_TD_AUTOSCALE=0 keeps the host-known scale and raises.
+            if e.status != -6 or self.auto_scale or os.environ.get("DQ_TD_AUTOSCALE") is not None:
+                raise
+            self.auto_scale = True
+            self.range_switches = getattr(self, "range_switches", 0) + 1
+            import warnings
+            warnings.warn("a TD error beyond the fused backward's host-known gradient scale: the updates since the last synchronisation that met it were "
+                          "discarded (whole, on every rank); the loop now measures the gradient scale per minibatch (DQNCore.auto_scale = True)")
         return float(m[0]), float(m[1])
 
     def repack(self):
@@ -527,18 +548,27 @@ class DQNCore:
         if self._rccl is None and not self._rccl_tried and _dist.dist_path(self.world_size):
             self._rccl_tried = True
             self._rccl = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
+            # DQ_DIST_MODE=overlap: a second communicator for the dense range's all-reduce on the side stream (the same collective call on every rank)
+            if self._rccl is not None and os.environ.get("DQ_DIST_MODE") == "overlap":
+                self._rccl2 = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
 
     def _comm_ready(self):
         self.ensure_comm()
         return self._rccl is not None
 
-    def close_comm(self):
+    def close_comm(self, abort=False):
         """Destroys the learner's own RCCL communicator (dist.RcclComm) -- every rank, behind a synchronisation, BEFORE the process group
-        that did its rendezvous is destroyed; a later several-GPU update would create a new one."""
+        that did its rendezvous is destroyed; a later several-GPU update would create a new one.  abort: the caller is leaving through an exception
+        (DQNAgent.fit's finally): ncclCommAbort instead of ncclCommDestroy, which could wait for peers inside a collective this rank never joins."""
         if self._rccl is not None:
-            torch.cuda.synchronize(self.device)
-            self._rccl.close()
-        self._rccl, self._rccl_tried = None, False
+            try:
+                torch.cuda.synchronize(self.device)
+            finally:
+                if self._rccl2 is not None:
+                    self._rccl2.close(abort=abort)
+                self._rccl.close(abort=abort)
+                self._rccl = None
+        self._rccl, self._rccl2, self._rccl_tried = None, None, False
 
     def close(self):
         """Releases what outlives the Python objects: the learner's RCCL communicator (before torch.distributed.destroy_process_group)."""
@@ -586,6 +616,7 @@ class DQNCore:
         assert getattr(self, "_train_ring", None) is None
         self._flush_stats()
         self._join_env()
+        self.env.disarm_patch_output()                               # (nothing armed for the training ring survives the switch of rings)
         self._train_ring = (self.patch_ring if self.compact else self._obs_ring, self.action_ring, self.reward_ring, self.terminal_ring, self.T,
                             self.cur, self.filled, self._presampled, self.started)
         T = 3
@@ -602,6 +633,7 @@ class DQNCore:
     def end_eval(self):
         self._flush_stats()
         self._join_env()
+        self.env.disarm_patch_output()
         (ring, self.action_ring, self.reward_ring, self.terminal_ring, self.T, self.cur, self.filled, self._presampled,
          self.started) = self._train_ring
         if self.compact:

@@ -66,7 +66,7 @@ static const unsigned char CW_SLOT1[64] = {53, 20, 30, 3, 27, 1, 22, 62, 56, 58,
 static const unsigned char CW_SLOT2[64] = {53, 7, 57, 61, 58, 34, 37, 23, 22, 47, 43, 8, 28, 17, 3, 50, 12, 49, 16, 35, 11, 24, 63, 6, 14, 48, 52, 26, 20, 46, 45, 25, 56, 15, 44, 4, 54, 36, 1, 33, 9, 29, 27, 62, 51, 41, 0, 32, 30, 21, 13, 40, 42, 19, 2, 59, 5, 18, 60, 39, 38, 31, 55, 10};
 
 __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
-    constexpr int D = 5, OW1 = D, OW2 = D - 1, OW3 = D - 2, R1 = D * D, R2 = OW2 * OW2, R3 = OW3 * OW3, T1 = 2;
+    constexpr int D = 5, OW2 = D - 1, OW3 = D - 2, R1 = D * D, R2 = OW2 * OW2, R3 = OW3 * OW3, T1 = 2;
     static_assert(R2 == 16 && R3 <= 16 && R1 <= 32, "one row tile for the second and third convolution, two for the first");
     constexpr int PL = 1024, SM = 2048;                             // bytes: piece l behind piece h, sample 1 behind sample 0
     extern __shared__ __attribute__((aligned(16))) u8 smem[];

@@ -149,34 +149,36 @@ __global__ __launch_bounds__(256) void td_metrics_kernel(float* __restrict__ met
     if (threadIdx.x == 0) { metrics[0] = s_loss[0] / (float)B; metrics[1] = s_q[0] / (float)B; }
 }
 
-// Keras 2.2 Adam.get_updates (common.h dq_adam1).  A non-finite gradient element (the fused backward's range guard, include/deepq_hip.h
-// dq_qnet_range_check; behind an all-reduce every rank sees the same ones) leaves its parameter and moments untouched and raises *flag
-// (nullable) -- the rule of the optimizer step that rides on the fused backward's final reduction, so that the several-GPU branch, where
-// the all-reduce comes between backward and update, behaves the same on EVERY rank.
-__device__ __forceinline__ void dq_adam1_guarded(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps, bool& bad) {
-    if (__builtin_isfinite(g)) dq_adam1(p, g, m, v, lr_t, b1, b2, eps);
+// Keras 2.2 Adam.get_updates (common.h dq_adam1).  With a flag word (dq_qnet_adam_step: the several-GPU branch) a non-finite gradient element (the
+// fused backward's range guard, include/deepq_hip.h dq_qnet_range_check; behind an all-reduce every rank sees the same ones) leaves its parameter
+// and moments untouched and raises *flag -- the rule of the optimizer step that rides on the fused backward's final reduction, so that the branch
+// where the all-reduce comes between backward and update behaves the same on EVERY rank.  WITHOUT a flag (the public dq_adam_step) the update is
+// Keras': a NaN gradient propagates into the parameter and the divergence is visible, not silently skipped.
+__device__ __forceinline__ void dq_adam1_guarded(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps, bool guard, bool& bad) {
+    if (!guard || __builtin_isfinite(g)) dq_adam1(p, g, m, v, lr_t, b1, b2, eps);
     else bad = true;
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             size_t n, float lr_t, float b1, float b2, float eps, unsigned* __restrict__ flag) {
     const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     bool bad = false;
+    const bool guard = flag != nullptr;
     if (i4 + 3 < n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                         reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
         float4 pp = *reinterpret_cast<float4*>(p + i4);
         const float4 gg = *reinterpret_cast<const float4*>(g + i4);
         float4 mm = *reinterpret_cast<float4*>(m + i4), vv = *reinterpret_cast<float4*>(v + i4);
-        dq_adam1_guarded(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, bad);
-        dq_adam1_guarded(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, bad);
-        dq_adam1_guarded(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, bad);
-        dq_adam1_guarded(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps, bad);
+        dq_adam1_guarded(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, guard, bad);
+        dq_adam1_guarded(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, guard, bad);
+        dq_adam1_guarded(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, guard, bad);
+        dq_adam1_guarded(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps, guard, bad);
         *reinterpret_cast<float4*>(p + i4) = pp;
         *reinterpret_cast<float4*>(m + i4) = mm;
         *reinterpret_cast<float4*>(v + i4) = vv;
     } else {
         for (size_t i = i4; i < n && i < i4 + 4; ++i) {
             float pi = p[i], mi = m[i], vi = v[i];
-            dq_adam1_guarded(pi, g[i], mi, vi, lr_t, b1, b2, eps, bad);
+            dq_adam1_guarded(pi, g[i], mi, vi, lr_t, b1, b2, eps, guard, bad);
             p[i] = pi; m[i] = mi; v[i] = vi;
         }
     }

@@ -616,6 +616,14 @@ static dq_status fill_common(dq_env* E, EnvParams& p, int epb, bool rider = fals
     return DQ_OK;
 }
 
+// dq_env_patch_output arms ONE launch.  Whatever happens to the call that was meant to consume it -- a failed precondition in front of fill_common, an
+// error in a pre-pass -- the arming does not survive that call: a later, unrelated reset / step of the handle must not write d * d words per lattice
+// into a ring slot that may have been freed or replaced since.
+struct PatchDisarm {
+    dq_env* E;
+    ~PatchDisarm() { if (E) E->patch_next = nullptr; }
+};
+
 static dq_status launch_env(dq_env* E, EnvParams& p, hipStream_t st) {
     const dq_status rc = fill_common(E, p, ENVS_PER_BLOCK);
     if (rc != DQ_OK) return rc;
@@ -627,6 +635,7 @@ static dq_status launch_env(dq_env* E, EnvParams& p, hipStream_t st) {
 
 dq_status dq_env_reset(dq_env* E, const uint8_t* which_dev, uint8_t* obs_dev, uint64_t* legal_dev,
                        uint32_t* lifetime_dev, void* stream) {
+    PatchDisarm disarm{E};
     DQ_REQUIRE(E, DQ_ERR_INVALID, "dq_env_reset: null handle");
     EnvParams p;
     memset(&p, 0, sizeof(p));
@@ -637,6 +646,7 @@ dq_status dq_env_reset(dq_env* E, const uint8_t* which_dev, uint8_t* obs_dev, ui
 dq_status dq_env_step(dq_env* E, const int32_t* action_dev, int auto_reset, uint8_t* obs_dev,
                       float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev, uint32_t* lifetime_dev,
                       uint8_t* was_reset_dev, void* stream) {
+    PatchDisarm disarm{E};
     DQ_REQUIRE(E && action_dev, DQ_ERR_INVALID, "dq_env_step: null argument");
     DQ_REQUIRE(E->lut_x, DQ_ERR_STATE, "dq_env_step: no referee installed (dq_env_build_referee / dq_env_set_referee)");
     EnvParams p;
@@ -680,6 +690,7 @@ static dq_status fill_act_step(dq_env* E, const float* q_dev, double eps, int ma
 static dq_status act_step(dq_env* E, const float* q_dev, double eps, int masked_greedy, const uint32_t seed[2], uint64_t t,
                           int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
                           uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sj, void* stream) {
+    PatchDisarm disarm{E};
     EnvParams p;
     const dq_status rc = fill_act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev,
                                        lifetime_dev, was_reset_dev, sj, 64 * ENVS_PER_BLOCK, p);
@@ -755,6 +766,7 @@ dq_status env_fill_act_step(dq_env* E, const float* q_dev, double eps, int maske
                             int32_t* action_dev, int auto_reset, uint8_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t* legal_dev,
                             uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sj, uint64_t* stats_dev, EnvParams* p,
                             size_t* lds, int threads) {
+    PatchDisarm disarm{E};                                          // (fill_common has copied the pointer into *p by the time this runs on the success path)
     DQ_REQUIRE(E && !E->mlp_layers, DQ_ERR_UNSUPPORTED, "a step whose referee is the Dense stack (dq_env_set_referee_mlp) does not ride: make the separate calls");
     DQ_REQUIRE(threads == 512 || threads == 256, DQ_ERR_INVALID, "env_fill_act_step: 256 or 512 threads per carrying block");
     dq_status rc = fill_act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev,

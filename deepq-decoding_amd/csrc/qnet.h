@@ -70,6 +70,7 @@ struct dq_qnet {
     int patch_depth;             // syndrome planes of the observation (0: not configured); the remaining input planes are action planes
     int patch_kd;                // data bits per pixel = 4 patch_depth + action planes (<= 32)
     int patch_stride;            // words per observation row
+    int patch_cfg_depth, patch_cfg_stride;      // the first configuration ever set on this handle: packed buffers and tables made under it stay valid only for it
     int* ptab;                   // device tables (PT_*)
     int last_patch;              // the last training forward read patch words (the backward takes the same form)
     unsigned bwd_serial;         // fused backwards' dense phases launched so far: the tag of the range guard's early half (fused_bwd.hip skip_word)

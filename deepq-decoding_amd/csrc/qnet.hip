@@ -502,11 +502,18 @@ dq_status dq_qnet_set_patch_input(dq_qnet* Q, int n_syndrome_planes, int stride_
     const int r1 = Q->L[0].rows;
     DQ_REQUIRE(stride_words >= r1 && stride_words <= 64 && (stride_words & (stride_words - 1)) == 0 && stride_words >= 4, DQ_ERR_INVALID,
                "dq_qnet_set_patch_input: stride_words must be a power of two in [max(4, d * d), 64]");
+    // One configuration per handle: the tables below and every packed buffer made under them (the compact first kernel, the per-pixel bias) belong to
+    // (planes, stride); a second core on the same handle with another volume depth -- or a disable / re-enable with other values -- would silently leave the first
+    // one's packed weights inconsistent with the tables.  Switching it off and on again with the SAME values is allowed.
+    DQ_REQUIRE(!Q->patch_cfg_depth || (Q->patch_cfg_depth == n_syndrome_planes && Q->patch_cfg_stride == stride_words), DQ_ERR_STATE,
+               "dq_qnet_set_patch_input: this handle is configured for %d syndrome planes, rows of %d words; create another handle for (%d, %d)",
+               Q->patch_cfg_depth, Q->patch_cfg_stride, n_syndrome_planes, stride_words);
     int tab[PT_TOTAL];
     fused_patch_tables(Q, n_syndrome_planes, stride_words, tab);
     Q->ptab = Q->kofftab + 96 + (CONV_FWD_TABS + 5) * CONV_ROWTAB;  // (behind the row tables, same allocation: dq_qnet_create)
     DQ_HIP(hipMemcpy(Q->ptab, tab, sizeof(tab), hipMemcpyHostToDevice));
     Q->patch_depth = n_syndrome_planes; Q->patch_kd = 4 * n_syndrome_planes + (Q->L[0].cin - n_syndrome_planes); Q->patch_stride = stride_words;
+    Q->patch_cfg_depth = n_syndrome_planes; Q->patch_cfg_stride = stride_words;
     return DQ_OK;
 }
 

@@ -123,6 +123,8 @@ class RcclComm:
             L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
             L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
             L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            L.ncclCommAbort.argtypes = [ctypes.c_void_p]
+            L.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
             if rank == 0:
                 self._check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
         except (OSError, RuntimeError, AttributeError) as e:
@@ -148,9 +150,34 @@ class RcclComm:
         self._check(self.lib.ncclAllReduce(flat.data_ptr(), flat.data_ptr(), flat.numel(), 7, 0, self.comm, stream), "ncclAllReduce")   # ncclFloat32, ncclSum
         return flat
 
-    def close(self):
+    def count(self):
+        """Ranks of the communicator as RCCL itself reports them (ncclCommCount) -- not WORLD_SIZE: a mis-joined communicator shows here."""
+        import ctypes
+        n = ctypes.c_int(-1)
+        self._check(self.lib.ncclCommCount(self.comm, ctypes.byref(n)), "ncclCommCount")
+        return n.value
+
+    def preflight(self):
+        """One all-reduce of a rank-stamped vector, checked on the host against what `world` ranks must give: element i = sum_r (r + i / 8) over the ranks
+        = world (world - 1) / 2 + world i / 8.  Raises on every rank that sees anything else -- a communicator that was joined by the wrong set of ranks
+        (or with a truncated ncclUniqueId: the bug fixed in round 4) fails here, loudly, before any timed region.  Returns ncclCommCount's answer."""
+        n = self.count()
+        if n != self.world:
+            raise RuntimeError(f"RCCL communicator holds {n} ranks, {self.world} expected (rank {self.rank})")
+        i = torch.arange(64, dtype=torch.float32, device=self.device) / 8.0
+        v = (float(self.rank) + i).contiguous()
+        self.allreduce_sum_(v)
+        torch.cuda.synchronize(self.device)
+        want = self.world * (self.world - 1) / 2.0 + self.world * i
+        if not torch.equal(v, want):
+            raise RuntimeError(f"RCCL pre-flight all-reduce over {self.world} ranks returned {v[:4].tolist()} ..., expected {want[:4].tolist()} ... (rank {self.rank})")
+        return n
+
+    def close(self, abort=False):
+        """ncclCommDestroy (every rank has issued the same collectives and drained them) -- or, leaving through an exception, ncclCommAbort: a destroy
+        can wait for peers that are still inside a collective this rank will never join."""
         if getattr(self, "comm", None):
-            self.lib.ncclCommDestroy(self.comm)
+            (self.lib.ncclCommAbort if abort else self.lib.ncclCommDestroy)(self.comm)
             self.comm = None
 
 

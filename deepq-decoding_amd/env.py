@@ -44,10 +44,35 @@ def _static_plane(d):
     return v.astype(np.uint8)
 
 
+_CONVERT_ROWS = 1 << 15      # observations converted at a time (the int64 temporaries below are 8 bytes per cell: a whole 2^20-transition ring at once
+                             # allocated ~7 GB -- the configuration the compact ring is meant for then failed to restore a pickled memory)
+
+
+def _in_chunks(fn, x, trailing):
+    """fn over the rows of x (its last `trailing` dimensions form a row), _CONVERT_ROWS rows at a time."""
+    lead = tuple(x.shape[:x.dim() - trailing])
+    rows = 1
+    for v in lead:
+        rows *= int(v)
+    if rows <= _CONVERT_ROWS:
+        return fn(x)
+    flat = x.reshape((rows,) + tuple(x.shape[x.dim() - trailing:]))
+    first = fn(flat[:_CONVERT_ROWS])
+    out = torch.empty((rows,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+    out[:_CONVERT_ROWS] = first
+    for i in range(_CONVERT_ROWS, rows, _CONVERT_ROWS):
+        out[i:i + _CONVERT_ROWS] = fn(flat[i:i + _CONVERT_ROWS])
+    return out.reshape(lead + tuple(out.shape[1:]))
+
+
 def patch_to_obs(patch, d, depth, layers):
     """Patch words (int32 tensor [..., stride >= d*d]: dq_env_patch_output) -> the padded uint8 observation [..., depth + layers, 2d+1, 2d+1]
     the reference builds (padding_syndrome / padding_actions, ENV:273-314).  The image is a fixed function of the words: syndrome cell (a, b)
     of plane j is bit 4 j + 2 dy + dx of pixel (a - dy, b - dx), action plane l's cell of qubit p is bit 4 depth + l of pixel p."""
+    return _in_chunks(lambda x: _patch_to_obs(x, d, depth, layers), patch, 1)
+
+
+def _patch_to_obs(patch, d, depth, layers):
     n = 2 * d + 1
     w = patch[..., :d * d].to(torch.int64) & 0xFFFFFFFF
     lead = w.shape[:-1]
@@ -73,6 +98,10 @@ def patch_to_obs(patch, d, depth, layers):
 def obs_to_patch(obs, d, depth, layers, stride=None):
     """The inverse of patch_to_obs on observations the environment can produce: uint8 [..., C, 2d+1, 2d+1] -> int32 [..., stride]."""
     stride = patch_stride_words(d) if stride is None else stride
+    return _in_chunks(lambda x: _obs_to_patch(x, d, depth, layers, stride), obs, 3)
+
+
+def _obs_to_patch(obs, d, depth, layers, stride):
     o = obs.to(torch.int64)
     lead = o.shape[:-3]
     w = torch.zeros(lead + (d, d), dtype=torch.int64, device=obs.device)
@@ -275,8 +304,22 @@ class VectorEnv:
     def arm_patch_output(self, out_patch):
         """The NEXT reset / step / act_step launch of this handle also writes the lattices' patch words into `out_patch`
         (int32 [n_envs, patch_stride], 16-byte aligned); one call arms one launch."""
+        assert not self.wide, "patch words are written by the d <= 7 kernels only (a wide handle never consumes the arming)"
         assert out_patch.dtype == torch.int32 and out_patch.is_cuda and out_patch.is_contiguous() and out_patch.shape == (self.n_envs, self.patch_stride)
         check(self.L.dq_env_patch_output(self._h, ptr(out_patch), self.patch_stride))
+
+    def disarm_patch_output(self):
+        """Withdraws arm_patch_output (callers that arm and then fail before their launch: the library itself disarms on every launch attempt)."""
+        if not self.wide and getattr(self, "_h", None):
+            self.L.dq_env_patch_output(self._h, None, self.patch_stride)
+
+    def _launch(self, fn, *args):
+        """check(fn(*args)); an exception on the way (argument conversion included) leaves no armed patch output behind."""
+        try:
+            check(fn(*args))
+        except BaseException:
+            self.disarm_patch_output()
+            raise
 
     def patch_to_obs(self, patch):
         return patch_to_obs(patch, self.d, self.volume_depth, self.n_action_layers)
@@ -292,7 +335,7 @@ class VectorEnv:
         w = None if which is None else torch.as_tensor(which, dtype=torch.uint8, device=self.device).contiguous()
         if out_patch is not None:
             self.arm_patch_output(out_patch)
-        check(getattr(self.L, self._pfx + "reset")(self._h, ptr(w), ptr(obs), ptr(self.legal), ptr(self.lifetime), self._stream()))
+        self._launch(getattr(self.L, self._pfx + "reset"), self._h, ptr(w), ptr(obs), ptr(self.legal), ptr(self.lifetime), self._stream())
         if which is None:
             self.done.zero_()
         else:
@@ -310,8 +353,8 @@ class VectorEnv:
             check(self.L.dq_envb_step(self._h, ptr(action), int(auto_reset), ptr(obs), ptr(self.reward), ptr(self.done),
                                       ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), ptr(self.inexact), self._stream()))
         else:
-            check(self.L.dq_env_step(self._h, ptr(action), int(auto_reset), ptr(obs), ptr(self.reward), ptr(self.done),
-                                     ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), self._stream()))
+            self._launch(self.L.dq_env_step, self._h, ptr(action), int(auto_reset), ptr(obs), ptr(self.reward), ptr(self.done),
+                         ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), self._stream())
         return obs, self.reward, self.done
 
     def act_step(self, t, q=None, eps=1.0, masked_greedy=False, auto_reset=True, out_obs=None, out_action=None, out_patch=None):
@@ -327,9 +370,8 @@ class VectorEnv:
                                           ptr(obs), ptr(self.reward), ptr(self.done), ptr(self.legal), ptr(self.lifetime),
                                           ptr(self.was_reset), ptr(self.inexact), self._stream()))
         else:
-            check(self.L.dq_env_act_step(self._h, ptr(q), float(eps), int(masked_greedy), seed, int(t), ptr(out_action), int(auto_reset),
-                                         ptr(obs), ptr(self.reward), ptr(self.done), ptr(self.legal), ptr(self.lifetime),
-                                         ptr(self.was_reset), self._stream()))
+            self._launch(self.L.dq_env_act_step, self._h, ptr(q), float(eps), int(masked_greedy), seed, int(t), ptr(out_action), int(auto_reset),
+                         ptr(obs), ptr(self.reward), ptr(self.done), ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), self._stream())
         return out_action
 
     def select_actions(self, t, q=None, eps=1.0, masked_greedy=False, out=None):

@@ -560,7 +560,8 @@ dq_status dq_episode_stats(const uint8_t* done_dev, const uint8_t* was_reset_dev
 
 /* keras.optimizers.Adam (Keras 2.2): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMAs; p -= lr_t*m/(sqrt(v)+epsilon).
  * t = 1 for the first update. */
-/* (A non-finite gradient element leaves its parameter and moments untouched -- as the optimizer step riding on the fused backward does.) */
+/* (Keras' update as it is: a non-finite gradient element propagates into its parameter and moments -- a diverged run stays visible.  The guarded
+ * form -- such elements skipped and flagged -- is dq_qnet_adam_step and the optimizer step riding on the fused backward.) */
 dq_status dq_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, size_t n, double lr,
                        double beta_1, double beta_2, double epsilon, uint64_t t, void* stream);
 

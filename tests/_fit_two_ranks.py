@@ -23,10 +23,15 @@ def main():
     SYNC_INTERVAL = 4 if len(sys.argv) > 2 and sys.argv[2] == "single4" else None
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    if os.environ.get("DQ_DIST_FORCE") == "1":                      # (one rank through the REAL backend: the learner gets a RCCL communicator of its own)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     dq = importlib.import_module("deepq-decoding_amd")
     if len(sys.argv) > 2 and sys.argv[2] == "range":
         return main_range(dq, out_dir, rank, world)
+    if len(sys.argv) > 2 and sys.argv[2] == "fitrange":
+        return main_fit_range(dq, out_dir, rank, world)
     if single:
         return main_single(dq, out_dir, rank)
     N = 64
@@ -86,6 +91,47 @@ def main_range(dq, out_dir, rank, world):
     finite = bool(torch.isfinite(core.params).all())
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(dict(unchanged=unchanged, raised=raised, params=chk, finite=finite, moved=not torch.equal(core.params, before)), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main_fit_range(dq, out_dir, rank, world):
+    """A DQ_ERR_RANGE raised INSIDE DQNAgent.fit: rank 0's callback poisons ITS replay rewards in the middle of the run; the update
+    that samples them is discarded on every rank and every rank's fit() raises DeepQError(DQ_ERR_RANGE) at the same synchronisation -- and must leave
+    with the learner's communicator closed (core._rccl None, a later fit() would create a new one) and the process group still usable."""
+    N = 64
+    cfg = dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    env = dq.VectorEnv(n_envs=N, env_id_base=rank * N, **cfg)
+    model = dq.build_convolutional_nn([[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]], env.obs_shape, env.num_actions)
+    agent = dq.DQNAgent(model=model, nb_actions=env.num_actions, memory=dq.SequentialMemory(limit=N * 16, window_length=1), nb_steps_warmup=N * 4,
+                        target_model_update=N * 50, policy=dq.EpsGreedyQPolicy(eps=0.3, masked_greedy=True), test_policy=dq.GreedyQPolicy(masked_greedy=True),
+                        gamma=0.99, enable_dueling_network=True, batch_size=N, seed=(1, 2))
+    agent.compile(dq.Adam(lr=1e-4))
+    state = dict(comm_seen=None, episodes=0)
+
+    class Poison:                                                   # (callbacks run on rank 0 only)
+        def on_train_begin(self): pass
+        def on_train_end(self): pass
+        def on_episode_end(self, episode, logs):
+            state["episodes"] += 1
+            if state["episodes"] == 3:
+                agent._core.reward_ring.fill_(1e6)
+
+    raised, status = False, None
+    try:
+        agent.fit(env, nb_steps=N * 400, callbacks=[Poison()] if rank == 0 else [], verbose=0, episode_averaging_length=30, success_threshold=None,
+                  stopping_patience=None, min_nb_steps=0, single_cycle=False, sync_interval=4)
+    except dq.DeepQError as e:
+        raised, status = True, e.status
+    core = agent._core
+    closed = core._rccl is None and not core._rccl_tried
+    t = torch.tensor([rank + 1.0])
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t)                                              # the process group survived
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(dict(raised=raised, status=status, closed=closed, step=agent.step, group_sum=float(t.item()), finite=bool(torch.isfinite(core.params).all()),
+                       params=int(core.params.view(torch.int32).to(torch.int64).sum().item()), training=bool(agent.training)), f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -294,6 +294,52 @@ def test_device_loop_at_distance_nine_matches_oracle_loop(dq, torch_mod):
     assert n_updates >= 5
 
 
+def test_a_td_error_beyond_the_host_known_scale_switches_the_loop_to_the_measured_scale(dq, torch_mod, monkeypatch):
+    """with default settings a TD error of ~1e6 (rewards poisoned) no longer ends the run -- the updates that met it are
+    discarded whole, read_metrics() warns ONCE and switches DQNCore.auto_scale on for good (the gradient scale measured per minibatch carries any finite
+    TD error: keras-rl's delta_clip = inf), after which updates on the same poisoned memory move the parameters, finite.  DQ_TD_AUTOSCALE=0 keeps
+    the host-known scale: the same situation raises DQ_ERR_RANGE (tests/test_distributed_gpu.py covers that path under two ranks and inside fit())."""
+    torch = torch_mod
+    import warnings
+    monkeypatch.delenv("DQ_TD_AUTOSCALE", raising=False)
+    N = 64
+    env = dq.VectorEnv(n_envs=N, d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+    net = dq.QNetwork(env.obs_shape, [[64, 3, 2], [32, 2, 1], [32, 2, 1]], [[512, 0.2]], env.num_actions, max_batch=N)
+    core = dq.DQNCore(env, net, batch_size=N, memory_limit=N * 8, gamma=0.99, lr=1e-3, seed=(5, 6))
+    core.reset_env()
+    for _ in range(4):
+        core.act_and_step(1.0, use_q=False)
+    for _ in range(3):
+        core.step_and_update(0.5)
+    core.read_metrics()
+    assert core.auto_scale is False
+    before = core.params.clone()
+    core.reward_ring.fill_(1e6)
+    core.step_and_update(0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(core.params, before)                         # discarded whole
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        core.read_metrics()
+    assert core.auto_scale is True and any("measures the gradient scale" in str(x.message) for x in w)
+    core.reward_ring.fill_(1e6)                                     # (the step above wrote a fresh slot)
+    for _ in range(3):
+        core.step_and_update(0.5)
+    loss, mean_q = core.read_metrics()                              # no warning, no error: carried
+    assert bool(torch.isfinite(core.params).all()) and not torch.equal(core.params, before) and np.isfinite(loss)
+    # the explicit switch keeps the error
+    monkeypatch.setenv("DQ_TD_AUTOSCALE", "0")
+    core2 = dq.DQNCore(env, net, batch_size=N, memory_limit=N * 8, gamma=0.99, lr=1e-3, seed=(5, 6))
+    core2.reset_env()
+    for _ in range(4):
+        core2.act_and_step(1.0, use_q=False)
+    core2.reward_ring.fill_(1e6)
+    core2.step_and_update(0.5)
+    with pytest.raises(dq.DeepQError) as ei:
+        core2.read_metrics()
+    assert ei.value.status == -6 and core2.auto_scale is False
+
+
 def _make_agent(dq, model_shape, n_actions, batch_size=32, warmup=64, target=200, limit=5000, seed=(1, 2)):
     model = dq.build_convolutional_nn(C_LAYERS, FF_LAYERS, model_shape, n_actions)
     memory = dq.SequentialMemory(limit=limit, window_length=1)
@@ -736,8 +782,9 @@ def test_reference_training_run_replayed_against_its_own_record(dq, torch_mod):
     dicts, committed as data: tests/golden/training_history_d5_x_0.001.npz) replayed through runner.train_single_point -> DQNAgent.fit
     with the same recipe -- one lattice, batch 32, Adam 1e-5, epsilon 1 -> 0.02 over 200 000 steps, target copy every 5000, warm-up 1000 --
     for its first 120 000 steps (the whole 998 377-step run: tools/replay_reference_training.py, record in profiles/).  Random numbers
-    and referee differ by construction, so the comparison is statistical: mean_eps exact; mean_q within x2, loss within x4 and the
-    rolling lifetime within x3 of the reference's curve at 10 000 / 25 000 / 50 000 / 100 000 steps (measured: within 10 %)."""
+    and referee differ by construction, so the comparison is statistical: mean_eps exact; mean_q within x1.25, loss within x2 and the
+    rolling lifetime within x1.5 of the reference's curve at 10 000 / 25 000 / 50 000 / 100 000 steps (measured: within 10 %, the loss within
+    x1.7; round 4 asserted x2 / x4 / x3).  The shortened run's greedy lifetime is printed, not judged (the record is the finished agent's)."""
     import sys
     tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
     sys.path.insert(0, tools)

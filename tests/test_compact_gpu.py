@@ -20,7 +20,7 @@ GEOM = {"c1": (3, 3, 1, 10), "c2": (5, 5, 1, 26), "c3": (5, 5, 2, 51), "c5": (7,
 
 
 def tol(ref):
-    return 1e-5 * max(1.0, float(np.abs(np.asarray(ref)).max()))
+    return max(1e-5, 2e-6 * float(np.abs(np.asarray(ref)).max()))
 
 
 @pytest.fixture(scope="module")

@@ -180,7 +180,7 @@ class _FakeRccl:
             comm_ref._obj.value = 1
             return 0
         self.ncclGetErrorString, self.ncclGetUniqueId, self.ncclCommInitRank = _Fn(lambda rc: b"fake"), _Fn(get_id), _Fn(init_rank)
-        self.ncclAllReduce, self.ncclCommDestroy = _Fn(lambda *a: 0), _Fn(lambda c: 0)
+        self.ncclAllReduce, self.ncclCommDestroy, self.ncclCommAbort, self.ncclCommCount = _Fn(lambda *a: 0), _Fn(lambda c: 0), _Fn(lambda c: 0), _Fn(lambda c, n: 0)
 
 
 def _rccl_id_worker(rank, world, port, out_dir):

@@ -143,8 +143,49 @@ def test_range_guard_discards_the_update_on_every_rank(tmp_path):
     their next read_metrics(), the replicas stay bit-identical and the loop carries on afterwards."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "tests", "_fit_two_ranks.py"), str(tmp_path), "range"]
-    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(DQ_TD_AUTOSCALE="0"), capture_output=True, text=True, timeout=600)      # (0: the host-known scale for good -- the error is raised)
     assert r.returncode == 0, r.stderr[-3000:]
     a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
     assert a == b, (a, b)
     assert a["unchanged"] and a["raised"] and a["finite"] and a["moved"]
+
+
+@pytest.mark.gpu
+def test_a_range_error_inside_fit_leaves_every_rank_with_the_communicator_closed(tmp_path):
+    """DQNAgent.fit's exits: a DQ_ERR_RANGE raised inside fit() -- rank 0's replay rewards poisoned mid-run -- reaches EVERY rank at
+    the same synchronisation; each leaves fit() through its exception handler with the learner's communicator closed (aborted, not destroyed), the
+    agent no longer `training`, the replicas still finite and identical, and the process group usable.  Two ranks over gloo, then ONE rank through
+    the real RCCL backend (DQ_DIST_FORCE=1: the learner holds a RcclComm of its own there, so `closed` means ncclCommAbort has run)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "tests", "_fit_two_ranks.py"), str(tmp_path), "fitrange"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(DQ_TD_AUTOSCALE="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
+    for x in (a, b):
+        assert x["raised"] and x["status"] == -6 and x["closed"] and x["finite"] and not x["training"] and x["group_sum"] == 3.0, x
+    assert a["step"] == b["step"] and a["params"] == b["params"]
+    one = tmp_path / "one"
+    one.mkdir()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", os.path.join(ROOT, "tests", "_fit_two_ranks.py"), str(one), "fitrange"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(DQ_DIST_FORCE="1", DQ_TD_AUTOSCALE="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    x = json.load(open(one / "rank0.json"))
+    assert x["raised"] and x["status"] == -6 and x["closed"] and x["finite"] and not x["training"] and x["group_sum"] == 1.0, x
+
+
+@pytest.mark.gpu
+def test_rccl_preflight_on_a_one_rank_group():
+    """dist.RcclComm.preflight (bench.py --gpus N runs it before its warm-up): ncclCommCount's answer and a checked all-reduce of a rank-stamped vector."""
+    code = ("import os, torch, importlib, torch.distributed as dist\n"
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29553', RANK='0', WORLD_SIZE='1')\n"
+            "torch.cuda.set_device(0); dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+            "D = importlib.import_module('deepq-decoding_amd.dist')\n"
+            "c = D.RcclComm(0, 1, 'cuda:0')\n"
+            "assert c.count() == 1 and c.preflight() == 1\n"
+            "c.world = 2\n"
+            "try:\n    c.preflight(); raise SystemExit('a one-rank communicator passed a two-rank pre-flight')\n"
+            "except RuntimeError as e:\n    assert 'holds 1 ranks, 2 expected' in str(e)\n"
+            "c.close(); dist.destroy_process_group(); print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

@@ -17,8 +17,9 @@ SHAPES = {"c1": ((4, 7, 7), 10), "c2": ((6, 11, 11), 26), "c3": ((7, 11, 11), 51
 
 
 def tol(ref):
-    """1e-5 * max(1, max |ref|): see the module docstring."""
-    return 1e-5 * max(1.0, float(np.abs(np.asarray(ref)).max()))
+    """max(1e-5, 2e-6 max |ref|): absolute 1e-5 (BASELINE.json north_star) up to |Q| = 5, then 2e-6 of the largest value -- five times what the fused
+    chains measure on the reference's trained agents (4.2e-7 of max |Q|, tests/test_shipped_weights.py), where no fp32 implementation meets an absolute 1e-5."""
+    return max(1e-5, 2e-6 * float(np.abs(np.asarray(ref)).max()))
 
 
 @pytest.fixture(scope="module")
@@ -158,7 +159,7 @@ def test_backward_at_baseline_batch_matches_oracle(dq, torch_mod, name, batch):
     # get dq = 0: they still run through every kernel, but their masks cannot matter.
     fragile = O.fragile_samples(cache)                                      # thr = 2e-6 (oracle/dqn_oracle.py)
     print(f"{name} B={batch}: {fragile.mean():.3%} of the samples have a ReLU pre-activation within 2e-6 of 0")
-    assert fragile.mean() < 0.1
+    assert fragile.mean() < 0.05
     dq_[fragile] = 0.0
     dq_t = torch.from_numpy(dq_).cuda()
     g = net.backward(params, dq_t).cpu().numpy()
@@ -669,8 +670,8 @@ def test_qnet_at_baseline_size_properties(dq, torch_mod):
 
 def test_guarded_adam_step_skips_and_flags_non_finite_elements(dq, torch_mod):
     """dq_qnet_adam_step (the several-GPU branch's optimizer step behind the gradient all-reduce): an element whose gradient is inf / NaN leaves
-    its parameter and moments untouched and raises the handle's range flag, every other element takes dq_adam_step's update bit for bit; dq_adam_step
-    itself skips such elements too (without a flag)."""
+    its parameter and moments untouched and raises the handle's range flag, every other element takes dq_adam_step's update bit for bit.  The public
+    dq_adam_step is Keras' update: a non-finite gradient element PROPAGATES into its parameter and moments (a divergence stays visible)."""
     torch = torch_mod
     from importlib import import_module
     Q = import_module("deepq-decoding_amd.qnet")
@@ -696,5 +697,8 @@ def test_guarded_adam_step_skips_and_flags_non_finite_elements(dq, torch_mod):
         ok = torch.ones(net.n_params, dtype=torch.bool, device="cuda")
         ok[bad] = False
         assert torch.equal(p_[ok], ref_p[ok]) and torch.equal(m_[ok], ref_m[ok]) and torch.equal(v_[ok], ref_v[ok])
-        assert torch.equal(p_[bad], params[bad]) and bool((m_[bad] == 0.01).all()) and bool((v_[bad] == 0.02).all())
+        if guarded:
+            assert torch.equal(p_[bad], params[bad]) and bool((m_[bad] == 0.01).all()) and bool((v_[bad] == 0.02).all())
+        else:
+            assert not bool(torch.isfinite(p_[bad]).any()) and not bool(torch.isfinite(m_[bad]).any())
         assert torch.isfinite(p_).all()

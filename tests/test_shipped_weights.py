@@ -4,10 +4,12 @@ example of /root/reference/README.md:694-829 (d = 5, X noise, agent d5_x/0.007, 
 
 Tolerance (BASELINE.json north_star: "within 1e-5 on Q-values/loss"): the shipped agents' Q-values are 10 - 70, where float32 itself
 resolves ~4e-6 per value and an ordinary fp32 contraction is 1 - 3e-5 away from float64; an ABSOLUTE 1e-5 is therefore only meaningful
-for |Q| <~ 1.  The bound used here is SCALE-AWARE, 1e-5 * max(1, max |Q|) (i.e. 1e-5 relative to the largest Q-value of the batch), and
+for |Q| <~ 1.  The bound used here is SCALE-AWARE, max(1e-5, 2e-6 max |Q|) (round 5: five times the measured error instead of 24 times), and
 it is accompanied by side-by-side errors of three fp32-class implementations against the float64 oracle on the same inputs:
-the fused f16x2 chains (operands carried as two f16 pieces = 22 significant bits, f32 accumulation), the per-layer true-f32 MFMA path,
-and torch-CPU fp32 -- with the requirement err_fused <= 1.5 * err_per_layer."""
+the fused f16x2 chains (operands carried as two f16 pieces = 22 significant bits, f32 accumulation) on both input forms (uint8 images:
+the workgroup-per-group conv kernels; patch words: the wave-private conv forward), the per-layer true-f32 MFMA path, and torch-CPU fp32 --
+with the requirements err_fused <= 1.1 * err_torch_fp32 and err_fused <= err_per_layer: the fused chains may not be further from float64
+than a genuine fp32 implementation is."""
 import numpy as np
 import pytest
 
@@ -18,7 +20,8 @@ AGENTS = [("d5_x", "0.007", (6, 11, 11), 26), ("d5_dp", "0.007", (7, 11, 11), 51
 
 
 def scale_tol(q_ref):
-    return 1e-5 * max(1.0, float(np.abs(q_ref).max()))
+    """max(1e-5, 2e-6 max |Q|): at |Q| = 40 that is 8e-5, five times the measured 1.7e-5 (round 4 asserted 4e-4 there)."""
+    return max(1e-5, 2e-6 * float(np.abs(q_ref).max()))
 
 
 def _spec(shape, A):
@@ -112,9 +115,9 @@ def test_readme_known_answer_on_the_hip_forward(dq, torch_mod):
 @pytest.mark.gpu
 @pytest.mark.parametrize("family,p,shape,A", AGENTS)
 def test_forward_parity_on_shipped_weights_at_baseline_batch(dq, torch_mod, family, p, shape, A):
-    """B = 4096 real observations through the shipped agent: fused chains, per-layer f32 MFMA path and torch-CPU fp32, each against the
-    float64 oracle.  Bound: 1e-5 * max(1, max |Q|); and the fused path may not be more than 1.5x further from float64 than the true-f32
-    per-layer path.  Greedy actions agree with the oracle's wherever the oracle's top two Q-values are further apart than the bound."""
+    """B = 4096 real observations through the shipped agent: fused chains (both input forms), per-layer f32 MFMA path and torch-CPU fp32, each
+    against the float64 oracle.  Bound: max(1e-5, 2e-6 max |Q|); and the fused paths may not be further from float64 than the true-f32
+    per-layer path, nor more than 1.1x further than torch-CPU fp32.  Greedy actions agree with the oracle's wherever the oracle's top two Q-values are further apart than the bound."""
     torch = torch_mod
     from oracle import torch_dqn
     _, flat = shipped.shipped_weights(family, p)
@@ -132,13 +135,27 @@ def test_forward_parity_on_shipped_weights_at_baseline_batch(dq, torch_mod, fami
         top2 = np.sort(q_ref, axis=1)[:, -2:]
         clear = top2[:, 1] - top2[:, 0] > 2 * tol
         assert clear.mean() > 0.99 and np.array_equal(np.argmax(q, axis=1)[clear], np.argmax(q_ref, axis=1)[clear])
+    # the same observations as patch words (include/deepq_hip.h dq_env_patch_output): the loop's form, read by csrc/conv_wave.hip at d = 5
+    import importlib
+    E = importlib.import_module("deepq-decoding_amd.env")
+    cfg = shipped.CONFIGS[family]
+    depth, layers, stride = cfg["volume_depth"], shape[0] - cfg["volume_depth"], E.patch_stride_words(cfg["d"])
+    net.set_fused(True)
+    net.set_patch_input(depth, stride)
+    patch = E.obs_to_patch(torch.from_numpy(obs), cfg["d"], depth, layers, stride).cuda().contiguous()
+    q = net.forward_multi([dict(params=params, obs=patch, patch=True)])[0].cpu().numpy().astype(np.float64)
+    err["fused-patch"] = np.abs(q - q_ref).max()
+    top2 = np.sort(q_ref, axis=1)[:, -2:]
+    clear = top2[:, 1] - top2[:, 0] > 2 * tol
+    assert np.array_equal(np.argmax(q, axis=1)[clear], np.argmax(q_ref, axis=1)[clear])
     t = torch_dqn.TorchDQN(spec, flat)
     err["torch-fp32"] = np.abs(t.forward(t.params, obs).detach().numpy().astype(np.float64) - q_ref).max()
     err["f16x2-exact-acc"] = np.abs(O.forward_f16x2_emulated(spec, flat, obs) - q_ref).max()
     print(f"{family}/{p}: max|Q| {np.abs(q_ref).max():.1f}  bound {tol:.2e}  max abs error vs float64: " +
           "  ".join(f"{k} {v:.2e}" for k, v in err.items()))
-    assert err["fused"] < tol and err["per-layer"] < tol and err["torch-fp32"] < tol
-    assert err["fused"] <= 1.5 * err["per-layer"], err
+    assert err["fused"] < tol and err["fused-patch"] < tol and err["per-layer"] < tol and err["torch-fp32"] < tol
+    assert err["fused"] <= err["per-layer"] and err["fused-patch"] <= err["per-layer"], err
+    assert err["fused"] <= 1.1 * err["torch-fp32"] and err["fused-patch"] <= 1.1 * err["torch-fp32"], err
 
 
 def _td_like_dq(rng, B, A, lo=1.0, hi=50.0):
@@ -168,7 +185,7 @@ def test_backward_parity_on_shipped_weights(dq, torch_mod, family, p, shape, A):
     dq_ = _td_like_dq(rng, B, A)
     fragile = O.fragile_samples(cache, rel=1e-6)
     print(f"{family}/{p}: {fragile.mean():.2%} fragile samples")
-    assert fragile.mean() < 0.1
+    assert fragile.mean() < 0.02                                                            # (measured 0.7 - 1.3 %)
     dq_[fragile] = 0.0
     g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
     net, params = _net(dq, torch, shape, A, flat, B)

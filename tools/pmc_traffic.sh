@@ -10,18 +10,25 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf "gpurun_out/pmc_$c"
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $c --kernel-trace -d "$root/gpurun_out/pmc_$c" -o pmc --output-format csv -- python "$root/bench.py" --mode "$mode" --config "$config" --steps 40 --warmup 5 --no-cpu-baseline "$@" > "$root/gpurun_out/pmc_$c.log" 2>&1)
 done
-MODE="$mode" CONFIG="$config" python3 - <<'PY'
+MODE="$mode" CONFIG="$config" EXTRA="$*" python3 - <<'PY'
 import csv, glob, json, collections, importlib, os, sys
 sys.path.insert(0, os.getcwd())
 out = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg, cnt = collections.Counter(), collections.Counter()
+    rows = collections.defaultdict(list)
     for f in glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c:
                 continue
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
-            agg[k] += float(r["Counter_Value"]); cnt[k] += 1
+            rows[k].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    # the LAST 40 launches of every kernel = those of the 40 timed steps: the set-up's launches of the same kernel (ring fill: one-job forwards of
+    # conv_wave_kernel / dense_chain_kernel, resets of env_kernel) come first and are not what `roofline.traffic` describes
+    for k, v in rows.items():
+        v.sort()
+        for _, x in v[-40:]:
+            agg[k] += x; cnt[k] += 1
     for k in agg:
         out[k][c + "_KB_per_launch"] = agg[k] / cnt[k]
         out[k]["launches_" + c] = cnt[k]
@@ -31,10 +38,13 @@ for k, v in out.items():
     v["hbm_bytes_per_launch_raw"] = (f + w) * 1024.0
 mode, config = os.environ["MODE"], os.environ["CONFIG"]
 digest = importlib.import_module("deepq-decoding_amd.bench_loop").csrc_digest()
+extra = os.environ.get("EXTRA", "").split()
+arg = lambda name, default: int(extra[extra.index(name) + 1]) if name in extra else default
+shape = {"minibatch": arg("--minibatch", 0), "updates_per_step": arg("--updates-per-step", 1), "lattices": arg("--lattices", 0)}      # 0 = the configuration's default
 path = f"gpurun_out/pmc_traffic_{mode}_{config}.json"
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --mode {mode} --config {config} --steps 40 --warmup 5 --no-cpu-baseline`",
            "correction": "MI355X_MICROARCH.md HBM section: unit KB; gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B -> x2; WRITE_SIZE uncalibrated (used as is)",
-           "csrc_sha256": digest, "kernels": out}, open(path, "w"), indent=1)
+           "csrc_sha256": digest, "shape": shape, "launches_averaged": "the last 40 of each kernel (the timed steps)", "kernels": out}, open(path, "w"), indent=1)
 print(path, digest[:16])
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"])[:12]:
     print(f"{k[:40]:40s} fetch {v.get('FETCH_SIZE_KB_per_launch', 0):10.1f} KB  write {v.get('WRITE_SIZE_KB_per_launch', 0):10.1f} KB  corrected {v['hbm_bytes_per_launch_corrected'] / 1e6:8.2f} MB/launch")

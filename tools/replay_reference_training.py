@@ -103,9 +103,11 @@ def run(family="d5_x", p="0.001", max_steps=None, lattices=1, seed=(20181012, 7)
 def compare(res):
     """Rows (checkpoint step, metric, ours, reference) + the verdicts.  Bands (stated in DESIGN.md section 5): mean_eps exact to 1e-9 at every
     episode (against the annealing rule at OUR episode boundaries -- the reference's records obey the same rule to 3e-16, tests/test_host_logic.py);
-    mean_q within a factor 2 of the reference's at every checkpoint up to the end of the run, loss within a factor 4 (it is a noisy per-episode
-    mean of squared TD errors), the rolling lifetime within a factor 3 while it climbs (a learning curve's position in time varies run to run;
-    the reference has ONE run) and the greedy lifetime at the end of a full-length run within x2.2 of all_results.p (the spread of this build's own eight seeds is x2.6)."""
+    mean_q within a factor 1.25 of the reference's at every checkpoint up to the end of the run (measured over nine replays: within 10 %), loss within a
+    factor 2 (a noisy per-episode mean of squared TD errors; measured: within 1.7), the rolling lifetime within a factor 1.5 while it climbs (a learning
+    curve's position in time varies run to run and the reference has ONE run; measured: 0.89 - 1.02) and -- for a FULL-LENGTH run only -- the greedy
+    lifetime at the end within x2.2 of all_results.p (the spread of this build's own eight seeds is x2.6).  A shortened run's agent is not compared with
+    the record of the finished one: its row is listed as "not judged".  (Round 4 asserted x2 / x4 / x3.)"""
     ours, g, var = res["ours"], res["record"], res["var"]
     S = np.array(ours["nb_steps"])
     rows, ok = [], True
@@ -128,7 +130,7 @@ def compare(res):
     for at in CHECKPOINTS:
         if at > last:
             break
-        for key, band, fn in (("mean_q", 2.0, curve_at), ("loss", 4.0, curve_at), ("episode_lifetimes_rolling_avg", 3.0, last_at)):
+        for key, band, fn in (("mean_q", 1.25, curve_at), ("loss", 2.0, curve_at), ("episode_lifetimes_rolling_avg", 1.5, last_at)):
             a = fn(S, ours[key], at)
             b = fn(g["nb_steps"], g[key], at)
             good = (not np.isnan(a)) and (not np.isnan(b)) and b / band <= a <= b * band
@@ -140,9 +142,13 @@ def compare(res):
     full = last >= 0.95 * res["fixed"]["max_timesteps"] and res["fixed"]["max_timesteps"] >= 900000
     # (one run against one run: eight seeds of THIS build's replay gave 13.7 k ... 36.1 k, median 21.2 k, at p = 0.001 against the reference's 27.7 k --
     # profiles/r04_replay_d5_x_0.001_*.json --, the same recipe's agents differ by x2.6 among themselves)
-    good = (ref_life / 2.2 <= res["eval_lifetime"] <= ref_life * 2.2) if full else True
-    rows.append((last, f"greedy lifetime at p = {res['p']} ({res['eval_episodes']} episodes; reference: all_results.p, 101 episodes)", res["eval_lifetime"], ref_life, good))
-    ok &= good
+    if full:
+        good = ref_life / 2.2 <= res["eval_lifetime"] <= ref_life * 2.2
+        rows.append((last, f"greedy lifetime at p = {res['p']} ({res['eval_episodes']} episodes; reference: all_results.p, 101 episodes)", res["eval_lifetime"], ref_life, good))
+        ok &= good
+    else:
+        rows.append((last, f"greedy lifetime at p = {res['p']} after {last} of {res['fixed']['max_timesteps']} steps (NOT JUDGED: the record is the finished agent's)",
+                     res["eval_lifetime"], ref_life, True))
     return rows, bool(ok)
 
 
