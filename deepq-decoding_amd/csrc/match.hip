@@ -10,6 +10,7 @@ struct dq_match {
     int d, n[2], w10[2];
     u8* dist_dev[2];
     u8* distB_dev[2];
+    u32* pool;              // match_dev.h: DQ_MATCH_POOL_SLOTS scratch tables of the clusters beyond DQ_MATCH_MAX_DEFECTS defects, then their lock words
     std::vector<u8> dist[2], distB[2];
 };
 
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(64) void match_decode_kernel(MatchComp cx, MatchCom
 
 void match_comp(const dq_match* M, int comp, MatchComp* out) {
     out->dist = M->dist_dev[comp]; out->distB = M->distB_dev[comp]; out->n = M->n[comp]; out->w10 = M->w10[comp];
+    out->pool = M->pool; out->pool_lock = M->pool + ((size_t)DQ_MATCH_POOL_SLOTS << DQ_MATCH_MAX_BIG);
 }
 
 extern "C" {
@@ -38,6 +40,7 @@ dq_status dq_match_create(int d, dq_match** out) {
     DQ_REQUIRE(d >= 3 && d <= 15 && (d & 1), DQ_ERR_INVALID, "for the surface code d must be odd! (3 <= d <= 15)");
     dq_match* M = new dq_match();
     M->d = d;
+    M->pool = nullptr;
     LatticeHost L;
     lattice_build(d, &L);
     for (int comp = 0; comp < 2; ++comp) {
@@ -52,6 +55,15 @@ dq_status dq_match_create(int d, dq_match** out) {
             dq_set_error("dq_match_create: device allocation / upload failed (is a GPU present?)");
             for (int c2 = 0; c2 < 2; ++c2) { (void)hipFree(M->dist_dev[c2]); (void)hipFree(M->distB_dev[c2]); }
             delete M;
+            return DQ_ERR_HIP;
+        }
+    }
+    {
+        const size_t words = ((size_t)DQ_MATCH_POOL_SLOTS << DQ_MATCH_MAX_BIG) + DQ_MATCH_POOL_SLOTS;
+        if (hipMalloc(&M->pool, words * sizeof(u32)) != hipSuccess ||
+            hipMemset(M->pool + ((size_t)DQ_MATCH_POOL_SLOTS << DQ_MATCH_MAX_BIG), 0, DQ_MATCH_POOL_SLOTS * sizeof(u32)) != hipSuccess) {
+            dq_set_error("dq_match_create: scratch pool allocation failed");
+            dq_match_destroy(M);
             return DQ_ERR_HIP;
         }
     }
@@ -73,13 +85,14 @@ dq_status dq_match_create(int d, dq_match** out) {
 void dq_match_destroy(dq_match* M) {
     if (!M) return;
     for (int comp = 0; comp < 2; ++comp) { (void)hipFree(M->dist_dev[comp]); (void)hipFree(M->distB_dev[comp]); }
+    (void)hipFree(M->pool);
     delete M;
 }
 
 dq_status dq_match_info(const dq_match* M, int* nodes_per_component, int* max_defects, int* w10) {
     DQ_REQUIRE(M, DQ_ERR_INVALID, "dq_match_info: null argument");
     if (nodes_per_component) *nodes_per_component = M->n[0];
-    if (max_defects) *max_defects = DQ_MATCH_MAX_DEFECTS;
+    if (max_defects) *max_defects = DQ_MATCH_MAX_BIG;          // (defects of one CLUSTER that are matched exactly)
     if (w10) *w10 = M->w10[0];
     return DQ_OK;
 }

@@ -224,8 +224,11 @@ dq_status dq_env_get_tables(const dq_env* env, uint64_t* stab_qmask, uint64_t* q
  *   defects_dev  uint64 [batch][2 components][2 words]: bit i of a component = its i-th plaquette in row-major (a, b) order (the
  *                look-up referee's index convention); component 0 = type-3 plaquettes (X part), 1 = type-1 plaquettes (Z part)
  *   class_dev    uint8 [batch]: X part (+ 2 * Z part when both_components != 0) -- generate_one_hot_labels_surface_code's index
- *   inexact_dev  uint8 [batch] or NULL: 1 where a component had more than max_defects defects (the lowest max_defects are matched
- *                exactly, every further one goes to its nearer boundary)
+ *   inexact_dev  uint8 [batch] or NULL: 1 where the answer is not exact.  The defects are split into CLUSTERS (pairs that can never be worth
+ *                matching -- two boundary paths of the same total class are no longer -- separate them; the clusters' weights combine exactly) and
+ *                a cluster of up to max_defects (20) defects is matched exactly: up to 14 in LDS, beyond that in a scratch table in device
+ *                memory (rare, slower).  Inexact: a cluster beyond max_defects (its lowest max_defects matched exactly, the others sent to
+ *                their nearer boundary) or more than 32 defects in one component (those beyond the 32nd likewise)
  * ------------------------------------------------------------------------------------------- */
 typedef struct dq_match dq_match;
 dq_status dq_match_create(int d, dq_match** out);

@@ -20,15 +20,25 @@ single perfect-measurement round is small):
     bound: every part of a decomposition is at least that long; upper bound: the XOR of the chosen shortest paths has the right syndrome
     and class and at most that weight.)
   * f[S][c] over subsets S of the defects, lowest defect u of S either goes to the boundary or pairs with another v in S.
-  * More than MAX_DEFECTS defects (never seen at the surveyed error rates): the MAX_DEFECTS lowest ones are solved exactly, every further
-    one goes to its nearer boundary (ties -> class 0 path) -- deterministic, flagged `exact = False`.
+  * CLUSTERS (round 5).  A pair (u, v) whose shortest path of class c' is not strictly shorter than the best two boundary paths of the same total class
+    (min over c1 of distB[u][c1] + distB[v][c1 ^ c']) for EITHER c' never needs to be matched: in any pairing, for any target class, the pair can be
+    replaced by those two boundary paths at no greater weight and the same class.  So with the graph "u ~ v iff dist[u][v][c'] < that bound for some c'",
+    an optimal pairing exists that pairs defects only inside the connected components ("clusters") of that graph, and
+        (w_0, w_1)(D) = the (min, +) XOR-convolution of the clusters' (w_0, w_1):   (a0, a1) * (b0, b1) = (min(a0 + b0, a1 + b1), min(a0 + b1, a1 + b0)).
+    The subset DP runs per cluster: exact as long as no single cluster holds more than MAX_DEFECTS defects, whatever their total (up to MAX_LIST).
+    (Until round 4 the first 14 defects of the whole component were solved exactly and every further one was sent to its nearer boundary: a learning
+    agent's d = 9 fit met that fallback 629 times in one short run -- Environments.py:144-151 decides `done` with this answer.)
+  * Fallbacks, deterministic and flagged `exact = False`: of a cluster of more than MAX_DEFECTS defects the MAX_DEFECTS lowest are solved exactly and
+    every further one goes to its nearer boundary (ties -> the class-0 path); so does every defect beyond the first MAX_LIST of the component.
 """
 import numpy as np
 
 from . import referee
 
-MAX_DEFECTS = 14
+MAX_DEFECTS = 20                # per cluster (the device: up to 14 in LDS, up to 20 in a scratch table in device memory)
+MAX_LIST = 32                   # defects of a component that are listed and clustered
 INF = 255
+BIG = 1 << 20
 
 
 class ComponentGraph:
@@ -78,13 +88,9 @@ class ComponentGraph:
             w10 = min(w10, int(self.dist[u, u, 1]))
         self.w10 = min(w10, INF)
 
-    def weights(self, defects):
-        """(w_0, w_1, exact) for the defect list (node indices, ascending)."""
-        defects = list(defects)
-        extra = defects[MAX_DEFECTS:]
-        core = defects[:MAX_DEFECTS]
+    def _dp_recursive(self, core):
+        """f[all of `core`][c], c = 0, 1: exact subset DP in its textbook form (lowest defect of S -> boundary or -> a partner in S); small k (tests)."""
         k = len(core)
-        BIG = 1 << 20
         f = np.full((1 << k, 2), BIG, dtype=np.int64)
         f[0, 0] = 0
         for S in range(1, 1 << k):
@@ -104,15 +110,90 @@ class ComponentGraph:
                         if self.dist[u, v, cp] != INF:
                             best = min(best, f[rest ^ jbit, c ^ cp] + int(self.dist[u, v, cp]))
                     R ^= jbit
-                f[S, c] = best
-        w = [int(f[(1 << k) - 1, 0]), int(f[(1 << k) - 1, 1])]
-        for u in extra:                                  # beyond MAX_DEFECTS: nearer boundary, ties -> the class-0 path
+                f[S, c] = min(best, BIG)
+        return [int(f[(1 << k) - 1, 0]), int(f[(1 << k) - 1, 1])]
+
+    def _dp(self, core):
+        """The same minimum, walked like the device does: level by level of the subsets' HIGHEST defect (both predecessors of a subset lie below 2^h),
+        a level's 2^h subsets at once (numpy)."""
+        core = list(core)
+        k = len(core)
+        f = np.full((1 << k, 2), BIG, dtype=np.int64)
+        f[0, 0] = 0
+        d = lambda u, v, c: BIG if self.dist[u, v, c] == INF else int(self.dist[u, v, c])
+        b = lambda u, c: BIG if self.distB[u, c] == INF else int(self.distB[u, c])
+        for h in range(k):
+            base = 1 << h
+            r = np.arange(base)
+            g0, g1 = f[:base, 0], f[:base, 1]
+            b0, b1 = b(core[h], 0), b(core[h], 1)
+            best0, best1 = np.minimum(g0 + b0, g1 + b1), np.minimum(g1 + b0, g0 + b1)
+            for v in range(h):
+                has = (r >> v) & 1 == 1
+                rr = r ^ (1 << v)
+                q0, q1 = f[rr, 0], f[rr, 1]
+                d0, d1 = d(core[h], core[v], 0), d(core[h], core[v], 1)
+                c0, c1 = np.minimum(q0 + d0, q1 + d1), np.minimum(q1 + d0, q0 + d1)
+                best0 = np.where(has, np.minimum(best0, c0), best0)
+                best1 = np.where(has, np.minimum(best1, c1), best1)
+            f[base:2 * base, 0], f[base:2 * base, 1] = np.minimum(best0, BIG), np.minimum(best1, BIG)
+        return [int(f[(1 << k) - 1, 0]), int(f[(1 << k) - 1, 1])]
+
+    def _to_boundary(self, w, extra):
+        """Every defect of `extra` to its nearer boundary (ties -> the class-0 path) on top of (w_0, w_1)."""
+        for u in extra:
             cp = 1 if self.distB[u, 1] < self.distB[u, 0] else 0
             add = int(self.distB[u, cp])
             w = [w[cp] + add, w[1 ^ cp] + add]                 # new class c = old class c ^ cp
+        return w
+
+    def connected(self, u, v):
+        """The pair may be worth matching: for some path class its shortest path is strictly shorter than the best two boundary paths of that total class."""
+        b = lambda x, c: BIG if self.distB[x, c] == INF else int(self.distB[x, c])
+        for cp in (0, 1):
+            if self.dist[u, v, cp] == INF:
+                continue
+            if int(self.dist[u, v, cp]) < min(b(u, 0) + b(v, cp), b(u, 1) + b(v, 1 ^ cp)):
+                return True
+        return False
+
+    def clusters(self, defects):
+        """Connected components of `connected` over the defect list, each ascending, ordered by their lowest member."""
+        defects = list(defects)
+        n = len(defects)
+        comp = list(range(n))
+        changed = True
+        while changed:                                   # label propagation to the component's lowest index (what the wave does)
+            changed = False
+            for i in range(n):
+                m = comp[i]
+                for j in range(n):
+                    if j != i and self.connected(defects[i], defects[j]):
+                        m = min(m, comp[j])
+                if m != comp[i]:
+                    comp[i], changed = m, True
+        return [[defects[i] for i in range(n) if comp[i] == r] for r in range(n) if comp[r] == r]
+
+    def weights(self, defects):
+        """(w_0, w_1, exact) for the defect list (node indices, ascending)."""
+        defects = list(defects)
+        listed, beyond = defects[:MAX_LIST], defects[MAX_LIST:]
+        exact = not beyond
+        w = [0, BIG]
+        for cl in self.clusters(listed):
+            wc = self._dp(cl[:MAX_DEFECTS])
+            if len(cl) > MAX_DEFECTS:
+                wc, exact = self._to_boundary(wc, cl[MAX_DEFECTS:]), False
+            w = [min(w[0] + wc[0], w[1] + wc[1], BIG), min(w[0] + wc[1], w[1] + wc[0], BIG)]
+        w = self._to_boundary(w, beyond)
         w0 = min(w[0], w[1] + self.w10)
         w1 = min(w[1], w[0] + self.w10)
-        return w0, w1, not extra
+        return w0, w1, exact
+
+    def weights_unclustered(self, defects):
+        """(w_0, w_1) by ONE subset DP over all the defects (tests: what the clustered answer must equal; 2^k table, k <= ~20)."""
+        w = self._dp(list(defects))
+        return min(w[0], w[1] + self.w10), min(w[1], w[0] + self.w10)
 
     def classify(self, index):
         """Predicted class of the syndrome whose bit i is the i-th plaquette of lattice.typed_order (the look-up referee's index)."""

@@ -188,4 +188,4 @@ def test_rccl_preflight_on_a_one_rank_group():
             "except RuntimeError as e:\n    assert 'holds 1 ranks, 2 expected' in str(e)\n"
             "c.close(); dist.destroy_process_group(); print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stderr[-2000:]     # (RCCL prints its version banner through C stdio at exit, behind the line)

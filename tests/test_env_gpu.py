@@ -605,18 +605,32 @@ def test_matching_referee_on_the_gpu(dq, torch_mod, d):
         return [v & 0xFFFFFFFFFFFFFFFF, v >> 64]
 
     cases = [([], [])] + [([i], [n - 1 - i]) for i in range(n)]
-    for k in list(range(2, 13)) + [M.MAX_DEFECTS, M.MAX_DEFECTS + 1, min(n, M.MAX_DEFECTS + 5)]:
+    # (13 .. 16: around the 14 defects the LDS table holds -- beyond it the cluster is solved in the scratch pool; MAX_DEFECTS + 1 ..: the flagged fallback;
+    # 33 ..: beyond the 32 listed defects of a component)
+    for k in list(range(2, 13)) + [13, 14, 15, 16, 18, M.MAX_DEFECTS, M.MAX_DEFECTS + 1, min(n, M.MAX_DEFECTS + 5), min(n, 33), min(n, 40)]:
         for _ in range(6 if k <= 10 else 2):
             kk = min(k, n)
             cases.append((sorted(rng.choice(n, size=kk, replace=False)), sorted(rng.choice(n, size=min(kk, 6), replace=False))))
     defects = np.array([[words(x), words(z)] for x, z in cases], dtype=np.uint64)
     cls, flag = R.decode(defects)
     cls, flag = cls.cpu().numpy(), flag.cpu().numpy()
+    paths = set()
     for i, (x, z) in enumerate(cases):
         wx0, wx1, ex = graphs[0].weights(x)
         wz0, wz1, ez = graphs[1].weights(z)
         assert cls[i] == int(wx1 < wx0) + 2 * int(wz1 < wz0), (d, i, x, z)
         assert flag[i] == int(not (ex and ez))
+        big = max([len(c) for c in graphs[0].clusters(list(x)[:M.MAX_LIST])] or [0])
+        paths.add("inexact" if not ex else "pool" if big > 14 else "lds")
+    if d >= 7:
+        assert paths == {"lds", "pool", "inexact"}, paths           # every path of csrc/match_dev.h was taken
+    # many concurrent waves through the scratch pool's eight slots: the same answers (a slot is taken with an atomic and given back)
+    if d >= 9:
+        heavy = [c for c in cases if 15 <= len(c[0]) <= 18][:2]
+        many = np.array([[words(x), words(z)] for x, z in heavy] * 100, dtype=np.uint64)
+        c2, f2 = R.decode(many)
+        c2 = c2.cpu().numpy().reshape(100, len(heavy))
+        assert (c2 == c2[0]).all() and not f2.cpu().numpy().any()
     if d <= 7:                                                      # against the look-up referee the environment builds on the GPU
         env = dq.VectorEnv(n_envs=4, d=d, error_model="DP", use_Y=False, volume_depth=3, p_phys=0.01, p_meas=0.01)
         lx, lz = env.get_referee()

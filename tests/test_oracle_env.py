@@ -143,10 +143,41 @@ def test_matching_referee_equals_the_lookup_referee(d):
                     idx.append(sum(1 << int(b) for b in rng.choice(g.n, size=k, replace=False)))
         bad = [i for i in idx if g.classify(i) != lut[i]]
         assert not bad, (d, typ, bad[:5])
-    # beyond MAX_DEFECTS the rule is deterministic and flagged
+        if d == 7:
+            # 13 - 22 defects on the 24 plaquettes: beyond the 14 the LDS table holds, through the clusters and the big table, still
+            # the look-up referee's answer -- an independent exact check of the cluster argument (the table comes from a breadth-first search over
+            # error patterns, not from matching)
+            sizes = []
+            for k in (13, 15, 16, 17, 18, 19, 20):
+                for _ in range(3):
+                    D = sorted(int(b) for b in rng.choice(g.n, size=k, replace=False))
+                    w0, w1, exact = g.weights(D)
+                    assert exact and int(w1 < w0) == lut[sum(1 << b for b in D)], (k, D)
+                    sizes.append(max(len(c) for c in g.clusters(D)))
+            assert max(sizes) > 14                              # (the big-table path was exercised, not only small clusters)
+    # beyond MAX_DEFECTS in ONE cluster the rule is deterministic and flagged
     g = M.ComponentGraph(7, 3)
     w0, w1, exact = g.weights(list(range(M.MAX_DEFECTS + 3)))
     assert not exact and min(w0, w1) < 255
+
+
+def test_matching_referee_clusters_at_distance_nine():
+    """d = 9 (no table to compare with): the clustered answer equals ONE subset DP over all the defects for 15 - 18 random defects, the level-wise
+    walk equals the textbook recursion, and far-apart defect groups do split into clusters (so that 25 defects in three groups are still exact)."""
+    from oracle import matching_referee as M
+    g = M.ComponentGraph(9, 3)
+    rng = np.random.RandomState(3)
+    for k in (6, 9, 11):
+        D = sorted(int(b) for b in rng.choice(g.n, size=k, replace=False))
+        assert g._dp(D) == g._dp_recursive(D)
+    for k in (15, 16, 18):
+        D = sorted(int(b) for b in rng.choice(g.n, size=k, replace=False))
+        w0, w1, exact = g.weights(D)
+        assert exact and (w0, w1) == g.weights_unclustered(D)
+    # two defects next to opposite boundaries never need each other
+    far = [u for u in range(g.n) if min(g.distB[u]) == 1]
+    a, b = far[0], max(far, key=lambda v: min(g.dist[far[0], v]))
+    assert not g.connected(a, b) and len(g.clusters(sorted([a, b]))) == 2
 
 
 @pytest.mark.parametrize("d", [3, 5])
