@@ -606,7 +606,7 @@ class DQNCore:
                 self._inexact_acc.zero_()
                 import warnings
                 warnings.warn(f"{n} lattice-steps since the last synchronisation were refereed by the matching decoder's inexact fallback "
-                              f"(> 14 defects in one component; {self.inexact_total} in total): their reward / done are heuristic")
+                              f"(a cluster of more than 20 defects, or more than 32 defects in one component; {self.inexact_total} in total): their reward / done are heuristic")
         return s
 
     # -- evaluation on a scratch ring ---------------------------------------------------------------------------------------
