@@ -33,7 +33,7 @@
 //
 // LDS: [c1w 8 KB | c2w 32 KB | conv3 16 KB | bits table 4 KB | per wave 4 KB] = 124 KB.  Inside a wave's 4 KB: sample s at 2048 s, piece l 1024 bytes
 // behind piece h, and the 16-byte chunk c of pixel p at slot CW_SLOT1[2 p + c] (quarter image: 2 chunks per pixel) / CW_SLOT2[4 p + c] (a2: 4 chunks)
-// -- placements found by annealing (tools/probe/wave_layout.py) under which every ds_read_b128 of an operand touches 16 distinct bank quadruples in each
+// -- placements found by annealing (tools/probe/wave_layout.py 5) under which every ds_read_b128 of an operand touches 16 distinct bank quadruples in each
 // of its four lane groups (MI355X_MICROARCH.md LDS table) for both taps rows / all four taps; with rows in pixel order every such read took 8 cycles instead of 4.
 // Workgroups are dealt to the launch's weight sets in proportion to their samples (a workgroup serves ONE packed buffer); inside a weight set every
 // job's samples are split evenly over its workgroups, so the training job's stores are spread over all of them.
