@@ -146,6 +146,7 @@ SIGNATURES = {
     "dq_qnet_td_backward_phase0": (_i, [_vp, _vp, ctypes.POINTER(TdJob), _vp, _vp]),
     "dq_qnet_td_backward_phase0_env": (_i, [_vp, _vp, ctypes.POINTER(TdJob), _vp, _vp, ctypes.POINTER(EnvStepJob), _vp]),
     "dq_replay_sample": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
+    "dq_replay_sample_multi": (_i, [_vp, _i, _i, _i, _i, _i, _seedp, _u64, _i, _u32, _vp, _vp]),
     "dq_td_target": (_i, [_vp, _vp, _vp, _vp, _vp, _dbl, _i, _i, _vp, _vp]),
     "dq_td_loss_grad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _vp, _vp, _vp]),
     "dq_episode_stats": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),

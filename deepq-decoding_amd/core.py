@@ -81,6 +81,8 @@ class DQNCore:
         self.enable_double_dqn = enable_double_dqn
         self.seed = tuple(env.seed) if seed is None else tuple(seed)
         self.rank, self.world_size, self.pg = rank, world_size, process_group
+        self.last_index = None       # rows of the most recent update (self.index, or a row of _index_multi)
+        self._index_multi = None     # [k - 1][B] rows of the extra updates of a vector step (_extra_updates)
         self._rccl, self._rccl2, self._rccl_tried = None, None, False       # the learner's own RCCL communicator (dist.make_rccl), created at the first several-GPU update
         self.L = _lib.lib()
         dev = self.device
@@ -277,17 +279,45 @@ class DQNCore:
                                           self.N, ptr(self.stats), self._stream()))
             self._stats_pending = None
 
-    def update(self):
-        """One minibatch update (keras-rl DQNAgent.backward's training branch)."""
+    def update(self, rows=None):
+        """One minibatch update (keras-rl DQNAgent.backward's training branch).  rows: its minibatch, already drawn (_extra_updates)."""
         assert self.filled >= MIN_FILLED, "fewer than three complete transitions in the replay ring"
         self._join_env()
         B, N, T = self.batch_size, self.N, self.T
         self.updates += 1
         t = self.updates
         _, sample_base = _dist.shard(self.rank, N, B)
-        self._take_minibatch(t, self.cur, self.filled, sample_base)
-        self.net.forward_multi(self._update_jobs(t, sample_base))
-        self._learn(t)
+        if rows is None:
+            self._take_minibatch(t, self.cur, self.filled, sample_base)
+            self.last_index = self.index
+            self.net.forward_multi(self._update_jobs(t, sample_base))
+            self._learn(t)
+            return
+        self.last_index = rows                                      # (the rows of the last update: self.index keeps its own buffer for the look-ahead draws)
+        own, self.index = self.index, rows                          # (every job record and the TD step read self.index)
+        try:
+            self.net.forward_multi(self._update_jobs(t, sample_base))
+            self._learn(t)
+        finally:
+            self.index = own
+
+    def _extra_updates(self, k):
+        """k further updates on the ring as it stands (DQNAgent.updates_per_vector_step - 1).  The first one's minibatch came with the environment
+        launch; the others' are drawn by ONE launch here (dq_replay_sample_multi: the draws of consecutive updates on one ring state do not depend
+        on each other) instead of a launch in front of every update -- round 5: one launch fewer per extra update."""
+        if k <= 0:
+            return
+        self.update()
+        if k == 1:
+            return
+        B = self.batch_size
+        if self._index_multi is None or self._index_multi.shape[0] < k - 1:
+            self._index_multi = torch.empty((k - 1, B), dtype=torch.int32, device=self.device)
+        _, sample_base = _dist.shard(self.rank, self.N, B)
+        _q.replay_sample_multi(self.terminal_ring, self.N, self.T, self.cur, self.filled, B, self.seed, self.updates + 1, k - 1,
+                               sample_base=sample_base, out=self._index_multi)
+        for i in range(k - 1):
+            self.update(rows=self._index_multi[i])
 
     def _take_minibatch(self, t, head, filled, sample_base):
         """self.index <- rows of update t on a ring with `head` / `filled`: the look-ahead draw if an environment launch made exactly
@@ -454,6 +484,7 @@ class DQNCore:
         t = self.updates + 1
         _, sample_base = _dist.shard(self.rank, N, B)
         self._take_minibatch(t, nxt, filled, sample_base)        # (drawn from the ring as it WILL be after this step)
+        self.last_index = self.index
         jobs = self._update_jobs(t, sample_base)
         jobs.append(self._obs_job(params=self.params, slot=cur, batch=N, out=self.q_act, packed=self.params_pk))
         self.net.forward_multi(jobs)
@@ -482,8 +513,7 @@ class DQNCore:
             except BaseException:
                 env.disarm_patch_output()                           # (an error in front of the riding launch: no armed ring slot outlives the call)
                 raise
-            for _ in range(extra_updates):
-                self.update()
+            self._extra_updates(extra_updates)
             return
         args = (env._h, ptr(self.q_act), float(eps), int(masked_greedy), seed, int(self.vector_steps), ptr(self.action_ring[cur]), 1,
                 self._obs_slot(nxt), ptr(self.reward_ring[cur]), ptr(self.terminal_ring[cur]), ptr(env.legal),
@@ -507,8 +537,7 @@ class DQNCore:
         self.vector_steps += 1
         self.updates = t
         self._learn(t)
-        for _ in range(extra_updates):
-            self.update()
+        self._extra_updates(extra_updates)
 
     def read_metrics(self):
         """(loss, mean_q) of the last update on this rank; reduces the per-block partials first (syncs)."""

@@ -20,6 +20,15 @@ __global__ void replay_sample_kernel(const u8* __restrict__ terminal, int n_envs
     index[b] = row;
 }
 
+// the minibatches of n_updates consecutive updates t0, t0 + 1, ... on ONE ring state, in one launch: index[u][b] = the row update t0 + u draws for sample b
+__global__ void replay_sample_multi_kernel(const u8* __restrict__ terminal, int n_envs, int n_slots, int head_slot, int filled,
+                                           int batch, u32 seed0, u32 seed1, u64 t0, int n_updates, u32 sample_base, int32_t* __restrict__ index) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)batch * n_updates) return;
+    const int u = (int)(i / batch), b = (int)(i - (long long)u * batch);
+    index[i] = dq_replay_row(terminal, n_envs, n_slots, head_slot, filled, batch, seed0, seed1, t0 + (u64)u, sample_base + (u32)b);
+}
+
 // y_b = r_b + gamma * (1 - terminal_b) * Q_target(s1_b)[argmax_a Q_online(s1_b)[a]]; one wave per sample
 __global__ void td_target_kernel(const float* __restrict__ q_online, const float* __restrict__ q_target,
                                  const float* __restrict__ reward, const u8* __restrict__ terminal,
@@ -329,6 +338,19 @@ dq_status dq_replay_sample(const uint8_t* terminal_ring_dev, int n_envs, int n_s
     DQ_REQUIRE((long long)n_envs * n_slots < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_replay_sample: ring too large for 32-bit rows");
     replay_sample_kernel<<<(batch + 255) / 256, 256, 0, (hipStream_t)stream>>>(terminal_ring_dev, n_envs, n_slots, head_slot, filled_slots,
                                                                              batch, seed[0], seed[1], t, sample_base, index_dev);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}
+
+dq_status dq_replay_sample_multi(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots, int batch,
+                                 const uint32_t seed[2], uint64_t t0, int n_updates, uint32_t sample_base, int32_t* index_dev, void* stream) {
+    DQ_REQUIRE(terminal_ring_dev && index_dev && seed, DQ_ERR_INVALID, "dq_replay_sample_multi: null argument");
+    DQ_REQUIRE(n_envs >= 1 && n_slots >= 4 && batch >= 1 && n_updates >= 1 && head_slot >= 0 && head_slot < n_slots, DQ_ERR_INVALID, "dq_replay_sample_multi: bad sizes");
+    DQ_REQUIRE(filled_slots >= DQ_REPLAY_MIN_FILLED && filled_slots <= n_slots, DQ_ERR_STATE, "dq_replay_sample_multi: need at least three complete transitions per lattice");
+    DQ_REQUIRE((long long)n_envs * n_slots < (1ll << 31) && (long long)batch * n_updates < (1ll << 31), DQ_ERR_UNSUPPORTED, "dq_replay_sample_multi: too large for 32-bit rows");
+    const long long total = (long long)batch * n_updates;
+    replay_sample_multi_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(terminal_ring_dev, n_envs, n_slots, head_slot, filled_slots,
+                                                                                              batch, seed[0], seed[1], t0, n_updates, sample_base, index_dev);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

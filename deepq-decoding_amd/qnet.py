@@ -359,6 +359,16 @@ def adam_step(params, grads, m, v, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7
                                   float(epsilon), int(t), _lib.current_stream(params.device)))
 
 
+def replay_sample_multi(terminal_ring, n_envs, n_slots, head_slot, filled_slots, batch, seed, t0, n_updates, sample_base=0, out=None):
+    """index[u] = replay_sample(..., t = t0 + u): the minibatches of n_updates consecutive updates on one ring state, one launch."""
+    if out is None:
+        out = torch.empty((n_updates, batch), dtype=torch.int32, device=terminal_ring.device)
+    assert out.is_contiguous() and out.numel() >= n_updates * batch
+    check(_lib.lib().dq_replay_sample_multi(ptr(terminal_ring), int(n_envs), int(n_slots), int(head_slot), int(filled_slots), int(batch),
+                                            _seed_arr(seed), int(t0), int(n_updates), int(sample_base), ptr(out), _lib.current_stream(terminal_ring.device)))
+    return out
+
+
 def replay_sample(terminal_ring, n_envs, n_slots, head_slot, filled_slots, batch, seed, t, sample_base=0, out=None):
     if out is None:
         out = torch.empty(batch, dtype=torch.int32, device=terminal_ring.device)

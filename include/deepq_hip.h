@@ -520,6 +520,13 @@ dq_status dq_replay_sample(const uint8_t* terminal_ring_dev, int n_envs, int n_s
                            int batch, const uint32_t seed[2], uint64_t t, uint32_t sample_base, int32_t* index_dev,
                            void* stream);
 
+/* The same for n_updates consecutive updates t0, t0 + 1, ... drawn on ONE ring state, in one launch: index_dev int32 [n_updates][batch], row u = what
+ * dq_replay_sample gives for t = t0 + u.  (The reference trains one minibatch per environment step, Single_Point_Training_Script.py:119-127; with N
+ * lattices per vector step that is several updates per step on the same memory -- their draws do not depend on each other.) */
+dq_status dq_replay_sample_multi(const uint8_t* terminal_ring_dev, int n_envs, int n_slots, int head_slot, int filled_slots,
+                                 int batch, const uint32_t seed[2], uint64_t t0, int n_updates, uint32_t sample_base,
+                                 int32_t* index_dev, void* stream);
+
 /* Double-DQN target: y_b = reward[r_b] + gamma * (1 - terminal[r_b]) * Q_target(s1_b)[argmax_a Q_online(s1_b)[a]],
  * r_b = index_dev ? index_dev[b] : b. */
 dq_status dq_td_target(const float* q_online_s1_dev, const float* q_target_s1_dev, const float* reward_dev,

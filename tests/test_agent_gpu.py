@@ -186,7 +186,7 @@ def test_device_loop_with_three_updates_per_vector_step(dq, torch_mod):
                 p = core.params.cpu().numpy().astype(np.float64)
                 m, v = core.m.cpu().numpy().astype(np.float64), core.v.cpu().numpy().astype(np.float64)
         assert core.updates == u
-        assert np.array_equal(core.index.cpu().numpy(), idx)        # the last update's rows
+        assert np.array_equal(core.last_index.cpu().numpy(), idx)   # the last update's rows (extra updates beyond the first read a row of ONE multi-update draw)
         met = np.array(core.read_metrics())
         assert abs(met[0] - loss) < 2e-5 and abs(met[1] - mean_q) < 2e-5, (met, loss, mean_q)
         big = np.abs(g) > 1e-6

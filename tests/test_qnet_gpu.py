@@ -558,6 +558,14 @@ def test_replay_sample_rule(dq, torch_mod):
         if batch >= 20 * len(allowed):
             counts = np.bincount(idx, minlength=n_slots * n_envs)[sorted(allowed)]
             assert counts.min() > 0.15 * batch / len(allowed) and counts.max() < 3.0 * batch / len(allowed)
+    # several consecutive updates' minibatches in ONE launch (dq_replay_sample_multi: the extra updates of a vector step): row u = update t + u's own draw
+    from importlib import import_module
+    Q = import_module("deepq-decoding_amd.qnet")
+    term = (rng.rand(50, 64) < 0.15).astype(np.uint8)
+    term_t = torch.from_numpy(term).cuda()
+    multi = Q.replay_sample_multi(term_t, 64, 50, 17, 50, 777, seed, t, 5, sample_base=base).cpu().numpy()
+    for u in range(5):
+        assert np.array_equal(multi[u], dq.replay_sample(term_t, 64, 50, 17, 50, 777, seed, t + u, sample_base=base).cpu().numpy()), u
     # WITHOUT replacement (keras-rl random.sample) whenever the candidates suffice: no terminals -> every row of a minibatch distinct,
     # up to the whole candidate set (batch == M: a permutation of it); with terminals the first draws that stand are distinct among
     # themselves (only redraws may repeat a row).  Marginally uniform: over many updates a fixed sample position visits the rows evenly.
