@@ -1,13 +1,13 @@
 #!/bin/bash
 # The round's final measurement set (GPU box, repo root): tools/final_measure.sh <tag>
-tag="${1:-r04}"
+tag="${1:-r05}"
 tools/measure.sh "$tag" 2>&1 | tail -12
 tools/pmc_any.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" sqA bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -8 | tee gpurun_out/$tag/sqA.txt
 tools/pmc_any.sh "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" sqB bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -8 | tee gpurun_out/$tag/sqB.txt
 rm -rf gpurun_out/sqA gpurun_out/sqB
-# the same four + four SQ counters with the uint8 ring (the round-3 form of the first convolution), for the deltas NOTEBOOK.md quotes
-DQ_COMPACT_OBS=0 tools/pmc_any.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" sqA bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -8 | tee gpurun_out/$tag/sqA_uint8ring.txt
-DQ_COMPACT_OBS=0 tools/pmc_any.sh "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" sqB bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -8 | tee gpurun_out/$tag/sqB_uint8ring.txt
+# the same four + four SQ counters with the round-4 forward (DQ_CONV_FORM=group), for the deltas NOTEBOOK.md quotes
+DQ_CONV_FORM=group tools/pmc_any.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" sqA bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -8 | tee gpurun_out/$tag/sqA_groupform.txt
+DQ_CONV_FORM=group tools/pmc_any.sh "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" sqB bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>&1 | tail -8 | tee gpurun_out/$tag/sqB_groupform.txt
 rm -rf gpurun_out/sqA gpurun_out/sqB
 # the printed error / fragile-fraction lines of the shipped-weight and replay tests (keep them in profiles/)
 python -m pytest tests/test_shipped_weights.py tests/test_agent_gpu.py -q -s -m gpu -k "shipped or replayed or beyond" 2>&1 | grep -vE "^\s*$|warnings.warn|UserWarning" | tail -80 > gpurun_out/$tag/test_printed_lines.txt
