@@ -83,6 +83,16 @@ class DQNCore:
         self.rank, self.world_size, self.pg = rank, world_size, process_group
         self.last_index = None       # rows of the most recent update (self.index, or a row of _index_multi)
         self._index_multi = None     # [k - 1][B] rows of the extra updates of a vector step (_extra_updates)
+        # The extra updates' TARGET forwards on a second stream (round 5; DQ_TARGET_AHEAD=1, off by default): the target network does not change inside a
+        # vector step and all the extra updates' rows are drawn by one launch in front of them (dq_replay_sample_multi), so Q_target(s1) of update i
+        # needs nothing update i - 1 produces.  A second network handle (its own per-job scratch) evaluates it on a side stream, released by a mark
+        # inside update i - 1's backward (dq_qnet_mark_conv_backward) and handed to update i's TD launch by an event; the updates' own launch pair then
+        # carries two forwards instead of three.  Bit-identical results (tests/test_agent_gpu.py) -- and SLOWER on one MI355X: 32 updates of 4096 per
+        # vector step run 123.9 us per update on one stream and 138.5 us this way (135.8 us with the side stream running free): the main stream's
+        # kernels do shrink to 113.5 us, but the two event hand-offs per update cost more than the 10 us they move (NOTEBOOK.md Round 5 section 3;
+        # the same result as DQ_ENV_STREAM in round 1 and DQ_DIST_MODE=overlap in round 4).
+        self.target_ahead = os.environ.get("DQ_TARGET_AHEAD", "0") == "1"
+        self._side = None            # (QNetwork, stream, row event, [events], Q_target(s1) rows [k - 1][B][A])
         self._rccl, self._rccl2, self._rccl_tried = None, None, False       # the learner's own RCCL communicator (dist.make_rccl), created at the first several-GPU update
         self.L = _lib.lib()
         dev = self.device
@@ -279,8 +289,9 @@ class DQNCore:
                                           self.N, ptr(self.stats), self._stream()))
             self._stats_pending = None
 
-    def update(self, rows=None):
-        """One minibatch update (keras-rl DQNAgent.backward's training branch).  rows: its minibatch, already drawn (_extra_updates)."""
+    def update(self, rows=None, target_ready=None):
+        """One minibatch update (keras-rl DQNAgent.backward's training branch).  rows: its minibatch, already drawn (_extra_updates);
+        target_ready: (Q_target(s1) of those rows, the event behind the side-stream forward that writes it)."""
         assert self.filled >= MIN_FILLED, "fewer than three complete transitions in the replay ring"
         self._join_env()
         B, N, T = self.batch_size, self.N, self.T
@@ -295,11 +306,15 @@ class DQNCore:
             return
         self.last_index = rows                                      # (the rows of the last update: self.index keeps its own buffer for the look-ahead draws)
         own, self.index = self.index, rows                          # (every job record and the TD step read self.index)
+        own_q1 = self.q1_target
         try:
-            self.net.forward_multi(self._update_jobs(t, sample_base))
+            self.net.forward_multi(self._update_jobs(t, sample_base, with_target=target_ready is None))
+            if target_ready is not None:
+                self.q1_target = target_ready[0]
+                torch.cuda.current_stream(self.device).wait_event(target_ready[1])
             self._learn(t)
         finally:
-            self.index = own
+            self.index, self.q1_target = own, own_q1
 
     def _extra_updates(self, k):
         """k further updates on the ring as it stands (DQNAgent.updates_per_vector_step - 1).  The first one's minibatch came with the environment
@@ -316,8 +331,53 @@ class DQNCore:
         _, sample_base = _dist.shard(self.rank, self.N, B)
         _q.replay_sample_multi(self.terminal_ring, self.N, self.T, self.cur, self.filled, B, self.seed, self.updates + 1, k - 1,
                                sample_base=sample_base, out=self._index_multi)
+        if not (self.target_ahead and self.net.fused_supported and self.net.fused_enabled):
+            for i in range(k - 1):
+                self.update(rows=self._index_multi[i])
+            return
+        # Q_target(s1) of update i + 1 on the side stream, released by a mark inside update i's backward (dq_qnet_mark_conv_backward: behind the
+        # convolutional backward's launch -- the final reduction and the repacking that follow leave most of the device idle) and handed to update
+        # i + 1's TD launch by an event of its own.  The first one goes out at once.
+        side = self._side_setup(k - 1)
+        self._side_forward(0, None)
         for i in range(k - 1):
-            self.update(rows=self._index_multi[i])
+            last = i + 1 == k - 1
+            if not last:
+                self.net.mark_conv_backward(side[5][i])
+            try:
+                self.update(rows=self._index_multi[i], target_ready=(side[4][i], side[3][i]))
+            finally:
+                self.net.mark_conv_backward(None)
+            if not last:
+                self._side_forward(i + 1, side[5][i])
+
+    def _side_setup(self, n):
+        B, net = self.batch_size, self.net
+        if self._side is None:
+            net2 = _q.QNetwork(net.input_shape, net.c_layers, net.ff_layers, net.n_actions, dueling=net.dueling, max_batch=net.max_batch, device=self.device)
+            if self.compact:
+                net2.set_patch_input(self.env.volume_depth, self.env.patch_stride)
+            # [network handle with its own per-job scratch, stream, event behind the rows' draw, per-update "Q_target ready" events, Q_target(s1) rows,
+            #  per-update marks inside the backward]
+            self._side = [net2, torch.cuda.Stream(device=self.device), torch.cuda.Event(), [], None, []]
+        side = self._side
+        if side[4] is None or side[4].shape[0] < n:
+            side[4] = torch.empty((n, B, self.A), dtype=torch.float32, device=self.device)
+        while len(side[3]) < n:
+            side[3].append(torch.cuda.Event())
+            side[5].append(torch.cuda.Event())
+        side[2].record(torch.cuda.current_stream(self.device))      # behind the launch that drew the rows (and behind every reader of last step's Q_target rows)
+        return side
+
+    def _side_forward(self, i, after):
+        """Q_target(s1) of extra update i (rows self._index_multi[i]) on the side stream, behind `after` (an event of the main stream) or, the first one,
+        behind the rows' draw."""
+        net2, stream, e_rows, ready, q1, _ = self._side
+        with torch.cuda.stream(stream):
+            stream.wait_event(e_rows if after is None else after)
+            net2.forward_multi([self._obs_job(params=self.target, batch=self.batch_size, index=self._index_multi[i], index_off=self.N,
+                                              index_mod=self.T * self.N, out=q1[i], packed=self.target_pk)])
+            ready[i].record(stream)
 
     def _take_minibatch(self, t, head, filled, sample_base):
         """self.index <- rows of update t on a ring with `head` / `filled`: the look-ahead draw if an environment launch made exactly
@@ -329,12 +389,14 @@ class DQNCore:
                              out=self.index)
         self._presampled = None
 
-    def _update_jobs(self, t, sample_base):
+    def _update_jobs(self, t, sample_base, with_target=True):
         # Q_online(s1) picks the action, Q_target(s1) values it (double DQN; without it Q_target does both); the training forward
         # on s0 is independent of both, so the three share one pair of launches
         B, N = self.batch_size, self.N
         rows = self.T * N
-        jobs = [self._obs_job(params=self.target, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target, packed=self.target_pk)]
+        jobs = []
+        if with_target:
+            jobs.append(self._obs_job(params=self.target, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_target, packed=self.target_pk))
         if self.enable_double_dqn:
             jobs.append(self._obs_job(params=self.params, batch=B, index=self.index, index_off=N, index_mod=rows, out=self.q1_online,
                                       packed=self.params_pk))

@@ -2041,6 +2041,11 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;
     dq_launch(DQ_K_CONV_BWD, ck, dim3(wgs), dim3(CB_THREADS), cp.lds, st, ca);
     DQ_LAUNCH_CHECK();
+    if (Q->mark_event) {                                            // dq_qnet_mark_conv_backward: the caller's side stream starts from here
+        const hipError_t me = hipEventRecord(static_cast<hipEvent_t>(Q->mark_event), st);
+        Q->mark_event = nullptr;
+        DQ_HIP(me);
+    }
 
     // ---- 4. fixed-order reductions of the partials into the flat gradient ------------------------------------------------
     ReduceArgs ra;

@@ -63,6 +63,7 @@ struct dq_qnet {
     u32* keep_bits;
     DropTag kb_tag;              // what keep_bits holds (valid = 1)
     DropTag last_drop;           // the last fused training forward's dropout draw (valid = 0: none)
+    void* mark_event;            // dq_qnet_mark_conv_backward: hipEvent_t recorded behind the next fused convolutional backward's launch (one-shot)
     float grad_scale_hint;       // dq_qnet_set_grad_scale: loss scale of caller-supplied dq (0 = unknown: measured on the device)
     float bwd_scale;             // fused backward: power-of-two scale the gradients of the last dense phase carry (0: the device-computed one)
     int use_fused;               // fused LDS-resident chains when the configuration allows it

@@ -477,6 +477,12 @@ dq_status dq_qnet_set_grad_scale(dq_qnet* Q, double grad_scale) {
     return DQ_OK;
 }
 
+dq_status dq_qnet_mark_conv_backward(dq_qnet* Q, void* hip_event) {
+    DQ_REQUIRE(Q, DQ_ERR_INVALID, "dq_qnet_mark_conv_backward: null handle");
+    Q->mark_event = hip_event;
+    return DQ_OK;
+}
+
 dq_status dq_qnet_range_check(dq_qnet* Q, void* stream) {
     DQ_REQUIRE(Q, DQ_ERR_INVALID, "dq_qnet_range_check: null handle");
     unsigned* flag = fused_range_flag(Q);
@@ -626,6 +632,7 @@ static dq_status backward_phases(dq_qnet* Q, const float* params_dev, const floa
     const int B = Q->last_train_batch, nl = Q->n_layers, nc = Q->cfg.n_conv;
     DQ_SAME_PATH(Q, Q->use_fused && fused_backward_supported(Q));
     if (Q->use_fused && fused_backward_supported(Q)) return fused_backward(Q, params_dev, dq_dev, grads_dev, phases, st);
+    Q->mark_event = nullptr;                                        // (dq_qnet_mark_conv_backward: the per-layer path has no such point)
     if (phases & 1) {
         // gradient w.r.t. the last layer's (linear) output
         float* g = Q->gz[nl - 1];

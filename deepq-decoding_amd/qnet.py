@@ -64,6 +64,13 @@ class QNetwork:
         measures max |dq| on the device).  See include/deepq_hip.h dq_qnet_set_grad_scale."""
         check(self.L.dq_qnet_set_grad_scale(self._h, float(grad_scale)))
 
+    def mark_conv_backward(self, event):
+        """The next fused backward records `event` (torch.cuda.Event) right behind its convolutional kernel's launch
+        (include/deepq_hip.h dq_qnet_mark_conv_backward); None clears a pending mark."""
+        if event is not None and not event.cuda_event:
+            event.record(torch.cuda.current_stream(self.device))    # (torch creates the hipEvent_t lazily, at the first record)
+        check(self.L.dq_qnet_mark_conv_backward(self._h, ctypes.c_void_p(event.cuda_event) if event is not None else None))
+
     def set_patch_input(self, n_syndrome_planes, stride_words):
         """Declare the observation's plane structure so that jobs may read patch words (include/deepq_hip.h dq_qnet_set_patch_input,
         dq_env_patch_output; `patch=True` in a forward_multi job) instead of padded uint8 images.  Call before pack()."""

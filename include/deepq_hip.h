@@ -389,6 +389,14 @@ dq_status dq_qnet_backward(dq_qnet* net, const float* params_dev, const float* d
  * the fused TD path is used, and the two paths give the same bits.  0 (default) = not declared.  No reference counterpart. */
 dq_status dq_qnet_set_grad_scale(dq_qnet* net, double grad_scale);
 
+/* A mark inside the NEXT fused backward of this network (dq_qnet_backward*, dq_qnet_td_backward*): `hip_event` (a hipEvent_t) is recorded on that
+ * call's stream right behind the launch of the convolutional backward, i.e. in front of the final reduction / optimizer step and whatever the
+ * caller launches next -- the point from which the device has idle capacity until the next forward (the reduction and the weight repacking are a
+ * few hundred small workgroups).  A caller with independent work for another stream (the NEXT update's target-network forward: DQNCore's extra
+ * updates of a vector step) makes that stream wait for the mark.  One-shot: consumed by one backward; NULL clears it.  Ignored (and cleared)
+ * by backwards that do not run the fused convolutional kernel.  No reference counterpart. */
+dq_status dq_qnet_mark_conv_backward(dq_qnet* net, void* hip_event);
+
 /* Range guard of the fused backward.  Its gradients travel as f16 pieces (finite up to 65504 after the scale S above): a TD error so
  * large that some S x gradient leaves that range becomes inf / NaN in the weight gradient, where fp32 arithmetic (the reference's
  * TensorFlow) would still be finite.  That is never silent: the final reduction raises a device-side flag for every non-finite
