@@ -1,0 +1,425 @@
+// The convolutional backward in workgroups of SIXTEEN waves (round 5): the same arithmetic as fused_bwd.hip's conv_bwd_chain_kernel<2, true> -- data AND weight
+// gradients of Conv2D(64, 3, strides=2) - Conv2D(32, 2) - Conv2D(32, 2) (/root/reference/example_notebooks/Function_Library.py:352-365) on f16x2 pieces,
+// patch-word observations, groups of 8 samples whose images live in LDS -- re-tiled so that a CU holds four waves per SIMD instead of two:
+//
+//   conv_bwd_chain_kernel   8 waves x 218 VGPRs: the data gradients' weights sit in registers (64 per wave and phase, streamed from L2 by every wave and
+//                           group: 256 KB per group through the CU's 64 B/clk vector-memory path), a wave owns 2 x 2 tiles of dW2 and row tiles of
+//                           2 column tiles in g2 / g1 (13 tiles on 4 waves: 4, 3, 3, 3 -- and the two 4-tile waves share a SIMD).  Counters: MFMA busy 17 %,
+//                           VALU + MFMA issue 28 K and LDS 24 K of the kernel's 66 K cycles per SIMD / CU, 47 % of the wave cycles parked.
+//   conv_bwd16_kernel       16 waves x <= 128 VGPRs.  The data gradients' weights (qnet.h cdw: 48 KB, channel-tile order) are copied into LDS once per
+//                           workgroup and a wave fetches the four blocks of ITS channel tile from there at the top of a phase.  The data gradients run
+//                           TRANSPOSED (first operand = weights, rows = 16 input channels; second = the gradient rows of 16 pixels): a lane then holds four
+//                           consecutive channels of ONE pixel -- mask and result are one 8-byte LDS access per piece (they were four 4-byte ones) -- and a
+//                           unit of work is (row tile, channel tile): 16 units in g2 (one per wave), 52 in g1 (4, 3, 3, 3 per wave quadruple, 12 MFMAs each).
+//                           dW3 / dW2 are split by tile (a wave owns one 16 x 16 tile of dW3 and one 16 x 32 strip of dW2: 24 accumulator registers instead of
+//                           48), dW1 by tile and row-block parity (the two halves meet in LDS at the end).  a1 is single-buffered (its rows padded to 144
+//                           bytes: the 8-byte mask / result accesses of 16 consecutive pixels then fall into distinct banks) and requested right behind the
+//                           barrier that retires the previous group's dW1 -- it is first needed three phases later.
+//
+// LDS (153.6 KB): [cdw 48 KB | a1 / g1 planes 58 KB | a2 / g2 planes 20.2 KB | g3 planes 11.4 KB | patch image 6.25 KB | observations 1 KB | tables].
+#include "conv_bwd.h"
+
+#define C16_THREADS 1024
+#define C16_WAVES 16
+#define C16_S 8                         // samples per group
+#define C16_R1 25
+#define C16_R2 16
+#define C16_R3 9
+#define C16_OW1 5
+#define C16_OW2 4
+#define C16_OW3 3
+#define A1S 72                          // halves per LDS row of the a1 planes: 64 + 8 of padding (9 LDS-DMA slots of 16 bytes, the last one's lane inactive)
+#define C16_A1_CHUNKS ((C16_S * C16_R1 * 9 + 63) / 64)      // 1 KB LDS-DMA pieces per a1 plane (29)
+#define C16_LA1 (C16_A1_CHUNKS * 512)   // halves from a1's h plane to its l plane
+#define C16_LA2 ((C16_S * C16_R2 + 1) * PL32)
+#define C16_LG3 ((C16_S * C16_R3 + 1) * PL32)
+#define C16_KP 32                       // bytes per row of the patch image (K_data + 5 <= 32 columns)
+// byte offsets
+#define C16_OFF_W 0
+#define C16_OFF_A1 (24 * 2048)
+#define C16_OFF_A2 (C16_OFF_A1 + 2 * C16_LA1 * 2)
+#define C16_OFF_G3 (C16_OFF_A2 + ((2 * C16_LA2 * 2 + 1023) & ~1023))
+#define C16_OFF_COL (C16_OFF_G3 + ((2 * C16_LG3 * 2 + 1023) & ~1023))
+#define C16_OFF_IN (C16_OFF_COL + C16_S * C16_R1 * C16_KP)
+#define C16_OFF_T1 (C16_OFF_IN + C16_S * 128)
+#define C16_OFF_D1 (C16_OFF_T1 + 4 * C16_S * C16_R1)
+#define C16_OFF_T2 (C16_OFF_D1 + 4 * C16_S * C16_R1)
+#define C16_OFF_D2 (C16_OFF_T2 + 4 * C16_S * C16_R2)
+#define C16_OFF_T3 (C16_OFF_D2 + 4 * C16_S * C16_R2)
+#define C16_OFF_KO (C16_OFF_T3 + 4 * C16_S * C16_R3)
+#define C16_OFF_LUT (C16_OFF_KO + 96 * 4)
+#define C16_LDS (C16_OFF_LUT + 2048)
+static_assert(C16_LDS <= CHAIN_LDS_MAX, "LDS budget");
+static_assert(C16_OFF_T1 % 16 == 0 && C16_OFF_LUT % 16 == 0 && C16_OFF_COL % 16 == 0, "alignment");
+
+size_t conv_bwd16_lds() { return C16_LDS; }
+
+// Development aid (build with -DC16_STAMPS, tools/probe/build_c16_stamps.sh): shader-cycle stamps of every wave of workgroup 9 at the phase boundaries,
+// read back by tools/probe/c16_stamps.py through dq_dbg_read_c16
+#ifdef C16_STAMPS
+static __device__ unsigned long long c16_dbg[32 * 16];
+extern "C" void dq_dbg_read_c16(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(c16_dbg), sizeof(c16_dbg)); }
+#define C16_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 9) c16_dbg[(i) * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define C16_STAMP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const u8* s_wb = smem + C16_OFF_W;                                              // cdw blocks: 2048 bytes each (h pieces, then l)
+    unsigned short* s_a1 = reinterpret_cast<unsigned short*>(smem + C16_OFF_A1);   // a1, then g1 in place: piece planes [2][rows][A1S]
+    unsigned short* s_a2 = reinterpret_cast<unsigned short*>(smem + C16_OFF_A2);   // a2, then g2 in place: [2][S r2 + 1][PL32]
+    unsigned short* s_g3 = reinterpret_cast<unsigned short*>(smem + C16_OFF_G3);   // g3: [2][S r3 + 1][PL32]
+    u8* s_col = smem + C16_OFF_COL;                                                // patch image [S r1][32] bytes
+    u8* s_in = smem + C16_OFF_IN;                                                  // the group's observation rows (patch words)
+    int* t1 = reinterpret_cast<int*>(smem + C16_OFF_T1);
+    int* d1 = reinterpret_cast<int*>(smem + C16_OFF_D1);
+    int* t2 = reinterpret_cast<int*>(smem + C16_OFF_T2);
+    int* d2 = reinterpret_cast<int*>(smem + C16_OFF_D2);
+    int* t3 = reinterpret_cast<int*>(smem + C16_OFF_T3);
+    int* s_ko = reinterpret_cast<int*>(smem + C16_OFF_KO);
+    uint2* s_lut = reinterpret_cast<uint2*>(smem + C16_OFF_LUT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
+    constexpr int S = C16_S, r1 = C16_R1, r2 = C16_R2, r3 = C16_R3;
+    constexpr int zero2 = S * r2, zero3 = S * r3, LA1 = C16_LA1, LA2 = C16_LA2, LG3 = C16_LG3, KP = C16_KP;
+    const int in_bytes = a.slot;
+
+    // this wave's replay row of the workgroup's first group (waves 0 .. 7: one sample each), requested before anything else
+    auto obs_row = [&](int g) {
+        const int gb0 = g * S, gns = min(S, a.batch - gb0);
+        int row = gb0 + min(wave & 7, gns - 1);
+        if (a.index) {
+            const __attribute__((address_space(4))) int32_t* idx = (const __attribute__((address_space(4))) int32_t*)(uintptr_t)a.index;
+            row = idx[row] + a.index_off;
+            if (row >= a.index_mod) row -= a.index_mod;
+        }
+        return row;
+    };
+    C16_STAMP(0);
+    const int row_first = __builtin_amdgcn_readfirstlane(obs_row((int)blockIdx.x));
+    // ---- the data gradients' weights: 48 one-KB pieces, three per wave ---------------------------------------------------------------------------
+    {
+        const char* src = reinterpret_cast<const char*>(a.packed + a.pk_cdw);
+        for (int c = wave; c < 48; c += C16_WAVES) lds_dma16(src + c * 1024 + lane * 16, lds_addr(smem + C16_OFF_W + c * 1024));
+    }
+    // ---- every image goes global -> LDS by LDS-DMA (lds_dma16, qnet.h) --------------------------------------------------------------------------------
+    // (the lane number made opaque at every use inside the group loop: hipcc otherwise hoists each copy's per-lane address arithmetic out of the loop as
+    // invariants -- two registers per copy instruction -- and spills them)
+    auto opq = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    auto issue_a1 = [&](int g) {
+        const int lane = opq(tid & 63);
+        const int gb0 = g * S, rows = min(S, a.batch - gb0) * r1, slots = rows * 9, chunks = (slots + 63) >> 6;
+        for (int c = wave; c < 2 * chunks; c += C16_WAVES) {
+            const int piece = c >= chunks ? 1 : 0, ch = c - piece * chunks;
+            const int q = ch * 64 + lane, row = q / 9, part = q - row * 9;
+            if (q < slots && part < 8)
+                lds_dma16(a.a1p + piece * a.a1_lo + (size_t)(gb0 * r1 + row) * 64 + part * 8, lds_addr(s_a1 + piece * LA1 + ch * 512));
+        }
+    };
+    auto issue_pl32 = [&](const unsigned short* src, size_t src_lo, int rows, unsigned short* dst, int dst_lo) {
+        const int lane = opq(tid & 63);
+        const int slots = rows * 5, chunks = (slots + 63) >> 6;
+        for (int c = wave; c < 2 * chunks; c += C16_WAVES) {
+            const int piece = c >= chunks ? 1 : 0, ch = c - piece * chunks;
+            const int q = ch * 64 + lane, row = q / 5, part = q - row * 5;
+            if (q < slots && part < 4)
+                lds_dma16(src + piece * src_lo + (size_t)row * 32 + part * 8, lds_addr(dst + piece * dst_lo + ch * 512));
+        }
+    };
+    auto issue_a2 = [&](int g, int rows) { issue_pl32(a.a2p + (size_t)g * S * r2 * 32, a.a2_lo, rows, s_a2, LA2); };
+    auto issue_g3 = [&](int g, int rows) { issue_pl32(a.g3p + (size_t)g * S * r3 * 32, a.g3_lo, rows, s_g3, LG3); };
+    auto issue_obs = [&](int g, int row) {
+        const int gns = min(S, a.batch - g * S), lane = opq(tid & 63);
+        if (wave < gns && lane < (in_bytes >> 4)) lds_dma16(a.obs + (size_t)row * in_bytes + 16 * lane, lds_addr(s_in + wave * in_bytes));
+    };
+    {
+        const int g = blockIdx.x, gns = min(S, a.batch - g * S);
+        issue_obs(g, row_first);
+        issue_g3(g, gns * r3);
+        issue_a2(g, gns * r2);
+        issue_a1(g);
+    }
+    // ---- group-independent tables (host-built, qnet.h PT_BWD / fused_conv_bwd_row_tables) and zero rows ---------------------------------------------
+    if (tid < S * r1) {
+        t1[tid] = a.rowtab1[tid];                                   // (s * stride_words + p) | the pixel's constant-cell mask << 16
+        d1[tid] = a.rowtab[4 * CONV_ROWTAB + tid];                  // row of g2 at the a1 pixel's own position | iy << 16 | ix << 24
+    } else if (tid < S * r1 + S * r2) {
+        const int m = tid - S * r1;
+        t2[m] = (a.rowtab[CONV_ROWTAB + m] >> 6) * A1S;             // half offset of the a1 row under output pixel m of the second convolution (the table holds row * 64)
+        d2[m] = a.rowtab[3 * CONV_ROWTAB + m];                      // row of g3 at the a2 pixel's own position | iy << 16 | ix << 24
+    } else if (tid < S * r1 + S * r2 + S * r3) {
+        const int m = tid - S * r1 - S * r2;
+        t3[m] = a.rowtab[2 * CONV_ROWTAB + m];                      // half offset of the a2 row under output pixel m of the third convolution
+    } else if (tid < S * r1 + S * r2 + S * r3 + 96) {
+        const int m = tid - S * r1 - S * r2 - S * r3;
+        s_ko[m] = a.srctab[m];
+    } else if (tid >= 768) {
+        const u32 b = (u32)tid - 768u;
+        s_lut[b] = uint2{(b & 1u) | (b & 2u) << 7 | (b & 4u) << 14 | (b & 8u) << 21, ((b >> 4) & 1u) | ((b >> 4) & 2u) << 7 | ((b >> 4) & 4u) << 14 | ((b >> 4) & 8u) << 21};
+    }
+    if (tid < PL32) { s_a2[zero2 * PL32 + tid] = 0; s_a2[LA2 + zero2 * PL32 + tid] = 0; s_g3[zero3 * PL32 + tid] = 0; s_g3[LG3 + zero3 * PL32 + tid] = 0; }
+
+    C16_STAMP(1);
+    // ---- per-wave roles -----------------------------------------------------------------------------------------------------------------------------
+    // dW3 [128 x 32]: wave w owns k-tile w >> 1 (tap (w >> 1) >> 1, channels 16 ((w >> 1) & 1) ..) x column tile w & 1
+    // dW2 [256 x 32]: wave w owns k-tile w (tap w >> 2, channels 16 (w & 3) ..) x both column tiles
+    // dW1 [32 x 64]:  wave w owns tile w & 7 (k-tile (w & 7) >> 2, column tile w & 3) on the row blocks of parity w >> 3
+    // g2: unit (row tile w >> 1, channel tile w & 1);  g1: units (row tile (w >> 2) + 4 i, channel tile w & 3)
+    const int kt3 = wave >> 1, nt3 = wave & 1;
+    const int aoff3 = ((kt3 >> 2) * C16_OW2 + ((kt3 >> 1) & 1)) * PL32 + 16 * (kt3 & 1);
+    const int aoff2 = ((wave >> 3) * C16_OW1 + ((wave >> 2) & 1)) * A1S + 16 * (wave & 3);
+    f32x4 acc3 = {0.f, 0.f, 0.f, 0.f}, acc3l = acc3, acc2[2] = {acc3, acc3}, acc2l[2] = {acc3, acc3}, acc1 = acc3, acc1l = acc3;
+    float bs3 = 0.f;                                                // this thread's share of g3's column tid & 31
+    float bs2[2] = {0.f, 0.f}, bs1[2] = {0.f, 0.f};                // g2's columns 2 (tid & 15), + 1 (threads < 512) / g1's columns 2 (tid & 31), + 1: this thread's row class
+
+    // Transposed data gradient of one unit: rows m = 16 T + j of the activation image `act` (row stride AS halves, l plane act_lo halves further), channels
+    // 16 nt + 4 kq .. + 3:  act <- (sum over taps  W[tap]^T g[pixel - tap]) * [act > 0], in place; g = piece planes [rows][PL32] with an all-zero row `zero_row`.
+    // dtab[m]: row of g at the pixel's own position | iy << 16 | ix << 24.
+    auto dgrad_unit = [&](const F16x2 (&bw)[4], const unsigned short* g, int g_lo, int zero_row, unsigned short* act, int act_lo, int AS, int nt,
+                          const int* dtab, int oh, int ow, int M, int T, int j, int kq) {
+        const int m = 16 * T + j, mc = min(m, M - 1);
+        const int de = dtab[mc];
+        const int gbase = de & 0xffff, iy = (de >> 16) & 0xff, ix = (de >> 24) & 0xff;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, accx = acc0;
+        unsigned short* pa = act + mc * AS + 16 * nt + 4 * kq;
+        const uint2 mh = *reinterpret_cast<const uint2*>(pa), ml = *reinterpret_cast<const uint2*>(pa + act_lo);
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {                            // two taps' gradient rows in flight (all four: 32 more registers than the 128 allow)
+            F16x2 gv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int tap = 2 * tp + u;
+                const int oy = iy - (tap >> 1), ox = ix - (tap & 1);
+                const bool valid = (unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow;
+                const int grow = valid ? gbase - (tap >> 1) * ow - (tap & 1) : zero_row;
+                const unsigned short* gp = g + grow * PL32 + 8 * kq;
+                gv[u].h = *reinterpret_cast<const u32x4*>(gp);
+                gv[u].l = *reinterpret_cast<const u32x4*>(gp + g_lo);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) mma_f16x3(bw[2 * tp + u], gv[u], acc0, accx);
+        }
+        const u32 b0 = mh.x | ml.x, b1 = mh.y | ml.y;
+        const bool in = m < M;
+        const float v0 = (in && (b0 & 0x7fffu) != 0u) ? f16x2_sum(acc0[0], accx[0]) : 0.f;
+        const float v1 = (in && (b0 & 0x7fff0000u) != 0u) ? f16x2_sum(acc0[1], accx[1]) : 0.f;
+        const float v2 = (in && (b1 & 0x7fffu) != 0u) ? f16x2_sum(acc0[2], accx[2]) : 0.f;
+        const float v3 = (in && (b1 & 0x7fff0000u) != 0u) ? f16x2_sum(acc0[3], accx[3]) : 0.f;
+        u32 h0, l0, h1, l1;
+        split_f16x2_pair(v0, v1, h0, l0);
+        split_f16x2_pair(v2, v3, h1, l1);
+        if (in) {
+            *reinterpret_cast<uint2*>(pa) = uint2{h0, h1};
+            *reinterpret_cast<uint2*>(pa + act_lo) = uint2{l0, l1};
+        }
+    };
+    auto load_bw = [&](F16x2 (&bw)[4], int block0, int stride, int lane) {       // blocks block0 + tap * stride of the LDS copy
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            const u8* p = s_wb + (block0 + tap * stride) * 2048 + lane * 16;
+            bw[tap].h = *reinterpret_cast<const u32x4*>(p);
+            bw[tap].l = *reinterpret_cast<const u32x4*>(p + 1024);
+        }
+    };
+    // halves of g's pieces whose rows lie past M cleared (element e = half e of the operand; row of element e: m0 + rb + 4 or 1 x ...)
+    auto mask_rows = [&](F16x2& G, int m0, int M, int rb, int rstep) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const u32 lo = m0 + rb + rstep * ((2 * d) & 3) + 16 * ((2 * d) >> 2) < M ? 0xffffu : 0u;
+            const u32 hi = m0 + rb + rstep * ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < M ? 0xffff0000u : 0u;
+            G.h[d] &= lo | hi; G.l[d] &= lo | hi;
+        }
+    };
+
+    int sb = 2;
+    (void)sb;
+    for (int grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
+        const int b0 = grp * S, ns = min(S, a.batch - b0);
+        const int M1 = ns * r1, M2 = ns * r2, M3 = ns * r3;
+        const int nxt = grp + (int)gridDim.x;
+        const int ns_nxt = min(S, a.batch - nxt * S);
+        const int row_nxt = nxt < a.groups ? obs_row(nxt) : 0;
+        // (lane-derived values re-derived per group from an opaque lane number: as loop invariants they -- and every address formed from them -- would be
+        // held in registers across all phases)
+        const int lane = opq(tid & 63), j = lane & 15, kq = lane >> 4, ri = j >> 2, cseg = 4 * (j & 3);
+        C16_STAMP(sb + 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        C16_STAMP(sb + 1);
+        // ---- patch image: row m = the bits of pixel m's word (data), then of its constant mask, one byte each -------------------------------------------
+        if (tid < M1 * (KP / 8)) {
+            const int m = tid >> 2, g = tid & 3;
+            const int e = t1[m];
+            const u64 bits = (u64)reinterpret_cast<const u32*>(s_in)[e & 0xffff] | (u64)(u32)(e >> 16) << a.kd;
+            *reinterpret_cast<uint2*>(s_col + m * KP + 8 * g) = s_lut[(u32)(bits >> (8 * g)) & 0xffu];
+        }
+        // the third convolution's bias gradient = column sums of g3, from its pieces
+        for (int row = tid >> 5; row < M3; row += C16_THREADS / 32) {
+            const unsigned short* gp = s_g3 + row * PL32 + (tid & 31);
+            bs3 += (float)__builtin_bit_cast(_Float16, gp[0]) + (float)__builtin_bit_cast(_Float16, gp[LG3]) * F16_LO_INV;
+        }
+        C16_STAMP(sb + 2);
+        // ---- dW3 += im2col(a2)^T g3: lane group kq supplies rows m0 + 4 kq + (e & 3) + 16 (e >> 2) of both operands -----------------------------------------
+        for (int m0 = 0; m0 < M3; m0 += 32) {
+            const int ra = min(m0 + 4 * kq + ri, M3 - 1), rb = min(m0 + 16 + 4 * kq + ri, M3 - 1);
+            const F16x2 A = lds_tr8(s_a2 + t3[ra] + aoff3 + cseg, s_a2 + t3[rb] + aoff3 + cseg, LA2);
+            F16x2 G = lds_tr8(s_g3 + ra * PL32 + 16 * nt3 + cseg, s_g3 + rb * PL32 + 16 * nt3 + cseg, LG3);
+            if (m0 + 32 > M3) mask_rows(G, m0, M3, 4 * kq, 1);
+            mma_f16x3(A, G, acc3, acc3l);
+        }
+        C16_STAMP(sb + 3);
+        __syncthreads();                                            // every wave is done reading a2; the patch image is complete
+        C16_STAMP(sb + 4);
+        // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 ----------------------------------------------------------------------------------------------
+        {
+            F16x2 bw[4];
+            load_bw(bw, nt3, 2, lane);
+            if (16 * (wave >> 1) < M2) dgrad_unit(bw, s_g3, LG3, zero3, s_a2, LA2, PL32, nt3, d2, C16_OW3, C16_OW3, M2, wave >> 1, j, kq);
+        }
+        C16_STAMP(sb + 5);
+        __syncthreads();
+        C16_STAMP(sb + 6);
+        if (nxt < a.groups) {                                       // the observation rows and g3 are dead now
+            issue_obs(nxt, row_nxt);
+            issue_g3(nxt, ns_nxt * r3);
+        }
+        // the second convolution's bias gradient = column sums of g2, from its pieces: thread (column pair tid & 15, row class tid >> 4 < 32) adds its rows
+        if (tid < 512) {
+            for (int row = tid >> 4; row < M2; row += 32) {
+                const unsigned short* gp = s_a2 + row * PL32 + 2 * (tid & 15);
+                const f16x2 h = __builtin_bit_cast(f16x2, *reinterpret_cast<const u32*>(gp)), l = __builtin_bit_cast(f16x2, *reinterpret_cast<const u32*>(gp + LA2));
+                bs2[0] += (float)h[0] + (float)l[0] * F16_LO_INV; bs2[1] += (float)h[1] + (float)l[1] * F16_LO_INV;
+            }
+        }
+        // ---- dW2 += im2col(a1)^T g2 -------------------------------------------------------------------------------------------------------------------------
+        for (int m0 = 0; m0 < M2; m0 += 32) {
+            const int ra = min(m0 + 4 * kq + ri, M2 - 1), rb = min(m0 + 16 + 4 * kq + ri, M2 - 1);
+            const F16x2 A = lds_tr8(s_a1 + t2[ra] + aoff2 + cseg, s_a1 + t2[rb] + aoff2 + cseg, LA1);
+            const unsigned short* p0 = s_a2 + ra * PL32 + cseg;
+            const unsigned short* p1 = s_a2 + rb * PL32 + cseg;
+            F16x2 G0 = lds_tr8(p0, p1, LA2), G1 = lds_tr8(p0 + 16, p1 + 16, LA2);
+            if (m0 + 32 > M2) { mask_rows(G0, m0, M2, 4 * kq, 1); mask_rows(G1, m0, M2, 4 * kq, 1); }
+            mma_f16x3(A, G0, acc2[0], acc2l[0]);
+            mma_f16x3(A, G1, acc2[1], acc2l[1]);
+        }
+        C16_STAMP(sb + 7);
+        __syncthreads();                                            // every wave is done reading a1
+        C16_STAMP(sb + 8);
+        // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1 ----------------------------------------------------------------------------------------------
+        {
+            F16x2 bw[4];
+            load_bw(bw, 8 + (wave & 3), 4, lane);
+            for (int T = wave >> 2; 16 * T < M1; T += 4) dgrad_unit(bw, s_a2, LA2, zero2, s_a1, LA1, A1S, wave & 3, d1, C16_OW2, C16_OW2, M1, T, j, kq);
+        }
+        C16_STAMP(sb + 9);
+        __syncthreads();
+        C16_STAMP(sb + 10);
+        if (nxt < a.groups) issue_a2(nxt, ns_nxt * r2);            // g2 (in a2) is dead
+        // the first convolution's bias gradient = column sums of g1: thread (column pair tid & 31, row class tid >> 5)
+        for (int row = tid >> 5; row < M1; row += 32) {
+            const unsigned short* gp = s_a1 + row * A1S + 2 * (tid & 31);
+            const f16x2 h = __builtin_bit_cast(f16x2, *reinterpret_cast<const u32*>(gp)), l = __builtin_bit_cast(f16x2, *reinterpret_cast<const u32*>(gp + LA1));
+            bs1[0] += (float)h[0] + (float)l[0] * F16_LO_INV; bs1[1] += (float)h[1] + (float)l[1] * F16_LO_INV;
+        }
+        // ---- dW1 += patches^T g1: binary patch operand (one MFMA per piece of g1); lane group kq supplies rows m0 + kq + 4 (e & 3) + 16 (e >> 2) ------------------
+        {
+            const int w8 = wave & 7;
+            const int cs = 16 * (w8 & 3) + 4 * (j & 3), rj = kq + 4 * (j >> 2);
+            const int re = j >> 1, rowb = kq + 4 * (re & 3) + 16 * (re >> 2);      // the patch row (inside a block) this lane points at
+            const u8* cp = s_col + 16 * (w8 >> 2) + 8 * (j & 1);
+            for (int m0 = 32 * (wave >> 3); m0 < M1; m0 += 64) {
+                const int ra = min(m0 + rj, M1 - 1), rb = min(m0 + 16 + rj, M1 - 1);
+                F16x2 G = lds_tr8(s_a1 + ra * A1S + cs, s_a1 + rb * A1S + cs, LA1);
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(cp + min(m0 + rowb, M1 - 1) * KP));
+                if (m0 + 32 > M1) mask_rows(G, m0, M1, kq, 4);
+                u32x4 av;
+                av[0] = __umul24(__builtin_amdgcn_perm(0u, (u32)v[0], 0x0c010c00u), 0x3c00u);
+                av[1] = __umul24(__builtin_amdgcn_perm(0u, (u32)v[0], 0x0c030c02u), 0x3c00u);
+                av[2] = __umul24(__builtin_amdgcn_perm(0u, (u32)v[1], 0x0c010c00u), 0x3c00u);
+                av[3] = __umul24(__builtin_amdgcn_perm(0u, (u32)v[1], 0x0c030c02u), 0x3c00u);
+                acc1 = MFMA_F16(av, G.h, acc1);
+                acc1l = MFMA_F16(av, G.l, acc1l);
+            }
+        }
+        C16_STAMP(sb + 11);
+        __syncthreads();                                            // every wave is done with a1 / g1
+        if (nxt < a.groups) issue_a1(nxt);
+        sb += 12;
+    }
+    C16_STAMP(26);
+
+    // ---- one partial per workgroup ----------------------------------------------------------------------------------------------------------------------
+    float* out = a.partial + (size_t)blockIdx.x * a.pstride;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        out[a.w_off[2] + (16 * kt3 + 4 * kq + r) * 32 + 16 * nt3 + j] = f16x2_sum(acc3[r], acc3l[r]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) out[a.w_off[1] + (16 * wave + 4 * kq + r) * 32 + 16 * t + j] = f16x2_sum(acc2[t][r], acc2l[t][r]);
+    }
+    C16_STAMP(27);
+    {
+        // (the last group's closing barrier: every LDS image is dead)
+        float* s_b = reinterpret_cast<float*>(smem);                // [0, 1024) g3's classes | [1024, 2048) g2's | [2048, 4096) g1's
+        float* s_res = s_b + 4096;                                  // the patch image's gradient [32][64], then scattered to the kernel's Keras rows
+        const int w8 = wave & 7, kt = w8 >> 2, nt = w8 & 3;
+        if (wave >= 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_res[(16 * kt + 4 * kq + r) * 64 + 16 * nt + j] = f16x2_sum(acc1[r], acc1l[r]);
+        }
+        s_b[tid] = bs3;                                             // thread (column tid & 31, row class tid >> 5)
+        if (tid < 512) { s_b[1024 + (tid >> 4) * 32 + 2 * (tid & 15)] = bs2[0]; s_b[1024 + (tid >> 4) * 32 + 2 * (tid & 15) + 1] = bs2[1]; }
+        s_b[2048 + (tid >> 5) * 64 + 2 * (tid & 31)] = bs1[0]; s_b[2048 + (tid >> 5) * 64 + 2 * (tid & 31) + 1] = bs1[1];
+        __syncthreads();
+        if (wave < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_res[(16 * kt + 4 * kq + r) * 64 + 16 * nt + j] += f16x2_sum(acc1[r], acc1l[r]);
+        }
+        if (tid < 32) {
+            float v = 0.f;
+#pragma unroll
+            for (int cl = 0; cl < 32; ++cl) v += s_b[1024 + cl * 32 + tid];
+            out[a.b_off[1] + tid] = v;
+        } else if (tid < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int cl = 0; cl < 32; ++cl) v += s_b[cl * 32 + (tid - 32)];
+            out[a.b_off[2] + tid - 32] = v;
+        } else if (tid < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int cl = 0; cl < 32; ++cl) v += s_b[2048 + cl * 64 + (tid - 64)];
+            out[a.b_off[0] + tid - 64] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < a.K1 * 64; i += C16_THREADS) {
+            const int src = s_ko[i >> 6];
+            out[a.w_off[0] + i] = src >= 0 ? s_res[src * 64 + (i & 63)] : 0.f;
+        }
+    }
+    C16_STAMP(28);
+}
+
+// Patch-word input with K_data + 5 <= 32 columns, the three convolutions 64 x 3 x s2 / 32 x 2 / 32 x 2 on a 5 x 5 first output (d = 5): everything else
+// takes conv_bwd_chain_kernel.
+bool conv_bwd16_supported(const dq_qnet* Q) {
+    if (Q->cfg.n_conv != 3 || !Q->patch_depth || Q->patch_kd + 5 > 32) return false;
+    const Layer &L1 = Q->L[0], &L2 = Q->L[1], &L3 = Q->L[2];
+    if (L1.cout != 64 || L1.k != 3 || L1.s != 2 || L1.oh != 5 || L1.ow != 5) return false;
+    if (L2.cin != 64 || L2.cout != 32 || L2.k != 2 || L2.s != 1 || L3.cin != 32 || L3.cout != 32 || L3.k != 2 || L3.s != 1) return false;
+    if (4 * Q->patch_stride > 128 || L2.rows != C16_R2 || L3.rows != C16_R3) return false;
+    return fused_pack_layout(Q).cdw_blocks == 24 && Q->patch_kd + 6 <= 32;
+}
+
+dq_status conv_bwd16_launch(const dq_qnet* Q, ConvBwdArgs& a, int wgs, hipStream_t st) {
+    (void)Q;
+    static unsigned long long attr_devs = 0;
+    const unsigned long long dev_bit = dq_device_bit();
+    if (!(attr_devs & dev_bit)) {
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS));
+        attr_devs |= dev_bit;
+    }
+    dq_launch(DQ_K_CONV_BWD, conv_bwd16_kernel, dim3(wgs), dim3(C16_THREADS), C16_LDS, st, a);
+    DQ_LAUNCH_CHECK();
+    return DQ_OK;
+}

@@ -1350,6 +1350,7 @@ struct PackArgs {
     int p_depth, p_C, b1_off;           // syndrome planes, input planes, the first bias in params
     int c1w_off, c1w_blocks, p_kd;      // the wave-private conv forward's first kernel (qnet.h c1w): u32x4 offset, blocks (4 or 0), data bits per word
     int c2w_off, c2w_blocks;            // ... and its second (qnet.h c2w): 16 blocks or 0
+    int cdw_off, cdw_blocks;            // the 16-wave convolutional backward's data-gradient weights (qnet.h cdw): 24 blocks or 0
 };
 
 // Wc for networks with more than 64 actions (N2, N3 <= 112; qnet.h wc): Wc[a][n1] = P[0] + P[1 + a] - mean_a' P[1 + a'],  P = W2[n1] W3 (the plain
@@ -1508,6 +1509,17 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
                 const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
                 u32x4* dst = pk + a.c2w_off + (size_t)b * PK_BLOCK + lane;
                 dst[0] = o.h; dst[PK_LO] = o.l;
+            } else if (rc - 4 - a.b1p_rows - a.c1w_blocks - a.c2w_blocks < a.cdw_blocks) {     // cdw block: conv3 (tap, t) 0 .. 7, conv2 (tap, t) 8 .. 23 (qnet.h)
+                const int b = rc - 4 - a.b1p_rows - a.c1w_blocks - a.c2w_blocks;
+                const bool c3 = b < 8;
+                const int bb = c3 ? b : b - 8, tap = c3 ? bb >> 1 : bb >> 2, t = c3 ? bb & 1 : bb & 3, cin = c3 ? 32 : 64;
+                const float* w = params + (c3 ? w3_off : w2_off) + (size_t)(tap * cin + 16 * t + j) * 32 + 8 * kb;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = w[e];
+                const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+                u32x4* dst = pk + a.cdw_off + (size_t)b * PK_BLOCK + lane;
+                dst[0] = o.h; dst[PK_LO] = o.l;
             }
             return;
         }
@@ -1633,7 +1645,9 @@ PackLayout fused_pack_layout(const dq_qnet* Q) {
     P.c1w_blocks = P.b1p_rows ? 4 : 0;                                // (filled when the patch input has K_data + 6 <= 32; the space is there either way)
     P.c2w = P.c1w + (size_t)P.c1w_blocks * PK_BLOCK;
     P.c2w_blocks = P.c1w_blocks ? 16 : 0;
-    P.total = P.c2w + (size_t)P.c2w_blocks * PK_BLOCK;
+    P.cdw = P.c2w + (size_t)P.c2w_blocks * PK_BLOCK;
+    P.cdw_blocks = P.c1w_blocks ? 24 : 0;
+    P.total = P.cdw + (size_t)P.cdw_blocks * PK_BLOCK;
     return P;
 }
 size_t fused_packed_w1t_u32x4(const dq_qnet* Q) { return fused_pack_layout(Q).total; }
@@ -1666,8 +1680,9 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     a.c1c_off = (int)PL.c1c; a.b1p_off = (int)PL.b1p; a.b1p_rows = PL.b1p_rows; a.p_depth = Q->patch_depth; a.p_C = Q->L[0].cin; a.b1_off = (int)Q->L[0].b_off;
     a.c1w_off = (int)PL.c1w; a.p_kd = Q->patch_kd; a.c1w_blocks = a.ptab && Q->patch_kd + 6 <= 32 ? PL.c1w_blocks : 0;
     a.c2w_off = (int)PL.c2w; a.c2w_blocks = a.c1w_blocks ? PL.c2w_blocks : 0;
+    a.cdw_off = (int)PL.cdw; a.cdw_blocks = a.c1w_blocks ? PL.cdw_blocks : 0;
     a.pack_wgs = (PK_TOTAL_BLOCKS + PL.d1_blocks + PL.d2_blocks + PL.d2t_blocks + PL.d1t_blocks + (PL.w3q_rows ? PL.w3q_rows + 1 : 0) + a.wc_waves +
-                  (a.ptab ? 4 + PL.b1p_rows + a.c1w_blocks + a.c2w_blocks : 0) + 3) / 4;
+                  (a.ptab ? 4 + PL.b1p_rows + a.c1w_blocks + a.c2w_blocks + a.cdw_blocks : 0) + 3) / 4;
     // (the f32 transposes W1T / W2T this kernel used to append are gone with their last reader: both data gradients read packed pieces)
     // more than 64 actions: Wc by workgroups of their own behind the others, W3 staged in LDS (pack_wide_wc_block)
     const bool wide_wc = PL.wc_rows && PL.NT2 == 8;

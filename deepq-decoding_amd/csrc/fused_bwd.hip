@@ -13,6 +13,7 @@
 // Configurations the fused chains do not cover run through qnet.hip's per-layer kernels.
 #include <type_traits>
 #include "qnet.h"
+#include "conv_bwd.h"
 #include "env_dev.h"
 
 // Build-time switches of one-box A/B comparisons (tools/build_ab.sh): GX_PIN = a sched_barrier pin of the gX weight ring, GX_RING = its
@@ -699,26 +700,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
 // Bias gradients (column sums of G) come out of the matrix pipe as well: a tile whose A operand is all ones.  Rows past the slice are
 // re-reads of its last row, and zeroed in G only (a zero factor kills the product); columns past K / N are clamped too and only reach
 // accumulators that are never stored.
-// Row stride (halves) of an LDS piece-plane image of 32 channels: 64 data bytes + 16 of padding, filled by LDS-DMA in 16-byte slots
-#define PL32 40
-
-// Transposing LDS read (ds_read_b64_tr_b16, tools/probe/tr_probe.hip): within a 16-lane group, lanes 4r .. 4r+3 each point at a 4-half
-// segment of row r (r = 0 .. 3, any addresses); lane i receives column i of those four rows.  Two of them are the eight reduction
-// indices of a 16 x 16 x 32 MFMA operand held ROW-major in LDS -- what the weight gradients (a reduction over pixels / batch rows) need.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 lds_tr4(const unsigned short* p) {
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
-    return __builtin_bit_cast(uint2, v);
-}
-// rows p0 (reduction indices 0 .. 3 of this lane group) and p1 (4 .. 7), both pieces (l plane `lo` halves further)
-__device__ __forceinline__ F16x2 lds_tr8(const unsigned short* p0, const unsigned short* p1, int lo) {
-    const uint2 a = lds_tr4(p0), b = lds_tr4(p1), c = lds_tr4(p0 + lo), d = lds_tr4(p1 + lo);
-    F16x2 o;
-    o.h = u32x4{a.x, a.y, b.x, b.y};
-    o.l = u32x4{c.x, c.y, d.x, d.y};
-    return o;
-}
-
 #define WGRAD_THREADS 256
 #ifndef DQ_RIDE_WGRAD_DEFAULT
 #define DQ_RIDE_WGRAD_DEFAULT 0        // 1: the environment step rides on the dense weight gradients' launch by default (fused_rider_threads)
@@ -1106,35 +1087,6 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
 #define CB_THREADS 512
 #define CB_WAVES 8
 
-struct ConvBwdArgs {
-    const float* params;
-    const u8* obs;
-    const int32_t* index;
-    int index_off, index_mod;
-    const unsigned short* a1p;          // saved first-convolution output [batch*r1][64] as f16 piece planes (h plane; the l plane a1_lo halves further)
-    size_t a1_lo;
-    const unsigned short* a2p;          // saved second-convolution output [batch*r2][32] as f16 piece planes (h plane; the l plane a2_lo halves further)
-    size_t a2_lo;
-    const unsigned short* g3p;          // [batch*r3][32] gradient w.r.t. conv3's pre-activation output, as f16 piece planes (l plane g3_lo halves further)
-    size_t g3_lo;
-    const u32x4* packed;                // f16 pieces of the conv kernels (qnet.h PK_*), those of the training forward
-    int batch, S, groups;
-    int C, H, W, k1, st1, K1;
-    int oh1, ow1, oh2, ow2, oh3, ow3;
-    int w_off[3], b_off[3];
-    float* partial;                     // [gridDim.x][pstride]
-    size_t pstride;
-    int slot;
-    int off_mis, off_a1, off_a2, off_g3, off_t1, off_t2, off_t3, off_ko, off_tp, off_d2, off_d1;
-    int a1_alt;                         // bytes from the a1 image to its second buffer, 0 = single-buffered
-    const int* kofftab;                 // [96] conv1 weight row k -> byte offset inside an observation, -1 past K1
-    const int* rowtab;                  // [5][CONV_ROWTAB] host-built row tables (fused_conv_bwd_row_tables): the kernel copies them into LDS and never divides
-    // patch-word input (the kernel's CP instances; qnet.h PT_*, include/deepq_hip.h dq_env_patch_output): the observation rows are `slot` bytes of u32
-    // words (one per first-convolution output pixel), 16-byte aligned
-    const int* rowtab1;                 // the first table: rowtab, or qnet.h PT_BWD (row m -> word index s * stride + p | the pixel's constant-cell mask << 16)
-    const int* srctab;                  // qnet.h PT_SRC: Keras row of the first kernel -> column of the patch image, -1: gradient 0
-    int kd, off_lut;                    // data bits per pixel; LDS: byte -> its eight bits as bytes 0 / 1 (256 x 8 bytes), built by the workgroup
-};
 
 // Copies `rows` rows of CH floats from global memory into an LDS image with row stride PS.  Loads are issued NB at a time before
 // the first store: a load -> store loop body costs one full memory latency per trip.
@@ -2035,12 +1987,22 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.off_d2 = cp.off_d2; ca.off_d1 = cp.off_d1; ca.rowtab = Q->kofftab + 96 + CONV_FWD_TABS * CONV_ROWTAB;
     ca.rowtab1 = patch ? Q->ptab + PT_BWD : ca.rowtab; ca.srctab = patch ? Q->ptab + PT_SRC : nullptr; ca.kd = Q->patch_kd; ca.off_lut = cp.off_lut;
     DQ_REQUIRE(!patch || (reinterpret_cast<uintptr_t>(ca.obs) & 15) == 0, DQ_ERR_INVALID, "fused_backward: patch-word rows must be 16-byte aligned");
+    // the 16-wave form (conv_bwd16.hip) where it applies and the minibatch gives every CU work (groups of 8 samples); DQ_CONV_BWD_FORM=8: this file's kernel
+    // (A/B runs, tests; read per call)
+    const char* form = getenv("DQ_CONV_BWD_FORM");
+    const bool form16 = patch && conv_bwd16_supported(Q) && (B >= 1024 || (form && form[0] == '1')) && !(form && form[0] == '8');      // (=16: whatever the minibatch)
+    if (form16) { ca.S = 8; ca.groups = (B + 7) / 8; ca.pk_cdw = (int)PL.cdw; }
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
+    if (form16) {
+        const dq_status rc = conv_bwd16_launch(Q, ca, wgs, st);
+        if (rc != DQ_OK) return rc;
+    } else {
     conv_bwd_kernel_t ck = patch ? (cp.KG1 == 2 ? conv_bwd_chain_kernel<2, true> : conv_bwd_chain_kernel<3, true>)
                          : cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;
     dq_launch(DQ_K_CONV_BWD, ck, dim3(wgs), dim3(CB_THREADS), cp.lds, st, ca);
     DQ_LAUNCH_CHECK();
+    }
     if (Q->mark_event) {                                            // dq_qnet_mark_conv_backward: the caller's side stream starts from here
         const hipError_t me = hipEventRecord(static_cast<hipEvent_t>(Q->mark_event), st);
         Q->mark_event = nullptr;

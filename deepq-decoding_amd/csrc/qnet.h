@@ -240,7 +240,9 @@ struct ConvJob {
 //                                                Present when K_data + 6 <= 32 (c1w_blocks = 4, else 0)
 //   c2w      [4 quarters][2 ky][2 column tiles]  the second convolution for conv_wave.hip: a K block = the taps (ky, 0), (ky, 1) x 16 input channels:
 //                                                B(slot (kb, e), col = 2j + t) = W2[(2 ky + (kb >> 1)) * 64 + 16 quarter + 8 (kb & 1) + e][col]
-struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, c1c, b1p, c1w, c2w, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows, b1p_rows, c1w_blocks, c2w_blocks; };   // offsets in u32x4
+//   cdw      [8 + 16 blocks]                     the data gradients' weights for conv_bwd16.hip, read as the FIRST operand (rows = the input channels of a tile of 16:
+//                                                the transposed product): conv3 [4 taps][2 tiles], then conv2 [4 taps][4 tiles]: B(n = 8kb + e, c = 16 t + j) = W[tap][c][n]
+struct PackLayout { size_t dense1, dense2, dense2t, dense1t, w3q, wc, c1c, b1p, c1w, c2w, cdw, total; int d1_blocks, d2_blocks, d2t_blocks, d1t_blocks, NT2, KB2, w3q_rows, wc_rows, b1p_rows, c1w_blocks, c2w_blocks, cdw_blocks; };   // offsets in u32x4
 PackLayout fused_pack_layout(const dq_qnet* Q);
 static inline int dq_planes_small_ld(const dq_qnet* Q) { return Q->cfg.n_actions + 1 <= 64 ? 64 : 128; }
 static inline size_t dq_planes_halves(const dq_qnet* Q) {      // total size of dq_qnet.planes
