@@ -52,7 +52,9 @@ def pmc_traffic(kernel, mode="loop", config="c3", minibatch=0, updates_per_step=
             return None
         ks = rec["kernels"]
         # the conv forward family's step launch is conv_wave_kernel (patch words, d = 5), else the persistent conv_chain_pkernel, else conv_chain_kernel
-        names = ("conv_wave_kernel", "conv_chain_pkernel", "conv_chain_kernel") if kernel == "conv_chain_kernel" else (kernel,)
+        # ... the conv backward family's is conv_bwd16_kernel (the same conditions, minibatch >= 1024), else conv_bwd_chain_kernel
+        names = ("conv_wave_kernel", "conv_chain_pkernel", "conv_chain_kernel") if kernel == "conv_chain_kernel" else \
+                ("conv_bwd16_kernel", "conv_bwd_chain_kernel") if kernel == "conv_bwd_chain_kernel" else (kernel,)
         for name in names:
             if name in ks:
                 return ks[name]["hbm_bytes_per_launch_corrected"]

@@ -31,6 +31,7 @@ struct ConvBwdArgs {
     // words (one per first-convolution output pixel), 16-byte aligned
     const int* rowtab1;                 // the first table: rowtab, or qnet.h PT_BWD (row m -> word index s * stride + p | the pixel's constant-cell mask << 16)
     const int* srctab;                  // qnet.h PT_SRC: Keras row of the first kernel -> column of the patch image, -1: gradient 0
+    const int* tab16;                   // conv_bwd16.hip: its table blob (qnet.h PT_C16), device
     int pk_cdw;                         // conv_bwd16.hip: u32x4 offset of the packed data-gradient weights in channel-tile order (qnet.h cdw)
     int kd, off_lut;                    // data bits per pixel; LDS: byte -> its eight bits as bytes 0 / 1 (256 x 8 bytes), built by the workgroup
 };

@@ -41,16 +41,21 @@
 #define C16_OFF_G3 (C16_OFF_A2 + ((2 * C16_LA2 * 2 + 1023) & ~1023))
 #define C16_OFF_COL (C16_OFF_G3 + ((2 * C16_LG3 * 2 + 1023) & ~1023))
 #define C16_OFF_IN (C16_OFF_COL + C16_S * C16_R1 * C16_KP)
-#define C16_OFF_T1 (C16_OFF_IN + C16_S * 128)
-#define C16_OFF_D1 (C16_OFF_T1 + 4 * C16_S * C16_R1)
-#define C16_OFF_T2 (C16_OFF_D1 + 4 * C16_S * C16_R1)
-#define C16_OFF_D2 (C16_OFF_T2 + 4 * C16_S * C16_R2)
-#define C16_OFF_T3 (C16_OFF_D2 + 4 * C16_S * C16_R2)
-#define C16_OFF_KO (C16_OFF_T3 + 4 * C16_S * C16_R3)
-#define C16_OFF_LUT (C16_OFF_KO + 96 * 4)
-#define C16_LDS (C16_OFF_LUT + 2048)
+#define C16_OFF_TAB (C16_OFF_IN + C16_S * 128)                // the host-built tables (qnet.h PT_C16), copied as they are: 12 KB
+#define C16_LDS (C16_OFF_TAB + 4 * PT_C16_INTS)
+// table sections (ints into the blob)
+#define TB_D1 0                         // [200] x 4: a1 pixel m -> {g2 row (halves from the image) under taps 0 | 1 << 16, taps 2 | 3 << 16, a1 row of m, 0}; the zero row for a tap outside
+#define TB_D2 800                       // [128] x 4: a2 pixel m -> {g3 row under taps 0 | 1, 2 | 3, a2 row of m, 0}
+#define TB_T2 1312                      // [128]: second-convolution output pixel m -> a1 row under it | g2 row m << 16
+#define TB_T3 1440                      // [72]: third-convolution output pixel m -> a2 row under it | g3 row m << 16
+#define TB_T1 1520                      // [200]: first-convolution output pixel m -> g1 row m | byte offset of its patch-image row << 16
+#define TB_TP 1720                      // [200]: ... -> (s * stride_words + p) | the pixel's constant-cell mask << 16 (qnet.h PT_BWD)
+#define TB_KO 1920                      // [96]: Keras row of the first kernel -> column of the patch image, -1: gradient 0 (qnet.h PT_SRC)
+#define TB_INV 2016                     // [400]: reserved (row placement maps of the three images)
+#define TB_LUT 2416                     // [256] x 2: byte -> its bits as eight bytes
+static_assert(TB_LUT + 512 <= PT_C16_INTS, "table blob");
 static_assert(C16_LDS <= CHAIN_LDS_MAX, "LDS budget");
-static_assert(C16_OFF_T1 % 16 == 0 && C16_OFF_LUT % 16 == 0 && C16_OFF_COL % 16 == 0, "alignment");
+static_assert(C16_OFF_TAB % 16 == 0 && C16_OFF_COL % 16 == 0, "alignment");
 
 size_t conv_bwd16_lds() { return C16_LDS; }
 
@@ -72,13 +77,11 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
     unsigned short* s_g3 = reinterpret_cast<unsigned short*>(smem + C16_OFF_G3);   // g3: [2][S r3 + 1][PL32]
     u8* s_col = smem + C16_OFF_COL;                                                // patch image [S r1][32] bytes
     u8* s_in = smem + C16_OFF_IN;                                                  // the group's observation rows (patch words)
-    int* t1 = reinterpret_cast<int*>(smem + C16_OFF_T1);
-    int* d1 = reinterpret_cast<int*>(smem + C16_OFF_D1);
-    int* t2 = reinterpret_cast<int*>(smem + C16_OFF_T2);
-    int* d2 = reinterpret_cast<int*>(smem + C16_OFF_D2);
-    int* t3 = reinterpret_cast<int*>(smem + C16_OFF_T3);
-    int* s_ko = reinterpret_cast<int*>(smem + C16_OFF_KO);
-    uint2* s_lut = reinterpret_cast<uint2*>(smem + C16_OFF_LUT);
+    const int* tab = reinterpret_cast<const int*>(smem + C16_OFF_TAB);
+    const int4* td1 = reinterpret_cast<const int4*>(tab + TB_D1);
+    const int4* td2 = reinterpret_cast<const int4*>(tab + TB_D2);
+    const int *t2 = tab + TB_T2, *t3 = tab + TB_T3, *t1 = tab + TB_T1, *tp = tab + TB_TP, *s_ko = tab + TB_KO;
+    const uint2* s_lut = reinterpret_cast<const uint2*>(tab + TB_LUT);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     constexpr int S = C16_S, r1 = C16_R1, r2 = C16_R2, r3 = C16_R3;
     constexpr int zero2 = S * r2, zero3 = S * r3, LA1 = C16_LA1, LA2 = C16_LA2, LG3 = C16_LG3, KP = C16_KP;
@@ -97,11 +100,6 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
     };
     C16_STAMP(0);
     const int row_first = __builtin_amdgcn_readfirstlane(obs_row((int)blockIdx.x));
-    // ---- the data gradients' weights: 48 one-KB pieces, three per wave ---------------------------------------------------------------------------
-    {
-        const char* src = reinterpret_cast<const char*>(a.packed + a.pk_cdw);
-        for (int c = wave; c < 48; c += C16_WAVES) lds_dma16(src + c * 1024 + lane * 16, lds_addr(smem + C16_OFF_W + c * 1024));
-    }
     // ---- every image goes global -> LDS by LDS-DMA (lds_dma16, qnet.h) --------------------------------------------------------------------------------
     // (the lane number made opaque at every use inside the group loop: hipcc otherwise hoists each copy's per-lane address arithmetic out of the loop as
     // invariants -- two registers per copy instruction -- and spills them)
@@ -132,33 +130,21 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         const int gns = min(S, a.batch - g * S), lane = opq(tid & 63);
         if (wave < gns && lane < (in_bytes >> 4)) lds_dma16(a.obs + (size_t)row * in_bytes + 16 * lane, lds_addr(s_in + wave * in_bytes));
     };
+    // Copies of the first group, in the order of their first use: tables, observations, g3, a2 (patch image, dW3) | the data gradients' weights (g2) | a1 (dW2):
+    // a wave's copies land in order, so the group loop waits for the first set only before it starts (every CU requests its 150 KB at once: the whole
+    // set took 9.5 K cycles to land)
     {
         const int g = blockIdx.x, gns = min(S, a.batch - g * S);
+        const char* tsrc = reinterpret_cast<const char*>(a.tab16);
+        for (int c = wave; c < 4 * PT_C16_INTS / 1024; c += C16_WAVES) lds_dma16(tsrc + c * 1024 + lane * 16, lds_addr(smem + C16_OFF_TAB + c * 1024));
         issue_obs(g, row_first);
         issue_g3(g, gns * r3);
         issue_a2(g, gns * r2);
+        const char* wsrc = reinterpret_cast<const char*>(a.packed + a.pk_cdw);
+        for (int c = wave; c < 48; c += C16_WAVES) lds_dma16(wsrc + c * 1024 + lane * 16, lds_addr(smem + C16_OFF_W + c * 1024));
         issue_a1(g);
     }
-    // ---- group-independent tables (host-built, qnet.h PT_BWD / fused_conv_bwd_row_tables) and zero rows ---------------------------------------------
-    if (tid < S * r1) {
-        t1[tid] = a.rowtab1[tid];                                   // (s * stride_words + p) | the pixel's constant-cell mask << 16
-        d1[tid] = a.rowtab[4 * CONV_ROWTAB + tid];                  // row of g2 at the a1 pixel's own position | iy << 16 | ix << 24
-    } else if (tid < S * r1 + S * r2) {
-        const int m = tid - S * r1;
-        t2[m] = (a.rowtab[CONV_ROWTAB + m] >> 6) * A1S;             // half offset of the a1 row under output pixel m of the second convolution (the table holds row * 64)
-        d2[m] = a.rowtab[3 * CONV_ROWTAB + m];                      // row of g3 at the a2 pixel's own position | iy << 16 | ix << 24
-    } else if (tid < S * r1 + S * r2 + S * r3) {
-        const int m = tid - S * r1 - S * r2;
-        t3[m] = a.rowtab[2 * CONV_ROWTAB + m];                      // half offset of the a2 row under output pixel m of the third convolution
-    } else if (tid < S * r1 + S * r2 + S * r3 + 96) {
-        const int m = tid - S * r1 - S * r2 - S * r3;
-        s_ko[m] = a.srctab[m];
-    } else if (tid >= 768) {
-        const u32 b = (u32)tid - 768u;
-        s_lut[b] = uint2{(b & 1u) | (b & 2u) << 7 | (b & 4u) << 14 | (b & 8u) << 21, ((b >> 4) & 1u) | ((b >> 4) & 2u) << 7 | ((b >> 4) & 4u) << 14 | ((b >> 4) & 8u) << 21};
-    }
     if (tid < PL32) { s_a2[zero2 * PL32 + tid] = 0; s_a2[LA2 + zero2 * PL32 + tid] = 0; s_g3[zero3 * PL32 + tid] = 0; s_g3[LG3 + zero3 * PL32 + tid] = 0; }
-
     C16_STAMP(1);
     // ---- per-wave roles -----------------------------------------------------------------------------------------------------------------------------
     // dW3 [128 x 32]: wave w owns k-tile w >> 1 (tap (w >> 1) >> 1, channels 16 ((w >> 1) & 1) ..) x column tile w & 1
@@ -175,24 +161,20 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
     // Transposed data gradient of one unit: rows m = 16 T + j of the activation image `act` (row stride AS halves, l plane act_lo halves further), channels
     // 16 nt + 4 kq .. + 3:  act <- (sum over taps  W[tap]^T g[pixel - tap]) * [act > 0], in place; g = piece planes [rows][PL32] with an all-zero row `zero_row`.
     // dtab[m]: row of g at the pixel's own position | iy << 16 | ix << 24.
-    auto dgrad_unit = [&](const F16x2 (&bw)[4], const unsigned short* g, int g_lo, int zero_row, unsigned short* act, int act_lo, int AS, int nt,
-                          const int* dtab, int oh, int ow, int M, int T, int j, int kq) {
-        const int m = 16 * T + j, mc = min(m, M - 1);
-        const int de = dtab[mc];
-        const int gbase = de & 0xffff, iy = (de >> 16) & 0xff, ix = (de >> 24) & 0xff;
+    auto dgrad_unit = [&](const F16x2 (&bw)[4], const unsigned short* g, int g_lo, unsigned short* act, int act_lo, int nt, const int4* dtab, int M, int T,
+                          int j, int kq) {
+        const int m = 16 * T + j;
+        const int4 de = dtab[min(m, M - 1)];                        // the four taps' gradient rows and this pixel's own row: ready-made offsets (conv_bwd16_tables)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, accx = acc0;
-        unsigned short* pa = act + mc * AS + 16 * nt + 4 * kq;
+        unsigned short* pa = act + de.z + 16 * nt + 4 * kq;
         const uint2 mh = *reinterpret_cast<const uint2*>(pa), ml = *reinterpret_cast<const uint2*>(pa + act_lo);
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {                            // two taps' gradient rows in flight (all four: 32 more registers than the 128 allow)
             F16x2 gv[2];
+            const u32 e = (u32)(tp ? de.y : de.x);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int tap = 2 * tp + u;
-                const int oy = iy - (tap >> 1), ox = ix - (tap & 1);
-                const bool valid = (unsigned)oy < (unsigned)oh && (unsigned)ox < (unsigned)ow;
-                const int grow = valid ? gbase - (tap >> 1) * ow - (tap & 1) : zero_row;
-                const unsigned short* gp = g + grow * PL32 + 8 * kq;
+                const unsigned short* gp = g + (u ? e >> 16 : e & 0xffffu) + 8 * kq;
                 gv[u].h = *reinterpret_cast<const u32x4*>(gp);
                 gv[u].l = *reinterpret_cast<const u32x4*>(gp + g_lo);
             }
@@ -243,13 +225,24 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         // held in registers across all phases)
         const int lane = opq(tid & 63), j = lane & 15, kq = lane >> 4, ri = j >> 2, cseg = 4 * (j & 3);
         C16_STAMP(sb + 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's a1 copies of THIS group (the last it issued; 29 one-KB pieces per plane of a full group): they may stay in flight until dW2 -- and, in
+        // the first group, so may the weights' until g2.  (vmcnt is an immediate: the exact count or, for a partial group, 0.)
+        const int na1 = ns == S ? (2 * C16_A1_CHUNKS - wave + C16_WAVES - 1) / C16_WAVES : 0;
+        if (grp == (int)blockIdx.x) {
+            if (na1 == 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (na1 == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (na1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (na1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         C16_STAMP(sb + 1);
         // ---- patch image: row m = the bits of pixel m's word (data), then of its constant mask, one byte each -------------------------------------------
         if (tid < M1 * (KP / 8)) {
             const int m = tid >> 2, g = tid & 3;
-            const int e = t1[m];
+            const int e = tp[m];
             const u64 bits = (u64)reinterpret_cast<const u32*>(s_in)[e & 0xffff] | (u64)(u32)(e >> 16) << a.kd;
             *reinterpret_cast<uint2*>(s_col + m * KP + 8 * g) = s_lut[(u32)(bits >> (8 * g)) & 0xffu];
         }
@@ -261,22 +254,26 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         C16_STAMP(sb + 2);
         // ---- dW3 += im2col(a2)^T g3: lane group kq supplies rows m0 + 4 kq + (e & 3) + 16 (e >> 2) of both operands -----------------------------------------
         for (int m0 = 0; m0 < M3; m0 += 32) {
-            const int ra = min(m0 + 4 * kq + ri, M3 - 1), rb = min(m0 + 16 + 4 * kq + ri, M3 - 1);
-            const F16x2 A = lds_tr8(s_a2 + t3[ra] + aoff3 + cseg, s_a2 + t3[rb] + aoff3 + cseg, LA2);
-            F16x2 G = lds_tr8(s_g3 + ra * PL32 + 16 * nt3 + cseg, s_g3 + rb * PL32 + 16 * nt3 + cseg, LG3);
+            const u32 ea = (u32)t3[min(m0 + 4 * kq + ri, M3 - 1)], eb = (u32)t3[min(m0 + 16 + 4 * kq + ri, M3 - 1)];      // a2 row under the pixel | g3 row << 16
+            const F16x2 A = lds_tr8(s_a2 + (ea & 0xffffu) + aoff3 + cseg, s_a2 + (eb & 0xffffu) + aoff3 + cseg, LA2);
+            F16x2 G = lds_tr8(s_g3 + (ea >> 16) + 16 * nt3 + cseg, s_g3 + (eb >> 16) + 16 * nt3 + cseg, LG3);
             if (m0 + 32 > M3) mask_rows(G, m0, M3, 4 * kq, 1);
             mma_f16x3(A, G, acc3, acc3l);
         }
         C16_STAMP(sb + 3);
+        if (na1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (first group: the weights have landed)
+        else if (na1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                            // every wave is done reading a2; the patch image is complete
         C16_STAMP(sb + 4);
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 ----------------------------------------------------------------------------------------------
         {
             F16x2 bw[4];
             load_bw(bw, nt3, 2, lane);
-            if (16 * (wave >> 1) < M2) dgrad_unit(bw, s_g3, LG3, zero3, s_a2, LA2, PL32, nt3, d2, C16_OW3, C16_OW3, M2, wave >> 1, j, kq);
+            if (16 * (wave >> 1) < M2) dgrad_unit(bw, s_g3, LG3, s_a2, LA2, nt3, td2, M2, wave >> 1, j, kq);
         }
         C16_STAMP(sb + 5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // a1 has landed
         __syncthreads();
         C16_STAMP(sb + 6);
         if (nxt < a.groups) {                                       // the observation rows and g3 are dead now
@@ -293,10 +290,10 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         }
         // ---- dW2 += im2col(a1)^T g2 -------------------------------------------------------------------------------------------------------------------------
         for (int m0 = 0; m0 < M2; m0 += 32) {
-            const int ra = min(m0 + 4 * kq + ri, M2 - 1), rb = min(m0 + 16 + 4 * kq + ri, M2 - 1);
-            const F16x2 A = lds_tr8(s_a1 + t2[ra] + aoff2 + cseg, s_a1 + t2[rb] + aoff2 + cseg, LA1);
-            const unsigned short* p0 = s_a2 + ra * PL32 + cseg;
-            const unsigned short* p1 = s_a2 + rb * PL32 + cseg;
+            const u32 ea = (u32)t2[min(m0 + 4 * kq + ri, M2 - 1)], eb = (u32)t2[min(m0 + 16 + 4 * kq + ri, M2 - 1)];      // a1 row under the pixel | g2 row << 16
+            const F16x2 A = lds_tr8(s_a1 + (ea & 0xffffu) + aoff2 + cseg, s_a1 + (eb & 0xffffu) + aoff2 + cseg, LA1);
+            const unsigned short* p0 = s_a2 + (ea >> 16) + cseg;
+            const unsigned short* p1 = s_a2 + (eb >> 16) + cseg;
             F16x2 G0 = lds_tr8(p0, p1, LA2), G1 = lds_tr8(p0 + 16, p1 + 16, LA2);
             if (m0 + 32 > M2) { mask_rows(G0, m0, M2, 4 * kq, 1); mask_rows(G1, m0, M2, 4 * kq, 1); }
             mma_f16x3(A, G0, acc2[0], acc2l[0]);
@@ -309,7 +306,7 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         {
             F16x2 bw[4];
             load_bw(bw, 8 + (wave & 3), 4, lane);
-            for (int T = wave >> 2; 16 * T < M1; T += 4) dgrad_unit(bw, s_a2, LA2, zero2, s_a1, LA1, A1S, wave & 3, d1, C16_OW2, C16_OW2, M1, T, j, kq);
+            for (int T = wave >> 2; 16 * T < M1; T += 4) dgrad_unit(bw, s_a2, LA2, s_a1, LA1, wave & 3, td1, M1, T, j, kq);
         }
         C16_STAMP(sb + 9);
         __syncthreads();
@@ -328,10 +325,10 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
             const int re = j >> 1, rowb = kq + 4 * (re & 3) + 16 * (re >> 2);      // the patch row (inside a block) this lane points at
             const u8* cp = s_col + 16 * (w8 >> 2) + 8 * (j & 1);
             for (int m0 = 32 * (wave >> 3); m0 < M1; m0 += 64) {
-                const int ra = min(m0 + rj, M1 - 1), rb = min(m0 + 16 + rj, M1 - 1);
-                F16x2 G = lds_tr8(s_a1 + ra * A1S + cs, s_a1 + rb * A1S + cs, LA1);
+                const u32 ea = (u32)t1[min(m0 + rj, M1 - 1)], eb = (u32)t1[min(m0 + 16 + rj, M1 - 1)], ep = (u32)t1[min(m0 + rowb, M1 - 1)];      // g1 row | patch row << 16
+                F16x2 G = lds_tr8(s_a1 + (ea & 0xffffu) + cs, s_a1 + (eb & 0xffffu) + cs, LA1);
                 typedef int i32x2 __attribute__((ext_vector_type(2)));
-                const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(cp + min(m0 + rowb, M1 - 1) * KP));
+                const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(cp + (ep >> 16)));
                 if (m0 + 32 > M1) mask_rows(G, m0, M1, kq, 4);
                 u32x4 av;
                 av[0] = __umul24(__builtin_amdgcn_perm(0u, (u32)v[0], 0x0c010c00u), 0x3c00u);
@@ -398,6 +395,50 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         }
     }
     C16_STAMP(28);
+}
+
+// The kernel's LDS-resident tables (qnet.h PT_C16; sections TB_* above), built once per dq_qnet_set_patch_input and copied by LDS-DMA as they are: every
+// LDS address the kernel forms from a row number comes out of them, so the placement of the three images' rows is THEIR business (row r of a1 / g1 at
+// A1S r halves, of a2 / g2 and g3 at PL32 r).
+void conv_bwd16_tables(const dq_qnet* Q, int stride_words, const int* pt_const, const int* pt_src, int* out) {
+    memset(out, 0, sizeof(int) * PT_C16_INTS);
+    if (Q->cfg.n_conv != 3 || Q->L[0].oh != C16_OW1 || Q->L[0].ow != C16_OW1 || Q->L[1].rows != C16_R2 || Q->L[2].rows != C16_R3) return;
+    constexpr int S = C16_S;
+    auto a1row = [](int r) { return r * A1S; };
+    auto a2row = [](int r) { return r * PL32; };                     // (a2 / g2 image; row S r2 = the all-zero row)
+    auto g3row = [](int r) { return r * PL32; };
+    for (int m = 0; m < S * C16_R1; ++m) {
+        const int s = m / C16_R1, p = m % C16_R1, iy = p / C16_OW1, ix = p % C16_OW1;
+        int tapo[4];
+        for (int tap = 0; tap < 4; ++tap) {
+            const int oy = iy - (tap >> 1), ox = ix - (tap & 1);
+            const bool valid = oy >= 0 && oy < C16_OW2 && ox >= 0 && ox < C16_OW2;
+            tapo[tap] = a2row(valid ? s * C16_R2 + oy * C16_OW2 + ox : S * C16_R2);
+        }
+        out[TB_D1 + 4 * m] = tapo[0] | tapo[1] << 16; out[TB_D1 + 4 * m + 1] = tapo[2] | tapo[3] << 16; out[TB_D1 + 4 * m + 2] = a1row(m);
+        out[TB_T1 + m] = a1row(m) | (m * C16_KP) << 16;
+        out[TB_TP + m] = (s * stride_words + p) | pt_const[p] << 16;
+    }
+    for (int m = 0; m < S * C16_R2; ++m) {
+        const int s = m / C16_R2, p = m % C16_R2, iy = p / C16_OW2, ix = p % C16_OW2;
+        int tapo[4];
+        for (int tap = 0; tap < 4; ++tap) {
+            const int oy = iy - (tap >> 1), ox = ix - (tap & 1);
+            const bool valid = oy >= 0 && oy < C16_OW3 && ox >= 0 && ox < C16_OW3;
+            tapo[tap] = g3row(valid ? s * C16_R3 + oy * C16_OW3 + ox : S * C16_R3);
+        }
+        out[TB_D2 + 4 * m] = tapo[0] | tapo[1] << 16; out[TB_D2 + 4 * m + 1] = tapo[2] | tapo[3] << 16; out[TB_D2 + 4 * m + 2] = a2row(m);
+        out[TB_T2 + m] = a1row(s * C16_R1 + iy * C16_OW1 + ix) | a2row(m) << 16;
+    }
+    for (int m = 0; m < S * C16_R3; ++m) {
+        const int s = m / C16_R3, p = m % C16_R3, iy = p / C16_OW3, ix = p % C16_OW3;
+        out[TB_T3 + m] = a2row(s * C16_R2 + iy * C16_OW2 + ix) | g3row(m) << 16;
+    }
+    for (int k = 0; k < 96; ++k) out[TB_KO + k] = pt_src[k];
+    for (unsigned b = 0; b < 256; ++b) {
+        out[TB_LUT + 2 * b] = (int)((b & 1u) | (b & 2u) << 7 | (b & 4u) << 14 | (b & 8u) << 21);
+        out[TB_LUT + 2 * b + 1] = (int)(((b >> 4) & 1u) | ((b >> 4) & 2u) << 7 | ((b >> 4) & 4u) << 14 | ((b >> 4) & 8u) << 21);
+    }
 }
 
 // Patch-word input with K_data + 5 <= 32 columns, the three convolutions 64 x 3 x s2 / 32 x 2 / 32 x 2 on a 5 x 5 first output (d = 5): everything else
