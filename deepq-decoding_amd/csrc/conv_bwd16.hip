@@ -17,6 +17,7 @@
 //                           barrier that retires the previous group's dW1 -- it is first needed three phases later.
 //
 // LDS (153.6 KB): [cdw 48 KB | a1 / g1 planes 58 KB | a2 / g2 planes 20.2 KB | g3 planes 11.4 KB | patch image 6.25 KB | observations 1 KB | tables].
+#include <type_traits>
 #include "conv_bwd.h"
 
 #define C16_THREADS 1024
@@ -33,7 +34,8 @@
 #define C16_LA1 (C16_A1_CHUNKS * 512)   // halves from a1's h plane to its l plane
 #define C16_LA2 ((C16_S * C16_R2 + 1) * PL32)
 #define C16_LG3 ((C16_S * C16_R3 + 1) * PL32)
-#define C16_KP 32                       // bytes per row of the patch image (K_data + 5 <= 32 columns)
+#define C16_KP 40                       // bytes per row of the patch image: 32 columns (K_data + 5 <= 31 used, column 31 = 1) + 8 of padding -- the sixteen rows a
+                                        // 32-lane group of dW1's 8-bit transposing read touches then fall on distinct banks (32 bytes apart: rows r, r + 8 on the same)
 // byte offsets
 #define C16_OFF_W 0
 #define C16_OFF_A1 (24 * 2048)
@@ -48,11 +50,9 @@
 #define TB_D2 800                       // [128] x 4: a2 pixel m -> {g3 row under taps 0 | 1, 2 | 3, a2 row of m, 0}
 #define TB_T2 1312                      // [128]: second-convolution output pixel m -> a1 row under it | g2 row m << 16
 #define TB_T3 1440                      // [72]: third-convolution output pixel m -> a2 row under it | g3 row m << 16
-#define TB_T1 1520                      // [200]: first-convolution output pixel m -> g1 row m | byte offset of its patch-image row << 16
-#define TB_TP 1720                      // [200]: ... -> (s * stride_words + p) | the pixel's constant-cell mask << 16 (qnet.h PT_BWD)
-#define TB_KO 1920                      // [96]: Keras row of the first kernel -> column of the patch image, -1: gradient 0 (qnet.h PT_SRC)
-#define TB_INV 2016                     // [400]: reserved (row placement maps of the three images)
-#define TB_LUT 2416                     // [256] x 2: byte -> its bits as eight bytes
+#define TB_TP 1520                      // [200]: first-convolution output pixel m -> (s * stride_words + p) | (its constant-cell mask | the bit of column 31) << 16 (qnet.h PT_BWD)
+#define TB_KO 1720                      // [96]: Keras row of the first kernel -> column of the patch image, -1: gradient 0 (qnet.h PT_SRC)
+#define TB_LUT 1816                     // [256] x 2: byte -> its bits as eight bytes
 static_assert(TB_LUT + 512 <= PT_C16_INTS, "table blob");
 static_assert(C16_LDS <= CHAIN_LDS_MAX, "LDS budget");
 static_assert(C16_OFF_TAB % 16 == 0 && C16_OFF_COL % 16 == 0, "alignment");
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
     const int* tab = reinterpret_cast<const int*>(smem + C16_OFF_TAB);
     const int4* td1 = reinterpret_cast<const int4*>(tab + TB_D1);
     const int4* td2 = reinterpret_cast<const int4*>(tab + TB_D2);
-    const int *t2 = tab + TB_T2, *t3 = tab + TB_T3, *t1 = tab + TB_T1, *tp = tab + TB_TP, *s_ko = tab + TB_KO;
+    const int *t2 = tab + TB_T2, *t3 = tab + TB_T3, *tp = tab + TB_TP, *s_ko = tab + TB_KO;
     const uint2* s_lut = reinterpret_cast<const uint2*>(tab + TB_LUT);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
     constexpr int S = C16_S, r1 = C16_R1, r2 = C16_R2, r3 = C16_R3;
@@ -89,8 +89,7 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
 
     // this wave's replay row of the workgroup's first group (waves 0 .. 7: one sample each), requested before anything else
     auto obs_row = [&](int g) {
-        const int gb0 = g * S, gns = min(S, a.batch - gb0);
-        int row = gb0 + min(wave & 7, gns - 1);
+        int row = g * S + (wave & 7);
         if (a.index) {
             const __attribute__((address_space(4))) int32_t* idx = (const __attribute__((address_space(4))) int32_t*)(uintptr_t)a.index;
             row = idx[row] + a.index_off;
@@ -106,7 +105,8 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
     auto opq = [](int x) { asm volatile("" : "+v"(x)); return x; };
     auto issue_a1 = [&](int g) {
         const int lane = opq(tid & 63);
-        const int gb0 = g * S, rows = min(S, a.batch - gb0) * r1, slots = rows * 9, chunks = (slots + 63) >> 6;
+        constexpr int rows = S * r1, slots = rows * 9, chunks = (slots + 63) >> 6;
+        const int gb0 = g * S;
         for (int c = wave; c < 2 * chunks; c += C16_WAVES) {
             const int piece = c >= chunks ? 1 : 0, ch = c - piece * chunks;
             const int q = ch * 64 + lane, row = q / 9, part = q - row * 9;
@@ -127,14 +127,15 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
     auto issue_a2 = [&](int g, int rows) { issue_pl32(a.a2p + (size_t)g * S * r2 * 32, a.a2_lo, rows, s_a2, LA2); };
     auto issue_g3 = [&](int g, int rows) { issue_pl32(a.g3p + (size_t)g * S * r3 * 32, a.g3_lo, rows, s_g3, LG3); };
     auto issue_obs = [&](int g, int row) {
-        const int gns = min(S, a.batch - g * S), lane = opq(tid & 63);
-        if (wave < gns && lane < (in_bytes >> 4)) lds_dma16(a.obs + (size_t)row * in_bytes + 16 * lane, lds_addr(s_in + wave * in_bytes));
+        const int lane = opq(tid & 63);
+        if (wave < S && lane < (in_bytes >> 4)) lds_dma16(a.obs + (size_t)row * in_bytes + 16 * lane, lds_addr(s_in + wave * in_bytes));
     };
     // Copies of the first group, in the order of their first use: tables, observations, g3, a2 (patch image, dW3) | the data gradients' weights (g2) | a1 (dW2):
     // a wave's copies land in order, so the group loop waits for the first set only before it starts (every CU requests its 150 KB at once: the whole
     // set took 9.5 K cycles to land)
     {
-        const int g = blockIdx.x, gns = min(S, a.batch - g * S);
+        const int g = blockIdx.x;
+        constexpr int gns = S;
         const char* tsrc = reinterpret_cast<const char*>(a.tab16);
         for (int c = wave; c < 4 * PT_C16_INTS / 1024; c += C16_WAVES) lds_dma16(tsrc + c * 1024 + lane * 16, lds_addr(smem + C16_OFF_TAB + c * 1024));
         issue_obs(g, row_first);
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
     const int aoff2 = ((wave >> 3) * C16_OW1 + ((wave >> 2) & 1)) * A1S + 16 * (wave & 3);
     f32x4 acc3 = {0.f, 0.f, 0.f, 0.f}, acc3l = acc3, acc2[2] = {acc3, acc3}, acc2l[2] = {acc3, acc3}, acc1 = acc3, acc1l = acc3;
     float bs3 = 0.f;                                                // this thread's share of g3's column tid & 31
-    float bs2[2] = {0.f, 0.f}, bs1[2] = {0.f, 0.f};                // g2's columns 2 (tid & 15), + 1 (threads < 512) / g1's columns 2 (tid & 31), + 1: this thread's row class
+    float bs2[2] = {0.f, 0.f};                                      // g2's columns 2 (tid & 15), + 1 (threads < 512): this thread's row class
 
     // Transposed data gradient of one unit: rows m = 16 T + j of the activation image `act` (row stride AS halves, l plane act_lo halves further), channels
     // 16 nt + 4 kq .. + 3:  act <- (sum over taps  W[tap]^T g[pixel - tap]) * [act > 0], in place; g = piece planes [rows][PL32] with an all-zero row `zero_row`.
@@ -203,44 +204,45 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
             bw[tap].l = *reinterpret_cast<const u32x4*>(p + 1024);
         }
     };
-    // halves of g's pieces whose rows lie past M cleared (element e = half e of the operand; row of element e: m0 + rb + 4 or 1 x ...)
-    auto mask_rows = [&](F16x2& G, int m0, int M, int rb, int rstep) {
+    // The 32 rows of a K block are dealt to the lanes so that the EIGHT rows a 32-lane group of a transposing read touches (lane groups kq = 0, 1 / 2, 3; four
+    // rows per read and lane group) have the same parity: element e of lane group kq is row m0 + (kq >> 1) + 8 (kq & 1) + 2 (e & 3) + 16 (e >> 2).  With rows
+    // 80 bytes (a2 / g2, g3) or 144 bytes (a1 / g1) apart, eight same-parity rows put their 32-byte windows on eight disjoint quarters of the 64 banks; eight
+    // CONSECUTIVE rows (the first assignment: 4 kq + e) overlapped pairwise -- every such read took twice its cycles (tools/probe/c16_lds_model.py).
+    // (Any assignment is a permutation of the reduction index as long as both operands use it.)
+    // mask_rows: halves of G's pieces whose rows lie past M cleared (element e = half e of the operand)
+    auto mask_rows = [&](F16x2& G, int m0, int M, int kq) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const u32 lo = m0 + rb + rstep * ((2 * d) & 3) + 16 * ((2 * d) >> 2) < M ? 0xffffu : 0u;
-            const u32 hi = m0 + rb + rstep * ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < M ? 0xffff0000u : 0u;
+            const int rb = m0 + (kq >> 1) + 8 * (kq & 1);
+            const u32 lo = rb + 2 * ((2 * d) & 3) + 16 * ((2 * d) >> 2) < M ? 0xffffu : 0u;
+            const u32 hi = rb + 2 * ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < M ? 0xffff0000u : 0u;
             G.h[d] &= lo | hi; G.l[d] &= lo | hi;
         }
     };
-
     int sb = 2;
     (void)sb;
     for (int grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
-        const int b0 = grp * S, ns = min(S, a.batch - b0);
-        const int M1 = ns * r1, M2 = ns * r2, M3 = ns * r3;
+        // (whole groups only: conv_bwd16_launch refuses a minibatch that is not a multiple of 8 -- the row counts are compile-time, the loops unroll)
+        constexpr int ns = S, M1 = S * r1, M2 = S * r2, M3 = S * r3, ns_nxt = S;
         const int nxt = grp + (int)gridDim.x;
-        const int ns_nxt = min(S, a.batch - nxt * S);
         const int row_nxt = nxt < a.groups ? obs_row(nxt) : 0;
         // (lane-derived values re-derived per group from an opaque lane number: as loop invariants they -- and every address formed from them -- would be
         // held in registers across all phases)
-        const int lane = opq(tid & 63), j = lane & 15, kq = lane >> 4, ri = j >> 2, cseg = 4 * (j & 3);
+        const int lane = opq(tid & 63), j = lane & 15, kq = lane >> 4, cseg = 4 * (j & 3);
+        const int rq = (kq >> 1) + 8 * (kq & 1) + 2 * (j >> 2);       // the row (inside a K block) this lane points at in a transposing read; the second read: + 16
         C16_STAMP(sb + 0);
         // this wave's a1 copies of THIS group (the last it issued; 29 one-KB pieces per plane of a full group): they may stay in flight until dW2 -- and, in
         // the first group, so may the weights' until g2.  (vmcnt is an immediate: the exact count or, for a partial group, 0.)
-        const int na1 = ns == S ? (2 * C16_A1_CHUNKS - wave + C16_WAVES - 1) / C16_WAVES : 0;
-        if (grp == (int)blockIdx.x) {
+        const int na1 = (2 * C16_A1_CHUNKS - wave + C16_WAVES - 1) / C16_WAVES;
+        if (grp == (int)blockIdx.x) {                               // first group: the weights' and a1's copies may stay in flight
             if (na1 == 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else if (na1 == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (na1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (na1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // later groups: observations, g3, a2 (requested during the previous group)
+        __syncthreads();                                            // ... and every wave has left the previous group's dW1: a1 / g1 is free
+        if (grp != (int)blockIdx.x) issue_a1(grp);                  // first needed by dW2, two phases on
         C16_STAMP(sb + 1);
         // ---- patch image: row m = the bits of pixel m's word (data), then of its constant mask, one byte each -------------------------------------------
-        if (tid < M1 * (KP / 8)) {
+        if (tid < M1 * 4) {
             const int m = tid >> 2, g = tid & 3;
             const int e = tp[m];
             const u64 bits = (u64)reinterpret_cast<const u32*>(s_in)[e & 0xffff] | (u64)(u32)(e >> 16) << a.kd;
@@ -252,18 +254,23 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
             bs3 += (float)__builtin_bit_cast(_Float16, gp[0]) + (float)__builtin_bit_cast(_Float16, gp[LG3]) * F16_LO_INV;
         }
         C16_STAMP(sb + 2);
-        // ---- dW3 += im2col(a2)^T g3: lane group kq supplies rows m0 + 4 kq + (e & 3) + 16 (e >> 2) of both operands -----------------------------------------
-        for (int m0 = 0; m0 < M3; m0 += 32) {
-            const u32 ea = (u32)t3[min(m0 + 4 * kq + ri, M3 - 1)], eb = (u32)t3[min(m0 + 16 + 4 * kq + ri, M3 - 1)];      // a2 row under the pixel | g3 row << 16
-            const F16x2 A = lds_tr8(s_a2 + (ea & 0xffffu) + aoff3 + cseg, s_a2 + (eb & 0xffffu) + aoff3 + cseg, LA2);
-            F16x2 G = lds_tr8(s_g3 + (ea >> 16) + 16 * nt3 + cseg, s_g3 + (eb >> 16) + 16 * nt3 + cseg, LG3);
-            if (m0 + 32 > M3) mask_rows(G, m0, M3, 4 * kq, 1);
-            mma_f16x3(A, G, acc3, acc3l);
+        // ---- dW3 += im2col(a2)^T g3 (rows of a K block: see mask_rows) -----------------------------------------
+        {
+            u32 e3[2 * ((M3 + 31) / 32)];                           // (every block's table entries first: one LDS latency for the phase instead of one per block)
+#pragma unroll
+            for (int i = 0; i < 2 * ((M3 + 31) / 32); ++i) e3[i] = (u32)t3[min(16 * i + rq, M3 - 1)];      // a2 row under the pixel | g3 row << 16
+#pragma unroll
+            for (int m0 = 0; m0 < M3; m0 += 32) {
+                const u32 ea = e3[m0 >> 4], eb = e3[(m0 >> 4) + 1];
+                const F16x2 A = lds_tr8(s_a2 + (ea & 0xffffu) + aoff3 + cseg, s_a2 + (eb & 0xffffu) + aoff3 + cseg, LA2);
+                F16x2 G = lds_tr8(s_g3 + (ea >> 16) + 16 * nt3 + cseg, s_g3 + (eb >> 16) + 16 * nt3 + cseg, LG3);
+                if (m0 + 32 > M3) mask_rows(G, m0, M3, kq);
+                mma_f16x3(A, G, acc3, acc3l);
+            }
         }
         C16_STAMP(sb + 3);
-        if (na1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (first group: the weights have landed)
-        else if (na1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (na1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (first group: the weights have landed; a1 may stay in flight)
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __syncthreads();                                            // every wave is done reading a2; the patch image is complete
         C16_STAMP(sb + 4);
         // ---- g2 = (g3 (*) W3^T) * [a2 > 0], in place over a2 ----------------------------------------------------------------------------------------------
@@ -289,47 +296,98 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
             }
         }
         // ---- dW2 += im2col(a1)^T g2 -------------------------------------------------------------------------------------------------------------------------
-        for (int m0 = 0; m0 < M2; m0 += 32) {
-            const u32 ea = (u32)t2[min(m0 + 4 * kq + ri, M2 - 1)], eb = (u32)t2[min(m0 + 16 + 4 * kq + ri, M2 - 1)];      // a1 row under the pixel | g2 row << 16
-            const F16x2 A = lds_tr8(s_a1 + (ea & 0xffffu) + aoff2 + cseg, s_a1 + (eb & 0xffffu) + aoff2 + cseg, LA1);
-            const unsigned short* p0 = s_a2 + (ea >> 16) + cseg;
-            const unsigned short* p1 = s_a2 + (eb >> 16) + cseg;
-            F16x2 G0 = lds_tr8(p0, p1, LA2), G1 = lds_tr8(p0 + 16, p1 + 16, LA2);
-            if (m0 + 32 > M2) { mask_rows(G0, m0, M2, 4 * kq, 1); mask_rows(G1, m0, M2, 4 * kq, 1); }
-            mma_f16x3(A, G0, acc2[0], acc2l[0]);
-            mma_f16x3(A, G1, acc2[1], acc2l[1]);
+        {
+            u32 e2[2 * (M2 / 32)];
+#pragma unroll
+            for (int i = 0; i < 2 * (M2 / 32); ++i) e2[i] = (u32)t2[16 * i + rq];      // a1 row under the pixel | g2 row << 16
+#pragma unroll
+            for (int m0 = 0; m0 < M2; m0 += 32) {
+                const u32 ea = e2[m0 >> 4], eb = e2[(m0 >> 4) + 1];
+                const F16x2 A = lds_tr8(s_a1 + (ea & 0xffffu) + aoff2 + cseg, s_a1 + (eb & 0xffffu) + aoff2 + cseg, LA1);
+                const unsigned short* p0 = s_a2 + (ea >> 16) + cseg;
+                const unsigned short* p1 = s_a2 + (eb >> 16) + cseg;
+                F16x2 G0 = lds_tr8(p0, p1, LA2), G1 = lds_tr8(p0 + 16, p1 + 16, LA2);
+                mma_f16x3(A, G0, acc2[0], acc2l[0]);
+                mma_f16x3(A, G1, acc2[1], acc2l[1]);
+            }
         }
         C16_STAMP(sb + 7);
         __syncthreads();                                            // every wave is done reading a1
         C16_STAMP(sb + 8);
         // ---- g1 = (g2 (*) W2^T) * [a1 > 0], in place over a1 ----------------------------------------------------------------------------------------------
+        // Wave w < 13 takes row tile w with all four channel tiles: the four taps' gradient rows (the reads that can conflict) are fetched ONCE and held,
+        // the weights of a channel tile stream from the LDS copy (lane-ordered blocks: conflict-free).  As (row tile, channel tile) units -- every unit
+        // fetching its gradient rows again -- the phase was LDS-bound: 5.2 K of its 5.6 K cycles, 3.6 K of them those reads at 2.2 cycles per ideal one.
+        // Row tiles 0 .. 11: one wave each, all four channel tiles.  The thirteenth (8 of its 16 rows exist): waves 12 .. 15, one channel tile each -- every
+        // SIMD then carries 3 x 48 + 12 MFMAs (with the whole tile on wave 12 its SIMD carried 4 x 48 and set the phase: 6.3 K cycles against the others' 4.7 K).
         {
-            F16x2 bw[4];
-            load_bw(bw, 8 + (wave & 3), 4, lane);
-            for (int T = wave >> 2; 16 * T < M1; T += 4) dgrad_unit(bw, s_a2, LA2, s_a1, LA1, wave & 3, td1, M1, T, j, kq);
+            const int T = wave < 12 ? wave : 12;
+            const int m = 16 * T + j;
+            const int4 de = td1[min(m, M1 - 1)];                    // the four taps' g2 rows and this pixel's own a1 row: ready-made offsets (conv_bwd16_tables)
+            const bool in = m < M1;
+            auto tiles = [&](int nt0, auto two) {
+                constexpr int NT = decltype(two)::value;
+                f32x4 acc0[NT], accx[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) { acc0[u] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[u] = acc0[u]; }
+#pragma unroll
+                for (int tap = 0; tap < 4; ++tap) {
+                    const u32 e = (u32)(tap & 2 ? de.y : de.x);
+                    const unsigned short* gp = s_a2 + (tap & 1 ? e >> 16 : e & 0xffffu) + 8 * kq;
+                    F16x2 gv, bw[NT];
+                    gv.h = *reinterpret_cast<const u32x4*>(gp);
+                    gv.l = *reinterpret_cast<const u32x4*>(gp + LA2);
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        const u8* p = s_wb + (8 + tap * 4 + nt0 + u) * 2048 + lane * 16;
+                        bw[u].h = *reinterpret_cast<const u32x4*>(p);
+                        bw[u].l = *reinterpret_cast<const u32x4*>(p + 1024);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) mma_f16x3(bw[u], gv, acc0[u], accx[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    unsigned short* pa = s_a1 + de.z + 16 * (nt0 + u) + 4 * kq;
+                    const uint2 mh = *reinterpret_cast<const uint2*>(pa), ml = *reinterpret_cast<const uint2*>(pa + LA1);
+                    const u32 b0 = mh.x | ml.x, b1 = mh.y | ml.y;
+                    const float v0 = (in && (b0 & 0x7fffu) != 0u) ? f16x2_sum(acc0[u][0], accx[u][0]) : 0.f;
+                    const float v1 = (in && (b0 & 0x7fff0000u) != 0u) ? f16x2_sum(acc0[u][1], accx[u][1]) : 0.f;
+                    const float v2 = (in && (b1 & 0x7fffu) != 0u) ? f16x2_sum(acc0[u][2], accx[u][2]) : 0.f;
+                    const float v3 = (in && (b1 & 0x7fff0000u) != 0u) ? f16x2_sum(acc0[u][3], accx[u][3]) : 0.f;
+                    u32 h0, l0, h1, l1;
+                    split_f16x2_pair(v0, v1, h0, l0);
+                    split_f16x2_pair(v2, v3, h1, l1);
+                    if (in) {
+                        *reinterpret_cast<uint2*>(pa) = uint2{h0, h1};
+                        *reinterpret_cast<uint2*>(pa + LA1) = uint2{l0, l1};
+                    }
+                }
+            };
+            // (two channel tiles at a time: one accumulator pair per pass made hipcc emit read, wait, MFMA, wait, ... -- an LDS latency in front of every pair
+            // of MFMAs --, all four at once spills)
+            if (wave < 12) { tiles(0, std::integral_constant<int, 2>{}); tiles(2, std::integral_constant<int, 2>{}); }
+            else tiles(wave - 12, std::integral_constant<int, 1>{});
         }
         C16_STAMP(sb + 9);
         __syncthreads();
         C16_STAMP(sb + 10);
         if (nxt < a.groups) issue_a2(nxt, ns_nxt * r2);            // g2 (in a2) is dead
-        // the first convolution's bias gradient = column sums of g1: thread (column pair tid & 31, row class tid >> 5)
-        for (int row = tid >> 5; row < M1; row += 32) {
-            const unsigned short* gp = s_a1 + row * A1S + 2 * (tid & 31);
-            const f16x2 h = __builtin_bit_cast(f16x2, *reinterpret_cast<const u32*>(gp)), l = __builtin_bit_cast(f16x2, *reinterpret_cast<const u32*>(gp + LA1));
-            bs1[0] += (float)h[0] + (float)l[0] * F16_LO_INV; bs1[1] += (float)h[1] + (float)l[1] * F16_LO_INV;
-        }
-        // ---- dW1 += patches^T g1: binary patch operand (one MFMA per piece of g1); lane group kq supplies rows m0 + kq + 4 (e & 3) + 16 (e >> 2) ------------------
+        // (the first convolution's bias gradient comes out of dW1: column 31 of the patch image is 1 for every pixel -- conv_bwd16_tables -- so row 31 of
+        // the product is g1's column sums)
+        // ---- dW1 += patches^T g1: binary patch operand (one MFMA per piece of g1); rows as in dW2 / dW3 ------------------
         {
             const int w8 = wave & 7;
-            const int cs = 16 * (w8 & 3) + 4 * (j & 3), rj = kq + 4 * (j >> 2);
-            const int re = j >> 1, rowb = kq + 4 * (re & 3) + 16 * (re >> 2);      // the patch row (inside a block) this lane points at
+            const int cs = 16 * (w8 & 3) + 4 * (j & 3), rj = rq;
+            const int re = j >> 1, rowb = (kq >> 1) + 8 * (kq & 1) + 2 * (re & 3) + 16 * (re >> 2);      // the patch row (inside a block) this lane points at
             const u8* cp = s_col + 16 * (w8 >> 2) + 8 * (j & 1);
-            for (int m0 = 32 * (wave >> 3); m0 < M1; m0 += 64) {
-                const u32 ea = (u32)t1[min(m0 + rj, M1 - 1)], eb = (u32)t1[min(m0 + 16 + rj, M1 - 1)], ep = (u32)t1[min(m0 + rowb, M1 - 1)];      // g1 row | patch row << 16
-                F16x2 G = lds_tr8(s_a1 + (ea & 0xffffu) + cs, s_a1 + (eb & 0xffffu) + cs, LA1);
-                typedef int i32x2 __attribute__((ext_vector_type(2)));
-                const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(cp + (ep >> 16)));
-                if (m0 + 32 > M1) mask_rows(G, m0, M1, kq, 4);
+            typedef int i32x2 __attribute__((ext_vector_type(2)));
+            auto rd = [&](int m0, F16x2& G, i32x2& v) {                // (rows of g1 and of the patch image are where their numbers say: no table)
+                G = lds_tr8(s_a1 + min(m0 + rj, M1 - 1) * A1S + cs, s_a1 + min(m0 + 16 + rj, M1 - 1) * A1S + cs, LA1);
+                v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) i32x2*)(cp + min(m0 + rowb, M1 - 1) * KP));
+            };
+            auto mm = [&](int m0, F16x2& G, const i32x2& v) {
+                if (m0 + 32 > M1) mask_rows(G, m0, M1, kq);
                 u32x4 av;
                 av[0] = __umul24(__builtin_amdgcn_perm(0u, (u32)v[0], 0x0c010c00u), 0x3c00u);
                 av[1] = __umul24(__builtin_amdgcn_perm(0u, (u32)v[0], 0x0c030c02u), 0x3c00u);
@@ -337,11 +395,21 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
                 av[3] = __umul24(__builtin_amdgcn_perm(0u, (u32)v[1], 0x0c030c02u), 0x3c00u);
                 acc1 = MFMA_F16(av, G.h, acc1);
                 acc1l = MFMA_F16(av, G.l, acc1l);
+            };
+            // two blocks' reads in flight (the seventh block belongs to the even half; the odd half's fourth trip re-reads rows of its third, masked to zero:
+            // NO condition around an MFMA -- fused_bwd.hip)
+            const int mh0 = 32 * (wave >> 3);
+#pragma unroll
+            for (int mb = 0; mb < 4; mb += 2) {
+                F16x2 Ga, Gb;
+                i32x2 va, vb;
+                rd(mh0 + 64 * mb, Ga, va);
+                rd(mh0 + 64 * mb + 64, Gb, vb);
+                mm(mh0 + 64 * mb, Ga, va);
+                mm(mh0 + 64 * mb + 64, Gb, vb);
             }
         }
         C16_STAMP(sb + 11);
-        __syncthreads();                                            // every wave is done with a1 / g1
-        if (nxt < a.groups) issue_a1(nxt);
         sb += 12;
     }
     C16_STAMP(26);
@@ -356,8 +424,8 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
     }
     C16_STAMP(27);
     {
-        // (the last group's closing barrier: every LDS image is dead)
-        float* s_b = reinterpret_cast<float*>(smem);                // [0, 1024) g3's classes | [1024, 2048) g2's | [2048, 4096) g1's
+        // (these overlay the weights' LDS copy, last read in front of the g1 phase's closing barrier)
+        float* s_b = reinterpret_cast<float*>(smem);                // [0, 1024) g3's classes | [1024, 2048) g2's
         float* s_res = s_b + 4096;                                  // the patch image's gradient [32][64], then scattered to the kernel's Keras rows
         const int w8 = wave & 7, kt = w8 >> 2, nt = w8 & 3;
         if (wave >= 8) {
@@ -366,7 +434,6 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         }
         s_b[tid] = bs3;                                             // thread (column tid & 31, row class tid >> 5)
         if (tid < 512) { s_b[1024 + (tid >> 4) * 32 + 2 * (tid & 15)] = bs2[0]; s_b[1024 + (tid >> 4) * 32 + 2 * (tid & 15) + 1] = bs2[1]; }
-        s_b[2048 + (tid >> 5) * 64 + 2 * (tid & 31)] = bs1[0]; s_b[2048 + (tid >> 5) * 64 + 2 * (tid & 31) + 1] = bs1[1];
         __syncthreads();
         if (wave < 8) {
 #pragma unroll
@@ -382,17 +449,13 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
 #pragma unroll
             for (int cl = 0; cl < 32; ++cl) v += s_b[cl * 32 + (tid - 32)];
             out[a.b_off[2] + tid - 32] = v;
-        } else if (tid < 128) {
-            float v = 0.f;
-#pragma unroll
-            for (int cl = 0; cl < 32; ++cl) v += s_b[2048 + cl * 64 + (tid - 64)];
-            out[a.b_off[0] + tid - 64] = v;
         }
         __syncthreads();
         for (int i = tid; i < a.K1 * 64; i += C16_THREADS) {
             const int src = s_ko[i >> 6];
             out[a.w_off[0] + i] = src >= 0 ? s_res[src * 64 + (i & 63)] : 0.f;
         }
+        if (tid < 64) out[a.b_off[0] + tid] = s_res[31 * 64 + tid];       // the all-ones column of the patch image: g1's column sums
     }
     C16_STAMP(28);
 }
@@ -400,9 +463,9 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
 // The kernel's LDS-resident tables (qnet.h PT_C16; sections TB_* above), built once per dq_qnet_set_patch_input and copied by LDS-DMA as they are: every
 // LDS address the kernel forms from a row number comes out of them, so the placement of the three images' rows is THEIR business (row r of a1 / g1 at
 // A1S r halves, of a2 / g2 and g3 at PL32 r).
-void conv_bwd16_tables(const dq_qnet* Q, int stride_words, const int* pt_const, const int* pt_src, int* out) {
+void conv_bwd16_tables(const dq_qnet* Q, int kd, int stride_words, const int* pt_const, const int* pt_src, int* out) {
     memset(out, 0, sizeof(int) * PT_C16_INTS);
-    if (Q->cfg.n_conv != 3 || Q->L[0].oh != C16_OW1 || Q->L[0].ow != C16_OW1 || Q->L[1].rows != C16_R2 || Q->L[2].rows != C16_R3) return;
+    if (kd + 6 > 32 || Q->cfg.n_conv != 3 || Q->L[0].oh != C16_OW1 || Q->L[0].ow != C16_OW1 || Q->L[1].rows != C16_R2 || Q->L[2].rows != C16_R3) return;
     constexpr int S = C16_S;
     auto a1row = [](int r) { return r * A1S; };
     auto a2row = [](int r) { return r * PL32; };                     // (a2 / g2 image; row S r2 = the all-zero row)
@@ -416,8 +479,7 @@ void conv_bwd16_tables(const dq_qnet* Q, int stride_words, const int* pt_const, 
             tapo[tap] = a2row(valid ? s * C16_R2 + oy * C16_OW2 + ox : S * C16_R2);
         }
         out[TB_D1 + 4 * m] = tapo[0] | tapo[1] << 16; out[TB_D1 + 4 * m + 1] = tapo[2] | tapo[3] << 16; out[TB_D1 + 4 * m + 2] = a1row(m);
-        out[TB_T1 + m] = a1row(m) | (m * C16_KP) << 16;
-        out[TB_TP + m] = (s * stride_words + p) | pt_const[p] << 16;
+        out[TB_TP + m] = (s * stride_words + p) | (pt_const[p] | 1 << (31 - kd)) << 16;     // (+ column 31 of the patch image: constant 1 -> the bias gradient)
     }
     for (int m = 0; m < S * C16_R2; ++m) {
         const int s = m / C16_R2, p = m % C16_R2, iy = p / C16_OW2, ix = p % C16_OW2;
@@ -454,6 +516,7 @@ bool conv_bwd16_supported(const dq_qnet* Q) {
 
 dq_status conv_bwd16_launch(const dq_qnet* Q, ConvBwdArgs& a, int wgs, hipStream_t st) {
     (void)Q;
+    DQ_REQUIRE(a.batch % C16_S == 0 && a.S == C16_S, DQ_ERR_INVALID, "conv_bwd16_launch: whole groups of 8 samples only");
     static unsigned long long attr_devs = 0;
     const unsigned long long dev_bit = dq_device_bit();
     if (!(attr_devs & dev_bit)) {

@@ -1844,7 +1844,7 @@ void fused_patch_tables(const dq_qnet* Q, int depth, int stride_words, int* tab)
         tab[PT_BWD + m] = (s * stride_words + pix) | tab[PT_CONST + pix] << 16;
     }
     conv_wave_lane_table(Q, kd, tab + PT_CONST, tab + PT_WAVE);
-    conv_bwd16_tables(Q, stride_words, tab + PT_CONST, tab + PT_SRC, tab + PT_C16);
+    conv_bwd16_tables(Q, kd, stride_words, tab + PT_CONST, tab + PT_SRC, tab + PT_C16);
 }
 
 struct DensePlan { int ldx, ld2, ld3, off_x, off_h, off_part, off_y2, off_y3, NT2; size_t lds; };

@@ -1990,7 +1990,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     // the 16-wave form (conv_bwd16.hip) where it applies and the minibatch gives every CU work (groups of 8 samples); DQ_CONV_BWD_FORM=8: this file's kernel
     // (A/B runs, tests; read per call)
     const char* form = getenv("DQ_CONV_BWD_FORM");
-    const bool form16 = patch && conv_bwd16_supported(Q) && (B >= 1024 || (form && form[0] == '1')) && !(form && form[0] == '8');      // (=16: whatever the minibatch)
+    const bool form16 = patch && conv_bwd16_supported(Q) && B % 8 == 0 && (B >= 1024 || (form && form[0] == '1')) && !(form && form[0] == '8');      // (=16: whatever the minibatch)
     if (form16) { ca.S = 8; ca.groups = (B + 7) / 8; ca.pk_cdw = (int)PL.cdw; ca.tab16 = Q->ptab + PT_C16; }
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
     if (form16) {

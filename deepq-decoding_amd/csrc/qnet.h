@@ -16,7 +16,7 @@
 #define PT_WAVE (PT_BWD + CONV_ROWTAB)    // [64][PT_WAVE_LD] conv_wave.hip: the per-lane constants of its prologue (conv_wave_lane_table), 16-byte aligned rows
 #define PT_WAVE_LD 20
 #define PT_C16 (PT_WAVE + 64 * PT_WAVE_LD)    // [PT_C16_INTS] conv_bwd16.hip: its LDS-resident tables, ready to be copied as they are (conv_bwd16_tables), 16-byte aligned
-#define PT_C16_INTS 3072
+#define PT_C16_INTS 2560
 #define PT_TOTAL (PT_C16 + PT_C16_INTS)
 
 struct Layer {
@@ -297,7 +297,7 @@ struct ConvWaveArgs {
 bool conv_wave_supported(const dq_qnet* Q);
 dq_status conv_wave_launch(const dq_qnet* Q, ConvWaveArgs& a, int n_cu, hipStream_t st);
 void conv_wave_lane_table(const dq_qnet* Q, int kd, const int* pt_const, int* out);
-void conv_bwd16_tables(const dq_qnet* Q, int stride_words, const int* pt_const, const int* pt_src, int* out);      // out: int[PT_C16_INTS] (qnet.h PT_C16)      // out: int[64 * PT_WAVE_LD] (qnet.h PT_WAVE)
+void conv_bwd16_tables(const dq_qnet* Q, int kd, int stride_words, const int* pt_const, const int* pt_src, int* out);      // out: int[PT_C16_INTS] (qnet.h PT_C16)      // out: int[64 * PT_WAVE_LD] (qnet.h PT_WAVE)
 // qnet.hip: per-layer backward pieces (also used by the fused backward for layers it does not cover)
 dq_status layer_wgrad(dq_qnet* Q, int layer, float* grads_dev, hipStream_t st);
 dq_status layer_dgrad(dq_qnet* Q, const float* params_dev, int layer, hipStream_t st);
