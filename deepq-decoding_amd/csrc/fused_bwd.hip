@@ -1051,6 +1051,7 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     // slower: 7.7 against 6.6 us for the launch)
     const int i = (bx - S.block0) * 64 + threadIdx.x, g = threadIdx.y;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                     // four independent chains: the loop is load-latency-bound
+    // (all 32 loads of the 256-slice case in flight at once -- the loop unrolled -- measured slower: 8.9 against 7.6 us)
     if (i < S.n) {
         int k = g;
         for (; k + 24 < S.slices; k += 32) {
