@@ -184,8 +184,15 @@ class FullLoop:
             # the wave-private form (csrc/conv_wave.hip): whole 16-row tiles per sample -- 2 tiles for conv1's 25 pixels, one for conv2's 16 and for
             # conv3's 9 -- so the ISSUED count includes the padding rows: 2 x 32 x 64 x 32 + 3 x 16 x 32 x 256 + 3 x 16 x 32 x 128 MACs per sample
             conv_fwd = (2.0 * 32 * 64 * 32 + 3.0 * 16 * 32 * 256 + 3.0 * 16 * 32 * 128) / conv
+        conv_bwd = (c1_bwd + 3.0 * rest + 3.0 * rest) / (conv + rest)      # weight gradients + data gradients
+        Bk = self.B
+        if getattr(self.core, "compact", False) and d == 5 and 4 * self.env.volume_depth + self.env.n_action_layers + 6 <= 32 and Bk % 8 == 0 and Bk >= 1024 \
+                and os.environ.get("DQ_CONV_BWD_FORM", "16")[:1] != "8":
+            # the 16-wave form (csrc/conv_bwd16.hip), per sample of a group of 8: g2 16 rows x 128 x 32, g1 26 rows (13 tiles of 16 for 200 pixels) x 128 x 64,
+            # dW3 12 rows (three blocks of 32 for 72) x 128 x 32, dW2 16 x 256 x 32 -- three MFMAs per product -- and dW1 32 rows (eight blocks for 200) x 32 x 64, two
+            conv_bwd = (3.0 * (16 * 128 * 32 + 26 * 128 * 64 + 12 * 128 * 32 + 16 * 256 * 32) + 2.0 * 32 * 32 * 64) / (conv + rest)
         return {"conv_chain_kernel": conv_fwd,
-                "conv_bwd_chain_kernel": (c1_bwd + 3.0 * rest + 3.0 * rest) / (conv + rest),     # weight gradients + data gradients
+                "conv_bwd_chain_kernel": conv_bwd,
                 "dense_chain_kernel": 3.0, "dense_bwd_chain_kernel": 3.0, "dense_wgrad_kernel": 3.0}
 
     def _family_id(self, name):

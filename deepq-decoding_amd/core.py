@@ -93,6 +93,8 @@ class DQNCore:
         # the same result as DQ_ENV_STREAM in round 1 and DQ_DIST_MODE=overlap in round 4).
         self.target_ahead = os.environ.get("DQ_TARGET_AHEAD", "0") == "1"
         self._side = None            # (QNetwork, stream, row event, [events], Q_target(s1) rows [k - 1][B][A])
+        self.pair_targets = os.environ.get("DQ_PAIR_TARGETS", "1") != "0"      # extra updates in pairs (_extra_updates); 0: three forwards per launch pair
+        self._q1_pair = None
         self._rccl, self._rccl2, self._rccl_tried = None, None, False       # the learner's own RCCL communicator (dist.make_rccl), created at the first several-GPU update
         self.L = _lib.lib()
         dev = self.device
@@ -289,9 +291,10 @@ class DQNCore:
                                           self.N, ptr(self.stats), self._stream()))
             self._stats_pending = None
 
-    def update(self, rows=None, target_ready=None):
+    def update(self, rows=None, target_ready=None, target_next=None):
         """One minibatch update (keras-rl DQNAgent.backward's training branch).  rows: its minibatch, already drawn (_extra_updates);
-        target_ready: (Q_target(s1) of those rows, the event behind the side-stream forward that writes it)."""
+        target_ready: (Q_target(s1) of those rows, None or the event behind the forward that writes it): no target job in this update's launch pair;
+        target_next: (rows of the NEXT update, buffer): its Q_target(s1) rides on this update's launch pair as a fourth job."""
         assert self.filled >= MIN_FILLED, "fewer than three complete transitions in the replay ring"
         self._join_env()
         B, N, T = self.batch_size, self.N, self.T
@@ -308,10 +311,15 @@ class DQNCore:
         own, self.index = self.index, rows                          # (every job record and the TD step read self.index)
         own_q1 = self.q1_target
         try:
-            self.net.forward_multi(self._update_jobs(t, sample_base, with_target=target_ready is None))
+            jobs = self._update_jobs(t, sample_base, with_target=target_ready is None)
+            if target_next is not None:
+                jobs.insert(0, self._obs_job(params=self.target, batch=B, index=target_next[0], index_off=N, index_mod=T * N, out=target_next[1],
+                                             packed=self.target_pk))
+            self.net.forward_multi(jobs)
             if target_ready is not None:
                 self.q1_target = target_ready[0]
-                torch.cuda.current_stream(self.device).wait_event(target_ready[1])
+                if target_ready[1] is not None:
+                    torch.cuda.current_stream(self.device).wait_event(target_ready[1])
             self._learn(t)
         finally:
             self.index, self.q1_target = own, own_q1
@@ -332,6 +340,21 @@ class DQNCore:
         _q.replay_sample_multi(self.terminal_ring, self.N, self.T, self.cur, self.filled, B, self.seed, self.updates + 1, k - 1,
                                sample_base=sample_base, out=self._index_multi)
         if not (self.target_ahead and self.net.fused_supported and self.net.fused_enabled):
+            # The target network does not change inside a vector step and the rows of all these updates are known, so Q_target(s1) of update i + 1 needs
+            # nothing update i produces: updates go in PAIRS -- the first one's launch pair carries four forwards (its own three and the second's target
+            # forward), the second one's two.  At c3 the wave-private convolution kernel then runs 2 + 1 whole trips per pair of updates where three
+            # forwards per launch are 1.5 trips timed as 2 each, and the dense kernel fills the chip (256 workgroups) instead of 192.
+            if self.pair_targets and self.net.fused_supported and self.net.fused_enabled:
+                if self._q1_pair is None:
+                    self._q1_pair = torch.empty((B, self.A), dtype=torch.float32, device=self.device)
+                i = 0
+                while i + 1 < k - 1:
+                    self.update(rows=self._index_multi[i], target_next=(self._index_multi[i + 1], self._q1_pair))
+                    self.update(rows=self._index_multi[i + 1], target_ready=(self._q1_pair, None))
+                    i += 2
+                if i < k - 1:
+                    self.update(rows=self._index_multi[i])
+                return
             for i in range(k - 1):
                 self.update(rows=self._index_multi[i])
             return

@@ -196,31 +196,33 @@ def test_device_loop_with_three_updates_per_vector_step(dq, torch_mod):
 
 
 @pytest.mark.gpu
-def test_target_forwards_on_the_side_stream_change_no_bit(dq, torch_mod):
-    """DQNCore.target_ahead (the extra updates' Q_target(s1) evaluated on a second stream through a second network handle, one event per
-    update) against the one-stream order: the same parameters, optimizer state and last minibatch, bit for bit, at the headline's per-GPU
-    shape in small (256 lattices, minibatch 256, five updates per vector step, a hard target copy in between)."""
+def test_extra_updates_in_pairs_and_on_the_side_stream_change_no_bit(dq, torch_mod):
+    """The extra updates of a vector step in their three orders -- three forwards per launch pair (the plain order), in PAIRS (DQNCore.pair_targets, the
+    default: the second update's target forward rides on the first one's launch pair), and with the target forwards on a second stream
+    (DQNCore.target_ahead: a second network handle, one event per update) --: the same parameters, optimizer state and last minibatch, bit for bit, at the
+    headline's per-GPU shape in small (256 lattices, minibatch 256, five and four updates per vector step, a hard target copy in between)."""
     torch = torch_mod
     seed = (0xA11CE, 0xB0B)
     out = []
-    for ahead in (True, False):
+    for pairs, ahead in ((False, False), (True, False), (False, True)):
         env = dq.VectorEnv(n_envs=256, seed=seed, **C3)
         net = dq.QNetwork(env.obs_shape, C_LAYERS, FF_LAYERS, env.num_actions, max_batch=256)
         core = dq.DQNCore(env, net, batch_size=256, memory_limit=256 * 16, lr=1e-3, seed=seed)
-        core.target_ahead = ahead
+        core.pair_targets, core.target_ahead = pairs, ahead
         core.reset_env()
         for _ in range(4):
             core.act_and_step(1.0)
         for t in range(6):
-            core.step_and_update(0.3, extra_updates=4)
+            core.step_and_update(0.3, extra_updates=4 if t & 1 else 3)      # (three extra updates beyond the first: a pair and a single)
             if t == 2:
                 core.update_target_hard()
         torch.cuda.synchronize()
-        assert (core._side is not None) == ahead
+        assert (core._side is not None) == ahead and (core._q1_pair is not None) == pairs
         out.append([x.cpu().numpy().copy() for x in (core.params, core.m, core.v, core.last_index)] + [core.read_metrics(), core.updates])
-    for a, b in zip(out[0][:4], out[1][:4]):
-        assert np.array_equal(a, b)
-    assert out[0][4] == out[1][4] and out[0][5] == out[1][5] == 30
+    for other in out[1:]:
+        for a, b in zip(out[0][:4], other[:4]):
+            assert np.array_equal(a, b)
+        assert out[0][4] == other[4] and out[0][5] == other[5] == 27
 
 
 class _PyVecEnv:

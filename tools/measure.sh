@@ -24,6 +24,10 @@ python bench.py --minibatch 32 --updates-per-step 4096 --steps 4 --warmup 1 --no
 # the round-4 forward (one workgroup per group of samples, weights streamed from L2) beside the wave-private one (csrc/conv_wave.hip), same box
 DQ_CONV_FORM=group python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_groupform.json"
 DQ_CONV_FORM=group python bench.py --updates-per-step 32 --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_ratio32_groupform.json"
+# the 8-wave convolutional backward (csrc/fused_bwd.hip conv_bwd_chain_kernel) beside the 16-wave one (csrc/conv_bwd16.hip), same box; both round-4 forms together
+DQ_CONV_BWD_FORM=8 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_bwd8form.json"
+DQ_CONV_BWD_FORM=8 DQ_CONV_FORM=group python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_round4forms.json"
+DQ_PAIR_TARGETS=0 python bench.py --updates-per-step 32 --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_ratio32_unpaired.json"
 # the uint8 ring beside the patch-word ring (DQNCore.compact), same box
 DQ_COMPACT_OBS=0 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_uint8ring.json"
 DQ_COMPACT_OBS=0 python bench.py --config c5 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c5_loop_uint8ring.json"
