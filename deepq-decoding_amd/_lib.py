@@ -128,6 +128,7 @@ SIGNATURES = {
                                 ctypes.POINTER(ctypes.c_int32 * 4), ctypes.POINTER(ctypes.c_int32)]),
     "dq_qnet_set_fused": (_i, [_vp, _i]),
     "dq_qnet_set_grad_scale": (_i, [_vp, _dbl]),
+    "dq_struct_size": (ctypes.c_long, [_i]),
     "dq_qnet_mark_conv_backward": (_i, [_vp, _vp]),
     "dq_qnet_range_check": (_i, [_vp, _vp]),
     "dq_qnet_fused_supported": (_i, [_vp]),

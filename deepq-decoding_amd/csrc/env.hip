@@ -297,6 +297,18 @@ extern "C" {
 
 int dq_version(void) { return 1; }
 const char* dq_last_error(void) { return g_err; }
+long dq_struct_size(int id) {
+    switch (id) {
+        case 0: return (long)sizeof(dq_env_cfg);
+        case 1: return (long)sizeof(dq_env_info);
+        case 2: return (long)sizeof(dq_sample_job);
+        case 3: return (long)sizeof(dq_qnet_cfg);
+        case 4: return (long)sizeof(dq_qnet_job);
+        case 5: return (long)sizeof(dq_td_job);
+        case 6: return (long)sizeof(dq_env_step_job);
+        default: return -1;
+    }
+}
 int dq_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -63,6 +63,10 @@ enum { DQ_STREAM_ENV = 0, DQ_STREAM_POLICY = 1, DQ_STREAM_REPLAY = 2, DQ_STREAM_
 
 int dq_version(void);
 const char* dq_last_error(void);
+/* sizeof() of the public structs as THIS library was compiled: 0 dq_env_cfg, 1 dq_env_info, 2 dq_sample_job, 3 dq_qnet_cfg, 4 dq_qnet_job, 5 dq_td_job,
+ * 6 dq_env_step_job; -1 for any other id.  A binding (the ctypes structures of _lib.py) checks its own layouts against it: a struct of the wrong size handed
+ * across the boundary is silent memory corruption (tests/test_abi.py).  No reference counterpart. */
+long dq_struct_size(int id);
 /* Number of visible HIP devices (0 if none / runtime unavailable).  Never fails. */
 int dq_device_count(void);
 

@@ -60,3 +60,14 @@ def test_header_is_plain_c(built_lib, tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "deepq_hip.h"\nint main(void){ dq_env_cfg c; (void)c; return dq_version() < 0; }\n')
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
+
+
+def test_struct_layouts_match_the_library(dq):
+    """Every ctypes structure of the binding has the size the library was compiled with (include/deepq_hip.h dq_struct_size): a by-value or by-pointer
+    struct of the wrong size is silent corruption -- the class of bug round 4 found in the ncclUniqueId of dist.py."""
+    import importlib
+    L = importlib.import_module("deepq-decoding_amd._lib")
+    lib = L.lib()
+    for i, st in enumerate((L.EnvCfg, L.EnvInfo, L.SampleJob, L.QNetCfg, L.QNetJob, L.TdJob, L.EnvStepJob)):
+        assert lib.dq_struct_size(i) == ctypes.sizeof(st), (i, st.__name__, lib.dq_struct_size(i), ctypes.sizeof(st))
+    assert lib.dq_struct_size(99) == -1
