@@ -834,7 +834,7 @@ __device__ __forceinline__ void dense_wgrad_body(const DenseWgradArgs& a, const 
         }
     };
     // ---- operands: row-major piece planes in LDS -> MFMA operand order by transposing reads (lds_tr8: this lane points at row ri, column
-    //      segment cseg of each four-row read; lane group kb supplies rows 4kb + (e & 3) + 16 (e >> 2) of a 32-row block) ------------------
+    //      segment cseg of each four-row read; lane group kb supplies rows (kb >> 1) + 8 (kb & 1) + 2 (e & 3) + 16 (e >> 2) of a 32-row block) ------------------
     const int ri = j >> 2, cseg = 4 * (j & 3);
     f32x4 acc[2][2], accx[2][2], accb[2], accbx[2];                 // [k tile][n tile]: leading products / 2^11-scaled cross terms; bias tiles
 #pragma unroll
@@ -849,7 +849,9 @@ __device__ __forceinline__ void dense_wgrad_body(const DenseWgradArgs& a, const 
         const bool tail = m0 + WG_ROWS * it + WG_ROWS > m1;         // wave-uniform: only the slice's last iteration masks rows
 #pragma unroll
         for (int blk = 0; blk < WG_ROWS / 32; ++blk) {
-            const int r0 = (32 * blk + 4 * kb + ri) * WG_PS, r1 = r0 + 16 * WG_PS;
+            // (rows of a block dealt so that the eight rows a 32-lane group of a transposing read touches have ONE parity: rows 144 bytes apart, eight same-parity
+            // rows put their 32-byte windows on disjoint quarters of the banks -- conv_bwd16.hip; eight consecutive rows overlapped pairwise)
+            const int r0 = (32 * blk + (kb >> 1) + 8 * (kb & 1) + 2 * ri) * WG_PS, r1 = r0 + 16 * WG_PS;
             F16x2 xa[2], gb[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -860,9 +862,9 @@ __device__ __forceinline__ void dense_wgrad_body(const DenseWgradArgs& a, const 
             if (tail) {                                             // rows of G past the slice: their halves cleared (element e = half e of the operand)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const int rb = m0 + WG_ROWS * it + 32 * blk + 4 * kb;
-                    const u32 lo = rb + ((2 * d) & 3) + 16 * ((2 * d) >> 2) < m1 ? 0xffffu : 0u;
-                    const u32 hi = rb + ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < m1 ? 0xffff0000u : 0u;
+                    const int rb = m0 + WG_ROWS * it + 32 * blk + (kb >> 1) + 8 * (kb & 1);
+                    const u32 lo = rb + 2 * ((2 * d) & 3) + 16 * ((2 * d) >> 2) < m1 ? 0xffffu : 0u;
+                    const u32 hi = rb + 2 * ((2 * d + 1) & 3) + 16 * ((2 * d + 1) >> 2) < m1 ? 0xffff0000u : 0u;
 #pragma unroll
                     for (int t = 0; t < 2; ++t) { gb[t].h[d] &= lo | hi; gb[t].l[d] &= lo | hi; }
                 }
