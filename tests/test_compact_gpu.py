@@ -239,6 +239,34 @@ def test_training_forward_backward_from_patch_words(dq, torch_mod, name, batch):
             assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-7
 
 
+@pytest.mark.parametrize("name,batch", [("c3", 264), ("c3", 2048), ("c2", 1032), ("c3y", 1024)])
+def test_sixteen_wave_conv_backward(dq, torch_mod, monkeypatch, name, batch):
+    """csrc/conv_bwd16.hip (patch words at d = 5, minibatches that are multiples of 8; the default from 1024 samples) against the float64 oracle at the
+    bounds of the test above, against csrc/fused_bwd.hip's 8-wave kernel on the same saved activations (DQ_CONV_BWD_FORM=8) to round-off, and run to run
+    (bit-identical: fixed-order sums)."""
+    torch = torch_mod
+    spec, net, params, flat, obs, patch, rng = _setup(dq, torch, name, batch)
+    seed, t, base = (5, 6), 424242, 11
+    keep = O.dropout_keep_mask(seed, t, base + np.arange(batch), 512, 0.2)
+    dq_ = (rng.randn(batch, spec.n_actions) / batch).astype(np.float32)
+    g = {}
+    for form in ("16", "8"):
+        monkeypatch.setenv("DQ_CONV_BWD_FORM", form)
+        net.forward_multi([dict(params=params, obs=patch, patch=True, training=True, seed=seed, t=t, sample_base=base)])
+        g[form] = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
+        assert np.array_equal(g[form], net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy())
+    _, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
+    g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
+    assert np.abs(g["16"] - g_ref).max() < 2e-5 * max(np.abs(g_ref).max(), 1.0)
+    for (gk, gb), (rk, rb), (ok, ob) in zip(spec.split(g["16"]), spec.split(g_ref), spec.split(g["8"])):
+        for a, b, c in ((gk, rk, ok), (gb, rb, ob)):
+            assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-7
+            assert np.abs(a - c).max() <= 1e-5 * np.abs(c).max() + 1e-8
+    # rows of the first kernel no observation can excite are exactly 0 in both
+    k16, k8 = spec.split(g["16"])[0][0].reshape(-1, 64), spec.split(g["8"])[0][0].reshape(-1, 64)
+    assert np.array_equal(np.abs(k16).max(axis=1) == 0, np.abs(k8).max(axis=1) == 0)
+
+
 @pytest.mark.parametrize("cfg,n,batch", [(dict(d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011), 512, 512),
                                          (dict(d=7, error_model="DP", use_Y=False, volume_depth=7, p_phys=0.005, p_meas=0.005), 128, 128),
                                          (dict(d=3, error_model="X", use_Y=False, volume_depth=3, p_phys=0.005, p_meas=0.005), 1, 32)])
