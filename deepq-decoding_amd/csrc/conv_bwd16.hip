@@ -6,17 +6,23 @@
 //                           group: 256 KB per group through the CU's 64 B/clk vector-memory path), a wave owns 2 x 2 tiles of dW2 and row tiles of
 //                           2 column tiles in g2 / g1 (13 tiles on 4 waves: 4, 3, 3, 3 -- and the two 4-tile waves share a SIMD).  Counters: MFMA busy 17 %,
 //                           VALU + MFMA issue 28 K and LDS 24 K of the kernel's 66 K cycles per SIMD / CU, 47 % of the wave cycles parked.
-//   conv_bwd16_kernel       16 waves x <= 128 VGPRs.  The data gradients' weights (qnet.h cdw: 48 KB, channel-tile order) are copied into LDS once per
-//                           workgroup and a wave fetches the four blocks of ITS channel tile from there at the top of a phase.  The data gradients run
-//                           TRANSPOSED (first operand = weights, rows = 16 input channels; second = the gradient rows of 16 pixels): a lane then holds four
-//                           consecutive channels of ONE pixel -- mask and result are one 8-byte LDS access per piece (they were four 4-byte ones) -- and a
-//                           unit of work is (row tile, channel tile): 16 units in g2 (one per wave), 52 in g1 (4, 3, 3, 3 per wave quadruple, 12 MFMAs each).
-//                           dW3 / dW2 are split by tile (a wave owns one 16 x 16 tile of dW3 and one 16 x 32 strip of dW2: 24 accumulator registers instead of
-//                           48), dW1 by tile and row-block parity (the two halves meet in LDS at the end).  a1 is single-buffered (its rows padded to 144
-//                           bytes: the 8-byte mask / result accesses of 16 consecutive pixels then fall into distinct banks) and requested right behind the
-//                           barrier that retires the previous group's dW1 -- it is first needed three phases later.
+//   conv_bwd16_kernel       16 waves x <= 128 VGPRs (111).  The data gradients' weights (qnet.h cdw: 48 KB, channel-tile order) are copied into LDS once per
+//                           workgroup.  The data gradients run TRANSPOSED (first operand = weights, rows = 16 input channels; second = the gradient rows of
+//                           16 pixels): a lane then holds four consecutive channels of ONE pixel -- mask and result are one 8-byte LDS access per piece
+//                           (they were four 4-byte ones).  g2: 16 units (row tile, channel tile), one per wave, its four weight blocks fetched at the top
+//                           of the phase.  g1: by ROW TILE -- the four taps' gradient rows (the reads that can conflict) are read once per pass and held,
+//                           the weights stream from the LDS copy (lane-ordered blocks: conflict-free), two channel tiles at a time; the thirteenth row
+//                           tile (8 of 16 rows) is split over four waves so that every SIMD carries the same MFMAs.  dW3 / dW2 are split by tile (a wave
+//                           owns one 16 x 16 tile of dW3 and one 16 x 32 strip of dW2: 24 accumulator registers instead of 48), dW1 by tile and row-block
+//                           parity (the two halves meet in LDS at the end; the first bias gradient is row 31 of dW1: an all-ones patch column).  The rows
+//                           of a K block are dealt so that a transposing read touches eight rows of ONE parity: conflict-free G operands (mask_rows).
+//                           a1 is single-buffered (its rows padded to 144 bytes: the 8-byte mask / result accesses of 16 consecutive pixels then fall into
+//                           distinct banks) and requested behind the group's first barrier -- it is first needed two phases later.  Every LDS address that
+//                           depends on a row number comes out of host-built tables (conv_bwd16_tables) copied by LDS-DMA with everything else.
+//                           Whole groups only (minibatch a multiple of 8): the row counts are compile-time and every loop unrolls.
 //
-// LDS (153.6 KB): [cdw 48 KB | a1 / g1 planes 58 KB | a2 / g2 planes 20.2 KB | g3 planes 11.4 KB | patch image 6.25 KB | observations 1 KB | tables].
+// LDS (157.8 KB): [cdw 48 KB | a1 / g1 planes 58 KB | a2 / g2 planes 20.2 KB | g3 planes 11.4 KB | patch image 7.8 KB | observations 1 KB | tables 10 KB].
+// Steps, counters and what was tried and lost: NOTEBOOK.md Round 5 section 3.
 #include <type_traits>
 #include "conv_bwd.h"
 
