@@ -35,7 +35,7 @@ rm -rf "$out/prof"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -- python "$root/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$root/$out/prof.log" 2>&1)
 python tools/rocprof_summary.py $(ls $out/prof/*/*.db | head -1) "$out/loop_c3_kernel_stats.csv"
 # per (kernel, grid): the step's launches apart from the set-up's (ring fill, resets) of the same kernels
-python tools/rocprof_shapes.py $(ls $out/prof/*/*.db | head -1) > "$out/loop_c3_kernel_shapes.txt"
+python tools/rocprof_shapes.py $(ls $out/prof/*/*.db | head -1) 500 > "$out/loop_c3_kernel_shapes.txt"
 rm -rf "$out/prof"
 head -12 "$out/loop_c3_kernel_stats.csv" | cut -c1-120
 for f in $out/bench_*.json; do python - "$f" <<'PY'
