@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--minibatch", type=int, default=0, help="DQN minibatch per rank (default: n_envs)")
     ap.add_argument("--lattices", type=int, default=0, help="lattices per rank (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ratio-steps", type=int, default=100,
+                    help="vector steps of the second timed leg at the reference's replay ratio (32 trained samples per environment step), run behind the "
+                         "headline region of a default 1-GPU loop run and printed as `reference_replay_ratio`; 0 = skip it")
     ap.add_argument("--updates-per-step", type=int, default=1,
                     help="minibatch updates per vector step (loop mode).  The reference trains 32 samples per environment step "
                          "(one 32-sample update per step, Single_Point_Training_Script.py:119-127): --updates-per-step 32 at the default "
@@ -370,6 +373,9 @@ def main():
                                     f"{n_local} lattices/GPU, mode={mode}", **runner.config()),
         }
         out.update(runner.report(args.steps, dt, world))
+        if world == 1 and mode == "loop" and args.updates_per_step == 1 and args.ratio_steps > 0 and hasattr(runner, "reference_ratio_leg"):
+            # the driver's line carries the whole claim: the same loop at the reference's training intensity (k = 32 n / B updates per vector step)
+            out["reference_replay_ratio"] = runner.reference_ratio_leg(steps=args.ratio_steps, warmup=max(2, args.ratio_steps // 10))
         if params_checksum is not None:
             out["params_checksum"] = params_checksum
         if world > 1 or force_dist:

@@ -127,10 +127,12 @@ SIGNATURES = {
     "dq_qnet_layer_info": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                 ctypes.POINTER(ctypes.c_int32 * 4), ctypes.POINTER(ctypes.c_int32)]),
     "dq_qnet_set_fused": (_i, [_vp, _i]),
+    "dq_qnet_set_kernel_forms": (_i, [_vp, _i, _i, _i]),
     "dq_qnet_set_grad_scale": (_i, [_vp, _dbl]),
     "dq_struct_size": (ctypes.c_long, [_i]),
     "dq_qnet_mark_conv_backward": (_i, [_vp, _vp]),
     "dq_qnet_range_check": (_i, [_vp, _vp]),
+    "dq_qnet_range_discarded": (_i, [_vp, ctypes.POINTER(ctypes.c_uint), _vp]),
     "dq_qnet_fused_supported": (_i, [_vp]),
     "dq_qnet_set_patch_input": (_i, [_vp, _i, _i]),
     "dq_qnet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _seedp, _u64, _u32, _vp, _vp]),
@@ -160,9 +162,11 @@ SIGNATURES = {
     "dq_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _dbl, _dbl, _u64, _vp]),
     "dq_prof_kernel_count": (_i, []),
     "dq_prof_kernel_name": (ctypes.c_char_p, [_i]),
+    "dq_prof_kernel_symbol": (ctypes.c_char_p, [_i]),
     "dq_prof_arm": (_i, [_i, _i]),
     "dq_prof_stride": (_i, [_i]),
     "dq_prof_collect": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_dbl)]),
+    "dq_prof_collect_spread": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_dbl), ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
 }
 
 _lib = None

@@ -19,47 +19,54 @@ MFMA_F16_PEAK_TFLOPS = 2500.0        # dense f16 / bf16 (MI355X_MICROARCH.md); t
 HBM_PEAK_GBS = 8000.0
 
 
+def _code_only(text):
+    """A C / HIP source with comments and all whitespace removed: what the compiler sees, up to token spacing."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def csrc_digest():
-    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/deepq_hip.h): stamps a PMC pass with the code it measured."""
+    """sha256 over the CODE of the kernel sources (csrc/*.hip, csrc/*.h, include/deepq_hip.h; comments and whitespace stripped, so
+    that editing a comment does not orphan a measurement): stamps a PMC pass with the code it measured."""
     import glob
     import hashlib
-    import os
     here = os.path.dirname(os.path.abspath(__file__))
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h"))) + \
             [os.path.join(here, "..", "include", "deepq_hip.h")]:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()
 
 
-def pmc_traffic(kernel, mode="loop", config="c3", minibatch=0, updates_per_step=1, lattices=0):
-    """HBM bytes per launch of `kernel` from the committed PMC pass profiles/pmc_traffic_<mode>_<config>.json (tools/pmc_traffic.sh:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied).  PMC counters cannot be collected
-    inside a timed run, so this is a recorded value -- valid only for the kernel sources it was taken with AND for the launch shape it was
-    taken at: the file carries the sources' sha256 (csrc_digest) and the pass's minibatch / updates per step / lattices (0 = the
-    configuration's default); anything else (stale pass, another shape, missing file, unknown kernel) gives None."""
+def pmc_record(mode="loop", config="c3"):
+    """The committed PMC pass of (mode, config) as a dict, or None when the file is missing / unreadable."""
     import json
-    import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"pmc_traffic_{mode}_{config}.json")
     try:
         with open(path) as f:
-            rec = json.load(f)
-        if rec.get("csrc_sha256") != csrc_digest():
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def pmc_traffic(symbol, mode="loop", config="c3", minibatch=0, updates_per_step=1, lattices=0):
+    """HBM bytes per launch of the kernel SYMBOL that ran (dq_prof_kernel_symbol: `conv_wave_kernel`, not its family alias) from the committed PMC pass
+    profiles/pmc_traffic_<mode>_<config>.json (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction
+    applied).  PMC counters cannot be collected inside a timed run, so this is a recorded value -- valid only for the kernel code it was taken with AND
+    for the launch shape it was taken at: the file carries the sources' code digest (csrc_digest) and the pass's minibatch / updates per step /
+    lattices (0 = the configuration's default); anything else (stale pass, another shape, another form of the family, missing file) gives None."""
+    rec = pmc_record(mode, config)
+    try:
+        if rec is None or rec.get("csrc_sha256") != csrc_digest():
             return None
         shape = rec.get("shape", {"minibatch": 0, "updates_per_step": 1, "lattices": 0})
         if (int(shape.get("minibatch", 0)), int(shape.get("updates_per_step", 1)), int(shape.get("lattices", 0))) != (int(minibatch), int(updates_per_step), int(lattices)):
             return None
-        ks = rec["kernels"]
-        # the conv forward family's step launch is conv_wave_kernel (patch words, d = 5), else the persistent conv_chain_pkernel, else conv_chain_kernel
-        # ... the conv backward family's is conv_bwd16_kernel (the same conditions, minibatch >= 1024), else conv_bwd_chain_kernel
-        names = ("conv_wave_kernel", "conv_chain_pkernel", "conv_chain_kernel") if kernel == "conv_chain_kernel" else \
-                ("conv_bwd16_kernel", "conv_bwd_chain_kernel") if kernel == "conv_bwd_chain_kernel" else (kernel,)
-        for name in names:
-            if name in ks:
-                return ks[name]["hbm_bytes_per_launch_corrected"]
-        return None
-    except (OSError, KeyError, ValueError):
+        return rec["kernels"][symbol]["hbm_bytes_per_launch_corrected"]
+    except (KeyError, ValueError, TypeError):
         return None
 
 
@@ -191,6 +198,9 @@ class FullLoop:
             # the 16-wave form (csrc/conv_bwd16.hip), per sample of a group of 8: g2 16 rows x 128 x 32, g1 26 rows (13 tiles of 16 for 200 pixels) x 128 x 64,
             # dW3 12 rows (three blocks of 32 for 72) x 128 x 32, dW2 16 x 256 x 32 -- three MFMAs per product -- and dW1 32 rows (eight blocks for 200) x 32 x 64, two
             conv_bwd = (3.0 * (16 * 128 * 32 + 26 * 128 * 64 + 12 * 128 * 32 + 16 * 256 * 32) + 2.0 * 32 * 32 * 64) / (conv + rest)
+            if os.environ.get("DQ_CONV_FORM", "w")[:1] != "g" and os.environ.get("DQ_CONV_BWD_A1", "r")[:1] != "s":
+                # round 6: a1 recomputed from the patch words (26 rows per sample x K 32 x 64 channels, one MFMA per weight piece) instead of read back from HBM
+                conv_bwd += 2.0 * 26 * 32 * 64 / (conv + rest)
         return {"conv_chain_kernel": conv_fwd,
                 "conv_bwd_chain_kernel": conv_bwd,
                 "dense_chain_kernel": 3.0, "dense_bwd_chain_kernel": 3.0, "dense_wgrad_kernel": 3.0}
@@ -202,9 +212,33 @@ class FullLoop:
         raise KeyError(name)
 
     def _collect(self):
-        n, ms = ctypes.c_int(), ctypes.c_double()
-        _lib.check(self.L.dq_prof_collect(ctypes.byref(n), ctypes.byref(ms)))
+        n, ms, lo, hi = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(self.L.dq_prof_collect_spread(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(lo), ctypes.byref(hi)))
+        self.last_spread_ms = (lo.value, hi.value)
         return n.value, ms.value
+
+    def reference_ratio_leg(self, steps=100, warmup=10):
+        """A second timed region at the REFERENCE's replay ratio -- 32 trained samples per environment step (keras-rl train_interval = 1, batch_size = 32:
+        TRAIN:119-127), i.e. k = 32 n / B minibatch updates of B per vector step of n lattices -- on the same loop, ring and parameters: `warmup` untimed
+        vector steps, then `steps` timed ones between two device synchronisations.  One GPU only (bench.py runs it behind the headline region)."""
+        import time
+        k_old, self.k = self.k, max(1, 32 * self.n // self.B)
+        try:
+            for _ in range(warmup):
+                self.step(timed=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(timed=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            k = self.k
+        finally:
+            self.k = k_old
+        return dict(value=self.n * steps / dt, unit="env_steps/s", ms_per_step=1e3 * dt / steps, steps=steps, warmup=warmup, updates_per_vector_step=k,
+                    minibatch=self.B, samples_trained_per_env_step=k * self.B / self.n, updates_per_s=k * steps / dt, dqn_samples_per_s=k * steps * self.B / dt,
+                    us_per_update=1e6 * dt / (steps * k),
+                    reference="one 32-sample minibatch per environment step: cluster_scripts/d5_dp/0.001/Single_Point_Training_Script.py:119-127")
 
     def pick_dominant(self, probe_steps=4):
         """Times every family over a few untimed steps and arms the one with the largest total duration."""
@@ -276,8 +310,11 @@ class FullLoop:
                 # the peak is that of the pipe the kernel runs on: f32-class products cost `issued` f16 MFMA flops each, so the f16
                 # pipe's dense peak divided by that (frac = issued f16 flops / f16 peak); the f32-input MFMA peak is quoted beside it
                 peak = MFMA_F16_PEAK_TFLOPS / issued if issued else MFMA_F32_PEAK_TFLOPS
-                roof = dict(kernel=self.prof_family, bound=bound, achieved=achieved, peak=peak, unit="TFLOP/s",
-                            frac=achieved / peak, traffic=pmc_traffic(self.prof_family, self.mode, self.config_name, self.pmc_minibatch, self.k, self.pmc_lattices), avg_launch_us=avg_s * 1e6,
+                # the symbol the family's launches used (conv_chain_kernel is a family: conv_wave_kernel / conv_chain_pkernel / conv_chain_kernel)
+                symbol = self.L.dq_prof_kernel_symbol(self._family_id(self.prof_family)).decode() or self.prof_family
+                roof = dict(kernel=symbol, family=self.prof_family, bound=bound, achieved=achieved, peak=peak, unit="TFLOP/s",
+                            frac=achieved / peak, traffic=pmc_traffic(symbol, self.mode, self.config_name, self.pmc_minibatch, self.k, self.pmc_lattices), avg_launch_us=avg_s * 1e6,
+                            min_launch_us=self.last_spread_ms[0] * 1e3, max_launch_us=self.last_spread_ms[1] * 1e3,
                             launches_timed=launches, algorithmic_flops_per_launch=per_launch)
                 if issued:
                     roof["pipe"] = dict(name="f16 MFMA (v_mfma_f32_16x16x32_f16)", peak=MFMA_F16_PEAK_TFLOPS, issued_tflops=achieved * issued,

@@ -165,6 +165,8 @@ class DQNCore:
         # read_metrics() at the next synchronisation switches this on for good, with a warning (DQ_TD_AUTOSCALE=0: raises DQ_ERR_RANGE instead):
         # nothing is ever partially applied)
         self.auto_scale = os.environ.get("DQ_TD_AUTOSCALE", "0") == "1"
+        self.discarded_updates = 0   # optimizer steps the range guard discarded whole in this run (read_metrics; the reference would have applied them)
+        self._range_ok_at = 0        # self.updates at the last synchronisation that found the range flag clear
         self.local_stats = [0, 0, 0, 0]
         self.inexact_total = 0
         self._inexact_acc = torch.zeros((), dtype=torch.int64, device=dev) if getattr(env, "wide", False) else None
@@ -633,16 +635,22 @@ class DQNCore:
         try:
             self.net.check_range()   # (already synchronised) a gradient beyond the fused backward's range is never silent ...
         except _lib.DeepQError as e:
-            # ... and with the default settings it is not fatal either: the updates that met it were discarded WHOLE on every rank (nothing partially
-            # applied), and from here on the gradient scale is MEASURED per minibatch (dq_td_job.auto_scale, +3 us per update), which carries any finite
-            # TD error -- keras-rl's delta_clip = inf without a user switch.  Sticky.  DQ_TD_AUTOSCALE=0 keeps the host-known scale and raises.
+            # ... and with the default settings it is not fatal either: an update whose TD step met such a sample was discarded WHOLE on every rank (no
+            # parameter moved; `updates` and Adam's t advanced past it -- the reference, fp32 with delta_clip = inf, would have applied it: the count is
+            # kept in self.discarded_updates and logged), and from here on the gradient scale is MEASURED per minibatch (dq_td_job.auto_scale, +3 us per
+            # update), which carries any finite TD error.  Sticky.  DQ_TD_AUTOSCALE=0 keeps the host-known scale and raises; DQ_TD_AUTOSCALE=1 measures
+            # from the first update (nothing is ever discarded).
+            n_lost = self.net.range_discarded()
+            self.discarded_updates += n_lost
             if e.status != -6 or self.auto_scale or os.environ.get("DQ_TD_AUTOSCALE") is not None:
                 raise
             self.auto_scale = True
             self.range_switches = getattr(self, "range_switches", 0) + 1
             import warnings
-            warnings.warn("a TD error beyond the fused backward's host-known gradient scale: the updates since the last synchronisation that met it were "
-                          "discarded (whole, on every rank); the loop now measures the gradient scale per minibatch (DQNCore.auto_scale = True)")
+            warnings.warn(f"a TD error beyond the fused backward's host-known gradient scale: {n_lost} of the {self.updates - self._range_ok_at} updates since "
+                          f"the last synchronisation were discarded (whole, on every rank; {self.discarded_updates} in this run: the reference would have applied "
+                          "them); the loop now measures the gradient scale per minibatch (DQNCore.auto_scale = True) -- set DQ_TD_AUTOSCALE=1 to start that way")
+        self._range_ok_at = self.updates
         return float(m[0]), float(m[1])
 
     def repack(self):
@@ -675,13 +683,28 @@ class DQNCore:
         that did its rendezvous is destroyed; a later several-GPU update would create a new one.  abort: the caller is leaving through an exception
         (DQNAgent.fit's finally): ncclCommAbort instead of ncclCommDestroy, which could wait for peers inside a collective this rank never joins."""
         if self._rccl is not None:
-            try:
-                torch.cuda.synchronize(self.device)
-            finally:
-                if self._rccl2 is not None:
-                    self._rccl2.close(abort=abort)
-                self._rccl.close(abort=abort)
-                self._rccl = None
+            if abort:
+                # the abort path exists for a collective this rank has queued and its peers will never join: a device synchronisation IN FRONT of
+                # ncclCommAbort would wait for exactly that collective, for ever.  Abort first; then drain what is left, and never let a (sticky) HIP
+                # error raised by that drain replace the exception that is unwinding through fit()
+                try:
+                    if self._rccl2 is not None:
+                        self._rccl2.close(abort=True)
+                    self._rccl.close(abort=True)
+                finally:
+                    self._rccl = self._rccl2 = None
+                    try:
+                        torch.cuda.synchronize(self.device)
+                    except Exception:
+                        pass
+            else:
+                try:
+                    torch.cuda.synchronize(self.device)
+                finally:
+                    if self._rccl2 is not None:
+                        self._rccl2.close(abort=False)
+                    self._rccl.close(abort=False)
+                    self._rccl = None
         self._rccl, self._rccl2, self._rccl_tried = None, None, False
 
     def close(self):

@@ -52,11 +52,13 @@ void dq_prof_end(int kernel_id, hipStream_t st);
 // recorded in front of and one behind the launch also measure the two marker packets, ~3.5 us on a 42 us kernel).
 int dq_prof_pair(int kernel_id, hipEvent_t* start, hipEvent_t* stop);      // 1: this launch is timed -> its pair (counted); 2: DQ_PROF_BRACKET=1, the bracketing
                                                                             // form for comparison; 0: an ordinary launch
+void dq_prof_note_symbol(int kernel_id, const char* symbol);                // the kernel symbol a family's last launch used (dq_prof_kernel_symbol)
 #ifdef __HIPCC__
 #include <hip/hip_ext.h>
 template <typename K, typename... A>
-static inline void dq_launch(int kernel_id, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+static inline void dq_launch(int kernel_id, const char* symbol, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
     hipEvent_t e0, e1;
+    dq_prof_note_symbol(kernel_id, symbol);
     const int how = dq_prof_pair(kernel_id, &e0, &e1);
     if (how == 1) hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, args...);
     else {

@@ -33,6 +33,8 @@ struct ConvBwdArgs {
     const int* srctab;                  // qnet.h PT_SRC: Keras row of the first kernel -> column of the patch image, -1: gradient 0
     const int* tab16;                   // conv_bwd16.hip: its table blob (qnet.h PT_C16), device
     int pk_cdw;                         // conv_bwd16.hip: u32x4 offset of the packed data-gradient weights in channel-tile order (qnet.h cdw)
+    int pk_c1w;                         // conv_bwd16.hip, a1 recomputed: u32x4 offset of the first kernel's quarters with the per-pixel bias folded in (qnet.h c1w)
+    int a1_recompute;                   // conv_bwd16.hip: the training forward (conv_wave_kernel) did not save a1: recompute it from the patch words, the forward's own bits
     int kd, off_lut;                    // data bits per pixel; LDS: byte -> its eight bits as bytes 0 / 1 (256 x 8 bytes), built by the workgroup
 };
 

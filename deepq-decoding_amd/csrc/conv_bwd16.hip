@@ -75,6 +75,12 @@ extern "C" void dq_dbg_read_c16(unsigned long long* out) { (void)hipMemcpyFromSy
 #define C16_STAMP(i) do { } while (0)
 #endif
 
+// RC (round 6): the training forward (conv_wave_kernel) did not save a1; this kernel recomputes it from the patch image it builds anyway (dW1's operand) with the
+// forward's own instructions -- first operand = the c1w quarter (per-pixel bias folded into the K = 32 block), second = the pixel's 32 bits as f16 0 / 1, one MFMA per
+// weight piece, f16x2_sum, ReLU, split -- so the a1 pieces, the ReLU masks and every gradient are bit-identical to the saved-plane form's, while the forward writes
+// 26 MB less (c3, 4096 samples) and this kernel fetches 26 MB less: its largest start-up copy (58 of the first group's 150 KB) is gone.  52 units (13 row tiles x 4
+// quarters) of 2 MFMAs per group over the 16 waves, in the g2 phase (a1 is first read two barriers later).
+template <bool RC>
 __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const u8* s_wb = smem + C16_OFF_W;                                              // cdw blocks: 2048 bytes each (h pieces, then l)
@@ -136,6 +142,12 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         const int lane = opq(tid & 63);
         if (wave < S && lane < (in_bytes >> 4)) lds_dma16(a.obs + (size_t)row * in_bytes + 16 * lane, lds_addr(s_in + wave * in_bytes));
     };
+    // RC: this wave's quarter (wave & 3) of the first kernel, both pieces: ordinary loads, issued in front of every copy (a wave's memory operations retire in order)
+    u32x4 w1h = {0u, 0u, 0u, 0u}, w1l = w1h;
+    if constexpr (RC) {
+        const u32x4* c1 = a.packed + a.pk_c1w + (wave & 3) * PK_BLOCK + lane;
+        w1h = c1[0]; w1l = c1[PK_LO];
+    }
     // Copies of the first group, in the order of their first use: tables, observations, g3, a2 (patch image, dW3) | the data gradients' weights (g2) | a1 (dW2):
     // a wave's copies land in order, so the group loop waits for the first set only before it starts (every CU requests its 150 KB at once: the whole
     // set took 9.5 K cycles to land)
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         issue_a2(g, gns * r2);
         const char* wsrc = reinterpret_cast<const char*>(a.packed + a.pk_cdw);
         for (int c = wave; c < 48; c += C16_WAVES) lds_dma16(wsrc + c * 1024 + lane * 16, lds_addr(smem + C16_OFF_W + c * 1024));
-        issue_a1(g);
+        if constexpr (!RC) issue_a1(g);
     }
     if (tid < PL32) { s_a2[zero2 * PL32 + tid] = 0; s_a2[LA2 + zero2 * PL32 + tid] = 0; s_g3[zero3 * PL32 + tid] = 0; s_g3[LG3 + zero3 * PL32 + tid] = 0; }
     C16_STAMP(1);
@@ -241,11 +253,12 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
         // the first group, so may the weights' until g2.  (vmcnt is an immediate: the exact count or, for a partial group, 0.)
         const int na1 = (2 * C16_A1_CHUNKS - wave + C16_WAVES - 1) / C16_WAVES;
         if (grp == (int)blockIdx.x) {                               // first group: the weights' and a1's copies may stay in flight
-            if (na1 == 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            if constexpr (RC) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // (three 1 KB pieces of the weights per wave)
+            else if (na1 == 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // later groups: observations, g3, a2 (requested during the previous group)
         __syncthreads();                                            // ... and every wave has left the previous group's dW1: a1 / g1 is free
-        if (grp != (int)blockIdx.x) issue_a1(grp);                  // first needed by dW2, two phases on
+        if constexpr (!RC) { if (grp != (int)blockIdx.x) issue_a1(grp); }      // first needed by dW2, two phases on
         C16_STAMP(sb + 1);
         // ---- patch image: row m = the bits of pixel m's word (data), then of its constant mask, one byte each -------------------------------------------
         if (tid < M1 * 4) {
@@ -275,7 +288,8 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
             }
         }
         C16_STAMP(sb + 3);
-        if (na1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (first group: the weights have landed; a1 may stay in flight)
+        if constexpr (RC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (first group: the weights have landed)
+        else if (na1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // (first group: the weights have landed; a1 may stay in flight)
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __syncthreads();                                            // every wave is done reading a2; the patch image is complete
         C16_STAMP(sb + 4);
@@ -285,8 +299,36 @@ __global__ __launch_bounds__(C16_THREADS) void conv_bwd16_kernel(ConvBwdArgs a) 
             load_bw(bw, nt3, 2, lane);
             if (16 * (wave >> 1) < M2) dgrad_unit(bw, s_g3, LG3, s_a2, LA2, nt3, td2, M2, wave >> 1, j, kq);
         }
+        if constexpr (RC) {
+            // ---- a1 = relu(conv1(patch words)): this wave's quarter of 16 channels on row tiles (wave >> 2) + 4 i -- conv_wave.hip's conv1, instruction for instruction
+            //      (transposed: a lane ends up with channels 4 kq .. + 3 of pixel 16 T + j: one 8-byte store per piece into the a1 planes, as g1's in-place writes) ----
+            const int q1 = wave & 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int T = (wave >> 2) + 4 * i;                  // wave-uniform
+                if (T > 12) break;
+                const int m = 16 * T + j;
+                const uint2 v = *reinterpret_cast<const uint2*>(s_col + min(m, M1 - 1) * KP + 8 * kq);      // the pixel's bits 8 kq .. + 7 as bytes 0 / 1
+                u32x4 bits;
+                bits[0] = __umul24(__builtin_amdgcn_perm(0u, v.x, 0x0c010c00u), 0x3c00u);
+                bits[1] = __umul24(__builtin_amdgcn_perm(0u, v.x, 0x0c030c02u), 0x3c00u);
+                bits[2] = __umul24(__builtin_amdgcn_perm(0u, v.y, 0x0c010c00u), 0x3c00u);
+                bits[3] = __umul24(__builtin_amdgcn_perm(0u, v.y, 0x0c030c02u), 0x3c00u);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 ah = MFMA_F16(w1h, bits, z), al = MFMA_F16(w1l, bits, z);
+                const f32x4 vs = f16x2_sum(ah, al);
+                uint2 hp, lp;
+                split_f16x2_pair(relu1(vs[0]), relu1(vs[1]), hp.x, lp.x);
+                split_f16x2_pair(relu1(vs[2]), relu1(vs[3]), hp.y, lp.y);
+                unsigned short* pa = s_a1 + min(m, M1 - 1) * A1S + 16 * q1 + 4 * kq;
+                if (m < M1) {
+                    *reinterpret_cast<uint2*>(pa) = hp;
+                    *reinterpret_cast<uint2*>(pa + LA1) = lp;
+                }
+            }
+        }
         C16_STAMP(sb + 5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // a1 has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // a1 has landed (RC: nothing is in flight; the barrier publishes the recomputed a1)
         __syncthreads();
         C16_STAMP(sb + 6);
         if (nxt < a.groups) {                                       // the observation rows and g3 are dead now
@@ -485,7 +527,9 @@ void conv_bwd16_tables(const dq_qnet* Q, int kd, int stride_words, const int* pt
             tapo[tap] = a2row(valid ? s * C16_R2 + oy * C16_OW2 + ox : S * C16_R2);
         }
         out[TB_D1 + 4 * m] = tapo[0] | tapo[1] << 16; out[TB_D1 + 4 * m + 1] = tapo[2] | tapo[3] << 16; out[TB_D1 + 4 * m + 2] = a1row(m);
-        out[TB_TP + m] = (s * stride_words + p) | (pt_const[p] | 1 << (31 - kd)) << 16;     // (+ column 31 of the patch image: constant 1 -> the bias gradient)
+        // (+ column 31 of the patch image: constant 1 -> the bias gradient; + column K_data + 5: the forward's bias row of the c1w block -- a1 recomputed from this
+        // image (RC) is conv_wave.hip's a1 bit for bit; no Keras row maps to that column, so dW1 does not see it, and c1w's row 31 is 0)
+        out[TB_TP + m] = (s * stride_words + p) | (pt_const[p] | 1 << (31 - kd) | 1 << 5) << 16;
     }
     for (int m = 0; m < S * C16_R2; ++m) {
         const int s = m / C16_R2, p = m % C16_R2, iy = p / C16_OW2, ix = p % C16_OW2;
@@ -526,10 +570,12 @@ dq_status conv_bwd16_launch(const dq_qnet* Q, ConvBwdArgs& a, int wgs, hipStream
     static unsigned long long attr_devs = 0;
     const unsigned long long dev_bit = dq_device_bit();
     if (!(attr_devs & dev_bit)) {
-        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS));
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS));
+        DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS));
         attr_devs |= dev_bit;
     }
-    dq_launch(DQ_K_CONV_BWD, conv_bwd16_kernel, dim3(wgs), dim3(C16_THREADS), C16_LDS, st, a);
+    if (a.a1_recompute) dq_launch(DQ_K_CONV_BWD, "conv_bwd16_kernel", conv_bwd16_kernel<true>, dim3(wgs), dim3(C16_THREADS), C16_LDS, st, a);
+    else dq_launch(DQ_K_CONV_BWD, "conv_bwd16_kernel", conv_bwd16_kernel<false>, dim3(wgs), dim3(C16_THREADS), C16_LDS, st, a);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

@@ -29,7 +29,8 @@
 //           wave instead of 25.6, which is what lets 16 waves of two samples fit beside the weights.
 //   conv2   per (quarter, ky): B = 4 ds_read_b128, A = 2 per sample, 12 MFMAs.  Its output a2 (split on write) OVERLAYS the dead quarter image.
 //   conv3   per tap the same on the a2 images; its output leaves as f32 rows (the dense chain's input), rows < 9 only.
-//   training job: the a1 quarters and a2 are copied to the piece planes the convolutional backward reads, 16 bytes per lane, from the LDS images.
+//   training job: a2 (and, for a backward that does not recompute it -- ConvJob.write_all bit 1 --, the a1 quarters) are copied to the piece planes the
+//           convolutional backward reads, 16 bytes per lane, from the LDS images.
 //
 // LDS: [c1w 8 KB | c2w 32 KB | conv3 16 KB | bits table 4 KB | per wave 4 KB] = 124 KB.  Inside a wave's 4 KB: sample s at 2048 s, piece l 1024 bytes
 // behind piece h, and the 16-byte chunk c of pixel p at slot CW_SLOT1[2 p + c] (quarter image: 2 chunks per pixel) / CW_SLOT2[4 p + c] (a2: 4 chunks)
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
         Pair nn;
         CW_PAIR_OF(nn, p + 2 * CW_WAVES);
         rows_of(nn, rn0, rn1);
-        const bool train = J.write_all != 0;                        // wave-uniform
+        const bool train = J.write_all != 0, save_a1 = (J.write_all & 2) != 0;      // wave-uniform
 
 #ifndef CW_BITS_LIVE
 #define CW_BITS_LIVE 1                                              // 1: the four expanded bytes stay in 16 registers over the quarters; 0: re-read from the table per quarter
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
                     *reinterpret_cast<uint2*>(s_img + s * SM + PL + wa1[u]) = lp;
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (train) {                                            // a1 piece planes [sample pixel][64 halves]: this quarter's 32 bytes of every pixel
+            if (save_a1) {                                          // a1 piece planes [sample pixel][64 halves]: this quarter's 32 bytes of every pixel (only for a
+                                                                    // backward that reads them: conv_bwd16_kernel recomputes a1 from the patch words, round 6)
                 const u32 cg1 = (u32)((lane >> 1) * 128 + 16 * (lane & 1));      // (recomputed: a register less over the pair)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -415,7 +417,7 @@ dq_status conv_wave_launch(const dq_qnet* Q, ConvWaveArgs& a, int n_cu, hipStrea
             }
         for (; q < FWD_MAX_JOBS; ++q) { S.job[q] = last; S.end[q] = end; S.batch[q] = a.job[last].batch; }
     }
-    dq_launch(DQ_K_CONV_CHAIN, conv_wave_kernel, dim3(acc), dim3(CW_THREADS), CW_LDS, st, a);
+    dq_launch(DQ_K_CONV_CHAIN, "conv_wave_kernel", conv_wave_kernel, dim3(acc), dim3(CW_THREADS), CW_LDS, st, a);
     DQ_LAUNCH_CHECK();
     (void)Q;
     return DQ_OK;

@@ -192,6 +192,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         }
     }
     if (bad && flag) atomicOr(flag, 1u);
+    // a WHOLE update discarded by the range guard's early half arrives here as NaN in every element (fused_bwd.hip reduce_finish; through the all-reduce
+    // on every rank): counted once per optimizer step in the word behind the flag's (dq_qnet_range_discarded)
+    if (flag && blockIdx.x == 0 && threadIdx.x == 0 && n > 0 && !__builtin_isfinite(g[0]) && !__builtin_isfinite(g[n - 1])) atomicAdd(flag + 4, 1u);
 }
 
 // stats[0] += #episodes that ended this step, stats[1] += sum of their lifetimes, stats[2] += #rewards == 1,

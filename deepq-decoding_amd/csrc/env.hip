@@ -639,7 +639,7 @@ struct PatchDisarm {
 static dq_status launch_env(dq_env* E, EnvParams& p, hipStream_t st) {
     const dq_status rc = fill_common(E, p, ENVS_PER_BLOCK);
     if (rc != DQ_OK) return rc;
-    dq_launch(DQ_K_ENV, env_kernel, dim3(p.env_blocks + p.s_blocks), dim3(64 * ENVS_PER_BLOCK),
+    dq_launch(DQ_K_ENV, "env_kernel", env_kernel, dim3(p.env_blocks + p.s_blocks), dim3(64 * ENVS_PER_BLOCK),
               env_block_lds((p.pair ? 2 : 1) * ENVS_PER_BLOCK, ENVS_PER_BLOCK, p.obs_size, p.lut_words), st, p);
     DQ_LAUNCH_CHECK();
     return DQ_OK;

@@ -1995,7 +1995,12 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         }
         C.params = jb.params_dev; C.packed = static_cast<const u32x4*>(packed); C.obs = jb.obs_dev; C.index = jb.index_dev; C.index_off = jb.index_off;
         C.index_mod = jb.index_mod > 0 ? jb.index_mod : 0x7fffffff;
-        C.batch = jb.batch; C.write_all = training; C.wg0 = conv_wgs; ca.wg_first[i] = conv_wgs; da.wg_first[i] = dense_wgs;
+        // (a conv_wave_kernel training job whose backward is conv_bwd16_kernel does not save a1 -- 26 MB of writes at c3, read straight back --: that backward
+        // recomputes it from the patch words, the same bits; qnet.h conv_bwd_a1)
+        const bool wave_form = patch && conv_wave_supported(Q) && Q->conv_form == 0;
+        const bool a1_saved = !(training && wave_form && Q->conv_bwd_a1 == 0 && conv_bwd16_applies(Q, jb.batch, patch));
+        if (training) Q->last_a1_saved = a1_saved ? 1 : 0;
+        C.batch = jb.batch; C.write_all = training ? (a1_saved ? 3 : 1) : 0; C.wg0 = conv_wgs; ca.wg_first[i] = conv_wgs; da.wg_first[i] = dense_wgs;
         C.act_out[0] = nullptr; C.act_out[1] = nullptr; C.act_out[2] = x;
         C.a1_pl = reinterpret_cast<unsigned short*>(Q->act[0][0]); C.a1_lo = (size_t)Q->cfg.max_batch * L1.rows * 64;
         C.a2_pl = reinterpret_cast<unsigned short*>(Q->act[0][1]); C.a2_lo = (size_t)Q->cfg.max_batch * L2.rows * 32;
@@ -2027,9 +2032,9 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
     }
     for (int i = n_jobs; i < FWD_MAX_JOBS; ++i) ca.wg_first[i] = da.wg_first[i] = 0x7fffffff;
-    // the wave-private form (conv_wave.hip) for patch words at d = 5; DQ_CONV_FORM=group keeps the workgroup-per-group kernels (read per call: tests flip it)
-    const char* cf = getenv("DQ_CONV_FORM");
-    if (patch && conv_wave_supported(Q) && !(cf && cf[0] == 'g')) {
+    // the wave-private form (conv_wave.hip) for patch words at d = 5; conv_form 1 (dq_qnet_set_kernel_forms, DQ_CONV_FORM=group at creation) keeps the
+    // workgroup-per-group kernels
+    if (patch && conv_wave_supported(Q) && Q->conv_form == 0) {
         ConvWaveArgs wa;
         memset(&wa, 0, sizeof(wa));
         for (int i = 0; i < n_jobs; ++i) wa.job[i] = ca.job[i];
@@ -2044,12 +2049,12 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         int grid = pp.per_cu * n_cu;
         if (persist_grid > 0) grid = persist_grid;
         if (grid > conv_wgs) grid = conv_wgs;
-        dq_launch(DQ_K_CONV_CHAIN, pk, dim3(grid), dim3(CONV_THREADS), pp.lds, st, ca);
+        dq_launch(DQ_K_CONV_CHAIN, "conv_chain_pkernel", pk, dim3(grid), dim3(CONV_THREADS), pp.lds, st, ca);
     } else {
-        dq_launch(DQ_K_CONV_CHAIN, ck, dim3(conv_wgs), dim3(CONV_THREADS), cp.lds, st, ca);
+        dq_launch(DQ_K_CONV_CHAIN, "conv_chain_kernel", ck, dim3(conv_wgs), dim3(CONV_THREADS), cp.lds, st, ca);
     }
     DQ_LAUNCH_CHECK();
-    dq_launch(DQ_K_DENSE_CHAIN, dk, dim3(dense_wgs), dim3(DENSE_THREADS), dp.lds, st, da);
+    dq_launch(DQ_K_DENSE_CHAIN, "dense_chain_kernel", dk, dim3(dense_wgs), dim3(DENSE_THREADS), dp.lds, st, da);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
 }

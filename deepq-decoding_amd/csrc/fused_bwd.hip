@@ -1025,6 +1025,9 @@ __global__ __launch_bounds__(512) void reduce_slices_kernel(ReduceArgs a) {
     // training forward's dropout keep bits
     if ((int)blockIdx.x < a.drop.wgs) { dropout_ahead(a.drop, (int)blockIdx.x * 512 + threadIdx.y * 64 + threadIdx.x); return; }
     const unsigned bx = blockIdx.x - (unsigned)a.drop.wgs;
+    // the optimizer step rides on this launch and the TD step discarded the whole update: counted once (dq_qnet_range_discarded; with a separate optimizer
+    // step -- several GPUs -- dqn.hip adam_kernel counts it, on every rank)
+    if (bx == 0 && threadIdx.x == 0 && threadIdx.y == 0 && a.adam && a.skip_word && __builtin_nontemporal_load(a.skip_word) == a.skip_tag) atomicAdd(a.range_flag + 4, 1u);
     const ReduceSeg& S = a.seg[bx >= (unsigned)a.seg[1].block0 ? 1 : 0];
     const float inv = a.gs_dev ? a.gs_dev[1] : a.inv_gs;
     if (S.vec == 1) {
@@ -1785,6 +1788,10 @@ size_t fused_backward_workspace_floats(const dq_qnet* Q) {
 }
 
 // the range guard's flag word (include/deepq_hip.h dq_qnet_range_check): the third of the four words behind the partials
+bool conv_bwd16_applies(const dq_qnet* Q, int B, bool patch) {
+    return patch && conv_bwd16_supported(Q) && B % 8 == 0 && (B >= 1024 || Q->conv_bwd_form == 2) && Q->conv_bwd_form != 1;
+}
+
 unsigned* fused_range_flag(const dq_qnet* Q) {
     if (!Q->fpartial) return nullptr;
     return reinterpret_cast<unsigned*>(Q->fpartial + (size_t)DENSE_WGRAD_SLICES * dense_pstride(Q) + (size_t)CONV_BWD_MAX_WGS * Q->L[Q->cfg.n_conv].w_off) + 2;
@@ -1903,7 +1910,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         void (*dbk)(DenseBwdArgs, EnvParams) = dp.NT2 == 4 ? (td ? dense_bwd_chain_kernel<4, true, true> : dense_bwd_chain_kernel<4, false, true>)
                                                             : (td ? (wide_short ? dense_bwd_chain_kernel<7, true, true> : dense_bwd_chain_kernel<7, true, false>)
                                                                   : dense_bwd_chain_kernel<7, false, false>);
-        dq_launch(DQ_K_DENSE_BWD, dbk, dim3(da.dense_wgs + stat_wgs), dim3(DENSE_THREADS), lds, st, da, ep);
+        dq_launch(DQ_K_DENSE_BWD, "dense_bwd_chain_kernel", dbk, dim3(da.dense_wgs + stat_wgs), dim3(DENSE_THREADS), lds, st, da, ep);
     }
     DQ_LAUNCH_CHECK();
 
@@ -1944,8 +1951,8 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
         DQ_REQUIRE(rider_lds <= DENSE_WGRAD_LDS, DQ_ERR_UNSUPPORTED, "fused_backward: the riding environment step needs more LDS than the dense weight gradients' launch has");
         wep = *rider; wa.env_on = ride_on_wgrad(); ride_wgs = wep.env_blocks + wep.s_blocks; wa.env_wgs = ride_wgs;
     }
-    if (ride_wgrad) dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_ride_kernel, dim3(tiles * sy + ride_wgs), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa, wep);
-    else dq_launch(DQ_K_DENSE_WGRAD, dense_wgrad_kernel, dim3(tiles * sy), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa);
+    if (ride_wgrad) dq_launch(DQ_K_DENSE_WGRAD, "dense_wgrad_ride_kernel", dense_wgrad_ride_kernel, dim3(tiles * sy + ride_wgs), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa, wep);
+    else dq_launch(DQ_K_DENSE_WGRAD, "dense_wgrad_kernel", dense_wgrad_kernel, dim3(tiles * sy), dim3(WGRAD_THREADS), DENSE_WGRAD_LDS, st, wa);
     DQ_LAUNCH_CHECK();
 
     if (phases != 3) {                                              // phased: the dense gradients are complete (and reducible) now
@@ -1990,11 +1997,13 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     ca.off_d2 = cp.off_d2; ca.off_d1 = cp.off_d1; ca.rowtab = Q->kofftab + 96 + CONV_FWD_TABS * CONV_ROWTAB;
     ca.rowtab1 = patch ? Q->ptab + PT_BWD : ca.rowtab; ca.srctab = patch ? Q->ptab + PT_SRC : nullptr; ca.kd = Q->patch_kd; ca.off_lut = cp.off_lut;
     DQ_REQUIRE(!patch || (reinterpret_cast<uintptr_t>(ca.obs) & 15) == 0, DQ_ERR_INVALID, "fused_backward: patch-word rows must be 16-byte aligned");
-    // the 16-wave form (conv_bwd16.hip) where it applies and the minibatch gives every CU work (groups of 8 samples); DQ_CONV_BWD_FORM=8: this file's kernel
-    // (A/B runs, tests; read per call)
-    const char* form = getenv("DQ_CONV_BWD_FORM");
-    const bool form16 = patch && conv_bwd16_supported(Q) && B % 8 == 0 && (B >= 1024 || (form && form[0] == '1')) && !(form && form[0] == '8');      // (=16: whatever the minibatch)
-    if (form16) { ca.S = 8; ca.groups = (B + 7) / 8; ca.pk_cdw = (int)PL.cdw; ca.tab16 = Q->ptab + PT_C16; }
+    // the 16-wave form (conv_bwd16.hip) where it applies and the minibatch gives every CU work (groups of 8 samples); conv_bwd_form 1: this file's kernel,
+    // 2: the 16-wave form whatever the minibatch (dq_qnet_set_kernel_forms; DQ_CONV_BWD_FORM=8 / 16 at creation)
+    const bool form16 = conv_bwd16_applies(Q, B, patch);
+    // a1: saved by the training forward, or recomputed here from the patch words when that forward (conv_wave_kernel) left it out -- the two must agree
+    DQ_REQUIRE(Q->last_a1_saved || form16, DQ_ERR_STATE, "fused_backward: the training forward did not save the first convolution's output (it expected conv_bwd16_kernel to "
+               "recompute it) and this backward takes another form: dq_qnet_set_kernel_forms between a training forward and its backward");
+    if (form16) { ca.S = 8; ca.groups = (B + 7) / 8; ca.pk_cdw = (int)PL.cdw; ca.tab16 = Q->ptab + PT_C16; ca.pk_c1w = (int)PL.c1w; ca.a1_recompute = Q->last_a1_saved ? 0 : 1; }
     const int wgs = ca.groups < CONV_BWD_MAX_WGS ? ca.groups : CONV_BWD_MAX_WGS;
     if (form16) {
         const dq_status rc = conv_bwd16_launch(Q, ca, wgs, st);
@@ -2003,7 +2012,7 @@ dq_status fused_backward(dq_qnet* Q, const float* params_dev, const float* dq_de
     conv_bwd_kernel_t ck = patch ? (cp.KG1 == 2 ? conv_bwd_chain_kernel<2, true> : conv_bwd_chain_kernel<3, true>)
                          : cp.KG1 == 3 ? conv_bwd_chain_kernel<3> : cp.KG1 == 4 ? conv_bwd_chain_kernel<4>
                          : cp.KG1 == 5 ? conv_bwd_chain_kernel<5> : conv_bwd_chain_kernel<6>;
-    dq_launch(DQ_K_CONV_BWD, ck, dim3(wgs), dim3(CB_THREADS), cp.lds, st, ca);
+    dq_launch(DQ_K_CONV_BWD, "conv_bwd_chain_kernel", ck, dim3(wgs), dim3(CB_THREADS), cp.lds, st, ca);
     DQ_LAUNCH_CHECK();
     }
     if (Q->mark_event) {                                            // dq_qnet_mark_conv_backward: the caller's side stream starts from here

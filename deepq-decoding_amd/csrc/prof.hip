@@ -12,6 +12,9 @@ static const char* const kNames[DQ_K_COUNT] = {
     "reduce_partials_kernel", "td_kernels", "adam_kernel", "dense_bwd_chain_kernel", "dense_wgrad_kernel", "conv_bwd_chain_kernel",
 };
 
+static const char* g_symbol[DQ_K_COUNT];    // the symbol each family's LAST launch used (string literals of the launch sites)
+void dq_prof_note_symbol(int id, const char* symbol) { if (id >= 0 && id < DQ_K_COUNT) g_symbol[id] = symbol; }
+
 static int g_armed = -1;
 static int g_used = 0;
 static int g_stride = 1, g_seen = 0;          // every g_stride-th launch of the armed family is timed
@@ -56,6 +59,8 @@ int dq_prof_kernel_count(void) { return DQ_K_COUNT; }
 
 const char* dq_prof_kernel_name(int id) { return id >= 0 && id < DQ_K_COUNT ? kNames[id] : ""; }
 
+const char* dq_prof_kernel_symbol(int id) { return id >= 0 && id < DQ_K_COUNT && g_symbol[id] ? g_symbol[id] : ""; }
+
 dq_status dq_prof_stride(int stride) {
     DQ_REQUIRE(stride >= 1, DQ_ERR_INVALID, "dq_prof_stride: stride must be >= 1");
     g_stride = stride; g_seen = 0;
@@ -82,19 +87,26 @@ dq_status dq_prof_arm(int kernel_id, int max_launches) {
     return DQ_OK;
 }
 
-dq_status dq_prof_collect(int* launches, double* total_ms) {
+dq_status dq_prof_collect_spread(int* launches, double* total_ms, double* min_ms, double* max_ms) {
     DQ_REQUIRE(launches && total_ms, DQ_ERR_INVALID, "dq_prof_collect: null argument");
     *launches = 0;
     *total_ms = 0.0;
+    double lo = 0.0, hi = 0.0;
     if (g_used > 0) DQ_HIP(hipEventSynchronize(g_events[2 * g_used - 1]));
     for (int i = 0; i < g_used; ++i) {
         float ms = 0.f;
         DQ_HIP(hipEventElapsedTime(&ms, g_events[2 * i], g_events[2 * i + 1]));
         *total_ms += ms;
+        if (i == 0 || ms < lo) lo = ms;
+        if (i == 0 || ms > hi) hi = ms;
     }
+    if (min_ms) *min_ms = lo;
+    if (max_ms) *max_ms = hi;
     *launches = g_used;
     g_used = 0;
     return DQ_OK;
 }
+
+dq_status dq_prof_collect(int* launches, double* total_ms) { return dq_prof_collect_spread(launches, total_ms, nullptr, nullptr); }
 
 }  // extern "C"

@@ -69,6 +69,14 @@ struct dq_qnet {
     float grad_scale_hint;       // dq_qnet_set_grad_scale: loss scale of caller-supplied dq (0 = unknown: measured on the device)
     float bwd_scale;             // fused backward: power-of-two scale the gradients of the last dense phase carry (0: the device-computed one)
     int use_fused;               // fused LDS-resident chains when the configuration allows it
+    // which FORM of a kernel family runs where several exist (dq_qnet_set_kernel_forms; initial value from DQ_CONV_FORM / DQ_CONV_BWD_FORM, read ONCE at
+    // dq_qnet_create: a handle's summation order does not follow a mutable process environment)
+    int conv_form;               // 0: conv_wave_kernel where it applies, 1: the workgroup-per-group kernels (fused.hip)
+    int conv_bwd_form;           // 0: conv_bwd16_kernel where it applies and the minibatch is >= 1024, 1: always conv_bwd_chain_kernel, 2: conv_bwd16_kernel whatever the minibatch
+    int conv_bwd_a1;             // 0: conv_bwd16_kernel RECOMPUTES the first convolution's output from the patch words where the training forward was conv_wave_kernel
+                                 // (which then does not save it: round 6), 1: every training forward saves a1, every backward reads the saved planes
+    int last_a1_saved;           // the last training forward wrote the a1 piece planes (the backward that recomputes a1 must follow a forward that did NOT, and
+                                 // the other way round: dq_qnet_set_kernel_forms between the two is refused)
     // patch-word input (dq_qnet_set_patch_input): observations as d * d words per sample instead of the padded uint8 image
     int patch_depth;             // syndrome planes of the observation (0: not configured); the remaining input planes are action planes
     int patch_kd;                // data bits per pixel = 4 patch_depth + action planes (<= 32)
@@ -203,7 +211,8 @@ struct ConvJob {
     size_t a1_lo;
     unsigned short* a2_pl;             // convolution's output is kept as f16 piece planes [batch*oh2*ow2][32] (h plane; the l plane a2_lo halves
     size_t a2_lo;                      // further) -- the form the convolutional backward consumes it in (fused_bwd.hip)
-    int write_all;                     // training: write every layer
+    int write_all;                     // training: bit 0 = write every layer the backward reads; bit 1 (conv_wave_kernel only) = ... including a1 (else the
+                                       // backward recomputes it from the patch words: conv_bwd16.hip)
     int wg0;                           // first workgroup of this job
 };
 
@@ -271,6 +280,9 @@ bool fused_conv_bwd_row_tables(const dq_qnet* Q, int* tab);  // tab: int[5 * CON
 bool fused_patch_supported(const dq_qnet* Q, int depth);     // patch-word input possible for this network with `depth` syndrome planes
 void fused_patch_tables(const dq_qnet* Q, int depth, int stride_words, int* tab);      // tab: int[PT_TOTAL]
 dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, hipStream_t st);
+// Does a training minibatch of B samples take conv_bwd16_kernel (fused_bwd.hip fused_backward's rule, shared with the forward: a conv_wave_kernel training job
+// saves a1 only when its backward will read it)?
+bool conv_bwd16_applies(const dq_qnet* Q, int B, bool patch);
 // conv_wave.hip: the conv forward's wave-private form (one sample per wave, weights in LDS, no barriers): patch-word input, d = 5
 struct ConvWaveArgs {
     ConvJob job[FWD_MAX_JOBS];

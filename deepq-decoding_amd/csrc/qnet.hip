@@ -382,6 +382,15 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
     Q->n_layers = n;
     Q->n_params = off;
     Q->use_fused = 1;
+    {
+        const char* cf = getenv("DQ_CONV_FORM");
+        const char* bf = getenv("DQ_CONV_BWD_FORM");
+        Q->conv_form = cf && cf[0] == 'g' ? 1 : 0;
+        Q->conv_bwd_form = bf && bf[0] == '8' ? 1 : bf && bf[0] == '1' ? 2 : 0;
+        const char* a1 = getenv("DQ_CONV_BWD_A1");                  // =saved: the round-5 form (a1 through HBM), for A/B runs
+        Q->conv_bwd_a1 = a1 && a1[0] == 's' ? 1 : 0;
+        Q->last_a1_saved = 1;
+    }
     // workspaces
     size_t max_partial = 0;
     hipError_t e = hipSuccess;
@@ -427,7 +436,7 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
     const size_t fws = fused_backward_workspace_floats(Q);
     if (e == hipSuccess && fused_forward_supported(Q)) e = hipMalloc(&Q->keep_bits, (size_t)Q->cfg.max_batch * 16 * sizeof(u32));
     if (e == hipSuccess && fws) e = hipMalloc(&Q->fpartial, fws * sizeof(float));
-    if (e == hipSuccess && fws) e = hipMemset(Q->fpartial + fws - 8, 0, 8 * sizeof(float));       // {S, 1/S}, range flag, spare; td_scale_kernel's work words, spare
+    if (e == hipSuccess && fws) e = hipMemset(Q->fpartial + fws - 8, 0, 8 * sizeof(float));       // {S, 1/S}, range flag, skip word; td_scale_kernel's two work words, discarded-update count, spare
     Q->partial_floats = max_partial;
     if (e != hipSuccess) { dq_set_error("dq_qnet_create: %s", hipGetErrorString(e)); dq_qnet_destroy(Q); return DQ_ERR_HIP; }
     *out = Q;
@@ -471,6 +480,14 @@ dq_status dq_qnet_set_fused(dq_qnet* Q, int enable) {
     return DQ_OK;
 }
 
+dq_status dq_qnet_set_kernel_forms(dq_qnet* Q, int conv_forward_form, int conv_backward_form, int conv_backward_a1) {
+    DQ_REQUIRE(Q && conv_forward_form <= 1 && conv_backward_form <= 2 && conv_backward_a1 <= 1, DQ_ERR_INVALID, "dq_qnet_set_kernel_forms: bad argument");
+    if (conv_forward_form >= 0) Q->conv_form = conv_forward_form;
+    if (conv_backward_form >= 0) Q->conv_bwd_form = conv_backward_form;
+    if (conv_backward_a1 >= 0) Q->conv_bwd_a1 = conv_backward_a1;
+    return DQ_OK;
+}
+
 dq_status dq_qnet_set_grad_scale(dq_qnet* Q, double grad_scale) {
     DQ_REQUIRE(Q && grad_scale >= 0.0 && grad_scale < 1e30, DQ_ERR_INVALID, "dq_qnet_set_grad_scale: bad argument");
     Q->grad_scale_hint = (float)grad_scale;
@@ -493,9 +510,23 @@ dq_status dq_qnet_range_check(dq_qnet* Q, void* stream) {
     DQ_HIP(hipStreamSynchronize(st));
     if (!host) return DQ_OK;
     DQ_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
-    dq_set_error("dq_qnet_range_check: a gradient of the fused backward left the range of its f16 pieces (non-finite weight gradient: "
-                 "TD errors of several thousand); the affected parameters were not updated.  dq_qnet_set_fused(net, 0) selects the f32 path");
+    dq_set_error("dq_qnet_range_check: a gradient of the fused backward left the range of its f16 pieces (TD errors of several thousand with the host-known "
+                 "gradient scale): an update whose TD step saw such a sample was discarded WHOLE -- no parameter moved, on any rank; count: "
+                 "dq_qnet_range_discarded --, a lone non-finite gradient element behind a passing TD step left only its own parameter and moments untouched.  "
+                 "dq_td_job.auto_scale carries any finite TD error; dq_qnet_set_fused(net, 0) selects the f32 path");
     return DQ_ERR_RANGE;
+}
+
+dq_status dq_qnet_range_discarded(dq_qnet* Q, unsigned* count, void* stream) {
+    DQ_REQUIRE(Q && count, DQ_ERR_INVALID, "dq_qnet_range_discarded: null argument");
+    *count = 0;
+    unsigned* flag = fused_range_flag(Q);
+    if (!flag) return DQ_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DQ_HIP(hipMemcpyAsync(count, flag + 4, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    DQ_HIP(hipStreamSynchronize(st));
+    if (*count) DQ_HIP(hipMemsetAsync(flag + 4, 0, sizeof(unsigned), st));
+    return DQ_OK;
 }
 
 int dq_qnet_fused_supported(const dq_qnet* Q) { return Q && fused_forward_supported(Q) ? 1 : 0; }

@@ -77,10 +77,25 @@ class QNetwork:
         check(self.L.dq_qnet_set_patch_input(self._h, int(n_syndrome_planes), int(stride_words)))
         self.patch_planes = int(n_syndrome_planes)
 
+    def set_kernel_forms(self, conv_forward=None, conv_backward=None, conv_backward_a1=None):
+        """Which form of the convolution kernels this handle runs (include/deepq_hip.h dq_qnet_set_kernel_forms): conv_forward "wave" | "group", conv_backward
+        "default" | "8" | "16", conv_backward_a1 "recompute" | "saved"; None keeps the current choice (initially DQ_CONV_FORM / DQ_CONV_BWD_FORM / DQ_CONV_BWD_A1
+        as they were when the handle was created)."""
+        f = {None: -1, "wave": 0, "group": 1}[conv_forward]
+        b = {None: -1, "default": 0, "8": 1, "16": 2}[conv_backward]
+        a1 = {None: -1, "recompute": 0, "saved": 1}[conv_backward_a1]
+        check(self.L.dq_qnet_set_kernel_forms(self._h, f, b, a1))
+
     def check_range(self):
         """Synchronises the current stream; raises DeepQError(status=DQ_ERR_RANGE) if a gradient of the fused backward left the range of
         its f16 pieces since the last call (include/deepq_hip.h dq_qnet_range_check)."""
         check(self.L.dq_qnet_range_check(self._h, self._stream()))
+
+    def range_discarded(self):
+        """Optimizer steps the range guard discarded whole since the last call (include/deepq_hip.h dq_qnet_range_discarded); synchronises."""
+        n = ctypes.c_uint(0)
+        check(self.L.dq_qnet_range_discarded(self._h, ctypes.byref(n), self._stream()))
+        return int(n.value)
 
     @property
     def fused_supported(self):

@@ -326,6 +326,16 @@ dq_status dq_qnet_layer_info(const dq_qnet* net, int layer, int64_t* kernel_offs
  * training forward saves its activations in the form ITS backward reads (the fused one mostly as f16 piece planes), so a backward
  * must run on the path its training forward ran on: switching between the two calls makes the backward return DQ_ERR_STATE. */
 dq_status dq_qnet_set_fused(dq_qnet* net, int enable);
+/* Where the fused path has several FORMS of a kernel (same results to round-off, different summation order), which one this handle runs; a negative value keeps
+ * the current choice.  conv_forward_form: 0 = conv_wave_kernel where it applies (patch words, d = 5), 1 = the workgroup-per-group kernels.  conv_backward_form:
+ * 0 = conv_bwd16_kernel where it applies and the minibatch is >= 1024, 1 = conv_bwd_chain_kernel always, 2 = conv_bwd16_kernel whatever the minibatch.
+ * conv_backward_a1: 0 = where a conv_wave_kernel training forward is followed by conv_bwd16_kernel, the forward does not save the first convolution's output and
+ * the backward recomputes it from the patch words (the forward's own instructions: bit-identical gradients, 52 MB less HBM traffic per update at 4096 samples),
+ * 1 = every training forward saves it and every backward reads the saved planes.  Set between a training forward and its backward, a change that makes the
+ * backward need what the forward did not save is refused there (DQ_ERR_STATE).  The initial values come from DQ_CONV_FORM (=group -> 1) / DQ_CONV_BWD_FORM
+ * (=8 -> 1, =16 -> 2) / DQ_CONV_BWD_A1 (=saved -> 1) read ONCE by dq_qnet_create; nothing re-reads the environment per call, so every rank that created its handle
+ * under the same environment sums in the same order.  A/B measurements and tests.  No reference counterpart. */
+dq_status dq_qnet_set_kernel_forms(dq_qnet* net, int conv_forward_form, int conv_backward_form, int conv_backward_a1);
 int dq_qnet_fused_supported(const dq_qnet* net);
 
 /* model.predict_on_batch (training == 0) / the forward half of train_on_batch (training != 0: dropout
@@ -410,6 +420,11 @@ dq_status dq_qnet_mark_conv_backward(dq_qnet* net, void* hip_event);
  * S x grad_scale in [4, 8) the guard trips for |TD error| of a few thousand (the reference's recorded losses, trained_models/ * / * /
  * training_history.json, stay below 160, i.e. |TD error| ~ 20).  No reference counterpart. */
 dq_status dq_qnet_range_check(dq_qnet* net, void* stream);
+/* How many optimizer steps the guard's early half discarded WHOLE since the last call (the TD step saw a sample beyond the host-known scale's range: the
+ * final reduction wrote NaN into every gradient element and moved no parameter -- with several ranks the all-reduce carries the NaNs to all of them and
+ * dq_qnet_adam_step counts on each); synchronises `stream`, clears the count.  What the reference (delta_clip = inf, fp32) would have applied and this
+ * path did not: the agent loop logs it.  No reference counterpart. */
+dq_status dq_qnet_range_discarded(dq_qnet* net, unsigned* count, void* stream);
 
 /* The same backward in two phases, for overlapping the gradient all-reduce with compute on several GPUs (no reference
  * counterpart): phase 0 = dueling + dense layers -> grads_dev[dq_qnet_conv_param_count(net) ..) complete; phase 1 = the
@@ -600,9 +615,16 @@ dq_status dq_adam_step(float* params_dev, const float* grads_dev, float* m_dev, 
  * ------------------------------------------------------------------------------------------- */
 int dq_prof_kernel_count(void);
 const char* dq_prof_kernel_name(int kernel_id);
+/* The kernel SYMBOL the family's most recent launch used ("" before its first launch): a family has several forms
+ * (conv_chain_kernel: conv_wave_kernel / conv_chain_pkernel / conv_chain_kernel; conv_bwd_chain_kernel: conv_bwd16_kernel /
+ * conv_bwd_chain_kernel), and a measurement must name the one that ran. */
+const char* dq_prof_kernel_symbol(int kernel_id);
 dq_status dq_prof_arm(int kernel_id, int max_launches);
 dq_status dq_prof_stride(int stride);
 dq_status dq_prof_collect(int* launches, double* total_ms);
+/* The same with the shortest and the longest of the recorded launches (either pointer may be NULL): the spread a reader needs to tell a
+ * slower box from a slower kernel. */
+dq_status dq_prof_collect_spread(int* launches, double* total_ms, double* min_ms, double* max_ms);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,16 @@ from . import philox
 
 
 class QNetSpec:
-    def __init__(self, input_shape, c_layers, ff_layers, n_actions, dueling=True):
+    def __init__(self, input_shape, c_layers, ff_layers, n_actions, dueling=True, dueling_mean="row"):
+        # dueling_mean: which mean the dueling head's Lambda subtracts.  "row" (default, what the product implements): the mean over the ACTIONS of each
+        # sample, Q(s, a) = V(s) + A(s, a) - mean_a' A(s, a') -- equation (9) of Wang et al. 2016 (arXiv:1511.06581), the paper the reference cites for its
+        # dueling head (README.md:261, manuscript TEX:501,630), and keras-rl master's `K.mean(a[:, 1:], axis=1, keepdims=True)`.  "batch": the form upstream
+        # keras-rl 0.4.2 is reported to have shipped with, `K.mean(a[:, 1:], keepdims=True)` -- no axis, i.e. ONE mean over batch AND actions, which makes a
+        # state's Q-values depend on the other states of the batch.  The reference's fork (github.com/R-Sweke/keras-rl, README.md:33) is not in the tree, so
+        # which of the two its training ran is UNPINNED; the two coincide for a batch of one (every acting / test forward, every shipped-agent check) and
+        # differ in the 32-sample training forwards, targets and gradient (tests/test_oracle_dqn.py prints by how much).  DESIGN.md section 6.
+        assert dueling_mean in ("row", "batch")
+        self.dueling_mean = dueling_mean
         self.input_shape = tuple(int(x) for x in input_shape)          # (C, H, W)
         self.c_layers = [tuple(int(x) for x in l) for l in c_layers]   # [filters, kernel, stride]
         self.ff_layers = [(int(l[0]), float(l[1])) for l in ff_layers]  # [units, dropout rate]
@@ -124,6 +133,13 @@ def _im2col(x, k, s):
     return cols.reshape(B, oh, ow, k * k * C)
 
 
+def _dueling_mean(spec, adv):
+    """The mean the dueling head subtracts from the advantages (QNetSpec.dueling_mean): per sample, or one number for the whole batch."""
+    if getattr(spec, "dueling_mean", "row") == "batch":
+        return adv.mean(keepdims=True)
+    return adv.mean(axis=1, keepdims=True)
+
+
 def forward(spec, flat_params, obs, training=False, keep_masks=None):
     """Returns (Q (B,A) float64, cache).  keep_masks: list of boolean (B, units) arrays, one per dropout layer
     with rate > 0 (training only)."""
@@ -155,7 +171,7 @@ def forward(spec, flat_params, obs, training=False, keep_masks=None):
             cache["layers"].append(dict(kind="dense", x=x, y=y, z=z, keep=keep, rate=L["dropout"], relu=L["relu"]))
             x = y_out
     if spec.dueling:
-        q = x[:, 0:1] + x[:, 1:] - x[:, 1:].mean(axis=1, keepdims=True)
+        q = x[:, 0:1] + x[:, 1:] - _dueling_mean(spec, x[:, 1:])
     else:
         q = x
     cache["head_in"] = x
@@ -186,7 +202,10 @@ def backward(spec, flat_params, cache, dq):
         A = spec.n_actions
         g = np.zeros((dq.shape[0], A + 1))
         g[:, 0] = dq.sum(axis=1)
-        g[:, 1:] = dq - dq.sum(axis=1, keepdims=True) / A
+        if getattr(spec, "dueling_mean", "row") == "batch":
+            g[:, 1:] = dq - dq.sum() / (A * dq.shape[0])                       # one mean over batch and actions: every sample receives the batch's total
+        else:
+            g[:, 1:] = dq - dq.sum(axis=1, keepdims=True) / A
     else:
         g = dq
     grads = [None] * len(P)
@@ -296,5 +315,5 @@ def forward_f16x2_emulated(spec, flat_params, obs):
             z = mm(x, Wk) + b64
             x = (np.maximum(z, 0.0) if L["relu"] else z).astype(np.float32).astype(np.float64)
     if spec.dueling:
-        return x[:, 0:1] + x[:, 1:] - x[:, 1:].mean(axis=1, keepdims=True)
+        return x[:, 0:1] + x[:, 1:] - _dueling_mean(spec, x[:, 1:])
     return x

@@ -30,6 +30,8 @@ def main():
     dq = importlib.import_module("deepq-decoding_amd")
     if len(sys.argv) > 2 and sys.argv[2] == "range":
         return main_range(dq, out_dir, rank, world)
+    if len(sys.argv) > 2 and sys.argv[2] == "rangeauto":
+        return main_range(dq, out_dir, rank, world, default_path=True)
     if len(sys.argv) > 2 and sys.argv[2] == "fitrange":
         return main_fit_range(dq, out_dir, rank, world)
     if single:
@@ -57,7 +59,7 @@ def main():
     dist.destroy_process_group()
 
 
-def main_range(dq, out_dir, rank, world):
+def main_range(dq, out_dir, rank, world, default_path=False):
     """The range guard under several ranks: ONE rank's minibatch holds TD errors beyond the fused backward's range.  The whole update must
     be discarded on EVERY rank (the overflowing rank turns its gradient into NaNs, the all-reduce carries them to the others, the guarded Adam step skips
     and flags them), the replicas stay bit-identical, and every rank reports DQ_ERR_RANGE at the same synchronisation point."""
@@ -78,19 +80,32 @@ def main_range(dq, out_dir, rank, world):
     core.step_and_update(0.5)
     torch.cuda.synchronize()
     unchanged = bool(torch.equal(core.params, before))
-    raised = False
-    try:
-        core.read_metrics()
-    except dq.DeepQError as e:
-        raised = e.status == -6
-    if rank == 0:
-        core.reward_ring.zero_()
-    core.step_and_update(0.5)                                       # the loop carries on
+    raised, warned = False, False
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        try:
+            core.read_metrics()
+        except dq.DeepQError as e:
+            raised = e.status == -6
+        warned = any("measures the gradient scale" in str(x.message) for x in w)
+    if default_path:
+        # DQ_TD_AUTOSCALE unset: no error -- every rank warns at the SAME synchronisation, counts the one discarded update, and switches to the
+        # measured scale; the poisoned memory is then CARRIED (rank 0 keeps its 1e6 rewards), the replicas stay bit-identical
+        if rank == 0:
+            core.reward_ring.fill_(1e6)
+        for _ in range(3):
+            core.step_and_update(0.5)
+    else:
+        if rank == 0:
+            core.reward_ring.zero_()
+        core.step_and_update(0.5)                                   # the loop carries on
     core.read_metrics()
     chk = int(core.params.view(torch.int32).to(torch.int64).sum().item())
     finite = bool(torch.isfinite(core.params).all())
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
-        json.dump(dict(unchanged=unchanged, raised=raised, params=chk, finite=finite, moved=not torch.equal(core.params, before)), f)
+        json.dump(dict(unchanged=unchanged, raised=raised, warned=warned, auto_scale=bool(core.auto_scale), discarded=int(core.discarded_updates), params=chk,
+                       finite=finite, moved=not torch.equal(core.params, before)), f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -351,7 +351,8 @@ def test_a_td_error_beyond_the_host_known_scale_switches_the_loop_to_the_measure
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         core.read_metrics()
-    assert core.auto_scale is True and any("measures the gradient scale" in str(x.message) for x in w)
+    assert core.auto_scale is True and any("measures the gradient scale" in str(x.message) and "1 of the 1 updates" in str(x.message) for x in w)
+    assert core.discarded_updates == 1                              # counted on the device (dq_qnet_range_discarded), logged in the warning
     core.reward_ring.fill_(1e6)                                     # (the step above wrote a fresh slot)
     for _ in range(3):
         core.step_and_update(0.5)
@@ -367,7 +368,7 @@ def test_a_td_error_beyond_the_host_known_scale_switches_the_loop_to_the_measure
     core2.step_and_update(0.5)
     with pytest.raises(dq.DeepQError) as ei:
         core2.read_metrics()
-    assert ei.value.status == -6 and core2.auto_scale is False
+    assert ei.value.status == -6 and core2.auto_scale is False and core2.discarded_updates == 1
 
 
 def _make_agent(dq, model_shape, n_actions, batch_size=32, warmup=64, target=200, limit=5000, seed=(1, 2)):

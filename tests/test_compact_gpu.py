@@ -113,9 +113,9 @@ def test_forward_from_patch_words(dq, torch_mod, name, batch):
     # the workgroup-per-group kernels (DQ_CONV_FORM=group; the default at d = 5 is the wave-private form, csrc/conv_wave.hip): the persistent kernel and
     # the one-group kernel give the same bits (as for the uint8 form), and the same Q-values as the default form to round-off
     import os
-    old = {k: os.environ.get(k) for k in ("DQ_CONV_PERSIST", "DQ_CONV_FORM")}
+    old = {k: os.environ.get(k) for k in ("DQ_CONV_PERSIST",)}
     try:
-        os.environ["DQ_CONV_FORM"] = "group"
+        net.set_kernel_forms(conv_forward="group")
         os.environ["DQ_CONV_PERSIST"] = "2"
         q_p = net.forward_multi([dict(params=params, obs=patch, patch=True)])[0].cpu().numpy()
         os.environ["DQ_CONV_PERSIST"] = "0"
@@ -184,7 +184,7 @@ def test_wave_private_conv_forward(dq, torch_mod, monkeypatch, name):
         tiny = [net.forward_multi([dict(params=params, obs=obs_t[7:7 + n], packed=pk1, patch=True)])[0].clone() for n in (1, 2, 3, 31, 33)]
         return qs, g, alone, tiny
 
-    monkeypatch.delenv("DQ_CONV_FORM", raising=False)
+    net.set_kernel_forms(conv_forward="wave")
     qs, g, alone, tiny = run()
     refs = [O.forward(spec, flat, obs[:4099])[0], O.forward(spec, flat2, obs[:3])[0], None, O.forward(spec, flat2, obs[(idx + 4099 - 50) % 4099])[0]]
     for q, r in zip(qs, refs):
@@ -194,7 +194,7 @@ def test_wave_private_conv_forward(dq, torch_mod, monkeypatch, name):
         assert torch.equal(a, q)
     for n, q in zip((1, 2, 3, 31, 33), tiny):
         assert torch.equal(q, qs[0][7:7 + n]), n
-    monkeypatch.setenv("DQ_CONV_FORM", "group")
+    net.set_kernel_forms(conv_forward="group")
     qs_g, g_g, _, tiny_g = run()
     for a, b, r in zip(qs, qs_g, refs):
         scale = tol(b.cpu().numpy())
@@ -250,11 +250,28 @@ def test_sixteen_wave_conv_backward(dq, torch_mod, monkeypatch, name, batch):
     keep = O.dropout_keep_mask(seed, t, base + np.arange(batch), 512, 0.2)
     dq_ = (rng.randn(batch, spec.n_actions) / batch).astype(np.float32)
     g = {}
-    for form in ("16", "8"):
-        monkeypatch.setenv("DQ_CONV_BWD_FORM", form)
-        net.forward_multi([dict(params=params, obs=patch, patch=True, training=True, seed=seed, t=t, sample_base=base)])
+    # "16": the default -- the training forward (conv_wave_kernel) does not save a1, the backward recomputes it from the patch words (round 6); "16saved": the
+    # round-5 form, a1 through HBM; "8": fused_bwd.hip's kernel, always on saved planes
+    job = dict(params=params, obs=patch, patch=True, training=True, seed=seed, t=t, sample_base=base)
+    for form in ("16saved", "16", "8"):
+        if form == "16":
+            # poison the saved a1 planes first: a training forward in the saving form on OTHER observations (rows reversed) -- the recomputing forward below must
+            # leave them as they are, and a backward that still read them would differentiate the wrong activations
+            net.set_kernel_forms(conv_backward="16", conv_backward_a1="saved")
+            net.forward_multi([dict(job, obs=torch.flip(patch, dims=[0]).contiguous())])
+        net.set_kernel_forms(conv_backward=form[:2].rstrip("s"), conv_backward_a1="saved" if form == "16saved" else "recompute")
+        net.forward_multi([job])
         g[form] = net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy()
         assert np.array_equal(g[form], net.backward(params, torch.from_numpy(dq_).cuda()).cpu().numpy())
+    # recomputed a1 == saved a1, bit for bit: identical gradients
+    assert np.array_equal(g["16"], g["16saved"])
+    # a change of form between a training forward and its backward that leaves the backward without a1 is refused
+    net.set_kernel_forms(conv_backward="16", conv_backward_a1="recompute")
+    net.forward_multi([dict(params=params, obs=patch, patch=True, training=True, seed=seed, t=t, sample_base=base)])
+    net.set_kernel_forms(conv_backward="8")
+    with pytest.raises(dq.DeepQError):
+        net.backward(params, torch.from_numpy(dq_).cuda())
+    net.set_kernel_forms(conv_backward="default")
     _, cache = O.forward(spec, flat, obs, training=True, keep_masks=[keep])
     g_ref = O.backward(spec, flat, cache, dq_.astype(np.float64))
     assert np.abs(g["16"] - g_ref).max() < 2e-5 * max(np.abs(g_ref).max(), 1.0)

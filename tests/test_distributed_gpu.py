@@ -147,7 +147,23 @@ def test_range_guard_discards_the_update_on_every_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
     assert a == b, (a, b)
-    assert a["unchanged"] and a["raised"] and a["finite"] and a["moved"]
+    assert a["unchanged"] and a["raised"] and a["finite"] and a["moved"] and a["discarded"] == 1 and not a["auto_scale"]
+
+
+@pytest.mark.gpu
+def test_range_guard_default_path_keeps_two_ranks_identical_and_running(tmp_path):
+    """The DEFAULT settings (DQ_TD_AUTOSCALE unset): the same situation does not raise -- both ranks discard the update whole, warn at the same
+    synchronisation, count ONE discarded update each (dq_qnet_range_discarded: rank 1 learns of it through the NaNs of the all-reduced gradient), switch to
+    the measured gradient scale, and then carry rank 0's poisoned memory with finite, bit-identical parameters."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29553", os.path.join(ROOT, "tests", "_fit_two_ranks.py"), str(tmp_path), "rangeauto"]
+    env = _clean_env()
+    env.pop("DQ_TD_AUTOSCALE", None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (json.load(open(tmp_path / f"rank{k}.json")) for k in (0, 1))
+    assert a == b, (a, b)
+    assert a["unchanged"] and not a["raised"] and a["warned"] and a["auto_scale"] and a["discarded"] == 1 and a["finite"] and a["moved"]
 
 
 @pytest.mark.gpu

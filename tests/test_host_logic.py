@@ -476,6 +476,29 @@ def test_live_timing_samples_the_launches():
     assert bl.prof_stride(5) == 1 and bl.prof_stride(1) == 1
 
 
+def test_pmc_stamp_matches_sources():
+    """`roofline.traffic` of the driver's line comes from the committed PMC passes (profiles/pmc_traffic_*.json), which bench.py refuses when they were
+    taken with other kernel code (round 5: a comment edit orphaned them and BENCH_r05 carried `traffic: null`).  (a) the stamp hashes CODE only -- comments
+    and whitespace do not move it; (b) the committed passes carry the digest of the sources at HEAD and answer for the symbols the default runs launch."""
+    import importlib
+    bl = importlib.import_module("deepq-decoding_amd.bench_loop")
+    a = "int f(int x) { /* doc */ return x + 1;   // trailing\n}\n"
+    b = "int f(int x){\n  return x+1;\n}   /* other\n comment */\n"
+    assert bl._code_only(a) == bl._code_only(b) and bl._code_only(a) != bl._code_only(a.replace("+ 1", "+ 2"))
+    digest = bl.csrc_digest()
+    for mode, config, symbol in (("loop", "c3", "conv_wave_kernel"), ("loop", "c3", "conv_bwd16_kernel"), ("loop", "c3", "dense_chain_kernel"),
+                                 ("loop", "c5", "dense_chain_kernel"), ("loop", "c2", "conv_wave_kernel"), ("env", "c3", "env_kernel")):
+        rec = bl.pmc_record(mode, config)
+        assert rec is not None, f"profiles/pmc_traffic_{mode}_{config}.json is missing"
+        assert rec["csrc_sha256"] == digest, (f"profiles/pmc_traffic_{mode}_{config}.json was measured with other kernel code ({rec['csrc_sha256'][:12]} != "
+                                              f"{digest[:12]}): run tools/restamp_pmc.sh on the GPU box and commit profiles/pmc_traffic_*.json")
+        got = bl.pmc_traffic(symbol, mode, config)
+        assert got is not None and got > 0, (mode, config, symbol)
+    # a family alias or a form that did not run is NOT answered with another kernel's bytes
+    assert bl.pmc_traffic("conv_chain_kernel", "loop", "c3") is None
+    assert bl.pmc_traffic("conv_wave_kernel", "loop", "c3", minibatch=32) is None
+
+
 @pytest.mark.parametrize("name", ["training_history_d5_x_0.001", "training_history_d5_dp_0.001"])
 def test_reference_mean_eps_records_pin_the_step_arithmetic(dq, name):
     """The reference's own training records (trained_models/<family>/0.001/training_history.json, committed as arrays) pin keras-rl's step

@@ -32,7 +32,8 @@ def torch_forward(spec, flat, obs, keep=None):
                 x = torch.where(keep[mi], x / (1.0 - L["dropout"]), torch.zeros_like(x))
                 mi += 1
     if spec.dueling:
-        x = x[:, 0:1] + x[:, 1:] - x[:, 1:].mean(dim=1, keepdim=True)
+        m = x[:, 1:].mean() if getattr(spec, "dueling_mean", "row") == "batch" else x[:, 1:].mean(dim=1, keepdim=True)
+        x = x[:, 0:1] + x[:, 1:] - m
     return x
 
 
@@ -234,3 +235,48 @@ def test_dueling_layer_folds_into_one_matrix(name):
     assert np.abs(gh1 - s[:, None] * Wc[a_b] * mask).max() < 1e-12
     # Wc by the pack kernel's route: the plain product's row, folded along the row
     assert np.abs(Wc - fold(W2 @ W3).T).max() < 1e-12
+
+
+def test_dueling_mean_row_and_batch_forms():
+    """The one point of the update rule the tree cannot pin (oracle/dqn_oracle.py QNetSpec.dueling_mean): the dueling head's mean per
+    sample ("row": Wang et al. eq. 9, keras-rl master, what the HIP kernels fold into W3') or over batch AND actions ("batch": upstream keras-rl 0.4.2's
+    axis-less K.mean).  Checked here: (a) both oracle forms equal torch autograd of their own definition; (b) batch-of-one forwards are IDENTICAL -- every
+    acting / test forward and every shipped-agent check is form-independent; (c) at the reference's minibatch of 32 the forms differ by a per-batch shift of
+    the Q-values (argmax over actions unchanged within a sample) and by a gradient difference that is printed, not hidden."""
+    shape, A = SPECS["c3"]
+    row = O.QNetSpec(shape, C_LAYERS, FF_LAYERS, A, dueling_mean="row")
+    bat = O.QNetSpec(shape, C_LAYERS, FF_LAYERS, A, dueling_mean="batch")
+    rng = np.random.RandomState(11)
+    flat = O.glorot_init(row, (5, 6)).astype(np.float64) + rng.randn(row.n_params) * 0.01
+    B = 32
+    obs = (rng.rand(B, *shape) < 0.3).astype(np.float64)
+    q_row, c_row = O.forward(row, flat, obs)
+    q_bat, c_bat = O.forward(bat, flat, obs)
+    # (b) batch of one
+    for b in range(4):
+        q1r, _ = O.forward(row, flat, obs[b:b + 1])
+        q1b, _ = O.forward(bat, flat, obs[b:b + 1])
+        assert np.array_equal(q1r, q1b) and np.allclose(q1r[0], q_row[b], atol=1e-12)
+    # (c) the batch form shifts every sample's Q-values by (its own advantage mean - the batch's): same greedy action, different TD targets
+    adv = c_row["head_in"][:, 1:]
+    shift = adv.mean(axis=1, keepdims=True) - adv.mean()
+    assert np.allclose(q_bat, q_row + shift, atol=1e-12)
+    assert np.array_equal(q_bat.argmax(axis=1), q_row.argmax(axis=1))
+    # (a) + the gradient difference of one 32-sample update with the same targets
+    action = rng.randint(0, A, size=B)
+    y = rng.randn(B)
+    grads = {}
+    for name, spec, q, cache in (("row", row, q_row, c_row), ("batch", bat, q_bat, c_bat)):
+        _, _, dq = O.loss_and_grad(q, action, y)
+        g = O.backward(spec, flat, cache, dq)
+        tp = torch.tensor(flat, dtype=torch.float64, requires_grad=True)
+        tq = torch_forward(spec, tp, torch.tensor(obs))
+        assert np.allclose(tq.detach().numpy(), q, atol=1e-12)
+        (tq * torch.tensor(dq)).sum().backward()
+        assert np.allclose(g, tp.grad.numpy(), atol=1e-12), name
+        grads[name] = g
+    diff = np.abs(grads["row"] - grads["batch"]).max()
+    rel = np.linalg.norm(grads["row"] - grads["batch"]) / np.linalg.norm(grads["row"])
+    print(f"dueling mean, B = 32, random weights: max |Q_batch - Q_row| = {np.abs(shift).max():.3e}; gradient difference max {diff:.3e}, "
+          f"relative (2-norm) {rel:.3e}")
+    assert diff > 0.0          # the forms ARE different at B = 32: the choice is documented, not immaterial
