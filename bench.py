@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--minibatch", type=int, default=0, help="DQN minibatch per rank (default: n_envs)")
     ap.add_argument("--lattices", type=int, default=0, help="lattices per rank (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--env-steps-per-launch", type=int, default=32, help="--mode env: agent steps per environment launch (dq_env_act_steps); 1 = one launch per step")
+    ap.add_argument("--env-obs", default="patch", choices=["patch", "uint8"], help="--mode env: successor observations as the loop's patch words or as the reference's uint8 planes")
     ap.add_argument("--ratio-steps", type=int, default=100,
                     help="vector steps of the second timed leg at the reference's replay ratio (32 trained samples per environment step), run behind the "
                          "headline region of a default 1-GPU loop run and printed as `reference_replay_ratio`; 0 = skip it")
@@ -272,7 +274,7 @@ def main():
     mode = args.mode
 
     if mode == "env":
-        runner = EnvOnly(dq, cfg, n_local, rank)
+        runner = EnvOnly(dq, cfg, n_local, rank, steps_per_launch=args.env_steps_per_launch, obs_form=args.env_obs)
     else:
         runner = importlib.import_module("deepq-decoding_amd.bench_loop").FullLoop(
             dq, cfg, n_local, rank, world, args.minibatch or n_local, mode=mode, config_name=args.config, updates_per_step=max(1, args.updates_per_step))
@@ -435,45 +437,83 @@ def allreduce_probe(torch, dist, core, backend, iters=20):
 
 
 class EnvOnly:
-    """Environment kernel + device policy only (uniform over legal actions, auto-reset)."""
+    """Environment kernel + device policy only (uniform over legal actions, auto-reset): T agent steps per LAUNCH (dq_env_act_steps: selection, step / reset, the
+    transition into a replay ring whose slot advances on the device, the lattices' state in registers from step to step), so that the figure is the kernel's and
+    not one launch latency per 4096-lattice step (SURVEY.md section 7 "hard parts")."""
     dtype = "u64 bit-planes / u8"
 
-    def __init__(self, dq, cfg, n_local, rank):
+    def __init__(self, dq, cfg, n_local, rank, steps_per_launch=16, ring_slots=32, obs_form="patch"):
         import torch
         self.torch = torch
         self.cfg, self.n = cfg, n_local
         self.env = dq.VectorEnv(n_envs=n_local, env_id_base=rank * n_local, **cfg)
         self.env.reset()
-        self.action = torch.zeros(n_local, dtype=torch.int32, device="cuda")
+        self.T = max(1, int(steps_per_launch))
+        self.slots = max(ring_slots, 2)
+        dev = self.env.device
+        self.action = torch.zeros((self.slots, n_local), dtype=torch.int32, device=dev)
+        self.reward = torch.zeros((self.slots, n_local), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((self.slots, n_local), dtype=torch.uint8, device=dev)
+        # the successor observation as the LOOP stores it -- patch words, d * d u32 per lattice (DESIGN.md section 3) -- or as the reference's uint8 planes
+        self.obs_form = obs_form
+        self.obs = torch.zeros((self.slots, n_local) + tuple(self.env.obs_shape), dtype=torch.uint8, device=dev) if obs_form == "uint8" else None
+        self.patch = torch.zeros((self.slots, n_local, self.env.patch_stride), dtype=torch.int32, device=dev) if obs_form == "patch" else None
         self.t = 0
+        self.pending = 0             # steps of the last launch not yet counted
+        self.left = None             # steps left in the timed region (arm)
         self.bl = importlib.import_module("deepq-decoding_amd.bench_loop")
         self.L = importlib.import_module("deepq-decoding_amd._lib").lib()
         self.armed = False
+        self.launch_steps = []
 
     def arm(self, steps):
-        # ONE launch per step: the uniform-legal policy fused in front of the step (dq_env_act_step with no Q-values == dq_policy_select + dq_env_step);
         # a sample of the launches carries a HIP event pair (the dispatch's own timestamps, prof.hip)
-        self.armed = self.bl.prof_arm(self.L, "env_kernel", steps, 1)
+        self.pending, self.left = 0, steps
+        self.launch_steps = []
+        self.armed = self.bl.prof_arm(self.L, "env_kernel", (steps + self.T - 1) // self.T, 1)
 
     def step(self, timed):
-        self.env.act_step(self.t, q=None, eps=1.0, auto_reset=True, out_action=self.action)
-        self.t += 1
+        """One vector step; every T-th call launches the next T (the timed region's last launch: what is left of it)."""
+        if self.pending == 0:
+            k = self.T if self.left is None else max(1, min(self.T, self.left))
+            self.env.act_steps(k, self.t, self.action, self.reward, self.done, obs_ring=self.obs, patch_ring=self.patch, slot0=self.t % self.slots)
+            self.t += k
+            self.pending = k
+            if self.left is not None:
+                self.launch_steps.append(k)
+        self.pending -= 1
+        if self.left is not None:
+            self.left -= 1
 
     def config(self):
-        return dict(policy="uniform over legal actions (device, fused in front of the step: one launch)", auto_reset=True)
+        return dict(policy="uniform over legal actions (device, fused in front of the step)", auto_reset=True, steps_per_launch=self.T,
+                    ring_slots=self.slots, observations=("patch words (d*d u32 per lattice)" if self.obs_form == "patch" else "uint8 planes") + " into a replay ring")
 
     def report(self, steps, dt, world):
         if not self.armed:
             return {"roofline": None}
-        launches, total_ms = self.bl.prof_collect(self.L)
+        n, ms, lo, hi = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self.L.dq_prof_collect_spread(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(lo), ctypes.byref(hi))
+        symbol = self.L.dq_prof_kernel_symbol(0).decode() or "env_kernel"
+        self.L.dq_prof_arm(-1, 0)
+        launches, total_ms = n.value, ms.value
         if not launches:
             return {"roofline": None}
-        ms = total_ms / launches
-        bytes_per_launch = env_bytes_per_step(self.cfg) * self.n
-        achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-        return {"roofline": dict(kernel="env_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                                 frac=achieved / HBM_PEAK_GBS, traffic=self.bl.pmc_traffic("env_kernel", "env", "c3"), avg_launch_us=ms * 1e3,
-                                 launches_timed=launches, algorithmic_bytes_per_launch=bytes_per_launch)}
+        ms_l = total_ms / launches
+        # SURVEY.md 8(d): B_env per lattice-step = 2 S (state record read + written) + scalars + legal words + the uint8 observation; with T steps per launch the
+        # record moves once per LAUNCH, the rest once per step
+        S = 96 if self.cfg["d"] <= 5 else 160
+        per_step = env_bytes_per_step(self.cfg) - 2 * S
+        if self.obs_form == "patch":     # d * d words instead of the C x (2d+1)^2 uint8 image
+            layers = 1 if self.cfg["error_model"] == "X" else (3 if self.cfg["use_Y"] else 2)
+            per_step += 4 * self.cfg["d"] ** 2 - (self.cfg["volume_depth"] + layers) * (2 * self.cfg["d"] + 1) ** 2
+        k = sum(self.launch_steps) / max(1, len(self.launch_steps))          # steps per launch in the timed region
+        bytes_per_launch = self.n * (per_step * k + 2 * S)
+        achieved = bytes_per_launch / (ms_l * 1e-3) / 1e9
+        return {"roofline": dict(kernel=symbol, family="env_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                                 frac=achieved / HBM_PEAK_GBS, traffic=self.bl.pmc_traffic(symbol, "env", "c3"), avg_launch_us=ms_l * 1e3,
+                                 min_launch_us=lo.value * 1e3, max_launch_us=hi.value * 1e3, launches_timed=launches, steps_per_launch=k,
+                                 algorithmic_bytes_per_launch=bytes_per_launch, lattice_steps_per_s_in_kernel=self.n * k / (ms_l * 1e-3))}
 
 
 if __name__ == "__main__":

@@ -77,6 +77,12 @@ class EnvStepJob(ctypes.Structure):
                 ("was_reset_dev", ctypes.c_void_p), ("sample", ctypes.POINTER(SampleJob)), ("stats_dev", ctypes.c_void_p)]
 
 
+class EnvRing(ctypes.Structure):
+    """dq_env_ring (include/deepq_hip.h)."""
+    _fields_ = [("action_ring_dev", ctypes.c_void_p), ("reward_ring_dev", ctypes.c_void_p), ("done_ring_dev", ctypes.c_void_p), ("obs_ring_dev", ctypes.c_void_p),
+                ("patch_ring_dev", ctypes.c_void_p), ("patch_stride_words", ctypes.c_int32), ("n_slots", ctypes.c_int32), ("slot0", ctypes.c_int32)]
+
+
 _vp, _i, _u32, _u64, _dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_double
 _sz = ctypes.c_size_t
 _seedp = ctypes.POINTER(ctypes.c_uint32)
@@ -101,6 +107,7 @@ SIGNATURES = {
     "dq_env_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_act_step": (_i, [_vp, _vp, _dbl, _i, _seedp, _u64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dq_env_act_step_sample": (_i, [_vp, _vp, _dbl, _i, _seedp, _u64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(SampleJob), _vp]),
+    "dq_env_act_steps": (_i, [_vp, _i, _seedp, _u64, ctypes.POINTER(EnvRing), _i, _vp, _vp, _vp, _vp]),
     "dq_env_patch_output": (_i, [_vp, _vp, _i]),
     "dq_env_export_state": (_i, [_vp, _vp, _vp]),
     "dq_env_import_state": (_i, [_vp, _vp, _vp]),

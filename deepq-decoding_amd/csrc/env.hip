@@ -147,6 +147,12 @@ __global__ __launch_bounds__(256) void env_kernel(EnvParams p) {
     else env_block<ENVS_PER_BLOCK>(p, (int)blockIdx.x, smem);
 }
 
+// p.steps agent steps of the lattices in one launch (env_dev.h env_block2<EPB, true>; dq_env_act_steps): d <= 5 (two lattices per wave)
+__global__ __launch_bounds__(256) void env_multi_kernel(EnvParams p) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    env_block2<2 * ENVS_PER_BLOCK, true>(p, (int)blockIdx.x, smem);
+}
+
 // ---- state export / import (tests, checkpointing) ------------------------------------------------
 __global__ void env_export_kernel(const EnvTables* tab, const u64* state, u64* out, int n_envs, int sw, int depth) {
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -306,6 +312,7 @@ long dq_struct_size(int id) {
         case 4: return (long)sizeof(dq_qnet_job);
         case 5: return (long)sizeof(dq_td_job);
         case 6: return (long)sizeof(dq_env_step_job);
+        case 7: return (long)sizeof(dq_env_ring);
         default: return -1;
     }
 }
@@ -735,6 +742,46 @@ dq_status dq_env_act_step_sample(dq_env* E, const float* q_dev, double eps, int 
     DQ_REQUIRE(sample, DQ_ERR_INVALID, "dq_env_act_step_sample: null sampling job");
     return act_step(E, q_dev, eps, masked_greedy, seed, t, action_dev, auto_reset, obs_dev, reward_dev, done_dev, legal_dev, lifetime_dev,
                     was_reset_dev, sample, stream);
+}
+
+dq_status dq_env_act_steps(dq_env* E, int n_steps, const uint32_t seed[2], uint64_t t0, const dq_env_ring* ring, int auto_reset, uint64_t* legal_dev,
+                           uint32_t* lifetime_dev, uint8_t* was_reset_dev, void* stream) {
+    DQ_REQUIRE(E && ring && seed && n_steps >= 1, DQ_ERR_INVALID, "dq_env_act_steps: null argument / no steps");
+    DQ_REQUIRE(ring->action_ring_dev && ring->n_slots >= 2 && ring->slot0 >= 0 && ring->slot0 < ring->n_slots, DQ_ERR_INVALID, "dq_env_act_steps: bad ring");
+    DQ_REQUIRE(!ring->patch_ring_dev || (ring->patch_stride_words >= E->cfg.d * E->cfg.d && 4 * E->cfg.volume_depth + E->info.n_action_layers <= 32),
+               DQ_ERR_INVALID, "dq_env_act_steps: patch words need stride_words >= d * d and at most 32 data bits per pixel");
+    const size_t n = (size_t)E->cfg.n_envs, obs_size = (size_t)E->info.obs_c * E->P;
+    if (env_pairs(E) && !E->mlp_layers) {
+        // ONE launch: the lattices' state stays in registers over the steps, every step's transition goes to its ring slot
+        PatchDisarm disarm{E};
+        EnvParams p;
+        dq_status rc = fill_act_step(E, nullptr, 1.0, 0, seed, t0, ring->action_ring_dev, auto_reset, ring->obs_ring_dev, ring->reward_ring_dev,
+                                     ring->done_ring_dev, legal_dev, lifetime_dev, was_reset_dev, nullptr, 64 * ENVS_PER_BLOCK, p);
+        if (rc != DQ_OK) return rc;
+        rc = fill_common(E, p, ENVS_PER_BLOCK);
+        if (rc != DQ_OK) return rc;
+        DQ_REQUIRE(p.pair, DQ_ERR_STATE, "dq_env_act_steps: DQ_ENV_PAIR=1 restricts the two-per-wave form to riders");
+        p.patch = ring->patch_ring_dev; p.patch_stride = ring->patch_stride_words;
+        p.steps = n_steps; p.ring_slots = ring->n_slots; p.ring_slot0 = ring->slot0;
+        dq_launch(DQ_K_ENV, "env_multi_kernel", env_multi_kernel, dim3(p.env_blocks), dim3(64 * ENVS_PER_BLOCK),
+                  env_block_lds(2 * ENVS_PER_BLOCK, ENVS_PER_BLOCK, p.obs_size, p.lut_words), (hipStream_t)stream, p);
+        DQ_LAUNCH_CHECK();
+        return DQ_OK;
+    }
+    // lattices past half a wave (d = 7) / a Dense-stack referee: the same steps as n_steps launches of dq_env_act_step -- the same bits
+    for (int s = 0; s < n_steps; ++s) {
+        const size_t cur = (size_t)((ring->slot0 + s) % ring->n_slots), nxt = (size_t)((ring->slot0 + s + 1) % ring->n_slots);
+        if (ring->patch_ring_dev) {
+            const dq_status rc = dq_env_patch_output(E, ring->patch_ring_dev + nxt * n * ring->patch_stride_words, ring->patch_stride_words);
+            if (rc != DQ_OK) return rc;
+        }
+        const dq_status rc = dq_env_act_step(E, nullptr, 1.0, 0, seed, t0 + (uint64_t)s, ring->action_ring_dev + cur * n, auto_reset,
+                                             ring->obs_ring_dev ? ring->obs_ring_dev + nxt * n * obs_size : nullptr,
+                                             ring->reward_ring_dev ? ring->reward_ring_dev + cur * n : nullptr, ring->done_ring_dev ? ring->done_ring_dev + cur * n : nullptr,
+                                             legal_dev, lifetime_dev, was_reset_dev, stream);
+        if (rc != DQ_OK) return rc;
+    }
+    return DQ_OK;
 }
 
 dq_status dq_env_patch_output(dq_env* E, uint32_t* patch_dev, int stride_words) {

@@ -70,6 +70,9 @@ struct EnvParams {
     // padding_syndrome / padding_actions (ENV:273-314).  Row i = lattice i, patch_stride words apart.  NULL: not written.
     u32* patch;
     int patch_stride;
+    // several agent steps in one launch (env_block2<EPB, true>, dq_env_act_steps): action / reward / done / obs / patch are RING bases ([ring_slots][n_envs] ...),
+    // step s writes slot (ring_slot0 + s) mod ring_slots (the successor observation: the slot behind it); policy counter pt + s
+    int steps, ring_slots, ring_slot0;
 };
 
 // The lattice's patch words (EnvParams.patch): lane p < d2 composes pixel p's word from the volume words `vol` (LDS, lane-shared) and the
@@ -414,7 +417,11 @@ static __device__ __forceinline__ u64 half_bcast64(u64 v, int src) {
     return ((u64)hi << 32) | lo;
 }
 
-template <int EPB>
+// MULTI (round 6, dq_env_act_steps): p.steps consecutive agent steps of the block's lattices in ONE launch -- selection (uniform over the legal moves: no Q row),
+// step / auto-reset, transition into the replay ring --, the lattice's state carried in registers from step to step, the outputs of step s going to ring slot
+// (ring_slot0 + s) mod ring_slots (action, reward, done) and the successor observation to the slot behind it: an acting loop of T steps costs one launch
+// latency instead of T.  Same words, same bits as T launches (policy counter pt + s).
+template <int EPB, bool MULTI = false>
 static __device__ __forceinline__ void env_block2(const EnvParams& p, const int block, u8* __restrict__ smem) {
     constexpr int THREADS = 32 * EPB;
     u64* s_vol = reinterpret_cast<u64*>(smem);                              // [EPB][16]
@@ -460,16 +467,32 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
 
     u64 comp0 = 0, comp1 = 0;
     if (p.stats && hl < 4) s_est2[slot][hl] = 0;
+    // the lattice's state: loaded once, carried over the steps of a MULTI launch
+    u64 xmask = 0, zmask = 0, acted = 0, round = 0, legal0 = 0, legal1 = 0;
+    u32 lifetime = 0;
+    int done = 0;
     if (active) {
-        u64 xmask = half_bcast64(word, 0), zmask = half_bcast64(word, 1), acted = half_bcast64(word, 2);
-        u64 round = half_bcast64(word, 3);
+        xmask = half_bcast64(word, 0); zmask = half_bcast64(word, 1); acted = half_bcast64(word, 2);
+        round = half_bcast64(word, 3);
         comp0 = half_bcast64(word, 4);
         comp1 = half_bcast64(word, 5);
-        u64 legal0 = half_bcast64(word, 6), legal1 = half_bcast64(word, 7);
+        legal0 = half_bcast64(word, 6); legal1 = half_bcast64(word, 7);
         const u64 meta = half_bcast64(word, 8);
-        u32 lifetime = (u32)meta;
-        int done = (int)((meta >> 32) & 1);
+        lifetime = (u32)meta;
+        done = (int)((meta >> 32) & 1);
         if (hl >= STATE_FIXED && hl < STATE_FIXED + p.depth) vol[hl - STATE_FIXED] = word;
+    }
+    const int n_steps = MULTI ? p.steps : 1;
+  for (int step_no = 0; step_no < n_steps; ++step_no) {
+    // this step's outputs: the launch's own, or (MULTI) the ring slots of step step_no
+    int32_t* const action_out = MULTI ? p.action_out + (size_t)((p.ring_slot0 + step_no) % p.ring_slots) * p.n_envs : p.action_out;
+    float* const reward_out = MULTI && p.reward ? p.reward + (size_t)((p.ring_slot0 + step_no) % p.ring_slots) * p.n_envs : p.reward;
+    u8* const done_out = MULTI && p.done ? p.done + (size_t)((p.ring_slot0 + step_no) % p.ring_slots) * p.n_envs : p.done;
+    u8* const obs_out = MULTI && p.obs ? p.obs + (size_t)((p.ring_slot0 + step_no + 1) % p.ring_slots) * p.n_envs * p.obs_size : p.obs;
+    u32* const patch_out = MULTI && p.patch ? p.patch + (size_t)((p.ring_slot0 + step_no + 1) % p.ring_slots) * p.n_envs * p.patch_stride : p.patch;
+    const u64 pt = MULTI ? p.pt + (u64)step_no : p.pt;
+    const bool last_step = step_no + 1 == n_steps;
+    if (active) {
         DQ_STAMP(DQ_TAG_ENV, 1);
 
         bool do_reset;
@@ -487,7 +510,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
         int a_sel = 0;
         if (p.policy) {                                                     // EpsGreedyQPolicy / GreedyQPolicy(masked_greedy), see policy.hip
             u32 w[4];
-            philox4x32_10((u32)p.pt, (u32)(p.pt >> 32), p.env_id_base + (u32)i, (u32)DQ_STREAM_POLICY << 16, p.pseed0, p.pseed1, w);
+            philox4x32_10((u32)pt, (u32)(pt >> 32), p.env_id_base + (u32)i, (u32)DQ_STREAM_POLICY << 16, p.pseed0, p.pseed1, w);
             if (p.q == nullptr || (u64)w[1] < p.T_eps) {                    // explore: k-th smallest legal action
                 const int n_legal = __popcll(legal0) + __popcll(legal1);
                 a_sel = kth_set_bit128(legal0, legal1, (int)__umulhi(w[0], (u32)n_legal));
@@ -510,7 +533,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
                 dq_argmax_take(best, best_a, __shfl_xor(best, 16), __shfl_xor(best_a, 16));   // ... combined: every lane of the half ends with the result
                 a_sel = best_a;
             }
-            if (hl == 0) p.action_out[i] = a_sel;
+            if (hl == 0) action_out[i] = a_sel;
         }
         DQ_STAMP(DQ_TAG_ENV, 2);
         if (do_step) {
@@ -595,13 +618,13 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
         o = hl == 3 ? round : o;  o = hl == 4 ? comp0 : o;  o = hl == 5 ? comp1 : o;
         o = hl == 6 ? legal0 : o; o = hl == 7 ? legal1 : o; o = hl == 8 ? meta_out : o;
         if (hl >= STATE_FIXED && hl < STATE_FIXED + p.depth) o = vol[hl - STATE_FIXED];
-        if (hl < p.sw) rec[hl] = o;
+        if (hl < p.sw && (!MULTI || last_step)) rec[hl] = o;
         if (hl == 0) {
-            if (p.reward) p.reward[i] = reward;
-            if (p.done) p.done[i] = (u8)done;
-            if (p.lifetime) p.lifetime[i] = lifetime;
-            if (p.was_reset) p.was_reset[i] = (u8)(p.mode == 1 && do_reset);
-            if (p.legal) { p.legal[2 * (size_t)i] = legal0; p.legal[2 * (size_t)i + 1] = legal1; }
+            if (reward_out) reward_out[i] = reward;
+            if (done_out) done_out[i] = (u8)done;
+            if (p.lifetime && (!MULTI || last_step)) p.lifetime[i] = lifetime;
+            if (p.was_reset && (!MULTI || last_step)) p.was_reset[i] = (u8)(p.mode == 1 && do_reset);
+            if (p.legal && (!MULTI || last_step)) { p.legal[2 * (size_t)i] = legal0; p.legal[2 * (size_t)i + 1] = legal1; }
             if (p.stats) {                                                  // dq_episode_stats' sums for this lattice
                 const bool stepped = p.mode == 1 && !do_reset, ended = stepped && done;
                 s_est2[slot][0] = ended; s_est2[slot][1] = ended ? lifetime : 0;
@@ -612,7 +635,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
 
         // ---- observation planes into the LDS stage (ENV:174-175, 200-201, 273-314): this lane's cells (hl, hl + 32, ...) of every plane, their
         //      table words from registers (env_block's comment) -------------------------------------------------------------------------------
-        if (p.obs) {
+        if (obs_out) {
             u8* st = s_stage + slot * p.obs_size;
             for (int j = 0; j < p.depth; ++j) {
                 const u64 v = vol[j];
@@ -637,14 +660,35 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
                 }
             }
         }
-        if (p.patch) {                                                      // compact observation (env_block's comment)
+        if (patch_out) {                                                    // compact observation (env_block's comment)
             env_wave_sync();
             const u32 w = env_patch_word(p, vol, comp0, comp1, pstab, hl);
-            if (hl < p.d2) p.patch[(size_t)i * p.patch_stride + hl] = w;
+            if (hl < p.d2) patch_out[(size_t)i * p.patch_stride + hl] = w;
+            if (MULTI) env_wave_sync();                                     // (the next step's volume overwrites the words these lanes have just read)
         }
         DQ_STAMP(DQ_TAG_ENV, 6);
     }
 
+    if constexpr (MULTI) {
+        // uint8 planes: the block's stage leaves for this step's ring slot; a barrier each side (the next step refills the stage).  No bookkeeping,
+        // no sampling in this form (dq_env_act_steps)
+        if (obs_out) {                                                      // block-uniform
+            __syncthreads();
+            const int first = block * EPB, n_valid = min(EPB, p.n_envs - first), total = n_valid * p.obs_size;
+            u8* g = obs_out + (size_t)first * p.obs_size;
+            if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+                const env_u32x4* s128 = reinterpret_cast<const env_u32x4*>(s_stage);
+                env_u32x4* g128 = reinterpret_cast<env_u32x4*>(g);
+                const int nq = total >> 4;
+                for (int k = tid; k < nq; k += THREADS) g128[k] = s128[k];
+                for (int k = (nq << 4) + tid; k < total; k += THREADS) g[k] = s_stage[k];
+            } else {
+                for (int k = tid; k < total; k += THREADS) g[k] = s_stage[k];
+            }
+            __syncthreads();
+        }
+        continue;
+    }
     if (!p.obs && !p.stats) { env_inline_sampling<THREADS>(p, block); return; }    // block-uniform
     __syncthreads();                                                        // the stage (and the bookkeeping words) visible
     DQ_STAMP(DQ_TAG_ENV, 7);
@@ -679,6 +723,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
     DQ_STAMP(DQ_TAG_ENV, 8);
     env_inline_sampling<THREADS>(p, block);
     DQ_STAMP(DQ_TAG_ENV, 9);
+  }     // (steps of a MULTI launch; one trip otherwise)
 }
 
 // env.hip: validates the arguments of dq_env_act_step(_sample) and fills the parameters of a step WITHOUT launching it: the caller

@@ -374,6 +374,22 @@ class VectorEnv:
                          ptr(obs), ptr(self.reward), ptr(self.done), ptr(self.legal), ptr(self.lifetime), ptr(self.was_reset), self._stream())
         return out_action
 
+    def act_steps(self, n_steps, t0, action_ring, reward_ring=None, done_ring=None, obs_ring=None, patch_ring=None, slot0=0, auto_reset=True):
+        """n_steps agent steps of an acting loop under the uniform-over-legal policy in ONE launch (include/deepq_hip.h dq_env_act_steps): step s = policy counter
+        t0 + s; its transition goes to slot (slot0 + s) mod T of the rings `action_ring` int32 [T, n], `reward_ring` float32 [T, n], `done_ring` uint8 [T, n], the
+        successor observation to the slot behind it of `obs_ring` uint8 [T, n, C, H, W] / `patch_ring` int32 [T, n, stride].  self.legal / lifetime / was_reset hold
+        the last step's values; self.obs / reward / done are NOT updated (they live in the rings).  Same bits as n_steps calls of act_step(t0 + s, q=None)."""
+        if self.wide:
+            raise NotImplementedError("act_steps: not offered by the wide environment")
+        T = int(action_ring.shape[0])
+        for r in (action_ring, reward_ring, done_ring, obs_ring, patch_ring):
+            assert r is None or (r.is_contiguous() and int(r.shape[0]) == T and int(r.shape[1]) == self.n_envs)
+        ring = _lib.EnvRing(action_ring_dev=ptr(action_ring), reward_ring_dev=ptr(reward_ring), done_ring_dev=ptr(done_ring), obs_ring_dev=ptr(obs_ring),
+                            patch_ring_dev=ptr(patch_ring), patch_stride_words=int(patch_ring.shape[2]) if patch_ring is not None else 0, n_slots=T, slot0=int(slot0) % T)
+        seed = (ctypes.c_uint32 * 2)(*self.seed)
+        self._launch(self.L.dq_env_act_steps, self._h, int(n_steps), seed, int(t0), ctypes.byref(ring), int(auto_reset), ptr(self.legal), ptr(self.lifetime),
+                     ptr(self.was_reset), self._stream())
+
     def select_actions(self, t, q=None, eps=1.0, masked_greedy=False, out=None):
         """Epsilon-greedy over the legal set on the device (include/deepq_hip.h: dq_policy_select)."""
         if out is None:

@@ -187,6 +187,26 @@ dq_status dq_env_act_step_sample(dq_env* env, const float* q_dev, double eps, in
                                  uint64_t* legal_dev, uint32_t* lifetime_dev, uint8_t* was_reset_dev, const dq_sample_job* sample,
                                  void* stream);
 
+/* n_steps consecutive agent steps of an ACTING loop in one launch (round 6; SURVEY.md section 7 "hard parts": a 4096-lattice step is launch-latency-bound):
+ * per step s = 0 .. n_steps - 1 -- dq_env_act_step with q_dev == NULL (uniform over the legal moves: keras-rl's warm-up / random policy), policy counter
+ * t0 + s -- the transition lands in the caller's replay ring: slot c = (slot0 + s) mod n_slots of action_ring_dev int32 [n_slots][n_envs], reward_ring_dev
+ * float [n_slots][n_envs] and done_ring_dev uint8 [n_slots][n_envs] (each nullable but the first), the successor observation in slot c + 1 (mod n_slots) of
+ * obs_ring_dev uint8 [n_slots][n_envs][C][H][W] and / or patch_ring_dev uint32 [n_slots][n_envs][patch_stride_words] (nullable).  legal_dev / lifetime_dev /
+ * was_reset_dev receive the LAST step's values.  Same bits as n_steps calls of dq_env_act_step(NULL, ...) with the same counters (tests run the C oracle's 60-step
+ * comparison through this entry).  d <= 5 runs as ONE launch with the lattices' state in registers from step to step; d = 7 (and a Dense-stack referee) as
+ * n_steps launches.  Does not consume a dq_env_patch_output arming. */
+typedef struct dq_env_ring {
+    int32_t* action_ring_dev;
+    float* reward_ring_dev;
+    uint8_t* done_ring_dev;
+    uint8_t* obs_ring_dev;
+    uint32_t* patch_ring_dev;
+    int32_t patch_stride_words;
+    int32_t n_slots, slot0;
+} dq_env_ring;
+dq_status dq_env_act_steps(dq_env* env, int n_steps, const uint32_t seed[2], uint64_t t0, const dq_env_ring* ring, int auto_reset, uint64_t* legal_dev,
+                           uint32_t* lifetime_dev, uint8_t* was_reset_dev, void* stream);
+
 /* Compact observation ("patch words").  The observation the reference builds -- padding_syndrome / padding_actions,
  * Environments.py:273-314 -- feeds Conv2D(64, 3, strides=2) (Function_Library.py:353): output pixel (oy, ox) of that convolution sees
  * the 3 x 3 patch at padded cell (2 oy, 2 ox), of which only the four CORNERS of every syndrome plane (even-even cells: grid cells

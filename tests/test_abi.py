@@ -68,6 +68,6 @@ def test_struct_layouts_match_the_library(dq):
     import importlib
     L = importlib.import_module("deepq-decoding_amd._lib")
     lib = L.lib()
-    for i, st in enumerate((L.EnvCfg, L.EnvInfo, L.SampleJob, L.QNetCfg, L.QNetJob, L.TdJob, L.EnvStepJob)):
+    for i, st in enumerate((L.EnvCfg, L.EnvInfo, L.SampleJob, L.QNetCfg, L.QNetJob, L.TdJob, L.EnvStepJob, L.EnvRing)):
         assert lib.dq_struct_size(i) == ctypes.sizeof(st), (i, st.__name__, lib.dq_struct_size(i), ctypes.sizeof(st))
     assert lib.dq_struct_size(99) == -1

@@ -220,6 +220,55 @@ def test_full_size_vs_c_oracle(dq, torch_mod, name, n_envs, steps):
     env.close()
 
 
+@pytest.mark.parametrize("name,n_envs,steps,chunk", [("c3", 4096, 60, 16), ("c2", 4096, 40, 7), ("c3", 1027, 25, 25), ("c3y", 2048, 30, 8), ("d3dp", 4096, 24, 5),
+                                                     ("c5", 1024, 18, 6), ("d7x", 512, 12, 4)])
+def test_act_steps_entry_vs_c_oracle(dq, torch_mod, name, n_envs, steps, chunk):
+    """dq_env_act_steps: `chunk` agent steps per LAUNCH -- selection (uniform over legal), step / auto-reset, transition into the ring with the
+    slot advanced on the device, the lattices' state in registers from step to step (d <= 5; d = 7 takes the per-step fallback) -- against the C oracle stepped one
+    step at a time: every ring entry of every step (action, reward, done, uint8 observation AND patch words), and the final state, bit for bit.  The 60-step c3
+    comparison of test_full_size_vs_c_oracle runs through this entry; a ring of 9 slots makes the slot number wrap inside a launch."""
+    from oracle import c_oracle
+    torch = torch_mod
+    cfg = CONFIGS[name]
+    seed, base = (0x5EED, 0xD0DEC0DE), 4096 * 3
+    env = dq.VectorEnv(n_envs=n_envs, seed=seed, env_id_base=base, **cfg)
+    ref = c_oracle.COracleEnv(n_envs=n_envs, seed=seed, env_id_base=base, **cfg)
+    env.reset()
+    ref.reset()
+    T = 9
+    dev = env.device
+    action = torch.full((T, n_envs), -7, dtype=torch.int32, device=dev)
+    reward = torch.full((T, n_envs), -7.0, dtype=torch.float32, device=dev)
+    done = torch.full((T, n_envs), 7, dtype=torch.uint8, device=dev)
+    obs = torch.full((T, n_envs) + tuple(env.obs_shape), 7, dtype=torch.uint8, device=dev)
+    patch = torch.zeros((T, n_envs, env.patch_stride), dtype=torch.int32, device=dev)
+    slot, t = 5, 0
+    while t < steps:
+        k = min(chunk, steps - t)
+        env.act_steps(k, t, action, reward, done, obs_ring=obs, patch_ring=patch, slot0=slot)
+        a_h, r_h, d_h, o_h, p_h = (x.cpu().numpy() for x in (action, reward, done, obs, patch))
+        for s in range(k):
+            a_ref = ref.policy_uniform_legal(t + s)
+            ref.step(a_ref, auto_reset=True)
+            c, nx = (slot + s) % T, (slot + s + 1) % T
+            if k - s <= T - 1:      # (a launch longer than the ring overwrites its own oldest slots: only the surviving ones can be compared)
+                assert np.array_equal(a_h[c], a_ref), (name, "action", t + s)
+                assert np.array_equal(r_h[c], ref.reward), (name, "reward", t + s)
+                assert np.array_equal(d_h[c], ref.done), (name, "done", t + s)
+            if k - s <= T - 1:
+                assert np.array_equal(o_h[nx], ref.obs), (name, "obs", t + s)
+                assert np.array_equal(env.patch_to_obs(patch[nx]).cpu().numpy(), ref.obs), (name, "patch", t + s)
+        slot, t = (slot + k) % T, t + k
+        assert np.array_equal(env.lifetime.cpu().numpy().view(np.uint32), ref.lifetime), (name, "lifetime", t)
+        assert np.array_equal(_np_u64(env.legal), ref.legal), (name, "legal", t)
+        assert np.array_equal(env.was_reset.cpu().numpy(), ref.was_reset)
+    st, rs = _np_u64(env.export_state()), ref.export()
+    assert np.array_equal(st[:, 0], rs["xmask"]) and np.array_equal(st[:, 1], rs["zmask"])
+    assert np.array_equal(st[:, 2], rs["true_word"]) and np.array_equal(st[:, 3], rs["summed"])
+    assert np.array_equal(st[:, 5], rs["round"]) and np.array_equal(st[:, 11:], rs["volume"])
+    env.close()
+
+
 def test_sharding_invariance(dq, torch_mod):
     """Results depend on the global lattice id only: 2 x 512 lattices == 1 x 1024 lattices."""
     torch = torch_mod

@@ -487,7 +487,7 @@ def test_pmc_stamp_matches_sources():
     assert bl._code_only(a) == bl._code_only(b) and bl._code_only(a) != bl._code_only(a.replace("+ 1", "+ 2"))
     digest = bl.csrc_digest()
     for mode, config, symbol in (("loop", "c3", "conv_wave_kernel"), ("loop", "c3", "conv_bwd16_kernel"), ("loop", "c3", "dense_chain_kernel"),
-                                 ("loop", "c5", "dense_chain_kernel"), ("loop", "c2", "conv_wave_kernel"), ("env", "c3", "env_kernel")):
+                                 ("loop", "c5", "dense_chain_kernel"), ("loop", "c2", "conv_wave_kernel"), ("env", "c3", "env_multi_kernel")):
         rec = bl.pmc_record(mode, config)
         assert rec is not None, f"profiles/pmc_traffic_{mode}_{config}.json is missing"
         assert rec["csrc_sha256"] == digest, (f"profiles/pmc_traffic_{mode}_{config}.json was measured with other kernel code ({rec['csrc_sha256'][:12]} != "
