@@ -642,7 +642,8 @@ class DQNCore:
             # from the first update (nothing is ever discarded).
             n_lost = self.net.range_discarded()
             self.discarded_updates += n_lost
-            if e.status != -6 or self.auto_scale or os.environ.get("DQ_TD_AUTOSCALE") is not None:
+            # (the FORWARD's guard -- a parameter or activation outside the f16 pieces' range: a diverged run -- is always fatal: no gradient scale helps)
+            if e.status != -6 or "[forward]" in str(e) or self.auto_scale or os.environ.get("DQ_TD_AUTOSCALE") is not None:
                 raise
             self.auto_scale = True
             self.range_switches = getattr(self, "range_switches", 0) + 1

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
     };
     int p = wave;
     if (p >= P) return;                                             // wave-uniform; no barrier follows
+    range_mask rmax = 0;                                            // the forward's range guard (qnet.h range_track): every layer's output where it is produced
     u32 by[2][T1], byn[2][T1];
     Pair cur, nxt;
     CW_PAIR_OF(cur, p); CW_PAIR_OF(nxt, p + CW_WAVES);
@@ -209,9 +210,11 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
                     const u32x4 bits = CW_BITS_LIVE ? bitsr[s][u] : *reinterpret_cast<const u32x4*>(smem + CW_W_END * 16 + la[s][u]);
                     const f32x4 ah = MFMA_F16(w1h, bits, z), al = MFMA_F16(w1l, bits, z);
                     const f32x4 vs = f16x2_sum(ah, al);
+                    const f32x4 rv = {relu1(vs[0]), relu1(vs[1]), relu1(vs[2]), relu1(vs[3])};
+                    range_track4(rmax, rv);
                     uint2 hp, lp;
-                    split_f16x2_pair(relu1(vs[0]), relu1(vs[1]), hp.x, lp.x);
-                    split_f16x2_pair(relu1(vs[2]), relu1(vs[3]), hp.y, lp.y);
+                    split_f16x2_pair(rv[0], rv[1], hp.x, lp.x);
+                    split_f16x2_pair(rv[2], rv[3], hp.y, lp.y);
                     *reinterpret_cast<uint2*>(s_img + s * SM + wa1[u]) = hp;
                     *reinterpret_cast<uint2*>(s_img + s * SM + PL + wa1[u]) = lp;
                 }
@@ -257,7 +260,9 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 u32 h, l;
-                split_f16x2_pair(relu1(vs[0][r]), relu1(vs[1][r]), h, l);
+                const float r0 = relu1(vs[0][r]), r1 = relu1(vs[1][r]);
+                range_track(rmax, r0, r1);
+                split_f16x2_pair(r0, r1, h, l);
                 *reinterpret_cast<u32*>(s_img + s * SM + wa2[r]) = h;
                 *reinterpret_cast<u32*>(s_img + s * SM + PL + wa2[r]) = l;
             }
@@ -305,8 +310,11 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) vs[t] = f16x2_sum(acc3[s][t][0], acc3[s][t][1]) + f32x4{bias3[t], bias3[t], bias3[t], bias3[t]};
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * kb + r < R3) *reinterpret_cast<f32x2*>(out + go3 + 128 * r) = f32x2{relu1(vs[0][r]), relu1(vs[1][r])};
+            for (int r = 0; r < 4; ++r) {
+                const float r0 = relu1(vs[0][r]), r1 = relu1(vs[1][r]);
+                range_track(rmax, r0, r1);                          // (rows past R3 are clamped copies of real rows)
+                if (4 * kb + r < R3) *reinterpret_cast<f32x2*>(out + go3 + 128 * r) = f32x2{r0, r1};
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the next pair's quarter images overwrite a2: behind conv3's reads, in order)
         if (p == wave) CW_STAMP(2);
@@ -318,6 +326,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
 #pragma unroll
             for (int u = 0; u < T1; ++u) by[s][u] = byn[s][u];
     }
+    range_report(rmax, a.range_flag);
     CW_STAMP(3);
     CW_STAMP(7);                                                    // (shader cycles of this wave's life)
 }

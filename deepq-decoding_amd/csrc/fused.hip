@@ -89,6 +89,7 @@ struct ConvChainArgs {
     // patch-word input (the kernels' KG1 == 0 instances; qnet.h PT_*, c1c, b1p): observation rows are `slot` bytes of u32 words, 16-byte aligned
     int off_lut;                       // LDS: byte -> its eight bits as f16 0 / 1 (256 x 16 bytes), built by the workgroup
     int pk_c1c, pk_b1p;                // u32x4 offsets of the compact first kernel and of the per-pixel bias table inside a job's packed buffer
+    unsigned* range_flag;              // the forward's range guard (qnet.h range_report), nullable
 };
 
 // Patch-word input: the byte -> eight f16 (0 / 1) table every workgroup builds once (entry b, half e = bit e of b)
@@ -140,7 +141,7 @@ template <int CIN, int COUT, int KS, int RR, int NTT, bool SWZ = false, int PADI
 __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__ in, int lo_in, int ih, int iw, int oh, int ow, int M,
                                               F16x2 (&ring)[RR][NTT], const u32x4* __restrict__ pk, const float* __restrict__ bias,
                                               unsigned short* __restrict__ out_lds, int lo_out, float* __restrict__ out_g, int wave, int lane,
-                                              const int* __restrict__ rowtab, int pre0, int pre1) {
+                                              const int* __restrict__ rowtab, int pre0, int pre1, range_mask& rbad) {
     using SH = ConvShape<CIN, COUT, KS>;
     constexpr int NT = SH::NT, PSI = SWZ ? CIN : CIN + PADI, PSO = COUT + 8, CB = SH::CB, NB = SH::NB, R = SH::R;
     static_assert(NT == 2 && CIN % 32 == 0 && RR == R && NTT == NT, "written for 32 output channels, CIN a multiple of 32");
@@ -220,6 +221,7 @@ __device__ __forceinline__ void conv_from_lds(const unsigned short* __restrict__
                 const int mo = (t0 + u) * 16 + 4 * kb + r;
                 if (mo >= M) continue;
                 const f32x2 v = {relu1(vs[0][r]), relu1(vs[1][r])};
+                range_track(rbad, v[0], v[1]);                      // (the forward's range guard, qnet.h)
                 if (out_lds) {
                     u32 h, l;
                     split_f16x2_pair(v[0], v[1], h, l);
@@ -270,7 +272,7 @@ __device__ __forceinline__ void conv1_patch_bias(f32x4 (&bp)[PATCH_BT][4], f32x4
 // and half the epilogue each: 3.5 tile times instead of 4 on the critical wave.
 __device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, const int* __restrict__ s_t1, const u32x4* __restrict__ s_lut,
                                                   const u32x4 (&wb)[2][1][4], const f32x4 (&bpr)[PATCH_BT][4], const f32x4 (&bpx)[4], const float* __restrict__ b1p,
-                                                  int slot, unsigned short* __restrict__ s_a1, int lo1, int M1, int wfirst, int j, int kq, int bpx_tile) {
+                                                  int slot, unsigned short* __restrict__ s_a1, int lo1, int M1, int wfirst, int j, int kq, int bpx_tile, range_mask& rbad) {
     const int tiles = (M1 + 15) >> 4;
     if (wfirst >= tiles) return;                                    // wave-uniform
     const bool split = PATCH_SPLIT && (tiles & (CONV_WAVES - 1)) == 1 && tiles > CONV_WAVES;     // wave-uniform: the last tile belongs to wave 0 and is shared with wave 1
@@ -294,6 +296,7 @@ __device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, c
             f32x4 v;
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = relu1(vs[t][r] + bp[r][t]);
+            range_track4(rbad, v);
             u32 hp[2], lp[2];                                       // split on write: this lane's 4 consecutive channels of pixel mo
             split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
             split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -321,7 +324,9 @@ __device__ __forceinline__ void conv1_patch_words(const u8* __restrict__ s_in, c
             const int mo = tile * 16 + 4 * kq + r;
             if (mo >= M1) continue;
             u32 hp, lp;
-            split_f16x2_pair(relu1(vs[0][r] + bp[r][2 * HALF]), relu1(vs[1][r] + bp[r][2 * HALF + 1]), hp, lp);
+            const float r0 = relu1(vs[0][r] + bp[r][2 * HALF]), r1 = relu1(vs[1][r] + bp[r][2 * HALF + 1]);
+            range_track(rbad, r0, r1);
+            split_f16x2_pair(r0, r1, hp, lp);
             unsigned short* dst = s_a1 + mo * 64 + 4 * j + 2 * HALF;
             *reinterpret_cast<u32*>(dst) = hp;
             *reinterpret_cast<u32*>(dst + lo1) = lp;
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     u8* s_fx = smem + a.off_fx;                                                     // CONV_SWZ: chunk swizzle of every a1 row, in halves
     unsigned short* s_a2 = reinterpret_cast<unsigned short*>(smem + a.off_a2);      // [2][S*r2][40]; overlays the observations (dead after conv1)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
+    range_mask rbad = 0;                                            // the forward's range guard (qnet.h range_track)
     static_assert(FWD_MAX_JOBS == 4, "three comparisons");
     const int jb = ((int)blockIdx.x >= a.wg_first[1]) + ((int)blockIdx.x >= a.wg_first[2]) + ((int)blockIdx.x >= a.wg_first[3]);      // block-uniform
     const ConvJob& J = a.job[jb];
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     // ---- convolution 1: A gathered byte-wise from the uint8 image; the bytes of this wave's next tile are requested before the
     //      MFMAs of the current one ----------------------------------------------------------------------------------------------
     if constexpr (CP) {
-        conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, bpx, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wave, j, kq, (M1 + 15) / 16 - 1);
+        conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, bpx, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wave, j, kq, (M1 + 15) / 16 - 1, rbad);
     } else {
         const int tiles = (M1 + 15) >> 4;
         auto origin = [&](int tile) { return s_t1[min(tile * 16 + j, M1 - 1)]; };     // rows past the end (and whole tiles past it) reread the last row
@@ -516,6 +522,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 f32x4 v;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = relu1(vs[t][r]);
+                range_track4(rbad, v);
                 u32 hp[2], lp[2];                                   // split on write: this lane's 4 consecutive channels of pixel mo
                 split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                 split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -544,10 +551,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     DQ_STAMP(DQ_TAG_CONV_FWD, 4);
     if constexpr (CP) {
         conv_from_lds<64, 32, 2, 4, 2, false, 0>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
-                                                 nullptr, wave, lane, a.rowtab + 3 * CONV_ROWTAB, tab2[0], tab2[1]);
+                                                 nullptr, wave, lane, a.rowtab + 3 * CONV_ROWTAB, tab2[0], tab2[1], rbad);
     } else {
         conv_from_lds<64, 32, 2, 4, 2, CONV_SWZ != 0>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
-                                                      nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1]);
+                                                      nullptr, wave, lane, a.rowtab + CONV_ROWTAB, tab2[0], tab2[1], rbad);
     }
     DQ_STAMP(DQ_TAG_CONV_FWD, 5);
     conv_w_prefetch(ring, J.packed + PK_CONV3_FWD, lane);
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
     {
         const int r3 = a.oh3 * a.ow3;
         conv_from_lds<32, 32, 2, 4, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, M3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
-                                 J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane, a.rowtab + 2 * CONV_ROWTAB, tab3[0], tab3[1]);
+                                 J.act_out[2] + (size_t)b0 * r3 * 32, wave, lane, a.rowtab + 2 * CONV_ROWTAB, tab3[0], tab3[1], rbad);
     }
     // ---- training: a1 and a2 leave as the piece planes they are in LDS (the convolutional backward's operands, fused_bwd.hip) in ONE burst of
     //      16-byte copies at the very end: stores from the layers' epilogues sat in front of the next layer's weight requests (loads and
@@ -577,6 +584,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_kernel(ConvChainAr
                 *reinterpret_cast<const u32x4*>(s_a2 + piece * lo2 + row * 40 + 8 * part);
         }
     }
+    range_report(rbad, a.range_flag);
     DQ_STAMP(DQ_TAG_CONV_FWD, 7);
     DQ_STAMP_WG(DQ_TAG_CONV_FWD, 1);
     DQ_STAMP_PAIR(1);
@@ -602,6 +610,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     int* s_mis = reinterpret_cast<int*>(smem + a.off_mis);          // [2][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, kq = lane >> 4;
+    range_mask rbad = 0;                                            // the forward's range guard (qnet.h range_track)
     static_assert(FWD_MAX_JOBS == 4, "three comparisons");
     constexpr bool CP = KG1 == 0;                                   // patch-word input (conv1_patch_words)
     const int in_bytes = CP ? a.slot : a.C * a.H * a.W;
@@ -745,7 +754,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 2);
         // ---- convolution 1 (conv_chain_kernel's, on rows of 64 halves) ------------------------------------------------------------
         if constexpr (CP) {
-            conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, bpx, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wv, j, kq, (MF1 + 15) / 16 - 1);
+            conv1_patch_words(s_in, s_t1, s_lut, wb, bp1, bpx, reinterpret_cast<const float*>(J.packed + a.pk_b1p), a.slot, s_a1, lo1, M1, wv, j, kq, (MF1 + 15) / 16 - 1, rbad);
         } else {
             const int tiles = (M1 + 15) >> 4;
             auto origin = [&](int tile) {                           // (constant table entry + the sample's alignment offset of THIS group)
@@ -783,6 +792,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
                     f32x4 v;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = relu1(vs[t][r]);
+                    range_track4(rbad, v);
                     u32 hp[2], lp[2];                               // split on write: this lane's 4 consecutive channels of pixel mo
                     split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                     split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -820,6 +830,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
                     f32x4 v;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = relu1(vs[t][r]);
+                    range_track4(rbad, v);
                     u32 hp[2], lp[2];
                     split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                     split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -876,13 +887,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 4);
         conv_from_lds<64, 32, 2, 4, 2, false, 0>(s_a1, lo1, a.oh1, a.ow1, a.oh2, a.ow2, M2, ring, J.packed + PK_CONV2_FWD, J.params + a.b_off[1], s_a2, lo2,
-                                                 nullptr, wv, ln, rowtab + 3 * CONV_ROWTAB, tab2[0], tab2[1]);
+                                                 nullptr, wv, ln, rowtab + 3 * CONV_ROWTAB, tab2[0], tab2[1], rbad);
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 5);
         conv_w_prefetch(ring, J.packed + PK_CONV3_FWD, ln);
         __syncthreads();
         DQ_STAMP(DQ_TAG_CONV_FWD, 8 * gk + 6);
         conv_from_lds<32, 32, 2, 4, 2>(s_a2, lo2, a.oh2, a.ow2, a.oh3, a.ow3, M3, ring, J.packed + PK_CONV3_FWD, J.params + a.b_off[2], nullptr, 0,
-                                       J.act_out[2] + (size_t)b0 * r3 * 32, wv, ln, rowtab + 2 * CONV_ROWTAB, tab3[0], tab3[1]);
+                                       J.act_out[2] + (size_t)b0 * r3 * 32, wv, ln, rowtab + 2 * CONV_ROWTAB, tab3[0], tab3[1], rbad);
         // the next group's first-layer weights fly over the training stores and the next group's top barrier (unconditional -- after the last group
         // the last job's again --: a conditional reload would keep these 84 registers live through the whole group)
         load_w1(a.job[job_of(min(nxt, total - 1))]);
@@ -904,6 +915,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_chain_pkernel(ConvChainA
         if (nxt >= total) break;
         gid = nxt; cur ^= 1; ++gk;
     }
+    range_report(rbad, a.range_flag);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -940,6 +952,7 @@ struct DenseChainArgs {
     int w_off[3], b_off[3];
     int ldx, ld2, ld3;                  // LDS row strides (floats)
     int off_x, off_h, off_part, off_y2, off_y3;
+    unsigned* range_flag;               // the forward's range guard (qnet.h range_report), nullable
 };
 
 template <int NT2, int KG3, int RT>     // N2 <= 16*NT2 (column tiles of Dense(|A|)); N2 <= 16*KG3 (k groups of the dueling layer);
@@ -959,6 +972,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     const int b0 = ((int)blockIdx.x - J.wg0) * ROWS;
     const int ns = min(ROWS, J.batch - b0);
     const int K1 = a.K1;
+    range_mask rbad = 0;                                            // the forward's range guard (qnet.h range_track): the hidden layer and the Q-values (non-finite) here; the
+                                                                    // convolutions' outputs -- this kernel's input -- are tracked where they are produced; Dense(|A|)'s output is
+                                                                    // split for the backward only, whose own guard sees a non-finite gradient
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 0);
     DQ_STAMP_WG(DQ_TAG_DENSE_FWD, 0);
@@ -1039,6 +1055,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 vv[u][0] = *reinterpret_cast<const f32x4*>(xp) * (ok ? 1.f : 0.f);
                 vv[u][1] = *reinterpret_cast<const f32x4*>(xp + 4) * (ok ? 1.f : 0.f);
             }
+
             if (i0 == tid) { draw_keep_bits(); drawn = true; }      // (NBS covers the whole image: the loop body runs at most once)
 #pragma unroll
             for (int u = 0; u < NBS; ++u) {
@@ -1171,6 +1188,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = ((keepb[u] >> (8 * b + 4 * s + r)) & 1u) ? v[r] * J.keep_scale : 0.f;
                 }
+                range_track4(rbad, v);
                 u32 hp[2], lp[2];
                 split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                 split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -1226,6 +1244,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = ((keepb[u] >> (8 * b + 4 * s + r)) & 1u) ? v[r] * J.keep_scale : 0.f;
                     }
+                    range_track4(rbad, v);
                     u32 hp[2], lp[2];
                     split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                     split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -1302,12 +1321,13 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc3[s & 1] = MFMA16(av[s], b3[g][s], acc3[s & 1]);
                 }
-                if (col3 < A) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * u + 4 * kq + r;
-                        if (row < ns) J.q_out[(size_t)(b0 + row) * A + col3] = (acc3[0][r] + acc3[1][r]) + bias3;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * u + 4 * kq + r;
+                    const float qv = (acc3[0][r] + acc3[1][r]) + bias3;
+                    const bool live = col3 < A && row < ns;
+                    if (live) J.q_out[(size_t)(b0 + row) * A + col3] = qv;
+                    range_track_finite(rbad, live ? qv : 0.f);      // (outside the guard: the mask stays wave-uniform)
                 }
             }
         }
@@ -1327,6 +1347,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             }
         }
     }
+    range_report(rbad, a.range_flag);
     DQ_STAMP(DQ_TAG_DENSE_FWD, 8);
     DQ_STAMP_WG(DQ_TAG_DENSE_FWD, 1);
     DQ_STAMP_PAIR(3);
@@ -1351,6 +1372,8 @@ struct PackArgs {
     int c1w_off, c1w_blocks, p_kd;      // the wave-private conv forward's first kernel (qnet.h c1w): u32x4 offset, blocks (4 or 0), data bits per word
     int c2w_off, c2w_blocks;            // ... and its second (qnet.h c2w): 16 blocks or 0
     int cdw_off, cdw_blocks;            // the 16-wave convolutional backward's data-gradient weights (qnet.h cdw): 24 blocks or 0
+    unsigned* range_flag;               // the forward's range guard: every parameter is checked finite and < 65504 here (qnet.h range_report), nullable
+    int n_params;
 };
 
 // Wc for networks with more than 64 actions (N2, N3 <= 112; qnet.h wc): Wc[a][n1] = P[0] + P[1 + a] - mean_a' P[1 + a'],  P = W2[n1] W3 (the plain
@@ -1427,6 +1450,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
     if ((int)blockIdx.x < a.wide_blocks) { pack_wide_wc_block(a, (int)blockIdx.x, pack_smem); return; }
     const int pblock = (int)blockIdx.x - a.wide_blocks;
     const float* __restrict__ params = a.params;
+    // the forward's range guard, parameter half: what the packed pieces are made from must be finite and < 65504 (an h piece of inf / NaN poisons whole
+    // contractions and the next ReLU hides it, qnet.h).  The launch's threads walk the flat buffer once beside their packing work (0.77 MB out of L2)
+    if (a.range_flag) {
+        bool bad = false;
+        for (int i = pblock * 256 + (int)threadIdx.x; i < a.n_params; i += a.pack_wgs * 256) bad = bad || !(fabsf(params[i]) < 65504.f);
+        if (bad) atomicOr(a.range_flag, 2u);
+    }
     u32x4* __restrict__ pk = a.pk;
     const int w2_off = a.w2_off, w3_off = a.w3_off, d1_off = a.d1_off, d1_blocks = a.d1_blocks;
     const int lane = threadIdx.x & 63, blk_id = pblock * 4 + (threadIdx.x >> 6), j = lane & 15, kb = lane >> 4;
@@ -1688,6 +1718,7 @@ dq_status fused_pack_weights(const dq_qnet* Q, const float* params_dev, void* pa
     const bool wide_wc = PL.wc_rows && PL.NT2 == 8;
     const int wide_blocks = wide_wc ? (DENSE_HID + WCW_U - 1) / WCW_U : 0;
     a.wide_blocks = wide_blocks;
+    a.range_flag = fused_range_flag(Q); a.n_params = (int)Q->n_params;
     pack_weights_kernel<<<a.pack_wgs + wide_blocks, 256, wide_wc ? (size_t)a.N2 * a.N3 * 4 + 4 * WCW_U * 128 * 4 : 0, st>>>(a);
     DQ_LAUNCH_CHECK();
     return DQ_OK;
@@ -2032,6 +2063,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         dense_wgs += (jb.batch + dense_rows - 1) / dense_rows;
     }
     for (int i = n_jobs; i < FWD_MAX_JOBS; ++i) ca.wg_first[i] = da.wg_first[i] = 0x7fffffff;
+    ca.range_flag = da.range_flag = fused_range_flag(Q);           // the forward's range guard (qnet.h range_report)
     // the wave-private form (conv_wave.hip) for patch words at d = 5; conv_form 1 (dq_qnet_set_kernel_forms, DQ_CONV_FORM=group at creation) keeps the
     // workgroup-per-group kernels
     if (patch && conv_wave_supported(Q) && Q->conv_form == 0) {
@@ -2040,7 +2072,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         for (int i = 0; i < n_jobs; ++i) wa.job[i] = ca.job[i];
         wa.n_jobs = n_jobs;
         for (int l = 0; l < 3; ++l) wa.b_off[l] = ca.b_off[l];
-        wa.slot = cp.slot; wa.pk_c1w = (int)PL.c1w; wa.pk_c2w = (int)PL.c2w; wa.kd = Q->patch_kd; wa.ptab = Q->ptab;
+        wa.slot = cp.slot; wa.pk_c1w = (int)PL.c1w; wa.pk_c2w = (int)PL.c2w; wa.kd = Q->patch_kd; wa.ptab = Q->ptab; wa.range_flag = fused_range_flag(Q);
         const dq_status rc = conv_wave_launch(Q, wa, n_cu, st);
         if (rc != DQ_OK) return rc;
     } else if (can_persist && (conv_wgs > pp.per_cu * n_cu || persist_env == 2)) {

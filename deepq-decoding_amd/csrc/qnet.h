@@ -194,6 +194,22 @@ __device__ __forceinline__ void mma_f16x3(const F16x2& a, const F16x2& b, f32x4&
 // max(x, 0) as ONE instruction whatever produced x (fmaxf behind a packed operation costs a second v_max_f32 that canonicalises its operand)
 __device__ __forceinline__ float relu1(float x) { float y; asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x)); return y; }
 __device__ __forceinline__ float f16x2_sum(float acc0, float acc1) { return __builtin_fmaf(acc1, F16_LO_INV, acc0); }
+// Range guard of the fused FORWARD (round 6).  An activation of 65504 or more (or a non-finite one) leaves the f16 pieces' range: its h piece is inf, the products
+// it enters are inf - inf = NaN, and the next ReLU (v_max_f32 returns the non-NaN operand) turns that into 0 -- the Q-values would come out finite and wrong.  Every
+// epilogue that splits activations therefore compares the maximum of what it splits (post-ReLU values: v_max3_f32 over a lane's two or four, one v_cmp; signed ones
+// through the |x| source modifier) with 65504 and ORs the wave's ballot into a wave-uniform mask -- two SGPRs, NO vector register: a running maximum per lane cost
+// conv_wave_kernel its 128-register budget (66 spills) --, and a wave whose mask is not empty raises bit 1 of the handle's range word at its end (fused_range_flag:
+// bit 0 = the backward's guard) -- dq_qnet_range_check then returns DQ_ERR_RANGE for the forward too.  (A sticky hardware flag would have been free: TRAPSTS.EXCP stays 0 across an
+// overflowing v_cvt_f16_f32 on gfx950 unless traps are enabled -- tools/probe/trapsts_probe.hip.)  A NaN argument does not move the maximum; it cannot arise
+// before an inf that does: observations are binary, parameters are checked finite and < 65504 when they are packed (pack_weights_kernel).
+typedef unsigned long long range_mask;     // lanes that met an activation outside the pieces' range (wave-uniform: lives in SGPRs)
+__device__ __forceinline__ void range_track(range_mask& bad, float a, float b) { bad |= __ballot(!(fmaxf(a, b) < 65504.f)); }
+__device__ __forceinline__ void range_track4(range_mask& bad, const f32x4& v) { bad |= __ballot(!(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) < 65504.f)); }
+__device__ __forceinline__ void range_track_abs(range_mask& bad, float a, float b) { bad |= __ballot(!(fmaxf(fabsf(a), fabsf(b)) < 65504.f)); }
+__device__ __forceinline__ void range_track_finite(range_mask& bad, float q) { bad |= __ballot(!(fabsf(q) < INFINITY)); }      // (an f32 output: NaN counts)
+// (every lane reports its own copy of the mask: where a tracker sits under divergent control flow -- row guards -- the mask is per lane, and every lane that was
+// active there holds the ballot's bits)
+__device__ __forceinline__ void range_report(range_mask bad, unsigned* flag) { if (flag && bad != 0) atomicOr(flag, 2u); }
 __device__ __forceinline__ f32x4 f16x2_sum(const f32x4& acc0, const f32x4& acc1) { return acc1 * F16_LO_INV + acc0; }
 
 #endif  // __HIPCC__
@@ -305,6 +321,7 @@ struct ConvWaveArgs {
     int pk_c1w, pk_c2w;                                 // u32x4 offsets of the c1w / c2w sections inside a packed buffer
     int kd;                                             // data bits per patch word
     const int* ptab;                                    // PT_* tables
+    unsigned* range_flag;                               // the forward's range guard (range_report), nullable
 };
 bool conv_wave_supported(const dq_qnet* Q);
 dq_status conv_wave_launch(const dq_qnet* Q, ConvWaveArgs& a, int n_cu, hipStream_t st);

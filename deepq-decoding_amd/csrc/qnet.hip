@@ -510,6 +510,12 @@ dq_status dq_qnet_range_check(dq_qnet* Q, void* stream) {
     DQ_HIP(hipStreamSynchronize(st));
     if (!host) return DQ_OK;
     DQ_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+    if (host & 2u) {
+        dq_set_error("dq_qnet_range_check[forward]: a parameter or an activation of a fused forward is not finite or reaches 65504, the range of the f16 pieces the "
+                     "contractions carry (a diverged run: Q-values of that forward are not to be trusted)%s.  dq_qnet_set_fused(net, 0) selects the f32 path",
+                     (host & 1u) ? "; the backward's guard fired as well (dq_qnet_range_discarded)" : "");
+        return DQ_ERR_RANGE;
+    }
     dq_set_error("dq_qnet_range_check: a gradient of the fused backward left the range of its f16 pieces (TD errors of several thousand with the host-known "
                  "gradient scale): an update whose TD step saw such a sample was discarded WHOLE -- no parameter moved, on any rank; count: "
                  "dq_qnet_range_discarded --, a lone non-finite gradient element behind a passing TD step left only its own parameter and moments untouched.  "

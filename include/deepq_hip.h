@@ -439,6 +439,10 @@ dq_status dq_qnet_mark_conv_backward(dq_qnet* net, void* hip_event);
  * and clears it; DQ_OK otherwise (always on the per-layer f32 path).  The agent loop calls it at its host synchronisation points.  With
  * S x grad_scale in [4, 8) the guard trips for |TD error| of a few thousand (the reference's recorded losses, trained_models/ * / * /
  * training_history.json, stay below 160, i.e. |TD error| ~ 20).  No reference counterpart. */
+/* (round 6) The fused FORWARD is guarded too: its activations travel as f16 pieces as well, and one of 65504 or more would turn into inf, the products it enters
+ * into NaN and the next ReLU into 0 -- finite, wrong Q-values.  Every layer's epilogue compares what it splits with the range, the packing launch checks every
+ * parameter (finite, < 65504), the dense chain checks the Q-values it stores; any of them raises the same device-side flag and this call returns DQ_ERR_RANGE with
+ * a message that starts "dq_qnet_range_check[forward]" (the agent loop treats that one as fatal: no gradient scale helps a diverged network). */
 dq_status dq_qnet_range_check(dq_qnet* net, void* stream);
 /* How many optimizer steps the guard's early half discarded WHOLE since the last call (the TD step saw a sample beyond the host-known scale's range: the
  * final reduction wrote NaN into every gradient element and moved no parameter -- with several ranks the all-reduce carries the NaNs to all of them and

@@ -157,9 +157,11 @@ def test_backward_at_baseline_batch_matches_oracle(dq, torch_mod, name, batch):
     # A ReLU pre-activation within fp32 round-off of 0 may fall on the other side in another summation order, which changes that
     # sample's gradient by a finite amount; with ~3000 units x thousands of samples some always are.  Such samples (a few per cent)
     # get dq = 0: they still run through every kernel, but their masks cannot matter.
-    fragile = O.fragile_samples(cache)                                      # thr = 2e-6 (oracle/dqn_oracle.py)
-    print(f"{name} B={batch}: {fragile.mean():.3%} of the samples have a ReLU pre-activation within 2e-6 of 0")
-    assert fragile.mean() < 0.05
+    # (round 6: the threshold halved to 1e-6 -- five times the HIP paths' measured pre-activation error on unit-scale weights -- and the bound set at the measured
+    # share: 1.1-2.9 % of a minibatch on these random weights (the largest: d = 7, X noise), where 2e-6 zeroed 2.6-4.3 %; profiles/r06_test_printed_lines.txt)
+    fragile = O.fragile_samples(cache, thr=1e-6)
+    print(f"{name} B={batch}: {fragile.mean():.3%} of the samples have a ReLU pre-activation within 1e-6 of 0")
+    assert fragile.mean() < 0.032
     dq_[fragile] = 0.0
     dq_t = torch.from_numpy(dq_).cuda()
     g = net.backward(params, dq_t).cpu().numpy()
@@ -710,3 +712,73 @@ def test_guarded_adam_step_skips_and_flags_non_finite_elements(dq, torch_mod):
         else:
             assert not bool(torch.isfinite(p_[bad]).any()) and not bool(torch.isfinite(m_[bad]).any())
         assert bool(torch.isfinite(p_).all()) == guarded
+
+
+@pytest.mark.parametrize("name,batch,patch", [("c3", 300, False), ("c3", 300, True), ("c5", 64, False), ("c1", 37, False)])
+def test_forward_range_guard(dq, torch_mod, name, batch, patch):
+    """the fused FORWARD carries activations as f16 pieces (finite below 65504); one that leaves that range becomes inf, the products it enters NaN,
+    and the next ReLU (v_max_f32) would turn that into 0 -- finite, wrong Q-values.  Every layer's epilogue therefore tracks what it splits and the packing launch
+    checks every parameter (csrc/qnet.h range_track); dq_qnet_range_check reports DQ_ERR_RANGE "[forward]".  Healthy weights: silent.  Per-layer f32 path: no guard
+    needed, none raised.  patch: patch-word observations, i.e. conv_wave_kernel at d = 5."""
+    torch = torch_mod
+    spec, net, params, flat, obs, rng = _setup(dq, torch, name, batch)
+    obs_t = torch.from_numpy(obs).cuda()
+    if patch:
+        env = dq.VectorEnv(n_envs=1, d=5, error_model="DP", use_Y=False, volume_depth=5, p_phys=0.011, p_meas=0.011)
+        # observations the environment can produce (the embedding's constant cells set): rebuild them from random data bits
+        words = torch.from_numpy(rng.randint(0, 1 << 22, size=(batch, env.patch_stride)).astype(np.int32)).cuda()
+        obs_t = env.patch_to_obs(words)
+        net.set_patch_input(env.volume_depth, env.patch_stride)
+        fwd = lambda p: net.forward_multi([dict(params=p, obs=words, patch=True)])[0]
+    else:
+        fwd = lambda p: net.forward(p, obs_t)
+    q = fwd(params)
+    net.check_range()                                               # healthy: nothing raised
+    assert bool(torch.isfinite(q).all())
+    offs = spec.offsets() if hasattr(spec, "offsets") else None
+    shapes = spec.param_shapes()
+    starts, o = [], 0
+    for (ks, bs) in shapes:
+        starts.append((o, int(np.prod(ks))))
+        o += int(np.prod(ks)) + int(np.prod(bs))
+    cases = {}
+    for li, label in ((0, "conv1"), (1, "conv2"), (2, "conv3"), (3, "dense512")):
+        p = params.clone()
+        k0, kn = starts[li]
+        p[k0:k0 + kn] *= 0.9 * 65504.0 / float(p[k0:k0 + kn].abs().max())      # the layer's largest weight at 0.9 of the range: its activations (sums of many) outside
+        assert float(p.abs().max()) < 65504.0
+        cases[label] = p
+    p = params.clone(); p[starts[1][0] + 5] = 7.0e4; cases["a parameter of 70000"] = p
+    p = params.clone(); p[starts[3][0] + 9] = float("nan"); cases["a NaN parameter"] = p
+    p = params.clone(); p[starts[0][0] + starts[0][1] + 3] = float("inf"); cases["an infinite bias"] = p
+    obs_np = obs_t.cpu().numpy()
+    n_expected = 0
+    for label, p in cases.items():
+        # what SHOULD happen, from the float64 oracle: the largest activation any layer produces under these parameters (a scaled layer of a small network --
+        # d = 3: 32 inputs to Dense(512) -- may stay inside the range: then the guard must stay silent)
+        p_np = p.cpu().numpy().astype(np.float64)
+        with np.errstate(all="ignore"):
+            _, cache = O.forward(spec, p_np, obs_np)
+        act = max(float(np.nanmax(np.abs(C["y"]))) if np.isfinite(C["y"]).any() else np.inf for C in cache["layers"][:4])
+        bad_param = not np.all(np.abs(p_np) < 65504.0)
+        if not bad_param and 5.5e4 < act < 7.5e4:
+            continue                                                # (too close to the boundary to call from float64)
+        expect = bad_param or not act < 65504.0
+        fwd(p)
+        if expect:
+            n_expected += 1
+            with pytest.raises(dq.DeepQError, match="forward") as ei:
+                net.check_range()
+                pytest.fail(f"forward range guard silent for: {label} (largest activation {act:.3g})")
+            assert ei.value.status == -6 and "[forward]" in str(ei.value), label
+        print(f"forward range guard, {name} patch={patch}: {label}: largest activation {act:.3g} -> {'raised' if expect else 'silent'}")
+        net.check_range()                                           # reported once, then clear / never raised
+    assert n_expected >= 5
+    fwd(params)
+    net.check_range()
+    # the per-layer path computes in f32: the same weights overflow nothing there
+    if not patch:
+        net.set_fused(False)
+        q2 = net.forward(cases["conv2"], obs_t)
+        net.check_range()
+        assert bool(torch.isfinite(q2).all())
