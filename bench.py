@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--env-steps-per-launch", type=int, default=32, help="--mode env: agent steps per environment launch (dq_env_act_steps); 1 = one launch per step")
     ap.add_argument("--env-obs", default="patch", choices=["patch", "uint8"], help="--mode env: successor observations as the loop's patch words or as the reference's uint8 planes")
+    ap.add_argument("--dist-probe-steps", type=int, default=50,
+                    help="--gpus N > 1: untimed vector steps per form of the gradient exchange (single / overlap) timed before the timed region, which then runs "
+                         "in the faster; 0 or an explicit DQ_DIST_MODE: no probing")
     ap.add_argument("--ratio-steps", type=int, default=100,
                     help="vector steps of the second timed leg at the reference's replay ratio (32 trained samples per environment step), run behind the "
                          "headline region of a default 1-GPU loop run and printed as `reference_replay_ratio`; 0 = skip it")
@@ -304,6 +307,29 @@ def main():
             rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
     for _ in range(args.warmup):
         runner.step(timed=False)
+    dist_tune = None
+    if (world > 1 or force_dist) and mode == "loop" and hasattr(runner, "core") and "DQ_DIST_MODE" not in os.environ and args.dist_probe_steps > 0:
+        # Self-tuning exchange: which form of the gradient all-reduce wins depends on wire time no 1-GPU box can show (DESIGN.md section 7:
+        # `single` up to 4 ranks, about even at 8).  Both are timed here, untimed by the contract -- `dist_probe_steps` vector steps each behind a barrier, MAX over
+        # the ranks so that every rank sees the same two numbers -- and the timed region runs in the faster.  An explicit DQ_DIST_MODE switches this off.
+        dist_tune = {"probe_steps": args.dist_probe_steps, "us_per_step": {}}
+        for m in ("single", "overlap"):
+            os.environ["DQ_DIST_MODE"] = m
+            runner.core.ensure_comm(with_overlap=(m == "overlap"))
+            for _ in range(5):
+                runner.step(timed=False)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.dist_probe_steps):
+                runner.step(timed=False)
+            sync()
+            tm = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dist_tune["us_per_step"][m] = 1e6 * float(tm.item()) / args.dist_probe_steps
+        dist_tune["chosen"] = min(dist_tune["us_per_step"], key=dist_tune["us_per_step"].get)
+        os.environ["DQ_DIST_MODE"] = dist_tune["chosen"]
+        for _ in range(5):
+            runner.step(timed=False)
     if hasattr(runner, "pick_dominant"):
         runner.pick_dominant()          # untimed probe: which kernel family takes the most time per step
     if os.environ.get("DQ_BENCH_NO_ARM") != "1":     # (diagnostic: the timed region without any event, no roofline object)
@@ -385,6 +411,8 @@ def main():
             out["dist_backend"] = "rccl" if backend == "nccl" else backend
             out["replicas_identical"] = replicas_identical
             out["allreduce"] = allreduce
+            out["dist_mode"] = dict(dist_tune, how="both forms timed before the timed region, the faster one ran") if dist_tune else \
+                dict(chosen=os.environ.get("DQ_DIST_MODE", "single"), how="DQ_DIST_MODE" if "DQ_DIST_MODE" in os.environ else "default")
         if world == 1 and not args.no_cpu_baseline:
             full = dict(cfg, n_envs=n_local)
             if mode == "env":

@@ -664,16 +664,17 @@ class DQNCore:
         if self.target_pk is not None:
             self.target_pk.copy_(self.params_pk)
 
-    def ensure_comm(self):
+    def ensure_comm(self, with_overlap=False):
         """Creates the learner's own RCCL communicator if the several-GPU branch will use one (dist.make_rccl: a collective call -- every rank, at the
         same point; None for gloo groups / DQ_DIST_NATIVE=0).  Called by the first several-GPU update; bench.py calls it in front of its warm-up
-        steps so that the rendezvous (~1 s) can never fall into a timed region."""
+        steps so that the rendezvous (~1 s) can never fall into a timed region.  with_overlap: also the side stream's communicator, whatever DQ_DIST_MODE
+        says now (bench.py times both forms of the exchange and runs the faster: every rank calls this alike)."""
         if self._rccl is None and not self._rccl_tried and _dist.dist_path(self.world_size):
             self._rccl_tried = True
             self._rccl = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
-            # DQ_DIST_MODE=overlap: a second communicator for the dense range's all-reduce on the side stream (the same collective call on every rank)
-            if self._rccl is not None and os.environ.get("DQ_DIST_MODE") == "overlap":
-                self._rccl2 = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
+        # DQ_DIST_MODE=overlap: a second communicator for the dense range's all-reduce on the side stream (the same collective call on every rank)
+        if self._rccl is not None and self._rccl2 is None and (with_overlap or os.environ.get("DQ_DIST_MODE") == "overlap"):
+            self._rccl2 = _dist.make_rccl(self.rank, self.world_size, self.device, self.pg)
 
     def _comm_ready(self):
         self.ensure_comm()

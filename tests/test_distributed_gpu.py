@@ -19,11 +19,15 @@ def _clean_env(**extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["single", "overlap"])
+@pytest.mark.parametrize("mode", ["single", "overlap", None])
 def test_bench_self_launches_two_ranks_that_stay_identical(mode):
     # (overlap: on a gloo group -- no RCCL communicator of the learner's own -- the mode takes the split form through torch.distributed)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(DQ_DIST_BACKEND="gloo", DQ_DIST_MODE=mode), capture_output=True, text=True, timeout=600)
+    # mode None (round 6): no DQ_DIST_MODE -- bench.py times both forms before the timed region, every rank picks the same one, the line says which and why
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--dist-probe-steps", "6"]
+    env = _clean_env(DQ_DIST_BACKEND="gloo", **({"DQ_DIST_MODE": mode} if mode else {}))
+    if mode is None:
+        env.pop("DQ_DIST_MODE", None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1                                           # rank 0 only
@@ -34,6 +38,12 @@ def test_bench_self_launches_two_ranks_that_stay_identical(mode):
     assert out["dist_backend"] == "gloo" and out["rccl_ranks"] == 0
     ar = out["allreduce"]
     assert ar["dense_bytes"] + ar["conv_bytes"] == 4 * out["config"]["n_params"] and ar["dense_us"] > 0 and ar["conv_us"] > 0
+    dm = out["dist_mode"]
+    if mode is None:
+        assert dm["chosen"] in ("single", "overlap") and set(dm["us_per_step"]) == {"single", "overlap"} and dm["probe_steps"] == 6
+        assert dm["us_per_step"][dm["chosen"]] == min(dm["us_per_step"].values()) and ar["exposed_us_per_step"] is not None
+    else:
+        assert dm["chosen"] == mode and dm["how"] == "DQ_DIST_MODE"
 
 
 @pytest.mark.gpu
@@ -45,7 +55,8 @@ def test_one_rank_rccl_group_drives_the_several_gpu_branch():
     range asynchronously on the process group's stream behind the convolutional backward, convolutional range on the critical path).  With
     one rank the sum is the identity, so the parameters after the run must be the bits the one-GPU branch (Adam fused on the reduction) leaves."""
     def run(**extra):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4", "--no-cpu-baseline"]
+        # (--dist-probe-steps 0: no timing of both exchange forms in front of the timed region -- its extra steps would move the parameters this test compares)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--dist-probe-steps", "0", "--ratio-steps", "0"]
         r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(**extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = r.stdout.strip().splitlines()
