@@ -210,11 +210,10 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
                     const u32x4 bits = CW_BITS_LIVE ? bitsr[s][u] : *reinterpret_cast<const u32x4*>(smem + CW_W_END * 16 + la[s][u]);
                     const f32x4 ah = MFMA_F16(w1h, bits, z), al = MFMA_F16(w1l, bits, z);
                     const f32x4 vs = f16x2_sum(ah, al);
-                    const f32x4 rv = {relu1(vs[0]), relu1(vs[1]), relu1(vs[2]), relu1(vs[3])};
-                    range_track4(rmax, rv);
+                    // (no run-time range check here: the operand is binary, so a1 is bounded by the c1w block's positive column sums, checked when it is packed)
                     uint2 hp, lp;
-                    split_f16x2_pair(rv[0], rv[1], hp.x, lp.x);
-                    split_f16x2_pair(rv[2], rv[3], hp.y, lp.y);
+                    split_f16x2_pair(relu1(vs[0]), relu1(vs[1]), hp.x, lp.x);
+                    split_f16x2_pair(relu1(vs[2]), relu1(vs[3]), hp.y, lp.y);
                     *reinterpret_cast<uint2*>(s_img + s * SM + wa1[u]) = hp;
                     *reinterpret_cast<uint2*>(s_img + s * SM + PL + wa1[u]) = lp;
                 }
@@ -252,6 +251,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
         // ---- conv2 epilogue: a2 images (split on write) over the dead quarter image ------------------------------------------------------------------
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         const f32x2 bias2 = *reinterpret_cast<const f32x2*>(bias_p + a.b_off[1]);      // (per pair, through L1: four registers less over the pair)
+        float rm2 = 0.f;                                            // this epilogue's maximum (qnet.h range_max)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f32x4 vs[2];
@@ -261,12 +261,13 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
             for (int r = 0; r < 4; ++r) {
                 u32 h, l;
                 const float r0 = relu1(vs[0][r]), r1 = relu1(vs[1][r]);
-                range_track(rmax, r0, r1);
+                range_max(rm2, r0, r1);
                 split_f16x2_pair(r0, r1, h, l);
                 *reinterpret_cast<u32*>(s_img + s * SM + wa2[r]) = h;
                 *reinterpret_cast<u32*>(s_img + s * SM + PL + wa2[r]) = l;
             }
         }
+        range_commit(rmax, rm2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (train) {                                                // a2 piece planes [sample pixel][32 halves]
             const u32 cg2 = (u32)(16 * lane);
@@ -302,20 +303,33 @@ __global__ __launch_bounds__(CW_THREADS) void conv_wave_kernel(ConvWaveArgs a) {
                 for (int t = 0; t < 2; ++t) mma_f16x3(av, bw[t], acc3[s][t][0], acc3[s][t][1]);
             }
         }
+        float rm3 = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (s == 1 && !two) break;
-            u8* out = reinterpret_cast<u8*>(J.act_out[2] + (size_t)(b0 + s) * R3 * 32);
+            // split on write (round 6): the dense chain's operand, the dense weight gradients' and the data gradient's mask are these pieces -- the f32 copy had no
+            // other reader, and splitting it again cost the dense chain's staging phase its vector ALU work: rows [pixel][32] of halves, 4 bytes per lane and piece
+            u8* out = reinterpret_cast<u8*>(J.x_pl + (size_t)(b0 + s) * R3 * 32);
+            u8* outf = reinterpret_cast<u8*>(J.act_out[2] + (size_t)(b0 + s) * R3 * 32);      // (training job: the f32 rows too -- the dense data gradient's ReLU mask)
             f32x4 vs[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) vs[t] = f16x2_sum(acc3[s][t][0], acc3[s][t][1]) + f32x4{bias3[t], bias3[t], bias3[t], bias3[t]};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float r0 = relu1(vs[0][r]), r1 = relu1(vs[1][r]);
-                range_track(rmax, r0, r1);                          // (rows past R3 are clamped copies of real rows)
-                if (4 * kb + r < R3) *reinterpret_cast<f32x2*>(out + go3 + 128 * r) = f32x2{r0, r1};
+                range_max(rm3, r0, r1);                             // (rows past R3 are clamped copies of real rows)
+                u32 h, l;
+                split_f16x2_pair(r0, r1, h, l);
+                if (4 * kb + r < R3) {
+                    if (J.x_pl) {                                   // (wave-uniform)
+                        *reinterpret_cast<u32*>(out + (go3 >> 1) + 64 * r) = h;
+                        *reinterpret_cast<u32*>(out + (go3 >> 1) + 64 * r + 2 * J.x_lo) = l;
+                    }
+                    if (train || !J.x_pl) *reinterpret_cast<f32x2*>(outf + go3 + 128 * r) = f32x2{r0, r1};
+                }
             }
         }
+        range_commit(rmax, rm3);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (the next pair's quarter images overwrite a2: behind conv3's reads, in order)
         if (p == wave) CW_STAMP(2);
         p += CW_WAVES;

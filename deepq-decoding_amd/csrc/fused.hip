@@ -926,6 +926,8 @@ struct DenseJob {
     const float* params;
     const u32x4* packed;                // f16 pieces (qnet.h); the hidden layer's blocks start at DenseChainArgs.pk_dense1
     const float* x;                     // [batch, K1]: NHWC flatten of the last convolution
+    const unsigned short* xp;           // != NULL (round 6, behind conv_wave_kernel): the same rows as ready-made f16 piece planes [batch][K1] (h plane; the l plane xp_lo
+    size_t xp_lo;                       // halves further), staged by LDS-DMA; x is then not read
     int batch;
     float keep_scale;                   // > 0: dropout active on the hidden layer's output
     u32 drop_T;                         // a unit is dropped iff its 16-bit draw < drop_T (dq_rate_threshold16)
@@ -1038,7 +1040,21 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
             keepb[u] = bits;
         }
     };
-    {
+    if (J.xp) {                                                     // block-uniform
+        // the rows arrive as piece planes (conv_wave_kernel splits on write): global -> LDS by LDS-DMA, 16-byte slots in lane order -- slot q of a plane = part
+        // q % (K1 / 8 + 1) of row q / (K1 / 8 + 1), the last part of a row being its padding (that lane copies nothing).  No registers, no vector ALU work; rows past the
+        // batch re-read its last row (their results are never stored).  In training the planes ARE the weight gradients' operand: nothing to write back.
+        const int spr = (K1 >> 3) + 1, slots = ROWS * spr, chunks = (slots + 63) >> 6;
+        for (int c = wave; c < 2 * chunks; c += DENSE_WAVES) {
+            const int piece = c >= chunks ? 1 : 0, ch = c - piece * chunks;
+            const int q = ch * 64 + lane, row = q / spr, part = q - row * spr;
+            if (q < slots && part < spr - 1)
+                lds_dma16(J.xp + piece * J.xp_lo + (size_t)(b0 + min(row, ns - 1)) * K1 + part * 8, lds_addr(s_pl + piece * ROWS * LDP + ch * 512));
+        }
+        draw_keep_bits();
+        for (int i = tid; i < ROWS * a.ld2; i += DENSE_THREADS) s_y2[i] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the copies (and the first weight block requested above) have landed
+    } else {
         // eight consecutive values per item: two 16-byte loads in, ONE 16-byte store per piece out (LDS plane, and in training the global
         // plane: stores are issue-bound per instruction -- as pairs of 8-byte stores they were twice as many for the same bytes)
         const int q8 = K1 >> 3;                                     // items per row (K1 is a multiple of 32)
@@ -1176,6 +1192,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     // the hidden epilogue of row tile u in registers: bias, ReLU, dropout, split -> this wave's two K = 32 blocks of Dense(|A|)'s operand
     auto hidden_pieces = [&](int u, F16x2 (&hb)[2]) {
         const int row = 16 * u + j;                                 // this lane's sample
+        float rm = 0.f;                                             // this epilogue's maximum (qnet.h range_max)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
 #pragma unroll
@@ -1188,7 +1205,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = ((keepb[u] >> (8 * b + 4 * s + r)) & 1u) ? v[r] * J.keep_scale : 0.f;
                 }
-                range_track4(rbad, v);
+                range_max4(rm, v);
                 u32 hp[2], lp[2];
                 split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                 split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -1201,6 +1218,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                 *reinterpret_cast<u32x4*>(gp + (size_t)J.plane_rows * DENSE_HID) = hb[b].l;
             }
         }
+        range_commit(rbad, rm);
     };
     if constexpr (WIDE2) {
         static_assert(!WIDE2 || (ROWS / PR == 1 && UP == 2), "one reduction pass over both row tiles");
@@ -1232,6 +1250,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         for (int uu = 0; uu < (WIDE2 ? 0 : UP); ++uu) {
             const int u = pass * UP + uu, row = 16 * u + j;         // this lane's sample
             F16x2 hb[2];                                            // the sample's units 8kq .. 8kq+7 of this wave's two blocks, as pieces
+            float rm = 0.f;                                         // this epilogue's maximum (qnet.h range_max)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
 #pragma unroll
@@ -1244,7 +1263,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = ((keepb[u] >> (8 * b + 4 * s + r)) & 1u) ? v[r] * J.keep_scale : 0.f;
                     }
-                    range_track4(rbad, v);
+                    range_max4(rm, v);
                     u32 hp[2], lp[2];
                     split_f16x2_pair(v[0], v[1], hp[0], lp[0]);
                     split_f16x2_pair(v[2], v[3], hp[1], lp[1]);
@@ -1260,6 +1279,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
                     *reinterpret_cast<u32x4*>(gp + (size_t)J.plane_rows * DENSE_HID) = hb[b].l;
                 }
             }
+            range_commit(rbad, rm);
             f32x4 acc2[NTW][2];                                      // (NTW == NT2 here: the WIDE2 form ran above)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) { acc2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t][1] = acc2[t][0]; }
@@ -1530,6 +1550,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
                 const F16x2 o = split_f16x2(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
                 u32x4* dst = pk + a.c1w_off + (size_t)bq * PK_BLOCK + lane;
                 dst[0] = o.h; dst[PK_LO] = o.l;
+                // the forward's range guard for conv_wave_kernel's first layer (qnet.h): its operand is binary, so channel `col` of a1 can never exceed the sum of this
+                // column's positive entries (data rows, constant rows and the bias row alike) -- checked here, once per parameter change, instead of per activation
+                if (a.range_flag) {
+                    float pos = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pos += fmaxf(v[e], 0.f);
+                    pos += __shfl_xor(pos, 16); pos += __shfl_xor(pos, 32);
+                    if (!(pos < 65504.f)) atomicOr(a.range_flag, 2u);
+                }
             } else if (rc - 4 - a.b1p_rows - a.c1w_blocks < a.c2w_blocks) {    // c2w block (quarter, ky, t) (qnet.h)
                 const int b = rc - 4 - a.b1p_rows - a.c1w_blocks, t = b & 1, ky = (b >> 1) & 1, qt = b >> 2;
                 const float* w = params + w2_off + (size_t)((2 * ky + (kb >> 1)) * 64 + 16 * qt + 8 * (kb & 1)) * 32 + 2 * j + t;
@@ -2033,11 +2062,16 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         if (training) Q->last_a1_saved = a1_saved ? 1 : 0;
         C.batch = jb.batch; C.write_all = training ? (a1_saved ? 3 : 1) : 0; C.wg0 = conv_wgs; ca.wg_first[i] = conv_wgs; da.wg_first[i] = dense_wgs;
         C.act_out[0] = nullptr; C.act_out[1] = nullptr; C.act_out[2] = x;
+        // conv_wave_kernel leaves the last convolution's output as piece planes: the training job's straight into the weight gradients' operand (qnet.h dq_plane 0),
+        // an inference job's into its scratch buffer (the same bytes as the f32 rows it held)
+        unsigned short* xpl = nullptr;
+        if (wave_form && Q->x_planes) xpl = training ? dq_plane(Q, 0) : reinterpret_cast<unsigned short*>(Q->xinf[i]);
+        C.x_pl = xpl; C.x_lo = (size_t)Q->cfg.max_batch * D1.nin;
         C.a1_pl = reinterpret_cast<unsigned short*>(Q->act[0][0]); C.a1_lo = (size_t)Q->cfg.max_batch * L1.rows * 64;
         C.a2_pl = reinterpret_cast<unsigned short*>(Q->act[0][1]); C.a2_lo = (size_t)Q->cfg.max_batch * L2.rows * 32;
         conv_wgs += (jb.batch + cp.S - 1) / cp.S;
         DenseJob& D = da.job[i];
-        D.params = jb.params_dev; D.packed = static_cast<const u32x4*>(packed); D.x = x; D.batch = jb.batch; D.wg0 = dense_wgs;
+        D.params = jb.params_dev; D.packed = static_cast<const u32x4*>(packed); D.x = x; D.xp = xpl; D.xp_lo = (size_t)Q->cfg.max_batch * D1.nin; D.batch = jb.batch; D.wg0 = dense_wgs;
         if (training && D1.dropout > 0.f) {
             D.keep_scale = (float)(1.0 / (1.0 - (double)D1.dropout));
             D.drop_T = dq_rate_threshold16((double)D1.dropout);
@@ -2055,7 +2089,7 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         D.seed0 = jb.seed[0]; D.seed1 = jb.seed[1]; D.sample_base = jb.sample_base; D.t = jb.t;
         if (training) {
             D.plane_rows = Q->cfg.max_batch; D.small_ld = dq_planes_small_ld(Q);
-            D.x_pl = dq_plane(Q, 0); D.h1_pl = dq_plane(Q, 1); D.y2_pl = dq_plane(Q, 5);
+            D.x_pl = xpl ? nullptr : dq_plane(Q, 0); D.h1_pl = dq_plane(Q, 1); D.y2_pl = dq_plane(Q, 5);      // (x planes: written by conv_wave_kernel already)
             Q->last_train_batch = jb.batch; Q->last_train_fused = 1; Q->last_obs = jb.obs_dev; Q->last_index = jb.index_dev;
             Q->last_index_off = jb.index_off; Q->last_index_mod = jb.index_mod; Q->last_train_packed = packed; Q->last_patch = patch ? 1 : 0;
         }

@@ -75,6 +75,9 @@ struct dq_qnet {
     int conv_bwd_form;           // 0: conv_bwd16_kernel where it applies and the minibatch is >= 1024, 1: always conv_bwd_chain_kernel, 2: conv_bwd16_kernel whatever the minibatch
     int conv_bwd_a1;             // 0: conv_bwd16_kernel RECOMPUTES the first convolution's output from the patch words where the training forward was conv_wave_kernel
                                  // (which then does not save it: round 6), 1: every training forward saves a1, every backward reads the saved planes
+    int x_planes;                // 0 (default): the last convolution's output reaches the dense chain as f32 rows, split by its staging phase; 1 (DQ_X_PLANES=1 at
+                                 // dq_qnet_create): conv_wave_kernel splits on write and the dense chain stages the piece planes by LDS-DMA (ConvJob.x_pl) -- round 6, built,
+                                 // bit-identical, measured: dense forward -1.15 us, conv forward +0.7 us, the free-running step 0.5-1 % SLOWER (NOTEBOOK.md): off
     int last_a1_saved;           // the last training forward wrote the a1 piece planes (the backward that recomputes a1 must follow a forward that did NOT, and
                                  // the other way round: dq_qnet_set_kernel_forms between the two is refused)
     // patch-word input (dq_qnet_set_patch_input): observations as d * d words per sample instead of the padded uint8 image
@@ -196,17 +199,32 @@ __device__ __forceinline__ float relu1(float x) { float y; asm("v_max_f32 %0, 0,
 __device__ __forceinline__ float f16x2_sum(float acc0, float acc1) { return __builtin_fmaf(acc1, F16_LO_INV, acc0); }
 // Range guard of the fused FORWARD (round 6).  An activation of 65504 or more (or a non-finite one) leaves the f16 pieces' range: its h piece is inf, the products
 // it enters are inf - inf = NaN, and the next ReLU (v_max_f32 returns the non-NaN operand) turns that into 0 -- the Q-values would come out finite and wrong.  Every
-// epilogue that splits activations therefore compares the maximum of what it splits (post-ReLU values: v_max3_f32 over a lane's two or four, one v_cmp; signed ones
-// through the |x| source modifier) with 65504 and ORs the wave's ballot into a wave-uniform mask -- two SGPRs, NO vector register: a running maximum per lane cost
-// conv_wave_kernel its 128-register budget (66 spills) --, and a wave whose mask is not empty raises bit 1 of the handle's range word at its end (fused_range_flag:
-// bit 0 = the backward's guard) -- dq_qnet_range_check then returns DQ_ERR_RANGE for the forward too.  (A sticky hardware flag would have been free: TRAPSTS.EXCP stays 0 across an
+// epilogue that splits activations therefore folds what it splits into a per-lane maximum that lives for THAT epilogue only (post-ReLU values: one v_max3_f32
+// per pair -- range_max), compares it with 65504 once at the epilogue's end and ORs the wave's ballot into a wave-uniform mask (range_commit: two SGPRs; a maximum
+// kept per lane across the whole kernel cost conv_wave_kernel its 128-register budget -- 66 spills --, a ballot per pair of values cost it 2.9 of its 29.4 us).  A
+// wave whose mask is not empty raises bit 1 of the handle's range word at its end (fused_range_flag: bit 0 = the backward's guard) -- dq_qnet_range_check then
+// returns DQ_ERR_RANGE for the forward too.  conv_wave_kernel's FIRST layer is guarded without any run-time work: its input is binary, so a1[c] <= the sum of the
+// positive entries of column c of the c1w block (bias and constant rows included) -- checked by pack_weights_kernel where it builds that block.  (A sticky hardware flag would have been free: TRAPSTS.EXCP stays 0 across an
 // overflowing v_cvt_f16_f32 on gfx950 unless traps are enabled -- tools/probe/trapsts_probe.hip.)  A NaN argument does not move the maximum; it cannot arise
 // before an inf that does: observations are binary, parameters are checked finite and < 65504 when they are packed (pack_weights_kernel).
 typedef unsigned long long range_mask;     // lanes that met an activation outside the pieces' range (wave-uniform: lives in SGPRs)
+#ifdef DQ_NO_RANGE_TRACK                   // (A/B builds, tools/build_ab.sh: what the guard costs)
+__device__ __forceinline__ void range_track(range_mask&, float, float) {}
+__device__ __forceinline__ void range_track4(range_mask&, const f32x4&) {}
+__device__ __forceinline__ void range_track_abs(range_mask&, float, float) {}
+__device__ __forceinline__ void range_track_finite(range_mask&, float) {}
+__device__ __forceinline__ void range_max(float&, float, float) {}
+__device__ __forceinline__ void range_max4(float&, const f32x4&) {}
+__device__ __forceinline__ void range_commit(range_mask&, float) {}
+#else
+__device__ __forceinline__ void range_max(float& m, float a, float b) { m = fmaxf(m, fmaxf(a, b)); }                                       // one v_max3_f32
+__device__ __forceinline__ void range_max4(float& m, const f32x4& v) { m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); }       // two
+__device__ __forceinline__ void range_commit(range_mask& bad, float m) { bad |= __ballot(!(m < 65504.f)); }
 __device__ __forceinline__ void range_track(range_mask& bad, float a, float b) { bad |= __ballot(!(fmaxf(a, b) < 65504.f)); }
 __device__ __forceinline__ void range_track4(range_mask& bad, const f32x4& v) { bad |= __ballot(!(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) < 65504.f)); }
 __device__ __forceinline__ void range_track_abs(range_mask& bad, float a, float b) { bad |= __ballot(!(fmaxf(fabsf(a), fabsf(b)) < 65504.f)); }
 __device__ __forceinline__ void range_track_finite(range_mask& bad, float q) { bad |= __ballot(!(fabsf(q) < INFINITY)); }      // (an f32 output: NaN counts)
+#endif
 // (every lane reports its own copy of the mask: where a tracker sits under divergent control flow -- row guards -- the mask is per lane, and every lane that was
 // active there holds the ballot's bits)
 __device__ __forceinline__ void range_report(range_mask bad, unsigned* flag) { if (flag && bad != 0) atomicOr(flag, 2u); }
@@ -227,6 +245,9 @@ struct ConvJob {
     size_t a1_lo;
     unsigned short* a2_pl;             // convolution's output is kept as f16 piece planes [batch*oh2*ow2][32] (h plane; the l plane a2_lo halves
     size_t a2_lo;                      // further) -- the form the convolutional backward consumes it in (fused_bwd.hip)
+    unsigned short* x_pl;              // != NULL (conv_wave_kernel, round 6): the LAST convolution's output leaves as f16 piece planes [batch][oh3*ow3*cout] (h plane; the l
+    size_t x_lo;                       // plane x_lo halves further): the dense chain stages them by LDS-DMA (no split, no registers) and the dense weight gradients read
+                                       // the same planes; f32 act_out[2] is then written for the training job only (the dense data gradient's ReLU mask)
     int write_all;                     // training: bit 0 = write every layer the backward reads; bit 1 (conv_wave_kernel only) = ... including a1 (else the
                                        // backward recomputes it from the patch words: conv_bwd16.hip)
     int wg0;                           // first workgroup of this job

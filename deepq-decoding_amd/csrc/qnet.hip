@@ -390,6 +390,8 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         const char* a1 = getenv("DQ_CONV_BWD_A1");                  // =saved: the round-5 form (a1 through HBM), for A/B runs
         Q->conv_bwd_a1 = a1 && a1[0] == 's' ? 1 : 0;
         Q->last_a1_saved = 1;
+        const char* xp = getenv("DQ_X_PLANES");
+        Q->x_planes = xp && xp[0] == '1' ? 1 : 0;
     }
     // workspaces
     size_t max_partial = 0;

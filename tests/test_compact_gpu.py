@@ -341,3 +341,23 @@ def test_configurations_beyond_one_word_per_pixel_keep_the_uint8_ring(dq, torch_
         core.step_and_update(0.3)
     loss, mean_q = core.read_metrics()
     assert np.isfinite(loss) and np.isfinite(mean_q)
+
+
+def test_last_convolution_output_as_piece_planes_changes_no_bit(dq, torch_mod, monkeypatch):
+    """DQ_X_PLANES=1 (round 6, off by default: measured no faster): conv_wave_kernel splits the last convolution's output on write and the dense chain stages the
+    piece planes by LDS-DMA instead of splitting f32 rows itself -- the same split of the same f32 values, so Q-values and gradients are bit-identical to the
+    default path, for inference jobs (planes in the job's scratch buffer), the training job (planes straight into the weight gradients' operand) and ragged batches."""
+    torch = torch_mod
+    out = {}
+    for planes in ("0", "1"):
+        monkeypatch.setenv("DQ_X_PLANES", planes)
+        spec, net, params, flat, obs, patch, rng = _setup(dq, torch, "c3", 1091)
+        seed, t, base = (5, 6), 77, 3
+        dq_ = (np.random.RandomState(3).randn(1091, spec.n_actions) / 1091).astype(np.float32)
+        q_inf = net.forward_multi([dict(params=params, obs=patch, patch=True), dict(params=params, obs=patch[:37].contiguous(), patch=True)])
+        q_inf = [q.clone() for q in q_inf]
+        q_tr = net.forward_multi([dict(params=params, obs=patch, patch=True, training=True, seed=seed, t=t, sample_base=base)])[0].clone()
+        g = net.backward(params, torch.from_numpy(dq_).cuda()).clone()
+        out[planes] = q_inf + [q_tr, g]
+    for a, b in zip(out["0"], out["1"]):
+        assert torch.equal(a, b)

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r06g; o=gpurun_out/r06g
-python -m pytest tests/test_distributed_gpu.py tests/test_shipped_weights.py -m gpu -x -q > $o/gputests2.log 2>&1; tail -4 $o/gputests2.log | cut -c1-300
-bash tools/r06/c5_prof.sh
+mkdir -p gpurun_out/r06m; o=gpurun_out/r06m
+python -m pytest tests -m gpu -x -q > $o/gputests.log 2>&1; tail -6 $o/gputests.log | cut -c1-300
+tools/restamp_pmc.sh > $o/restamp.log 2>&1; tail -2 $o/restamp.log
