@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--minibatch", type=int, default=0, help="DQN minibatch per rank (default: n_envs)")
     ap.add_argument("--lattices", type=int, default=0, help="lattices per rank (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--env-steps-per-launch", type=int, default=32, help="--mode env: agent steps per environment launch (dq_env_act_steps); 1 = one launch per step")
+    ap.add_argument("--env-steps-per-launch", type=int, default=64, help="--mode env: agent steps per environment launch (dq_env_act_steps); 1 = one launch per step")
     ap.add_argument("--env-obs", default="patch", choices=["patch", "uint8"], help="--mode env: successor observations as the loop's patch words or as the reference's uint8 planes")
     ap.add_argument("--dist-probe-steps", type=int, default=50,
                     help="--gpus N > 1: untimed vector steps per form of the gradient exchange (single / overlap) timed before the timed region, which then runs "

@@ -175,14 +175,22 @@ __device__ __forceinline__ void dq_wave_argmax(float& best, int& best_a) {
 }
 
 // index of the k-th (0-based) set bit of a 128-bit mask; -1 if fewer bits are set
+// (round 6: constant time, no loop -- the word by three comparisons against the words' running bit counts, the bit inside it by a binary search on the bit counts of
+// halves; "drop the k lowest set bits" was up to 50 trips of 64-bit arithmetic per lattice, and the two lattices of a wave waited for the longer one)
 __device__ __forceinline__ int kth_set_bit128(u64 lo, u64 hi, int k) {
-    const int nlo = __popcll(lo);
-    u64 m = lo;
-    int base = 0;
-    if (k >= nlo) { m = hi; k -= nlo; base = 64; }
-    if (k >= __popcll(m)) return -1;
-    for (int i = 0; i < k; ++i) m &= m - 1;      // drop the k lowest set bits
-    return base + __ffsll((long long)m) - 1;
+    const u32 w0 = (u32)lo, w1 = (u32)(lo >> 32), w2 = (u32)hi, w3 = (u32)(hi >> 32);
+    const int c0 = __popc(w0), c1 = c0 + __popc(w1), c2 = c1 + __popc(w2), c3 = c2 + __popc(w3);
+    if (k < 0 || k >= c3) return -1;
+    const bool s1 = k >= c0, s2 = k >= c1, s3 = k >= c2;
+    u32 m = s3 ? w3 : s2 ? w2 : s1 ? w1 : w0;
+    int kk = k - (s3 ? c2 : s2 ? c1 : s1 ? c0 : 0), pos = 32 * ((int)s1 + (int)s2 + (int)s3);
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1) {
+        const int t = __popc(m & ((1u << h) - 1u));
+        const bool up = kk >= t;
+        kk -= up ? t : 0; pos += up ? h : 0; m = up ? m >> h : m;
+    }
+    return pos;
 }
 
 // Replay row of minibatch sample `sample_id` of update t (shared by every launch that carries the sampling along).

@@ -96,6 +96,24 @@ static __device__ __forceinline__ u32 env_patch_word(const EnvParams& p, const v
     return w;
 }
 
+// The same for lattices whose stabilizers fit 32 bits (the two-per-wave form, d <= 5): the corners' shifts and validity are loop invariants of the caller (ps is a
+// per-lane constant), a plane costs four bit-field extracts and one masked insert
+static __device__ __forceinline__ u32 env_patch_word32(const EnvParams& p, const volatile u64* vol, u64 comp0, u64 comp1, u32 ps, int pix) {
+    const u32 s0 = ps & 0xffu, s1 = (ps >> 8) & 0xffu, s2 = (ps >> 16) & 0xffu, s3 = ps >> 24;
+    const u32 valid = (s0 < 32u ? 1u : 0u) | (s1 < 32u ? 2u : 0u) | (s2 < 32u ? 4u : 0u) | (s3 < 32u ? 8u : 0u);
+    u32 w = 0;
+    for (int j = 0; j < p.depth; ++j) {
+        const u32 v = (u32)vol[j];
+        const u32 nib = ((v >> (s0 & 31u)) & 1u) | (((v >> (s1 & 31u)) & 1u) << 1) | (((v >> (s2 & 31u)) & 1u) << 2) | (((v >> (s3 & 31u)) & 1u) << 3);
+        w |= (nib & valid) << (4 * j);
+    }
+    for (int l = 0; l < p.layers; ++l) {
+        const int a = l * p.d2 + pix;
+        w |= (u32)(((a < 64 ? comp0 : comp1) >> (a & 63)) & 1) << (4 * p.depth + l);
+    }
+    return w;
+}
+
 // lanes of one wave hand words to each other through LDS (the per-wave referee tables, the volume words): wavefront-scope release / acquire
 // + wave barrier, so that the ordering does not rest on the compiler's aliasing analysis (as match_dev.h match_wave_sync)
 static __device__ __forceinline__ void env_wave_sync() {
@@ -612,13 +630,15 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
         DQ_STAMP(DQ_TAG_ENV, 4);
 
         // ---- state record and scalar outputs ----------------------------------------------------
-        const u64 meta_out = (u64)lifetime | ((u64)done << 32);
-        u64 o = 0;
-        o = hl == 0 ? xmask : o;  o = hl == 1 ? zmask : o;  o = hl == 2 ? acted : o;
-        o = hl == 3 ? round : o;  o = hl == 4 ? comp0 : o;  o = hl == 5 ? comp1 : o;
-        o = hl == 6 ? legal0 : o; o = hl == 7 ? legal1 : o; o = hl == 8 ? meta_out : o;
-        if (hl >= STATE_FIXED && hl < STATE_FIXED + p.depth) o = vol[hl - STATE_FIXED];
-        if (hl < p.sw && (!MULTI || last_step)) rec[hl] = o;
+        if (!MULTI || last_step) {                                          // (the record leaves once per launch)
+            const u64 meta_out = (u64)lifetime | ((u64)done << 32);
+            u64 o = 0;
+            o = hl == 0 ? xmask : o;  o = hl == 1 ? zmask : o;  o = hl == 2 ? acted : o;
+            o = hl == 3 ? round : o;  o = hl == 4 ? comp0 : o;  o = hl == 5 ? comp1 : o;
+            o = hl == 6 ? legal0 : o; o = hl == 7 ? legal1 : o; o = hl == 8 ? meta_out : o;
+            if (hl >= STATE_FIXED && hl < STATE_FIXED + p.depth) o = vol[hl - STATE_FIXED];
+            if (hl < p.sw) rec[hl] = o;
+        }
         if (hl == 0) {
             if (reward_out) reward_out[i] = reward;
             if (done_out) done_out[i] = (u8)done;
@@ -662,7 +682,7 @@ static __device__ __forceinline__ void env_block2(const EnvParams& p, const int 
         }
         if (patch_out) {                                                    // compact observation (env_block's comment)
             env_wave_sync();
-            const u32 w = env_patch_word(p, vol, comp0, comp1, pstab, hl);
+            const u32 w = env_patch_word32(p, vol, comp0, comp1, pstab, hl);      // (n_stab <= 32 in this form)
             if (hl < p.d2) patch_out[(size_t)i * p.patch_stride + hl] = w;
             if (MULTI) env_wave_sync();                                     // (the next step's volume overwrites the words these lanes have just read)
         }

@@ -6,8 +6,8 @@
 #   bench.py prints `roofline.traffic` from it only while the sources still hash to that value).
 root="${GRAFT_REPO_ROOT:-$PWD}"; cd "$root"; mkdir -p gpurun_out
 mode="${1:-loop}"; config="${2:-c3}"; shift; shift
-# (--mode env launches 32 agent steps at a time -- dq_env_act_steps --: 1280 steps = 40 full launches, 32 untimed ones in front)
-steps=40; warmup=5; if [ "$mode" = env ]; then steps=1280; warmup=32; fi
+# (--mode env launches 64 agent steps at a time -- dq_env_act_steps --: 2560 steps = 40 full launches, 64 untimed ones in front)
+steps=40; warmup=5; if [ "$mode" = env ]; then steps=2560; warmup=64; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf "gpurun_out/pmc_$c"
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $c --kernel-trace -d "$root/gpurun_out/pmc_$c" -o pmc --output-format csv -- python "$root/bench.py" --mode "$mode" --config "$config" --steps $steps --warmup $warmup --no-cpu-baseline "$@" > "$root/gpurun_out/pmc_$c.log" 2>&1)
