@@ -14,7 +14,11 @@ tools/pmc_traffic.sh env c3 > "$out/pmc_env.log" 2>&1; cp gpurun_out/pmc_traffic
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 python bench.py 2>"$out/bench_c3_loop.err" | line > "$out/bench_c3_loop.json"
 for cfg in c2 c5; do python bench.py --config $cfg --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_${cfg}_loop.json"; done
-for mode in act learn env; do python bench.py --mode $mode --steps 1000 --warmup 50 2>/dev/null | line > "$out/bench_c3_${mode}.json"; done
+for mode in act learn; do python bench.py --mode $mode --steps 1000 --warmup 50 2>/dev/null | line > "$out/bench_c3_${mode}.json"; done
+# environment only: 64 agent steps per launch (dq_env_act_steps; patch words into a ring), then one step per launch, then the reference's uint8 planes at 64 per launch
+python bench.py --mode env --steps 2560 --warmup 256 2>/dev/null | line > "$out/bench_c3_env.json"
+python bench.py --mode env --env-steps-per-launch 1 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_env_T1.json"
+python bench.py --mode env --env-obs uint8 --steps 2560 --warmup 256 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_env_uint8.json"
 python bench.py --minibatch 32 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_mb32.json"
 # the reference's replay ratio, 32 trained samples per environment step (one 32-sample update per step, TRAIN:119-127), three ways:
 # 32 updates of 4096 per vector step; 4 updates of 32768; and the reference's own schedule, 4096 updates of 32 (a few steps: 0.3 s each)
@@ -28,6 +32,9 @@ DQ_CONV_FORM=group python bench.py --updates-per-step 32 --steps 100 --warmup 5 
 DQ_CONV_BWD_FORM=8 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_bwd8form.json"
 DQ_CONV_BWD_FORM=8 DQ_CONV_FORM=group python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_round4forms.json"
 DQ_PAIR_TARGETS=0 python bench.py --updates-per-step 32 --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_ratio32_unpaired.json"
+# round 6: a1 through HBM (the round-5 form) beside the recomputing conv backward; the last convolution's output as piece planes (built, off by default)
+DQ_CONV_BWD_A1=saved python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_a1saved.json"
+DQ_X_PLANES=1 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_xplanes.json"
 # the uint8 ring beside the patch-word ring (DQNCore.compact), same box
 DQ_COMPACT_OBS=0 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_uint8ring.json"
 DQ_COMPACT_OBS=0 python bench.py --config c5 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c5_loop_uint8ring.json"
