@@ -39,7 +39,7 @@ DQ_X_PLANES=1 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/
 DQ_COMPACT_OBS=0 python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c3_loop_uint8ring.json"
 DQ_COMPACT_OBS=0 python bench.py --config c5 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | line > "$out/bench_c5_loop_uint8ring.json"
 rm -rf "$out/prof"
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -- python "$root/bench.py" --steps 500 --warmup 50 --no-cpu-baseline > "$root/$out/prof.log" 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -- python "$root/bench.py" --steps 500 --warmup 50 --no-cpu-baseline --ratio-steps 0 > "$root/$out/prof.log" 2>&1)
 python tools/rocprof_summary.py $(ls $out/prof/*/*.db | head -1) "$out/loop_c3_kernel_stats.csv"
 # per (kernel, grid): the step's launches apart from the set-up's (ring fill, resets) of the same kernels
 python tools/rocprof_shapes.py $(ls $out/prof/*/*.db | head -1) 500 > "$out/loop_c3_kernel_shapes.txt"

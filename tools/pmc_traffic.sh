@@ -10,7 +10,7 @@ mode="${1:-loop}"; config="${2:-c3}"; shift; shift
 steps=40; warmup=5; if [ "$mode" = env ]; then steps=2560; warmup=64; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf "gpurun_out/pmc_$c"
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $c --kernel-trace -d "$root/gpurun_out/pmc_$c" -o pmc --output-format csv -- python "$root/bench.py" --mode "$mode" --config "$config" --steps $steps --warmup $warmup --no-cpu-baseline "$@" > "$root/gpurun_out/pmc_$c.log" 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $c --kernel-trace -d "$root/gpurun_out/pmc_$c" -o pmc --output-format csv -- python "$root/bench.py" --mode "$mode" --config "$config" --steps $steps --warmup $warmup --no-cpu-baseline --ratio-steps 0 "$@" > "$root/gpurun_out/pmc_$c.log" 2>&1)
 done
 MODE="$mode" CONFIG="$config" EXTRA="$*" python3 - <<'PY'
 import csv, glob, json, collections, importlib, os, sys
@@ -44,7 +44,7 @@ extra = os.environ.get("EXTRA", "").split()
 arg = lambda name, default: int(extra[extra.index(name) + 1]) if name in extra else default
 shape = {"minibatch": arg("--minibatch", 0), "updates_per_step": arg("--updates-per-step", 1), "lattices": arg("--lattices", 0)}      # 0 = the configuration's default
 path = f"gpurun_out/pmc_traffic_{mode}_{config}.json"
-json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --mode {mode} --config {config} --steps 40 --warmup 5 --no-cpu-baseline`",
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --mode {mode} --config {config} --steps 40 --warmup 5 --no-cpu-baseline --ratio-steps 0` (--mode env: 2560 / 64)",
            "correction": "MI355X_MICROARCH.md HBM section: unit KB; gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B -> x2; WRITE_SIZE uncalibrated (used as is)",
            "csrc_sha256": digest, "shape": shape, "launches_averaged": "the last 40 of each kernel (the timed steps)", "kernels": out}, open(path, "w"), indent=1)
 print(path, digest[:16])
