@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void policy_wide_kernel(const float* __restric
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 void match_comp(const struct dq_match* M, int comp, MatchComp* out);     // match.hip
+dq_status match_reset_locks(const struct dq_match* M, hipStream_t st);   // match.hip: the scratch pool's lock words, in front of every launch that may take a slot
 
 struct dq_envb {
     dq_env_cfg cfg;
@@ -533,6 +534,7 @@ static dq_status big_launch(dq_envb* E, const BigParams& p, hipStream_t st) {
     const int blocks = (p.n_envs + BIG_EPB - 1) / BIG_EPB;
     const size_t lds = BIG_EPB * big_wave_lds(p.sw);
     DQ_REQUIRE(lds <= 160 * 1024, DQ_ERR_UNSUPPORTED, "lattice record too large for LDS");
+    { const dq_status rc = match_reset_locks(E->match, st); if (rc != DQ_OK) return rc; }
     dq_prof_begin(DQ_K_ENV, st);
     switch (E->W) {
         case 1: env_big_kernel<1><<<blocks, 64 * BIG_EPB, lds, st>>>(p); break;

@@ -32,6 +32,14 @@ void match_comp(const dq_match* M, int comp, MatchComp* out) {
     out->pool = M->pool; out->pool_lock = M->pool + ((size_t)DQ_MATCH_POOL_SLOTS << DQ_MATCH_MAX_BIG);
 }
 
+// The scratch pool's lock words are re-zeroed on the launch's own stream in front of every launch that may take a slot (dq_match_decode, the wide environment's
+// step): a kernel that faulted or was killed while holding one would otherwise leave it taken and every later big-cluster decode on this handle spinning for ever
+// (ADVICE r5).  Launches of ONE handle are stream-ordered (the handle is not thread-safe), so no live holder can be wiped.
+dq_status match_reset_locks(const dq_match* M, hipStream_t st) {
+    if (M && M->pool) DQ_HIP(hipMemsetAsync(M->pool + ((size_t)DQ_MATCH_POOL_SLOTS << DQ_MATCH_MAX_BIG), 0, DQ_MATCH_POOL_SLOTS * sizeof(u32), st));
+    return DQ_OK;
+}
+
 extern "C" {
 
 void dq_match_destroy(dq_match* M);
@@ -112,6 +120,7 @@ dq_status dq_match_decode(const dq_match* M, const uint64_t* defects_dev, int ba
     MatchComp cx, cz;
     match_comp(M, 0, &cx);
     match_comp(M, 1, &cz);
+    { const dq_status rc = match_reset_locks(M, (hipStream_t)stream); if (rc != DQ_OK) return rc; }
     match_decode_kernel<<<batch, 64, DQ_MATCH_LDS, (hipStream_t)stream>>>(cx, cz, defects_dev, batch, both_components, class_dev, inexact_dev);
     DQ_LAUNCH_CHECK();
     return DQ_OK;

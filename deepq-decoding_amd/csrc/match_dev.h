@@ -231,7 +231,10 @@ static __device__ __forceinline__ int match_classify(const MatchComp& T, u64 d0,
         if (k <= DQ_MATCH_MAX_DEFECTS) {
             match_dp_lds(s_cl, s_pd, s_pb, f, k, lane, w0, w1);
         } else {
-            // a slot of the scratch pool: lane 0 takes the first free one (spinning over the slots: holders always finish), every lane uses it, lane 0 frees it
+            // a slot of the scratch pool: lane 0 takes the first free one (spinning over the slots: holders always finish -- and a slot left taken by a launch that
+            // died is freed by the host in front of the next launch, match.hip match_reset_locks), every lane uses it, lane 0 frees it.  Worst case: a cluster of
+            // DQ_MATCH_MAX_BIG = 20 defects walks 2^20 subsets through device memory, a multi-millisecond stall of its wave (and of the vector step that waits for it);
+            // the d = 9 fit of the test suite meets 15-20-defect clusters on a few dozen of its ~10^5 lattice-steps
             int slot = 0;
             if (lane == 0) {
                 for (;; slot = (slot + 1) % DQ_MATCH_POOL_SLOTS) {
