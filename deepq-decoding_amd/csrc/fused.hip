@@ -957,9 +957,16 @@ struct DenseChainArgs {
     unsigned* range_flag;               // the forward's range guard (qnet.h range_report), nullable
 };
 
-template <int NT2, int KG3, int RT>     // N2 <= 16*NT2 (column tiles of Dense(|A|)); N2 <= 16*KG3 (k groups of the dueling layer);
+// LEAN (round 6; NT2 = 4, RT = 2 only; measured SLOWER, off by default -- see fused_forward_multi): the same arithmetic in at most 128 VGPRs, so that TWO workgroups
+// share a CU (4 waves per SIMD), in the hope that one's staging, epilogues and reductions run under the other's MFMAs -- the one-workgroup-per-CU form runs its phases
+// one after the other with the matrix pipe busy ~40 % of the kernel.  What it gives up: the hidden layer's weights are held as ONE ring of four tiles refilled in place (no second block in flight: the other waves of the SIMD cover the latency),
+// Dense(|A|)'s weights come one K block at a time behind the hidden epilogues of BOTH row tiles (the accumulators die first), the folded dueling layer's operand is
+// requested where it is used; 32 rows per weight stream instead of 64 (twice the L2 -> CU bytes, under the MFMAs of twice the waves).  Every accumulator sees the
+// same products in the same order as in the other forms: the same bits.
+template <int NT2, int KG3, int RT, bool LEAN = false>     // N2 <= 16*NT2 (column tiles of Dense(|A|)); N2 <= 16*KG3 (k groups of the dueling layer);
                                         // RT row tiles of 16 samples per workgroup
-__global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChainArgs a) {
+__global__ __launch_bounds__(DENSE_THREADS, LEAN ? 4 : 2) void dense_chain_kernel(DenseChainArgs a) {
+    static_assert(!LEAN || (NT2 == 4 && RT == 2), "the lean form is written for 32-sample workgroups of the 64-action geometry");
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     float* s_x = reinterpret_cast<float*>(smem + a.off_x);
     float* s_part = reinterpret_cast<float*>(smem + a.off_part);
@@ -1110,7 +1117,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     // the input pieces of step (b, u) + 1 are read from LDS BEFORE step (b, u)'s MFMAs are issued (DENSE_XPIPE; xq[parity of the step]):
     // read next to their use, every row tile of every block waited out one LDS latency with the matrix pipe idle
     F16x2 xq[2];
-    if (DENSE_XPIPE) x_read(0, 0, xq[0]);
+    if (DENSE_XPIPE && !LEAN) x_read(0, 0, xq[0]);
     auto do_block = [&](int b, F16x2 (&cur)[4], F16x2 (&nxt)[4], auto ptag) {
         constexpr int P0 = decltype(ptag)::value;                   // parity of step (b, 0)
         const u32x4* pn = pkw + (size_t)min(b + 1, KB - 1) * 32 * PK_BLOCK;      // next block: unconditional, clamped prefetch
@@ -1132,12 +1139,29 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     };
     using par0 = std::integral_constant<int, 0>;
     using par1 = std::integral_constant<int, (RT & 1)>;             // an odd RT alternates the parity from block to block
+    if constexpr (LEAN) {
+        // one ring of four tiles (bw[0]), each slot refilled with the NEXT block's tile right behind the MFMAs that read it; the block's input pieces for both
+        // row tiles read at its top
+        for (int blk = 0; blk < KB; ++blk) {
+            const u32x4* pn = pkw + (size_t)min(blk + 1, KB - 1) * 32 * PK_BLOCK;      // (past the last block: re-reads it, unused)
+            F16x2 xv[RT];
+#pragma unroll
+            for (int u = 0; u < RT; ++u) x_read(blk, u, xv[u]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int u = 0; u < RT; ++u) mma_f16x3(bw[0][t], xv[u], acc[u][t][0], acc[u][t][1]);
+                bw[0][t].h = pn[t * PK_BLOCK]; bw[0][t].l = pn[t * PK_BLOCK + PK_LO];
+            }
+        }
+    } else {
     int blk = 0;
     for (; blk + 1 < KB; blk += 2) {                                // no condition around the MFMAs inside the loop
         do_block(blk, bw[0], bw[1], par0{});
         do_block(blk + 1, bw[1], bw[0], par1{});
     }
     if (blk < KB) do_block(blk, bw[0], bw[1], par0{});               // odd block count (K1 = 288: 9 blocks)
+    }
 
     DQ_STAMP(DQ_TAG_DENSE_FWD, 2);
     // ---- Dense(|A|)^T's weights for this wave's 64 units (two K = 32 blocks x NT2 tiles of 16 outputs: qnet.h dense2) start flying
@@ -1156,7 +1180,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
             for (int t = 0; t < NTW; ++t) { w[b][t].h = pk2[(b * NT2 + t0 + t) * PK_BLOCK]; w[b][t].l = pk2[(b * NT2 + t0 + t) * PK_BLOCK + PK_LO]; }
     };
-    if constexpr (!WIDE2) load_w2(w2, 0);
+    if constexpr (!WIDE2 && !LEAN) load_w2(w2, 0);
     // The dueling layer Dense(|A| + 1) and the combination Q = V + A - mean(A) are ONE linear map of Dense(|A|)'s output: pack_weights_kernel
     // folds them into W3' [16 KG3][16 NT2] (zero past N2 / past |A|) and b3' (PackLayout.w3q), so that the last phase's MFMA accumulators ARE the
     // Q-values (round 3: a separate combination -- every wave reading eight rows back from LDS, butterfly sums, a barrier in between -- was 5K of a
@@ -1172,14 +1196,15 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     const bool act3 = a.N3 > 0 && part < parts;
     const int col3 = 16 * ct3 + j;
     float bias3 = 0.f;
-    if (act3) {                                                     // (requested here, used three barriers later; unconditional: the table is zero-padded)
+    auto load_b3 = [&]() {
         const float* w3q = reinterpret_cast<const float*>(J.packed + a.pk_w3q);
         bias3 = w3q[16 * KG3 * PW + col3];
 #pragma unroll
         for (int g = 0; g < KG3; ++g)
 #pragma unroll
             for (int s = 0; s < 4; ++s) b3[g][s] = w3q[(16 * g + 4 * kq + s) * PW + col3];
-    }
+    };
+    if (act3 && !LEAN) load_b3();                                   // (requested here, used three barriers later; unconditional: the table is zero-padded.  LEAN: where it is used)
     const int rcol = tid & 63;                                      // column (+ 64 cc) of the cross-wave reduction below
     float bias2r[(PW + 63) / 64];
 #pragma unroll
@@ -1220,6 +1245,29 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
         }
         range_commit(rbad, rm);
     };
+    if constexpr (LEAN) {
+        static_assert(!LEAN || (ROWS / PR == 1 && UP == 2), "one reduction pass over both row tiles");
+        F16x2 hbw[2][2];
+        hidden_pieces(0, hbw[0]);
+        hidden_pieces(1, hbw[1]);                                   // (the hidden accumulators are dead from here)
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            f32x4 acc2[NT2][2];
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) { acc2[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t][1] = acc2[t][0]; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {                           // one K block of Dense(|A|)'s weights at a time (re-read per row tile: 16 KB per wave out of L2)
+                F16x2 wb[NT2];
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) { wb[t].h = pk2[(b * NT2 + t) * PK_BLOCK]; wb[t].l = pk2[(b * NT2 + t) * PK_BLOCK + PK_LO]; }
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) mma_f16x3(wb[t], hbw[uu][b], acc2[t][0], acc2[t][1]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT2; ++t)
+                *reinterpret_cast<f32x4*>(s_part + (wave * PR + 16 * uu + j) * PWP + 16 * t + 4 * kq) = f16x2_sum(acc2[t][0], acc2[t][1]);
+        }
+    }
     if constexpr (WIDE2) {
         static_assert(!WIDE2 || (ROWS / PR == 1 && UP == 2), "one reduction pass over both row tiles");
         F16x2 hbw[2][2];
@@ -1247,7 +1295,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
 #pragma unroll
     for (int pass = 0; pass < ROWS / PR; ++pass) {
 #pragma unroll
-        for (int uu = 0; uu < (WIDE2 ? 0 : UP); ++uu) {
+        for (int uu = 0; uu < (WIDE2 || LEAN ? 0 : UP); ++uu) {
             const int u = pass * UP + uu, row = 16 * u + j;         // this lane's sample
             F16x2 hb[2];                                            // the sample's units 8kq .. 8kq+7 of this wave's two blocks, as pieces
             float rm = 0.f;                                         // this epilogue's maximum (qnet.h range_max)
@@ -1332,6 +1380,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_chain_kernel(DenseChai
     // ---- Q = y2 W3' + b3' (the dueling layer and its combination, folded: see above), straight from the accumulators to global memory ----
     if (a.N3 > 0) {
         if (act3) {
+            if constexpr (LEAN) load_b3();
             for (int u = part; u < RT; u += parts) {
                 f32x4 acc3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // two chains: a dependent f32 MFMA waits for its predecessor
                 const float* yrow = s_y2 + (16 * u + j) * a.ld2 + 4 * kq;
@@ -1972,9 +2021,9 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         const conv_kernel_t pks[5] = {conv_chain_pkernel<3>, conv_chain_pkernel<4>, conv_chain_pkernel<5>, conv_chain_pkernel<6>, conv_chain_pkernel<0>};
         for (int i = 0; i < 5; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
-        const dense_kernel_t dks[5] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<4, 4, 4>,
-                                       dense_chain_kernel<8, 8, 2>};
-        for (int i = 0; i < 5; ++i)
+        const dense_kernel_t dks[6] = {dense_chain_kernel<4, 4, 1>, dense_chain_kernel<8, 8, 1>, dense_chain_kernel<4, 4, 2>, dense_chain_kernel<4, 4, 4>,
+                                       dense_chain_kernel<8, 8, 2>, dense_chain_kernel<4, 4, 2, true>};
+        for (int i = 0; i < 6; ++i)
             DQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_MAX));
         attr_devs |= dev_bit;
     }
@@ -2026,8 +2075,21 @@ dq_status fused_forward_multi(dq_qnet* Q, int n_jobs, const dq_qnet_job* jobs, h
         if (forced < 0) { const char* e = getenv("DQ_DENSE_RT"); forced = e ? atoi(e) : 0; }
         if ((forced == 1 || forced == 2 || forced == 4) && plan_dense(Q, &dpx, forced)) { RT = forced; dp = dpx; }
     }
+    // The lean form (round 6; dense_chain_kernel<4, 4, 2, true>: <= 128 VGPRs, two workgroups per CU) -- built, bit-identical, REFUTED: 28.6 against 26.4 us for the
+    // step's four forwards (the two co-resident workgroups run the SAME phase at the same time: they share the matrix pipe in the hidden layer and both wait in the
+    // staging and reduction phases, while every CU streams the hidden layer's weights twice; NOTEBOOK.md round 6 section 7).  Off; DQ_DENSE_LEAN=1: where 32-row
+    // workgroups outnumber the CUs, 2: wherever they fit (A/B runs, the tests' second form; read once per handle at dq_qnet_create)
+    bool lean = false;
+    {
+        const int lean_mode = Q->dense_lean;
+        DensePlan dl;
+        if (lean_mode > 0 && dp.NT2 == 4 && plan_dense(Q, &dl, 2) && 2 * dl.lds <= CHAIN_LDS_MAX && ((tiles16 + 1) / 2 > n_cu || lean_mode == 2)) {
+            lean = true; RT = 2; dp = dl;
+        }
+    }
     const int dense_rows = 16 * RT;
-    const dense_kernel_t dk = dp.NT2 == 4 ? (RT == 4 ? dense_chain_kernel<4, 4, 4> : RT == 2 ? dense_chain_kernel<4, 4, 2> : dense_chain_kernel<4, 4, 1>)
+    const dense_kernel_t dk = lean ? dense_chain_kernel<4, 4, 2, true>
+                            : dp.NT2 == 4 ? (RT == 4 ? dense_chain_kernel<4, 4, 4> : RT == 2 ? dense_chain_kernel<4, 4, 2> : dense_chain_kernel<4, 4, 1>)
                                           : (RT == 2 ? dense_chain_kernel<8, 8, 2> : dense_chain_kernel<8, 8, 1>);
     da.ldx = dp.ldx; da.ld2 = dp.ld2; da.ld3 = dp.ld3;
     da.off_x = dp.off_x; da.off_h = dp.off_h; da.off_part = dp.off_part; da.off_y2 = dp.off_y2; da.off_y3 = dp.off_y3;

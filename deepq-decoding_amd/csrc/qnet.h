@@ -78,6 +78,7 @@ struct dq_qnet {
     int x_planes;                // 0 (default): the last convolution's output reaches the dense chain as f32 rows, split by its staging phase; 1 (DQ_X_PLANES=1 at
                                  // dq_qnet_create): conv_wave_kernel splits on write and the dense chain stages the piece planes by LDS-DMA (ConvJob.x_pl) -- round 6, built,
                                  // bit-identical, measured: dense forward -1.15 us, conv forward +0.7 us, the free-running step 0.5-1 % SLOWER (NOTEBOOK.md): off
+    int dense_lean;              // DQ_DENSE_LEAN at dq_qnet_create: 0 (default) never, 1 the lean dense forward where 32-row workgroups outnumber the CUs, 2 wherever they fit
     int last_a1_saved;           // the last training forward wrote the a1 piece planes (the backward that recomputes a1 must follow a forward that did NOT, and
                                  // the other way round: dq_qnet_set_kernel_forms between the two is refused)
     // patch-word input (dq_qnet_set_patch_input): observations as d * d words per sample instead of the padded uint8 image

@@ -392,6 +392,8 @@ dq_status dq_qnet_create(const dq_qnet_cfg* cfg, dq_qnet** out) {
         Q->last_a1_saved = 1;
         const char* xp = getenv("DQ_X_PLANES");
         Q->x_planes = xp && xp[0] == '1' ? 1 : 0;
+        const char* dl = getenv("DQ_DENSE_LEAN");
+        Q->dense_lean = dl ? atoi(dl) : 0;
     }
     // workspaces
     size_t max_partial = 0;

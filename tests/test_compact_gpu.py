@@ -361,3 +361,23 @@ def test_last_convolution_output_as_piece_planes_changes_no_bit(dq, torch_mod, m
         out[planes] = q_inf + [q_tr, g]
     for a, b in zip(out["0"], out["1"]):
         assert torch.equal(a, b)
+
+
+def test_lean_dense_forward_changes_no_bit(dq, torch_mod, monkeypatch):
+    """DQ_DENSE_LEAN=2 (round 6, off by default: measured slower): the dense forward in at most 128 VGPRs, two 32-row workgroups per CU -- one ring of weight tiles
+    refilled in place, Dense(|A|)'s weights one K block at a time -- feeds every accumulator the same products in the same order: Q-values, the saved planes the
+    backward reads, and therefore the gradients are bit-identical to the default form's, for full, ragged and tiny batches."""
+    torch = torch_mod
+    out = {}
+    for lean in ("0", "2"):
+        monkeypatch.setenv("DQ_DENSE_LEAN", lean)
+        spec, net, params, flat, obs, patch, rng = _setup(dq, torch, "c3", 1091)
+        seed, t, base = (5, 6), 77, 3
+        dq_ = (np.random.RandomState(3).randn(1091, spec.n_actions) / 1091).astype(np.float32)
+        q_inf = [q.clone() for q in net.forward_multi([dict(params=params, obs=patch, patch=True), dict(params=params, obs=patch[:37].contiguous(), patch=True)])]
+        q_one = net.forward_multi([dict(params=params, obs=patch[5:6].contiguous(), patch=True)])[0].clone()
+        q_tr = net.forward_multi([dict(params=params, obs=patch, patch=True, training=True, seed=seed, t=t, sample_base=base)])[0].clone()
+        g = net.backward(params, torch.from_numpy(dq_).cuda()).clone()
+        out[lean] = q_inf + [q_one, q_tr, g]
+    for a, b in zip(out["0"], out["2"]):
+        assert torch.equal(a, b)
