@@ -277,7 +277,7 @@ def main():
     mode = args.mode
 
     if mode == "env":
-        runner = EnvOnly(dq, cfg, n_local, rank, steps_per_launch=args.env_steps_per_launch, obs_form=args.env_obs)
+        runner = EnvOnly(dq, cfg, n_local, rank, steps_per_launch=args.env_steps_per_launch, obs_form=args.env_obs, config_name=args.config)
     else:
         runner = importlib.import_module("deepq-decoding_amd.bench_loop").FullLoop(
             dq, cfg, n_local, rank, world, args.minibatch or n_local, mode=mode, config_name=args.config, updates_per_step=max(1, args.updates_per_step))
@@ -470,10 +470,10 @@ class EnvOnly:
     not one launch latency per 4096-lattice step (SURVEY.md section 7 "hard parts")."""
     dtype = "u64 bit-planes / u8"
 
-    def __init__(self, dq, cfg, n_local, rank, steps_per_launch=16, ring_slots=32, obs_form="patch"):
+    def __init__(self, dq, cfg, n_local, rank, steps_per_launch=16, ring_slots=32, obs_form="patch", config_name="c3"):
         import torch
         self.torch = torch
-        self.cfg, self.n = cfg, n_local
+        self.cfg, self.n, self.config_name = cfg, n_local, config_name
         self.env = dq.VectorEnv(n_envs=n_local, env_id_base=rank * n_local, **cfg)
         self.env.reset()
         self.T = max(1, int(steps_per_launch))
@@ -539,7 +539,7 @@ class EnvOnly:
         bytes_per_launch = self.n * (per_step * k + 2 * S)
         achieved = bytes_per_launch / (ms_l * 1e-3) / 1e9
         return {"roofline": dict(kernel=symbol, family="env_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                                 frac=achieved / HBM_PEAK_GBS, traffic=self.bl.pmc_traffic(symbol, "env", "c3"), avg_launch_us=ms_l * 1e3,
+                                 frac=achieved / HBM_PEAK_GBS, traffic=self.bl.pmc_traffic(symbol, "env", self.config_name) if self.obs_form == "patch" and k == 64 else None, avg_launch_us=ms_l * 1e3,
                                  min_launch_us=lo.value * 1e3, max_launch_us=hi.value * 1e3, launches_timed=launches, steps_per_launch=k,
                                  algorithmic_bytes_per_launch=bytes_per_launch, lattice_steps_per_s_in_kernel=self.n * k / (ms_l * 1e-3))}
 
