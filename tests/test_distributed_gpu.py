@@ -216,3 +216,27 @@ def test_rccl_preflight_on_a_one_rank_group():
             "c.close(); dist.destroy_process_group(); print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stderr[-2000:]     # (RCCL prints its version banner through C stdio at exit, behind the line)
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_the_whole_claim():
+    """a driver-shaped run (`python bench.py --steps 20 --warmup 5`, cpu baseline off here for time) prints ONE line whose `roofline` names the
+    kernel SYMBOL that ran beside its family, carries the launch spread and a non-null PMC traffic (the committed pass matches the sources: the CPU suite's
+    test_pmc_stamp_matches_sources), and whose `reference_replay_ratio` is a second timed leg at 32 trained samples per environment step."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--ratio-steps", "20"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5 and out["vs_baseline"] is None and out["higher_is_better"] is True
+    assert "d=5" in out["config"]["workload"] and "4096 lattices" in out["config"]["workload"] and out["unit"] == "env_steps/s"
+    roof = out["roofline"]
+    assert roof["kernel"] == "conv_wave_kernel" and roof["family"] == "conv_chain_kernel" and roof["bound"] == "mfma"
+    assert 0.0 < roof["frac"] < 1.0 and roof["min_launch_us"] <= roof["avg_launch_us"] <= roof["max_launch_us"] and roof["launches_timed"] == 5
+    assert roof["traffic"] is not None and 1e6 < roof["traffic"] < 2e8, "profiles/pmc_traffic_loop_c3.json is stale or does not list conv_wave_kernel"
+    # the dominant kernel's live duration fits the step, the algorithmic rate stays below the pipe's peak
+    assert roof["avg_launch_us"] < 1e3 * out["ms_per_step"] and roof["achieved"] < roof["peak"]
+    ratio = out["reference_replay_ratio"]
+    assert ratio["updates_per_vector_step"] == 32 and ratio["samples_trained_per_env_step"] == 32.0 and ratio["steps"] == 20
+    assert ratio["value"] > 5e5 and abs(ratio["value"] - 4096 * 1e3 / ratio["ms_per_step"]) < 1.0
