@@ -714,7 +714,12 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_bwd_chain_kernel(Dense
 #define WG_NK ((4 * WG_NCH + 3) / 4)    // ... per wave and iteration
 #define WG_IMG (WG_ROWS * WG_PS)        // halves per image (WG_ROWS rows of one operand and piece)
 #define WG_BUF (4 * WG_IMG)             // ... per buffer: [operand][piece]
-#define DENSE_WGRAD_LDS ((2 * WG_BUF * 2) > 64 * 68 * 4 ? (2 * WG_BUF * 2) : 64 * 68 * 4)      // two buffers (the finished tile is staged over them)
+#ifndef WG_NBUF
+#define WG_NBUF 2                       // operand buffers per workgroup: WG_NBUF - 1 iterations' copies in flight under the one being multiplied (2: two workgroups per CU;
+                                        // 4 -- 144 KB, one workgroup per CU, three iterations in flight -- with WG_SLICES_TARGET 5: round 6's experiment, NOTEBOOK.md)
+#endif
+#define DENSE_WGRAD_LDS ((WG_NBUF * WG_BUF * 2) > 64 * 68 * 4 ? (WG_NBUF * WG_BUF * 2) : 64 * 68 * 4)      // the buffers (the finished tile is staged over them)
+static_assert(DENSE_WGRAD_LDS <= CHAIN_LDS_MAX && (WG_NBUF - 2) * WG_NK <= 63, "LDS budget / s_waitcnt vmcnt range");
 
 struct WgradOperand {
     const float* f32;                   // [batch, cols] f32 (+ 16 bytes of slack), or NULL when the operand comes as piece planes:
@@ -823,7 +828,7 @@ __device__ __forceinline__ void dense_wgrad_body(const DenseWgradArgs& a, const 
     }
     const int ldx = L.X.ld, ldg = L.G.ld;
     auto issue = [&](int it) {
-        unsigned short* dst = s_t + (it & 1) * WG_BUF;
+        unsigned short* dst = s_t + (it % WG_NBUF) * WG_BUF;
 #pragma unroll
         for (int k = 0; k < WG_NK; ++k) {
             const int c = wave + 4 * k, img = min(c / WG_NCH, 3), ch = c - (c / WG_NCH) * WG_NCH;      // wave-uniform
@@ -845,7 +850,7 @@ __device__ __forceinline__ void dense_wgrad_body(const DenseWgradArgs& a, const 
     for (int tb = 0; tb < 2; ++tb) { accb[tb] = f32x4{0.f, 0.f, 0.f, 0.f}; accbx[tb] = accb[tb]; }
     const u32x4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};     // f16 1.0 x 8
     auto mm = [&](int it) {                                         // the iteration's two blocks: 16 transposing reads + 16 MFMAs each
-        const unsigned short* base = s_t + (it & 1) * WG_BUF;
+        const unsigned short* base = s_t + (it % WG_NBUF) * WG_BUF;
         const bool tail = m0 + WG_ROWS * it + WG_ROWS > m1;         // wave-uniform: only the slice's last iteration masks rows
 #pragma unroll
         for (int blk = 0; blk < WG_ROWS / 32; ++blk) {
@@ -880,13 +885,19 @@ __device__ __forceinline__ void dense_wgrad_body(const DenseWgradArgs& a, const 
     };
     // one step: this wave's copies of iteration `it` have landed; meet (everybody's have, and everybody has left the other buffer); request
     // iteration it + 1 into that buffer; multiply
-    issue(0);
+    // (WG_NBUF buffers: the copies of iterations it + 1 .. it + WG_NBUF - 2 may stay in flight across the wait for iteration it's -- a wave's copies land in order,
+    // WG_NK instructions per iteration; the count is an immediate, so the slice's last iterations, with fewer behind them, take their own)
+#pragma unroll
+    for (int u = 0; u < WG_NBUF - 1; ++u) if (u < n_it) issue(u);
     for (int it = 0; it < n_it; ++it) {
         DQ_STAMP(DQ_TAG_DENSE_WGRAD, 1 + 3 * min(it, 7));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int behind = min(n_it - 1 - it, WG_NBUF - 2);         // wave-uniform
+        if (WG_NBUF >= 4 && behind == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WG_NK) : "memory");
+        else if (WG_NBUF >= 3 && behind == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WG_NK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         DQ_STAMP(DQ_TAG_DENSE_WGRAD, 2 + 3 * min(it, 7));
-        if (it + 1 < n_it) issue(it + 1);
+        if (it + WG_NBUF - 1 < n_it) issue(it + WG_NBUF - 1);
         DQ_STAMP(DQ_TAG_DENSE_WGRAD, 3 + 3 * min(it, 7));
         mm(it);
     }
@@ -933,7 +944,7 @@ __device__ __forceinline__ void dense_wgrad_body(const DenseWgradArgs& a, const 
     DQ_STAMP_PAIR2(2);
 }
 
-__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wgrad_kernel(DenseWgradArgs a) {
+__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : WG_NBUF > 2 ? 1 : 2) void dense_wgrad_kernel(DenseWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     dense_wgrad_body(a, (int)blockIdx.x, smem);
 }
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wg
 // DQ_RIDE_ON=wgrad / wgrad_first (A/B runs; NOTEBOOK.md, Round 4 section 9: measured slower): the riding environment step (env_dev.h, 256 threads per
 // block) behind the gradient tiles (env_on 1) or in front of them (env_on 2); block-uniform.  A kernel of its own: the default launch keeps its
 // registers and its kernel-argument segment.
-__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : 2) void dense_wgrad_ride_kernel(DenseWgradArgs a, EnvParams env) {
+__global__ __launch_bounds__(WGRAD_THREADS, WG_ROWS == 32 ? 4 : WG_NBUF > 2 ? 1 : 2) void dense_wgrad_ride_kernel(DenseWgradArgs a, EnvParams env) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const int wblock = (int)blockIdx.x - (a.env_on == 2 ? a.env_wgs : 0);
     if (a.env_on == 2 ? wblock < 0 : wblock >= a.wg_count) {
