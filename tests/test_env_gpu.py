@@ -928,3 +928,53 @@ def test_dense_stack_referee_evaluated_on_the_device(dq, torch_mod):
     obs = single.reset()
     obs, r, dn, _ = single.step(single.identity_index)
     assert obs.shape == single.observation_space.shape and single._v.mlp_referee
+
+
+def test_act_steps_edge_cases(dq, torch_mod):
+    """dq_env_act_steps at the edges of its contract: one step per launch on a two-slot ring; no observation ring at all (actions only); sticky `done`
+    (auto_reset = 0: a finished lattice stays finished over the remaining steps of the launch, its reward 0, its state untouched); a launch that equals the same
+    steps taken through act_step one by one; bad rings are refused."""
+    import ctypes
+    import importlib
+    torch = torch_mod
+    cfg = CONFIGS["c3"]
+    n, seed = 300, (7, 8)
+    a = dq.VectorEnv(n_envs=n, seed=seed, **cfg)
+    b = dq.VectorEnv(n_envs=n, seed=seed, **cfg)
+    a.reset(); b.reset()
+    T = 2
+    act = torch.zeros((T, n), dtype=torch.int32, device=a.device)
+    rew = torch.zeros((T, n), dtype=torch.float32, device=a.device)
+    don = torch.zeros((T, n), dtype=torch.uint8, device=a.device)
+    patch = torch.zeros((T, n, a.patch_stride), dtype=torch.int32, device=a.device)
+    for t in range(9):                                              # one step per launch, two slots: slot t % 2, successor in the other
+        a.act_steps(1, t, act, rew, don, patch_ring=patch, slot0=t)
+        pb = torch.zeros((n, b.patch_stride), dtype=torch.int32, device=b.device)
+        ab = b.act_step(t, q=None, auto_reset=True, out_patch=pb)
+        assert torch.equal(act[t % T], ab) and torch.equal(rew[t % T], b.reward) and torch.equal(don[t % T], b.done)
+        assert torch.equal(patch[(t + 1) % T][:, :25], pb[:, :25])
+    assert torch.equal(a.export_state(), b.export_state())
+    # actions only: every other ring NULL
+    a.act_steps(5, 9, torch.zeros((8, n), dtype=torch.int32, device=a.device))
+    for t in range(9, 14):
+        b.act_step(t, q=None, auto_reset=True)
+    assert torch.equal(a.export_state(), b.export_state()) and torch.equal(a.legal, b.legal) and torch.equal(a.lifetime, b.lifetime)
+    # sticky done over a 40-step launch
+    T = 64
+    act = torch.zeros((T, n), dtype=torch.int32, device=a.device)
+    rew = torch.full((T, n), -1.0, dtype=torch.float32, device=a.device)
+    don = torch.zeros((T, n), dtype=torch.uint8, device=a.device)
+    a.act_steps(40, 14, act, rew, don, slot0=0, auto_reset=False)
+    d = don[:40].cpu().numpy()
+    assert d.max() == 1 and (np.diff(d.astype(np.int8), axis=0) >= 0).all()          # once done, done
+    for t in range(14, 54):
+        b.act_step(t, q=None, auto_reset=False)
+    assert torch.equal(a.export_state(), b.export_state()) and torch.equal(don[39], b.done)
+    # refused: a ring of one slot, a slot outside the ring, no action ring
+    L = importlib.import_module("deepq-decoding_amd._lib")
+    seedc = (ctypes.c_uint32 * 2)(*seed)
+    for ring in (L.EnvRing(action_ring_dev=act.data_ptr(), n_slots=1, slot0=0), L.EnvRing(action_ring_dev=act.data_ptr(), n_slots=4, slot0=4),
+                 L.EnvRing(action_ring_dev=None, n_slots=4, slot0=0)):
+        assert a.L.dq_env_act_steps(a._h, 2, seedc, 0, ctypes.byref(ring), 1, None, None, None, None) == -1      # DQ_ERR_INVALID
+    assert a.L.dq_env_act_steps(a._h, 0, seedc, 0, ctypes.byref(L.EnvRing(action_ring_dev=act.data_ptr(), n_slots=4, slot0=0)), 1, None, None, None, None) != 0
+    a.close(); b.close()
