@@ -401,6 +401,9 @@ def main():
                                     f"{n_local} lattices/GPU, mode={mode}", **runner.config()),
         }
         out.update(runner.report(args.steps, dt, world))
+        dg = importlib.import_module("deepq-decoding_amd._digest").csrc_digest()
+        lib_dg = importlib.import_module("deepq-decoding_amd._lib").lib().dq_build_digest().decode()
+        out["build"] = dict(library_digest=lib_dg[:16], sources_digest=dg[:16], library_built_from_these_sources=lib_dg == dg)      # (the .so is prebuilt: say which sources it is)
         if world == 1 and mode == "loop" and args.updates_per_step == 1 and args.ratio_steps > 0 and hasattr(runner, "reference_ratio_leg"):
             # the driver's line carries the whole claim: the same loop at the reference's training intensity (k = 32 n / B updates per vector step)
             out["reference_replay_ratio"] = runner.reference_ratio_leg(steps=args.ratio_steps, warmup=max(2, args.ratio_steps // 10))

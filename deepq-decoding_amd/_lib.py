@@ -90,6 +90,7 @@ _seedp = ctypes.POINTER(ctypes.c_uint32)
 # name -> (restype, argtypes); must list every symbol include/deepq_hip.h declares
 SIGNATURES = {
     "dq_version": (_i, []),
+    "dq_build_digest": (ctypes.c_char_p, []),
     "dq_last_error": (ctypes.c_char_p, []),
     "dq_device_count": (_i, []),
     "dq_env_create": (_i, [ctypes.POINTER(EnvCfg), ctypes.POINTER(_vp)]),

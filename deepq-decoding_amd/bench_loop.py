@@ -19,26 +19,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0        # dense f16 / bf16 (MI355X_MICROARCH.md); t
 HBM_PEAK_GBS = 8000.0
 
 
-def _code_only(text):
-    """A C / HIP source with comments and all whitespace removed: what the compiler sees, up to token spacing."""
-    import re
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    text = re.sub(r"//[^\n]*", "", text)
-    return re.sub(r"\s+", "", text)
-
-
-def csrc_digest():
-    """sha256 over the CODE of the kernel sources (csrc/*.hip, csrc/*.h, include/deepq_hip.h; comments and whitespace stripped, so
-    that editing a comment does not orphan a measurement): stamps a PMC pass with the code it measured."""
-    import glob
-    import hashlib
-    here = os.path.dirname(os.path.abspath(__file__))
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h"))) + \
-            [os.path.join(here, "..", "include", "deepq_hip.h")]:
-        h.update(os.path.basename(f).encode())
-        h.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
-    return h.hexdigest()
+from ._digest import code_only as _code_only, csrc_digest      # (the stamp of a PMC pass = the code digest of the kernel sources it measured)
 
 
 def pmc_record(mode="loop", config="c3"):

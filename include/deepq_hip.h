@@ -62,6 +62,10 @@ enum { DQ_MODEL_X = 0, DQ_MODEL_DP = 1, DQ_MODEL_IIDXZ = 2 };
 enum { DQ_STREAM_ENV = 0, DQ_STREAM_POLICY = 1, DQ_STREAM_REPLAY = 2, DQ_STREAM_DROPOUT = 3, DQ_STREAM_INIT = 4 };
 
 int dq_version(void);
+/* sha256 (hex) over the CODE of the kernel sources this library was built from (csrc/, include/deepq_hip.h; comments and whitespace stripped:
+ * deepq-decoding_amd/_digest.py): a binding compares it with the tree's, so that a prebuilt .so carried to another box is known to be the one these sources
+ * build (tests/test_abi.py, the -m gpu suite). */
+const char* dq_build_digest(void);
 const char* dq_last_error(void);
 /* sizeof() of the public structs as THIS library was compiled: 0 dq_env_cfg, 1 dq_env_info, 2 dq_sample_job, 3 dq_qnet_cfg, 4 dq_qnet_job, 5 dq_td_job,
  * 6 dq_env_step_job; -1 for any other id.  A binding (the ctypes structures of _lib.py) checks its own layouts against it: a struct of the wrong size handed

@@ -71,3 +71,19 @@ def test_struct_layouts_match_the_library(dq):
     for i, st in enumerate((L.EnvCfg, L.EnvInfo, L.SampleJob, L.QNetCfg, L.QNetJob, L.TdJob, L.EnvStepJob, L.EnvRing)):
         assert lib.dq_struct_size(i) == ctypes.sizeof(st), (i, st.__name__, lib.dq_struct_size(i), ctypes.sizeof(st))
     assert lib.dq_struct_size(99) == -1
+
+
+def test_library_is_built_from_these_sources(dq, built_lib):
+    """build.py compiles the sources' code digest into the library (dq_build_digest, deepq-decoding_amd/_digest.py): after a build it equals the tree's."""
+    from importlib import import_module
+    L, D = import_module("deepq-decoding_amd._lib"), import_module("deepq-decoding_amd._digest")
+    assert L.lib().dq_build_digest().decode() == D.csrc_digest()
+
+
+@pytest.mark.gpu
+def test_the_library_on_this_box_is_the_one_these_sources_build(dq):
+    """the -m gpu suite runs a PREBUILT libdeepq_hip.so (git-ignored, carried to the GPU box) and never recompiles.  The digest compiled into
+    it must be the digest of the sources that travelled with it -- checked here WITHOUT building, on whatever .so the process has loaded."""
+    from importlib import import_module
+    L, D = import_module("deepq-decoding_amd._lib"), import_module("deepq-decoding_amd._digest")
+    assert L.lib().dq_build_digest().decode() == D.csrc_digest(), "deepq-decoding_amd/lib/libdeepq_hip.so was built from other kernel sources: run deepq-decoding_amd/build.py"

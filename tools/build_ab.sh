@@ -15,5 +15,5 @@ while [ $# -ge 2 ]; do
 done
 objs=""
 for src in deepq-decoding_amd/csrc/*.hip; do o=$(basename $src .hip); if [ -n "${repl[$o]}" ]; then objs="$objs ${repl[$o]}"; else objs="$objs deepq-decoding_amd/lib/$o.o"; fi; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/probe/ab/$name.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/probe/ab/$name.so $objs deepq-decoding_amd/lib/build_digest.o      # (+ the regular build's digest unit: dq_build_digest)
 ls -la tools/probe/ab/$name.so

@@ -12,7 +12,7 @@ for tag in "$@"; do
   extra=""; if [ $tag = 6 ]; then extra="-DDQ_STAMP_BLOCK=300"; fi      # tag 6: a RIDING environment workgroup of the dense backward's launch (blocks >= 256)
   ( /opt/rocm/bin/hipcc $FLAGS -DDQ_STAMPS=$tag $extra -c deepq-decoding_amd/csrc/$f.hip -o /tmp/stamp_${f}_$tag.o
     objs=""; for src in deepq-decoding_amd/csrc/*.hip; do o=$(basename $src .hip); if [ $o = $f ]; then objs="$objs /tmp/stamp_${f}_$tag.o"; else objs="$objs deepq-decoding_amd/lib/$o.o"; fi; done
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/probe/stamps/s$tag.so $objs ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/probe/stamps/s$tag.so $objs deepq-decoding_amd/lib/build_digest.o ) &
 done
 wait
 ls -la tools/probe/stamps/
